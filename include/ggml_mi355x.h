@@ -1,0 +1,74 @@
+/*
+ * ggml_mi355x.h — the C-ABI of libggml-mi355x.so, the MI355X (gfx950) ggml backend.
+ *
+ * This is the drop-in boundary.  The reference binds a device backend in exactly one way:
+ *
+ *   ggml_backend_load_all()                          /root/reference/llama-box/engine_param.hpp:542-545
+ *     -> ggml_backend_load_best("hip", silent, dir)  /root/reference/llama-box/patches/llama.cpp/pure_cpu.patch:80-92
+ *     -> $GGML_BACKEND_PATH                          /root/reference/llama-box/patches/llama.cpp/pure_cpu.patch:101-102
+ *   each of which dlopen()s the library and resolves the two symbols below (what ggml's
+ *   GGML_BACKEND_DL_IMPL / GGML_BACKEND_DL_SCORE_IMPL macros expand to in every stock backend).
+ *
+ * Everything else crosses the boundary through the vtables reachable from the returned registration
+ * object (struct layouts: include/ggml_abi.h).  No torch / C++ types appear in any signature.
+ */
+#ifndef GGML_MI355X_H
+#define GGML_MI355X_H
+#include "ggml_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGML_MI355X_NAME "MI355X"
+#define GGML_MI355X_MAX_DEVICES 16
+
+/* Replaces: ggml_backend_init() exported by libggml-hip.so (ggml-backend-reg.cpp dl entry; call site
+ * pure_cpu.patch:80-102).  Returns the backend registration (api_version == GGML_BACKEND_API_VERSION), or NULL
+ * when no gfx950 device is visible. */
+ggml_backend_reg_t ggml_backend_init(void);
+
+/* Replaces: ggml_backend_score() (optional DL export used by ggml_backend_load_best to rank variants).
+ * 0 = unusable on this system (no HIP device of arch gfx950), otherwise > 0. */
+int ggml_backend_score(void);
+
+/* Static-registration spelling of the same object (what ggml_backend_cuda_reg() is to the CUDA backend;
+ * pure_cpu.patch:18-62 shows the static registry constructor that would call it). */
+ggml_backend_reg_t ggml_backend_mi355x_reg(void);
+
+/*
+ * Names served by reg->iface.get_proc_address (pattern: llama-box/patches/llama.cpp/dynamic_link.patch:5-20,
+ * llama-box/engine_param.hpp:99-101, llama-box/rpcserver.hpp:402-403):
+ *
+ *   "ggml_backend_get_features"        ggml_backend_get_features_t
+ *   "ggml_backend_split_buffer_type"   ggml_backend_split_buffer_type_t   (row-split hook of -sm row; NULL until the
+ *                                      single-process split lands — the tensor-parallel path of this round is the
+ *                                      one-process-per-GPU form below)
+ *   "ggml_backend_mi355x_tp_init"      ggml_backend_mi355x_tp_init_t
+ *   "ggml_backend_mi355x_tp_rowpar_buffer_type"   ggml_backend_mi355x_tp_rowpar_buffer_type_t
+ *   "ggml_backend_mi355x_set_option"   ggml_backend_mi355x_set_option_t
+ *   "ggml_backend_mi355x_get_stat"     ggml_backend_mi355x_get_stat_t
+ *   "ggml_backend_mi355x_timing_report" ggml_backend_mi355x_timing_report_t
+ *   "ggml_backend_mi355x_tp_get_unique_id" ggml_backend_mi355x_tp_get_unique_id_t
+ */
+
+/* One-process-per-GPU tensor parallelism over RCCL/xGMI.  `unique_id` is the 128-byte ncclUniqueId produced by
+ * rank 0 (ncclGetUniqueId) and distributed by the launcher (bench.py uses torch.distributed for that).  After a
+ * successful call, MUL_MAT nodes whose src0 lives in the "rowpar" buffer type are followed by an in-stream
+ * all-reduce(sum) of their f32 result across ranks.  Returns 0 on success. */
+typedef int (*ggml_backend_mi355x_tp_init_t)(ggml_backend_t backend, int rank, int world_size, const void * unique_id, size_t unique_id_size);
+typedef int (*ggml_backend_mi355x_tp_get_unique_id_t)(void * unique_id_out, size_t unique_id_size);
+typedef ggml_backend_buffer_type_t (*ggml_backend_mi355x_tp_rowpar_buffer_type_t)(int device);
+
+/* Runtime options (string key/value), e.g. ("graphs","0"), ("fusion","0"), ("mmvq_rows","2"). 0 = accepted. */
+typedef int (*ggml_backend_mi355x_set_option_t)(ggml_backend_t backend, const char * key, const char * value);
+/* Counters for tests/bench: "graph_launches", "graph_captures", "eager_nodes", "kernel_launches", "fused_nodes". */
+typedef int64_t (*ggml_backend_mi355x_get_stat_t)(ggml_backend_t backend, const char * key);
+/* Timing helper for bench.py (option "timing"="1": graphs off, every kernel class bracketed by hipEvents on the
+ * backend's own stream — torch.cuda.Event cannot see that stream).  Writes lines "class count total_ms bytes". */
+typedef int (*ggml_backend_mi355x_timing_report_t)(ggml_backend_t backend, char * buf, size_t size, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGML_MI355X_H */

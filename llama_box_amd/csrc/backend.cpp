@@ -1,0 +1,436 @@
+// backend.cpp — registration, device, buffer-type, buffer and backend vtables of the MI355X ggml backend.
+//
+// The shapes of these tables are the drop-in boundary (include/ggml_abi.h cites the in-tree
+// evidence for each signature).  Design is MI355X-first: one HIP stream per backend instance (llama-box forces
+// GPU_MAX_HW_QUEUES=1, /root/reference/llama-box/engine.cpp:16-20, so nothing here relies on queue-level
+// overlap), buffers are plain hipMalloc arenas sized for 288 GB parts, repeated graphs are replayed as hipGraphs.
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace mi355x {
+
+int log_level() {
+    static int lvl = [] {
+        const char * e = getenv("GGML_MI355X_LOG");
+        return e ? atoi(e) : 0;
+    }();
+    return lvl;
+}
+
+// ------------------------------------------------------------------------------------------------ devices
+struct device_ctx {
+    int device = 0;  // HIP ordinal
+    std::string name, description;
+    ggml_backend_buffer_type buft{};
+    ggml_backend_buffer_type buft_rowpar{};
+    ggml_backend_buffer_type buft_host{};
+};
+
+struct reg_ctx {
+    std::vector<ggml_backend_device *> devices;
+};
+
+static ggml_backend_reg g_reg;
+static reg_ctx g_reg_ctx;
+static std::once_flag g_reg_once;
+static ggml_guid g_guid = {0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x2d, 0x67, 0x67, 0x6d, 0x6c, 0x2d, 0x62, 0x6b, 0x6e, 0x64};
+
+static device_ctx * dctx(ggml_backend_dev_t dev) { return (device_ctx *) dev->context; }
+
+// ------------------------------------------------------------------------------------------------ buffers
+typedef ggml_backend_buffer_t (*buffer_init_fn)(ggml_backend_buffer_type_t, struct ggml_backend_buffer_i, void *, size_t);
+
+// libggml-base's ggml_backend_buffer_init when we are loaded by a ggml host; own allocation otherwise (the host
+// frees the object with `delete`, both sides share libstdc++'s allocator)
+static ggml_backend_buffer_t make_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * context, size_t size) {
+    static buffer_init_fn host_fn = (buffer_init_fn) dlsym(RTLD_DEFAULT, "ggml_backend_buffer_init");
+    if (host_fn) return host_fn(buft, iface, context, size);
+    return new ggml_backend_buffer{iface, buft, context, size, GGML_BACKEND_BUFFER_USAGE_ANY};
+}
+
+static void buf_free(ggml_backend_buffer_t b) {
+    buffer_ctx * c = (buffer_ctx *) b->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipFree(c->base));
+    delete c;
+}
+static void * buf_get_base(ggml_backend_buffer_t b) { return ((buffer_ctx *) b->context)->base; }
+static enum ggml_status buf_init_tensor(ggml_backend_buffer_t, ggml_tensor *) { return GGML_STATUS_SUCCESS; }
+static void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t value, size_t offset, size_t size) {
+    buffer_ctx * c = (buffer_ctx *) b->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemset((char *) t->data + offset, value, size));
+    HIP_CHECK(hipDeviceSynchronize());
+}
+static void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t offset, size_t size) {
+    buffer_ctx * c = (buffer_ctx *) b->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemcpy((char *) t->data + offset, data, size, hipMemcpyHostToDevice));
+}
+static void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t offset, size_t size) {
+    buffer_ctx * c = (buffer_ctx *) b->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemcpy(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost));
+}
+static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst) {
+    ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
+    if (!buffer_is_ours(sb)) return false;
+    buffer_ctx * sc = (buffer_ctx *) sb->context;
+    buffer_ctx * dc = (buffer_ctx *) b->context;
+    const size_t n = ggml_abi_nbytes(src);
+    if (sc->device == dc->device) {
+        HIP_CHECK(hipSetDevice(dc->device));
+        HIP_CHECK(hipMemcpy(dst->data, src->data, n, hipMemcpyDeviceToDevice));
+    } else {
+        HIP_CHECK(hipMemcpyPeer(dst->data, dc->device, src->data, sc->device, n));
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    return true;
+}
+static void buf_clear(ggml_backend_buffer_t b, uint8_t value) {
+    buffer_ctx * c = (buffer_ctx *) b->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemset(c->base, value, c->size));
+    HIP_CHECK(hipDeviceSynchronize());
+}
+static const ggml_backend_buffer_i k_buffer_iface = {buf_free, buf_get_base, buf_init_tensor, buf_memset_tensor, buf_set_tensor,
+                                                     buf_get_tensor, buf_cpy_tensor, buf_clear, nullptr};
+
+bool buffer_is_ours(ggml_backend_buffer_t b) { return b != nullptr && b->iface.free_buffer == buf_free; }
+bool buffer_is_rowpar(ggml_backend_buffer_t b) { return buffer_is_ours(b) && ((buffer_ctx *) b->context)->rowpar; }
+
+// ---- device buffer type
+struct buft_ctx {
+    int device;
+    bool rowpar;
+    std::string name;
+};
+static const char * buft_get_name(ggml_backend_buffer_type_t buft) { return ((buft_ctx *) buft->context)->name.c_str(); }
+static ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
+    buft_ctx * bc = (buft_ctx *) buft->context;
+    HIP_CHECK(hipSetDevice(bc->device));
+    void * p = nullptr;
+    hipError_t err = hipMalloc(&p, size > 0 ? size : 1);
+    if (err != hipSuccess) {
+        (void) hipGetLastError();
+        MI_ERR("allocating %.2f MiB on device %d: hipMalloc failed: %s", size / 1024.0 / 1024.0, bc->device, hipGetErrorString(err));
+        return nullptr;  // handled by hosts: llama-box/rpcserver.hpp:1068-1080
+    }
+    buffer_ctx * c = new buffer_ctx{bc->device, p, size, bc->rowpar};
+    return make_buffer(buft, k_buffer_iface, c, size);
+}
+static size_t buft_alignment(ggml_backend_buffer_type_t) { return 256; }
+static size_t buft_max_size(ggml_backend_buffer_type_t buft) {
+    buft_ctx * bc = (buft_ctx *) buft->context;
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, bc->device));
+    return prop.totalGlobalMem;
+}
+static size_t buft_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * t) {
+    // kernels never read past the last block of a row, so no row padding is needed; keep 16-byte granularity
+    return (ggml_abi_nbytes(t) + 15) / 16 * 16;
+}
+static bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
+static const ggml_backend_buffer_type_i k_buft_iface = {buft_get_name, buft_alloc, buft_alignment, buft_max_size, buft_alloc_size, buft_is_host};
+
+// ---- pinned host buffer type (uploads at PCIe rate; llama.cpp asks for it via get_host_buffer_type)
+static void hbuf_free(ggml_backend_buffer_t b) { HIP_CHECK(hipHostFree(b->context)); }
+static void * hbuf_base(ggml_backend_buffer_t b) { return b->context; }
+static void hbuf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, size_t off, size_t sz) { memset((char *) t->data + off, v, sz); }
+static void hbuf_set(ggml_backend_buffer_t, ggml_tensor * t, const void * d, size_t off, size_t sz) { memcpy((char *) t->data + off, d, sz); }
+static void hbuf_get(ggml_backend_buffer_t, const ggml_tensor * t, void * d, size_t off, size_t sz) { memcpy(d, (const char *) t->data + off, sz); }
+static void hbuf_clear(ggml_backend_buffer_t b, uint8_t v) { memset(b->context, v, b->size); }
+static const char * hbuft_name(ggml_backend_buffer_type_t) { return GGML_MI355X_NAME "_Host"; }
+static ggml_backend_buffer_t hbuft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
+    void * p = nullptr;
+    hipError_t err = hipHostMalloc(&p, size > 0 ? size : 1, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        (void) hipGetLastError();
+        return nullptr;
+    }
+    ggml_backend_buffer_i iface = {hbuf_free, hbuf_base, nullptr, hbuf_memset, hbuf_set, hbuf_get, nullptr, hbuf_clear, nullptr};
+    return make_buffer(buft, iface, p, size);
+}
+static size_t hbuft_alignment(ggml_backend_buffer_type_t) { return 64; }
+static bool hbuft_is_host(ggml_backend_buffer_type_t) { return true; }
+
+// ------------------------------------------------------------------------------------------------ backend
+static const char * be_get_name(ggml_backend_t be) { return ((backend_ctx *) be->context)->name.c_str(); }
+static void be_free(ggml_backend_t be) {
+    backend_ctx * c = (backend_ctx *) be->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    free_graph_cache(c);
+    tp_free(c);
+    if (c->ws) HIP_CHECK(hipFree(c->ws));
+    HIP_CHECK(hipStreamDestroy(c->stream));
+    delete c;
+    delete be;
+}
+static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void * data, size_t offset, size_t size) {
+    backend_ctx * c = (backend_ctx *) be->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemcpyAsync((char *) t->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
+}
+static void be_get_tensor_async(ggml_backend_t be, const ggml_tensor * t, void * data, size_t offset, size_t size) {
+    backend_ctx * c = (backend_ctx *) be->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
+}
+static bool be_is_ours(ggml_backend_t be);
+static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, const ggml_tensor * src, ggml_tensor * dst) {
+    if (!be_is_ours(be_src) || !be_is_ours(be_dst)) return false;
+    ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
+    ggml_backend_buffer_t db = dst->view_src ? dst->view_src->buffer : dst->buffer;
+    if (!buffer_is_ours(sb) || !buffer_is_ours(db)) return false;
+    backend_ctx * cs = (backend_ctx *) be_src->context;
+    backend_ctx * cd = (backend_ctx *) be_dst->context;
+    const size_t n = ggml_abi_nbytes(src);
+    if (cs->device == cd->device) {
+        HIP_CHECK(hipSetDevice(cs->device));
+        HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, cs->stream));
+    } else {
+        HIP_CHECK(hipSetDevice(cs->device));
+        HIP_CHECK(hipMemcpyPeerAsync(dst->data, cd->device, src->data, cs->device, n, cs->stream));
+    }
+    if (be_src != be_dst) {  // make the destination stream wait for the copy
+        hipEvent_t ev;
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev, cs->stream));
+        HIP_CHECK(hipSetDevice(cd->device));
+        HIP_CHECK(hipStreamWaitEvent(cd->stream, ev, 0));
+        HIP_CHECK(hipEventDestroy(ev));
+    }
+    return true;
+}
+static void be_synchronize(ggml_backend_t be) {
+    backend_ctx * c = (backend_ctx *) be->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+static enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph * g) {
+    backend_ctx * c = (backend_ctx *) be->context;
+    if (hipSetDevice(c->device) != hipSuccess) return GGML_STATUS_FAILED;
+    return graph_compute(c, g);
+}
+static void be_event_record(ggml_backend_t be, ggml_backend_event_t ev) {
+    backend_ctx * c = (backend_ctx *) be->context;
+    HIP_CHECK(hipEventRecord((hipEvent_t) ev->context, c->stream));
+}
+static void be_event_wait(ggml_backend_t be, ggml_backend_event_t ev) {
+    backend_ctx * c = (backend_ctx *) be->context;
+    HIP_CHECK(hipStreamWaitEvent(c->stream, (hipEvent_t) ev->context, 0));
+}
+static const ggml_backend_i k_backend_iface = {
+    be_get_name, be_free, be_set_tensor_async, be_get_tensor_async, be_cpy_tensor_async, be_synchronize,
+    /* graph_plan_create */ nullptr, /* graph_plan_free */ nullptr, /* graph_plan_update */ nullptr, /* graph_plan_compute */ nullptr,
+    be_graph_compute, be_event_record, be_event_wait,
+#if GGML_ABI_HAS_GRAPH_OPTIMIZE
+    nullptr,
+#endif
+};
+static bool be_is_ours(ggml_backend_t be) { return be != nullptr && be->iface.get_name == be_get_name; }
+
+// ------------------------------------------------------------------------------------------------ device iface
+static const char * dev_get_name(ggml_backend_dev_t dev) { return dctx(dev)->name.c_str(); }
+static const char * dev_get_description(ggml_backend_dev_t dev) { return dctx(dev)->description.c_str(); }
+static void dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
+    HIP_CHECK(hipSetDevice(dctx(dev)->device));
+    HIP_CHECK(hipMemGetInfo(free, total));
+}
+static enum ggml_backend_dev_type dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+static void dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props * props) {
+    props->name = dev_get_name(dev);
+    props->description = dev_get_description(dev);
+    props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
+    dev_get_memory(dev, &props->memory_free, &props->memory_total);
+    props->caps = {/* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ false, /* events */ true};
+}
+static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
+    device_ctx * d = dctx(dev);
+    HIP_CHECK(hipSetDevice(d->device));
+    backend_ctx * c = new backend_ctx();
+    c->device = d->device;
+    c->name = d->name;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->opt.graphs = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_FUSION")) c->opt.fusion = atoi(e) != 0;
+    return new ggml_backend{&g_guid, k_backend_iface, dev, c};
+}
+static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &dctx(dev)->buft; }
+static ggml_backend_buffer_type_t dev_get_host_buffer_type(ggml_backend_dev_t dev) { return &dctx(dev)->buft_host; }
+static bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) { return supports_op(op); }
+static bool dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    if (buft->iface.get_name != buft_get_name) return false;
+    return ((buft_ctx *) buft->context)->device == dctx(dev)->device;
+}
+static bool dev_offload_op(ggml_backend_dev_t, const ggml_tensor * op) {
+    // same policy as the stock GPU backends: weights left on the host are worth uploading for batches >= 32
+    const int64_t batch = op->op == GGML_OP_MUL_MAT ? op->ne[1] : 0;
+    return batch >= 32;
+}
+static ggml_backend_event_t dev_event_new(ggml_backend_dev_t dev) {
+    HIP_CHECK(hipSetDevice(dctx(dev)->device));
+    hipEvent_t ev;
+    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return new ggml_backend_event{dev, ev};
+}
+static void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t ev) {
+    HIP_CHECK(hipEventDestroy((hipEvent_t) ev->context));
+    delete ev;
+}
+static void dev_event_synchronize(ggml_backend_dev_t, ggml_backend_event_t ev) { HIP_CHECK(hipEventSynchronize((hipEvent_t) ev->context)); }
+static const ggml_backend_device_i k_device_iface = {
+    dev_get_name, dev_get_description, dev_get_memory, dev_get_type, dev_get_props, dev_init_backend, dev_get_buffer_type,
+    dev_get_host_buffer_type, /* buffer_from_host_ptr */ nullptr, dev_supports_op, dev_supports_buft, dev_offload_op,
+    dev_event_new, dev_event_free, dev_event_synchronize,
+};
+
+// ------------------------------------------------------------------------------------------------ proc addresses
+static ggml_backend_feature g_features[] = {{"ARCH", "gfx950"}, {"WAVE", "64"}, {"GRAPHS", "1"}, {"RCCL_TP", "1"}, {nullptr, nullptr}};
+static ggml_backend_feature * get_features(ggml_backend_reg_t) { return g_features; }
+
+static int api_tp_init(ggml_backend_t be, int rank, int world, const void * uid, size_t n) {
+    if (!be_is_ours(be)) return -1;
+    return tp_init((backend_ctx *) be->context, rank, world, uid, n);
+}
+static int api_tp_get_unique_id(void * out, size_t n) { return tp_get_unique_id(out, n); }
+static ggml_backend_buffer_type_t api_tp_rowpar_buft(int device) {
+    if (device < 0 || device >= (int) g_reg_ctx.devices.size()) return nullptr;
+    return &dctx(g_reg_ctx.devices[device])->buft_rowpar;
+}
+static int api_set_option(ggml_backend_t be, const char * key, const char * value) {
+    if (!be_is_ours(be)) return -1;
+    backend_ctx * c = (backend_ctx *) be->context;
+    const std::string k = key;
+    const int v = atoi(value);
+    if (k == "graphs") c->opt.graphs = v != 0;
+    else if (k == "fusion") c->opt.fusion = v != 0;
+    else if (k == "mmvq_max_cols") c->opt.mmvq_max_cols = v;
+    else if (k == "fa_splits") c->opt.fa_splits = v;
+    else if (k == "timing") c->opt.timing = v != 0;
+    else return -1;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    free_graph_cache(c);
+    return 0;
+}
+static int64_t api_get_stat(ggml_backend_t be, const char * key) {
+    if (!be_is_ours(be)) return -1;
+    backend_ctx * c = (backend_ctx *) be->context;
+    const std::string k = key;
+    if (k == "graph_launches") return c->st.graph_launches;
+    if (k == "graph_captures") return c->st.graph_captures;
+    if (k == "eager_graphs") return c->st.eager_graphs;
+    if (k == "kernel_launches") return c->st.kernel_launches;
+    if (k == "fused_nodes") return c->st.fused_nodes;
+    if (k == "allreduces") return c->st.allreduces;
+    return -1;
+}
+static int api_timing_report(ggml_backend_t be, char * buf, size_t size, int reset) {
+    if (!be_is_ours(be) || !buf || size == 0) return -1;
+    backend_ctx * c = (backend_ctx *) be->context;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (auto & pe : c->pending_events) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
+        c->timing[pe.first].total_ms += ms;
+        c->timing[pe.first].count += 1;
+        HIP_CHECK(hipEventDestroy(pe.second.first));
+        HIP_CHECK(hipEventDestroy(pe.second.second));
+    }
+    c->pending_events.clear();
+    std::string out;
+    for (auto & kv : c->timing) {
+        if (kv.first.rfind("bytes:", 0) == 0) continue;
+        auto itb = c->timing.find("bytes:" + kv.first);
+        char line[256];
+        snprintf(line, sizeof(line), "%s %lld %.6f %.0f\n", kv.first.c_str(), (long long) kv.second.count, kv.second.total_ms,
+                 itb == c->timing.end() ? 0.0 : itb->second.total_ms);
+        out += line;
+    }
+    snprintf(buf, size, "%s", out.c_str());
+    if (reset) c->timing.clear();
+    return 0;
+}
+
+static const char * reg_get_name(ggml_backend_reg_t) { return GGML_MI355X_NAME; }
+static size_t reg_get_device_count(ggml_backend_reg_t) { return g_reg_ctx.devices.size(); }
+static ggml_backend_dev_t reg_get_device(ggml_backend_reg_t, size_t i) { return i < g_reg_ctx.devices.size() ? g_reg_ctx.devices[i] : nullptr; }
+static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
+    const std::string n = name;
+    if (n == "ggml_backend_get_features") return (void *) get_features;
+    if (n == "ggml_backend_mi355x_tp_init") return (void *) api_tp_init;
+    if (n == "ggml_backend_mi355x_tp_get_unique_id") return (void *) api_tp_get_unique_id;
+    if (n == "ggml_backend_mi355x_tp_rowpar_buffer_type") return (void *) api_tp_rowpar_buft;
+    if (n == "ggml_backend_mi355x_set_option") return (void *) api_set_option;
+    if (n == "ggml_backend_mi355x_get_stat") return (void *) api_get_stat;
+    if (n == "ggml_backend_mi355x_timing_report") return (void *) api_timing_report;
+    return nullptr;  // incl. "ggml_backend_split_buffer_type": hosts treat NULL as "row split unsupported"
+}
+static const ggml_backend_reg_i k_reg_iface = {reg_get_name, reg_get_device_count, reg_get_device, reg_get_proc_address};
+
+static int count_gfx950() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void) hipGetLastError();
+        return 0;
+    }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+static void init_reg() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void) hipGetLastError();
+        n = 0;
+    }
+    for (int i = 0; i < n && (int) g_reg_ctx.devices.size() < GGML_MI355X_MAX_DEVICES; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            MI_INFO("skipping HIP device %d (%s): not gfx950", i, prop.gcnArchName);
+            continue;
+        }
+        device_ctx * d = new device_ctx();
+        d->device = i;
+        d->name = std::string(GGML_MI355X_NAME) + std::to_string(g_reg_ctx.devices.size());
+        d->description = prop.name;
+        ggml_backend_device * dev = new ggml_backend_device{k_device_iface, &g_reg, d};
+        d->buft = {k_buft_iface, dev, new buft_ctx{i, false, d->name}};
+        d->buft_rowpar = {k_buft_iface, dev, new buft_ctx{i, true, d->name + "_RowPar"}};
+        d->buft_host = {{hbuft_name, hbuft_alloc, hbuft_alignment, nullptr, nullptr, hbuft_is_host}, dev, nullptr};
+        g_reg_ctx.devices.push_back(dev);
+    }
+    int api = GGML_BACKEND_API_VERSION;
+    if (const char * e = getenv("GGML_MI355X_API_VERSION")) api = atoi(e);
+    g_reg = {api, k_reg_iface, &g_reg_ctx};
+}
+
+}  // namespace mi355x
+
+extern "C" {
+
+__attribute__((visibility("default"))) ggml_backend_reg_t ggml_backend_mi355x_reg(void) {
+    std::call_once(mi355x::g_reg_once, mi355x::init_reg);
+    return &mi355x::g_reg;
+}
+
+__attribute__((visibility("default"))) ggml_backend_reg_t ggml_backend_init(void) {
+    ggml_backend_reg_t reg = ggml_backend_mi355x_reg();
+    if (mi355x::g_reg_ctx.devices.empty()) {
+        MI_ERR("no gfx950 (MI355X) device visible: backend not registered");
+        return nullptr;
+    }
+    return reg;
+}
+
+__attribute__((visibility("default"))) int ggml_backend_score(void) { return mi355x::count_gfx950() > 0 ? 100 : 0; }
+}

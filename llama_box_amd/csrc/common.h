@@ -1,0 +1,133 @@
+// common.h — internal declarations shared by the backend's translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ggml_mi355x.h"
+
+#define MI_LOG(level, ...)                                    \
+    do {                                                      \
+        if ((level) <= mi355x::log_level()) {                 \
+            fprintf(stderr, "ggml-mi355x: " __VA_ARGS__);     \
+            fprintf(stderr, "\n");                            \
+        }                                                     \
+    } while (0)
+#define MI_ERR(...) MI_LOG(0, __VA_ARGS__)
+#define MI_INFO(...) MI_LOG(1, __VA_ARGS__)
+#define MI_DBG(...) MI_LOG(2, __VA_ARGS__)
+
+// abort-on-error, the convention of every ggml backend for non-graph entry points (SURVEY.md §8b "Error conventions")
+#define HIP_CHECK(expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t err_ = (expr);                                                                               \
+        if (err_ != hipSuccess) {                                                                               \
+            fprintf(stderr, "ggml-mi355x: HIP error %d (%s) at %s:%d: %s\n", (int) err_, hipGetErrorString(err_), __FILE__, __LINE__, #expr); \
+            abort();                                                                                            \
+        }                                                                                                       \
+    } while (0)
+
+namespace mi355x {
+
+int log_level();
+
+// device-side layout of a Q8_K-quantised activation block (the ggml block_q8_K fields, 16-byte aligned:
+// qs | bsums | d) — produced by quantize kernels, consumed by the K-quant matvec / GEMM kernels
+struct q8k_dev {
+    int8_t qs[256];
+    int16_t bsums[16];
+    float d;
+    float pad[3];
+};
+static_assert(sizeof(q8k_dev) == 304, "q8k_dev");
+// Q8_0-quantised activation block for Q8_0 weights: d already rounded through fp16 (as block_q8_0.d is)
+struct q80_dev {
+    int8_t qs[32];
+    float d;
+};
+static_assert(sizeof(q80_dev) == 36, "q80_dev");
+
+struct backend_ctx;
+
+struct options {
+    bool graphs = true;        // hipGraph capture + replay of repeated graphs
+    bool fusion = true;        // node fusion (norm+mul, mul_mat+add, ...)
+    int mmvq_max_cols = 8;     // widest batch handled by the bandwidth-bound matvec kernels
+    int fa_splits = 0;         // 0 = auto
+    bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)
+};
+
+struct stats {
+    int64_t graph_launches = 0, graph_captures = 0, eager_graphs = 0, kernel_launches = 0, fused_nodes = 0, allreduces = 0;
+};
+
+struct tp_state;  // tp.cpp
+
+struct cached_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int seen = 0;
+    uint64_t last_use = 0;
+};
+
+struct timing_slot {
+    double total_ms = 0;
+    int64_t count = 0;
+};
+
+struct backend_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string name;
+    options opt;
+    stats st;
+    // scratch (quantised activations, attention partials); grown outside capture only
+    void * ws = nullptr;
+    size_t ws_size = 0;
+    // activation-quantisation cache: which src1 tensor the q8 scratch currently holds
+    const void * q8_src = nullptr;
+    int q8_kind = 0;
+    size_t q8_bytes = 0;
+    uint64_t q8_epoch = 0;
+    // hipGraph cache
+    std::unordered_map<uint64_t, cached_graph> graphs;
+    uint64_t tick = 0;
+    bool capturing = false;
+    // tensor parallel
+    tp_state * tp = nullptr;
+    // per-class kernel timing (bench)
+    std::map<std::string, timing_slot> timing;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
+};
+
+// ---- buffers (backend.cpp) ----
+struct buffer_ctx {
+    int device = 0;
+    void * base = nullptr;
+    size_t size = 0;
+    bool rowpar = false;  // tensor-parallel reducing buffer type
+};
+bool buffer_is_ours(ggml_backend_buffer_t b);
+bool buffer_is_rowpar(ggml_backend_buffer_t b);
+
+// ---- graph execution (graph.cpp) ----
+bool supports_op(const ggml_tensor * op);
+enum ggml_status graph_compute(backend_ctx * ctx, ggml_cgraph * g);
+void free_graph_cache(backend_ctx * ctx);
+
+// ---- tensor parallel (tp.cpp) ----
+int tp_init(backend_ctx * ctx, int rank, int world, const void * uid, size_t uid_size);
+int tp_get_unique_id(void * out, size_t size);
+bool tp_active(const backend_ctx * ctx);
+// in-stream sum all-reduce of n floats at ptr (capturable)
+bool tp_all_reduce(backend_ctx * ctx, float * ptr, size_t n);
+void tp_free(backend_ctx * ctx);
+
+}  // namespace mi355x

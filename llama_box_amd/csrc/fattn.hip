@@ -1,0 +1,249 @@
+// fattn.hip — FLASH_ATTN_EXT for f16 K/V with GQA: online-softmax attention, split over the KV range.
+//
+// Restates ggml_compute_forward_flash_attn_ext_f16: Q is rounded to f16,
+// s = (K·Q)*scale (+softcap) + slope*mask, masked (-inf) positions are skipped, running (max, sum) softmax.
+// Deliberate difference: the CPU accumulates V in f16 (ggml_vec_mad_f16); this kernel accumulates in f32, so its
+// result is closer to exact arithmetic than the CPU's and agrees with it to f16-accumulation noise (tests bound it
+// with the NMSE gate upstream's test-backend-ops uses for this op).
+//
+// Decode-first layout (batch-1 / small-batch attention is bound by the KV bytes, 131 072 B x n_past per token for
+// Llama-3-8B): one workgroup per (KV split, KV head, query token) serves ALL G query heads that share the KV head,
+// so K/V are read once per group.  A K/V row (D halves) is covered by D/8 lanes with 16-byte loads: a wave64 load
+// instruction moves 8 (D=64) or 4 (D=128) whole rows = 1 KiB, fully coalesced.  Scores are finished with a
+// sub-wave butterfly; there is no LDS traffic in the KV loop.  Partial (m, l, acc) triples are merged across
+// sub-rows (shuffles), waves (LDS) and splits (second tiny kernel).
+#include "dev_util.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+struct fa_geom {
+    int n_q, n_head, n_kv_head, n_kv, n_splits, has_mask;
+    float scale, softcap, max_bias, m0, m1;
+    uint32_t n_head_log2;
+};
+
+template <int D, int G>
+__global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
+                                                     const tdesc dst, const fa_geom geo, float * __restrict__ ws) {
+    constexpr int LPR = D / 8;     // lanes per K/V row
+    constexpr int RPW = 64 / LPR;  // rows per wave-instruction
+    __shared__ float sh[4][G][D + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int split = blockIdx.x, kvh = blockIdx.y;
+    const int tok = blockIdx.z % geo.n_q, bat = blockIdx.z / geo.n_q;
+    const int per = (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
+    const int kv0 = split * per, kv1 = min(geo.n_kv, kv0 + per);
+    const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
+
+    float qr[G][8], acc[G][8], m[G], l[G], slope[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int h = kvh * G + g;
+        const float * qp = (const float *) (q.data + (int64_t) tok * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]) + sl * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            qr[g][i] = h2f(f2h(qp[i]));  // q_to_vec_dot: Q is converted to K's vec_dot_type (f16)
+            acc[g][i] = 0.0f;
+        }
+        m[g] = -INFINITY;
+        l[g] = 0.0f;
+        slope[g] = geo.max_bias > 0.0f ? ((uint32_t) h < geo.n_head_log2 ? powf(geo.m0, (float) (h + 1)) : powf(geo.m1, (float) (2 * (h - geo.n_head_log2) + 1))) : 1.0f;
+    }
+    const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
+    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
+
+    for (int p0 = kv0 + wave * RPW; p0 < kv1; p0 += 4 * RPW) {
+        const int p = p0 + sub;
+        const bool inr = p < kv1;
+        const int pc = inr ? p : kv1 - 1;
+        const float mv = mp ? h2f(mp[pc]) : 0.0f;
+        const uint4 kraw = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);
+        const uint4 vraw = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);
+        const uint32_t ku[4] = {kraw.x, kraw.y, kraw.z, kraw.w}, vu[4] = {vraw.x, vraw.y, vraw.z, vraw.w};
+        float kf[8], vf[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kf[2 * i] = h2f((uint16_t) (ku[i] & 0xFFFF));
+            kf[2 * i + 1] = h2f((uint16_t) (ku[i] >> 16));
+            vf[2 * i] = h2f((uint16_t) (vu[i] & 0xFFFF));
+            vf[2 * i + 1] = h2f((uint16_t) (vu[i] >> 16));
+        }
+        float s[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t = fmaf(kf[i], qr[g][i], t);
+            s[g] = t;
+        }
+#pragma unroll
+        for (int o = LPR >> 1; o > 0; o >>= 1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) s[g] += __shfl_xor(s[g], o, 64);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float sv = s[g] * geo.scale;
+            if (geo.softcap != 0.0f) sv = geo.softcap * tanhf(sv);
+            const float mvs = slope[g] * mv;
+            sv += mvs;
+            const bool use = inr && !(mvs == -INFINITY);
+            if (use) {
+                float vs = 1.0f;
+                if (sv > m[g]) {
+                    const float ms = expf(m[g] - sv);
+                    l[g] *= ms;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[g][i] *= ms;
+                    m[g] = sv;
+                } else {
+                    vs = expf(sv - m[g]);
+                }
+                l[g] += vs;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[g][i] = fmaf(vs, vf[i], acc[g][i]);
+            }
+        }
+    }
+    // merge the RPW sub-rows of the wave
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float mo = __shfl_xor(m[g], o, 64), lo = __shfl_xor(l[g], o, 64);
+            const float mn = fmaxf(m[g], mo);
+            const float ca = m[g] == -INFINITY ? 0.0f : expf(m[g] - mn);
+            const float cb = mo == -INFINITY ? 0.0f : expf(mo - mn);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float ao = __shfl_xor(acc[g][i], o, 64);
+                acc[g][i] = acc[g][i] * ca + ao * cb;
+            }
+            l[g] = l[g] * ca + lo * cb;
+            m[g] = mn;
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sh[wave][g][sl * 8 + i] = acc[g][i];
+            if (sl == 0) {
+                sh[wave][g][D] = m[g];
+                sh[wave][g][D + 1] = l[g];
+            }
+        }
+    }
+    __syncthreads();
+    // merge the 4 waves; one thread per (g, d)
+    for (int e = tid; e < G * D; e += 256) {
+        const int g = e / D, dd = e % D;
+        float mt = -INFINITY;
+        for (int w = 0; w < 4; ++w) mt = fmaxf(mt, sh[w][g][D]);
+        float a = 0.0f, lt = 0.0f;
+        for (int w = 0; w < 4; ++w) {
+            const float mw = sh[w][g][D];
+            const float c = mw == -INFINITY ? 0.0f : expf(mw - mt);
+            a += sh[w][g][dd] * c;
+            lt += sh[w][g][D + 1] * c;
+        }
+        const int h = kvh * G + g;
+        if (geo.n_splits == 1) {
+            if (sinks) {
+                const float sk = sinks[h];
+                const float mn = fmaxf(mt, sk);
+                const float c = mt == -INFINITY ? 0.0f : expf(mt - mn);
+                a *= c;
+                lt = lt * c + expf(sk - mn);
+            }
+            float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+            out[dd] = a * (1.0f / lt);
+        } else {
+            float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits + split) * (D + 2);
+            rec[dd] = a;
+            if (dd == 0) {
+                rec[D] = mt;
+                rec[D + 1] = lt;
+            }
+        }
+    }
+}
+
+template <int D> __global__ void __launch_bounds__(64) k_fattn_combine(const float * __restrict__ ws, const float * __restrict__ sinks, const tdesc dst, const fa_geom geo) {
+    const int h = blockIdx.x, tok = blockIdx.y, bat = blockIdx.z;
+    const float * base = ws + (((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits * (D + 2);
+    float mt = -INFINITY;
+    for (int s = 0; s < geo.n_splits; ++s) mt = fmaxf(mt, base[(int64_t) s * (D + 2) + D]);
+    float sink_term = 0.0f, mn = mt;
+    if (sinks) {
+        mn = fmaxf(mt, sinks[h]);
+        sink_term = expf(sinks[h] - mn);
+    }
+    float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+    for (int dd = threadIdx.x; dd < D; dd += 64) {
+        float a = 0.0f, lt = 0.0f;
+        for (int s = 0; s < geo.n_splits; ++s) {
+            const float * rec = base + (int64_t) s * (D + 2);
+            const float c = rec[D] == -INFINITY ? 0.0f : expf(rec[D] - mn);
+            a += rec[dd] * c;
+            lt += rec[D + 1] * c;
+        }
+        lt += sink_term;
+        out[dd] = a * (1.0f / lt);
+    }
+}
+
+int fattn_pick_splits(const tdesc & q, const tdesc & k) {
+    const int64_t n_kv = k.ne[1];
+    const int64_t groups = k.ne[2] * q.ne[1] * q.ne[3];
+    int64_t want = (768 + groups - 1) / groups;  // ~3 workgroups per CU
+    const int64_t max_by_len = std::max<int64_t>(1, n_kv / 64);
+    want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(max_by_len, 64)));
+    return (int) want;
+}
+size_t fattn_workspace_bytes(const tdesc & q, const tdesc & v, int n_splits) {
+    if (n_splits <= 1) return 0;
+    return (size_t) (q.ne[1] * q.ne[3] * q.ne[2]) * (size_t) n_splits * (size_t) (v.ne[0] + 2) * sizeof(float);
+}
+
+template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc & mask, const float * sinks,
+                                              const tdesc & dst, const fa_geom & geo, float * ws) {
+    dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, (unsigned) (geo.n_q * q.ne[3]));
+    hipLaunchKernelGGL((k_fattn_split<D, G>), grid, dim3(256), 0, s, q, k, v, mask, sinks, dst, geo, ws);
+    if (geo.n_splits > 1) {
+        dim3 g2((unsigned) geo.n_head, (unsigned) geo.n_q, (unsigned) q.ne[3]);
+        hipLaunchKernelGGL((k_fattn_combine<D>), g2, dim3(64), 0, s, ws, sinks, dst, geo);
+    }
+}
+
+void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
+                       const fattn_params & p, void * workspace) {
+    fa_geom geo;
+    geo.n_q = (int) q.ne[1];
+    geo.n_head = (int) q.ne[2];
+    geo.n_kv_head = (int) k.ne[2];
+    geo.n_kv = (int) k.ne[1];
+    geo.n_splits = p.n_splits;
+    geo.has_mask = mask ? 1 : 0;
+    geo.scale = p.logit_softcap != 0.0f ? p.scale / p.logit_softcap : p.scale;
+    geo.softcap = p.logit_softcap;
+    geo.max_bias = p.max_bias;
+    geo.n_head_log2 = 1u << (uint32_t) floor(log2((double) geo.n_head));
+    geo.m0 = powf(2.0f, -(p.max_bias) / (float) geo.n_head_log2);
+    geo.m1 = powf(2.0f, -(p.max_bias / 2.0f) / (float) geo.n_head_log2);
+    const int D = (int) k.ne[0], G = geo.n_head / geo.n_kv_head;
+    const tdesc mk = mask ? *mask : q;
+    float * ws = (float *) workspace;
+#define FA_CASE(DD, GG) \
+    if (D == DD && G == GG) { launch_fa<DD, GG>(s, q, k, v, mk, sinks, dst, geo, ws); return; }
+    FA_CASE(64, 1) FA_CASE(64, 2) FA_CASE(64, 4) FA_CASE(64, 8)
+    FA_CASE(128, 1) FA_CASE(128, 2) FA_CASE(128, 4) FA_CASE(128, 7) FA_CASE(128, 8)
+#undef FA_CASE
+    MI_ERR("launch_flash_attn: unsupported head_dim %d / group %d", D, G);
+    abort();
+}
+
+}  // namespace mi355x

@@ -1,0 +1,562 @@
+// graph.cpp — ggml_backend_i::graph_compute for the MI355X backend: node dispatch, chain fusion, activation-
+// quantisation reuse, scratch sizing and hipGraph capture/replay.
+//
+// Entry: ggml_backend_sched_graph_compute -> backend.graph_compute (direct use at
+// /root/reference/llama-box/rpcserver.hpp:1390).  llama-box's decode loop submits the SAME graph topology every
+// step (one llama_decode per engine iteration, llama-box/httpserver.hpp:3591), ~290 nodes of 3-90 us each, which is
+// host-launch-bound if issued eagerly (MI355X_MICROARCH.md "graph-replay-floor").  So: a graph whose fingerprint
+// (ops, shapes, strides, addresses, params) repeats is captured once into a hipGraph and replayed; the stock
+// backend's CUDA-graph path (GGML_CUDA_GRAPHS, /root/reference/CMakeLists.txt:56-58) plays the same role there.
+// Errors inside compute return GGML_STATUS_FAILED (-> llama_decode rc -2, llama-box/httpserver.hpp:3541-3545).
+#include <algorithm>
+#include <cmath>
+
+#include "kernels.h"
+
+namespace mi355x {
+
+static bool is_quant(int t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }
+static int act_kind(int wtype) { return wtype == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K; }
+static bool is_f32_contig(const ggml_tensor * t) { return t->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(t); }
+static bool rows_contig(const ggml_tensor * t) { return t->nb[0] == ggml_abi_type_size(t->type); }
+static bool same_shape(const ggml_tensor * a, const ggml_tensor * b) {
+    for (int i = 0; i < 4; ++i) if (a->ne[i] != b->ne[i]) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ supports_op
+bool supports_op(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0];
+    const ggml_tensor * b = op->src[1];
+    switch (op->op) {
+        case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            return true;
+        case GGML_OP_MUL_MAT: {
+            if (!a || !b || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(op)) return false;
+            if (is_quant(a->type)) {
+                return a->ne[2] == 1 && a->ne[3] == 1 && rows_contig(a) && b->nb[0] == 4 && a->ne[0] % ggml_abi_blck_size(a->type) == 0;
+            }
+            if (a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32) return true;
+            return false;
+        }
+        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV:
+            return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32;
+        case GGML_OP_SCALE:
+            return is_f32_contig(a) && is_f32_contig(op);
+        case GGML_OP_RMS_NORM:
+            return a->type == GGML_TYPE_F32 && a->nb[0] == 4 && op->nb[0] == 4;
+        case GGML_OP_UNARY: {
+            const int u = op->op_params[0];
+            const bool ok = u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_RELU || u == GGML_UNARY_OP_NEG || u == GGML_UNARY_OP_EXP ||
+                            u == GGML_UNARY_OP_TANH || u == GGML_UNARY_OP_SIGMOID;
+            return ok && is_f32_contig(a) && is_f32_contig(op);
+        }
+        case GGML_OP_GLU:
+            return op->op_params[0] == GGML_GLU_OP_SWIGLU && a->type == GGML_TYPE_F32 && a->nb[0] == 4 && (!b || (b->type == GGML_TYPE_F32 && b->nb[0] == 4)) &&
+                   a->ne[2] == 1 && a->ne[3] == 1 && op->nb[0] == 4;
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
+            const int st = a->type, dt = op->type;
+            if (st == GGML_TYPE_I32 && dt == GGML_TYPE_I32) return true;
+            return (st == GGML_TYPE_F32 || st == GGML_TYPE_F16) && (dt == GGML_TYPE_F32 || dt == GGML_TYPE_F16);
+        }
+        case GGML_OP_GET_ROWS:
+            return b->type == GGML_TYPE_I32 && op->type == GGML_TYPE_F32 && rows_contig(a) && op->nb[0] == 4 &&
+                   (is_quant(a->type) || a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32);
+        case GGML_OP_SET_ROWS:
+            return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_I64 && a->nb[0] == 4 && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) &&
+                   op->nb[0] == ggml_abi_type_size(op->type);
+        case GGML_OP_SOFT_MAX:
+            return is_f32_contig(a) && is_f32_contig(op) && (!b || ((b->type == GGML_TYPE_F16 || b->type == GGML_TYPE_F32) && rows_contig(b)));
+        case GGML_OP_ROPE: {
+            const int mode = op->op_params[2];
+            if (mode & GGML_ROPE_TYPE_MROPE) return false;  // mrope/vision (mrope.patch) are served by the CPU backend
+            return (a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16) && a->type == op->type && rows_contig(a) && rows_contig(op) && b->type == GGML_TYPE_I32;
+        }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            const ggml_tensor * k = op->src[1];
+            const ggml_tensor * v = op->src[2];
+            const ggml_tensor * m = op->src[3];
+            if (a->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return false;
+            if (k->ne[0] != v->ne[0] || (k->ne[0] != 64 && k->ne[0] != 128)) return false;
+            if (a->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || (k->nb[1] % 16) || (v->nb[1] % 16) || (k->nb[2] % 16) || (v->nb[2] % 16)) return false;
+            if (m && (m->type != GGML_TYPE_F16 || m->ne[2] != 1 || !rows_contig(m))) return false;
+            if (a->ne[2] % k->ne[2] != 0 || k->ne[2] != v->ne[2]) return false;
+            const int64_t g = a->ne[2] / k->ne[2];
+            if (k->ne[0] == 64) return g == 1 || g == 2 || g == 4 || g == 8;
+            return g == 1 || g == 2 || g == 4 || g == 7 || g == 8;
+        }
+        case GGML_OP_ARGMAX:
+            return a->type == GGML_TYPE_F32 && a->nb[0] == 4;
+        default:
+            return false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scratch
+static bool ensure_ws(backend_ctx * c, size_t need) {
+    if (need <= c->ws_size) return true;
+    if (c->capturing) return false;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->ws) HIP_CHECK(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_size = 0;
+    const size_t sz = (need + (size_t) (8u << 20)) & ~(size_t) 255;
+    if (hipMalloc(&c->ws, sz) != hipSuccess) {
+        (void) hipGetLastError();
+        MI_ERR("failed to allocate %.1f MiB of scratch", sz / 1048576.0);
+        return false;
+    }
+    c->ws_size = sz;
+    c->q8_src = nullptr;
+    free_graph_cache(c);  // captured graphs hold the old scratch address
+    return true;
+}
+
+struct ws_plan {
+    size_t act_bytes = 0;  // region A: quantised activations
+    size_t aux_bytes = 0;  // region B: attention partials
+};
+
+static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
+    ws_plan p;
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        if (n->op == GGML_OP_MUL_MAT && is_quant(n->src[0]->type)) {
+            const ggml_tensor * b = n->src[1];
+            p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], b->ne[1] * b->ne[2] * b->ne[3]));
+        } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
+            const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
+            const int ns = c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k);
+            p.aux_bytes = std::max(p.aux_bytes, fattn_workspace_bytes(q, v, ns));
+        }
+    }
+    p.act_bytes = (p.act_bytes + 255) & ~(size_t) 255;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------ timing (bench)
+struct timed_scope {
+    backend_ctx * c;
+    std::string cls;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    timed_scope(backend_ctx * c_, const char * cls_, double bytes) : c(c_), cls(cls_) {
+        if (!c->opt.timing || c->capturing) return;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, c->stream));
+        c->timing[cls].total_ms += 0;  // create slot
+        c->timing["bytes:" + cls].total_ms += bytes;
+    }
+    ~timed_scope() {
+        if (!e0) return;
+        HIP_CHECK(hipEventRecord(e1, c->stream));
+        c->pending_events.push_back({cls, {e0, e1}});
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ node execution
+struct exec_state {
+    backend_ctx * c;
+    ggml_cgraph * g;
+    std::unordered_map<const ggml_tensor *, int> uses;
+    size_t act_off = 0, aux_off = 0;
+};
+
+static int use_count(const exec_state & st, const ggml_tensor * t) {
+    auto it = st.uses.find(t);
+    return it == st.uses.end() ? 0 : it->second;
+}
+static bool single_use(const exec_state & st, const ggml_tensor * t) { return use_count(st, t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT); }
+
+// returns the device pointer of src1 quantised for weight type `wtype`, quantising only if the scratch does not
+// already hold exactly this tensor (Q/K/V and gate/up share their input)
+static const void * quantized_src1(exec_state & st, const ggml_tensor * b, int wtype) {
+    backend_ctx * c = st.c;
+    const int kind = act_kind(wtype);
+    void * dst = (char *) c->ws + st.act_off;
+    if (c->q8_src == b->data && c->q8_kind == kind && c->q8_bytes == ggml_abi_nbytes(b)) return dst;
+    {
+        timed_scope ts(c, "quantize_act", (double) ggml_abi_nbytes(b));
+        launch_quantize_act(c->stream, kind, TD(b), dst);
+        c->st.kernel_launches++;
+    }
+    c->q8_src = b->data;
+    c->q8_kind = kind;
+    c->q8_bytes = ggml_abi_nbytes(b);
+    return dst;
+}
+
+static const char * type_tag(int t) {
+    switch (t) {
+        case GGML_TYPE_Q4_K: return "q4_K";
+        case GGML_TYPE_Q5_K: return "q5_K";
+        case GGML_TYPE_Q6_K: return "q6_K";
+        case GGML_TYPE_Q8_0: return "q8_0";
+        default: return "f";
+    }
+}
+
+// quantised mat-mul, optionally with fused epilogue; w2 != null -> SwiGLU over (w, w2)
+static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_tensor * w2, const ggml_tensor * b, ggml_tensor * dst,
+                          const ggml_tensor * add, const ggml_tensor * add2) {
+    backend_ctx * c = st.c;
+    const int64_t K = w->ne[0], N = w->ne[1];
+    const int64_t M = b->ne[1] * b->ne[2] * b->ne[3];
+    const void * act = quantized_src1(st, b, w->type);
+    const double wbytes = (double) ggml_abi_row_size(w->type, K) * (double) N * (w2 ? 2.0 : 1.0);
+    if (M > c->opt.mmvq_max_cols && !w2 && !add && mmq_supported(w->type, K, N, M)) {
+        timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
+        launch_mmq(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4));
+        c->st.kernel_launches++;
+        return true;
+    }
+    mmvq_args a{};
+    a.W = (const uint8_t *) w->data;
+    a.W2 = w2 ? (const uint8_t *) w2->data : nullptr;
+    a.w_nb1 = (int64_t) w->nb[1];
+    a.type = w->type;
+    a.K = (int) K;
+    a.N = (int) N;
+    a.ncols = (int) M;
+    a.act = act;
+    a.dst = (float *) dst->data;
+    a.dst_stride = (int64_t) (dst->nb[1] / 4);
+    auto addend = [&](const ggml_tensor * t, const float *& p, int64_t & stride) {
+        p = nullptr;
+        stride = 0;
+        if (!t) return;
+        p = (const float *) t->data;
+        stride = (t->ne[1] * t->ne[2] * t->ne[3] == 1) ? 0 : (int64_t) (t->nb[1] / 4);
+    };
+    addend(add, a.add, a.add_stride);
+    addend(add2, a.add2, a.add2_stride);
+    const int rpw = (M == 1 && N >= 2048) ? 2 : 1;
+    char cls[64];
+    snprintf(cls, sizeof(cls), "mmvq_%s%s_nc%d", type_tag(w->type), w2 ? "_glu" : "", (int) std::min<int64_t>(M, 8));
+    // the column loop lives in launch_mmvq (chunks of <= 8); weights are re-streamed once per chunk
+    timed_scope ts(c, cls, wbytes * (double) ((M + 7) / 8));
+    launch_mmvq(c->stream, a, rpw);
+    c->st.kernel_launches += (M + 7) / 8;
+    return true;
+}
+
+static bool quant_mm_ok(const ggml_tensor * n) {
+    return n->op == GGML_OP_MUL_MAT && is_quant(n->src[0]->type) && ggml_abi_is_contiguous(n);
+}
+// an ADD whose one operand is `x` and whose other operand is a bias row or a same-shape residual; returns the other
+static const ggml_tensor * add_partner(const ggml_tensor * add, const ggml_tensor * x) {
+    if (add->op != GGML_OP_ADD || add->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(add)) return nullptr;
+    const ggml_tensor * o = add->src[0] == x ? add->src[1] : (add->src[1] == x ? add->src[0] : nullptr);
+    if (!o || o == x || o->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(o)) return nullptr;
+    if (add->src[0] != x && !same_shape(add->src[0], add)) return nullptr;  // x must be the broadcast target when it is src1
+    if (o->ne[0] != x->ne[0]) return nullptr;
+    const int64_t orows = o->ne[1] * o->ne[2] * o->ne[3];
+    if (orows != 1 && !same_shape(o, x)) return nullptr;
+    if (!same_shape(add, x)) return nullptr;
+    return o;
+}
+
+// executes node i (possibly fusing followers); returns number of nodes consumed, or -1 on failure
+static int run_node(exec_state & st, int i) {
+    backend_ctx * c = st.c;
+    ggml_cgraph * g = st.g;
+    ggml_tensor * n = g->nodes[i];
+    const ggml_tensor * a = n->src[0];
+    const ggml_tensor * b = n->src[1];
+    hipStream_t s = c->stream;
+    const bool fuse = c->opt.fusion;
+    auto next = [&](int k) -> ggml_tensor * { return i + k < g->n_nodes ? g->nodes[i + k] : nullptr; };
+
+    switch (n->op) {
+        case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            return 1;
+
+        case GGML_OP_RMS_NORM: {
+            // RMS_NORM -> MUL(norm, w): one kernel writing the MUL's output
+            ggml_tensor * m = next(1);
+            if (fuse && m && m->op == GGML_OP_MUL && single_use(st, n) && m->type == GGML_TYPE_F32 && m->nb[0] == 4) {
+                const ggml_tensor * w = m->src[0] == n ? m->src[1] : (m->src[1] == n ? m->src[0] : nullptr);
+                if (w && w->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(w) && w->ne[0] == n->ne[0] && ggml_abi_nelements(w) == w->ne[0] && same_shape(m, n)) {
+                    const tdesc wd = TD(w);
+                    timed_scope ts(c, "rms_norm_mul", (double) ggml_abi_nbytes(a) * 2);
+                    launch_rms_norm(s, TD(a), TD(m), ggml_abi_op_param_f32(n, 0), &wd);
+                    c->st.kernel_launches++;
+                    c->st.fused_nodes++;
+                    return 2;
+                }
+            }
+            timed_scope ts(c, "rms_norm", (double) ggml_abi_nbytes(a) * 2);
+            launch_rms_norm(s, TD(a), TD(n), ggml_abi_op_param_f32(n, 0), nullptr);
+            c->st.kernel_launches++;
+            return 1;
+        }
+
+        case GGML_OP_MUL_MAT: {
+            if (!is_quant(a->type)) {
+                timed_scope ts(c, "mul_mat_f", (double) ggml_abi_nbytes(a));
+                launch_mul_mat_f(s, TD(a), TD(b), TD(n));
+                c->st.kernel_launches++;
+                return 1;
+            }
+            const bool rowpar = tp_active(c) && buffer_is_rowpar(a->view_src ? a->view_src->buffer : a->buffer);
+            const int64_t M = b->ne[1] * b->ne[2] * b->ne[3];
+            if (fuse && !rowpar && M <= c->opt.mmvq_max_cols) {
+                // gate/up/SwiGLU: MUL_MAT(Wg,x) MUL_MAT(Wu,x) GLU(g,u)
+                ggml_tensor * n2 = next(1);
+                ggml_tensor * n3 = next(2);
+                if (n2 && n3 && quant_mm_ok(n2) && n2->src[1] == b && n2->src[0]->type == a->type && same_shape(n2->src[0], a) &&
+                    n2->src[0]->nb[1] == a->nb[1] && n3->op == GGML_OP_GLU && n3->op_params[0] == GGML_GLU_OP_SWIGLU && n3->op_params[1] == 0 &&
+                    n3->src[0] == n && n3->src[1] == n2 && single_use(st, n) && single_use(st, n2) && ggml_abi_is_contiguous(n3)) {
+                    if (!run_mul_mat_q(st, a, n2->src[0], b, n3, nullptr, nullptr)) return -1;
+                    c->st.fused_nodes += 2;
+                    return 3;
+                }
+                // MUL_MAT -> ADD (bias or residual) [-> ADD]
+                ggml_tensor * a1 = next(1);
+                const ggml_tensor * o1 = (a1 && single_use(st, n)) ? add_partner(a1, n) : nullptr;
+                if (o1) {
+                    ggml_tensor * a2 = next(2);
+                    const ggml_tensor * o2 = (a2 && single_use(st, a1)) ? add_partner(a2, a1) : nullptr;
+                    if (o2) {
+                        if (!run_mul_mat_q(st, a, nullptr, b, a2, o1, o2)) return -1;
+                        c->st.fused_nodes += 2;
+                        return 3;
+                    }
+                    if (!run_mul_mat_q(st, a, nullptr, b, a1, o1, nullptr)) return -1;
+                    c->st.fused_nodes += 1;
+                    return 2;
+                }
+            }
+            if (!run_mul_mat_q(st, a, nullptr, b, n, nullptr, nullptr)) return -1;
+            if (rowpar) {
+                if (!tp_all_reduce(c, (float *) n->data, (size_t) ggml_abi_nelements(n))) return -1;
+                c->st.allreduces++;
+            }
+            return 1;
+        }
+
+        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: {
+            timed_scope ts(c, "binary", (double) ggml_abi_nbytes(n) * 3);
+            launch_binary(s, n->op, TD(a), TD(b), TD(n));
+            c->st.kernel_launches++;
+            return 1;
+        }
+        case GGML_OP_SCALE:
+            launch_scale(s, TD(a), TD(n), ggml_abi_op_param_f32(n, 0), ggml_abi_op_param_f32(n, 1));
+            c->st.kernel_launches++;
+            return 1;
+        case GGML_OP_UNARY:
+            launch_unary(s, n->op_params[0], TD(a), TD(n));
+            c->st.kernel_launches++;
+            return 1;
+        case GGML_OP_GLU: {
+            const tdesc bd = b ? TD(b) : TD(a);
+            timed_scope ts(c, "swiglu", (double) ggml_abi_nbytes(n) * 3);
+            launch_swiglu(s, TD(a), b ? &bd : nullptr, TD(n), n->op_params[1]);
+            c->st.kernel_launches++;
+            return 1;
+        }
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
+            if (a->type == n->type && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(n)) {
+                if (hipMemcpyAsync(n->data, a->data, ggml_abi_nbytes(a), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+            } else {
+                timed_scope ts(c, "cpy", (double) ggml_abi_nbytes(n) * 2);
+                launch_cpy(s, TD(a), TD(n));
+            }
+            c->st.kernel_launches++;
+            return 1;
+        }
+        case GGML_OP_GET_ROWS: {
+            timed_scope ts(c, "get_rows", (double) ggml_abi_nbytes(n));
+            launch_get_rows(s, TD(a), TD(b), TD(n));
+            c->st.kernel_launches++;
+            return 1;
+        }
+        case GGML_OP_SET_ROWS: {
+            timed_scope ts(c, "set_rows", (double) ggml_abi_nbytes(a));
+            launch_set_rows(s, TD(a), TD(b), TD(n));
+            c->st.kernel_launches++;
+            return 1;
+        }
+        case GGML_OP_SOFT_MAX: {
+            const tdesc md = b ? TD(b) : TD(a);
+            timed_scope ts(c, "soft_max", (double) ggml_abi_nbytes(n) * 2);
+            launch_soft_max(s, TD(a), b ? &md : nullptr, n->src[2] ? (const float *) n->src[2]->data : nullptr, TD(n), ggml_abi_op_param_f32(n, 0), ggml_abi_op_param_f32(n, 1));
+            c->st.kernel_launches++;
+            return 1;
+        }
+        case GGML_OP_ROPE: {
+            rope_params p;
+            p.n_dims = n->op_params[1];
+            p.mode = n->op_params[2];
+            p.n_ctx_orig = n->op_params[4];
+            p.freq_base = ggml_abi_op_param_f32(n, 5);
+            p.freq_scale = ggml_abi_op_param_f32(n, 6);
+            p.ext_factor = ggml_abi_op_param_f32(n, 7);
+            p.attn_factor = ggml_abi_op_param_f32(n, 8);
+            p.beta_fast = ggml_abi_op_param_f32(n, 9);
+            p.beta_slow = ggml_abi_op_param_f32(n, 10);
+            timed_scope ts(c, "rope", (double) ggml_abi_nbytes(n) * 2);
+            launch_rope(s, TD(a), TD(b), n->src[2] ? (const float *) n->src[2]->data : nullptr, TD(n), p);
+            c->st.kernel_launches++;
+            return 1;
+        }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            const ggml_tensor * k = n->src[1];
+            const ggml_tensor * v = n->src[2];
+            const ggml_tensor * m = n->src[3];
+            fattn_params p;
+            p.scale = ggml_abi_op_param_f32(n, 0);
+            p.max_bias = ggml_abi_op_param_f32(n, 1);
+            p.logit_softcap = ggml_abi_op_param_f32(n, 2);
+            const tdesc qd = TD(a), kd = TD(k), vd = TD(v);
+            p.n_splits = c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd);
+            const tdesc md = m ? TD(m) : qd;
+            timed_scope ts(c, "flash_attn", (double) (k->ne[1] * k->ne[2] * k->ne[0] * 2 * 2));
+            launch_flash_attn(s, qd, kd, vd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p, (char *) c->ws + st.aux_off);
+            c->st.kernel_launches += p.n_splits > 1 ? 2 : 1;
+            return 1;
+        }
+        case GGML_OP_ARGMAX:
+            launch_argmax(s, TD(a), TD(n));
+            c->st.kernel_launches++;
+            return 1;
+        default:
+            MI_ERR("graph_compute: unsupported op %d (node %d '%s')", (int) n->op, i, n->name);
+            return -1;
+    }
+}
+
+static bool run_nodes(backend_ctx * c, ggml_cgraph * g, const ws_plan & wp) {
+    exec_state st{c, g, {}, 0, wp.act_bytes};
+    st.uses.reserve((size_t) g->n_nodes * 2);
+    for (int i = 0; i < g->n_nodes; ++i)
+        for (int s = 0; s < GGML_MAX_SRC; ++s)
+            if (g->nodes[i]->src[s]) st.uses[g->nodes[i]->src[s]]++;
+    c->q8_src = nullptr;  // inputs change between graph launches
+    for (int i = 0; i < g->n_nodes;) {
+        ggml_tensor * n = g->nodes[i];
+        if (ggml_abi_nelements(n) == 0) { i++; continue; }
+        // anything that writes memory invalidates a cached quantisation of that memory
+        const int used = run_node(st, i);
+        if (used < 0) return false;
+        for (int k = 0; k < used; ++k) if (g->nodes[i + k]->data == c->q8_src) c->q8_src = nullptr;
+        i += used;
+    }
+    return hipGetLastError() == hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------ hipGraph cache
+static inline void fnv(uint64_t & h, const void * p, size_t n) {
+    const uint8_t * b = (const uint8_t *) p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001B3ull; }
+}
+static uint64_t fingerprint(const ggml_cgraph * g) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    fnv(h, &g->n_nodes, sizeof(int));
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        fnv(h, &n->op, sizeof(n->op));
+        fnv(h, &n->type, sizeof(n->type));
+        fnv(h, n->ne, sizeof(n->ne));
+        fnv(h, n->nb, sizeof(n->nb));
+        fnv(h, &n->data, sizeof(n->data));
+        fnv(h, n->op_params, sizeof(n->op_params));
+        fnv(h, &n->flags, sizeof(n->flags));
+        for (int s = 0; s < GGML_MAX_SRC; ++s) {
+            const ggml_tensor * t = n->src[s];
+            if (!t) continue;
+            fnv(h, &t->data, sizeof(t->data));
+            fnv(h, t->ne, sizeof(t->ne));
+            fnv(h, t->nb, sizeof(t->nb));
+            fnv(h, &t->type, sizeof(t->type));
+        }
+    }
+    return h;
+}
+
+void free_graph_cache(backend_ctx * c) {
+    for (auto & kv : c->graphs) {
+        if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void) hipGraphDestroy(kv.second.graph);
+    }
+    c->graphs.clear();
+}
+
+enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
+    if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
+    const ws_plan wp = plan_ws(c, g);
+    if (!ensure_ws(c, wp.act_bytes + wp.aux_bytes + 256)) return GGML_STATUS_ALLOC_FAILED;
+    c->tick++;
+    const bool want_graph = c->opt.graphs && !c->opt.timing && g->n_nodes >= 8;
+    if (!want_graph) {
+        c->st.eager_graphs++;
+        return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+    }
+    const uint64_t fp = fingerprint(g);
+    cached_graph & cg = c->graphs[fp];
+    cg.last_use = c->tick;
+    cg.seen++;
+    if (cg.exec) {
+        if (hipGraphLaunch(cg.exec, c->stream) != hipSuccess) {
+            (void) hipGetLastError();
+            return GGML_STATUS_FAILED;
+        }
+        c->st.graph_launches++;
+        return GGML_STATUS_SUCCESS;
+    }
+    if (cg.seen < 2 || cg.seen > 1000000) {  // first sighting: run eagerly (one-off prefill graphs never pay for capture)
+        c->st.eager_graphs++;
+        const bool ok = run_nodes(c, g, wp);
+        if (c->graphs.size() > 64) {  // bound the cache: drop everything that is not instantiated and old
+            for (auto it = c->graphs.begin(); it != c->graphs.end();) {
+                if (it->second.last_use + 256 < c->tick) {
+                    if (it->second.exec) (void) hipGraphExecDestroy(it->second.exec);
+                    if (it->second.graph) (void) hipGraphDestroy(it->second.graph);
+                    it = c->graphs.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
+        return ok ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+    }
+    // second sighting: capture, instantiate, replay
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void) hipGetLastError();
+        c->st.eager_graphs++;
+        return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+    }
+    c->capturing = true;
+    const bool ok = run_nodes(c, g, wp);
+    c->capturing = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+    if (!ok || e_end != hipSuccess || graph == nullptr) {
+        (void) hipGetLastError();
+        if (graph) (void) hipGraphDestroy(graph);
+        MI_INFO("hipGraph capture failed (ok=%d, err=%d); running this topology eagerly from now on", (int) ok, (int) e_end);
+        cg.seen = 1000001;  // never try again
+        c->st.eager_graphs++;
+        return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || exec == nullptr) {
+        (void) hipGetLastError();
+        (void) hipGraphDestroy(graph);
+        cg.seen = 1000001;
+        c->st.eager_graphs++;
+        return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+    }
+    cg.graph = graph;
+    cg.exec = exec;
+    c->st.graph_captures++;
+    if (hipGraphLaunch(cg.exec, c->stream) != hipSuccess) {
+        (void) hipGetLastError();
+        return GGML_STATUS_FAILED;
+    }
+    c->st.graph_launches++;
+    return GGML_STATUS_SUCCESS;
+}
+
+}  // namespace mi355x

@@ -1,0 +1,86 @@
+// kernels.h — host-callable launchers of the hand-written gfx950 kernels (internal; not part of the C-ABI).
+#pragma once
+#include "common.h"
+
+namespace mi355x {
+
+// plain-data view of a ggml_tensor that can be passed to kernels by value
+struct tdesc {
+    char * data;
+    int64_t ne[4];
+    int64_t nb[4];  // bytes
+    int type;
+};
+inline tdesc TD(const ggml_tensor * t) {
+    tdesc d;
+    d.data = (char *) t->data;
+    for (int i = 0; i < 4; ++i) {
+        d.ne[i] = t->ne[i];
+        d.nb[i] = (int64_t) t->nb[i];
+    }
+    d.type = (int) t->type;
+    return d;
+}
+
+// ---- activation quantisation (quantize.hip)
+// src: f32 rows of K elements (dim0 contiguous), any strides on dims 1..3; rows are enumerated i1 fastest.
+// kind: GGML_TYPE_Q8_K -> q8k_dev[rows][K/256]; GGML_TYPE_Q8_0 -> q80_dev[rows][K/32]
+size_t quantized_act_bytes(int kind, int64_t K, int64_t rows);
+void launch_quantize_act(hipStream_t s, int kind, const tdesc & src, void * dst);
+
+// ---- bandwidth-bound quantised mat-vec, 1..8 activation columns (mmvq.hip)
+struct mmvq_args {
+    const uint8_t * W;     // [N] rows, row stride w_nb1 bytes
+    const uint8_t * W2;    // optional second matrix (fused gate/up): out = silu(W·x) * (W2·x)
+    int64_t w_nb1;
+    int type;              // ggml_type of W
+    int K, N;
+    int ncols;             // 1..8
+    const void * act;      // quantised activations [ncols][K/blk]
+    float * dst;           // dst[col * dst_stride + row]
+    int64_t dst_stride;    // elements
+    const float * add;     // optional: dst += add[col * add_stride + row]  (bias: add_stride = 0; residual: = dst_stride)
+    int64_t add_stride;
+    const float * add2;    // optional second addend (bias AND residual)
+    int64_t add2_stride;
+};
+void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave);
+
+// ---- f16 / f32 weights (K cache, V cache, small dense) (mmf.hip): dst = src0 · src1 with ggml broadcasting;
+// src1 rounded to f16 first when src0 is f16 (ggml-cpu vec_dot_type semantics)
+void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, const tdesc & dst);
+
+// ---- prefill: quantised weights x many columns through MFMA (mmq.hip)
+bool mmq_supported(int type, int64_t K, int64_t N, int64_t M);
+size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M);
+void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride);
+
+// ---- element-wise / normalisation / data movement (ops.hip)
+void launch_rms_norm(hipStream_t s, const tdesc & src, const tdesc & dst, float eps, const tdesc * mul_w /* optional fused weight */);
+void launch_binary(hipStream_t s, int op, const tdesc & a, const tdesc & b, const tdesc & dst);
+void launch_scale(hipStream_t s, const tdesc & src, const tdesc & dst, float scale, float bias);
+void launch_unary(hipStream_t s, int uop, const tdesc & src, const tdesc & dst);
+void launch_swiglu(hipStream_t s, const tdesc & a, const tdesc * b, const tdesc & dst, int swapped);
+void launch_cpy(hipStream_t s, const tdesc & src, const tdesc & dst);
+void launch_get_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
+void launch_set_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
+void launch_argmax(hipStream_t s, const tdesc & src, const tdesc & dst);
+
+struct rope_params {
+    int n_dims, mode, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+};
+void launch_rope(hipStream_t s, const tdesc & src, const tdesc & pos, const float * freq_factors, const tdesc & dst, const rope_params & p);
+void launch_soft_max(hipStream_t s, const tdesc & src, const tdesc * mask, const float * sinks, const tdesc & dst, float scale, float max_bias);
+
+// ---- attention (fattn.hip)
+struct fattn_params {
+    float scale, max_bias, logit_softcap;
+    int n_splits;  // KV splits per (token, kv-head group)
+};
+size_t fattn_workspace_bytes(const tdesc & q, const tdesc & v, int n_splits);
+int fattn_pick_splits(const tdesc & q, const tdesc & k);
+void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks,
+                       const tdesc & dst, const fattn_params & p, void * workspace);
+
+}  // namespace mi355x

@@ -1,0 +1,409 @@
+// ops.hip — normalisation, element-wise, RoPE, soft-max and data-movement kernels of the hot path.
+//
+// Each kernel restates the ggml-cpu routine named in its comment with the same
+// arithmetic per element (this file is compiled with -ffp-contract=off, so `a*b - c` is two roundings exactly as
+// in the CPU reference) and a wave64 mapping: rows are reduced with 64-lane butterflies, f32 is moved as float4.
+// These ops are launch-bound at decode sizes; graph.cpp fuses the common chains so most of them disappear.
+#include "dev_util.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+// block-wide reductions over 256 threads (4 waves)
+__device__ __forceinline__ double block_sum_d(double v, double * sh) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
+__device__ __forceinline__ float block_max_f(float v, float * sh) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = sh[0];
+    const int nw = blockDim.x >> 6;
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, sh[i]);
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------ RMS_NORM (+MUL)
+// ggml_compute_forward_rms_norm_f32: sum of squares accumulated in double, scale = 1/sqrtf(mean + eps), y = x*scale;
+// optional fused `* w` (the MUL node that always follows in llm_build_*)
+__global__ void __launch_bounds__(256) k_rms_norm(const tdesc a, const tdesc d, const float eps, const float * __restrict__ w) {
+    __shared__ double sh[4];
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % a.ne[1], i2 = (row / a.ne[1]) % a.ne[2], i3 = row / (a.ne[1] * a.ne[2]);
+    const float * x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    float * y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const int64_t n = a.ne[0];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = x[i];
+        s += (double) (v * v);
+    }
+    s = block_sum_d(s, sh);
+    const float mean = (float) (s / (double) n);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = x[i] * scale;
+        if (w) v = v * w[i];
+        y[i] = v;
+    }
+}
+void launch_rms_norm(hipStream_t s, const tdesc & src, const tdesc & dst, float eps, const tdesc * mul_w) {
+    const int64_t rows = src.ne[1] * src.ne[2] * src.ne[3];
+    hipLaunchKernelGGL(k_rms_norm, dim3((unsigned) rows), dim3(256), 0, s, src, dst, eps, mul_w ? (const float *) mul_w->data : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ ADD/SUB/MUL/DIV
+__global__ void __launch_bounds__(256) k_binary(const int op, const tdesc a, const tdesc b, const tdesc d) {
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % a.ne[1], i2 = (row / a.ne[1]) % a.ne[2], i3 = row / (a.ne[1] * a.ne[2]);
+    const char * pa = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+    const char * pb = b.data + (i1 % b.ne[1]) * b.nb[1] + (i2 % b.ne[2]) * b.nb[2] + (i3 % b.ne[3]) * b.nb[3];
+    char * pd = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+    for (int64_t i0 = threadIdx.x; i0 < a.ne[0]; i0 += blockDim.x) {
+        const float x = *(const float *) (pa + i0 * a.nb[0]);
+        const float y = *(const float *) (pb + (i0 % b.ne[0]) * b.nb[0]);
+        float r;
+        switch (op) {
+            case GGML_OP_ADD: r = x + y; break;
+            case GGML_OP_SUB: r = x - y; break;
+            case GGML_OP_MUL: r = x * y; break;
+            default: r = x / y; break;
+        }
+        *(float *) (pd + i0 * d.nb[0]) = r;
+    }
+}
+void launch_binary(hipStream_t s, int op, const tdesc & a, const tdesc & b, const tdesc & d) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    hipLaunchKernelGGL(k_binary, dim3((unsigned) rows), dim3(256), 0, s, op, a, b, d);
+}
+
+// ------------------------------------------------------------------------------------------------ SCALE / UNARY / GLU
+// scale: dst = scale*x + bias (llama-box/patches/llama.cpp/ggml-cuda.patch:8-15)
+__global__ void __launch_bounds__(256) k_scale(const float * __restrict__ x, float * __restrict__ y, const int64_t n, const float sc, const float bias) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const float p = x[i] * sc;
+        y[i] = p + bias;
+    }
+}
+void launch_scale(hipStream_t s, const tdesc & src, const tdesc & dst, float scale, float bias) {
+    const int64_t n = src.ne[0] * src.ne[1] * src.ne[2] * src.ne[3];
+    const unsigned grid = (unsigned) std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_scale, dim3(grid), dim3(256), 0, s, (const float *) src.data, (float *) dst.data, n, scale, bias);
+}
+
+__global__ void __launch_bounds__(256) k_unary(const int uop, const float * __restrict__ x, float * __restrict__ y, const int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float r;
+        switch (uop) {
+            case GGML_UNARY_OP_SILU: r = silu_f(v); break;
+            case GGML_UNARY_OP_RELU: r = v > 0.f ? v : 0.f; break;
+            case GGML_UNARY_OP_NEG: r = -v; break;
+            case GGML_UNARY_OP_EXP: r = expf(v); break;
+            case GGML_UNARY_OP_TANH: r = tanhf(v); break;
+            default: r = 1.f / (1.f + expf(-v)); break;  // SIGMOID
+        }
+        y[i] = r;
+    }
+}
+void launch_unary(hipStream_t s, int uop, const tdesc & src, const tdesc & dst) {
+    const int64_t n = src.ne[0] * src.ne[1] * src.ne[2] * src.ne[3];
+    const unsigned grid = (unsigned) std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_unary, dim3(grid), dim3(256), 0, s, uop, (const float *) src.data, (float *) dst.data, n);
+}
+
+// swiglu: y = silu(a) * b (ggml_compute_forward_swiglu_f32); split form (two tensors) or the two halves of one row
+__global__ void __launch_bounds__(256) k_swiglu(const char * __restrict__ pa, const char * __restrict__ pb, char * __restrict__ pd, const int64_t nc,
+                                                const int64_t nba1, const int64_t nbb1, const int64_t nbd1) {
+    const int64_t row = blockIdx.x;
+    const float * a = (const float *) (pa + row * nba1);
+    const float * b = (const float *) (pb + row * nbb1);
+    float * y = (float *) (pd + row * nbd1);
+    for (int64_t i = threadIdx.x; i < nc; i += blockDim.x) y[i] = silu_f(a[i]) * b[i];
+}
+void launch_swiglu(hipStream_t s, const tdesc & a, const tdesc * b, const tdesc & d, int swapped) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    const int64_t nc = d.ne[0];
+    const char * pa = a.data;
+    const char * pb = b ? b->data : a.data;
+    if (!b) {
+        pa += swapped ? nc * 4 : 0;
+        pb += swapped ? 0 : nc * 4;
+    }
+    hipLaunchKernelGGL(k_swiglu, dim3((unsigned) rows), dim3(256), 0, s, pa, pb, d.data, nc, a.nb[1], b ? b->nb[1] : a.nb[1], d.nb[1]);
+}
+
+// ------------------------------------------------------------------------------------------------ CPY / DUP / CONT
+// ggml_compute_forward_dup: same logical element order on both sides, f32/f16 conversion (RNE)
+template <typename TS, typename TDST> __device__ __forceinline__ TDST conv(TS v);
+template <> __device__ __forceinline__ float conv<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ uint16_t conv<float, uint16_t>(float v) { return f2h(v); }
+template <> __device__ __forceinline__ float conv<uint16_t, float>(uint16_t v) { return h2f(v); }
+template <> __device__ __forceinline__ uint16_t conv<uint16_t, uint16_t>(uint16_t v) { return v; }
+template <> __device__ __forceinline__ int32_t conv<int32_t, int32_t>(int32_t v) { return v; }
+
+template <typename TS, typename TDST> __global__ void __launch_bounds__(256) k_cpy(const tdesc a, const tdesc d, const int64_t n) {
+    for (int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t) gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int64_t s0 = r % a.ne[0]; r /= a.ne[0];
+        const int64_t s1 = r % a.ne[1]; r /= a.ne[1];
+        const int64_t s2 = r % a.ne[2]; r /= a.ne[2];
+        const int64_t s3 = r;
+        r = e;
+        const int64_t d0 = r % d.ne[0]; r /= d.ne[0];
+        const int64_t d1 = r % d.ne[1]; r /= d.ne[1];
+        const int64_t d2 = r % d.ne[2]; r /= d.ne[2];
+        const int64_t d3 = r;
+        const TS v = *(const TS *) (a.data + s0 * a.nb[0] + s1 * a.nb[1] + s2 * a.nb[2] + s3 * a.nb[3]);
+        *(TDST *) (d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]) = conv<TS, TDST>(v);
+    }
+}
+void launch_cpy(hipStream_t s, const tdesc & a, const tdesc & d) {
+    const int64_t n = a.ne[0] * a.ne[1] * a.ne[2] * a.ne[3];
+    const unsigned grid = (unsigned) std::min<int64_t>((n + 255) / 256, 4096);
+    const int st = a.type, dt = d.type;
+    if (st == GGML_TYPE_F32 && dt == GGML_TYPE_F32) hipLaunchKernelGGL((k_cpy<float, float>), dim3(grid), dim3(256), 0, s, a, d, n);
+    else if (st == GGML_TYPE_F32 && dt == GGML_TYPE_F16) hipLaunchKernelGGL((k_cpy<float, uint16_t>), dim3(grid), dim3(256), 0, s, a, d, n);
+    else if (st == GGML_TYPE_F16 && dt == GGML_TYPE_F32) hipLaunchKernelGGL((k_cpy<uint16_t, float>), dim3(grid), dim3(256), 0, s, a, d, n);
+    else if (st == GGML_TYPE_F16 && dt == GGML_TYPE_F16) hipLaunchKernelGGL((k_cpy<uint16_t, uint16_t>), dim3(grid), dim3(256), 0, s, a, d, n);
+    else if (st == GGML_TYPE_I32 && dt == GGML_TYPE_I32) hipLaunchKernelGGL((k_cpy<int32_t, int32_t>), dim3(grid), dim3(256), 0, s, a, d, n);
+    else { MI_ERR("launch_cpy: unsupported types %d -> %d", st, dt); abort(); }
+}
+
+// ------------------------------------------------------------------------------------------------ GET_ROWS
+// dequantize_row_{q8_0,q4_K,q5_K,q6_K} element formulas: one workgroup per gathered row
+__device__ __forceinline__ void k4_scale_min(int j, const uint8_t * q, int & sc, int & m) {
+    if (j < 4) { sc = q[j] & 63; m = q[j + 4] & 63; }
+    else { sc = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+__device__ __forceinline__ float dequant_elem(const int type, const uint8_t * __restrict__ row, const int64_t i) {
+    switch (type) {
+        case GGML_TYPE_F32: return ((const float *) row)[i];
+        case GGML_TYPE_F16: return h2f(((const uint16_t *) row)[i]);
+        case GGML_TYPE_Q8_0: {
+            const uint8_t * b = row + (i >> 5) * 34;
+            return (float) (int8_t) b[2 + (i & 31)] * h2f(ld16(b));
+        }
+        case GGML_TYPE_Q4_K:
+        case GGML_TYPE_Q5_K: {
+            const bool q5 = type == GGML_TYPE_Q5_K;
+            const uint8_t * b = row + (i >> 8) * (q5 ? 176 : 144);
+            const int e = (int) (i & 255), is = e >> 5, l = e & 31, j = e >> 6;
+            const float d = h2f(ld16(b)), mn = h2f(ld16(b + 2));
+            int sc, m;
+            k4_scale_min(is, b + 4, sc, m);
+            const uint8_t * qs = b + (q5 ? 48 : 16) + 32 * j;
+            int q = (is & 1) ? (qs[l] >> 4) : (qs[l] & 0xF);
+            if (q5) q += ((b[16 + l] >> is) & 1) ? 16 : 0;
+            const float d1 = d * (float) sc, m1 = mn * (float) m;
+            return d1 * (float) q - m1;
+        }
+        case GGML_TYPE_Q6_K: {
+            const uint8_t * b = row + (i >> 8) * 210;
+            const int e = (int) (i & 255), h = e >> 7, r = e & 127, k = r >> 5, l = r & 31;
+            const uint8_t * ql = b + 64 * h, * qh = b + 128 + 32 * h;
+            const int8_t * sc = (const int8_t *) (b + 192 + 8 * h);
+            const int lo = (k & 1) ? ql[l + 32] : ql[l];
+            const int nib = (k & 2) ? (lo >> 4) : (lo & 0xF);
+            const int q = (int) (int8_t) (nib | (((qh[l] >> (2 * k)) & 3) << 4)) - 32;
+            const float d = h2f(ld16(b + 208));
+            return d * (float) sc[(l >> 4) + 2 * k] * (float) q;
+        }
+        default: return 0.0f;
+    }
+}
+__global__ void __launch_bounds__(256) k_get_rows(const tdesc a, const tdesc idx, const tdesc d) {
+    const int64_t r = blockIdx.x;
+    const int64_t i10 = r % idx.ne[0], i11 = (r / idx.ne[0]) % idx.ne[1], i12 = r / (idx.ne[0] * idx.ne[1]);
+    const int32_t i01 = *(const int32_t *) (idx.data + i10 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+    const uint8_t * row = (const uint8_t *) (a.data + (int64_t) i01 * a.nb[1] + i11 * a.nb[2] + i12 * a.nb[3]);
+    float * y = (float *) (d.data + i10 * d.nb[1] + i11 * d.nb[2] + i12 * d.nb[3]);
+    for (int64_t i = threadIdx.x; i < a.ne[0]; i += blockDim.x) y[i] = dequant_elem(a.type, row, i);
+}
+void launch_get_rows(hipStream_t s, const tdesc & a, const tdesc & idx, const tdesc & d) {
+    const int64_t rows = idx.ne[0] * idx.ne[1] * idx.ne[2];
+    hipLaunchKernelGGL(k_get_rows, dim3((unsigned) rows), dim3(256), 0, s, a, idx, d);
+}
+
+// ------------------------------------------------------------------------------------------------ SET_ROWS
+// ggml_compute_forward_set_rows_f32: dst row idx[i] = convert(src row i); I64 indices; f32 -> f32 / f16 (RNE)
+__global__ void __launch_bounds__(256) k_set_rows(const tdesc a, const tdesc idx, const tdesc d) {
+    const int64_t nc = a.ne[0];
+    if (nc == 1) {  // element scatter (transposed V cache): one thread per row
+        const int64_t total = a.ne[1] * a.ne[2] * a.ne[3];
+        for (int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (int64_t) gridDim.x * blockDim.x) {
+            const int64_t i01 = r % a.ne[1], i02 = (r / a.ne[1]) % a.ne[2], i03 = r / (a.ne[1] * a.ne[2]);
+            const int64_t i1 = *(const int64_t *) (idx.data + i01 * idx.nb[0] + (i02 % idx.ne[1]) * idx.nb[1] + (i03 % idx.ne[2]) * idx.nb[2]);
+            const float v = *(const float *) (a.data + i01 * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3]);
+            char * p = d.data + i1 * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3];
+            if (d.type == GGML_TYPE_F16) *(uint16_t *) p = f2h(v); else *(float *) p = v;
+        }
+        return;
+    }
+    const int64_t r = blockIdx.x;
+    const int64_t i01 = r % a.ne[1], i02 = (r / a.ne[1]) % a.ne[2], i03 = r / (a.ne[1] * a.ne[2]);
+    const int64_t i1 = *(const int64_t *) (idx.data + i01 * idx.nb[0] + (i02 % idx.ne[1]) * idx.nb[1] + (i03 % idx.ne[2]) * idx.nb[2]);
+    const float * x = (const float *) (a.data + i01 * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3]);
+    char * p = d.data + i1 * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3];
+    if (d.type == GGML_TYPE_F16) for (int64_t i = threadIdx.x; i < nc; i += blockDim.x) ((uint16_t *) p)[i] = f2h(x[i]);
+    else for (int64_t i = threadIdx.x; i < nc; i += blockDim.x) ((float *) p)[i] = x[i];
+}
+void launch_set_rows(hipStream_t s, const tdesc & a, const tdesc & idx, const tdesc & d) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    const unsigned grid = a.ne[0] == 1 ? (unsigned) std::min<int64_t>((rows + 255) / 256, 4096) : (unsigned) rows;
+    hipLaunchKernelGGL(k_set_rows, dim3(grid), dim3(256), 0, s, a, idx, d);
+}
+
+// ------------------------------------------------------------------------------------------------ ARGMAX
+__global__ void __launch_bounds__(256) k_argmax(const tdesc a, const tdesc d) {
+    __shared__ float smax[4];
+    __shared__ int sidx[4];
+    const int64_t row = blockIdx.x;
+    const float * x = (const float *) (a.data + row * a.nb[1]);
+    float mx = -INFINITY;
+    int mi = 0x7FFFFFFF;
+    for (int64_t i = threadIdx.x; i < a.ne[0]; i += blockDim.x) {
+        const float v = x[i];
+        if (v > mx) { mx = v; mi = (int) i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { smax[wave] = mx; sidx[wave] = mi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) if (smax[w] > mx || (smax[w] == mx && sidx[w] < mi)) { mx = smax[w]; mi = sidx[w]; }
+        ((int32_t *) d.data)[row] = mi == 0x7FFFFFFF ? 0 : mi;
+    }
+}
+void launch_argmax(hipStream_t s, const tdesc & a, const tdesc & d) {
+    hipLaunchKernelGGL(k_argmax, dim3((unsigned) a.ne[1]), dim3(256), 0, s, a, d);
+}
+
+// ------------------------------------------------------------------------------------------------ ROPE
+// ggml_compute_forward_rope_f32/_f16 (patch->ggml-cpu/ops.cpp:6204,:6390; llama-box/patches/llama.cpp/mrope.patch:5-26).
+// theta for pair i is produced by the SAME chain of f32 multiplies as the CPU's cache loop (theta *= theta_scale),
+// so the angle is bit-identical; cosf/sinf are the accurate device versions.  normal: pairs (2i, 2i+1); neox: (i, i+n/2).
+__device__ __forceinline__ float yarn_ramp(const float low, const float high, const int i0) {
+    const float y = ((float) (i0 / 2) - low) / fmaxf(0.001f, high - low);
+    return 1.0f - fminf(1.0f, fmaxf(0.0f, y));
+}
+template <bool F16IO> __global__ void __launch_bounds__(64) k_rope(const tdesc a, const tdesc pos, const float * __restrict__ ff, const tdesc d, const rope_params p,
+                                                               const float theta_scale, const float corr0, const float corr1) {
+    // grid: (token i2, batch i3); lanes = pairs; loop over heads inside so the angle is computed once per (token, pair)
+    const int64_t i2 = blockIdx.x, i3 = blockIdx.y;
+    const int n_pairs = p.n_dims / 2;
+    const float pos_f = (float) *(const int32_t *) (pos.data + i2 * pos.nb[0]);
+    for (int ip = threadIdx.x; ip < n_pairs; ip += blockDim.x) {
+        float theta = pos_f;
+        for (int k = 0; k < ip; ++k) theta *= theta_scale;
+        const float fq = ff ? ff[ip] : 1.0f;
+        const float theta_extrap = theta / fq;
+        const float theta_interp = p.freq_scale * theta_extrap;
+        float th = theta_interp, mscale = p.attn_factor;
+        if (p.ext_factor != 0.0f) {
+            const float ramp_mix = yarn_ramp(corr0, corr1, 2 * ip) * p.ext_factor;
+            th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+            mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
+        }
+        const float cs = cosf(th) * mscale, sn = sinf(th) * mscale;
+        const bool neox = (p.mode & GGML_ROPE_TYPE_NEOX) != 0;
+        const int ia = neox ? ip : 2 * ip, ib = neox ? ip + n_pairs : 2 * ip + 1;
+        for (int64_t i1 = 0; i1 < a.ne[1]; ++i1) {
+            const char * src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+            char * dst = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+            if (F16IO) {
+                const float x0 = h2f(((const uint16_t *) src)[ia]), x1 = h2f(((const uint16_t *) src)[ib]);
+                ((uint16_t *) dst)[ia] = f2h(x0 * cs - x1 * sn);
+                ((uint16_t *) dst)[ib] = f2h(x0 * sn + x1 * cs);
+            } else {
+                const float x0 = ((const float *) src)[ia], x1 = ((const float *) src)[ib];
+                ((float *) dst)[ia] = x0 * cs - x1 * sn;
+                ((float *) dst)[ib] = x0 * sn + x1 * cs;
+            }
+        }
+    }
+    // pass-through tail beyond n_dims
+    for (int64_t i0 = p.n_dims + threadIdx.x; i0 < a.ne[0]; i0 += blockDim.x) {
+        for (int64_t i1 = 0; i1 < a.ne[1]; ++i1) {
+            const char * src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+            char * dst = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+            if (F16IO) ((uint16_t *) dst)[i0] = ((const uint16_t *) src)[i0];
+            else ((float *) dst)[i0] = ((const float *) src)[i0];
+        }
+    }
+}
+void launch_rope(hipStream_t s, const tdesc & a, const tdesc & pos, const float * ff, const tdesc & d, const rope_params & p) {
+    const float theta_scale = powf(p.freq_base, -2.0f / (float) p.n_dims);
+    // ggml_rope_yarn_corr_dims
+    auto corr_dim = [&](float n_rot) { return (float) p.n_dims * logf((float) p.n_ctx_orig / (n_rot * 2.0f * (float) M_PI)) / (2.0f * logf(p.freq_base)); };
+    const float c0 = fmaxf(0.0f, floorf(corr_dim(p.beta_fast)));
+    const float c1 = fminf((float) (p.n_dims - 1), ceilf(corr_dim(p.beta_slow)));
+    dim3 grid((unsigned) a.ne[2], (unsigned) a.ne[3]);
+    if (a.type == GGML_TYPE_F16) hipLaunchKernelGGL(k_rope<true>, grid, dim3(64), 0, s, a, pos, ff, d, p, theta_scale, c0, c1);
+    else hipLaunchKernelGGL(k_rope<false>, grid, dim3(64), 0, s, a, pos, ff, d, p, theta_scale, c0, c1);
+}
+
+// ------------------------------------------------------------------------------------------------ SOFT_MAX
+// ggml_compute_forward_soft_max_f32 with llama-box's zero-sum guard (llama-box/patches/llama.cpp/ggml-cpu.patch:5-15):
+// w = x*scale + slope*mask; max; p = expf(w - max); sum in double; if (isnan(sum) || sum == 0) sum = -inf; p *= 1/sum
+__global__ void __launch_bounds__(256) k_soft_max(const tdesc a, const tdesc m, const int has_mask, const float * __restrict__ sinks, const tdesc d,
+                                                  const float scale, const float max_bias, const float m0, const float m1, const uint32_t n_head_log2) {
+    __shared__ double shd[4];
+    __shared__ float shf[4];
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % a.ne[1], i2 = (row / a.ne[1]) % a.ne[2], i3 = row / (a.ne[1] * a.ne[2]);
+    const float * x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    float * y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const char * mp = has_mask ? m.data + i1 * m.nb[1] + (i2 % m.ne[2]) * m.nb[2] + (i3 % m.ne[3]) * m.nb[3] : nullptr;
+    const uint32_t h = (uint32_t) i2;
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const int64_t n = a.ne[0];
+    float mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float w = x[i] * scale;
+        if (mp) {
+            const float mv = m.type == GGML_TYPE_F16 ? h2f(((const uint16_t *) mp)[i]) : ((const float *) mp)[i];
+            w += slope * mv;
+        }
+        y[i] = w;
+        mx = fmaxf(mx, w);
+    }
+    mx = block_max_f(mx, shf);
+    if (sinks) mx = fmaxf(mx, sinks[i2]);
+    double sum = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = expf(y[i] - mx);
+        y[i] = v;
+        sum += (double) v;
+    }
+    sum = block_sum_d(sum, shd);
+    if (sinks) sum += (double) expf(sinks[i2] - mx);
+    if (isnan(sum) || sum == 0.0) sum = -INFINITY;
+    const float inv = (float) (1.0 / sum);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) y[i] *= inv;
+}
+void launch_soft_max(hipStream_t s, const tdesc & a, const tdesc * mask, const float * sinks, const tdesc & d, float scale, float max_bias) {
+    const uint32_t n_head = (uint32_t) a.ne[2];
+    const uint32_t n_head_log2 = 1u << (uint32_t) floor(log2((double) n_head));
+    const float m0 = powf(2.0f, -(max_bias) / (float) n_head_log2);
+    const float m1 = powf(2.0f, -(max_bias / 2.0f) / (float) n_head_log2);
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    tdesc dummy = a;
+    hipLaunchKernelGGL(k_soft_max, dim3((unsigned) rows), dim3(256), 0, s, a, mask ? *mask : dummy, mask ? 1 : 0, sinks, d, scale, max_bias, m0, m1, n_head_log2);
+}
+
+}  // namespace mi355x

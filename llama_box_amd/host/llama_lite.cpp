@@ -1,0 +1,822 @@
+// llama_lite.cpp — see llama_lite.h.  Own driver: model container (synthetic or GGUF), unified KV cache,
+// per-micro-batch graph construction in the op order llm_build_llama / llm_build_qwen2 emit,
+// and a llama_decode-shaped entry point.  Harness code; depends only on ggml_lite.h (never on the oracle).
+#include "llama_lite.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gguf_lite.h"
+
+#define LLM_ASSERT(x)                                                                           \
+    do {                                                                                        \
+        if (!(x)) {                                                                             \
+            fprintf(stderr, "llama_lite: %s:%d: assertion failed: %s\n", __FILE__, __LINE__, #x); \
+            abort();                                                                            \
+        }                                                                                       \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------- utilities
+static uint16_t f32_to_f16(float f) {  // IEEE binary16, round-to-nearest-even
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t) ((x >> 16) & 0x8000);
+    const uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) return (uint16_t) (sign | 0x7C00 | (ax > 0x7F800000u ? 0x200 : 0));
+    if (ax >= 0x477FF000u) return (uint16_t) (sign | 0x7C00);
+    if (ax < 0x33000001u) return sign;
+    const int32_t e = (int32_t) (ax >> 23) - 127;
+    uint32_t man = (ax & 0x7FFFFFu) | 0x800000u, shift = 13, base = 0;
+    if (e < -14) shift = (uint32_t) (13 + (-14 - e));
+    else { base = (uint32_t) (e + 15) << 10; man &= 0x7FFFFFu; }
+    const uint32_t halfway = 1u << (shift - 1), rem = man & ((1u << shift) - 1);
+    uint32_t q = man >> shift;
+    if (rem > halfway || (rem == halfway && (q & 1))) q++;
+    return (uint16_t) (sign | (base + q));
+}
+
+static inline uint64_t splitmix64(uint64_t & s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline float u01(uint64_t r) { return (float) ((r >> 40) * (1.0 / 16777216.0)); }
+
+static double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------ synthetic quant blocks
+// Blocks are sampled directly in the packed domain (SURVEY.md §8d "Synthetic inputs"): quants uniform, 6-bit
+// scales uniform with mins tied to scales so that dequantised weights are ~zero-mean with std ~ s/sqrt(K).
+// Every block is a pure function of (seed, tensor id, GLOBAL row, GLOBAL block-in-row) so that a
+// tensor-parallel shard generates exactly the bytes the unsharded model holds at the same coordinates.
+static void synth_block(ggml_type type, uint64_t key, int64_t K, uint8_t * out) {
+    uint64_t s = key;
+    const float scale = 0.5f + u01(splitmix64(s));  // s in U(0.5, 1.5)
+    const float rk = 1.0f / sqrtf((float) K);
+    auto fill = [&](uint8_t * p, size_t n) {
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t r = splitmix64(s);
+            memcpy(p + i, &r, 8);
+        }
+        if (i < n) {
+            uint64_t r = splitmix64(s);
+            memcpy(p + i, &r, n - i);
+        }
+    };
+    switch (type) {
+        case GGML_TYPE_Q8_0: {
+            block_q8_0 * b = (block_q8_0 *) out;
+            fill((uint8_t *) b->qs, 32);
+            for (int i = 0; i < 32; ++i) if (b->qs[i] == -128) b->qs[i] = -127;
+            b->d = f32_to_f16(scale * rk / 73.0f);
+        } break;
+        case GGML_TYPE_Q4_K:
+        case GGML_TYPE_Q5_K: {
+            uint8_t * p = out;
+            uint8_t sc[8], mn[8];
+            uint64_t r = splitmix64(s), r2 = splitmix64(s);
+            for (int j = 0; j < 8; ++j) {
+                sc[j] = (uint8_t) (8 + ((r >> (8 * j)) & 0xFF) % 56);
+                int m = (int) sc[j] + (int) ((r2 >> (8 * j)) & 0xFF) % 9 - 4;
+                mn[j] = (uint8_t) std::min(63, std::max(0, m));
+            }
+            const bool q5 = type == GGML_TYPE_Q5_K;
+            const float qmean = q5 ? 15.5f : 7.5f, qstd = q5 ? 9.2f : 4.6f;
+            const float d = scale * rk / (36.0f * qstd);
+            const uint16_t hd = f32_to_f16(d), hm = f32_to_f16(d * qmean);
+            memcpy(p, &hd, 2);
+            memcpy(p + 2, &hm, 2);
+            uint8_t * q = p + 4;
+            for (int j = 0; j < 4; ++j) {
+                q[j] = (uint8_t) ((sc[j] & 63) | ((sc[j + 4] >> 4) << 6));
+                q[j + 4] = (uint8_t) ((mn[j] & 63) | ((mn[j + 4] >> 4) << 6));
+                q[j + 8] = (uint8_t) ((sc[j + 4] & 0xF) | ((mn[j + 4] & 0xF) << 4));
+            }
+            fill(p + 16, q5 ? 32 + 128 : 128);
+        } break;
+        case GGML_TYPE_Q6_K: {
+            block_q6_K * b = (block_q6_K *) out;
+            fill(b->ql, 128 + 64);
+            uint64_t r = splitmix64(s), r2 = splitmix64(s);
+            for (int j = 0; j < 16; ++j) {
+                uint64_t rr = j < 8 ? r : r2;
+                int v = 16 + (int) ((rr >> (8 * (j & 7))) & 0x7F) % 112;  // 16..127
+                if ((rr >> (8 * (j & 7) + 7)) & 1) v = -v;
+                b->scales[j] = (int8_t) v;
+            }
+            b->d = f32_to_f16(scale * rk / (70.0f * 18.5f));
+        } break;
+        default: LLM_ASSERT(!"synth_block: unsupported type");
+    }
+}
+
+struct synth_spec {
+    uint64_t seed;
+    int tensor_id;
+    ggml_type type;
+    int64_t K_global;       // full row length (elements)
+    int64_t row_off;        // global index of local row 0
+    int64_t blk_off;        // global block index (within a row) of local block 0
+    int64_t blocks_per_row; // local
+    int64_t blocks_per_row_global;
+    int64_t n_rows;         // local
+    float f32_lo, f32_hi;   // for F32 tensors
+};
+
+static void synth_rows(const synth_spec & sp, int64_t row0, int64_t row1, uint8_t * dst) {
+    const size_t bs = ggml_abi_type_size(sp.type);
+    if (sp.type == GGML_TYPE_F32 || sp.type == GGML_TYPE_F16) {
+        const int64_t n = sp.blocks_per_row;  // elements per local row
+        for (int64_t r = row0; r < row1; ++r) {
+            for (int64_t i = 0; i < n; ++i) {
+                uint64_t s = sp.seed ^ ((uint64_t) sp.tensor_id * 0xD1B54A32D192ED03ull) ^ ((uint64_t) ((r + sp.row_off) * sp.blocks_per_row_global + i + sp.blk_off) * 0x9E3779B97F4A7C15ull);
+                const float v = sp.f32_lo + (sp.f32_hi - sp.f32_lo) * u01(splitmix64(s));
+                if (sp.type == GGML_TYPE_F32) memcpy(dst + ((r - row0) * n + i) * 4, &v, 4);
+                else { uint16_t h = f32_to_f16(v); memcpy(dst + ((r - row0) * n + i) * 2, &h, 2); }
+            }
+        }
+        return;
+    }
+    for (int64_t r = row0; r < row1; ++r) {
+        for (int64_t b = 0; b < sp.blocks_per_row; ++b) {
+            const uint64_t gb = (uint64_t) ((r + sp.row_off) * sp.blocks_per_row_global + b + sp.blk_off);
+            const uint64_t key = sp.seed ^ ((uint64_t) sp.tensor_id * 0xD1B54A32D192ED03ull) ^ (gb * 0x9E3779B97F4A7C15ull);
+            synth_block(sp.type, key, sp.K_global, dst + (size_t) ((r - row0) * sp.blocks_per_row + b) * bs);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- presets
+extern "C" int llm_preset(const char * name, struct llm_hparams * hp) {
+    memset(hp, 0, sizeof(*hp));
+    auto set = [&](const char * arch, int L, int E, int H, int HKV, int HD, int FF, int V, int CTX, float base, float eps, int rope, int bias, int ft) {
+        snprintf(hp->arch, sizeof(hp->arch), "%s", arch);
+        hp->n_layer = L; hp->n_embd = E; hp->n_head = H; hp->n_head_kv = HKV; hp->n_embd_head = HD; hp->n_ff = FF;
+        hp->n_vocab = V; hp->n_ctx_train = CTX; hp->rope_freq_base = base; hp->rms_eps = eps; hp->rope_type = rope;
+        hp->qkv_bias = bias; hp->ftype = ft;
+    };
+    const std::string n = name;
+    if (n == "tinyllama-1.1b-q8_0") set("llama", 22, 2048, 32, 4, 64, 5632, 32000, 2048, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q8_0);
+    else if (n == "llama3-8b-q4_k_m") set("llama", 32, 4096, 32, 8, 128, 14336, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M);
+    else if (n == "llama3-70b-q4_k_m") { set("llama", 80, 8192, 64, 8, 128, 28672, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M); hp->attn_v_q5k_70b = 1; }
+    else if (n == "qwen2-7b-q5_k_m") set("qwen2", 28, 3584, 28, 4, 128, 18944, 152064, 32768, 1000000.0f, 1e-6f, GGML_ROPE_TYPE_NEOX, 1, LLM_FTYPE_Q5_K_M);
+    else if (n == "test-llama") set("llama", 3, 256, 4, 2, 64, 512, 512, 512, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_MIXED);
+    else if (n == "test-qwen2") set("qwen2", 2, 256, 4, 2, 64, 768, 768, 512, 1000000.0f, 1e-6f, GGML_ROPE_TYPE_NEOX, 1, LLM_FTYPE_MIXED);
+    else return -1;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- model
+struct llm_layer {
+    ggml_tensor *attn_norm = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr;
+    ggml_tensor *bq = nullptr, *bk = nullptr, *bv = nullptr;
+    ggml_tensor *ffn_norm = nullptr, *ffn_gate = nullptr, *ffn_up = nullptr, *ffn_down = nullptr;
+};
+
+struct tensor_plan {
+    std::string name;
+    ggml_type type;
+    int64_t ne0, ne1;       // LOCAL shape
+    int64_t K_global;       // global ne0
+    int64_t row_off, k_off; // shard offsets (elements)
+    int tensor_id;
+    bool rowpar;            // lives in the reducing (row-parallel) buffer type
+    float lo, hi;
+};
+
+struct llm_model {
+    llm_hparams hp{};
+    int tp_rank = 0, tp_size = 1;
+    int n_head_l = 0, n_head_kv_l = 0, n_ff_l = 0, n_vocab_l = 0;
+    ggml_context * ctx = nullptr;
+    std::vector<ggml_backend_buffer_t> buffers;
+    ggml_tensor *tok_embd = nullptr, *output_norm = nullptr, *output = nullptr;
+    std::vector<llm_layer> layers;
+    uint64_t stream_bytes = 0, total_bytes = 0;
+};
+
+static bool use_more_bits(int i, int n) { return i < n / 8 || i >= 7 * n / 8 || (i - n / 8) % 3 == 2; }
+
+static ggml_type pick_type(const llm_hparams & hp, const char * what, int il) {
+    const bool more = use_more_bits(il, hp.n_layer);
+    const std::string w = what;
+    switch (hp.ftype) {
+        case LLM_FTYPE_Q8_0: return GGML_TYPE_Q8_0;
+        case LLM_FTYPE_Q6_K: return GGML_TYPE_Q6_K;
+        case LLM_FTYPE_F16: return GGML_TYPE_F16;
+        case LLM_FTYPE_Q4_K_M:
+            if (w == "output") return GGML_TYPE_Q6_K;
+            if (w == "attn_v") return more ? GGML_TYPE_Q6_K : (hp.attn_v_q5k_70b ? GGML_TYPE_Q5_K : GGML_TYPE_Q4_K);
+            if (w == "ffn_down") return more ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K;
+            return GGML_TYPE_Q4_K;
+        case LLM_FTYPE_Q5_K_M:
+            if (w == "output") return GGML_TYPE_Q6_K;
+            if (w == "attn_v" || w == "ffn_down") return more ? GGML_TYPE_Q6_K : GGML_TYPE_Q5_K;
+            return GGML_TYPE_Q5_K;
+        case LLM_FTYPE_MIXED: {
+            static const ggml_type cyc[4] = {GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K, GGML_TYPE_Q8_0};
+            unsigned h = (unsigned) il * 7u;
+            for (char c : w) h = h * 31u + (unsigned char) c;
+            return cyc[h % 4];
+        }
+        default: return GGML_TYPE_Q8_0;
+    }
+}
+
+static std::vector<tensor_plan> make_plan(const llm_hparams & hp, int tp_rank, int tp_size) {
+    std::vector<tensor_plan> plan;
+    int id = 0;
+    const int64_t E = hp.n_embd, HD = hp.n_embd_head;
+    LLM_ASSERT(hp.n_head % tp_size == 0 && hp.n_head_kv % tp_size == 0 && hp.n_ff % tp_size == 0 && hp.n_vocab % tp_size == 0);
+    const int64_t nq = (int64_t) hp.n_head * HD, nkv = (int64_t) hp.n_head_kv * HD;
+    const int64_t nq_l = nq / tp_size, nkv_l = nkv / tp_size, ff_l = hp.n_ff / tp_size, v_l = hp.n_vocab / tp_size;
+    auto add = [&](const std::string & name, ggml_type type, int64_t ne0, int64_t ne1, int64_t Kg, int64_t row_off, int64_t k_off, bool rowpar, float lo = 0, float hi = 0) {
+        plan.push_back({name, type, ne0, ne1, Kg, row_off, k_off, id++, rowpar, lo, hi});
+    };
+    add("token_embd.weight", pick_type(hp, "token_embd", 0), E, hp.n_vocab, E, 0, 0, false);
+    for (int il = 0; il < hp.n_layer; ++il) {
+        const std::string p = "blk." + std::to_string(il) + ".";
+        add(p + "attn_norm.weight", GGML_TYPE_F32, E, 1, E, 0, 0, false, 0.5f, 1.5f);
+        add(p + "attn_q.weight", pick_type(hp, "attn_q", il), E, nq_l, E, tp_rank * nq_l, 0, false);
+        add(p + "attn_k.weight", pick_type(hp, "attn_k", il), E, nkv_l, E, tp_rank * nkv_l, 0, false);
+        add(p + "attn_v.weight", pick_type(hp, "attn_v", il), E, nkv_l, E, tp_rank * nkv_l, 0, false);
+        if (hp.qkv_bias) {
+            add(p + "attn_q.bias", GGML_TYPE_F32, nq_l, 1, nq, 0, tp_rank * nq_l, false, -0.1f, 0.1f);
+            add(p + "attn_k.bias", GGML_TYPE_F32, nkv_l, 1, nkv, 0, tp_rank * nkv_l, false, -0.1f, 0.1f);
+            add(p + "attn_v.bias", GGML_TYPE_F32, nkv_l, 1, nkv, 0, tp_rank * nkv_l, false, -0.1f, 0.1f);
+        }
+        add(p + "attn_output.weight", pick_type(hp, "attn_output", il), nq_l, E, nq, 0, tp_rank * nq_l, tp_size > 1);
+        add(p + "ffn_norm.weight", GGML_TYPE_F32, E, 1, E, 0, 0, false, 0.5f, 1.5f);
+        add(p + "ffn_gate.weight", pick_type(hp, "ffn_gate", il), E, ff_l, E, tp_rank * ff_l, 0, false);
+        add(p + "ffn_up.weight", pick_type(hp, "ffn_up", il), E, ff_l, E, tp_rank * ff_l, 0, false);
+        add(p + "ffn_down.weight", pick_type(hp, "ffn_down", il), ff_l, E, hp.n_ff, 0, tp_rank * ff_l, tp_size > 1);
+    }
+    add("output_norm.weight", GGML_TYPE_F32, E, 1, E, 0, 0, false, 0.5f, 1.5f);
+    add("output.weight", pick_type(hp, "output", 0), E, v_l, E, tp_rank * v_l, 0, false);
+    for (auto & t : plan) {
+        LLM_ASSERT(t.ne0 % ggml_abi_blck_size(t.type) == 0 && t.k_off % ggml_abi_blck_size(t.type) == 0);
+    }
+    return plan;
+}
+
+static synth_spec spec_of(const tensor_plan & t, uint64_t seed) {
+    const int64_t blck = ggml_abi_blck_size(t.type);
+    synth_spec sp{};
+    sp.seed = seed;
+    sp.tensor_id = t.tensor_id;
+    sp.type = t.type;
+    sp.K_global = t.K_global;
+    sp.row_off = t.row_off;
+    sp.blk_off = t.k_off / blck;
+    sp.blocks_per_row = t.ne0 / blck;
+    sp.blocks_per_row_global = t.K_global / blck;
+    sp.n_rows = t.ne1;
+    sp.f32_lo = t.lo;
+    sp.f32_hi = t.hi;
+    return sp;
+}
+
+static void bind_tensors(llm_model * m) {
+    const llm_hparams & hp = m->hp;
+    m->tok_embd = ggml_get_tensor(m->ctx, "token_embd.weight");
+    m->output_norm = ggml_get_tensor(m->ctx, "output_norm.weight");
+    m->output = ggml_get_tensor(m->ctx, "output.weight");
+    if (!m->output) m->output = m->tok_embd;  // tied embeddings
+    LLM_ASSERT(m->tok_embd && m->output_norm);
+    m->layers.resize(hp.n_layer);
+    for (int il = 0; il < hp.n_layer; ++il) {
+        const std::string p = "blk." + std::to_string(il) + ".";
+        auto g = [&](const char * s) { return ggml_get_tensor(m->ctx, (p + s).c_str()); };
+        llm_layer & L = m->layers[il];
+        L.attn_norm = g("attn_norm.weight"); L.wq = g("attn_q.weight"); L.wk = g("attn_k.weight"); L.wv = g("attn_v.weight");
+        L.wo = g("attn_output.weight"); L.bq = g("attn_q.bias"); L.bk = g("attn_k.bias"); L.bv = g("attn_v.bias");
+        L.ffn_norm = g("ffn_norm.weight"); L.ffn_gate = g("ffn_gate.weight"); L.ffn_up = g("ffn_up.weight"); L.ffn_down = g("ffn_down.weight");
+        LLM_ASSERT(L.attn_norm && L.wq && L.wk && L.wv && L.wo && L.ffn_norm && L.ffn_gate && L.ffn_up && L.ffn_down);
+    }
+    m->n_head_l = hp.n_head / m->tp_size;
+    m->n_head_kv_l = hp.n_head_kv / m->tp_size;
+    m->n_ff_l = hp.n_ff / m->tp_size;
+    m->n_vocab_l = (int) m->output->ne[1];
+    m->stream_bytes = 0;
+    m->total_bytes = 0;
+    for (ggml_tensor * t = ggml_get_first_tensor(m->ctx); t; t = ggml_get_next_tensor(m->ctx, t)) {
+        m->total_bytes += ggml_nbytes(t);
+        if (t == m->tok_embd && m->output != m->tok_embd) m->stream_bytes += ggml_row_size(t->type, t->ne[0]);
+        else m->stream_bytes += ggml_nbytes(t);
+    }
+}
+
+extern "C" struct llm_model * llm_model_synth(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, int tp_rank, int tp_size,
+                                              ggml_backend_buffer_type_t rowpar_buft) {
+    llm_model * m = new llm_model();
+    m->hp = *hp;
+    m->tp_rank = tp_rank;
+    m->tp_size = tp_size;
+    m->ctx = ggml_init({0, nullptr, true});
+    std::vector<tensor_plan> plan = make_plan(*hp, tp_rank, tp_size);
+    // two allocation groups: ordinary weights, and row-parallel weights (in the backend's reducing buffer type)
+    ggml_context * ctx_rp = (tp_size > 1 && rowpar_buft) ? ggml_init({0, nullptr, true}) : nullptr;
+    std::vector<ggml_tensor *> ts;
+    for (auto & t : plan) {
+        // tensors are created in m->ctx for lookup; row-parallel ones are allocated separately below
+        ggml_tensor * x = ggml_new_tensor_2d(m->ctx, t.type, t.ne0, t.ne1);
+        ggml_set_name(x, t.name.c_str());
+        ts.push_back(x);
+    }
+    (void) ctx_rp;
+    // allocate: ordinary group first
+    {
+        const size_t align = ggml_backend_buft_get_alignment(buft);
+        size_t total = 0, total_rp = 0;
+        for (size_t i = 0; i < plan.size(); ++i) {
+            size_t & acc = (plan[i].rowpar && rowpar_buft) ? total_rp : total;
+            acc = (acc + align - 1) / align * align + ggml_backend_buft_get_alloc_size(buft, ts[i]);
+        }
+        ggml_backend_buffer_t buf = ggml_backend_buft_alloc_buffer(buft, total + align);
+        ggml_backend_buffer_t buf_rp = (total_rp && rowpar_buft) ? ggml_backend_buft_alloc_buffer(rowpar_buft, total_rp + align) : nullptr;
+        if (!buf || (total_rp && rowpar_buft && !buf_rp)) {
+            fprintf(stderr, "llm_model_synth: failed to allocate %zu bytes of weights\n", total + total_rp);
+            llm_model_free(m);
+            return nullptr;
+        }
+        ggml_backend_buffer_set_usage(buf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+        m->buffers.push_back(buf);
+        if (buf_rp) {
+            ggml_backend_buffer_set_usage(buf_rp, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+            m->buffers.push_back(buf_rp);
+        }
+        size_t off = 0, off_rp = 0;
+        for (size_t i = 0; i < plan.size(); ++i) {
+            const bool rp = plan[i].rowpar && rowpar_buft;
+            size_t & o = rp ? off_rp : off;
+            ggml_backend_buffer_t b = rp ? buf_rp : buf;
+            o = (o + align - 1) / align * align;
+            ts[i]->data = (char *) ggml_backend_buffer_get_base(b) + o;
+            ts[i]->buffer = b;
+            if (b->iface.init_tensor) b->iface.init_tensor(b, ts[i]);
+            o += ggml_backend_buft_get_alloc_size(buft, ts[i]);
+        }
+    }
+    // generate + upload in chunks of rows, generation multi-threaded (each block is independent)
+    const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<uint8_t> stage;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        const synth_spec sp = spec_of(plan[i], seed);
+        const size_t row_bytes = ggml_row_size(plan[i].type, plan[i].ne0);
+        const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t) ((64u << 20) / row_bytes));
+        for (int64_t r0 = 0; r0 < plan[i].ne1; r0 += rows_per_chunk) {
+            const int64_t r1 = std::min<int64_t>(plan[i].ne1, r0 + rows_per_chunk);
+            stage.resize((size_t) (r1 - r0) * row_bytes);
+            std::vector<std::thread> th;
+            const int64_t per = (r1 - r0 + nthr - 1) / nthr;
+            for (unsigned t = 0; t < nthr; ++t) {
+                const int64_t a = r0 + t * per, b = std::min(r1, a + per);
+                if (a >= b) break;
+                th.emplace_back([&, a, b]() { synth_rows(sp, a, b, stage.data() + (size_t) (a - r0) * row_bytes); });
+            }
+            for (auto & x : th) x.join();
+            ggml_backend_tensor_set(ts[i], stage.data(), (size_t) r0 * row_bytes, stage.size());
+        }
+    }
+    bind_tensors(m);
+    return m;
+}
+
+struct gguf_fill_ctx {
+    const std::vector<tensor_plan> * plan;
+    uint64_t seed;
+};
+static void gguf_fill(const gguf_tensor_info & ti, void * dst, void * user) {
+    gguf_fill_ctx * c = (gguf_fill_ctx *) user;
+    for (auto & t : *c->plan) {
+        if (t.name == ti.name) {
+            synth_rows(spec_of(t, c->seed), 0, t.ne1, (uint8_t *) dst);
+            return;
+        }
+    }
+    LLM_ASSERT(!"gguf_fill: unknown tensor");
+}
+
+extern "C" int llm_synth_gguf(const struct llm_hparams * hp, uint64_t seed, const char * path) {
+    std::vector<tensor_plan> plan = make_plan(*hp, 0, 1);
+    gguf_writer w;
+    const std::string a = hp->arch;
+    w.set_str("general.architecture", a);
+    w.set_str("general.name", "synthetic-" + a);
+    w.set_u32("general.alignment", 32);
+    w.set_u32("general.file_type", (uint32_t) hp->ftype);
+    w.set_u32(a + ".block_count", (uint32_t) hp->n_layer);
+    w.set_u32(a + ".context_length", (uint32_t) hp->n_ctx_train);
+    w.set_u32(a + ".embedding_length", (uint32_t) hp->n_embd);
+    w.set_u32(a + ".feed_forward_length", (uint32_t) hp->n_ff);
+    w.set_u32(a + ".attention.head_count", (uint32_t) hp->n_head);
+    w.set_u32(a + ".attention.head_count_kv", (uint32_t) hp->n_head_kv);
+    w.set_f32(a + ".attention.layer_norm_rms_epsilon", hp->rms_eps);
+    w.set_f32(a + ".rope.freq_base", hp->rope_freq_base);
+    w.set_u32(a + ".rope.dimension_count", (uint32_t) hp->n_embd_head);
+    w.set_u32(a + ".vocab_size", (uint32_t) hp->n_vocab);
+    w.set_str("tokenizer.ggml.model", "no_vocab");
+    for (auto & t : plan) {
+        const int64_t ne[2] = {t.ne0, t.ne1};
+        w.add_tensor(t.name, t.type, t.ne1 == 1 ? 1 : 2, ne);
+    }
+    gguf_fill_ctx fc{&plan, seed};
+    return w.write(path, gguf_fill, &fc) ? 0 : -1;
+}
+
+extern "C" struct llm_model * llm_model_load(const char * path, ggml_backend_buffer_type_t buft) {
+    gguf_file * f = gguf_open(path);
+    if (!f) return nullptr;
+    llm_model * m = new llm_model();
+    llm_hparams & hp = m->hp;
+    const std::string a = f->get_s("general.architecture", "llama");
+    snprintf(hp.arch, sizeof(hp.arch), "%s", a.c_str());
+    hp.n_layer = (int) f->get_u(a + ".block_count");
+    hp.n_ctx_train = (int) f->get_u(a + ".context_length");
+    hp.n_embd = (int) f->get_u(a + ".embedding_length");
+    hp.n_ff = (int) f->get_u(a + ".feed_forward_length");
+    hp.n_head = (int) f->get_u(a + ".attention.head_count");
+    hp.n_head_kv = (int) f->get_u(a + ".attention.head_count_kv", hp.n_head);
+    hp.rms_eps = (float) f->get_f(a + ".attention.layer_norm_rms_epsilon", 1e-5);
+    hp.rope_freq_base = (float) f->get_f(a + ".rope.freq_base", 10000.0);
+    hp.n_embd_head = (int) f->get_u(a + ".rope.dimension_count", hp.n_head ? hp.n_embd / hp.n_head : 0);
+    hp.ftype = (int) f->get_u("general.file_type");
+    hp.rope_type = a == "qwen2" ? GGML_ROPE_TYPE_NEOX : 0;
+    const gguf_tensor_info * te = f->find("token_embd.weight");
+    if (!te || hp.n_layer <= 0 || hp.n_embd <= 0 || hp.n_head <= 0) {
+        fprintf(stderr, "llm_model_load: %s: missing hyper-parameters or token_embd.weight\n", path);
+        delete f;
+        delete m;
+        return nullptr;
+    }
+    hp.n_vocab = (int) f->get_u(a + ".vocab_size", (uint64_t) te->ne[1]);
+    hp.qkv_bias = f->find("blk.0.attn_q.bias") != nullptr;
+    m->ctx = ggml_init({0, nullptr, true});
+    for (auto & ti : f->tensors) {
+        ggml_tensor * t = ggml_new_tensor(m->ctx, ti.type, ti.n_dims, ti.ne);
+        ggml_set_name(t, ti.name.c_str());
+    }
+    ggml_backend_buffer_t buf = ggml_backend_alloc_ctx_tensors_from_buft(m->ctx, buft);
+    if (!buf) {
+        fprintf(stderr, "llm_model_load: failed to allocate weights\n");
+        delete f;
+        llm_model_free(m);
+        return nullptr;
+    }
+    ggml_backend_buffer_set_usage(buf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+    m->buffers.push_back(buf);
+    for (auto & ti : f->tensors) ggml_backend_tensor_set(ggml_get_tensor(m->ctx, ti.name.c_str()), f->tensor_data(ti), 0, ti.size);
+    delete f;
+    bind_tensors(m);
+    return m;
+}
+
+extern "C" void llm_model_free(struct llm_model * m) {
+    if (!m) return;
+    for (auto b : m->buffers) ggml_backend_buffer_free(b);
+    ggml_free(m->ctx);
+    delete m;
+}
+extern "C" const struct llm_hparams * llm_model_hparams(const struct llm_model * m) { return &m->hp; }
+extern "C" uint64_t llm_model_stream_bytes(const struct llm_model * m) { return m->stream_bytes; }
+extern "C" uint64_t llm_model_total_bytes(const struct llm_model * m) { return m->total_bytes; }
+extern "C" struct ggml_tensor * llm_model_tensor(struct llm_model * m, const char * name) { return ggml_get_tensor(m->ctx, name); }
+
+// ---------------------------------------------------------------------------------------------- context
+struct kv_cell {
+    int32_t pos = -1;
+    int32_t seq = -1;
+};
+
+struct graph_key {
+    int n_tokens = -1, n_kv = -1, n_outputs = -1;
+    bool operator==(const graph_key & o) const { return n_tokens == o.n_tokens && n_kv == o.n_kv && n_outputs == o.n_outputs; }
+};
+
+struct llm_context {
+    llm_model * model = nullptr;
+    ggml_backend_t backend = nullptr;
+    llm_compute_fn compute = nullptr;
+    llm_context_params p{};
+    ggml_backend_buffer_type_t buft = nullptr;
+    // KV cache
+    ggml_context * ctx_kv = nullptr;
+    ggml_backend_buffer_t buf_kv = nullptr;
+    std::vector<ggml_tensor *> k_l, v_l;
+    std::vector<kv_cell> cells;
+    int kv_head = 0;
+    // compute graph
+    ggml_gallocr_t galloc = nullptr;
+    ggml_context * ctx_compute = nullptr;
+    ggml_cgraph * gf = nullptr;
+    graph_key key;
+    ggml_tensor *inp_tokens = nullptr, *inp_pos = nullptr, *inp_mask = nullptr, *inp_k_idxs = nullptr, *inp_v_idxs = nullptr, *inp_out_ids = nullptr;
+    ggml_tensor * t_logits = nullptr;
+    // outputs
+    std::vector<float> logits;
+    int n_outputs = 0;
+    double timings[4] = {0, 0, 0, 0};
+};
+
+static ggml_tensor * named(ggml_tensor * t, const char * base, int il) {
+    char buf[96];
+    if (il >= 0) snprintf(buf, sizeof(buf), "%s-%d", base, il);
+    else snprintf(buf, sizeof(buf), "%s", base);
+    return ggml_set_name(t, buf);
+}
+
+static void build_graph(llm_context * c, int n_tokens, int n_kv, int n_outputs) {
+    llm_model * m = c->model;
+    const llm_hparams & hp = m->hp;
+    if (c->ctx_compute) ggml_free(c->ctx_compute);
+    c->ctx_compute = ggml_init({0, nullptr, true});
+    ggml_context * ctx = c->ctx_compute;
+    ggml_cgraph * gf = ggml_new_graph_custom(ctx, 8192, false);
+    const int64_t HD = hp.n_embd_head, NH = m->n_head_l, NKV = m->n_head_kv_l;
+    const int64_t n_embd_k = NKV * HD, n_ctx = c->p.n_ctx;
+    const bool fa = c->p.flash_attn != 0;
+    const float kq_scale = 1.0f / sqrtf((float) HD);
+
+    c->inp_tokens = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_tokens);
+    ggml_set_input(named(c->inp_tokens, "inp_tokens", -1));
+    c->inp_pos = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_tokens);
+    ggml_set_input(named(c->inp_pos, "inp_pos", -1));
+    const int64_t n_tok_pad = (n_tokens + 63) / 64 * 64;  // GGML_KQ_MASK_PAD
+    c->inp_mask = ggml_new_tensor_2d(ctx, fa ? GGML_TYPE_F16 : GGML_TYPE_F32, n_kv, n_tok_pad);
+    ggml_set_input(named(c->inp_mask, "KQ_mask", -1));
+    c->inp_k_idxs = ggml_new_tensor_1d(ctx, GGML_TYPE_I64, n_tokens);
+    ggml_set_input(named(c->inp_k_idxs, "k_idxs", -1));
+    c->inp_v_idxs = nullptr;
+    if (!fa) {
+        c->inp_v_idxs = ggml_new_tensor_1d(ctx, GGML_TYPE_I64, (int64_t) n_tokens * n_embd_k);
+        ggml_set_input(named(c->inp_v_idxs, "v_idxs", -1));
+    }
+    c->inp_out_ids = nullptr;
+    if (n_outputs < n_tokens) {
+        c->inp_out_ids = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_outputs);
+        ggml_set_input(named(c->inp_out_ids, "out_ids", -1));
+    }
+
+    ggml_tensor * inpL = named(ggml_get_rows(ctx, m->tok_embd, c->inp_tokens), "inp_embd", -1);
+    for (int il = 0; il < hp.n_layer; ++il) {
+        const llm_layer & L = m->layers[il];
+        ggml_tensor * inpSA = inpL;
+        ggml_tensor * cur = named(ggml_rms_norm(ctx, inpL, hp.rms_eps), "norm", il);
+        cur = named(ggml_mul(ctx, cur, L.attn_norm), "attn_norm", il);
+        ggml_tensor * Qcur = named(ggml_mul_mat(ctx, L.wq, cur), "Qcur", il);
+        if (L.bq) Qcur = named(ggml_add(ctx, Qcur, L.bq), "Qcur_b", il);
+        ggml_tensor * Kcur = named(ggml_mul_mat(ctx, L.wk, cur), "Kcur", il);
+        if (L.bk) Kcur = named(ggml_add(ctx, Kcur, L.bk), "Kcur_b", il);
+        ggml_tensor * Vcur = named(ggml_mul_mat(ctx, L.wv, cur), "Vcur", il);
+        if (L.bv) Vcur = named(ggml_add(ctx, Vcur, L.bv), "Vcur_b", il);
+        Qcur = ggml_reshape_3d(ctx, Qcur, HD, NH, n_tokens);
+        Kcur = ggml_reshape_3d(ctx, Kcur, HD, NKV, n_tokens);
+        Vcur = ggml_reshape_3d(ctx, Vcur, HD, NKV, n_tokens);
+        Qcur = named(ggml_rope_ext(ctx, Qcur, c->inp_pos, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f), "Qcur_rope", il);
+        Kcur = named(ggml_rope_ext(ctx, Kcur, c->inp_pos, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f), "Kcur_rope", il);
+        // store K/V into the cache at the slots chosen for this micro-batch
+        ggml_tensor * k_cache = c->k_l[il];
+        ggml_tensor * v_cache = c->v_l[il];
+        ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, k_cache, ggml_reshape_2d(ctx, Kcur, n_embd_k, n_tokens), c->inp_k_idxs), "k_store", il));
+        if (fa) {
+            ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, v_cache, ggml_reshape_2d(ctx, Vcur, n_embd_k, n_tokens), c->inp_k_idxs), "v_store", il));
+        } else {
+            // transposed V cache: every element is its own row of length 1
+            ggml_tensor * v_view = ggml_reshape_2d(ctx, v_cache, 1, n_ctx * n_embd_k);
+            ggml_tensor * v_src = ggml_reshape_2d(ctx, Vcur, 1, (int64_t) n_tokens * n_embd_k);
+            ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, v_view, v_src, c->inp_v_idxs), "v_store", il));
+        }
+        ggml_tensor * q = ggml_permute(ctx, Qcur, 0, 2, 1, 3);  // [HD, n_tokens, NH]
+        ggml_tensor * k = ggml_view_3d(ctx, k_cache, HD, n_kv, NKV, ggml_row_size(k_cache->type, n_embd_k), ggml_row_size(k_cache->type, HD), 0);
+        if (fa) {
+            ggml_tensor * v = ggml_view_3d(ctx, v_cache, HD, n_kv, NKV, ggml_row_size(v_cache->type, n_embd_k), ggml_row_size(v_cache->type, HD), 0);
+            cur = ggml_flash_attn_ext(ctx, q, k, v, c->inp_mask, kq_scale, 0.0f, 0.0f);
+            ggml_flash_attn_ext_set_prec(cur, GGML_PREC_F32);
+            named(cur, "fattn", il);
+            cur = ggml_reshape_2d(ctx, cur, HD * NH, n_tokens);
+        } else {
+            ggml_tensor * v = ggml_view_3d(ctx, v_cache, n_kv, HD, NKV, ggml_row_size(v_cache->type, n_ctx), ggml_row_size(v_cache->type, n_ctx) * HD, 0);
+            ggml_tensor * kq = named(ggml_mul_mat(ctx, k, q), "kq", il);  // [n_kv, n_tokens, NH]
+            ggml_mul_mat_set_prec(kq, GGML_PREC_F32);
+            kq = named(ggml_soft_max_ext(ctx, kq, c->inp_mask, kq_scale, 0.0f), "kq_soft_max", il);
+            ggml_tensor * kqv = named(ggml_mul_mat(ctx, v, kq), "kqv", il);  // [HD, n_tokens, NH]
+            cur = ggml_permute(ctx, kqv, 0, 2, 1, 3);
+            cur = named(ggml_cont_2d(ctx, cur, HD * NH, n_tokens), "kqv_out", il);
+        }
+        cur = named(ggml_mul_mat(ctx, L.wo, cur), "attn_out", il);
+        if (il == hp.n_layer - 1 && c->inp_out_ids) {
+            cur = ggml_get_rows(ctx, cur, c->inp_out_ids);
+            inpSA = ggml_get_rows(ctx, inpSA, c->inp_out_ids);
+        }
+        ggml_tensor * ffn_inp = named(ggml_add(ctx, cur, inpSA), "ffn_inp", il);
+        cur = named(ggml_rms_norm(ctx, ffn_inp, hp.rms_eps), "norm_ffn", il);
+        cur = named(ggml_mul(ctx, cur, L.ffn_norm), "ffn_norm", il);
+        ggml_tensor * gate = named(ggml_mul_mat(ctx, L.ffn_gate, cur), "ffn_gate", il);
+        ggml_tensor * up = named(ggml_mul_mat(ctx, L.ffn_up, cur), "ffn_up", il);
+        cur = named(ggml_swiglu_split(ctx, gate, up), "ffn_swiglu", il);
+        cur = named(ggml_mul_mat(ctx, L.ffn_down, cur), "ffn_out", il);
+        cur = named(ggml_add(ctx, cur, ffn_inp), "l_out", il);
+        inpL = cur;
+    }
+    ggml_tensor * cur = named(ggml_rms_norm(ctx, inpL, hp.rms_eps), "norm_final", -1);
+    cur = named(ggml_mul(ctx, cur, m->output_norm), "result_norm", -1);
+    cur = named(ggml_mul_mat(ctx, m->output, cur), "result_output", -1);
+    ggml_set_output(cur);
+    ggml_build_forward_expand(gf, cur);
+    c->t_logits = cur;
+    c->gf = gf;
+}
+
+extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backend_t backend, llm_compute_fn compute, const struct llm_context_params * p) {
+    if ((backend == nullptr) == (compute == nullptr)) {
+        fprintf(stderr, "llm_context_new: exactly one of backend / compute must be given\n");
+        return nullptr;
+    }
+    llm_context * c = new llm_context();
+    c->model = m;
+    c->backend = backend;
+    c->compute = compute;
+    c->p = *p;
+    if (c->p.n_ubatch <= 0) c->p.n_ubatch = 512;
+    if (c->p.n_ctx <= 0) c->p.n_ctx = 512;
+    c->p.n_ctx = (c->p.n_ctx + 255) / 256 * 256;
+    c->buft = backend ? ggml_backend_dev_buffer_type(backend->device) : ggml_backend_cpu_buffer_type();
+    const llm_hparams & hp = m->hp;
+    const int64_t n_embd_k = (int64_t) m->n_head_kv_l * hp.n_embd_head;
+    c->ctx_kv = ggml_init({0, nullptr, true});
+    for (int il = 0; il < hp.n_layer; ++il) {
+        ggml_tensor * k = ggml_new_tensor_2d(c->ctx_kv, GGML_TYPE_F16, n_embd_k, c->p.n_ctx);
+        ggml_tensor * v = c->p.flash_attn ? ggml_new_tensor_2d(c->ctx_kv, GGML_TYPE_F16, n_embd_k, c->p.n_ctx)
+                                          : ggml_new_tensor_2d(c->ctx_kv, GGML_TYPE_F16, c->p.n_ctx, n_embd_k);
+        named(k, "cache_k_l", il);
+        named(v, "cache_v_l", il);
+        c->k_l.push_back(k);
+        c->v_l.push_back(v);
+    }
+    c->buf_kv = ggml_backend_alloc_ctx_tensors_from_buft(c->ctx_kv, c->buft);
+    if (!c->buf_kv) {
+        fprintf(stderr, "llm_context_new: failed to allocate the KV cache\n");
+        llm_context_free(c);
+        return nullptr;
+    }
+    ggml_backend_buffer_clear(c->buf_kv, 0);
+    c->cells.assign(c->p.n_ctx, kv_cell());
+    c->galloc = ggml_gallocr_new(c->buft);
+    // reserve the worst-case graph (full micro-batch over the full cache) so later graphs re-use one buffer
+    build_graph(c, std::min(c->p.n_ubatch, c->p.n_ctx), c->p.n_ctx, std::min(c->p.n_ubatch, c->p.n_ctx));
+    if (!ggml_gallocr_reserve(c->galloc, c->gf)) {
+        fprintf(stderr, "llm_context_new: failed to reserve the compute buffer\n");
+        llm_context_free(c);
+        return nullptr;
+    }
+    c->key = graph_key();
+    return c;
+}
+
+extern "C" void llm_context_free(struct llm_context * c) {
+    if (!c) return;
+    if (c->ctx_compute) ggml_free(c->ctx_compute);
+    if (c->galloc) ggml_gallocr_free(c->galloc);
+    if (c->buf_kv) ggml_backend_buffer_free(c->buf_kv);
+    if (c->ctx_kv) ggml_free(c->ctx_kv);
+    delete c;
+}
+
+extern "C" void llm_kv_clear(struct llm_context * c) {
+    for (auto & x : c->cells) x = kv_cell();
+    c->kv_head = 0;
+}
+extern "C" int llm_kv_seq_rm(struct llm_context * c, int seq_id, int p0, int p1) {
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = INT32_MAX;
+    for (auto & x : c->cells)
+        if (x.pos >= p0 && x.pos < p1 && (seq_id < 0 || x.seq == seq_id)) x = kv_cell();
+    c->kv_head = 0;
+    return 1;
+}
+
+static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const int8_t * want, float * logits_out, int * n_out_acc) {
+    llm_model * m = c->model;
+    const llm_hparams & hp = m->hp;
+    const int n_ctx = c->p.n_ctx;
+    const double t0 = now_us();
+    // find free cells (first fit from kv_head, wrapping once)
+    std::vector<int> slots;
+    for (int i = 0, at = c->kv_head; i < n_ctx && (int) slots.size() < n_tokens; ++i, at = (at + 1) % n_ctx)
+        if (c->cells[at].pos < 0) slots.push_back(at);
+    if ((int) slots.size() < n_tokens) return 1;
+    for (int i = 0; i < n_tokens; ++i) {
+        c->cells[slots[i]].pos = pos[i];
+        c->cells[slots[i]].seq = seq_id ? seq_id[i] : 0;
+    }
+    c->kv_head = (slots.back() + 1) % n_ctx;
+    int used_max = 0;
+    for (int i = 0; i < n_ctx; ++i) if (c->cells[i].pos >= 0) used_max = i + 1;
+    const int n_kv = std::min(n_ctx, (used_max + 255) / 256 * 256);
+    std::vector<int32_t> out_ids;
+    for (int i = 0; i < n_tokens; ++i) if (!want || want[i]) out_ids.push_back(i);
+    const int n_outputs = (int) out_ids.size();
+    if (n_outputs == 0) out_ids.push_back(n_tokens - 1);  // keep the graph shape valid; result discarded
+    const int n_out_graph = std::max(1, n_outputs);
+
+    graph_key key{n_tokens, n_kv, n_out_graph};
+    if (!(c->p.graph_reuse && key == c->key && c->gf)) {
+        build_graph(c, n_tokens, n_kv, n_out_graph);
+        if (!ggml_gallocr_alloc_graph(c->galloc, c->gf)) return -2;
+        c->key = key;
+    }
+    const double t1 = now_us();
+
+    // inputs
+    const bool fa = c->p.flash_attn != 0;
+    ggml_backend_tensor_set(c->inp_tokens, tokens, 0, (size_t) n_tokens * 4);
+    ggml_backend_tensor_set(c->inp_pos, pos, 0, (size_t) n_tokens * 4);
+    std::vector<int64_t> kidx(n_tokens);
+    for (int i = 0; i < n_tokens; ++i) kidx[i] = slots[i];
+    ggml_backend_tensor_set(c->inp_k_idxs, kidx.data(), 0, kidx.size() * 8);
+    if (c->inp_v_idxs) {
+        const int64_t n_embd_k = (int64_t) m->n_head_kv_l * hp.n_embd_head;
+        std::vector<int64_t> vidx((size_t) n_tokens * n_embd_k);
+        for (int i = 0; i < n_tokens; ++i)
+            for (int64_t j = 0; j < n_embd_k; ++j) vidx[(size_t) i * n_embd_k + j] = j * n_ctx + slots[i];
+        ggml_backend_tensor_set(c->inp_v_idxs, vidx.data(), 0, vidx.size() * 8);
+    }
+    if (c->inp_out_ids) ggml_backend_tensor_set(c->inp_out_ids, out_ids.data(), 0, (size_t) n_out_graph * 4);
+    {
+        const int64_t n_tok_pad = c->inp_mask->ne[1];
+        const uint16_t NEG_INF_H = 0xFC00;
+        if (fa) {
+            std::vector<uint16_t> mask((size_t) n_kv * n_tok_pad, NEG_INF_H);
+            for (int i = 0; i < n_tokens; ++i) {
+                const int s = seq_id ? seq_id[i] : 0;
+                for (int j = 0; j < n_kv; ++j)
+                    if (c->cells[j].pos >= 0 && c->cells[j].seq == s && c->cells[j].pos <= pos[i]) mask[(size_t) i * n_kv + j] = 0;
+            }
+            ggml_backend_tensor_set(c->inp_mask, mask.data(), 0, mask.size() * 2);
+        } else {
+            std::vector<float> mask((size_t) n_kv * n_tok_pad, -INFINITY);
+            for (int i = 0; i < n_tokens; ++i) {
+                const int s = seq_id ? seq_id[i] : 0;
+                for (int j = 0; j < n_kv; ++j)
+                    if (c->cells[j].pos >= 0 && c->cells[j].seq == s && c->cells[j].pos <= pos[i]) mask[(size_t) i * n_kv + j] = 0.0f;
+            }
+            ggml_backend_tensor_set(c->inp_mask, mask.data(), 0, mask.size() * 4);
+        }
+    }
+    const double t2 = now_us();
+    enum ggml_status st = c->backend ? ggml_backend_graph_compute(c->backend, c->gf) : c->compute(c->gf, c->p.n_threads);
+    const double t3 = now_us();
+    if (st != GGML_STATUS_SUCCESS) {
+        for (int i = 0; i < n_tokens; ++i) c->cells[slots[i]] = kv_cell();  // roll the slots back
+        return -2;
+    }
+    if (n_outputs > 0) {
+        ggml_backend_tensor_get(c->t_logits, logits_out, 0, (size_t) n_outputs * m->n_vocab_l * 4);
+        *n_out_acc += n_outputs;
+    }
+    const double t4 = now_us();
+    c->timings[0] += t1 - t0;
+    c->timings[1] += t2 - t1;
+    c->timings[2] += t3 - t2;
+    c->timings[3] += t4 - t3;
+    return 0;
+}
+
+extern "C" int llm_decode(struct llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const int8_t * want_logits) {
+    if (n_tokens <= 0 || !tokens || !pos) return -1;
+    for (int i = 0; i < n_tokens; ++i)
+        if (tokens[i] < 0 || tokens[i] >= c->model->hp.n_vocab || pos[i] < 0) return -1;
+    int n_total_out = 0;
+    for (int i = 0; i < n_tokens; ++i) n_total_out += (!want_logits || want_logits[i]) ? 1 : 0;
+    c->logits.resize((size_t) std::max(1, n_total_out) * c->model->n_vocab_l);
+    c->n_outputs = 0;
+    for (int k = 0; k < 4; ++k) c->timings[k] = 0;
+    for (int i0 = 0; i0 < n_tokens; i0 += c->p.n_ubatch) {
+        const int n = std::min(c->p.n_ubatch, n_tokens - i0);
+        int rc = decode_ubatch(c, n, tokens + i0, pos + i0, seq_id ? seq_id + i0 : nullptr, want_logits ? want_logits + i0 : nullptr,
+                               c->logits.data() + (size_t) c->n_outputs * c->model->n_vocab_l, &c->n_outputs);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+extern "C" int llm_n_outputs(const struct llm_context * c) { return c->n_outputs; }
+extern "C" float * llm_get_logits(struct llm_context * c) { return c->logits.data(); }
+extern "C" float * llm_get_logits_ith(struct llm_context * c, int i) {
+    if (i < 0 || i >= c->n_outputs) return nullptr;
+    return c->logits.data() + (size_t) i * c->model->n_vocab_l;
+}
+extern "C" struct ggml_cgraph * llm_last_graph(struct llm_context * c) { return c->gf; }
+extern "C" void llm_last_timings(const struct llm_context * c, double out[4]) {
+    for (int k = 0; k < 4; ++k) out[k] = c->timings[k];
+}

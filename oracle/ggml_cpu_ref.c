@@ -1,0 +1,949 @@
+/*
+ * ggml_cpu_ref.c — plain-C restatement of the ggml-cpu *generic* algorithms for the hot path.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED (see oracle.h).
+ *
+ * Every function names the upstream routine it restates.  The upstream sources are absent from
+ * /root/reference (un-vendored llama.cpp submodule); anchors are the patch-pinned lines where a
+ * hunk exists and otherwise the published algorithm.
+ *
+ * Build: see oracle/Makefile (-O3 -ffp-contract=off so that float expressions are evaluated
+ * exactly as written: one rounding per operation, no FMA contraction).
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef double ggml_float; /* ggml-cpu accumulates scalar reductions in double */
+
+/* ------------------------------------------------------------------------------------------ */
+/* fp16 <-> fp32 (IEEE binary16, round-to-nearest-even; same results as F16C / ggml's fallback) */
+/* ------------------------------------------------------------------------------------------ */
+float oracle_fp16_to_fp32(ggml_fp16_t h) {
+    const uint32_t sign = (uint32_t) (h & 0x8000) << 16;
+    const uint32_t exp = (h >> 10) & 0x1F;
+    const uint32_t man = h & 0x3FF;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal: value = man * 2^-24 */
+            float f = (float) man * 5.9604644775390625e-08f;
+            memcpy(&bits, &f, 4);
+            bits |= sign;
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7F800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 112) << 23) | (man << 13);
+    }
+    float out;
+    memcpy(&out, &bits, 4);
+    return out;
+}
+
+ggml_fp16_t oracle_fp32_to_fp16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t) ((x >> 16) & 0x8000);
+    const uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) { /* inf / nan */
+        return (ggml_fp16_t) (sign | 0x7C00 | ((ax > 0x7F800000u) ? (0x200 | ((ax >> 13) & 0x3FF)) : 0));
+    }
+    if (ax >= 0x477FF000u) { /* >= 65520 rounds to inf */
+        return (ggml_fp16_t) (sign | 0x7C00);
+    }
+    if (ax < 0x33000001u) { /* <= 2^-25 rounds to zero (2^-25 exactly ties to even = 0) */
+        return sign;
+    }
+    const int32_t e = (int32_t) (ax >> 23) - 127;
+    uint32_t man = (ax & 0x7FFFFFu) | 0x800000u;
+    uint32_t shift;
+    uint32_t base;
+    if (e < -14) { /* subnormal half */
+        shift = (uint32_t) (13 + (-14 - e));
+        base = 0;
+    } else {
+        shift = 13;
+        base = (uint32_t) (e + 15) << 10;
+        man &= 0x7FFFFFu;
+    }
+    const uint32_t halfway = 1u << (shift - 1);
+    const uint32_t rem = man & ((1u << shift) - 1);
+    uint32_t q = man >> shift;
+    if (rem > halfway || (rem == halfway && (q & 1))) q++;
+    return (ggml_fp16_t) (sign | (base + q)); /* carry into exponent is the correct behaviour */
+}
+
+#define F16(x) oracle_fp16_to_fp32(x)
+
+/* ------------------------------------------------------------------------------------------ */
+/* dequantisation: dequantize_row_{q8_0,q4_K,q5_K,q6_K} (ggml-quants.c) */
+/* ------------------------------------------------------------------------------------------ */
+static inline void get_scale_min_k4(int j, const uint8_t * q, uint8_t * d, uint8_t * m) {
+    if (j < 4) {
+        *d = q[j] & 63;
+        *m = q[j + 4] & 63;
+    } else {
+        *d = (uint8_t) ((q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4));
+        *m = (uint8_t) ((q[j + 4] >> 4) | ((q[j - 0] >> 6) << 4));
+    }
+}
+
+static void dequantize_row_q8_0(const block_q8_0 * x, float * y, int64_t k) {
+    const int64_t nb = k / QK8_0;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = F16(x[i].d);
+        for (int j = 0; j < QK8_0; ++j) y[i * QK8_0 + j] = x[i].qs[j] * d;
+    }
+}
+
+static void dequantize_row_q4_K(const block_q4_K * x, float * y, int64_t k) {
+    const int64_t nb = k / QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const uint8_t * q = x[i].qs;
+        const float d = F16(x[i].d);
+        const float min = F16(x[i].dmin);
+        int is = 0;
+        uint8_t sc, m;
+        for (int j = 0; j < QK_K; j += 64) {
+            get_scale_min_k4(is + 0, x[i].scales, &sc, &m);
+            const float d1 = d * sc;
+            const float m1 = min * m;
+            get_scale_min_k4(is + 1, x[i].scales, &sc, &m);
+            const float d2 = d * sc;
+            const float m2 = min * m;
+            for (int l = 0; l < 32; ++l) *y++ = d1 * (q[l] & 0xF) - m1;
+            for (int l = 0; l < 32; ++l) *y++ = d2 * (q[l] >> 4) - m2;
+            q += 32;
+            is += 2;
+        }
+    }
+}
+
+static void dequantize_row_q5_K(const block_q5_K * x, float * y, int64_t k) {
+    const int64_t nb = k / QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const uint8_t * ql = x[i].qs;
+        const uint8_t * qh = x[i].qh;
+        const float d = F16(x[i].d);
+        const float min = F16(x[i].dmin);
+        int is = 0;
+        uint8_t sc, m;
+        uint8_t u1 = 1, u2 = 2;
+        for (int j = 0; j < QK_K; j += 64) {
+            get_scale_min_k4(is + 0, x[i].scales, &sc, &m);
+            const float d1 = d * sc;
+            const float m1 = min * m;
+            get_scale_min_k4(is + 1, x[i].scales, &sc, &m);
+            const float d2 = d * sc;
+            const float m2 = min * m;
+            for (int l = 0; l < 32; ++l) *y++ = d1 * ((ql[l] & 0xF) + (qh[l] & u1 ? 16 : 0)) - m1;
+            for (int l = 0; l < 32; ++l) *y++ = d2 * ((ql[l] >> 4) + (qh[l] & u2 ? 16 : 0)) - m2;
+            ql += 32;
+            is += 2;
+            u1 <<= 2;
+            u2 <<= 2;
+        }
+    }
+}
+
+static void dequantize_row_q6_K(const block_q6_K * x, float * y, int64_t k) {
+    const int64_t nb = k / QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = F16(x[i].d);
+        const uint8_t * ql = x[i].ql;
+        const uint8_t * qh = x[i].qh;
+        const int8_t * sc = x[i].scales;
+        for (int n = 0; n < QK_K; n += 128) {
+            for (int l = 0; l < 32; ++l) {
+                const int is = l / 16;
+                const int8_t q1 = (int8_t) ((ql[l + 0] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                const int8_t q2 = (int8_t) ((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                const int8_t q3 = (int8_t) ((ql[l + 0] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                const int8_t q4 = (int8_t) ((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                y[l + 0] = d * sc[is + 0] * q1;
+                y[l + 32] = d * sc[is + 2] * q2;
+                y[l + 64] = d * sc[is + 4] * q3;
+                y[l + 96] = d * sc[is + 6] * q4;
+            }
+            y += 128;
+            ql += 64;
+            qh += 32;
+            sc += 8;
+        }
+    }
+}
+
+void oracle_dequantize_row(enum ggml_type type, const void * x, float * y, int64_t k) {
+    switch (type) {
+        case GGML_TYPE_F32: memcpy(y, x, (size_t) k * 4); break;
+        case GGML_TYPE_F16: for (int64_t i = 0; i < k; ++i) y[i] = F16(((const ggml_fp16_t *) x)[i]); break;
+        case GGML_TYPE_Q8_0: dequantize_row_q8_0((const block_q8_0 *) x, y, k); break;
+        case GGML_TYPE_Q4_K: dequantize_row_q4_K((const block_q4_K *) x, y, k); break;
+        case GGML_TYPE_Q5_K: dequantize_row_q5_K((const block_q5_K *) x, y, k); break;
+        case GGML_TYPE_Q6_K: dequantize_row_q6_K((const block_q6_K *) x, y, k); break;
+        default: abort();
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* activation quantisation: quantize_row_q8_0_ref / quantize_row_q8_K_ref (Appendix A.3)        */
+/* ------------------------------------------------------------------------------------------ */
+void oracle_quantize_row_q8_0(const float * x, block_q8_0 * y, int64_t k) {
+    const int64_t nb = k / QK8_0;
+    for (int64_t i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK8_0; j++) {
+            const float v = fabsf(x[i * QK8_0 + j]);
+            if (v > amax) amax = v;
+        }
+        const float d = amax / ((1 << 7) - 1);
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = oracle_fp32_to_fp16(d);
+        for (int j = 0; j < QK8_0; ++j) {
+            const float x0 = x[i * QK8_0 + j] * id;
+            y[i].qs[j] = (int8_t) roundf(x0);
+        }
+    }
+}
+
+/* round-half-even through the float magic-number add (ggml's nearest_int) */
+static inline int nearest_int(float fval) {
+    float val = fval + 12582912.f;
+    int i;
+    memcpy(&i, &val, sizeof(int));
+    return (i & 0x007fffff) - 0x00400000;
+}
+
+void oracle_quantize_row_q8_K(const float * x, block_q8_K * y, int64_t k) {
+    const int64_t nb = k / QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        float max = 0;
+        float amax = 0;
+        for (int j = 0; j < QK_K; ++j) {
+            float ax = fabsf(x[j]);
+            if (ax > amax) {
+                amax = ax;
+                max = x[j];
+            }
+        }
+        if (!amax) {
+            y[i].d = 0;
+            memset(y[i].qs, 0, QK_K);
+            memset(y[i].bsums, 0, sizeof(y[i].bsums)); /* upstream leaves these unset; they are multiplied by d=0 */
+            x += QK_K;
+            continue;
+        }
+        const float iscale = -127.f / max;
+        for (int j = 0; j < QK_K; ++j) {
+            int v = nearest_int(iscale * x[j]);
+            y[i].qs[j] = (int8_t) (v < 127 ? v : 127);
+        }
+        for (int j = 0; j < QK_K / 16; ++j) {
+            int sum = 0;
+            for (int ii = 0; ii < 16; ++ii) sum += y[i].qs[j * 16 + ii];
+            y[i].bsums[j] = (int16_t) sum;
+        }
+        y[i].d = 1 / iscale;
+        x += QK_K;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* block dot products: ggml_vec_dot_*_generic (ggml-cpu/quants.c; Appendix A.3)                 */
+/* ------------------------------------------------------------------------------------------ */
+float oracle_vec_dot_q8_0_q8_0(int64_t n, const block_q8_0 * x, const block_q8_0 * y) {
+    const int64_t nb = n / QK8_0;
+    float sumf = 0;
+    for (int64_t ib = 0; ib < nb; ++ib) {
+        int sumi = 0;
+        for (int j = 0; j < QK8_0; j++) sumi += x[ib].qs[j] * y[ib].qs[j];
+        sumf += sumi * (F16(x[ib].d) * F16(y[ib].d));
+    }
+    return sumf;
+}
+
+static float vec_dot_k45(int64_t n, const uint8_t * xb, size_t xstride, int is5, const block_q8_K * y) {
+    const int64_t nb = n / QK_K;
+    int8_t aux8[QK_K];
+    int16_t aux16[8];
+    float sums[8];
+    int32_t aux32[8];
+    memset(sums, 0, sizeof(sums));
+    float sumf = 0;
+    for (int64_t i = 0; i < nb; ++i) {
+        const uint8_t * blk = xb + (size_t) i * xstride;
+        ggml_fp16_t hd, hdmin;
+        memcpy(&hd, blk, 2);
+        memcpy(&hdmin, blk + 2, 2);
+        const uint8_t * scales12 = blk + 4;
+        const uint8_t * hm = is5 ? blk + 16 : NULL;
+        const uint8_t * q4 = is5 ? blk + 48 : blk + 16;
+        const int8_t * q8 = y[i].qs;
+        memset(aux32, 0, sizeof(aux32));
+        int8_t * a = aux8;
+        uint8_t m = 1;
+        for (int j = 0; j < QK_K / 64; ++j) {
+            for (int l = 0; l < 32; ++l) a[l] = (int8_t) ((q4[l] & 0xF) + ((is5 && (hm[l] & m)) ? 16 : 0));
+            a += 32;
+            m <<= 1;
+            for (int l = 0; l < 32; ++l) a[l] = (int8_t) ((q4[l] >> 4) + ((is5 && (hm[l] & m)) ? 16 : 0));
+            a += 32;
+            m <<= 1;
+            q4 += 32;
+        }
+        uint8_t scales[8], mins[8];
+        for (int j = 0; j < 8; ++j) get_scale_min_k4(j, scales12, &scales[j], &mins[j]);
+        int sumi = 0;
+        for (int j = 0; j < QK_K / 16; ++j) sumi += y[i].bsums[j] * mins[j / 2];
+        a = aux8;
+        int is = 0;
+        for (int j = 0; j < QK_K / 32; ++j) {
+            int32_t scale = scales[is++];
+            for (int g = 0; g < 4; ++g) {
+                for (int l = 0; l < 8; ++l) aux16[l] = (int16_t) (q8[l] * a[l]);
+                for (int l = 0; l < 8; ++l) aux32[l] += scale * aux16[l];
+                q8 += 8;
+                a += 8;
+            }
+        }
+        const float d = F16(hd) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
+        const float dmin = F16(hdmin) * y[i].d;
+        sumf -= dmin * sumi;
+    }
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
+    return sumf;
+}
+
+float oracle_vec_dot_q4_K_q8_K(int64_t n, const block_q4_K * x, const block_q8_K * y) {
+    return vec_dot_k45(n, (const uint8_t *) x, sizeof(block_q4_K), 0, y);
+}
+float oracle_vec_dot_q5_K_q8_K(int64_t n, const block_q5_K * x, const block_q8_K * y) {
+    return vec_dot_k45(n, (const uint8_t *) x, sizeof(block_q5_K), 1, y);
+}
+
+float oracle_vec_dot_q6_K_q8_K(int64_t n, const block_q6_K * x, const block_q8_K * y) {
+    const int64_t nb = n / QK_K;
+    int8_t aux8[QK_K];
+    int16_t aux16[8];
+    float sums[8];
+    int32_t aux32[8];
+    memset(sums, 0, sizeof(sums));
+    float sumf = 0;
+    for (int64_t i = 0; i < nb; ++i) {
+        const uint8_t * q4 = x[i].ql;
+        const uint8_t * qh = x[i].qh;
+        const int8_t * q8 = y[i].qs;
+        memset(aux32, 0, sizeof(aux32));
+        int8_t * a = aux8;
+        for (int j = 0; j < QK_K; j += 128) {
+            for (int l = 0; l < 32; ++l) {
+                a[l + 0] = (int8_t) ((q4[l + 0] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                a[l + 32] = (int8_t) ((q4[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                a[l + 64] = (int8_t) ((q4[l + 0] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                a[l + 96] = (int8_t) ((q4[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+            }
+            a += 128;
+            q4 += 64;
+            qh += 32;
+        }
+        a = aux8;
+        int is = 0;
+        for (int j = 0; j < QK_K / 16; ++j) {
+            int scale = x[i].scales[is++];
+            for (int g = 0; g < 2; ++g) {
+                for (int l = 0; l < 8; ++l) aux16[l] = (int16_t) (q8[l] * a[l]);
+                for (int l = 0; l < 8; ++l) aux32[l] += scale * aux16[l];
+                q8 += 8;
+                a += 8;
+            }
+        }
+        const float d = F16(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
+    }
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
+    return sumf;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* helpers                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+#define TDATA(t) ((char *) (t)->data)
+
+static inline float op_f32(const struct ggml_tensor * t, int i) {
+    float v;
+    memcpy(&v, &t->op_params[i], 4);
+    return v;
+}
+
+static int g_max_threads = 0;
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    if (!g_max_threads) g_max_threads = omp_get_max_threads();
+    return g_max_threads;
+#else
+    return 1;
+#endif
+}
+
+static enum ggml_type vec_dot_type(enum ggml_type t) {
+    switch (t) {
+        case GGML_TYPE_F32: return GGML_TYPE_F32;
+        case GGML_TYPE_F16: return GGML_TYPE_F16;
+        case GGML_TYPE_Q8_0: return GGML_TYPE_Q8_0;
+        case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: case GGML_TYPE_Q6_K: return GGML_TYPE_Q8_K;
+        default: return GGML_TYPE_COUNT;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* MUL_MAT: ggml_compute_forward_mul_mat (ggml-cpu.c) — src1 rows converted to vec_dot_type,     */
+/* then one vec_dot per (src0 row, src1 row); dims 2/3 of src0 broadcast over src1.              */
+/* ------------------------------------------------------------------------------------------ */
+static enum ggml_status op_mul_mat(struct ggml_tensor * dst, int nth) {
+    const struct ggml_tensor * src0 = dst->src[0];
+    const struct ggml_tensor * src1 = dst->src[1];
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    const int64_t ne10 = src1->ne[0], ne11 = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
+    if (ne00 != ne10 || src1->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return GGML_STATUS_FAILED;
+    const enum ggml_type vdt = vec_dot_type(src0->type);
+    if (vdt == GGML_TYPE_COUNT) return GGML_STATUS_FAILED;
+    const size_t row_size = ggml_abi_row_size(vdt, ne10);
+    const int64_t nrows1 = ne11 * ne12 * ne13;
+    char * wdata = (char *) malloc(row_size * (size_t) nrows1 + 64);
+    if (!wdata) return GGML_STATUS_ALLOC_FAILED;
+
+    /* convert src1 to vec_dot_type, one contiguous row per (i11,i12,i13) */
+#pragma omp parallel for num_threads(nth) schedule(static)
+    for (int64_t r = 0; r < nrows1; ++r) {
+        const int64_t i11 = r % ne11, i12 = (r / ne11) % ne12, i13 = r / (ne11 * ne12);
+        const char * s = TDATA(src1) + i11 * src1->nb[1] + i12 * src1->nb[2] + i13 * src1->nb[3];
+        char * w = wdata + (size_t) r * row_size;
+        if (src1->nb[0] != sizeof(float)) abort();
+        switch (vdt) {
+            case GGML_TYPE_F32: memcpy(w, s, (size_t) ne10 * 4); break;
+            case GGML_TYPE_F16:
+                for (int64_t i = 0; i < ne10; ++i) ((ggml_fp16_t *) w)[i] = oracle_fp32_to_fp16(((const float *) s)[i]);
+                break;
+            case GGML_TYPE_Q8_0: oracle_quantize_row_q8_0((const float *) s, (block_q8_0 *) w, ne10); break;
+            case GGML_TYPE_Q8_K: oracle_quantize_row_q8_K((const float *) s, (block_q8_K *) w, ne10); break;
+            default: abort();
+        }
+    }
+
+    const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
+    const int64_t total = ne01 * nrows1;
+#pragma omp parallel for num_threads(nth) schedule(static)
+    for (int64_t idx = 0; idx < total; ++idx) {
+        /* src0 row fastest so that consecutive iterations stream the weight matrix */
+        const int64_t i01 = idx % ne01;
+        const int64_t r = idx / ne01;
+        const int64_t i11 = r % ne11, i12 = (r / ne11) % ne12, i13 = r / (ne11 * ne12);
+        const int64_t i02 = i12 / r2, i03 = i13 / r3;
+        const char * a = TDATA(src0) + i01 * src0->nb[1] + i02 * src0->nb[2] + i03 * src0->nb[3];
+        const char * w = wdata + (size_t) r * row_size;
+        float * d = (float *) (TDATA(dst) + i01 * dst->nb[0] + i11 * dst->nb[1] + i12 * dst->nb[2] + i13 * dst->nb[3]);
+        switch (src0->type) {
+            case GGML_TYPE_F32: { /* ggml_vec_dot_f32 generic: double accumulation of float products */
+                ggml_float s = 0.0;
+                const float * x = (const float *) a;
+                const float * y = (const float *) w;
+                for (int64_t i = 0; i < ne00; ++i) s += (ggml_float) (x[i] * y[i]);
+                *d = (float) s;
+            } break;
+            case GGML_TYPE_F16: { /* ggml_vec_dot_f16 generic */
+                ggml_float s = 0.0;
+                const ggml_fp16_t * x = (const ggml_fp16_t *) a;
+                const ggml_fp16_t * y = (const ggml_fp16_t *) w;
+                for (int64_t i = 0; i < ne00; ++i) s += (ggml_float) (F16(x[i]) * F16(y[i]));
+                *d = (float) s;
+            } break;
+            case GGML_TYPE_Q8_0: *d = oracle_vec_dot_q8_0_q8_0(ne00, (const block_q8_0 *) a, (const block_q8_0 *) w); break;
+            case GGML_TYPE_Q4_K: *d = oracle_vec_dot_q4_K_q8_K(ne00, (const block_q4_K *) a, (const block_q8_K *) w); break;
+            case GGML_TYPE_Q5_K: *d = oracle_vec_dot_q5_K_q8_K(ne00, (const block_q5_K *) a, (const block_q8_K *) w); break;
+            case GGML_TYPE_Q6_K: *d = oracle_vec_dot_q6_K_q8_K(ne00, (const block_q6_K *) a, (const block_q8_K *) w); break;
+            default: abort();
+        }
+    }
+    free(wdata);
+    return GGML_STATUS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* element-wise binary ops with ggml broadcasting (ggml_compute_forward_{add,sub,mul,div}_f32)  */
+/* ------------------------------------------------------------------------------------------ */
+static enum ggml_status op_binary(struct ggml_tensor * dst, int nth) {
+    const struct ggml_tensor * a = dst->src[0];
+    const struct ggml_tensor * b = dst->src[1];
+    if (a->type != GGML_TYPE_F32 || b->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return GGML_STATUS_FAILED;
+    const int64_t nr = ggml_abi_nrows(a);
+    const enum ggml_op op = dst->op;
+#pragma omp parallel for num_threads(nth) schedule(static)
+    for (int64_t ir = 0; ir < nr; ++ir) {
+        const int64_t i01 = ir % a->ne[1], i02 = (ir / a->ne[1]) % a->ne[2], i03 = ir / (a->ne[1] * a->ne[2]);
+        const int64_t i11 = i01 % b->ne[1], i12 = i02 % b->ne[2], i13 = i03 % b->ne[3];
+        const char * pa = TDATA(a) + i01 * a->nb[1] + i02 * a->nb[2] + i03 * a->nb[3];
+        const char * pb = TDATA(b) + i11 * b->nb[1] + i12 * b->nb[2] + i13 * b->nb[3];
+        char * pd = TDATA(dst) + i01 * dst->nb[1] + i02 * dst->nb[2] + i03 * dst->nb[3];
+        for (int64_t i0 = 0; i0 < a->ne[0]; ++i0) {
+            const float x = *(const float *) (pa + i0 * a->nb[0]);
+            const float y = *(const float *) (pb + (i0 % b->ne[0]) * b->nb[0]);
+            float r;
+            switch (op) {
+                case GGML_OP_ADD: r = x + y; break;
+                case GGML_OP_SUB: r = x - y; break;
+                case GGML_OP_MUL: r = x * y; break;
+                default: r = x / y; break;
+            }
+            *(float *) (pd + i0 * dst->nb[0]) = r;
+        }
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* SCALE: dst = scale*x + bias (llama-box/patches/llama.cpp/ggml-cuda.patch:8-15) */
+static enum ggml_status op_scale(struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    if (a->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(a) || !ggml_abi_is_contiguous(dst)) return GGML_STATUS_FAILED;
+    const float s = op_f32(dst, 0), b = op_f32(dst, 1);
+    const int64_t n = ggml_abi_nelements(a);
+    const float * x = (const float *) a->data;
+    float * y = (float *) dst->data;
+    for (int64_t i = 0; i < n; ++i) {
+        const float p = x[i] * s;
+        y[i] = p + b;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* RMS_NORM: ggml_compute_forward_rms_norm_f32 — sum of squares in double, scale = 1/sqrtf(mean+eps) */
+static enum ggml_status op_rms_norm(struct ggml_tensor * dst, int nth) {
+    const struct ggml_tensor * a = dst->src[0];
+    if (a->type != GGML_TYPE_F32 || a->nb[0] != 4 || dst->nb[0] != 4) return GGML_STATUS_FAILED;
+    const float eps = op_f32(dst, 0);
+    const int64_t ne00 = a->ne[0];
+    const int64_t nr = ggml_abi_nrows(a);
+#pragma omp parallel for num_threads(nth) schedule(static)
+    for (int64_t ir = 0; ir < nr; ++ir) {
+        const int64_t i01 = ir % a->ne[1], i02 = (ir / a->ne[1]) % a->ne[2], i03 = ir / (a->ne[1] * a->ne[2]);
+        const float * x = (const float *) (TDATA(a) + i01 * a->nb[1] + i02 * a->nb[2] + i03 * a->nb[3]);
+        float * y = (float *) (TDATA(dst) + i01 * dst->nb[1] + i02 * dst->nb[2] + i03 * dst->nb[3]);
+        ggml_float sum = 0.0;
+        for (int64_t i = 0; i < ne00; ++i) sum += (ggml_float) (x[i] * x[i]);
+        const float mean = (float) (sum / ne00);
+        const float scale = 1.0f / sqrtf(mean + eps);
+        for (int64_t i = 0; i < ne00; ++i) y[i] = x[i] * scale;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* UNARY: silu(x) = x/(1+expf(-x)) etc. (ggml-cpu/vec.h scalar forms) */
+static inline float silu_f32(float x) { return x / (1.0f + expf(-x)); }
+static enum ggml_status op_unary(struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    if (a->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(a) || !ggml_abi_is_contiguous(dst)) return GGML_STATUS_FAILED;
+    const int64_t n = ggml_abi_nelements(a);
+    const float * x = (const float *) a->data;
+    float * y = (float *) dst->data;
+    const int uop = dst->op_params[0];
+    for (int64_t i = 0; i < n; ++i) {
+        switch (uop) {
+            case GGML_UNARY_OP_SILU: y[i] = silu_f32(x[i]); break;
+            case GGML_UNARY_OP_RELU: y[i] = x[i] > 0.f ? x[i] : 0.f; break;
+            case GGML_UNARY_OP_NEG: y[i] = -x[i]; break;
+            case GGML_UNARY_OP_EXP: y[i] = expf(x[i]); break;
+            case GGML_UNARY_OP_TANH: y[i] = tanhf(x[i]); break;
+            case GGML_UNARY_OP_SIGMOID: y[i] = 1.f / (1.f + expf(-x[i])); break;
+            default: return GGML_STATUS_FAILED;
+        }
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* GLU (SWIGLU): ggml_compute_forward_swiglu_f32 — y = silu(x) * g; split (src1) or fused halves */
+static enum ggml_status op_glu(struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    const struct ggml_tensor * b = dst->src[1];
+    if (dst->op_params[0] != GGML_GLU_OP_SWIGLU || a->type != GGML_TYPE_F32) return GGML_STATUS_FAILED;
+    const int swapped = dst->op_params[1];
+    const int64_t nc = b ? a->ne[0] : a->ne[0] / 2;
+    const int64_t nr = ggml_abi_nrows(a);
+    if (dst->ne[0] != nc) return GGML_STATUS_FAILED;
+    for (int64_t ir = 0; ir < nr; ++ir) {
+        const float * pa = (const float *) (TDATA(a) + ir * a->nb[1]);
+        const float * pb = b ? (const float *) (TDATA(b) + ir * b->nb[1]) : pa;
+        if (!b) {
+            pa += swapped ? nc : 0;
+            pb += swapped ? 0 : nc;
+        }
+        float * y = (float *) (TDATA(dst) + ir * dst->nb[1]);
+        for (int64_t i = 0; i < nc; ++i) y[i] = silu_f32(pa[i]) * pb[i];
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* GET_ROWS: ggml_compute_forward_get_rows — dst row (i10,i11,i12) = dequant(src0 row (idx,i11,i12)) */
+static enum ggml_status op_get_rows(struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    const struct ggml_tensor * idx = dst->src[1];
+    if (idx->type != GGML_TYPE_I32 || dst->type != GGML_TYPE_F32) return GGML_STATUS_FAILED;
+    const int64_t nc = a->ne[0];
+    for (int64_t i12 = 0; i12 < idx->ne[2]; ++i12)
+        for (int64_t i11 = 0; i11 < idx->ne[1]; ++i11)
+            for (int64_t i10 = 0; i10 < idx->ne[0]; ++i10) {
+                const int32_t i01 = *(const int32_t *) (TDATA(idx) + i10 * idx->nb[0] + i11 * idx->nb[1] + i12 * idx->nb[2]);
+                if (i01 < 0 || i01 >= a->ne[1]) return GGML_STATUS_FAILED;
+                oracle_dequantize_row(a->type, TDATA(a) + i01 * a->nb[1] + i11 * a->nb[2] + i12 * a->nb[3],
+                                      (float *) (TDATA(dst) + i10 * dst->nb[1] + i11 * dst->nb[2] + i12 * dst->nb[3]), nc);
+            }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* SET_ROWS: ggml_compute_forward_set_rows_f32 — dst row idx[i] = convert(src0 row i), I64 indices */
+static enum ggml_status op_set_rows(struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    const struct ggml_tensor * idx = dst->src[1];
+    if (a->type != GGML_TYPE_F32 || idx->type != GGML_TYPE_I64) return GGML_STATUS_FAILED;
+    if (dst->type != GGML_TYPE_F32 && dst->type != GGML_TYPE_F16) return GGML_STATUS_FAILED;
+    const int64_t nc = a->ne[0];
+    for (int64_t i03 = 0; i03 < a->ne[3]; ++i03)
+        for (int64_t i02 = 0; i02 < a->ne[2]; ++i02)
+            for (int64_t i01 = 0; i01 < a->ne[1]; ++i01) {
+                const int64_t i12 = i03 % idx->ne[2], i11 = i02 % idx->ne[1], i10 = i01;
+                const int64_t i1 = *(const int64_t *) (TDATA(idx) + i10 * idx->nb[0] + i11 * idx->nb[1] + i12 * idx->nb[2]);
+                if (i1 < 0 || i1 >= dst->ne[1]) return GGML_STATUS_FAILED;
+                const float * s = (const float *) (TDATA(a) + i01 * a->nb[1] + i02 * a->nb[2] + i03 * a->nb[3]);
+                char * d = TDATA(dst) + i1 * dst->nb[1] + i02 * dst->nb[2] + i03 * dst->nb[3];
+                if (dst->type == GGML_TYPE_F32) memcpy(d, s, (size_t) nc * 4);
+                else for (int64_t i = 0; i < nc; ++i) ((ggml_fp16_t *) d)[i] = oracle_fp32_to_fp16(s[i]);
+            }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* CPY / DUP / CONT: ggml_compute_forward_dup — logical element order, f32/f16 conversion */
+static enum ggml_status op_cpy(struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    const int64_t n = ggml_abi_nelements(a);
+    if (n != ggml_abi_nelements(dst)) return GGML_STATUS_FAILED;
+    if (a->type == dst->type && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(dst)) {
+        memcpy(dst->data, a->data, ggml_abi_nbytes(a));
+        return GGML_STATUS_SUCCESS;
+    }
+    const int sf32 = a->type == GGML_TYPE_F32, sf16 = a->type == GGML_TYPE_F16;
+    const int df32 = dst->type == GGML_TYPE_F32, df16 = dst->type == GGML_TYPE_F16;
+    const int si32 = a->type == GGML_TYPE_I32 && dst->type == GGML_TYPE_I32;
+    if (!si32 && (!(sf32 || sf16) || !(df32 || df16))) return GGML_STATUS_FAILED;
+    for (int64_t e = 0; e < n; ++e) {
+        int64_t r = e;
+        const int64_t s0 = r % a->ne[0]; r /= a->ne[0];
+        const int64_t s1 = r % a->ne[1]; r /= a->ne[1];
+        const int64_t s2 = r % a->ne[2]; r /= a->ne[2];
+        const int64_t s3 = r;
+        r = e;
+        const int64_t d0 = r % dst->ne[0]; r /= dst->ne[0];
+        const int64_t d1 = r % dst->ne[1]; r /= dst->ne[1];
+        const int64_t d2 = r % dst->ne[2]; r /= dst->ne[2];
+        const int64_t d3 = r;
+        const char * ps = TDATA(a) + s0 * a->nb[0] + s1 * a->nb[1] + s2 * a->nb[2] + s3 * a->nb[3];
+        char * pd = TDATA(dst) + d0 * dst->nb[0] + d1 * dst->nb[1] + d2 * dst->nb[2] + d3 * dst->nb[3];
+        if (si32) { memcpy(pd, ps, 4); continue; }
+        if (sf32 && df32) memcpy(pd, ps, 4);
+        else if (sf16 && df16) memcpy(pd, ps, 2);
+        else if (sf32 && df16) { float v; memcpy(&v, ps, 4); ggml_fp16_t h = oracle_fp32_to_fp16(v); memcpy(pd, &h, 2); }
+        else { ggml_fp16_t h; memcpy(&h, ps, 2); float v = F16(h); memcpy(pd, &v, 4); }
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SOFT_MAX: ggml_compute_forward_soft_max_f32, with llama-box's zero-sum guard                  */
+/* (llama-box/patches/llama.cpp/ggml-cpu.patch:5-15: assert(sum>0) -> sum = -INFINITY)           */
+/* ------------------------------------------------------------------------------------------ */
+static enum ggml_status op_soft_max(struct ggml_tensor * dst, int nth) {
+    const struct ggml_tensor * a = dst->src[0];
+    const struct ggml_tensor * mask = dst->src[1];
+    const struct ggml_tensor * sinks = dst->src[2];
+    if (a->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(a) || !ggml_abi_is_contiguous(dst)) return GGML_STATUS_FAILED;
+    if (mask && mask->type != GGML_TYPE_F16 && mask->type != GGML_TYPE_F32) return GGML_STATUS_FAILED;
+    const float scale = op_f32(dst, 0), max_bias = op_f32(dst, 1);
+    const int64_t nc = a->ne[0], ne01 = a->ne[1], ne02 = a->ne[2], ne03 = a->ne[3];
+    const uint32_t n_head = (uint32_t) ne02;
+    const uint32_t n_head_log2 = 1u << (uint32_t) floor(log2(n_head));
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2);
+    const float m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    const int64_t nr = ne01 * ne02 * ne03;
+    int fail = 0;
+#pragma omp parallel for num_threads(nth) schedule(static)
+    for (int64_t ir = 0; ir < nr; ++ir) {
+        const int64_t i01 = ir % ne01, i02 = (ir / ne01) % ne02, i03 = ir / (ne01 * ne02);
+        const uint32_t h = (uint32_t) i02;
+        const float slope = (max_bias > 0.0f) ? (h < n_head_log2 ? powf(m0, h + 1) : powf(m1, 2 * (h - n_head_log2) + 1)) : 1.0f;
+        const float * sp = (const float *) (TDATA(a) + i01 * a->nb[1] + i02 * a->nb[2] + i03 * a->nb[3]);
+        float * dp = (float *) (TDATA(dst) + i01 * dst->nb[1] + i02 * dst->nb[2] + i03 * dst->nb[3]);
+        float * wp = (float *) malloc((size_t) nc * 4);
+        if (!wp) { fail = 1; continue; }
+        for (int64_t i = 0; i < nc; ++i) wp[i] = sp[i] * scale;
+        if (mask) {
+            const char * mp = TDATA(mask) + i01 * mask->nb[1] + (i02 % mask->ne[2]) * mask->nb[2] + (i03 % mask->ne[3]) * mask->nb[3];
+            if (mask->type == GGML_TYPE_F16) for (int64_t i = 0; i < nc; ++i) wp[i] += slope * F16(((const ggml_fp16_t *) mp)[i]);
+            else for (int64_t i = 0; i < nc; ++i) wp[i] += slope * ((const float *) mp)[i];
+        }
+        float max = -INFINITY;
+        for (int64_t i = 0; i < nc; ++i) if (wp[i] > max) max = wp[i];
+        const float * sk = sinks ? (const float *) sinks->data : NULL;
+        if (sk && sk[i02] > max) max = sk[i02];
+        ggml_float sum = 0.0;
+        for (int64_t i = 0; i < nc; ++i) {
+            const float val = expf(wp[i] - max);
+            sum += (ggml_float) val;
+            dp[i] = val;
+        }
+        if (sk) sum += (ggml_float) expf(sk[i02] - max);
+        if (isnan(sum) || sum == 0) sum = -INFINITY; /* llama-box patch */
+        sum = 1.0 / sum;
+        const float fs = (float) sum;
+        for (int64_t i = 0; i < nc; ++i) dp[i] *= fs;
+        free(wp);
+    }
+    return fail ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ROPE: ggml_compute_forward_rope_f32/_f16 (patch->ggml-cpu/ops.cpp:6204,:6390; mrope.patch:5-26) */
+/* ------------------------------------------------------------------------------------------ */
+static float rope_yarn_ramp(const float low, const float high, const int i0) {
+    const float y = (i0 / 2 - low) / fmaxf(0.001f, high - low);
+    return 1 - fminf(1, fmaxf(0, y));
+}
+static void rope_yarn(float theta_extrap, float freq_scale, const float corr_dims[2], int64_t i0, float ext_factor,
+                      float mscale, float * cos_theta, float * sin_theta) {
+    float theta_interp = freq_scale * theta_extrap;
+    float theta = theta_interp;
+    if (ext_factor != 0.0f) {
+        float ramp_mix = rope_yarn_ramp(corr_dims[0], corr_dims[1], (int) i0) * ext_factor;
+        theta = theta_interp * (1 - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+    }
+    *cos_theta = cosf(theta) * mscale;
+    *sin_theta = sinf(theta) * mscale;
+}
+static float rope_yarn_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) {
+    return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(base));
+}
+static void rope_yarn_corr_dims(int n_dims, int n_ctx_orig, float freq_base, float beta_fast, float beta_slow, float dims[2]) {
+    float start = floorf(rope_yarn_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base));
+    float end = ceilf(rope_yarn_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));
+    dims[0] = fmaxf(0, start);
+    dims[1] = fminf((float) (n_dims - 1), end);
+}
+
+static enum ggml_status op_rope(struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    const struct ggml_tensor * pos_t = dst->src[1];
+    const struct ggml_tensor * ff_t = dst->src[2];
+    const int n_dims = dst->op_params[1];
+    const int mode = dst->op_params[2];
+    const int n_ctx_orig = dst->op_params[4];
+    const float freq_base = op_f32(dst, 5), freq_scale = op_f32(dst, 6), ext_factor = op_f32(dst, 7);
+    const float attn_factor = op_f32(dst, 8), beta_fast = op_f32(dst, 9), beta_slow = op_f32(dst, 10);
+    if (mode & GGML_ROPE_TYPE_MROPE) return GGML_STATUS_FAILED; /* mrope/vision: out of scope (not in BASELINE configs) */
+    if (a->type != dst->type || (a->type != GGML_TYPE_F32 && a->type != GGML_TYPE_F16)) return GGML_STATUS_FAILED;
+    if (pos_t->type != GGML_TYPE_I32) return GGML_STATUS_FAILED;
+    const int is_neox = mode & GGML_ROPE_TYPE_NEOX;
+    const int is16 = a->type == GGML_TYPE_F16;
+    const int64_t ne0 = a->ne[0], ne1 = a->ne[1], ne2 = a->ne[2], ne3 = a->ne[3];
+    const float theta_scale = powf(freq_base, -2.0f / n_dims);
+    float corr_dims[2];
+    rope_yarn_corr_dims(n_dims, n_ctx_orig, freq_base, beta_fast, beta_slow, corr_dims);
+    const float * freq_factors = ff_t ? (const float *) ff_t->data : NULL;
+    const int32_t * pos = (const int32_t *) pos_t->data;
+    float * cache = (float *) malloc((size_t) ne0 * 4 + 16);
+    for (int64_t i3 = 0; i3 < ne3; i3++) {
+        for (int64_t i2 = 0; i2 < ne2; i2++) {
+            /* ggml_rope_cache_init: theta advanced by repeated multiplication */
+            float theta = (float) pos[i2];
+            for (int64_t i0 = 0; i0 < ne0; i0 += 2) {
+                const float ff = freq_factors ? freq_factors[i0 / 2] : 1.0f;
+                rope_yarn(theta / ff, freq_scale, corr_dims, i0, ext_factor, attn_factor, &cache[i0 + 0], &cache[i0 + 1]);
+                theta *= theta_scale;
+            }
+            for (int64_t i1 = 0; i1 < ne1; i1++) {
+                const char * src = TDATA(a) + i3 * a->nb[3] + i2 * a->nb[2] + i1 * a->nb[1];
+                char * dp = TDATA(dst) + i3 * dst->nb[3] + i2 * dst->nb[2] + i1 * dst->nb[1];
+                for (int64_t i0 = 0; i0 < n_dims; i0 += 2) {
+                    const float cos_theta = cache[i0 + 0], sin_theta = cache[i0 + 1];
+                    const int64_t ia = is_neox ? i0 / 2 : i0;
+                    const int64_t ib = is_neox ? i0 / 2 + n_dims / 2 : i0 + 1;
+                    if (is16) {
+                        const float x0 = F16(((const ggml_fp16_t *) src)[ia]), x1 = F16(((const ggml_fp16_t *) src)[ib]);
+                        ((ggml_fp16_t *) dp)[ia] = oracle_fp32_to_fp16(x0 * cos_theta - x1 * sin_theta);
+                        ((ggml_fp16_t *) dp)[ib] = oracle_fp32_to_fp16(x0 * sin_theta + x1 * cos_theta);
+                    } else {
+                        const float x0 = ((const float *) src)[ia], x1 = ((const float *) src)[ib];
+                        ((float *) dp)[ia] = x0 * cos_theta - x1 * sin_theta;
+                        ((float *) dp)[ib] = x0 * sin_theta + x1 * cos_theta;
+                    }
+                }
+                for (int64_t i0 = n_dims; i0 < ne0; ++i0) { /* pass-through tail */
+                    if (is16) ((ggml_fp16_t *) dp)[i0] = ((const ggml_fp16_t *) src)[i0];
+                    else ((float *) dp)[i0] = ((const float *) src)[i0];
+                }
+            }
+        }
+    }
+    free(cache);
+    return GGML_STATUS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* FLASH_ATTN_EXT: ggml_compute_forward_flash_attn_ext_f16 — online softmax per query row,       */
+/* Q rounded to f16, K·Q dot in double, V accumulated IN F16 when V is f16 (Appendix A.3).       */
+/* ------------------------------------------------------------------------------------------ */
+static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
+    const struct ggml_tensor * q = dst->src[0];
+    const struct ggml_tensor * k = dst->src[1];
+    const struct ggml_tensor * v = dst->src[2];
+    const struct ggml_tensor * mask = dst->src[3];
+    const struct ggml_tensor * sinks = dst->src[4];
+    if (q->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return GGML_STATUS_FAILED;
+    if (mask && mask->type != GGML_TYPE_F16) return GGML_STATUS_FAILED;
+    const int64_t DK = k->ne[0], DV = v->ne[0];
+    const int64_t neq1 = q->ne[1], neq2 = q->ne[2], neq3 = q->ne[3];
+    const int64_t nek1 = k->ne[1];
+    const int64_t rk2 = neq2 / k->ne[2], rk3 = neq3 / k->ne[3];
+    const int64_t rv2 = neq2 / v->ne[2], rv3 = neq3 / v->ne[3];
+    float scale = op_f32(dst, 0);
+    const float max_bias = op_f32(dst, 1);
+    const float logit_softcap = op_f32(dst, 2);
+    if (logit_softcap != 0) scale /= logit_softcap;
+    const uint32_t n_head = (uint32_t) neq2;
+    const uint32_t n_head_log2 = 1u << (uint32_t) floor(log2(n_head));
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2);
+    const float m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    const int64_t nr = neq1 * neq2 * neq3;
+    int fail = 0;
+#pragma omp parallel for num_threads(nth) schedule(dynamic, 4)
+    for (int64_t ir = 0; ir < nr; ++ir) {
+        const int64_t iq3 = ir / (neq2 * neq1), iq2 = (ir - iq3 * neq2 * neq1) / neq1, iq1 = ir - iq3 * neq2 * neq1 - iq2 * neq1;
+        const uint32_t h = (uint32_t) iq2;
+        const float slope = (max_bias > 0.0f) ? (h < n_head_log2 ? powf(m0, h + 1) : powf(m1, 2 * (h - n_head_log2) + 1)) : 1.0f;
+        float S = 0.0f, M = -INFINITY;
+        float * VKQ32 = (float *) calloc((size_t) DV, 4);
+        ggml_fp16_t * VKQ16 = (ggml_fp16_t *) calloc((size_t) DV, 2);
+        ggml_fp16_t * Q16 = (ggml_fp16_t *) malloc((size_t) DK * 2);
+        if (!VKQ32 || !VKQ16 || !Q16) { fail = 1; free(VKQ32); free(VKQ16); free(Q16); continue; }
+        const ggml_fp16_t * mp = mask ? (const ggml_fp16_t *) (TDATA(mask) + iq1 * mask->nb[1] + (iq2 % mask->ne[2]) * mask->nb[2] + (iq3 % mask->ne[3]) * mask->nb[3]) : NULL;
+        const int64_t ik3 = iq3 / rk3, ik2 = iq2 / rk2, iv3 = iq3 / rv3, iv2 = iq2 / rv2;
+        const float * pq = (const float *) (TDATA(q) + iq1 * q->nb[1] + iq2 * q->nb[2] + iq3 * q->nb[3]);
+        for (int64_t i = 0; i < DK; ++i) Q16[i] = oracle_fp32_to_fp16(pq[i]);
+        for (int64_t ic = 0; ic < nek1; ++ic) {
+            const float mv = mp ? slope * F16(mp[ic]) : 0.0f;
+            if (mv == -INFINITY) continue;
+            const ggml_fp16_t * kd = (const ggml_fp16_t *) (TDATA(k) + ic * k->nb[1] + ik2 * k->nb[2] + ik3 * k->nb[3]);
+            ggml_float acc = 0.0;
+            for (int64_t i = 0; i < DK; ++i) acc += (ggml_float) (F16(kd[i]) * F16(Q16[i]));
+            float s = (float) acc;
+            s = s * scale;
+            if (logit_softcap != 0.0f) s = logit_softcap * tanhf(s);
+            s += mv;
+            const float Mold = M;
+            float ms = 1.0f, vs = 1.0f;
+            const ggml_fp16_t * vd = (const ggml_fp16_t *) (TDATA(v) + ic * v->nb[1] + iv2 * v->nb[2] + iv3 * v->nb[3]);
+            if (s > M) {
+                M = s;
+                ms = expf(Mold - M);
+                for (int64_t i = 0; i < DV; ++i) VKQ16[i] = oracle_fp32_to_fp16(F16(VKQ16[i]) * ms); /* ggml_vec_scale_f16 */
+            } else {
+                vs = expf(s - M);
+            }
+            for (int64_t i = 0; i < DV; ++i) { /* ggml_vec_mad_f16 */
+                const float p = F16(vd[i]) * vs;
+                VKQ16[i] = oracle_fp32_to_fp16(F16(VKQ16[i]) + p);
+            }
+            S = S * ms + vs;
+        }
+        for (int64_t i = 0; i < DV; ++i) VKQ32[i] = F16(VKQ16[i]);
+        if (sinks) {
+            const float s = ((const float *) sinks->data)[h];
+            float ms = 1.0f, vs = 1.0f;
+            if (s > M) {
+                ms = expf(M - s);
+                for (int64_t i = 0; i < DV; ++i) VKQ32[i] *= ms;
+            } else {
+                vs = expf(s - M);
+            }
+            S = S * ms + vs;
+        }
+        const float S_inv = 1.0f / S;
+        for (int64_t i = 0; i < DV; ++i) VKQ32[i] *= S_inv;
+        /* dst layout [DV, n_head, n_q, batch] (permuted) */
+        memcpy(TDATA(dst) + (iq3 * dst->ne[2] * dst->ne[1] + iq2 + iq1 * dst->ne[1]) * dst->nb[1], VKQ32, (size_t) DV * 4);
+        free(VKQ32);
+        free(VKQ16);
+        free(Q16);
+    }
+    return fail ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_SUCCESS;
+}
+
+/* ARGMAX: ggml_compute_forward_argmax_f32 — first index of the row maximum */
+static enum ggml_status op_argmax(struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    if (a->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_I32) return GGML_STATUS_FAILED;
+    for (int64_t i1 = 0; i1 < a->ne[1]; ++i1) {
+        const float * x = (const float *) (TDATA(a) + i1 * a->nb[1]);
+        float mx = -INFINITY;
+        int32_t idx = 0;
+        for (int64_t i = 0; i < a->ne[0]; ++i) if (x[i] > mx) { mx = x[i]; idx = (int32_t) i; }
+        ((int32_t *) dst->data)[i1] = idx;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+int oracle_supports_op(const struct ggml_tensor * node) {
+    switch (node->op) {
+        case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+        case GGML_OP_MUL_MAT: case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV:
+        case GGML_OP_SCALE: case GGML_OP_RMS_NORM: case GGML_OP_UNARY: case GGML_OP_GLU: case GGML_OP_GET_ROWS:
+        case GGML_OP_SET_ROWS: case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: case GGML_OP_SOFT_MAX:
+        case GGML_OP_ROPE: case GGML_OP_FLASH_ATTN_EXT: case GGML_OP_ARGMAX:
+            return 1;
+        default: return 0;
+    }
+}
+
+enum ggml_status oracle_compute_node(struct ggml_tensor * node, int n_threads) {
+    int nth = n_threads > 0 ? n_threads : oracle_max_threads();
+    switch (node->op) {
+        case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            return GGML_STATUS_SUCCESS;
+        case GGML_OP_MUL_MAT: return op_mul_mat(node, nth);
+        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: return op_binary(node, nth);
+        case GGML_OP_SCALE: return op_scale(node);
+        case GGML_OP_RMS_NORM: return op_rms_norm(node, nth);
+        case GGML_OP_UNARY: return op_unary(node);
+        case GGML_OP_GLU: return op_glu(node);
+        case GGML_OP_GET_ROWS: return op_get_rows(node);
+        case GGML_OP_SET_ROWS: return op_set_rows(node);
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: return op_cpy(node);
+        case GGML_OP_SOFT_MAX: return op_soft_max(node, nth);
+        case GGML_OP_ROPE: return op_rope(node);
+        case GGML_OP_FLASH_ATTN_EXT: return op_flash_attn_ext(node, nth);
+        case GGML_OP_ARGMAX: return op_argmax(node);
+        default: return GGML_STATUS_FAILED;
+    }
+}
+
+enum ggml_status oracle_graph_compute(struct ggml_cgraph * graph, int n_threads) {
+    for (int i = 0; i < graph->n_nodes; ++i) {
+        enum ggml_status st = oracle_compute_node(graph->nodes[i], n_threads);
+        if (st != GGML_STATUS_SUCCESS) return st;
+    }
+    return GGML_STATUS_SUCCESS;
+}
