@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — decode tokens/s (+ prefill tokens/s) of the MI355X backend on BASELINE.json's headline config.
+
+Workload (N=1): BASELINE.json configs[1] — Llama-3-8B Q4_K_M (synthetic GGUF-exact tensor set, random-init: no
+checkpoints exist offline), all layers on one MI355X, 2048-token prefill then batch-1 decode.  A "step" is one pass
+of the hot path over one batch: llama_decode of one token (graph submit through the backend C-ABI + logits to host),
+exactly what llama-box's engine loop does per iteration (llama-box/httpserver.hpp:3591, llama-bench "tg" semantics).
+
+N>1 (one process per GPU, launched by torch.distributed.run): the same model tensor-split across ranks — column-
+parallel wq/wk/wv/gate/up, row-parallel wo/down with an RCCL all-reduce of the f32 partial results over xGMI
+(csrc/tp.cpp); one token stream, so "scaling" is "strong".  torch is used for plumbing only (rendezvous, barrier,
+max-reduce of the timings, torch.cuda.synchronize()).
+
+Extra objects on the JSON line: "roofline" (dominant kernel class, hipEvent-timed on the backend's own stream in a
+separate eager pass of the same decode steps; algorithmic bytes = the weight bytes each launch streams) and
+"cpu_baseline" (the CPU oracle = our restatement of ggml-cpu, kind "port", timed on this host's cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--preset", default="llama3-8b-q4_k_m")
+    ap.add_argument("--prefill", type=int, default=2048)
+    ap.add_argument("--fa", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=0, help="debug only: override n_layer (result is then NOT a valid bench)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--timing-steps", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import numpy as np
+    import torch  # first: one HIP runtime per process (torch's and /opt/rocm's share the SONAME)
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane on gloo; the data-path collective is RCCL inside the backend
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import llama_box_amd as L
+    from model_util import Context, Model, preset
+
+    H = L.host()
+    be = L.Backend(local_rank)
+    hp = preset(args.preset)
+    if args.layers > 0:
+        hp.n_layer = args.layers
+    parallelism = "single"
+    tp_size, tp_rank = 1, 0
+    if world > 1:
+        try:
+            uid = [be.tp_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            be.tp_init(rank, world, uid[0])
+            tp_size, tp_rank = world, rank
+            parallelism = f"tp{world} (row/column tensor-split, RCCL all-reduce x{2 * hp.n_layer}/token)"
+        except Exception as e:  # keep the scaling run alive and say what happened
+            parallelism = f"replicas x{world} (tensor-split init failed: {e})"
+    t_load = time.time()
+    model = Model(hp, 0x5EED, be.buft, tp_rank=tp_rank, tp_size=tp_size, rowpar_buft=be.rowpar_buft() if tp_size > 1 else None)
+    t_load = time.time() - t_load
+    n_ctx = (args.prefill + args.warmup + args.steps + args.timing_steps + 64 + 255) // 256 * 256
+    ctx = Context(model, backend=be, n_ctx=n_ctx, n_ubatch=512, flash_attn=args.fa, graph_reuse=1)
+    rng = np.random.default_rng(1 + 0 * rank)
+    toks = rng.integers(0, hp.n_vocab, args.prefill + args.warmup + args.steps + args.timing_steps + 8)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- prefill (reported beside the headline; v1 path = column chunks of the bandwidth kernel)
+    pos = 0
+    prefill_tok_s = None
+    if args.prefill > 0:
+        sync()
+        t0 = time.perf_counter()
+        rc, _ = ctx.decode(toks[: args.prefill], range(args.prefill), want=[0] * (args.prefill - 1) + [1])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        assert rc == 0, f"prefill failed rc={rc}"
+        prefill_tok_s = args.prefill / (t1 - t0)
+        pos = args.prefill
+
+    def step(i):
+        rc, lg = ctx.decode([int(toks[pos + i])], [pos + i])
+        assert rc == 0, f"decode failed rc={rc}"
+        return lg
+
+    for i in range(args.warmup):
+        step(i)
+    pos += args.warmup
+    g0 = be.stat("graph_launches")
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    pos += args.steps
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    graph_steps = be.stat("graph_launches") - g0
+    streams = 1 if tp_size > 1 or world == 1 else world
+    tok_s = streams * args.steps / elapsed
+    host_split = ctx.timings()
+
+    # ---- per-kernel-class timing pass (eager, hipEvents on the backend's stream)
+    roofline = None
+    classes = {}
+    try:
+        be.set_option("timing", 1)
+        for i in range(args.timing_steps):
+            step(i)
+        classes = be.timing_report()
+        be.set_option("timing", 0)
+        pos += args.timing_steps
+        mm = {k: v for k, v in classes.items() if k.startswith("mmvq") or k.startswith("mmq")}
+        if mm:
+            dom = max(mm, key=lambda k: mm[k][1])
+            cnt, ms, nbytes = mm[dom]
+            ach = nbytes / (ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": None, "launches": cnt, "avg_us": round(ms * 1e3 / cnt, 2), "alg_bytes_per_launch": round(nbytes / cnt)}
+    except Exception as e:
+        roofline = {"error": str(e)}
+
+    # ---- CPU baseline: the oracle (restated ggml-cpu), same model shape, on this host's cores
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            import harness as T
+            t_c = time.time()
+            mc = Model(hp, 0x5EED, H.ggml_backend_cpu_buffer_type())
+            nth = T.oracle().oracle_max_threads()
+            cc = Context(mc, compute=T.oracle_compute_fn(nth), n_ctx=256, flash_attn=args.fa, n_threads=nth)
+            cc.decode([int(toks[0])], [0])  # touch the weights once
+            tc0 = time.perf_counter()
+            for i in range(args.cpu_steps):
+                cc.decode([int(toks[1 + i])], [1 + i])
+            tc = time.perf_counter() - tc0
+            cpu_baseline = {"value": round(args.cpu_steps / tc, 3), "unit": "tokens/s", "cores": nth, "kind": "port",
+                            "sample": f"{args.cpu_steps} batch-1 decode steps at n_past 1..{args.cpu_steps} of the same synthetic {args.preset} model, OpenMP threads={nth}; CPU restatement of ggml-cpu (oracle/), NOT llama-box's binary",
+                            "setup_s": round(time.time() - t_c - tc, 1)}
+            cc.free()
+            mc.free()
+        except Exception as e:
+            cpu_baseline = {"error": str(e)}
+
+    if rank == 0:
+        w_bytes = model.stream_bytes()
+        kv_per_tok = 2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * 2
+        n_past = args.prefill + args.warmup + args.steps // 2
+        job_bytes = (w_bytes + kv_per_tok * n_past) * (tok_s / streams)
+        out = {
+            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M",
+            "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None, "dtype": "q4_K/q6_K weights x q8_K activations (int8 dot, f32 accumulate)",
+            "data": "synthetic (GGUF-exact tensor set, directly sampled quant blocks, random token ids)",
+            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then batch-1 decode, flash_attn={args.fa}, n_ctx={n_ctx}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
+                       "parallelism": parallelism, "n_past_mid": n_past, "weight_bytes_per_token_per_gpu": w_bytes, "kv_bytes_per_token_per_gpu": kv_per_tok * n_past},
+            "prefill_tok_s": round(prefill_tok_s, 1) if prefill_tok_s else None,
+            "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),
+            "graph_replayed_steps": int(graph_steps),
+            "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "kernel_classes_us": {k: round(v[1] * 1e3 / max(1, v[0]), 2) for k, v in sorted(classes.items())},
+            "model_load_s": round(t_load, 1),
+        }
+        print(json.dumps(out))
+    ctx.free()
+    model.free()
+    be.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,9 +59,9 @@ static double now_us() {
 // scales uniform with mins tied to scales so that dequantised weights are ~zero-mean with std ~ s/sqrt(K).
 // Every block is a pure function of (seed, tensor id, GLOBAL row, GLOBAL block-in-row) so that a
 // tensor-parallel shard generates exactly the bytes the unsharded model holds at the same coordinates.
-static void synth_block(ggml_type type, uint64_t key, int64_t K, uint8_t * out) {
+static void synth_block(ggml_type type, uint64_t key, int64_t K, float wscale, uint8_t * out) {
     uint64_t s = key;
-    const float scale = 0.5f + u01(splitmix64(s));  // s in U(0.5, 1.5)
+    const float scale = wscale * (0.5f + u01(splitmix64(s)));  // s in U(0.5, 1.5) x per-tensor gain
     const float rk = 1.0f / sqrtf((float) K);
     auto fill = [&](uint8_t * p, size_t n) {
         size_t i = 0;
@@ -132,6 +132,7 @@ struct synth_spec {
     int64_t blocks_per_row_global;
     int64_t n_rows;         // local
     float f32_lo, f32_hi;   // for F32 tensors
+    float wscale;           // gain of quantised tensors
 };
 
 static void synth_rows(const synth_spec & sp, int64_t row0, int64_t row1, uint8_t * dst) {
@@ -152,7 +153,7 @@ static void synth_rows(const synth_spec & sp, int64_t row0, int64_t row1, uint8_
         for (int64_t b = 0; b < sp.blocks_per_row; ++b) {
             const uint64_t gb = (uint64_t) ((r + sp.row_off) * sp.blocks_per_row_global + b + sp.blk_off);
             const uint64_t key = sp.seed ^ ((uint64_t) sp.tensor_id * 0xD1B54A32D192ED03ull) ^ (gb * 0x9E3779B97F4A7C15ull);
-            synth_block(sp.type, key, sp.K_global, dst + (size_t) ((r - row0) * sp.blocks_per_row + b) * bs);
+            synth_block(sp.type, key, sp.K_global, sp.wscale, dst + (size_t) ((r - row0) * sp.blocks_per_row + b) * bs);
         }
     }
 }
@@ -172,6 +173,7 @@ extern "C" int llm_preset(const char * name, struct llm_hparams * hp) {
     else if (n == "llama3-70b-q4_k_m") { set("llama", 80, 8192, 64, 8, 128, 28672, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M); hp->attn_v_q5k_70b = 1; }
     else if (n == "qwen2-7b-q5_k_m") set("qwen2", 28, 3584, 28, 4, 128, 18944, 152064, 32768, 1000000.0f, 1e-6f, GGML_ROPE_TYPE_NEOX, 1, LLM_FTYPE_Q5_K_M);
     else if (n == "test-llama") set("llama", 3, 256, 4, 2, 64, 512, 512, 512, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_MIXED);
+    else if (n == "test-llama-tp") set("llama", 2, 512, 8, 4, 64, 1024, 512, 512, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_MIXED);
     else if (n == "test-qwen2") set("qwen2", 2, 256, 4, 2, 64, 768, 768, 512, 1000000.0f, 1e-6f, GGML_ROPE_TYPE_NEOX, 1, LLM_FTYPE_MIXED);
     else return -1;
     return 0;
@@ -193,6 +195,7 @@ struct tensor_plan {
     int tensor_id;
     bool rowpar;            // lives in the reducing (row-parallel) buffer type
     float lo, hi;
+    float wscale;
 };
 
 struct llm_model {
@@ -242,7 +245,11 @@ static std::vector<tensor_plan> make_plan(const llm_hparams & hp, int tp_rank, i
     const int64_t nq = (int64_t) hp.n_head * HD, nkv = (int64_t) hp.n_head_kv * HD;
     const int64_t nq_l = nq / tp_size, nkv_l = nkv / tp_size, ff_l = hp.n_ff / tp_size, v_l = hp.n_vocab / tp_size;
     auto add = [&](const std::string & name, ggml_type type, int64_t ne0, int64_t ne1, int64_t Kg, int64_t row_off, int64_t k_off, bool rowpar, float lo = 0, float hi = 0) {
-        plan.push_back({name, type, ne0, ne1, Kg, row_off, k_off, id++, rowpar, lo, hi});
+        // residual-branch output projections get a small gain, as in trained transformers: the residual stream stays
+        // dominated by its own history, so one-ulp differences are not chaotically amplified layer over layer
+        const bool branch_out = name.find("attn_output") != std::string::npos || name.find("ffn_down") != std::string::npos;
+        const float gain = name == "token_embd.weight" ? sqrtf((float) hp.n_embd) : (branch_out ? 0.25f : 1.0f);  // embeddings ~N(0,1)
+        plan.push_back({name, type, ne0, ne1, Kg, row_off, k_off, id++, rowpar, lo, hi, gain});
     };
     add("token_embd.weight", pick_type(hp, "token_embd", 0), E, hp.n_vocab, E, 0, 0, false);
     for (int il = 0; il < hp.n_layer; ++il) {
@@ -284,6 +291,7 @@ static synth_spec spec_of(const tensor_plan & t, uint64_t seed) {
     sp.n_rows = t.ne1;
     sp.f32_lo = t.lo;
     sp.f32_hi = t.hi;
+    sp.wscale = t.wscale;
     return sp;
 }
 
@@ -369,7 +377,7 @@ extern "C" struct llm_model * llm_model_synth(const struct llm_hparams * hp, uin
         }
     }
     // generate + upload in chunks of rows, generation multi-threaded (each block is independent)
-    const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nthr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     std::vector<uint8_t> stage;
     for (size_t i = 0; i < plan.size(); ++i) {
         const synth_spec sp = spec_of(plan[i], seed);

@@ -1,0 +1,94 @@
+"""Helpers shared by the model-level tests, smoke() and bench.py: a thin object wrapper over llama_lite's C API."""
+import ctypes as C
+
+import numpy as np
+
+import llama_box_amd as L
+
+
+def preset(name, **over):
+    hp = L.HParams()
+    if L.host().llm_preset(name.encode(), C.byref(hp)) != 0:
+        raise ValueError(name)
+    for k, v in over.items():
+        setattr(hp, k, v)
+    return hp
+
+
+class Model:
+    def __init__(self, hp=None, seed=1234, buft=None, path=None, tp_rank=0, tp_size=1, rowpar_buft=None):
+        H = L.host()
+        self.H = H
+        if path is not None:
+            self.m = H.llm_model_load(path.encode(), buft)
+        else:
+            self.m = H.llm_model_synth(C.byref(hp), seed, buft, tp_rank, tp_size, rowpar_buft)
+        if not self.m:
+            raise RuntimeError("model creation failed")
+        self.hp = H.llm_model_hparams(self.m).contents
+        self.n_vocab_local = self.hp.n_vocab // tp_size
+
+    def stream_bytes(self):
+        return int(self.H.llm_model_stream_bytes(self.m))
+
+    def free(self):
+        if self.m:
+            self.H.llm_model_free(self.m)
+            self.m = None
+
+
+class Context:
+    def __init__(self, model, backend=None, compute=None, n_ctx=512, n_ubatch=512, flash_attn=0, n_threads=0, graph_reuse=1):
+        H = L.host()
+        self.H = H
+        self.model = model
+        self._compute = compute if compute is not None else L.COMPUTE_FN()
+        cp = L.ContextParams(n_ctx, n_ubatch, flash_attn, n_threads, graph_reuse)
+        self.c = H.llm_context_new(model.m, backend.backend if backend is not None else None, self._compute, C.byref(cp))
+        if not self.c:
+            raise RuntimeError("context creation failed")
+
+    def decode(self, tokens, pos, seq=None, want=None):
+        n = len(tokens)
+        tk = (C.c_int32 * n)(*[int(t) for t in tokens])
+        ps = (C.c_int32 * n)(*[int(p) for p in pos])
+        sq = (C.c_int32 * n)(*[int(s) for s in seq]) if seq is not None else None
+        wl = (C.c_int8 * n)(*[int(w) for w in want]) if want is not None else None
+        rc = self.H.llm_decode(self.c, n, tk, ps, sq, wl)
+        if rc != 0:
+            return rc, None
+        no = self.H.llm_n_outputs(self.c)
+        nv = self.model.n_vocab_local
+        lg = np.ctypeslib.as_array(self.H.llm_get_logits(self.c), shape=(max(no, 1), nv))[:no].copy()
+        return 0, lg
+
+    def clear(self):
+        self.H.llm_kv_clear(self.c)
+
+    def timings(self):
+        out = (C.c_double * 4)()
+        self.H.llm_last_timings(self.c, out)
+        return list(out)
+
+    def free(self):
+        if self.c:
+            self.H.llm_context_free(self.c)
+            self.c = None
+
+
+def greedy(ctx, prompt, n_gen):
+    """Prefill `prompt`, then n_gen greedy steps. Returns (token ids, list of logits rows used for each pick)."""
+    rc, lg = ctx.decode(prompt, range(len(prompt)), want=[0] * (len(prompt) - 1) + [1])
+    assert rc == 0, rc
+    ids, rows = [], []
+    pos = len(prompt)
+    row = lg[-1]
+    for _ in range(n_gen):
+        t = int(np.argmax(row))
+        ids.append(t)
+        rows.append(row)
+        rc, lg = ctx.decode([t], [pos])
+        assert rc == 0, rc
+        row = lg[0]
+        pos += 1
+    return ids, rows
