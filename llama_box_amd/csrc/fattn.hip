@@ -55,56 +55,68 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
     const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
     const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
 
-    for (int p0 = kv0 + wave * RPW; p0 < kv1; p0 += 4 * RPW) {
-        const int p = p0 + sub;
-        const bool inr = p < kv1;
-        const int pc = inr ? p : kv1 - 1;
-        const float mv = mp ? h2f(mp[pc]) : 0.0f;
-        const uint4 kraw = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);
-        const uint4 vraw = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);
-        const uint32_t ku[4] = {kraw.x, kraw.y, kraw.z, kraw.w}, vu[4] = {vraw.x, vraw.y, vraw.z, vraw.w};
-        float kf[8], vf[8];
+    // two independent row groups per trip (A, B): their K/V loads are all issued before any use, so one trip costs
+    // one memory round trip instead of two
+    for (int p0 = kv0 + wave * RPW; p0 < kv1; p0 += 8 * RPW) {
+        int pp[2];
+        bool inr[2];
+        float mv[2];
+        uint4 kraw[2], vraw[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            kf[2 * i] = h2f((uint16_t) (ku[i] & 0xFFFF));
-            kf[2 * i + 1] = h2f((uint16_t) (ku[i] >> 16));
-            vf[2 * i] = h2f((uint16_t) (vu[i] & 0xFFFF));
-            vf[2 * i + 1] = h2f((uint16_t) (vu[i] >> 16));
-        }
-        float s[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float t = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t = fmaf(kf[i], qr[g][i], t);
-            s[g] = t;
+        for (int u = 0; u < 2; ++u) {
+            pp[u] = p0 + u * 4 * RPW + sub;
+            inr[u] = pp[u] < kv1;
+            const int pc = inr[u] ? pp[u] : kv1 - 1;
+            mv[u] = mp ? h2f(mp[pc]) : 0.0f;
+            kraw[u] = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);
+            vraw[u] = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);
         }
 #pragma unroll
-        for (int o = LPR >> 1; o > 0; o >>= 1) {
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
+            float kf[8], vf[8];
 #pragma unroll
-            for (int g = 0; g < G; ++g) s[g] += __shfl_xor(s[g], o, 64);
-        }
+            for (int i = 0; i < 4; ++i) {
+                kf[2 * i] = h2f((uint16_t) (ku[i] & 0xFFFF));
+                kf[2 * i + 1] = h2f((uint16_t) (ku[i] >> 16));
+                vf[2 * i] = h2f((uint16_t) (vu[i] & 0xFFFF));
+                vf[2 * i + 1] = h2f((uint16_t) (vu[i] >> 16));
+            }
+            float sc[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float sv = s[g] * geo.scale;
-            if (geo.softcap != 0.0f) sv = geo.softcap * tanhf(sv);
-            const float mvs = slope[g] * mv;
-            sv += mvs;
-            const bool use = inr && !(mvs == -INFINITY);
-            if (use) {
-                float vs = 1.0f;
-                if (sv > m[g]) {
-                    const float ms = expf(m[g] - sv);
-                    l[g] *= ms;
+            for (int g = 0; g < G; ++g) {
+                float t = 0.0f;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[g][i] *= ms;
-                    m[g] = sv;
-                } else {
-                    vs = expf(sv - m[g]);
+                for (int i = 0; i < 8; ++i) t = fmaf(kf[i], qr[g][i], t);
+                sc[g] = t;
+            }
+#pragma unroll
+            for (int o = LPR >> 1; o > 0; o >>= 1) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) sc[g] += __shfl_xor(sc[g], o, 64);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float sv = sc[g] * geo.scale;
+                if (geo.softcap != 0.0f) sv = geo.softcap * tanhf(sv);
+                const float mvs = slope[g] * mv[u];
+                sv += mvs;
+                const bool use = inr[u] && !(mvs == -INFINITY);
+                if (use) {
+                    float vs = 1.0f;
+                    if (sv > m[g]) {
+                        const float ms = expf(m[g] - sv);
+                        l[g] *= ms;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[g][i] *= ms;
+                        m[g] = sv;
+                    } else {
+                        vs = expf(sv - m[g]);
+                    }
+                    l[g] += vs;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[g][i] = fmaf(vs, vf[i], acc[g][i]);
                 }
-                l[g] += vs;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[g][i] = fmaf(vs, vf[i], acc[g][i]);
             }
         }
     }
@@ -173,26 +185,32 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
 }
 
 template <int D> __global__ void __launch_bounds__(64) k_fattn_combine(const float * __restrict__ ws, const float * __restrict__ sinks, const tdesc dst, const fa_geom geo) {
-    const int h = blockIdx.x, tok = blockIdx.y, bat = blockIdx.z;
-    const float * base = ws + (((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits * (D + 2);
-    float mt = -INFINITY;
-    for (int s = 0; s < geo.n_splits; ++s) mt = fmaxf(mt, base[(int64_t) s * (D + 2) + D]);
-    float sink_term = 0.0f, mn = mt;
+    const int h = blockIdx.x, tok = blockIdx.y, bat = blockIdx.z, lane = threadIdx.x;
+    const float * __restrict__ base = ws + (((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits * (D + 2);
+    // lane s owns split s (n_splits <= 64): one round trip fetches every (m, l) pair
+    const bool has = lane < geo.n_splits;
+    const float ms = has ? base[(int64_t) lane * (D + 2) + D] : -INFINITY;
+    const float ls = has ? base[(int64_t) lane * (D + 2) + D + 1] : 0.0f;
+    float mn = wave_max(ms);
+    float sink_term = 0.0f;
     if (sinks) {
-        mn = fmaxf(mt, sinks[h]);
+        mn = fmaxf(mn, sinks[h]);
         sink_term = expf(sinks[h] - mn);
     }
+    const float cs = ms == -INFINITY ? 0.0f : expf(ms - mn);
+    const float lt = wave_sum(ls * cs) + sink_term;
+    const float inv = 1.0f / lt;
     float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
-    for (int dd = threadIdx.x; dd < D; dd += 64) {
-        float a = 0.0f, lt = 0.0f;
-        for (int s = 0; s < geo.n_splits; ++s) {
-            const float * rec = base + (int64_t) s * (D + 2);
-            const float c = rec[D] == -INFINITY ? 0.0f : expf(rec[D] - mn);
-            a += rec[dd] * c;
-            lt += rec[D + 1] * c;
+    for (int dd = lane; dd < D; dd += 64) {
+        float a = 0.0f;
+        for (int s0 = 0; s0 < geo.n_splits; s0 += 8) {
+            float r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = (s0 + u) < geo.n_splits ? base[(int64_t) (s0 + u) * (D + 2) + dd] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += r[u] * __shfl(cs, (s0 + u) & 63, 64);
         }
-        lt += sink_term;
-        out[dd] = a * (1.0f / lt);
+        out[dd] = a * inv;
     }
 }
 

@@ -126,7 +126,7 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], b->ne[1] * b->ne[2] * b->ne[3]));
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
-            const int ns = c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k);
+            const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k));
             p.aux_bytes = std::max(p.aux_bytes, fattn_workspace_bytes(q, v, ns));
         }
     }
@@ -155,11 +155,19 @@ struct timed_scope {
 };
 
 // ------------------------------------------------------------------------------------------------ node execution
+struct deferred_norm {
+    const ggml_tensor * x;  // RMS_NORM input (residual stream)
+    const ggml_tensor * w;  // norm weight
+    float eps;
+};
 struct exec_state {
     backend_ctx * c;
     ggml_cgraph * g;
     std::unordered_map<const ggml_tensor *, int> uses;
     size_t act_off = 0, aux_off = 0;
+    // [RMS_NORM -> MUL] pairs whose result is consumed only by single-column K-quant mat-vecs: nothing is launched
+    // for them; each consumer recomputes norm*w in its prologue (mmvq.hip PRO=2)
+    std::unordered_map<const ggml_tensor *, deferred_norm> deferred;
 };
 
 static int use_count(const exec_state & st, const ggml_tensor * t) {
@@ -202,8 +210,35 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     backend_ctx * c = st.c;
     const int64_t K = w->ne[0], N = w->ne[1];
     const int64_t M = b->ne[1] * b->ne[2] * b->ne[3];
-    const void * act = quantized_src1(st, b, w->type);
     const double wbytes = (double) ggml_abi_row_size(w->type, K) * (double) N * (w2 ? 2.0 : 1.0);
+    const bool kquant = w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K;
+    auto dn = st.deferred.find(b);
+    const bool pro_norm = dn != st.deferred.end();
+    const bool pro_f32 = !pro_norm && c->opt.fusion && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
+    if (pro_norm || pro_f32) {
+        mmvq_args a{};
+        a.W = (const uint8_t *) w->data;
+        a.W2 = w2 ? (const uint8_t *) w2->data : nullptr;
+        a.w_nb1 = (int64_t) w->nb[1];
+        a.type = w->type;
+        a.K = (int) K;
+        a.N = (int) N;
+        a.ncols = 1;
+        a.dst = (float *) dst->data;
+        a.dst_stride = (int64_t) (dst->nb[1] / 4);
+        a.add = add ? (const float *) add->data : nullptr;
+        a.add2 = add2 ? (const float *) add2->data : nullptr;
+        a.x = pro_norm ? (const float *) dn->second.x->data : (const float *) b->data;
+        a.norm_w = pro_norm ? (const float *) dn->second.w->data : nullptr;
+        a.eps = pro_norm ? dn->second.eps : 0.0f;
+        char cls[64];
+        snprintf(cls, sizeof(cls), "mmvq_%s%s_%s", type_tag(w->type), w2 ? "_glu" : "", pro_norm ? "normpro" : "f32pro");
+        timed_scope ts(c, cls, wbytes);
+        launch_mmvq(c->stream, a, 1);
+        c->st.kernel_launches++;
+        return true;
+    }
+    const void * act = quantized_src1(st, b, w->type);
     if (M > c->opt.mmvq_max_cols && !w2 && !add && mmq_supported(w->type, K, N, M)) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
         launch_mmq(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4));
@@ -256,6 +291,39 @@ static const ggml_tensor * add_partner(const ggml_tensor * add, const ggml_tenso
     return o;
 }
 
+// May the pair [RMS_NORM n (node i), MUL m (node i+1)] be left un-launched?  Yes when m is a single row consumed ONLY
+// as src1 of K-quant MUL_MATs (each recomputes norm*w in its prologue), and no node up to the last consumer writes
+// memory overlapping x — the host allocator may already have recycled x's block if the norm was its last reader.
+static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, const ggml_tensor * m, const ggml_tensor * x, const ggml_tensor * w) {
+    if (ggml_abi_nrows(m) != 1 || (m->flags & GGML_TENSOR_FLAG_OUTPUT) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    if (!ggml_abi_is_contiguous(x) || ((((uintptr_t) x->data) | ((uintptr_t) w->data)) & 15) || (x->ne[0] % 256) != 0) return false;
+    const ggml_cgraph * g = st.g;
+    int last = -1, n_cons = 0;
+    for (int j = i + 2; j < g->n_nodes; ++j) {
+        const ggml_tensor * t = g->nodes[j];
+        for (int s = 0; s < GGML_MAX_SRC; ++s) {
+            if (t->src[s] != m) continue;
+            const ggml_tensor * wt = t->src[0];
+            const bool ok = t->op == GGML_OP_MUL_MAT && s == 1 && (wt->type == GGML_TYPE_Q4_K || wt->type == GGML_TYPE_Q5_K || wt->type == GGML_TYPE_Q6_K) &&
+                            wt->ne[2] == 1 && wt->ne[3] == 1 && ggml_abi_is_contiguous(t) && !(st.c->tp && buffer_is_rowpar(wt->view_src ? wt->view_src->buffer : wt->buffer));
+            if (!ok) return false;
+            last = j;
+            n_cons++;
+        }
+    }
+    if (n_cons == 0 || n_cons != use_count(st, m)) return false;
+    const char * x0 = (const char *) x->data;
+    const char * x1 = x0 + ggml_abi_nbytes(x);
+    for (int j = i + 2; j <= last; ++j) {
+        const ggml_tensor * t = g->nodes[j];
+        if (t->op == GGML_OP_NONE || t->op == GGML_OP_VIEW || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE) continue;
+        const char * t0 = (const char *) t->data;
+        const char * t1 = t0 + ggml_abi_nbytes(t);
+        if (t0 < x1 && x0 < t1) return false;
+    }
+    return true;
+}
+
 // executes node i (possibly fusing followers); returns number of nodes consumed, or -1 on failure
 static int run_node(exec_state & st, int i) {
     backend_ctx * c = st.c;
@@ -277,6 +345,11 @@ static int run_node(exec_state & st, int i) {
             if (fuse && m && m->op == GGML_OP_MUL && single_use(st, n) && m->type == GGML_TYPE_F32 && m->nb[0] == 4) {
                 const ggml_tensor * w = m->src[0] == n ? m->src[1] : (m->src[1] == n ? m->src[0] : nullptr);
                 if (w && w->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(w) && w->ne[0] == n->ne[0] && ggml_abi_nelements(w) == w->ne[0] && same_shape(m, n)) {
+                    if (can_defer_norm(st, i, n, m, a, w)) {
+                        st.deferred[m] = {a, w, ggml_abi_op_param_f32(n, 0)};
+                        c->st.fused_nodes += 2;
+                        return 2;
+                    }
                     const tdesc wd = TD(w);
                     timed_scope ts(c, "rms_norm_mul", (double) ggml_abi_nbytes(a) * 2);
                     launch_rms_norm(s, TD(a), TD(m), ggml_abi_op_param_f32(n, 0), &wd);
@@ -410,7 +483,7 @@ static int run_node(exec_state & st, int i) {
             p.max_bias = ggml_abi_op_param_f32(n, 1);
             p.logit_softcap = ggml_abi_op_param_f32(n, 2);
             const tdesc qd = TD(a), kd = TD(k), vd = TD(v);
-            p.n_splits = c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd);
+            p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd));
             const tdesc md = m ? TD(m) : qd;
             timed_scope ts(c, "flash_attn", (double) (k->ne[1] * k->ne[2] * k->ne[0] * 2 * 2));
             launch_flash_attn(s, qd, kd, vd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p, (char *) c->ws + st.aux_off);

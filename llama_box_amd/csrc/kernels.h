@@ -43,6 +43,11 @@ struct mmvq_args {
     int64_t add_stride;
     const float * add2;    // optional second addend (bias AND residual)
     int64_t add2_stride;
+    // fused activation prologue (ncols == 1, K-quants): x != null -> the kernel quantises f32 x itself (act unused);
+    // norm_w != null additionally applies RMS_NORM(x, eps) * norm_w first
+    const float * x;
+    const float * norm_w;
+    float eps;
 };
 void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave);
 

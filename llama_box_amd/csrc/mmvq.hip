@@ -198,16 +198,24 @@ struct T_Q80 {
 };
 
 // ------------------------------------------------------------------------------------------------ kernel
-template <typename T, int NC, int R, bool GLU, bool ACT_LDS>
-__global__ void __launch_bounds__(256) k_mmvq(const mmvq_args a) {
+// PRO selects how the workgroup obtains its Q8 activations:
+//   0  already quantised in global memory (quantize.hip) -> copied to LDS
+//   3  already quantised, read straight from global/L2 (batches whose activations exceed the LDS budget)
+//   1  f32 activations: every workgroup quantises the row itself into LDS (no separate quantize launch)
+//   2  f32 residual stream + norm weight: RMS_NORM, * w and the quantisation all happen in the prologue, so
+//      [RMS_NORM -> MUL -> quantise -> MUL_MAT] is ONE launch; arithmetic per element is identical to the unfused
+//      kernels (sum of squares in double, (x*scale)*w with two roundings, CPU-identical Q8_K rounding)
+template <typename T, int NC, int R, bool GLU, int PRO, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::act act;
+    constexpr int NT = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = a.K / T::BLK;
     const int npairs = nblk * T::PPB;
-    const int row0 = (blockIdx.x * 4 + wave) * R;
+    const int row0 = (blockIdx.x * WAVES + wave) * R;
 
-    // issue the first weight loads before touching the activations so HBM latency overlaps the LDS staging
+    // issue the first weight loads before touching the activations so HBM latency overlaps the prologue
     const uint8_t * rows[R];
     const uint8_t * rows2[R];
 #pragma unroll
@@ -227,20 +235,75 @@ __global__ void __launch_bounds__(256) k_mmvq(const mmvq_args a) {
     }
 
     const act * y;
-    if (ACT_LDS) {
+    if constexpr (PRO == 0) {
         const int nwords = (int) ((size_t) a.ncols * nblk * sizeof(act) / 4);
         const uint32_t * src = (const uint32_t *) a.act;
         uint32_t * dst = (uint32_t *) smem;
         if ((sizeof(act) & 15) == 0) {
             const int nvec = nwords >> 2;
-            for (int i = tid; i < nvec; i += 256) ((uint4 *) dst)[i] = ((const uint4 *) src)[i];
+            for (int i = tid; i < nvec; i += NT) ((uint4 *) dst)[i] = ((const uint4 *) src)[i];
         } else {
-            for (int i = tid; i < nwords; i += 256) dst[i] = src[i];
+            for (int i = tid; i < nwords; i += NT) dst[i] = src[i];
+        }
+        __syncthreads();
+        y = (const act *) smem;
+    } else if constexpr (PRO == 3) {
+        y = (const act *) a.act;
+    } else if constexpr (T::BLK == 256) {
+        q8k_dev * yl = (q8k_dev *) smem;
+        const float4 * x4 = (const float4 *) a.x;
+        const float4 * w4 = (const float4 *) a.norm_w;
+        float scale = 1.0f;
+        if constexpr (PRO == 2) {
+            double * red = (double *) (smem + (size_t) nblk * sizeof(q8k_dev));
+            const int n4 = a.K >> 2;
+            double ss = 0.0;
+            for (int i0 = tid; i0 < n4; i0 += 4 * NT) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i0 + u * NT;
+                    v[u] = idx < n4 ? x4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ss += (double) (v[u].x * v[u].x) + (double) (v[u].y * v[u].y) + (double) (v[u].z * v[u].z) + (double) (v[u].w * v[u].w);
+            }
+            ss = wave_sum_d(ss);
+            if (lane == 0) red[wave] = ss;
+            __syncthreads();
+            double tot = 0.0;
+#pragma unroll
+            for (int i = 0; i < WAVES; ++i) tot += red[i];
+            const float mean = (float) (tot / (double) a.K);
+            scale = 1.0f / sqrtf(mean + a.eps);
+        }
+        for (int b0 = wave; b0 < nblk; b0 += 4 * WAVES) {
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u * WAVES;
+                if (b < nblk) {
+                    float4 t = x4[b * 64 + lane];
+                    if constexpr (PRO == 2) {
+                        const float4 g = w4[b * 64 + lane];
+                        t.x = (t.x * scale) * g.x;
+                        t.y = (t.y * scale) * g.y;
+                        t.z = (t.z * scale) * g.z;
+                        t.w = (t.w * scale) * g.w;
+                    }
+                    v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u * WAVES;
+                if (b < nblk) wave_quantize_q8_K(v[u], lane, yl + b);
+            }
         }
         __syncthreads();
         y = (const act *) smem;
     } else {
-        y = (const act *) a.act;
+        y = (const act *) a.act;  // unreachable: the launcher never pairs PRO 1/2 with Q8_0 weights
     }
     if (row0 >= a.N) return;
 
@@ -295,18 +358,41 @@ __global__ void __launch_bounds__(256) k_mmvq(const mmvq_args a) {
     }
 }
 
-template <typename T, int NC, int R, bool GLU, bool ACT_LDS> static void launch_one(hipStream_t s, const mmvq_args & a, size_t lds) {
-    const int rows_per_block = 4 * R;
+template <typename T, int NC, int R, bool GLU, int PRO, int WAVES> static void launch_one(hipStream_t s, const mmvq_args & a, size_t lds) {
+    const int rows_per_block = WAVES * R;
     const unsigned grid = (unsigned) ((a.N + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((k_mmvq<T, NC, R, GLU, ACT_LDS>), dim3(grid), dim3(256), ACT_LDS ? lds : 0, s, a);
+    hipLaunchKernelGGL((k_mmvq<T, NC, R, GLU, PRO, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
+}
+
+// f32-activation prologue variants (single column, K-quants): geometry chosen by N so that small matrices still
+// spread over >= 256 workgroups while large ones amortise the prologue over 16 rows per workgroup
+template <typename T, int PRO> static void launch_pro(hipStream_t s, const mmvq_args & a) {
+    const int nblk = a.K / T::BLK;
+    const size_t lds = (size_t) nblk * sizeof(q8k_dev) + 64;
+    const bool glu = a.W2 != nullptr;
+    if (a.N <= 2048) {
+        if (glu) launch_one<T, 1, 1, true, PRO, 4>(s, a, lds); else launch_one<T, 1, 1, false, PRO, 4>(s, a, lds);
+    } else if (a.N < 8192) {
+        if (glu) launch_one<T, 1, 1, true, PRO, 8>(s, a, lds); else launch_one<T, 1, 1, false, PRO, 8>(s, a, lds);
+    } else {
+        if (glu) launch_one<T, 1, 2, true, PRO, 8>(s, a, lds); else launch_one<T, 1, 2, false, PRO, 8>(s, a, lds);
+    }
 }
 
 template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a0, int rows_per_wave) {
     mmvq_args a = a0;
     const int nblk = a.K / T::BLK;
     const bool glu = a.W2 != nullptr;
-    // activations are laid out [ncols][nblk]; a template wider than ncols reads (but never writes) columns that
-    // do not exist, so the padded columns are pointed back at column 0 by running with NC <= ncols only
+    if (a0.x != nullptr) {
+        if constexpr (T::BLK == 256) {
+            if (a0.norm_w) launch_pro<T, 2>(s, a0); else launch_pro<T, 1>(s, a0);
+            return;
+        } else {
+            MI_ERR("launch_mmvq: f32 prologue requested for a non K-quant type");
+            abort();
+        }
+    }
+    // activations are laid out [ncols][nblk]; the column loop runs templates of exactly 8/4/2/1 columns
     int done = 0;
     while (done < a0.ncols) {
         const int left = a0.ncols - done;
@@ -320,17 +406,17 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
         const bool fits = lds <= 64 * 1024;
         if (nc == 1) {
             const bool r2 = rows_per_wave >= 2;
-            if (glu) { if (r2) launch_one<T, 1, 2, true, true>(s, a, lds); else launch_one<T, 1, 1, true, true>(s, a, lds); }
-            else     { if (r2) launch_one<T, 1, 2, false, true>(s, a, lds); else launch_one<T, 1, 1, false, true>(s, a, lds); }
+            if (glu) { if (r2) launch_one<T, 1, 2, true, 0, 4>(s, a, lds); else launch_one<T, 1, 1, true, 0, 4>(s, a, lds); }
+            else     { if (r2) launch_one<T, 1, 2, false, 0, 4>(s, a, lds); else launch_one<T, 1, 1, false, 0, 4>(s, a, lds); }
         } else if (nc == 2) {
-            if (glu) { if (fits) launch_one<T, 2, 1, true, true>(s, a, lds); else launch_one<T, 2, 1, true, false>(s, a, lds); }
-            else     { if (fits) launch_one<T, 2, 1, false, true>(s, a, lds); else launch_one<T, 2, 1, false, false>(s, a, lds); }
+            if (glu) { if (fits) launch_one<T, 2, 1, true, 0, 4>(s, a, lds); else launch_one<T, 2, 1, true, 3, 4>(s, a, 0); }
+            else     { if (fits) launch_one<T, 2, 1, false, 0, 4>(s, a, lds); else launch_one<T, 2, 1, false, 3, 4>(s, a, 0); }
         } else if (nc == 4) {
-            if (glu) { if (fits) launch_one<T, 4, 1, true, true>(s, a, lds); else launch_one<T, 4, 1, true, false>(s, a, lds); }
-            else     { if (fits) launch_one<T, 4, 1, false, true>(s, a, lds); else launch_one<T, 4, 1, false, false>(s, a, lds); }
+            if (glu) { if (fits) launch_one<T, 4, 1, true, 0, 4>(s, a, lds); else launch_one<T, 4, 1, true, 3, 4>(s, a, 0); }
+            else     { if (fits) launch_one<T, 4, 1, false, 0, 4>(s, a, lds); else launch_one<T, 4, 1, false, 3, 4>(s, a, 0); }
         } else {
-            if (glu) { if (fits) launch_one<T, 8, 1, true, true>(s, a, lds); else launch_one<T, 8, 1, true, false>(s, a, lds); }
-            else     { if (fits) launch_one<T, 8, 1, false, true>(s, a, lds); else launch_one<T, 8, 1, false, false>(s, a, lds); }
+            if (glu) { if (fits) launch_one<T, 8, 1, true, 0, 4>(s, a, lds); else launch_one<T, 8, 1, true, 3, 4>(s, a, 0); }
+            else     { if (fits) launch_one<T, 8, 1, false, 0, 4>(s, a, lds); else launch_one<T, 8, 1, false, 3, 4>(s, a, 0); }
         }
         done += nc;
     }

@@ -4,6 +4,8 @@
 // arithmetic per element (this file is compiled with -ffp-contract=off, so `a*b - c` is two roundings exactly as
 // in the CPU reference) and a wave64 mapping: rows are reduced with 64-lane butterflies, f32 is moved as float4.
 // These ops are launch-bound at decode sizes; graph.cpp fuses the common chains so most of them disappear.
+#include <algorithm>
+
 #include "dev_util.h"
 #include "kernels.h"
 
@@ -40,21 +42,60 @@ __global__ void __launch_bounds__(256) k_rms_norm(const tdesc a, const tdesc d, 
     __shared__ double sh[4];
     const int64_t row = blockIdx.x;
     const int64_t i1 = row % a.ne[1], i2 = (row / a.ne[1]) % a.ne[2], i3 = row / (a.ne[1] * a.ne[2]);
-    const float * x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
-    float * y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const float * __restrict__ x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    float * __restrict__ y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
     const int64_t n = a.ne[0];
+    const bool vec = (n & 3) == 0 && ((((uintptr_t) x) | ((uintptr_t) y) | ((uintptr_t) w)) & 15) == 0;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float v = x[i];
-        s += (double) (v * v);
+    if (vec) {
+        // up to 4 independent 16-byte loads per thread per trip: a 4096-wide row is ONE round trip to L2
+        const float4 * x4 = (const float4 *) x;
+        const int64_t n4 = n >> 2;
+        for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (i0 + 256 * u) < n4 ? x4[i0 + 256 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += (double) (v[u].x * v[u].x) + (double) (v[u].y * v[u].y) + (double) (v[u].z * v[u].z) + (double) (v[u].w * v[u].w);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const float v = x[i];
+            s += (double) (v * v);
+        }
     }
     s = block_sum_d(s, sh);
     const float mean = (float) (s / (double) n);
     const float scale = 1.0f / sqrtf(mean + eps);
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        float v = x[i] * scale;
-        if (w) v = v * w[i];
-        y[i] = v;
+    if (vec) {
+        const float4 * x4 = (const float4 *) x;
+        const float4 * w4 = (const float4 *) w;
+        float4 * y4 = (float4 *) y;
+        const int64_t n4 = n >> 2;
+        for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+            float4 v[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + 256 * u;
+                if (i < n4) { v[u] = x4[i]; if (w) g[u] = w4[i]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + 256 * u;
+                if (i < n4) {
+                    float4 r;
+                    r.x = v[u].x * scale; r.y = v[u].y * scale; r.z = v[u].z * scale; r.w = v[u].w * scale;
+                    if (w) { r.x = r.x * g[u].x; r.y = r.y * g[u].y; r.z = r.z * g[u].z; r.w = r.w * g[u].w; }
+                    y4[i] = r;
+                }
+            }
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            float v = x[i] * scale;
+            if (w) v = v * w[i];
+            y[i] = v;
+        }
     }
 }
 void launch_rms_norm(hipStream_t s, const tdesc & src, const tdesc & dst, float eps, const tdesc * mul_w) {
@@ -253,8 +294,31 @@ __global__ void __launch_bounds__(256) k_set_rows(const tdesc a, const tdesc idx
     const int64_t r = blockIdx.x;
     const int64_t i01 = r % a.ne[1], i02 = (r / a.ne[1]) % a.ne[2], i03 = r / (a.ne[1] * a.ne[2]);
     const int64_t i1 = *(const int64_t *) (idx.data + i01 * idx.nb[0] + (i02 % idx.ne[1]) * idx.nb[1] + (i03 % idx.ne[2]) * idx.nb[2]);
-    const float * x = (const float *) (a.data + i01 * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3]);
-    char * p = d.data + i1 * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3];
+    const float * __restrict__ x = (const float *) (a.data + i01 * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3]);
+    char * __restrict__ p = d.data + i1 * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3];
+    if ((nc & 3) == 0 && ((((uintptr_t) x) | ((uintptr_t) p)) & 15) == 0) {
+        const int64_t n4 = nc >> 2;
+        for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + 256 * u < n4) v[u] = ((const float4 *) x)[i0 + 256 * u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + 256 * u;
+                if (i < n4) {
+                    if (d.type == GGML_TYPE_F16) {
+                        uint2 h;
+                        h.x = (uint32_t) f2h(v[u].x) | ((uint32_t) f2h(v[u].y) << 16);
+                        h.y = (uint32_t) f2h(v[u].z) | ((uint32_t) f2h(v[u].w) << 16);
+                        ((uint2 *) p)[i] = h;
+                    } else {
+                        ((float4 *) p)[i] = v[u];
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (d.type == GGML_TYPE_F16) for (int64_t i = threadIdx.x; i < nc; i += blockDim.x) ((uint16_t *) p)[i] = f2h(x[i]);
     else for (int64_t i = threadIdx.x; i < nc; i += blockDim.x) ((float *) p)[i] = x[i];
 }
@@ -303,13 +367,20 @@ __device__ __forceinline__ float yarn_ramp(const float low, const float high, co
 }
 template <bool F16IO> __global__ void __launch_bounds__(64) k_rope(const tdesc a, const tdesc pos, const float * __restrict__ ff, const tdesc d, const rope_params p,
                                                                const float theta_scale, const float corr0, const float corr1) {
-    // grid: (token i2, batch i3); lanes = pairs; loop over heads inside so the angle is computed once per (token, pair)
-    const int64_t i2 = blockIdx.x, i3 = blockIdx.y;
+    // grid: (head i1, token i2, batch i3); lanes = rotation pairs, so all loads of a launch are independent
+    const int64_t i1 = blockIdx.x, i2 = blockIdx.y, i3 = blockIdx.z;
     const int n_pairs = p.n_dims / 2;
     const float pos_f = (float) *(const int32_t *) (pos.data + i2 * pos.nb[0]);
+    const char * __restrict__ src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+    char * __restrict__ dst = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+    const bool neox = (p.mode & GGML_ROPE_TYPE_NEOX) != 0;
     for (int ip = threadIdx.x; ip < n_pairs; ip += blockDim.x) {
+        const int ia = neox ? ip : 2 * ip, ib = neox ? ip + n_pairs : 2 * ip + 1;
+        float x0, x1;
+        if (F16IO) { x0 = h2f(((const uint16_t *) src)[ia]); x1 = h2f(((const uint16_t *) src)[ib]); }
+        else { x0 = ((const float *) src)[ia]; x1 = ((const float *) src)[ib]; }
         float theta = pos_f;
-        for (int k = 0; k < ip; ++k) theta *= theta_scale;
+        for (int k = 0; k < ip; ++k) theta *= theta_scale;  // the CPU's exact multiply chain
         const float fq = ff ? ff[ip] : 1.0f;
         const float theta_extrap = theta / fq;
         const float theta_interp = p.freq_scale * theta_extrap;
@@ -320,30 +391,17 @@ template <bool F16IO> __global__ void __launch_bounds__(64) k_rope(const tdesc a
             mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
         }
         const float cs = cosf(th) * mscale, sn = sinf(th) * mscale;
-        const bool neox = (p.mode & GGML_ROPE_TYPE_NEOX) != 0;
-        const int ia = neox ? ip : 2 * ip, ib = neox ? ip + n_pairs : 2 * ip + 1;
-        for (int64_t i1 = 0; i1 < a.ne[1]; ++i1) {
-            const char * src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
-            char * dst = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
-            if (F16IO) {
-                const float x0 = h2f(((const uint16_t *) src)[ia]), x1 = h2f(((const uint16_t *) src)[ib]);
-                ((uint16_t *) dst)[ia] = f2h(x0 * cs - x1 * sn);
-                ((uint16_t *) dst)[ib] = f2h(x0 * sn + x1 * cs);
-            } else {
-                const float x0 = ((const float *) src)[ia], x1 = ((const float *) src)[ib];
-                ((float *) dst)[ia] = x0 * cs - x1 * sn;
-                ((float *) dst)[ib] = x0 * sn + x1 * cs;
-            }
+        if (F16IO) {
+            ((uint16_t *) dst)[ia] = f2h(x0 * cs - x1 * sn);
+            ((uint16_t *) dst)[ib] = f2h(x0 * sn + x1 * cs);
+        } else {
+            ((float *) dst)[ia] = x0 * cs - x1 * sn;
+            ((float *) dst)[ib] = x0 * sn + x1 * cs;
         }
     }
-    // pass-through tail beyond n_dims
-    for (int64_t i0 = p.n_dims + threadIdx.x; i0 < a.ne[0]; i0 += blockDim.x) {
-        for (int64_t i1 = 0; i1 < a.ne[1]; ++i1) {
-            const char * src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
-            char * dst = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
-            if (F16IO) ((uint16_t *) dst)[i0] = ((const uint16_t *) src)[i0];
-            else ((float *) dst)[i0] = ((const float *) src)[i0];
-        }
+    for (int64_t i0 = p.n_dims + threadIdx.x; i0 < a.ne[0]; i0 += blockDim.x) {  // pass-through tail beyond n_dims
+        if (F16IO) ((uint16_t *) dst)[i0] = ((const uint16_t *) src)[i0];
+        else ((float *) dst)[i0] = ((const float *) src)[i0];
     }
 }
 void launch_rope(hipStream_t s, const tdesc & a, const tdesc & pos, const float * ff, const tdesc & d, const rope_params & p) {
@@ -352,7 +410,7 @@ void launch_rope(hipStream_t s, const tdesc & a, const tdesc & pos, const float 
     auto corr_dim = [&](float n_rot) { return (float) p.n_dims * logf((float) p.n_ctx_orig / (n_rot * 2.0f * (float) M_PI)) / (2.0f * logf(p.freq_base)); };
     const float c0 = fmaxf(0.0f, floorf(corr_dim(p.beta_fast)));
     const float c1 = fminf((float) (p.n_dims - 1), ceilf(corr_dim(p.beta_slow)));
-    dim3 grid((unsigned) a.ne[2], (unsigned) a.ne[3]);
+    dim3 grid((unsigned) a.ne[1], (unsigned) a.ne[2], (unsigned) a.ne[3]);
     if (a.type == GGML_TYPE_F16) hipLaunchKernelGGL(k_rope<true>, grid, dim3(64), 0, s, a, pos, ff, d, p, theta_scale, c0, c1);
     else hipLaunchKernelGGL(k_rope<false>, grid, dim3(64), 0, s, a, pos, ff, d, p, theta_scale, c0, c1);
 }

@@ -25,43 +25,7 @@ __global__ void __launch_bounds__(64) k_quantize_q8_K(const char * __restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = x[lane * 4 + k];
     }
-    // (amax, first index achieving it, signed value there) — "first" reproduces the CPU's strict `ax > amax` scan
-    float amax = 0.0f, mx = 0.0f;
-    int idx = lane * 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float ax = fabsf(v[k]);
-        if (ax > amax) { amax = ax; mx = v[k]; idx = lane * 4 + k; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float oa = __shfl_xor(amax, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        const float om = __shfl_xor(mx, o, 64);
-        const bool take = oa > amax || (oa == amax && oi < idx);
-        if (take) { amax = oa; idx = oi; mx = om; }
-    }
-    q8k_dev * y = dst + gid;
-    int q[4] = {0, 0, 0, 0};
-    float iscale = 0.0f;
-    if (amax != 0.0f) {
-        iscale = -127.f / mx;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = (int) rintf(iscale * v[k]);  // round-half-even == ggml's nearest_int()
-            q[k] = r < 127 ? r : 127;
-        }
-    }
-    const uint32_t packed = (uint32_t) (q[0] & 0xFF) | ((uint32_t) (q[1] & 0xFF) << 8) | ((uint32_t) (q[2] & 0xFF) << 16) | ((uint32_t) (q[3] & 0xFF) << 24);
-    ((uint32_t *) y->qs)[lane] = packed;
-    int s = q[0] + q[1] + q[2] + q[3];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if ((lane & 3) == 0) y->bsums[lane >> 2] = (int16_t) s;
-    if (lane == 0) {
-        y->d = amax != 0.0f ? 1.0f / iscale : 0.0f;
-        y->pad[0] = y->pad[1] = y->pad[2] = 0.0f;
-    }
+    wave_quantize_q8_K(v, lane, dst + gid);
 }
 
 // Q8_0 activations: 8 lanes per 32-element block; d = amax/127 stored through fp16; q = roundf(x * (1/d))

@@ -803,7 +803,8 @@ static alloc_plan plan_graph(ggml_gallocr_t ga, ggml_cgraph * g) {
             if (!n->src[s]) continue;
             ggml_tensor * r = root(n->src[s]);
             if (r->op == GGML_OP_NONE || (r->flags & (GGML_TENSOR_FLAG_OUTPUT | GGML_TENSOR_FLAG_INPUT))) continue;
-            if (last_use[r] == i) release(r);
+            static const bool no_reuse = getenv("GGML_LITE_NO_REUSE") != nullptr;  // debugging: keep every intermediate
+            if (last_use[r] == i && !no_reuse) release(r);
         }
     }
     return plan;

@@ -6,9 +6,14 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_log.txt
 echo "== rocminfo =="; (rocminfo | grep -E "Marketing Name|gfx9" | head -4) 2>&1
+if [ -n "${NODE_DIFF:-}" ]; then
+echo "== node diff =="
+timeout 300 python scripts/node_diff.py $NODE_DIFF > gpurun_out/node_diff.log 2>&1; grep -E "<<<<" gpurun_out/node_diff.log | head -20; tail -n 3 gpurun_out/node_diff.log
+timeout 300 python scripts/node_diff.py $NODE_DIFF 0 > gpurun_out/node_diff_nofuse.log 2>&1; grep -E "<<<<" gpurun_out/node_diff_nofuse.log | head -20
+fi
 echo "== pytest -m gpu =="
-timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-tail -n 40 gpurun_out/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=12 ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+tail -n 45 gpurun_out/pytest_gpu.log | cut -c1-220
 echo "== smoke =="
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 5 gpurun_out/smoke.log
 echo "== bench =="

@@ -57,7 +57,7 @@ def oracle():
     return _oracle
 
 
-def oracle_compute_fn(n_threads=0):
+def oracle_compute_fn(n_threads=4):
     """llm_compute_fn wrapping the oracle (keep the returned object alive while the context lives)."""
     lib = oracle()
 
@@ -135,7 +135,7 @@ class G:
             self.inputs.append((t, raw))
         return t
 
-    def compute(self, outs, n_threads=0):
+    def compute(self, outs, n_threads=4):
         """Allocates every tensor, uploads inputs, evaluates the graph for `outs`, returns numpy copies of `outs`."""
         H = self.H
         gf = H.ggml_new_graph_custom(self.ctx, 4096, False)
@@ -192,7 +192,7 @@ class G:
             self.ctx = None
 
 
-def run_case(build, target, n_threads=0):
+def run_case(build, target, n_threads=4):
     g = G(target)
     try:
         outs = build(g)

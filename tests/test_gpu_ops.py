@@ -6,7 +6,7 @@ Gates (written per case):
   * element-wise f32 ops with one rounding per operation ............. bit-exact (kernels built with -ffp-contract=off)
   * quantised MUL_MAT: integer block sums are exact, only the f32 scale-accumulate ORDER differs -> NMSE <= 1e-10
   * reductions / transcendental ops (rms_norm, rope, soft_max) ....... NMSE <= 1e-12 .. 1e-10
-  * FLASH_ATTN_EXT: the CPU accumulates V in f16, the kernel in f32 -> NMSE <= 2e-5 (upstream's gate for this op is 5e-4)
+  * FLASH_ATTN_EXT: the CPU accumulates V in f16 (noise grows with n_kv), the kernel in f32 -> NMSE <= 1e-4 (upstream's gate for this op is 5e-4)
 """
 import numpy as np
 import pytest
@@ -396,7 +396,7 @@ def test_flash_attn(backend, H, plog, HD, NH, NKV, nq, nkv, splits, softcap, ali
         ref, got = both(build, backend)
     finally:
         backend.set_option("fa_splits", 0)
-    T.compare(f"flash_attn D={HD} H={NH}/{NKV} nq={nq} nkv={nkv} splits={splits} cap={softcap} alibi={alibi} sinks={sinks}", got[0], ref[0], max_nmse=2e-5, log=plog)
+    T.compare(f"flash_attn D={HD} H={NH}/{NKV} nq={nq} nkv={nkv} splits={splits} cap={softcap} alibi={alibi} sinks={sinks}", got[0], ref[0], max_nmse=1e-4, log=plog)
     # and against exact (float64) attention: the f32-accumulating kernel must be CLOSER to it than the f16-accumulating CPU path
     kf = kc[:nkv].astype(np.float64).reshape(nkv, NKV, HD)
     vf = vc[:nkv].astype(np.float64).reshape(nkv, NKV, HD)
