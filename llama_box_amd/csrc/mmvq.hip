@@ -16,6 +16,8 @@
 //     element-wise launches that would otherwise sit between the mat-vecs of a layer.
 //
 // Algorithmic bytes per launch = N * K/blk * bytes_per_block (+ K*1.19 activations, negligible).
+#include <algorithm>
+
 #include "dev_util.h"
 #include "kernels.h"
 
@@ -358,25 +360,156 @@ __global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ streaming kernel
+// Single-column (batch-1 decode) variant built around what the profile showed: with one short row per wave the
+// launch is bound by a CHAIN of memory round trips (prologue -> first load -> second load), not by bandwidth.  Here
+//   * the grid is one 16-wave workgroup per CU (<= 256), all resident at once: no second scheduling round;
+//   * every wave walks its rows (row = wave id + t * total waves: consecutive waves read consecutive rows, so the
+//     chip sweeps the matrix front to back) as a flat sequence of items (row, chunk of U lane-pairs) and always has
+//     the NEXT item's loads in flight while it computes the current one;
+//   * the first item is requested before the activation prologue, so HBM latency hides under it;
+//   * the prologue (PRO as above) runs once per workgroup with 1024 threads: one L2 round trip for x (and w), the
+//     RMS-norm reduction, CPU-identical Q8_K quantisation straight into LDS.
+template <typename T, bool GLU, int PRO>
+__global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename T::act act;
+    constexpr int WAVES = 16, NT = 1024, U = GLU ? 1 : 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = a.K / T::BLK;
+    const int npairs = nblk * T::PPB;
+    const int nchunks = (npairs + 64 * U - 1) / (64 * U);
+    const int GW = gridDim.x * WAVES;
+    int row = blockIdx.x * WAVES + wave, ch = 0;
+    bool have = row < a.N;
+
+    struct item {
+        typename T::raw w[U];
+        typename T::raw w2[U];
+    };
+    auto load_item = [&](const int r, const int c, item & it) {
+        const uint8_t * rp = a.W + (size_t) r * a.w_nb1;
+        const uint8_t * rp2 = GLU ? a.W2 + (size_t) r * a.w_nb1 : nullptr;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = (c * U + u) * 64 + lane;
+            if (p < npairs) {
+                it.w[u] = T::load(rp, p);
+                if (GLU) it.w2[u] = T::load(rp2, p);
+            }
+        }
+    };
+    item cur;
+    if (have) load_item(row, 0, cur);
+
+    // ---- activation prologue
+    if constexpr (PRO == 0) {
+        const int nwords = (int) ((size_t) nblk * sizeof(act) / 4);
+        const uint32_t * src = (const uint32_t *) a.act;
+        uint32_t * dst = (uint32_t *) smem;
+        if ((sizeof(act) & 15) == 0) {
+            const int nvec = nwords >> 2;
+            for (int i = tid; i < nvec; i += NT) ((uint4 *) dst)[i] = ((const uint4 *) src)[i];
+        } else {
+            for (int i = tid; i < nwords; i += NT) dst[i] = src[i];
+        }
+    } else if constexpr (T::BLK == 256) {
+        q8k_dev * yl = (q8k_dev *) smem;
+        const float4 * x4 = (const float4 *) a.x;
+        const float4 * w4 = (const float4 *) a.norm_w;
+        for (int b0 = wave; b0 < nblk; b0 += 4 * WAVES) {
+            float4 v[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u * WAVES;
+                if (b < nblk) {
+                    v[u] = x4[b * 64 + lane];
+                    if (PRO == 2) g[u] = w4[b * 64 + lane];
+                } else {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            float scale = 1.0f;
+            if constexpr (PRO == 2) {  // launcher guarantees nblk <= 4*WAVES: this loop body runs once and sees the whole row
+                double * red = (double *) (smem + (size_t) nblk * sizeof(q8k_dev));
+                double ss = 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ss += (double) (v[u].x * v[u].x) + (double) (v[u].y * v[u].y) + (double) (v[u].z * v[u].z) + (double) (v[u].w * v[u].w);
+                ss = wave_sum_d(ss);
+                if (lane == 0) red[wave] = ss;
+                __syncthreads();
+                double tot = 0.0;
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) tot += red[i];
+                const float mean = (float) (tot / (double) a.K);
+                scale = 1.0f / sqrtf(mean + a.eps);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u * WAVES;
+                if (b < nblk) {
+                    float t[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    if constexpr (PRO == 2) {
+                        t[0] = (t[0] * scale) * g[u].x;
+                        t[1] = (t[1] * scale) * g[u].y;
+                        t[2] = (t[2] * scale) * g[u].z;
+                        t[3] = (t[3] * scale) * g[u].w;
+                    }
+                    wave_quantize_q8_K(t, lane, yl + b);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const act * y = (const act *) smem;
+
+    float acc = 0.0f, acc2 = 0.0f;
+    while (have) {
+        int nrow = row, nch = ch + 1;
+        if (nch == nchunks) { nch = 0; nrow = row + GW; }
+        const bool nhave = nrow < a.N;
+        item nxt;
+        if (nhave) load_item(nrow, nch, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = (ch * U + u) * 64 + lane;
+            if (p < npairs) {
+                T::template dot<1>(cur.w[u], p, y, nblk, &acc);
+                if (GLU) T::template dot<1>(cur.w2[u], p, y, nblk, &acc2);
+            }
+        }
+        if (ch == nchunks - 1) {
+            float v = wave_sum(acc);
+            if (GLU) {
+                const float g = wave_sum(acc2);
+                v = silu_f(v) * g;
+            }
+            if (lane == 0) {
+                if (a.add) v += a.add[row];
+                if (a.add2) v += a.add2[row];
+                a.dst[row] = v;
+            }
+            acc = 0.0f;
+            acc2 = 0.0f;
+        }
+        cur = nxt;
+        row = nrow;
+        ch = nch;
+        have = nhave;
+    }
+}
+
+template <typename T, bool GLU, int PRO> static void launch_stream(hipStream_t s, const mmvq_args & a) {
+    const int nblk = a.K / T::BLK;
+    const size_t lds = (size_t) nblk * sizeof(typename T::act) + 16 * sizeof(double) + 16;
+    const unsigned grid = (unsigned) std::min<int64_t>(256, ((int64_t) a.N + 15) / 16);
+    hipLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, a);
+}
+
 template <typename T, int NC, int R, bool GLU, int PRO, int WAVES> static void launch_one(hipStream_t s, const mmvq_args & a, size_t lds) {
     const int rows_per_block = WAVES * R;
     const unsigned grid = (unsigned) ((a.N + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL((k_mmvq<T, NC, R, GLU, PRO, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
-}
-
-// f32-activation prologue variants (single column, K-quants): geometry chosen by N so that small matrices still
-// spread over >= 256 workgroups while large ones amortise the prologue over 16 rows per workgroup
-template <typename T, int PRO> static void launch_pro(hipStream_t s, const mmvq_args & a) {
-    const int nblk = a.K / T::BLK;
-    const size_t lds = (size_t) nblk * sizeof(q8k_dev) + 64;
-    const bool glu = a.W2 != nullptr;
-    if (a.N <= 2048) {
-        if (glu) launch_one<T, 1, 1, true, PRO, 4>(s, a, lds); else launch_one<T, 1, 1, false, PRO, 4>(s, a, lds);
-    } else if (a.N < 8192) {
-        if (glu) launch_one<T, 1, 1, true, PRO, 8>(s, a, lds); else launch_one<T, 1, 1, false, PRO, 8>(s, a, lds);
-    } else {
-        if (glu) launch_one<T, 1, 2, true, PRO, 8>(s, a, lds); else launch_one<T, 1, 2, false, PRO, 8>(s, a, lds);
-    }
 }
 
 template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a0, int rows_per_wave) {
@@ -385,12 +518,17 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
     const bool glu = a.W2 != nullptr;
     if (a0.x != nullptr) {
         if constexpr (T::BLK == 256) {
-            if (a0.norm_w) launch_pro<T, 2>(s, a0); else launch_pro<T, 1>(s, a0);
+            if (a0.norm_w) { if (glu) launch_stream<T, true, 2>(s, a0); else launch_stream<T, false, 2>(s, a0); }
+            else           { if (glu) launch_stream<T, true, 1>(s, a0); else launch_stream<T, false, 1>(s, a0); }
             return;
         } else {
             MI_ERR("launch_mmvq: f32 prologue requested for a non K-quant type");
             abort();
         }
+    }
+    if (a0.ncols == 1 && (size_t) nblk * sizeof(typename T::act) <= 60 * 1024) {
+        if (glu) launch_stream<T, true, 0>(s, a0); else launch_stream<T, false, 0>(s, a0);
+        return;
     }
     // activations are laid out [ncols][nblk]; the column loop runs templates of exactly 8/4/2/1 columns
     int done = 0;

@@ -20,6 +20,13 @@
 
 typedef double ggml_float; /* ggml-cpu accumulates scalar reductions in double */
 
+/* Summation-order variant.  0 = the generic ggml-cpu order (blocks first to last).  1 = blocks last to first: an
+ * equally valid f32 evaluation order (every SIMD build of ggml-cpu has its own), used by the tests to measure how far
+ * the network's logits move under a change of summation order ALONE — the yardstick for the GPU-vs-oracle gates. */
+static int g_variant = 0;
+void oracle_set_variant(int v) { g_variant = v; }
+#define BLK_IDX(i, nb) (g_variant ? ((nb) - 1 - (i)) : (i))
+
 /* ------------------------------------------------------------------------------------------ */
 /* fp16 <-> fp32 (IEEE binary16, round-to-nearest-even; same results as F16C / ggml's fallback) */
 /* ------------------------------------------------------------------------------------------ */
@@ -260,7 +267,8 @@ void oracle_quantize_row_q8_K(const float * x, block_q8_K * y, int64_t k) {
 float oracle_vec_dot_q8_0_q8_0(int64_t n, const block_q8_0 * x, const block_q8_0 * y) {
     const int64_t nb = n / QK8_0;
     float sumf = 0;
-    for (int64_t ib = 0; ib < nb; ++ib) {
+    for (int64_t ib_ = 0; ib_ < nb; ++ib_) {
+        const int64_t ib = BLK_IDX(ib_, nb);
         int sumi = 0;
         for (int j = 0; j < QK8_0; j++) sumi += x[ib].qs[j] * y[ib].qs[j];
         sumf += sumi * (F16(x[ib].d) * F16(y[ib].d));
@@ -276,7 +284,8 @@ static float vec_dot_k45(int64_t n, const uint8_t * xb, size_t xstride, int is5,
     int32_t aux32[8];
     memset(sums, 0, sizeof(sums));
     float sumf = 0;
-    for (int64_t i = 0; i < nb; ++i) {
+    for (int64_t i_ = 0; i_ < nb; ++i_) {
+        const int64_t i = BLK_IDX(i_, nb);
         const uint8_t * blk = xb + (size_t) i * xstride;
         ggml_fp16_t hd, hdmin;
         memcpy(&hd, blk, 2);
@@ -336,7 +345,8 @@ float oracle_vec_dot_q6_K_q8_K(int64_t n, const block_q6_K * x, const block_q8_K
     int32_t aux32[8];
     memset(sums, 0, sizeof(sums));
     float sumf = 0;
-    for (int64_t i = 0; i < nb; ++i) {
+    for (int64_t i_ = 0; i_ < nb; ++i_) {
+        const int64_t i = BLK_IDX(i_, nb);
         const uint8_t * q4 = x[i].ql;
         const uint8_t * qh = x[i].qh;
         const int8_t * q8 = y[i].qs;
