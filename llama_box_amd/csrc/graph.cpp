@@ -296,7 +296,7 @@ static const ggml_tensor * add_partner(const ggml_tensor * add, const ggml_tenso
 // memory overlapping x — the host allocator may already have recycled x's block if the norm was its last reader.
 static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, const ggml_tensor * m, const ggml_tensor * x, const ggml_tensor * w) {
     if (ggml_abi_nrows(m) != 1 || (m->flags & GGML_TENSOR_FLAG_OUTPUT) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
-    if (!ggml_abi_is_contiguous(x) || ((((uintptr_t) x->data) | ((uintptr_t) w->data)) & 15) || (x->ne[0] % 256) != 0) return false;
+    if (!ggml_abi_is_contiguous(x) || ((((uintptr_t) x->data) | ((uintptr_t) w->data)) & 15) || (x->ne[0] % 256) != 0 || x->ne[0] > 16384) return false;
     const ggml_cgraph * g = st.g;
     int last = -1, n_cons = 0;
     for (int j = i + 2; j < g->n_nodes; ++j) {

@@ -417,7 +417,10 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         q8k_dev * yl = (q8k_dev *) smem;
         const float4 * x4 = (const float4 *) a.x;
         const float4 * w4 = (const float4 *) a.norm_w;
-        for (int b0 = wave; b0 < nblk; b0 += 4 * WAVES) {
+        // batch 0 (blocks wave, wave+16, wave+32, wave+48) is special: with the norm it must hold the WHOLE row
+        // (launcher guarantees nblk <= 64) because the scale needs the full sum of squares; the barrier sits outside
+        // any wave-dependent control flow
+        for (int b0 = wave; b0 < nblk || b0 == wave; b0 += 4 * WAVES) {
             float4 v[4], g[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -427,17 +430,18 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
                     if (PRO == 2) g[u] = w4[b * 64 + lane];
                 } else {
                     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[u] = v[u];
                 }
             }
             float scale = 1.0f;
-            if constexpr (PRO == 2) {  // launcher guarantees nblk <= 4*WAVES: this loop body runs once and sees the whole row
+            if constexpr (PRO == 2) {
                 double * red = (double *) (smem + (size_t) nblk * sizeof(q8k_dev));
                 double ss = 0.0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ss += (double) (v[u].x * v[u].x) + (double) (v[u].y * v[u].y) + (double) (v[u].z * v[u].z) + (double) (v[u].w * v[u].w);
                 ss = wave_sum_d(ss);
                 if (lane == 0) red[wave] = ss;
-                __syncthreads();
+                __syncthreads();  // reached exactly once by every wave: the loop condition admits b0 == wave
                 double tot = 0.0;
 #pragma unroll
                 for (int i = 0; i < WAVES; ++i) tot += red[i];
@@ -458,6 +462,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
                     wave_quantize_q8_K(t, lane, yl + b);
                 }
             }
+            if constexpr (PRO == 2) break;  // single batch by construction
         }
     }
     __syncthreads();
