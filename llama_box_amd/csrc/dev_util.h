@@ -89,4 +89,26 @@ template <typename Q8K> __device__ __forceinline__ void wave_quantize_q8_K(const
     }
 }
 
+// rotary-embedding angle for pair `ip` of a token at position pos_f: the same chain of f32 multiplies as ggml-cpu's
+// rope cache loop (theta *= theta_scale per pair), then the YaRN mix and the accurate cosf/sinf
+struct rope_consts {
+    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
+};
+__device__ __forceinline__ void rope_cos_sin(const int ip, const float pos_f, const float * __restrict__ ff, const rope_consts rc, float & cs, float & sn) {
+    float theta = pos_f;
+    for (int k = 0; k < ip; ++k) theta *= rc.theta_scale;
+    const float fq = ff ? ff[ip] : 1.0f;
+    const float theta_extrap = theta / fq;
+    const float theta_interp = rc.freq_scale * theta_extrap;
+    float th = theta_interp, mscale = rc.attn_factor;
+    if (rc.ext_factor != 0.0f) {
+        const float y = ((float) ip - rc.corr0) / fmaxf(0.001f, rc.corr1 - rc.corr0);
+        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * rc.ext_factor;
+        th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / rc.freq_scale);
+    }
+    cs = cosf(th) * mscale;
+    sn = sinf(th) * mscale;
+}
+
 }  // namespace mi355x

@@ -168,6 +168,7 @@ struct exec_state {
     // [RMS_NORM -> MUL] pairs whose result is consumed only by single-column K-quant mat-vecs: nothing is launched
     // for them; each consumer recomputes norm*w in its prologue (mmvq.hip PRO=2)
     std::unordered_map<const ggml_tensor *, deferred_norm> deferred;
+    std::vector<char> done;  // nodes already executed out of order by a multi-chain fusion
 };
 
 static int use_count(const exec_state & st, const ggml_tensor * t) {
@@ -324,6 +325,177 @@ static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, 
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------ fused Q/K/V
+static bool is_view_op(const ggml_tensor * t) {
+    return t->op == GGML_OP_NONE || t->op == GGML_OP_VIEW || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE;
+}
+struct qkv_chain {
+    const ggml_tensor * mm = nullptr;
+    const ggml_tensor * bias = nullptr;
+    const ggml_tensor * rope = nullptr;
+    const ggml_tensor * store = nullptr;    // SET_ROWS node (f16 cache rows)
+    const ggml_tensor * out_f32 = nullptr;  // otherwise: last materialised f32 tensor of the chain
+    std::vector<int> nodes;
+};
+// follows mm -> [ADD bias] -> (RESHAPE)* -> [ROPE] -> (RESHAPE)* -> [SET_ROWS]; stops at the first consumer it cannot absorb
+static bool follow_qkv_chain(const exec_state & st, int start, int limit, qkv_chain & ch) {
+    const ggml_cgraph * g = st.g;
+    const ggml_tensor * cur = g->nodes[start];
+    ch.mm = cur;
+    ch.nodes.push_back(start);
+    const int64_t N = cur->ne[0];
+    for (;;) {
+        if (!single_use(st, cur)) break;
+        int j = -1;
+        for (int k = start + 1; k < limit && j < 0; ++k)
+            for (int sidx = 0; sidx < GGML_MAX_SRC; ++sidx)
+                if (g->nodes[k]->src[sidx] == cur) { j = k; break; }
+        if (j < 0) break;
+        const ggml_tensor * c = g->nodes[j];
+        if (c->op == GGML_OP_RESHAPE && c->src[0] == cur) {
+            cur = c;
+            ch.nodes.push_back(j);
+            continue;
+        }
+        if (c->op == GGML_OP_ADD && !ch.bias && !ch.rope) {
+            const ggml_tensor * o = add_partner(c, cur);
+            if (o && ggml_abi_nelements(o) == N && ggml_abi_nrows(c) == 1) {
+                ch.bias = o;
+                cur = c;
+                ch.nodes.push_back(j);
+                continue;
+            }
+            break;
+        }
+        if (c->op == GGML_OP_ROPE && c->src[0] == cur && !ch.rope && c->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(c)) {
+            ch.rope = c;
+            cur = c;
+            ch.nodes.push_back(j);
+            continue;
+        }
+        if (c->op == GGML_OP_SET_ROWS && c->src[0] == cur && c->type == GGML_TYPE_F16 && c->ne[0] == N && cur->ne[0] == N && ggml_abi_nelements(cur) == N &&
+            c->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(c->src[1]) == 1 && c->nb[0] == 2) {
+            ch.store = c;
+            ch.nodes.push_back(j);
+            return true;
+        }
+        break;
+    }
+    ch.out_f32 = cur;
+    return ggml_abi_is_contiguous(cur) && cur->type == GGML_TYPE_F32;
+}
+
+// at a single-column K-quant MUL_MAT: try to run it together with its siblings (same src1) and their bias / rope / cache
+// store chains as ONE launch (qkv.hip).  Returns true if launched; the absorbed nodes are flagged in st.done.
+static bool try_fuse_qkv(exec_state & st, int i) {
+    backend_ctx * c = st.c;
+    ggml_cgraph * g = st.g;
+    const ggml_tensor * n = g->nodes[i];
+    const ggml_tensor * X = n->src[1];
+    auto kq = [](const ggml_tensor * w) { return (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K) && w->ne[2] == 1 && w->ne[3] == 1 && rows_contig(w) && (w->ne[1] % 2) == 0; };
+    if (ggml_abi_nrows(X) != 1 || X->type != GGML_TYPE_F32 || (X->ne[0] % 256) != 0) return false;
+    auto dn = st.deferred.find(X);
+    const bool norm = dn != st.deferred.end();
+    if (!norm && (X->nb[0] != 4 || (((uintptr_t) X->data) & 15))) return false;
+    if (norm && X->ne[0] > 8192) return false;  // qkv.hip holds the whole row in one prologue batch
+    const int limit = std::min(g->n_nodes, i + 40);
+    std::vector<qkv_chain> chains;
+    for (int k = i; k < limit && chains.size() < 3; ++k) {
+        const ggml_tensor * t = g->nodes[k];
+        if (t->op != GGML_OP_MUL_MAT || t->src[1] != X) continue;
+        if (!kq(t->src[0]) || !ggml_abi_is_contiguous(t) || st.done[k]) return false;
+        if (c->tp && buffer_is_rowpar(t->src[0]->view_src ? t->src[0]->view_src->buffer : t->src[0]->buffer)) return false;
+        qkv_chain ch;
+        if (!follow_qkv_chain(st, k, limit, ch)) return false;
+        chains.push_back(ch);
+    }
+    if (chains.size() < 2) return false;
+    // every consumer of X must be one of the collected mat-muls (otherwise a fourth sibling would be left behind; fine, but keep it simple)
+    int last = i;
+    std::vector<char> in_set(g->n_nodes, 0);
+    for (auto & ch : chains) for (int k : ch.nodes) { in_set[k] = 1; last = std::max(last, k); }
+    for (int k = i; k <= last; ++k)
+        if (!in_set[k] && !is_view_op(g->nodes[k])) return false;  // an unrelated node sits inside the window: do not reorder around it
+    // rope / store consistency
+    const ggml_tensor * rope0 = nullptr;
+    const ggml_tensor * idx0 = nullptr;
+    for (auto & ch : chains) {
+        if (ch.rope) {
+            const ggml_tensor * r = ch.rope;
+            const int mode = r->op_params[2];
+            if ((mode & GGML_ROPE_TYPE_MROPE) || r->op_params[1] != r->ne[0] || r->ne[2] != 1 || r->ne[3] != 1 || (r->ne[0] % 2) || r->ne[0] > 256) return false;
+            if (r->ne[0] * r->ne[1] != ch.mm->ne[0]) return false;
+            if (rope0 && (memcmp(rope0->op_params, r->op_params, sizeof(r->op_params)) != 0 || rope0->src[1] != r->src[1] || rope0->src[2] != r->src[2] || rope0->ne[0] != r->ne[0])) return false;
+            rope0 = r;
+        }
+        if (ch.store) {
+            if (idx0 && idx0->data != ch.store->src[1]->data) return false;
+            idx0 = ch.store->src[1];
+        }
+    }
+    // at most two distinct weight formats per launch (template pair)
+    int type_a = chains[0].mm->src[0]->type, type_b = type_a;
+    for (auto & ch : chains) {
+        const int t = ch.mm->src[0]->type;
+        if (t == type_a) continue;
+        if (type_b == type_a) type_b = t;
+        else if (t != type_b) return false;
+    }
+    qkv_args a{};
+    a.nseg = (int) chains.size();
+    a.K = (int) X->ne[0];
+    double bytes = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const qkv_chain & ch = chains[s];
+        const ggml_tensor * w = ch.mm->src[0];
+        qkv_seg & sg = a.seg[s];
+        sg.W = (const uint8_t *) w->data;
+        sg.w_nb1 = (int64_t) w->nb[1];
+        sg.alt = (w->type == type_a) ? 0 : 1;
+        sg.N = (int) w->ne[1];
+        sg.bias = ch.bias ? (const float *) ch.bias->data : nullptr;
+        sg.rope = ch.rope ? 1 : 0;
+        sg.store_f16 = ch.store ? 1 : 0;
+        sg.out = ch.store ? (char *) ch.store->data : (char *) ch.out_f32->data;
+        sg.row_stride = ch.store ? (int64_t) ch.store->nb[1] : 0;
+        bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];
+    }
+    a.x = norm ? (const float *) dn->second.x->data : (const float *) X->data;
+    a.norm_w = norm ? (const float *) dn->second.w->data : nullptr;
+    a.eps = norm ? dn->second.eps : 0.0f;
+    if (rope0) {
+        rope_params p;
+        p.n_dims = rope0->op_params[1];
+        p.mode = rope0->op_params[2];
+        p.n_ctx_orig = rope0->op_params[4];
+        p.freq_base = ggml_abi_op_param_f32(rope0, 5);
+        p.freq_scale = ggml_abi_op_param_f32(rope0, 6);
+        p.ext_factor = ggml_abi_op_param_f32(rope0, 7);
+        p.attn_factor = ggml_abi_op_param_f32(rope0, 8);
+        p.beta_fast = ggml_abi_op_param_f32(rope0, 9);
+        p.beta_slow = ggml_abi_op_param_f32(rope0, 10);
+        rope_host_consts(p, a.theta_scale, a.corr0, a.corr1);
+        a.head_dim = (int) rope0->ne[0];
+        a.neox = (p.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0;
+        a.pos = (const int32_t *) rope0->src[1]->data;
+        a.freq_factors = rope0->src[2] ? (const float *) rope0->src[2]->data : nullptr;
+        a.freq_scale = p.freq_scale;
+        a.ext_factor = p.ext_factor;
+        a.attn_factor = p.attn_factor;
+    } else {
+        a.head_dim = 2;
+        a.pos = nullptr;
+    }
+    a.slot = idx0 ? (const int64_t *) idx0->data : nullptr;
+    {
+        timed_scope ts(c, norm ? "qkv_fused_normpro" : "qkv_fused_f32pro", bytes);
+        launch_qkv(c->stream, a, type_a, type_b);
+    }
+    c->st.kernel_launches++;
+    for (auto & ch : chains) for (int k : ch.nodes) { st.done[k] = 1; c->st.fused_nodes++; }
+    return true;
+}
+
 // executes node i (possibly fusing followers); returns number of nodes consumed, or -1 on failure
 static int run_node(exec_state & st, int i) {
     backend_ctx * c = st.c;
@@ -373,6 +545,7 @@ static int run_node(exec_state & st, int i) {
             }
             const bool rowpar = tp_active(c) && buffer_is_rowpar(a->view_src ? a->view_src->buffer : a->buffer);
             const int64_t M = b->ne[1] * b->ne[2] * b->ne[3];
+            if (fuse && !rowpar && M == 1 && try_fuse_qkv(st, i)) return 1;
             if (fuse && !rowpar && M <= c->opt.mmvq_max_cols) {
                 // gate/up/SwiGLU: MUL_MAT(Wg,x) MUL_MAT(Wu,x) GLU(g,u)
                 ggml_tensor * n2 = next(1);
@@ -507,9 +680,10 @@ static bool run_nodes(backend_ctx * c, ggml_cgraph * g, const ws_plan & wp) {
         for (int s = 0; s < GGML_MAX_SRC; ++s)
             if (g->nodes[i]->src[s]) st.uses[g->nodes[i]->src[s]]++;
     c->q8_src = nullptr;  // inputs change between graph launches
+    st.done.assign((size_t) g->n_nodes, 0);
     for (int i = 0; i < g->n_nodes;) {
         ggml_tensor * n = g->nodes[i];
-        if (ggml_abi_nelements(n) == 0) { i++; continue; }
+        if (ggml_abi_nelements(n) == 0 || st.done[i]) { i++; continue; }
         // anything that writes memory invalidates a cached quantisation of that memory
         const int used = run_node(st, i);
         if (used < 0) return false;

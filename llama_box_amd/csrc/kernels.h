@@ -51,6 +51,33 @@ struct mmvq_args {
 };
 void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave);
 
+// ---- fused Q/K/V projection for one token (qkv.hip): up to three K-quant mat-vecs that share their input, with the
+// activation prologue of mmvq (f32 or RMS_NORM*w), optional bias, rotary embedding and the KV-cache store in the epilogue
+struct qkv_seg {
+    const uint8_t * W;
+    int64_t w_nb1;
+    int alt, N;           // alt: 0 = first weight format of the launch, 1 = second
+    const float * bias;   // optional [N]
+    int rope;             // rotate pairs of this segment
+    int store_f16;        // 1: f16 into row `slot` of a cache tensor (out + slot*row_stride), 0: f32 at out
+    char * out;
+    int64_t row_stride;
+};
+struct qkv_args {
+    qkv_seg seg[3];
+    int nseg, K;
+    const float * x;
+    const float * norm_w;  // optional
+    float eps;
+    int head_dim, neox;
+    const int32_t * pos;
+    const float * freq_factors;
+    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
+    const int64_t * slot;
+};
+bool qkv_types_supported(int type_a, int type_b);
+void launch_qkv(hipStream_t s, const qkv_args & a, int type_a, int type_b);
+
 // ---- f16 / f32 weights (K cache, V cache, small dense) (mmf.hip): dst = src0 · src1 with ggml broadcasting;
 // src1 rounded to f16 first when src0 is f16 (ggml-cpu vec_dot_type semantics)
 void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, const tdesc & dst);
@@ -75,6 +102,7 @@ struct rope_params {
     int n_dims, mode, n_ctx_orig;
     float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
 };
+void rope_host_consts(const rope_params & p, float & theta_scale, float & corr0, float & corr1);
 void launch_rope(hipStream_t s, const tdesc & src, const tdesc & pos, const float * freq_factors, const tdesc & dst, const rope_params & p);
 void launch_soft_max(hipStream_t s, const tdesc & src, const tdesc * mask, const float * sinks, const tdesc & dst, float scale, float max_bias);
 

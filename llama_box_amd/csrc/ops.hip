@@ -379,18 +379,8 @@ template <bool F16IO> __global__ void __launch_bounds__(64) k_rope(const tdesc a
         float x0, x1;
         if (F16IO) { x0 = h2f(((const uint16_t *) src)[ia]); x1 = h2f(((const uint16_t *) src)[ib]); }
         else { x0 = ((const float *) src)[ia]; x1 = ((const float *) src)[ib]; }
-        float theta = pos_f;
-        for (int k = 0; k < ip; ++k) theta *= theta_scale;  // the CPU's exact multiply chain
-        const float fq = ff ? ff[ip] : 1.0f;
-        const float theta_extrap = theta / fq;
-        const float theta_interp = p.freq_scale * theta_extrap;
-        float th = theta_interp, mscale = p.attn_factor;
-        if (p.ext_factor != 0.0f) {
-            const float ramp_mix = yarn_ramp(corr0, corr1, 2 * ip) * p.ext_factor;
-            th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
-            mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
-        }
-        const float cs = cosf(th) * mscale, sn = sinf(th) * mscale;
+        float cs, sn;
+        rope_cos_sin(ip, pos_f, ff, rope_consts{theta_scale, p.freq_scale, p.ext_factor, p.attn_factor, corr0, corr1}, cs, sn);
         if (F16IO) {
             ((uint16_t *) dst)[ia] = f2h(x0 * cs - x1 * sn);
             ((uint16_t *) dst)[ib] = f2h(x0 * sn + x1 * cs);
@@ -404,12 +394,16 @@ template <bool F16IO> __global__ void __launch_bounds__(64) k_rope(const tdesc a
         else ((float *) dst)[i0] = ((const float *) src)[i0];
     }
 }
-void launch_rope(hipStream_t s, const tdesc & a, const tdesc & pos, const float * ff, const tdesc & d, const rope_params & p) {
-    const float theta_scale = powf(p.freq_base, -2.0f / (float) p.n_dims);
+void rope_host_consts(const rope_params & p, float & theta_scale, float & c0, float & c1) {
+    theta_scale = powf(p.freq_base, -2.0f / (float) p.n_dims);
     // ggml_rope_yarn_corr_dims
     auto corr_dim = [&](float n_rot) { return (float) p.n_dims * logf((float) p.n_ctx_orig / (n_rot * 2.0f * (float) M_PI)) / (2.0f * logf(p.freq_base)); };
-    const float c0 = fmaxf(0.0f, floorf(corr_dim(p.beta_fast)));
-    const float c1 = fminf((float) (p.n_dims - 1), ceilf(corr_dim(p.beta_slow)));
+    c0 = fmaxf(0.0f, floorf(corr_dim(p.beta_fast)));
+    c1 = fminf((float) (p.n_dims - 1), ceilf(corr_dim(p.beta_slow)));
+}
+void launch_rope(hipStream_t s, const tdesc & a, const tdesc & pos, const float * ff, const tdesc & d, const rope_params & p) {
+    float theta_scale, c0, c1;
+    rope_host_consts(p, theta_scale, c0, c1);
     dim3 grid((unsigned) a.ne[1], (unsigned) a.ne[2], (unsigned) a.ne[3]);
     if (a.type == GGML_TYPE_F16) hipLaunchKernelGGL(k_rope<true>, grid, dim3(64), 0, s, a, pos, ff, d, p, theta_scale, c0, c1);
     else hipLaunchKernelGGL(k_rope<false>, grid, dim3(64), 0, s, a, pos, ff, d, p, theta_scale, c0, c1);
