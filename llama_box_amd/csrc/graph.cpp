@@ -410,6 +410,9 @@ static bool try_fuse_qkv(exec_state & st, int i) {
         chains.push_back(ch);
     }
     if (chains.size() < 2) return false;
+    bool attn = false;  // only attention projections (something rotates or lands in the KV cache); gate/up siblings have their own fusion
+    for (auto & ch : chains) attn = attn || ch.rope || ch.store;
+    if (!attn) return false;
     // every consumer of X must be one of the collected mat-muls (otherwise a fourth sibling would be left behind; fine, but keep it simple)
     int last = i;
     std::vector<char> in_set(g->n_nodes, 0);

@@ -193,6 +193,7 @@ struct T_Q80 {
     typedef q80_dev act;
     static constexpr int BLK = 32, BYTES = 34, PPB = 1;
     struct raw { uint32_t q[8]; uint16_t d; };
+    static constexpr int DW = 9;
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
         const uint8_t * blk = row + (size_t) p * BYTES;
         raw r;

@@ -739,7 +739,9 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     const int n_out_graph = std::max(1, n_outputs);
 
     graph_key key{n_tokens, n_kv, n_out_graph};
+    bool rebuilt = false;
     if (!(c->p.graph_reuse && key == c->key && c->gf)) {
+        rebuilt = true;
         build_graph(c, n_tokens, n_kv, n_out_graph);
         if (!ggml_gallocr_alloc_graph(c->galloc, c->gf)) return -2;
         c->key = key;
@@ -762,10 +764,13 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     }
     if (c->inp_out_ids) ggml_backend_tensor_set(c->inp_out_ids, out_ids.data(), 0, (size_t) n_out_graph * 4);
     {
+        // rows beyond n_tokens are padding (GGML_KQ_MASK_PAD) that no kernel reads: they are written once when the
+        // graph is (re)built and skipped on re-use, which keeps the per-step upload at n_tokens * n_kv entries
         const int64_t n_tok_pad = c->inp_mask->ne[1];
+        const int64_t rows = rebuilt ? n_tok_pad : n_tokens;
         const uint16_t NEG_INF_H = 0xFC00;
         if (fa) {
-            std::vector<uint16_t> mask((size_t) n_kv * n_tok_pad, NEG_INF_H);
+            std::vector<uint16_t> mask((size_t) n_kv * rows, NEG_INF_H);
             for (int i = 0; i < n_tokens; ++i) {
                 const int s = seq_id ? seq_id[i] : 0;
                 for (int j = 0; j < n_kv; ++j)
@@ -773,7 +778,7 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
             }
             ggml_backend_tensor_set(c->inp_mask, mask.data(), 0, mask.size() * 2);
         } else {
-            std::vector<float> mask((size_t) n_kv * n_tok_pad, -INFINITY);
+            std::vector<float> mask((size_t) n_kv * rows, -INFINITY);
             for (int i = 0; i < n_tokens; ++i) {
                 const int s = seq_id ? seq_id[i] : 0;
                 for (int j = 0; j < n_kv; ++j)

@@ -28,6 +28,8 @@ def both(build, backend):
 MM_SHAPES = [  # (K, N, M)
     (256, 8, 1), (512, 33, 1), (4096, 64, 1), (4096, 257, 1), (14336, 16, 1), (2048, 40, 1),
     (1024, 48, 2), (1024, 48, 3), (512, 64, 4), (512, 20, 5), (768, 32, 8), (512, 24, 9), (512, 16, 19),
+    # M >= 9 takes the MFMA path (mmq.hip) for K-quants: full tiles, ragged rows/columns, several super-blocks
+    (512, 128, 128), (1024, 200, 300), (4096, 256, 160), (256, 130, 33), (2048, 384, 512),
 ]
 
 
