@@ -197,9 +197,9 @@ template <typename T, bool GLU, int PRO>
 __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::act act;
-    // pairs per item: ~32 dwords of weights per lane per matrix (16 for the two-matrix GLU form); with the next item
-    // prefetched that is 8 KiB (4 KiB) per wave = 128 KiB per CU in flight, what a ~4 us loaded HBM latency needs
-    constexpr int WAVES = 16, NT = 1024, UB = (GLU ? 16 : 32) / T::DW, U = UB < 1 ? 1 : (UB > 4 ? 4 : UB);
+    // pairs per item: ~16 dwords of weights per lane per matrix (8 for the two-matrix GLU form).  Measured on MI355X:
+    // doubling this (128 KiB per CU in flight) made every variant 5-25 % SLOWER — the launch is not in-flight-bound
+    constexpr int WAVES = 16, NT = 1024, UB = (GLU ? 8 : 16) / T::DW, U = UB < 1 ? 1 : (UB > 4 ? 4 : UB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = a.K / T::BLK;
     const int npairs = nblk * T::PPB;
