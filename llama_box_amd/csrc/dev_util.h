@@ -8,20 +8,63 @@ namespace mi355x {
 
 #define MI_WAVE 64
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- wave64 reductions on the DPP data path (no LDS crossbar): the profile showed every __shfl_xor lowered to
+// ds_bpermute_b32 (~100+ cycles each, 6 in a dependent chain per row); DPP row rotates cost a few cycles.
+// Pattern: all-reduce inside each row of 16 lanes with row_ror 8/4/2/1, then combine the four rows through SGPRs.
+template <int CTRL> __device__ __forceinline__ float dpp_f32(const float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i32(const int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(const double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) (u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+#define MI_DPP_ROR8 0x128
+#define MI_DPP_ROR4 0x124
+#define MI_DPP_ROR2 0x122
+#define MI_DPP_ROR1 0x121
+#define MI_DPP_QUAD_XOR1 0xB1  /* quad_perm [1,0,3,2] */
+#define MI_DPP_QUAD_XOR2 0x4E  /* quad_perm [2,3,0,1] */
+#define MI_DPP_HALF_MIRROR 0x141
+
+__device__ __forceinline__ float readlane_f32(const float v, const int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// sum over the 16 lanes of each DPP row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<MI_DPP_ROR8>(v);
+    v += dpp_f32<MI_DPP_ROR4>(v);
+    v += dpp_f32<MI_DPP_ROR2>(v);
+    v += dpp_f32<MI_DPP_ROR1>(v);
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return ((readlane_f32(v, 0) + readlane_f32(v, 16)) + readlane_f32(v, 32)) + readlane_f32(v, 48);
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_f64<MI_DPP_ROR8>(v);
+    v += dpp_f64<MI_DPP_ROR4>(v);
+    v += dpp_f64<MI_DPP_ROR2>(v);
+    v += dpp_f64<MI_DPP_ROR1>(v);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    double r[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) u, 16 * i);
+        const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (u >> 32), 16 * i);
+        r[i] = __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+    }
+    return ((r[0] + r[1]) + r[2]) + r[3];
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<MI_DPP_ROR8>(v));
+    v = fmaxf(v, dpp_f32<MI_DPP_ROR4>(v));
+    v = fmaxf(v, dpp_f32<MI_DPP_ROR2>(v));
+    v = fmaxf(v, dpp_f32<MI_DPP_ROR1>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
 }
 
 // IEEE binary16 <-> f32, round-to-nearest-even (v_cvt_f16_f32 / v_cvt_f32_f16), bit-identical to the CPU path
@@ -52,24 +95,21 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x));
 // arg-max of |x| defines the sign of the scale, iscale = -127/max, round-half-even, clamp to 127, 16-value bsums).
 // v[0..3] are the lane's four consecutive values; y may point to LDS or global memory.
 template <typename Q8K> __device__ __forceinline__ void wave_quantize_q8_K(const float (&v)[4], const int lane, Q8K * y) {
-    float amax = 0.0f, mx = 0.0f;
-    int idx = lane * 4;
+    // lane-local: largest |x| and the FIRST element attaining it (the CPU scans with a strict `ax > amax`)
+    float amax_l = 0.0f, mx_l = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float ax = fabsf(v[k]);
-        if (ax > amax) { amax = ax; mx = v[k]; idx = lane * 4 + k; }
+        if (ax > amax_l) { amax_l = ax; mx_l = v[k]; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float oa = __shfl_xor(amax, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        const float om = __shfl_xor(mx, o, 64);
-        const bool take = oa > amax || (oa == amax && oi < idx);
-        if (take) { amax = oa; idx = oi; mx = om; }
-    }
+    const float amax = wave_max(amax_l);
     int q[4] = {0, 0, 0, 0};
     float iscale = 0.0f;
     if (amax != 0.0f) {
+        // lanes hold consecutive groups of four values, so the lowest lane attaining amax holds the first index
+        const unsigned long long hit = __ballot(amax_l == amax);
+        const int first = __ffsll((long long) hit) - 1;
+        const float mx = readlane_f32(mx_l, first);
         iscale = -127.f / mx;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -80,8 +120,8 @@ template <typename Q8K> __device__ __forceinline__ void wave_quantize_q8_K(const
     const uint32_t packed = (uint32_t) (q[0] & 0xFF) | ((uint32_t) (q[1] & 0xFF) << 8) | ((uint32_t) (q[2] & 0xFF) << 16) | ((uint32_t) (q[3] & 0xFF) << 24);
     ((uint32_t *) y->qs)[lane] = packed;
     int s = q[0] + q[1] + q[2] + q[3];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+    s += dpp_i32<MI_DPP_QUAD_XOR1>(s);
+    s += dpp_i32<MI_DPP_QUAD_XOR2>(s);
     if ((lane & 3) == 0) y->bsums[lane >> 2] = (int16_t) s;
     if (lane == 0) {
         y->d = amax != 0.0f ? 1.0f / iscale : 0.0f;

@@ -90,10 +90,16 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
                 for (int i = 0; i < 8; ++i) t = fmaf(kf[i], qr[g][i], t);
                 sc[g] = t;
             }
+            // finish the D-wide dot inside the LPR lanes of the row on the DPP path (LPR = 16: one DPP row; LPR = 8: half a row)
 #pragma unroll
-            for (int o = LPR >> 1; o > 0; o >>= 1) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) sc[g] += __shfl_xor(sc[g], o, 64);
+            for (int g = 0; g < G; ++g) {
+                if constexpr (LPR == 16) {
+                    sc[g] = row16_sum(sc[g]);
+                } else {
+                    sc[g] += dpp_f32<MI_DPP_QUAD_XOR1>(sc[g]);
+                    sc[g] += dpp_f32<MI_DPP_QUAD_XOR2>(sc[g]);
+                    sc[g] += dpp_f32<MI_DPP_HALF_MIRROR>(sc[g]);
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
