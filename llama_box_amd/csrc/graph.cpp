@@ -436,36 +436,12 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             idx0 = ch.store->src[1];
         }
     }
-    // at most two distinct weight formats per launch (template pair)
-    int type_a = chains[0].mm->src[0]->type, type_b = type_a;
-    for (auto & ch : chains) {
-        const int t = ch.mm->src[0]->type;
-        if (t == type_a) continue;
-        if (type_b == type_a) type_b = t;
-        else if (t != type_b) return false;
-    }
-    qkv_args a{};
-    a.nseg = (int) chains.size();
-    a.K = (int) X->ne[0];
-    double bytes = 0;
-    for (int s = 0; s < a.nseg; ++s) {
-        const qkv_chain & ch = chains[s];
-        const ggml_tensor * w = ch.mm->src[0];
-        qkv_seg & sg = a.seg[s];
-        sg.W = (const uint8_t *) w->data;
-        sg.w_nb1 = (int64_t) w->nb[1];
-        sg.alt = (w->type == type_a) ? 0 : 1;
-        sg.N = (int) w->ne[1];
-        sg.bias = ch.bias ? (const float *) ch.bias->data : nullptr;
-        sg.rope = ch.rope ? 1 : 0;
-        sg.store_f16 = ch.store ? 1 : 0;
-        sg.out = ch.store ? (char *) ch.store->data : (char *) ch.out_f32->data;
-        sg.row_stride = ch.store ? (int64_t) ch.store->nb[1] : 0;
-        bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];
-    }
-    a.x = norm ? (const float *) dn->second.x->data : (const float *) X->data;
-    a.norm_w = norm ? (const float *) dn->second.w->data : nullptr;
-    a.eps = norm ? dn->second.eps : 0.0f;
+    // rope parameters shared by every launch of this group
+    qkv_args base{};
+    base.K = (int) X->ne[0];
+    base.x = norm ? (const float *) dn->second.x->data : (const float *) X->data;
+    base.norm_w = norm ? (const float *) dn->second.w->data : nullptr;
+    base.eps = norm ? dn->second.eps : 0.0f;
     if (rope0) {
         rope_params p;
         p.n_dims = rope0->op_params[1];
@@ -477,24 +453,50 @@ static bool try_fuse_qkv(exec_state & st, int i) {
         p.attn_factor = ggml_abi_op_param_f32(rope0, 8);
         p.beta_fast = ggml_abi_op_param_f32(rope0, 9);
         p.beta_slow = ggml_abi_op_param_f32(rope0, 10);
-        rope_host_consts(p, a.theta_scale, a.corr0, a.corr1);
-        a.head_dim = (int) rope0->ne[0];
-        a.neox = (p.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0;
-        a.pos = (const int32_t *) rope0->src[1]->data;
-        a.freq_factors = rope0->src[2] ? (const float *) rope0->src[2]->data : nullptr;
-        a.freq_scale = p.freq_scale;
-        a.ext_factor = p.ext_factor;
-        a.attn_factor = p.attn_factor;
+        rope_host_consts(p, base.theta_scale, base.corr0, base.corr1);
+        base.head_dim = (int) rope0->ne[0];
+        base.neox = (p.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0;
+        base.pos = (const int32_t *) rope0->src[1]->data;
+        base.freq_factors = rope0->src[2] ? (const float *) rope0->src[2]->data : nullptr;
+        base.freq_scale = p.freq_scale;
+        base.ext_factor = p.ext_factor;
+        base.attn_factor = p.attn_factor;
     } else {
-        a.head_dim = 2;
-        a.pos = nullptr;
+        base.head_dim = 2;
+        base.pos = nullptr;
     }
-    a.slot = idx0 ? (const int64_t *) idx0->data : nullptr;
-    {
-        timed_scope ts(c, norm ? "qkv_fused_normpro" : "qkv_fused_f32pro", bytes);
-        launch_qkv(c->stream, a, type_a, type_b);
+    base.slot = idx0 ? (const int64_t *) idx0->data : nullptr;
+    // one launch per weight format (Q4_K_M: {wq, wk} Q4_K and, in the "more bits" layers, {wv} Q6_K)
+    std::vector<char> launched(chains.size(), 0);
+    for (size_t first = 0; first < chains.size(); ++first) {
+        if (launched[first]) continue;
+        const int type = chains[first].mm->src[0]->type;
+        qkv_args a = base;
+        a.nseg = 0;
+        double bytes = 0;
+        for (size_t s = first; s < chains.size(); ++s) {
+            const qkv_chain & ch = chains[s];
+            const ggml_tensor * w = ch.mm->src[0];
+            if (launched[s] || w->type != type) continue;
+            launched[s] = 1;
+            qkv_seg & sg = a.seg[a.nseg++];
+            sg.W = (const uint8_t *) w->data;
+            sg.w_nb1 = (int64_t) w->nb[1];
+            sg.alt = 0;
+            sg.N = (int) w->ne[1];
+            sg.bias = ch.bias ? (const float *) ch.bias->data : nullptr;
+            sg.rope = ch.rope ? 1 : 0;
+            sg.store_f16 = ch.store ? 1 : 0;
+            sg.out = ch.store ? (char *) ch.store->data : (char *) ch.out_f32->data;
+            sg.row_stride = ch.store ? (int64_t) ch.store->nb[1] : 0;
+            bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];
+        }
+        char cls[64];
+        snprintf(cls, sizeof(cls), "qkv_fused_%s_%s", type_tag(type), norm ? "normpro" : "f32pro");
+        timed_scope ts(c, cls, bytes);
+        launch_qkv(c->stream, a, type, type);
+        c->st.kernel_launches++;
     }
-    c->st.kernel_launches++;
     for (auto & ch : chains) for (int k : ch.nodes) { st.done[k] = 1; c->st.fused_nodes++; }
     return true;
 }

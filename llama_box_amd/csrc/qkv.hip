@@ -17,44 +17,51 @@
 namespace mi355x {
 
 // pairs a lane holds per row and trip: sized so that K = 4096 is ONE trip per row for every format
-template <typename T> struct qkv_u { static constexpr int U = T::PPB == 16 ? 4 : (T::DW > 8 ? 1 : 2); static constexpr int DW = U * T::DW; };
+template <typename T> struct qkv_u { static constexpr int U = T::DW > 8 ? 1 : 2; static constexpr int DW = U * T::DW; };
 
-template <typename T> __device__ __forceinline__ void chunk_load(const uint8_t * __restrict__ row, const int c, const int lane, const int npairs, uint32_t * d) {
+// the weight registers of one unit (two rows) of format T: statically indexed, so they stay in VGPRs
+template <typename T> struct qkv_regs { typename T::raw w[2][qkv_u<T>::U]; };
+template <typename T> __device__ __forceinline__ void qkv_load(const uint8_t * __restrict__ row0, const uint8_t * __restrict__ row1, const int c, const int lane,
+                                                               const int npairs, qkv_regs<T> & r) {
     constexpr int U = qkv_u<T>::U;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int p = (c * U + u) * 64 + lane;
         if (p < npairs) {
-            const typename T::raw r = T::load(row, p);
-            T::pack(r, d + u * T::DW);
+            r.w[0][u] = T::load(row0, p);
+            r.w[1][u] = T::load(row1, p);
         }
     }
 }
-template <typename T> __device__ __forceinline__ void chunk_dot(const uint32_t * d, const int c, const int lane, const int npairs, const q8k_dev * __restrict__ y, const int nblk, float & acc) {
+template <typename T> __device__ __forceinline__ void qkv_dot(const qkv_regs<T> & r, const int c, const int lane, const int npairs, const q8k_dev * __restrict__ y,
+                                                              const int nblk, float & acc0, float & acc1) {
     constexpr int U = qkv_u<T>::U;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int p = (c * U + u) * 64 + lane;
         if (p < npairs) {
-            const typename T::raw r = T::unpack(d + u * T::DW);
-            T::template dot<1>(r, p, y, nblk, &acc);
+            T::template dot<1>(r.w[0][u], p, y, nblk, &acc0);
+            T::template dot<1>(r.w[1][u], p, y, nblk, &acc1);
         }
     }
 }
+// all trips of one unit; trip 0 is already in `r`
+template <typename T> __device__ __forceinline__ void qkv_unit(qkv_regs<T> & r, const uint8_t * row0, const uint8_t * row1, const int lane, const int nblk,
+                                                               const q8k_dev * __restrict__ y, float & acc0, float & acc1) {
+    const int npairs = nblk * T::PPB;
+    constexpr int per_chunk = 64 * qkv_u<T>::U;
+    const int nch = (npairs + per_chunk - 1) / per_chunk;
+    for (int c = 0; c < nch; ++c) {
+        if (c > 0) qkv_load<T>(row0, row1, c, lane, npairs, r);
+        qkv_dot<T>(r, c, lane, npairs, y, nblk, acc0, acc1);
+    }
+}
 
-// TA: weight format of the segments flagged alt == 0, TB: of those flagged alt == 1 (Q4_K_M: wq/wk Q4_K, wv Q6_K in the
-// "more bits" layers).  The branch on sg.alt is wave-uniform.
-template <typename TA, typename TB>
+// One weight format per launch (a second format — Q4_K_M keeps wv in Q6_K in its "more bits" layers — gets its own
+// launch from graph.cpp): holding register sets for two formats at once spilled, and spilled weight registers go
+// through scratch memory, which cost 15 us per layer in the first version of this kernel.
+template <typename T>
 __global__ void __launch_bounds__(1024) k_qkv_stream(const qkv_args a) {
-    constexpr int BUF_DW = qkv_u<TA>::DW > qkv_u<TB>::DW ? qkv_u<TA>::DW : qkv_u<TB>::DW;
-    auto load_any = [](const int alt, const uint8_t * row, const int c, const int lane, const int npairs, uint32_t * d) {
-        if (alt) chunk_load<TB>(row, c, lane, npairs, d); else chunk_load<TA>(row, c, lane, npairs, d);
-    };
-    auto dot_any = [](const int alt, const uint32_t * d, const int c, const int lane, const int npairs, const q8k_dev * y, const int nblk, float & acc) {
-        if (alt) chunk_dot<TB>(d, c, lane, npairs, y, nblk, acc); else chunk_dot<TA>(d, c, lane, npairs, y, nblk, acc);
-    };
-    auto type_ppb = [](const int alt) { return alt ? (int) TB::PPB : (int) TA::PPB; };
-    auto type_pairs_per_chunk = [](const int alt) { return 64 * (alt ? (int) qkv_u<TB>::U : (int) qkv_u<TA>::U); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WAVES = 16, QB = 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,13 +93,10 @@ __global__ void __launch_bounds__(1024) k_qkv_stream(const qkv_args a) {
             r1 = r0 + 1;
         }
     };
-    uint32_t buf[2][BUF_DW];
-    int npairs = 0;
+    qkv_regs<T> ra;
     if (have) {
         locate();
-        npairs = nblk * type_ppb(sg.alt);
-        load_any(sg.alt, sg.W + (size_t) r0 * sg.w_nb1, 0, lane, npairs, buf[0]);
-        load_any(sg.alt, sg.W + (size_t) r1 * sg.w_nb1, 0, lane, npairs, buf[1]);
+        qkv_load<T>(sg.W + (size_t) r0 * sg.w_nb1, sg.W + (size_t) r1 * sg.w_nb1, 0, lane, nblk * T::PPB, ra);
     }
 
     // ---- prologue A: rotary table for this token (threads 0 .. head_dim/2-1)
@@ -156,17 +160,10 @@ __global__ void __launch_bounds__(1024) k_qkv_stream(const qkv_args a) {
     const int64_t slot = a.slot ? a.slot[0] : 0;
     while (have) {
         float acc0 = 0.0f, acc1 = 0.0f;
-        const int per_chunk = type_pairs_per_chunk(sg.alt);
-        const int nch = (npairs + per_chunk - 1) / per_chunk;
-        const uint8_t * row0 = sg.W + (size_t) r0 * sg.w_nb1;
-        const uint8_t * row1 = sg.W + (size_t) r1 * sg.w_nb1;
-        for (int c = 0; c < nch; ++c) {
-            if (c > 0) {
-                load_any(sg.alt, row0, c, lane, npairs, buf[0]);
-                load_any(sg.alt, row1, c, lane, npairs, buf[1]);
-            }
-            dot_any(sg.alt, buf[0], c, lane, npairs, yl, nblk, acc0);
-            dot_any(sg.alt, buf[1], c, lane, npairs, yl, nblk, acc1);
+        {
+            const uint8_t * row0 = sg.W + (size_t) r0 * sg.w_nb1;
+            const uint8_t * row1 = sg.W + (size_t) r1 * sg.w_nb1;
+            qkv_unit<T>(ra, row0, row1, lane, nblk, yl, acc0, acc1);
         }
         float v0 = wave_sum(acc0), v1 = wave_sum(acc1);
         if (lane == 0) {
@@ -195,15 +192,9 @@ __global__ void __launch_bounds__(1024) k_qkv_stream(const qkv_args a) {
         have = u < UT;
         if (have) {
             locate();
-            npairs = nblk * type_ppb(sg.alt);
-            load_any(sg.alt, sg.W + (size_t) r0 * sg.w_nb1, 0, lane, npairs, buf[0]);
-            load_any(sg.alt, sg.W + (size_t) r1 * sg.w_nb1, 0, lane, npairs, buf[1]);
+            qkv_load<T>(sg.W + (size_t) r0 * sg.w_nb1, sg.W + (size_t) r1 * sg.w_nb1, 0, lane, nblk * T::PPB, ra);
         }
     }
-}
-
-template <typename TA, typename TB> static void launch_qkv_t(hipStream_t s, const qkv_args & a, unsigned grid, size_t lds) {
-    hipLaunchKernelGGL((k_qkv_stream<TA, TB>), dim3(grid), dim3(1024), lds, s, a);
 }
 
 bool qkv_types_supported(int ta, int tb) {
@@ -211,20 +202,17 @@ bool qkv_types_supported(int ta, int tb) {
     return ok(ta) && ok(tb);
 }
 
-// a.seg[i].alt selects the second format; the caller guarantees at most two distinct formats among the segments
-void launch_qkv(hipStream_t s, const qkv_args & a, int type_a, int type_b) {
+// all segments of `a` share the weight format `type`
+void launch_qkv(hipStream_t s, const qkv_args & a, int type, int) {
     const int nblk = a.K / 256;
     int units = 0;
     for (int i = 0; i < a.nseg; ++i) units += a.seg[i].N / 2;
     const size_t lds = (size_t) nblk * sizeof(q8k_dev) + 16 * sizeof(double) + (size_t) a.head_dim * sizeof(float) + 16;
     const unsigned grid = (unsigned) std::min(256, (units + 15) / 16);
-#define QKV_CASE(A, TA_, B, TB_) if (type_a == A && type_b == B) { launch_qkv_t<TA_, TB_>(s, a, grid, lds); return; }
-    QKV_CASE(GGML_TYPE_Q4_K, T_Q4K, GGML_TYPE_Q4_K, T_Q4K) QKV_CASE(GGML_TYPE_Q4_K, T_Q4K, GGML_TYPE_Q5_K, T_Q5K) QKV_CASE(GGML_TYPE_Q4_K, T_Q4K, GGML_TYPE_Q6_K, T_Q6K)
-    QKV_CASE(GGML_TYPE_Q5_K, T_Q5K, GGML_TYPE_Q4_K, T_Q4K) QKV_CASE(GGML_TYPE_Q5_K, T_Q5K, GGML_TYPE_Q5_K, T_Q5K) QKV_CASE(GGML_TYPE_Q5_K, T_Q5K, GGML_TYPE_Q6_K, T_Q6K)
-    QKV_CASE(GGML_TYPE_Q6_K, T_Q6K, GGML_TYPE_Q4_K, T_Q4K) QKV_CASE(GGML_TYPE_Q6_K, T_Q6K, GGML_TYPE_Q5_K, T_Q5K) QKV_CASE(GGML_TYPE_Q6_K, T_Q6K, GGML_TYPE_Q6_K, T_Q6K)
-#undef QKV_CASE
-    MI_ERR("launch_qkv: unsupported weight formats %d/%d", type_a, type_b);
-    abort();
+    if (type == GGML_TYPE_Q4_K) hipLaunchKernelGGL(k_qkv_stream<T_Q4K>, dim3(grid), dim3(1024), lds, s, a);
+    else if (type == GGML_TYPE_Q5_K) hipLaunchKernelGGL(k_qkv_stream<T_Q5K>, dim3(grid), dim3(1024), lds, s, a);
+    else if (type == GGML_TYPE_Q6_K) hipLaunchKernelGGL(k_qkv_stream<T_Q6K>, dim3(grid), dim3(1024), lds, s, a);
+    else { MI_ERR("launch_qkv: unsupported weight format %d", type); abort(); }
 }
 
 }  // namespace mi355x
