@@ -258,6 +258,8 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->opt.graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->opt.fusion = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_PROLOGUE")) c->opt.prologue = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_QKV")) c->opt.qkv = atoi(e) != 0;
     return new ggml_backend{&g_guid, k_backend_iface, dev, c};
 }
 static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &dctx(dev)->buft; }
@@ -309,6 +311,8 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     const int v = atoi(value);
     if (k == "graphs") c->opt.graphs = v != 0;
     else if (k == "fusion") c->opt.fusion = v != 0;
+    else if (k == "prologue") c->opt.prologue = v != 0;
+    else if (k == "qkv") c->opt.qkv = v != 0;
     else if (k == "mmvq_max_cols") c->opt.mmvq_max_cols = v;
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "timing") c->opt.timing = v != 0;

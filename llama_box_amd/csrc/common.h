@@ -59,6 +59,8 @@ struct backend_ctx;
 struct options {
     bool graphs = true;        // hipGraph capture + replay of repeated graphs
     bool fusion = true;        // node fusion (norm+mul, mul_mat+add, ...)
+    bool prologue = true;      // fold RMS_NORM / activation quantisation into the mat-vec prologue
+    bool qkv = true;           // fused Q/K/V + rope + cache store launch
     int mmvq_max_cols = 8;     // widest batch handled by the bandwidth-bound matvec kernels
     int fa_splits = 0;         // 0 = auto
     bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)

@@ -55,16 +55,15 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
     const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
     const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
 
-    // NG independent row groups per trip: their K/V loads are all issued before any use, so a trip costs one memory
-    // round trip; with the default split length (64 positions) a workgroup needs exactly one trip
-    constexpr int NG = 4;
-    for (int p0 = kv0 + wave * RPW; p0 < kv1; p0 += NG * 4 * RPW) {
-        int pp[NG];
-        bool inr[NG];
-        float mv[NG];
-        uint4 kraw[NG], vraw[NG];
+    // two independent row groups per trip (A, B): their K/V loads are all issued before any use, so one trip costs
+    // one memory round trip instead of two
+    for (int p0 = kv0 + wave * RPW; p0 < kv1; p0 += 8 * RPW) {
+        int pp[2];
+        bool inr[2];
+        float mv[2];
+        uint4 kraw[2], vraw[2];
 #pragma unroll
-        for (int u = 0; u < NG; ++u) {
+        for (int u = 0; u < 2; ++u) {
             pp[u] = p0 + u * 4 * RPW + sub;
             inr[u] = pp[u] < kv1;
             const int pc = inr[u] ? pp[u] : kv1 - 1;
@@ -73,7 +72,7 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
             vraw[u] = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);
         }
 #pragma unroll
-        for (int u = 0; u < NG; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
             float kf[8], vf[8];
 #pragma unroll

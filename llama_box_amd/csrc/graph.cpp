@@ -215,7 +215,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const bool kquant = w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K;
     auto dn = st.deferred.find(b);
     const bool pro_norm = dn != st.deferred.end();
-    const bool pro_f32 = !pro_norm && c->opt.fusion && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
+    const bool pro_f32 = !pro_norm && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
     if (pro_norm || pro_f32) {
         mmvq_args a{};
         a.W = (const uint8_t *) w->data;
@@ -522,7 +522,7 @@ static int run_node(exec_state & st, int i) {
             if (fuse && m && m->op == GGML_OP_MUL && single_use(st, n) && m->type == GGML_TYPE_F32 && m->nb[0] == 4) {
                 const ggml_tensor * w = m->src[0] == n ? m->src[1] : (m->src[1] == n ? m->src[0] : nullptr);
                 if (w && w->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(w) && w->ne[0] == n->ne[0] && ggml_abi_nelements(w) == w->ne[0] && same_shape(m, n)) {
-                    if (can_defer_norm(st, i, n, m, a, w)) {
+                    if (c->opt.prologue && can_defer_norm(st, i, n, m, a, w)) {
                         st.deferred[m] = {a, w, ggml_abi_op_param_f32(n, 0)};
                         c->st.fused_nodes += 2;
                         return 2;
@@ -550,7 +550,7 @@ static int run_node(exec_state & st, int i) {
             }
             const bool rowpar = tp_active(c) && buffer_is_rowpar(a->view_src ? a->view_src->buffer : a->buffer);
             const int64_t M = b->ne[1] * b->ne[2] * b->ne[3];
-            if (fuse && !rowpar && M == 1 && try_fuse_qkv(st, i)) return 1;
+            if (fuse && c->opt.qkv && !rowpar && M == 1 && try_fuse_qkv(st, i)) return 1;
             if (fuse && !rowpar && M <= c->opt.mmvq_max_cols) {
                 // gate/up/SwiGLU: MUL_MAT(Wg,x) MUL_MAT(Wu,x) GLU(g,u)
                 ggml_tensor * n2 = next(1);

@@ -147,31 +147,15 @@ struct T_Q6K {
         r.ql0 = d[0]; r.ql1 = d[1]; r.qh = d[2]; r.s0 = d[3]; r.s1 = d[4]; r.d = (uint16_t) d[5];
         return r;
     }
-    // Q6_K blocks are 210 B: every odd block starts 2 bytes off a dword.  Misaligned dword loads are the slow path
-    // of the memory pipe (they were ~2x slower per byte than Q4_K in round-1 profiles), so each field is fetched as
-    // dword-aligned 8 / 12 bytes and shifted into place with v_alignbit (shift = 0 or 16 bits).
-    static __device__ __forceinline__ uint32_t ld32_shifted(const uint8_t * p) {
-        const uint32_t off = (uint32_t) ((uintptr_t) p & 2);  // 0 or 2 (block starts are 2-byte aligned)
-        const uint32_t * q = (const uint32_t *) (p - off);      // pointer arithmetic keeps the global address space
-        const uint32_t lo = q[0], hi = q[1];
-        return __builtin_amdgcn_alignbit(hi, lo, off * 8);
-    }
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
         const uint8_t * blk = row + (size_t) (p >> 4) * BYTES;
         const int h = (p >> 3) & 1, t = p & 7;
         raw r;
-        r.ql0 = ld32_shifted(blk + 64 * h + 4 * t);
-        r.ql1 = ld32_shifted(blk + 64 * h + 32 + 4 * t);
-        r.qh = ld32_shifted(blk + 128 + 32 * h + 4 * t);
-        {
-            const uint8_t * ps = blk + 192 + 8 * h;
-            const uint32_t off = (uint32_t) ((uintptr_t) ps & 2);
-            const uint32_t * q = (const uint32_t *) (ps - off);
-            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
-            const uint32_t sh = off * 8;
-            r.s0 = __builtin_amdgcn_alignbit(w1, w0, sh);
-            r.s1 = __builtin_amdgcn_alignbit(w2, w1, sh);
-        }
+        r.ql0 = ld32_a2(blk + 64 * h + 4 * t);
+        r.ql1 = ld32_a2(blk + 64 * h + 32 + 4 * t);
+        r.qh = ld32_a2(blk + 128 + 32 * h + 4 * t);
+        r.s0 = ld32_a2(blk + 192 + 8 * h);
+        r.s1 = ld32_a2(blk + 196 + 8 * h);
         r.d = ld16(blk + 208);
         return r;
     }
