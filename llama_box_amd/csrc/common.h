@@ -42,11 +42,12 @@ int log_level();
 // qs | bsums | d) — produced by quantize kernels, consumed by the K-quant matvec / GEMM kernels
 struct q8k_dev {
     int8_t qs[256];
-    int16_t bsums[16];
+    int16_t bsums[16];  // block_q8_K.bsums: sums over 16 values
+    int16_t bs32[8];    // sums over 32 values (what the Q4_K/Q5_K mins term needs per sub-block)
     float d;
     float pad[3];
 };
-static_assert(sizeof(q8k_dev) == 304, "q8k_dev");
+static_assert(sizeof(q8k_dev) == 320, "q8k_dev");
 // Q8_0-quantised activation block for Q8_0 weights: d already rounded through fp16 (as block_q8_0.d is)
 struct q80_dev {
     int8_t qs[32];

@@ -123,6 +123,8 @@ template <typename Q8K> __device__ __forceinline__ void wave_quantize_q8_K(const
     s += dpp_i32<MI_DPP_QUAD_XOR1>(s);
     s += dpp_i32<MI_DPP_QUAD_XOR2>(s);
     if ((lane & 3) == 0) y->bsums[lane >> 2] = (int16_t) s;
+    const int s32 = s + dpp_i32<MI_DPP_HALF_MIRROR>(s);  // every lane of a quad holds the quad sum: add the other quad of the 8-lane group
+    if ((lane & 7) == 0) y->bs32[lane >> 3] = (int16_t) s32;
     if (lane == 0) {
         y->d = amax != 0.0f ? 1.0f / iscale : 0.0f;
         y->pad[0] = y->pad[1] = y->pad[2] = 0.0f;

@@ -26,49 +26,46 @@ __device__ __forceinline__ void k4_scale_pair(uint32_t hy, uint32_t hz, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------ Q4_K
+// 4 lanes per super-block: lane j owns the 32 qs bytes of 64-value group j (low nibbles = sub-block 2j, high = 2j+1).
+// Round-1 ISA count: with 16 bytes per lane the loop spent ~94 VALU instructions per 16 B of weights (scale unpacking
+// and predication repeated per lane), enough to make the 66 MB gate/up launch ALU-limited; 32 B per lane amortises the
+// header work over twice the bytes and K = 4096 becomes exactly one 64-lane trip per row.
 struct T_Q4K {
     typedef q8k_dev act;
-    static constexpr int BLK = 256, BYTES = 144, PPB = 8;  // pairs (lanes) per block
-    struct raw { uint4 hdr, q; };
-    static constexpr int DW = 8;
-    static __device__ __forceinline__ void pack(const raw & r, uint32_t * d) {
-        d[0] = r.hdr.x; d[1] = r.hdr.y; d[2] = r.hdr.z; d[3] = r.hdr.w; d[4] = r.q.x; d[5] = r.q.y; d[6] = r.q.z; d[7] = r.q.w;
-    }
-    static __device__ __forceinline__ raw unpack(const uint32_t * d) {
-        raw r;
-        r.hdr = make_uint4(d[0], d[1], d[2], d[3]);
-        r.q = make_uint4(d[4], d[5], d[6], d[7]);
-        return r;
-    }
+    static constexpr int BLK = 256, BYTES = 144, PPB = 4;
+    struct raw { uint4 hdr, q0, q1; };
+    static constexpr int DW = 12;
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
-        const uint8_t * blk = row + (size_t) (p >> 3) * BYTES;
+        const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         raw r;
         r.hdr = *(const uint4 *) blk;
-        r.q = *(const uint4 *) (blk + 16 + 16 * (p & 7));
+        r.q0 = *(const uint4 *) (blk + 16 + 32 * (p & 3));
+        r.q1 = *(const uint4 *) (blk + 32 + 32 * (p & 3));
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
-        const int b = p >> 3, c = p & 7, j = c >> 1;
+        const int b = p >> 2, j = p & 3;
         const float d = h2f((uint16_t) (r.hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (r.hdr.x >> 16));
         int sc0, sc1, m0, m1;
         k4_scale_pair(r.hdr.y, r.hdr.z, r.hdr.w, j, sc0, sc1, m0, m1);
-        const int e0 = 64 * j + 16 * (c & 1);
-        const uint32_t qv[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+        const uint32_t qv[8] = {r.q0.x, r.q0.y, r.q0.z, r.q0.w, r.q1.x, r.q1.y, r.q1.z, r.q1.w};
 #pragma unroll
         for (int col = 0; col < NC; ++col) {
             const act * yb = y + (size_t) col * nblk + b;
-            const uint4 ylo = *(const uint4 *) (yb->qs + e0);
-            const uint4 yhi = *(const uint4 *) (yb->qs + e0 + 32);
-            const uint32_t yl[4] = {ylo.x, ylo.y, ylo.z, ylo.w}, yh[4] = {yhi.x, yhi.y, yhi.z, yhi.w};
+            const uint4 * yq = (const uint4 *) (yb->qs + 64 * j);
+            const uint4 y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+            const uint32_t yl[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+            const uint32_t yh[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
             int s_lo = 0, s_hi = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 s_lo = dot4((int) (qv[k] & 0x0F0F0F0Fu), (int) yl[k], s_lo);
                 s_hi = dot4((int) ((qv[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], s_hi);
             }
-            const int bs_lo = yb->bsums[4 * j + (c & 1)], bs_hi = yb->bsums[4 * j + 2 + (c & 1)];
-            const int isum = sc0 * s_lo + sc1 * s_hi;
-            const int msum = m0 * bs_lo + m1 * bs_hi;
+            const uint32_t bs = *(const uint32_t *) (yb->bs32 + 2 * j);  // sums of q8 over sub-blocks 2j, 2j+1
+            const int bs_lo = (int) (int16_t) (bs & 0xFFFF), bs_hi = (int) (int16_t) (bs >> 16);
+            const int isum = __mul24(sc0, s_lo) + __mul24(sc1, s_hi);
+            const int msum = __mul24(m0, bs_lo) + __mul24(m1, bs_hi);
             acc[col] += yb->d * (d * (float) isum - dmin * (float) msum);
         }
     }
@@ -77,97 +74,87 @@ struct T_Q4K {
 // ------------------------------------------------------------------------------------------------ Q5_K
 struct T_Q5K {
     typedef q8k_dev act;
-    static constexpr int BLK = 256, BYTES = 176, PPB = 8;
-    struct raw { uint4 hdr, qh, q; };
-    static constexpr int DW = 12;
-    static __device__ __forceinline__ void pack(const raw & r, uint32_t * d) {
-        d[0] = r.hdr.x; d[1] = r.hdr.y; d[2] = r.hdr.z; d[3] = r.hdr.w; d[4] = r.qh.x; d[5] = r.qh.y; d[6] = r.qh.z; d[7] = r.qh.w;
-        d[8] = r.q.x; d[9] = r.q.y; d[10] = r.q.z; d[11] = r.q.w;
-    }
-    static __device__ __forceinline__ raw unpack(const uint32_t * d) {
-        raw r;
-        r.hdr = make_uint4(d[0], d[1], d[2], d[3]);
-        r.qh = make_uint4(d[4], d[5], d[6], d[7]);
-        r.q = make_uint4(d[8], d[9], d[10], d[11]);
-        return r;
-    }
+    static constexpr int BLK = 256, BYTES = 176, PPB = 4;
+    struct raw { uint4 hdr, h0, h1, q0, q1; };
+    static constexpr int DW = 20;
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
-        const uint8_t * blk = row + (size_t) (p >> 3) * BYTES;
+        const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         raw r;
         r.hdr = *(const uint4 *) blk;
-        r.qh = *(const uint4 *) (blk + 16 + 16 * (p & 1));
-        r.q = *(const uint4 *) (blk + 48 + 16 * (p & 7));
+        r.h0 = *(const uint4 *) (blk + 16);
+        r.h1 = *(const uint4 *) (blk + 32);
+        r.q0 = *(const uint4 *) (blk + 48 + 32 * (p & 3));
+        r.q1 = *(const uint4 *) (blk + 64 + 32 * (p & 3));
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
-        const int b = p >> 3, c = p & 7, j = c >> 1;
+        const int b = p >> 2, j = p & 3;
         const float d = h2f((uint16_t) (r.hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (r.hdr.x >> 16));
         int sc0, sc1, m0, m1;
         k4_scale_pair(r.hdr.y, r.hdr.z, r.hdr.w, j, sc0, sc1, m0, m1);
-        const int e0 = 64 * j + 16 * (c & 1);
-        const uint32_t qv[4] = {r.q.x, r.q.y, r.q.z, r.q.w}, qh[4] = {r.qh.x, r.qh.y, r.qh.z, r.qh.w};
-        uint32_t lo[4], hi[4];
+        const uint32_t qv[8] = {r.q0.x, r.q0.y, r.q0.z, r.q0.w, r.q1.x, r.q1.y, r.q1.z, r.q1.w};
+        const uint32_t qh[8] = {r.h0.x, r.h0.y, r.h0.z, r.h0.w, r.h1.x, r.h1.y, r.h1.z, r.h1.w};
+        uint32_t lo[8], hi[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             lo[k] = (qv[k] & 0x0F0F0F0Fu) | (((qh[k] >> (2 * j)) & 0x01010101u) << 4);
             hi[k] = ((qv[k] >> 4) & 0x0F0F0F0Fu) | (((qh[k] >> (2 * j + 1)) & 0x01010101u) << 4);
         }
 #pragma unroll
         for (int col = 0; col < NC; ++col) {
             const act * yb = y + (size_t) col * nblk + b;
-            const uint4 ylo = *(const uint4 *) (yb->qs + e0);
-            const uint4 yhi = *(const uint4 *) (yb->qs + e0 + 32);
-            const uint32_t yl[4] = {ylo.x, ylo.y, ylo.z, ylo.w}, yh[4] = {yhi.x, yhi.y, yhi.z, yhi.w};
+            const uint4 * yq = (const uint4 *) (yb->qs + 64 * j);
+            const uint4 y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+            const uint32_t yl[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+            const uint32_t yh[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
             int s_lo = 0, s_hi = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 s_lo = dot4((int) lo[k], (int) yl[k], s_lo);
                 s_hi = dot4((int) hi[k], (int) yh[k], s_hi);
             }
-            const int bs_lo = yb->bsums[4 * j + (c & 1)], bs_hi = yb->bsums[4 * j + 2 + (c & 1)];
-            const int isum = sc0 * s_lo + sc1 * s_hi;
-            const int msum = m0 * bs_lo + m1 * bs_hi;
+            const uint32_t bs = *(const uint32_t *) (yb->bs32 + 2 * j);
+            const int bs_lo = (int) (int16_t) (bs & 0xFFFF), bs_hi = (int) (int16_t) (bs >> 16);
+            const int isum = __mul24(sc0, s_lo) + __mul24(sc1, s_hi);
+            const int msum = __mul24(m0, bs_lo) + __mul24(m1, bs_hi);
             acc[col] += yb->d * (d * (float) isum - dmin * (float) msum);
         }
     }
 };
 
 // ------------------------------------------------------------------------------------------------ Q6_K
-// 16 lanes per super-block: lane (h, t) owns l = 4t..4t+3 of half h, i.e. 16 of the 256 values
+// 8 lanes per super-block: lane (h, t) owns l = 8t..8t+7 of half h, i.e. 32 of the 256 values (8 bytes of ql twice, 8 of qh)
 struct T_Q6K {
     typedef q8k_dev act;
-    static constexpr int BLK = 256, BYTES = 210, PPB = 16;
-    struct raw { uint32_t ql0, ql1, qh, s0, s1; uint16_t d; };
-    static constexpr int DW = 6;
-    static __device__ __forceinline__ void pack(const raw & r, uint32_t * d) {
-        d[0] = r.ql0; d[1] = r.ql1; d[2] = r.qh; d[3] = r.s0; d[4] = r.s1; d[5] = r.d;
-    }
-    static __device__ __forceinline__ raw unpack(const uint32_t * d) {
-        raw r;
-        r.ql0 = d[0]; r.ql1 = d[1]; r.qh = d[2]; r.s0 = d[3]; r.s1 = d[4]; r.d = (uint16_t) d[5];
-        return r;
-    }
+    static constexpr int BLK = 256, BYTES = 210, PPB = 8;
+    struct raw { uint32_t ql0[2], ql1[2], qh[2], s0, s1; uint16_t d; };
+    static constexpr int DW = 9;
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
-        const uint8_t * blk = row + (size_t) (p >> 4) * BYTES;
-        const int h = (p >> 3) & 1, t = p & 7;
+        const uint8_t * blk = row + (size_t) (p >> 3) * BYTES;
+        const int h = (p >> 2) & 1, t = p & 3;
         raw r;
-        r.ql0 = ld32_a2(blk + 64 * h + 4 * t);
-        r.ql1 = ld32_a2(blk + 64 * h + 32 + 4 * t);
-        r.qh = ld32_a2(blk + 128 + 32 * h + 4 * t);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            r.ql0[i] = ld32_a2(blk + 64 * h + 8 * t + 4 * i);
+            r.ql1[i] = ld32_a2(blk + 64 * h + 32 + 8 * t + 4 * i);
+            r.qh[i] = ld32_a2(blk + 128 + 32 * h + 8 * t + 4 * i);
+        }
         r.s0 = ld32_a2(blk + 192 + 8 * h);
         r.s1 = ld32_a2(blk + 196 + 8 * h);
         r.d = ld16(blk + 208);
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
-        const int b = p >> 4, h = (p >> 3) & 1, t = p & 7, is = t >> 2;
+        const int b = p >> 3, h = (p >> 2) & 1, t = p & 3, is = t >> 1;
         const float d = h2f(r.d);
-        const uint32_t v[4] = {
-            (r.ql0 & 0x0F0F0F0Fu) | ((r.qh & 0x03030303u) << 4),
-            (r.ql1 & 0x0F0F0F0Fu) | (((r.qh >> 2) & 0x03030303u) << 4),
-            ((r.ql0 >> 4) & 0x0F0F0F0Fu) | (((r.qh >> 4) & 0x03030303u) << 4),
-            ((r.ql1 >> 4) & 0x0F0F0F0Fu) | (((r.qh >> 6) & 0x03030303u) << 4),
-        };
+        uint32_t v[4][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v[0][i] = (r.ql0[i] & 0x0F0F0F0Fu) | ((r.qh[i] & 0x03030303u) << 4);
+            v[1][i] = (r.ql1[i] & 0x0F0F0F0Fu) | (((r.qh[i] >> 2) & 0x03030303u) << 4);
+            v[2][i] = ((r.ql0[i] >> 4) & 0x0F0F0F0Fu) | (((r.qh[i] >> 4) & 0x03030303u) << 4);
+            v[3][i] = ((r.ql1[i] >> 4) & 0x0F0F0F0Fu) | (((r.qh[i] >> 6) & 0x03030303u) << 4);
+        }
         const int sc[4] = {
             (int) (int8_t) (r.s0 >> (8 * is)), (int) (int8_t) (r.s0 >> (8 * (is + 2))),
             (int) (int8_t) (r.s1 >> (8 * is)), (int) (int8_t) (r.s1 >> (8 * (is + 2))),
@@ -178,10 +165,13 @@ struct T_Q6K {
             int isum = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int yk = *(const int *) (yb->qs + 128 * h + 32 * k + 4 * t);
+                const uint2 yk = *(const uint2 *) (yb->qs + 128 * h + 32 * k + 8 * t);
                 // sum (q - 32) * y = dot(q, y) - 32 * sum(y)
-                const int s = dot4((int) v[k], yk, 0) - 32 * dot4(0x01010101, yk, 0);
-                isum += sc[k] * s;
+                int s = dot4((int) v[k][0], (int) yk.x, 0);
+                s = dot4((int) v[k][1], (int) yk.y, s);
+                int ys = dot4(0x01010101, (int) yk.x, 0);
+                ys = dot4(0x01010101, (int) yk.y, ys);
+                isum += __mul24(sc[k], s - 32 * ys);
             }
             acc[col] += yb->d * d * (float) isum;
         }
