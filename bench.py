@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--preset", default="llama3-8b-q4_k_m")
     ap.add_argument("--prefill", type=int, default=2048)
     ap.add_argument("--fa", type=int, default=1)
+    ap.add_argument("--np", type=int, default=1, help="parallel sequences decoded per step (llama-box -np continuous batching)")
+    ap.add_argument("--ubatch", type=int, default=512)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override n_layer (result is then NOT a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
@@ -79,10 +81,10 @@ def main():
     t_load = time.time()
     model = Model(hp, 0x5EED, be.buft, tp_rank=tp_rank, tp_size=tp_size, rowpar_buft=be.rowpar_buft() if tp_size > 1 else None)
     t_load = time.time() - t_load
-    n_ctx = (args.prefill + args.warmup + args.steps + args.timing_steps + 64 + 255) // 256 * 256
-    ctx = Context(model, backend=be, n_ctx=n_ctx, n_ubatch=512, flash_attn=args.fa, graph_reuse=1)
+    n_ctx = (args.np * (args.prefill + args.warmup + args.steps + args.timing_steps + 64) + 255) // 256 * 256
+    ctx = Context(model, backend=be, n_ctx=n_ctx, n_ubatch=args.ubatch, flash_attn=args.fa, graph_reuse=1)
     rng = np.random.default_rng(1 + 0 * rank)
-    toks = rng.integers(0, hp.n_vocab, args.prefill + args.warmup + args.steps + args.timing_steps + 8)
+    toks = rng.integers(0, hp.n_vocab, args.np * (args.prefill + args.warmup + args.steps + args.timing_steps + 8))
 
     def sync():
         if dist is not None:
@@ -95,15 +97,16 @@ def main():
     if args.prefill > 0:
         sync()
         t0 = time.perf_counter()
-        rc, _ = ctx.decode(toks[: args.prefill], range(args.prefill), want=[0] * (args.prefill - 1) + [1])
+        for sq in range(args.np):  # llama-box never mixes prefill and decode in one batch (httpserver.hpp:3742, :4042)
+            rc, _ = ctx.decode(toks[sq * args.prefill: (sq + 1) * args.prefill], range(args.prefill), seq=[sq] * args.prefill, want=[0] * (args.prefill - 1) + [1])
+            assert rc == 0, f"prefill failed rc={rc}"
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        assert rc == 0, f"prefill failed rc={rc}"
-        prefill_tok_s = args.prefill / (t1 - t0)
+        prefill_tok_s = args.np * args.prefill / (t1 - t0)
         pos = args.prefill
 
     def step(i):
-        rc, lg = ctx.decode([int(toks[pos + i])], [pos + i])
+        rc, lg = ctx.decode([int(toks[(pos + i) * args.np + sq]) for sq in range(args.np)], [pos + i] * args.np, seq=list(range(args.np)))
         assert rc == 0, f"decode failed rc={rc}"
         return lg
 
@@ -127,7 +130,7 @@ def main():
         elapsed = float(t[0])
     graph_steps = be.stat("graph_launches") - g0
     streams = 1 if tp_size > 1 or world == 1 else world
-    tok_s = streams * args.steps / elapsed
+    tok_s = streams * args.np * args.steps / elapsed
     host_split = ctx.timings()
 
     # ---- per-kernel-class timing pass (eager, hipEvents on the backend's stream)
@@ -176,14 +179,14 @@ def main():
         w_bytes = model.stream_bytes()
         kv_per_tok = 2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * 2
         n_past = args.prefill + args.warmup + args.steps // 2
-        job_bytes = (w_bytes + kv_per_tok * n_past) * (tok_s / streams)
+        job_bytes = (w_bytes + args.np * kv_per_tok * n_past) * (tok_s / streams / args.np)
         out = {
             "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M",
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None, "dtype": "q4_K/q6_K weights x q8_K activations (int8 dot, f32 accumulate)",
             "data": "synthetic (GGUF-exact tensor set, directly sampled quant blocks, random token ids)",
-            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then batch-1 decode, flash_attn={args.fa}, n_ctx={n_ctx}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
+            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode, flash_attn={args.fa}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
                        "parallelism": parallelism, "n_past_mid": n_past, "weight_bytes_per_token_per_gpu": w_bytes, "kv_bytes_per_token_per_gpu": kv_per_tok * n_past},
             "prefill_tok_s": round(prefill_tok_s, 1) if prefill_tok_s else None,
             "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),

@@ -42,6 +42,26 @@ struct mmq_args {
     int n_panels, m_tiles;
 };
 
+// ---- packed integer -> f16 conversion without per-value cvt instructions.  For 0 <= n < 1024 the f16 with bits
+// 0x6400 | n is exactly 1024 + n (ulp of the [1024, 2048) binade is 1), so OR-ing the bias into both halves of a dword
+// and one v_pk_add_f16 of -1024 turns two 16-bit integers into two exact halves.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t u16x2_to_h2(const uint32_t n2, const float bias) {  // n2: two u16 < 1024; result = n - bias'
+    const uint32_t biased = n2 | 0x64006400u;
+    half2v h = __builtin_bit_cast(half2v, biased);
+    const _Float16 b = (_Float16) bias;
+    h = h - (half2v){b, b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+// bytes (b0,b1,b2,b3) of x -> (b0 | b1<<16), (b2 | b3<<16)
+__device__ __forceinline__ uint32_t bytes01_to_u16x2(const uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c010c00u); }
+__device__ __forceinline__ uint32_t bytes23_to_u16x2(const uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c030c02u); }
+__device__ __forceinline__ uint32_t pk_mul_u16(const uint32_t a, const uint32_t b) {
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    const ushort2v r = __builtin_bit_cast(ushort2v, a) * __builtin_bit_cast(ushort2v, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
 __device__ __forceinline__ uint32_t pack_h2(const int a, const int b) {
     const _Float16 x = (_Float16) a, y = (_Float16) b;
     uint16_t ux, uy;
@@ -132,6 +152,7 @@ __global__ void __launch_bounds__(512) k_mmq(const mmq_args a) {
             (void) m0_; (void) m1_;
             const uint32_t qv[4] = {g_q.x, g_q.y, g_q.z, g_q.w};
             uint32_t lo[8], hi[8];
+            const uint32_t sc0p = (uint32_t) sc0 * 0x00010001u, sc1p = (uint32_t) sc1 * 0x00010001u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 uint32_t l4 = qv[k] & 0x0F0F0F0Fu, h4 = (qv[k] >> 4) & 0x0F0F0F0Fu;
@@ -140,10 +161,17 @@ __global__ void __launch_bounds__(512) k_mmq(const mmq_args a) {
                     l4 |= ((qh >> (2 * j2)) & 0x01010101u) << 4;
                     h4 |= ((qh >> (2 * j2 + 1)) & 0x01010101u) << 4;
                 }
-                lo[2 * k] = pack_h2(sc0 * (int) (l4 & 0xFF), sc0 * (int) ((l4 >> 8) & 0xFF));
-                lo[2 * k + 1] = pack_h2(sc0 * (int) ((l4 >> 16) & 0xFF), sc0 * (int) (l4 >> 24));
-                hi[2 * k] = pack_h2(sc1 * (int) (h4 & 0xFF), sc1 * (int) ((h4 >> 8) & 0xFF));
-                hi[2 * k + 1] = pack_h2(sc1 * (int) ((h4 >> 16) & 0xFF), sc1 * (int) (h4 >> 24));
+                if constexpr (QT == 4) {  // sc*q <= 945 < 1024: packed u16 multiply + bias trick, no cvt
+                    lo[2 * k] = u16x2_to_h2(pk_mul_u16(bytes01_to_u16x2(l4), sc0p), 1024.0f);
+                    lo[2 * k + 1] = u16x2_to_h2(pk_mul_u16(bytes23_to_u16x2(l4), sc0p), 1024.0f);
+                    hi[2 * k] = u16x2_to_h2(pk_mul_u16(bytes01_to_u16x2(h4), sc1p), 1024.0f);
+                    hi[2 * k + 1] = u16x2_to_h2(pk_mul_u16(bytes23_to_u16x2(h4), sc1p), 1024.0f);
+                } else {  // Q5_K reaches 63*31 = 1953: keep the converting path
+                    lo[2 * k] = pack_h2(sc0 * (int) (l4 & 0xFF), sc0 * (int) ((l4 >> 8) & 0xFF));
+                    lo[2 * k + 1] = pack_h2(sc0 * (int) ((l4 >> 16) & 0xFF), sc0 * (int) (l4 >> 24));
+                    hi[2 * k] = pack_h2(sc1 * (int) (h4 & 0xFF), sc1 * (int) ((h4 >> 8) & 0xFF));
+                    hi[2 * k + 1] = pack_h2(sc1 * (int) ((h4 >> 16) & 0xFF), sc1 * (int) (h4 >> 24));
+                }
             }
             // element offsets inside the half: low nibbles -> 64*(aq>>1) + 16*(aq&1) + i, high nibbles -> +32
             char * dstA = A1 + arow * MQ_AS + (64 * (aq >> 1) + 16 * (aq & 1)) * 2;
@@ -180,17 +208,24 @@ __global__ void __launch_bounds__(512) k_mmq(const mmq_args a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int sh = sc[k] >> 4, sl = sc[k] & 15;  // sc = 16*sh + sl, sh in [-8,7], sl in [0,15]
+                const uint32_t shp = ((uint32_t) sh & 0xFFFFu) * 0x00010001u, slp = (uint32_t) sl * 0x00010001u;
                 uint32_t o1[4], o2[4];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const uint32_t ql = (k & 1) ? g6_ql[2 + i] : g6_ql[i];
                     const uint32_t nib = (k & 2) ? ((ql >> 4) & 0x0F0F0F0Fu) : (ql & 0x0F0F0F0Fu);
                     const uint32_t v = nib | (((g6_qh[i] >> (2 * k)) & 0x03030303u) << 4);
-                    const int q0 = (int) (v & 0xFF) - 32, q1 = (int) ((v >> 8) & 0xFF) - 32, q2 = (int) ((v >> 16) & 0xFF) - 32, q3 = (int) (v >> 24) - 32;
-                    o1[2 * i] = pack_h2(sh * q0, sh * q1);
-                    o1[2 * i + 1] = pack_h2(sh * q2, sh * q3);
-                    o2[2 * i] = pack_h2(sl * q0, sl * q1);
-                    o2[2 * i + 1] = pack_h2(sl * q2, sl * q3);
+                    // packed 16-bit lanes: (q - 32) * s + 512 lies in [32, 992] -> bias trick with 1024 + 512, no cvt
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        typedef short short2v __attribute__((ext_vector_type(2)));
+                        const uint32_t u = hh ? bytes23_to_u16x2(v) : bytes01_to_u16x2(v);
+                        const short2v qm = __builtin_bit_cast(short2v, u) - (short2v){32, 32};
+                        const short2v p1 = qm * __builtin_bit_cast(short2v, shp) + (short2v){512, 512};
+                        const short2v p2 = qm * __builtin_bit_cast(short2v, slp) + (short2v){512, 512};
+                        o1[2 * i + hh] = u16x2_to_h2(__builtin_bit_cast(uint32_t, p1), 1536.0f);
+                        o2[2 * i + hh] = u16x2_to_h2(__builtin_bit_cast(uint32_t, p2), 1536.0f);
+                    }
                 }
                 const int off = arow * MQ_AS + (32 * k + 8 * aq) * 2;
                 *(uint4 *) (A1 + off) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
@@ -204,9 +239,10 @@ __global__ void __launch_bounds__(512) k_mmq(const mmq_args a) {
             uint32_t o[16];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const uint32_t w = bvalid ? bw[k] : 0u;
-                o[2 * k] = pack_h2((int) (int8_t) (w & 0xFF), (int) (int8_t) ((w >> 8) & 0xFF));
-                o[2 * k + 1] = pack_h2((int) (int8_t) ((w >> 16) & 0xFF), (int) (int8_t) (w >> 24));
+                // int8 n -> byte n ^ 0x80 = n + 128 in [1, 255] -> f16 via the bias trick with bias 1024 + 128
+                const uint32_t w = (bvalid ? bw[k] : 0u) ^ 0x80808080u;
+                o[2 * k] = u16x2_to_h2(bytes01_to_u16x2(w), 1152.0f);
+                o[2 * k + 1] = u16x2_to_h2(bytes23_to_u16x2(w), 1152.0f);
             }
             uint4 * db = (uint4 *) (Bt + bcol * MQ_AS + 32 * bq * 2);
             db[0] = make_uint4(o[0], o[1], o[2], o[3]);
