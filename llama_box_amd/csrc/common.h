@@ -62,7 +62,8 @@ struct options {
     bool fusion = true;        // node fusion (norm+mul, mul_mat+add, ...)
     bool prologue = true;      // fold RMS_NORM / activation quantisation into the mat-vec prologue
     bool qkv = true;           // fused Q/K/V + rope + cache store launch
-    int mmvq_max_cols = 8;     // widest batch handled by the bandwidth-bound matvec kernels
+    int mmvq_max_cols = 8;     // widest single launch of the bandwidth-bound matvec kernels
+    int mmq_min_cols = 33;     // batches at least this wide go to the MFMA kernel; narrower ones are chunks of 8 mat-vec columns
     int fa_splits = 0;         // 0 = auto
     bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)
 };

@@ -28,7 +28,11 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
                                                      const tdesc dst, const fa_geom geo, float * __restrict__ ws) {
     constexpr int LPR = D / 8;     // lanes per K/V row
     constexpr int RPW = 64 / LPR;  // rows per wave-instruction
-    __shared__ float sh[4][G][D + 2];
+    constexpr bool SLOTS_ALL = (size_t) 4 * RPW * G * (D + 2) * sizeof(float) <= 48 * 1024;
+    constexpr int NSLOT = SLOTS_ALL ? 4 * RPW : 4;
+    __shared__ float sh[NSLOT][G][D + 2];
+    __shared__ float coef[NSLOT][G];
+    __shared__ float mtot[G];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane / LPR, sl = lane % LPR;
     const int split = blockIdx.x, kvh = blockIdx.y;
@@ -55,25 +59,37 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
     const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
     const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
 
-    // two independent row groups per trip (A, B): their K/V loads are all issued before any use, so one trip costs
-    // one memory round trip instead of two
-    for (int p0 = kv0 + wave * RPW; p0 < kv1; p0 += 8 * RPW) {
-        int pp[2];
-        bool inr[2];
-        float mv[2];
-        uint4 kraw[2], vraw[2];
+    // NG independent row groups per trip; the NEXT trip's K/V loads are issued before the current trip is consumed, so
+    // the memory round trips of successive trips overlap with the softmax arithmetic
+    constexpr int NG = 2;
+    struct trip_regs {
+        uint4 kraw[NG], vraw[NG];
+        float mv[NG];
+        bool inr[NG];
+    };
+    auto load_trip = [&](const int p0, trip_regs & t) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            pp[u] = p0 + u * 4 * RPW + sub;
-            inr[u] = pp[u] < kv1;
-            const int pc = inr[u] ? pp[u] : kv1 - 1;
-            mv[u] = mp ? h2f(mp[pc]) : 0.0f;
-            kraw[u] = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);
-            vraw[u] = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);
+        for (int u = 0; u < NG; ++u) {
+            const int p = p0 + u * 4 * RPW + sub;
+            t.inr[u] = p < kv1;
+            const int pc = t.inr[u] ? p : kv1 - 1;
+            t.mv[u] = mp ? h2f(mp[pc]) : 0.0f;
+            t.kraw[u] = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);
+            t.vraw[u] = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);
         }
+    };
+    trip_regs cur;
+    int p0 = kv0 + wave * RPW;
+    bool have = p0 < kv1;
+    if (have) load_trip(p0, cur);
+    while (have) {
+        const int pn = p0 + NG * 4 * RPW;
+        const bool nhave = pn < kv1;
+        trip_regs nxt;
+        if (nhave) load_trip(pn, nxt);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
+        for (int u = 0; u < NG; ++u) {
+            const uint32_t ku[4] = {cur.kraw[u].x, cur.kraw[u].y, cur.kraw[u].z, cur.kraw[u].w}, vu[4] = {cur.vraw[u].x, cur.vraw[u].y, cur.vraw[u].z, cur.vraw[u].w};
             float kf[8], vf[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -105,9 +121,9 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
             for (int g = 0; g < G; ++g) {
                 float sv = sc[g] * geo.scale;
                 if (geo.softcap != 0.0f) sv = geo.softcap * tanhf(sv);
-                const float mvs = slope[g] * mv[u];
+                const float mvs = slope[g] * cur.mv[u];
                 sv += mvs;
-                const bool use = inr[u] && !(mvs == -INFINITY);
+                const bool use = cur.inr[u] && !(mvs == -INFINITY);
                 if (use) {
                     float vs = 1.0f;
                     if (sv > m[g]) {
@@ -125,46 +141,63 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
                 }
             }
         }
+        cur = nxt;
+        p0 = pn;
+        have = nhave;
     }
-    // merge the RPW sub-rows of the wave
+    // every (wave, sub-row) partial goes to LDS as its own slot (no cross-lane shuffles: the round-1 profile showed the
+    // 10 x G ds_bpermute per merge level dominating short splits); when the slots would not fit, sub-rows are first
+    // merged in registers
+    if constexpr (!SLOTS_ALL) {
 #pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) {
+        for (int o = LPR; o < 64; o <<= 1) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float mo = __shfl_xor(m[g], o, 64), lo = __shfl_xor(l[g], o, 64);
-            const float mn = fmaxf(m[g], mo);
-            const float ca = m[g] == -INFINITY ? 0.0f : expf(m[g] - mn);
-            const float cb = mo == -INFINITY ? 0.0f : expf(mo - mn);
+            for (int g = 0; g < G; ++g) {
+                const float mo = __shfl_xor(m[g], o, 64), lo = __shfl_xor(l[g], o, 64);
+                const float mn = fmaxf(m[g], mo);
+                const float ca = m[g] == -INFINITY ? 0.0f : expf(m[g] - mn);
+                const float cb = mo == -INFINITY ? 0.0f : expf(mo - mn);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float ao = __shfl_xor(acc[g][i], o, 64);
-                acc[g][i] = acc[g][i] * ca + ao * cb;
+                for (int i = 0; i < 8; ++i) {
+                    const float ao = __shfl_xor(acc[g][i], o, 64);
+                    acc[g][i] = acc[g][i] * ca + ao * cb;
+                }
+                l[g] = l[g] * ca + lo * cb;
+                m[g] = mn;
             }
-            l[g] = l[g] * ca + lo * cb;
-            m[g] = mn;
         }
     }
-    if (sub == 0) {
+    if (SLOTS_ALL || sub == 0) {
+        const int slot = SLOTS_ALL ? wave * RPW + sub : wave;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) sh[wave][g][sl * 8 + i] = acc[g][i];
+            for (int i = 0; i < 8; ++i) sh[slot][g][sl * 8 + i] = acc[g][i];
             if (sl == 0) {
-                sh[wave][g][D] = m[g];
-                sh[wave][g][D + 1] = l[g];
+                sh[slot][g][D] = m[g];
+                sh[slot][g][D + 1] = l[g];
             }
         }
     }
     __syncthreads();
-    // merge the 4 waves; one thread per (g, d)
+    // per (slot, g): coefficient exp(m_slot - m_total), stored over the slot's m
+    if (tid < NSLOT * G) {
+        const int slot = tid / G, g = tid % G;
+        float mt = -INFINITY;
+        for (int w = 0; w < NSLOT; ++w) mt = fmaxf(mt, sh[w][g][D]);
+        const float mw = sh[slot][g][D];
+        coef[slot][g] = mw == -INFINITY ? 0.0f : expf(mw - mt);
+        if (slot == 0) mtot[g] = mt;
+    }
+    __syncthreads();
+    // merge the slots; one thread per (g, d)
     for (int e = tid; e < G * D; e += 256) {
         const int g = e / D, dd = e % D;
-        float mt = -INFINITY;
-        for (int w = 0; w < 4; ++w) mt = fmaxf(mt, sh[w][g][D]);
+        const float mt = mtot[g];
         float a = 0.0f, lt = 0.0f;
-        for (int w = 0; w < 4; ++w) {
-            const float mw = sh[w][g][D];
-            const float c = mw == -INFINITY ? 0.0f : expf(mw - mt);
+#pragma unroll 4
+        for (int w = 0; w < NSLOT; ++w) {
+            const float c = coef[w][g];
             a += sh[w][g][dd] * c;
             lt += sh[w][g][D + 1] * c;
         }

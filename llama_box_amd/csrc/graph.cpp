@@ -240,7 +240,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         return true;
     }
     const void * act = quantized_src1(st, b, w->type);
-    if (M > c->opt.mmvq_max_cols && !w2 && !add && mmq_supported(w->type, K, N, M)) {
+    if (M >= c->opt.mmq_min_cols && !w2 && !add && mmq_supported(w->type, K, N, M)) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
         launch_mmq(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4));
         c->st.kernel_launches++;
