@@ -278,6 +278,7 @@ template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, co
 
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
                        const fattn_params & p, void * workspace) {
+    if (launch_flash_attn_mma(s, q, k, v, mask, sinks, dst, p)) return;
     fa_geom geo;
     geo.n_q = (int) q.ne[1];
     geo.n_head = (int) q.ne[2];

@@ -1,0 +1,216 @@
+// fattn_mma.hip — FLASH_ATTN_EXT for batches of query tokens (prefill) on the gfx950 matrix cores.
+//
+// Same contract as fattn.hip (restates ggml_compute_forward_flash_attn_ext_f16: Q rounded to f16, s = (K·Q)*scale +
+// mask, online softmax, f32 accumulation of P·V), but a workgroup owns 64 query tokens of one head and walks the KV
+// range in 64-position tiles staged through LDS, so K/V are read once per 64 queries instead of once per query.
+//
+// Layout (wave64, v_mfma_f32_32x32x16_f16), chosen so that NO cross-lane data movement is needed between the two GEMMs:
+//   * scores are computed TRANSPOSED, S^T = K·Q^T: A = K tile rows (LDS, 16-byte reads), B = Q^T fragments kept in
+//     registers for the whole kernel.  In the accumulator a lane then holds one query (column = lane & 31) and 16 of the
+//     32 KV positions of the tile — the row max / row sum of the online softmax are lane-local plus ONE exchange with
+//     lane ^ 32, and the running max, sum and the rescale factor are per-lane scalars.
+//   * O^T = V^T·P^T: the B operand must hold 8 KV positions of one query per lane — exactly what the lane already has
+//     (registers 8s..8s+7 of the score tile), in the order {4h..4h+3, 8+4h..8+4h+3} (h = lane >> 5).  The contraction
+//     index is only a label, so instead of permuting P the A operand reads V^T in that same order: V is transposed while
+//     it is staged (V^T[d][kv] in LDS), and a lane reads two 8-byte runs of the row of its output dimension.
+//   * O^T accumulators again have the query in the column, so alpha-rescaling and the final 1/l are per-lane scalars and
+//     the result is written as float4 runs along d.
+// P is rounded to f16 for the second GEMM (the CPU path rounds the whole accumulation to f16 at every step).
+#include <algorithm>
+
+#include "dev_util.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+struct fam_geom {
+    int n_q, n_head, n_kv_head, n_kv, has_mask;
+    float scale;
+};
+
+template <int D>
+__global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo) {
+    constexpr int BKV = 64;
+    constexpr int KS = (D + 8) * 2;    // K tile row stride (bytes): odd multiple of 16 -> conflict-free ds_read_b128
+    constexpr int VS = (BKV + 4) * 2;  // V^T tile row stride (bytes): 34 dwords -> conflict-free ds_read_b64 across 32 rows
+    constexpr int NS = D / 16;         // MFMA k-steps over the head dimension
+    constexpr int ND = D / 32;         // output d-tiles
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char * Kt = smem;                  // [BKV][D+8] f16
+    char * Vt = smem + BKV * KS;       // [D][BKV+4] f16 (transposed)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, kg = lane >> 5;
+    const int h = blockIdx.y, bat = blockIdx.z;
+    const int kvh = h / (geo.n_head / geo.n_kv_head);
+    const int qi = blockIdx.x * 64 + wave * 32 + fr;  // this lane's query token
+    const int qrow = min(qi, geo.n_q - 1);
+    const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
+
+    // Q^T fragments: step s needs head dims 16s + 8kg .. +7 of this lane's query (Q -> f16, as the CPU's q_to_vec_dot)
+    half8 qf[NS];
+    {
+        const float * qp = (const float *) (q.data + (int64_t) qrow * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a = *(const float4 *) (qp + 16 * s + 8 * kg), b = *(const float4 *) (qp + 16 * s + 8 * kg + 4);
+            qf[s] = (half8){(_Float16) a.x, (_Float16) a.y, (_Float16) a.z, (_Float16) a.w, (_Float16) b.x, (_Float16) b.y, (_Float16) b.z, (_Float16) b.w};
+        }
+    }
+    const uint16_t * mrow = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) qrow * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3];
+    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3];
+
+    float16v O[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] = 0.0f;
+    const float16v zero = O[0];
+    float m = -INFINITY, l = 0.0f;
+
+    // staging roles: thread -> KV row (tid >> 1) and half of the head dimension (tid & 1)
+    const int srow = tid >> 1, spart = tid & 1;
+    constexpr int CH = D / 16;  // 16-byte chunks per thread per tile (half a row)
+
+    for (int kv0 = 0; kv0 < geo.n_kv; kv0 += BKV) {
+        __syncthreads();
+        {
+            const int pos = min(kv0 + srow, geo.n_kv - 1);
+            const uint4 * kp = (const uint4 *) (kbase + (int64_t) pos * k.nb[1]) + spart * CH;
+            const uint4 * vp = (const uint4 *) (vbase + (int64_t) pos * v.nb[1]) + spart * CH;
+            uint4 kr[CH], vr[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { kr[i] = kp[i]; vr[i] = vp[i]; }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) *(uint4 *) (Kt + srow * KS + (spart * CH + i) * 16) = kr[i];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int d0 = (spart * CH + i) * 8;
+                const uint32_t w[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    *(uint16_t *) (Vt + (d0 + 2 * e) * VS + srow * 2) = (uint16_t) (w[e] & 0xFFFF);
+                    *(uint16_t *) (Vt + (d0 + 2 * e + 1) * VS + srow * 2) = (uint16_t) (w[e] >> 16);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K·Q^T for the two 32-position halves of the tile
+        float16v S[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            S[t] = zero;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const half8 a = *(const half8 *) (Kt + (32 * t + fr) * KS + (16 * s + 8 * kg) * 2);
+                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
+            }
+        }
+        // ---- scale, mask, online softmax (lane = one query; registers = 32 of the tile's 64 KV positions)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int p0 = kv0 + 32 * t + 8 * g4 + 4 * kg;  // four consecutive KV positions: registers 4*g4 .. 4*g4+3
+                float mv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (mrow) {
+                    const uint2 mw = *(const uint2 *) (mrow + min(p0, geo.n_kv - 4));
+                    mv[0] = h2f((uint16_t) (mw.x & 0xFFFF)); mv[1] = h2f((uint16_t) (mw.x >> 16));
+                    mv[2] = h2f((uint16_t) (mw.y & 0xFFFF)); mv[3] = h2f((uint16_t) (mw.y >> 16));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = S[t][4 * g4 + e] * geo.scale + mv[e];
+                    if (p0 + e >= geo.n_kv) sv = -INFINITY;
+                    S[t][4 * g4 + e] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        if (__all(m_new == -INFINITY)) continue;  // nothing visible to any query of this wave yet (barriers are at the loop top)
+        const float alpha = m == -INFINITY ? 0.0f : expf(m - m_new);
+        float rs = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sv = S[t][r];
+                const float p = sv == -INFINITY ? 0.0f : expf(sv - m_new);
+                S[t][r] = p;
+                rs += p;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+        // ---- O^T += V^T·P^T
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8 pb;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pb[u] = (_Float16) S[t][8 * s2 + u];
+                const int kvo = (32 * t + 16 * s2 + 4 * kg) * 2;  // byte offset of this half's first run inside a V^T row
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    const char * vrow = Vt + (32 * dt + fr) * VS + kvo;
+                    const half4v a0 = *(const half4v *) vrow, a1 = *(const half4v *) (vrow + 16);
+                    const half8 a = (half8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, O[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (qi < geo.n_q) {
+        const float inv = 1.0f / l;
+        float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) qi * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = 32 * dt + 8 * g4 + 4 * kg;
+                *(float4 *) (out + d0) = make_float4(O[dt][4 * g4] * inv, O[dt][4 * g4 + 1] * inv, O[dt][4 * g4 + 2] * inv, O[dt][4 * g4 + 3] * inv);
+            }
+    }
+}
+
+// returns false when this variant does not apply (caller falls back to the split-KV kernel)
+bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
+                           const fattn_params & p) {
+    const int D = (int) k.ne[0];
+    if (q.ne[1] < 32 || sinks != nullptr || p.max_bias != 0.0f || p.logit_softcap != 0.0f || (D != 64 && D != 128)) return false;
+    if ((k.ne[1] % 4) != 0 || (q.nb[1] % 16) || (q.nb[2] % 16) || (((uintptr_t) q.data) & 15) || (dst.nb[1] % 16) || (dst.nb[2] % 16) || (((uintptr_t) dst.data) & 15)) return false;
+    if (mask && ((mask->nb[1] % 8) || (((uintptr_t) mask->data) & 7))) return false;
+    fam_geom geo;
+    geo.n_q = (int) q.ne[1];
+    geo.n_head = (int) q.ne[2];
+    geo.n_kv_head = (int) k.ne[2];
+    geo.n_kv = (int) k.ne[1];
+    geo.has_mask = mask ? 1 : 0;
+    geo.scale = p.scale;
+    const tdesc mk = mask ? *mask : q;
+    dim3 grid((unsigned) ((geo.n_q + 63) / 64), (unsigned) geo.n_head, (unsigned) q.ne[3]);
+    if (D == 128) {
+        const size_t lds = 64 * (128 + 8) * 2 + 128 * (64 + 4) * 2;
+        hipLaunchKernelGGL(k_fattn_mma<128>, grid, dim3(128), lds, s, q, k, v, mk, dst, geo);
+    } else {
+        const size_t lds = 64 * (64 + 8) * 2 + 64 * (64 + 4) * 2;
+        hipLaunchKernelGGL(k_fattn_mma<64>, grid, dim3(128), lds, s, q, k, v, mk, dst, geo);
+    }
+    return true;
+}
+
+}  // namespace mi355x

@@ -115,5 +115,8 @@ size_t fattn_workspace_bytes(const tdesc & q, const tdesc & v, int n_splits);
 int fattn_pick_splits(const tdesc & q, const tdesc & k);
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks,
                        const tdesc & dst, const fattn_params & p, void * workspace);
+// matrix-core variant for batches of >= 32 query tokens (fattn_mma.hip); false = does not apply
+bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
+                           const fattn_params & p);
 
 }  // namespace mi355x

@@ -365,6 +365,13 @@ FA_CASES = [  # (HD, NH, NKV, n_q, n_kv, splits, softcap, alibi, sinks)
     (64, 4, 2, 2, 256, 2, 0.0, 8.0, False),
     (128, 16, 2, 1, 768, 3, 0.0, 0.0, True),
     (64, 2, 1, 7, 256, 0, 0.0, 0.0, False),
+    # >= 32 query tokens: the matrix-core kernel (fattn_mma.hip); ragged query tiles, fully-masked KV tiles, KV tails
+    (128, 32, 8, 64, 512, 0, 0.0, 0.0, False),
+    (128, 8, 2, 200, 256, 0, 0.0, 0.0, False),
+    (128, 4, 4, 33, 260, 0, 0.0, 0.0, False),
+    (64, 4, 2, 96, 256, 0, 0.0, 0.0, False),
+    (64, 8, 1, 130, 1024, 0, 0.0, 0.0, False),
+    (128, 4, 2, 40, 256, 2, 20.0, 0.0, False),  # softcap -> falls back to the split-KV kernel
 ]
 
 
@@ -375,7 +382,8 @@ def test_flash_attn(backend, H, plog, HD, NH, NKV, nq, nkv, splits, softcap, ali
     q = rng.standard_normal((NH, nq, HD)).astype(np.float32)
     kc = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
     vc = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
-    mask = np.full((64, nkv), -np.inf, np.float16)
+    MR = (max(nq, 1) + 63) // 64 * 64
+    mask = np.full((MR, nkv), -np.inf, np.float16)
     for t in range(nq):
         mask[t, : nkv - nq + t + 1 - 17] = 0  # causal-ish with a masked tail (padding cells)
         mask[t, 5] = -np.inf                  # a hole (cell of another sequence)
@@ -388,7 +396,7 @@ def test_flash_attn(backend, H, plog, HD, NH, NKV, nq, nkv, splits, softcap, ali
         v_cache = g.new(L.F16, [NKV * HD, NCTX], vc)
         k = H.ggml_view_3d(g.ctx, k_cache, HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
         v = H.ggml_view_3d(g.ctx, v_cache, HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
-        r = H.ggml_flash_attn_ext(g.ctx, tq, k, v, g.new(L.F16, [nkv, 64], mask), 1.0 / np.sqrt(HD), alibi, softcap)
+        r = H.ggml_flash_attn_ext(g.ctx, tq, k, v, g.new(L.F16, [nkv, MR], mask), 1.0 / np.sqrt(HD), alibi, softcap)
         H.ggml_flash_attn_ext_set_prec(r, 10)
         if sinks:
             H.ggml_flash_attn_ext_add_sinks(r, g.new(L.F32, [NH], sk))
@@ -421,7 +429,8 @@ def test_flash_attn(backend, H, plog, HD, NH, NKV, nq, nkv, splits, softcap, ali
             exact[t, h] = (p @ vf[:, h // (NH // NKV)]) / den
     e_gpu, e_cpu = T.nmse(got[0].reshape(nq, NH, HD), exact), T.nmse(ref[0].reshape(nq, NH, HD), exact)
     plog(f"    vs exact attention: kernel nmse={e_gpu:.3e}  cpu-oracle nmse={e_cpu:.3e}")
-    assert e_gpu <= 1e-9 and e_gpu <= e_cpu * 1.01 + 1e-12
+    # (the matrix-core kernel rounds P to f16 once per element; the CPU path rounds the whole V accumulator every step)
+    assert e_gpu <= (1e-9 if nq < 32 or softcap else 3e-7) and e_gpu <= e_cpu * 1.01 + 1e-12
 
 
 # ------------------------------------------------------------------------------------------------ fused chains
