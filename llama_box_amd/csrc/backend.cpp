@@ -261,6 +261,8 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_PROLOGUE")) c->opt.prologue = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_QKV")) c->opt.qkv = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_MIN_COLS")) c->opt.mmq_min_cols = atoi(e);
+    if (const char * e = getenv("GGML_MI355X_MMQ_I8")) c->opt.mmq_i8 = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_MMQ_BN")) c->opt.mmq_bn = atoi(e);
     return new ggml_backend{&g_guid, k_backend_iface, dev, c};
 }
 static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &dctx(dev)->buft; }
@@ -316,6 +318,8 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "qkv") c->opt.qkv = v != 0;
     else if (k == "mmvq_max_cols") c->opt.mmvq_max_cols = v;
     else if (k == "mmq_min_cols") c->opt.mmq_min_cols = v;
+    else if (k == "mmq_i8") c->opt.mmq_i8 = v != 0;
+    else if (k == "mmq_bn") c->opt.mmq_bn = v;
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "timing") c->opt.timing = v != 0;
     else return -1;

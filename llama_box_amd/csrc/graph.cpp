@@ -242,6 +242,9 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const void * act = quantized_src1(st, b, w->type);
     if (M >= c->opt.mmq_min_cols && !w2 && !add && mmq_supported(w->type, K, N, M)) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
+        if (c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M))
+            launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn);
+        else
         launch_mmq(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4));
         c->st.kernel_launches++;
         return true;

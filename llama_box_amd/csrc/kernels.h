@@ -85,6 +85,9 @@ void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, con
 // ---- prefill: quantised weights x many columns through MFMA (mmq.hip)
 bool mmq_supported(int type, int64_t K, int64_t N, int64_t M);
 size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M);
+// int8-matrix-core variant for Q4_K / Q5_K (mmq_i8.hip); force_bn: 0 = auto, 64 / 128 = weight-panel height
+bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M);
+void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn);
 void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride);
 
 // ---- element-wise / normalisation / data movement (ops.hip)

@@ -1,0 +1,326 @@
+// mmq_i8.hip — prefill / large-batch mat-mul for Q4_K and Q5_K weights on the gfx950 INTEGER matrix cores.
+//
+// Same contract as mmq.hip (ggml-cpu's ggml_vec_dot_q{4,5}_K_q8_K: integer block sums on Q8_K activations, one f32
+// scale-accumulate per super-block — SURVEY.md §8a row a6), but the block sums are computed by v_mfma_i32_32x32x32_i8:
+//   * the activation tile is the raw int8 of the Q8_K blocks — copied global -> LDS, no conversion at all;
+//   * the weight tile must carry the 6-bit sub-block scale (it changes every 32 values of K, i.e. every MFMA), and
+//     sc * q does not fit int8.  The scale is therefore split into small digits, sc = 8*s1 + s0 (Q4_K: q <= 15, digits
+//     <= 7, products <= 105) or sc = 16*s2 + 4*s1 + s0 (Q5_K: q <= 31, digits <= 3, products <= 93), one int8 tile
+//     ("piece") per digit, one MFMA per piece, and the int32 accumulators are recombined with shifts — still exactly
+//     the CPU's integers (int32 accumulation never rounds, unlike the f32 accumulation of the f16 variant which is
+//     exact only below 2^24).  i8 MFMA runs at twice the f16 rate, so two pieces cost what the f16 kernel's one costs;
+//   * four nibbles of a dword are multiplied by their digit with ONE v_pk_mul_lo_u16 (each byte product < 256, so no
+//     carries cross bytes): the whole weight staging is ~30 VALU per 32 weights instead of ~90;
+//   * the mins term keeps the f16 MFMA step of mmq.hip (one per super-block).
+// LDS tiles are [row][128 B of K] with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 — conflict-free for the
+// ds_read_b128 lane groups of gfx950 without padding — and DOUBLE-buffered: trip t+1 is converted and written while
+// the MFMAs of trip t run, one barrier per trip.  BN = 128 (8 waves) or 64 (4 waves; used when the grid would not
+// fill 256 CUs otherwise); each wave owns 32 weight rows x 64 activation columns.
+#include <algorithm>
+
+#include "dev_util.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int16v __attribute__((ext_vector_type(16)));
+
+struct mmq8_args {
+    const uint8_t * W;
+    int64_t w_nb1;
+    int K, N, M;
+    const q8k_dev * act;  // [M][K/256]
+    float * dst;
+    int64_t dst_stride;
+    int n_panels, m_tiles;
+};
+
+constexpr int MI_BM = 128;
+constexpr int MI_MS = (16 + 8) * 2;  // row stride of the 16-wide f16 mins / bsums tiles (48 B)
+
+__device__ __forceinline__ uint32_t pk_mul_u16x2(const uint32_t a, const uint32_t b) {
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    const ushort2v r = __builtin_bit_cast(ushort2v, a) * __builtin_bit_cast(ushort2v, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pack_h2i(const int a, const int b) {
+    const _Float16 x = (_Float16) a, y = (_Float16) b;
+    uint16_t ux, uy;
+    __builtin_memcpy(&ux, &x, 2);
+    __builtin_memcpy(&uy, &y, 2);
+    return (uint32_t) ux | ((uint32_t) uy << 16);
+}
+__device__ __forceinline__ int sw_off(const int row, const int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int QT, int BN>
+__global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = BN * 4;
+    constexpr int NP = QT == 4 ? 2 : 3;
+    constexpr int BYTES = QT == 4 ? 144 : 176;
+    constexpr int TA = BN * 128, TB = MI_BM * 128, STAGE = NP * TA + TB;
+    constexpr int NBC = (MI_BM * 8) / NT;  // 16-byte activation chunks per thread per trip
+    char * Am = smem + 2 * STAGE;                   // mins  [BN][24] f16
+    char * Bm = Am + BN * MI_MS;                    // bsums [128][24] f16
+    float2 * dd = (float2 *) (Bm + MI_BM * MI_MS);  // (d, dmin) per row
+    float * dyv = (float *) (dd + BN);              // dy per column
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int panel = (qb / a.m_tiles) * 8 + xcd, mt = qb % a.m_tiles;
+    if (panel >= a.n_panels) return;
+    const int n0 = panel * BN, m0 = mt * MI_BM;
+    const int nblk = a.K / 256;
+    const int nslab = wave % (BN / 32), mhalf = wave / (BN / 32);
+
+    // staging roles
+    const int arow = tid >> 2, aq = tid & 3;
+    const uint8_t * wrow = a.W + (size_t) min(n0 + arow, a.N - 1) * a.w_nb1;
+    // (scalars, not arrays: arrays captured by the staging lambdas end up in scratch memory)
+    auto b_src = [&](const int i) { const int c = tid + i * NT; return a.act[(size_t) min(m0 + (c >> 3), a.M - 1) * nblk].qs + 16 * (c & 7); };
+    auto b_off = [&](const int i) { const int c = tid + i * NT; return sw_off(c >> 3, c & 7); };
+    const int8_t * bsrc0 = b_src(0), * bsrc1 = b_src(1), * bsrc2 = b_src(NBC > 2 ? 2 : 0), * bsrc3 = b_src(NBC > 2 ? 3 : 0);
+    const int boff0 = b_off(0), boff1 = b_off(1), boff2 = b_off(NBC > 2 ? 2 : 0), boff3 = b_off(NBC > 2 ? 3 : 0);
+    const q8k_dev * mcol = a.act + (size_t) min(m0 + (tid & 127), a.M - 1) * nblk;  // column whose bsums / d this thread stages (tid < 128)
+    const int c_lo = 4 * (aq >> 1) + (aq & 1);
+    const int aoff_lo = sw_off(arow, c_lo), aoff_hi = sw_off(arow, c_lo + 2);
+
+    float16v C[2];
+    int16v acc[NP][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            C[t][r] = 0.0f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[p][t][r] = 0;
+        }
+    const float16v zerof = C[0];
+
+    // raw global data of the NEXT trip to be staged
+    uint4 g_hdr, g_q, g_qh, g_b0, g_b1, g_b2, g_b3, g_bs0, g_bs1;
+    float g_dy = 0.0f;
+    auto issue_loads = [&](const int sb, const int h) {
+        const uint8_t * blk = wrow + (size_t) sb * BYTES;
+        g_hdr = *(const uint4 *) blk;
+        g_q = *(const uint4 *) (blk + (QT == 5 ? 48 : 16) + 64 * h + 16 * aq);
+        if constexpr (QT == 5) g_qh = *(const uint4 *) (blk + 16 + 16 * (aq & 1));
+        const size_t bo = (size_t) sb * sizeof(q8k_dev) + 128 * h;
+        g_b0 = *(const uint4 *) (bsrc0 + bo);
+        g_b1 = *(const uint4 *) (bsrc1 + bo);
+        if constexpr (NBC > 2) {
+            g_b2 = *(const uint4 *) (bsrc2 + bo);
+            g_b3 = *(const uint4 *) (bsrc3 + bo);
+        }
+        if (h == 1 && tid < 128) {
+            g_bs0 = *(const uint4 *) mcol[sb].bsums;
+            g_bs1 = *(const uint4 *) (mcol[sb].bsums + 8);
+            g_dy = mcol[sb].d;
+        }
+    };
+
+    auto stage = [&](const int h) {
+        char * buf = smem + h * STAGE;
+        // ---- weight pieces: this thread owns 16 values of sub-block 2*j2 (low nibbles) and of 2*j2+1 (high nibbles)
+        const int j2 = 2 * h + (aq >> 1);
+        uint32_t scp;  // (sc of sub-block 2*j2) | (sc of 2*j2+1) << 8
+        {
+            const int sh = 16 * (j2 & 1);
+            const uint32_t aa = (g_hdr.y >> sh) & 0xFFFFu, ww = (g_hdr.w >> sh) & 0xFFFFu;
+            scp = j2 < 2 ? (aa & 0x3F3Fu) : ((ww & 0x0F0Fu) | ((aa & 0xC0C0u) >> 2));
+        }
+        const uint32_t sc0 = scp & 0xFF, sc1 = scp >> 8;
+        uint32_t dlo[NP], dhi[NP];  // per-piece digits, replicated into both 16-bit lanes
+        if constexpr (QT == 4) {
+            dlo[0] = (sc0 >> 3) * 0x00010001u; dlo[1] = (sc0 & 7) * 0x00010001u;
+            dhi[0] = (sc1 >> 3) * 0x00010001u; dhi[1] = (sc1 & 7) * 0x00010001u;
+        } else {
+            dlo[0] = (sc0 >> 4) * 0x00010001u; dlo[1] = ((sc0 >> 2) & 3) * 0x00010001u; dlo[2] = (sc0 & 3) * 0x00010001u;
+            dhi[0] = (sc1 >> 4) * 0x00010001u; dhi[1] = ((sc1 >> 2) & 3) * 0x00010001u; dhi[2] = (sc1 & 3) * 0x00010001u;
+        }
+        const uint32_t qv[4] = {g_q.x, g_q.y, g_q.z, g_q.w};
+        uint32_t l4[4], h4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            l4[k] = qv[k] & 0x0F0F0F0Fu;
+            h4[k] = (qv[k] >> 4) & 0x0F0F0F0Fu;
+            if constexpr (QT == 5) {
+                const uint32_t qh = k == 0 ? g_qh.x : (k == 1 ? g_qh.y : (k == 2 ? g_qh.z : g_qh.w));
+                l4[k] |= ((qh >> (2 * j2)) & 0x01010101u) << 4;
+                h4[k] |= ((qh >> (2 * j2 + 1)) & 0x01010101u) << 4;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            char * Ap = buf + p * TA;
+            *(uint4 *) (Ap + aoff_lo) = make_uint4(pk_mul_u16x2(l4[0], dlo[p]), pk_mul_u16x2(l4[1], dlo[p]), pk_mul_u16x2(l4[2], dlo[p]), pk_mul_u16x2(l4[3], dlo[p]));
+            *(uint4 *) (Ap + aoff_hi) = make_uint4(pk_mul_u16x2(h4[0], dhi[p]), pk_mul_u16x2(h4[1], dhi[p]), pk_mul_u16x2(h4[2], dhi[p]), pk_mul_u16x2(h4[3], dhi[p]));
+        }
+        // ---- activation tile: raw int8
+        char * Bt = buf + NP * TA;
+        *(uint4 *) (Bt + boff0) = g_b0;
+        *(uint4 *) (Bt + boff1) = g_b1;
+        if constexpr (NBC > 2) {
+            *(uint4 *) (Bt + boff2) = g_b2;
+            *(uint4 *) (Bt + boff3) = g_b3;
+        }
+        // ---- per-super-block metadata (staged with the second half; consumed at the end of that trip)
+        if (h == 1) {
+            if (aq == 0) {
+                const float d = h2f((uint16_t) (g_hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (g_hdr.x >> 16));
+                dd[arow] = make_float2(d, dmin);
+                const uint32_t hz = g_hdr.z, hw = g_hdr.w;
+                uint32_t pm[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int mlo = (int) ((hz >> (8 * j)) & 63);
+                    const int mhi = (int) (((hw >> (8 * j + 4)) & 0xF) | ((((hz >> (8 * j)) & 0xFF) >> 6) << 4));
+                    pm[j] = pack_h2i(mlo, mlo);
+                    pm[j + 4] = pack_h2i(mhi, mhi);
+                }
+                uint4 * dm = (uint4 *) (Am + arow * MI_MS);
+                dm[0] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+                dm[1] = make_uint4(pm[4], pm[5], pm[6], pm[7]);
+            }
+            if (tid < 128) {
+                dyv[tid] = g_dy;
+                const uint32_t bw[8] = {g_bs0.x, g_bs0.y, g_bs0.z, g_bs0.w, g_bs1.x, g_bs1.y, g_bs1.z, g_bs1.w};
+                uint32_t pb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = pack_h2i((int) (int16_t) (bw[j] & 0xFFFF), (int) (int16_t) (bw[j] >> 16));
+                uint4 * dbm = (uint4 *) (Bm + tid * MI_MS);
+                dbm[0] = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+                dbm[1] = make_uint4(pb[4], pb[5], pb[6], pb[7]);
+            }
+        }
+    };
+
+    const int fr = lane & 31, kg = lane >> 5;
+    const int swz = (fr >> 1) & 7;
+    const int arow_off = (nslab * 32 + fr) * 128;
+    const int brow_off[2] = {(mhalf * 64 + fr) * 128, (mhalf * 64 + 32 + fr) * 128};
+
+    auto mma = [&](const int h) {
+        const char * buf = smem + h * STAGE;
+        const char * Bt = buf + NP * TA;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int co = ((2 * ks + kg) ^ swz) << 4;
+            int4v fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fb[t] = *(const int4v *) (Bt + brow_off[t] + co);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int4v fa = *(const int4v *) (buf + p * TA + arow_off + co);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[p][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[t], acc[p][t], 0, 0, 0);
+            }
+        }
+    };
+
+    auto fold = [&]() {
+        const half8 fam = *(const half8 *) (Am + (nslab * 32 + fr) * MI_MS + kg * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const half8 fbm = *(const half8 *) (Bm + (mhalf * 64 + t * 32 + fr) * MI_MS + kg * 16);
+            const float16v am = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fbm, zerof, 0, 0, 0);
+            const float dy = dyv[mhalf * 64 + t * 32 + fr];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = nslab * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const float2 sd = dd[i];
+                int isum;
+                if constexpr (QT == 4) isum = (acc[0][t][r] << 3) + acc[1][t][r];
+                else isum = (acc[0][t][r] << 4) + (acc[1][t][r] << 2) + acc[2][t][r];
+                const float v = sd.x * (float) isum - sd.y * am[r];
+                C[t][r] += dy * v;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[p][t][r] = 0;
+            }
+        }
+    };
+
+    issue_loads(0, 0);
+    stage(0);
+    issue_loads(0, 1);
+    __syncthreads();
+    for (int sb = 0; sb < nblk; ++sb) {
+        // trip (sb, 0): convert + write the second half while the MFMAs of the first half run
+        stage(1);
+        if (sb + 1 < nblk) issue_loads(sb + 1, 0);
+        mma(0);
+        __syncthreads();
+        // trip (sb, 1)
+        if (sb + 1 < nblk) {
+            stage(0);
+            issue_loads(sb + 1, 1);
+        }
+        mma(1);
+        fold();
+        __syncthreads();
+    }
+    // ---- store: lane holds column (token) j and 4 runs of 4 consecutive rows
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m0 + mhalf * 64 + t * 32 + fr;
+        if (m >= a.M) continue;
+        float * out = a.dst + (size_t) m * a.dst_stride;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + nslab * 32 + 8 * g + 4 * kg;
+            if (n + 3 < a.N && ((((uintptr_t) (out + n)) & 15) == 0)) {
+                *(float4 *) (out + n) = make_float4(C[t][4 * g], C[t][4 * g + 1], C[t][4 * g + 2], C[t][4 * g + 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < a.N) out[n + r] = C[t][4 * g + r];
+            }
+        }
+    }
+}
+
+bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M) {
+    (void) N;
+    return (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K) && (K % 256) == 0 && M >= 9;
+}
+
+template <int QT, int BN> static void launch_mmq8_t(hipStream_t s, mmq8_args a) {
+    constexpr int NP = QT == 4 ? 2 : 3;
+    const size_t lds = 2 * (size_t) (NP * BN * 128 + MI_BM * 128) + (size_t) (BN + MI_BM) * MI_MS + BN * sizeof(float2) + MI_BM * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) k_mmq_i8<QT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        attr_set = true;
+    }
+    a.n_panels = (a.N + BN - 1) / BN;
+    a.m_tiles = (a.M + MI_BM - 1) / MI_BM;
+    const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
+    hipLaunchKernelGGL((k_mmq_i8<QT, BN>), dim3(grid), dim3(BN * 4), lds, s, a);
+}
+
+void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn) {
+    mmq8_args a;
+    a.W = W;
+    a.w_nb1 = w_nb1;
+    a.K = K;
+    a.N = N;
+    a.M = M;
+    a.act = (const q8k_dev *) act_q8k;
+    a.dst = dst;
+    a.dst_stride = dst_stride;
+    a.n_panels = a.m_tiles = 0;
+    // 128-row panels unless that leaves CUs idle (256 CUs, one 8-wave workgroup each)
+    const int64_t wg128 = (int64_t) ((N + 127) / 128) * ((M + MI_BM - 1) / MI_BM);
+    const int bn = force_bn ? force_bn : (wg128 >= 256 ? 128 : 64);
+    if (type == GGML_TYPE_Q4_K) {
+        if (bn == 128) launch_mmq8_t<4, 128>(s, a);
+        else launch_mmq8_t<4, 64>(s, a);
+    } else {
+        if (bn == 128) launch_mmq8_t<5, 128>(s, a);
+        else launch_mmq8_t<5, 64>(s, a);
+    }
+}
+
+}  // namespace mi355x

@@ -49,6 +49,29 @@ def test_mul_mat_q(backend, H, plog, qt, K, N, M):
     T.compare(f"mul_mat {QNAME[qt]} K={K} N={N} M={M}", got[0], ref[0], max_nmse=1e-10, log=plog)
 
 
+@pytest.mark.parametrize("i8,bn", [(1, 64), (1, 128), (0, 0)])
+@pytest.mark.parametrize("qt", [L.Q4_K, L.Q5_K])
+@pytest.mark.parametrize("K,N,M", [(512, 128, 128), (1024, 200, 300), (2048, 384, 512), (256, 130, 33)])
+def test_mul_mat_q_matrix_core_variants(backend, H, plog, qt, K, N, M, i8, bn):
+    """Q4_K / Q5_K batches: int8-MFMA kernel with 64- and 128-row panels (mmq_i8.hip) and the f16-MFMA kernel (mmq.hip)."""
+    rng = np.random.default_rng(K * 31 + N * 7 + M + qt)
+    w = T.rand_weight(qt, K, N, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    x[1, 256:512] = 0.0
+
+    def build(g):
+        return H.ggml_mul_mat(g.ctx, g.new(qt, [K, N], w), g.new(L.F32, [K, M], x))
+
+    backend.set_option("mmq_i8", i8)
+    backend.set_option("mmq_bn", bn)
+    try:
+        ref, got = both(build, backend)
+    finally:
+        backend.set_option("mmq_i8", 1)
+        backend.set_option("mmq_bn", 0)
+    T.compare(f"mul_mat {QNAME[qt]} K={K} N={N} M={M} i8={i8} bn={bn}", got[0], ref[0], max_nmse=1e-10, log=plog)
+
+
 @pytest.mark.parametrize("qt", QTYPES)
 def test_mul_mat_q_3d_src1(backend, H, plog, qt):
     """src1 with ne12 > 1 (all rows of src1 are columns of the product) and a strided (permuted) src1."""
