@@ -28,6 +28,55 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+# kernel-class tag (graph.cpp timed_scope) -> substring of the kernel symbol rocprofv3 reports
+def _class_to_symbol(cls):
+    parts = cls.split("_")
+    if parts[0] != "mmvq":
+        return None
+    ty = {"q4": "T_Q4K", "q5": "T_Q5K", "q6": "T_Q6K", "q8": "T_Q80"}.get(parts[1])
+    if ty is None:
+        return None
+    glu = "true" if "glu" in parts else "false"
+    pro = "2" if cls.endswith("normpro") else "1"
+    return f"k_mmvq_stream<mi355x::{ty}, {glu}, {pro}>"
+
+
+def pmc_traffic(symbol, args):
+    """HBM bytes per launch of `symbol` from rocprofv3's FETCH_SIZE (its own --pmc pass over a short decode run of this
+    same script).  FETCH_SIZE is in KiB and, on gfx950, tallies the 128-byte requests of wide streaming reads at 64 B
+    (MI355X_MICROARCH.md, HBM section): bytes = FETCH_SIZE * 1024 * 2."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_CHILD="1")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", out, "-o", "pmc", "--output-format", "csv", "--",
+           sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--prefill", "256", "--timing-steps", "0", "--no-cpu-baseline",
+           "--pmc-traffic", "0", "--preset", args.preset, "--fa", str(args.fa), "--np", str(args.np)]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None, "no counter_collection.csv"
+        tot, n = 0.0, 0
+        with open(files[0]) as f:
+            for row in csv.DictReader(f):
+                if symbol in row.get("Kernel_Name", "") and row.get("Counter_Name") == "FETCH_SIZE":
+                    tot += float(row["Counter_Value"])
+                    n += 1
+        if n == 0:
+            return None, f"kernel {symbol} not in the PMC pass"
+        return tot / n * 1024.0 * 2.0, f"rocprofv3 --pmc FETCH_SIZE, own pass, {n} launches, KiB x 1024 x 2 (gfx950 half-count correction)"
+    except Exception as e:  # never let the optional pass break the bench line
+        return None, str(e)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--timing-steps", type=int, default=16)
+    ap.add_argument("--pmc-traffic", type=int, default=1, help="1: re-run a short decode under rocprofv3 --pmc FETCH_SIZE (own pass) for roofline.traffic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,6 +202,13 @@ def main():
                         "traffic": None, "launches": cnt, "avg_us": round(ms * 1e3 / cnt, 2), "alg_bytes_per_launch": round(nbytes / cnt)}
     except Exception as e:
         roofline = {"error": str(e)}
+    if roofline and "kernel" in roofline and args.pmc_traffic and rank == 0 and world == 1 and not os.environ.get("BENCH_PMC_CHILD"):
+        sym = _class_to_symbol(roofline["kernel"])
+        if sym:
+            torch.cuda.synchronize()
+            tr, how = pmc_traffic(sym, args)
+            roofline["traffic"] = round(tr) if tr else None
+            roofline["traffic_source"] = how
 
     # ---- CPU baseline: the oracle (restated ggml-cpu), same model shape, on this host's cores
     cpu_baseline = None

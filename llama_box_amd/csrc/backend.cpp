@@ -261,6 +261,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_PROLOGUE")) c->opt.prologue = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_QKV")) c->opt.qkv = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_MIN_COLS")) c->opt.mmq_min_cols = atoi(e);
+    if (const char * e = getenv("GGML_MI355X_FA_SPLITS")) c->opt.fa_splits = atoi(e);
     if (const char * e = getenv("GGML_MI355X_MMQ_I8")) c->opt.mmq_i8 = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_BN")) c->opt.mmq_bn = atoi(e);
     return new ggml_backend{&g_guid, k_backend_iface, dev, c};

@@ -23,16 +23,26 @@ struct fa_geom {
     uint32_t n_head_log2;
 };
 
+// element-wise all-reduce over the four 16-lane DPP rows of a wave (lane l ends with x[l&15] + x[16+(l&15)] + ...):
+// gfx950's v_permlane{16,32}_swap exchange odd/even rows (halves) of two registers, so two swaps and two adds do it
+// without touching LDS.  (Inline asm: with identical operands the builtin form folds to x + x in this compiler.)
+__device__ __forceinline__ float xrow_allsum(const float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float y = a + b;
+    a = y;
+    b = y;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 template <int D, int G>
 __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
                                                      const tdesc dst, const fa_geom geo, float * __restrict__ ws) {
     constexpr int LPR = D / 8;     // lanes per K/V row
     constexpr int RPW = 64 / LPR;  // rows per wave-instruction
-    constexpr bool SLOTS_ALL = (size_t) 4 * RPW * G * (D + 2) * sizeof(float) <= 48 * 1024;
-    constexpr int NSLOT = SLOTS_ALL ? 4 * RPW : 4;
-    __shared__ float sh[NSLOT][G][D + 2];
-    __shared__ float coef[NSLOT][G];
-    __shared__ float mtot[G];
+    constexpr int NG = 4;          // row groups in flight per wave and trip: 4 waves x NG x RPW positions per trip
+    __shared__ float sh[4][G][D + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane / LPR, sl = lane % LPR;
     const int split = blockIdx.x, kvh = blockIdx.y;
@@ -40,167 +50,146 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
     const int per = (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
     const int kv0 = split * per, kv1 = min(geo.n_kv, kv0 + per);
     const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
+    const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
+    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
+
+    // K/V of the first trip are requested before anything else: for decode-sized splits that is the only trip, and
+    // the whole kernel is then ONE memory round trip + arithmetic + the cross-wave merge
+    uint4 kraw[NG], vraw[NG];
+    float mv[NG];
+    bool inr[NG];
+    int p0 = kv0 + wave * RPW;
+#define FA_LOAD_TRIP()                                                        \
+    _Pragma("unroll") for (int u = 0; u < NG; ++u) {                         \
+        const int p = p0 + u * 4 * RPW + sub;                                 \
+        inr[u] = p < kv1;                                                     \
+        const int pc = min(p, kv1 - 1);                                       \
+        mv[u] = mp ? h2f(mp[pc]) : 0.0f;                                      \
+        kraw[u] = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);          \
+        vraw[u] = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);          \
+    }
+    if (kv0 < kv1) { FA_LOAD_TRIP() }
 
     float qr[G][8], acc[G][8], m[G], l[G], slope[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int h = kvh * G + g;
-        const float * qp = (const float *) (q.data + (int64_t) tok * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]) + sl * 8;
+        const float4 * qp = (const float4 *) ((const float *) (q.data + (int64_t) tok * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]) + sl * 8);
+        const float4 qa = qp[0], qb = qp[1];
+        const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            qr[g][i] = h2f(f2h(qp[i]));  // q_to_vec_dot: Q is converted to K's vec_dot_type (f16)
+            qr[g][i] = h2f(f2h(qv[i]));  // q_to_vec_dot: Q is converted to K's vec_dot_type (f16)
             acc[g][i] = 0.0f;
         }
         m[g] = -INFINITY;
         l[g] = 0.0f;
         slope[g] = geo.max_bias > 0.0f ? ((uint32_t) h < geo.n_head_log2 ? powf(geo.m0, (float) (h + 1)) : powf(geo.m1, (float) (2 * (h - geo.n_head_log2) + 1))) : 1.0f;
     }
-    const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
-    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
-    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
 
-    // NG independent row groups per trip; the NEXT trip's K/V loads are issued before the current trip is consumed, so
-    // the memory round trips of successive trips overlap with the softmax arithmetic
-    constexpr int NG = 2;
-    struct trip_regs {
-        uint4 kraw[NG], vraw[NG];
-        float mv[NG];
-        bool inr[NG];
-    };
-    auto load_trip = [&](const int p0, trip_regs & t) {
+    // One softmax state per WAVE (not per row): a trip computes all its scores first, takes the wave-wide maximum on the
+    // DPP path, rescales once, and only then exponentiates — one expf per (position, head), no data-dependent branches,
+    // and the rows of a wave later merge by plain addition.
+    for (; p0 < kv1; p0 += NG * 4 * RPW) {
+        float sc[NG][G];
+        float vf[NG][8];
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
-            const int p = p0 + u * 4 * RPW + sub;
-            t.inr[u] = p < kv1;
-            const int pc = t.inr[u] ? p : kv1 - 1;
-            t.mv[u] = mp ? h2f(mp[pc]) : 0.0f;
-            t.kraw[u] = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);
-            t.vraw[u] = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);
-        }
-    };
-    trip_regs cur;
-    int p0 = kv0 + wave * RPW;
-    bool have = p0 < kv1;
-    if (have) load_trip(p0, cur);
-    while (have) {
-        const int pn = p0 + NG * 4 * RPW;
-        const bool nhave = pn < kv1;
-        trip_regs nxt;
-        if (nhave) load_trip(pn, nxt);
-#pragma unroll
-        for (int u = 0; u < NG; ++u) {
-            const uint32_t ku[4] = {cur.kraw[u].x, cur.kraw[u].y, cur.kraw[u].z, cur.kraw[u].w}, vu[4] = {cur.vraw[u].x, cur.vraw[u].y, cur.vraw[u].z, cur.vraw[u].w};
-            float kf[8], vf[8];
+            const uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
+            float kf[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 kf[2 * i] = h2f((uint16_t) (ku[i] & 0xFFFF));
                 kf[2 * i + 1] = h2f((uint16_t) (ku[i] >> 16));
-                vf[2 * i] = h2f((uint16_t) (vu[i] & 0xFFFF));
-                vf[2 * i + 1] = h2f((uint16_t) (vu[i] >> 16));
+                vf[u][2 * i] = h2f((uint16_t) (vu[i] & 0xFFFF));
+                vf[u][2 * i + 1] = h2f((uint16_t) (vu[i] >> 16));
             }
-            float sc[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 float t = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) t = fmaf(kf[i], qr[g][i], t);
-                sc[g] = t;
-            }
-            // finish the D-wide dot inside the LPR lanes of the row on the DPP path (LPR = 16: one DPP row; LPR = 8: half a row)
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
+                // finish the D-wide dot inside the LPR lanes of the row on the DPP path
                 if constexpr (LPR == 16) {
-                    sc[g] = row16_sum(sc[g]);
+                    t = row16_sum(t);
                 } else {
-                    sc[g] += dpp_f32<MI_DPP_QUAD_XOR1>(sc[g]);
-                    sc[g] += dpp_f32<MI_DPP_QUAD_XOR2>(sc[g]);
-                    sc[g] += dpp_f32<MI_DPP_HALF_MIRROR>(sc[g]);
+                    t += dpp_f32<MI_DPP_QUAD_XOR1>(t);
+                    t += dpp_f32<MI_DPP_QUAD_XOR2>(t);
+                    t += dpp_f32<MI_DPP_HALF_MIRROR>(t);
                 }
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float sv = sc[g] * geo.scale;
+                float sv = t * geo.scale;
                 if (geo.softcap != 0.0f) sv = geo.softcap * tanhf(sv);
-                const float mvs = slope[g] * cur.mv[u];
+                const float mvs = slope[g] * mv[u];
                 sv += mvs;
-                const bool use = cur.inr[u] && !(mvs == -INFINITY);
-                if (use) {
-                    float vs = 1.0f;
-                    if (sv > m[g]) {
-                        const float ms = expf(m[g] - sv);
-                        l[g] *= ms;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[g][i] *= ms;
-                        m[g] = sv;
-                    } else {
-                        vs = expf(sv - m[g]);
-                    }
-                    l[g] += vs;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[g][i] = fmaf(vs, vf[i], acc[g][i]);
-                }
+                sc[u][g] = (inr[u] && !(mvs == -INFINITY)) ? sv : -INFINITY;
             }
         }
-        cur = nxt;
-        p0 = pn;
-        have = nhave;
-    }
-    // every (wave, sub-row) partial goes to LDS as its own slot (no cross-lane shuffles: the round-1 profile showed the
-    // 10 x G ds_bpermute per merge level dominating short splits); when the slots would not fit, sub-rows are first
-    // merged in registers
-    if constexpr (!SLOTS_ALL) {
-#pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const float mo = __shfl_xor(m[g], o, 64), lo = __shfl_xor(l[g], o, 64);
-                const float mn = fmaxf(m[g], mo);
-                const float ca = m[g] == -INFINITY ? 0.0f : expf(m[g] - mn);
-                const float cb = mo == -INFINITY ? 0.0f : expf(mo - mn);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float ao = __shfl_xor(acc[g][i], o, 64);
-                    acc[g][i] = acc[g][i] * ca + ao * cb;
-                }
-                l[g] = l[g] * ca + lo * cb;
-                m[g] = mn;
-            }
+        const bool more = p0 + NG * 4 * RPW < kv1;
+        if (more) {  // long splits (prefill-sized KV per workgroup): next trip's loads go out before the exponentials
+            p0 += NG * 4 * RPW;
+            FA_LOAD_TRIP()
+            p0 -= NG * 4 * RPW;
         }
-    }
-    if (SLOTS_ALL || sub == 0) {
-        const int slot = SLOTS_ALL ? wave * RPW + sub : wave;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            float mx = sc[0][g];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) sh[slot][g][sl * 8 + i] = acc[g][i];
+            for (int u = 1; u < NG; ++u) mx = fmaxf(mx, sc[u][g]);
+            mx = wave_max(mx);
+            const float mn = fmaxf(m[g], mx);
+            if (mn == -INFINITY) continue;  // wave-uniform: nothing visible yet
+            const float alpha = m[g] == -INFINITY ? 0.0f : expf(m[g] - mn);
+            float ps = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[g][i] *= alpha;
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const float pe = sc[u][g] == -INFINITY ? 0.0f : expf(sc[u][g] - mn);
+                ps += pe;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[g][i] = fmaf(pe, vf[u][i], acc[g][i]);
+            }
+            l[g] = l[g] * alpha + ps;
+            m[g] = mn;
+        }
+    }
+#undef FA_LOAD_TRIP
+    // rows of the wave share (m); their partial sums add up element-wise across the sub-rows
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float lt = l[g];
+        if constexpr (LPR == 8) lt += dpp_f32<MI_DPP_ROR8>(lt);
+        lt = xrow_allsum(lt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float a = acc[g][i];
+            if constexpr (LPR == 8) a += dpp_f32<MI_DPP_ROR8>(a);
+            acc[g][i] = xrow_allsum(a);
+        }
+        l[g] = lt;
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            *(float4 *) &sh[wave][g][sl * 8] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+            *(float4 *) &sh[wave][g][sl * 8 + 4] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
             if (sl == 0) {
-                sh[slot][g][D] = m[g];
-                sh[slot][g][D + 1] = l[g];
+                sh[wave][g][D] = m[g];
+                sh[wave][g][D + 1] = l[g];
             }
         }
     }
     __syncthreads();
-    // per (slot, g): coefficient exp(m_slot - m_total), stored over the slot's m
-    if (tid < NSLOT * G) {
-        const int slot = tid / G, g = tid % G;
-        float mt = -INFINITY;
-        for (int w = 0; w < NSLOT; ++w) mt = fmaxf(mt, sh[w][g][D]);
-        const float mw = sh[slot][g][D];
-        coef[slot][g] = mw == -INFINITY ? 0.0f : expf(mw - mt);
-        if (slot == 0) mtot[g] = mt;
-    }
-    __syncthreads();
-    // merge the slots; one thread per (g, d)
+    // merge the four waves; one thread per (g, d)
     for (int e = tid; e < G * D; e += 256) {
         const int g = e / D, dd = e % D;
-        const float mt = mtot[g];
-        float a = 0.0f, lt = 0.0f;
-#pragma unroll 4
-        for (int w = 0; w < NSLOT; ++w) {
-            const float c = coef[w][g];
-            a += sh[w][g][dd] * c;
-            lt += sh[w][g][D + 1] * c;
-        }
+        const float m0 = sh[0][g][D], m1 = sh[1][g][D], m2 = sh[2][g][D], m3 = sh[3][g][D];
+        const float mt = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float c0 = m0 == -INFINITY ? 0.0f : expf(m0 - mt), c1 = m1 == -INFINITY ? 0.0f : expf(m1 - mt);
+        const float c2 = m2 == -INFINITY ? 0.0f : expf(m2 - mt), c3 = m3 == -INFINITY ? 0.0f : expf(m3 - mt);
+        float a = ((sh[0][g][dd] * c0 + sh[1][g][dd] * c1) + sh[2][g][dd] * c2) + sh[3][g][dd] * c3;
+        float lt = ((sh[0][g][D + 1] * c0 + sh[1][g][D + 1] * c1) + sh[2][g][D + 1] * c2) + sh[3][g][D + 1] * c3;
         const int h = kvh * G + g;
         if (geo.n_splits == 1) {
             if (sinks) {
@@ -217,6 +206,228 @@ __global__ void __launch_bounds__(256) k_fattn_split(const tdesc q, const tdesc 
             rec[dd] = a;
             if (dd == 0) {
                 rec[D] = mt;
+                rec[D + 1] = lt;
+            }
+        }
+    }
+}
+
+// ---- decode kernel for head_dim 128 with the softmax done LANE-PARALLEL ------------------------------------------
+// The generic kernel above finishes every (position, head) score on all 16 lanes of a row and then runs the same
+// exponential 16 times in a row — ~1200 dependent VALU instructions per trip with one wave per SIMD, which is what
+// bounded batch-1 attention (12 us per layer for 8.7 MB of KV).  Here a trip owns exactly 16 (row group u, head g)
+// pairs per KV row, and a 4-level transpose-reduce leaves the finished score of pair j in lane j of the row: scale,
+// mask, running max, ONE v_exp_f32 and the running sum are then done once per lane for all 16 pairs at the same
+// time, and P.V takes each probability straight out of its lane with a DPP row broadcast on the fma.  K stays packed
+// f16 (v_dot2_f32_f16 against the f16-rounded Q).  Rows of the wave merge with permlane swaps (two values per swap),
+// waves through four LDS slots.  G = 2 / 4 / 8 query heads per KV head (7 runs as 8 with a zero head).
+#define MI_DPP_NEWBCAST(n) (0x150 + (n))
+typedef _Float16 fa_half2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float fa_exp2(const float x) { return __builtin_amdgcn_exp2f(x); }
+// (x.lo+x.hi | y.lo+y.hi): lanes 0-31 get the two-half total of x, lanes 32-63 that of y
+__device__ __forceinline__ float swap32_pairsum(float x, float y) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+// rows (0,1,2,3) get (c.r0+c.r1, d.r0+d.r1, c.r2+c.r3, d.r2+d.r3)
+__device__ __forceinline__ float swap16_pairsum(float c, float d) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+    return c + d;
+}
+__device__ __forceinline__ float xrow_allmax(const float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    const float y = fmaxf(a, b);
+    a = y;
+    b = y;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+template <int G>
+__global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
+                                                      const tdesc dst, const fa_geom geo, float * __restrict__ ws, const int g_real) {
+    constexpr int D = 128, NG = 16 / G;
+    constexpr float LOG2E = 1.4426950408889634f;
+    __shared__ float sh[4][G][D + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane >> 4, sl = lane & 15;
+    const int ul = sl / G, gl = sl % G;  // the (row group, head) pair this lane owns in the lane-parallel part
+    const int split = blockIdx.x, kvh = blockIdx.y;
+    const int tok = blockIdx.z % geo.n_q, bat = blockIdx.z / geo.n_q;
+    const int per = (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
+    const int kv0 = split * per, kv1 = min(geo.n_kv, kv0 + per);
+    const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
+    const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
+    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
+
+    // a trip covers NG*16 consecutive positions: position of (u, wave, sub) = p0 + u*16 + wave*4 + sub
+    uint4 kraw[NG], vraw[NG];
+    float mvl = 0.0f;   // mask value / validity of THIS lane's pair (ul, sub)
+    bool okl = false;
+    int p0 = kv0;
+#define FA_LOAD_TRIP()                                                                  \
+    {                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < NG; ++u) {                               \
+            const int pc = min(p0 + u * 16 + wave * 4 + sub, kv1 - 1);                  \
+            kraw[u] = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);                \
+            vraw[u] = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);                \
+        }                                                                               \
+        const int pl = p0 + ul * 16 + wave * 4 + sub;                                   \
+        okl = pl < kv1;                                                                 \
+        mvl = mp ? h2f(mp[min(pl, kv1 - 1)]) : 0.0f;                                    \
+    }
+    if (kv0 < kv1) FA_LOAD_TRIP()
+
+    fa_half2 qh[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int h = kvh * g_real + min(g, g_real - 1);
+        const float4 * qp = (const float4 *) ((const float *) (q.data + (int64_t) tok * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]) + sl * 8);
+        const float4 qa = qp[0], qb = qp[1];
+        const float z = g < g_real ? 1.0f : 0.0f;
+        qh[g][0] = (fa_half2){(_Float16) (qa.x * z), (_Float16) (qa.y * z)};  // q_to_vec_dot: Q -> f16 (round to nearest even)
+        qh[g][1] = (fa_half2){(_Float16) (qa.z * z), (_Float16) (qa.w * z)};
+        qh[g][2] = (fa_half2){(_Float16) (qb.x * z), (_Float16) (qb.y * z)};
+        qh[g][3] = (fa_half2){(_Float16) (qb.z * z), (_Float16) (qb.w * z)};
+    }
+    float acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[g][i] = 0.0f;
+    float m = -INFINITY, l = 0.0f;  // running max / sum of head gl (max is wave-uniform per head, the sum a per-lane partial)
+    const bool b3 = (sl & 8) != 0, b2 = (sl & 4) != 0, b1 = (sl & 2) != 0, b0 = (sl & 1) != 0;
+    const float sc2 = geo.scale * LOG2E;  // scores are kept in the log2 domain: p = 2^(s*scale*log2e + mask*log2e - m)
+
+    for (; p0 < kv1; p0 += NG * 16) {
+        // ---- partial dots of this lane's 8 dims for the 16 (u, g) pairs
+        float t[16];
+        float vf[NG][8];
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vf[u][2 * i] = h2f((uint16_t) (vu[i] & 0xFFFF));
+                vf[u][2 * i + 1] = h2f((uint16_t) (vu[i] >> 16));
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d = __builtin_amdgcn_fdot2(__builtin_bit_cast(fa_half2, ku[i]), qh[g][i], d, false);
+                t[u * G + g] = d;
+            }
+        }
+        const bool more = p0 + NG * 16 < kv1;
+        const float mv_cur = mvl;
+        const bool ok_cur = okl;
+        if (more) {  // long splits: the next trip's loads go out before the reductions
+            p0 += NG * 16;
+            FA_LOAD_TRIP()
+            p0 -= NG * 16;
+        }
+        // ---- transpose-reduce over the 16 lanes of the row: lane j ends with the complete dot of pair j
+        float w8[8], w4[4], w2[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float keep = b3 ? t[j + 8] : t[j], send = b3 ? t[j] : t[j + 8];
+            w8[j] = keep + dpp_f32<MI_DPP_ROR8>(send);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float keep = b2 ? w8[j + 4] : w8[j], send = b2 ? w8[j] : w8[j + 4];
+            w4[j] = keep + dpp_f32<MI_DPP_HALF_MIRROR>(send);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = b1 ? w4[j + 2] : w4[j], send = b1 ? w4[j] : w4[j + 2];
+            w2[j] = keep + dpp_f32<MI_DPP_QUAD_XOR2>(send);
+        }
+        float sv;
+        {
+            const float keep = b0 ? w2[1] : w2[0], send = b0 ? w2[0] : w2[1];
+            sv = keep + dpp_f32<MI_DPP_QUAD_XOR1>(send);
+        }
+        // ---- softmax bookkeeping, once per lane for its own pair
+        sv = (ok_cur && !(mv_cur == -INFINITY)) ? fmaf(sv, sc2, mv_cur * LOG2E) : -INFINITY;
+        float mx = sv;
+        if constexpr (G <= 2) mx = fmaxf(mx, dpp_f32<MI_DPP_ROR2>(mx));
+        if constexpr (G <= 4) mx = fmaxf(mx, dpp_f32<MI_DPP_ROR4>(mx));
+        mx = fmaxf(mx, dpp_f32<MI_DPP_ROR8>(mx));
+        mx = xrow_allmax(mx);
+        const float mn = fmaxf(m, mx);
+        const float mref = mn == -INFINITY ? 0.0f : mn;  // nothing visible yet: every exponent below is -inf -> 0
+        const float alpha = fa_exp2(m - mref);
+        const float pe = fa_exp2(sv - mref);
+        l = l * alpha + pe;
+        m = mn;
+        // ---- rescale and accumulate: probabilities / factors come out of their lanes by DPP row broadcast
+#define FA_HEAD(g)                                                                          \
+    if constexpr ((g) < G) {                                                                \
+        const float ag_ = dpp_f32<MI_DPP_NEWBCAST((g))>(alpha);                             \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[(g)][i] *= ag_;                  \
+    }
+        FA_HEAD(0) FA_HEAD(1) FA_HEAD(2) FA_HEAD(3) FA_HEAD(4) FA_HEAD(5) FA_HEAD(6) FA_HEAD(7)
+#undef FA_HEAD
+#define FA_PAIR(j)                                                                          \
+    {                                                                                       \
+        const float pj_ = dpp_f32<MI_DPP_NEWBCAST((j))>(pe);                                \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[(j) % G][i] = fmaf(pj_, vf[(j) / G][i], acc[(j) % G][i]); \
+    }
+        FA_PAIR(0) FA_PAIR(1) FA_PAIR(2) FA_PAIR(3) FA_PAIR(4) FA_PAIR(5) FA_PAIR(6) FA_PAIR(7)
+        FA_PAIR(8) FA_PAIR(9) FA_PAIR(10) FA_PAIR(11) FA_PAIR(12) FA_PAIR(13) FA_PAIR(14) FA_PAIR(15)
+#undef FA_PAIR
+    }
+#undef FA_LOAD_TRIP
+    // ---- sum of head gl over the row groups (lanes gl, gl+G, ...) and the four rows
+    if constexpr (G <= 2) l += dpp_f32<MI_DPP_ROR2>(l);
+    if constexpr (G <= 4) l += dpp_f32<MI_DPP_ROR4>(l);
+    l += dpp_f32<MI_DPP_ROR8>(l);
+    l = xrow_allsum(l);
+    // ---- accumulators: the four rows add up; pair-wise swaps reduce four values per register, row r of register kk
+    //      ends with the total of value 4*kk + r (value index = g*8 + i)
+#pragma unroll
+    for (int kk = 0; kk < 2 * G; ++kk) {
+        const int g = (4 * kk) / 8, i0 = (4 * kk) % 8;
+        const float y1 = swap32_pairsum(acc[g][i0], acc[g][i0 + 2]);
+        const float y2 = swap32_pairsum(acc[g][i0 + 1], acc[g][i0 + 3]);
+        const float z = swap16_pairsum(y1, y2);
+        sh[wave][g][sl * 8 + i0 + sub] = z;
+    }
+    if (sub == 0 && ul == 0) {
+        sh[wave][gl][D] = m;
+        sh[wave][gl][D + 1] = l;
+    }
+    __syncthreads();
+    // ---- merge the four waves; one thread per (g, d)
+    for (int e = tid; e < g_real * D; e += 256) {
+        const int g = e / D, dd = e % D;
+        const float m0 = sh[0][g][D], m1 = sh[1][g][D], m2 = sh[2][g][D], m3 = sh[3][g][D];
+        const float mt = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float mref = mt == -INFINITY ? 0.0f : mt;
+        const float c0 = fa_exp2(m0 - mref), c1 = fa_exp2(m1 - mref), c2 = fa_exp2(m2 - mref), c3 = fa_exp2(m3 - mref);
+        float a = ((sh[0][g][dd] * c0 + sh[1][g][dd] * c1) + sh[2][g][dd] * c2) + sh[3][g][dd] * c3;
+        float lt = ((sh[0][g][D + 1] * c0 + sh[1][g][D + 1] * c1) + sh[2][g][D + 1] * c2) + sh[3][g][D + 1] * c3;
+        const int h = kvh * g_real + g;
+        const float mt_e = mt * (1.0f / LOG2E);  // records and sinks use the natural-log domain of the generic kernel
+        if (geo.n_splits == 1) {
+            if (sinks) {
+                const float sk = sinks[h];
+                const float mn = fmaxf(mt_e, sk);
+                const float c = mt == -INFINITY ? 0.0f : expf(mt_e - mn);
+                a *= c;
+                lt = lt * c + expf(sk - mn);
+            }
+            float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+            out[dd] = a * (1.0f / lt);
+        } else {
+            float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits + split) * (D + 2);
+            rec[dd] = a;
+            if (dd == 0) {
+                rec[D] = mt_e;
                 rec[D + 1] = lt;
             }
         }
@@ -295,6 +506,19 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     const int D = (int) k.ne[0], G = geo.n_head / geo.n_kv_head;
     const tdesc mk = mask ? *mask : q;
     float * ws = (float *) workspace;
+    // batch-1 / small-batch decode at head_dim 128 without soft-capping or ALiBi: the lane-parallel kernel
+    if (D == 128 && p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 2 || G == 4 || G == 7 || G == 8) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 &&
+        ((uintptr_t) q.data & 15) == 0) {
+        dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, (unsigned) (geo.n_q * q.ne[3]));
+        if (G == 2) hipLaunchKernelGGL((k_fattn_dec128<2>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);
+        else if (G == 4) hipLaunchKernelGGL((k_fattn_dec128<4>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);
+        else hipLaunchKernelGGL((k_fattn_dec128<8>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);
+        if (geo.n_splits > 1) {
+            dim3 g2((unsigned) geo.n_head, (unsigned) geo.n_q, (unsigned) q.ne[3]);
+            hipLaunchKernelGGL((k_fattn_combine<128>), g2, dim3(64), 0, s, ws, sinks, dst, geo);
+        }
+        return;
+    }
 #define FA_CASE(DD, GG) \
     if (D == DD && G == GG) { launch_fa<DD, GG>(s, q, k, v, mk, sinks, dst, geo, ws); return; }
     FA_CASE(64, 1) FA_CASE(64, 2) FA_CASE(64, 4) FA_CASE(64, 8)

@@ -388,6 +388,12 @@ FA_CASES = [  # (HD, NH, NKV, n_q, n_kv, splits, softcap, alibi, sinks)
     (64, 4, 2, 2, 256, 2, 0.0, 8.0, False),
     (128, 16, 2, 1, 768, 3, 0.0, 0.0, True),
     (64, 2, 1, 7, 256, 0, 0.0, 0.0, False),
+    # lane-parallel decode kernel (head_dim 128, G = 2 / 4 / 7 / 8): several trips per split, ragged split ends, sinks
+    (128, 8, 4, 2, 512, 0, 0.0, 0.0, False),
+    (128, 32, 8, 1, 2048, 2, 0.0, 0.0, False),
+    (128, 32, 8, 3, 1000, 3, 0.0, 0.0, True),
+    (128, 28, 4, 2, 1024, 5, 0.0, 0.0, False),
+    (128, 16, 2, 4, 300, 1, 0.0, 0.0, True),
     # >= 32 query tokens: the matrix-core kernel (fattn_mma.hip); ragged query tiles, fully-masked KV tiles, KV tails
     (128, 32, 8, 64, 512, 0, 0.0, 0.0, False),
     (128, 8, 2, 200, 256, 0, 0.0, 0.0, False),
