@@ -434,10 +434,12 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     }
 }
 
-template <int D> __global__ void __launch_bounds__(64) k_fattn_combine(const float * __restrict__ ws, const float * __restrict__ sinks, const tdesc dst, const fa_geom geo) {
-    const int h = blockIdx.x, tok = blockIdx.y, bat = blockIdx.z, lane = threadIdx.x;
+template <int D> __global__ void __launch_bounds__(D) k_fattn_combine(const float * __restrict__ ws, const float * __restrict__ sinks, const tdesc dst, const fa_geom geo) {
+    // one thread per output dimension; every wave recomputes the (<= 64) split coefficients lane-parallel (lane s owns
+    // split s: ONE round trip fetches every (m, l) pair), then the coefficients come out of their lanes through SGPRs
+    // (v_readlane with compile-time indices) while up to 32 partial values per thread are in flight at once
+    const int h = blockIdx.x, tok = blockIdx.y, bat = blockIdx.z, dd = threadIdx.x, lane = threadIdx.x & 63;
     const float * __restrict__ base = ws + (((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits * (D + 2);
-    // lane s owns split s (n_splits <= 64): one round trip fetches every (m, l) pair
     const bool has = lane < geo.n_splits;
     const float ms = has ? base[(int64_t) lane * (D + 2) + D] : -INFINITY;
     const float ls = has ? base[(int64_t) lane * (D + 2) + D + 1] : 0.0f;
@@ -449,19 +451,18 @@ template <int D> __global__ void __launch_bounds__(64) k_fattn_combine(const flo
     }
     const float cs = ms == -INFINITY ? 0.0f : expf(ms - mn);
     const float lt = wave_sum(ls * cs) + sink_term;
-    const float inv = 1.0f / lt;
-    float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
-    for (int dd = lane; dd < D; dd += 64) {
-        float a = 0.0f;
-        for (int s0 = 0; s0 < geo.n_splits; s0 += 8) {
-            float r[8];
+    float a = 0.0f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) r[u] = (s0 + u) < geo.n_splits ? base[(int64_t) (s0 + u) * (D + 2) + dd] : 0.0f;
+    for (int s0 = 0; s0 < 64; s0 += 32) {
+        if (s0 >= geo.n_splits) break;
+        float r[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a += r[u] * __shfl(cs, (s0 + u) & 63, 64);
-        }
-        out[dd] = a * inv;
+        for (int u = 0; u < 32; ++u) r[u] = (s0 + u) < geo.n_splits ? base[(int64_t) (s0 + u) * (D + 2) + dd] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) a += r[u] * readlane_f32(cs, s0 + u);
     }
+    float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+    out[dd] = a * (1.0f / lt);
 }
 
 int fattn_pick_splits(const tdesc & q, const tdesc & k) {
@@ -483,7 +484,7 @@ template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, co
     hipLaunchKernelGGL((k_fattn_split<D, G>), grid, dim3(256), 0, s, q, k, v, mask, sinks, dst, geo, ws);
     if (geo.n_splits > 1) {
         dim3 g2((unsigned) geo.n_head, (unsigned) geo.n_q, (unsigned) q.ne[3]);
-        hipLaunchKernelGGL((k_fattn_combine<D>), g2, dim3(64), 0, s, ws, sinks, dst, geo);
+        hipLaunchKernelGGL((k_fattn_combine<D>), g2, dim3(D), 0, s, ws, sinks, dst, geo);
     }
 }
 
@@ -515,7 +516,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         else hipLaunchKernelGGL((k_fattn_dec128<8>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);
         if (geo.n_splits > 1) {
             dim3 g2((unsigned) geo.n_head, (unsigned) geo.n_q, (unsigned) q.ne[3]);
-            hipLaunchKernelGGL((k_fattn_combine<128>), g2, dim3(64), 0, s, ws, sinks, dst, geo);
+            hipLaunchKernelGGL((k_fattn_combine<128>), g2, dim3(128), 0, s, ws, sinks, dst, geo);
         }
         return;
     }

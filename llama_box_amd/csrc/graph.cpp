@@ -469,23 +469,29 @@ static bool try_fuse_qkv(exec_state & st, int i) {
         base.pos = nullptr;
     }
     base.slot = idx0 ? (const int64_t *) idx0->data : nullptr;
-    // one launch per weight format (Q4_K_M: {wq, wk} Q4_K and, in the "more bits" layers, {wv} Q6_K)
+    // one launch for up to two weight formats (Q4_K_M: {wq, wk} Q4_K and, in the "more bits" layers, {wv} Q6_K — each format gets
+    // its own range of workgroups inside the launch); a third format, or a pair qkv.hip has no instantiation for, launches separately
     std::vector<char> launched(chains.size(), 0);
     for (size_t first = 0; first < chains.size(); ++first) {
         if (launched[first]) continue;
         const int type = chains[first].mm->src[0]->type;
+        int type_b = type;
+        for (size_t s = first + 1; s < chains.size(); ++s) {
+            const int t2 = chains[s].mm->src[0]->type;
+            if (!launched[s] && t2 != type && qkv_types_supported(type, t2)) { type_b = t2; break; }
+        }
         qkv_args a = base;
         a.nseg = 0;
         double bytes = 0;
         for (size_t s = first; s < chains.size(); ++s) {
             const qkv_chain & ch = chains[s];
             const ggml_tensor * w = ch.mm->src[0];
-            if (launched[s] || w->type != type) continue;
+            if (launched[s] || (w->type != type && w->type != type_b)) continue;
             launched[s] = 1;
             qkv_seg & sg = a.seg[a.nseg++];
             sg.W = (const uint8_t *) w->data;
             sg.w_nb1 = (int64_t) w->nb[1];
-            sg.alt = 0;
+            sg.alt = w->type == type ? 0 : 1;
             sg.N = (int) w->ne[1];
             sg.bias = ch.bias ? (const float *) ch.bias->data : nullptr;
             sg.rope = ch.rope ? 1 : 0;
@@ -495,9 +501,10 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];
         }
         char cls[64];
-        snprintf(cls, sizeof(cls), "qkv_fused_%s_%s", type_tag(type), norm ? "normpro" : "f32pro");
+        if (type_b == type) snprintf(cls, sizeof(cls), "qkv_fused_%s_%s", type_tag(type), norm ? "normpro" : "f32pro");
+        else snprintf(cls, sizeof(cls), "qkv_fused_%s+%s_%s", type_tag(type), type_tag(type_b), norm ? "normpro" : "f32pro");
         timed_scope ts(c, cls, bytes);
-        launch_qkv(c->stream, a, type, type);
+        launch_qkv(c->stream, a, type, type_b);
         c->st.kernel_launches++;
     }
     for (auto & ch : chains) for (int k : ch.nodes) { st.done[k] = 1; c->st.fused_nodes++; }

@@ -57,25 +57,29 @@ template <typename T> __device__ __forceinline__ void qkv_unit(qkv_regs<T> & r, 
     }
 }
 
-// One weight format per launch (a second format — Q4_K_M keeps wv in Q6_K in its "more bits" layers — gets its own
-// launch from graph.cpp): holding register sets for two formats at once spilled, and spilled weight registers go
-// through scratch memory, which cost 15 us per layer in the first version of this kernel.
-template <typename T>
-__global__ void __launch_bounds__(1024) k_qkv_stream(const qkv_args a) {
+// The work of one workgroup for the segments stored in weight format T (seg.alt == alt); `wg` of `nwg` workgroups share
+// those segments.  A launch with two formats (Q4_K_M keeps wv in Q6_K in its "more bits" layers) gives each format its
+// own range of workgroups: a workgroup only ever executes one instantiation, so the register demand is the maximum of
+// the two, not the sum — holding both register sets in one code path spilled weight registers to scratch memory.
+template <typename TA, typename TB>
+__global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (a generic lambda, not a device function: passing the kernel-argument struct to a function copies it to scratch)
+    auto body = [&](auto tag, const int alt, const int wg, const int nwg) {
+    using T = decltype(tag);
     constexpr int WAVES = 16, QB = 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = a.K / 256;
     q8k_dev * yl = (q8k_dev *) smem;
     double * red = (double *) (smem + (size_t) nblk * sizeof(q8k_dev));
     float * cs_tab = (float *) (red + WAVES);  // [head_dim/2][2]
-    const int GW = gridDim.x * WAVES;
+    const int GW = nwg * WAVES;
     const int half = a.head_dim >> 1;
-    const int u0 = a.seg[0].N >> 1;
-    const int u1 = u0 + (a.nseg > 1 ? a.seg[1].N >> 1 : 0);
-    const int UT = u1 + (a.nseg > 2 ? a.seg[2].N >> 1 : 0);
+    const int u0 = a.seg[0].alt == alt ? a.seg[0].N >> 1 : 0;
+    const int u1 = u0 + (a.nseg > 1 && a.seg[1].alt == alt ? a.seg[1].N >> 1 : 0);
+    const int UT = u1 + (a.nseg > 2 && a.seg[2].alt == alt ? a.seg[2].N >> 1 : 0);
 
-    int u = blockIdx.x * WAVES + wave;
+    int u = wg * WAVES + wave;
     bool have = u < UT;
     int si = 0, r0 = 0, r1 = 0, pair_i = 0;
     qkv_seg sg = a.seg[0];
@@ -195,24 +199,54 @@ __global__ void __launch_bounds__(1024) k_qkv_stream(const qkv_args a) {
             qkv_load<T>(sg.W + (size_t) r0 * sg.w_nb1, sg.W + (size_t) r1 * sg.w_nb1, 0, lane, nblk * T::PPB, ra);
         }
     }
+    };
+    if constexpr (std::is_same<TA, TB>::value) {
+        body(TA{}, 0, (int) blockIdx.x, (int) gridDim.x);
+    } else {
+        if ((int) blockIdx.x < a.wg_a) body(TA{}, 0, (int) blockIdx.x, a.wg_a);
+        else body(TB{}, 1, (int) blockIdx.x - a.wg_a, (int) gridDim.x - a.wg_a);
+    }
 }
+
 
 bool qkv_types_supported(int ta, int tb) {
     auto ok = [](int t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K; };
-    return ok(ta) && ok(tb);
+    if (ta == tb) return ok(ta);
+    return (ta == GGML_TYPE_Q4_K && tb == GGML_TYPE_Q6_K) || (ta == GGML_TYPE_Q5_K && tb == GGML_TYPE_Q6_K) || (ta == GGML_TYPE_Q4_K && tb == GGML_TYPE_Q5_K);
 }
 
-// all segments of `a` share the weight format `type`
-void launch_qkv(hipStream_t s, const qkv_args & a, int type, int) {
+// segments with alt == 0 are stored in type_a, those with alt == 1 in type_b (type_b == type_a: one format)
+void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
+    qkv_args a = a0;
     const int nblk = a.K / 256;
-    int units = 0;
-    for (int i = 0; i < a.nseg; ++i) units += a.seg[i].N / 2;
+    int units[2] = {0, 0};
+    double bytes[2] = {0, 0};
+    for (int i = 0; i < a.nseg; ++i) {
+        units[a.seg[i].alt ? 1 : 0] += a.seg[i].N / 2;
+        bytes[a.seg[i].alt ? 1 : 0] += (double) a.seg[i].N * (double) a.seg[i].w_nb1;
+    }
     const size_t lds = (size_t) nblk * sizeof(q8k_dev) + 16 * sizeof(double) + (size_t) a.head_dim * sizeof(float) + 16;
-    const unsigned grid = (unsigned) std::min(256, (units + 15) / 16);
-    if (type == GGML_TYPE_Q4_K) hipLaunchKernelGGL(k_qkv_stream<T_Q4K>, dim3(grid), dim3(1024), lds, s, a);
-    else if (type == GGML_TYPE_Q5_K) hipLaunchKernelGGL(k_qkv_stream<T_Q5K>, dim3(grid), dim3(1024), lds, s, a);
-    else if (type == GGML_TYPE_Q6_K) hipLaunchKernelGGL(k_qkv_stream<T_Q6K>, dim3(grid), dim3(1024), lds, s, a);
-    else { MI_ERR("launch_qkv: unsupported weight format %d", type); abort(); }
+    if (type_a == type_b || units[1] == 0) {
+        const unsigned grid = (unsigned) std::min(256, (units[0] + 15) / 16);
+        a.wg_a = (int) grid;
+        if (type_a == GGML_TYPE_Q4_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q4K>), dim3(grid), dim3(1024), lds, s, a);
+        else if (type_a == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q5K>), dim3(grid), dim3(1024), lds, s, a);
+        else if (type_a == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q6K, T_Q6K>), dim3(grid), dim3(1024), lds, s, a);
+        else { MI_ERR("launch_qkv: unsupported weight format %d", type_a); abort(); }
+        return;
+    }
+    // one workgroup per CU at most; when the units would need more, share the 256 slots by weight bytes
+    int ga = (units[0] + 15) / 16, gb = (units[1] + 15) / 16;
+    if (ga + gb > 256) {
+        gb = std::max(1, std::min(255, (int) (256.0 * bytes[1] / (bytes[0] + bytes[1]) + 0.5)));
+        ga = 256 - gb;
+    }
+    a.wg_a = ga;
+    const dim3 grid((unsigned) (ga + gb));
+    if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q6K>), grid, dim3(1024), lds, s, a);
+    else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q6K>), grid, dim3(1024), lds, s, a);
+    else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q5K>), grid, dim3(1024), lds, s, a);
+    else { MI_ERR("launch_qkv: unsupported weight format pair %d/%d", type_a, type_b); abort(); }
 }
 
 }  // namespace mi355x

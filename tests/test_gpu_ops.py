@@ -462,6 +462,56 @@ def test_flash_attn(backend, H, plog, HD, NH, NKV, nq, nkv, splits, softcap, ali
     assert e_gpu <= (1e-9 if nq < 32 or softcap else 3e-7) and e_gpu <= e_cpu * 1.01 + 1e-12
 
 
+# ------------------------------------------------------------------------------------------------ fused Q/K/V
+@pytest.mark.parametrize("tq,tv,bias", [(L.Q4_K, L.Q4_K, False), (L.Q4_K, L.Q6_K, False), (L.Q5_K, L.Q6_K, True), (L.Q6_K, L.Q6_K, True), (L.Q4_K, L.Q5_K, False)])
+def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias):
+    """One decode token through norm -> {wq, wk, wv} -> (+bias) -> rope(q, k) -> KV-cache store, the node pattern of
+    llama_lite / llm_build_llama.  wq/wk in one K-quant format and wv in another take ONE launch (qkv.hip gives each
+    format its own workgroups); result must equal the oracle and the unfused execution."""
+    rng = np.random.default_rng(5 + tq * 7 + tv)
+    E, HD, NH, NKV, NCTX, slot, pos = 1024, 128, 8, 2, 32, 11, 7
+    x = rng.standard_normal((1, E)).astype(np.float32)
+    nw = rng.uniform(0.5, 1.5, E).astype(np.float32)
+    wq, wk, wv = T.rand_weight(tq, E, NH * HD, rng), T.rand_weight(tq, E, NKV * HD, rng), T.rand_weight(tv, E, NKV * HD, rng)
+    bq, bk, bv = (rng.standard_normal(n).astype(np.float32) for n in (NH * HD, NKV * HD, NKV * HD))
+    kc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    vc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+
+    def build(g):
+        cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, g.new(L.F32, [E, 1], x), 1e-5), g.new(L.F32, [E], nw))
+        q = H.ggml_mul_mat(g.ctx, g.new(tq, [E, NH * HD], wq), cur)
+        k = H.ggml_mul_mat(g.ctx, g.new(tq, [E, NKV * HD], wk), cur)
+        v = H.ggml_mul_mat(g.ctx, g.new(tv, [E, NKV * HD], wv), cur)
+        if bias:
+            q = H.ggml_add(g.ctx, q, g.new(L.F32, [NH * HD], bq))
+            k = H.ggml_add(g.ctx, k, g.new(L.F32, [NKV * HD], bk))
+            v = H.ggml_add(g.ctx, v, g.new(L.F32, [NKV * HD], bv))
+        tp = g.new(L.I32, [1], np.array([pos], np.int32))
+        idx = g.new(L.I64, [1], np.array([slot], np.int64))
+        q = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, q, HD, NH, 1), tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        k = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, k, HD, NKV, 1), tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        v = H.ggml_reshape_3d(g.ctx, v, HD, NKV, 1)
+        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], kc0), H.ggml_reshape_2d(g.ctx, k, NKV * HD, 1), idx)
+        vs = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], vc0), H.ggml_reshape_2d(g.ctx, v, NKV * HD, 1), idx)
+        return [q, ks, vs]
+
+    ref = T.run_case(build, "oracle")
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    backend.set_option("fusion", 0)
+    try:
+        plain = T.run_case(build, backend)
+    finally:
+        backend.set_option("fusion", 1)
+    plog(f"    fused qkv {QNAME[tq]}/{QNAME[tv]} bias={bias}: {launches} kernel launch(es)")
+    assert launches == 1, launches
+    for name, a, b, c in zip(("q_rope", "k_cache", "v_cache"), got, ref, plain):
+        a32, b32, c32 = (np.asarray(t).astype(np.float32) for t in (a, b, c))
+        T.compare(f"fused qkv {QNAME[tq]}/{QNAME[tv]} {name}", a32, b32, max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
+        T.compare(f"fused qkv {QNAME[tq]}/{QNAME[tv]} {name} vs unfused", a32, c32, max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
+
+
 # ------------------------------------------------------------------------------------------------ fused chains
 @pytest.mark.parametrize("qt", QTYPES)
 @pytest.mark.parametrize("M", [1, 4])
