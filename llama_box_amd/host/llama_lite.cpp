@@ -535,6 +535,13 @@ struct llm_context {
     std::vector<float> logits;
     int n_outputs = 0;
     double timings[4] = {0, 0, 0, 0};
+    // pinned host staging, as llama.cpp does it (inputs are uploaded with tensor_set_async out of host-buffer-type memory,
+    // logits come back with tensor_get_async into the pinned output buffer; ONE synchronize per micro-batch):
+    // [ inputs of one micro-batch | logits of up to pin_out_rows outputs ]
+    ggml_backend_buffer_t buf_pin = nullptr;
+    char * pin = nullptr;
+    size_t pin_in_bytes = 0;
+    int pin_out_rows = 0;
 };
 
 static ggml_tensor * named(ggml_tensor * t, const char * base, int il) {
@@ -689,6 +696,22 @@ extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backe
         return nullptr;
     }
     c->key = graph_key();
+    if (backend) {
+        ggml_backend_buffer_type_t hbuft = ggml_backend_dev_host_buffer_type(backend->device);
+        if (hbuft) {
+            const size_t nub = (size_t) std::min(c->p.n_ubatch, c->p.n_ctx);
+            const size_t n_tok_pad = (nub + 63) / 64 * 64;
+            size_t in_bytes = nub * (4 + 4 + 8 + 4) + n_tok_pad * (size_t) c->p.n_ctx * (c->p.flash_attn ? 2 : 4) + 256;
+            if (!c->p.flash_attn) in_bytes += nub * (size_t) n_embd_k * 8;
+            in_bytes = (in_bytes + 255) / 256 * 256;
+            c->pin_out_rows = 64;
+            c->buf_pin = ggml_backend_buft_alloc_buffer(hbuft, in_bytes + (size_t) c->pin_out_rows * m->n_vocab_l * 4);
+            if (c->buf_pin) {
+                c->pin = (char *) ggml_backend_buffer_get_base(c->buf_pin);
+                c->pin_in_bytes = in_bytes;
+            }
+        }
+    }
     return c;
 }
 
@@ -696,6 +719,7 @@ extern "C" void llm_context_free(struct llm_context * c) {
     if (!c) return;
     if (c->ctx_compute) ggml_free(c->ctx_compute);
     if (c->galloc) ggml_gallocr_free(c->galloc);
+    if (c->buf_pin) ggml_backend_buffer_free(c->buf_pin);
     if (c->buf_kv) ggml_backend_buffer_free(c->buf_kv);
     if (c->ctx_kv) ggml_free(c->ctx_kv);
     delete c;
@@ -748,21 +772,42 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     }
     const double t1 = now_us();
 
-    // inputs
+    // inputs: filled straight into the pinned staging area and uploaded asynchronously on the backend's stream (the copies
+    // and the graph are stream-ordered); without a device backend (CPU oracle) the plain blocking setter is used
     const bool fa = c->p.flash_attn != 0;
-    ggml_backend_tensor_set(c->inp_tokens, tokens, 0, (size_t) n_tokens * 4);
-    ggml_backend_tensor_set(c->inp_pos, pos, 0, (size_t) n_tokens * 4);
-    std::vector<int64_t> kidx(n_tokens);
-    for (int i = 0; i < n_tokens; ++i) kidx[i] = slots[i];
-    ggml_backend_tensor_set(c->inp_k_idxs, kidx.data(), 0, kidx.size() * 8);
+    const bool async_io = c->backend != nullptr && c->pin != nullptr;
+    size_t pin_at = 0;
+    std::vector<char> heap;  // CPU-oracle path
+    auto upload = [&](ggml_tensor * t, size_t bytes, auto fill) {
+        char * dst;
+        if (async_io) {
+            pin_at = (pin_at + 63) / 64 * 64;
+            LLM_ASSERT(pin_at + bytes <= c->pin_in_bytes);
+            dst = c->pin + pin_at;
+            pin_at += bytes;
+        } else {
+            heap.resize(bytes);
+            dst = heap.data();
+        }
+        fill(dst);
+        if (async_io) ggml_backend_tensor_set_async(c->backend, t, dst, 0, bytes);
+        else ggml_backend_tensor_set(t, dst, 0, bytes);
+    };
+    upload(c->inp_tokens, (size_t) n_tokens * 4, [&](char * d) { memcpy(d, tokens, (size_t) n_tokens * 4); });
+    upload(c->inp_pos, (size_t) n_tokens * 4, [&](char * d) { memcpy(d, pos, (size_t) n_tokens * 4); });
+    upload(c->inp_k_idxs, (size_t) n_tokens * 8, [&](char * d) {
+        int64_t * k = (int64_t *) d;
+        for (int i = 0; i < n_tokens; ++i) k[i] = slots[i];
+    });
     if (c->inp_v_idxs) {
         const int64_t n_embd_k = (int64_t) m->n_head_kv_l * hp.n_embd_head;
-        std::vector<int64_t> vidx((size_t) n_tokens * n_embd_k);
-        for (int i = 0; i < n_tokens; ++i)
-            for (int64_t j = 0; j < n_embd_k; ++j) vidx[(size_t) i * n_embd_k + j] = j * n_ctx + slots[i];
-        ggml_backend_tensor_set(c->inp_v_idxs, vidx.data(), 0, vidx.size() * 8);
+        upload(c->inp_v_idxs, (size_t) n_tokens * n_embd_k * 8, [&](char * d) {
+            int64_t * vidx = (int64_t *) d;
+            for (int i = 0; i < n_tokens; ++i)
+                for (int64_t j = 0; j < n_embd_k; ++j) vidx[(size_t) i * n_embd_k + j] = j * n_ctx + slots[i];
+        });
     }
-    if (c->inp_out_ids) ggml_backend_tensor_set(c->inp_out_ids, out_ids.data(), 0, (size_t) n_out_graph * 4);
+    if (c->inp_out_ids) upload(c->inp_out_ids, (size_t) n_out_graph * 4, [&](char * d) { memcpy(d, out_ids.data(), (size_t) n_out_graph * 4); });
     {
         // rows beyond n_tokens are padding (GGML_KQ_MASK_PAD) that no kernel reads: they are written once when the
         // graph is (re)built and skipped on re-use, which keeps the per-step upload at n_tokens * n_kv entries
@@ -770,32 +815,46 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
         const int64_t rows = rebuilt ? n_tok_pad : n_tokens;
         const uint16_t NEG_INF_H = 0xFC00;
         if (fa) {
-            std::vector<uint16_t> mask((size_t) n_kv * rows, NEG_INF_H);
-            for (int i = 0; i < n_tokens; ++i) {
-                const int s = seq_id ? seq_id[i] : 0;
-                for (int j = 0; j < n_kv; ++j)
-                    if (c->cells[j].pos >= 0 && c->cells[j].seq == s && c->cells[j].pos <= pos[i]) mask[(size_t) i * n_kv + j] = 0;
-            }
-            ggml_backend_tensor_set(c->inp_mask, mask.data(), 0, mask.size() * 2);
+            upload(c->inp_mask, (size_t) n_kv * rows * 2, [&](char * d) {
+                uint16_t * mask = (uint16_t *) d;
+                for (size_t e = 0; e < (size_t) n_kv * rows; ++e) mask[e] = NEG_INF_H;
+                for (int i = 0; i < n_tokens; ++i) {
+                    const int s = seq_id ? seq_id[i] : 0;
+                    for (int j = 0; j < n_kv; ++j)
+                        if (c->cells[j].pos >= 0 && c->cells[j].seq == s && c->cells[j].pos <= pos[i]) mask[(size_t) i * n_kv + j] = 0;
+                }
+            });
         } else {
-            std::vector<float> mask((size_t) n_kv * rows, -INFINITY);
-            for (int i = 0; i < n_tokens; ++i) {
-                const int s = seq_id ? seq_id[i] : 0;
-                for (int j = 0; j < n_kv; ++j)
-                    if (c->cells[j].pos >= 0 && c->cells[j].seq == s && c->cells[j].pos <= pos[i]) mask[(size_t) i * n_kv + j] = 0.0f;
-            }
-            ggml_backend_tensor_set(c->inp_mask, mask.data(), 0, mask.size() * 4);
+            upload(c->inp_mask, (size_t) n_kv * rows * 4, [&](char * d) {
+                float * mask = (float *) d;
+                for (size_t e = 0; e < (size_t) n_kv * rows; ++e) mask[e] = -INFINITY;
+                for (int i = 0; i < n_tokens; ++i) {
+                    const int s = seq_id ? seq_id[i] : 0;
+                    for (int j = 0; j < n_kv; ++j)
+                        if (c->cells[j].pos >= 0 && c->cells[j].seq == s && c->cells[j].pos <= pos[i]) mask[(size_t) i * n_kv + j] = 0.0f;
+                }
+            });
         }
     }
     const double t2 = now_us();
-    enum ggml_status st = c->backend ? ggml_backend_graph_compute(c->backend, c->gf) : c->compute(c->gf, c->p.n_threads);
+    const size_t logit_bytes = (size_t) n_outputs * m->n_vocab_l * 4;
+    const bool async_out = async_io && n_outputs > 0 && n_outputs <= c->pin_out_rows;
+    enum ggml_status st;
+    if (async_io) {
+        st = ggml_backend_graph_compute_async(c->backend, c->gf);
+        if (st == GGML_STATUS_SUCCESS && async_out) ggml_backend_tensor_get_async(c->backend, c->t_logits, c->pin + c->pin_in_bytes, 0, logit_bytes);
+        ggml_backend_synchronize(c->backend);
+    } else {
+        st = c->backend ? ggml_backend_graph_compute(c->backend, c->gf) : c->compute(c->gf, c->p.n_threads);
+    }
     const double t3 = now_us();
     if (st != GGML_STATUS_SUCCESS) {
         for (int i = 0; i < n_tokens; ++i) c->cells[slots[i]] = kv_cell();  // roll the slots back
         return -2;
     }
     if (n_outputs > 0) {
-        ggml_backend_tensor_get(c->t_logits, logits_out, 0, (size_t) n_outputs * m->n_vocab_l * 4);
+        if (async_out) memcpy(logits_out, c->pin + c->pin_in_bytes, logit_bytes);
+        else ggml_backend_tensor_get(c->t_logits, logits_out, 0, logit_bytes);
         *n_out_acc += n_outputs;
     }
     const double t4 = now_us();
