@@ -48,6 +48,7 @@ struct mmvq_args {
     const float * x;
     const float * norm_w;
     float eps;
+    int balance_tail;  // set by the launcher: spread the last, partial pass of rows evenly over the workgroups
 };
 void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave);
 

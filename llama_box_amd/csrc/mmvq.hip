@@ -205,7 +205,20 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     const int npairs = nblk * T::PPB;
     const int nchunks = (npairs + 64 * U - 1) / (64 * U);
     const int GW = gridDim.x * WAVES;
+    // rows are dealt one per wave and pass (row = pass*GW + block*16 + wave); the LAST, partial pass is spread evenly over
+    // the workgroups instead (rem_per rows each), so that every CU streams until the end: with N = 14336 (3.5 passes)
+    // the natural order left half of the CUs idle for the final eighth of the launch
+    const int full = a.balance_tail ? (a.N / GW) * GW : ((a.N + GW - 1) / GW) * GW, rem = a.N - (a.balance_tail ? full : a.N);
+    const int rem_per = (rem + (int) gridDim.x - 1) / (int) gridDim.x;
+    auto next_row = [&](const int r) {
+        const int nr = r + GW;
+        if (nr < full) return nr;
+        if (r >= full) return a.N;  // the remainder pass was this wave's last
+        const int rr = full + (int) blockIdx.x * rem_per + wave;
+        return (wave < rem_per && rr < a.N) ? rr : a.N;
+    };
     int row = blockIdx.x * WAVES + wave, ch = 0;
+    if (full == 0) row = (wave < rem_per && (int) blockIdx.x * rem_per + wave < a.N) ? (int) blockIdx.x * rem_per + wave : a.N;
     bool have = row < a.N;
 
     struct item {
@@ -296,7 +309,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     float acc = 0.0f, acc2 = 0.0f;
     while (have) {
         int nrow = row, nch = ch + 1;
-        if (nch == nchunks) { nch = 0; nrow = row + GW; }
+        if (nch == nchunks) { nch = 0; nrow = next_row(row); }
         const bool nhave = nrow < a.N;
         item nxt;
         if (nhave) load_item(nrow, nch, nxt);
@@ -333,7 +346,10 @@ template <typename T, bool GLU, int PRO> static void launch_stream(hipStream_t s
     const int nblk = a.K / T::BLK;
     const size_t lds = (size_t) nblk * sizeof(typename T::act) + 16 * sizeof(double) + 16;
     const unsigned grid = (unsigned) std::min<int64_t>(256, ((int64_t) a.N + 15) / 16);
-    hipLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, a);
+    static const int bal = getenv("GGML_MI355X_BALANCE_TAIL") ? atoi(getenv("GGML_MI355X_BALANCE_TAIL")) : 1;
+    mmvq_args a2 = a;
+    a2.balance_tail = bal;
+    hipLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, a2);
 }
 
 template <typename T, int NC, int R, bool GLU, int PRO, int WAVES> static void launch_one(hipStream_t s, const mmvq_args & a, size_t lds) {

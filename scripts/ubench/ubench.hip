@@ -105,5 +105,24 @@ int main() {
             printf("stream %7.1f MB U=%d    : %.2f us/kernel  -> %.2f TB/s\n", B / 1048576.0, U, us, B / us / 1e6);
         }
     }
+    // the same kernel over a working set that is re-used: 192 MB cycle = resident in the 256 MB Infinity Cache after the first
+    // pass, 24 MB cycle = resident in the 8 x 4 MB L2s (what a weight prefetch one layer ahead could buy)
+    for (size_t B : {(size_t) 9437184, (size_t) 33 << 20, (size_t) 66 << 20}) {
+        for (size_t cyc : {pool_bytes, (size_t) 192 << 20, (size_t) 24 << 20}) {
+            if (cyc < B) continue;
+            auto ge = capture([&] {
+                size_t off = 0;
+                for (int i = 0; i < CH; ++i) {
+                    if (off + B > cyc) off = 0;
+                    const uint4 * W = pool + off / 16;
+                    off += B;
+                    const float4 * x = (i & 1) ? b : a; float4 * o = (i & 1) ? a : b;
+                    hipLaunchKernelGGL(k_stream<4>, dim3(256), dim3(1024), 0, s, W, B / 16, x, o);
+                }
+            });
+            const double us = run_graph(s, ge, 8) / CH;
+            printf("reuse  %7.1f MB cycle %6.0f MB : %.2f us/kernel  -> %.2f TB/s\n", B / 1048576.0, cyc / 1048576.0, us, B / us / 1e6);
+        }
+    }
     return 0;
 }
