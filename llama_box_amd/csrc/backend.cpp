@@ -9,6 +9,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "kernels.h"
 
 namespace mi355x {
 

@@ -139,17 +139,36 @@ struct timed_scope {
     backend_ctx * c;
     std::string cls;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    timed_scope(backend_ctx * c_, const char * cls_, double bytes) : c(c_), cls(cls_) {
+    bool probe;
+    // probe = true: the class is ONE streaming mat-vec launch whose launcher can time the kernel itself (launch_probe)
+    timed_scope(backend_ctx * c_, const char * cls_, double bytes, bool probe_ = false) : c(c_), cls(cls_), probe(probe_) {
         if (!c->opt.timing || c->capturing) return;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, c->stream));
+        if (probe) {
+            g_launch_probe.e0 = e0;
+            g_launch_probe.e1 = e1;
+            g_launch_probe.armed = true;
+            g_launch_probe.used = false;
+        } else {
+            HIP_CHECK(hipEventRecord(e0, c->stream));
+        }
         c->timing[cls].total_ms += 0;  // create slot
         c->timing["bytes:" + cls].total_ms += bytes;
     }
     ~timed_scope() {
         if (!e0) return;
-        HIP_CHECK(hipEventRecord(e1, c->stream));
+        if (probe) {
+            const bool used = g_launch_probe.used;
+            g_launch_probe = launch_probe();
+            if (!used) {  // the launcher took a path without the probe: nothing was recorded
+                HIP_CHECK(hipEventDestroy(e0));
+                HIP_CHECK(hipEventDestroy(e1));
+                return;
+            }
+        } else {
+            HIP_CHECK(hipEventRecord(e1, c->stream));
+        }
         c->pending_events.push_back({cls, {e0, e1}});
     }
 };
@@ -234,7 +253,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         a.eps = pro_norm ? dn->second.eps : 0.0f;
         char cls[64];
         snprintf(cls, sizeof(cls), "mmvq_%s%s_%s", type_tag(w->type), w2 ? "_glu" : "", pro_norm ? "normpro" : "f32pro");
-        timed_scope ts(c, cls, wbytes);
+        timed_scope ts(c, cls, wbytes, true);
         launch_mmvq(c->stream, a, 1);
         c->st.kernel_launches++;
         return true;

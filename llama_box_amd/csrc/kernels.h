@@ -51,6 +51,13 @@ struct mmvq_args {
     int balance_tail;  // set by the launcher: spread the last, partial pass of rows evenly over the workgroups
 };
 void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave);
+// bench timing pass: when armed, the next streaming mat-vec launch records the kernel's own begin / end timestamps into
+// (e0, e1) through hipExtLaunchKernelGGL instead of being bracketed by host-side hipEventRecord calls
+struct launch_probe {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool armed = false, used = false;
+};
+extern thread_local launch_probe g_launch_probe;
 
 // ---- fused Q/K/V projection for one token (qkv.hip): up to three K-quant mat-vecs that share their input, with the
 // activation prologue of mmvq (f32 or RMS_NORM*w), optional bias, rotary embedding and the KV-cache store in the epilogue
@@ -102,6 +109,7 @@ void launch_cpy(hipStream_t s, const tdesc & src, const tdesc & dst);
 void launch_get_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
 void launch_set_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
 void launch_argmax(hipStream_t s, const tdesc & src, const tdesc & dst);
+
 
 struct rope_params {
     int n_dims, mode, n_ctx_orig;

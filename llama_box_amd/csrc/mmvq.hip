@@ -16,11 +16,16 @@
 //     element-wise launches that would otherwise sit between the mat-vecs of a layer.
 //
 // Algorithmic bytes per launch = N * K/blk * bytes_per_block (+ K*1.19 activations, negligible).
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 
 #include "mmvq_types.h"
 
 namespace mi355x {
+
+thread_local launch_probe g_launch_probe;
 
 // ------------------------------------------------------------------------------------------------ kernel
 // PRO selects how the workgroup obtains its Q8 activations:
@@ -349,7 +354,12 @@ template <typename T, bool GLU, int PRO> static void launch_stream(hipStream_t s
     static const int bal = getenv("GGML_MI355X_BALANCE_TAIL") ? atoi(getenv("GGML_MI355X_BALANCE_TAIL")) : 1;
     mmvq_args a2 = a;
     a2.balance_tail = bal;
-    hipLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, a2);
+    if (g_launch_probe.armed && !g_launch_probe.used) {
+        hipExtLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, g_launch_probe.e0, g_launch_probe.e1, 0, a2);
+        g_launch_probe.used = true;
+    } else {
+        hipLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, a2);
+    }
 }
 
 template <typename T, int NC, int R, bool GLU, int PRO, int WAVES> static void launch_one(hipStream_t s, const mmvq_args & a, size_t lds) {
