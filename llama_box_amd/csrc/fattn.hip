@@ -465,7 +465,18 @@ template <int D> __global__ void __launch_bounds__(D) k_fattn_combine(const floa
     out[dd] = a * (1.0f / lt);
 }
 
+void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits) {
+    fa_geom geo{};
+    geo.n_q = n_q;
+    geo.n_head = n_head;
+    geo.n_splits = n_splits;
+    dim3 g2((unsigned) n_head, (unsigned) n_q, (unsigned) n_batch);
+    if (D == 128) hipLaunchKernelGGL((k_fattn_combine<128>), g2, dim3(128), 0, s, ws, sinks, dst, geo);
+    else hipLaunchKernelGGL((k_fattn_combine<64>), g2, dim3(64), 0, s, ws, sinks, dst, geo);
+}
+
 int fattn_pick_splits(const tdesc & q, const tdesc & k) {
+    if (q.ne[1] >= 32 && (k.ne[0] == 64 || k.ne[0] == 128)) return fattn_mma_pick_splits(q, k);  // (soft-capped / ALiBi batches fall back to the generic kernel with this count)
     const int64_t n_kv = k.ne[1];
     const int64_t groups = k.ne[2] * q.ne[1] * q.ne[3];
     int64_t want = (768 + groups - 1) / groups;  // ~3 workgroups per CU
@@ -490,7 +501,7 @@ template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, co
 
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
                        const fattn_params & p, void * workspace) {
-    if (launch_flash_attn_mma(s, q, k, v, mask, sinks, dst, p)) return;
+    if (launch_flash_attn_mma(s, q, k, v, mask, sinks, dst, p, workspace)) return;
     fa_geom geo;
     geo.n_q = (int) q.ne[1];
     geo.n_head = (int) q.ne[2];

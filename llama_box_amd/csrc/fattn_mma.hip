@@ -28,12 +28,12 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 struct fam_geom {
-    int n_q, n_head, n_kv_head, n_kv, has_mask;
+    int n_q, n_head, n_kv_head, n_kv, has_mask, n_splits;
     float scale;
 };
 
 template <int D>
-__global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo) {
+__global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo, float * __restrict__ ws) {
     constexpr int BKV = 64;
     constexpr int KS = (D + 8) * 2;    // K tile row stride (bytes): odd multiple of 16 -> conflict-free ds_read_b128
     constexpr int VS = (BKV + 4) * 2;  // V^T tile row stride (bytes): 34 dwords -> conflict-free ds_read_b64 across 32 rows
@@ -45,7 +45,12 @@ __global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, kg = lane >> 5;
-    const int h = blockIdx.y, bat = blockIdx.z;
+    const int h = blockIdx.y, bat = blockIdx.z / geo.n_splits, split = blockIdx.z % geo.n_splits;
+    // KV range of this split (whole 64-position tiles); few query tiles x heads do not fill 256 CUs on their own — e.g. 32
+    // continuous-batching sequences decoding one token each over a 17k-cell unified cache — so the KV range is split as in
+    // the decode kernel and k_fattn_combine merges the (m, l, O) records
+    const int tiles = (geo.n_kv + BKV - 1) / BKV, tps = (tiles + geo.n_splits - 1) / geo.n_splits;
+    const int kv_begin = split * tps * BKV, kv_end = min(geo.n_kv, kv_begin + tps * BKV);
     const int kvh = h / (geo.n_head / geo.n_kv_head);
     const int qi = blockIdx.x * 64 + wave * 32 + fr;  // this lane's query token
     const int qrow = min(qi, geo.n_q - 1);
@@ -77,7 +82,7 @@ __global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k,
     const int srow = tid >> 1, spart = tid & 1;
     constexpr int CH = D / 16;  // 16-byte chunks per thread per tile (half a row)
 
-    for (int kv0 = 0; kv0 < geo.n_kv; kv0 += BKV) {
+    for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
         __syncthreads();
         {
             const int pos = min(kv0 + srow, geo.n_kv - 1);
@@ -175,21 +180,44 @@ __global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k,
         }
     }
     if (qi < geo.n_q) {
-        const float inv = 1.0f / l;
-        float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) qi * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+        if (geo.n_splits == 1) {
+            const float inv = 1.0f / l;
+            float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) qi * dst.nb[2] + (int64_t) bat * dst.nb[3]);
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = 32 * dt + 8 * g4 + 4 * kg;
-                *(float4 *) (out + d0) = make_float4(O[dt][4 * g4] * inv, O[dt][4 * g4 + 1] * inv, O[dt][4 * g4 + 2] * inv, O[dt][4 * g4 + 3] * inv);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = 32 * dt + 8 * g4 + 4 * kg;
+                    *(float4 *) (out + d0) = make_float4(O[dt][4 * g4] * inv, O[dt][4 * g4 + 1] * inv, O[dt][4 * g4 + 2] * inv, O[dt][4 * g4 + 3] * inv);
+                }
+        } else {  // partial record (O relative to m, m, l) in the layout k_fattn_combine reads
+            float * rec = ws + ((((int64_t) bat * geo.n_q + qi) * geo.n_head + h) * geo.n_splits + split) * (D + 2);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = 32 * dt + 8 * g4 + 4 * kg;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rec[d0 + e] = O[dt][4 * g4 + e];
+                }
+            if (kg == 0) {
+                rec[D] = m;
+                rec[D + 1] = l;
             }
+        }
     }
 }
 
 // returns false when this variant does not apply (caller falls back to the split-KV kernel)
+int fattn_mma_pick_splits(const tdesc & q, const tdesc & k) {
+    const int64_t wgs = ((q.ne[1] + 63) / 64) * q.ne[2] * q.ne[3];
+    const int64_t tiles = (k.ne[1] + 63) / 64;
+    int64_t want = (512 + wgs - 1) / wgs;  // ~2 workgroups per CU
+    want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, tiles / 4)));
+    return (int) want;
+}
 bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
-                           const fattn_params & p) {
+                           const fattn_params & p, void * workspace) {
     const int D = (int) k.ne[0];
     if (q.ne[1] < 32 || sinks != nullptr || p.max_bias != 0.0f || p.logit_softcap != 0.0f || (D != 64 && D != 128)) return false;
     if ((k.ne[1] % 4) != 0 || (q.nb[1] % 16) || (q.nb[2] % 16) || (((uintptr_t) q.data) & 15) || (dst.nb[1] % 16) || (dst.nb[2] % 16) || (((uintptr_t) dst.data) & 15)) return false;
@@ -201,15 +229,18 @@ bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, cons
     geo.n_kv = (int) k.ne[1];
     geo.has_mask = mask ? 1 : 0;
     geo.scale = p.scale;
+    geo.n_splits = std::max(1, p.n_splits);
     const tdesc mk = mask ? *mask : q;
-    dim3 grid((unsigned) ((geo.n_q + 63) / 64), (unsigned) geo.n_head, (unsigned) q.ne[3]);
+    float * ws = (float *) workspace;
+    dim3 grid((unsigned) ((geo.n_q + 63) / 64), (unsigned) geo.n_head, (unsigned) (q.ne[3] * geo.n_splits));
     if (D == 128) {
         const size_t lds = 64 * (128 + 8) * 2 + 128 * (64 + 4) * 2;
-        hipLaunchKernelGGL(k_fattn_mma<128>, grid, dim3(128), lds, s, q, k, v, mk, dst, geo);
+        hipLaunchKernelGGL(k_fattn_mma<128>, grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws);
     } else {
         const size_t lds = 64 * (64 + 8) * 2 + 64 * (64 + 4) * 2;
-        hipLaunchKernelGGL(k_fattn_mma<64>, grid, dim3(128), lds, s, q, k, v, mk, dst, geo);
+        hipLaunchKernelGGL(k_fattn_mma<64>, grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws);
     }
+    if (geo.n_splits > 1) launch_flash_attn_combine(s, (int) k.ne[0], ws, sinks, dst, (int) q.ne[1], (int) q.ne[2], (int) q.ne[3], geo.n_splits);
     return true;
 }
 

@@ -130,6 +130,8 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
                        const tdesc & dst, const fattn_params & p, void * workspace);
 // matrix-core variant for batches of >= 32 query tokens (fattn_mma.hip); false = does not apply
 bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
-                           const fattn_params & p);
+                           const fattn_params & p, void * workspace);
+int fattn_mma_pick_splits(const tdesc & q, const tdesc & k);
+void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits);
 
 }  // namespace mi355x

@@ -401,6 +401,11 @@ FA_CASES = [  # (HD, NH, NKV, n_q, n_kv, splits, softcap, alibi, sinks)
     (64, 4, 2, 96, 256, 0, 0.0, 0.0, False),
     (64, 8, 1, 130, 1024, 0, 0.0, 0.0, False),
     (128, 4, 2, 40, 256, 2, 20.0, 0.0, False),  # softcap -> falls back to the split-KV kernel
+    # matrix-core kernel with the KV range split over workgroups (+ combine): -np 32 style batches over a long unified cache
+    (128, 32, 8, 32, 2048, 4, 0.0, 0.0, False),
+    (128, 8, 2, 40, 1024, 0, 0.0, 0.0, False),
+    (64, 4, 2, 96, 512, 3, 0.0, 0.0, False),
+    (128, 16, 4, 33, 1100, 5, 0.0, 0.0, False),
 ]
 
 
