@@ -63,7 +63,7 @@ struct options {
     bool prologue = true;      // fold RMS_NORM / activation quantisation into the mat-vec prologue
     bool qkv = true;           // fused Q/K/V + rope + cache store launch
     int mmvq_max_cols = 8;     // widest single launch of the bandwidth-bound matvec kernels
-    int mmq_min_cols = 33;     // batches at least this wide go to the MFMA kernel; narrower ones are chunks of 8 mat-vec columns
+    int mmq_min_cols = 9;      // batches at least this wide go to the matrix-core kernels (split-K below 65 columns); narrower ones are one 8-column mat-vec pass
     bool mmq_i8 = true;        // Q4_K/Q5_K batches on the int8 matrix cores (mmq_i8.hip) instead of the f16 variant (mmq.hip)
     int mmq_bn = 0;            // force the weight-panel height of mmq_i8 (64 / 128); 0 = pick by grid size
     int fa_splits = 0;         // 0 = auto

@@ -124,6 +124,8 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
         if (n->op == GGML_OP_MUL_MAT && is_quant(n->src[0]->type)) {
             const ggml_tensor * b = n->src[1];
             p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], b->ne[1] * b->ne[2] * b->ne[3]));
+            const int64_t Mc = b->ne[1] * b->ne[2] * b->ne[3];
+            if (Mc >= c->opt.mmq_min_cols && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc));
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
             const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k));
@@ -261,10 +263,13 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const void * act = quantized_src1(st, b, w->type);
     if (M >= c->opt.mmq_min_cols && !w2 && !add && mmq_supported(w->type, K, N, M)) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
+        const int ks = (N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M) : 1;
+        float * part = (float *) ((char *) c->ws + st.aux_off);
         if (c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M))
-            launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn);
+            launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn, ks, part);
         else
-        launch_mmq(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4));
+            launch_mmq(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), ks, part);
+        if (ks > 1) c->st.kernel_launches++;
         c->st.kernel_launches++;
         return true;
     }

@@ -40,6 +40,8 @@ struct mmq_args {
     float * dst;
     int64_t dst_stride;
     int n_panels, m_tiles;
+    int ksplit;    // see mmq_i8.hip: blockIdx.y owns a range of super-blocks, partial [M][N] results go to part
+    float * part;
 };
 
 // ---- packed integer -> f16 conversion without per-value cvt instructions.  For 0 <= n < 1024 the f16 with bits
@@ -92,6 +94,7 @@ __global__ void __launch_bounds__(512) k_mmq(const mmq_args a) {
     if (panel >= a.n_panels) return;
     const int n0 = panel * MQ_BN, m0 = mt * MQ_BM;
     const int nblk = a.K / 256;
+    const int sb_lo = (int) (((int64_t) blockIdx.y * nblk) / a.ksplit), sb_hi = (int) (((int64_t) (blockIdx.y + 1) * nblk) / a.ksplit);
     const int nslab = wave & 3, mhalf = wave >> 2;
 
     // staging roles
@@ -268,9 +271,9 @@ __global__ void __launch_bounds__(512) k_mmq(const mmq_args a) {
     const char * pa2 = A2 + (nslab * 32 + fr) * MQ_AS + kg * 16;
     const char * pb[2] = {Bt + (mhalf * 64 + fr) * MQ_AS + kg * 16, Bt + (mhalf * 64 + 32 + fr) * MQ_AS + kg * 16};
 
-    issue_loads(0, 0);
-    const int trips = nblk * 2;
-    for (int it = 0; it < trips; ++it) {
+    issue_loads(sb_lo, 0);
+    const int trips = sb_hi * 2;
+    for (int it = sb_lo * 2; it < trips; ++it) {
         const int sb = it >> 1, h = it & 1;
         __syncthreads();  // everyone finished reading the previous tiles
         stage(sb, h);
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(512) k_mmq(const mmq_args a) {
     for (int t = 0; t < 2; ++t) {
         const int m = m0 + mhalf * 64 + t * 32 + fr;
         if (m >= a.M) continue;
-        float * out = a.dst + (size_t) m * a.dst_stride;
+        float * out = a.ksplit > 1 ? a.part + ((size_t) blockIdx.y * a.M + m) * a.N : a.dst + (size_t) m * a.dst_stride;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = n0 + nslab * 32 + 8 * g + 4 * kg;
@@ -337,7 +340,10 @@ bool mmq_supported(int type, int64_t K, int64_t N, int64_t M) {
     (void) N;
     return (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K) && (K % 256) == 0 && M >= 9;
 }
-size_t mmq_workspace_bytes(int, int64_t, int64_t, int64_t) { return 0; }
+size_t mmq_workspace_bytes(int, int64_t K, int64_t N, int64_t M) {
+    const int ks = mmq_pick_ksplit(K, N, M);
+    return ks > 1 ? (size_t) ks * (size_t) M * (size_t) N * sizeof(float) : 0;
+}
 
 template <int QT> static void launch_mmq_t(hipStream_t s, const mmq_args & a) {
     const bool q6 = QT == 6;
@@ -348,10 +354,10 @@ template <int QT> static void launch_mmq_t(hipStream_t s, const mmq_args & a) {
         attr_set = true;
     }
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
-    hipLaunchKernelGGL((k_mmq<QT>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((k_mmq<QT>), dim3(grid, (unsigned) a.ksplit), dim3(512), lds, s, a);
 }
 
-void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride) {
+void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int ksplit, float * part) {
     mmq_args a;
     a.W = W;
     a.w_nb1 = w_nb1;
@@ -363,9 +369,12 @@ void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K
     a.dst_stride = dst_stride;
     a.n_panels = (N + MQ_BN - 1) / MQ_BN;
     a.m_tiles = (M + MQ_BM - 1) / MQ_BM;
+    a.ksplit = std::max(1, ksplit);
+    a.part = part;
     if (type == GGML_TYPE_Q4_K) launch_mmq_t<4>(s, a);
     else if (type == GGML_TYPE_Q5_K) launch_mmq_t<5>(s, a);
     else launch_mmq_t<6>(s, a);
+    if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride);
 }
 
 }  // namespace mi355x

@@ -36,6 +36,8 @@ struct mmq8_args {
     float * dst;
     int64_t dst_stride;
     int n_panels, m_tiles;
+    int ksplit;          // > 1: blockIdx.y owns a contiguous range of super-blocks and writes its partial [M][N] result ...
+    float * part;        // ... to part + blockIdx.y * M * N (summed in a fixed order by k_splitk_reduce)
 };
 
 constexpr int MI_BM = 128;
@@ -73,7 +75,9 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
     const int panel = (qb / a.m_tiles) * 8 + xcd, mt = qb % a.m_tiles;
     if (panel >= a.n_panels) return;
     const int n0 = panel * BN, m0 = mt * MI_BM;
-    const int nblk = a.K / 256;
+    const int nblk_all = a.K / 256;
+    const int sb_lo = (int) (((int64_t) blockIdx.y * nblk_all) / a.ksplit), sb_hi = (int) (((int64_t) (blockIdx.y + 1) * nblk_all) / a.ksplit);
+    const int nblk = nblk_all;  // row stride of the activation blocks
     const int nslab = wave % (BN / 32), mhalf = wave / (BN / 32);
 
     // staging roles
@@ -243,18 +247,18 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
         }
     };
 
-    issue_loads(0, 0);
+    issue_loads(sb_lo, 0);
     stage(0);
-    issue_loads(0, 1);
+    issue_loads(sb_lo, 1);
     __syncthreads();
-    for (int sb = 0; sb < nblk; ++sb) {
+    for (int sb = sb_lo; sb < sb_hi; ++sb) {
         // trip (sb, 0): convert + write the second half while the MFMAs of the first half run
         stage(1);
-        if (sb + 1 < nblk) issue_loads(sb + 1, 0);
+        if (sb + 1 < sb_hi) issue_loads(sb + 1, 0);
         mma(0);
         __syncthreads();
         // trip (sb, 1)
-        if (sb + 1 < nblk) {
+        if (sb + 1 < sb_hi) {
             stage(0);
             issue_loads(sb + 1, 1);
         }
@@ -267,7 +271,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
     for (int t = 0; t < 2; ++t) {
         const int m = m0 + mhalf * 64 + t * 32 + fr;
         if (m >= a.M) continue;
-        float * out = a.dst + (size_t) m * a.dst_stride;
+        float * out = a.ksplit > 1 ? a.part + ((size_t) blockIdx.y * a.M + m) * a.N : a.dst + (size_t) m * a.dst_stride;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = n0 + nslab * 32 + 8 * g + 4 * kg;
@@ -297,10 +301,34 @@ template <int QT, int BN> static void launch_mmq8_t(hipStream_t s, mmq8_args a) 
     a.n_panels = (a.N + BN - 1) / BN;
     a.m_tiles = (a.M + MI_BM - 1) / MI_BM;
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
-    hipLaunchKernelGGL((k_mmq_i8<QT, BN>), dim3(grid), dim3(BN * 4), lds, s, a);
+    hipLaunchKernelGGL((k_mmq_i8<QT, BN>), dim3(grid, (unsigned) a.ksplit), dim3(BN * 4), lds, s, a);
 }
 
-void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn) {
+// few activation columns (continuous-batching decode, M <= 64) leave N/64 x 1 workgroups — far fewer than 256 CUs — so
+// the K range is split over blockIdx.y and the partial products are summed in a fixed order by a second tiny kernel
+int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M) {
+    if (M > 64) return 1;
+    const int64_t wgs = ((N + 63) / 64) * ((M + 127) / 128), nblk = K / 256;
+    return (int) std::max<int64_t>(1, std::min<int64_t>(nblk, 768 / std::max<int64_t>(1, wgs)));
+}
+__global__ void __launch_bounds__(256) k_splitk_reduce(const float * __restrict__ part, const int ks, const int64_t mn, const int N, float * __restrict__ dst, const int64_t dst_stride) {
+    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= mn) return;
+    float4 acc = *(const float4 *) (part + e);
+    for (int k = 1; k < ks; ++k) {
+        const float4 v = *(const float4 *) (part + (int64_t) k * mn + e);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int64_t m = e / N, n = e % N;  // N % 4 == 0 (checked by the launcher)
+    *(float4 *) (dst + m * dst_stride + n) = acc;
+}
+void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride) {
+    const int64_t mn = (int64_t) M * N;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned) ((mn / 4 + 255) / 256)), dim3(256), 0, s, part, ks, mn, N, dst, dst_stride);
+}
+
+void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
+                   int ksplit, float * part) {
     mmq8_args a;
     a.W = W;
     a.w_nb1 = w_nb1;
@@ -311,9 +339,11 @@ void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, in
     a.dst = dst;
     a.dst_stride = dst_stride;
     a.n_panels = a.m_tiles = 0;
+    a.ksplit = std::max(1, ksplit);
+    a.part = part;
     // 128-row panels unless that leaves CUs idle (256 CUs, one 8-wave workgroup each)
     const int64_t wg128 = (int64_t) ((N + 127) / 128) * ((M + MI_BM - 1) / MI_BM);
-    const int bn = force_bn ? force_bn : (wg128 >= 256 ? 128 : 64);
+    const int bn = force_bn ? force_bn : (wg128 >= 256 && a.ksplit == 1 ? 128 : 64);
     if (type == GGML_TYPE_Q4_K) {
         if (bn == 128) launch_mmq8_t<4, 128>(s, a);
         else launch_mmq8_t<4, 64>(s, a);
@@ -321,6 +351,7 @@ void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, in
         if (bn == 128) launch_mmq8_t<5, 128>(s, a);
         else launch_mmq8_t<5, 64>(s, a);
     }
+    if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride);
 }
 
 }  // namespace mi355x
