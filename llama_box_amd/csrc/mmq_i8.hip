@@ -61,8 +61,9 @@ template <int QT, int BN>
 __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = BN * 4;
-    constexpr int NP = QT == 4 ? 2 : 3;
-    constexpr int BYTES = QT == 4 ? 144 : 176;
+    constexpr int NP = QT == 5 ? 3 : 2;
+    constexpr int BYTES = QT == 4 ? 144 : (QT == 5 ? 176 : 210);
+    constexpr bool Q6 = QT == 6;
     constexpr int TA = BN * 128, TB = MI_BM * 128, STAGE = NP * TA + TB;
     constexpr int NBC = (MI_BM * 8) / NT;  // 16-byte activation chunks per thread per trip
     char * Am = smem + 2 * STAGE;                   // mins  [BN][24] f16
@@ -106,12 +107,27 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
 
     // raw global data of the NEXT trip to be staged
     uint4 g_hdr, g_q, g_qh, g_b0, g_b1, g_b2, g_b3, g_bs0, g_bs1;
+    uint32_t g6_ql0 = 0, g6_ql1 = 0, g6_ql2 = 0, g6_ql3 = 0, g6_qh0 = 0, g6_qh1 = 0, g6_sc0 = 0, g6_sc1 = 0;  // Q6_K: 2-byte aligned blocks, dword loads
+    uint16_t g6_d = 0;
     float g_dy = 0.0f;
     auto issue_loads = [&](const int sb, const int h) {
         const uint8_t * blk = wrow + (size_t) sb * BYTES;
-        g_hdr = *(const uint4 *) blk;
-        g_q = *(const uint4 *) (blk + (QT == 5 ? 48 : 16) + 64 * h + 16 * aq);
-        if constexpr (QT == 5) g_qh = *(const uint4 *) (blk + 16 + 16 * (aq & 1));
+        if constexpr (!Q6) {
+            g_hdr = *(const uint4 *) blk;
+            g_q = *(const uint4 *) (blk + (QT == 5 ? 48 : 16) + 64 * h + 16 * aq);
+            if constexpr (QT == 5) g_qh = *(const uint4 *) (blk + 16 + 16 * (aq & 1));
+        } else {
+            // half h of a Q6_K block: ql[64h .. 64h+63], qh[32h .. 32h+31], scales[8h .. 8h+7]; this thread owns l = 8*aq .. 8*aq+7
+            g6_ql0 = ld32_a2(blk + 64 * h + 8 * aq);
+            g6_ql1 = ld32_a2(blk + 64 * h + 8 * aq + 4);
+            g6_ql2 = ld32_a2(blk + 64 * h + 32 + 8 * aq);
+            g6_ql3 = ld32_a2(blk + 64 * h + 32 + 8 * aq + 4);
+            g6_qh0 = ld32_a2(blk + 128 + 32 * h + 8 * aq);
+            g6_qh1 = ld32_a2(blk + 128 + 32 * h + 8 * aq + 4);
+            g6_sc0 = ld32_a2(blk + 192 + 8 * h);
+            g6_sc1 = ld32_a2(blk + 192 + 8 * h + 4);
+            g6_d = ld16(blk + 208);
+        }
         const size_t bo = (size_t) sb * sizeof(q8k_dev) + 128 * h;
         g_b0 = *(const uint4 *) (bsrc0 + bo);
         g_b1 = *(const uint4 *) (bsrc1 + bo);
@@ -120,14 +136,17 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
             g_b3 = *(const uint4 *) (bsrc3 + bo);
         }
         if (h == 1 && tid < 128) {
-            g_bs0 = *(const uint4 *) mcol[sb].bsums;
-            g_bs1 = *(const uint4 *) (mcol[sb].bsums + 8);
+            if constexpr (!Q6) {
+                g_bs0 = *(const uint4 *) mcol[sb].bsums;
+                g_bs1 = *(const uint4 *) (mcol[sb].bsums + 8);
+            }
             g_dy = mcol[sb].d;
         }
     };
 
     auto stage = [&](const int h) {
         char * buf = smem + h * STAGE;
+        if constexpr (!Q6) {
         // ---- weight pieces: this thread owns 16 values of sub-block 2*j2 (low nibbles) and of 2*j2+1 (high nibbles)
         const int j2 = 2 * h + (aq >> 1);
         uint32_t scp;  // (sc of sub-block 2*j2) | (sc of 2*j2+1) << 8
@@ -163,6 +182,38 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
             *(uint4 *) (Ap + aoff_lo) = make_uint4(pk_mul_u16x2(l4[0], dlo[p]), pk_mul_u16x2(l4[1], dlo[p]), pk_mul_u16x2(l4[2], dlo[p]), pk_mul_u16x2(l4[3], dlo[p]));
             *(uint4 *) (Ap + aoff_hi) = make_uint4(pk_mul_u16x2(h4[0], dhi[p]), pk_mul_u16x2(h4[1], dhi[p]), pk_mul_u16x2(h4[2], dhi[p]), pk_mul_u16x2(h4[3], dhi[p]));
         }
+        } else {
+            // Q6_K: values q - 32 in [-32, 31] times an int8 scale reach +-4096, so the PRODUCT is split instead of the scale:
+            // p = (q - 32) * sc = 64 * p1 + p0 with p0 = p & 63 in [0, 63] and p1 = p >> 6 in [-64, 62] — two int8 pieces again.
+            // This thread: l = 8*aq .. +7 of the four 32-value groups w = 0..3 of the half -> elements 32*w + l, scale 2*w + (aq >> 1)
+            typedef short short2v __attribute__((ext_vector_type(2)));
+            const int is = aq >> 1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t scw = (w & 2) ? g6_sc1 : g6_sc0;                           // scales 4*(w>>1) .. +3 of the half
+                const int sc = (int) (int8_t) (scw >> (8 * (2 * (w & 1) + is)));           // scale index 2*w + is
+                const uint32_t scp = ((uint32_t) sc & 0xFFFFu) * 0x00010001u;
+                const uint32_t cp = ((uint32_t) (-32 * sc) & 0xFFFFu) * 0x00010001u;
+                uint32_t o1[2], o0[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint32_t ql = (w & 1) ? (i ? g6_ql3 : g6_ql2) : (i ? g6_ql1 : g6_ql0);
+                    const uint32_t qh = i ? g6_qh1 : g6_qh0;
+                    const uint32_t nib = (w & 2) ? ((ql >> 4) & 0x0F0F0F0Fu) : (ql & 0x0F0F0F0Fu);
+                    const uint32_t u = nib | (((qh >> (2 * w)) & 0x03030303u) << 4);   // four 6-bit values
+                    const short2v pa = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, u, 0x0c010c00u)) * __builtin_bit_cast(short2v, scp) + __builtin_bit_cast(short2v, cp);
+                    const short2v pb = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, u, 0x0c030c02u)) * __builtin_bit_cast(short2v, scp) + __builtin_bit_cast(short2v, cp);
+                    const uint32_t pa1 = __builtin_bit_cast(uint32_t, pa >> (short2v){6, 6}), pb1 = __builtin_bit_cast(uint32_t, pb >> (short2v){6, 6});
+                    const uint32_t pa0 = __builtin_bit_cast(uint32_t, pa) & 0x003F003Fu, pb0 = __builtin_bit_cast(uint32_t, pb) & 0x003F003Fu;
+                    // low bytes of the four 16-bit lanes -> one dword (element order 0,1,2,3)
+                    o1[i] = __builtin_amdgcn_perm(pb1, pa1, 0x06040200u);
+                    o0[i] = __builtin_amdgcn_perm(pb0, pa0, 0x06040200u);
+                }
+                const int off = sw_off(arow, 2 * w + is) + 8 * (aq & 1);
+                *(uint2 *) (buf + off) = make_uint2(o1[0], o1[1]);
+                *(uint2 *) (buf + TA + off) = make_uint2(o0[0], o0[1]);
+            }
+        }
         // ---- activation tile: raw int8
         char * Bt = buf + NP * TA;
         *(uint4 *) (Bt + boff0) = g_b0;
@@ -173,7 +224,11 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
         }
         // ---- per-super-block metadata (staged with the second half; consumed at the end of that trip)
         if (h == 1) {
-            if (aq == 0) {
+            if constexpr (Q6) {
+                if (aq == 0) dd[arow] = make_float2(h2f(g6_d), 0.0f);
+                if (tid < 128) dyv[tid] = g_dy;
+            }
+            if (!Q6 && aq == 0) {
                 const float d = h2f((uint16_t) (g_hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (g_hdr.x >> 16));
                 dd[arow] = make_float2(d, dmin);
                 const uint32_t hz = g_hdr.z, hw = g_hdr.w;
@@ -189,7 +244,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
                 dm[0] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
                 dm[1] = make_uint4(pm[4], pm[5], pm[6], pm[7]);
             }
-            if (tid < 128) {
+            if (!Q6 && tid < 128) {
                 dyv[tid] = g_dy;
                 const uint32_t bw[8] = {g_bs0.x, g_bs0.y, g_bs0.z, g_bs0.w, g_bs1.x, g_bs1.y, g_bs1.z, g_bs1.w};
                 uint32_t pb[8];
@@ -226,11 +281,15 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
     };
 
     auto fold = [&]() {
-        const half8 fam = *(const half8 *) (Am + (nslab * 32 + fr) * MI_MS + kg * 16);
+        half8 fam;
+        if constexpr (!Q6) fam = *(const half8 *) (Am + (nslab * 32 + fr) * MI_MS + kg * 16);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const half8 fbm = *(const half8 *) (Bm + (mhalf * 64 + t * 32 + fr) * MI_MS + kg * 16);
-            const float16v am = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fbm, zerof, 0, 0, 0);
+            float16v am = zerof;
+            if constexpr (!Q6) {
+                const half8 fbm = *(const half8 *) (Bm + (mhalf * 64 + t * 32 + fr) * MI_MS + kg * 16);
+                am = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fbm, zerof, 0, 0, 0);
+            }
             const float dy = dyv[mhalf * 64 + t * 32 + fr];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -238,8 +297,9 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
                 const float2 sd = dd[i];
                 int isum;
                 if constexpr (QT == 4) isum = (acc[0][t][r] << 3) + acc[1][t][r];
-                else isum = (acc[0][t][r] << 4) + (acc[1][t][r] << 2) + acc[2][t][r];
-                const float v = sd.x * (float) isum - sd.y * am[r];
+                else if constexpr (QT == 5) isum = (acc[0][t][r] << 4) + (acc[1][t][r] << 2) + acc[2][t][r];
+                else isum = (acc[0][t][r] << 6) + acc[1][t][r];
+                const float v = Q6 ? sd.x * (float) isum : sd.x * (float) isum - sd.y * am[r];
                 C[t][r] += dy * v;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) acc[p][t][r] = 0;
@@ -287,11 +347,11 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
 
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M) {
     (void) N;
-    return (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K) && (K % 256) == 0 && M >= 9;
+    return (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K) && (K % 256) == 0 && M >= 9;
 }
 
 template <int QT, int BN> static void launch_mmq8_t(hipStream_t s, mmq8_args a) {
-    constexpr int NP = QT == 4 ? 2 : 3;
+    constexpr int NP = QT == 5 ? 3 : 2;
     const size_t lds = 2 * (size_t) (NP * BN * 128 + MI_BM * 128) + (size_t) (BN + MI_BM) * MI_MS + BN * sizeof(float2) + MI_BM * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -347,9 +407,12 @@ void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, in
     if (type == GGML_TYPE_Q4_K) {
         if (bn == 128) launch_mmq8_t<4, 128>(s, a);
         else launch_mmq8_t<4, 64>(s, a);
-    } else {
+    } else if (type == GGML_TYPE_Q5_K) {
         if (bn == 128) launch_mmq8_t<5, 128>(s, a);
         else launch_mmq8_t<5, 64>(s, a);
+    } else {
+        if (bn == 128) launch_mmq8_t<6, 128>(s, a);
+        else launch_mmq8_t<6, 64>(s, a);
     }
     if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride);
 }
