@@ -190,6 +190,7 @@ struct exec_state {
     // for them; each consumer recomputes norm*w in its prologue (mmvq.hip PRO=2)
     std::unordered_map<const ggml_tensor *, deferred_norm> deferred;
     std::vector<char> done;  // nodes already executed out of order by a multi-chain fusion
+    bool q8_fresh = false;   // the node just executed produced the quantised-activation cache for its own output
 };
 
 static int use_count(const exec_state & st, const ggml_tensor * t) {
@@ -322,6 +323,38 @@ static const ggml_tensor * add_partner(const ggml_tensor * add, const ggml_tenso
 // May the pair [RMS_NORM n (node i), MUL m (node i+1)] be left un-launched?  Yes when m is a single row consumed ONLY
 // as src1 of K-quant MUL_MATs (each recomputes norm*w in its prologue), and no node up to the last consumer writes
 // memory overlapping x — the host allocator may already have recycled x's block if the norm was its last reader.
+// Batches (M > 1): may the producer of `t` (node index `at`) write ONLY the Q8_K blocks of its result into the activation
+// scratch?  Yes when every use of t is src1 of a K-quant MUL_MAT and no other quantised mat-mul (which would overwrite the
+// scratch) runs before the last of them.
+static bool quant_consumers_only(const exec_state & st, int at, const ggml_tensor * t) {
+    if ((t->flags & GGML_TENSOR_FLAG_OUTPUT) || t->type != GGML_TYPE_F32 || (t->ne[0] % 256) != 0 || t->ne[0] > 16384 * 4) return false;
+    const ggml_cgraph * g = st.g;
+    int last = -1, n_cons = 0;
+    for (int j = at + 1; j < g->n_nodes; ++j) {
+        const ggml_tensor * u = g->nodes[j];
+        for (int s = 0; s < GGML_MAX_SRC; ++s) {
+            if (u->src[s] != t) continue;
+            const ggml_tensor * wt = u->src[0];
+            if (!(u->op == GGML_OP_MUL_MAT && s == 1 && (wt->type == GGML_TYPE_Q4_K || wt->type == GGML_TYPE_Q5_K || wt->type == GGML_TYPE_Q6_K))) return false;
+            last = j;
+            n_cons++;
+        }
+    }
+    if (n_cons == 0 || n_cons != use_count(st, t)) return false;
+    for (int j = at + 1; j <= last; ++j) {
+        const ggml_tensor * u = g->nodes[j];
+        if (u->op == GGML_OP_MUL_MAT && is_quant(u->src[0]->type) && u->src[1] != t) return false;
+        if (u->op == GGML_OP_MUL_MAT_ID) return false;
+    }
+    return true;
+}
+static void mark_q8_cache(exec_state & st, const ggml_tensor * t) {
+    st.c->q8_src = t->data;
+    st.c->q8_kind = GGML_TYPE_Q8_K;
+    st.c->q8_bytes = ggml_abi_nbytes(t);
+    st.q8_fresh = true;
+}
+
 static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, const ggml_tensor * m, const ggml_tensor * x, const ggml_tensor * w) {
     if (ggml_abi_nrows(m) != 1 || (m->flags & GGML_TENSOR_FLAG_OUTPUT) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
     if (!ggml_abi_is_contiguous(x) || ((((uintptr_t) x->data) | ((uintptr_t) w->data)) & 15) || (x->ne[0] % 256) != 0 || x->ne[0] > 16384) return false;
@@ -561,6 +594,15 @@ static int run_node(exec_state & st, int i) {
                         c->st.fused_nodes += 2;
                         return 2;
                     }
+                    if (c->opt.prologue && ggml_abi_nrows(m) > 1 && a->nb[0] == 4 && (a->nb[1] % 16) == 0 && a->ne[0] <= 16384 &&
+                        !((((uintptr_t) a->data) | ((uintptr_t) w->data)) & 15) && quant_consumers_only(st, i + 1, m)) {
+                        timed_scope ts(c, "rms_norm_mul_quantize", (double) ggml_abi_nbytes(a));
+                        launch_rms_norm_mul_quantize(s, TD(a), (const float *) w->data, ggml_abi_op_param_f32(n, 0), (char *) c->ws + st.act_off);
+                        mark_q8_cache(st, m);
+                        c->st.kernel_launches++;
+                        c->st.fused_nodes += 2;
+                        return 2;
+                    }
                     const tdesc wd = TD(w);
                     timed_scope ts(c, "rms_norm_mul", (double) ggml_abi_nbytes(a) * 2);
                     launch_rms_norm(s, TD(a), TD(m), ggml_abi_op_param_f32(n, 0), &wd);
@@ -636,6 +678,15 @@ static int run_node(exec_state & st, int i) {
             return 1;
         case GGML_OP_GLU: {
             const tdesc bd = b ? TD(b) : TD(a);
+            if (fuse && c->opt.prologue && ggml_abi_nrows(n) > 1 && (a->nb[1] % 16) == 0 && (!b || (b->nb[1] % 16) == 0) && !(((uintptr_t) a->data) & 15) &&
+                (!b || !(((uintptr_t) b->data) & 15)) && (b || ((n->ne[0] * 4) % 16) == 0) && quant_consumers_only(st, i, n)) {
+                timed_scope ts(c, "swiglu_quantize", (double) ggml_abi_nbytes(n) * 2);
+                launch_swiglu_quantize(s, TD(a), b ? &bd : nullptr, n->ne[0], n->op_params[1], (char *) c->ws + st.act_off);
+                mark_q8_cache(st, n);
+                c->st.kernel_launches++;
+                c->st.fused_nodes++;
+                return 1;
+            }
             timed_scope ts(c, "swiglu", (double) ggml_abi_nbytes(n) * 3);
             launch_swiglu(s, TD(a), b ? &bd : nullptr, TD(n), n->op_params[1]);
             c->st.kernel_launches++;
@@ -726,7 +777,9 @@ static bool run_nodes(backend_ctx * c, ggml_cgraph * g, const ws_plan & wp) {
         // anything that writes memory invalidates a cached quantisation of that memory
         const int used = run_node(st, i);
         if (used < 0) return false;
-        for (int k = 0; k < used; ++k) if (g->nodes[i + k]->data == c->q8_src) c->q8_src = nullptr;
+        if (!st.q8_fresh)
+            for (int k = 0; k < used; ++k) if (g->nodes[i + k]->data == c->q8_src) c->q8_src = nullptr;
+        st.q8_fresh = false;
         i += used;
     }
     return hipGetLastError() == hipSuccess;

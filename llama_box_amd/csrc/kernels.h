@@ -109,6 +109,9 @@ void launch_binary(hipStream_t s, int op, const tdesc & a, const tdesc & b, cons
 void launch_scale(hipStream_t s, const tdesc & src, const tdesc & dst, float scale, float bias);
 void launch_unary(hipStream_t s, int uop, const tdesc & src, const tdesc & dst);
 void launch_swiglu(hipStream_t s, const tdesc & a, const tdesc * b, const tdesc & dst, int swapped);
+// producers fused with the Q8_K activation quantisation (quantize.hip): the f32 intermediate is not written
+void launch_rms_norm_mul_quantize(hipStream_t s, const tdesc & x, const float * w, float eps, void * dst_q8k);
+void launch_swiglu_quantize(hipStream_t s, const tdesc & a, const tdesc * b, int64_t nc, int swapped, void * dst_q8k);
 void launch_cpy(hipStream_t s, const tdesc & src, const tdesc & dst);
 void launch_get_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
 void launch_set_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);

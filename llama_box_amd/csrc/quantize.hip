@@ -62,6 +62,78 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const char * __restrict__ 
     if ((lane & 7) == 0) y->d = h2f(f2h(d));
 }
 
+// ---- producers fused with the quantisation (batches: the f32 intermediate is never written).  Same f32 arithmetic as the
+// stand-alone kernels (ops.hip k_rms_norm + k_binary MUL, k_swiglu), so the Q8_K blocks are the ones the unfused path builds.
+// RMS_NORM(x) * w -> Q8_K: one 16-wave workgroup per row, wave w owns blocks w, w+16, w+32, w+48 (K <= 16384)
+__global__ void __launch_bounds__(1024) k_rms_norm_mul_q8_K(const char * __restrict__ src, const int64_t nb1, const float * __restrict__ w, const float eps, const int K,
+                                                            q8k_dev * __restrict__ dst) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = K / 256;
+    const float4 * x4 = (const float4 *) (src + (int64_t) blockIdx.x * nb1);
+    const float4 * w4 = (const float4 *) w;
+    float4 v[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int b = wave + 16 * u;
+        if (b < nblk) {
+            v[u] = x4[b * 64 + lane];
+            g[u] = w4[b * 64 + lane];
+        } else {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g[u] = v[u];
+        }
+    }
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ss += (double) (v[u].x * v[u].x) + (double) (v[u].y * v[u].y) + (double) (v[u].z * v[u].z) + (double) (v[u].w * v[u].w);
+    ss = wave_sum_d(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    const float mean = (float) (tot / (double) K);
+    const float scale = 1.0f / sqrtf(mean + eps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int b = wave + 16 * u;
+        if (b < nblk) {
+            float t[4] = {(v[u].x * scale) * g[u].x, (v[u].y * scale) * g[u].y, (v[u].z * scale) * g[u].z, (v[u].w * scale) * g[u].w};
+            wave_quantize_q8_K(t, lane, dst + (int64_t) blockIdx.x * nblk + b);
+        }
+    }
+}
+void launch_rms_norm_mul_quantize(hipStream_t s, const tdesc & x, const float * w, float eps, void * dst) {
+    const int64_t rows = x.ne[1] * x.ne[2] * x.ne[3];
+    hipLaunchKernelGGL(k_rms_norm_mul_q8_K, dim3((unsigned) rows), dim3(1024), 0, s, x.data, x.nb[1], w, eps, (int) x.ne[0], (q8k_dev *) dst);
+}
+
+// silu(a) * b -> Q8_K: one wave per 256-value block, four blocks per workgroup
+__global__ void __launch_bounds__(256) k_swiglu_q8_K(const char * __restrict__ pa, const char * __restrict__ pb, const int64_t nba1, const int64_t nbb1, const int nb_per_row,
+                                                     const int64_t total, q8k_dev * __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gid = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= total) return;
+    const int64_t row = gid / nb_per_row;
+    const int ib = (int) (gid - row * nb_per_row);
+    const float4 a = ((const float4 *) (pa + row * nba1))[ib * 64 + lane], b = ((const float4 *) (pb + row * nbb1))[ib * 64 + lane];
+    float t[4] = {silu_f(a.x) * b.x, silu_f(a.y) * b.y, silu_f(a.z) * b.z, silu_f(a.w) * b.w};
+    wave_quantize_q8_K(t, lane, dst + gid);
+}
+void launch_swiglu_quantize(hipStream_t s, const tdesc & a, const tdesc * b, int64_t nc, int swapped, void * dst) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    const char * pa = a.data;
+    const char * pb = b ? b->data : a.data;
+    if (!b) {
+        pa += swapped ? nc * 4 : 0;
+        pb += swapped ? 0 : nc * 4;
+    }
+    const int nb = (int) (nc / 256);
+    const int64_t total = rows * nb;
+    hipLaunchKernelGGL(k_swiglu_q8_K, dim3((unsigned) ((total + 3) / 4)), dim3(256), 0, s, pa, pb, a.nb[1], b ? b->nb[1] : a.nb[1], nb, total, (q8k_dev *) dst);
+}
+
 size_t quantized_act_bytes(int kind, int64_t K, int64_t rows) {
     if (kind == GGML_TYPE_Q8_K) return (size_t) rows * (size_t) (K / 256) * sizeof(q8k_dev);
     return (size_t) rows * (size_t) (K / 32) * sizeof(q80_dev);
