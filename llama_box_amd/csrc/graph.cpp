@@ -262,12 +262,16 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         return true;
     }
     const void * act = quantized_src1(st, b, w->type);
-    if (M >= c->opt.mmq_min_cols && !w2 && !add && mmq_supported(w->type, K, N, M)) {
+    const bool i8 = c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M);
+    if (M >= c->opt.mmq_min_cols && !w2 && !add2 && (!add || i8) && mmq_supported(w->type, K, N, M)) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
         const int ks = (N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M) : 1;
         float * part = (float *) ((char *) c->ws + st.aux_off);
-        if (c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M))
-            launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn, ks, part);
+        if (i8) {
+            const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
+            launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn, ks, part,
+                          add ? (const float *) add->data : nullptr, (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4));
+        }
         else
             launch_mmq(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), ks, part);
         if (ks > 1) c->st.kernel_launches++;
@@ -320,9 +324,6 @@ static const ggml_tensor * add_partner(const ggml_tensor * add, const ggml_tenso
     return o;
 }
 
-// May the pair [RMS_NORM n (node i), MUL m (node i+1)] be left un-launched?  Yes when m is a single row consumed ONLY
-// as src1 of K-quant MUL_MATs (each recomputes norm*w in its prologue), and no node up to the last consumer writes
-// memory overlapping x — the host allocator may already have recycled x's block if the norm was its last reader.
 // Batches (M > 1): may the producer of `t` (node index `at`) write ONLY the Q8_K blocks of its result into the activation
 // scratch?  Yes when every use of t is src1 of a K-quant MUL_MAT and no other quantised mat-mul (which would overwrite the
 // scratch) runs before the last of them.
@@ -355,6 +356,9 @@ static void mark_q8_cache(exec_state & st, const ggml_tensor * t) {
     st.q8_fresh = true;
 }
 
+// May the pair [RMS_NORM n (node i), MUL m (node i+1)] be left un-launched?  Yes when m is a single row consumed ONLY
+// as src1 of K-quant MUL_MATs (each recomputes norm*w in its prologue), and no node up to the last consumer writes
+// memory overlapping x — the host allocator may already have recycled x's block if the norm was its last reader.
 static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, const ggml_tensor * m, const ggml_tensor * x, const ggml_tensor * w) {
     if (ggml_abi_nrows(m) != 1 || (m->flags & GGML_TENSOR_FLAG_OUTPUT) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
     if (!ggml_abi_is_contiguous(x) || ((((uintptr_t) x->data) | ((uintptr_t) w->data)) & 15) || (x->ne[0] % 256) != 0 || x->ne[0] > 16384) return false;
@@ -649,6 +653,16 @@ static int run_node(exec_state & st, int i) {
                         c->st.fused_nodes += 2;
                         return 3;
                     }
+                    if (!run_mul_mat_q(st, a, nullptr, b, a1, o1, nullptr)) return -1;
+                    c->st.fused_nodes += 1;
+                    return 2;
+                }
+            }
+            if (fuse && !rowpar && M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) {
+                // batches: MUL_MAT -> ADD (bias row or residual) rides in the GEMM's store
+                ggml_tensor * a1 = next(1);
+                const ggml_tensor * o1 = (a1 && single_use(st, n)) ? add_partner(a1, n) : nullptr;
+                if (o1) {
                     if (!run_mul_mat_q(st, a, nullptr, b, a1, o1, nullptr)) return -1;
                     c->st.fused_nodes += 1;
                     return 2;

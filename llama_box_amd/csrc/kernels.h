@@ -98,9 +98,9 @@ size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M);
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M);
 // ksplit > 1: the K range is split over that many workgroup rows, partials in `part` (mmq_workspace_bytes), summed in a fixed order
 int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M);
-void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride);
+void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part);
+                   int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride);
 void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int ksplit, float * part);
 
 // ---- element-wise / normalisation / data movement (ops.hip)

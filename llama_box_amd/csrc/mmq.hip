@@ -374,7 +374,7 @@ void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K
     if (type == GGML_TYPE_Q4_K) launch_mmq_t<4>(s, a);
     else if (type == GGML_TYPE_Q5_K) launch_mmq_t<5>(s, a);
     else launch_mmq_t<6>(s, a);
-    if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride);
+    if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride, nullptr, 0);
 }
 
 }  // namespace mi355x

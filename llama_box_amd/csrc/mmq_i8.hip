@@ -38,6 +38,8 @@ struct mmq8_args {
     int n_panels, m_tiles;
     int ksplit;          // > 1: blockIdx.y owns a contiguous range of super-blocks and writes its partial [M][N] result ...
     float * part;        // ... to part + blockIdx.y * M * N (summed in a fixed order by k_splitk_reduce)
+    const float * add;   // optional epilogue: + add[m * add_stride + n] (bias row: stride 0, residual: stride N)
+    int64_t add_stride;
 };
 
 constexpr int MI_BM = 128;
@@ -332,14 +334,20 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
         const int m = m0 + mhalf * 64 + t * 32 + fr;
         if (m >= a.M) continue;
         float * out = a.ksplit > 1 ? a.part + ((size_t) blockIdx.y * a.M + m) * a.N : a.dst + (size_t) m * a.dst_stride;
+        const float * ad = (a.add && a.ksplit == 1) ? a.add + (size_t) m * a.add_stride : nullptr;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = n0 + nslab * 32 + 8 * g + 4 * kg;
+            float c4[4] = {C[t][4 * g], C[t][4 * g + 1], C[t][4 * g + 2], C[t][4 * g + 3]};
+            if (ad) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < a.N) c4[r] += ad[n + r];
+            }
             if (n + 3 < a.N && ((((uintptr_t) (out + n)) & 15) == 0)) {
-                *(float4 *) (out + n) = make_float4(C[t][4 * g], C[t][4 * g + 1], C[t][4 * g + 2], C[t][4 * g + 3]);
+                *(float4 *) (out + n) = make_float4(c4[0], c4[1], c4[2], c4[3]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < a.N) out[n + r] = C[t][4 * g + r];
+                for (int r = 0; r < 4; ++r) if (n + r < a.N) out[n + r] = c4[r];
             }
         }
     }
@@ -371,7 +379,8 @@ int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M) {
     const int64_t wgs = ((N + 63) / 64) * ((M + 127) / 128), nblk = K / 256;
     return (int) std::max<int64_t>(1, std::min<int64_t>(nblk, 768 / std::max<int64_t>(1, wgs)));
 }
-__global__ void __launch_bounds__(256) k_splitk_reduce(const float * __restrict__ part, const int ks, const int64_t mn, const int N, float * __restrict__ dst, const int64_t dst_stride) {
+__global__ void __launch_bounds__(256) k_splitk_reduce(const float * __restrict__ part, const int ks, const int64_t mn, const int N, float * __restrict__ dst, const int64_t dst_stride,
+                                                       const float * __restrict__ add, const int64_t add_stride) {
     const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= mn) return;
     float4 acc = *(const float4 *) (part + e);
@@ -380,15 +389,19 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float * __restrict_
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     const int64_t m = e / N, n = e % N;  // N % 4 == 0 (checked by the launcher)
+    if (add) {
+        const float * ad = add + m * add_stride + n;
+        acc.x += ad[0]; acc.y += ad[1]; acc.z += ad[2]; acc.w += ad[3];
+    }
     *(float4 *) (dst + m * dst_stride + n) = acc;
 }
-void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride) {
+void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride, const float * add, int64_t add_stride) {
     const int64_t mn = (int64_t) M * N;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned) ((mn / 4 + 255) / 256)), dim3(256), 0, s, part, ks, mn, N, dst, dst_stride);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned) ((mn / 4 + 255) / 256)), dim3(256), 0, s, part, ks, mn, N, dst, dst_stride, add, add_stride);
 }
 
 void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part) {
+                   int ksplit, float * part, const float * add, int64_t add_stride) {
     mmq8_args a;
     a.W = W;
     a.w_nb1 = w_nb1;
@@ -401,6 +414,8 @@ void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, in
     a.n_panels = a.m_tiles = 0;
     a.ksplit = std::max(1, ksplit);
     a.part = part;
+    a.add = add;
+    a.add_stride = add_stride;
     // 128-row panels unless that leaves CUs idle (256 CUs, one 8-wave workgroup each)
     const int64_t wg128 = (int64_t) ((N + 127) / 128) * ((M + MI_BM - 1) / MI_BM);
     const int bn = force_bn ? force_bn : (wg128 >= 256 && a.ksplit == 1 ? 128 : 64);
@@ -414,7 +429,7 @@ void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, in
         if (bn == 128) launch_mmq8_t<6, 128>(s, a);
         else launch_mmq8_t<6, 64>(s, a);
     }
-    if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride);
+    if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride, add, add_stride);
 }
 
 }  // namespace mi355x

@@ -25,11 +25,11 @@ int main(int argc, char ** argv) {
         std::vector<uint8_t> ha(ab); for (size_t i = 0; i < ab; ++i) ha[i] = (uint8_t) (i * 40503u >> 7);
         CK(hipMemcpy(A, ha.data(), ab, hipMemcpyHostToDevice));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) launch_mmq_i8(s, GGML_TYPE_Q4_K, W, (int64_t) (sh.K / 256) * 144, sh.K, sh.N, sh.M, A, O, sh.N, mt, 1, nullptr);
+        for (int i = 0; i < 3; ++i) launch_mmq_i8(s, GGML_TYPE_Q4_K, W, (int64_t) (sh.K / 256) * 144, sh.K, sh.N, sh.M, A, O, sh.N, mt, 1, nullptr, nullptr, 0);
         CK(hipStreamSynchronize(s));
         const int reps = 20;
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < reps; ++i) launch_mmq_i8(s, GGML_TYPE_Q4_K, W, (int64_t) (sh.K / 256) * 144, sh.K, sh.N, sh.M, A, O, sh.N, mt, 1, nullptr);
+        for (int i = 0; i < reps; ++i) launch_mmq_i8(s, GGML_TYPE_Q4_K, W, (int64_t) (sh.K / 256) * 144, sh.K, sh.N, sh.M, A, O, sh.N, mt, 1, nullptr, nullptr, 0);
         CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps, tf = 2.0 * sh.N * sh.K * sh.M / (us * 1e-6) / 1e12;

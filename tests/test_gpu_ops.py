@@ -519,7 +519,7 @@ def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias):
 
 # ------------------------------------------------------------------------------------------------ fused chains
 @pytest.mark.parametrize("qt", QTYPES)
-@pytest.mark.parametrize("M", [1, 4])
+@pytest.mark.parametrize("M", [1, 4, 32, 130])
 def test_fused_chains_equal_unfused(backend, H, plog, qt, M):
     """norm->mul->{gate,up}->swiglu->down->+bias->+residual with fusion on == fusion off == oracle."""
     rng = np.random.default_rng(21 + qt + M)
