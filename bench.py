@@ -144,6 +144,7 @@ def main():
     # ---- prefill (reported beside the headline; v1 path = column chunks of the bandwidth kernel)
     pos = 0
     prefill_tok_s = None
+    prefill_host_split = [0, 0, 0, 0]
     if args.prefill > 0:
         sync()
         t0 = time.perf_counter()
@@ -153,6 +154,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         prefill_tok_s = args.np * args.prefill / (t1 - t0)
+        prefill_host_split = ctx.timings()  # of the last sequence's prefill: summed over its micro-batches
         pos = args.prefill
 
     def step(i):
@@ -251,6 +253,7 @@ def main():
             "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode, flash_attn={args.fa}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
                        "parallelism": parallelism, "n_past_mid": n_past, "weight_bytes_per_token_per_gpu": w_bytes, "kv_bytes_per_token_per_gpu": kv_per_tok * n_past},
             "prefill_tok_s": round(prefill_tok_s, 1) if prefill_tok_s else None,
+            "prefill_host_us": {"build": round(prefill_host_split[0], 1), "inputs": round(prefill_host_split[1], 1), "compute+sync": round(prefill_host_split[2], 1), "logits_d2h": round(prefill_host_split[3], 1)} if prefill_tok_s else None,
             "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),
             "graph_replayed_steps": int(graph_steps),
             "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},

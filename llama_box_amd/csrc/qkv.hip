@@ -67,12 +67,13 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
     // (a generic lambda, not a device function: passing the kernel-argument struct to a function copies it to scratch)
     auto body = [&](auto tag, const int alt, const int wg, const int nwg) {
     using T = decltype(tag);
-    constexpr int WAVES = 16, QB = 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
+    constexpr int MAXW = 16, QB = 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
+    const int WAVES = (int) blockDim.x >> 6;  // 8..16 waves: the launcher sizes the workgroup so that units/WAVES ~ 256 workgroups
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = a.K / 256;
     q8k_dev * yl = (q8k_dev *) smem;
     double * red = (double *) (smem + (size_t) nblk * sizeof(q8k_dev));
-    float * cs_tab = (float *) (red + WAVES);  // [head_dim/2][2]
+    float * cs_tab = (float *) (red + MAXW);  // [head_dim/2][2]
     const int GW = nwg * WAVES;
     const int half = a.head_dim >> 1;
     const int u0 = a.seg[0].alt == alt ? a.seg[0].N >> 1 : 0;
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
                 __syncthreads();
                 double tot = 0.0;
 #pragma unroll
-                for (int i = 0; i < WAVES; ++i) tot += red[i];
+                for (int i = 0; i < MAXW; ++i) tot += i < WAVES ? red[i] : 0.0;
                 const float mean = (float) (tot / (double) a.K);
                 scale = 1.0f / sqrtf(mean + a.eps);
             }
@@ -226,26 +227,31 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
         bytes[a.seg[i].alt ? 1 : 0] += (double) a.seg[i].N * (double) a.seg[i].w_nb1;
     }
     const size_t lds = (size_t) nblk * sizeof(q8k_dev) + 16 * sizeof(double) + (size_t) a.head_dim * sizeof(float) + 16;
+    // waves per workgroup: 8..16, chosen so that the row-pair units spread over ~256 workgroups (Llama-3-8B: 3072 units ->
+    // 12 waves x 256 workgroups; with fixed 16-wave workgroups a quarter of the CUs had nothing to do); the norm prologue
+    // needs the whole activation row in one batch of 2 blocks per wave
+    const int nw = std::min(16, std::max((nblk + 1) / 2, std::max(8, (units[0] + units[1] + 255) / 256)));
+    const dim3 block((unsigned) nw * 64);
     if (type_a == type_b || units[1] == 0) {
-        const unsigned grid = (unsigned) std::min(256, (units[0] + 15) / 16);
+        const unsigned grid = (unsigned) std::min(256, (units[0] + nw - 1) / nw);
         a.wg_a = (int) grid;
-        if (type_a == GGML_TYPE_Q4_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q4K>), dim3(grid), dim3(1024), lds, s, a);
-        else if (type_a == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q5K>), dim3(grid), dim3(1024), lds, s, a);
-        else if (type_a == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q6K, T_Q6K>), dim3(grid), dim3(1024), lds, s, a);
+        if (type_a == GGML_TYPE_Q4_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q4K>), dim3(grid), block, lds, s, a);
+        else if (type_a == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q5K>), dim3(grid), block, lds, s, a);
+        else if (type_a == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q6K, T_Q6K>), dim3(grid), block, lds, s, a);
         else { MI_ERR("launch_qkv: unsupported weight format %d", type_a); abort(); }
         return;
     }
     // one workgroup per CU at most; when the units would need more, share the 256 slots by weight bytes
-    int ga = (units[0] + 15) / 16, gb = (units[1] + 15) / 16;
+    int ga = (units[0] + nw - 1) / nw, gb = (units[1] + nw - 1) / nw;
     if (ga + gb > 256) {
         gb = std::max(1, std::min(255, (int) (256.0 * bytes[1] / (bytes[0] + bytes[1]) + 0.5)));
         ga = 256 - gb;
     }
     a.wg_a = ga;
     const dim3 grid((unsigned) (ga + gb));
-    if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q6K>), grid, dim3(1024), lds, s, a);
-    else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q6K>), grid, dim3(1024), lds, s, a);
-    else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q5K>), grid, dim3(1024), lds, s, a);
+    if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q6K>), grid, block, lds, s, a);
+    else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q6K>), grid, block, lds, s, a);
+    else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q5K>), grid, block, lds, s, a);
     else { MI_ERR("launch_qkv: unsupported weight format pair %d/%d", type_a, type_b); abort(); }
 }
 
