@@ -375,9 +375,13 @@ template <int QT, int BN> static void launch_mmq8_t(hipStream_t s, mmq8_args a) 
 // few activation columns (continuous-batching decode, M <= 64) leave N/64 x 1 workgroups — far fewer than 256 CUs — so
 // the K range is split over blockIdx.y and the partial products are summed in a fixed order by a second tiny kernel
 int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M) {
-    if (M > 64) return 1;
     const int64_t wgs = ((N + 63) / 64) * ((M + 127) / 128), nblk = K / 256;
-    return (int) std::max<int64_t>(1, std::min<int64_t>(nblk, 768 / std::max<int64_t>(1, wgs)));
+    if (M <= 64) return (int) std::max<int64_t>(1, std::min<int64_t>(nblk, 768 / std::max<int64_t>(1, wgs)));
+    // wide batches (prefill micro-batches): only when the output is too small to occupy the chip (wk/wv: 64 workgroups at
+    // M = 512), or when a long K leaves exactly one workgroup per CU (ffn_down): measured 36 -> 19 us and 134 -> 117 us
+    if (wgs < 256) return (int) std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, nblk / 4), 256 / wgs));
+    if (wgs == 256 && nblk >= 32) return 2;
+    return 1;
 }
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float * __restrict__ part, const int ks, const int64_t mn, const int N, float * __restrict__ dst, const int64_t dst_stride,
                                                        const float * __restrict__ add, const int64_t add_stride) {
