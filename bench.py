@@ -157,8 +157,10 @@ def main():
         prefill_host_split = ctx.timings()  # of the last sequence's prefill: summed over its micro-batches
         pos = args.prefill
 
+    seq_ids = list(range(args.np))
+
     def step(i):
-        rc, lg = ctx.decode([int(toks[(pos + i) * args.np + sq]) for sq in range(args.np)], [pos + i] * args.np, seq=list(range(args.np)))
+        rc, lg = ctx.decode([int(toks[(pos + i) * args.np + sq]) for sq in range(args.np)], [pos + i] * args.np, seq=seq_ids, copy_logits=False)
         assert rc == 0, f"decode failed rc={rc}"
         return lg
 

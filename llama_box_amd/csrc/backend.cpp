@@ -167,6 +167,7 @@ static void be_free(ggml_backend_t be) {
     free_graph_cache(c);
     tp_free(c);
     if (c->ws) HIP_CHECK(hipFree(c->ws));
+    if (c->up_ring) HIP_CHECK(hipHostFree(c->up_ring));
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c;
     delete be;
@@ -174,6 +175,24 @@ static void be_free(ggml_backend_t be) {
 static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
     HIP_CHECK(hipSetDevice(c->device));
+    constexpr size_t SMALL = 64 * 1024, RING = 4u << 20;
+    if (size > 0 && size <= SMALL && c->opt.small_uploads) {
+        if (!c->up_ring) {
+            if (hipHostMalloc((void **) &c->up_ring, RING, hipHostMallocDefault) == hipSuccess) c->up_cap = RING;
+            else { (void) hipGetLastError(); c->up_ring = nullptr; c->opt.small_uploads = false; }
+        }
+        if (c->up_ring) {
+            size_t at = (c->up_head + 255) & ~(size_t) 255;
+            if (at + size > c->up_cap) {  // wrap: everything staged so far must have been consumed
+                HIP_CHECK(hipStreamSynchronize(c->stream));
+                at = 0;
+            }
+            memcpy(c->up_ring + at, data, size);
+            c->up_head = at + size;
+            launch_upload_small(c->stream, (char *) t->data + offset, c->up_ring + at, size);
+            return;
+        }
+    }
     HIP_CHECK(hipMemcpyAsync((char *) t->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_tensor_async(ggml_backend_t be, const ggml_tensor * t, void * data, size_t offset, size_t size) {
@@ -263,6 +282,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_QKV")) c->opt.qkv = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_MIN_COLS")) c->opt.mmq_min_cols = atoi(e);
     if (const char * e = getenv("GGML_MI355X_FA_SPLITS")) c->opt.fa_splits = atoi(e);
+    if (const char * e = getenv("GGML_MI355X_SMALL_UPLOADS")) c->opt.small_uploads = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_I8")) c->opt.mmq_i8 = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_BN")) c->opt.mmq_bn = atoi(e);
     return new ggml_backend{&g_guid, k_backend_iface, dev, c};
@@ -323,6 +343,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "mmq_i8") c->opt.mmq_i8 = v != 0;
     else if (k == "mmq_bn") c->opt.mmq_bn = v;
     else if (k == "fa_splits") c->opt.fa_splits = v;
+    else if (k == "small_uploads") c->opt.small_uploads = v != 0;
     else if (k == "timing") c->opt.timing = v != 0;
     else return -1;
     HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -67,6 +67,7 @@ struct options {
     bool mmq_i8 = true;        // Q4_K/Q5_K batches on the int8 matrix cores (mmq_i8.hip) instead of the f16 variant (mmq.hip)
     int mmq_bn = 0;            // force the weight-panel height of mmq_i8 (64 / 128); 0 = pick by grid size
     int fa_splits = 0;         // 0 = auto
+    bool small_uploads = true; // set_tensor_async of <= 64 KiB: pinned ring + copy kernel instead of a blit
     bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)
 };
 
@@ -108,6 +109,10 @@ struct backend_ctx {
     bool capturing = false;
     // tensor parallel
     tp_state * tp = nullptr;
+    // small host->device uploads (token ids, positions, cache indices, one mask row): staged in a pinned ring and moved by a
+    // tiny kernel — a blit through hipMemcpyAsync costs ~25 us of stream time per copy, five of them per decode step
+    char * up_ring = nullptr;
+    size_t up_cap = 0, up_head = 0;
     // per-class kernel timing (bench)
     std::map<std::string, timing_slot> timing;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;

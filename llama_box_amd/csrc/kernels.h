@@ -116,6 +116,7 @@ void launch_cpy(hipStream_t s, const tdesc & src, const tdesc & dst);
 void launch_get_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
 void launch_set_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
 void launch_argmax(hipStream_t s, const tdesc & src, const tdesc & dst);
+void launch_upload_small(hipStream_t s, void * dst, const void * pinned_src, size_t n);
 
 
 struct rope_params {

@@ -458,4 +458,22 @@ void launch_soft_max(hipStream_t s, const tdesc & a, const tdesc * mask, const f
     hipLaunchKernelGGL(k_soft_max, dim3((unsigned) rows), dim3(256), 0, s, a, mask ? *mask : dummy, mask ? 1 : 0, sinks, d, scale, max_bias, m0, m1, n_head_log2);
 }
 
+// ---- small upload: copies `n` bytes from pinned host memory (device-visible) into device memory inside the stream
+__global__ void __launch_bounds__(256) k_upload_small(char * __restrict__ dst, const char * __restrict__ src, const size_t n, const int vec) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (vec == 16) {
+        if (i * 16 < n) ((uint4 *) dst)[i] = ((const uint4 *) src)[i];
+    } else if (vec == 4) {
+        if (i * 4 < n) ((uint32_t *) dst)[i] = ((const uint32_t *) src)[i];
+    } else {
+        if (i < n) dst[i] = src[i];
+    }
+}
+void launch_upload_small(hipStream_t s, void * dst, const void * pinned_src, size_t n) {
+    const uintptr_t al = (uintptr_t) dst | (uintptr_t) pinned_src | (uintptr_t) n;
+    const int vec = (al & 15) == 0 ? 16 : ((al & 3) == 0 ? 4 : 1);
+    const size_t items = (n + vec - 1) / vec;
+    hipLaunchKernelGGL(k_upload_small, dim3((unsigned) ((items + 255) / 256)), dim3(256), 0, s, (char *) dst, (const char *) pinned_src, n, vec);
+}
+
 }  // namespace mi355x

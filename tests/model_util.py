@@ -48,7 +48,9 @@ class Context:
         if not self.c:
             raise RuntimeError("context creation failed")
 
-    def decode(self, tokens, pos, seq=None, want=None):
+    def decode(self, tokens, pos, seq=None, want=None, copy_logits=True):
+        """copy_logits=False returns a VIEW of the context's logits buffer (valid until the next decode): what an engine
+        loop that samples in place would use; the default copies (tests keep results across calls)."""
         n = len(tokens)
         tk = (C.c_int32 * n)(*[int(t) for t in tokens])
         ps = (C.c_int32 * n)(*[int(p) for p in pos])
@@ -59,8 +61,8 @@ class Context:
             return rc, None
         no = self.H.llm_n_outputs(self.c)
         nv = self.model.n_vocab_local
-        lg = np.ctypeslib.as_array(self.H.llm_get_logits(self.c), shape=(max(no, 1), nv))[:no].copy()
-        return 0, lg
+        lg = np.ctypeslib.as_array(self.H.llm_get_logits(self.c), shape=(max(no, 1), nv))[:no]
+        return 0, (lg.copy() if copy_logits else lg)
 
     def clear(self):
         self.H.llm_kv_clear(self.c)
