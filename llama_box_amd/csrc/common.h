@@ -42,7 +42,8 @@ int log_level();
 // qs | bsums | d) — produced by quantize kernels, consumed by the K-quant matvec / GEMM kernels
 struct q8k_dev {
     int8_t qs[256];
-    int16_t bsums[16];  // block_q8_K.bsums: sums over 16 values
+    uint16_t bsums[16]; // block_q8_K.bsums (sums over 16 values, |.| <= 2032) stored as IEEE f16 — exact — because their only
+                        // readers are the matrix-core GEMMs, which feed them to an f16 MFMA as they are
     int16_t bs32[8];    // sums over 32 values (what the Q4_K/Q5_K mins term needs per sub-block)
     float d;
     float pad[3];

@@ -122,7 +122,7 @@ template <typename Q8K> __device__ __forceinline__ void wave_quantize_q8_K(const
     int s = q[0] + q[1] + q[2] + q[3];
     s += dpp_i32<MI_DPP_QUAD_XOR1>(s);
     s += dpp_i32<MI_DPP_QUAD_XOR2>(s);
-    if ((lane & 3) == 0) y->bsums[lane >> 2] = (int16_t) s;
+    if ((lane & 3) == 0) y->bsums[lane >> 2] = f2h((float) s);  // |s| <= 2032: exact in f16
     const int s32 = s + dpp_i32<MI_DPP_HALF_MIRROR>(s);  // every lane of a quad holds the quad sum: add the other quad of the 8-lane group
     if ((lane & 7) == 0) y->bs32[lane >> 3] = (int16_t) s32;
     if (lane == 0) {

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(512) k_mmq(const mmq_args a) {
                 if constexpr (!Q6) {
                     uint32_t pb[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pb[j] = bvalid ? pack_h2((int) ycol[sb].bsums[2 * j], (int) ycol[sb].bsums[2 * j + 1]) : 0u;
+                    for (int j = 0; j < 8; ++j) pb[j] = bvalid ? ((const uint32_t *) ycol[sb].bsums)[j] : 0u;  // already f16
                     uint4 * dbm = (uint4 *) (Bm + bcol * MQ_MS);
                     dbm[0] = make_uint4(pb[0], pb[1], pb[2], pb[3]);
                     dbm[1] = make_uint4(pb[4], pb[5], pb[6], pb[7]);

@@ -234,13 +234,18 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
                 const float d = h2f((uint16_t) (g_hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (g_hdr.x >> 16));
                 dd[arow] = make_float2(d, dmin);
                 const uint32_t hz = g_hdr.z, hw = g_hdr.w;
+                const uint32_t mlo = hz & 0x3F3F3F3Fu, mhi = ((hw >> 4) & 0x0F0F0F0Fu) | ((hz >> 2) & 0x30303030u);  // mins 0..3 / 4..7 as bytes
                 uint32_t pm[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int mlo = (int) ((hz >> (8 * j)) & 63);
-                    const int mhi = (int) (((hw >> (8 * j + 4)) & 0xF) | ((((hz >> (8 * j)) & 0xFF) >> 6) << 4));
-                    pm[j] = pack_h2i(mlo, mlo);
-                    pm[j + 4] = pack_h2i(mhi, mhi);
+                for (int j = 0; j < 4; ++j) {  // byte j into both 16-bit lanes, then 0x6400 | n == 1024 + n in f16
+                    typedef _Float16 half2m __attribute__((ext_vector_type(2)));
+                    const uint32_t sel = 0x0c000c00u | (uint32_t) j | ((uint32_t) j << 16);
+                    half2m a2 = __builtin_bit_cast(half2m, __builtin_amdgcn_perm(0u, mlo, sel) | 0x64006400u);
+                    half2m b2 = __builtin_bit_cast(half2m, __builtin_amdgcn_perm(0u, mhi, sel) | 0x64006400u);
+                    a2 = a2 - (half2m){(_Float16) 1024.0f, (_Float16) 1024.0f};
+                    b2 = b2 - (half2m){(_Float16) 1024.0f, (_Float16) 1024.0f};
+                    pm[j] = __builtin_bit_cast(uint32_t, a2);
+                    pm[j + 4] = __builtin_bit_cast(uint32_t, b2);
                 }
                 uint4 * dm = (uint4 *) (Am + arow * MI_MS);
                 dm[0] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
@@ -248,13 +253,9 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
             }
             if (!Q6 && tid < 128) {
                 dyv[tid] = g_dy;
-                const uint32_t bw[8] = {g_bs0.x, g_bs0.y, g_bs0.z, g_bs0.w, g_bs1.x, g_bs1.y, g_bs1.z, g_bs1.w};
-                uint32_t pb[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = pack_h2i((int) (int16_t) (bw[j] & 0xFFFF), (int) (int16_t) (bw[j] >> 16));
-                uint4 * dbm = (uint4 *) (Bm + tid * MI_MS);
-                dbm[0] = make_uint4(pb[0], pb[1], pb[2], pb[3]);
-                dbm[1] = make_uint4(pb[4], pb[5], pb[6], pb[7]);
+                uint4 * dbm = (uint4 *) (Bm + tid * MI_MS);  // the Q8_K bsums are stored as f16 already
+                dbm[0] = g_bs0;
+                dbm[1] = g_bs1;
             }
         }
     };
