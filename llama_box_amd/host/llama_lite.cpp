@@ -540,8 +540,12 @@ struct llm_context {
     // [ inputs of one micro-batch | logits of up to pin_out_rows outputs ]
     ggml_backend_buffer_t buf_pin = nullptr;
     char * pin = nullptr;
-    size_t pin_in_bytes = 0;
+    size_t pin_in_bytes = 0;   // per input slot
     int pin_out_rows = 0;
+    // micro-batches without outputs are not waited for (as llama.cpp: the wait happens when results are fetched); each
+    // in-flight micro-batch keeps its own input slot, so the host builds and stages batch i+1 while the GPU runs batch i
+    static constexpr int PIN_SLOTS = 4;
+    int pin_slot = 0, in_flight = 0;
 };
 
 static ggml_tensor * named(ggml_tensor * t, const char * base, int il) {
@@ -705,7 +709,7 @@ extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backe
             if (!c->p.flash_attn) in_bytes += nub * (size_t) n_embd_k * 8;
             in_bytes = (in_bytes + 255) / 256 * 256;
             c->pin_out_rows = 64;
-            c->buf_pin = ggml_backend_buft_alloc_buffer(hbuft, in_bytes + (size_t) c->pin_out_rows * m->n_vocab_l * 4);
+            c->buf_pin = ggml_backend_buft_alloc_buffer(hbuft, in_bytes * llm_context::PIN_SLOTS + (size_t) c->pin_out_rows * m->n_vocab_l * 4);
             if (c->buf_pin) {
                 c->pin = (char *) ggml_backend_buffer_get_base(c->buf_pin);
                 c->pin_in_bytes = in_bytes;
@@ -738,7 +742,8 @@ extern "C" int llm_kv_seq_rm(struct llm_context * c, int seq_id, int p0, int p1)
     return 1;
 }
 
-static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const int8_t * want, float * logits_out, int * n_out_acc) {
+static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const int8_t * want, float * logits_out, int * n_out_acc,
+                         bool defer_sync) {
     llm_model * m = c->model;
     const llm_hparams & hp = m->hp;
     const int n_ctx = c->p.n_ctx;
@@ -776,6 +781,13 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     // and the graph are stream-ordered); without a device backend (CPU oracle) the plain blocking setter is used
     const bool fa = c->p.flash_attn != 0;
     const bool async_io = c->backend != nullptr && c->pin != nullptr;
+    if (async_io && c->in_flight >= llm_context::PIN_SLOTS - 1) {  // the slot about to be re-used may still be in flight
+        ggml_backend_synchronize(c->backend);
+        c->in_flight = 0;
+    }
+    char * const pin_in = c->pin ? c->pin + (size_t) c->pin_slot * c->pin_in_bytes : nullptr;
+    char * const pin_out = c->pin ? c->pin + (size_t) llm_context::PIN_SLOTS * c->pin_in_bytes : nullptr;
+    c->pin_slot = (c->pin_slot + 1) % llm_context::PIN_SLOTS;
     size_t pin_at = 0;
     std::vector<char> heap;  // CPU-oracle path
     auto upload = [&](ggml_tensor * t, size_t bytes, auto fill) {
@@ -783,7 +795,7 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
         if (async_io) {
             pin_at = (pin_at + 63) / 64 * 64;
             LLM_ASSERT(pin_at + bytes <= c->pin_in_bytes);
-            dst = c->pin + pin_at;
+            dst = pin_in + pin_at;
             pin_at += bytes;
         } else {
             heap.resize(bytes);
@@ -842,8 +854,13 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     enum ggml_status st;
     if (async_io) {
         st = ggml_backend_graph_compute_async(c->backend, c->gf);
-        if (st == GGML_STATUS_SUCCESS && async_out) ggml_backend_tensor_get_async(c->backend, c->t_logits, c->pin + c->pin_in_bytes, 0, logit_bytes);
-        ggml_backend_synchronize(c->backend);
+        if (st == GGML_STATUS_SUCCESS && async_out) ggml_backend_tensor_get_async(c->backend, c->t_logits, pin_out, 0, logit_bytes);
+        if (n_outputs > 0 || st != GGML_STATUS_SUCCESS || !defer_sync) {
+            ggml_backend_synchronize(c->backend);
+            c->in_flight = 0;
+        } else {
+            c->in_flight++;
+        }
     } else {
         st = c->backend ? ggml_backend_graph_compute(c->backend, c->gf) : c->compute(c->gf, c->p.n_threads);
     }
@@ -853,7 +870,7 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
         return -2;
     }
     if (n_outputs > 0) {
-        if (async_out) memcpy(logits_out, c->pin + c->pin_in_bytes, logit_bytes);
+        if (async_out) memcpy(logits_out, pin_out, logit_bytes);
         else ggml_backend_tensor_get(c->t_logits, logits_out, 0, logit_bytes);
         *n_out_acc += n_outputs;
     }
@@ -877,8 +894,15 @@ extern "C" int llm_decode(struct llm_context * c, int n_tokens, const int32_t * 
     for (int i0 = 0; i0 < n_tokens; i0 += c->p.n_ubatch) {
         const int n = std::min(c->p.n_ubatch, n_tokens - i0);
         int rc = decode_ubatch(c, n, tokens + i0, pos + i0, seq_id ? seq_id + i0 : nullptr, want_logits ? want_logits + i0 : nullptr,
-                               c->logits.data() + (size_t) c->n_outputs * c->model->n_vocab_l, &c->n_outputs);
-        if (rc != 0) return rc;
+                               c->logits.data() + (size_t) c->n_outputs * c->model->n_vocab_l, &c->n_outputs, /*defer_sync=*/i0 + n < n_tokens);
+        if (rc != 0) {
+            if (c->backend && c->in_flight) { ggml_backend_synchronize(c->backend); c->in_flight = 0; }
+            return rc;
+        }
+    }
+    if (c->backend && c->in_flight) {  // the call returns with everything finished
+        ggml_backend_synchronize(c->backend);
+        c->in_flight = 0;
     }
     return 0;
 }
