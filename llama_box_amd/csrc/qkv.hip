@@ -230,7 +230,10 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     // waves per workgroup: 8..16, chosen so that the row-pair units spread over ~256 workgroups (Llama-3-8B: 3072 units ->
     // 12 waves x 256 workgroups; with fixed 16-wave workgroups a quarter of the CUs had nothing to do); the norm prologue
     // needs the whole activation row in one batch of 2 blocks per wave
-    const int nw = std::min(16, std::max((nblk + 1) / 2, std::max(8, (units[0] + units[1] + 255) / 256)));
+    static const int force_nw = getenv("GGML_MI355X_QKV_WAVES") ? atoi(getenv("GGML_MI355X_QKV_WAVES")) : 0;
+    int nw = std::min(16, std::max((nblk + 1) / 2, 8));
+    while (nw < 16 && (units[0] + nw - 1) / nw + (units[1] + nw - 1) / nw > 256) ++nw;  // smallest workgroup that still gives every wave one unit
+    if (force_nw) nw = force_nw;
     const dim3 block((unsigned) nw * 64);
     if (type_a == type_b || units[1] == 0) {
         const unsigned grid = (unsigned) std::min(256, (units[0] + nw - 1) / nw);
