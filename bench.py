@@ -103,6 +103,8 @@ def main():
     import numpy as np
     import torch  # first: one HIP runtime per process (torch's and /opt/rocm's share the SONAME)
 
+    n_dev = max(1, torch.cuda.device_count())
+    local_rank %= n_dev  # (more ranks than GPUs only happens in the single-GPU dry run of the multi-rank path)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -120,14 +122,28 @@ def main():
     parallelism = "single"
     tp_size, tp_rank = 1, 0
     if world > 1:
-        try:
-            uid = [be.tp_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            be.tp_init(rank, world, uid[0])
+        # every step of the set-up is agreed on by all ranks over gloo, so that a rank that cannot load RCCL (or cannot create
+        # the communicator) never leaves the others blocked in a collective: any failure -> every rank runs a full replica
+        uid, err = [None], ""
+        if rank == 0:
+            try:
+                uid[0] = be.tp_unique_id()
+            except Exception as e:
+                err = f"unique id: {e}"
+        dist.broadcast_object_list(uid, src=0)
+        ok = 1 if uid[0] is not None else 0
+        if ok:
+            try:
+                be.tp_init(rank, world, uid[0])
+            except Exception as e:
+                ok, err = 0, f"comm init: {e}"
+        agreed = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed[0]) == 1:
             tp_size, tp_rank = world, rank
             parallelism = f"tp{world} (row/column tensor-split, RCCL all-reduce x{2 * hp.n_layer}/token)"
-        except Exception as e:  # keep the scaling run alive and say what happened
-            parallelism = f"replicas x{world} (tensor-split init failed: {e})"
+        else:
+            parallelism = f"replicas x{world} (tensor-split set-up failed on some rank{': ' + err if err else ''})"
     t_load = time.time()
     model = Model(hp, 0x5EED, be.buft, tp_rank=tp_rank, tp_size=tp_size, rowpar_buft=be.rowpar_buft() if tp_size > 1 else None)
     t_load = time.time() - t_load
