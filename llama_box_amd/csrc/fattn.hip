@@ -244,7 +244,9 @@ __device__ __forceinline__ float xrow_allmax(const float x) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return fmaxf(a, b);
 }
-template <int G>
+// SKIP = true (several query tokens, e.g. -np 32 decode over a unified cache where each token sees ~1/32 of the cells): the mask
+// of the whole split is read first — one round trip — and trips without a visible position for this wave load no K/V at all.
+template <int G, bool SKIP>
 __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
                                                       const tdesc dst, const fa_geom geo, float * __restrict__ ws, const int g_real) {
     constexpr int D = 128, NG = 16 / G;
@@ -254,10 +256,32 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     const int sub = lane >> 4, sl = lane & 15;
     const int ul = sl / G, gl = sl % G;  // the (row group, head) pair this lane owns in the lane-parallel part
     const int split = blockIdx.x, kvh = blockIdx.y;
-    const int tok = blockIdx.z % geo.n_q, bat = blockIdx.z / geo.n_q;
-    const int per = (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
-    const int kv0 = split * per, kv1 = min(geo.n_kv, kv0 + per);
+    // SKIP (a few query tokens, each seeing its own part of a unified cache): the workgroup first asks the mask whether its
+    // token can see anything in its split — one 8-byte load per lane covers 256 positions — and leaves an empty record
+    // if not: of the 64 x 32 (split, token) pairs of a -np 32 decode step only ~1/16 touch K/V at all
+    const int tok = (int) blockIdx.z % geo.n_q, bat = (int) blockIdx.z / geo.n_q;
+    const int per = SKIP ? ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64 : (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
+    const int kv0 = min(split * per, geo.n_kv), kv1 = min(geo.n_kv, kv0 + per);
     const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
+    if constexpr (SKIP) {
+        const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]);
+        bool any = false;
+        for (int c0 = kv0; c0 < kv1; c0 += 256) {
+            const int pp = c0 + 4 * lane;
+            if (pp < kv1) {  // kv0 and n_kv are multiples of 4 (checked by the launcher): the 4 positions are in range together
+                const uint2 w = *(const uint2 *) (mrow + pp);
+                any = any || w.x != 0xFC00FC00u || w.y != 0xFC00FC00u;
+            }
+        }
+        if (!__any(any)) {  // every wave reaches the same verdict: no barrier has been passed yet
+            if (tid < g_real) {
+                float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + kvh * g_real + tid) * geo.n_splits + split) * (D + 2);
+                rec[D] = -INFINITY;
+                rec[D + 1] = 0.0f;
+            }
+            return;
+        }
+    }
     const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
     const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
     const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
@@ -278,7 +302,25 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
         okl = pl < kv1;                                                                 \
         mvl = mp ? h2f(mp[min(pl, kv1 - 1)]) : 0.0f;                                    \
     }
-    if (kv0 < kv1) FA_LOAD_TRIP()
+    uint32_t vis = 0xFFFFFFFFu;  // bit i: trip i has a position this wave can see
+    if constexpr (SKIP) {
+        vis = 0;
+        const int ntrips = (kv1 - kv0 + NG * 16 - 1) / (NG * 16);  // <= 32 (launcher bounds the split length)
+        for (int i0 = 0; i0 < ntrips; i0 += 8) {
+            uint16_t mraw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pl = kv0 + (i0 + i) * NG * 16 + ul * 16 + wave * 4 + sub;
+                mraw[i] = (i0 + i < ntrips && pl < kv1) ? (mp ? mp[pl] : (uint16_t) 0) : (uint16_t) 0xFC00;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (__any(mraw[i] != 0xFC00)) vis |= 1u << (i0 + i);
+        }
+        if (vis & 1u) FA_LOAD_TRIP()
+    } else {
+        if (kv0 < kv1) FA_LOAD_TRIP()
+    }
 
     fa_half2 qh[G][4];
 #pragma unroll
@@ -301,7 +343,17 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     const bool b3 = (sl & 8) != 0, b2 = (sl & 4) != 0, b1 = (sl & 2) != 0, b0 = (sl & 1) != 0;
     const float sc2 = geo.scale * LOG2E;  // scores are kept in the log2 domain: p = 2^(s*scale*log2e + mask*log2e - m)
 
-    for (; p0 < kv1; p0 += NG * 16) {
+    for (int trip = 0; p0 < kv1; p0 += NG * 16, ++trip) {
+        if constexpr (SKIP) {
+            if (!((vis >> trip) & 1u)) {  // nothing visible: only keep the pipeline primed for the next trip
+                if (p0 + NG * 16 < kv1 && ((vis >> (trip + 1)) & 1u)) {
+                    p0 += NG * 16;
+                    FA_LOAD_TRIP()
+                    p0 -= NG * 16;
+                }
+                continue;
+            }
+        }
         // ---- partial dots of this lane's 8 dims for the 16 (u, g) pairs
         float t[16];
         float vf[NG][8];
@@ -321,7 +373,7 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
                 t[u * G + g] = d;
             }
         }
-        const bool more = p0 + NG * 16 < kv1;
+        const bool more = p0 + NG * 16 < kv1 && (!SKIP || ((vis >> (trip + 1)) & 1u));
         const float mv_cur = mvl;
         const bool ok_cur = okl;
         if (more) {  // long splits: the next trip's loads go out before the reductions
@@ -457,7 +509,7 @@ template <int D> __global__ void __launch_bounds__(D) k_fattn_combine(const floa
         if (s0 >= geo.n_splits) break;
         float r[32];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) r[u] = (s0 + u) < geo.n_splits ? base[(int64_t) (s0 + u) * (D + 2) + dd] : 0.0f;
+        for (int u = 0; u < 32; ++u) r[u] = ((s0 + u) < geo.n_splits && readlane_f32(cs, s0 + u) != 0.0f) ? base[(int64_t) (s0 + u) * (D + 2) + dd] : 0.0f;  // empty records carry no data
 #pragma unroll
         for (int u = 0; u < 32; ++u) a += r[u] * readlane_f32(cs, s0 + u);
     }
@@ -478,6 +530,10 @@ void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const flo
 int fattn_pick_splits(const tdesc & q, const tdesc & k) {
     if (q.ne[1] >= 32 && (k.ne[0] == 64 || k.ne[0] == 128)) return fattn_mma_pick_splits(q, k);  // (soft-capped / ALiBi batches fall back to the generic kernel with this count)
     const int64_t n_kv = k.ne[1];
+    if (q.ne[1] > 1) {  // a few tokens (continuous-batching decode): short splits, so that whole trips can be skipped by their mask
+        const int64_t by_len = (n_kv + 255) / 256;
+        return (int) std::max<int64_t>(1, std::min<int64_t>(64, std::min<int64_t>(by_len, std::max<int64_t>(1, n_kv / 64))));
+    }
     const int64_t groups = k.ne[2] * q.ne[1] * q.ne[3];
     int64_t want = (768 + groups - 1) / groups;  // ~3 workgroups per CU
     const int64_t max_by_len = std::max<int64_t>(1, n_kv / 64);
@@ -522,9 +578,18 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     if (D == 128 && p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 2 || G == 4 || G == 7 || G == 8) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 &&
         ((uintptr_t) q.data & 15) == 0) {
         dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, (unsigned) (geo.n_q * q.ne[3]));
-        if (G == 2) hipLaunchKernelGGL((k_fattn_dec128<2>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);
-        else if (G == 4) hipLaunchKernelGGL((k_fattn_dec128<4>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);
-        else hipLaunchKernelGGL((k_fattn_dec128<8>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);
+        // several query tokens with a mask: skip the KV trips a token cannot see — needs splits of at most 32 trips
+        const int per = ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64;
+        static const bool skip_on = !getenv("GGML_MI355X_FA_SKIP") || atoi(getenv("GGML_MI355X_FA_SKIP")) != 0;
+        const bool skip = skip_on && geo.n_q > 1 && geo.n_q <= 64 && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
+                          (mask->nb[3] % 8) == 0 && ((uintptr_t) mask->data & 7) == 0 && geo.n_splits > 1;
+#define FA_DEC(GG)                                                                                                              \
+    {                                                                                                                           \
+        if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);  \
+        else hipLaunchKernelGGL((k_fattn_dec128<GG, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);      \
+    }
+        if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
+#undef FA_DEC
         if (geo.n_splits > 1) {
             dim3 g2((unsigned) geo.n_head, (unsigned) geo.n_q, (unsigned) q.ne[3]);
             hipLaunchKernelGGL((k_fattn_combine<128>), g2, dim3(128), 0, s, ws, sinks, dst, geo);

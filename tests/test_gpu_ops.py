@@ -467,6 +467,32 @@ def test_flash_attn(backend, H, plog, HD, NH, NKV, nq, nkv, splits, softcap, ali
     assert e_gpu <= (1e-9 if nq < 32 or softcap else 3e-7) and e_gpu <= e_cpu * 1.01 + 1e-12
 
 
+@pytest.mark.parametrize("HD,NH,NKV,nseq,per_seq", [(128, 32, 8, 32, 64), (128, 8, 2, 12, 100), (128, 28, 4, 5, 300), (128, 16, 2, 48, 48), (64, 8, 2, 16, 64)])
+def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq, per_seq):
+    """-np style decode batch: token i belongs to sequence i and sees only that sequence's cells of the unified cache (a block-diagonal
+    mask).  The decode kernel reads the mask of its split first and skips KV trips no position of which is visible."""
+    rng = np.random.default_rng(HD + NH + nseq + per_seq)
+    nkv = (nseq * per_seq + 255) // 256 * 256
+    q = rng.standard_normal((NH, nseq, HD)).astype(np.float32)
+    kc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    vc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    MR = (nseq + 63) // 64 * 64
+    mask = np.full((MR, nkv), -np.inf, np.float16)
+    for t in range(nseq):
+        mask[t, t * per_seq: t * per_seq + per_seq - (t % 7)] = 0  # ragged sequence lengths
+
+    def build(g):
+        tq = g.new(L.F32, [HD, nseq, NH], q)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], kc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], vc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        r = H.ggml_flash_attn_ext(g.ctx, tq, k, v, g.new(L.F16, [nkv, MR], mask), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(r, 10)
+        return r
+
+    ref, got = both(build, backend)
+    T.compare(f"flash_attn block-diagonal D={HD} H={NH}/{NKV} nseq={nseq} per_seq={per_seq}", got[0], ref[0], max_nmse=1e-4, log=plog)
+
+
 # ------------------------------------------------------------------------------------------------ fused Q/K/V
 @pytest.mark.parametrize("tq,tv,bias", [(L.Q4_K, L.Q4_K, False), (L.Q4_K, L.Q6_K, False), (L.Q5_K, L.Q6_K, True), (L.Q6_K, L.Q6_K, True), (L.Q4_K, L.Q5_K, False)])
 def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias):
