@@ -140,6 +140,7 @@ _SIGS = {
     "llm_model_stream_bytes": (C.c_uint64, [_P]), "llm_model_total_bytes": (C.c_uint64, [_P]), "llm_model_tensor": (TP, [_P, _S]),
     "llm_context_new": (_P, [_P, _P, COMPUTE_FN, C.POINTER(ContextParams)]), "llm_context_free": (None, [_P]),
     "llm_decode": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int8)]),
+    "llm_decode_steps": (_I, [_P, _I, _I, C.POINTER(C.c_int32), _I]),
     "llm_n_outputs": (_I, [_P]), "llm_get_logits": (C.POINTER(C.c_float), [_P]), "llm_get_logits_ith": (C.POINTER(C.c_float), [_P, _I]),
     "llm_kv_clear": (None, [_P]), "llm_kv_seq_rm": (_I, [_P, _I, _I, _I]), "llm_last_graph": (C.POINTER(CGraph), [_P]),
     "llm_last_timings": (None, [_P, C.POINTER(C.c_double)]),

@@ -906,6 +906,20 @@ extern "C" int llm_decode(struct llm_context * c, int n_tokens, const int32_t * 
     }
     return 0;
 }
+extern "C" int llm_decode_steps(struct llm_context * c, int n_steps, int n_par, const int32_t * tokens, int pos0) {
+    if (n_steps <= 0 || n_par <= 0 || !tokens) return -1;
+    std::vector<int32_t> pos((size_t) n_par), seq((size_t) n_par);
+    for (int s = 0; s < n_par; ++s) seq[s] = s;
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n_steps; ++i) {
+        for (int s = 0; s < n_par; ++s) pos[s] = pos0 + i;
+        const int rc = llm_decode(c, n_par, tokens + (size_t) i * n_par, pos.data(), seq.data(), nullptr);
+        if (rc != 0) return rc;
+        for (int k = 0; k < 4; ++k) acc[k] += c->timings[k];
+    }
+    for (int k = 0; k < 4; ++k) c->timings[k] = acc[k];
+    return 0;
+}
 extern "C" int llm_n_outputs(const struct llm_context * c) { return c->n_outputs; }
 extern "C" float * llm_get_logits(struct llm_context * c) { return c->logits.data(); }
 extern "C" float * llm_get_logits_ith(struct llm_context * c, int i) {

@@ -70,6 +70,11 @@ struct llm_context * llm_context_new(struct llm_model * m, ggml_backend_t backen
 void llm_context_free(struct llm_context * c);
 /* return codes as llama_decode: 0 ok, 1 no KV slot, -1 invalid batch, -2 compute/alloc failure */
 int llm_decode(struct llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const int8_t * want_logits);
+/* n_steps consecutive decode steps of n_par sequences (one token each, sequence ids 0..n_par-1, positions pos0+step): the
+   engine loop's hot part without a scripting language between the steps — tokens is [n_steps][n_par].  Logits of every step
+   are fetched to the host exactly as llm_decode does; after the call they hold the last step's.  llm_last_timings then
+   reports the sums over all steps.  Returns 0 or the first failing llm_decode's code. */
+int llm_decode_steps(struct llm_context * c, int n_steps, int n_par, const int32_t * tokens, int pos0);
 int llm_n_outputs(const struct llm_context * c);
 float * llm_get_logits(struct llm_context * c);            /* [n_outputs][n_vocab], host memory */
 float * llm_get_logits_ith(struct llm_context * c, int i); /* i-th output row of the last llm_decode */

@@ -64,6 +64,12 @@ class Context:
         lg = np.ctypeslib.as_array(self.H.llm_get_logits(self.c), shape=(max(no, 1), nv))[:no]
         return 0, (lg.copy() if copy_logits else lg)
 
+    def decode_steps(self, tokens, n_par, pos0):
+        """n_steps decode steps of n_par sequences inside the host library (tokens: [n_steps][n_par] ints); returns rc."""
+        flat = [int(t) for row in tokens for t in row]
+        arr = (C.c_int32 * len(flat))(*flat)
+        return self.H.llm_decode_steps(self.c, len(tokens), n_par, arr, int(pos0))
+
     def clear(self):
         self.H.llm_kv_clear(self.c)
 
