@@ -495,6 +495,16 @@ template <int D> __global__ void __launch_bounds__(D) k_fattn_combine(const floa
     const bool has = lane < geo.n_splits;
     const float ms = has ? base[(int64_t) lane * (D + 2) + D] : -INFINITY;
     const float ls = has ? base[(int64_t) lane * (D + 2) + D + 1] : 0.0f;
+    // the partial values are requested together with the (m, l) pairs — ONE memory round trip for the whole kernel; a split
+    // that left an empty record (coefficient 0) may hold anything there, so it is masked by a select, not by a multiply
+    float r0[32], r1[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) r0[u] = u < geo.n_splits ? base[(int64_t) u * (D + 2) + dd] : 0.0f;
+    const bool second = geo.n_splits > 32;
+    if (second) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) r1[u] = (32 + u) < geo.n_splits ? base[(int64_t) (32 + u) * (D + 2) + dd] : 0.0f;
+    }
     float mn = wave_max(ms);
     float sink_term = 0.0f;
     if (sinks) {
@@ -505,13 +515,16 @@ template <int D> __global__ void __launch_bounds__(D) k_fattn_combine(const floa
     const float lt = wave_sum(ls * cs) + sink_term;
     float a = 0.0f;
 #pragma unroll
-    for (int s0 = 0; s0 < 64; s0 += 32) {
-        if (s0 >= geo.n_splits) break;
-        float r[32];
+    for (int u = 0; u < 32; ++u) {
+        const float c = readlane_f32(cs, u);
+        a += c != 0.0f ? r0[u] * c : 0.0f;
+    }
+    if (second) {
 #pragma unroll
-        for (int u = 0; u < 32; ++u) r[u] = ((s0 + u) < geo.n_splits && readlane_f32(cs, s0 + u) != 0.0f) ? base[(int64_t) (s0 + u) * (D + 2) + dd] : 0.0f;  // empty records carry no data
-#pragma unroll
-        for (int u = 0; u < 32; ++u) a += r[u] * readlane_f32(cs, s0 + u);
+        for (int u = 0; u < 32; ++u) {
+            const float c = readlane_f32(cs, 32 + u);
+            a += c != 0.0f ? r1[u] * c : 0.0f;
+        }
     }
     float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
     out[dd] = a * (1.0f / lt);
