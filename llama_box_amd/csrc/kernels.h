@@ -101,6 +101,9 @@ int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M);
 void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
                    int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride);
+// Q8_0 weights x Q8_0 activations, one int8 MFMA per 32-value block + immediate f32 scale-accumulate (mmq_q80.hip)
+bool mmq_q80_supported(int type, int64_t K, int64_t N, int64_t M);
+void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int ksplit, float * part);
 
 // ---- element-wise / normalisation / data movement (ops.hip)

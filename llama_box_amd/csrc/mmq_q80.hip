@@ -1,0 +1,176 @@
+// mmq_q80.hip — batched mat-mul for Q8_0 weights on the gfx950 INTEGER matrix cores.
+//
+// ggml-cpu's ggml_vec_dot_q8_0_q8_0 quantises the activations to Q8_0 as well and sums,
+// per 32-value block, sumi * (d_w * d_x) in f32.  A block is exactly the K extent of v_mfma_i32_32x32x32_i8, so one MFMA
+// with a zero accumulator yields the 32x32 integer block sums, and the f32 scale-accumulate follows at once — there is no
+// super-block to amortise it over, which makes this kernel VALU-bound (4 VALU per output and block against one MFMA per
+// 1024 outputs): the matrix core only replaces the 32 multiply-adds per output and block.  Still an order of magnitude
+// faster than running the batch as 8-column mat-vec passes, which re-stream the weights once per pass.
+// Tile 128 weight rows x 128 columns x 128 K (4 blocks) per trip, 8 waves (32 x 64 each), double-buffered LDS: raw int8 of
+// both operands in the XOR-swizzled [row][128 B] image of mmq_i8.hip plus the 4 block scales of every row / column.
+#include <algorithm>
+
+#include "dev_util.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+typedef float float16q __attribute__((ext_vector_type(16)));
+typedef int int4q __attribute__((ext_vector_type(4)));
+typedef int int16q __attribute__((ext_vector_type(16)));
+
+struct mmq80_args {
+    const uint8_t * W;
+    int64_t w_nb1;
+    int K, N, M;
+    const q80_dev * act;  // [M][K/32]
+    float * dst;
+    int64_t dst_stride;
+    int n_panels, m_tiles;
+    const float * add;
+    int64_t add_stride;
+};
+
+constexpr int Q80_T = 128 * 128;                // bytes of one operand tile
+constexpr int Q80_STAGE = 2 * Q80_T + 2 * 128 * 16;  // A | B | dw[128][4] | da[128][4]
+
+__device__ __forceinline__ int sw_offq(const int row, const int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ void __launch_bounds__(512, 1) k_mmq_q80(const mmq80_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int panel = (qb / a.m_tiles) * 8 + xcd, mt = qb % a.m_tiles;
+    if (panel >= a.n_panels) return;
+    const int n0 = panel * 128, m0 = mt * 128;
+    const int nb32 = a.K / 32, trips = a.K / 128;
+    const int nslab = wave & 3, mhalf = wave >> 2;
+
+    // staging roles: thread -> (row | column, block of the trip)
+    const int srow = tid >> 2, sq = tid & 3;
+    const uint8_t * wblk = a.W + (size_t) min(n0 + srow, a.N - 1) * a.w_nb1 + (size_t) sq * 34;
+    const q80_dev * yblk = a.act + (size_t) min(m0 + srow, a.M - 1) * nb32 + sq;
+    const int off0 = sw_offq(srow, 2 * sq), off1 = sw_offq(srow, 2 * sq + 1);
+
+    uint32_t ga0, ga1, ga2, ga3, ga4, ga5, ga6, ga7, gb0, gb1, gb2, gb3, gb4, gb5, gb6, gb7;
+    uint16_t gad = 0;
+    float gbd = 0.0f;
+    auto issue_loads = [&](const int t) {
+        const uint8_t * p = wblk + (size_t) t * 4 * 34;  // Q8_0 blocks are 2-byte aligned: dword loads typed accordingly
+        gad = ld16(p);
+        ga0 = ld32_a2(p + 2); ga1 = ld32_a2(p + 6); ga2 = ld32_a2(p + 10); ga3 = ld32_a2(p + 14);
+        ga4 = ld32_a2(p + 18); ga5 = ld32_a2(p + 22); ga6 = ld32_a2(p + 26); ga7 = ld32_a2(p + 30);
+        const q80_dev * y = yblk + (size_t) t * 4;
+        const uint32_t * yq = (const uint32_t *) y->qs;
+        gb0 = yq[0]; gb1 = yq[1]; gb2 = yq[2]; gb3 = yq[3]; gb4 = yq[4]; gb5 = yq[5]; gb6 = yq[6]; gb7 = yq[7];
+        gbd = y->d;
+    };
+    auto stage = [&](const int t) {
+        char * buf = smem + (t & 1) * Q80_STAGE;
+        *(uint4 *) (buf + off0) = make_uint4(ga0, ga1, ga2, ga3);
+        *(uint4 *) (buf + off1) = make_uint4(ga4, ga5, ga6, ga7);
+        *(uint4 *) (buf + Q80_T + off0) = make_uint4(gb0, gb1, gb2, gb3);
+        *(uint4 *) (buf + Q80_T + off1) = make_uint4(gb4, gb5, gb6, gb7);
+        ((float *) (buf + 2 * Q80_T))[sq * 128 + srow] = h2f(gad);              // scales are stored [block][row] so that the four
+        ((float *) (buf + 2 * Q80_T + 128 * 16))[sq * 128 + srow] = gbd;        // consecutive rows of an accumulator quad are one 16-byte read
+    };
+
+    const int fr = lane & 31, kg = lane >> 5;
+    const int swz = (fr >> 1) & 7;
+    const int arow_off = (nslab * 32 + fr) * 128;
+    const int brow_off0 = (mhalf * 64 + fr) * 128, brow_off1 = (mhalf * 64 + 32 + fr) * 128;
+    float16q C0, C1;
+    int16q zi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { C0[r] = 0.0f; C1[r] = 0.0f; zi[r] = 0; }
+
+    issue_loads(0);
+    stage(0);
+    if (trips > 1) issue_loads(1);
+    __syncthreads();
+    for (int t = 0; t < trips; ++t) {
+        if (t + 1 < trips) {
+            stage(t + 1);
+            if (t + 2 < trips) issue_loads(t + 2);
+        }
+        const char * buf = smem + (t & 1) * Q80_STAGE;
+        const float * dwt = (const float *) (buf + 2 * Q80_T);
+        const float * dat = (const float *) (buf + 2 * Q80_T + 128 * 16);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const int co = ((2 * blk + kg) ^ swz) << 4;
+            const int4q fa = *(const int4q *) (buf + arow_off + co);
+            const int4q fb0 = *(const int4q *) (buf + Q80_T + brow_off0 + co), fb1 = *(const int4q *) (buf + Q80_T + brow_off1 + co);
+            const float y0 = dat[blk * 128 + mhalf * 64 + fr], y1 = dat[blk * 128 + mhalf * 64 + 32 + fr];
+            float x[16];  // block scale of the 16 rows this lane's accumulator registers belong to
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v = *(const float4 *) (dwt + blk * 128 + nslab * 32 + 8 * g4 + 4 * kg);
+                x[4 * g4] = v.x; x[4 * g4 + 1] = v.y; x[4 * g4 + 2] = v.z; x[4 * g4 + 3] = v.w;
+            }
+            const int16q s0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb0, zi, 0, 0, 0);
+            const int16q s1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb1, zi, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                C0[r] += (float) s0[r] * (x[r] * y0);  // sumf += sumi * (d_w * d_x), as the CPU does
+                C1[r] += (float) s1[r] * (x[r] * y1);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int m = m0 + mhalf * 64 + tt * 32 + fr;
+        if (m >= a.M) continue;
+        float * out = a.dst + (size_t) m * a.dst_stride;
+        const float * ad = a.add ? a.add + (size_t) m * a.add_stride : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + nslab * 32 + 8 * g + 4 * kg;
+            float c4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c4[r] = tt ? C1[4 * g + r] : C0[4 * g + r];
+            if (ad) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < a.N) c4[r] += ad[n + r];
+            }
+            if (n + 3 < a.N && ((((uintptr_t) (out + n)) & 15) == 0)) {
+                *(float4 *) (out + n) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < a.N) out[n + r] = c4[r];
+            }
+        }
+    }
+}
+
+bool mmq_q80_supported(int type, int64_t K, int64_t N, int64_t M) {
+    (void) N;
+    return type == GGML_TYPE_Q8_0 && (K % 128) == 0 && M >= 9;
+}
+
+void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride) {
+    mmq80_args a;
+    a.W = W;
+    a.w_nb1 = w_nb1;
+    a.K = K;
+    a.N = N;
+    a.M = M;
+    a.act = (const q80_dev *) act_q80;
+    a.dst = dst;
+    a.dst_stride = dst_stride;
+    a.n_panels = (N + 127) / 128;
+    a.m_tiles = (M + 127) / 128;
+    a.add = add;
+    a.add_stride = add_stride;
+    const size_t lds = 2 * (size_t) Q80_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) k_mmq_q80, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
+    hipLaunchKernelGGL(k_mmq_q80, dim3(grid), dim3(512), lds, s, a);
+}
+
+}  // namespace mi355x
