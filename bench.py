@@ -260,6 +260,16 @@ def main():
         except Exception as e:
             cpu_baseline = {"error": str(e)}
 
+    # prefill against the matrix-core roofline: 2 flop per weight of the layer mat-muls per token (the output matrix runs for the
+    # last token only) + causal attention (QK^T and PV: 2 x 2 x n_embd x mean visible positions per token and layer)
+    prefill_roofline = None
+    if prefill_tok_s and tp_size == 1:
+        E, FF, KV = hp.n_embd, hp.n_ff, hp.n_head_kv * hp.n_embd_head
+        w_layer = E * E + 2 * E * KV + E * E + 3 * E * FF
+        flop_tok = 2.0 * hp.n_layer * w_layer + hp.n_layer * 4.0 * E * (args.prefill / 2.0)
+        ach = flop_tok * (prefill_tok_s / args.np) * args.np / 1e12
+        prefill_roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                            "flop_per_token": round(flop_tok), "note": "dense f16 MFMA peak; the GEMMs run on the int8 matrix cores (2x rate) with two digit passes per weight"}
     if rank == 0:
         w_bytes = model.stream_bytes()
         kv_per_tok = 2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * 2
@@ -275,6 +285,7 @@ def main():
                        "parallelism": parallelism, "n_past_mid": n_past, "weight_bytes_per_token_per_gpu": w_bytes, "kv_bytes_per_token_per_gpu": kv_per_tok * n_past},
             "prefill_tok_s": round(prefill_tok_s, 1) if prefill_tok_s else None,
             "prefill_host_us": {"build": round(prefill_host_split[0], 1), "inputs": round(prefill_host_split[1], 1), "compute+sync": round(prefill_host_split[2], 1), "logits_d2h": round(prefill_host_split[3], 1)} if prefill_tok_s else None,
+            "prefill_roofline": prefill_roofline,
             "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),
             "graph_replayed_steps": int(graph_steps),
             "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},

@@ -32,8 +32,9 @@ struct fam_geom {
     float scale;
 };
 
-template <int D>
-__global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo, float * __restrict__ ws) {
+// NW waves of 32 queries each share one staged K/V tile (NW = 4: 128 queries per workgroup, half the staging work per query)
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo, float * __restrict__ ws) {
     constexpr int BKV = 64;
     constexpr int KS = (D + 8) * 2;    // K tile row stride (bytes): odd multiple of 16 -> conflict-free ds_read_b128
     constexpr int VS = (BKV + 4) * 2;  // V^T tile row stride (bytes): 34 dwords -> conflict-free ds_read_b64 across 32 rows
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k,
     const int tiles = (geo.n_kv + BKV - 1) / BKV, tps = (tiles + geo.n_splits - 1) / geo.n_splits;
     const int kv_begin = split * tps * BKV, kv_end = min(geo.n_kv, kv_begin + tps * BKV);
     const int kvh = h / (geo.n_head / geo.n_kv_head);
-    const int qi = blockIdx.x * 64 + wave * 32 + fr;  // this lane's query token
+    const int qi = blockIdx.x * (NW * 32) + wave * 32 + fr;  // this lane's query token
     const int qrow = min(qi, geo.n_q - 1);
     const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
 
@@ -78,9 +79,9 @@ __global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k,
     const float16v zero = O[0];
     float m = -INFINITY, l = 0.0f;
 
-    // staging roles: thread -> KV row (tid >> 1) and half of the head dimension (tid & 1)
-    const int srow = tid >> 1, spart = tid & 1;
-    constexpr int CH = D / 16;  // 16-byte chunks per thread per tile (half a row)
+    // staging roles: thread -> KV row and its slice of the head dimension (NW parts)
+    const int srow = tid / NW, spart = tid % NW;
+    constexpr int CH = D / (8 * NW);  // 16-byte chunks per thread per tile
 
     for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
         __syncthreads();
@@ -210,7 +211,8 @@ __global__ void __launch_bounds__(128) k_fattn_mma(const tdesc q, const tdesc k,
 
 // returns false when this variant does not apply (caller falls back to the split-KV kernel)
 int fattn_mma_pick_splits(const tdesc & q, const tdesc & k) {
-    const int64_t wgs = ((q.ne[1] + 63) / 64) * q.ne[2] * q.ne[3];
+    const int64_t qt = q.ne[1] >= 256 ? 128 : 64;
+    const int64_t wgs = ((q.ne[1] + qt - 1) / qt) * q.ne[2] * q.ne[3];
     const int64_t tiles = (k.ne[1] + 63) / 64;
     int64_t want = (512 + wgs - 1) / wgs;  // ~2 workgroups per CU
     want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, tiles / 4)));
@@ -232,13 +234,16 @@ bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, cons
     geo.n_splits = std::max(1, p.n_splits);
     const tdesc mk = mask ? *mask : q;
     float * ws = (float *) workspace;
-    dim3 grid((unsigned) ((geo.n_q + 63) / 64), (unsigned) geo.n_head, (unsigned) (q.ne[3] * geo.n_splits));
+    const int nw = geo.n_q >= 256 ? 4 : 2;  // 128-query workgroups when there are enough queries to keep the grid full
+    dim3 grid((unsigned) ((geo.n_q + nw * 32 - 1) / (nw * 32)), (unsigned) geo.n_head, (unsigned) (q.ne[3] * geo.n_splits));
     if (D == 128) {
         const size_t lds = 64 * (128 + 8) * 2 + 128 * (64 + 4) * 2;
-        hipLaunchKernelGGL(k_fattn_mma<128>, grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws);
+        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<128, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws);
+        else hipLaunchKernelGGL((k_fattn_mma<128, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws);
     } else {
         const size_t lds = 64 * (64 + 8) * 2 + 64 * (64 + 4) * 2;
-        hipLaunchKernelGGL(k_fattn_mma<64>, grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws);
+        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<64, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws);
+        else hipLaunchKernelGGL((k_fattn_mma<64, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws);
     }
     if (geo.n_splits > 1) launch_flash_attn_combine(s, (int) k.ne[0], ws, sinks, dst, (int) q.ne[1], (int) q.ne[2], (int) q.ne[3], geo.n_splits);
     return true;
