@@ -91,6 +91,23 @@ __device__ __forceinline__ uint16_t ld16(const void * p) { return *(const u16_a2
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
+// One wave64 quantises 256 values to EIGHT Q8_0 blocks exactly as ggml-cpu's quantize_row_q8_0_ref does (8 lanes per 32-value
+// block: d = amax / 127 stored through fp16, q = roundf(x / d) with the unrounded d).  y points at the first of the 8 blocks.
+template <typename Q80> __device__ __forceinline__ void wave_quantize_q8_0(const float (&v)[4], const int lane, Q80 * y) {
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_QUAD_XOR1>(amax));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_QUAD_XOR2>(amax));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_HALF_MIRROR>(amax));
+    const float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) packed |= (uint32_t) ((int) roundf(v[k] * id) & 0xFF) << (8 * k);
+    Q80 * blk = y + (lane >> 3);
+    ((uint32_t *) blk->qs)[lane & 7] = packed;
+    if ((lane & 7) == 0) blk->d = h2f(f2h(d));
+}
+
 // One wave64 quantises one 256-value block to Q8_K exactly as ggml-cpu's quantize_row_q8_K_ref does (first-index
 // arg-max of |x| defines the sign of the scale, iscale = -127/max, round-half-even, clamp to 127, 16-value bsums).
 // v[0..3] are the lane's four consecutive values; y may point to LDS or global memory.

@@ -234,7 +234,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const int64_t K = w->ne[0], N = w->ne[1];
     const int64_t M = b->ne[1] * b->ne[2] * b->ne[3];
     const double wbytes = (double) ggml_abi_row_size(w->type, K) * (double) N * (w2 ? 2.0 : 1.0);
-    const bool kquant = w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K;
+    const bool kquant = w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K || (w->type == GGML_TYPE_Q8_0 && (K % 256) == 0);  // formats with the mat-vec prologue
     auto dn = st.deferred.find(b);
     const bool pro_norm = dn != st.deferred.end();
     const bool pro_f32 = !pro_norm && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
@@ -377,7 +377,7 @@ static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, 
         for (int s = 0; s < GGML_MAX_SRC; ++s) {
             if (t->src[s] != m) continue;
             const ggml_tensor * wt = t->src[0];
-            const bool ok = t->op == GGML_OP_MUL_MAT && s == 1 && (wt->type == GGML_TYPE_Q4_K || wt->type == GGML_TYPE_Q5_K || wt->type == GGML_TYPE_Q6_K) &&
+            const bool ok = t->op == GGML_OP_MUL_MAT && s == 1 && (wt->type == GGML_TYPE_Q4_K || wt->type == GGML_TYPE_Q5_K || wt->type == GGML_TYPE_Q6_K || wt->type == GGML_TYPE_Q8_0) &&
                             wt->ne[2] == 1 && wt->ne[3] == 1 && ggml_abi_is_contiguous(t) && !(st.c->tp && buffer_is_rowpar(wt->view_src ? wt->view_src->buffer : wt->buffer));
             if (!ok) return false;
             last = j;

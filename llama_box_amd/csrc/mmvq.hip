@@ -256,19 +256,22 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         } else {
             for (int i = tid; i < nwords; i += NT) dst[i] = src[i];
         }
-    } else if constexpr (T::BLK == 256) {
-        q8k_dev * yl = (q8k_dev *) smem;
+    } else {
+        // one wave per 256-value chunk: a Q8_K block, or eight Q8_0 blocks (launcher guarantees K % 256 == 0)
+        act * yl = (act *) smem;
+        constexpr int BPC = 256 / T::BLK;  // activation blocks per chunk
+        const int nchk = a.K / 256;
         const float4 * x4 = (const float4 *) a.x;
         const float4 * w4 = (const float4 *) a.norm_w;
         // batch 0 (blocks wave, wave+16, wave+32, wave+48) is special: with the norm it must hold the WHOLE row
         // (launcher guarantees nblk <= 64) because the scale needs the full sum of squares; the barrier sits outside
         // any wave-dependent control flow
-        for (int b0 = wave; b0 < nblk || b0 == wave; b0 += 4 * WAVES) {
+        for (int b0 = wave; b0 < nchk || b0 == wave; b0 += 4 * WAVES) {
             float4 v[4], g[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int b = b0 + u * WAVES;
-                if (b < nblk) {
+                if (b < nchk) {
                     v[u] = x4[b * 64 + lane];
                     if (PRO == 2) g[u] = w4[b * 64 + lane];
                 } else {
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
             }
             float scale = 1.0f;
             if constexpr (PRO == 2) {
-                double * red = (double *) (smem + (size_t) nblk * sizeof(q8k_dev));
+                double * red = (double *) (smem + (size_t) nblk * sizeof(act));
                 double ss = 0.0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ss += (double) (v[u].x * v[u].x) + (double) (v[u].y * v[u].y) + (double) (v[u].z * v[u].z) + (double) (v[u].w * v[u].w);
@@ -294,7 +297,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int b = b0 + u * WAVES;
-                if (b < nblk) {
+                if (b < nchk) {
                     float t[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
                     if constexpr (PRO == 2) {
                         t[0] = (t[0] * scale) * g[u].x;
@@ -302,7 +305,8 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
                         t[2] = (t[2] * scale) * g[u].z;
                         t[3] = (t[3] * scale) * g[u].w;
                     }
-                    wave_quantize_q8_K(t, lane, yl + b);
+                    if constexpr (BPC == 1) wave_quantize_q8_K(t, lane, yl + b);
+                    else wave_quantize_q8_0(t, lane, yl + (size_t) b * BPC);
                 }
             }
             if constexpr (PRO == 2) break;  // single batch by construction
@@ -373,14 +377,13 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
     const int nblk = a.K / T::BLK;
     const bool glu = a.W2 != nullptr;
     if (a0.x != nullptr) {
-        if constexpr (T::BLK == 256) {
-            if (a0.norm_w) { if (glu) launch_stream<T, true, 2>(s, a0); else launch_stream<T, false, 2>(s, a0); }
-            else           { if (glu) launch_stream<T, true, 1>(s, a0); else launch_stream<T, false, 1>(s, a0); }
-            return;
-        } else {
-            MI_ERR("launch_mmvq: f32 prologue requested for a non K-quant type");
+        if ((a0.K % 256) != 0) {
+            MI_ERR("launch_mmvq: the f32 prologue needs K %% 256 == 0 (K = %d)", a0.K);
             abort();
         }
+        if (a0.norm_w) { if (glu) launch_stream<T, true, 2>(s, a0); else launch_stream<T, false, 2>(s, a0); }
+        else           { if (glu) launch_stream<T, true, 1>(s, a0); else launch_stream<T, false, 1>(s, a0); }
+        return;
     }
     if (a0.ncols == 1 && (size_t) nblk * sizeof(typename T::act) <= 60 * 1024) {
         if (glu) launch_stream<T, true, 0>(s, a0); else launch_stream<T, false, 0>(s, a0);
