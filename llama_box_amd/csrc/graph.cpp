@@ -464,7 +464,7 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     ggml_cgraph * g = st.g;
     const ggml_tensor * n = g->nodes[i];
     const ggml_tensor * X = n->src[1];
-    auto kq = [](const ggml_tensor * w) { return (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K) && w->ne[2] == 1 && w->ne[3] == 1 && rows_contig(w) && (w->ne[1] % 2) == 0; };
+    auto kq = [](const ggml_tensor * w) { return (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K || w->type == GGML_TYPE_Q8_0) && w->ne[2] == 1 && w->ne[3] == 1 && rows_contig(w) && (w->ne[1] % 2) == 0; };
     if (ggml_abi_nrows(X) != 1 || X->type != GGML_TYPE_F32 || (X->ne[0] % 256) != 0) return false;
     auto dn = st.deferred.find(X);
     const bool norm = dn != st.deferred.end();

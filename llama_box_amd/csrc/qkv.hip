@@ -33,7 +33,7 @@ template <typename T> __device__ __forceinline__ void qkv_load(const uint8_t * _
         }
     }
 }
-template <typename T> __device__ __forceinline__ void qkv_dot(const qkv_regs<T> & r, const int c, const int lane, const int npairs, const q8k_dev * __restrict__ y,
+template <typename T> __device__ __forceinline__ void qkv_dot(const qkv_regs<T> & r, const int c, const int lane, const int npairs, const typename T::act * __restrict__ y,
                                                               const int nblk, float & acc0, float & acc1) {
     constexpr int U = qkv_u<T>::U;
 #pragma unroll
@@ -47,7 +47,7 @@ template <typename T> __device__ __forceinline__ void qkv_dot(const qkv_regs<T> 
 }
 // all trips of one unit; trip 0 is already in `r`
 template <typename T> __device__ __forceinline__ void qkv_unit(qkv_regs<T> & r, const uint8_t * row0, const uint8_t * row1, const int lane, const int nblk,
-                                                               const q8k_dev * __restrict__ y, float & acc0, float & acc1) {
+                                                               const typename T::act * __restrict__ y, float & acc0, float & acc1) {
     const int npairs = nblk * T::PPB;
     constexpr int per_chunk = 64 * qkv_u<T>::U;
     const int nch = (npairs + per_chunk - 1) / per_chunk;
@@ -70,9 +70,11 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
     constexpr int MAXW = 16, QB = 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
     const int WAVES = (int) blockDim.x >> 6;  // 8..16 waves: the launcher sizes the workgroup so that units/WAVES ~ 256 workgroups
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = a.K / 256;
-    q8k_dev * yl = (q8k_dev *) smem;
-    double * red = (double *) (smem + (size_t) nblk * sizeof(q8k_dev));
+    typedef typename T::act act;            // Q8_K blocks for the K-quants, Q8_0 blocks (8 per 256-value chunk) for Q8_0 weights
+    constexpr int BPC = 256 / T::BLK;
+    const int nchk = a.K / 256, nblk = nchk * BPC;
+    act * yl = (act *) smem;
+    double * red = (double *) (smem + (size_t) nblk * sizeof(act));
     float * cs_tab = (float *) (red + MAXW);  // [head_dim/2][2]
     const int GW = nwg * WAVES;
     const int half = a.head_dim >> 1;
@@ -116,12 +118,12 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
         const float4 * x4 = (const float4 *) a.x;
         const float4 * w4 = (const float4 *) a.norm_w;
         const bool norm = a.norm_w != nullptr;
-        for (int b0 = wave; b0 < nblk || b0 == wave; b0 += QB * WAVES) {
+        for (int b0 = wave; b0 < nchk || b0 == wave; b0 += QB * WAVES) {
             float4 v[QB], g[QB];
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int b = b0 + q * WAVES;
-                if (b < nblk) {
+                if (b < nchk) {
                     v[q] = x4[b * 64 + lane];
                     g[q] = norm ? w4[b * 64 + lane] : make_float4(1.f, 1.f, 1.f, 1.f);
                 } else {
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int b = b0 + q * WAVES;
-                if (b < nblk) {
+                if (b < nchk) {
                     float t[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
                     if (norm) {
                         t[0] = (t[0] * scale) * g[q].x;
@@ -154,7 +156,8 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
                         t[2] = (t[2] * scale) * g[q].z;
                         t[3] = (t[3] * scale) * g[q].w;
                     }
-                    wave_quantize_q8_K(t, lane, yl + b);
+                    if constexpr (BPC == 1) wave_quantize_q8_K(t, lane, yl + b);
+                    else wave_quantize_q8_0(t, lane, yl + (size_t) b * BPC);
                 }
             }
             if (norm) break;
@@ -212,21 +215,21 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
 
 bool qkv_types_supported(int ta, int tb) {
     auto ok = [](int t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K; };
-    if (ta == tb) return ok(ta);
+    if (ta == tb) return ok(ta) || ta == GGML_TYPE_Q8_0;
     return (ta == GGML_TYPE_Q4_K && tb == GGML_TYPE_Q6_K) || (ta == GGML_TYPE_Q5_K && tb == GGML_TYPE_Q6_K) || (ta == GGML_TYPE_Q4_K && tb == GGML_TYPE_Q5_K);
 }
 
 // segments with alt == 0 are stored in type_a, those with alt == 1 in type_b (type_b == type_a: one format)
 void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     qkv_args a = a0;
-    const int nblk = a.K / 256;
+    const int nblk = a.K / 256;  // 256-value chunks
     int units[2] = {0, 0};
     double bytes[2] = {0, 0};
     for (int i = 0; i < a.nseg; ++i) {
         units[a.seg[i].alt ? 1 : 0] += a.seg[i].N / 2;
         bytes[a.seg[i].alt ? 1 : 0] += (double) a.seg[i].N * (double) a.seg[i].w_nb1;
     }
-    const size_t lds = (size_t) nblk * sizeof(q8k_dev) + 16 * sizeof(double) + (size_t) a.head_dim * sizeof(float) + 16;
+    const size_t lds = (size_t) nblk * (type_a == GGML_TYPE_Q8_0 ? 8 * sizeof(q80_dev) : sizeof(q8k_dev)) + 16 * sizeof(double) + (size_t) a.head_dim * sizeof(float) + 16;
     // waves per workgroup: 8..16, chosen so that the row-pair units spread over ~256 workgroups (Llama-3-8B: 3072 units ->
     // 12 waves x 256 workgroups; with fixed 16-wave workgroups a quarter of the CUs had nothing to do); the norm prologue
     // needs the whole activation row in one batch of 2 blocks per wave
@@ -241,6 +244,7 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
         if (type_a == GGML_TYPE_Q4_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q4K>), dim3(grid), block, lds, s, a);
         else if (type_a == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q5K>), dim3(grid), block, lds, s, a);
         else if (type_a == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q6K, T_Q6K>), dim3(grid), block, lds, s, a);
+        else if (type_a == GGML_TYPE_Q8_0) hipLaunchKernelGGL((k_qkv_stream2<T_Q80, T_Q80>), dim3(grid), block, lds, s, a);
         else { MI_ERR("launch_qkv: unsupported weight format %d", type_a); abort(); }
         return;
     }

@@ -494,7 +494,7 @@ def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq
 
 
 # ------------------------------------------------------------------------------------------------ fused Q/K/V
-@pytest.mark.parametrize("tq,tv,bias", [(L.Q4_K, L.Q4_K, False), (L.Q4_K, L.Q6_K, False), (L.Q5_K, L.Q6_K, True), (L.Q6_K, L.Q6_K, True), (L.Q4_K, L.Q5_K, False)])
+@pytest.mark.parametrize("tq,tv,bias", [(L.Q4_K, L.Q4_K, False), (L.Q4_K, L.Q6_K, False), (L.Q5_K, L.Q6_K, True), (L.Q6_K, L.Q6_K, True), (L.Q4_K, L.Q5_K, False), (L.Q8_0, L.Q8_0, False), (L.Q8_0, L.Q8_0, True)])
 def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias):
     """One decode token through norm -> {wq, wk, wv} -> (+bias) -> rope(q, k) -> KV-cache store, the node pattern of
     llama_lite / llm_build_llama.  wq/wk in one K-quant format and wv in another take ONE launch (qkv.hip gives each
