@@ -78,7 +78,7 @@ class HParams(C.Structure):
 
 class ContextParams(C.Structure):
     _fields_ = [("n_ctx", C.c_int32), ("n_ubatch", C.c_int32), ("flash_attn", C.c_int32), ("n_threads", C.c_int32),
-                ("graph_reuse", C.c_int32)]
+                ("graph_reuse", C.c_int32), ("type_k", C.c_int32), ("type_v", C.c_int32)]
 
 
 class InitParams(C.Structure):

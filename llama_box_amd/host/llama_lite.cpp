@@ -673,10 +673,19 @@ extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backe
     c->buft = backend ? ggml_backend_dev_buffer_type(backend->device) : ggml_backend_cpu_buffer_type();
     const llm_hparams & hp = m->hp;
     const int64_t n_embd_k = (int64_t) m->n_head_kv_l * hp.n_embd_head;
+    const ggml_type type_k = c->p.type_k == 0 ? GGML_TYPE_F16 : (ggml_type) c->p.type_k;
+    const ggml_type type_v = c->p.type_v == 0 ? GGML_TYPE_F16 : (ggml_type) c->p.type_v;
+    const bool quant_kv = type_k != GGML_TYPE_F16 || type_v != GGML_TYPE_F16;
+    if ((type_k != GGML_TYPE_F16 && type_k != GGML_TYPE_Q8_0) || (type_v != GGML_TYPE_F16 && type_v != GGML_TYPE_Q8_0) || (quant_kv && !c->p.flash_attn) ||
+        (quant_kv && (hp.n_embd_head % 32) != 0)) {
+        fprintf(stderr, "llm_context_new: unsupported KV cache types %d/%d (f16 or q8_0; quantised caches need flash_attn)\n", (int) type_k, (int) type_v);
+        delete c;
+        return nullptr;
+    }
     c->ctx_kv = ggml_init({0, nullptr, true});
     for (int il = 0; il < hp.n_layer; ++il) {
-        ggml_tensor * k = ggml_new_tensor_2d(c->ctx_kv, GGML_TYPE_F16, n_embd_k, c->p.n_ctx);
-        ggml_tensor * v = c->p.flash_attn ? ggml_new_tensor_2d(c->ctx_kv, GGML_TYPE_F16, n_embd_k, c->p.n_ctx)
+        ggml_tensor * k = ggml_new_tensor_2d(c->ctx_kv, type_k, n_embd_k, c->p.n_ctx);
+        ggml_tensor * v = c->p.flash_attn ? ggml_new_tensor_2d(c->ctx_kv, type_v, n_embd_k, c->p.n_ctx)
                                           : ggml_new_tensor_2d(c->ctx_kv, GGML_TYPE_F16, c->p.n_ctx, n_embd_k);
         named(k, "cache_k_l", il);
         named(v, "cache_v_l", il);

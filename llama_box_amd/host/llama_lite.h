@@ -62,6 +62,8 @@ struct llm_context_params {
     int32_t flash_attn; /* 1: FLASH_ATTN_EXT, 0: MUL_MAT/SOFT_MAX/MUL_MAT with transposed V cache */
     int32_t n_threads;  /* for the external compute function */
     int32_t graph_reuse; /* keep the built graph while the topology key is unchanged */
+    int32_t type_k, type_v; /* ggml type of the K / V cache rows (llama-box -ctk / -ctv): 0 or GGML_TYPE_F16 = f16, GGML_TYPE_Q8_0 = q8_0
+                               (quantised caches need flash_attn, as in llama.cpp) */
 };
 struct llm_context;
 /* exactly one of backend / compute must be set: backend -> ggml_backend_graph_compute, else the callback

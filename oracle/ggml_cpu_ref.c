@@ -620,8 +620,9 @@ static enum ggml_status op_set_rows(struct ggml_tensor * dst) {
     const struct ggml_tensor * a = dst->src[0];
     const struct ggml_tensor * idx = dst->src[1];
     if (a->type != GGML_TYPE_F32 || idx->type != GGML_TYPE_I64) return GGML_STATUS_FAILED;
-    if (dst->type != GGML_TYPE_F32 && dst->type != GGML_TYPE_F16) return GGML_STATUS_FAILED;
+    if (dst->type != GGML_TYPE_F32 && dst->type != GGML_TYPE_F16 && dst->type != GGML_TYPE_Q8_0) return GGML_STATUS_FAILED;
     const int64_t nc = a->ne[0];
+    if (dst->type == GGML_TYPE_Q8_0 && (nc % 32) != 0) return GGML_STATUS_FAILED;
     for (int64_t i03 = 0; i03 < a->ne[3]; ++i03)
         for (int64_t i02 = 0; i02 < a->ne[2]; ++i02)
             for (int64_t i01 = 0; i01 < a->ne[1]; ++i01) {
@@ -631,6 +632,7 @@ static enum ggml_status op_set_rows(struct ggml_tensor * dst) {
                 const float * s = (const float *) (TDATA(a) + i01 * a->nb[1] + i02 * a->nb[2] + i03 * a->nb[3]);
                 char * d = TDATA(dst) + i1 * dst->nb[1] + i02 * dst->nb[2] + i03 * dst->nb[3];
                 if (dst->type == GGML_TYPE_F32) memcpy(d, s, (size_t) nc * 4);
+                else if (dst->type == GGML_TYPE_Q8_0) oracle_quantize_row_q8_0(s, (block_q8_0 *) d, nc); /* from_float of the destination type (quantised KV cache) */
                 else for (int64_t i = 0; i < nc; ++i) ((ggml_fp16_t *) d)[i] = oracle_fp32_to_fp16(s[i]);
             }
     return GGML_STATUS_SUCCESS;
@@ -814,6 +816,9 @@ static enum ggml_status op_rope(struct ggml_tensor * dst) {
 /* ------------------------------------------------------------------------------------------ */
 /* FLASH_ATTN_EXT: ggml_compute_forward_flash_attn_ext_f16 — online softmax per query row,       */
 /* Q rounded to f16, K·Q dot in double, V accumulated IN F16 when V is f16 (Appendix A.3).       */
+/* Quantised cache (-ctk/-ctv q8_0): Q goes through K's vec_dot_type (quantize_row_q8_0) and the  */
+/* score is ggml_vec_dot_q8_0_q8_0; a non-f16 V row is dequantised (to_float) and accumulated in  */
+/* f32 (ggml_vec_mad_f32) — the upstream routine's second branch.                                 */
 /* ------------------------------------------------------------------------------------------ */
 static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
     const struct ggml_tensor * q = dst->src[0];
@@ -821,7 +826,9 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
     const struct ggml_tensor * v = dst->src[2];
     const struct ggml_tensor * mask = dst->src[3];
     const struct ggml_tensor * sinks = dst->src[4];
-    if (q->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return GGML_STATUS_FAILED;
+    if (q->type != GGML_TYPE_F32 || (k->type != GGML_TYPE_F16 && k->type != GGML_TYPE_Q8_0) || (v->type != GGML_TYPE_F16 && v->type != GGML_TYPE_Q8_0)) return GGML_STATUS_FAILED;
+    const int kq8 = k->type == GGML_TYPE_Q8_0, vq8 = v->type == GGML_TYPE_Q8_0;
+    if ((kq8 && (k->ne[0] % 32) != 0) || (vq8 && (v->ne[0] % 32) != 0)) return GGML_STATUS_FAILED;
     if (mask && mask->type != GGML_TYPE_F16) return GGML_STATUS_FAILED;
     const int64_t DK = k->ne[0], DV = v->ne[0];
     const int64_t neq1 = q->ne[1], neq2 = q->ne[2], neq3 = q->ne[3];
@@ -847,18 +854,26 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
         float * VKQ32 = (float *) calloc((size_t) DV, 4);
         ggml_fp16_t * VKQ16 = (ggml_fp16_t *) calloc((size_t) DV, 2);
         ggml_fp16_t * Q16 = (ggml_fp16_t *) malloc((size_t) DK * 2);
-        if (!VKQ32 || !VKQ16 || !Q16) { fail = 1; free(VKQ32); free(VKQ16); free(Q16); continue; }
+        block_q8_0 * Qq = (block_q8_0 *) malloc((size_t) (DK / 32 + 1) * sizeof(block_q8_0));
+        float * V32 = (float *) malloc((size_t) DV * 4);
+        if (!VKQ32 || !VKQ16 || !Q16 || !Qq || !V32) { fail = 1; free(VKQ32); free(VKQ16); free(Q16); free(Qq); free(V32); continue; }
         const ggml_fp16_t * mp = mask ? (const ggml_fp16_t *) (TDATA(mask) + iq1 * mask->nb[1] + (iq2 % mask->ne[2]) * mask->nb[2] + (iq3 % mask->ne[3]) * mask->nb[3]) : NULL;
         const int64_t ik3 = iq3 / rk3, ik2 = iq2 / rk2, iv3 = iq3 / rv3, iv2 = iq2 / rv2;
         const float * pq = (const float *) (TDATA(q) + iq1 * q->nb[1] + iq2 * q->nb[2] + iq3 * q->nb[3]);
-        for (int64_t i = 0; i < DK; ++i) Q16[i] = oracle_fp32_to_fp16(pq[i]);
+        if (kq8) oracle_quantize_row_q8_0(pq, Qq, DK);
+        else for (int64_t i = 0; i < DK; ++i) Q16[i] = oracle_fp32_to_fp16(pq[i]);
         for (int64_t ic = 0; ic < nek1; ++ic) {
             const float mv = mp ? slope * F16(mp[ic]) : 0.0f;
             if (mv == -INFINITY) continue;
             const ggml_fp16_t * kd = (const ggml_fp16_t *) (TDATA(k) + ic * k->nb[1] + ik2 * k->nb[2] + ik3 * k->nb[3]);
-            ggml_float acc = 0.0;
-            for (int64_t i = 0; i < DK; ++i) acc += (ggml_float) (F16(kd[i]) * F16(Q16[i]));
-            float s = (float) acc;
+            float s;
+            if (kq8) {
+                s = oracle_vec_dot_q8_0_q8_0(DK, (const block_q8_0 *) kd, Qq);
+            } else {
+                ggml_float acc = 0.0;
+                for (int64_t i = 0; i < DK; ++i) acc += (ggml_float) (F16(kd[i]) * F16(Q16[i]));
+                s = (float) acc;
+            }
             s = s * scale;
             if (logit_softcap != 0.0f) s = logit_softcap * tanhf(s);
             s += mv;
@@ -868,17 +883,23 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
             if (s > M) {
                 M = s;
                 ms = expf(Mold - M);
-                for (int64_t i = 0; i < DV; ++i) VKQ16[i] = oracle_fp32_to_fp16(F16(VKQ16[i]) * ms); /* ggml_vec_scale_f16 */
+                if (vq8) for (int64_t i = 0; i < DV; ++i) VKQ32[i] *= ms;                                   /* ggml_vec_scale_f32 */
+                else for (int64_t i = 0; i < DV; ++i) VKQ16[i] = oracle_fp32_to_fp16(F16(VKQ16[i]) * ms); /* ggml_vec_scale_f16 */
             } else {
                 vs = expf(s - M);
             }
-            for (int64_t i = 0; i < DV; ++i) { /* ggml_vec_mad_f16 */
-                const float p = F16(vd[i]) * vs;
-                VKQ16[i] = oracle_fp32_to_fp16(F16(VKQ16[i]) + p);
+            if (vq8) { /* v_to_float + ggml_vec_mad_f32 */
+                dequantize_row_q8_0((const block_q8_0 *) vd, V32, DV);
+                for (int64_t i = 0; i < DV; ++i) VKQ32[i] += V32[i] * vs;
+            } else {
+                for (int64_t i = 0; i < DV; ++i) { /* ggml_vec_mad_f16 */
+                    const float p = F16(vd[i]) * vs;
+                    VKQ16[i] = oracle_fp32_to_fp16(F16(VKQ16[i]) + p);
+                }
             }
             S = S * ms + vs;
         }
-        for (int64_t i = 0; i < DV; ++i) VKQ32[i] = F16(VKQ16[i]);
+        if (!vq8) for (int64_t i = 0; i < DV; ++i) VKQ32[i] = F16(VKQ16[i]);
         if (sinks) {
             const float s = ((const float *) sinks->data)[h];
             float ms = 1.0f, vs = 1.0f;
@@ -897,6 +918,8 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
         free(VKQ32);
         free(VKQ16);
         free(Q16);
+        free(Qq);
+        free(V32);
     }
     return fail ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_SUCCESS;
 }

@@ -38,12 +38,12 @@ class Model:
 
 
 class Context:
-    def __init__(self, model, backend=None, compute=None, n_ctx=512, n_ubatch=512, flash_attn=0, n_threads=0, graph_reuse=1):
+    def __init__(self, model, backend=None, compute=None, n_ctx=512, n_ubatch=512, flash_attn=0, n_threads=0, graph_reuse=1, type_k=0, type_v=0):
         H = L.host()
         self.H = H
         self.model = model
         self._compute = compute if compute is not None else L.COMPUTE_FN()
-        cp = L.ContextParams(n_ctx, n_ubatch, flash_attn, n_threads, graph_reuse)
+        cp = L.ContextParams(n_ctx, n_ubatch, flash_attn, n_threads, graph_reuse, type_k, type_v)
         self.c = H.llm_context_new(model.m, backend.backend if backend is not None else None, self._compute, C.byref(cp))
         if not self.c:
             raise RuntimeError("context creation failed")

@@ -6,6 +6,7 @@ import re
 import tempfile
 
 import numpy as np
+import pytest
 
 import harness as T
 import llama_box_amd as L
@@ -157,9 +158,22 @@ def test_driver_on_oracle_determinism_reuse_and_batching(H):
         c3 = Context(m, compute=fn, flash_attn=1)
         rc, lf = c3.decode(prompt, range(len(prompt)))
         assert T.nmse(lf, lg) < 5e-3
+        # quantised KV cache (-ctk / -ctv q8_0): Q8_0 rounding of K, V and of the query moves the logits a little, not a lot;
+        # decode after prefill works on the quantised rows; a quantised cache without flash attention is refused
+        c4 = Context(m, compute=fn, flash_attn=1, type_k=L.Q8_0, type_v=L.Q8_0)
+        rc, lq = c4.decode(prompt, range(len(prompt)))
+        assert rc == 0 and not np.array_equal(lq, lf) and T.nmse(lq, lf) < 2e-2
+        rc, lq1 = c4.decode([11], [len(prompt)])
+        rc2, lf1 = c3.decode([11], [len(prompt)])
+        assert rc == 0 and rc2 == 0 and T.nmse(lq1, lf1) < 2e-2
+        c5 = Context(m, compute=fn, flash_attn=1, type_k=L.Q8_0)  # K only
+        rc, lk = c5.decode(prompt, range(len(prompt)))
+        assert rc == 0 and T.nmse(lk, lf) < 2e-2
+        with pytest.raises(RuntimeError):
+            Context(m, compute=fn, flash_attn=0, type_v=L.Q8_0)
         # return codes
         assert c3.decode([hp.n_vocab], [0])[0] == -1
-        for c in (c1, c2, c3):
+        for c in (c1, c2, c3, c4, c5):
             c.free()
     finally:
         m.free()
