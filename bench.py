@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--fa", type=int, default=1)
     ap.add_argument("--np", type=int, default=1, help="parallel sequences decoded per step (llama-box -np continuous batching)")
     ap.add_argument("--ubatch", type=int, default=512)
+    ap.add_argument("--ctkv", default="f16", choices=["f16", "q8_0"], help="KV cache type (llama-box --cache-type-k / --cache-type-v); the headline metric is quoted on f16")
     ap.add_argument("--layers", type=int, default=0, help="debug only: override n_layer (result is then NOT a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
@@ -147,8 +148,9 @@ def main():
     t_load = time.time()
     model = Model(hp, 0x5EED, be.buft, tp_rank=tp_rank, tp_size=tp_size, rowpar_buft=be.rowpar_buft() if tp_size > 1 else None)
     t_load = time.time() - t_load
+    kvt = L.Q8_0 if args.ctkv == "q8_0" else 0
     n_ctx = (args.np * (args.prefill + args.warmup + args.steps + args.timing_steps + 64) + 255) // 256 * 256
-    ctx = Context(model, backend=be, n_ctx=n_ctx, n_ubatch=args.ubatch, flash_attn=args.fa, graph_reuse=1)
+    ctx = Context(model, backend=be, n_ctx=n_ctx, n_ubatch=args.ubatch, flash_attn=args.fa, graph_reuse=1, type_k=kvt, type_v=kvt)
     rng = np.random.default_rng(1 + 0 * rank)
     toks = rng.integers(0, hp.n_vocab, args.np * (args.prefill + args.warmup + args.steps + args.timing_steps + 8))
 
@@ -281,7 +283,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None, "dtype": "q4_K/q6_K weights x q8_K activations (int8 dot, f32 accumulate)",
             "data": "synthetic (GGUF-exact tensor set, directly sampled quant blocks, random token ids)",
-            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode, flash_attn={args.fa}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
+            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode, flash_attn={args.fa}, kv_cache={args.ctkv}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
                        "parallelism": parallelism, "n_past_mid": n_past, "weight_bytes_per_token_per_gpu": w_bytes, "kv_bytes_per_token_per_gpu": kv_per_tok * n_past},
             "prefill_tok_s": round(prefill_tok_s, 1) if prefill_tok_s else None,
             "prefill_host_us": {"build": round(prefill_host_split[0], 1), "inputs": round(prefill_host_split[1], 1), "compute+sync": round(prefill_host_split[2], 1), "logits_d2h": round(prefill_host_split[3], 1)} if prefill_tok_s else None,

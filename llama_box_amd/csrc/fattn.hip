@@ -246,7 +246,10 @@ __device__ __forceinline__ float xrow_allmax(const float x) {
 }
 // SKIP = true (several query tokens, e.g. -np 32 decode over a unified cache where each token sees ~1/32 of the cells): the mask
 // of the whole split is read first — one round trip — and trips without a visible position for this wave load no K/V at all.
-template <int G, bool SKIP>
+// Q8 = true: K and V rows are block_q8_0 (quantised KV cache, -ctk/-ctv q8_0).  As in ggml-cpu the query is quantised to Q8_0
+// too (K's vec_dot_type), a score is sum over the four 32-value blocks of sumi * (d_k * d_q) with an integer block sum, and a
+// V row is de-quantised (q * d) and accumulated in f32.  A lane still owns 8 dims: 8 int8 of one block (lanes 4b..4b+3 = block b).
+template <int G, bool SKIP, bool Q8>
 __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
                                                       const tdesc dst, const fa_geom geo, float * __restrict__ ws, const int g_real) {
     constexpr int D = 128, NG = 16 / G;
@@ -283,8 +286,8 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
         }
     }
     const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
-    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + sl * 16;
-    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + sl * 16;
+    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + (Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
+    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + (Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
 
     // a trip covers NG*16 consecutive positions: position of (u, wave, sub) = p0 + u*16 + wave*4 + sub
     uint4 kraw[NG], vraw[NG];
@@ -295,8 +298,15 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     {                                                                                   \
         _Pragma("unroll") for (int u = 0; u < NG; ++u) {                               \
             const int pc = min(p0 + u * 16 + wave * 4 + sub, kv1 - 1);                  \
-            kraw[u] = *(const uint4 *) (kbase + (int64_t) pc * k.nb[1]);                \
-            vraw[u] = *(const uint4 *) (vbase + (int64_t) pc * v.nb[1]);                \
+            const char * kp_ = kbase + (int64_t) pc * k.nb[1];                          \
+            const char * vp_ = vbase + (int64_t) pc * v.nb[1];                          \
+            if constexpr (Q8) {  /* 8 quants (2-byte aligned) + the block's f16 scale */  \
+                kraw[u] = make_uint4(ld32_a2(kp_), ld32_a2(kp_ + 4), (uint32_t) ld16(kp_ - 2 - (sl & 3) * 8), 0u);  \
+                vraw[u] = make_uint4(ld32_a2(vp_), ld32_a2(vp_ + 4), (uint32_t) ld16(vp_ - 2 - (sl & 3) * 8), 0u);  \
+            } else {                                                                    \
+                kraw[u] = *(const uint4 *) kp_;                                         \
+                vraw[u] = *(const uint4 *) vp_;                                         \
+            }                                                                           \
         }                                                                               \
         const int pl = p0 + ul * 16 + wave * 4 + sub;                                   \
         okl = pl < kv1;                                                                 \
@@ -322,17 +332,39 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
         if (kv0 < kv1) FA_LOAD_TRIP()
     }
 
-    fa_half2 qh[G][4];
+    fa_half2 qh[G][4];    // f16 cache: the query as packed f16
+    int qq[G][2];         // q8_0 cache: the query's 8 int8 of this lane's block ...
+    float dq[G];          // ... and the block scale (through f16, as block_q8_0.d)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int h = kvh * g_real + min(g, g_real - 1);
         const float4 * qp = (const float4 *) ((const float *) (q.data + (int64_t) tok * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]) + sl * 8);
         const float4 qa = qp[0], qb = qp[1];
         const float z = g < g_real ? 1.0f : 0.0f;
-        qh[g][0] = (fa_half2){(_Float16) (qa.x * z), (_Float16) (qa.y * z)};  // q_to_vec_dot: Q -> f16 (round to nearest even)
-        qh[g][1] = (fa_half2){(_Float16) (qa.z * z), (_Float16) (qa.w * z)};
-        qh[g][2] = (fa_half2){(_Float16) (qb.x * z), (_Float16) (qb.y * z)};
-        qh[g][3] = (fa_half2){(_Float16) (qb.z * z), (_Float16) (qb.w * z)};
+        if constexpr (Q8) {  // quantize_row_q8_0 of the query: a block = the 4 lanes of a quad
+            const float xv[8] = {qa.x * z, qa.y * z, qa.z * z, qa.w * z, qb.x * z, qb.y * z, qb.z * z, qb.w * z};
+            float amax = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(xv[i]));
+            amax = fmaxf(amax, dpp_f32<MI_DPP_QUAD_XOR1>(amax));
+            amax = fmaxf(amax, dpp_f32<MI_DPP_QUAD_XOR2>(amax));
+            const float d = amax / 127.0f;
+            const float id = d != 0.0f ? 1.0f / d : 0.0f;
+            uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w0 |= (uint32_t) ((int) roundf(xv[i] * id) & 0xFF) << (8 * i);
+                w1 |= (uint32_t) ((int) roundf(xv[4 + i] * id) & 0xFF) << (8 * i);
+            }
+            qq[g][0] = (int) w0;
+            qq[g][1] = (int) w1;
+            dq[g] = h2f(f2h(d));
+        } else {
+            qh[g][0] = (fa_half2){(_Float16) (qa.x * z), (_Float16) (qa.y * z)};  // q_to_vec_dot: Q -> f16 (round to nearest even)
+            qh[g][1] = (fa_half2){(_Float16) (qa.z * z), (_Float16) (qa.w * z)};
+            qh[g][2] = (fa_half2){(_Float16) (qb.x * z), (_Float16) (qb.y * z)};
+            qh[g][3] = (fa_half2){(_Float16) (qb.z * z), (_Float16) (qb.w * z)};
+        }
     }
     float acc[G][8];
 #pragma unroll
@@ -360,17 +392,33 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
+            if constexpr (Q8) {
+                const float dv = h2f((uint16_t) vu[2]), dk = h2f((uint16_t) ku[2]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vf[u][2 * i] = h2f((uint16_t) (vu[i] & 0xFFFF));
-                vf[u][2 * i + 1] = h2f((uint16_t) (vu[i] >> 16));
-            }
+                for (int i = 0; i < 4; ++i) {  // dequantize_row_q8_0: q * d
+                    vf[u][i] = (float) (int) (int8_t) (vu[0] >> (8 * i)) * dv;
+                    vf[u][4 + i] = (float) (int) (int8_t) (vu[1] >> (8 * i)) * dv;
+                }
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float d = 0.0f;
+                for (int g = 0; g < G; ++g) {
+                    int isum = dot4((int) ku[0], qq[g][0], dot4((int) ku[1], qq[g][1], 0));
+                    isum += dpp_i32<MI_DPP_QUAD_XOR1>(isum);
+                    isum += dpp_i32<MI_DPP_QUAD_XOR2>(isum);  // the block's integer sum, in all 4 lanes of the quad
+                    t[u * G + g] = (sl & 3) == 0 ? (float) isum * (dk * dq[g]) : 0.0f;  // one lane per block feeds the 16-lane sum below
+                }
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d = __builtin_amdgcn_fdot2(__builtin_bit_cast(fa_half2, ku[i]), qh[g][i], d, false);
-                t[u * G + g] = d;
+                for (int i = 0; i < 4; ++i) {
+                    vf[u][2 * i] = h2f((uint16_t) (vu[i] & 0xFFFF));
+                    vf[u][2 * i + 1] = h2f((uint16_t) (vu[i] >> 16));
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d = __builtin_amdgcn_fdot2(__builtin_bit_cast(fa_half2, ku[i]), qh[g][i], d, false);
+                    t[u * G + g] = d;
+                }
             }
         }
         const bool more = p0 + NG * 16 < kv1 && (!SKIP || ((vis >> (trip + 1)) & 1u));
@@ -570,7 +618,8 @@ template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, co
 
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
                        const fattn_params & p, void * workspace) {
-    if (launch_flash_attn_mma(s, q, k, v, mask, sinks, dst, p, workspace)) return;
+    const bool q8 = p.kv_type == GGML_TYPE_Q8_0;
+    if (!q8 && launch_flash_attn_mma(s, q, k, v, mask, sinks, dst, p, workspace)) return;
     fa_geom geo;
     geo.n_q = (int) q.ne[1];
     geo.n_head = (int) q.ne[2];
@@ -594,12 +643,17 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         // several query tokens with a mask: skip the KV trips a token cannot see — needs splits of at most 32 trips
         const int per = ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64;
         static const bool skip_on = !getenv("GGML_MI355X_FA_SKIP") || atoi(getenv("GGML_MI355X_FA_SKIP")) != 0;
-        const bool skip = skip_on && geo.n_q > 1 && geo.n_q <= 64 && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
+        const bool skip = skip_on && geo.n_q > 1 && (geo.n_q <= 64 || q8) && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
                           (mask->nb[3] % 8) == 0 && ((uintptr_t) mask->data & 7) == 0 && geo.n_splits > 1;
-#define FA_DEC(GG)                                                                                                              \
-    {                                                                                                                           \
-        if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);  \
-        else hipLaunchKernelGGL((k_fattn_dec128<GG, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);      \
+#define FA_DEC(GG)                                                                                                                          \
+    {                                                                                                                                       \
+        if (q8) {                                                                                                                           \
+            if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, true, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);     \
+            else hipLaunchKernelGGL((k_fattn_dec128<GG, false, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);         \
+        } else {                                                                                                                            \
+            if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, true, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);    \
+            else hipLaunchKernelGGL((k_fattn_dec128<GG, false, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);        \
+        }                                                                                                                                   \
     }
         if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
 #undef FA_DEC
@@ -608,6 +662,10 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
             hipLaunchKernelGGL((k_fattn_combine<128>), g2, dim3(128), 0, s, ws, sinks, dst, geo);
         }
         return;
+    }
+    if (q8) {
+        MI_ERR("launch_flash_attn: q8_0 K/V reached the generic kernel (head_dim %d, group %d) — supports_op should have refused it", D, G);
+        abort();
     }
 #define FA_CASE(DD, GG) \
     if (D == DD && G == GG) { launch_fa<DD, GG>(s, q, k, v, mk, sinks, dst, geo, ws); return; }

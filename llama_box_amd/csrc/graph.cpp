@@ -63,6 +63,7 @@ bool supports_op(const ggml_tensor * op) {
             return b->type == GGML_TYPE_I32 && op->type == GGML_TYPE_F32 && rows_contig(a) && op->nb[0] == 4 &&
                    (is_quant(a->type) || a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32);
         case GGML_OP_SET_ROWS:
+            if (op->type == GGML_TYPE_Q8_0) return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_I64 && a->nb[0] == 4 && (a->ne[0] % 32) == 0 && (a->nb[1] % 16) == 0 && (a->nb[2] % 16) == 0 && (a->nb[3] % 16) == 0;
             return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_I64 && a->nb[0] == 4 && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) &&
                    op->nb[0] == ggml_abi_type_size(op->type);
         case GGML_OP_SOFT_MAX:
@@ -76,7 +77,17 @@ bool supports_op(const ggml_tensor * op) {
             const ggml_tensor * k = op->src[1];
             const ggml_tensor * v = op->src[2];
             const ggml_tensor * m = op->src[3];
-            if (a->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return false;
+            if (a->type != GGML_TYPE_F32) return false;
+            if (k->type == GGML_TYPE_Q8_0 && v->type == GGML_TYPE_Q8_0) {
+                // quantised KV cache: served by the lane-parallel kernel only (head_dim 128, 2/4/7/8 query heads per KV head, no
+                // soft-capping / ALiBi); anything else stays on the CPU backend
+                const int64_t g = k->ne[2] ? a->ne[2] / k->ne[2] : 0;
+                if (k->ne[0] != 128 || v->ne[0] != 128 || a->nb[0] != 4 || (a->nb[1] % 16) || (a->nb[2] % 16) || a->ne[2] % k->ne[2] != 0 || k->ne[2] != v->ne[2]) return false;
+                if (!(g == 2 || g == 4 || g == 7 || g == 8) || ggml_abi_op_param_f32(op, 1) != 0.0f || ggml_abi_op_param_f32(op, 2) != 0.0f) return false;
+                if ((k->nb[1] % 2) || (v->nb[1] % 2) || (k->nb[2] % 2) || (v->nb[2] % 2)) return false;
+                return !m || (m->type == GGML_TYPE_F16 && m->ne[2] == 1 && rows_contig(m));
+            }
+            if (k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return false;
             if (k->ne[0] != v->ne[0] || (k->ne[0] != 64 && k->ne[0] != 128)) return false;
             if (a->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || (k->nb[1] % 16) || (v->nb[1] % 16) || (k->nb[2] % 16) || (v->nb[2] % 16)) return false;
             if (m && (m->type != GGML_TYPE_F16 || m->ne[2] != 1 || !rows_contig(m))) return false;
@@ -445,8 +456,9 @@ static bool follow_qkv_chain(const exec_state & st, int start, int limit, qkv_ch
             ch.nodes.push_back(j);
             continue;
         }
-        if (c->op == GGML_OP_SET_ROWS && c->src[0] == cur && c->type == GGML_TYPE_F16 && c->ne[0] == N && cur->ne[0] == N && ggml_abi_nelements(cur) == N &&
-            c->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(c->src[1]) == 1 && c->nb[0] == 2) {
+        if (c->op == GGML_OP_SET_ROWS && c->src[0] == cur && c->ne[0] == N && cur->ne[0] == N && ggml_abi_nelements(cur) == N &&
+            c->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(c->src[1]) == 1 &&
+            ((c->type == GGML_TYPE_F16 && c->nb[0] == 2) || (c->type == GGML_TYPE_Q8_0 && (N % 32) == 0))) {
             ch.store = c;
             ch.nodes.push_back(j);
             return true;
@@ -494,7 +506,16 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     // rope / store consistency
     const ggml_tensor * rope0 = nullptr;
     const ggml_tensor * idx0 = nullptr;
+    bool q8_store = false;
+    for (auto & ch : chains) q8_store = q8_store || (ch.store && ch.store->type == GGML_TYPE_Q8_0);
     for (auto & ch : chains) {
+        if (q8_store) {
+            // quantised KV cache: a workgroup trip (16 row pairs) must be exactly one block_q8_0 of the cache row, which the
+            // interleaved pair layout gives when every segment is a multiple of 32 rows; the NeoX layout pairs rows
+            // (i, i + d/2) of two different blocks and stays on the unfused path
+            if ((ch.mm->ne[0] % 32) != 0) return false;
+            if (ch.rope && ((ch.rope->op_params[2] & GGML_ROPE_TYPE_NEOX) || (ch.rope->ne[0] % 32) != 0)) return false;
+        }
         if (ch.rope) {
             const ggml_tensor * r = ch.rope;
             const int mode = r->op_params[2];
@@ -564,7 +585,7 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             sg.N = (int) w->ne[1];
             sg.bias = ch.bias ? (const float *) ch.bias->data : nullptr;
             sg.rope = ch.rope ? 1 : 0;
-            sg.store_f16 = ch.store ? 1 : 0;
+            sg.store = !ch.store ? 0 : (ch.store->type == GGML_TYPE_Q8_0 ? 2 : 1);
             sg.out = ch.store ? (char *) ch.store->data : (char *) ch.out_f32->data;
             sg.row_stride = ch.store ? (int64_t) ch.store->nb[1] : 0;
             bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];
@@ -733,7 +754,8 @@ static int run_node(exec_state & st, int i) {
         }
         case GGML_OP_SET_ROWS: {
             timed_scope ts(c, "set_rows", (double) ggml_abi_nbytes(a));
-            launch_set_rows(s, TD(a), TD(b), TD(n));
+            if (n->type == GGML_TYPE_Q8_0) launch_set_rows_q8_0(s, TD(a), TD(b), TD(n));
+            else launch_set_rows(s, TD(a), TD(b), TD(n));
             c->st.kernel_launches++;
             return 1;
         }
@@ -770,6 +792,7 @@ static int run_node(exec_state & st, int i) {
             p.logit_softcap = ggml_abi_op_param_f32(n, 2);
             const tdesc qd = TD(a), kd = TD(k), vd = TD(v);
             p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd));
+            p.kv_type = k->type;
             const tdesc md = m ? TD(m) : qd;
             timed_scope ts(c, "flash_attn", (double) (k->ne[1] * k->ne[2] * k->ne[0] * 2 * 2));
             launch_flash_attn(s, qd, kd, vd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p, (char *) c->ws + st.aux_off);

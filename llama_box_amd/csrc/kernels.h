@@ -67,7 +67,7 @@ struct qkv_seg {
     int alt, N;           // alt: 0 = first weight format of the launch, 1 = second
     const float * bias;   // optional [N]
     int rope;             // rotate pairs of this segment
-    int store_f16;        // 1: f16 into row `slot` of a cache tensor (out + slot*row_stride), 0: f32 at out
+    int store;            // 0: f32 at out; 1: f16 / 2: block_q8_0 into row `slot` of a cache tensor (out + slot*row_stride)
     char * out;
     int64_t row_stride;
 };
@@ -118,6 +118,7 @@ void launch_swiglu_quantize(hipStream_t s, const tdesc & a, const tdesc * b, int
 void launch_cpy(hipStream_t s, const tdesc & src, const tdesc & dst);
 void launch_get_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
 void launch_set_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
+void launch_set_rows_q8_0(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);  // f32 rows -> block_q8_0 rows (quantised KV cache)
 void launch_argmax(hipStream_t s, const tdesc & src, const tdesc & dst);
 void launch_upload_small(hipStream_t s, void * dst, const void * pinned_src, size_t n);
 
@@ -134,6 +135,7 @@ void launch_soft_max(hipStream_t s, const tdesc & src, const tdesc * mask, const
 struct fattn_params {
     float scale, max_bias, logit_softcap;
     int n_splits;  // KV splits per (token, kv-head group)
+    int kv_type;   // GGML_TYPE_F16 or GGML_TYPE_Q8_0 (K and V alike)
 };
 size_t fattn_workspace_bytes(const tdesc & q, const tdesc & v, int n_splits);
 int fattn_pick_splits(const tdesc & q, const tdesc & k);

@@ -458,6 +458,41 @@ void launch_soft_max(hipStream_t s, const tdesc & a, const tdesc * mask, const f
     hipLaunchKernelGGL(k_soft_max, dim3((unsigned) rows), dim3(256), 0, s, a, mask ? *mask : dummy, mask ? 1 : 0, sinks, d, scale, max_bias, m0, m1, n_head_log2);
 }
 
+// ---- SET_ROWS into a Q8_0 tensor (quantised KV cache): quantize_row_q8_0_ref per 32 values — d = amax / 127 stored as f16,
+// q = roundf(x / d) with the unrounded d.  One wave per 256 source values (8 blocks, 8 lanes each); blocks are 34 bytes, so the
+// quants go out as 16-bit stores.
+__global__ void __launch_bounds__(64) k_set_rows_q8_0(const tdesc a, const tdesc idx, const tdesc d) {
+    const int lane = threadIdx.x;
+    const int64_t chunks = (a.ne[0] + 255) / 256;  // rows are whole blocks of 32; the last chunk of a row may be short
+    const int64_t gid = blockIdx.x;
+    const int64_t row = gid / chunks, ch = gid - row * chunks;
+    const int64_t i01 = row % a.ne[1], i02 = (row / a.ne[1]) % a.ne[2], i03 = row / (a.ne[1] * a.ne[2]);
+    const int64_t i12 = i03 % idx.ne[2], i11 = i02 % idx.ne[1];
+    const int64_t r = *(const int64_t *) (idx.data + i01 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+    const bool live = ch * 256 + lane * 4 < a.ne[0];
+    const float4 x = live ? ((const float4 *) (a.data + i01 * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3]))[ch * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float v[4] = {x.x, x.y, x.z, x.w};
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_QUAD_XOR1>(amax));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_QUAD_XOR2>(amax));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_HALF_MIRROR>(amax));
+    const float dd = amax / 127.0f;
+    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) packed |= (uint32_t) ((int) roundf(v[k] * id) & 0xFF) << (8 * k);
+    char * blk = d.data + r * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3] + (ch * 8 + (lane >> 3)) * 34;
+    if (!live) return;
+    uint16_t * qs = (uint16_t *) (blk + 2 + 4 * (lane & 7));
+    qs[0] = (uint16_t) (packed & 0xFFFF);
+    qs[1] = (uint16_t) (packed >> 16);
+    if ((lane & 7) == 0) *(uint16_t *) blk = f2h(dd);
+}
+void launch_set_rows_q8_0(hipStream_t s, const tdesc & a, const tdesc & idx, const tdesc & d) {
+    const int64_t blocks = ((a.ne[0] + 255) / 256) * a.ne[1] * a.ne[2] * a.ne[3];
+    hipLaunchKernelGGL(k_set_rows_q8_0, dim3((unsigned) blocks), dim3(64), 0, s, a, idx, d);
+}
+
 // ---- small upload: copies `n` bytes from pinned host memory (device-visible) into device memory inside the stream
 __global__ void __launch_bounds__(256) k_upload_small(char * __restrict__ dst, const char * __restrict__ src, const size_t n, const int vec) {
     const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;

@@ -61,7 +61,9 @@ template <typename T> __device__ __forceinline__ void qkv_unit(qkv_regs<T> & r, 
 // those segments.  A launch with two formats (Q4_K_M keeps wv in Q6_K in its "more bits" layers) gives each format its
 // own range of workgroups: a workgroup only ever executes one instantiation, so the register demand is the maximum of
 // the two, not the sum — holding both register sets in one code path spilled weight registers to scratch memory.
-template <typename TA, typename TB>
+// Q8S: the launch stores into a block_q8_0 KV cache (a separate instantiation: the block assembly costs registers the default
+// f16-cache kernel does not have to spare)
+template <typename TA, typename TB, bool Q8S>
 __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (a generic lambda, not a device function: passing the kernel-argument struct to a function copies it to scratch)
@@ -76,6 +78,7 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
     act * yl = (act *) smem;
     double * red = (double *) (smem + (size_t) nblk * sizeof(act));
     float * cs_tab = (float *) (red + MAXW);  // [head_dim/2][2]
+    float * stash = cs_tab + a.head_dim;      // [32]: one Q8_0 block of cache-row values (store == 2)
     const int GW = nwg * WAVES;
     const int half = a.head_dim >> 1;
     const int u0 = a.seg[0].alt == alt ? a.seg[0].N >> 1 : 0;
@@ -186,7 +189,10 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
                 v0 = t0;
                 v1 = t1;
             }
-            if (sg.store_f16) {
+            if (Q8S && sg.store == 2) {
+                stash[2 * wave] = v0;
+                stash[2 * wave + 1] = v1;
+            } else if (sg.store == 1) {
                 uint16_t * o = (uint16_t *) (sg.out + slot * sg.row_stride);
                 o[r0] = f2h(v0);
                 o[r1] = f2h(v1);
@@ -195,6 +201,26 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
                 o[r0] = v0;
                 o[r1] = v1;
             }
+        }
+        if (Q8S && sg.store == 2) {
+            // quantised KV cache: the 16 waves of this workgroup hold 32 consecutive values of the cache row (the launcher
+            // aligns the units; segment and trip count are workgroup-uniform) = one block_q8_0, quantised as
+            // quantize_row_q8_0_ref does: d = amax / 127 (stored f16), q = roundf(x * (1 / d))
+            __syncthreads();
+            if (wave == 0) {
+                const float x = stash[lane & 31];
+                float amax = fabsf(x);
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+                const float d = amax / 127.0f;
+                const float id = d != 0.0f ? 1.0f / d : 0.0f;
+                const int q = (int) roundf(x * id) & 0xFF;
+                const int qn = __shfl_down(q, 1);
+                char * blk = sg.out + slot * sg.row_stride + (size_t) ((r0 & ~31) >> 5) * 34;  // wave 0 owns rows base, base + 1
+                if (lane < 32 && (lane & 1) == 0) *(uint16_t *) (blk + 2 + lane) = (uint16_t) (q | (qn << 8));
+                if (lane == 0) *(uint16_t *) blk = f2h(d);
+            }
+            __syncthreads();
         }
         u += GW;
         have = u < UT;
@@ -229,7 +255,9 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
         units[a.seg[i].alt ? 1 : 0] += a.seg[i].N / 2;
         bytes[a.seg[i].alt ? 1 : 0] += (double) a.seg[i].N * (double) a.seg[i].w_nb1;
     }
-    const size_t lds = (size_t) nblk * (type_a == GGML_TYPE_Q8_0 ? 8 * sizeof(q80_dev) : sizeof(q8k_dev)) + 16 * sizeof(double) + (size_t) a.head_dim * sizeof(float) + 16;
+    const size_t lds = (size_t) nblk * (type_a == GGML_TYPE_Q8_0 ? 8 * sizeof(q80_dev) : sizeof(q8k_dev)) + 16 * sizeof(double) + (size_t) a.head_dim * sizeof(float) + 32 * sizeof(float) + 16;
+    bool q8_store = false;
+    for (int i = 0; i < a.nseg; ++i) q8_store = q8_store || a.seg[i].store == 2;
     // waves per workgroup: 8..16, chosen so that the row-pair units spread over ~256 workgroups (Llama-3-8B: 3072 units ->
     // 12 waves x 256 workgroups; with fixed 16-wave workgroups a quarter of the CUs had nothing to do); the norm prologue
     // needs the whole activation row in one batch of 2 blocks per wave
@@ -237,14 +265,20 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     int nw = std::min(16, std::max((nblk + 1) / 2, 8));
     while (nw < 16 && (units[0] + nw - 1) / nw + (units[1] + nw - 1) / nw > 256) ++nw;  // smallest workgroup that still gives every wave one unit
     if (force_nw) nw = force_nw;
+    if (q8_store) nw = 16;  // a workgroup trip = 16 row pairs = one block_q8_0 of the cache row (caller checked the alignment)
     const dim3 block((unsigned) nw * 64);
+#define QKV_LAUNCH(TA, TB, GRID)                                                                              \
+    do {                                                                                                      \
+        if (q8_store) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, true>), GRID, block, lds, s, a);              \
+        else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                      \
+    } while (0)
     if (type_a == type_b || units[1] == 0) {
         const unsigned grid = (unsigned) std::min(256, (units[0] + nw - 1) / nw);
         a.wg_a = (int) grid;
-        if (type_a == GGML_TYPE_Q4_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q4K>), dim3(grid), block, lds, s, a);
-        else if (type_a == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q5K>), dim3(grid), block, lds, s, a);
-        else if (type_a == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q6K, T_Q6K>), dim3(grid), block, lds, s, a);
-        else if (type_a == GGML_TYPE_Q8_0) hipLaunchKernelGGL((k_qkv_stream2<T_Q80, T_Q80>), dim3(grid), block, lds, s, a);
+        if (type_a == GGML_TYPE_Q4_K) QKV_LAUNCH(T_Q4K, T_Q4K, dim3(grid));
+        else if (type_a == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q5K, T_Q5K, dim3(grid));
+        else if (type_a == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q6K, T_Q6K, dim3(grid));
+        else if (type_a == GGML_TYPE_Q8_0) QKV_LAUNCH(T_Q80, T_Q80, dim3(grid));
         else { MI_ERR("launch_qkv: unsupported weight format %d", type_a); abort(); }
         return;
     }
@@ -256,9 +290,9 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     }
     a.wg_a = ga;
     const dim3 grid((unsigned) (ga + gb));
-    if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q6K>), grid, block, lds, s, a);
-    else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q5K, T_Q6K>), grid, block, lds, s, a);
-    else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_qkv_stream2<T_Q4K, T_Q5K>), grid, block, lds, s, a);
+    if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4K, T_Q6K, grid);
+    else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5K, T_Q6K, grid);
+    else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4K, T_Q5K, grid);
     else { MI_ERR("launch_qkv: unsupported weight format pair %d/%d", type_a, type_b); abort(); }
 }
 

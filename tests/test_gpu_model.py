@@ -125,6 +125,38 @@ def test_logits_flash_attn_path(backend, H, plog, name):
         _free(cc, cg, mc, mg)
 
 
+def test_logits_quantised_kv_cache(backend, H, plog):
+    """-ctk q8_0 [-ctv q8_0]: SET_ROWS quantises the new K/V rows into block_q8_0 and FLASH_ATTN_EXT reads them
+    (head_dim 128 models; llama-box exposes this as --cache-type-k / --cache-type-v)."""
+    tk = tv = L.Q8_0  # mixed q8_0 K / f16 V is not advertised by supports_op: ggml-sched would keep that attention on the CPU
+    hp = preset("test-llama", n_head=2, n_head_kv=1, n_embd_head=128)
+    mc = Model(hp, 1234, H.ggml_backend_cpu_buffer_type())
+    mg = Model(hp, 1234, backend.buft)
+    cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=1, type_k=tk, type_v=tv)
+    cg = Context(mg, backend=backend, flash_attn=1, type_k=tk, type_v=tv)
+    try:
+        rc, ref = cc.decode(PROMPT, range(len(PROMPT)))
+        rc2, got = cg.decode(PROMPT, range(len(PROMPT)))
+        assert rc == 0 and rc2 == 0
+        e = T.nmse(got, ref)
+        plog(f"q8_0 KV cache prompt logits: nmse(gpu, cpu)={e:.3e}")
+        assert e <= 1e-3
+        cc.clear(); cg.clear()
+        ids_ref, rows_ref = greedy(cc, PROMPT, 16)
+        ids_got, rows_got = greedy(cg, PROMPT, 16)
+        plog(f"q8_0 KV greedy ids ref={ids_ref} got={ids_got}")
+        # compare step logits up to the first divergence (after one, the two runs are fed different tokens)
+        n_same = next((i for i, (a, b) in enumerate(zip(ids_ref, ids_got)) if a != b), len(ids_ref))
+        for i in range(min(n_same + 1, len(rows_ref))):
+            assert T.nmse(rows_got[i], rows_ref[i]) <= 1e-3
+        if n_same < len(ids_ref):
+            r = np.sort(rows_ref[n_same])[::-1]
+            dev = float(np.max(np.abs(rows_got[n_same] - rows_ref[n_same])))
+            assert r[0] - r[1] <= 2 * dev, f"greedy ids diverge at step {n_same} with margin {r[0] - r[1]:.3e} > deviation {dev:.3e}"
+    finally:
+        _free(cc, cg, mc, mg)
+
+
 def test_hipgraph_replay_is_bit_identical_to_eager(backend, H, plog):
     hp = preset("test-llama")
     mg = Model(hp, 99, backend.buft)

@@ -467,6 +467,67 @@ def test_flash_attn(backend, H, plog, HD, NH, NKV, nq, nkv, splits, softcap, ali
     assert e_gpu <= (1e-9 if nq < 32 or softcap else 3e-7) and e_gpu <= e_cpu * 1.01 + 1e-12
 
 
+# quantised KV cache (-ctk q8_0 -ctv q8_0): SET_ROWS quantises f32 rows into block_q8_0, FLASH_ATTN_EXT reads the blocks
+FA_Q8_CASES = [  # (NH, NKV, n_q, n_kv, splits, sinks)
+    (32, 8, 1, 256, 0, False),
+    (32, 8, 1, 2048, 0, False),
+    (32, 8, 1, 1000, 3, True),
+    (28, 4, 1, 1024, 0, False),
+    (28, 4, 2, 700, 5, False),
+    (16, 2, 1, 768, 0, True),
+    (16, 2, 4, 300, 1, False),
+    (8, 4, 3, 512, 2, False),
+    (32, 8, 40, 512, 0, False),   # a prompt batch: per-token lane-parallel passes (no matrix-core kernel for quantised K/V yet)
+]
+
+
+@pytest.mark.parametrize("NH,NKV,nq,nkv,splits,sinks", FA_Q8_CASES)
+def test_flash_attn_q8_0_kv(backend, H, plog, NH, NKV, nq, nkv, splits, sinks):
+    HD = 128
+    rng = np.random.default_rng(NH * 3 + nkv + nq)
+    NCTX = nkv + 64
+    q = rng.standard_normal((NH, nq, HD)).astype(np.float32)
+    kf = (rng.standard_normal((nkv, NKV * HD)) * rng.uniform(0.3, 2.0, (nkv, 1))).astype(np.float32)
+    vf = (rng.standard_normal((nkv, NKV * HD)) * rng.uniform(0.3, 2.0, (nkv, 1))).astype(np.float32)
+    kf[3, :64] = 0.0  # all-zero blocks: d = 0
+    rows = rng.permutation(NCTX)[:nkv].astype(np.int64)
+    rows.sort()
+    rows[: nkv] = np.arange(nkv)  # the view reads cells [0, nkv)
+    MR = (nq + 63) // 64 * 64
+    mask = np.full((MR, nkv), -np.inf, np.float16)
+    for t in range(nq):
+        mask[t, : nkv - nq + t + 1 - 9] = 0
+        mask[t, 5] = -np.inf
+    sk = rng.standard_normal(NH).astype(np.float32)
+    rb = NKV * HD // 32 * 34  # bytes per cache row
+    backend.set_option("fa_splits", splits)
+
+    def build(g):
+        tq = g.new(L.F32, [HD, nq, NH], q)
+        k_cache = g.new(L.Q8_0, [NKV * HD, NCTX])
+        v_cache = g.new(L.Q8_0, [NKV * HD, NCTX])
+        idx = g.new(L.I64, [nkv], rows)
+        ks = H.ggml_set_rows(g.ctx, k_cache, g.new(L.F32, [NKV * HD, nkv], kf), idx)
+        vs = H.ggml_set_rows(g.ctx, v_cache, g.new(L.F32, [NKV * HD, nkv], vf), idx)
+        k = H.ggml_view_3d(g.ctx, ks, HD, nkv, NKV, rb, HD // 32 * 34, 0)
+        v = H.ggml_view_3d(g.ctx, vs, HD, nkv, NKV, rb, HD // 32 * 34, 0)
+        r = H.ggml_flash_attn_ext(g.ctx, tq, k, v, g.new(L.F16, [nkv, MR], mask), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(r, 10)
+        if sinks:
+            H.ggml_flash_attn_ext_add_sinks(r, g.new(L.F32, [NH], sk))
+        return [r, ks, vs]
+
+    try:
+        ref, got = both(build, backend)
+    finally:
+        backend.set_option("fa_splits", 0)
+    # the cache contents are integer work: byte-exact (rows [0, nkv) were written, the rest stays zero)
+    for name, i in (("K", 1), ("V", 2)):
+        assert np.array_equal(got[i], ref[i]), f"set_rows -> q8_0 {name} cache differs in {np.count_nonzero(got[i] != ref[i])} bytes"
+    plog(f"  set_rows -> q8_0 cache {NKV * HD}x{nkv}: byte-exact")
+    T.compare(f"flash_attn q8_0 KV H={NH}/{NKV} nq={nq} nkv={nkv} splits={splits} sinks={sinks}", got[0], ref[0], max_nmse=1e-6, log=plog)
+
+
 @pytest.mark.parametrize("HD,NH,NKV,nseq,per_seq", [(128, 32, 8, 32, 64), (128, 8, 2, 12, 100), (128, 28, 4, 5, 300), (128, 16, 2, 48, 48), (64, 8, 2, 16, 64)])
 def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq, per_seq):
     """-np style decode batch: token i belongs to sequence i and sees only that sequence's cells of the unified cache (a block-diagonal
@@ -495,7 +556,8 @@ def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq
 
 # ------------------------------------------------------------------------------------------------ fused Q/K/V
 @pytest.mark.parametrize("tq,tv,bias", [(L.Q4_K, L.Q4_K, False), (L.Q4_K, L.Q6_K, False), (L.Q5_K, L.Q6_K, True), (L.Q6_K, L.Q6_K, True), (L.Q4_K, L.Q5_K, False), (L.Q8_0, L.Q8_0, False), (L.Q8_0, L.Q8_0, True)])
-def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias):
+@pytest.mark.parametrize("kvt", [L.F16, L.Q8_0])
+def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias, kvt):
     """One decode token through norm -> {wq, wk, wv} -> (+bias) -> rope(q, k) -> KV-cache store, the node pattern of
     llama_lite / llm_build_llama.  wq/wk in one K-quant format and wv in another take ONE launch (qkv.hip gives each
     format its own workgroups); result must equal the oracle and the unfused execution."""
@@ -505,8 +567,20 @@ def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias):
     nw = rng.uniform(0.5, 1.5, E).astype(np.float32)
     wq, wk, wv = T.rand_weight(tq, E, NH * HD, rng), T.rand_weight(tq, E, NKV * HD, rng), T.rand_weight(tv, E, NKV * HD, rng)
     bq, bk, bv = (rng.standard_normal(n).astype(np.float32) for n in (NH * HD, NKV * HD, NKV * HD))
-    kc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
-    vc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    if kvt == L.F16:
+        kc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+        vc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    else:  # quantised KV cache: the launch assembles block_q8_0 rows (16 row pairs of a workgroup = one block)
+        kc0 = T.rand_weight(L.Q8_0, NKV * HD, NCTX, rng)
+        vc0 = T.rand_weight(L.Q8_0, NKV * HD, NCTX, rng)
+
+    def deq(t):
+        if kvt == L.F16:
+            return np.asarray(t).astype(np.float32)
+        if np.asarray(t).dtype != np.uint8:
+            return np.asarray(t).astype(np.float32)
+        blk = np.asarray(t).reshape(-1, 34)
+        return blk[:, :2].copy().view(np.float16).astype(np.float32) * blk[:, 2:].copy().view(np.int8).astype(np.float32)
 
     def build(g):
         cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, g.new(L.F32, [E, 1], x), 1e-5), g.new(L.F32, [E], nw))
@@ -522,8 +596,8 @@ def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias):
         q = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, q, HD, NH, 1), tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
         k = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, k, HD, NKV, 1), tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
         v = H.ggml_reshape_3d(g.ctx, v, HD, NKV, 1)
-        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], kc0), H.ggml_reshape_2d(g.ctx, k, NKV * HD, 1), idx)
-        vs = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], vc0), H.ggml_reshape_2d(g.ctx, v, NKV * HD, 1), idx)
+        ks = H.ggml_set_rows(g.ctx, g.new(kvt, [NKV * HD, NCTX], kc0), H.ggml_reshape_2d(g.ctx, k, NKV * HD, 1), idx)
+        vs = H.ggml_set_rows(g.ctx, g.new(kvt, [NKV * HD, NCTX], vc0), H.ggml_reshape_2d(g.ctx, v, NKV * HD, 1), idx)
         return [q, ks, vs]
 
     ref = T.run_case(build, "oracle")
@@ -535,12 +609,17 @@ def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias):
         plain = T.run_case(build, backend)
     finally:
         backend.set_option("fusion", 1)
-    plog(f"    fused qkv {QNAME[tq]}/{QNAME[tv]} bias={bias}: {launches} kernel launch(es)")
+    plog(f"    fused qkv {QNAME[tq]}/{QNAME[tv]} bias={bias} cache={QNAME[kvt]}: {launches} kernel launch(es)")
     assert launches == 1, launches
+    # (a Q8_0 cache row: one rounding flip of a code is 1/127 of the block's range, hence the looser bound against the oracle;
+    # fused and unfused GPU paths do the same arithmetic and must agree byte for byte)
+    tol_cache = 1e-6 if kvt == L.F16 else 1e-4
     for name, a, b, c in zip(("q_rope", "k_cache", "v_cache"), got, ref, plain):
-        a32, b32, c32 = (np.asarray(t).astype(np.float32) for t in (a, b, c))
-        T.compare(f"fused qkv {QNAME[tq]}/{QNAME[tv]} {name}", a32, b32, max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
-        T.compare(f"fused qkv {QNAME[tq]}/{QNAME[tv]} {name} vs unfused", a32, c32, max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
+        a32, b32, c32 = deq(a), deq(b), deq(c)
+        T.compare(f"fused qkv {QNAME[tq]}/{QNAME[tv]} {name}", a32, b32, max_nmse=tol_cache if name != "q_rope" else 1e-10, log=plog)
+        T.compare(f"fused qkv {QNAME[tq]}/{QNAME[tv]} {name} vs unfused", a32, c32, max_nmse=tol_cache if name != "q_rope" else 1e-10, log=plog)
+        if kvt == L.Q8_0 and name != "q_rope":
+            assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused q8_0 cache rows differ"
 
 
 # ------------------------------------------------------------------------------------------------ fused chains
