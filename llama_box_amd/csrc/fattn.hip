@@ -601,9 +601,34 @@ int fattn_pick_splits(const tdesc & q, const tdesc & k) {
     want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(max_by_len, 64)));
     return (int) want;
 }
-size_t fattn_workspace_bytes(const tdesc & q, const tdesc & v, int n_splits) {
+static size_t fattn_partials_bytes(const tdesc & q, const tdesc & v, int n_splits) {
     if (n_splits <= 1) return 0;
-    return (size_t) (q.ne[1] * q.ne[3] * q.ne[2]) * (size_t) n_splits * (size_t) (v.ne[0] + 2) * sizeof(float);
+    return ((size_t) (q.ne[1] * q.ne[3] * q.ne[2]) * (size_t) n_splits * (size_t) (v.ne[0] + 2) * sizeof(float) + 255) & ~(size_t) 255;
+}
+// prompt batches over a block_q8_0 cache run the matrix-core kernel on an f16 image of the K and V views (below)
+static bool fattn_q8_via_f16(const tdesc & q, int kv_type) { return kv_type == GGML_TYPE_Q8_0 && q.ne[1] >= 32; }
+size_t fattn_workspace_bytes(const tdesc & q, const tdesc & k, const tdesc & v, int n_splits, int kv_type) {
+    size_t b = fattn_partials_bytes(q, v, n_splits);
+    if (fattn_q8_via_f16(q, kv_type)) b += 2 * (size_t) (k.ne[0] * k.ne[1] * k.ne[2] * k.ne[3]) * sizeof(uint16_t) + 512;
+    return b;
+}
+
+// block_q8_0 K / V views [D, n_kv, n_kv_head] -> f16 rows [n_kv][n_kv_head * D]: one workgroup per cache cell and tensor,
+// a thread per 4 values (d * q is exact in f32; one rounding to f16)
+__global__ void __launch_bounds__(256) k_q8_0_rows_to_f16(const tdesc k, const tdesc v, uint16_t * __restrict__ ko, uint16_t * __restrict__ vo) {
+    const tdesc & t = blockIdx.y ? v : k;
+    uint16_t * out = blockIdx.y ? vo : ko;
+    const int64_t cell = blockIdx.x, per_head = t.ne[0] / 4, per_row = per_head * t.ne[2];
+    for (int64_t i = threadIdx.x; i < per_row; i += blockDim.x) {
+        const int64_t h = i / per_head, e = (i - h * per_head) * 4;
+        const char * blk = t.data + cell * t.nb[1] + h * t.nb[2] + (e >> 5) * 34;
+        const float d = h2f(ld16(blk));
+        const uint32_t qs = ld32_a2(blk + 2 + (e & 31));
+        uint16_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2h(d * (float) (int8_t) (qs >> (8 * j)));
+        *(uint2 *) (out + (cell * t.ne[2] + h) * t.ne[0] + e) = make_uint2(o[0] | ((uint32_t) o[1] << 16), o[2] | ((uint32_t) o[3] << 16));
+    }
 }
 
 template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc & mask, const float * sinks,
@@ -620,6 +645,28 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
                        const fattn_params & p, void * workspace) {
     const bool q8 = p.kv_type == GGML_TYPE_Q8_0;
     if (!q8 && launch_flash_attn_mma(s, q, k, v, mask, sinks, dst, p, workspace)) return;
+    if (fattn_q8_via_f16(q, p.kv_type) && k.ne[3] == 1 && v.ne[3] == 1 && flash_attn_mma_applies(q, k, mask, sinks, dst, p)) {
+        // a prompt batch over the quantised cache: the CPU quantises each query row to Q8_0 and takes integer block dots; here
+        // the cells are expanded to f16 once (exact up to the f16 rounding of d * q) and the f16 matrix-core kernel runs on
+        // that image with the queries in f16 — closer to exact attention than the CPU's 8-bit queries (tests pin that)
+        uint16_t * kf = (uint16_t *) ((char *) workspace + fattn_partials_bytes(q, v, p.n_splits));
+        uint16_t * vf = kf + (((size_t) (k.ne[0] * k.ne[1] * k.ne[2]) + 127) & ~(size_t) 127);
+        hipLaunchKernelGGL(k_q8_0_rows_to_f16, dim3((unsigned) k.ne[1], 2), dim3(256), 0, s, k, v, kf, vf);
+        tdesc k16 = k, v16 = v;
+        k16.data = (char *) kf;
+        v16.data = (char *) vf;
+        for (tdesc * t : {&k16, &v16}) {
+            t->nb[0] = 2;
+            t->nb[2] = t->ne[0] * 2;
+            t->nb[1] = t->ne[2] * t->nb[2];
+            t->nb[3] = t->ne[1] * t->nb[1];
+        }
+        fattn_params p16 = p;
+        p16.kv_type = GGML_TYPE_F16;
+        if (launch_flash_attn_mma(s, q, k16, v16, mask, sinks, dst, p16, workspace)) return;
+        MI_ERR("launch_flash_attn: the matrix-core kernel refused a batch flash_attn_mma_applies accepted");
+        abort();
+    }
     fa_geom geo;
     geo.n_q = (int) q.ne[1];
     geo.n_head = (int) q.ne[2];

@@ -218,12 +218,17 @@ int fattn_mma_pick_splits(const tdesc & q, const tdesc & k) {
     want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, tiles / 4)));
     return (int) want;
 }
-bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
-                           const fattn_params & p, void * workspace) {
+bool flash_attn_mma_applies(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p) {
     const int D = (int) k.ne[0];
     if (q.ne[1] < 32 || sinks != nullptr || p.max_bias != 0.0f || p.logit_softcap != 0.0f || (D != 64 && D != 128)) return false;
     if ((k.ne[1] % 4) != 0 || (q.nb[1] % 16) || (q.nb[2] % 16) || (((uintptr_t) q.data) & 15) || (dst.nb[1] % 16) || (dst.nb[2] % 16) || (((uintptr_t) dst.data) & 15)) return false;
     if (mask && ((mask->nb[1] % 8) || (((uintptr_t) mask->data) & 7))) return false;
+    return true;
+}
+bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
+                           const fattn_params & p, void * workspace) {
+    const int D = (int) k.ne[0];
+    if (!flash_attn_mma_applies(q, k, mask, sinks, dst, p)) return false;
     fam_geom geo;
     geo.n_q = (int) q.ne[1];
     geo.n_head = (int) q.ne[2];

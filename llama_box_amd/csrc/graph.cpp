@@ -140,7 +140,7 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
             const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k));
-            p.aux_bytes = std::max(p.aux_bytes, fattn_workspace_bytes(q, v, ns));
+            p.aux_bytes = std::max(p.aux_bytes, fattn_workspace_bytes(q, k, v, ns, n->src[1]->type));
         }
     }
     p.act_bytes = (p.act_bytes + 255) & ~(size_t) 255;

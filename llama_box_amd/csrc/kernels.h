@@ -137,7 +137,8 @@ struct fattn_params {
     int n_splits;  // KV splits per (token, kv-head group)
     int kv_type;   // GGML_TYPE_F16 or GGML_TYPE_Q8_0 (K and V alike)
 };
-size_t fattn_workspace_bytes(const tdesc & q, const tdesc & v, int n_splits);
+size_t fattn_workspace_bytes(const tdesc & q, const tdesc & k, const tdesc & v, int n_splits, int kv_type);
+bool flash_attn_mma_applies(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);
 int fattn_pick_splits(const tdesc & q, const tdesc & k);
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks,
                        const tdesc & dst, const fattn_params & p, void * workspace);
