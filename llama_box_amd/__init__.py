@@ -109,6 +109,7 @@ _SIGS = {
     "ggml_silu": (TP, [_P, TP]), "ggml_unary": (TP, [_P, TP, _I]), "ggml_swiglu": (TP, [_P, TP]), "ggml_swiglu_split": (TP, [_P, TP, TP]),
     "ggml_soft_max": (TP, [_P, TP]), "ggml_soft_max_ext": (TP, [_P, TP, TP, _F, _F]), "ggml_soft_max_add_sinks": (None, [TP, TP]),
     "ggml_rope_ext": (TP, [_P, TP, TP, TP, _I, _I, _I, _F, _F, _F, _F, _F, _F]),
+    "ggml_rope_ext_inplace": (TP, [_P, TP, TP, TP, _I, _I, _I, _F, _F, _F, _F, _F, _F]),
     "ggml_flash_attn_ext": (TP, [_P, TP, TP, TP, TP, _F, _F, _F]), "ggml_flash_attn_ext_set_prec": (None, [TP, _I]),
     "ggml_flash_attn_ext_add_sinks": (None, [TP, TP]), "ggml_argmax": (TP, [_P, TP]),
     "ggml_new_graph": (C.POINTER(CGraph), [_P]), "ggml_new_graph_custom": (C.POINTER(CGraph), [_P, _SZ, _B]),
@@ -142,7 +143,7 @@ _SIGS = {
     "llm_decode": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int8)]),
     "llm_decode_steps": (_I, [_P, _I, _I, C.POINTER(C.c_int32), _I]),
     "llm_n_outputs": (_I, [_P]), "llm_get_logits": (C.POINTER(C.c_float), [_P]), "llm_get_logits_ith": (C.POINTER(C.c_float), [_P, _I]),
-    "llm_kv_clear": (None, [_P]), "llm_kv_seq_rm": (_I, [_P, _I, _I, _I]), "llm_last_graph": (C.POINTER(CGraph), [_P]),
+    "llm_kv_clear": (None, [_P]), "llm_kv_seq_rm": (_I, [_P, _I, _I, _I]), "llm_kv_seq_add": (_I, [_P, _I, _I, _I, _I]), "llm_last_graph": (C.POINTER(CGraph), [_P]),
     "llm_last_timings": (None, [_P, C.POINTER(C.c_double)]),
 }
 

@@ -57,6 +57,8 @@ bool supports_op(const ggml_tensor * op) {
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
             const int st = a->type, dt = op->type;
             if (st == GGML_TYPE_I32 && dt == GGML_TYPE_I32) return true;
+            if ((st == GGML_TYPE_Q8_0 && dt == GGML_TYPE_F32) || (st == GGML_TYPE_F32 && dt == GGML_TYPE_Q8_0))  // K-shift of a quantised cache
+                return ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(op) && (a->ne[0] % 32) == 0;
             return (st == GGML_TYPE_F32 || st == GGML_TYPE_F16) && (dt == GGML_TYPE_F32 || dt == GGML_TYPE_F16);
         }
         case GGML_OP_GET_ROWS:
@@ -739,6 +741,9 @@ static int run_node(exec_state & st, int i) {
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
             if (a->type == n->type && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(n)) {
                 if (hipMemcpyAsync(n->data, a->data, ggml_abi_nbytes(a), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+            } else if (a->type == GGML_TYPE_Q8_0 || n->type == GGML_TYPE_Q8_0) {
+                timed_scope ts(c, "cpy_q8_0", (double) ggml_abi_nbytes(n) + (double) ggml_abi_nbytes(a));
+                launch_cpy_q8_0(s, a->data, n->data, ggml_abi_nelements(a), n->type == GGML_TYPE_Q8_0);
             } else {
                 timed_scope ts(c, "cpy", (double) ggml_abi_nbytes(n) * 2);
                 launch_cpy(s, TD(a), TD(n));

@@ -493,6 +493,44 @@ void launch_set_rows_q8_0(hipStream_t s, const tdesc & a, const tdesc & idx, con
     hipLaunchKernelGGL(k_set_rows_q8_0, dim3((unsigned) blocks), dim3(64), 0, s, a, idx, d);
 }
 
+// ---- CPY between a contiguous Q8_0 tensor and a contiguous F32 tensor: the K-shift of a quantised cache
+// (llama.cpp build_rope_shift: cast K to f32, rope, cpy back).  Same 8-lanes-per-block layout as k_set_rows_q8_0.
+__global__ void __launch_bounds__(256) k_cpy_q8_0_f32(const char * __restrict__ src, float * __restrict__ dst, const int64_t n4) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;  // 4 values each
+    if (i >= n4) return;
+    const char * blk = src + (i >> 3) * 34;
+    const float d = h2f(ld16(blk));
+    const uint32_t qs = ld32_a2(blk + 2 + 4 * (i & 7));
+    ((float4 *) dst)[i] = make_float4(d * (float) (int8_t) qs, d * (float) (int8_t) (qs >> 8), d * (float) (int8_t) (qs >> 16), d * (float) (int8_t) (qs >> 24));
+}
+__global__ void __launch_bounds__(256) k_cpy_f32_q8_0(const float * __restrict__ src, char * __restrict__ dst, const int64_t n4) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n4;  // n4 is a multiple of 8 (whole blocks), so the 8 lanes of a block are live together
+    const float4 x = live ? ((const float4 *) src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float v[4] = {x.x, x.y, x.z, x.w};
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_QUAD_XOR1>(amax));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_QUAD_XOR2>(amax));
+    amax = fmaxf(amax, dpp_f32<MI_DPP_HALF_MIRROR>(amax));
+    const float dd = amax / 127.0f;
+    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) packed |= (uint32_t) ((int) roundf(v[k] * id) & 0xFF) << (8 * k);
+    if (!live) return;
+    char * blk = dst + (i >> 3) * 34;
+    uint16_t * qs = (uint16_t *) (blk + 2 + 4 * (i & 7));
+    qs[0] = (uint16_t) (packed & 0xFFFF);
+    qs[1] = (uint16_t) (packed >> 16);
+    if ((i & 7) == 0) *(uint16_t *) blk = f2h(dd);
+}
+void launch_cpy_q8_0(hipStream_t s, const void * src, void * dst, int64_t n, bool to_q8) {
+    const int64_t n4 = n / 4;
+    const unsigned grid = (unsigned) ((n4 + 255) / 256);
+    if (to_q8) hipLaunchKernelGGL(k_cpy_f32_q8_0, dim3(grid), dim3(256), 0, s, (const float *) src, (char *) dst, n4);
+    else hipLaunchKernelGGL(k_cpy_q8_0_f32, dim3(grid), dim3(256), 0, s, (const char *) src, (float *) dst, n4);
+}
+
 // ---- small upload: copies `n` bytes from pinned host memory (device-visible) into device memory inside the stream
 __global__ void __launch_bounds__(256) k_upload_small(char * __restrict__ dst, const char * __restrict__ src, const size_t n, const int vec) {
     const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;

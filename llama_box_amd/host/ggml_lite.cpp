@@ -425,12 +425,12 @@ void ggml_soft_max_add_sinks(struct ggml_tensor * a, struct ggml_tensor * sinks)
     a->src[2] = sinks;
 }
 
-struct ggml_tensor * ggml_rope_ext(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c, int n_dims,
-                                   int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor,
-                                   float beta_fast, float beta_slow) {
+static struct ggml_tensor * rope_impl(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c, int n_dims,
+                                      int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor,
+                                      float beta_fast, float beta_slow, bool inplace) {
     LITE_ASSERT(b->type == GGML_TYPE_I32 && a->ne[2] == b->ne[0]);
     if (c) LITE_ASSERT(c->type == GGML_TYPE_F32 && c->ne[0] >= n_dims / 2);
-    ggml_tensor * r = dup_tensor(ctx, a);
+    ggml_tensor * r = inplace ? view_tensor(ctx, a) : dup_tensor(ctx, a);
     int32_t params[15] = {/*n_past*/ 0, n_dims, mode, /*n_ctx*/ 0, n_ctx_orig};
     memcpy(params + 5, &freq_base, 4);
     memcpy(params + 6, &freq_scale, 4);
@@ -445,6 +445,16 @@ struct ggml_tensor * ggml_rope_ext(struct ggml_context * ctx, struct ggml_tensor
     r->src[1] = b;
     r->src[2] = c;
     return r;
+}
+struct ggml_tensor * ggml_rope_ext(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c, int n_dims,
+                                   int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor,
+                                   float beta_fast, float beta_slow) {
+    return rope_impl(ctx, a, b, c, n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow, false);
+}
+struct ggml_tensor * ggml_rope_ext_inplace(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c, int n_dims,
+                                           int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor,
+                                           float beta_fast, float beta_slow) {
+    return rope_impl(ctx, a, b, c, n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow, true);
 }
 
 struct ggml_tensor * ggml_flash_attn_ext(struct ggml_context * ctx, struct ggml_tensor * q, struct ggml_tensor * k, struct ggml_tensor * v,

@@ -751,6 +751,63 @@ extern "C" int llm_kv_seq_rm(struct llm_context * c, int seq_id, int p0, int p1)
     return 1;
 }
 
+// K-shift: the graph llama.cpp's llama_kv_cache::build_rope_shift produces after llama_memory_seq_add (llama-box context
+// shift, httpserver.hpp:3453-3537).  Every cell's K row is rotated by the cell's position delta: in place on an f16 cache;
+// on a quantised cache through an f32 copy (cast -> rope -> cpy back, which re-quantises the rows).
+static int kv_apply_shift(llm_context * c, const std::vector<int32_t> & delta) {
+    llm_model * m = c->model;
+    const llm_hparams & hp = m->hp;
+    const int64_t HD = hp.n_embd_head, NKV = m->n_head_kv_l, n_ctx = c->p.n_ctx;
+    if (c->backend && c->in_flight) { ggml_backend_synchronize(c->backend); c->in_flight = 0; }
+    ggml_context * ctx = ggml_init({0, nullptr, true});
+    ggml_cgraph * gf = ggml_new_graph_custom(ctx, 1024, false);
+    ggml_tensor * shift = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_ctx);
+    ggml_set_input(named(shift, "k_shift", -1));
+    for (int il = 0; il < hp.n_layer; ++il) {
+        ggml_tensor * kc = c->k_l[il];
+        ggml_tensor * k = ggml_view_3d(ctx, kc, HD, NKV, n_ctx, ggml_row_size(kc->type, HD), ggml_row_size(kc->type, NKV * HD), 0);
+        ggml_tensor * r;
+        if (kc->type != GGML_TYPE_F16) {
+            ggml_tensor * tmp = ggml_cast(ctx, k, GGML_TYPE_F32);
+            tmp = ggml_rope_ext_inplace(ctx, tmp, shift, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
+            r = ggml_cpy(ctx, tmp, k);
+        } else {
+            r = ggml_rope_ext_inplace(ctx, k, shift, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
+        }
+        ggml_build_forward_expand(gf, named(r, "k_shifted", il));
+    }
+    ggml_gallocr_t ga = ggml_gallocr_new(c->buft);
+    int rc = 0;
+    if (!ga || !ggml_gallocr_alloc_graph(ga, gf)) rc = -2;
+    if (rc == 0) {
+        ggml_backend_tensor_set(shift, delta.data(), 0, (size_t) n_ctx * 4);
+        const enum ggml_status st = c->backend ? ggml_backend_graph_compute(c->backend, gf) : c->compute(gf, c->p.n_threads);
+        if (st != GGML_STATUS_SUCCESS) rc = -2;
+    }
+    if (ga) ggml_gallocr_free(ga);
+    ggml_free(ctx);
+    return rc;
+}
+// llama_memory_seq_add: positions [p0, p1) of a sequence move by `delta`; the cached K rows are re-rotated at once
+// (llama.cpp defers that to the next llama_decode's memory update — same result).  Returns 0, or -2 if the shift graph failed.
+extern "C" int llm_kv_seq_add(struct llm_context * c, int seq_id, int p0, int p1, int delta) {
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = INT32_MAX;
+    if (delta == 0) return 0;
+    std::vector<int32_t> d((size_t) c->p.n_ctx, 0);
+    bool any = false;
+    for (size_t i = 0; i < c->cells.size(); ++i) {
+        kv_cell & x = c->cells[i];
+        if (x.pos >= p0 && x.pos < p1 && (seq_id < 0 || x.seq == seq_id)) {
+            x.pos += delta;
+            d[i] = delta;
+            any = true;
+            if (x.pos < 0) x = kv_cell();  // shifted out of the sequence (llama.cpp frees such cells too)
+        }
+    }
+    return any ? kv_apply_shift(c, d) : 0;
+}
+
 static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const int8_t * want, float * logits_out, int * n_out_acc,
                          bool defer_sync) {
     llm_model * m = c->model;

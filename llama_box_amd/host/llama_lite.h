@@ -82,6 +82,9 @@ float * llm_get_logits(struct llm_context * c);            /* [n_outputs][n_voca
 float * llm_get_logits_ith(struct llm_context * c, int i); /* i-th output row of the last llm_decode */
 void llm_kv_clear(struct llm_context * c);
 int llm_kv_seq_rm(struct llm_context * c, int seq_id, int p0, int p1);
+/* llama_memory_seq_add + the K-shift graph it triggers (context shift, llama-box httpserver.hpp:3453-3537): positions
+   [p0, p1) of seq_id move by delta and the cached K rows are re-rotated by it (quantised caches: through an f32 copy) */
+int llm_kv_seq_add(struct llm_context * c, int seq_id, int p0, int p1, int delta);
 /* the graph of the last micro-batch (for inspection / per-node comparison in tests) */
 struct ggml_cgraph * llm_last_graph(struct llm_context * c);
 /* host-side time split of the last llm_decode, microseconds: [build+alloc, set inputs, compute+sync, get logits] */

@@ -647,6 +647,17 @@ static enum ggml_status op_cpy(struct ggml_tensor * dst) {
         memcpy(dst->data, a->data, ggml_abi_nbytes(a));
         return GGML_STATUS_SUCCESS;
     }
+    /* quantised KV cache, K-shift (llama.cpp build_rope_shift: cast to f32 -> rope -> cpy back): contiguous Q8_0 <-> F32
+       — ggml_compute_forward_dup_from_q dequantises whole rows, ggml_compute_forward_dup_f32 with a contiguous quantised
+       destination runs from_float (quantize_row_q8_0) over rows of ne00 values */
+    if (a->type == GGML_TYPE_Q8_0 && dst->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(dst)) {
+        dequantize_row_q8_0((const block_q8_0 *) TDATA(a), (float *) TDATA(dst), n);
+        return GGML_STATUS_SUCCESS;
+    }
+    if (a->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_Q8_0 && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(dst) && (a->ne[0] % 32) == 0) {
+        oracle_quantize_row_q8_0((const float *) TDATA(a), (block_q8_0 *) TDATA(dst), n);
+        return GGML_STATUS_SUCCESS;
+    }
     const int sf32 = a->type == GGML_TYPE_F32, sf16 = a->type == GGML_TYPE_F16;
     const int df32 = dst->type == GGML_TYPE_F32, df16 = dst->type == GGML_TYPE_F16;
     const int si32 = a->type == GGML_TYPE_I32 && dst->type == GGML_TYPE_I32;

@@ -73,6 +73,13 @@ class Context:
     def clear(self):
         self.H.llm_kv_clear(self.c)
 
+    def seq_rm(self, seq_id, p0, p1):
+        return self.H.llm_kv_seq_rm(self.c, seq_id, p0, p1)
+
+    def seq_add(self, seq_id, p0, p1, delta):
+        """llama_memory_seq_add + K-shift (context shift)."""
+        return self.H.llm_kv_seq_add(self.c, seq_id, p0, p1, delta)
+
     def timings(self):
         out = (C.c_double * 4)()
         self.H.llm_last_timings(self.c, out)

@@ -157,6 +157,35 @@ def test_logits_quantised_kv_cache(backend, H, plog):
         _free(cc, cg, mc, mg)
 
 
+@pytest.mark.parametrize("name,type_k", [("test-llama", 0), ("test-qwen2", 0), ("test-llama", L.Q8_0)])
+def test_context_shift_k_shift(backend, H, plog, name, type_k):
+    """llama-box context shift (httpserver.hpp:3453-3537): seq_rm + seq_add, K rows re-rotated on the device (f16 cache in
+    place; q8_0 cache through cast -> rope -> cpy), then decoding continues at the shifted positions."""
+    over = dict(n_head=2, n_head_kv=1, n_embd_head=128) if type_k else {}
+    hp = preset(name, **over)
+    mc = Model(hp, 1234, H.ggml_backend_cpu_buffer_type())
+    mg = Model(hp, 1234, backend.buft)
+    cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=1, type_k=type_k, type_v=type_k)
+    cg = Context(mg, backend=backend, flash_attn=1, type_k=type_k, type_v=type_k)
+    try:
+        n_keep, n_discard = 4, 6
+        for c in (cc, cg):
+            assert c.decode(PROMPT, range(len(PROMPT)))[0] == 0
+            assert c.seq_rm(0, n_keep, n_keep + n_discard) == 1
+            assert c.seq_add(0, n_keep + n_discard, len(PROMPT), -n_discard) == 0
+        pos = len(PROMPT) - n_discard
+        toks = [11, 200, 45]
+        for i, t in enumerate(toks):
+            rc, ref = cc.decode([t], [pos + i])
+            rc2, got = cg.decode([t], [pos + i])
+            assert rc == 0 and rc2 == 0
+            e = T.nmse(got, ref)
+            plog(f"{name} cache={'q8_0' if type_k else 'f16'} after context shift, step {i}: nmse(gpu, cpu)={e:.3e}")
+            assert e <= 1e-3
+    finally:
+        _free(cc, cg, mc, mg)
+
+
 def test_hipgraph_replay_is_bit_identical_to_eager(backend, H, plog):
     hp = preset("test-llama")
     mg = Model(hp, 99, backend.buft)

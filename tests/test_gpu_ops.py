@@ -291,6 +291,43 @@ def test_set_rows(backend, H, plog):
     T.compare("set_rows element scatter", got[0].view(np.uint16), ref[0].view(np.uint16), max_nmse=0.0, log=plog)
 
 
+def test_cpy_q8_0_f32_roundtrip_for_k_shift(backend, H, plog):
+    """K-shift of a quantised cache (llama.cpp build_rope_shift): cast(q8_0 view -> f32), in-place rope, cpy back (re-quantise)."""
+    rng = np.random.default_rng(21)
+    HD, NKV, NCTX = 128, 2, 40
+    kc = T.rand_weight(L.Q8_0, NKV * HD, NCTX, rng)
+    shift = rng.integers(-9, 3, NCTX).astype(np.int32)
+    shift[::3] = 0
+
+    def build(g):
+        cache = g.new(L.Q8_0, [NKV * HD, NCTX], kc)
+        k = H.ggml_view_3d(g.ctx, cache, HD, NKV, NCTX, HD // 32 * 34, NKV * HD // 32 * 34, 0)
+        f = H.ggml_cast(g.ctx, k, L.F32)
+        r = H.ggml_rope_ext_inplace(g.ctx, f, g.new(L.I32, [NCTX], shift), None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        return [H.ggml_cpy(g.ctx, r, k)]
+
+    def build_cast_only(g):
+        cache = g.new(L.Q8_0, [NKV * HD, NCTX], kc)
+        k = H.ggml_view_3d(g.ctx, cache, HD, NKV, NCTX, HD // 32 * 34, NKV * HD // 32 * 34, 0)
+        return [H.ggml_cast(g.ctx, k, L.F32)]
+
+    ref, got = both(build_cast_only, backend)
+    T.compare("cpy q8_0 -> f32", got[0].view(np.uint32), ref[0].view(np.uint32), max_nmse=0.0, log=plog)
+    ref, got = both(build, backend)
+
+    def deq(raw):
+        blk = np.asarray(raw).reshape(-1, 34)
+        return blk[:, :2].copy().view(np.float16).astype(np.float32) * blk[:, 2:].copy().view(np.int8).astype(np.float32)
+    same = np.count_nonzero(np.asarray(got[0]) == np.asarray(ref[0]))
+    plog(f"  q8_0 K-shift round trip: {same}/{np.asarray(ref[0]).size} bytes equal")
+    # sin/cos differ from libm in the last bit here and there: a re-quantised code may then flip by one
+    T.compare("cpy q8_0 -> f32 -> rope -> q8_0", deq(got[0]), deq(ref[0]), max_nmse=1e-5, log=plog)
+    assert same >= 0.995 * np.asarray(ref[0]).size
+    # cells with a zero shift are rotated by the identity and re-quantise to themselves
+    rows0 = np.asarray(got[0]).reshape(NCTX, -1)[shift == 0]
+    assert np.array_equal(rows0, np.asarray(kc).reshape(NCTX, -1)[shift == 0])
+
+
 def test_argmax(backend, H, plog):
     rng = np.random.default_rng(16)
     x = rng.standard_normal((5, 128256)).astype(np.float32)

@@ -179,6 +179,46 @@ def test_driver_on_oracle_determinism_reuse_and_batching(H):
         m.free()
 
 
+@pytest.mark.parametrize("name,type_k", [("test-llama", 0), ("test-qwen2", 0), ("test-llama", L.Q8_0)])
+def test_context_shift_k_shift_oracle(H, name, type_k):
+    """llama-box context shift (httpserver.hpp:3453-3537): seq_rm of [n_keep, n_keep + n_discard) + seq_add of the rest by
+    -n_discard re-rotates the cached K rows.  In a ONE-layer model a K row depends only on its own token and position, so the
+    shifted cache must equal a fresh prefill of the shortened sequence (up to the extra f16 / q8_0 rounding of the stored
+    rows) — that pins direction and magnitude of the shift on the oracle; the GPU is then compared with the oracle."""
+    over = dict(n_layer=1)
+    if type_k:
+        over.update(n_head=2, n_head_kv=1, n_embd_head=128)
+    hp = preset(name, **over)
+    m = Model(hp, 77, H.ggml_backend_cpu_buffer_type())
+    fn = T.oracle_compute_fn()
+    try:
+        prompt = [3, 9, 27, 81, 243, 217, 139, 411, 210, 118, 354, 40, 120, 360, 58, 174]
+        n_keep, n_discard = 3, 5
+        a = Context(m, compute=fn, flash_attn=1, type_k=type_k, type_v=type_k)
+        assert a.decode(prompt, range(len(prompt)))[0] == 0
+        assert a.seq_rm(0, n_keep, n_keep + n_discard) == 1
+        assert a.seq_add(0, n_keep + n_discard, len(prompt), -n_discard) == 0
+        rc, la = a.decode([11], [len(prompt) - n_discard])
+        assert rc == 0
+        b = Context(m, compute=fn, flash_attn=1, type_k=type_k, type_v=type_k)
+        short = prompt[:n_keep] + prompt[n_keep + n_discard:]
+        assert b.decode(short, range(len(short)))[0] == 0
+        rc, lb = b.decode([11], [len(short)])
+        assert rc == 0
+        # and the unshifted cache (positions left as they were) must NOT agree: the shift did something
+        c = Context(m, compute=fn, flash_attn=1, type_k=type_k, type_v=type_k)
+        assert c.decode(prompt, range(len(prompt)))[0] == 0
+        c.seq_rm(0, n_keep, n_keep + n_discard)
+        rc, lc = c.decode([11], [len(prompt)])
+        e_shift, e_noshift = T.nmse(la, lb), T.nmse(lc, lb)
+        assert e_shift <= (1e-5 if not type_k else 2e-3), e_shift
+        assert e_noshift > 20 * e_shift
+        for x in (a, b, c):
+            x.free()
+    finally:
+        m.free()
+
+
 def test_stream_bytes_matches_survey_for_llama3_8b(H):
     """Llama-3-8B Q4_K_M streams 4 617 398 528 B per decoded token (weights + norms + 1 embd row)."""
     hp = preset("llama3-8b-q4_k_m")
