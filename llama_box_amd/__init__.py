@@ -26,6 +26,8 @@ TYPE_BLCK = {F32: 1, F16: 1, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 25
 TYPE_SIZE = {F32: 4, F16: 2, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, I32: 4, I64: 8}
 GGML_MAX_NAME = 128
 ROPE_NEOX = 2
+ROPE_MROPE = 8    # ggml_rope_multi: four position streams over sections of the rotation pairs (Qwen2-VL)
+ROPE_VISION = 24  # mrope with independent sections, pairs (i, i + n_dims) over the whole row (vision towers)
 
 
 def build(verbose=False):
@@ -109,6 +111,7 @@ _SIGS = {
     "ggml_silu": (TP, [_P, TP]), "ggml_unary": (TP, [_P, TP, _I]), "ggml_swiglu": (TP, [_P, TP]), "ggml_swiglu_split": (TP, [_P, TP, TP]),
     "ggml_soft_max": (TP, [_P, TP]), "ggml_soft_max_ext": (TP, [_P, TP, TP, _F, _F]), "ggml_soft_max_add_sinks": (None, [TP, TP]),
     "ggml_rope_ext": (TP, [_P, TP, TP, TP, _I, _I, _I, _F, _F, _F, _F, _F, _F]),
+    "ggml_rope_multi": (TP, [_P, TP, TP, TP, _I, C.POINTER(C.c_int), _I, _I, _F, _F, _F, _F, _F, _F]),
     "ggml_rope_ext_inplace": (TP, [_P, TP, TP, TP, _I, _I, _I, _F, _F, _F, _F, _F, _F]),
     "ggml_flash_attn_ext": (TP, [_P, TP, TP, TP, TP, _F, _F, _F]), "ggml_flash_attn_ext_set_prec": (None, [TP, _I]),
     "ggml_flash_attn_ext_add_sinks": (None, [TP, TP]), "ggml_argmax": (TP, [_P, TP]),

@@ -153,9 +153,8 @@ template <typename Q8K> __device__ __forceinline__ void wave_quantize_q8_K(const
 struct rope_consts {
     float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
 };
-__device__ __forceinline__ void rope_cos_sin(const int ip, const float pos_f, const float * __restrict__ ff, const rope_consts rc, float & cs, float & sn) {
-    float theta = pos_f;
-    for (int k = 0; k < ip; ++k) theta *= rc.theta_scale;
+// rope_yarn for pair ip at angle theta
+__device__ __forceinline__ void rope_yarn_dev(const float theta, const int ip, const float * __restrict__ ff, const rope_consts rc, float & cs, float & sn) {
     const float fq = ff ? ff[ip] : 1.0f;
     const float theta_extrap = theta / fq;
     const float theta_interp = rc.freq_scale * theta_extrap;
@@ -168,6 +167,11 @@ __device__ __forceinline__ void rope_cos_sin(const int ip, const float pos_f, co
     }
     cs = cosf(th) * mscale;
     sn = sinf(th) * mscale;
+}
+__device__ __forceinline__ void rope_cos_sin(const int ip, const float pos_f, const float * __restrict__ ff, const rope_consts rc, float & cs, float & sn) {
+    float theta = pos_f;
+    for (int k = 0; k < ip; ++k) theta *= rc.theta_scale;
+    rope_yarn_dev(theta, ip, ff, rc, cs, sn);
 }
 
 }  // namespace mi355x

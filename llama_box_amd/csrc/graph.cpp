@@ -72,7 +72,16 @@ bool supports_op(const ggml_tensor * op) {
             return is_f32_contig(a) && is_f32_contig(op) && (!b || ((b->type == GGML_TYPE_F16 || b->type == GGML_TYPE_F32) && rows_contig(b)));
         case GGML_OP_ROPE: {
             const int mode = op->op_params[2];
-            if (mode & GGML_ROPE_TYPE_MROPE) return false;  // mrope/vision (mrope.patch) are served by the CPU backend
+            if (mode & GGML_ROPE_TYPE_MROPE) {
+                // ggml_rope_multi (Qwen2-VL sections, vision towers).  llama-box removes upstream's "some section > 0" assertion
+                // (mrope.patch:5-26); with all sections zero the reference loop divides by zero, so that case is refused
+                const int32_t * sec = op->op_params + 11;
+                const int64_t sect_dims = (int64_t) sec[0] + sec[1] + sec[2] + sec[3];
+                if (sec[0] < 0 || sec[1] < 0 || sec[2] < 0 || sec[3] < 0 || sect_dims <= 0 || sect_dims > a->ne[0]) return false;
+                if (!ggml_abi_is_contiguous(b) || ggml_abi_nelements(b) < 4 * a->ne[2]) return false;
+                if (mode == GGML_ROPE_TYPE_VISION && op->op_params[1] != a->ne[0] / 2) return false;
+                if (mode != GGML_ROPE_TYPE_VISION && op->op_params[1] > a->ne[0]) return false;
+            }
             return (a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16) && a->type == op->type && rows_contig(a) && rows_contig(op) && b->type == GGML_TYPE_I32;
         }
         case GGML_OP_FLASH_ATTN_EXT: {
@@ -782,6 +791,7 @@ static int run_node(exec_state & st, int i) {
             p.attn_factor = ggml_abi_op_param_f32(n, 8);
             p.beta_fast = ggml_abi_op_param_f32(n, 9);
             p.beta_slow = ggml_abi_op_param_f32(n, 10);
+            memcpy(p.sections, n->op_params + 11, sizeof(p.sections));
             timed_scope ts(c, "rope", (double) ggml_abi_nbytes(n) * 2);
             launch_rope(s, TD(a), TD(b), n->src[2] ? (const float *) n->src[2]->data : nullptr, TD(n), p);
             c->st.kernel_launches++;

@@ -127,6 +127,7 @@ void launch_upload_small(hipStream_t s, void * dst, const void * pinned_src, siz
 struct rope_params {
     int n_dims, mode, n_ctx_orig;
     float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+    int sections[4];  // ggml_rope_multi (mode & GGML_ROPE_TYPE_MROPE): pairs per position stream (time, height, width, extra)
 };
 void rope_host_consts(const rope_params & p, float & theta_scale, float & corr0, float & corr1);
 void launch_rope(hipStream_t s, const tdesc & src, const tdesc & pos, const float * freq_factors, const tdesc & dst, const rope_params & p);

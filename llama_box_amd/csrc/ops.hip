@@ -394,6 +394,58 @@ template <bool F16IO> __global__ void __launch_bounds__(64) k_rope(const tdesc a
         else ((float *) dst)[i0] = ((const float *) src)[i0];
     }
 }
+// ggml_rope_multi (ggml_mrope_cache_init): four position streams, one per section of the rotation pairs; every stream's angle
+// advances by theta_scale per pair, and in vision mode restarts from its position when its section begins.  A lane replays
+// that recurrence up to its own pair — a few hundred multiplies, and exactly the CPU's chain including its corner cases
+// (empty sections, sections that do not fill a cycle).  Pairs are (ic, ic + n_dims/2), vision: (ic, ic + n_dims) over the row.
+template <bool F16IO> __global__ void __launch_bounds__(64) k_rope_multi(const tdesc a, const int32_t * __restrict__ pos, const float * __restrict__ ff, const tdesc d,
+                                                                     const rope_params p, const float theta_scale, const float corr0, const float corr1) {
+    const int64_t i1 = blockIdx.x, i2 = blockIdx.y, i3 = blockIdx.z, ne2 = a.ne[2];
+    const bool vision = p.mode == GGML_ROPE_TYPE_VISION;
+    const int n_pairs = vision ? (int) (a.ne[0] / 2) : p.n_dims / 2;
+    const int off = vision ? p.n_dims : p.n_dims / 2;
+    const float base_t = (float) pos[i2], base_h = (float) pos[i2 + ne2], base_w = (float) pos[i2 + 2 * ne2], base_e = (float) pos[i2 + 3 * ne2];
+    const int s0 = p.sections[0], sec_w = s0 + p.sections[1], sec_e = sec_w + p.sections[2], sect_dims = sec_e + p.sections[3];
+    const char * __restrict__ src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+    char * __restrict__ dst = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+    for (int ic = threadIdx.x; ic < n_pairs; ic += blockDim.x) {
+        float tt = base_t, th = base_h, tw = base_w, te = base_e, theta = 0.0f;
+        for (int k = 0; k <= ic; ++k) {
+            const int sector = k % sect_dims;
+            if (vision) {
+                if (sector == 0) tt = base_t;
+                else if (sector == s0) th = base_h;
+                else if (sector == sec_w) tw = base_w;
+                else if (sector == sec_e) te = base_e;
+            }
+            if (k == ic) {
+                theta = tt;
+                if (sector >= s0 && sector < sec_w) theta = th;
+                else if (sector >= sec_w && sector < sec_e) theta = tw;
+                else if (sector >= sec_e) theta = te;
+            }
+            tt *= theta_scale; tw *= theta_scale; th *= theta_scale; te *= theta_scale;
+        }
+        float cs, sn;
+        rope_yarn_dev(theta, ic, ff, rope_consts{theta_scale, p.freq_scale, p.ext_factor, p.attn_factor, corr0, corr1}, cs, sn);
+        float x0, x1;
+        if (F16IO) { x0 = h2f(((const uint16_t *) src)[ic]); x1 = h2f(((const uint16_t *) src)[ic + off]); }
+        else { x0 = ((const float *) src)[ic]; x1 = ((const float *) src)[ic + off]; }
+        if (F16IO) {
+            ((uint16_t *) dst)[ic] = f2h(x0 * cs - x1 * sn);
+            ((uint16_t *) dst)[ic + off] = f2h(x0 * sn + x1 * cs);
+        } else {
+            ((float *) dst)[ic] = x0 * cs - x1 * sn;
+            ((float *) dst)[ic + off] = x0 * sn + x1 * cs;
+        }
+    }
+    if (!vision) {
+        for (int64_t i0 = p.n_dims + threadIdx.x; i0 < a.ne[0]; i0 += blockDim.x) {
+            if (F16IO) ((uint16_t *) dst)[i0] = ((const uint16_t *) src)[i0];
+            else ((float *) dst)[i0] = ((const float *) src)[i0];
+        }
+    }
+}
 void rope_host_consts(const rope_params & p, float & theta_scale, float & c0, float & c1) {
     theta_scale = powf(p.freq_base, -2.0f / (float) p.n_dims);
     // ggml_rope_yarn_corr_dims
@@ -405,6 +457,11 @@ void launch_rope(hipStream_t s, const tdesc & a, const tdesc & pos, const float 
     float theta_scale, c0, c1;
     rope_host_consts(p, theta_scale, c0, c1);
     dim3 grid((unsigned) a.ne[1], (unsigned) a.ne[2], (unsigned) a.ne[3]);
+    if (p.mode & GGML_ROPE_TYPE_MROPE) {
+        if (a.type == GGML_TYPE_F16) hipLaunchKernelGGL(k_rope_multi<true>, grid, dim3(64), 0, s, a, (const int32_t *) pos.data, ff, d, p, theta_scale, c0, c1);
+        else hipLaunchKernelGGL(k_rope_multi<false>, grid, dim3(64), 0, s, a, (const int32_t *) pos.data, ff, d, p, theta_scale, c0, c1);
+        return;
+    }
     if (a.type == GGML_TYPE_F16) hipLaunchKernelGGL(k_rope<true>, grid, dim3(64), 0, s, a, pos, ff, d, p, theta_scale, c0, c1);
     else hipLaunchKernelGGL(k_rope<false>, grid, dim3(64), 0, s, a, pos, ff, d, p, theta_scale, c0, c1);
 }

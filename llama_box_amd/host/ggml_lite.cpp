@@ -446,6 +446,28 @@ static struct ggml_tensor * rope_impl(struct ggml_context * ctx, struct ggml_ten
     r->src[2] = c;
     return r;
 }
+struct ggml_tensor * ggml_rope_multi(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c, int n_dims,
+                                     int sections[4], int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor,
+                                     float attn_factor, float beta_fast, float beta_slow) {
+    // multimodal rotary embedding: four position ids per token (b is [4 * n_tokens]), sections = pairs per stream
+    LITE_ASSERT((mode & 1) == 0 && b->type == GGML_TYPE_I32 && a->ne[2] * 4 == b->ne[0]);
+    if (c) LITE_ASSERT(c->type == GGML_TYPE_F32 && c->ne[0] >= n_dims / 2);
+    ggml_tensor * r = dup_tensor(ctx, a);
+    int32_t params[15] = {/*n_past*/ 0, n_dims, mode, /*n_ctx*/ 0, n_ctx_orig};
+    memcpy(params + 5, &freq_base, 4);
+    memcpy(params + 6, &freq_scale, 4);
+    memcpy(params + 7, &ext_factor, 4);
+    memcpy(params + 8, &attn_factor, 4);
+    memcpy(params + 9, &beta_fast, 4);
+    memcpy(params + 10, &beta_slow, 4);
+    memcpy(params + 11, sections, 16);
+    memcpy(r->op_params, params, sizeof(params));
+    r->op = GGML_OP_ROPE;
+    r->src[0] = a;
+    r->src[1] = b;
+    r->src[2] = c;
+    return r;
+}
 struct ggml_tensor * ggml_rope_ext(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c, int n_dims,
                                    int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor,
                                    float beta_fast, float beta_slow) {

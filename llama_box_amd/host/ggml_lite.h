@@ -92,6 +92,9 @@ void ggml_soft_max_add_sinks(struct ggml_tensor * a, struct ggml_tensor * sinks)
 struct ggml_tensor * ggml_rope_ext(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c,
                                    int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor,
                                    float attn_factor, float beta_fast, float beta_slow);
+struct ggml_tensor * ggml_rope_multi(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c,
+                                     int n_dims, int sections[4], int mode, int n_ctx_orig, float freq_base, float freq_scale,
+                                     float ext_factor, float attn_factor, float beta_fast, float beta_slow);
 struct ggml_tensor * ggml_rope_ext_inplace(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c,
                                    int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor,
                                    float attn_factor, float beta_fast, float beta_slow);

@@ -766,6 +766,39 @@ static void rope_yarn_corr_dims(int n_dims, int n_ctx_orig, float freq_base, flo
     dims[1] = fminf((float) (n_dims - 1), end);
 }
 
+/* ggml_mrope_cache_init (ggml_rope_multi: Qwen2-VL multimodal sections / vision towers): four position streams
+   (time, height, width, extra), one per `section` of the rotation pairs; all four angles advance by theta_scale every pair;
+   with independent sections (vision mode) an angle restarts from its position when its section begins.
+   llama-box drops the "some section > 0" assertion (mrope.patch:5-26); with all sections zero the upstream loop divides by
+   zero, so that case has no defined result and is refused here (and by the backend's supports_op). */
+static void mrope_cache_init(float theta_base_t, float theta_base_h, float theta_base_w, float theta_base_e, const int sections[4], int indep_sects,
+                             float freq_scale, const float * freq_factors, const float corr_dims[2], int64_t ne0, float ext_factor, float mscale,
+                             float * cache, float theta_scale) {
+    float theta_t = theta_base_t, theta_h = theta_base_h, theta_w = theta_base_w, theta_e = theta_base_e;
+    const int sect_dims = sections[0] + sections[1] + sections[2] + sections[3];
+    const int sec_w = sections[1] + sections[0];
+    const int sec_e = sections[2] + sec_w;
+    for (int64_t i0 = 0; i0 < ne0; i0 += 2) {
+        const float ff = freq_factors ? freq_factors[i0 / 2] : 1.0f;
+        const int sector = (int) ((i0 / 2) % sect_dims);
+        if (indep_sects) {
+            if (sector == 0) theta_t = theta_base_t;
+            else if (sector == sections[0]) theta_h = theta_base_h;
+            else if (sector == sec_w) theta_w = theta_base_w;
+            else if (sector == sec_e) theta_e = theta_base_e;
+        }
+        float theta = theta_t;
+        if (sector >= sections[0] && sector < sec_w) theta = theta_h;
+        else if (sector >= sec_w && sector < sec_w + sections[2]) theta = theta_w;
+        else if (sector >= sec_w + sections[2]) theta = theta_e;
+        rope_yarn(theta / ff, freq_scale, corr_dims, i0, ext_factor, mscale, &cache[i0 + 0], &cache[i0 + 1]);
+        theta_t *= theta_scale;
+        theta_w *= theta_scale;
+        theta_h *= theta_scale;
+        theta_e *= theta_scale;
+    }
+}
+
 static enum ggml_status op_rope(struct ggml_tensor * dst) {
     const struct ggml_tensor * a = dst->src[0];
     const struct ggml_tensor * pos_t = dst->src[1];
@@ -775,43 +808,64 @@ static enum ggml_status op_rope(struct ggml_tensor * dst) {
     const int n_ctx_orig = dst->op_params[4];
     const float freq_base = op_f32(dst, 5), freq_scale = op_f32(dst, 6), ext_factor = op_f32(dst, 7);
     const float attn_factor = op_f32(dst, 8), beta_fast = op_f32(dst, 9), beta_slow = op_f32(dst, 10);
-    if (mode & GGML_ROPE_TYPE_MROPE) return GGML_STATUS_FAILED; /* mrope/vision: out of scope (not in BASELINE configs) */
+    int sections[4];
+    memcpy(sections, dst->op_params + 11, sizeof(sections));
+    const int is_neox = mode & GGML_ROPE_TYPE_NEOX;
+    const int is_mrope = mode & GGML_ROPE_TYPE_MROPE;
+    const int is_vision = mode == GGML_ROPE_TYPE_VISION;
     if (a->type != dst->type || (a->type != GGML_TYPE_F32 && a->type != GGML_TYPE_F16)) return GGML_STATUS_FAILED;
     if (pos_t->type != GGML_TYPE_I32) return GGML_STATUS_FAILED;
-    const int is_neox = mode & GGML_ROPE_TYPE_NEOX;
     const int is16 = a->type == GGML_TYPE_F16;
     const int64_t ne0 = a->ne[0], ne1 = a->ne[1], ne2 = a->ne[2], ne3 = a->ne[3];
+    if (is_mrope) {
+        const int sect_dims = sections[0] + sections[1] + sections[2] + sections[3];
+        if (sect_dims <= 0 || sect_dims > ne0 || ggml_abi_nelements(pos_t) < 4 * ne2) return GGML_STATUS_FAILED;
+    }
+    if (is_vision && n_dims != ne0 / 2) return GGML_STATUS_FAILED;
     const float theta_scale = powf(freq_base, -2.0f / n_dims);
     float corr_dims[2];
     rope_yarn_corr_dims(n_dims, n_ctx_orig, freq_base, beta_fast, beta_slow, corr_dims);
     const float * freq_factors = ff_t ? (const float *) ff_t->data : NULL;
     const int32_t * pos = (const int32_t *) pos_t->data;
     float * cache = (float *) malloc((size_t) ne0 * 4 + 16);
+#define ROPE_LD(p, i) (is16 ? F16(((const ggml_fp16_t *) (p))[i]) : ((const float *) (p))[i])
+#define ROPE_ST(p, i, v) do { if (is16) ((ggml_fp16_t *) (p))[i] = oracle_fp32_to_fp16(v); else ((float *) (p))[i] = (v); } while (0)
     for (int64_t i3 = 0; i3 < ne3; i3++) {
         for (int64_t i2 = 0; i2 < ne2; i2++) {
-            /* ggml_rope_cache_init: theta advanced by repeated multiplication */
-            float theta = (float) pos[i2];
-            for (int64_t i0 = 0; i0 < ne0; i0 += 2) {
-                const float ff = freq_factors ? freq_factors[i0 / 2] : 1.0f;
-                rope_yarn(theta / ff, freq_scale, corr_dims, i0, ext_factor, attn_factor, &cache[i0 + 0], &cache[i0 + 1]);
-                theta *= theta_scale;
+            if (!is_mrope) {
+                /* ggml_rope_cache_init: theta advanced by repeated multiplication */
+                float theta = (float) pos[i2];
+                for (int64_t i0 = 0; i0 < ne0; i0 += 2) {
+                    const float ff = freq_factors ? freq_factors[i0 / 2] : 1.0f;
+                    rope_yarn(theta / ff, freq_scale, corr_dims, i0, ext_factor, attn_factor, &cache[i0 + 0], &cache[i0 + 1]);
+                    theta *= theta_scale;
+                }
+            } else {
+                mrope_cache_init((float) pos[i2], (float) pos[i2 + ne2], (float) pos[i2 + ne2 * 2], (float) pos[i2 + ne2 * 3], sections, is_vision,
+                                 freq_scale, freq_factors, corr_dims, ne0, ext_factor, attn_factor, cache, theta_scale);
             }
             for (int64_t i1 = 0; i1 < ne1; i1++) {
                 const char * src = TDATA(a) + i3 * a->nb[3] + i2 * a->nb[2] + i1 * a->nb[1];
                 char * dp = TDATA(dst) + i3 * dst->nb[3] + i2 * dst->nb[2] + i1 * dst->nb[1];
+                if (is_vision) {
+                    /* pairs (ic, ic + n_dims) over the WHOLE row (n_dims == ne0/2): the upstream routine's two loops */
+                    for (int64_t i0 = 0; i0 < ne0; i0 += 2) {
+                        const float cos_theta = cache[i0 + 0], sin_theta = cache[i0 + 1];
+                        const int64_t ic = i0 / 2;
+                        const float x0 = ROPE_LD(src, ic), x1 = ROPE_LD(src, ic + n_dims);
+                        ROPE_ST(dp, ic, x0 * cos_theta - x1 * sin_theta);
+                        ROPE_ST(dp, ic + n_dims, x0 * sin_theta + x1 * cos_theta);
+                    }
+                    continue;
+                }
                 for (int64_t i0 = 0; i0 < n_dims; i0 += 2) {
                     const float cos_theta = cache[i0 + 0], sin_theta = cache[i0 + 1];
-                    const int64_t ia = is_neox ? i0 / 2 : i0;
-                    const int64_t ib = is_neox ? i0 / 2 + n_dims / 2 : i0 + 1;
-                    if (is16) {
-                        const float x0 = F16(((const ggml_fp16_t *) src)[ia]), x1 = F16(((const ggml_fp16_t *) src)[ib]);
-                        ((ggml_fp16_t *) dp)[ia] = oracle_fp32_to_fp16(x0 * cos_theta - x1 * sin_theta);
-                        ((ggml_fp16_t *) dp)[ib] = oracle_fp32_to_fp16(x0 * sin_theta + x1 * cos_theta);
-                    } else {
-                        const float x0 = ((const float *) src)[ia], x1 = ((const float *) src)[ib];
-                        ((float *) dp)[ia] = x0 * cos_theta - x1 * sin_theta;
-                        ((float *) dp)[ib] = x0 * sin_theta + x1 * cos_theta;
-                    }
+                    const int half_pairs = is_neox || is_mrope;
+                    const int64_t ia = half_pairs ? i0 / 2 : i0;
+                    const int64_t ib = half_pairs ? i0 / 2 + n_dims / 2 : i0 + 1;
+                    const float x0 = ROPE_LD(src, ia), x1 = ROPE_LD(src, ib);
+                    ROPE_ST(dp, ia, x0 * cos_theta - x1 * sin_theta);
+                    ROPE_ST(dp, ib, x0 * sin_theta + x1 * cos_theta);
                 }
                 for (int64_t i0 = n_dims; i0 < ne0; ++i0) { /* pass-through tail */
                     if (is16) ((ggml_fp16_t *) dp)[i0] = ((const ggml_fp16_t *) src)[i0];
@@ -820,6 +874,8 @@ static enum ggml_status op_rope(struct ggml_tensor * dst) {
             }
         }
     }
+#undef ROPE_LD
+#undef ROPE_ST
     free(cache);
     return GGML_STATUS_SUCCESS;
 }

@@ -363,6 +363,35 @@ def test_rope(backend, H, plog, mode, variant):
     T.compare(f"rope mode={mode} {variant}", got[0], ref[0], max_nmse=1e-12, max_abs=5e-6, log=plog)
 
 
+@pytest.mark.parametrize("dt", [L.F32, L.F16])
+@pytest.mark.parametrize("case", ["mrope", "mrope_partial_ff", "vision", "vision_uneven", "mrope_empty_first"])
+def test_rope_multi(backend, H, plog, case, dt):
+    """ggml_rope_multi (llama-box/patches/llama.cpp/mrope.patch:5-41): Qwen2-VL style multimodal sections and the vision-tower
+    mode with independently restarting sections; corner cases of the reference recurrence included."""
+    import ctypes as C
+    rng = np.random.default_rng(23)
+    NH, NT = 3, 7
+    HD, n_dims, sections, mode, ff = {
+        "mrope": (128, 128, [16, 24, 24, 0], L.ROPE_MROPE, False),
+        "mrope_partial_ff": (128, 96, [8, 12, 12, 4], L.ROPE_MROPE, True),       # rotated part < row, freq factors, 4th stream
+        "vision": (80, 40, [20, 20, 20, 20], L.ROPE_VISION, False),
+        "vision_uneven": (64, 32, [5, 9, 7, 3], L.ROPE_VISION, True),            # cycle of 24 pairs: sections repeat, angles restart
+        "mrope_empty_first": (64, 64, [0, 10, 0, 6], L.ROPE_MROPE, False),
+    }[case]
+    npdt = np.float16 if dt == L.F16 else np.float32
+    x = rng.standard_normal((NT, NH, HD)).astype(npdt)
+    pos4 = rng.integers(0, 3000, 4 * NT).astype(np.int32)
+    ffv = rng.uniform(0.8, 4.0, HD // 2).astype(np.float32)
+
+    def build(g):
+        sec = (C.c_int * 4)(*sections)
+        return H.ggml_rope_multi(g.ctx, g.new(dt, [HD, NH, NT], x), g.new(L.I32, [4 * NT], pos4), g.new(L.F32, [HD // 2], ffv) if ff else None,
+                                 n_dims, sec, mode, 32768, 1000000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+
+    ref, got = both(build, backend)
+    T.compare(f"rope_multi {case} {QNAME[dt]}", got[0].astype(np.float32), ref[0].astype(np.float32), max_nmse=1e-7 if dt == L.F16 else 1e-9, log=plog)
+
+
 def test_rope_f16_kshift(backend, H, plog):
     """K-shift form: in-place-shaped rope on f16 data (llama-box context shift, httpserver.hpp:3453-3537)."""
     rng = np.random.default_rng(18)

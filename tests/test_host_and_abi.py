@@ -230,3 +230,64 @@ def test_stream_bytes_matches_survey_for_llama3_8b(H):
         total += (E * E * 2 + E * 1024 + E * FF * 2) * q4 + (E * 1024 + FF * E) * (q6 if more else q4) + 2 * E * 4
     total += V * E * q6 + E * 4 + E * q4
     assert int(total) == 4617398528
+
+
+def _rope_multi_oracle(H, x, pos4, n_dims, sections, mode, dt=None, freq_base=10000.0):
+    dt = dt or L.F32
+
+    def build(g):
+        ne = list(x.shape[::-1])
+        sec = (C.c_int * 4)(*sections)
+        return H.ggml_rope_multi(g.ctx, g.new(dt, ne, x), g.new(L.I32, [pos4.size], pos4), None, n_dims, sec, mode, 32768, freq_base, 1.0, 0.0, 1.0, 32.0, 1.0)
+
+    return T.run_case(build, "oracle")[0]
+
+
+def test_rope_multi_oracle_against_closed_form(H):
+    """ggml_rope_multi (mrope.patch touches exactly this routine): the oracle's recurrence against the closed form
+    theta(pair) = pos[stream(pair)] * base^(-2 * k / n_dims) in float64, k = pair index (mrope) or index within the section
+    (vision); and mrope with four identical position streams must reproduce NeoX rope bit for bit."""
+    rng = np.random.default_rng(31)
+    HD, NH, NT = 128, 3, 5
+    x = rng.standard_normal((NT, NH, HD)).astype(np.float32)
+    pos4 = rng.integers(0, 4000, 4 * NT).astype(np.int32)
+    sections = [16, 24, 24, 0]
+    got = _rope_multi_oracle(H, x, pos4, HD, sections, L.ROPE_MROPE, freq_base=1000000.0).reshape(NT, NH, HD)
+    half = HD // 2
+    ref = np.zeros_like(x, dtype=np.float64)
+    for t in range(NT):
+        for ic in range(half):
+            sector = ic % sum(sections)
+            stream = 0 if sector < 16 else (1 if sector < 40 else 2)
+            th = float(pos4[t + stream * NT]) * 1000000.0 ** (-2.0 * ic / HD)
+            c, s_ = np.cos(th), np.sin(th)
+            x0, x1 = x[t, :, ic].astype(np.float64), x[t, :, ic + half].astype(np.float64)
+            ref[t, :, ic], ref[t, :, ic + half] = x0 * c - x1 * s_, x0 * s_ + x1 * c
+    # the f32 recurrence theta *= theta_scale drifts from the float64 power by ~1e-6 relative per step; angles reach 4e3 rad
+    assert T.nmse(got, ref) < 1e-5
+    # identical streams == NeoX
+    p1 = rng.integers(0, 4000, NT).astype(np.int32)
+    same = _rope_multi_oracle(H, x, np.tile(p1, 4), HD, sections, L.ROPE_MROPE)
+
+    def build_neox(g):
+        return H.ggml_rope_ext(g.ctx, g.new(L.F32, [HD, NH, NT], x), g.new(L.I32, [NT], p1), None, HD, L.ROPE_NEOX, 32768, 10000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+    neox = T.run_case(build_neox, "oracle")[0]
+    assert np.array_equal(same.view(np.uint32), neox.view(np.uint32))
+    # vision mode: n_dims = head_dim / 2, sections of head_dim / 4 pairs, pairs (ic, ic + n_dims), each section's angle restarts
+    HDv = 80
+    xv = rng.standard_normal((NT, NH, HDv)).astype(np.float32)
+    sec_v = [HDv // 4] * 4
+    gv = _rope_multi_oracle(H, xv, pos4, HDv // 2, sec_v, L.ROPE_VISION).reshape(NT, NH, HDv)
+    refv = np.zeros_like(xv, dtype=np.float64)
+    nd = HDv // 2
+    for t in range(NT):
+        for ic in range(nd):
+            stream, k = (0, ic) if ic < HDv // 4 else (1, ic - HDv // 4)
+            th = float(pos4[t + stream * NT]) * 10000.0 ** (-2.0 * k / nd)
+            c, s_ = np.cos(th), np.sin(th)
+            x0, x1 = xv[t, :, ic].astype(np.float64), xv[t, :, ic + nd].astype(np.float64)
+            refv[t, :, ic], refv[t, :, ic + nd] = x0 * c - x1 * s_, x0 * s_ + x1 * c
+    assert T.nmse(gv, refv) < 1e-5
+    # all-zero sections: upstream divides by zero there (llama-box only removed the assertion) -> refused, not guessed
+    with pytest.raises(RuntimeError):
+        _rope_multi_oracle(H, x, pos4, HD, [0, 0, 0, 0], L.ROPE_MROPE)
