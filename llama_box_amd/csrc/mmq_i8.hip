@@ -59,6 +59,9 @@ __device__ __forceinline__ uint32_t pack_h2i(const int a, const int b) {
 }
 __device__ __forceinline__ int sw_off(const int row, const int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+#ifndef MMQ_FOLD_PACKED
+#define MMQ_FOLD_PACKED 0
+#endif
 template <int QT, int BN>
 __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,6 +109,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
             for (int p = 0; p < NP; ++p) acc[p][t][r] = 0;
         }
     const float16v zerof = C[0];
+    const int16v zeroi = acc[0][0];
 
     // raw global data of the NEXT trip to be staged
     uint4 g_hdr, g_q, g_qh, g_b0, g_b1, g_b2, g_b3, g_bs0, g_bs1;
@@ -265,6 +269,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
     const int arow_off = (nslab * 32 + fr) * 128;
     const int brow_off[2] = {(mhalf * 64 + fr) * 128, (mhalf * 64 + 32 + fr) * 128};
 
+    // (the first MFMA of a super-block takes a literal zero accumulator: the integer sums never have to be cleared)
     auto mma = [&](const int h) {
         const char * buf = smem + h * STAGE;
         const char * Bt = buf + NP * TA;
@@ -278,12 +283,14 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
             for (int p = 0; p < NP; ++p) {
                 const int4v fa = *(const int4v *) (buf + p * TA + arow_off + co);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[p][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[t], acc[p][t], 0, 0, 0);
+                for (int t = 0; t < 2; ++t) acc[p][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[t], (h == 0 && ks == 0) ? zeroi : acc[p][t], 0, 0, 0);
             }
         }
     };
 
+    // super-block fold on the packed-f32 pipe (v_pk_mul_f32 / v_pk_fma_f32): two accumulator rows per instruction
     auto fold = [&]() {
+        typedef float float2v __attribute__((ext_vector_type(2)));
         half8 fam;
         if constexpr (!Q6) fam = *(const half8 *) (Am + (nslab * 32 + fr) * MI_MS + kg * 16);
 #pragma unroll
@@ -294,18 +301,29 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
                 am = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fbm, zerof, 0, 0, 0);
             }
             const float dy = dyv[mhalf * 64 + t * 32 + fr];
+            const float2v dy2 = {dy, dy};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = nslab * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                const float2 sd = dd[i];
-                int isum;
-                if constexpr (QT == 4) isum = (acc[0][t][r] << 3) + acc[1][t][r];
-                else if constexpr (QT == 5) isum = (acc[0][t][r] << 4) + (acc[1][t][r] << 2) + acc[2][t][r];
-                else isum = (acc[0][t][r] << 6) + acc[1][t][r];
-                const float v = Q6 ? sd.x * (float) isum : sd.x * (float) isum - sd.y * am[r];
-                C[t][r] += dy * v;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) acc[p][t][r] = 0;
+            for (int r = 0; r < 16; r += 2) {
+                const int i = nslab * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;  // rows i, i + 1
+                const float4 sd = *(const float4 *) &dd[i];                   // (d, dmin) of both
+                int is0, is1;
+                if constexpr (QT == 4) { is0 = (acc[0][t][r] << 3) + acc[1][t][r]; is1 = (acc[0][t][r + 1] << 3) + acc[1][t][r + 1]; }
+                else if constexpr (QT == 5) {
+                    is0 = (acc[0][t][r] << 4) + (acc[1][t][r] << 2) + acc[2][t][r];
+                    is1 = (acc[0][t][r + 1] << 4) + (acc[1][t][r + 1] << 2) + acc[2][t][r + 1];
+                } else { is0 = (acc[0][t][r] << 6) + acc[1][t][r]; is1 = (acc[0][t][r + 1] << 6) + acc[1][t][r + 1]; }
+#if MMQ_FOLD_PACKED
+                float2v v = (float2v){(float) is0, (float) is1} * (float2v){sd.x, sd.z};
+                if constexpr (!Q6) v = __builtin_elementwise_fma(-(float2v){sd.y, sd.w}, (float2v){am[r], am[r + 1]}, v);
+                const float2v c = __builtin_elementwise_fma(dy2, v, (float2v){C[t][r], C[t][r + 1]});
+#else
+                float v0 = sd.x * (float) is0, v1 = sd.z * (float) is1;
+                if constexpr (!Q6) { v0 = __builtin_fmaf(-sd.y, am[r], v0); v1 = __builtin_fmaf(-sd.w, am[r + 1], v1); }
+                const float2v c = {__builtin_fmaf(dy, v0, C[t][r]), __builtin_fmaf(dy, v1, C[t][r + 1])};
+                (void) dy2;
+#endif
+                C[t][r] = c.x;
+                C[t][r + 1] = c.y;
             }
         }
     };
