@@ -168,6 +168,7 @@ static void be_free(ggml_backend_t be) {
     tp_free(c);
     if (c->ws) HIP_CHECK(hipFree(c->ws));
     if (c->up_ring) HIP_CHECK(hipHostFree(c->up_ring));
+    if (c->fa_lists) HIP_CHECK(hipFree(c->fa_lists));
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c;
     delete be;
@@ -276,6 +277,8 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     c->device = d->device;
     c->name = d->name;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->fa_lists_bytes = (size_t) 1 << 20;
+    if (hipMalloc((void **) &c->fa_lists, c->fa_lists_bytes) != hipSuccess) { (void) hipGetLastError(); c->fa_lists = nullptr; c->fa_lists_bytes = 0; }
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->opt.graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->opt.fusion = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_PROLOGUE")) c->opt.prologue = atoi(e) != 0;

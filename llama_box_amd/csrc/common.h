@@ -114,6 +114,10 @@ struct backend_ctx {
     // tiny kernel — a blit through hipMemcpyAsync costs ~25 us of stream time per copy, five of them per decode step
     char * up_ring = nullptr;
     size_t up_cap = 0, up_head = 0;
+    // attention over a unified cache with a few query tokens: per-token lists of visible tiles (fattn.hip, k_fattn_tile_scan),
+    // built once per graph execution and shared by the attention nodes of all layers
+    int * fa_lists = nullptr;
+    size_t fa_lists_bytes = 0;
     // per-class kernel timing (bench)
     std::map<std::string, timing_slot> timing;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;

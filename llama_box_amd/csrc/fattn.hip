@@ -249,9 +249,14 @@ __device__ __forceinline__ float xrow_allmax(const float x) {
 // Q8 = true: K and V rows are block_q8_0 (quantised KV cache, -ctk/-ctv q8_0).  As in ggml-cpu the query is quantised to Q8_0
 // too (K's vec_dot_type), a score is sum over the four 32-value blocks of sumi * (d_k * d_q) with an integer block sum, and a
 // V row is de-quantised (q * d) and accumulated in f32.  A lane still owns 8 dims: 8 int8 of one block (lanes 4b..4b+3 = block b).
-template <int G, bool SKIP, bool Q8>
+// MODE 2 (LIST): the visible tiles of every query token were listed once per graph by k_fattn_tile_scan (the mask is the same
+// tensor in every layer); split s of token t walks its share of THAT list, so the work is proportional to what the token can
+// see, not to the size of the unified cache, and no workgroup is launched just to find out that it has nothing to do.
+template <int G, int MODE, bool Q8>
 __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
-                                                      const tdesc dst, const fa_geom geo, float * __restrict__ ws, const int g_real) {
+                                                      const tdesc dst, const fa_geom geo, float * __restrict__ ws, const int g_real,
+                                                      const int * __restrict__ lists, const int list_stride) {
+    constexpr bool SKIP = MODE == 1, LIST = MODE == 2;
     constexpr int D = 128, NG = 16 / G;
     constexpr float LOG2E = 1.4426950408889634f;
     __shared__ float sh[4][G][D + 2];
@@ -264,7 +269,24 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     // if not: of the 64 x 32 (split, token) pairs of a -np 32 decode step only ~1/16 touch K/V at all
     const int tok = (int) blockIdx.z % geo.n_q, bat = (int) blockIdx.z / geo.n_q;
     const int per = SKIP ? ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64 : (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
-    const int kv0 = min(split * per, geo.n_kv), kv1 = min(geo.n_kv, kv0 + per);
+    const int kv0 = LIST ? 0 : min(split * per, geo.n_kv), kv1 = LIST ? geo.n_kv : min(geo.n_kv, kv0 + per);
+    const int * tl = nullptr;  // LIST: this token's visible tiles (tile = the NG*16 positions of one trip), entries [ti, ti1) are ours
+    int ti = 0, ti1 = 0;
+    if constexpr (LIST) {
+        const int * lt = lists + (int64_t) tok * list_stride;
+        const int cnt = lt[0], share = (cnt + geo.n_splits - 1) / geo.n_splits;
+        tl = lt + 1;
+        ti = split * share;
+        ti1 = min(cnt, ti + share);
+        if (ti >= ti1) {
+            if (tid < g_real) {
+                float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + kvh * g_real + tid) * geo.n_splits + split) * (128 + 2);
+                rec[128] = -INFINITY;
+                rec[129] = 0.0f;
+            }
+            return;
+        }
+    }
     const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
     if constexpr (SKIP) {
         const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]);
@@ -293,7 +315,7 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     uint4 kraw[NG], vraw[NG];
     float mvl = 0.0f;   // mask value / validity of THIS lane's pair (ul, sub)
     bool okl = false;
-    int p0 = kv0;
+    int p0 = LIST ? tl[ti] * (NG * 16) : kv0;
 #define FA_LOAD_TRIP()                                                                  \
     {                                                                                   \
         _Pragma("unroll") for (int u = 0; u < NG; ++u) {                               \
@@ -375,14 +397,20 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     const bool b3 = (sl & 8) != 0, b2 = (sl & 4) != 0, b1 = (sl & 2) != 0, b0 = (sl & 1) != 0;
     const float sc2 = geo.scale * LOG2E;  // scores are kept in the log2 domain: p = 2^(s*scale*log2e + mask*log2e - m)
 
-    for (int trip = 0; p0 < kv1; p0 += NG * 16, ++trip) {
+    for (int trip = 0; LIST ? ti < ti1 : p0 < kv1; ++trip) {
+        // position of the next trip (LIST: next entry of the tile list; otherwise the next NG*16 positions of the split)
+        int p_next = p0 + NG * 16;
+        if constexpr (LIST) {
+            ++ti;
+            p_next = ti < ti1 ? tl[ti] * (NG * 16) : kv1;
+        }
         if constexpr (SKIP) {
             if (!((vis >> trip) & 1u)) {  // nothing visible: only keep the pipeline primed for the next trip
-                if (p0 + NG * 16 < kv1 && ((vis >> (trip + 1)) & 1u)) {
-                    p0 += NG * 16;
+                if (p_next < kv1 && ((vis >> (trip + 1)) & 1u)) {
+                    p0 = p_next;
                     FA_LOAD_TRIP()
-                    p0 -= NG * 16;
                 }
+                p0 = p_next;
                 continue;
             }
         }
@@ -421,14 +449,11 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
                 }
             }
         }
-        const bool more = p0 + NG * 16 < kv1 && (!SKIP || ((vis >> (trip + 1)) & 1u));
+        const bool more = p_next < kv1 && (!SKIP || ((vis >> (trip + 1)) & 1u));
         const float mv_cur = mvl;
         const bool ok_cur = okl;
-        if (more) {  // long splits: the next trip's loads go out before the reductions
-            p0 += NG * 16;
-            FA_LOAD_TRIP()
-            p0 -= NG * 16;
-        }
+        p0 = p_next;  // (nothing below uses the current trip's position)
+        if (more) FA_LOAD_TRIP()  // long splits: the next trip's loads go out before the reductions
         // ---- transpose-reduce over the 16 lanes of the row: lane j ends with the complete dot of pair j
         float w8[8], w4[4], w2[2];
 #pragma unroll
@@ -589,9 +614,15 @@ void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const flo
 }
 
 int fattn_pick_splits(const tdesc & q, const tdesc & k) {
-    if (q.ne[1] >= 32 && (k.ne[0] == 64 || k.ne[0] == 128)) return fattn_mma_pick_splits(q, k);  // (soft-capped / ALiBi batches fall back to the generic kernel with this count)
+    if (q.ne[1] >= fattn_mma_min_q() && (k.ne[0] == 64 || k.ne[0] == 128)) return fattn_mma_pick_splits(q, k);  // (soft-capped / ALiBi batches fall back to the generic kernel with this count)
     const int64_t n_kv = k.ne[1];
-    if (q.ne[1] > 1) {  // a few tokens (continuous-batching decode): short splits, so that whole trips can be skipped by their mask
+    if (q.ne[1] > 1 && k.ne[0] == 128 && q.ne[3] == 1) {
+        // a few tokens at head_dim 128 (continuous-batching decode, speculative batches): the tile-list kernel — every split takes a
+        // share of the token's VISIBLE tiles, so the count follows the number of (token, kv head) groups, not the cache size
+        const int64_t groups = k.ne[2] * q.ne[1];
+        return (int) std::max<int64_t>(2, std::min<int64_t>(16, (768 + groups - 1) / groups));
+    }
+    if (q.ne[1] > 1) {  // a few tokens, other head sizes: short splits
         const int64_t by_len = (n_kv + 255) / 256;
         return (int) std::max<int64_t>(1, std::min<int64_t>(64, std::min<int64_t>(by_len, std::max<int64_t>(1, n_kv / 64))));
     }
@@ -606,7 +637,7 @@ static size_t fattn_partials_bytes(const tdesc & q, const tdesc & v, int n_split
     return ((size_t) (q.ne[1] * q.ne[3] * q.ne[2]) * (size_t) n_splits * (size_t) (v.ne[0] + 2) * sizeof(float) + 255) & ~(size_t) 255;
 }
 // prompt batches over a block_q8_0 cache run the matrix-core kernel on an f16 image of the K and V views (below)
-static bool fattn_q8_via_f16(const tdesc & q, int kv_type) { return kv_type == GGML_TYPE_Q8_0 && q.ne[1] >= 32; }
+static bool fattn_q8_via_f16(const tdesc & q, int kv_type) { return kv_type == GGML_TYPE_Q8_0 && q.ne[1] >= fattn_mma_min_q(); }
 size_t fattn_workspace_bytes(const tdesc & q, const tdesc & k, const tdesc & v, int n_splits, int kv_type) {
     size_t b = fattn_partials_bytes(q, v, n_splits);
     if (fattn_q8_via_f16(q, kv_type)) b += 2 * (size_t) (k.ne[0] * k.ne[1] * k.ne[2] * k.ne[3]) * sizeof(uint16_t) + 512;
@@ -639,6 +670,61 @@ template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, co
         dim3 g2((unsigned) geo.n_head, (unsigned) geo.n_q, (unsigned) q.ne[3]);
         hipLaunchKernelGGL((k_fattn_combine<D>), g2, dim3(D), 0, s, ws, sinks, dst, geo);
     }
+}
+
+// ---- tile lists: for every query token, the tiles (runs of `tile` cache cells) in which its mask row has anything but -inf, in
+// ascending order; lists[t * stride] = count, entries follow.  One workgroup per token; ordered compaction by ballots.
+__global__ void __launch_bounds__(256) k_fattn_tile_scan(const tdesc mask, const int n_kv, const int tile, int * __restrict__ lists, const int stride) {
+    __shared__ int wcnt[4];
+    const int tok = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1]);
+    int * out = lists + (int64_t) tok * stride;
+    const int n_tiles = (n_kv + tile - 1) / tile;
+    int base = 0;
+    for (int t0 = 0; t0 < n_tiles; t0 += 256) {
+        const int t = t0 + tid;
+        bool vis = false;
+        if (t < n_tiles) {
+            for (int c = 0; c < tile; c += 4) {
+                const int pp = t * tile + c;
+                if (pp < n_kv) {  // n_kv is a multiple of 4 (launcher): the four cells are in range together
+                    const uint2 w = *(const uint2 *) (mrow + pp);
+                    vis = vis || w.x != 0xFC00FC00u || w.y != 0xFC00FC00u;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(vis);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            woff += w < wave ? wcnt[w] : 0;
+            tot += wcnt[w];
+        }
+        if (vis) out[1 + base + woff + before] = t;
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = base;
+}
+// tile size of the list kernel for this attention shape, or 0 when it does not apply (then `lists` is not used)
+int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const fattn_params & p, size_t lists_bytes) {
+    const int64_t n_q = q.ne[1];
+    const int G = k.ne[2] > 0 ? (int) (q.ne[2] / k.ne[2]) : 0;
+    static const bool on = !getenv("GGML_MI355X_FA_LIST") || atoi(getenv("GGML_MI355X_FA_LIST")) != 0;
+    if (!on || n_q < 2 || n_q >= fattn_mma_min_q() || !mask || q.ne[3] != 1 || mask->ne[3] != 1 || k.ne[0] != 128) return 0;
+    if (p.logit_softcap != 0.0f || p.max_bias != 0.0f || !(G == 2 || G == 4 || G == 7 || G == 8) || p.n_splits < 2) return 0;
+    if ((k.ne[1] % 4) != 0 || (mask->nb[1] % 8) != 0 || ((uintptr_t) mask->data & 7) != 0 || mask->type != GGML_TYPE_F16) return 0;
+    const int tile = 16 * (16 / (G == 7 ? 8 : G));
+    const int64_t stride = (k.ne[1] + tile - 1) / tile + 1;
+    if ((size_t) (n_q * stride) * sizeof(int) > lists_bytes) return 0;
+    return tile;
+}
+void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, int tile, int * lists) {
+    const int stride = (n_kv + tile - 1) / tile + 1;
+    hipLaunchKernelGGL(k_fattn_tile_scan, dim3((unsigned) n_q), dim3(256), 0, s, mask, n_kv, tile, lists, stride);
 }
 
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
@@ -690,16 +776,21 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         // several query tokens with a mask: skip the KV trips a token cannot see — needs splits of at most 32 trips
         const int per = ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64;
         static const bool skip_on = !getenv("GGML_MI355X_FA_SKIP") || atoi(getenv("GGML_MI355X_FA_SKIP")) != 0;
-        const bool skip = skip_on && geo.n_q > 1 && (geo.n_q <= 64 || q8) && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
+        // p.lists set: the caller has run (or re-used) k_fattn_tile_scan for this mask with the tile size fattn_list_tile() gave
+        const bool list = p.lists != nullptr;
+        const int lstride = (geo.n_kv + 16 * (16 / (G == 7 ? 8 : G)) - 1) / (16 * (16 / (G == 7 ? 8 : G))) + 1;
+        const bool skip = !list && skip_on && geo.n_q > 1 && (geo.n_q <= 64 || q8) && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
                           (mask->nb[3] % 8) == 0 && ((uintptr_t) mask->data & 7) == 0 && geo.n_splits > 1;
 #define FA_DEC(GG)                                                                                                                          \
     {                                                                                                                                       \
         if (q8) {                                                                                                                           \
-            if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, true, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);     \
-            else hipLaunchKernelGGL((k_fattn_dec128<GG, false, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);         \
+            if (list) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride);      \
+            else if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, 1, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);       \
+            else hipLaunchKernelGGL((k_fattn_dec128<GG, 0, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);                 \
         } else {                                                                                                                            \
-            if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, true, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);    \
-            else hipLaunchKernelGGL((k_fattn_dec128<GG, false, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G);        \
+            if (list) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride);     \
+            else if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, 1, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);      \
+            else hipLaunchKernelGGL((k_fattn_dec128<GG, 0, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);                \
         }                                                                                                                                   \
     }
         if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)

@@ -218,9 +218,15 @@ int fattn_mma_pick_splits(const tdesc & q, const tdesc & k) {
     want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, tiles / 4)));
     return (int) want;
 }
+int fattn_mma_min_q() {
+    // up to 32 query tokens are served per token (tile-list / lane-parallel kernels): a -np 32 decode step has 32 tokens that
+    // each see their own 1/32 of a unified cache, which a dense 32-query tile would multiply through in full
+    static const int v = getenv("GGML_MI355X_FA_MMA_MIN_Q") ? std::max(32, atoi(getenv("GGML_MI355X_FA_MMA_MIN_Q"))) : 33;
+    return v;
+}
 bool flash_attn_mma_applies(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p) {
     const int D = (int) k.ne[0];
-    if (q.ne[1] < 32 || sinks != nullptr || p.max_bias != 0.0f || p.logit_softcap != 0.0f || (D != 64 && D != 128)) return false;
+    if (q.ne[1] < fattn_mma_min_q() || sinks != nullptr || p.max_bias != 0.0f || p.logit_softcap != 0.0f || (D != 64 && D != 128)) return false;
     if ((k.ne[1] % 4) != 0 || (q.nb[1] % 16) || (q.nb[2] % 16) || (((uintptr_t) q.data) & 15) || (dst.nb[1] % 16) || (dst.nb[2] % 16) || (((uintptr_t) dst.data) & 15)) return false;
     if (mask && ((mask->nb[1] % 8) || (((uintptr_t) mask->data) & 7))) return false;
     return true;

@@ -213,6 +213,9 @@ struct exec_state {
     std::unordered_map<const ggml_tensor *, deferred_norm> deferred;
     std::vector<char> done;  // nodes already executed out of order by a multi-chain fusion
     bool q8_fresh = false;   // the node just executed produced the quantised-activation cache for its own output
+    // tile lists (fattn.hip) valid for this mask tensor / tile size during this execution of the graph
+    const void * fa_list_mask = nullptr;
+    int fa_list_tile = 0;
 };
 
 static int use_count(const exec_state & st, const ggml_tensor * t) {
@@ -810,6 +813,18 @@ static int run_node(exec_state & st, int i) {
             p.kv_type = k->type;
             const tdesc md = m ? TD(m) : qd;
             timed_scope ts(c, "flash_attn", (double) (k->ne[1] * k->ne[2] * k->ne[0] * 2 * 2));
+            if (c->fa_lists) {
+                const int tile = fattn_list_tile(qd, kd, m ? &md : nullptr, p, c->fa_lists_bytes);
+                if (tile > 0) {
+                    if (st.fa_list_mask != m->data || st.fa_list_tile != tile) {  // first attention node of this graph run: list the tiles
+                        launch_fattn_tile_scan(s, md, (int) a->ne[1], (int) k->ne[1], tile, c->fa_lists);
+                        c->st.kernel_launches++;
+                        st.fa_list_mask = m->data;
+                        st.fa_list_tile = tile;
+                    }
+                    p.lists = c->fa_lists;
+                }
+            }
             launch_flash_attn(s, qd, kd, vd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p, (char *) c->ws + st.aux_off);
             c->st.kernel_launches += p.n_splits > 1 ? 2 : 1;
             return 1;

@@ -138,8 +138,13 @@ struct fattn_params {
     float scale, max_bias, logit_softcap;
     int n_splits;  // KV splits per (token, kv-head group)
     int kv_type;   // GGML_TYPE_F16 or GGML_TYPE_Q8_0 (K and V alike)
+    const int * lists = nullptr;  // per-token lists of visible tiles (launch_fattn_tile_scan), or nullptr
 };
+// few query tokens over a large unified cache (continuous batching): tile size for the tile-list attention kernel, 0 = not applicable
+int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const fattn_params & p, size_t lists_bytes);
+void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, int tile, int * lists);
 size_t fattn_workspace_bytes(const tdesc & q, const tdesc & k, const tdesc & v, int n_splits, int kv_type);
+int fattn_mma_min_q();  // query tokens from which the matrix-core attention kernel takes over (env GGML_MI355X_FA_MMA_MIN_Q)
 bool flash_attn_mma_applies(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);
 int fattn_pick_splits(const tdesc & q, const tdesc & k);
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks,

@@ -62,29 +62,39 @@ __device__ __forceinline__ int sw_off(const int row, const int chunk) { return r
 #ifndef MMQ_FOLD_PACKED
 #define MMQ_FOLD_PACKED 0
 #endif
-template <int QT, int BN>
-__global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_args a) {
+// BM = activation columns per workgroup.  128: each wave owns 32 rows x 64 columns and all four 32-wide K steps of a trip.
+// 64 / 32 (continuous-batching decode steps, M <= 64): every wave sees ALL columns (two / one 32-column tiles) and the two wave
+// groups split the K steps of a trip between them — the staging work (all threads unpack weights) is unchanged, the MFMA,
+// LDS-read and fold work shrinks with the tile instead of multiplying zeros; the two partial sums meet in LDS at the end.
+template <int QT, int BN, int BM = 128>
+__global__ void __launch_bounds__(BN * 4, BN == 64 ? (BM == 32 ? 3 : 2) : 1) k_mmq_i8(const mmq8_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = BN * 4;
     constexpr int NP = QT == 5 ? 3 : 2;
     constexpr int BYTES = QT == 4 ? 144 : (QT == 5 ? 176 : 210);
     constexpr bool Q6 = QT == 6;
-    constexpr int TA = BN * 128, TB = MI_BM * 128, STAGE = NP * TA + TB;
-    constexpr int NBC = (MI_BM * 8) / NT;  // 16-byte activation chunks per thread per trip
+    constexpr int TA = BN * 128, TB = BM * 128, STAGE = NP * TA + TB;
+    constexpr int NBC = (BM * 8) / NT;  // 16-byte activation chunks per thread per trip (1, 2 or 4)
+    constexpr int NTT = BM >= 64 ? 2 : 1;  // 32-column tiles per wave
+    constexpr int KG = BM == 128 ? 1 : 2;  // wave groups sharing the K steps of a trip
+    constexpr int NKS = 4 / KG;
+    static_assert(NBC == 1 || NBC == 2 || NBC == 4, "activation staging layout");
     char * Am = smem + 2 * STAGE;                   // mins  [BN][24] f16
-    char * Bm = Am + BN * MI_MS;                    // bsums [128][24] f16
-    float2 * dd = (float2 *) (Bm + MI_BM * MI_MS);  // (d, dmin) per row
+    char * Bm = Am + BN * MI_MS;                    // bsums [BM][24] f16
+    float2 * dd = (float2 *) (Bm + BM * MI_MS);     // (d, dmin) per row
     float * dyv = (float *) (dd + BN);              // dy per column
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int panel = (qb / a.m_tiles) * 8 + xcd, mt = qb % a.m_tiles;
     if (panel >= a.n_panels) return;
-    const int n0 = panel * BN, m0 = mt * MI_BM;
+    const int n0 = panel * BN, m0 = mt * BM;
     const int nblk_all = a.K / 256;
     const int sb_lo = (int) (((int64_t) blockIdx.y * nblk_all) / a.ksplit), sb_hi = (int) (((int64_t) (blockIdx.y + 1) * nblk_all) / a.ksplit);
     const int nblk = nblk_all;  // row stride of the activation blocks
     const int nslab = wave % (BN / 32), mhalf = wave / (BN / 32);
+    const int cb = KG == 1 ? mhalf * 64 : 0;   // first activation column of this wave
+    const int ks0 = KG == 1 ? 0 : mhalf * NKS;  // first K step of a trip this wave multiplies
 
     // staging roles
     const int arow = tid >> 2, aq = tid & 3;
@@ -92,16 +102,16 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
     // (scalars, not arrays: arrays captured by the staging lambdas end up in scratch memory)
     auto b_src = [&](const int i) { const int c = tid + i * NT; return a.act[(size_t) min(m0 + (c >> 3), a.M - 1) * nblk].qs + 16 * (c & 7); };
     auto b_off = [&](const int i) { const int c = tid + i * NT; return sw_off(c >> 3, c & 7); };
-    const int8_t * bsrc0 = b_src(0), * bsrc1 = b_src(1), * bsrc2 = b_src(NBC > 2 ? 2 : 0), * bsrc3 = b_src(NBC > 2 ? 3 : 0);
-    const int boff0 = b_off(0), boff1 = b_off(1), boff2 = b_off(NBC > 2 ? 2 : 0), boff3 = b_off(NBC > 2 ? 3 : 0);
-    const q8k_dev * mcol = a.act + (size_t) min(m0 + (tid & 127), a.M - 1) * nblk;  // column whose bsums / d this thread stages (tid < 128)
+    const int8_t * bsrc0 = b_src(0), * bsrc1 = b_src(NBC > 1 ? 1 : 0), * bsrc2 = b_src(NBC > 2 ? 2 : 0), * bsrc3 = b_src(NBC > 2 ? 3 : 0);
+    const int boff0 = b_off(0), boff1 = b_off(NBC > 1 ? 1 : 0), boff2 = b_off(NBC > 2 ? 2 : 0), boff3 = b_off(NBC > 2 ? 3 : 0);
+    const q8k_dev * mcol = a.act + (size_t) min(m0 + (tid & (BM - 1)), a.M - 1) * nblk;  // column whose bsums / d this thread stages (tid < BM)
     const int c_lo = 4 * (aq >> 1) + (aq & 1);
     const int aoff_lo = sw_off(arow, c_lo), aoff_hi = sw_off(arow, c_lo + 2);
 
-    float16v C[2];
-    int16v acc[NP][2];
+    float16v C[NTT];
+    int16v acc[NP][NTT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NTT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             C[t][r] = 0.0f;
@@ -136,12 +146,12 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
         }
         const size_t bo = (size_t) sb * sizeof(q8k_dev) + 128 * h;
         g_b0 = *(const uint4 *) (bsrc0 + bo);
-        g_b1 = *(const uint4 *) (bsrc1 + bo);
+        if constexpr (NBC > 1) g_b1 = *(const uint4 *) (bsrc1 + bo);
         if constexpr (NBC > 2) {
             g_b2 = *(const uint4 *) (bsrc2 + bo);
             g_b3 = *(const uint4 *) (bsrc3 + bo);
         }
-        if (h == 1 && tid < 128) {
+        if (h == 1 && tid < BM) {
             if constexpr (!Q6) {
                 g_bs0 = *(const uint4 *) mcol[sb].bsums;
                 g_bs1 = *(const uint4 *) (mcol[sb].bsums + 8);
@@ -223,7 +233,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
         // ---- activation tile: raw int8
         char * Bt = buf + NP * TA;
         *(uint4 *) (Bt + boff0) = g_b0;
-        *(uint4 *) (Bt + boff1) = g_b1;
+        if constexpr (NBC > 1) *(uint4 *) (Bt + boff1) = g_b1;
         if constexpr (NBC > 2) {
             *(uint4 *) (Bt + boff2) = g_b2;
             *(uint4 *) (Bt + boff3) = g_b3;
@@ -232,7 +242,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
         if (h == 1) {
             if constexpr (Q6) {
                 if (aq == 0) dd[arow] = make_float2(h2f(g6_d), 0.0f);
-                if (tid < 128) dyv[tid] = g_dy;
+                if (tid < BM) dyv[tid] = g_dy;
             }
             if (!Q6 && aq == 0) {
                 const float d = h2f((uint16_t) (g_hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (g_hdr.x >> 16));
@@ -255,7 +265,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
                 dm[0] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
                 dm[1] = make_uint4(pm[4], pm[5], pm[6], pm[7]);
             }
-            if (!Q6 && tid < 128) {
+            if (!Q6 && tid < BM) {
                 dyv[tid] = g_dy;
                 uint4 * dbm = (uint4 *) (Bm + tid * MI_MS);  // the Q8_K bsums are stored as f16 already
                 dbm[0] = g_bs0;
@@ -267,23 +277,23 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
     const int fr = lane & 31, kg = lane >> 5;
     const int swz = (fr >> 1) & 7;
     const int arow_off = (nslab * 32 + fr) * 128;
-    const int brow_off[2] = {(mhalf * 64 + fr) * 128, (mhalf * 64 + 32 + fr) * 128};
+    const int brow_off[2] = {(cb + fr) * 128, (cb + 32 + fr) * 128};
 
     // (the first MFMA of a super-block takes a literal zero accumulator: the integer sums never have to be cleared)
     auto mma = [&](const int h) {
         const char * buf = smem + h * STAGE;
         const char * Bt = buf + NP * TA;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int co = ((2 * ks + kg) ^ swz) << 4;
-            int4v fb[2];
+        for (int kk = 0; kk < NKS; ++kk) {
+            const int co = ((2 * (ks0 + kk) + kg) ^ swz) << 4;
+            int4v fb[NTT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) fb[t] = *(const int4v *) (Bt + brow_off[t] + co);
+            for (int t = 0; t < NTT; ++t) fb[t] = *(const int4v *) (Bt + brow_off[t] + co);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int4v fa = *(const int4v *) (buf + p * TA + arow_off + co);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[p][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[t], (h == 0 && ks == 0) ? zeroi : acc[p][t], 0, 0, 0);
+                for (int t = 0; t < NTT; ++t) acc[p][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[t], (h == 0 && kk == 0) ? zeroi : acc[p][t], 0, 0, 0);
             }
         }
     };
@@ -294,13 +304,15 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
         half8 fam;
         if constexpr (!Q6) fam = *(const half8 *) (Am + (nslab * 32 + fr) * MI_MS + kg * 16);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTT; ++t) {
             float16v am = zerof;
             if constexpr (!Q6) {
-                const half8 fbm = *(const half8 *) (Bm + (mhalf * 64 + t * 32 + fr) * MI_MS + kg * 16);
-                am = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fbm, zerof, 0, 0, 0);
+                if (KG == 1 || mhalf == 0) {  // the mins term belongs to the super-block, not to a K step: one wave group adds it
+                    const half8 fbm = *(const half8 *) (Bm + (cb + t * 32 + fr) * MI_MS + kg * 16);
+                    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fbm, zerof, 0, 0, 0);
+                }
             }
-            const float dy = dyv[mhalf * 64 + t * 32 + fr];
+            const float dy = dyv[cb + t * 32 + fr];
             const float2v dy2 = {dy, dy};
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -347,10 +359,27 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? 2 : 1) k_mmq_i8(const mmq8_
         fold();
         __syncthreads();
     }
+    if constexpr (KG == 2) {
+        // the two wave groups hold partial sums over disjoint K steps: group 1 hands its tile over through LDS (the loop ended
+        // with a barrier, the stage buffers are free)
+        float * red = (float *) smem;
+        if (mhalf == 1) {
+#pragma unroll
+            for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((nslab * NTT + t) * 16 + r) * 64 + lane] = C[t][r];
+        }
+        __syncthreads();
+        if (mhalf == 1) return;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) C[t][r] += red[((nslab * NTT + t) * 16 + r) * 64 + lane];
+    }
     // ---- store: lane holds column (token) j and 4 runs of 4 consecutive rows
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = m0 + mhalf * 64 + t * 32 + fr;
+    for (int t = 0; t < NTT; ++t) {
+        const int m = m0 + cb + t * 32 + fr;
         if (m >= a.M) continue;
         float * out = a.ksplit > 1 ? a.part + ((size_t) blockIdx.y * a.M + m) * a.N : a.dst + (size_t) m * a.dst_stride;
         const float * ad = (a.add && a.ksplit == 1) ? a.add + (size_t) m * a.add_stride : nullptr;
@@ -377,25 +406,26 @@ bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M) {
     return (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K) && (K % 256) == 0 && M >= 9;
 }
 
-template <int QT, int BN> static void launch_mmq8_t(hipStream_t s, mmq8_args a) {
+template <int QT, int BN, int BM = 128> static void launch_mmq8_t(hipStream_t s, mmq8_args a) {
     constexpr int NP = QT == 5 ? 3 : 2;
-    const size_t lds = 2 * (size_t) (NP * BN * 128 + MI_BM * 128) + (size_t) (BN + MI_BM) * MI_MS + BN * sizeof(float2) + MI_BM * sizeof(float);
+    const size_t lds = 2 * (size_t) (NP * BN * 128 + BM * 128) + (size_t) (BN + BM) * MI_MS + BN * sizeof(float2) + BM * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) k_mmq_i8<QT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) k_mmq_i8<QT, BN, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         attr_set = true;
     }
     a.n_panels = (a.N + BN - 1) / BN;
-    a.m_tiles = (a.M + MI_BM - 1) / MI_BM;
+    a.m_tiles = (a.M + BM - 1) / BM;
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
-    hipLaunchKernelGGL((k_mmq_i8<QT, BN>), dim3(grid, (unsigned) a.ksplit), dim3(BN * 4), lds, s, a);
+    hipLaunchKernelGGL((k_mmq_i8<QT, BN, BM>), dim3(grid, (unsigned) a.ksplit), dim3(BN * 4), lds, s, a);
 }
 
 // few activation columns (continuous-batching decode, M <= 64) leave N/64 x 1 workgroups — far fewer than 256 CUs — so
 // the K range is split over blockIdx.y and the partial products are summed in a fixed order by a second tiny kernel
 int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M) {
     const int64_t wgs = ((N + 63) / 64) * ((M + 127) / 128), nblk = K / 256;
-    if (M <= 64) return (int) std::max<int64_t>(1, std::min<int64_t>(nblk, 768 / std::max<int64_t>(1, wgs)));
+    static const int ks_target = getenv("GGML_MI355X_MMQ_KS_TARGET") ? atoi(getenv("GGML_MI355X_MMQ_KS_TARGET")) : 512;
+    if (M <= 64) return (int) std::max<int64_t>(1, std::min<int64_t>(nblk, ks_target / std::max<int64_t>(1, wgs)));
     // wide batches (prefill micro-batches): only when the output is too small to occupy the chip (wk/wv: 64 workgroups at
     // M = 512), or when a long K leaves exactly one workgroup per CU (ffn_down): measured 36 -> 19 us and 134 -> 117 us
     if (wgs < 256) return (int) std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, nblk / 4), 256 / wgs));
@@ -442,6 +472,20 @@ void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, in
     // 128-row panels unless that leaves CUs idle (256 CUs, one 8-wave workgroup each)
     const int64_t wg128 = (int64_t) ((N + 127) / 128) * ((M + MI_BM - 1) / MI_BM);
     const int bn = force_bn ? force_bn : (wg128 >= 256 && a.ksplit == 1 ? 128 : 64);
+    // continuous-batching decode steps: column tiles of 32 / 64 (64-row panels)
+    static const int force_bm = getenv("GGML_MI355X_MMQ_BM") ? atoi(getenv("GGML_MI355X_MMQ_BM")) : 0;
+    const int bm = force_bm ? force_bm : (M <= 32 ? 32 : (M <= 64 ? 64 : 128));
+    if (bm < 128 && bn == 64) {
+#define MMQ_SKINNY(QT)                                   \
+    {                                                    \
+        if (bm == 32) launch_mmq8_t<QT, 64, 32>(s, a);   \
+        else launch_mmq8_t<QT, 64, 64>(s, a);            \
+    }
+        if (type == GGML_TYPE_Q4_K) MMQ_SKINNY(4) else if (type == GGML_TYPE_Q5_K) MMQ_SKINNY(5) else MMQ_SKINNY(6)
+#undef MMQ_SKINNY
+        if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride, add, add_stride);
+        return;
+    }
     if (type == GGML_TYPE_Q4_K) {
         if (bn == 128) launch_mmq8_t<4, 128>(s, a);
         else launch_mmq8_t<4, 64>(s, a);

@@ -51,9 +51,10 @@ def test_mul_mat_q(backend, H, plog, qt, K, N, M):
 
 @pytest.mark.parametrize("i8,bn", [(1, 64), (1, 128), (0, 0)])
 @pytest.mark.parametrize("qt", [L.Q4_K, L.Q5_K, L.Q6_K])
-@pytest.mark.parametrize("K,N,M", [(512, 128, 128), (1024, 200, 300), (2048, 384, 512), (256, 130, 33), (4096, 256, 24)])
+@pytest.mark.parametrize("K,N,M", [(512, 128, 128), (1024, 200, 300), (2048, 384, 512), (256, 130, 33), (4096, 256, 24), (512, 200, 64), (1024, 96, 9), (2048, 384, 40), (4096, 1024, 32)])
 def test_mul_mat_q_matrix_core_variants(backend, H, plog, qt, K, N, M, i8, bn):
-    """K-quant batches: int8-MFMA kernel with 64- and 128-row panels (mmq_i8.hip) and the f16-MFMA kernel (mmq.hip)."""
+    """K-quant batches: the int8-MFMA GEMM with 64- and 128-row panels and 32 / 64 / 128-column tiles (mmq_i8.hip) and the
+    f16-MFMA kernel (mmq.hip)."""
     rng = np.random.default_rng(K * 31 + N * 7 + M + qt)
     w = T.rand_weight(qt, K, N, rng)
     x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
