@@ -66,6 +66,7 @@ struct options {
     int mmvq_max_cols = 8;     // widest single launch of the bandwidth-bound matvec kernels
     int mmq_min_cols = 9;      // batches at least this wide go to the matrix-core kernels (split-K below 65 columns); narrower ones are one 8-column mat-vec pass
     bool mmq_i8 = true;        // Q4_K/Q5_K batches on the int8 matrix cores (mmq_i8.hip) instead of the f16 variant (mmq.hip)
+    bool mm_merge = true;      // batches: sibling mat-muls over the same activations (wq/wk/wv, gate/up) as one launch
     int mmq_bn = 0;            // force the weight-panel height of mmq_i8 (64 / 128); 0 = pick by grid size
     int fa_splits = 0;         // 0 = auto
     bool small_uploads = true; // set_tensor_async of <= 64 KiB: pinned ring + copy kernel instead of a blit

@@ -147,7 +147,7 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             const ggml_tensor * b = n->src[1];
             p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], b->ne[1] * b->ne[2] * b->ne[3]));
             const int64_t Mc = b->ne[1] * b->ne[2] * b->ne[3];
-            if (Mc >= c->opt.mmq_min_cols && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc));
+            if (Mc >= c->opt.mmq_min_cols && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, 3 * mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc));  // (x3: up to three sibling matrices share a launch)
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
             const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k));
@@ -615,6 +615,86 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------ batches: sibling mat-muls
+// A batch's wq / wk / wv (and ffn_gate / ffn_up) multiply the same activations.  Launched one by one, the small ones cannot
+// fill the chip without a K split and its second kernel; as ONE launch over the concatenated row panels they can (mmq_i8.hip).
+// The siblings that follow node i in the graph are executed EARLY, at node i: legal when nothing between node i and a
+// sibling's own position reads or occupies the memory the sibling's result is written to (the graph allocator may have given
+// it a block that an earlier tensor still owns at node i's time).  Bias / residual ADDs directly after a member ride in its store.
+static bool ranges_overlap(const ggml_tensor * x, const ggml_tensor * y) {
+    if (!x->data || !y->data) return false;
+    const char * x0 = (const char *) x->data, * y0 = (const char *) y->data;
+    return x0 < y0 + ggml_abi_nbytes(y) && y0 < x0 + ggml_abi_nbytes(x);
+}
+static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number of nodes consumed at position i (0: not merged)
+    backend_ctx * c = st.c;
+    ggml_cgraph * g = st.g;
+    ggml_tensor * n0 = g->nodes[i];
+    const ggml_tensor * X = n0->src[1];
+    const int type = n0->src[0]->type;
+    const int64_t K = n0->src[0]->ne[0], M = X->ne[1] * X->ne[2] * X->ne[3];
+    struct member { int k; ggml_tensor * dst; const ggml_tensor * add; int n_nodes; };
+    auto eligible = [&](const ggml_tensor * t) {
+        const ggml_tensor * w = t->src[0];
+        return t->op == GGML_OP_MUL_MAT && t->src[1] == X && w->type == type && w->ne[0] == K && w->ne[2] == 1 && w->ne[3] == 1 && rows_contig(w) &&
+               mmq_i8_supported(w->type, K, w->ne[1], M) && (w->ne[1] % 4) == 0 && t->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(t) &&
+               !(tp_active(c) && buffer_is_rowpar(w->view_src ? w->view_src->buffer : w->buffer));
+    };
+    auto with_add = [&](int k) {  // member at node k, with the ADD that directly follows it folded in
+        ggml_tensor * t = g->nodes[k];
+        ggml_tensor * a1 = k + 1 < g->n_nodes ? g->nodes[k + 1] : nullptr;
+        const ggml_tensor * o1 = (a1 && !st.done[k + 1] && single_use(st, t)) ? add_partner(a1, t) : nullptr;
+        if (o1 && ggml_abi_is_contiguous(a1) && a1->type == GGML_TYPE_F32) return member{k, a1, o1, 2};
+        return member{k, t, nullptr, 1};
+    };
+    if (!eligible(n0)) return 0;
+    std::vector<member> ms{with_add(i)};
+    const int limit = std::min(g->n_nodes, i + 24);
+    for (int k = i + ms[0].n_nodes; k < limit && ms.size() < 3; ++k) {
+        ggml_tensor * t = g->nodes[k];
+        if (st.done[k] || !eligible(t)) continue;
+        const member m = with_add(k);
+        bool ok = true;
+        for (auto & o : ms) ok = ok && !ranges_overlap(m.dst, o.dst) && !ranges_overlap(m.dst, g->nodes[o.k]);
+        for (int j = i + 1; j < k && ok; ++j) {  // everything that runs between node i and the sibling's own position
+            const ggml_tensor * u = g->nodes[j];
+            bool is_member = false;
+            for (auto & o : ms) is_member = is_member || j == o.k || (o.n_nodes == 2 && j == o.k + 1);
+            if (!is_view_op(u) && !is_member && ranges_overlap(m.dst, u)) ok = false;
+            for (int sidx = 0; sidx < GGML_MAX_SRC && ok; ++sidx)
+                if (u->src[sidx] && ranges_overlap(m.dst, u->src[sidx])) ok = false;
+        }
+        if (ok && m.add && ranges_overlap(m.dst, m.add) && m.add->data != m.dst->data) ok = false;
+        if (ok) ms.push_back(m);
+    }
+    if (ms.size() < 2) return 0;
+    int64_t n_total = 0;
+    mmq_mat_desc mats[3];
+    double wbytes = 0;
+    for (size_t q = 0; q < ms.size(); ++q) {
+        const ggml_tensor * w = g->nodes[ms[q].k]->src[0];
+        const ggml_tensor * add = ms[q].add;
+        const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
+        if ((ms[q].dst->nb[1] % 16) != 0) return 0;
+        mats[q] = {(const uint8_t *) w->data, (int64_t) w->nb[1], (int) w->ne[1], (float *) ms[q].dst->data, (int64_t) (ms[q].dst->nb[1] / 4),
+                   add ? (const float *) add->data : nullptr, (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4)};
+        n_total += w->ne[1];
+        wbytes += (double) ggml_abi_row_size(w->type, K) * (double) w->ne[1];
+    }
+    const int ks = mmq_pick_ksplit(K, n_total, M);
+    if ((size_t) ks * (size_t) M * (size_t) n_total * sizeof(float) > c->ws_size - st.aux_off && ks > 1) return 0;
+    const void * act = quantized_src1(st, X, type);
+    {
+        timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (ms.size() == 3 ? "_x3" : "_x2")).c_str(), wbytes);
+        launch_mmq_i8_multi(c->stream, type, (int) ms.size(), mats, (int) K, (int) M, act, c->opt.mmq_bn, ks, (float *) ((char *) c->ws + st.aux_off));
+    }
+    c->st.kernel_launches += ks > 1 ? 2 : 1;
+    for (size_t q = 1; q < ms.size(); ++q)
+        for (int d = 0; d < ms[q].n_nodes; ++d) { st.done[ms[q].k + d] = 1; c->st.fused_nodes++; }
+    c->st.fused_nodes += ms[0].n_nodes - 1;
+    return ms[0].n_nodes;
+}
+
 // executes node i (possibly fusing followers); returns number of nodes consumed, or -1 on failure
 static int run_node(exec_state & st, int i) {
     backend_ctx * c = st.c;
@@ -700,6 +780,10 @@ static int run_node(exec_state & st, int i) {
                     c->st.fused_nodes += 1;
                     return 2;
                 }
+            }
+            if (fuse && !rowpar && c->opt.mm_merge && M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) {
+                const int used = try_merge_mm_batch(st, i);
+                if (used > 0) return used;
             }
             if (fuse && !rowpar && ((M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) ||
                                     (M >= 33 && mmq_q80_supported(a->type, a->ne[0], a->ne[1], M)))) {

@@ -95,6 +95,9 @@ void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, con
 bool mmq_supported(int type, int64_t K, int64_t N, int64_t M);
 size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M);
 // int8-matrix-core variant for Q4_K / Q5_K (mmq_i8.hip); force_bn: 0 = auto, 64 / 128 = weight-panel height
+struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
+// up to three matrices of one type against the same activations in one launch (wq/wk/wv, ffn_gate/ffn_up of a batch)
+void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part);
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M);
 // ksplit > 1: the K range is split over that many workgroup rows, partials in `part` (mmq_workspace_bytes), summed in a fixed order
 int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M);

@@ -28,18 +28,26 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef int int16v __attribute__((ext_vector_type(16)));
 
-struct mmq8_args {
+// Up to three weight matrices of one type that multiply the SAME activations (wq / wk / wv, ffn_gate / ffn_up) share a launch:
+// their row panels form one list (matrix i owns panels [panel0_i, panel0_{i+1})), which fills the chip where each of them
+// alone needed a K split — and a second kernel — to do so.
+struct mmq8_mat {
     const uint8_t * W;
     int64_t w_nb1;
-    int K, N, M;
-    const q8k_dev * act;  // [M][K/256]
+    int N, panel0;
     float * dst;
     int64_t dst_stride;
-    int n_panels, m_tiles;
-    int ksplit;          // > 1: blockIdx.y owns a contiguous range of super-blocks and writes its partial [M][N] result ...
-    float * part;        // ... to part + blockIdx.y * M * N (summed in a fixed order by k_splitk_reduce)
+    float * part;        // ksplit > 1: partial [ksplit][M][N] results of this matrix (summed in a fixed order by k_splitk_reduce)
     const float * add;   // optional epilogue: + add[m * add_stride + n] (bias row: stride 0, residual: stride N)
     int64_t add_stride;
+};
+struct mmq8_args {
+    mmq8_mat mat[3];
+    int n_mat;
+    int K, M;
+    const q8k_dev * act;  // [M][K/256]
+    int n_panels, m_tiles;
+    int ksplit;          // > 1: blockIdx.y owns a contiguous range of super-blocks and writes its partial result
 };
 
 constexpr int MI_BM = 128;
@@ -88,7 +96,14 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? (BM == 32 ? 3 : 2) : 1) k_m
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int panel = (qb / a.m_tiles) * 8 + xcd, mt = qb % a.m_tiles;
     if (panel >= a.n_panels) return;
-    const int n0 = panel * BN, m0 = mt * BM;
+    // the matrix this panel belongs to (selects, not indexing: the argument struct stays in the kernarg segment)
+    const int mi = (a.n_mat > 2 && panel >= a.mat[2].panel0) ? 2 : ((a.n_mat > 1 && panel >= a.mat[1].panel0) ? 1 : 0);
+#define MAT_SEL(f) (mi == 0 ? a.mat[0].f : (mi == 1 ? a.mat[1].f : a.mat[2].f))
+    const uint8_t * const mW = MAT_SEL(W);
+    const int64_t m_w_nb1 = MAT_SEL(w_nb1);
+    const int mN = MAT_SEL(N);
+    const int m_panel0 = MAT_SEL(panel0);
+    const int n0 = (panel - m_panel0) * BN, m0 = mt * BM;
     const int nblk_all = a.K / 256;
     const int sb_lo = (int) (((int64_t) blockIdx.y * nblk_all) / a.ksplit), sb_hi = (int) (((int64_t) (blockIdx.y + 1) * nblk_all) / a.ksplit);
     const int nblk = nblk_all;  // row stride of the activation blocks
@@ -98,7 +113,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? (BM == 32 ? 3 : 2) : 1) k_m
 
     // staging roles
     const int arow = tid >> 2, aq = tid & 3;
-    const uint8_t * wrow = a.W + (size_t) min(n0 + arow, a.N - 1) * a.w_nb1;
+    const uint8_t * wrow = mW + (size_t) min(n0 + arow, mN - 1) * m_w_nb1;
     // (scalars, not arrays: arrays captured by the staging lambdas end up in scratch memory)
     auto b_src = [&](const int i) { const int c = tid + i * NT; return a.act[(size_t) min(m0 + (c >> 3), a.M - 1) * nblk].qs + 16 * (c & 7); };
     auto b_off = [&](const int i) { const int c = tid + i * NT; return sw_off(c >> 3, c & 7); };
@@ -381,25 +396,28 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? (BM == 32 ? 3 : 2) : 1) k_m
     for (int t = 0; t < NTT; ++t) {
         const int m = m0 + cb + t * 32 + fr;
         if (m >= a.M) continue;
-        float * out = a.ksplit > 1 ? a.part + ((size_t) blockIdx.y * a.M + m) * a.N : a.dst + (size_t) m * a.dst_stride;
-        const float * ad = (a.add && a.ksplit == 1) ? a.add + (size_t) m * a.add_stride : nullptr;
+        float * out = a.ksplit > 1 ? MAT_SEL(part) + ((size_t) blockIdx.y * a.M + m) * mN : MAT_SEL(dst) + (size_t) m * MAT_SEL(dst_stride);
+        const float * m_add = MAT_SEL(add);
+        const float * ad = (m_add && a.ksplit == 1) ? m_add + (size_t) m * MAT_SEL(add_stride) : nullptr;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = n0 + nslab * 32 + 8 * g + 4 * kg;
             float c4[4] = {C[t][4 * g], C[t][4 * g + 1], C[t][4 * g + 2], C[t][4 * g + 3]};
             if (ad) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < a.N) c4[r] += ad[n + r];
+                for (int r = 0; r < 4; ++r) if (n + r < mN) c4[r] += ad[n + r];
             }
-            if (n + 3 < a.N && ((((uintptr_t) (out + n)) & 15) == 0)) {
+            if (n + 3 < mN && ((((uintptr_t) (out + n)) & 15) == 0)) {
                 *(float4 *) (out + n) = make_float4(c4[0], c4[1], c4[2], c4[3]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < a.N) out[n + r] = c4[r];
+                for (int r = 0; r < 4; ++r) if (n + r < mN) out[n + r] = c4[r];
             }
         }
     }
 }
+
+#undef MAT_SEL
 
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M) {
     (void) N;
@@ -414,7 +432,11 @@ template <int QT, int BN, int BM = 128> static void launch_mmq8_t(hipStream_t s,
         (void) hipFuncSetAttribute((const void *) k_mmq_i8<QT, BN, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         attr_set = true;
     }
-    a.n_panels = (a.N + BN - 1) / BN;
+    a.n_panels = 0;
+    for (int i = 0; i < a.n_mat; ++i) {
+        a.mat[i].panel0 = a.n_panels;
+        a.n_panels += (a.mat[i].N + BN - 1) / BN;
+    }
     a.m_tiles = (a.M + BM - 1) / BM;
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
     hipLaunchKernelGGL((k_mmq_i8<QT, BN, BM>), dim3(grid, (unsigned) a.ksplit), dim3(BN * 4), lds, s, a);
@@ -432,45 +454,83 @@ int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M) {
     if (wgs == 256 && nblk >= 32) return 2;
     return 1;
 }
-__global__ void __launch_bounds__(256) k_splitk_reduce(const float * __restrict__ part, const int ks, const int64_t mn, const int N, float * __restrict__ dst, const int64_t dst_stride,
-                                                       const float * __restrict__ add, const int64_t add_stride) {
-    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+struct splitk_mat { const float * part; int64_t mn; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
+struct splitk_args { splitk_mat mat[3]; int n_mat, ks; int64_t e1, e2; };  // matrix i owns float4 slots [e_i, e_{i+1}) (e0 = 0)
+__global__ void __launch_bounds__(256) k_splitk_reduce(const splitk_args a) {
+    int64_t q4 = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int mi = (a.n_mat > 2 && q4 >= a.e2) ? 2 : ((a.n_mat > 1 && q4 >= a.e1) ? 1 : 0);
+    q4 -= mi == 0 ? 0 : (mi == 1 ? a.e1 : a.e2);
+#define SK_SEL(f) (mi == 0 ? a.mat[0].f : (mi == 1 ? a.mat[1].f : a.mat[2].f))
+    const int64_t e = q4 * 4, mn = SK_SEL(mn);
     if (e >= mn) return;
+    const float * part = SK_SEL(part);
     float4 acc = *(const float4 *) (part + e);
-    for (int k = 1; k < ks; ++k) {
+    for (int k = 1; k < a.ks; ++k) {
         const float4 v = *(const float4 *) (part + (int64_t) k * mn + e);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+    const int N = SK_SEL(N);
     const int64_t m = e / N, n = e % N;  // N % 4 == 0 (checked by the launcher)
+    const float * add = SK_SEL(add);
     if (add) {
-        const float * ad = add + m * add_stride + n;
+        const float * ad = add + m * SK_SEL(add_stride) + n;
         acc.x += ad[0]; acc.y += ad[1]; acc.z += ad[2]; acc.w += ad[3];
     }
-    *(float4 *) (dst + m * dst_stride + n) = acc;
+    *(float4 *) (SK_SEL(dst) + m * SK_SEL(dst_stride) + n) = acc;
+#undef SK_SEL
+}
+static void launch_splitk_reduce_multi(hipStream_t s, const mmq8_args & g) {
+    splitk_args a{};
+    a.n_mat = g.n_mat;
+    a.ks = g.ksplit;
+    int64_t slots = 0;
+    for (int i = 0; i < g.n_mat; ++i) {
+        const mmq8_mat & m = g.mat[i];
+        a.mat[i] = {m.part, (int64_t) g.M * m.N, m.N, m.dst, m.dst_stride, m.add, m.add_stride};
+        if (i == 1) a.e1 = slots;
+        if (i == 2) a.e2 = slots;
+        slots += ((int64_t) g.M * m.N / 4 + 255) / 256 * 256;  // whole workgroups per matrix
+    }
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned) (slots / 256)), dim3(256), 0, s, a);
 }
 void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride, const float * add, int64_t add_stride) {
-    const int64_t mn = (int64_t) M * N;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned) ((mn / 4 + 255) / 256)), dim3(256), 0, s, part, ks, mn, N, dst, dst_stride, add, add_stride);
+    mmq8_args g{};
+    g.n_mat = 1;
+    g.M = M;
+    g.ksplit = ks;
+    g.mat[0].part = const_cast<float *>(part);
+    g.mat[0].N = N;
+    g.mat[0].dst = dst;
+    g.mat[0].dst_stride = dst_stride;
+    g.mat[0].add = add;
+    g.mat[0].add_stride = add_stride;
+    launch_splitk_reduce_multi(s, g);
 }
 
-void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part, const float * add, int64_t add_stride) {
-    mmq8_args a;
-    a.W = W;
-    a.w_nb1 = w_nb1;
+// n_mat (1..3) matrices of one type against the same activations; `part` holds ksplit * M * sum(N) floats when ksplit > 1
+void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part) {
+    mmq8_args a{};
+    a.n_mat = n_mat;
     a.K = K;
-    a.N = N;
     a.M = M;
     a.act = (const q8k_dev *) act_q8k;
-    a.dst = dst;
-    a.dst_stride = dst_stride;
-    a.n_panels = a.m_tiles = 0;
     a.ksplit = std::max(1, ksplit);
-    a.part = part;
-    a.add = add;
-    a.add_stride = add_stride;
+    int64_t panels128 = 0;
+    float * pp = part;
+    for (int i = 0; i < n_mat; ++i) {
+        a.mat[i].W = mats[i].W;
+        a.mat[i].w_nb1 = mats[i].w_nb1;
+        a.mat[i].N = mats[i].N;
+        a.mat[i].dst = mats[i].dst;
+        a.mat[i].dst_stride = mats[i].dst_stride;
+        a.mat[i].add = mats[i].add;
+        a.mat[i].add_stride = mats[i].add_stride;
+        a.mat[i].part = pp;
+        pp += (size_t) a.ksplit * M * mats[i].N;
+        panels128 += (mats[i].N + 127) / 128;
+    }
     // 128-row panels unless that leaves CUs idle (256 CUs, one 8-wave workgroup each)
-    const int64_t wg128 = (int64_t) ((N + 127) / 128) * ((M + MI_BM - 1) / MI_BM);
+    const int64_t wg128 = panels128 * ((M + MI_BM - 1) / MI_BM);
     const int bn = force_bn ? force_bn : (wg128 >= 256 && a.ksplit == 1 ? 128 : 64);
     // continuous-batching decode steps: column tiles of 32 / 64 (64-row panels)
     static const int force_bm = getenv("GGML_MI355X_MMQ_BM") ? atoi(getenv("GGML_MI355X_MMQ_BM")) : 0;
@@ -483,10 +543,7 @@ void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, in
     }
         if (type == GGML_TYPE_Q4_K) MMQ_SKINNY(4) else if (type == GGML_TYPE_Q5_K) MMQ_SKINNY(5) else MMQ_SKINNY(6)
 #undef MMQ_SKINNY
-        if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride, add, add_stride);
-        return;
-    }
-    if (type == GGML_TYPE_Q4_K) {
+    } else if (type == GGML_TYPE_Q4_K) {
         if (bn == 128) launch_mmq8_t<4, 128>(s, a);
         else launch_mmq8_t<4, 64>(s, a);
     } else if (type == GGML_TYPE_Q5_K) {
@@ -496,7 +553,12 @@ void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, in
         if (bn == 128) launch_mmq8_t<6, 128>(s, a);
         else launch_mmq8_t<6, 64>(s, a);
     }
-    if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride, add, add_stride);
+    if (a.ksplit > 1) launch_splitk_reduce_multi(s, a);
+}
+void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
+                   int ksplit, float * part, const float * add, int64_t add_stride) {
+    const mmq_mat_desc m{W, w_nb1, N, dst, dst_stride, add, add_stride};
+    launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part);
 }
 
 }  // namespace mi355x

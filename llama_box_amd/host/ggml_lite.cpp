@@ -828,9 +828,48 @@ static alloc_plan plan_graph(ggml_gallocr_t ga, ggml_cgraph * g) {
     };
     for (int i = 0; i < g->n_leafs; ++i)
         if (needs_alloc(g->leafs[i])) take(g->leafs[i]);  // inputs: never released
+    // ggml-alloc runs element-wise / row-wise ops IN PLACE when the parent is not needed afterwards (ggml_op_can_inplace): the
+    // result takes over the parent's block.  Mirrored here because it decides which tensors alias which in the graphs a backend
+    // sees (and a backend must be correct with dst == src).
+    auto can_inplace = [](const ggml_tensor * t) {
+        switch (t->op) {
+            case GGML_OP_SCALE: case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_UNARY: case GGML_OP_ROPE:
+            case GGML_OP_RMS_NORM: case GGML_OP_SOFT_MAX:
+                return true;
+            default:
+                return false;
+        }
+    };
+    auto same_layout = [](const ggml_tensor * a, const ggml_tensor * b) {
+        if (a->type != b->type) return false;
+        for (int d = 0; d < GGML_MAX_DIMS; ++d)
+            if (a->ne[d] != b->ne[d] || a->nb[d] != b->nb[d]) return false;
+        return true;
+    };
+    static const bool no_inplace = getenv("GGML_LITE_NO_INPLACE") != nullptr;
     for (int i = 0; i < g->n_nodes; ++i) {
         ggml_tensor * n = g->nodes[i];
-        if (needs_alloc(n)) take(n);
+        bool placed_inplace = false;
+        if (needs_alloc(n) && can_inplace(n) && !no_inplace) {
+            for (int s = 0; s < GGML_MAX_SRC && !placed_inplace; ++s) {
+                ggml_tensor * p = n->src[s];
+                if (!p || !same_layout(n, p)) continue;
+                ggml_tensor * r = root(p);
+                auto it = live.find(r);
+                if (it == live.end() || last_use[r] != i || (r->flags & (GGML_TENSOR_FLAG_OUTPUT | GGML_TENSOR_FLAG_INPUT)) || r->op == GGML_OP_NONE) continue;
+                if (p != r && p->view_offs != 0) continue;                       // a view that does not start at its source
+                if (ggml_nbytes(r) < ggml_nbytes(n)) continue;
+                bool other_src = false;                                          // the parent feeds this node twice (x * x): keep it simple
+                for (int s2 = 0; s2 < GGML_MAX_SRC; ++s2) other_src = other_src || (s2 != s && n->src[s2] && root(n->src[s2]) == r);
+                if (other_src) continue;
+                const blk b = it->second;
+                live.erase(it);
+                live[n] = b;
+                plan.placed.push_back({n, b.off});
+                placed_inplace = true;
+            }
+        }
+        if (!placed_inplace && needs_alloc(n)) take(n);
         for (int s = 0; s < GGML_MAX_SRC; ++s) {
             if (!n->src[s]) continue;
             ggml_tensor * r = root(n->src[s]);

@@ -604,6 +604,10 @@ static void build_graph(llm_context * c, int n_tokens, int n_kv, int n_outputs) 
         Vcur = ggml_reshape_3d(ctx, Vcur, HD, NKV, n_tokens);
         Qcur = named(ggml_rope_ext(ctx, Qcur, c->inp_pos, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f), "Qcur_rope", il);
         Kcur = named(ggml_rope_ext(ctx, Kcur, c->inp_pos, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f), "Kcur_rope", il);
+        // llama.cpp's build_attn adds q, k and v to the graph together before the cache stores ("so that they are not reordered")
+        ggml_build_forward_expand(gf, Qcur);
+        ggml_build_forward_expand(gf, Kcur);
+        ggml_build_forward_expand(gf, Vcur);
         // store K/V into the cache at the slots chosen for this micro-batch
         ggml_tensor * k_cache = c->k_l[il];
         ggml_tensor * v_cache = c->v_l[il];

@@ -73,6 +73,46 @@ def test_mul_mat_q_matrix_core_variants(backend, H, plog, qt, K, N, M, i8, bn):
     T.compare(f"mul_mat {QNAME[qt]} K={K} N={N} M={M} i8={i8} bn={bn}", got[0], ref[0], max_nmse=1e-10, log=plog)
 
 
+@pytest.mark.parametrize("qt", [L.Q4_K, L.Q5_K, L.Q6_K])
+@pytest.mark.parametrize("M,bias", [(32, False), (12, True), (64, True), (300, False), (512, True)])
+def test_sibling_mul_mats_share_a_launch(backend, H, plog, qt, M, bias):
+    """wq / wk / wv (and gate / up) of a batch multiply the same activations: one matrix-core launch over the concatenated row
+    panels (+ one split-K pass when the K range is split), bias ADDs folded into the store — equal to the oracle and to the
+    one-by-one execution bit for bit (same kernel, same tiles)."""
+    rng = np.random.default_rng(M * 7 + qt)
+    K, NQ, NK = 1024, 512, 128
+    wq, wk, wv = T.rand_weight(qt, K, NQ, rng), T.rand_weight(qt, K, NK, rng), T.rand_weight(qt, K, NK, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    bq, bk, bv = (rng.standard_normal(n).astype(np.float32) for n in (NQ, NK, NK))
+
+    def build(g):
+        cur = g.new(L.F32, [K, M], x)
+        outs = []
+        for w, n, b in ((wq, NQ, bq), (wk, NK, bk), (wv, NK, bv)):
+            r = H.ggml_mul_mat(g.ctx, g.new(qt, [K, n], w), cur)
+            if bias:
+                r = H.ggml_add(g.ctx, r, g.new(L.F32, [n], b))
+            outs.append(r)
+        return outs
+
+    ref = T.run_case(build, "oracle")
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    backend.set_option("mm_merge", 0)
+    try:
+        k1 = backend.stat("kernel_launches")
+        plain = T.run_case(build, backend)
+        launches_plain = backend.stat("kernel_launches") - k1
+    finally:
+        backend.set_option("mm_merge", 1)
+    plog(f"    sibling mat-muls {QNAME[qt]} M={M} bias={bias}: {launches} launches merged, {launches_plain} one by one")
+    assert launches <= 3 and launches < launches_plain  # quantise + GEMM (+ split-K pass)
+    for name, a, b, c in zip("qkv", got, ref, plain):
+        T.compare(f"sibling mat-muls {QNAME[qt]} M={M} bias={bias} {name}", a, b, max_nmse=1e-10, log=plog)
+        T.compare(f"sibling mat-muls {QNAME[qt]} M={M} bias={bias} {name} vs one by one", a, c, max_nmse=1e-12, log=plog)
+
+
 @pytest.mark.parametrize("qt", QTYPES)
 def test_mul_mat_q_3d_src1(backend, H, plog, qt):
     """src1 with ne12 > 1 (all rows of src1 are columns of the product) and a strided (permuted) src1."""
