@@ -634,9 +634,9 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     const int type = n0->src[0]->type;
     const int64_t K = n0->src[0]->ne[0], M = X->ne[1] * X->ne[2] * X->ne[3];
     struct member { int k; ggml_tensor * dst; const ggml_tensor * add; int n_nodes; };
-    auto eligible = [&](const ggml_tensor * t) {
+    auto eligible = [&](const ggml_tensor * t, bool same_type = true) {
         const ggml_tensor * w = t->src[0];
-        return t->op == GGML_OP_MUL_MAT && t->src[1] == X && w->type == type && w->ne[0] == K && w->ne[2] == 1 && w->ne[3] == 1 && rows_contig(w) &&
+        return t->op == GGML_OP_MUL_MAT && t->src[1] == X && (w->type == type) == same_type && w->ne[0] == K && w->ne[2] == 1 && w->ne[3] == 1 && rows_contig(w) &&
                mmq_i8_supported(w->type, K, w->ne[1], M) && (w->ne[1] % 4) == 0 && t->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(t) &&
                !(tp_active(c) && buffer_is_rowpar(w->view_src ? w->view_src->buffer : w->buffer));
     };
@@ -650,22 +650,28 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     if (!eligible(n0)) return 0;
     std::vector<member> ms{with_add(i)};
     const int limit = std::min(g->n_nodes, i + 24);
-    for (int k = i + ms[0].n_nodes; k < limit && ms.size() < 3; ++k) {
+    std::vector<member> others;  // siblings stored in another format: not part of the launch, but pulled forward behind it (their
+                                 // projections then no longer sit between the ropes and the cache stores: try_fuse_rope_store)
+    for (int k = i + ms[0].n_nodes; k < limit && ms.size() + others.size() < 3; ++k) {
         ggml_tensor * t = g->nodes[k];
-        if (st.done[k] || !eligible(t)) continue;
+        if (st.done[k]) continue;
+        const bool same = eligible(t), other = !same && eligible(t, false);
+        if (!same && !other) continue;
         const member m = with_add(k);
         bool ok = true;
         for (auto & o : ms) ok = ok && !ranges_overlap(m.dst, o.dst) && !ranges_overlap(m.dst, g->nodes[o.k]);
+        for (auto & o : others) ok = ok && !ranges_overlap(m.dst, o.dst) && !ranges_overlap(m.dst, g->nodes[o.k]);
         for (int j = i + 1; j < k && ok; ++j) {  // everything that runs between node i and the sibling's own position
             const ggml_tensor * u = g->nodes[j];
             bool is_member = false;
             for (auto & o : ms) is_member = is_member || j == o.k || (o.n_nodes == 2 && j == o.k + 1);
+            for (auto & o : others) is_member = is_member || j == o.k || (o.n_nodes == 2 && j == o.k + 1);
             if (!is_view_op(u) && !is_member && ranges_overlap(m.dst, u)) ok = false;
             for (int sidx = 0; sidx < GGML_MAX_SRC && ok; ++sidx)
                 if (u->src[sidx] && ranges_overlap(m.dst, u->src[sidx])) ok = false;
         }
         if (ok && m.add && ranges_overlap(m.dst, m.add) && m.add->data != m.dst->data) ok = false;
-        if (ok) ms.push_back(m);
+        if (ok) (same ? ms : others).push_back(m);
     }
     if (ms.size() < 2) return 0;
     int64_t n_total = 0;
@@ -692,7 +698,88 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     for (size_t q = 1; q < ms.size(); ++q)
         for (int d = 0; d < ms[q].n_nodes; ++d) { st.done[ms[q].k + d] = 1; c->st.fused_nodes++; }
     c->st.fused_nodes += ms[0].n_nodes - 1;
+    for (auto & o : others) {
+        if (!run_mul_mat_q(st, g->nodes[o.k]->src[0], nullptr, X, o.dst, o.add, nullptr)) return -1;
+        for (int d = 0; d < o.n_nodes; ++d) st.done[o.k + d] = 1;
+        c->st.fused_nodes += o.n_nodes - 1;
+    }
     return ms[0].n_nodes;
+}
+
+// ------------------------------------------------------------------------------------------------ batches: rope + cache stores
+// At ROPE(q) of a batch: ROPE(k) with the same parameters and positions, SET_ROWS(k cache <- rope(k)) and SET_ROWS(v cache <- v)
+// with one index vector follow (llama.cpp's build_attn: q, k, v expanded together, then cpy_k / cpy_v) — four launches that
+// each sit at the launch floor for a few dozen tokens.  When only views (and the K / V projections already executed with the Q
+// projection: try_merge_mm_batch) sit between them, they run as one (ops.hip: k_rope_qk_store); absorbed nodes are flagged done.
+static const ggml_tensor * through_views(const ggml_tensor * t) {
+    while (t && (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW) && t->src[0] && t->data == t->src[0]->data) t = t->src[0];
+    return t;
+}
+static bool try_fuse_rope_store(exec_state & st, int i) {
+    backend_ctx * c = st.c;
+    ggml_cgraph * g = st.g;
+    const ggml_tensor * rq = g->nodes[i];
+    const ggml_tensor * q = rq->src[0];
+    if (rq->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(rq) || q->type != GGML_TYPE_F32 || q->nb[0] != 4 || rq->ne[3] != 1 || rq->ne[2] < 2) return false;
+    if ((rq->op_params[2] & GGML_ROPE_TYPE_MROPE) || rq->src[1]->type != GGML_TYPE_I32 || !ggml_abi_is_contiguous(rq->src[1])) return false;
+    const int limit = std::min(g->n_nodes, i + 16);
+    int jk = -1, jks = -1, jvs = -1;
+    for (int k = i + 1; k < limit; ++k) {
+        const ggml_tensor * t = g->nodes[k];
+        if (st.done[k] || is_view_op(t)) continue;
+        if (t->op == GGML_OP_ROPE && jk < 0) { jk = k; continue; }
+        if (t->op == GGML_OP_SET_ROWS && jk >= 0 && jks < 0 && through_views(t->src[0]) == g->nodes[jk]) { jks = k; continue; }
+        if (t->op == GGML_OP_SET_ROWS && jks >= 0 && jvs < 0) { jvs = k; break; }
+        return false;  // anything else inside the window: leave the nodes alone
+    }
+    if (jk < 0 || jks < 0 || jvs < 0) return false;
+    const ggml_tensor * rk = g->nodes[jk];
+    const ggml_tensor * ks = g->nodes[jks];
+    const ggml_tensor * vs = g->nodes[jvs];
+    const ggml_tensor * ksrc = rk->src[0];
+    const ggml_tensor * vsrc = vs->src[0];
+    if (memcmp(rk->op_params, rq->op_params, sizeof(rq->op_params)) != 0 || rk->src[1] != rq->src[1] || rk->src[2] != rq->src[2]) return false;
+    if (rk->type != GGML_TYPE_F32 || ksrc->type != GGML_TYPE_F32 || ksrc->nb[0] != 4 || rk->ne[0] != rq->ne[0] || rk->ne[2] != rq->ne[2] || rk->ne[3] != 1) return false;
+    if (use_count(st, rk) != 1 || (rk->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;  // rope(k) lives only in the cache
+    const int64_t HD = rq->ne[0], NH = rq->ne[1], NKV = rk->ne[1], T = rq->ne[2];
+    // cache stores: f16 rows of NKV * HD values, one I64 index per token, both stores through the same indices
+    auto store_ok = [&](const ggml_tensor * sr, const ggml_tensor * src) {
+        return sr->type == GGML_TYPE_F16 && sr->nb[0] == 2 && sr->ne[0] == NKV * HD && src->ne[0] == NKV * HD && ggml_abi_nelements(src) == NKV * HD * T &&
+               sr->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(sr->src[1]) == T && ggml_abi_is_contiguous(sr->src[1]);
+    };
+    if (!store_ok(ks, ks->src[0]) || !store_ok(vs, vsrc) || ks->src[1]->data != vs->src[1]->data) return false;
+    if (vsrc->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(vsrc) || !ggml_abi_is_contiguous(ksrc) || ksrc->ne[0] != HD || ksrc->ne[1] != NKV) return false;
+    if ((rq->op_params[1] % 2) != 0 || rq->op_params[1] > HD) return false;
+    rope_store_args a{};
+    a.q_src = (const char *) q->data;
+    a.q_dst = (char *) rq->data;
+    a.k_src = (const char *) ksrc->data;
+    a.v_src = (const char *) vsrc->data;
+    a.q_nb1 = (int64_t) q->nb[1]; a.q_nb2 = (int64_t) q->nb[2];
+    a.qd_nb1 = (int64_t) rq->nb[1]; a.qd_nb2 = (int64_t) rq->nb[2];
+    a.k_nb1 = (int64_t) ksrc->nb[1]; a.k_nb2 = (int64_t) ksrc->nb[2];
+    a.v_nb1 = HD * 4; a.v_nb2 = NKV * HD * 4;
+    a.k_cache = (char *) ks->data; a.v_cache = (char *) vs->data;
+    a.kc_nb1 = (int64_t) ks->nb[1]; a.vc_nb1 = (int64_t) vs->nb[1];
+    a.idx = (const int64_t *) ks->src[1]->data;
+    a.pos = (const int32_t *) rq->src[1]->data;
+    a.ff = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
+    a.p.n_dims = rq->op_params[1];
+    a.p.mode = rq->op_params[2];
+    a.p.n_ctx_orig = rq->op_params[4];
+    a.p.freq_base = ggml_abi_op_param_f32(rq, 5);
+    a.p.freq_scale = ggml_abi_op_param_f32(rq, 6);
+    a.p.ext_factor = ggml_abi_op_param_f32(rq, 7);
+    a.p.attn_factor = ggml_abi_op_param_f32(rq, 8);
+    a.p.beta_fast = ggml_abi_op_param_f32(rq, 9);
+    a.p.beta_slow = ggml_abi_op_param_f32(rq, 10);
+    memset(a.p.sections, 0, sizeof(a.p.sections));
+    a.nh = (int) NH; a.nkv = (int) NKV; a.head_dim = (int) HD;
+    timed_scope ts(c, "rope_qk_store", (double) ggml_abi_nbytes(rq) * 2);
+    launch_rope_qk_store(c->stream, a, (int) T);
+    c->st.kernel_launches++;
+    for (int k : {jk, jks, jvs}) { st.done[k] = 1; c->st.fused_nodes++; }
+    return true;
 }
 
 // executes node i (possibly fusing followers); returns number of nodes consumed, or -1 on failure
@@ -783,7 +870,7 @@ static int run_node(exec_state & st, int i) {
             }
             if (fuse && !rowpar && c->opt.mm_merge && M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) {
                 const int used = try_merge_mm_batch(st, i);
-                if (used > 0) return used;
+                if (used != 0) return used;
             }
             if (fuse && !rowpar && ((M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) ||
                                     (M >= 33 && mmq_q80_supported(a->type, a->ne[0], a->ne[1], M)))) {
@@ -868,6 +955,7 @@ static int run_node(exec_state & st, int i) {
             return 1;
         }
         case GGML_OP_ROPE: {
+            if (fuse && try_fuse_rope_store(st, i)) return 1;
             rope_params p;
             p.n_dims = n->op_params[1];
             p.mode = n->op_params[2];

@@ -133,6 +133,20 @@ struct rope_params {
     int sections[4];  // ggml_rope_multi (mode & GGML_ROPE_TYPE_MROPE): pairs per position stream (time, height, width, extra)
 };
 void rope_host_consts(const rope_params & p, float & theta_scale, float & corr0, float & corr1);
+// batches: ROPE(q) + ROPE(k) + SET_ROWS(k) + SET_ROWS(v) in one launch (f32 sources [head_dim, heads, tokens], f16 cache rows)
+struct rope_store_args {
+    const char * q_src; char * q_dst; const char * k_src; const char * v_src;
+    int64_t q_nb1, q_nb2, qd_nb1, qd_nb2, k_nb1, k_nb2, v_nb1, v_nb2;
+    char * k_cache; char * v_cache;
+    int64_t kc_nb1, vc_nb1;
+    const int64_t * idx;
+    const int32_t * pos;
+    const float * ff;
+    rope_params p;
+    float theta_scale, corr0, corr1;
+    int nh, nkv, head_dim;
+};
+void launch_rope_qk_store(hipStream_t s, rope_store_args a, int n_tokens);
 void launch_rope(hipStream_t s, const tdesc & src, const tdesc & pos, const float * freq_factors, const tdesc & dst, const rope_params & p);
 void launch_soft_max(hipStream_t s, const tdesc & src, const tdesc * mask, const float * sinks, const tdesc & dst, float scale, float max_bias);
 

@@ -453,6 +453,57 @@ void rope_host_consts(const rope_params & p, float & theta_scale, float & c0, fl
     c0 = fmaxf(0.0f, floorf(corr_dim(p.beta_fast)));
     c1 = fminf((float) (p.n_dims - 1), ceilf(corr_dim(p.beta_slow)));
 }
+// Batches: ROPE(q), ROPE(k) -> SET_ROWS(k cache), SET_ROWS(v cache) as ONE launch (four nodes of every layer; at a few
+// dozen tokens each of them sits at the dependent-launch floor).  One 64-lane workgroup per (head slot, token): slots [0, nh) rotate
+// a query head f32 -> f32 (in place when the allocator made the rope in-place), [nh, nh + nkv) rotate a key head and store it as
+// f16 into the cache row the token's index names, the rest convert a value head.  Arithmetic per element is that of k_rope
+// followed by k_set_rows (f32 result, then one f16 rounding), so fused and unfused graphs agree bit for bit.
+__global__ void __launch_bounds__(64) k_rope_qk_store(const rope_store_args a) {
+    const int slot = blockIdx.x;
+    const int64_t t = blockIdx.y;
+    const float pos_f = (float) a.pos[t];
+    const int n_pairs = a.p.n_dims / 2;
+    const bool neox = (a.p.mode & GGML_ROPE_TYPE_NEOX) != 0;
+    const rope_consts rc{a.theta_scale, a.p.freq_scale, a.p.ext_factor, a.p.attn_factor, a.corr0, a.corr1};
+    if (slot < a.nh) {
+        const float * src = (const float *) (a.q_src + slot * a.q_nb1 + t * a.q_nb2);
+        float * dst = (float *) (a.q_dst + slot * a.qd_nb1 + t * a.qd_nb2);
+        for (int ip = threadIdx.x; ip < n_pairs; ip += 64) {
+            const int ia = neox ? ip : 2 * ip, ib = neox ? ip + n_pairs : 2 * ip + 1;
+            const float x0 = src[ia], x1 = src[ib];
+            float cs, sn;
+            rope_cos_sin(ip, pos_f, a.ff, rc, cs, sn);
+            dst[ia] = x0 * cs - x1 * sn;
+            dst[ib] = x0 * sn + x1 * cs;
+        }
+        for (int i0 = a.p.n_dims + threadIdx.x; i0 < a.head_dim; i0 += 64) dst[i0] = src[i0];
+        return;
+    }
+    const int64_t row = a.idx[t];
+    if (slot < a.nh + a.nkv) {
+        const int h = slot - a.nh;
+        const float * src = (const float *) (a.k_src + h * a.k_nb1 + t * a.k_nb2);
+        uint16_t * dst = (uint16_t *) (a.k_cache + row * a.kc_nb1) + (int64_t) h * a.head_dim;
+        for (int ip = threadIdx.x; ip < n_pairs; ip += 64) {
+            const int ia = neox ? ip : 2 * ip, ib = neox ? ip + n_pairs : 2 * ip + 1;
+            const float x0 = src[ia], x1 = src[ib];
+            float cs, sn;
+            rope_cos_sin(ip, pos_f, a.ff, rc, cs, sn);
+            dst[ia] = f2h(x0 * cs - x1 * sn);
+            dst[ib] = f2h(x0 * sn + x1 * cs);
+        }
+        for (int i0 = a.p.n_dims + threadIdx.x; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(src[i0]);
+        return;
+    }
+    const int h = slot - a.nh - a.nkv;
+    const float * src = (const float *) (a.v_src + h * a.v_nb1 + t * a.v_nb2);
+    uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * a.head_dim;
+    for (int i0 = threadIdx.x; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(src[i0]);
+}
+void launch_rope_qk_store(hipStream_t s, rope_store_args a, int n_tokens) {
+    rope_host_consts(a.p, a.theta_scale, a.corr0, a.corr1);
+    hipLaunchKernelGGL(k_rope_qk_store, dim3((unsigned) (a.nh + 2 * a.nkv), (unsigned) n_tokens), dim3(64), 0, s, a);
+}
 void launch_rope(hipStream_t s, const tdesc & a, const tdesc & pos, const float * ff, const tdesc & d, const rope_params & p) {
     float theta_scale, c0, c1;
     rope_host_consts(p, theta_scale, c0, c1);

@@ -755,6 +755,48 @@ def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias, kvt):
             assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused q8_0 cache rows differ"
 
 
+@pytest.mark.parametrize("mode,n_dims,T_", [(0, 128, 32), (L.ROPE_NEOX, 128, 5), (0, 64, 130)])
+def test_batch_rope_and_cache_stores_one_launch(backend, H, plog, mode, n_dims, T_):
+    """A batch's ROPE(q), ROPE(k), SET_ROWS(k cache), SET_ROWS(v cache) run as one launch (k_rope_qk_store) and equal both the
+    oracle and the node-by-node execution bit for bit."""
+    rng = np.random.default_rng(41 + T_)
+    HD, NH, NKV, NCTX = 128, 8, 2, 300
+    q = rng.standard_normal((T_, NH, HD)).astype(np.float32)
+    k = rng.standard_normal((T_, NKV, HD)).astype(np.float32)
+    v = rng.standard_normal((T_, NKV * HD)).astype(np.float32)
+    pos = rng.integers(0, 5000, T_).astype(np.int32)
+    rows = rng.permutation(NCTX)[:T_].astype(np.int64)
+    kc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    vc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+
+    def build(g):
+        tp = g.new(L.I32, [T_], pos)
+        idx = g.new(L.I64, [T_], rows)
+        # (the reshapes stand where llm_build_* has them: the projections come out 2-D)
+        q3 = H.ggml_reshape_3d(g.ctx, g.new(L.F32, [NH * HD, T_], q), HD, NH, T_)
+        k3 = H.ggml_reshape_3d(g.ctx, g.new(L.F32, [NKV * HD, T_], k), HD, NKV, T_)
+        qr = H.ggml_rope_ext(g.ctx, q3, tp, None, n_dims, mode, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        kr = H.ggml_rope_ext(g.ctx, k3, tp, None, n_dims, mode, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], kc0), H.ggml_reshape_2d(g.ctx, kr, NKV * HD, T_), idx)
+        vs = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], vc0), g.new(L.F32, [NKV * HD, T_], v), idx)
+        return [qr, ks, vs]
+
+    ref = T.run_case(build, "oracle")
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    backend.set_option("fusion", 0)
+    try:
+        plain = T.run_case(build, backend)
+    finally:
+        backend.set_option("fusion", 1)
+    assert launches == 1, launches
+    for name, a, b, c in zip(("q_rope", "k_cache", "v_cache"), got, ref, plain):
+        assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused differ"
+        T.compare(f"batch rope+store T={T_} mode={mode} n_dims={n_dims} {name}", np.asarray(a).astype(np.float32), np.asarray(b).astype(np.float32),
+                  max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
+
+
 # ------------------------------------------------------------------------------------------------ fused chains
 @pytest.mark.parametrize("qt", QTYPES)
 @pytest.mark.parametrize("M", [1, 4, 32, 130])
