@@ -533,6 +533,7 @@ struct llm_context {
     ggml_tensor * t_logits = nullptr;
     // outputs
     std::vector<float> logits;
+    float * logits_base = nullptr;  // where the last llm_decode's rows are: the pinned output area, or `logits`
     int n_outputs = 0;
     double timings[4] = {0, 0, 0, 0};
     // pinned host staging, as llama.cpp does it (inputs are uploaded with tensor_set_async out of host-buffer-type memory,
@@ -920,11 +921,14 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     }
     const double t2 = now_us();
     const size_t logit_bytes = (size_t) n_outputs * m->n_vocab_l * 4;
-    const bool async_out = async_io && n_outputs > 0 && n_outputs <= c->pin_out_rows;
+    // (logits_out inside the pinned output area: llm_decode found room for ALL outputs of the call there — the device writes the
+    // rows where llm_get_logits will read them, as llama.cpp's pinned output buffer works; otherwise staged + copied)
+    const bool direct_out = c->pin != nullptr && (char *) logits_out >= pin_out && (char *) logits_out < pin_out + (size_t) c->pin_out_rows * m->n_vocab_l * 4;
+    const bool async_out = async_io && n_outputs > 0 && (direct_out || n_outputs <= c->pin_out_rows);
     enum ggml_status st;
     if (async_io) {
         st = ggml_backend_graph_compute_async(c->backend, c->gf);
-        if (st == GGML_STATUS_SUCCESS && async_out) ggml_backend_tensor_get_async(c->backend, c->t_logits, pin_out, 0, logit_bytes);
+        if (st == GGML_STATUS_SUCCESS && async_out) ggml_backend_tensor_get_async(c->backend, c->t_logits, direct_out ? (void *) logits_out : (void *) pin_out, 0, logit_bytes);
         if (n_outputs > 0 || st != GGML_STATUS_SUCCESS || !defer_sync) {
             ggml_backend_synchronize(c->backend);
             c->in_flight = 0;
@@ -940,8 +944,8 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
         return -2;
     }
     if (n_outputs > 0) {
-        if (async_out) memcpy(logits_out, pin_out, logit_bytes);
-        else ggml_backend_tensor_get(c->t_logits, logits_out, 0, logit_bytes);
+        if (async_out && !direct_out) memcpy(logits_out, pin_out, logit_bytes);
+        else if (!async_out) ggml_backend_tensor_get(c->t_logits, logits_out, 0, logit_bytes);
         *n_out_acc += n_outputs;
     }
     const double t4 = now_us();
@@ -958,13 +962,20 @@ extern "C" int llm_decode(struct llm_context * c, int n_tokens, const int32_t * 
         if (tokens[i] < 0 || tokens[i] >= c->model->hp.n_vocab || pos[i] < 0) return -1;
     int n_total_out = 0;
     for (int i = 0; i < n_tokens; ++i) n_total_out += (!want_logits || want_logits[i]) ? 1 : 0;
-    c->logits.resize((size_t) std::max(1, n_total_out) * c->model->n_vocab_l);
+    // outputs land in the pinned area when they all fit (one sampled row per sequence: always, up to 64 sequences)
+    const bool pinned_out = c->backend != nullptr && c->pin != nullptr && n_total_out <= c->pin_out_rows;
+    if (pinned_out) {
+        c->logits_base = (float *) (c->pin + (size_t) llm_context::PIN_SLOTS * c->pin_in_bytes);
+    } else {
+        c->logits.resize((size_t) std::max(1, n_total_out) * c->model->n_vocab_l);
+        c->logits_base = c->logits.data();
+    }
     c->n_outputs = 0;
     for (int k = 0; k < 4; ++k) c->timings[k] = 0;
     for (int i0 = 0; i0 < n_tokens; i0 += c->p.n_ubatch) {
         const int n = std::min(c->p.n_ubatch, n_tokens - i0);
         int rc = decode_ubatch(c, n, tokens + i0, pos + i0, seq_id ? seq_id + i0 : nullptr, want_logits ? want_logits + i0 : nullptr,
-                               c->logits.data() + (size_t) c->n_outputs * c->model->n_vocab_l, &c->n_outputs, /*defer_sync=*/i0 + n < n_tokens);
+                               c->logits_base + (size_t) c->n_outputs * c->model->n_vocab_l, &c->n_outputs, /*defer_sync=*/i0 + n < n_tokens);
         if (rc != 0) {
             if (c->backend && c->in_flight) { ggml_backend_synchronize(c->backend); c->in_flight = 0; }
             return rc;
@@ -991,10 +1002,10 @@ extern "C" int llm_decode_steps(struct llm_context * c, int n_steps, int n_par, 
     return 0;
 }
 extern "C" int llm_n_outputs(const struct llm_context * c) { return c->n_outputs; }
-extern "C" float * llm_get_logits(struct llm_context * c) { return c->logits.data(); }
+extern "C" float * llm_get_logits(struct llm_context * c) { return c->logits_base; }
 extern "C" float * llm_get_logits_ith(struct llm_context * c, int i) {
     if (i < 0 || i >= c->n_outputs) return nullptr;
-    return c->logits.data() + (size_t) i * c->model->n_vocab_l;
+    return c->logits_base + (size_t) i * c->model->n_vocab_l;
 }
 extern "C" struct ggml_cgraph * llm_last_graph(struct llm_context * c) { return c->gf; }
 extern "C" void llm_last_timings(const struct llm_context * c, double out[4]) {
