@@ -279,7 +279,13 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
         ti = split * share;
         ti1 = min(cnt, ti + share);
         if (ti >= ti1) {
-            if (tid < g_real) {
+            if (geo.n_splits == 1) {
+                // a token that sees nothing and no combine pass to say so: the CPU's result for such a row is 0 * (1 / 0) = NaN
+                for (int e = tid; e < g_real * 128; e += 256) {
+                    float * out = (float *) (dst.data + (int64_t) (kvh * g_real + e / 128) * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+                    out[e % 128] = __builtin_nanf("");
+                }
+            } else if (tid < g_real) {
                 float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + kvh * g_real + tid) * geo.n_splits + split) * (128 + 2);
                 rec[128] = -INFINITY;
                 rec[129] = 0.0f;
@@ -620,6 +626,8 @@ int fattn_pick_splits(const tdesc & q, const tdesc & k) {
         // a few tokens at head_dim 128 (continuous-batching decode, speculative batches): the tile-list kernel — every split takes a
         // share of the token's VISIBLE tiles, so the count follows the number of (token, kv head) groups, not the cache size
         const int64_t groups = k.ne[2] * q.ne[1];
+        // (one pass without a combine was tried for -np 32 — 256 groups fill the chip by themselves — and lost: a trip of this
+        // kernel is a ~4 us dependent chain, three of them in sequence cost more than split + combine)
         return (int) std::max<int64_t>(2, std::min<int64_t>(16, (768 + groups - 1) / groups));
     }
     if (q.ne[1] > 1) {  // a few tokens, other head sizes: short splits
@@ -715,7 +723,7 @@ int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const 
     const int G = k.ne[2] > 0 ? (int) (q.ne[2] / k.ne[2]) : 0;
     static const bool on = !getenv("GGML_MI355X_FA_LIST") || atoi(getenv("GGML_MI355X_FA_LIST")) != 0;
     if (!on || n_q < 2 || n_q >= fattn_mma_min_q() || !mask || q.ne[3] != 1 || mask->ne[3] != 1 || k.ne[0] != 128) return 0;
-    if (p.logit_softcap != 0.0f || p.max_bias != 0.0f || !(G == 2 || G == 4 || G == 7 || G == 8) || p.n_splits < 2) return 0;
+    if (p.logit_softcap != 0.0f || p.max_bias != 0.0f || !(G == 2 || G == 4 || G == 7 || G == 8) || p.n_splits < 1) return 0;
     if ((k.ne[1] % 4) != 0 || (mask->nb[1] % 8) != 0 || ((uintptr_t) mask->data & 7) != 0 || mask->type != GGML_TYPE_F16) return 0;
     const int tile = 16 * (16 / (G == 7 ? 8 : G));
     const int64_t stride = (k.ne[1] + tile - 1) / tile + 1;
