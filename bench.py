@@ -274,14 +274,16 @@ def main():
                             "flop_per_token": round(flop_tok), "note": "dense f16 MFMA peak; the GEMMs run on the int8 matrix cores (2x rate) with two digit passes per weight"}
     if rank == 0:
         w_bytes = model.stream_bytes()
-        kv_per_tok = 2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * 2
+        kv_per_tok = int(2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * (34 / 32 if args.ctkv == "q8_0" else 2))
         n_past = args.prefill + args.warmup + args.steps // 2
         job_bytes = (w_bytes + args.np * kv_per_tok * n_past) * (tok_s / streams / args.np)
         out = {
-            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M",
+            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M" if args.preset == "llama3-8b-q4_k_m" and args.np == 1 else
+                      f"decode tokens/sec ({'batch-1' if args.np == 1 else f'-np {args.np} aggregate'}) + prefill tok/s, {args.preset} [secondary configuration, not the headline metric]",
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None, "dtype": "q4_K/q6_K weights x q8_K activations (int8 dot, f32 accumulate)",
+            "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None,
+            "dtype": ("q8_0 weights x q8_0 activations" if "q8_0" in args.preset else ("q5_K/q6_K" if "q5_k" in args.preset else "q4_K/q6_K") + " weights x q8_K activations") + " (int8 dot, f32 accumulate)",
             "data": "synthetic (GGUF-exact tensor set, directly sampled quant blocks, random token ids)",
             "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode, flash_attn={args.fa}, kv_cache={args.ctkv}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
                        "parallelism": parallelism, "n_past_mid": n_past, "weight_bytes_per_token_per_gpu": w_bytes, "kv_bytes_per_token_per_gpu": kv_per_tok * n_past},
