@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--fa", type=int, default=1)
     ap.add_argument("--np", type=int, default=1, help="parallel sequences decoded per step (llama-box -np continuous batching)")
     ap.add_argument("--ubatch", type=int, default=512)
+    ap.add_argument("--n-batch", type=int, default=2048, dest="n_batch", help="prompt tokens per llama_decode call (llama-box -b); several slots' prompts share a call")
     ap.add_argument("--ctkv", default="f16", choices=["f16", "q8_0"], help="KV cache type (llama-box --cache-type-k / --cache-type-v); the headline metric is quoted on f16")
     ap.add_argument("--layers", type=int, default=0, help="debug only: override n_layer (result is then NOT a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,8 +167,18 @@ def main():
     if args.prefill > 0:
         sync()
         t0 = time.perf_counter()
-        for sq in range(args.np):  # llama-box never mixes prefill and decode in one batch (httpserver.hpp:3742, :4042)
-            rc, _ = ctx.decode(toks[sq * args.prefill: (sq + 1) * args.prefill], range(args.prefill), seq=[sq] * args.prefill, want=[0] * (args.prefill - 1) + [1])
+        # llama-box never mixes prefill and decode in one batch (httpserver.hpp:3742, :4042), but it does fill a batch with the prompt
+        # tokens of several slots up to n_batch (2048): prompts go in whole, as many per llama_decode as fit
+        per_call = max(1, args.n_batch // args.prefill)
+        for s0 in range(0, args.np, per_call):
+            sqs = range(s0, min(args.np, s0 + per_call))
+            tk, ps, sq_ids, wt = [], [], [], []
+            for sq in sqs:
+                tk.extend(toks[sq * args.prefill: (sq + 1) * args.prefill])
+                ps.extend(range(args.prefill))
+                sq_ids.extend([sq] * args.prefill)
+                wt.extend([0] * (args.prefill - 1) + [1])
+            rc, _ = ctx.decode(tk, ps, seq=sq_ids, want=wt)
             assert rc == 0, f"prefill failed rc={rc}"
         torch.cuda.synchronize()
         t1 = time.perf_counter()

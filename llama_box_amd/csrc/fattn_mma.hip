@@ -34,7 +34,8 @@ struct fam_geom {
 
 // NW waves of 32 queries each share one staged K/V tile (NW = 4: 128 queries per workgroup, half the staging work per query)
 template <int D, int NW>
-__global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo, float * __restrict__ ws) {
+__global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo, float * __restrict__ ws,
+                                                       const uint8_t * __restrict__ vis) {
     constexpr int BKV = 64;
     constexpr int KS = (D + 8) * 2;    // K tile row stride (bytes): odd multiple of 16 -> conflict-free ds_read_b128
     constexpr int VS = (BKV + 4) * 2;  // V^T tile row stride (bytes): 34 dwords -> conflict-free ds_read_b64 across 32 rows
@@ -83,7 +84,19 @@ __global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdes
     const int srow = tid / NW, spart = tid % NW;
     constexpr int CH = D / (8 * NW);  // 16-byte chunks per thread per tile
 
+    // vis (k_fattn_vis_scan, once per graph run — the mask is the same tensor in every layer): byte [q tile of 32][kv tile of 64] says
+    // whether ANY of the 32 queries can see ANY of the 64 cells.  A causal prompt chunk skips the tiles above its diagonal; a
+    // continuous batch's prompt chunks (each sequence sees only its own cells of the unified cache) skip almost everything.
+    const uint8_t * visrow = vis ? vis + (int64_t) (blockIdx.x * NW) * tiles : nullptr;
+    const int n_qt = (geo.n_q + 31) / 32;
     for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
+        if (visrow) {  // workgroup-uniform: every thread evaluates the same NW bytes
+            const int kt = kv0 / BKV;
+            bool any = false;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) any = any || ((int) blockIdx.x * NW + w < n_qt && visrow[(int64_t) w * tiles + kt] != 0);
+            if (!any) continue;
+        }
         __syncthreads();
         {
             const int pos = min(kv0 + srow, geo.n_kv - 1);
@@ -218,6 +231,34 @@ int fattn_mma_pick_splits(const tdesc & q, const tdesc & k) {
     want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, tiles / 4)));
     return (int) want;
 }
+// one workgroup per 32-query tile; thread t looks at kv tile t, t + 256, ...: 32 mask rows x 64 cells (f16) each
+__global__ void __launch_bounds__(256) k_fattn_vis_scan(const tdesc mask, const int n_q, const int n_kv, uint8_t * __restrict__ vis) {
+    const int qt = blockIdx.x, tiles = (n_kv + 63) / 64;
+    for (int kt = threadIdx.x; kt < tiles; kt += 256) {
+        bool any = false;
+        for (int r = 0; r < 32 && !any; ++r) {
+            const int qi = qt * 32 + r;
+            if (qi >= n_q) break;
+            const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) qi * mask.nb[1]) + kt * 64;
+#pragma unroll
+            for (int c = 0; c < 64; c += 8) {
+                if (kt * 64 + c < n_kv) {  // n_kv % 4 == 0 and rows 8-byte aligned (launcher); a tail of 4 cells is read as 8 only when in range
+                    const uint2 w0 = *(const uint2 *) (mrow + c);
+                    any = any || w0.x != 0xFC00FC00u || w0.y != 0xFC00FC00u;
+                    if (kt * 64 + c + 4 < n_kv) {
+                        const uint2 w1 = *(const uint2 *) (mrow + c + 4);
+                        any = any || w1.x != 0xFC00FC00u || w1.y != 0xFC00FC00u;
+                    }
+                }
+            }
+        }
+        vis[(int64_t) qt * tiles + kt] = any ? 1 : 0;
+    }
+}
+size_t fattn_vis_bytes(const tdesc & q, const tdesc & k) { return (size_t) ((q.ne[1] + 31) / 32) * (size_t) ((k.ne[1] + 63) / 64); }
+void launch_fattn_vis_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, uint8_t * vis) {
+    hipLaunchKernelGGL(k_fattn_vis_scan, dim3((unsigned) ((n_q + 31) / 32)), dim3(256), 0, s, mask, n_q, n_kv, vis);
+}
 int fattn_mma_min_q() {
     // up to 32 query tokens are served per token (tile-list / lane-parallel kernels): a -np 32 decode step has 32 tokens that
     // each see their own 1/32 of a unified cache, which a dense 32-query tile would multiply through in full
@@ -249,12 +290,12 @@ bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, cons
     dim3 grid((unsigned) ((geo.n_q + nw * 32 - 1) / (nw * 32)), (unsigned) geo.n_head, (unsigned) (q.ne[3] * geo.n_splits));
     if (D == 128) {
         const size_t lds = 64 * (128 + 8) * 2 + 128 * (64 + 4) * 2;
-        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<128, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws);
-        else hipLaunchKernelGGL((k_fattn_mma<128, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws);
+        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<128, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
+        else hipLaunchKernelGGL((k_fattn_mma<128, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
     } else {
         const size_t lds = 64 * (64 + 8) * 2 + 64 * (64 + 4) * 2;
-        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<64, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws);
-        else hipLaunchKernelGGL((k_fattn_mma<64, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws);
+        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<64, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
+        else hipLaunchKernelGGL((k_fattn_mma<64, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
     }
     if (geo.n_splits > 1) launch_flash_attn_combine(s, (int) k.ne[0], ws, sinks, dst, (int) q.ne[1], (int) q.ne[2], (int) q.ne[3], geo.n_splits);
     return true;

@@ -995,6 +995,16 @@ static int run_node(exec_state & st, int i) {
                         st.fa_list_tile = tile;
                     }
                     p.lists = c->fa_lists;
+                } else if (m && a->ne[1] >= fattn_mma_min_q() && a->ne[3] == 1 && m->ne[3] == 1 && m->type == GGML_TYPE_F16 && (m->nb[1] % 8) == 0 && !(((uintptr_t) m->data) & 7) &&
+                           (k->ne[1] % 4) == 0 && fattn_vis_bytes(qd, kd) <= c->fa_lists_bytes && flash_attn_mma_applies(qd, kd, &md, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p)) {
+                    // prompt batches on the matrix-core kernel: which (query tile, kv tile) pairs hold anything visible — once per graph run
+                    if (st.fa_list_mask != m->data || st.fa_list_tile != -1) {
+                        launch_fattn_vis_scan(s, md, (int) a->ne[1], (int) k->ne[1], (uint8_t *) c->fa_lists);
+                        c->st.kernel_launches++;
+                        st.fa_list_mask = m->data;
+                        st.fa_list_tile = -1;
+                    }
+                    p.tile_vis = (const uint8_t *) c->fa_lists;
                 }
             }
             launch_flash_attn(s, qd, kd, vd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p, (char *) c->ws + st.aux_off);

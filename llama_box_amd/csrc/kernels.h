@@ -156,7 +156,10 @@ struct fattn_params {
     int n_splits;  // KV splits per (token, kv-head group)
     int kv_type;   // GGML_TYPE_F16 or GGML_TYPE_Q8_0 (K and V alike)
     const int * lists = nullptr;  // per-token lists of visible tiles (launch_fattn_tile_scan), or nullptr
+    const uint8_t * tile_vis = nullptr;  // matrix-core kernel: [q tile of 32][kv tile of 64] visibility bytes (launch_fattn_vis_scan), or nullptr
 };
+size_t fattn_vis_bytes(const tdesc & q, const tdesc & k);
+void launch_fattn_vis_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, uint8_t * vis);
 // few query tokens over a large unified cache (continuous batching): tile size for the tile-list attention kernel, 0 = not applicable
 int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const fattn_params & p, size_t lists_bytes);
 void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, int tile, int * lists);

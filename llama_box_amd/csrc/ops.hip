@@ -263,17 +263,19 @@ __device__ __forceinline__ float dequant_elem(const int type, const uint8_t * __
         default: return 0.0f;
     }
 }
-__global__ void __launch_bounds__(256) k_get_rows(const tdesc a, const tdesc idx, const tdesc d) {
+// (a decode step gathers ONE row: 1024 threads and independent iterations keep its chain of dependent byte loads short)
+__global__ void __launch_bounds__(1024) k_get_rows(const tdesc a, const tdesc idx, const tdesc d) {
     const int64_t r = blockIdx.x;
     const int64_t i10 = r % idx.ne[0], i11 = (r / idx.ne[0]) % idx.ne[1], i12 = r / (idx.ne[0] * idx.ne[1]);
     const int32_t i01 = *(const int32_t *) (idx.data + i10 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
     const uint8_t * row = (const uint8_t *) (a.data + (int64_t) i01 * a.nb[1] + i11 * a.nb[2] + i12 * a.nb[3]);
     float * y = (float *) (d.data + i10 * d.nb[1] + i11 * d.nb[2] + i12 * d.nb[3]);
+#pragma unroll 4
     for (int64_t i = threadIdx.x; i < a.ne[0]; i += blockDim.x) y[i] = dequant_elem(a.type, row, i);
 }
 void launch_get_rows(hipStream_t s, const tdesc & a, const tdesc & idx, const tdesc & d) {
     const int64_t rows = idx.ne[0] * idx.ne[1] * idx.ne[2];
-    hipLaunchKernelGGL(k_get_rows, dim3((unsigned) rows), dim3(256), 0, s, a, idx, d);
+    hipLaunchKernelGGL(k_get_rows, dim3((unsigned) rows), dim3((unsigned) std::min<int64_t>(1024, std::max<int64_t>(64, (a.ne[0] + 63) / 64 * 64))), 0, s, a, idx, d);
 }
 
 // ------------------------------------------------------------------------------------------------ SET_ROWS
