@@ -173,6 +173,13 @@ static void be_free(ggml_backend_t be) {
     delete c;
     delete be;
 }
+// small uploads wait in the pinned ring until something else is about to enter the stream (or the host asks to synchronise):
+// every entry point that touches the stream calls this first
+void flush_uploads(backend_ctx * c) {
+    if (c->up_pending.n == 0) return;
+    launch_upload_multi(c->stream, c->up_pending);
+    c->up_pending.n = 0;
+}
 static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
     HIP_CHECK(hipSetDevice(c->device));
@@ -185,20 +192,24 @@ static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void *
         if (c->up_ring) {
             size_t at = (c->up_head + 255) & ~(size_t) 255;
             if (at + size > c->up_cap) {  // wrap: everything staged so far must have been consumed
+                flush_uploads(c);
                 HIP_CHECK(hipStreamSynchronize(c->stream));
                 at = 0;
             }
             memcpy(c->up_ring + at, data, size);
             c->up_head = at + size;
-            launch_upload_small(c->stream, (char *) t->data + offset, c->up_ring + at, size);
+            if (c->up_pending.n == 8) flush_uploads(c);
+            c->up_pending.seg[c->up_pending.n++] = {(char *) t->data + offset, c->up_ring + at, size};
             return;
         }
     }
+    flush_uploads(c);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_tensor_async(ggml_backend_t be, const ggml_tensor * t, void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
     HIP_CHECK(hipSetDevice(c->device));
+    flush_uploads(c);
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
 }
 static bool be_is_ours(ggml_backend_t be);
@@ -209,6 +220,8 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
     if (!buffer_is_ours(sb) || !buffer_is_ours(db)) return false;
     backend_ctx * cs = (backend_ctx *) be_src->context;
     backend_ctx * cd = (backend_ctx *) be_dst->context;
+    flush_uploads(cs);
+    if (cd != cs) flush_uploads(cd);
     const size_t n = ggml_abi_nbytes(src);
     if (cs->device == cd->device) {
         HIP_CHECK(hipSetDevice(cs->device));
@@ -230,19 +243,23 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
 static void be_synchronize(ggml_backend_t be) {
     backend_ctx * c = (backend_ctx *) be->context;
     HIP_CHECK(hipSetDevice(c->device));
+    flush_uploads(c);
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 static enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph * g) {
     backend_ctx * c = (backend_ctx *) be->context;
     if (hipSetDevice(c->device) != hipSuccess) return GGML_STATUS_FAILED;
+    flush_uploads(c);
     return graph_compute(c, g);
 }
 static void be_event_record(ggml_backend_t be, ggml_backend_event_t ev) {
     backend_ctx * c = (backend_ctx *) be->context;
+    flush_uploads(c);
     HIP_CHECK(hipEventRecord((hipEvent_t) ev->context, c->stream));
 }
 static void be_event_wait(ggml_backend_t be, ggml_backend_event_t ev) {
     backend_ctx * c = (backend_ctx *) be->context;
+    flush_uploads(c);
     HIP_CHECK(hipStreamWaitEvent(c->stream, (hipEvent_t) ev->context, 0));
 }
 static const ggml_backend_i k_backend_iface = {

@@ -40,6 +40,10 @@ int log_level();
 
 // device-side layout of a Q8_K-quantised activation block (the ggml block_q8_K fields, 16-byte aligned:
 // qs | bsums | d) — produced by quantize kernels, consumed by the K-quant matvec / GEMM kernels
+// small host -> device uploads batched into one launch (ops.hip: k_upload_multi)
+struct upload_seg { char * dst; const char * src; size_t n; };
+struct upload_batch { upload_seg seg[8]; int n; };
+
 struct q8k_dev {
     int8_t qs[256];
     uint16_t bsums[16]; // block_q8_K.bsums (sums over 16 values, |.| <= 2032) stored as IEEE f16 — exact — because their only
@@ -115,6 +119,7 @@ struct backend_ctx {
     // tiny kernel — a blit through hipMemcpyAsync costs ~25 us of stream time per copy, five of them per decode step
     char * up_ring = nullptr;
     size_t up_cap = 0, up_head = 0;
+    upload_batch up_pending{};  // staged in the ring, not yet launched: flushed as ONE kernel before anything else enters the stream
     // attention over a unified cache with a few query tokens: per-token lists of visible tiles (fattn.hip, k_fattn_tile_scan),
     // built once per graph execution and shared by the attention nodes of all layers
     int * fa_lists = nullptr;
@@ -123,6 +128,8 @@ struct backend_ctx {
     std::map<std::string, timing_slot> timing;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
 };
+
+void flush_uploads(backend_ctx * c);  // launches the small uploads staged by set_tensor_async (backend.cpp)
 
 // ---- buffers (backend.cpp) ----
 struct buffer_ctx {

@@ -124,6 +124,7 @@ void launch_set_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const 
 void launch_cpy_q8_0(hipStream_t s, const void * src, void * dst, int64_t n_values, bool to_q8);  // contiguous Q8_0 <-> F32 (K-shift of a quantised cache)
 void launch_set_rows_q8_0(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);  // f32 rows -> block_q8_0 rows (quantised KV cache)
 void launch_argmax(hipStream_t s, const tdesc & src, const tdesc & dst);
+void launch_upload_multi(hipStream_t s, const upload_batch & b);  // up to 8 pinned-host -> device copies in one launch
 void launch_upload_small(hipStream_t s, void * dst, const void * pinned_src, size_t n);
 
 

@@ -659,4 +659,29 @@ void launch_upload_small(hipStream_t s, void * dst, const void * pinned_src, siz
     hipLaunchKernelGGL(k_upload_small, dim3((unsigned) ((items + 255) / 256)), dim3(256), 0, s, (char *) dst, (const char *) pinned_src, n, vec);
 }
 
+// several small uploads in ONE launch (a decode step brings token ids, positions, cache indices, a mask row and output ids:
+// five dependent ~4.5 us kernels otherwise); blockIdx.y = segment
+__global__ void __launch_bounds__(256) k_upload_multi(const upload_batch b) {
+    const upload_seg sg = b.seg[blockIdx.y];
+    const uintptr_t al = (uintptr_t) sg.dst | (uintptr_t) sg.src | (uintptr_t) sg.n;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;; i += (size_t) gridDim.x * 256) {
+        if ((al & 15) == 0) {
+            if (i * 16 >= sg.n) break;
+            ((uint4 *) sg.dst)[i] = ((const uint4 *) sg.src)[i];
+        } else if ((al & 3) == 0) {
+            if (i * 4 >= sg.n) break;
+            ((uint32_t *) sg.dst)[i] = ((const uint32_t *) sg.src)[i];
+        } else {
+            if (i >= sg.n) break;
+            sg.dst[i] = sg.src[i];
+        }
+    }
+}
+void launch_upload_multi(hipStream_t s, const upload_batch & b) {
+    size_t most = 0;
+    for (int i = 0; i < b.n; ++i) most = std::max(most, b.seg[i].n);
+    const unsigned gx = (unsigned) std::min<size_t>(16, (most / 16 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_upload_multi, dim3(gx, (unsigned) b.n), dim3(256), 0, s, b);
+}
+
 }  // namespace mi355x
