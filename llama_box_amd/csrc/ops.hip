@@ -456,55 +456,73 @@ void rope_host_consts(const rope_params & p, float & theta_scale, float & c0, fl
     c1 = fminf((float) (p.n_dims - 1), ceilf(corr_dim(p.beta_slow)));
 }
 // Batches: ROPE(q), ROPE(k) -> SET_ROWS(k cache), SET_ROWS(v cache) as ONE launch (four nodes of every layer; at a few
-// dozen tokens each of them sits at the dependent-launch floor).  One 64-lane workgroup per (head slot, token): slots [0, nh) rotate
-// a query head f32 -> f32 (in place when the allocator made the rope in-place), [nh, nh + nkv) rotate a key head and store it as
-// f16 into the cache row the token's index names, the rest convert a value head.  Arithmetic per element is that of k_rope
+// dozen tokens each of them sits at the dependent-launch floor).  Query heads are rotated f32 -> f32 (in place when the allocator
+// made the rope in-place), key heads are rotated and stored as f16 into the cache row the token's index names, value heads
+// are converted.  Arithmetic per element is that of k_rope
 // followed by k_set_rows (f32 result, then one f16 rounding), so fused and unfused graphs agree bit for bit.
-__global__ void __launch_bounds__(64) k_rope_qk_store(const rope_store_args a) {
-    const int slot = blockIdx.x;
-    const int64_t t = blockIdx.y;
+__global__ void __launch_bounds__(256) k_rope_qk_store(const rope_store_args a) {
+    // one workgroup per token; a thread owns rotation pair (tid & 63) [+ 64, ...] — its (cos, sin) is computed ONCE and serves every
+    // head — and the four waves share out the head slots: [0, nh) query heads, [nh, nh + nkv) key heads, then value heads
+    const int64_t t = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float pos_f = (float) a.pos[t];
     const int n_pairs = a.p.n_dims / 2;
     const bool neox = (a.p.mode & GGML_ROPE_TYPE_NEOX) != 0;
     const rope_consts rc{a.theta_scale, a.p.freq_scale, a.p.ext_factor, a.p.attn_factor, a.corr0, a.corr1};
-    if (slot < a.nh) {
-        const float * src = (const float *) (a.q_src + slot * a.q_nb1 + t * a.q_nb2);
-        float * dst = (float *) (a.q_dst + slot * a.qd_nb1 + t * a.qd_nb2);
-        for (int ip = threadIdx.x; ip < n_pairs; ip += 64) {
-            const int ia = neox ? ip : 2 * ip, ib = neox ? ip + n_pairs : 2 * ip + 1;
-            const float x0 = src[ia], x1 = src[ib];
-            float cs, sn;
-            rope_cos_sin(ip, pos_f, a.ff, rc, cs, sn);
-            dst[ia] = x0 * cs - x1 * sn;
-            dst[ib] = x0 * sn + x1 * cs;
-        }
-        for (int i0 = a.p.n_dims + threadIdx.x; i0 < a.head_dim; i0 += 64) dst[i0] = src[i0];
-        return;
-    }
     const int64_t row = a.idx[t];
-    if (slot < a.nh + a.nkv) {
-        const int h = slot - a.nh;
-        const float * src = (const float *) (a.k_src + h * a.k_nb1 + t * a.k_nb2);
-        uint16_t * dst = (uint16_t *) (a.k_cache + row * a.kc_nb1) + (int64_t) h * a.head_dim;
-        for (int ip = threadIdx.x; ip < n_pairs; ip += 64) {
-            const int ia = neox ? ip : 2 * ip, ib = neox ? ip + n_pairs : 2 * ip + 1;
-            const float x0 = src[ia], x1 = src[ib];
-            float cs, sn;
-            rope_cos_sin(ip, pos_f, a.ff, rc, cs, sn);
-            dst[ia] = f2h(x0 * cs - x1 * sn);
-            dst[ib] = f2h(x0 * sn + x1 * cs);
+    // blockIdx.y: this workgroup's share of the head slots (one share per token for big batches, where recomputing the angles
+    // per head is the cost; many shares for a few dozen tokens, where filling the chip is)
+    const int n_all = a.nh + 2 * a.nkv, per = (n_all + (int) gridDim.y - 1) / (int) gridDim.y;
+    const int s_lo = (int) blockIdx.y * per, n_slots = min(n_all, s_lo + per);
+    const int rot_hi = min(n_slots, a.nh + a.nkv);
+    for (int ip0 = 0; ip0 < n_pairs && s_lo < rot_hi; ip0 += 64) {
+        const int ip = ip0 + lane;
+        const bool act = ip < n_pairs;
+        float cs = 1.0f, sn = 0.0f;
+        if (act) rope_cos_sin(ip, pos_f, a.ff, rc, cs, sn);
+        const int ia = neox ? ip : 2 * ip, ib = neox ? ip + n_pairs : 2 * ip + 1;
+        for (int slot = s_lo + w; slot < rot_hi; slot += 4) {
+            if (!act) continue;
+            if (slot < a.nh) {
+                const float * src = (const float *) (a.q_src + slot * a.q_nb1 + t * a.q_nb2);
+                float * dst = (float *) (a.q_dst + slot * a.qd_nb1 + t * a.qd_nb2);
+                const float x0 = src[ia], x1 = src[ib];
+                dst[ia] = x0 * cs - x1 * sn;
+                dst[ib] = x0 * sn + x1 * cs;
+            } else {
+                const int h = slot - a.nh;
+                const float * src = (const float *) (a.k_src + h * a.k_nb1 + t * a.k_nb2);
+                uint16_t * dst = (uint16_t *) (a.k_cache + row * a.kc_nb1) + (int64_t) h * a.head_dim;
+                const float x0 = src[ia], x1 = src[ib];
+                dst[ia] = f2h(x0 * cs - x1 * sn);
+                dst[ib] = f2h(x0 * sn + x1 * cs);
+            }
         }
-        for (int i0 = a.p.n_dims + threadIdx.x; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(src[i0]);
-        return;
     }
-    const int h = slot - a.nh - a.nkv;
-    const float * src = (const float *) (a.v_src + h * a.v_nb1 + t * a.v_nb2);
-    uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * a.head_dim;
-    for (int i0 = threadIdx.x; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(src[i0]);
+    // pass-through tail of partially rotated heads, and the value heads
+    for (int slot = s_lo + w; slot < n_slots; slot += 4) {
+        if (slot < a.nh) {
+            const float * src = (const float *) (a.q_src + slot * a.q_nb1 + t * a.q_nb2);
+            float * dst = (float *) (a.q_dst + slot * a.qd_nb1 + t * a.qd_nb2);
+            for (int i0 = a.p.n_dims + lane; i0 < a.head_dim; i0 += 64) dst[i0] = src[i0];
+        } else if (slot < a.nh + a.nkv) {
+            const int h = slot - a.nh;
+            const float * src = (const float *) (a.k_src + h * a.k_nb1 + t * a.k_nb2);
+            uint16_t * dst = (uint16_t *) (a.k_cache + row * a.kc_nb1) + (int64_t) h * a.head_dim;
+            for (int i0 = a.p.n_dims + lane; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(src[i0]);
+        } else {
+            const int h = slot - a.nh - a.nkv;
+            const float * src = (const float *) (a.v_src + h * a.v_nb1 + t * a.v_nb2);
+            uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * a.head_dim;
+            for (int i0 = lane; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(src[i0]);
+        }
+    }
 }
 void launch_rope_qk_store(hipStream_t s, rope_store_args a, int n_tokens) {
     rope_host_consts(a.p, a.theta_scale, a.corr0, a.corr1);
-    hipLaunchKernelGGL(k_rope_qk_store, dim3((unsigned) (a.nh + 2 * a.nkv), (unsigned) n_tokens), dim3(64), 0, s, a);
+    const int n_all = a.nh + 2 * a.nkv;
+    const int shares = n_tokens >= 256 ? 1 : std::max(1, std::min((n_all + 3) / 4, 1024 / std::max(1, n_tokens)));
+    hipLaunchKernelGGL(k_rope_qk_store, dim3((unsigned) n_tokens, (unsigned) shares), dim3(256), 0, s, a);
 }
 void launch_rope(hipStream_t s, const tdesc & a, const tdesc & pos, const float * ff, const tdesc & d, const rope_params & p) {
     float theta_scale, c0, c1;
