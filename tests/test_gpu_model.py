@@ -265,6 +265,40 @@ def test_continuous_batching_shapes(backend, H, plog):
         _free(cc, cg, mc, mg)
 
 
+@pytest.mark.parametrize("name", ["test-llama", "test-qwen2"])
+@pytest.mark.parametrize("n_seq,n_tok", [(1, 2), (1, 9), (2, 16), (1, 33), (4, 40), (32, 3), (3, 130)])
+def test_batch_shapes_head_dim_128(backend, H, plog, name, n_seq, n_tok):
+    """Batches of every kind the engine produces — prompt chunks of one and of several sequences, then a decode step of all
+    sequences at once — through the batch-only paths (sibling projections in one launch, rope + cache stores in one launch, the
+    tile-list and the matrix-core attention with its visibility map), head_dim 128, against the oracle."""
+    hp = preset(name, n_head=4, n_head_kv=2, n_embd=512, n_embd_head=128)
+    mc = Model(hp, 99, H.ggml_backend_cpu_buffer_type())
+    mg = Model(hp, 99, backend.buft)
+    cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=1, n_ctx=1024)
+    cg = Context(mg, backend=backend, flash_attn=1, n_ctx=1024)
+    try:
+        rng = np.random.default_rng(n_seq * 1000 + n_tok)
+        toks = rng.integers(1, hp.n_vocab, n_seq * n_tok).tolist()
+        pos = [i for _ in range(n_seq) for i in range(n_tok)]
+        sid = [k for k in range(n_seq) for _ in range(n_tok)]
+        want = ([0] * (n_tok - 1) + [1]) * n_seq
+        rc, ref = cc.decode(toks, pos, sid, want)
+        rc2, got = cg.decode(toks, pos, sid, want)
+        assert rc == 0 and rc2 == 0 and got.shape == ref.shape
+        e = T.nmse(got, ref)
+        plog(f"{name} {n_seq} x {n_tok}-token prompts: nmse(gpu, cpu)={e:.3e}")
+        assert e <= 1e-3
+        nxt = [int(np.argmax(ref[k])) for k in range(n_seq)]
+        rc, r2 = cc.decode(nxt, [n_tok] * n_seq, list(range(n_seq)))
+        rc2, g2 = cg.decode(nxt, [n_tok] * n_seq, list(range(n_seq)))
+        assert rc == 0 and rc2 == 0
+        e2 = T.nmse(g2, r2)
+        plog(f"{name} decode step of {n_seq} sequences: nmse(gpu, cpu)={e2:.3e}")
+        assert e2 <= 1e-3
+    finally:
+        _free(cc, cg, mc, mg)
+
+
 def test_kv_full_returns_1_and_bad_batch_minus_1(backend, H):
     hp = preset("test-llama")
     mg = Model(hp, 5, backend.buft)
