@@ -565,11 +565,14 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     }
 }
 
-template <int D> __global__ void __launch_bounds__(D) k_fattn_combine(const float * __restrict__ ws, const float * __restrict__ sinks, const tdesc dst, const fa_geom geo) {
+// Q8OUT (head_dim 128, 256 threads = two heads): the result is consumed only by quantised mat-muls (wo of a batch) — it leaves
+// the kernel as Q8_K blocks (one block = the 256 values of the two heads of a (token, head pair)), not as f32
+template <int D, bool Q8OUT = false> __global__ void __launch_bounds__(Q8OUT ? 256 : D) k_fattn_combine(const float * __restrict__ ws, const float * __restrict__ sinks, const tdesc dst, const fa_geom geo,
+                                                                                                 q8k_dev * __restrict__ q8 = nullptr) {
     // one thread per output dimension; every wave recomputes the (<= 64) split coefficients lane-parallel (lane s owns
     // split s: ONE round trip fetches every (m, l) pair), then the coefficients come out of their lanes through SGPRs
     // (v_readlane with compile-time indices) while up to 32 partial values per thread are in flight at once
-    const int h = blockIdx.x, tok = blockIdx.y, bat = blockIdx.z, dd = threadIdx.x, lane = threadIdx.x & 63;
+    const int h = Q8OUT ? (int) blockIdx.x * (256 / D) + (int) threadIdx.x / D : (int) blockIdx.x, tok = blockIdx.y, bat = blockIdx.z, dd = threadIdx.x % D, lane = threadIdx.x & 63;
     const float * __restrict__ base = ws + (((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits * (D + 2);
     const bool has = lane < geo.n_splits;
     const float ms = has ? base[(int64_t) lane * (D + 2) + D] : -INFINITY;
@@ -605,16 +608,31 @@ template <int D> __global__ void __launch_bounds__(D) k_fattn_combine(const floa
             a += c != 0.0f ? r1[u] * c : 0.0f;
         }
     }
-    float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
-    out[dd] = a * (1.0f / lt);
+    if constexpr (Q8OUT) {
+        __shared__ float vals[256];
+        vals[threadIdx.x] = a * (1.0f / lt);
+        __syncthreads();
+        if (threadIdx.x < 64) {  // quantize_row_q8_K of the block, as k_quantize_q8_K does it
+            const float4 t4 = ((const float4 *) vals)[lane];
+            const float t[4] = {t4.x, t4.y, t4.z, t4.w};
+            wave_quantize_q8_K(t, lane, q8 + ((int64_t) bat * geo.n_q + tok) * (geo.n_head * D / 256) + blockIdx.x);
+        }
+    } else {
+        float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+        out[dd] = a * (1.0f / lt);
+    }
 }
 
-void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits) {
+void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits, void * q8_out) {
     fa_geom geo{};
     geo.n_q = n_q;
     geo.n_head = n_head;
     geo.n_splits = n_splits;
     dim3 g2((unsigned) n_head, (unsigned) n_q, (unsigned) n_batch);
+    if (q8_out && D == 128) {
+        hipLaunchKernelGGL((k_fattn_combine<128, true>), dim3((unsigned) (n_head / 2), (unsigned) n_q, (unsigned) n_batch), dim3(256), 0, s, ws, sinks, dst, geo, (q8k_dev *) q8_out);
+        return;
+    }
     if (D == 128) hipLaunchKernelGGL((k_fattn_combine<128>), g2, dim3(128), 0, s, ws, sinks, dst, geo);
     else hipLaunchKernelGGL((k_fattn_combine<64>), g2, dim3(64), 0, s, ws, sinks, dst, geo);
 }
@@ -735,6 +753,14 @@ void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv
     hipLaunchKernelGGL(k_fattn_tile_scan, dim3((unsigned) n_q), dim3(256), 0, s, mask, n_kv, tile, lists, stride);
 }
 
+// will launch_flash_attn end in the quantising combine pass for these arguments? (mirrors its dispatch)
+bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p) {
+    if (k.ne[0] != 128 || (q.ne[2] % 2) != 0 || p.n_splits < 2 || q.ne[3] != 1 || k.ne[2] <= 0) return false;
+    const bool q8 = p.kv_type == GGML_TYPE_Q8_0;
+    if ((!q8 || (fattn_q8_via_f16(q, p.kv_type) && k.ne[3] == 1)) && flash_attn_mma_applies(q, k, mask, sinks, dst, p)) return true;
+    const int G = (int) (q.ne[2] / k.ne[2]);
+    return p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 2 || G == 4 || G == 7 || G == 8) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 && ((uintptr_t) q.data & 15) == 0;
+}
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
                        const fattn_params & p, void * workspace) {
     const bool q8 = p.kv_type == GGML_TYPE_Q8_0;
@@ -803,10 +829,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     }
         if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
 #undef FA_DEC
-        if (geo.n_splits > 1) {
-            dim3 g2((unsigned) geo.n_head, (unsigned) geo.n_q, (unsigned) q.ne[3]);
-            hipLaunchKernelGGL((k_fattn_combine<128>), g2, dim3(128), 0, s, ws, sinks, dst, geo);
-        }
+        if (geo.n_splits > 1) launch_flash_attn_combine(s, 128, ws, sinks, dst, geo.n_q, geo.n_head, (int) q.ne[3], geo.n_splits, p.q8_out);
         return;
     }
     if (q8) {

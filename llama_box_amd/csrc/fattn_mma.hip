@@ -297,7 +297,7 @@ bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, cons
         if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<64, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
         else hipLaunchKernelGGL((k_fattn_mma<64, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
     }
-    if (geo.n_splits > 1) launch_flash_attn_combine(s, (int) k.ne[0], ws, sinks, dst, (int) q.ne[1], (int) q.ne[2], (int) q.ne[3], geo.n_splits);
+    if (geo.n_splits > 1) launch_flash_attn_combine(s, (int) k.ne[0], ws, sinks, dst, (int) q.ne[1], (int) q.ne[2], (int) q.ne[3], geo.n_splits, p.q8_out);
     return true;
 }
 

@@ -1007,7 +1007,24 @@ static int run_node(exec_state & st, int i) {
                     p.tile_vis = (const uint8_t *) c->fa_lists;
                 }
             }
+            // a batch's attention result read only by quantised mat-muls (wo), through the usual reshape: the combine pass writes
+            // Q8_K blocks into the activation scratch instead of f32 (one launch less per layer)
+            const ggml_tensor * q8_reader = nullptr;
+            if (fuse && c->opt.prologue && a->ne[1] > 1 && use_count(st, n) == 1 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(n)) {
+                for (int k = i + 1; k < std::min(g->n_nodes, i + 4) && !q8_reader; ++k) {
+                    const ggml_tensor * t = g->nodes[k];
+                    if ((t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW) && t->src[0] == n && t->data == n->data && ggml_abi_is_contiguous(t) && t->ne[0] == n->ne[0] * n->ne[1] &&
+                        t->ne[1] == n->ne[2] && quant_consumers_only(st, k, t) &&
+                        fattn_q8_out_ok(qd, kd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p))
+                        q8_reader = t;
+                }
+            }
+            if (q8_reader) p.q8_out = (char *) c->ws + st.act_off;
             launch_flash_attn(s, qd, kd, vd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p, (char *) c->ws + st.aux_off);
+            if (q8_reader) {
+                mark_q8_cache(st, q8_reader);
+                c->st.fused_nodes++;
+            }
             c->st.kernel_launches += p.n_splits > 1 ? 2 : 1;
             return 1;
         }
@@ -1036,7 +1053,7 @@ static bool run_nodes(backend_ctx * c, ggml_cgraph * g, const ws_plan & wp) {
         const int used = run_node(st, i);
         if (used < 0) return false;
         if (!st.q8_fresh)
-            for (int k = 0; k < used; ++k) if (g->nodes[i + k]->data == c->q8_src) c->q8_src = nullptr;
+            for (int k = 0; k < used; ++k) if (g->nodes[i + k]->data == c->q8_src && !is_view_op(g->nodes[i + k])) c->q8_src = nullptr;  // (views write nothing)
         st.q8_fresh = false;
         i += used;
     }

@@ -157,6 +157,8 @@ struct fattn_params {
     int n_splits;  // KV splits per (token, kv-head group)
     int kv_type;   // GGML_TYPE_F16 or GGML_TYPE_Q8_0 (K and V alike)
     const int * lists = nullptr;  // per-token lists of visible tiles (launch_fattn_tile_scan), or nullptr
+    void * q8_out = nullptr;  // the result's only readers are quantised mat-muls (wo of a batch): leave it as Q8_K blocks here — honoured by
+                              // the combine pass of the head_dim-128 kernels (n_splits > 1), see fattn_q8_out_ok()
     const uint8_t * tile_vis = nullptr;  // matrix-core kernel: [q tile of 32][kv tile of 64] visibility bytes (launch_fattn_vis_scan), or nullptr
 };
 size_t fattn_vis_bytes(const tdesc & q, const tdesc & k);
@@ -168,12 +170,13 @@ size_t fattn_workspace_bytes(const tdesc & q, const tdesc & k, const tdesc & v, 
 int fattn_mma_min_q();  // query tokens from which the matrix-core attention kernel takes over (env GGML_MI355X_FA_MMA_MIN_Q)
 bool flash_attn_mma_applies(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);
 int fattn_pick_splits(const tdesc & q, const tdesc & k);
+bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);  // will this launch end in the quantising combine?
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks,
                        const tdesc & dst, const fattn_params & p, void * workspace);
 // matrix-core variant for batches of >= 32 query tokens (fattn_mma.hip); false = does not apply
 bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
                            const fattn_params & p, void * workspace);
 int fattn_mma_pick_splits(const tdesc & q, const tdesc & k);
-void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits);
+void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits, void * q8_out = nullptr);
 
 }  // namespace mi355x
