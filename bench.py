@@ -110,6 +110,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        # one node: RCCL's bootstrap (and gloo) may use the loopback interface — the container's hostname / outward interface need
+        # not resolve on the GPU box
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist  # control plane on gloo; the data-path collective is RCCL inside the backend
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
