@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--ctkv", default="f16", choices=["f16", "q8_0"], help="KV cache type (llama-box --cache-type-k / --cache-type-v); the headline metric is quoted on f16")
     ap.add_argument("--layers", type=int, default=0, help="debug only: override n_layer (result is then NOT a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replica-leg", type=int, default=1, help="tensor-split runs: also time the GPUs as independent replicas (informational field)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--timing-steps", type=int, default=16)
     ap.add_argument("--pmc-traffic", type=int, default=1, help="1: re-run a short decode under rocprofv3 --pmc FETCH_SIZE (own pass) for roofline.traffic")
@@ -256,6 +257,36 @@ def main():
             roofline["traffic"] = round(tr) if tr else None
             roofline["traffic_source"] = how
 
+    # ---- tensor-split runs: the same GPUs as independent replicas (one full model and one sequence each), beside the headline value.
+    # Batch-1 decode of a model that fits one GPU is all-reduce-latency-bound under tensor split (Multi-GPU); what N GPUs
+    # are worth as N data-parallel engines is the other half of the picture.  Informational: `value` stays the tensor-split number.
+    w_bytes = model.stream_bytes()
+    replicas = None
+    if (tp_size > 1 and args.replica_leg) or (world > 1 and args.replica_leg == 2):  # (2: exercise the leg in the single-GPU dry run)
+        try:
+            ctx.free(); model.free()
+            ctx = model = None
+            model_r = Model(hp, 0x5EED, be.buft)
+            ctx_r = Context(model_r, backend=be, n_ctx=n_ctx, n_ubatch=args.ubatch, flash_attn=args.fa, graph_reuse=1, type_k=kvt, type_v=kvt)
+            if args.prefill > 0:
+                rc, _ = ctx_r.decode(toks[:args.prefill], range(args.prefill), want=[0] * (args.prefill - 1) + [1])
+                assert rc == 0
+            rows_w = [[int(toks[args.prefill + i])] for i in range(args.warmup)]
+            assert ctx_r.decode_steps(rows_w, 1, args.prefill) == 0
+            rows_t = [[int(toks[args.prefill + args.warmup + i])] for i in range(args.steps)]
+            sync()
+            tr0 = time.perf_counter()
+            assert ctx_r.decode_steps(rows_t, 1, args.prefill + args.warmup) == 0
+            torch.cuda.synchronize()
+            dist.barrier()
+            el = torch.tensor([time.perf_counter() - tr0], dtype=torch.float64)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            ctx_r.free(); model_r.free()
+            replicas = {"value": round(world * args.steps / float(el[0]), 2), "unit": "tokens/s", "scaling": "weak",
+                        "note": f"{world} independent batch-1 decodes, one full model per GPU, same barrier / max-over-ranks timing (eager launches: graph replay is off while a communicator is attached)"}
+        except Exception as e:
+            replicas = {"error": str(e)}
+
     # ---- CPU baseline: the oracle (restated ggml-cpu), same model shape, on this host's cores
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -289,7 +320,6 @@ def main():
         prefill_roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                             "flop_per_token": round(flop_tok), "note": "dense f16 MFMA peak; the GEMMs run on the int8 matrix cores (2x rate) with two digit passes per weight"}
     if rank == 0:
-        w_bytes = model.stream_bytes()
         kv_per_tok = int(2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * (34 / 32 if args.ctkv == "q8_0" else 2))
         n_past = args.prefill + args.warmup + args.steps // 2
         job_bytes = (w_bytes + args.np * kv_per_tok * n_past) * (tok_s / streams / args.np)
@@ -307,6 +337,7 @@ def main():
             "prefill_host_us": {"build": round(prefill_host_split[0], 1), "inputs": round(prefill_host_split[1], 1), "compute+sync": round(prefill_host_split[2], 1), "logits_d2h": round(prefill_host_split[3], 1)} if prefill_tok_s else None,
             "prefill_roofline": prefill_roofline,
             "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),
+            "replicas_on_the_same_gpus": replicas,
             "graph_replayed_steps": int(graph_steps),
             "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
@@ -314,8 +345,9 @@ def main():
             "model_load_s": round(t_load, 1),
         }
         print(json.dumps(out))
-    ctx.free()
-    model.free()
+    if ctx is not None:
+        ctx.free()
+        model.free()
     be.close()
     if dist is not None:
         dist.destroy_process_group()
