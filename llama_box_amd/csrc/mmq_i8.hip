@@ -1,4 +1,5 @@
-// mmq_i8.hip — prefill / large-batch mat-mul for Q4_K and Q5_K weights on the gfx950 INTEGER matrix cores.
+// mmq_i8.hip — batched mat-mul (9 columns and up: continuous-batching decode steps, prompt micro-batches) for Q4_K, Q5_K and
+// Q6_K weights on the gfx950 INTEGER matrix cores.
 //
 // Same contract as mmq.hip (ggml-cpu's ggml_vec_dot_q{4,5}_K_q8_K: integer block sums on Q8_K activations, one f32
 // scale-accumulate per super-block — SURVEY.md §8a row a6), but the block sums are computed by v_mfma_i32_32x32x32_i8:
@@ -15,7 +16,9 @@
 // LDS tiles are [row][128 B of K] with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 — conflict-free for the
 // ds_read_b128 lane groups of gfx950 without padding — and DOUBLE-buffered: trip t+1 is converted and written while
 // the MFMAs of trip t run, one barrier per trip.  BN = 128 (8 waves) or 64 (4 waves; used when the grid would not
-// fill 256 CUs otherwise); each wave owns 32 weight rows x 64 activation columns.
+// fill 256 CUs otherwise); each wave owns 32 weight rows x 64 activation columns (BM = 128), or all 64 / 32 columns of a
+// small batch with the K steps of a trip shared between two wave groups (BM = 64 / 32).  Q6_K splits the PRODUCT
+// (q - 32) * sc = 64 * p1 + p0 instead of the scale.  Up to three matrices over the same activations share a launch.
 #include <algorithm>
 
 #include "dev_util.h"
