@@ -644,7 +644,13 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         ggml_tensor * t = g->nodes[k];
         ggml_tensor * a1 = k + 1 < g->n_nodes ? g->nodes[k + 1] : nullptr;
         const ggml_tensor * o1 = (a1 && !st.done[k + 1] && single_use(st, t)) ? add_partner(a1, t) : nullptr;
-        if (o1 && ggml_abi_is_contiguous(a1) && a1->type == GGML_TYPE_F32) return member{k, a1, o1, 2};
+        if (o1 && ggml_abi_is_contiguous(a1) && a1->type == GGML_TYPE_F32) {
+            // the sibling runs early, at node i: what it adds must exist by then (a bias is a weight; a residual produced
+            // between node i and the sibling's own position is not there yet)
+            bool ready = true;
+            for (int j = i; j <= k && ready; ++j) ready = !ranges_overlap(g->nodes[j], o1) || is_view_op(g->nodes[j]);
+            if (ready) return member{k, a1, o1, 2};
+        }
         return member{k, t, nullptr, 1};
     };
     if (!eligible(n0)) return 0;
