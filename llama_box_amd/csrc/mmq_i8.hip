@@ -537,10 +537,11 @@ void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc 
     // continuous-batching decode steps: column tiles of 32 / 64 (always on 64-row panels — the output matrix included)
     static const int force_bm = getenv("GGML_MI355X_MMQ_BM") ? atoi(getenv("GGML_MI355X_MMQ_BM")) : 0;
     const int bm = force_bm ? force_bm : (M <= 32 ? 32 : (M <= 64 ? 64 : 128));
-    // 64-row panels (two independent 4-wave workgroups per CU) measure 2-3 % ahead of 128-row panels (one 8-wave workgroup behind one
-    // barrier) on every prompt shape of the 8B model; 128 stays available through the option
-    (void) wg128;
-    const int bn = force_bn ? force_bn : 64;
+    // 128-row panels (one 8-wave workgroup per CU) when they still fill the chip — except for Q4_K / Q6_K at K < 8192, where 64-row
+    // panels (two independent 4-wave workgroups per CU, not behind one barrier) measure 2-3 % ahead on every prompt shape of the 8B
+    // model; Q5_K (three pieces: the 64-row variant spills) and the 70B shapes measure 4-30 % ahead with 128
+    const bool prefer128 = type == GGML_TYPE_Q5_K || K >= 8192;
+    const int bn = force_bn ? force_bn : (bm == 128 && wg128 >= 256 && a.ksplit == 1 && prefer128 ? 128 : 64);
     if (bm < 128 && bn == 64) {
 #define MMQ_SKINNY(QT)                                   \
     {                                                    \
