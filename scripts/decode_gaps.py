@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Decode-step timeline from a rocprofv3 kernel-trace CSV: per step (launches between two output-matrix mat-vecs) the span, the
+time kernels were running, the idle gaps inside the step and the idle time between steps."""
+import csv, sys
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+ends = [i for i, r in enumerate(rows) if "T_Q6K, false, 2>" in r[2]]
+steps = []
+for a, b in zip(ends[:-1], ends[1:]):
+    st = rows[a + 1:b + 1]
+    if len(st) < 50: continue
+    busy = sum(e - s for s, e, _ in st)
+    inner = sum(max(0, st[i + 1][0] - st[i][1]) for i in range(len(st) - 1))
+    steps.append((st[0][0], st[-1][1], busy, inner, len(st)))
+tail = steps[-16:]
+for i, (s, e, busy, inner, n) in enumerate(tail):
+    nxt = tail[i + 1][0] - e if i + 1 < len(tail) else 0
+    print(f"step kernels={n} span={(e - s) / 1e3:8.1f} us busy={busy / 1e3:8.1f} inner_gaps={inner / 1e3:6.1f} gap_to_next_step={nxt / 1e3:6.1f}")
+big = {}
+st = rows[ends[-3] + 1:ends[-2] + 1]
+for i in range(len(st) - 1):
+    g = (st[i + 1][0] - st[i][1]) / 1e3
+    k = st[i + 1][2].replace("mi355x::", "").split("(")[0][:50]
+    a = big.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += g
+for k, (n, g) in sorted(big.items(), key=lambda kv: -kv[1][1])[:8]:
+    print(f"  gap before {k:50s}: {n:3d} x {g / n:5.2f} us")
