@@ -113,6 +113,35 @@ def test_sibling_mul_mats_share_a_launch(backend, H, plog, qt, M, bias):
         T.compare(f"sibling mat-muls {QNAME[qt]} M={M} bias={bias} {name} vs one by one", a, c, max_nmse=1e-12, log=plog)
 
 
+def _random_mm_shapes():
+    rng = np.random.default_rng(2024)
+    out = []
+    for i in range(40):
+        qt = QTYPES[i % 4]
+        K = int(rng.choice([256, 512, 768, 1024, 2048, 3584, 4096]))
+        N = int(rng.integers(1, 700))
+        M = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 10, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 100, 127, 128, 129, 200, 300]))
+        out.append((qt, K, N, M))
+    return out
+
+
+@pytest.mark.parametrize("qt,K,N,M", _random_mm_shapes())
+def test_mul_mat_q_random_shapes(backend, H, plog, qt, K, N, M):
+    """Seeded sweep over ragged shapes: every row count (panel tails, odd N), every column-count regime (mat-vec passes, 32 / 64 /
+    128-column matrix-core tiles and their tails) and K lengths that give uneven K splits — all formats."""
+    rng = np.random.default_rng(K * 7 + N * 13 + M * 17 + qt)
+    w = T.rand_weight(qt, K, N, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+
+    def build(g):
+        r = H.ggml_mul_mat(g.ctx, g.new(qt, [K, N], w), g.new(L.F32, [K, M], x))
+        return H.ggml_add(g.ctx, r, g.new(L.F32, [N], bias)) if (N + M) % 2 else r
+
+    ref, got = both(build, backend)
+    T.compare(f"mul_mat random {QNAME[qt]} K={K} N={N} M={M}", got[0], ref[0], max_nmse=1e-10, log=plog)
+
+
 @pytest.mark.parametrize("qt", QTYPES)
 def test_mul_mat_q_3d_src1(backend, H, plog, qt):
     """src1 with ne12 > 1 (all rows of src1 are columns of the product) and a strided (permuted) src1."""
