@@ -603,6 +603,52 @@ def test_flash_attn(backend, H, plog, HD, NH, NKV, nq, nkv, splits, softcap, ali
     assert e_gpu <= (1e-9 if nq < 32 or softcap else 3e-7) and e_gpu <= e_cpu * 1.01 + 1e-12
 
 
+def _random_fa_cases():
+    rng = np.random.default_rng(77)
+    heads = [(32, 8), (28, 4), (8, 2), (16, 2), (8, 8), (4, 2)]
+    out = []
+    for i in range(28):
+        NH, NKV = heads[int(rng.integers(len(heads)))]
+        nq = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 32, 33, 48, 64, 65, 130]))
+        nkv = int(rng.integers(8, 700)) * 4
+        nseq = int(rng.choice([1, 1, 2, 4, 8]))
+        out.append((NH, NKV, nq, nkv, nseq, i))
+    return out
+
+
+@pytest.mark.parametrize("NH,NKV,nq,nkv,nseq,case", _random_fa_cases())
+def test_flash_attn_random_masks(backend, H, plog, NH, NKV, nq, nkv, nseq, case):
+    """Seeded sweep at head_dim 128: query counts on both sides of every kernel boundary (1 / 2..32 tile lists / >= 33 matrix
+    cores), ragged cache lengths, one or several sequences in a unified cache (each query sees a random causal prefix of its own
+    sequence's scattered cells — whole tiles and whole splits with nothing visible) — against the oracle."""
+    HD = 128
+    rng = np.random.default_rng(1000 + case)
+    q = rng.standard_normal((NH, nq, HD)).astype(np.float32)
+    kc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    vc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    MR = (nq + 63) // 64 * 64
+    mask = np.full((MR, nkv), -np.inf, np.float16)
+    owner = rng.integers(0, nseq, nkv)               # which sequence a cell belongs to
+    if nseq > 1:                                      # contiguous runs, like a unified cache after several prompts
+        owner = np.sort(owner)
+    for t in range(nq):
+        cells = np.flatnonzero(owner == (t % nseq))
+        if cells.size == 0:
+            cells = np.arange(min(4, nkv))
+        n_vis = int(rng.integers(1, cells.size + 1))
+        mask[t, cells[:n_vis]] = 0
+    def build(g):
+        tq = g.new(L.F32, [HD, nq, NH], q)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], kc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], vc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        r = H.ggml_flash_attn_ext(g.ctx, tq, k, v, g.new(L.F16, [nkv, MR], mask), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(r, 10)
+        return r
+
+    ref, got = both(build, backend)
+    T.compare(f"flash_attn random H={NH}/{NKV} nq={nq} nkv={nkv} nseq={nseq}", got[0], ref[0], max_nmse=1e-4, log=plog)
+
+
 # quantised KV cache (-ctk q8_0 -ctv q8_0): SET_ROWS quantises f32 rows into block_q8_0, FLASH_ATTN_EXT reads the blocks
 FA_Q8_CASES = [  # (NH, NKV, n_q, n_kv, splits, sinks)
     (32, 8, 1, 256, 0, False),
