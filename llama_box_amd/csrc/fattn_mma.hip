@@ -72,6 +72,8 @@ __global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdes
     const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3];
     const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3];
 
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = geo.scale * LOG2E;
     float16v O[ND];
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdes
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float sv = S[t][4 * g4 + e] * geo.scale + mv[e];
+                    float sv = fmaf(S[t][4 * g4 + e], sc2, mv[e] * LOG2E);  // log2 domain: p = 2^(s - m) is ONE v_exp_f32
                     if (p0 + e >= geo.n_kv) sv = -INFINITY;
                     S[t][4 * g4 + e] = sv;
                     mx = fmaxf(mx, sv);
@@ -156,14 +158,15 @@ __global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdes
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx);
         if (__all(m_new == -INFINITY)) continue;  // nothing visible to any query of this wave yet (barriers are at the loop top)
-        const float alpha = m == -INFINITY ? 0.0f : expf(m - m_new);
+        const float mref = m_new == -INFINITY ? 0.0f : m_new;  // this query sees nothing yet: every exponent below is -inf -> 0
+        const float alpha = __builtin_amdgcn_exp2f(m - mref);
         float rs = 0.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float sv = S[t][r];
-                const float p = sv == -INFINITY ? 0.0f : expf(sv - m_new);
+                const float p = __builtin_amdgcn_exp2f(sv - mref);
                 S[t][r] = p;
                 rs += p;
             }
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdes
                     for (int e = 0; e < 4; ++e) rec[d0 + e] = O[dt][4 * g4 + e];
                 }
             if (kg == 0) {
-                rec[D] = m;
+                rec[D] = m * (1.0f / LOG2E);  // the combine pass works in the natural-log domain
                 rec[D + 1] = l;
             }
         }
