@@ -127,48 +127,52 @@ struct T_Q5K {
 struct T_Q6K {
     typedef q8k_dev act;
     static constexpr int BLK = 256, BYTES = 210, PPB = 8;
-    // A lane takes 16 CONSECUTIVE bytes of ql (and the 16 qh bytes that go with them): the eight lanes of a block read its ql as one
-    // 128-byte run, half the cache-line requests per byte of a mapping by value position.  Item j = p & 7 of a block: half h = j >> 2,
-    // ql row k = (j >> 1) & 1 (bytes 32k .. 32k+31 of the half), bytes 16e .. 16e+15 of it (e = j & 1).  Low nibbles are values
-    // 128h + 32k + 16e + i, high nibbles 128h + 64 + 32k + 16e + i; their qh bit pairs sit at bits 2k and 2k + 4.
-    struct raw { uint32_t ql[4], qh[4], s0, s1; uint16_t d; };
-    static constexpr int DW = 11;
+    struct raw { uint32_t ql0[2], ql1[2], qh[2], s0, s1; uint16_t d; };
+    static constexpr int DW = 9;
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
         const uint8_t * blk = row + (size_t) (p >> 3) * BYTES;
-        const int j = p & 7, h = j >> 2, k = (j >> 1) & 1, e = j & 1;
+        const int h = (p >> 2) & 1, t = p & 3;
         raw r;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // (2-byte aligned blocks: dword loads typed accordingly; the compiler merges them)
-            r.ql[i] = ld32_a2(blk + 64 * h + 32 * k + 16 * e + 4 * i);
-            r.qh[i] = ld32_a2(blk + 128 + 32 * h + 16 * e + 4 * i);
+        for (int i = 0; i < 2; ++i) {
+            r.ql0[i] = ld32_a2(blk + 64 * h + 8 * t + 4 * i);
+            r.ql1[i] = ld32_a2(blk + 64 * h + 32 + 8 * t + 4 * i);
+            r.qh[i] = ld32_a2(blk + 128 + 32 * h + 8 * t + 4 * i);
         }
-        r.s0 = ld32_a2(blk + 192 + 8 * h);  // scales 8h .. 8h+3: the low-nibble values' scale is byte 2k + e
-        r.s1 = ld32_a2(blk + 196 + 8 * h);  // scales 8h+4 .. 8h+7: the high-nibble values'
+        r.s0 = ld32_a2(blk + 192 + 8 * h);
+        r.s1 = ld32_a2(blk + 196 + 8 * h);
         r.d = ld16(blk + 208);
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
-        const int b = p >> 3, j = p & 7, h = j >> 2, k = (j >> 1) & 1, e = j & 1;
+        const int b = p >> 3, h = (p >> 2) & 1, t = p & 3, is = t >> 1;
         const float d = h2f(r.d);
-        uint32_t lo[4], hi[4];
+        uint32_t v[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lo[i] = (r.ql[i] & 0x0F0F0F0Fu) | (((r.qh[i] >> (2 * k)) & 0x03030303u) << 4);
-            hi[i] = ((r.ql[i] >> 4) & 0x0F0F0F0Fu) | (((r.qh[i] >> (2 * k + 4)) & 0x03030303u) << 4);
+        for (int i = 0; i < 2; ++i) {
+            v[0][i] = (r.ql0[i] & 0x0F0F0F0Fu) | ((r.qh[i] & 0x03030303u) << 4);
+            v[1][i] = (r.ql1[i] & 0x0F0F0F0Fu) | (((r.qh[i] >> 2) & 0x03030303u) << 4);
+            v[2][i] = ((r.ql0[i] >> 4) & 0x0F0F0F0Fu) | (((r.qh[i] >> 4) & 0x03030303u) << 4);
+            v[3][i] = ((r.ql1[i] >> 4) & 0x0F0F0F0Fu) | (((r.qh[i] >> 6) & 0x03030303u) << 4);
         }
-        const int sc_lo = (int) (int8_t) (r.s0 >> (8 * (2 * k + e))), sc_hi = (int) (int8_t) (r.s1 >> (8 * (2 * k + e)));
-        const int g = 8 * h + 2 * k + e;  // 16-value group of the low-nibble values (the high-nibble ones: g + 4)
+        const int sc[4] = {
+            (int) (int8_t) (r.s0 >> (8 * is)), (int) (int8_t) (r.s0 >> (8 * (is + 2))),
+            (int) (int8_t) (r.s1 >> (8 * is)), (int) (int8_t) (r.s1 >> (8 * (is + 2))),
+        };
 #pragma unroll
         for (int col = 0; col < NC; ++col) {
             const act * yb = y + (size_t) col * nblk + b;
-            const uint4 ylo = *(const uint4 *) (yb->qs + 16 * g), yhi = *(const uint4 *) (yb->qs + 16 * (g + 4));
-            int s_lo = dot4((int) lo[0], (int) ylo.x, 0), s_hi = dot4((int) hi[0], (int) yhi.x, 0);
-            s_lo = dot4((int) lo[1], (int) ylo.y, s_lo); s_hi = dot4((int) hi[1], (int) yhi.y, s_hi);
-            s_lo = dot4((int) lo[2], (int) ylo.z, s_lo); s_hi = dot4((int) hi[2], (int) yhi.z, s_hi);
-            s_lo = dot4((int) lo[3], (int) ylo.w, s_lo); s_hi = dot4((int) hi[3], (int) yhi.w, s_hi);
-            // sum (q - 32) * y = dot(q, y) - 32 * sum(y); the Q8_K block carries the sums over 16 values (exact small integers in f16)
-            const int ys_lo = (int) h2f(yb->bsums[g]), ys_hi = (int) h2f(yb->bsums[g + 4]);
-            const int isum = __mul24(sc_lo, s_lo - 32 * ys_lo) + __mul24(sc_hi, s_hi - 32 * ys_hi);
+            int isum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 yk = *(const uint2 *) (yb->qs + 128 * h + 32 * k + 8 * t);
+                // sum (q - 32) * y = dot(q, y) - 32 * sum(y)
+                int s = dot4((int) v[k][0], (int) yk.x, 0);
+                s = dot4((int) v[k][1], (int) yk.y, s);
+                int ys = dot4(0x01010101, (int) yk.x, 0);
+                ys = dot4(0x01010101, (int) yk.y, ys);
+                isum += __mul24(sc[k], s - 32 * ys);
+            }
             acc[col] += yb->d * d * (float) isum;
         }
     }
