@@ -216,6 +216,10 @@ struct exec_state {
     // tile lists (fattn.hip) valid for this mask tensor / tile size during this execution of the graph
     const void * fa_list_mask = nullptr;
     int fa_list_tile = 0;
+    // a split-K mat-mul whose partial products are summed by the norm + quantise kernel that reads it next (no reduce pass)
+    const ggml_tensor * sk_dst = nullptr;
+    splitk_src sk{};
+    int sk_next = -1;  // node index at which run_mul_mat_q may look ahead (set by the caller: first node after the consumed ones)
 };
 
 static int use_count(const exec_state & st, const ggml_tensor * t) {
@@ -252,6 +256,9 @@ static const char * type_tag(int t) {
     }
 }
 
+static bool is_view_op(const ggml_tensor * t);
+static bool quant_consumers_only(const exec_state & st, int at, const ggml_tensor * t);
+static bool same_shape(const ggml_tensor * a, const ggml_tensor * b);
 // quantised mat-mul, optionally with fused epilogue; w2 != null -> SwiGLU over (w, w2)
 static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_tensor * w2, const ggml_tensor * b, ggml_tensor * dst,
                           const ggml_tensor * add, const ggml_tensor * add2) {
@@ -302,8 +309,33 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         float * part = (float *) ((char *) c->ws + st.aux_off);
         if (i8) {
             const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
+            const int64_t add_stride = (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4);
+            // K split, and the next kernel is the RMS_NORM -> MUL -> Q8_K of exactly this result: it sums the partial products itself
+            // (writing the f32 result on the way) — one launch instead of reduce + norm
+            bool defer = false;
+            if (ks > 1 && c->opt.fusion && c->opt.prologue && st.sk_next >= 0 && ggml_abi_is_contiguous(dst) && (N % 256) == 0 && N <= 16384 && (!add || (add_stride % 4) == 0)) {
+                const ggml_cgraph * g = st.g;
+                int j = st.sk_next;
+                while (j < g->n_nodes && (st.done[j] || is_view_op(g->nodes[j]))) ++j;
+                if (j + 1 < g->n_nodes) {
+                    const ggml_tensor * rn = g->nodes[j];
+                    const ggml_tensor * m = g->nodes[j + 1];
+                    if (rn->op == GGML_OP_RMS_NORM && rn->src[0] == dst && m->op == GGML_OP_MUL && single_use(st, rn) && m->type == GGML_TYPE_F32 && m->nb[0] == 4) {
+                        const ggml_tensor * wn = m->src[0] == rn ? m->src[1] : (m->src[1] == rn ? m->src[0] : nullptr);
+                        defer = wn && wn->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(wn) && wn->ne[0] == rn->ne[0] && ggml_abi_nelements(wn) == wn->ne[0] && same_shape(m, rn) &&
+                                !(((uintptr_t) wn->data) & 15) && !(((uintptr_t) dst->data) & 15) && (!add || !(((uintptr_t) add->data) & 15)) && quant_consumers_only(st, j + 1, m);
+                    }
+                }
+            }
             launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn, ks, part,
-                          add ? (const float *) add->data : nullptr, (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4));
+                          add ? (const float *) add->data : nullptr, add_stride, !defer);
+            if (defer) {
+                st.sk_dst = dst;
+                st.sk = splitk_src{part, ks, (int64_t) M * N, add ? (const float *) add->data : nullptr, add_stride, (float *) dst->data, (int64_t) (dst->nb[1] / 4)};
+                c->st.kernel_launches++;
+                st.sk_next = -1;
+                return true;
+            }
         }
         else
             launch_mmq(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), ks, part);
@@ -788,6 +820,14 @@ static bool try_fuse_rope_store(exec_state & st, int i) {
     return true;
 }
 
+// a deferred split-K sum that its designated reader did not pick up after all: run the plain reduce pass now
+static void flush_deferred_splitk(exec_state & st) {
+    if (!st.sk_dst) return;
+    launch_splitk_reduce(st.c->stream, st.sk.part, st.sk.ks, (int) (st.sk.mn / st.sk_dst->ne[0]), (int) st.sk_dst->ne[0], st.sk.out, st.sk.out_stride, st.sk.add, st.sk.add_stride);
+    st.c->st.kernel_launches++;
+    st.sk_dst = nullptr;
+}
+
 // executes node i (possibly fusing followers); returns number of nodes consumed, or -1 on failure
 static int run_node(exec_state & st, int i) {
     backend_ctx * c = st.c;
@@ -799,6 +839,7 @@ static int run_node(exec_state & st, int i) {
     const bool fuse = c->opt.fusion;
     auto next = [&](int k) -> ggml_tensor * { return i + k < g->n_nodes ? g->nodes[i + k] : nullptr; };
 
+    if (st.sk_dst && !is_view_op(n) && !(n->op == GGML_OP_RMS_NORM && a == st.sk_dst)) flush_deferred_splitk(st);
     switch (n->op) {
         case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             return 1;
@@ -817,12 +858,17 @@ static int run_node(exec_state & st, int i) {
                     if (c->opt.prologue && ggml_abi_nrows(m) > 1 && a->nb[0] == 4 && (a->nb[1] % 16) == 0 && a->ne[0] <= 16384 &&
                         !((((uintptr_t) a->data) | ((uintptr_t) w->data)) & 15) && quant_consumers_only(st, i + 1, m)) {
                         timed_scope ts(c, "rms_norm_mul_quantize", (double) ggml_abi_nbytes(a));
+                        if (st.sk_dst == a) {  // the row is still split-K partial products: assemble it here
+                            launch_splitk_rms_norm_mul_quantize(s, st.sk, (int) ggml_abi_nrows(a), (int) a->ne[0], (const float *) w->data, ggml_abi_op_param_f32(n, 0), (char *) c->ws + st.act_off);
+                            st.sk_dst = nullptr;
+                        } else
                         launch_rms_norm_mul_quantize(s, TD(a), (const float *) w->data, ggml_abi_op_param_f32(n, 0), (char *) c->ws + st.act_off);
                         mark_q8_cache(st, m);
                         c->st.kernel_launches++;
                         c->st.fused_nodes += 2;
                         return 2;
                     }
+                    flush_deferred_splitk(st);
                     const tdesc wd = TD(w);
                     timed_scope ts(c, "rms_norm_mul", (double) ggml_abi_nbytes(a) * 2);
                     launch_rms_norm(s, TD(a), TD(m), ggml_abi_op_param_f32(n, 0), &wd);
@@ -884,12 +930,18 @@ static int run_node(exec_state & st, int i) {
                 ggml_tensor * a1 = next(1);
                 const ggml_tensor * o1 = (a1 && single_use(st, n)) ? add_partner(a1, n) : nullptr;
                 if (o1) {
-                    if (!run_mul_mat_q(st, a, nullptr, b, a1, o1, nullptr)) return -1;
+                    st.sk_next = i + 2;
+                    const bool ok = run_mul_mat_q(st, a, nullptr, b, a1, o1, nullptr);
+                    st.sk_next = -1;
+                    if (!ok) return -1;
                     c->st.fused_nodes += 1;
                     return 2;
                 }
             }
-            if (!run_mul_mat_q(st, a, nullptr, b, n, nullptr, nullptr)) return -1;
+            st.sk_next = i + 1;
+            const bool ok_mm = run_mul_mat_q(st, a, nullptr, b, n, nullptr, nullptr);
+            st.sk_next = -1;
+            if (!ok_mm) return -1;
             if (rowpar) {
                 if (!tp_all_reduce(c, (float *) n->data, (size_t) ggml_abi_nelements(n))) return -1;
                 c->st.allreduces++;

@@ -97,13 +97,13 @@ size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M);
 // int8-matrix-core variant for Q4_K / Q5_K (mmq_i8.hip); force_bn: 0 = auto, 64 / 128 = weight-panel height
 struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
 // up to three matrices of one type against the same activations in one launch (wq/wk/wv, ffn_gate/ffn_up of a batch)
-void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part);
+void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce = true);
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M);
 // ksplit > 1: the K range is split over that many workgroup rows, partials in `part` (mmq_workspace_bytes), summed in a fixed order
 int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M);
 void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride);
+                   int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride, bool reduce = true);
 // Q8_0 weights x Q8_0 activations, one int8 MFMA per 32-value block + immediate f32 scale-accumulate (mmq_q80.hip)
 bool mmq_q80_supported(int type, int64_t K, int64_t N, int64_t M);
 void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
@@ -116,6 +116,9 @@ void launch_scale(hipStream_t s, const tdesc & src, const tdesc & dst, float sca
 void launch_unary(hipStream_t s, int uop, const tdesc & src, const tdesc & dst);
 void launch_swiglu(hipStream_t s, const tdesc & a, const tdesc * b, const tdesc & dst, int swapped);
 // producers fused with the Q8_K activation quantisation (quantize.hip): the f32 intermediate is not written
+// the same with the row ASSEMBLED first from split-K partials (+ epilogue add) — and written out as f32, for its other readers
+struct splitk_src { const float * part; int ks; int64_t mn; const float * add; int64_t add_stride; float * out; int64_t out_stride; };
+void launch_splitk_rms_norm_mul_quantize(hipStream_t s, const splitk_src & sk, int rows, int K, const float * w, float eps, void * dst);
 void launch_rms_norm_mul_quantize(hipStream_t s, const tdesc & x, const float * w, float eps, void * dst_q8k);
 void launch_swiglu_quantize(hipStream_t s, const tdesc & a, const tdesc * b, int64_t nc, int swapped, void * dst_q8k);
 void launch_cpy(hipStream_t s, const tdesc & src, const tdesc & dst);

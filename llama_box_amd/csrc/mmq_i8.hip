@@ -511,7 +511,7 @@ void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int 
 }
 
 // n_mat (1..3) matrices of one type against the same activations; `part` holds ksplit * M * sum(N) floats when ksplit > 1
-void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part) {
+void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce) {
     mmq8_args a{};
     a.n_mat = n_mat;
     a.K = K;
@@ -560,12 +560,12 @@ void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc 
         if (bn == 128) launch_mmq8_t<6, 128>(s, a);
         else launch_mmq8_t<6, 64>(s, a);
     }
-    if (a.ksplit > 1) launch_splitk_reduce_multi(s, a);
+    if (a.ksplit > 1 && reduce) launch_splitk_reduce_multi(s, a);  // (!reduce: the caller's next kernel sums the partials itself)
 }
 void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part, const float * add, int64_t add_stride) {
+                   int ksplit, float * part, const float * add, int64_t add_stride, bool reduce) {
     const mmq_mat_desc m{W, w_nb1, N, dst, dst_stride, add, add_stride};
-    launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part);
+    launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part, reduce);
 }
 
 }  // namespace mi355x

@@ -65,8 +65,11 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const char * __restrict__ 
 // ---- producers fused with the quantisation (batches: the f32 intermediate is never written).  Same f32 arithmetic as the
 // stand-alone kernels (ops.hip k_rms_norm + k_binary MUL, k_swiglu), so the Q8_K blocks are the ones the unfused path builds.
 // RMS_NORM(x) * w -> Q8_K: one 16-wave workgroup per row, wave w owns blocks w, w+16, w+32, w+48 (K <= 16384)
+// SK: the row does not exist yet — it is the sum of the split-K partial products of the mat-mul before (in split order, then the
+// epilogue add: exactly what k_splitk_reduce computes), written out as f32 on the way because the residual stream reads it later
+template <bool SK>
 __global__ void __launch_bounds__(1024) k_rms_norm_mul_q8_K(const char * __restrict__ src, const int64_t nb1, const float * __restrict__ w, const float eps, const int K,
-                                                            q8k_dev * __restrict__ dst) {
+                                                            q8k_dev * __restrict__ dst, const splitk_src sk) {
     __shared__ double red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = K / 256;
@@ -77,7 +80,22 @@ __global__ void __launch_bounds__(1024) k_rms_norm_mul_q8_K(const char * __restr
     for (int u = 0; u < 4; ++u) {
         const int b = wave + 16 * u;
         if (b < nblk) {
-            v[u] = x4[b * 64 + lane];
+            if constexpr (SK) {
+                const int64_t e = (int64_t) blockIdx.x * K + (b * 64 + lane) * 4;
+                float4 acc = *(const float4 *) (sk.part + e);
+                for (int k = 1; k < sk.ks; ++k) {
+                    const float4 p = *(const float4 *) (sk.part + (int64_t) k * sk.mn + e);
+                    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+                }
+                if (sk.add) {
+                    const float4 ad = *(const float4 *) (sk.add + (int64_t) blockIdx.x * sk.add_stride + (b * 64 + lane) * 4);
+                    acc.x += ad.x; acc.y += ad.y; acc.z += ad.z; acc.w += ad.w;
+                }
+                *(float4 *) (sk.out + (int64_t) blockIdx.x * sk.out_stride + (b * 64 + lane) * 4) = acc;
+                v[u] = acc;
+            } else {
+                v[u] = x4[b * 64 + lane];
+            }
             g[u] = w4[b * 64 + lane];
         } else {
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -106,7 +124,10 @@ __global__ void __launch_bounds__(1024) k_rms_norm_mul_q8_K(const char * __restr
 }
 void launch_rms_norm_mul_quantize(hipStream_t s, const tdesc & x, const float * w, float eps, void * dst) {
     const int64_t rows = x.ne[1] * x.ne[2] * x.ne[3];
-    hipLaunchKernelGGL(k_rms_norm_mul_q8_K, dim3((unsigned) rows), dim3(1024), 0, s, x.data, x.nb[1], w, eps, (int) x.ne[0], (q8k_dev *) dst);
+    hipLaunchKernelGGL(k_rms_norm_mul_q8_K<false>, dim3((unsigned) rows), dim3(1024), 0, s, x.data, x.nb[1], w, eps, (int) x.ne[0], (q8k_dev *) dst, splitk_src{});
+}
+void launch_splitk_rms_norm_mul_quantize(hipStream_t s, const splitk_src & sk, int rows, int K, const float * w, float eps, void * dst) {
+    hipLaunchKernelGGL(k_rms_norm_mul_q8_K<true>, dim3((unsigned) rows), dim3(1024), 0, s, (const char *) nullptr, (int64_t) 0, w, eps, K, (q8k_dev *) dst, sk);
 }
 
 // silu(a) * b -> Q8_K: one wave per 256-value block, four blocks per workgroup
