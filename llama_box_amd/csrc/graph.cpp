@@ -220,6 +220,8 @@ struct exec_state {
     const ggml_tensor * sk_dst = nullptr;
     splitk_src sk{};
     int sk_next = -1;  // node index at which run_mul_mat_q may look ahead (set by the caller: first node after the consumed ones)
+    // merged Q/K/V projections whose split-K partial products are summed by the rope + cache-store kernel at node `node`
+    struct { int node = -1, n = 0, ks = 0, M = 0; mmq_mat_desc mats[3]; const ggml_tensor * dst[3]; const float * part = nullptr; } rs_sk;
 };
 
 static int use_count(const exec_state & st, const ggml_tensor * t) {
@@ -647,6 +649,15 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     return true;
 }
 
+struct rope_store_plan {
+    rope_store_args a{};
+    int T = 0;
+    int nodes[3] = {-1, -1, -1};                            // ROPE(k), SET_ROWS(k), SET_ROWS(v)
+    const ggml_tensor * src[3] = {nullptr, nullptr, nullptr};  // what ROPE(q), ROPE(k) and SET_ROWS(v) read
+};
+static bool plan_rope_store(const exec_state & st, int i, rope_store_plan & pl);
+static const ggml_tensor * through_views(const ggml_tensor * t);
+
 // ------------------------------------------------------------------------------------------------ batches: sibling mat-muls
 // A batch's wq / wk / wv (and ffn_gate / ffn_up) multiply the same activations.  Launched one by one, the small ones cannot
 // fill the chip without a K split and its second kernel; as ONE launch over the concatenated row panels they can (mmq_i8.hip).
@@ -728,19 +739,53 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     const int ks = mmq_pick_ksplit(K, n_total, M);
     if ((size_t) ks * (size_t) M * (size_t) n_total * sizeof(float) > c->ws_size - st.aux_off && ks > 1) return 0;
     const void * act = quantized_src1(st, X, type);
-    {
-        timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (ms.size() == 3 ? "_x3" : "_x2")).c_str(), wbytes);
-        launch_mmq_i8_multi(c->stream, type, (int) ms.size(), mats, (int) K, (int) M, act, c->opt.mmq_bn, ks, (float *) ((char *) c->ws + st.aux_off));
-    }
-    c->st.kernel_launches += ks > 1 ? 2 : 1;
     for (size_t q = 1; q < ms.size(); ++q)
         for (int d = 0; d < ms[q].n_nodes; ++d) { st.done[ms[q].k + d] = 1; c->st.fused_nodes++; }
-    c->st.fused_nodes += ms[0].n_nodes - 1;
-    for (auto & o : others) {
-        if (!run_mul_mat_q(st, g->nodes[o.k]->src[0], nullptr, X, o.dst, o.add, nullptr)) return -1;
+    for (auto & o : others)
         for (int d = 0; d < o.n_nodes; ++d) st.done[o.k + d] = 1;
+    // K split and the results are read only by the rope + cache-store kernel that follows (attention projections of a small batch):
+    // that kernel sums the partial products itself — no reduce pass, and the f32 projections are never written
+    bool defer = false;
+    int jr = -1;
+    if (ks > 1 && c->opt.fusion && st.rs_sk.node < 0) {
+        for (int k = i + ms[0].n_nodes; k < std::min(g->n_nodes, i + 24) && jr < 0; ++k)
+            if (!st.done[k] && !is_view_op(g->nodes[k])) jr = k;
+        rope_store_plan pl;
+        if (jr >= 0 && plan_rope_store(st, jr, pl)) {
+            defer = true;
+            for (size_t q = 0; q < ms.size() && defer; ++q) {
+                bool mapped = false;
+                for (int sidx = 0; sidx < 3; ++sidx) mapped = mapped || through_views(pl.src[sidx]) == ms[q].dst;
+                const int64_t arows = ms[q].add ? ms[q].add->ne[1] * ms[q].add->ne[2] * ms[q].add->ne[3] : 0;
+                // every reader of the projection must be that kernel (one reshape in between), and a folded ADD must be a bias row
+                defer = mapped && use_count(st, ms[q].dst) == 1 && !(ms[q].dst->flags & GGML_TENSOR_FLAG_OUTPUT) && (!ms[q].add || arows == 1) &&
+                        (mats[q].N % pl.a.head_dim) == 0;
+            }
+        }
+    }
+    float * part = (float *) ((char *) c->ws + st.aux_off);
+    {
+        timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (ms.size() == 3 ? "_x3" : "_x2")).c_str(), wbytes);
+        launch_mmq_i8_multi(c->stream, type, (int) ms.size(), mats, (int) K, (int) M, act, c->opt.mmq_bn, ks, part, !defer);
+    }
+    c->st.kernel_launches += (ks > 1 && !defer) ? 2 : 1;
+    c->st.fused_nodes += ms[0].n_nodes - 1;
+    size_t aux_bump = 0;
+    if (defer) {
+        st.rs_sk.node = jr;
+        st.rs_sk.n = (int) ms.size();
+        st.rs_sk.ks = ks;
+        st.rs_sk.M = (int) M;
+        st.rs_sk.part = part;
+        for (size_t q = 0; q < ms.size(); ++q) { st.rs_sk.mats[q] = mats[q]; st.rs_sk.dst[q] = ms[q].dst; }
+        aux_bump = ((size_t) ks * (size_t) M * (size_t) n_total * sizeof(float) + 255) & ~(size_t) 255;  // the partials stay live: later launches use the space behind them
+    }
+    st.aux_off += aux_bump;
+    for (auto & o : others) {
+        if (!run_mul_mat_q(st, g->nodes[o.k]->src[0], nullptr, X, o.dst, o.add, nullptr)) { st.aux_off -= aux_bump; return -1; }
         c->st.fused_nodes += o.n_nodes - 1;
     }
+    st.aux_off -= aux_bump;
     return ms[0].n_nodes;
 }
 
@@ -753,10 +798,10 @@ static const ggml_tensor * through_views(const ggml_tensor * t) {
     while (t && (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW) && t->src[0] && t->data == t->src[0]->data) t = t->src[0];
     return t;
 }
-static bool try_fuse_rope_store(exec_state & st, int i) {
-    backend_ctx * c = st.c;
+static bool plan_rope_store(const exec_state & st, int i, rope_store_plan & pl) {
     ggml_cgraph * g = st.g;
     const ggml_tensor * rq = g->nodes[i];
+    if (rq->op != GGML_OP_ROPE) return false;
     const ggml_tensor * q = rq->src[0];
     if (rq->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(rq) || q->type != GGML_TYPE_F32 || q->nb[0] != 4 || rq->ne[3] != 1 || rq->ne[2] < 2) return false;
     if ((rq->op_params[2] & GGML_ROPE_TYPE_MROPE) || rq->src[1]->type != GGML_TYPE_I32 || !ggml_abi_is_contiguous(rq->src[1])) return false;
@@ -813,11 +858,48 @@ static bool try_fuse_rope_store(exec_state & st, int i) {
     a.p.beta_slow = ggml_abi_op_param_f32(rq, 10);
     memset(a.p.sections, 0, sizeof(a.p.sections));
     a.nh = (int) NH; a.nkv = (int) NKV; a.head_dim = (int) HD;
-    timed_scope ts(c, "rope_qk_store", (double) ggml_abi_nbytes(rq) * 2);
-    launch_rope_qk_store(c->stream, a, (int) T);
-    c->st.kernel_launches++;
-    for (int k : {jk, jks, jvs}) { st.done[k] = 1; c->st.fused_nodes++; }
+    pl.a = a;
+    pl.T = (int) T;
+    pl.nodes[0] = jk; pl.nodes[1] = jks; pl.nodes[2] = jvs;
+    pl.src[0] = q; pl.src[1] = ksrc; pl.src[2] = vsrc;
     return true;
+}
+static void flush_deferred_qkv(exec_state & st);
+static bool try_fuse_rope_store(exec_state & st, int i) {
+    backend_ctx * c = st.c;
+    rope_store_plan pl;
+    if (!plan_rope_store(st, i, pl)) {
+        flush_deferred_qkv(st);
+        return false;
+    }
+    if (st.rs_sk.node == i) {
+        // the projections' split-K partial products were left unsummed for this kernel (try_merge_mm_batch): wire them in
+        const float * pp = st.rs_sk.part;
+        for (int q = 0; q < st.rs_sk.n; ++q) {
+            for (int sidx = 0; sidx < 3; ++sidx) {
+                if (through_views(pl.src[sidx]) != st.rs_sk.dst[q]) continue;
+                pl.a.sk[sidx].part = pp;
+                pl.a.sk[sidx].mn = (int64_t) st.rs_sk.M * st.rs_sk.mats[q].N;
+                pl.a.sk[sidx].bias = st.rs_sk.mats[q].add;
+                pl.a.sk[sidx].n = st.rs_sk.mats[q].N;
+            }
+            pp += (size_t) st.rs_sk.ks * st.rs_sk.M * st.rs_sk.mats[q].N;
+        }
+        pl.a.ks = st.rs_sk.ks;
+        st.rs_sk.node = -1;
+    }
+    timed_scope ts(c, "rope_qk_store", (double) ggml_abi_nbytes(st.g->nodes[i]) * 2);
+    launch_rope_qk_store(c->stream, pl.a, pl.T);
+    c->st.kernel_launches++;
+    for (int k : pl.nodes) { st.done[k] = 1; c->st.fused_nodes++; }
+    return true;
+}
+// the reader the unsummed projections were left for did not materialise: run their reduce pass now
+static void flush_deferred_qkv(exec_state & st) {
+    if (st.rs_sk.node < 0) return;
+    launch_splitk_reduce_mats(st.c->stream, st.rs_sk.n, st.rs_sk.mats, st.rs_sk.part, st.rs_sk.ks, st.rs_sk.M);
+    st.c->st.kernel_launches++;
+    st.rs_sk.node = -1;
 }
 
 // a deferred split-K sum that its designated reader did not pick up after all: run the plain reduce pass now
@@ -840,6 +922,7 @@ static int run_node(exec_state & st, int i) {
     auto next = [&](int k) -> ggml_tensor * { return i + k < g->n_nodes ? g->nodes[i + k] : nullptr; };
 
     if (st.sk_dst && !is_view_op(n) && !(n->op == GGML_OP_RMS_NORM && a == st.sk_dst)) flush_deferred_splitk(st);
+    if (st.rs_sk.node >= 0 && st.rs_sk.node != i && !is_view_op(n)) flush_deferred_qkv(st);
     switch (n->op) {
         case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             return 1;

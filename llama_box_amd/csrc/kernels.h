@@ -98,6 +98,7 @@ size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M);
 struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
 // up to three matrices of one type against the same activations in one launch (wq/wk/wv, ffn_gate/ffn_up of a batch)
 void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce = true);
+void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * mats, const float * part, int ks, int M);  // the reduce pass of launch_mmq_i8_multi(reduce = false), later
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M);
 // ksplit > 1: the K range is split over that many workgroup rows, partials in `part` (mmq_workspace_bytes), summed in a fixed order
 int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M);
@@ -149,6 +150,10 @@ struct rope_store_args {
     rope_params p;
     float theta_scale, corr0, corr1;
     int nh, nkv, head_dim;
+    // a source that is still the split-K partial products of its projection ([ks][tokens][rows] floats + optional bias row): the kernel
+    // sums them itself, in split order then bias — what the reduce pass would have written (part == nullptr: read *_src)
+    struct { const float * part; int64_t mn; const float * bias; int n; } sk[3];  // q, k, v
+    int ks;
 };
 void launch_rope_qk_store(hipStream_t s, rope_store_args a, int n_tokens);
 void launch_rope(hipStream_t s, const tdesc & src, const tdesc & pos, const float * freq_factors, const tdesc & dst, const rope_params & p);

@@ -562,6 +562,23 @@ void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc 
     }
     if (a.ksplit > 1 && reduce) launch_splitk_reduce_multi(s, a);  // (!reduce: the caller's next kernel sums the partials itself)
 }
+void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * mats, const float * part, int ks, int M) {
+    mmq8_args a{};
+    a.n_mat = n_mat;
+    a.M = M;
+    a.ksplit = ks;
+    float * pp = const_cast<float *>(part);
+    for (int i = 0; i < n_mat; ++i) {
+        a.mat[i].N = mats[i].N;
+        a.mat[i].dst = mats[i].dst;
+        a.mat[i].dst_stride = mats[i].dst_stride;
+        a.mat[i].add = mats[i].add;
+        a.mat[i].add_stride = mats[i].add_stride;
+        a.mat[i].part = pp;
+        pp += (size_t) ks * M * mats[i].N;
+    }
+    launch_splitk_reduce_multi(s, a);
+}
 void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
                    int ksplit, float * part, const float * add, int64_t add_stride, bool reduce) {
     const mmq_mat_desc m{W, w_nb1, N, dst, dst_stride, add, add_stride};

@@ -470,6 +470,16 @@ __global__ void __launch_bounds__(256) k_rope_qk_store(const rope_store_args a) 
     const bool neox = (a.p.mode & GGML_ROPE_TYPE_NEOX) != 0;
     const rope_consts rc{a.theta_scale, a.p.freq_scale, a.p.ext_factor, a.p.attn_factor, a.corr0, a.corr1};
     const int64_t row = a.idx[t];
+    // element i of head h of source s (0 q, 1 k, 2 v): from memory, or assembled from the split-K partial products of its projection
+    auto ld = [&](const int sidx, const float * src, const int h, const int i) -> float {
+        const float * part = a.sk[sidx].part;
+        if (part == nullptr) return src[i];
+        const int64_t e = t * a.sk[sidx].n + (int64_t) h * a.head_dim + i;
+        float v = part[e];
+        for (int k = 1; k < a.ks; ++k) v += part[(int64_t) k * a.sk[sidx].mn + e];
+        if (a.sk[sidx].bias) v += a.sk[sidx].bias[(int64_t) h * a.head_dim + i];
+        return v;
+    };
     // blockIdx.y: this workgroup's share of the head slots (one share per token for big batches, where recomputing the angles
     // per head is the cost; many shares for a few dozen tokens, where filling the chip is)
     const int n_all = a.nh + 2 * a.nkv, per = (n_all + (int) gridDim.y - 1) / (int) gridDim.y;
@@ -486,14 +496,14 @@ __global__ void __launch_bounds__(256) k_rope_qk_store(const rope_store_args a) 
             if (slot < a.nh) {
                 const float * src = (const float *) (a.q_src + slot * a.q_nb1 + t * a.q_nb2);
                 float * dst = (float *) (a.q_dst + slot * a.qd_nb1 + t * a.qd_nb2);
-                const float x0 = src[ia], x1 = src[ib];
+                const float x0 = ld(0, src, slot, ia), x1 = ld(0, src, slot, ib);
                 dst[ia] = x0 * cs - x1 * sn;
                 dst[ib] = x0 * sn + x1 * cs;
             } else {
                 const int h = slot - a.nh;
                 const float * src = (const float *) (a.k_src + h * a.k_nb1 + t * a.k_nb2);
                 uint16_t * dst = (uint16_t *) (a.k_cache + row * a.kc_nb1) + (int64_t) h * a.head_dim;
-                const float x0 = src[ia], x1 = src[ib];
+                const float x0 = ld(1, src, h, ia), x1 = ld(1, src, h, ib);
                 dst[ia] = f2h(x0 * cs - x1 * sn);
                 dst[ib] = f2h(x0 * sn + x1 * cs);
             }
@@ -504,17 +514,17 @@ __global__ void __launch_bounds__(256) k_rope_qk_store(const rope_store_args a) 
         if (slot < a.nh) {
             const float * src = (const float *) (a.q_src + slot * a.q_nb1 + t * a.q_nb2);
             float * dst = (float *) (a.q_dst + slot * a.qd_nb1 + t * a.qd_nb2);
-            for (int i0 = a.p.n_dims + lane; i0 < a.head_dim; i0 += 64) dst[i0] = src[i0];
+            for (int i0 = a.p.n_dims + lane; i0 < a.head_dim; i0 += 64) dst[i0] = ld(0, src, slot, i0);
         } else if (slot < a.nh + a.nkv) {
             const int h = slot - a.nh;
             const float * src = (const float *) (a.k_src + h * a.k_nb1 + t * a.k_nb2);
             uint16_t * dst = (uint16_t *) (a.k_cache + row * a.kc_nb1) + (int64_t) h * a.head_dim;
-            for (int i0 = a.p.n_dims + lane; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(src[i0]);
+            for (int i0 = a.p.n_dims + lane; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(ld(1, src, h, i0));
         } else {
             const int h = slot - a.nh - a.nkv;
             const float * src = (const float *) (a.v_src + h * a.v_nb1 + t * a.v_nb2);
             uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * a.head_dim;
-            for (int i0 = lane; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(src[i0]);
+            for (int i0 = lane; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(ld(2, src, h, i0));
         }
     }
 }
