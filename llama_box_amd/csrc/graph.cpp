@@ -1021,7 +1021,7 @@ static int run_node(exec_state & st, int i) {
                     return 2;
                 }
             }
-            st.sk_next = i + 1;
+            st.sk_next = rowpar ? -1 : i + 1;  // (a row-parallel result is all-reduced right after: its split-K sum cannot wait for the next kernel)
             const bool ok_mm = run_mul_mat_q(st, a, nullptr, b, n, nullptr, nullptr);
             st.sk_next = -1;
             if (!ok_mm) return -1;
