@@ -305,7 +305,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         return true;
     }
     const bool i8 = c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M);
-    if (M >= c->opt.mmq_min_cols && !w2 && !add2 && (!add || i8) && mmq_supported(w->type, K, N, M)) {
+    if (M >= c->opt.mmq_min_cols && !w2 && !add2 && (!add || i8) && (i8 || mmq_supported(w->type, K, N, M))) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
         const int ks = (N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M) : 1;
         float * part = (float *) ((char *) c->ws + st.aux_off);

@@ -1,4 +1,4 @@
-// mmq_i8.hip — batched mat-mul (9 columns and up: continuous-batching decode steps, prompt micro-batches) for Q4_K, Q5_K and
+// mmq_i8.hip — batched mat-mul (3 columns and up: continuous-batching decode steps, prompt micro-batches) for Q4_K, Q5_K and
 // Q6_K weights on the gfx950 INTEGER matrix cores.
 //
 // Same contract as mmq.hip (ggml-cpu's ggml_vec_dot_q{4,5}_K_q8_K: integer block sums on Q8_K activations, one f32
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(BN * 4, BN == 64 ? (BM == 32 ? 3 : 2) : 1) k_m
 
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M) {
     (void) N;
-    return (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K) && (K % 256) == 0 && M >= 9;
+    return (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K) && (K % 256) == 0 && M >= 2;
 }
 
 template <int QT, int BN, int BM = 128> static void launch_mmq8_t(hipStream_t s, mmq8_args a) {
