@@ -28,7 +28,7 @@ def both(build, backend):
 MM_SHAPES = [  # (K, N, M)
     (256, 8, 1), (512, 33, 1), (4096, 64, 1), (4096, 257, 1), (14336, 16, 1), (2048, 40, 1),
     (1024, 48, 2), (1024, 48, 3), (512, 64, 4), (512, 20, 5), (768, 32, 8), (512, 24, 9), (512, 16, 19),
-    # M >= 9 takes the MFMA path (mmq.hip) for K-quants: full tiles, ragged rows/columns, several super-blocks
+    # M >= 3 takes the matrix-core path for K-quants: full tiles, ragged rows/columns, several super-blocks
     (512, 128, 128), (1024, 200, 300), (4096, 256, 160), (256, 130, 33), (2048, 384, 512),
 ]
 
@@ -47,6 +47,26 @@ def test_mul_mat_q(backend, H, plog, qt, K, N, M):
 
     ref, got = both(build, backend)
     T.compare(f"mul_mat {QNAME[qt]} K={K} N={N} M={M}", got[0], ref[0], max_nmse=1e-10, log=plog)
+
+
+@pytest.mark.parametrize("qt", QTYPES)
+@pytest.mark.parametrize("K,N,M", [(1024, 48, 3), (512, 64, 4), (512, 20, 5), (768, 32, 8), (4096, 130, 7)])
+def test_mul_mat_q_multi_column_mat_vec(backend, H, plog, qt, K, N, M):
+    """3..8 columns on the multi-column mat-vec kernels (k_mmvq<T, NC>): the route taken when the matrix-core path is switched
+    off (mmq_min_cols above the batch) and, for Q8_0 weights, always below 33 columns."""
+    rng = np.random.default_rng(K + N + M + qt)
+    w = T.rand_weight(qt, K, N, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+
+    def build(g):
+        return H.ggml_mul_mat(g.ctx, g.new(qt, [K, N], w), g.new(L.F32, [K, M], x))
+
+    backend.set_option("mmq_min_cols", 9)
+    try:
+        ref, got = both(build, backend)
+    finally:
+        backend.set_option("mmq_min_cols", 3)
+    T.compare(f"mul_mat multi-column mat-vec {QNAME[qt]} K={K} N={N} M={M}", got[0], ref[0], max_nmse=1e-10, log=plog)
 
 
 @pytest.mark.parametrize("i8,bn", [(1, 64), (1, 128), (0, 0)])
