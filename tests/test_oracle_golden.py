@@ -156,3 +156,69 @@ def test_mul_mat_graph_matches_vec_dot(built, H):
             import golden.make_golden as GG  # noqa
             ref = np.array([[GG.vec_dot_exact(qt, w[n].reshape(-1, L.TYPE_SIZE[qt]), x[m]) for n in range(N)] for m in range(M)])
         assert T.nmse(y, ref) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------ property tests (hypothesis)
+# SURVEY.md §8c asks for them because the reference pins nothing: whatever bytes a block holds, the C oracle and the independent
+# NumPy restatement must agree bit for bit, scaling d by a power of two must scale the result exactly, and the integer dot
+# product must stay within the Q8 rounding bound of the real one.
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+import golden.make_golden as GG  # noqa: E402
+
+
+def _arbitrary_blocks(qt, data, n_blocks):
+    """Blocks of ARBITRARY bytes with finite, modest f16 scales (every bit pattern of quants / packed scales is legal)."""
+    bs = L.TYPE_SIZE[qt]
+    raw = np.frombuffer(data.draw(st.binary(min_size=bs * n_blocks, max_size=bs * n_blocks)), np.uint8).reshape(n_blocks, bs).copy()
+    scales = np.array(data.draw(st.lists(st.floats(-4.0, 4.0, width=16), min_size=2 * n_blocks, max_size=2 * n_blocks)), np.float16)
+    if qt == L.Q8_0:
+        raw[:, 0:2] = scales[:n_blocks].view(np.uint8).reshape(n_blocks, 2)
+    elif qt in (L.Q4_K, L.Q5_K):
+        raw[:, 0:2] = scales[:n_blocks].view(np.uint8).reshape(n_blocks, 2)
+        raw[:, 2:4] = scales[n_blocks:].view(np.uint8).reshape(n_blocks, 2)
+    else:
+        raw[:, 208:210] = scales[:n_blocks].view(np.uint8).reshape(n_blocks, 2)
+    return raw
+
+
+@pytest.mark.parametrize("name,qt", TYPES)
+@settings(max_examples=25, deadline=None)
+@given(data=st.data())
+def test_dequantize_arbitrary_bytes_matches_numpy(built, name, qt, data):
+    o = T.oracle()
+    blocks = _arbitrary_blocks(qt, data, 3)
+    n = blocks.shape[0] * L.TYPE_BLCK[qt]
+    y = np.empty(n, np.float32)
+    o.oracle_dequantize_row(qt, _ptr(blocks), _ptr(y), n)
+    ref = GG.dequant(qt, blocks).reshape(-1).astype(np.float32)
+    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+    # doubling every scale doubles every value exactly (no rounding is involved in a power-of-two factor)
+    b2 = blocks.copy()
+    cols = [(0, 2)] if qt == L.Q8_0 else ([(0, 2), (2, 4)] if qt in (L.Q4_K, L.Q5_K) else [(208, 210)])
+    for lo, hi in cols:
+        d = b2[:, lo:hi].copy().view(np.float16).astype(np.float32) * 2.0
+        b2[:, lo:hi] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    y2 = np.empty(n, np.float32)
+    o.oracle_dequantize_row(qt, _ptr(b2), _ptr(y2), n)
+    assert np.array_equal(y2, 2.0 * y)
+
+
+@settings(max_examples=25, deadline=None)
+@given(x=st.lists(st.floats(-1e4, 1e4, width=32), min_size=256, max_size=256), scale=st.sampled_from([1e-6, 1e-3, 1.0, 37.5]))
+def test_quantize_q8_K_properties(built, x, scale):
+    """quantize_row_q8_K: C oracle == NumPy restatement bit for bit; |x - d*q| <= |d|/2 (+ the clamp at 127); bsums are the sums."""
+    o = T.oracle()
+    xv = (np.array(x, np.float32) * np.float32(scale)).astype(np.float32)
+    out = np.zeros((1, 292), np.uint8)
+    o.oracle_quantize_row_q8_K(_ptr(xv), _ptr(out), 256)
+    d = out[0, 0:4].copy().view(np.float32)[0]
+    qs = out[0, 4:260].view(np.int8).astype(np.int32)
+    bs = out[0, 260:292].copy().view(np.int16).astype(np.int32)
+    gd, gq, gb = GG.quantize_q8_K(xv.reshape(1, 256))
+    assert np.float32(gd.reshape(-1)[0]).view(np.uint32) == np.float32(d).view(np.uint32)
+    assert np.array_equal(gq.reshape(-1).astype(np.int32), qs) and np.array_equal(gb.reshape(-1).astype(np.int32), bs)
+    assert np.array_equal(qs.reshape(16, 16).sum(axis=1), bs)
+    if d != 0.0:
+        err = np.abs(xv.astype(np.float64) - float(d) * qs)
+        assert np.all(err <= abs(float(d)) * (0.5 + 1e-6) + abs(float(d)) * (qs == 127))  # (a value rounding to 128 is clamped to 127)
