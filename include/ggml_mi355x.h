@@ -60,7 +60,9 @@ typedef int (*ggml_backend_mi355x_tp_init_t)(ggml_backend_t backend, int rank, i
 typedef int (*ggml_backend_mi355x_tp_get_unique_id_t)(void * unique_id_out, size_t unique_id_size);
 typedef ggml_backend_buffer_type_t (*ggml_backend_mi355x_tp_rowpar_buffer_type_t)(int device);
 
-/* Runtime options (string key/value), e.g. ("graphs","0"), ("fusion","0"), ("mmvq_rows","2"). 0 = accepted. */
+/* Runtime options (string key/value); 0 = accepted, -1 = unknown key.  Keys (INTEGRATION.md 4b lists the defaults and the
+ * environment variables that set the same things): "graphs", "fusion", "prologue", "qkv", "mm_merge", "mmq_i8", "mmq_bn",
+ * "mmq_min_cols", "mmvq_max_cols", "fa_splits", "small_uploads", "timing". */
 typedef int (*ggml_backend_mi355x_set_option_t)(ggml_backend_t backend, const char * key, const char * value);
 /* Counters for tests/bench: "graph_launches", "graph_captures", "eager_nodes", "kernel_launches", "fused_nodes". */
 typedef int64_t (*ggml_backend_mi355x_get_stat_t)(ggml_backend_t backend, const char * key);
