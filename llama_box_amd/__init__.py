@@ -66,9 +66,15 @@ assert C.sizeof(Tensor) == 272 + GGML_MAX_NAME
 TP = C.POINTER(Tensor)
 
 
+class HashSet(C.Structure):
+    _fields_ = [("size", C.c_size_t), ("used", C.POINTER(C.c_uint32)), ("keys", C.POINTER(TP))]
+
+
 class CGraph(C.Structure):
+    """struct ggml_cgraph (include/ggml_abi.h), complete: ggml_graph_view returns it by value."""
     _fields_ = [("size", C.c_int), ("n_nodes", C.c_int), ("n_leafs", C.c_int), ("nodes", C.POINTER(TP)),
-                ("grads", C.c_void_p), ("grad_accs", C.c_void_p), ("leafs", C.POINTER(TP))]
+                ("grads", C.c_void_p), ("grad_accs", C.c_void_p), ("leafs", C.POINTER(TP)),
+                ("use_counts", C.POINTER(C.c_int32)), ("visited_hash_set", HashSet), ("order", C.c_int)]
 
 
 class HParams(C.Structure):
@@ -117,7 +123,7 @@ _SIGS = {
     "ggml_flash_attn_ext_add_sinks": (None, [TP, TP]), "ggml_argmax": (TP, [_P, TP]),
     "ggml_new_graph": (C.POINTER(CGraph), [_P]), "ggml_new_graph_custom": (C.POINTER(CGraph), [_P, _SZ, _B]),
     "ggml_build_forward_expand": (None, [C.POINTER(CGraph), TP]), "ggml_graph_n_nodes": (_I, [C.POINTER(CGraph)]),
-    "ggml_graph_node": (TP, [C.POINTER(CGraph), _I]),
+    "ggml_graph_node": (TP, [C.POINTER(CGraph), _I]), "ggml_graph_view": (CGraph, [C.POINTER(CGraph), _I, _I]),
     # ggml-backend.h mirror
     "ggml_backend_load": (_P, [_S]), "ggml_backend_reg_name": (_S, [_P]), "ggml_backend_reg_dev_count": (_SZ, [_P]),
     "ggml_backend_reg_dev_get": (_P, [_P, _SZ]), "ggml_backend_reg_get_proc_address": (_P, [_P, _S]),

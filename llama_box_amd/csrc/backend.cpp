@@ -464,9 +464,40 @@ static void init_reg() {
         d->buft_host = {{hbuft_name, hbuft_alloc, hbuft_alignment, nullptr, nullptr, hbuft_is_host}, dev, nullptr};
         g_reg_ctx.devices.push_back(dev);
     }
-    int api = GGML_BACKEND_API_VERSION;
-    if (const char * e = getenv("GGML_MI355X_API_VERSION")) api = atoi(e);
-    g_reg = {api, k_reg_iface, &g_reg_ctx};
+    // (no run-time override of api_version: a host of another version also has other struct layouts — ggml_backend_dev_props
+    // grew a field between 1 and 2 — so registering under its number would be a lie; rebuild with -DGGML_BACKEND_API_VERSION=N)
+    g_reg = {GGML_BACKEND_API_VERSION, k_reg_iface, &g_reg_ctx};
+}
+
+// include/ggml_abi.h restates enum ggml_op from memory (the headers are un-vendored).  If the host was built from a
+// tree that numbers the operators differently — upstream inserts ops now and then — every dispatch after the insertion point would
+// silently run the wrong kernel.  The host's own name table settles it: ggml_op_name() lives in libggml-base, which a
+// GGML_BACKEND_DL host has loaded before it dlopen()s a backend.  A symbol that cannot be resolved (fully static host) is
+// logged and tolerated; a NAME MISMATCH refuses registration.
+static bool op_numbering_matches_host() {
+    typedef const char * (*op_name_fn)(int);
+    op_name_fn host_name = (op_name_fn) dlsym(RTLD_DEFAULT, "ggml_op_name");
+    if (!host_name) {
+        MI_INFO("ggml_op_name is not resolvable in this process: operator numbering of include/ggml_abi.h not verified against the host");
+        return true;
+    }
+    static const struct { int op; const char * name; } k_expect[] = {
+        {GGML_OP_NONE, "NONE"}, {GGML_OP_DUP, "DUP"}, {GGML_OP_ADD, "ADD"}, {GGML_OP_SUB, "SUB"}, {GGML_OP_MUL, "MUL"}, {GGML_OP_DIV, "DIV"},
+        {GGML_OP_ARGMAX, "ARGMAX"}, {GGML_OP_RMS_NORM, "RMS_NORM"}, {GGML_OP_MUL_MAT, "MUL_MAT"}, {GGML_OP_MUL_MAT_ID, "MUL_MAT_ID"}, {GGML_OP_SCALE, "SCALE"},
+        {GGML_OP_CPY, "CPY"}, {GGML_OP_CONT, "CONT"}, {GGML_OP_RESHAPE, "RESHAPE"}, {GGML_OP_VIEW, "VIEW"}, {GGML_OP_PERMUTE, "PERMUTE"},
+        {GGML_OP_TRANSPOSE, "TRANSPOSE"}, {GGML_OP_GET_ROWS, "GET_ROWS"}, {GGML_OP_SET_ROWS, "SET_ROWS"}, {GGML_OP_SOFT_MAX, "SOFT_MAX"},
+        {GGML_OP_ROPE, "ROPE"}, {GGML_OP_FLASH_ATTN_EXT, "FLASH_ATTN_EXT"}, {GGML_OP_UNARY, "UNARY"}, {GGML_OP_GLU, "GLU"},
+    };
+    bool ok = true;
+    for (const auto & e : k_expect) {
+        const char * got = host_name(e.op);
+        if (!got || strcmp(got, e.name) != 0) {
+            MI_ERR("operator numbering mismatch: this library was built with %s = %d, the host calls op %d \"%s\" — rebuild against the host's ggml.h (tools/abi_dump.c prints both tables)",
+                   e.name, e.op, e.op, got ? got : "(null)");
+            ok = false;
+        }
+    }
+    return ok;
 }
 
 }  // namespace mi355x
@@ -484,6 +515,8 @@ __attribute__((visibility("default"))) ggml_backend_reg_t ggml_backend_init(void
         MI_ERR("no gfx950 (MI355X) device visible: backend not registered");
         return nullptr;
     }
+    static const bool ops_ok = mi355x::op_numbering_matches_host();
+    if (!ops_ok) return nullptr;
     return reg;
 }
 

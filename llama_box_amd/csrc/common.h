@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -128,6 +129,23 @@ struct backend_ctx {
     std::map<std::string, timing_slot> timing;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, DEVICE) pair: llama-box's usual multi-GPU mode is one process
+// driving several MI355X, so "raised once per process" would leave every device but the first at the 64 KB default and its launches
+// failing.  `done` is one bit per device ordinal, owned by the launcher of that kernel instantiation.
+inline bool ensure_dyn_lds(const void * kernel, size_t bytes, std::atomic<uint32_t> & done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    const uint32_t bit = 1u << dev;
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes) != hipSuccess) {
+        (void) hipGetLastError();
+        MI_ERR("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed on device %d", bytes, dev);
+        return false;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 
 void flush_uploads(backend_ctx * c);  // launches the small uploads staged by set_tensor_async (backend.cpp)
 

@@ -202,16 +202,19 @@ struct deferred_norm {
     const ggml_tensor * x;  // RMS_NORM input (residual stream)
     const ggml_tensor * w;  // norm weight
     float eps;
+    const ggml_tensor * out;  // the MUL node: its memory is still written (by workgroup 0 of every consumer launch), see use_count()
 };
 struct exec_state {
     backend_ctx * c;
     ggml_cgraph * g;
     std::unordered_map<const ggml_tensor *, int> uses;
+    mutable std::unordered_map<const ggml_tensor *, int> uses_global;  // memo of graph_use_count()
     size_t act_off = 0, aux_off = 0;
     // [RMS_NORM -> MUL] pairs whose result is consumed only by single-column K-quant mat-vecs: nothing is launched
     // for them; each consumer recomputes norm*w in its prologue (mmvq.hip PRO=2)
     std::unordered_map<const ggml_tensor *, deferred_norm> deferred;
     std::vector<char> done;  // nodes already executed out of order by a multi-chain fusion
+    std::vector<int> ooo;    // ... those flagged during the current run_node call (quantised-activation cache invalidation)
     bool q8_fresh = false;   // the node just executed produced the quantised-activation cache for its own output
     // tile lists (fattn.hip) valid for this mask tensor / tile size during this execution of the graph
     const void * fa_list_mask = nullptr;
@@ -224,9 +227,40 @@ struct exec_state {
     struct { int node = -1, n = 0, ks = 0, M = 0; mmq_mat_desc mats[3]; const ggml_tensor * dst[3]; const float * part = nullptr; } rs_sk;
 };
 
+// Number of readers of t.  A backend is handed ONE split of the host's graph (ggml_backend_sched: ggml_graph_view of the full
+// graph), so counting the nodes it was given is not enough to call a tensor dead: the reader may sit in another backend's
+// split.  Since the fusion helpers (ggml_can_fuse) the cgraph carries use_counts for the WHOLE graph, indexed by the slot of
+// visited_hash_set, and views share the parent's table — that count wins when it is larger.  A host that provides no table
+// (use_counts == NULL) gets local counts only; the fusions that skip a write then rely on GGML_TENSOR_FLAG_OUTPUT alone, which is
+// why the one elision llama.cpp is known to read behind (result_norm = t_embd) is never an elision here: a deferred
+// RMS_NORM * w is still written, by workgroup 0 of its consumer (deferred_norm::out).
+static int graph_use_count(const ggml_cgraph * g, const ggml_tensor * t) {
+    const ggml_hash_set & hs = g->visited_hash_set;
+    if (!g->use_counts || !hs.size || !hs.used || !hs.keys) return -1;
+    const size_t h = ((size_t) (uintptr_t) t >> 4) % hs.size;  // ggml_hash / ggml_hash_find
+    size_t i = h;
+    while (hs.used[i >> 5] & (1u << (i & 31))) {
+        if (hs.keys[i] == t) return g->use_counts[i];
+        i = (i + 1) % hs.size;
+        if (i == h) break;
+    }
+    return -1;
+}
+static void mark_done(exec_state & st, int k) {
+    st.done[k] = 1;
+    st.ooo.push_back(k);
+}
 static int use_count(const exec_state & st, const ggml_tensor * t) {
     auto it = st.uses.find(t);
-    return it == st.uses.end() ? 0 : it->second;
+    const int local = it == st.uses.end() ? 0 : it->second;
+    auto ig = st.uses_global.find(t);
+    int glob;
+    if (ig != st.uses_global.end()) glob = ig->second;
+    else {
+        glob = graph_use_count(st.g, t);
+        st.uses_global.emplace(t, glob);
+    }
+    return std::max(local, glob);
 }
 static bool single_use(const exec_state & st, const ggml_tensor * t) { return use_count(st, t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT); }
 
@@ -288,6 +322,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         a.x = pro_norm ? (const float *) dn->second.x->data : (const float *) b->data;
         a.norm_w = pro_norm ? (const float *) dn->second.w->data : nullptr;
         a.eps = pro_norm ? dn->second.eps : 0.0f;
+        a.norm_out = pro_norm ? (float *) dn->second.out->data : nullptr;
         char cls[64];
         snprintf(cls, sizeof(cls), "mmvq_%s%s_%s", type_tag(w->type), w2 ? "_glu" : "", pro_norm ? "normpro" : "f32pro");
         timed_scope ts(c, cls, wbytes, true);
@@ -428,7 +463,7 @@ static void mark_q8_cache(exec_state & st, const ggml_tensor * t) {
 // memory overlapping x — the host allocator may already have recycled x's block if the norm was its last reader.
 static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, const ggml_tensor * m, const ggml_tensor * x, const ggml_tensor * w) {
     if (ggml_abi_nrows(m) != 1 || (m->flags & GGML_TENSOR_FLAG_OUTPUT) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
-    if (!ggml_abi_is_contiguous(x) || ((((uintptr_t) x->data) | ((uintptr_t) w->data)) & 15) || (x->ne[0] % 256) != 0 || x->ne[0] > 16384) return false;
+    if (!ggml_abi_is_contiguous(x) || !ggml_abi_is_contiguous(m) || ((((uintptr_t) x->data) | ((uintptr_t) w->data) | ((uintptr_t) m->data)) & 15) || (x->ne[0] % 256) != 0 || x->ne[0] > 16384) return false;
     const ggml_cgraph * g = st.g;
     int last = -1, n_cons = 0;
     for (int j = i + 2; j < g->n_nodes; ++j) {
@@ -457,6 +492,7 @@ static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, 
 }
 
 // ------------------------------------------------------------------------------------------------ fused Q/K/V
+static bool ranges_overlap(const ggml_tensor * x, const ggml_tensor * y);
 static bool is_view_op(const ggml_tensor * t) {
     return t->op == GGML_OP_NONE || t->op == GGML_OP_VIEW || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE;
 }
@@ -577,12 +613,20 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             idx0 = ch.store->src[1];
         }
     }
+    // every workgroup reads X in its prologue while others may already be storing results: when X is a materialised tensor
+    // (no deferred norm), none of the launch's outputs may live in memory the allocator recycled from X
+    if (!norm)
+        for (auto & ch : chains) {
+            const ggml_tensor * o = ch.store ? nullptr : ch.out_f32;
+            if (o && ranges_overlap(o, X)) return false;
+        }
     // rope parameters shared by every launch of this group
     qkv_args base{};
     base.K = (int) X->ne[0];
     base.x = norm ? (const float *) dn->second.x->data : (const float *) X->data;
     base.norm_w = norm ? (const float *) dn->second.w->data : nullptr;
     base.eps = norm ? dn->second.eps : 0.0f;
+    base.norm_out = norm ? (float *) dn->second.out->data : nullptr;
     if (rope0) {
         rope_params p;
         p.n_dims = rope0->op_params[1];
@@ -645,7 +689,7 @@ static bool try_fuse_qkv(exec_state & st, int i) {
         launch_qkv(c->stream, a, type, type_b);
         c->st.kernel_launches++;
     }
-    for (auto & ch : chains) for (int k : ch.nodes) { st.done[k] = 1; c->st.fused_nodes++; }
+    for (auto & ch : chains) for (int k : ch.nodes) { mark_done(st, k); c->st.fused_nodes++; }
     return true;
 }
 
@@ -740,9 +784,9 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     if ((size_t) ks * (size_t) M * (size_t) n_total * sizeof(float) > c->ws_size - st.aux_off && ks > 1) return 0;
     const void * act = quantized_src1(st, X, type);
     for (size_t q = 1; q < ms.size(); ++q)
-        for (int d = 0; d < ms[q].n_nodes; ++d) { st.done[ms[q].k + d] = 1; c->st.fused_nodes++; }
+        for (int d = 0; d < ms[q].n_nodes; ++d) { mark_done(st, ms[q].k + d); c->st.fused_nodes++; }
     for (auto & o : others)
-        for (int d = 0; d < o.n_nodes; ++d) st.done[o.k + d] = 1;
+        for (int d = 0; d < o.n_nodes; ++d) mark_done(st, o.k + d);
     // K split and the results are read only by the rope + cache-store kernel that follows (attention projections of a small batch):
     // that kernel sums the partial products itself — no reduce pass, and the f32 projections are never written
     bool defer = false;
@@ -891,7 +935,7 @@ static bool try_fuse_rope_store(exec_state & st, int i) {
     timed_scope ts(c, "rope_qk_store", (double) ggml_abi_nbytes(st.g->nodes[i]) * 2);
     launch_rope_qk_store(c->stream, pl.a, pl.T);
     c->st.kernel_launches++;
-    for (int k : pl.nodes) { st.done[k] = 1; c->st.fused_nodes++; }
+    for (int k : pl.nodes) { mark_done(st, k); c->st.fused_nodes++; }
     return true;
 }
 // the reader the unsummed projections were left for did not materialise: run their reduce pass now
@@ -934,7 +978,7 @@ static int run_node(exec_state & st, int i) {
                 const ggml_tensor * w = m->src[0] == n ? m->src[1] : (m->src[1] == n ? m->src[0] : nullptr);
                 if (w && w->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(w) && w->ne[0] == n->ne[0] && ggml_abi_nelements(w) == w->ne[0] && same_shape(m, n)) {
                     if (c->opt.prologue && can_defer_norm(st, i, n, m, a, w)) {
-                        st.deferred[m] = {a, w, ggml_abi_op_param_f32(n, 0)};
+                        st.deferred[m] = {a, w, ggml_abi_op_param_f32(n, 0), m};
                         c->st.fused_nodes += 2;
                         return 2;
                     }
@@ -1180,7 +1224,10 @@ static int run_node(exec_state & st, int i) {
 }
 
 static bool run_nodes(backend_ctx * c, ggml_cgraph * g, const ws_plan & wp) {
-    exec_state st{c, g, {}, 0, wp.act_bytes};
+    exec_state st{};
+    st.c = c;
+    st.g = g;
+    st.aux_off = wp.act_bytes;
     st.uses.reserve((size_t) g->n_nodes * 2);
     for (int i = 0; i < g->n_nodes; ++i)
         for (int s = 0; s < GGML_MAX_SRC; ++s)
@@ -1190,11 +1237,24 @@ static bool run_nodes(backend_ctx * c, ggml_cgraph * g, const ws_plan & wp) {
     for (int i = 0; i < g->n_nodes;) {
         ggml_tensor * n = g->nodes[i];
         if (ggml_abi_nelements(n) == 0 || st.done[i]) { i++; continue; }
-        // anything that writes memory invalidates a cached quantisation of that memory
+        // anything that writes memory invalidates a cached quantisation of that memory: every node executed by this call — the
+        // `used` consecutive ones and those a multi-chain fusion ran out of order — is checked by address RANGE (a recycled block
+        // may be written through a tensor that starts elsewhere in it)
+        st.ooo.clear();
         const int used = run_node(st, i);
         if (used < 0) return false;
-        if (!st.q8_fresh)
-            for (int k = 0; k < used; ++k) if (g->nodes[i + k]->data == c->q8_src && !is_view_op(g->nodes[i + k])) c->q8_src = nullptr;  // (views write nothing)
+        if (!st.q8_fresh && c->q8_src) {
+            const char * q0 = (const char *) c->q8_src, * q1 = q0 + c->q8_bytes;
+            auto hits = [&](const ggml_tensor * t) {
+                if (is_view_op(t) || !t->data) return false;  // (views write nothing)
+                const char * t0 = (const char *) t->data;
+                return t0 < q1 && q0 < t0 + ggml_abi_nbytes(t);
+            };
+            bool hit = false;
+            for (int k = 0; k < used && !hit; ++k) hit = hits(g->nodes[i + k]);
+            for (size_t k = 0; k < st.ooo.size() && !hit; ++k) hit = hits(g->nodes[st.ooo[k]]);
+            if (hit) c->q8_src = nullptr;
+        }
         st.q8_fresh = false;
         i += used;
     }

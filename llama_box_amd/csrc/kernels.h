@@ -48,6 +48,8 @@ struct mmvq_args {
     const float * x;
     const float * norm_w;
     float eps;
+    float * norm_out;  // norm_w != null: where RMS_NORM(x) * norm_w itself belongs (the graph's MUL node); written by workgroup 0 so that
+                       // the fusion never leaves a tensor of the graph unwritten (readers in another split, or the host, may exist)
     int balance_tail;  // set by the launcher: spread the last, partial pass of rows evenly over the workgroups
 };
 void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave);
@@ -77,6 +79,7 @@ struct qkv_args {
     const float * x;
     const float * norm_w;  // optional
     float eps;
+    float * norm_out;      // as mmvq_args::norm_out
     int head_dim, neox;
     const int32_t * pos;
     const float * freq_factors;

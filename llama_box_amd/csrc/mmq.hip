@@ -348,11 +348,8 @@ size_t mmq_workspace_bytes(int, int64_t K, int64_t N, int64_t M) {
 template <int QT> static void launch_mmq_t(hipStream_t s, const mmq_args & a) {
     const bool q6 = QT == 6;
     const size_t lds = (size_t) MQ_BN * MQ_AS * (q6 ? 2 : 1) + (size_t) MQ_BM * MQ_AS + (q6 ? 0 : (size_t) (MQ_BN + MQ_BM) * MQ_MS) + MQ_BN * sizeof(float2) + MQ_BM * sizeof(float) + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) k_mmq<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        attr_set = true;
-    }
+    static std::atomic<uint32_t> lds_raised{0};  // one bit per device (common.h: ensure_dyn_lds)
+    (void) ensure_dyn_lds((const void *) k_mmq<QT>, lds, lds_raised);  // on failure the launch below fails and graph_compute reports it
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
     hipLaunchKernelGGL((k_mmq<QT>), dim3(grid, (unsigned) a.ksplit), dim3(512), lds, s, a);
 }

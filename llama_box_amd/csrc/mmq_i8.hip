@@ -430,11 +430,8 @@ bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M) {
 template <int QT, int BN, int BM = 128> static void launch_mmq8_t(hipStream_t s, mmq8_args a) {
     constexpr int NP = QT == 5 ? 3 : 2;
     const size_t lds = 2 * (size_t) (NP * BN * 128 + BM * 128) + (size_t) (BN + BM) * MI_MS + BN * sizeof(float2) + BM * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) k_mmq_i8<QT, BN, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        attr_set = true;
-    }
+    static std::atomic<uint32_t> lds_raised{0};  // one bit per device (common.h: ensure_dyn_lds)
+    (void) ensure_dyn_lds((const void *) k_mmq_i8<QT, BN, BM>, lds, lds_raised);  // on failure the launch below fails and graph_compute reports it
     a.n_panels = 0;
     for (int i = 0; i < a.n_mat; ++i) {
         a.mat[i].panel0 = a.n_panels;

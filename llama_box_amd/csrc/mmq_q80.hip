@@ -164,11 +164,8 @@ void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int 
     a.add = add;
     a.add_stride = add_stride;
     const size_t lds = 2 * (size_t) Q80_STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) k_mmq_q80, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        attr_set = true;
-    }
+    static std::atomic<uint32_t> lds_raised{0};  // one bit per device (common.h: ensure_dyn_lds)
+    (void) ensure_dyn_lds((const void *) k_mmq_q80, lds, lds_raised);  // on failure the launch below fails and graph_compute reports it
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
     hipLaunchKernelGGL(k_mmq_q80, dim3(grid), dim3(512), lds, s, a);
 }

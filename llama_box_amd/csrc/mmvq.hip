@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
                         t.y = (t.y * scale) * g.y;
                         t.z = (t.z * scale) * g.z;
                         t.w = (t.w * scale) * g.w;
+                        if (a.norm_out && blockIdx.x == 0) ((float4 *) a.norm_out)[b * 64 + lane] = t;
                     }
                     v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
                 }
@@ -304,6 +305,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
                         t[1] = (t[1] * scale) * g[u].y;
                         t[2] = (t[2] * scale) * g[u].z;
                         t[3] = (t[3] * scale) * g[u].w;
+                        if (a.norm_out && blockIdx.x == 0) ((float4 *) a.norm_out)[b * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
                     }
                     if constexpr (BPC == 1) wave_quantize_q8_K(t, lane, yl + b);
                     else wave_quantize_q8_0(t, lane, yl + (size_t) b * BPC);

@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
                         t[1] = (t[1] * scale) * g[q].y;
                         t[2] = (t[2] * scale) * g[q].z;
                         t[3] = (t[3] * scale) * g[q].w;
+                        if (a.norm_out && blockIdx.x == 0) ((float4 *) a.norm_out)[b * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
                     }
                     if constexpr (BPC == 1) wave_quantize_q8_K(t, lane, yl + b);
                     else wave_quantize_q8_0(t, lane, yl + (size_t) b * BPC);

@@ -41,6 +41,8 @@ void ggml_free(struct ggml_context * ctx) {
         delete[] g->nodes;
         delete[] g->leafs;
         delete[] g->visited_hash_set.keys;
+        delete[] g->visited_hash_set.used;
+        delete[] g->use_counts;
         delete g;
     }
     delete ctx;
@@ -71,34 +73,22 @@ const char * ggml_type_name(enum ggml_type type) {
     }
 }
 
-const char * ggml_op_name(enum ggml_op op) {
-    switch (op) {
-        case GGML_OP_NONE: return "NONE";
-        case GGML_OP_DUP: return "DUP";
-        case GGML_OP_ADD: return "ADD";
-        case GGML_OP_SUB: return "SUB";
-        case GGML_OP_MUL: return "MUL";
-        case GGML_OP_DIV: return "DIV";
-        case GGML_OP_RMS_NORM: return "RMS_NORM";
-        case GGML_OP_MUL_MAT: return "MUL_MAT";
-        case GGML_OP_SCALE: return "SCALE";
-        case GGML_OP_CPY: return "CPY";
-        case GGML_OP_CONT: return "CONT";
-        case GGML_OP_RESHAPE: return "RESHAPE";
-        case GGML_OP_VIEW: return "VIEW";
-        case GGML_OP_PERMUTE: return "PERMUTE";
-        case GGML_OP_TRANSPOSE: return "TRANSPOSE";
-        case GGML_OP_GET_ROWS: return "GET_ROWS";
-        case GGML_OP_SET_ROWS: return "SET_ROWS";
-        case GGML_OP_SOFT_MAX: return "SOFT_MAX";
-        case GGML_OP_ROPE: return "ROPE";
-        case GGML_OP_FLASH_ATTN_EXT: return "FLASH_ATTN_EXT";
-        case GGML_OP_UNARY: return "UNARY";
-        case GGML_OP_GLU: return "GLU";
-        case GGML_OP_ARGMAX: return "ARGMAX";
-        default: return "OP?";
-    }
-}
+// GGML_OP_NAME (ggml.c): one entry per operator, in enum order — the backend checks its own numbering against this table at
+// load time (csrc/backend.cpp: op_numbering_matches_host)
+static const char * const k_op_name[GGML_OP_COUNT] = {
+    "NONE", "DUP", "ADD", "ADD_ID", "ADD1", "ACC", "SUB", "MUL",
+    "DIV", "SQR", "SQRT", "LOG", "SIN", "COS", "SUM", "SUM_ROWS",
+    "MEAN", "ARGMAX", "COUNT_EQUAL", "REPEAT", "REPEAT_BACK", "CONCAT", "SILU_BACK", "NORM",
+    "RMS_NORM", "RMS_NORM_BACK", "GROUP_NORM", "L2_NORM", "MUL_MAT", "MUL_MAT_ID", "OUT_PROD", "SCALE",
+    "SET", "CPY", "CONT", "RESHAPE", "VIEW", "PERMUTE", "TRANSPOSE", "GET_ROWS",
+    "GET_ROWS_BACK", "SET_ROWS", "DIAG", "DIAG_MASK_INF", "DIAG_MASK_ZERO", "SOFT_MAX", "SOFT_MAX_BACK", "ROPE",
+    "ROPE_BACK", "CLAMP", "CONV_TRANSPOSE_1D", "IM2COL", "IM2COL_BACK", "CONV_2D", "CONV_2D_DW", "CONV_TRANSPOSE_2D",
+    "POOL_1D", "POOL_2D", "POOL_2D_BACK", "UPSCALE", "PAD", "PAD_REFLECT_1D", "ROLL", "ARANGE",
+    "TIMESTEP_EMBEDDING", "ARGSORT", "LEAKY_RELU", "FLASH_ATTN_EXT", "FLASH_ATTN_BACK", "SSM_CONV", "SSM_SCAN", "WIN_PART",
+    "WIN_UNPART", "GET_REL_POS", "ADD_REL_POS", "RWKV_WKV6", "GATED_LINEAR_ATTN", "RWKV_WKV7", "UNARY", "MAP_CUSTOM1",
+    "MAP_CUSTOM2", "MAP_CUSTOM3", "CUSTOM", "CROSS_ENTROPY_LOSS", "CROSS_ENTROPY_LOSS_BACK", "OPT_STEP_ADAMW", "OPT_STEP_SGD", "GLU",
+};
+const char * ggml_op_name(enum ggml_op op) { return (int) op >= 0 && op < GGML_OP_COUNT ? k_op_name[op] : "OP?"; }
 
 // ------------------------------------------------------------------------------------------------ tensors
 static ggml_tensor * new_tensor_impl(ggml_context * ctx, ggml_type type, int n_dims, const int64_t * ne, ggml_tensor * view_src, size_t view_offs) {
@@ -526,30 +516,39 @@ struct ggml_cgraph * ggml_new_graph_custom(struct ggml_context * ctx, size_t siz
     g->leafs = new ggml_tensor *[size]();
     g->visited_hash_set.size = size * 2 + 1;
     g->visited_hash_set.keys = new ggml_tensor *[g->visited_hash_set.size]();
+    g->visited_hash_set.used = new ggml_bitset_t[(g->visited_hash_set.size + 31) / 32]();
+    g->use_counts = new int32_t[g->visited_hash_set.size]();
     g->order = GGML_CGRAPH_EVAL_ORDER_LEFT_TO_RIGHT;
     ctx->graphs.push_back(g);
     return g;
 }
 struct ggml_cgraph * ggml_new_graph(struct ggml_context * ctx) { return ggml_new_graph_custom(ctx, GGML_DEFAULT_GRAPH_SIZE, false); }
 
-static bool hash_insert(ggml_hash_set * hs, ggml_tensor * key) {  // true if newly inserted
-    size_t h = ((uintptr_t) key >> 4) % hs->size;
-    for (size_t n = 0; n < hs->size; ++n) {
-        size_t i = (h + n) % hs->size;
-        if (hs->keys[i] == key) return false;
-        if (hs->keys[i] == nullptr) {
-            hs->keys[i] = key;
-            return true;
-        }
+// ggml_hash_find (ggml-impl.h): hash = pointer >> 4, linear probing over the `used` bitset
+static size_t hash_find(const ggml_hash_set * hs, const ggml_tensor * key) {
+    const size_t h = ((size_t) (uintptr_t) key >> 4) % hs->size;
+    size_t i = h;
+    while ((hs->used[i >> 5] & (1u << (i & 31))) && hs->keys[i] != key) {
+        i = (i + 1) % hs->size;
+        LITE_ASSERT(i != h && "graph hash set full");
     }
-    LITE_ASSERT(!"graph hash set full");
-    return false;
+    return i;
 }
 
-static void visit_parents(ggml_cgraph * g, ggml_tensor * node) {
-    if (!hash_insert(&g->visited_hash_set, node)) return;
+// ggml_visit_parents: depth-first, and — as upstream since the fusion helpers (ggml_can_fuse) — counts every (node, src slot)
+// reference in use_counts[hash slot of the operand]; graph views (ggml_graph_view, what ggml_backend_sched hands a backend
+// for each split) share the parent's table, so a backend sees the WHOLE graph's counts for the nodes of its split
+static size_t visit_parents(ggml_cgraph * g, ggml_tensor * node) {
+    const size_t pos = hash_find(&g->visited_hash_set, node);
+    if (g->visited_hash_set.used[pos >> 5] & (1u << (pos & 31))) return pos;
+    g->visited_hash_set.keys[pos] = node;
+    g->visited_hash_set.used[pos >> 5] |= 1u << (pos & 31);
+    g->use_counts[pos] = 0;
     for (int i = 0; i < GGML_MAX_SRC; ++i)
-        if (node->src[i]) visit_parents(g, node->src[i]);
+        if (node->src[i]) {
+            const size_t sp = visit_parents(g, node->src[i]);
+            g->use_counts[sp]++;
+        }
     if (node->op == GGML_OP_NONE && !(node->flags & GGML_TENSOR_FLAG_PARAM)) {
         LITE_ASSERT(g->n_leafs < g->size);
         if (node->name[0] == 0) format_name(node, "leaf_%d", g->n_leafs);
@@ -559,6 +558,20 @@ static void visit_parents(ggml_cgraph * g, ggml_tensor * node) {
         if (node->name[0] == 0) format_name(node, "node_%d", g->n_nodes);
         g->nodes[g->n_nodes++] = node;
     }
+    return pos;
+}
+// ggml_graph_view (ggml.c): nodes [i0, i1) of cgraph0, returned by value; no leafs / grads; the hash set and the use counts
+// are the parent's
+struct ggml_cgraph ggml_graph_view(struct ggml_cgraph * cgraph0, int i0, int i1) {
+    LITE_ASSERT(0 <= i0 && i0 <= i1 && i1 <= cgraph0->n_nodes);
+    ggml_cgraph g;
+    memset(&g, 0, sizeof(g));
+    g.n_nodes = i1 - i0;
+    g.nodes = cgraph0->nodes + i0;
+    g.use_counts = cgraph0->use_counts;
+    g.visited_hash_set = cgraph0->visited_hash_set;
+    g.order = cgraph0->order;
+    return g;
 }
 void ggml_build_forward_expand(struct ggml_cgraph * cgraph, struct ggml_tensor * tensor) { visit_parents(cgraph, tensor); }
 int ggml_graph_n_nodes(struct ggml_cgraph * cgraph) { return cgraph->n_nodes; }
