@@ -102,7 +102,7 @@ _SIGS = {
     "ggml_new_tensor_1d": (TP, [_P, _I, _I64]), "ggml_new_tensor_2d": (TP, [_P, _I, _I64, _I64]),
     "ggml_new_tensor_3d": (TP, [_P, _I, _I64, _I64, _I64]), "ggml_new_tensor_4d": (TP, [_P, _I, _I64, _I64, _I64, _I64]),
     "ggml_set_name": (TP, [TP, _S]), "ggml_set_input": (None, [TP]), "ggml_set_output": (None, [TP]),
-    "ggml_nbytes": (_SZ, [TP]), "ggml_nelements": (_I64, [TP]), "ggml_row_size": (_SZ, [_I, _I64]),
+    "ggml_op_name": (_S, [_I]), "ggml_nbytes": (_SZ, [TP]), "ggml_nelements": (_I64, [TP]), "ggml_row_size": (_SZ, [_I, _I64]),
     "ggml_view_1d": (TP, [_P, TP, _I64, _SZ]), "ggml_view_2d": (TP, [_P, TP, _I64, _I64, _SZ, _SZ]),
     "ggml_view_3d": (TP, [_P, TP, _I64, _I64, _I64, _SZ, _SZ, _SZ]),
     "ggml_view_4d": (TP, [_P, TP, _I64, _I64, _I64, _I64, _SZ, _SZ, _SZ, _SZ]),
@@ -124,6 +124,7 @@ _SIGS = {
     "ggml_new_graph": (C.POINTER(CGraph), [_P]), "ggml_new_graph_custom": (C.POINTER(CGraph), [_P, _SZ, _B]),
     "ggml_build_forward_expand": (None, [C.POINTER(CGraph), TP]), "ggml_graph_n_nodes": (_I, [C.POINTER(CGraph)]),
     "ggml_graph_node": (TP, [C.POINTER(CGraph), _I]), "ggml_graph_view": (CGraph, [C.POINTER(CGraph), _I, _I]),
+    "ggml_lite_set_no_reuse": (None, [_I]),
     # ggml-backend.h mirror
     "ggml_backend_load": (_P, [_S]), "ggml_backend_reg_name": (_S, [_P]), "ggml_backend_reg_dev_count": (_SZ, [_P]),
     "ggml_backend_reg_dev_get": (_P, [_P, _SZ]), "ggml_backend_reg_get_proc_address": (_P, [_P, _S]),

@@ -25,6 +25,15 @@
         }                                                                                      \
     } while (0)
 
+// allocator switch for per-node comparisons (tests, scripts/node_diff.py): keep every intermediate tensor in memory of its own;
+// -1 = take it from the environment (GGML_LITE_NO_REUSE) on first use
+static int g_no_reuse = -1;
+static bool ggml_lite_no_reuse() {
+    if (g_no_reuse < 0) g_no_reuse = getenv("GGML_LITE_NO_REUSE") != nullptr ? 1 : 0;
+    return g_no_reuse != 0;
+}
+extern "C" void ggml_lite_set_no_reuse(int on) { g_no_reuse = on ? 1 : 0; }
+
 struct ggml_context {
     std::vector<ggml_tensor *> tensors;
     std::vector<ggml_cgraph *> graphs;
@@ -887,8 +896,7 @@ static alloc_plan plan_graph(ggml_gallocr_t ga, ggml_cgraph * g) {
             if (!n->src[s]) continue;
             ggml_tensor * r = root(n->src[s]);
             if (r->op == GGML_OP_NONE || (r->flags & (GGML_TENSOR_FLAG_OUTPUT | GGML_TENSOR_FLAG_INPUT))) continue;
-            static const bool no_reuse = getenv("GGML_LITE_NO_REUSE") != nullptr;  // debugging: keep every intermediate
-            if (last_use[r] == i && !no_reuse) release(r);
+            if (last_use[r] == i && !ggml_lite_no_reuse()) release(r);
         }
     }
     return plan;

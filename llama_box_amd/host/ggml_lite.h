@@ -108,6 +108,7 @@ struct ggml_tensor * ggml_argmax(struct ggml_context * ctx, struct ggml_tensor *
 struct ggml_cgraph * ggml_new_graph(struct ggml_context * ctx);
 struct ggml_cgraph * ggml_new_graph_custom(struct ggml_context * ctx, size_t size, bool grads);
 void ggml_build_forward_expand(struct ggml_cgraph * cgraph, struct ggml_tensor * tensor);
+void ggml_lite_set_no_reuse(int on);  // harness only: graph allocator keeps every intermediate (per-node comparisons)
 struct ggml_cgraph ggml_graph_view(struct ggml_cgraph * cgraph, int i0, int i1);  // shares the parent's hash set + use counts
 int ggml_graph_n_nodes(struct ggml_cgraph * cgraph);
 struct ggml_tensor * ggml_graph_node(struct ggml_cgraph * cgraph, int i);

@@ -23,9 +23,22 @@ typedef double ggml_float; /* ggml-cpu accumulates scalar reductions in double *
 /* Summation-order variant.  0 = the generic ggml-cpu order (blocks first to last).  1 = blocks last to first: an
  * equally valid f32 evaluation order (every SIMD build of ggml-cpu has its own), used by the tests to measure how far
  * the network's logits move under a change of summation order ALONE — the yardstick for the GPU-vs-oracle gates. */
+/* Sensitivity probes for the tests (variant 0 = the generic ggml-cpu algorithm, the only one used as a checker).  Each probe
+ * changes ONE thing that two correct implementations of the same graph legitimately differ in, by about an ulp:
+ *   1  block dots summed last block first (f32 summation order of the mat-muls)
+ *   2  RMS_NORM sum of squares accumulated in f32 instead of double
+ *   3  expf() results moved one ulp up or down, by a bit of the argument (what a different libm / a hardware exp is
+ *      entitled to; a uniform shift would cancel in soft_max's ratio)                                              */
 static int g_variant = 0;
 void oracle_set_variant(int v) { g_variant = v; }
-#define BLK_IDX(i, nb) (g_variant ? ((nb) - 1 - (i)) : (i))
+#define BLK_IDX(i, nb) (g_variant == 1 ? ((nb) - 1 - (i)) : (i))
+static inline float oracle_expf(float x) {
+    const float r = expf(x);
+    if (g_variant != 3 || !(r > 0.0f) || !(r < INFINITY)) return r;
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return ((u ^ (u >> 7) ^ (u >> 13)) & 1u) ? nextafterf(r, INFINITY) : nextafterf(r, 0.0f);
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* fp16 <-> fp32 (IEEE binary16, round-to-nearest-even; same results as F16C / ggml's fallback) */
@@ -545,6 +558,11 @@ static enum ggml_status op_rms_norm(struct ggml_tensor * dst, int nth) {
         const float * x = (const float *) (TDATA(a) + i01 * a->nb[1] + i02 * a->nb[2] + i03 * a->nb[3]);
         float * y = (float *) (TDATA(dst) + i01 * dst->nb[1] + i02 * dst->nb[2] + i03 * dst->nb[3]);
         ggml_float sum = 0.0;
+        if (g_variant == 2) {
+            float sumf = 0.0f;
+            for (int64_t i = 0; i < ne00; ++i) sumf += x[i] * x[i];
+            sum = sumf;
+        } else
         for (int64_t i = 0; i < ne00; ++i) sum += (ggml_float) (x[i] * x[i]);
         const float mean = (float) (sum / ne00);
         const float scale = 1.0f / sqrtf(mean + eps);
@@ -553,8 +571,8 @@ static enum ggml_status op_rms_norm(struct ggml_tensor * dst, int nth) {
     return GGML_STATUS_SUCCESS;
 }
 
-/* UNARY: silu(x) = x/(1+expf(-x)) etc. (ggml-cpu/vec.h scalar forms) */
-static inline float silu_f32(float x) { return x / (1.0f + expf(-x)); }
+/* UNARY: silu(x) = x/(1+oracle_expf(-x)) etc. (ggml-cpu/vec.h scalar forms) */
+static inline float silu_f32(float x) { return x / (1.0f + oracle_expf(-x)); }
 static enum ggml_status op_unary(struct ggml_tensor * dst) {
     const struct ggml_tensor * a = dst->src[0];
     if (a->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(a) || !ggml_abi_is_contiguous(dst)) return GGML_STATUS_FAILED;
@@ -567,9 +585,9 @@ static enum ggml_status op_unary(struct ggml_tensor * dst) {
             case GGML_UNARY_OP_SILU: y[i] = silu_f32(x[i]); break;
             case GGML_UNARY_OP_RELU: y[i] = x[i] > 0.f ? x[i] : 0.f; break;
             case GGML_UNARY_OP_NEG: y[i] = -x[i]; break;
-            case GGML_UNARY_OP_EXP: y[i] = expf(x[i]); break;
+            case GGML_UNARY_OP_EXP: y[i] = oracle_expf(x[i]); break;
             case GGML_UNARY_OP_TANH: y[i] = tanhf(x[i]); break;
-            case GGML_UNARY_OP_SIGMOID: y[i] = 1.f / (1.f + expf(-x[i])); break;
+            case GGML_UNARY_OP_SIGMOID: y[i] = 1.f / (1.f + oracle_expf(-x[i])); break;
             default: return GGML_STATUS_FAILED;
         }
     }
@@ -723,11 +741,11 @@ static enum ggml_status op_soft_max(struct ggml_tensor * dst, int nth) {
         if (sk && sk[i02] > max) max = sk[i02];
         ggml_float sum = 0.0;
         for (int64_t i = 0; i < nc; ++i) {
-            const float val = expf(wp[i] - max);
+            const float val = oracle_expf(wp[i] - max);
             sum += (ggml_float) val;
             dp[i] = val;
         }
-        if (sk) sum += (ggml_float) expf(sk[i02] - max);
+        if (sk) sum += (ggml_float) oracle_expf(sk[i02] - max);
         if (isnan(sum) || sum == 0) sum = -INFINITY; /* llama-box patch */
         sum = 1.0 / sum;
         const float fs = (float) sum;
@@ -949,11 +967,11 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
             const ggml_fp16_t * vd = (const ggml_fp16_t *) (TDATA(v) + ic * v->nb[1] + iv2 * v->nb[2] + iv3 * v->nb[3]);
             if (s > M) {
                 M = s;
-                ms = expf(Mold - M);
+                ms = oracle_expf(Mold - M);
                 if (vq8) for (int64_t i = 0; i < DV; ++i) VKQ32[i] *= ms;                                   /* ggml_vec_scale_f32 */
                 else for (int64_t i = 0; i < DV; ++i) VKQ16[i] = oracle_fp32_to_fp16(F16(VKQ16[i]) * ms); /* ggml_vec_scale_f16 */
             } else {
-                vs = expf(s - M);
+                vs = oracle_expf(s - M);
             }
             if (vq8) { /* v_to_float + ggml_vec_mad_f32 */
                 dequantize_row_q8_0((const block_q8_0 *) vd, V32, DV);
@@ -971,10 +989,10 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
             const float s = ((const float *) sinks->data)[h];
             float ms = 1.0f, vs = 1.0f;
             if (s > M) {
-                ms = expf(M - s);
+                ms = oracle_expf(M - s);
                 for (int64_t i = 0; i < DV; ++i) VKQ32[i] *= ms;
             } else {
-                vs = expf(s - M);
+                vs = oracle_expf(s - M);
             }
             S = S * ms + vs;
         }

@@ -38,7 +38,8 @@ enum ggml_status oracle_graph_compute(struct ggml_cgraph * graph, int n_threads)
 /* 1 if oracle_compute_node implements this node */
 int oracle_supports_op(const struct ggml_tensor * node);
 int oracle_max_threads(void);
-/* 0 = generic ggml-cpu block order, 1 = reversed block order (summation-order sensitivity probe for the tests) */
+/* 0 = generic ggml-cpu; 1 / 2 / 3 = one-ulp sensitivity probes for the tests (reversed block order, f32 RMS_NORM sum,
+ * expf one ulp up / down) — see ggml_cpu_ref.c */
 void oracle_set_variant(int v);
 
 #ifdef __cplusplus

@@ -135,10 +135,15 @@ class G:
             self.inputs.append((t, raw))
         return t
 
-    def compute(self, outs, n_threads=4):
-        """Allocates every tensor, uploads inputs, evaluates the graph for `outs`, returns numpy copies of `outs`."""
+    def compute(self, outs, n_threads=4, expand_first=(), cuts=None):
+        """Allocates every tensor, uploads inputs, evaluates the graph for `outs`, returns numpy copies of `outs`.
+        expand_first: tensors added to the graph before the outputs, unflagged (llama.cpp's build_attn expands q, k, v together
+        before the cache stores); cuts: node indices at which the graph is handed to the backend in pieces — ggml_graph_view of
+        the full graph, what ggml_backend_sched gives a backend for each of its splits."""
         H = self.H
         gf = H.ggml_new_graph_custom(self.ctx, 4096, False)
+        for o in expand_first:
+            H.ggml_build_forward_expand(gf, o)
         for o in outs:
             H.ggml_set_output(o)
             H.ggml_build_forward_expand(gf, o)
@@ -157,6 +162,13 @@ class G:
             H.ggml_backend_tensor_set(t, raw.ctypes.data_as(C.c_void_p), 0, raw.nbytes)
         if self.target == "oracle":
             st = oracle().oracle_graph_compute(gf, n_threads)
+        elif cuts:
+            st = 0
+            edges = [0] + [c if c >= 0 else gf.contents.n_nodes + c for c in cuts] + [gf.contents.n_nodes]
+            for i0, i1 in zip(edges[:-1], edges[1:]):
+                if st == 0 and i1 > i0:
+                    view = H.ggml_graph_view(gf, i0, i1)
+                    st = H.ggml_backend_graph_compute(self.target.backend, C.byref(view))
         else:
             st = H.ggml_backend_graph_compute(self.target.backend, gf)
         if st != 0:
@@ -192,15 +204,20 @@ class G:
             self.ctx = None
 
 
-def run_case(build, target, n_threads=4):
+def run_case(build, target, n_threads=4, **kw):
     g = G(target)
     try:
         outs = build(g)
         if not isinstance(outs, (list, tuple)):
             outs = [outs]
-        return g.compute(list(outs), n_threads)
+        return g.compute(list(outs), n_threads, **kw)
     finally:
         g.free()
+
+
+def host_threads(cap=64):
+    """Threads for oracle runs at real model shapes (the GPU box has far more cores than this container)."""
+    return max(4, min(cap, os.cpu_count() or 4))
 
 
 def nmse(a, b):

@@ -1,0 +1,344 @@
+"""GPU parity at the shapes BASELINE.json names (Llama-3-8B Q4_K_M, TinyLlama-1.1B Q8_0, Qwen2-7B Q5_K/Q6_K, Llama-3-70B
+Q4_K_M), all through the C-ABI against the CPU oracle.
+
+Why this file exists (VERDICT r01 "What's weak" #2): the op tests use small matrices, so the code the bench actually times —
+k_mmvq_stream's multi-pass walk with its balanced tail (N > 4096, N % 4096 != 0: ffn gate/up N = 14336, output N = 128256,
+Qwen2's 18944 / 152064), the 56- / 74- / 112-super-block rows of ffn_down, head_dim-128 attention over 8192 cells — never
+ran in a test.  Here they do, and in the forms the decode graph uses them (norm prologue, SwiGLU pair, residual epilogue,
+fused Q/K/V + rope + cache store).
+
+Teacher forcing (test_layer_teacher_forced): a layer is evaluated node group by node group; every group — exactly the
+launches of the decode path — is fed the ORACLE's values for its inputs, so no deviation can cascade from one group into the
+next and the per-op gates apply to the real graph at the real shapes:
+    quantised mat-vec chains (integer block sums exact, f32 accumulate order differs) ....... NMSE <= 1e-10
+    f16 cache rows written by the fused Q/K/V launch .......................................... <= one f16 rounding (1e-6)
+    FLASH_ATTN_EXT (the CPU accumulates V in f16, the kernel in f32) .......................... NMSE <= 1e-4, and closer to
+                                                                                               float64 attention than the CPU is
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import harness as T
+import llama_box_amd as L
+
+pytestmark = pytest.mark.gpu
+
+QNAME = {L.Q4_K: "q4_K", L.Q5_K: "q5_K", L.Q6_K: "q6_K", L.Q8_0: "q8_0"}
+NT = T.host_threads()
+
+
+def _seed(*key):
+    return zlib.crc32(repr(key).encode())  # (hash() of a str is salted per process)
+
+
+def _log(plog, msg):
+    plog("[baseline-shapes] " + msg)
+
+
+# ------------------------------------------------------------------------------------------------ (a) mat-vec at real shapes
+# (tag, weight type, K, N, forms).  forms: plain = MUL_MAT; res = MUL_MAT + residual ADD; norm = RMS_NORM*w -> MUL_MAT (deferred
+# into the mat-vec prologue); glu = RMS_NORM*w -> {gate, up} -> SwiGLU (one launch)
+REAL_MV = [
+    ("llama3-8b wo", L.Q4_K, 4096, 4096, ("plain", "res")),
+    ("llama3-8b ffn_gate/up", L.Q4_K, 4096, 14336, ("plain", "norm", "glu")),
+    ("llama3-8b ffn_down", L.Q4_K, 14336, 4096, ("plain", "res")),
+    ("llama3-8b ffn_down (more-bits layer)", L.Q6_K, 14336, 4096, ("plain", "res")),
+    ("llama3-8b output", L.Q6_K, 4096, 128256, ("norm",)),
+    ("tinyllama ffn_gate/up", L.Q8_0, 2048, 5632, ("plain", "norm", "glu")),
+    ("tinyllama ffn_down", L.Q8_0, 5632, 2048, ("plain", "res")),
+    ("tinyllama output", L.Q8_0, 2048, 32000, ("norm",)),
+    ("qwen2-7b ffn_gate/up", L.Q5_K, 3584, 18944, ("plain", "norm", "glu")),
+    ("qwen2-7b ffn_down", L.Q6_K, 18944, 3584, ("plain", "res")),
+    ("qwen2-7b wo", L.Q5_K, 3584, 3584, ("res",)),
+    ("qwen2-7b output", L.Q6_K, 3584, 152064, ("norm",)),
+    ("llama3-70b wo", L.Q4_K, 8192, 8192, ("res",)),
+    ("llama3-70b ffn_gate/up", L.Q4_K, 8192, 28672, ("norm", "glu")),
+    ("llama3-70b ffn_down", L.Q4_K, 28672, 8192, ("res",)),
+    ("llama3-70b ffn_down (more-bits layer)", L.Q6_K, 28672, 8192, ("plain", "res")),
+    ("llama3-70b attn_v", L.Q5_K, 8192, 1024, ("plain",)),
+]
+_MV_CASES = [(tag, qt, K, N, f) for tag, qt, K, N, forms in REAL_MV for f in forms]
+
+
+@pytest.mark.parametrize("tag,qt,K,N,form", _MV_CASES, ids=[f"{t.replace(' ', '_')}-{QNAME[q]}-{f}" for t, q, _, _, f in _MV_CASES])
+def test_mat_vec_real_shapes(backend, H, plog, tag, qt, K, N, form):
+    rng = np.random.default_rng(_seed(K, N, qt, form))
+    w = T.rand_weight(qt, K, N, rng)
+    w2 = T.rand_weight(qt, K, N, rng) if form == "glu" else None
+    x = (rng.standard_normal((1, K)) * rng.uniform(0.5, 2.0)).astype(np.float32)
+    nw = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    r = rng.standard_normal((1, N)).astype(np.float32)
+
+    def build(g):
+        cur = g.new(L.F32, [K, 1], x)
+        if form in ("norm", "glu"):
+            cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, cur, 1e-5), g.new(L.F32, [K], nw))
+        y = H.ggml_mul_mat(g.ctx, g.new(qt, [K, N], w), cur)
+        if form == "glu":
+            y = H.ggml_swiglu_split(g.ctx, y, H.ggml_mul_mat(g.ctx, g.new(qt, [K, N], w2), cur))
+        if form == "res":
+            y = H.ggml_add(g.ctx, y, g.new(L.F32, [N, 1], r))
+        return y
+
+    ref = T.run_case(build, "oracle", NT)
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    _log(plog, f"{tag} {QNAME[qt]} K={K} N={N} form={form}: {launches} launch(es)")
+    assert launches == 1, f"{tag} {form}: expected the one fused launch of the decode path, got {launches}"
+    T.compare(f"mat-vec {tag} {QNAME[qt]} K={K} N={N} {form}", got[0], ref[0], max_nmse=1e-10, log=plog)
+
+
+# ------------------------------------------------------------------------------------------------ (b) one real layer, teacher-forced
+class Spec:
+    def __init__(self, name, E, FF, NH, NKV, HD, t_qk, t_v, t_o, t_gu, t_d, bias, neox, base, eps, n_past, n_ctx_train):
+        self.__dict__.update(locals())
+
+
+LAYERS = [
+    # Llama-3-8B Q4_K_M: the plain layers (everything Q4_K) and the "more bits" layers (attn_v, ffn_down in Q6_K)
+    Spec("llama3-8b q4_k_m layer (plain)", 4096, 14336, 32, 8, 128, L.Q4_K, L.Q4_K, L.Q4_K, L.Q4_K, L.Q4_K, False, False, 500000.0, 1e-5, 2063, 8192),
+    Spec("llama3-8b q4_k_m layer (more bits)", 4096, 14336, 32, 8, 128, L.Q4_K, L.Q6_K, L.Q4_K, L.Q4_K, L.Q6_K, False, False, 500000.0, 1e-5, 2063, 8192),
+    # Qwen2-7B, Q5_K / Q6_K mix, 8192 cells of context (BASELINE config 5): NeoX rope, Q/K/V bias, 28/4 heads (7 per KV head)
+    Spec("qwen2-7b q5_k/q6_k layer @8192", 3584, 18944, 28, 4, 128, L.Q5_K, L.Q6_K, L.Q5_K, L.Q5_K, L.Q6_K, True, True, 1000000.0, 1e-6, 8191, 32768),
+    # Llama-3-70B Q4_K_M (config 4's model): attn_v in Q5_K in its plain layers
+    Spec("llama3-70b q4_k_m layer", 8192, 28672, 64, 8, 128, L.Q4_K, L.Q5_K, L.Q4_K, L.Q4_K, L.Q6_K, False, False, 500000.0, 1e-5, 1030, 8192),
+    # TinyLlama-1.1B Q8_0 (config 1's model): head_dim 64
+    Spec("tinyllama-1.1b q8_0 layer", 2048, 5632, 32, 4, 64, L.Q8_0, L.Q8_0, L.Q8_0, L.Q8_0, L.Q8_0, False, False, 10000.0, 1e-5, 143, 2048),
+]
+
+
+def _attention_f64(q, kc, vc, n_kv, NH, NKV, HD):
+    """Exact attention over cells [0, n_kv) in float64: q [NH, HD] f32 (already rotated; rounded to f16 first, as ggml-cpu's
+    q_to_vec_dot and the kernel both do), caches [n_ctx, NKV*HD] f16."""
+    q = q.astype(np.float16).astype(np.float64).reshape(NH, HD)
+    k = kc[:n_kv].astype(np.float64).reshape(n_kv, NKV, HD)
+    v = vc[:n_kv].astype(np.float64).reshape(n_kv, NKV, HD)
+    g = NH // NKV
+    out = np.empty((NH, HD))
+    for h in range(NH):
+        s = k[:, h // g, :] @ q[h] / np.sqrt(HD)
+        p = np.exp(s - s.max())
+        out[h] = (p / p.sum()) @ v[:, h // g, :]
+    return out
+
+
+@pytest.mark.parametrize("sp", LAYERS, ids=[s.name.replace(" ", "_") for s in LAYERS])
+def test_layer_teacher_forced(backend, H, plog, sp):
+    rng = np.random.default_rng(_seed(sp.name))
+    E, FF, NH, NKV, HD = sp.E, sp.FF, sp.NH, sp.NKV, sp.HD
+    EK = NKV * HD
+    n_kv = (sp.n_past + 1 + 255) // 256 * 256  # cells the graph covers (llama_lite: used cells rounded up to 256)
+    n_ctx = n_kv
+    pos, slot = sp.n_past, sp.n_past
+    mode = L.ROPE_NEOX if sp.neox else 0
+    W = dict(wq=T.rand_weight(sp.t_qk, E, NH * HD, rng), wk=T.rand_weight(sp.t_qk, E, EK, rng), wv=T.rand_weight(sp.t_v, E, EK, rng),
+             wo=T.rand_weight(sp.t_o, NH * HD, E, rng), wg=T.rand_weight(sp.t_gu, E, FF, rng), wu=T.rand_weight(sp.t_gu, E, FF, rng),
+             wd=T.rand_weight(sp.t_d, FF, E, rng))
+    nw1, nw2 = rng.uniform(0.5, 1.5, E).astype(np.float32), rng.uniform(0.5, 1.5, E).astype(np.float32)
+    bq, bk, bv = (rng.standard_normal(n).astype(np.float32) * 0.1 for n in (NH * HD, EK, EK))
+    x0 = rng.standard_normal((1, E)).astype(np.float32)
+    kc0 = (rng.standard_normal((n_ctx, EK)) * 0.5).astype(np.float16)
+    vc0 = (rng.standard_normal((n_ctx, EK)) * 0.5).astype(np.float16)
+    mask = np.full((64, n_kv), -np.inf, np.float16)  # [n_kv, GGML_KQ_MASK_PAD] in ggml order
+    mask[0, : sp.n_past + 1] = 0
+
+    def rope(g, t, nh, tp):
+        return H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, t, HD, nh, 1), tp, None, HD, mode, sp.n_ctx_train, sp.base, 1.0, 0.0, 1.0, 32.0, 1.0)
+
+    # ---- the five node groups of a decode layer (= the launches of the decode path); `inp` holds the values a group reads
+    def seg_qkv(g, inp):
+        x = g.new(L.F32, [E, 1], inp["x"])
+        cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, x, sp.eps), g.new(L.F32, [E], nw1))
+        q = H.ggml_mul_mat(g.ctx, g.new(sp.t_qk, [E, NH * HD], W["wq"]), cur)
+        k = H.ggml_mul_mat(g.ctx, g.new(sp.t_qk, [E, EK], W["wk"]), cur)
+        v = H.ggml_mul_mat(g.ctx, g.new(sp.t_v, [E, EK], W["wv"]), cur)
+        if sp.bias:
+            q = H.ggml_add(g.ctx, q, g.new(L.F32, [NH * HD], bq))
+            k = H.ggml_add(g.ctx, k, g.new(L.F32, [EK], bk))
+            v = H.ggml_add(g.ctx, v, g.new(L.F32, [EK], bv))
+        tp = g.new(L.I32, [1], np.array([pos], np.int32))
+        idx = g.new(L.I64, [1], np.array([slot], np.int64))
+        qr, kr = rope(g, q, NH, tp), rope(g, k, NKV, tp)
+        v3 = H.ggml_reshape_3d(g.ctx, v, HD, NKV, 1)
+        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [EK, n_ctx], inp["kc"]), H.ggml_reshape_2d(g.ctx, kr, EK, 1), idx)
+        vs = H.ggml_set_rows(g.ctx, g.new(L.F16, [EK, n_ctx], inp["vc"]), H.ggml_reshape_2d(g.ctx, v3, EK, 1), idx)
+        return dict(outs=[qr, ks, vs], first=[qr, kr, v3])
+
+    def seg_attn(g, inp):
+        qr = g.new(L.F32, [HD, NH, 1], inp["q_rope"])
+        kc = g.new(L.F16, [EK, n_ctx], inp["kc"])
+        vc = g.new(L.F16, [EK, n_ctx], inp["vc"])
+        q = H.ggml_permute(g.ctx, qr, 0, 2, 1, 3)
+        k = H.ggml_view_3d(g.ctx, kc, HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, vc, HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        fa = H.ggml_flash_attn_ext(g.ctx, q, k, v, g.new(L.F16, [n_kv, 64], mask), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(fa, 10)
+        return dict(outs=[fa], first=[])
+
+    def seg_wo(g, inp):
+        a = g.new(L.F32, [NH * HD, 1], inp["attn"])
+        y = H.ggml_mul_mat(g.ctx, g.new(sp.t_o, [NH * HD, E], W["wo"]), a)
+        return dict(outs=[H.ggml_add(g.ctx, y, g.new(L.F32, [E, 1], inp["x"]))], first=[])
+
+    def seg_ffn(g, inp):
+        f = g.new(L.F32, [E, 1], inp["ffn_inp"])
+        cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, f, sp.eps), g.new(L.F32, [E], nw2))
+        gate = H.ggml_mul_mat(g.ctx, g.new(sp.t_gu, [E, FF], W["wg"]), cur)
+        up = H.ggml_mul_mat(g.ctx, g.new(sp.t_gu, [E, FF], W["wu"]), cur)
+        return dict(outs=[H.ggml_swiglu_split(g.ctx, gate, up)], first=[])
+
+    def seg_down(g, inp):
+        a = g.new(L.F32, [FF, 1], inp["act"])
+        y = H.ggml_mul_mat(g.ctx, g.new(sp.t_d, [FF, E], W["wd"]), a)
+        return dict(outs=[H.ggml_add(g.ctx, y, g.new(L.F32, [E, 1], inp["ffn_inp"]))], first=[])
+
+    def run(seg, target, inp):
+        g = T.G(target)
+        try:
+            b = seg(g, inp)
+            k0 = backend.stat("kernel_launches") if target != "oracle" else 0
+            r = g.compute(b["outs"], NT, expand_first=b["first"])
+            return r, (backend.stat("kernel_launches") - k0 if target != "oracle" else 0)
+        finally:
+            g.free()
+
+    # ---- the oracle runs the layer end to end (its own outputs feed its next group), the GPU gets the oracle's values
+    vals = {"x": x0, "kc": kc0, "vc": vc0}
+    report = []
+    (q_o, kc_o, vc_o), _ = run(seg_qkv, "oracle", vals)
+    (q_g, kc_g, vc_g), n1 = run(seg_qkv, backend, vals)
+    T.compare(f"{sp.name}: q_rope", q_g, q_o, max_nmse=1e-10, log=plog)
+    for nm, a, b, c0 in (("k_cache", kc_g, kc_o, kc0), ("v_cache", vc_g, vc_o, vc0)):
+        a32, b32 = np.asarray(a).astype(np.float32).reshape(n_ctx, EK), np.asarray(b).astype(np.float32).reshape(n_ctx, EK)
+        T.compare(f"{sp.name}: {nm} new row", a32[slot], b32[slot], max_nmse=1e-6, log=plog)
+        other = np.ones(n_ctx, bool)
+        other[slot] = False
+        assert np.array_equal(np.asarray(a).reshape(n_ctx, EK)[other], c0[other]), f"{nm}: rows other than the new one were touched"
+    report.append(("qkv+rope+store", n1))
+
+    vals.update(q_rope=q_o, kc=np.asarray(kc_o).reshape(n_ctx, EK), vc=np.asarray(vc_o).reshape(n_ctx, EK))
+    (fa_o,), _ = run(seg_attn, "oracle", vals)
+    (fa_g,), n2 = run(seg_attn, backend, vals)
+    T.compare(f"{sp.name}: flash_attn n_kv={sp.n_past + 1} heads={NH}/{NKV} d={HD}", fa_g, fa_o, max_nmse=1e-4, log=plog)
+    exact = _attention_f64(np.asarray(q_o), vals["kc"], vals["vc"], sp.n_past + 1, NH, NKV, HD)
+    e_gpu, e_cpu = T.nmse(np.asarray(fa_g).reshape(NH, HD), exact), T.nmse(np.asarray(fa_o).reshape(NH, HD), exact)
+    _log(plog, f"{sp.name}: attention vs float64: gpu nmse={e_gpu:.3e}, cpu oracle (f16 V accumulation) nmse={e_cpu:.3e}")
+    assert e_gpu <= 1e-9 and e_gpu <= e_cpu * 1.01 + 1e-12
+    report.append(("flash_attn", n2))
+
+    vals.update(attn=np.asarray(fa_o).reshape(1, NH * HD))
+    (fi_o,), _ = run(seg_wo, "oracle", vals)
+    (fi_g,), n3 = run(seg_wo, backend, vals)
+    T.compare(f"{sp.name}: wo + residual (ffn_inp)", fi_g, fi_o, max_nmse=1e-10, log=plog)
+    report.append(("wo+res", n3))
+
+    vals.update(ffn_inp=np.asarray(fi_o).reshape(1, E))
+    (act_o,), _ = run(seg_ffn, "oracle", vals)
+    (act_g,), n4 = run(seg_ffn, backend, vals)
+    T.compare(f"{sp.name}: norm -> gate/up -> swiglu", act_g, act_o, max_nmse=1e-10, log=plog)
+    report.append(("gate/up/swiglu", n4))
+
+    vals.update(act=np.asarray(act_o).reshape(1, FF))
+    (lo_o,), _ = run(seg_down, "oracle", vals)
+    (lo_g,), n5 = run(seg_down, backend, vals)
+    T.compare(f"{sp.name}: ffn_down + residual (l_out)", lo_g, lo_o, max_nmse=1e-10, log=plog)
+    report.append(("down+res", n5))
+    _log(plog, f"{sp.name}: launches per group {report}")
+    # the groups must be the fused launches the decode path (and the bench) runs, not node-by-node fallbacks
+    assert n1 == 1 and n3 == 1 and n4 == 1 and n5 == 1 and n2 <= 2, report
+
+
+# ------------------------------------------------------------------------------------------------ (c) attention at 8192 cells
+@pytest.mark.parametrize("NH,NKV,n_kv,n_vis", [(28, 4, 8192, 8192), (28, 4, 8192, 7000), (32, 8, 8192, 8192), (64, 8, 8192, 8100)])
+def test_flash_attn_head_dim_128_at_8192(backend, H, plog, NH, NKV, n_kv, n_vis):
+    rng = np.random.default_rng(NH * 31 + n_vis)
+    HD, EK = 128, NKV * 128
+    q = rng.standard_normal((1, NH, HD)).astype(np.float32)
+    kc = (rng.standard_normal((n_kv, EK)) * 0.5).astype(np.float16)
+    vc = (rng.standard_normal((n_kv, EK)) * 0.5).astype(np.float16)
+    mask = np.full((64, n_kv), -np.inf, np.float16)
+    mask[0, :n_vis] = 0
+
+    def build(g):
+        qq = H.ggml_permute(g.ctx, g.new(L.F32, [HD, NH, 1], q), 0, 2, 1, 3)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [EK, n_kv], kc), HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [EK, n_kv], vc), HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        fa = H.ggml_flash_attn_ext(g.ctx, qq, k, v, g.new(L.F16, [n_kv, 64], mask), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(fa, 10)
+        return fa
+
+    ref = T.run_case(build, "oracle", NT)
+    got = T.run_case(build, backend)
+    T.compare(f"flash_attn d=128 heads={NH}/{NKV} n_kv={n_kv} visible={n_vis}", got[0], ref[0], max_nmse=1e-4, log=plog)
+    exact = _attention_f64(q[0], kc, vc, n_vis, NH, NKV, HD)
+    e = T.nmse(np.asarray(got[0]).reshape(NH, HD), exact)
+    _log(plog, f"flash_attn d=128 heads={NH}/{NKV} n_kv={n_kv} visible={n_vis}: gpu vs float64 nmse={e:.3e}")
+    assert e <= 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ split graphs
+def test_split_graph_keeps_tensors_read_by_another_split(backend, H, plog):
+    """ggml_backend_sched hands a backend ONE split (a ggml_graph_view).  A tensor whose other reader sits in the next split
+    must be written even if every reader inside this split could have absorbed it: RMS_NORM*w feeding wq here and wk in the
+    next split; gate/up results that a later split reads next to the SwiGLU; a projection read behind its residual ADD."""
+    rng = np.random.default_rng(77)
+    E, N = 1024, 512
+    x = rng.standard_normal((1, E)).astype(np.float32)
+    nw = rng.uniform(0.5, 1.5, E).astype(np.float32)
+    w1, w2, w3 = (T.rand_weight(L.Q4_K, E, N, rng) for _ in range(3))
+    r = rng.standard_normal((1, N)).astype(np.float32)
+
+    def build(g):
+        cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, g.new(L.F32, [E, 1], x), 1e-5), g.new(L.F32, [E], nw))
+        a = H.ggml_mul_mat(g.ctx, g.new(L.Q4_K, [E, N], w1), cur)          # split 1: norm, mul, mm(w1), add
+        a_res = H.ggml_add(g.ctx, a, g.new(L.F32, [N, 1], r))
+        b = H.ggml_mul_mat(g.ctx, g.new(L.Q4_K, [E, N], w2), cur)          # split 2: reads `cur` and `a` again
+        c = H.ggml_mul_mat(g.ctx, g.new(L.Q4_K, [E, N], w3), cur)
+        glu = H.ggml_swiglu_split(g.ctx, b, c)
+        both = H.ggml_add(g.ctx, glu, a)
+        return g, [a_res, both]
+
+    def run(target, cuts):
+        g = T.G(target)
+        try:
+            _, outs = build(g)
+            return g.compute(outs, 4, cuts=cuts)
+        finally:
+            g.free()
+
+    ref = run("oracle", None)
+    whole = run(backend, None)
+    for cuts in ([4], [3], [2], [4, 6], [3, 5, 7]):
+        got = run(backend, cuts)
+        for nm, a, b, c in zip(("mm+residual", "swiglu + earlier projection"), got, ref, whole):
+            T.compare(f"split graph cuts={cuts}: {nm}", a, b, max_nmse=1e-10, log=plog)
+            T.compare(f"split graph cuts={cuts}: {nm} vs unsplit", a, c, max_nmse=1e-12, log=plog)
+
+
+def test_deferred_norm_result_is_still_written(backend, H, plog):
+    """result_norm / t_embd: llama.cpp reads the final RMS_NORM*w from the host although only the lm_head consumes it in the
+    graph and the tensor is not flagged as an output.  The norm is folded into the mat-vec prologue — and written anyway."""
+    rng = np.random.default_rng(5)
+    E, N = 2048, 1000
+    x = rng.standard_normal((1, E)).astype(np.float32)
+    nw = rng.uniform(0.5, 1.5, E).astype(np.float32)
+    w = T.rand_weight(L.Q6_K, E, N, rng)
+    res = {}
+    for target in ("oracle", backend):
+        g = T.G(target)
+        try:
+            m = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, g.new(L.F32, [E, 1], x), 1e-5), g.new(L.F32, [E], nw))
+            y = H.ggml_mul_mat(g.ctx, g.new(L.Q6_K, [E, N], w), m)
+            k0 = backend.stat("kernel_launches")
+            out = g.compute([y], 4)
+            launches = backend.stat("kernel_launches") - k0
+            res[target == "oracle"] = (out[0], g.read(m), launches)  # m is NOT an output of the graph
+        finally:
+            g.free()
+    assert res[False][2] == 1, "norm was not folded into the mat-vec launch"
+    T.compare("lm_head over deferred norm", res[False][0], res[True][0], max_nmse=1e-10, log=plog)
+    T.compare("result_norm read behind the fused launch", res[False][1], res[True][1], max_nmse=1e-12, log=plog)
