@@ -293,6 +293,7 @@ static const char * type_tag(int t) {
 }
 
 static bool is_view_op(const ggml_tensor * t);
+static bool ranges_overlap(const ggml_tensor * x, const ggml_tensor * y);
 static bool quant_consumers_only(const exec_state & st, int at, const ggml_tensor * t);
 static bool same_shape(const ggml_tensor * a, const ggml_tensor * b);
 // quantised mat-mul, optionally with fused epilogue; w2 != null -> SwiGLU over (w, w2)
@@ -322,7 +323,9 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         a.x = pro_norm ? (const float *) dn->second.x->data : (const float *) b->data;
         a.norm_w = pro_norm ? (const float *) dn->second.w->data : nullptr;
         a.eps = pro_norm ? dn->second.eps : 0.0f;
-        a.norm_out = pro_norm ? (float *) dn->second.out->data : nullptr;
+        // (the allocator may have given THIS result the block of the norm's MUL node, free after its last reader — then that node is
+        // provably dead and is not written: the two stores would race inside one launch)
+        a.norm_out = (pro_norm && !ranges_overlap(dst, dn->second.out)) ? (float *) dn->second.out->data : nullptr;
         char cls[64];
         snprintf(cls, sizeof(cls), "mmvq_%s%s_%s", type_tag(w->type), w2 ? "_glu" : "", pro_norm ? "normpro" : "f32pro");
         timed_scope ts(c, cls, wbytes, true);
@@ -627,6 +630,10 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     base.norm_w = norm ? (const float *) dn->second.w->data : nullptr;
     base.eps = norm ? dn->second.eps : 0.0f;
     base.norm_out = norm ? (float *) dn->second.out->data : nullptr;
+    if (norm)  // a chain tensor that recycled the MUL node's block proves that node dead after this launch: do not write it (race)
+        for (auto & ch : chains)
+            for (int k : ch.nodes)
+                if (ranges_overlap(g->nodes[k], dn->second.out)) base.norm_out = nullptr;
     if (rope0) {
         rope_params p;
         p.n_dims = rope0->op_params[1];

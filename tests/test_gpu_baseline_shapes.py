@@ -223,11 +223,14 @@ def test_layer_teacher_forced(backend, H, plog, sp):
     vals.update(q_rope=q_o, kc=np.asarray(kc_o).reshape(n_ctx, EK), vc=np.asarray(vc_o).reshape(n_ctx, EK))
     (fa_o,), _ = run(seg_attn, "oracle", vals)
     (fa_g,), n2 = run(seg_attn, backend, vals)
-    T.compare(f"{sp.name}: flash_attn n_kv={sp.n_past + 1} heads={NH}/{NKV} d={HD}", fa_g, fa_o, max_nmse=1e-4, log=plog)
     exact = _attention_f64(np.asarray(q_o), vals["kc"], vals["vc"], sp.n_past + 1, NH, NKV, HD)
     e_gpu, e_cpu = T.nmse(np.asarray(fa_g).reshape(NH, HD), exact), T.nmse(np.asarray(fa_o).reshape(NH, HD), exact)
     _log(plog, f"{sp.name}: attention vs float64: gpu nmse={e_gpu:.3e}, cpu oracle (f16 V accumulation) nmse={e_cpu:.3e}")
+    # the CPU's f16 V accumulator loses precision with every cell (its distance from exact attention grows with n_kv: ~1e-5 at 2 k
+    # cells, ~2e-4 at 8 k); the kernel must be (much) closer to exact attention than the CPU is, and no further from the CPU than
+    # the CPU is from exact
     assert e_gpu <= 1e-9 and e_gpu <= e_cpu * 1.01 + 1e-12
+    T.compare(f"{sp.name}: flash_attn n_kv={sp.n_past + 1} heads={NH}/{NKV} d={HD}", fa_g, fa_o, max_nmse=max(1e-4, 1.5 * e_cpu), log=plog)
     report.append(("flash_attn", n2))
 
     vals.update(attn=np.asarray(fa_o).reshape(1, NH * HD))
@@ -273,11 +276,12 @@ def test_flash_attn_head_dim_128_at_8192(backend, H, plog, NH, NKV, n_kv, n_vis)
 
     ref = T.run_case(build, "oracle", NT)
     got = T.run_case(build, backend)
-    T.compare(f"flash_attn d=128 heads={NH}/{NKV} n_kv={n_kv} visible={n_vis}", got[0], ref[0], max_nmse=1e-4, log=plog)
     exact = _attention_f64(q[0], kc, vc, n_vis, NH, NKV, HD)
-    e = T.nmse(np.asarray(got[0]).reshape(NH, HD), exact)
-    _log(plog, f"flash_attn d=128 heads={NH}/{NKV} n_kv={n_kv} visible={n_vis}: gpu vs float64 nmse={e:.3e}")
-    assert e <= 1e-9
+    e, e_cpu = T.nmse(np.asarray(got[0]).reshape(NH, HD), exact), T.nmse(np.asarray(ref[0]).reshape(NH, HD), exact)
+    _log(plog, f"flash_attn d=128 heads={NH}/{NKV} n_kv={n_kv} visible={n_vis}: vs float64 gpu nmse={e:.3e}, cpu oracle (f16 V accumulation) nmse={e_cpu:.3e}")
+    assert e <= 1e-9 and e <= e_cpu
+    # (at 8 k cells the CPU's own f16 accumulation error is ~2e-4: the gate against the CPU follows it)
+    T.compare(f"flash_attn d=128 heads={NH}/{NKV} n_kv={n_kv} visible={n_vis}", got[0], ref[0], max_nmse=max(1e-4, 1.5 * e_cpu), log=plog)
 
 
 # ------------------------------------------------------------------------------------------------ split graphs
