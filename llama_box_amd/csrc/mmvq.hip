@@ -25,7 +25,19 @@
 
 namespace mi355x {
 
+// scripts/ubench/decode_lab.hip builds a private copy of this file with -DMI_LAB_STAMPS: wave 0 of every workgroup records the
+// 100 MHz wall clock at a few points of k_mmvq_stream (where does a launch's fixed cost go?).  Nothing of it exists in the product.
+#ifdef MI_LAB_STAMPS
+__device__ unsigned long long * g_lab_stamps = nullptr;
+// (the launch's slot in the stamp buffer rides in a.dst_stride, which the single-column kernel does not read)
+#define MI_STAMP(k) do { if (g_lab_stamps && threadIdx.x == 0) g_lab_stamps[((size_t) a.dst_stride * 256 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+void lab_set_stamps(unsigned long long * p) { (void) hipMemcpyToSymbol(HIP_SYMBOL(g_lab_stamps), &p, sizeof(p)); }
+#else
+#define MI_STAMP(k) do { } while (0)
+#endif
+
 thread_local launch_probe g_launch_probe;
+
 
 // ------------------------------------------------------------------------------------------------ kernel
 // PRO selects how the workgroup obtains its Q8 activations:
@@ -243,8 +255,52 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
             }
         }
     };
+    MI_STAMP(0);
+    // Order of the first requests (scripts/ubench/decode_lab.hip, stamp_lab.hip, prologue_probe.hip — DESIGN.md §4):
+    //   f32 prologue (PRO 1: wo, ffn_down): the activation row FIRST, then the first weights, both unconditionally (clamped
+    //     addresses): wo 6.0 -> 5.4 us, ffn_down Q4_K 11.7 -> 10.3, Q6_K 15.8 -> 14.7.  A load under `if (...)` makes hipcc's
+    //     wait-count pass assume it may not have been issued, and the first use of x then waits for the weights as well.
+    //   norm prologue (PRO 2: gate/up, lm_head): weights first, as in round 1 — with x AND the norm weights ahead of them the 66 MB
+    //     gate/up launch lost 1.2 us and the lm_head 10 us.  (What delays x is not its place in the wave's own queue but the other
+    //     waves' weight requests in the CU's memory pipeline: x returns 0.6 us after entry on an idle pipeline, 3-6 us behind
+    //     ~100 KB of weight requests per CU; holding the weights back until x has arrived leaves HBM idle for as long as it gains.)
+    constexpr int BPC = PRO == 0 ? 1 : 256 / T::BLK;  // activation blocks per 256-value chunk
+    const int nchk = a.K / 256;
+    float4 v[4], g[4];
     item cur;
-    if (have) load_item(row, 0, cur);
+    if constexpr (PRO == 1) {
+        const float4 * x4 = (const float4 *) a.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = x4[min(wave + u * WAVES, nchk - 1) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);  // keep the weight loads below behind them
+        const int rc = min(row, a.N - 1);
+        const uint8_t * rp = a.W + (size_t) rc * a.w_nb1;
+        const uint8_t * rp2 = GLU ? a.W2 + (size_t) rc * a.w_nb1 : nullptr;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = min(u * 64 + lane, npairs - 1);
+            cur.w[u] = T::load(rp, p);
+            if (GLU) cur.w2[u] = T::load(rp2, p);
+        }
+    } else {
+        if (have) load_item(row, 0, cur);
+        if constexpr (PRO == 2) {
+            const float4 * x4 = (const float4 *) a.x;
+            const float4 * w4 = (const float4 *) a.norm_w;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = wave + u * WAVES;
+                if (b < nchk) {
+                    v[u] = x4[b * 64 + lane];
+                    g[u] = w4[b * 64 + lane];
+                } else {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[u] = v[u];
+                }
+            }
+        }
+    }
+    MI_STAMP(1);
 
     // ---- activation prologue
     if constexpr (PRO == 0) {
@@ -260,24 +316,16 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     } else {
         // one wave per 256-value chunk: a Q8_K block, or eight Q8_0 blocks (launcher guarantees K % 256 == 0)
         act * yl = (act *) smem;
-        constexpr int BPC = 256 / T::BLK;  // activation blocks per chunk
-        const int nchk = a.K / 256;
         const float4 * x4 = (const float4 *) a.x;
-        const float4 * w4 = (const float4 *) a.norm_w;
-        // batch 0 (blocks wave, wave+16, wave+32, wave+48) is special: with the norm it must hold the WHOLE row
+        // batch 0 (blocks wave, wave+16, wave+32, wave+48: loaded above) is special: with the norm it must hold the WHOLE row
         // (launcher guarantees nblk <= 64) because the scale needs the full sum of squares; the barrier sits outside
-        // any wave-dependent control flow
+        // any wave-dependent control flow.  Further batches (f32 prologue only, K > 16384) load inside the loop.
         for (int b0 = wave; b0 < nchk || b0 == wave; b0 += 4 * WAVES) {
-            float4 v[4], g[4];
+            if (b0 != wave) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int b = b0 + u * WAVES;
-                if (b < nchk) {
-                    v[u] = x4[b * 64 + lane];
-                    if (PRO == 2) g[u] = w4[b * 64 + lane];
-                } else {
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    g[u] = v[u];
+                for (int u = 0; u < 4; ++u) {
+                    const int b = b0 + u * WAVES;
+                    v[u] = b < nchk ? x4[b * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             float scale = 1.0f;
@@ -287,6 +335,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ss += (double) (v[u].x * v[u].x) + (double) (v[u].y * v[u].y) + (double) (v[u].z * v[u].z) + (double) (v[u].w * v[u].w);
                 ss = wave_sum_d(ss);
+                MI_STAMP(2);
                 if (lane == 0) red[wave] = ss;
                 __syncthreads();  // reached exactly once by every wave: the loop condition admits b0 == wave
                 double tot = 0.0;
@@ -315,9 +364,11 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         }
     }
     __syncthreads();
+    MI_STAMP(3);
     const act * y = (const act *) smem;
 
     float acc = 0.0f, acc2 = 0.0f;
+    int lab_first = 1;
     while (have) {
         int nrow = row, nch = ch + 1;
         if (nch == nchunks) { nch = 0; nrow = next_row(row); }
@@ -350,7 +401,9 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         row = nrow;
         ch = nch;
         have = nhave;
+        if (lab_first) { MI_STAMP(4); lab_first = 0; }
     }
+    MI_STAMP(5);
 }
 
 template <typename T, bool GLU, int PRO> static void launch_stream(hipStream_t s, const mmvq_args & a) {
