@@ -207,6 +207,7 @@ def main():
     steps(args.warmup)
     pos += args.warmup
     g0 = be.stat("graph_launches")
+    gl0 = be.stat("graph_launch_host_ns")
     sync()
     t0 = time.perf_counter()
     steps(args.steps)
@@ -221,6 +222,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     graph_steps = be.stat("graph_launches") - g0
+    graph_launch_host_us = (be.stat("graph_launch_host_ns") - gl0) / 1e3 / max(1, graph_steps)
     streams = 1 if tp_size > 1 or world == 1 else world
     tok_s = streams * args.np * args.steps / elapsed
     host_split = [x / max(1, args.steps) for x in ctx.timings()]
@@ -338,7 +340,7 @@ def main():
             "prefill_roofline": prefill_roofline,
             "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),
             "replicas_on_the_same_gpus": replicas,
-            "graph_replayed_steps": int(graph_steps),
+            "graph_replayed_steps": int(graph_steps), "hipGraphLaunch_host_us": round(graph_launch_host_us, 1),
             "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernel_classes_us": {k: round(v[1] * 1e3 / max(1, v[0]), 2) for k, v in sorted(classes.items())},

@@ -382,6 +382,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "kernel_launches") return c->st.kernel_launches;
     if (k == "fused_nodes") return c->st.fused_nodes;
     if (k == "allreduces") return c->st.allreduces;
+    if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
     return -1;
 }
 static int api_timing_report(ggml_backend_t be, char * buf, size_t size, int reset) {

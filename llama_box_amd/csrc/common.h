@@ -80,6 +80,7 @@ struct options {
 
 struct stats {
     int64_t graph_launches = 0, graph_captures = 0, eager_graphs = 0, kernel_launches = 0, fused_nodes = 0, allreduces = 0;
+    int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)
 };
 
 struct tp_state;  // tp.cpp

@@ -9,6 +9,7 @@
 // backend's CUDA-graph path (GGML_CUDA_GRAPHS, /root/reference/CMakeLists.txt:56-58) plays the same role there.
 // Errors inside compute return GGML_STATUS_FAILED (-> llama_decode rc -2, llama-box/httpserver.hpp:3541-3545).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "kernels.h"
@@ -1320,10 +1321,12 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     cg.last_use = c->tick;
     cg.seen++;
     if (cg.exec) {
+        const auto t0 = std::chrono::steady_clock::now();
         if (hipGraphLaunch(cg.exec, c->stream) != hipSuccess) {
             (void) hipGetLastError();
             return GGML_STATUS_FAILED;
         }
+        c->st.graph_launch_host_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         c->st.graph_launches++;
         return GGML_STATUS_SUCCESS;
     }

@@ -123,41 +123,46 @@ struct T_Q5K {
 };
 
 // ------------------------------------------------------------------------------------------------ Q6_K
-// 8 lanes per super-block: lane (h, t) owns l = 8t..8t+7 of half h, i.e. 32 of the 256 values (8 bytes of ql twice, 8 of qh)
+// 4 lanes per super-block, 64 values each (round 2; round 1 used 8 lanes x 34 bytes fetched as five 8- / 2-byte loads, and the
+// Q6_K launches streamed at 3.1 TB/s where Q4_K reached 4.2): lane (h, t) owns l = 16t .. 16t+15 of half h, i.e. 16 bytes of
+// ql twice (low / high nibbles = the value groups 128h + {0, 64} + l and 128h + {32, 96} + l) and the 16 bytes of qh that carry
+// their upper two bits — three 16-byte loads at the format's 2-byte alignment (gfx950 serves unaligned global_load_dwordx4),
+// one 8-byte load for the half's scales and the f16 d.  The -32 offset of the 6-bit codes comes from the activation block's
+// 16-value sums (bsums) instead of a second dot product.
+struct __attribute__((packed, aligned(2))) u128_a2 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(2))) u64_a2 { uint32_t x, y; };
 struct T_Q6K {
     typedef q8k_dev act;
-    static constexpr int BLK = 256, BYTES = 210, PPB = 8;
-    struct raw { uint32_t ql0[2], ql1[2], qh[2], s0, s1; uint16_t d; };
-    static constexpr int DW = 9;
+    static constexpr int BLK = 256, BYTES = 210, PPB = 4;
+    struct raw { u128_a2 a, b, c; u64_a2 s; uint16_t d; };
+    static constexpr int DW = 15;
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
-        const uint8_t * blk = row + (size_t) (p >> 3) * BYTES;
-        const int h = (p >> 2) & 1, t = p & 3;
+        const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
+        const int h = (p >> 1) & 1, t = p & 1;
         raw r;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            r.ql0[i] = ld32_a2(blk + 64 * h + 8 * t + 4 * i);
-            r.ql1[i] = ld32_a2(blk + 64 * h + 32 + 8 * t + 4 * i);
-            r.qh[i] = ld32_a2(blk + 128 + 32 * h + 8 * t + 4 * i);
-        }
-        r.s0 = ld32_a2(blk + 192 + 8 * h);
-        r.s1 = ld32_a2(blk + 196 + 8 * h);
+        r.a = *(const u128_a2 *) (blk + 64 * h + 16 * t);
+        r.b = *(const u128_a2 *) (blk + 64 * h + 32 + 16 * t);
+        r.c = *(const u128_a2 *) (blk + 128 + 32 * h + 16 * t);
+        r.s = *(const u64_a2 *) (blk + 192 + 8 * h);
         r.d = ld16(blk + 208);
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
-        const int b = p >> 3, h = (p >> 2) & 1, t = p & 3, is = t >> 1;
+        const int b = p >> 2, h = (p >> 1) & 1, t = p & 1;
         const float d = h2f(r.d);
-        uint32_t v[4][2];
+        const uint32_t A[4] = {r.a.x, r.a.y, r.a.z, r.a.w}, B[4] = {r.b.x, r.b.y, r.b.z, r.b.w}, C[4] = {r.c.x, r.c.y, r.c.z, r.c.w};
+        uint32_t v[4][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            v[0][i] = (r.ql0[i] & 0x0F0F0F0Fu) | ((r.qh[i] & 0x03030303u) << 4);
-            v[1][i] = (r.ql1[i] & 0x0F0F0F0Fu) | (((r.qh[i] >> 2) & 0x03030303u) << 4);
-            v[2][i] = ((r.ql0[i] >> 4) & 0x0F0F0F0Fu) | (((r.qh[i] >> 4) & 0x03030303u) << 4);
-            v[3][i] = ((r.ql1[i] >> 4) & 0x0F0F0F0Fu) | (((r.qh[i] >> 6) & 0x03030303u) << 4);
+        for (int i = 0; i < 4; ++i) {
+            v[0][i] = (A[i] & 0x0F0F0F0Fu) | ((C[i] & 0x03030303u) << 4);
+            v[1][i] = (B[i] & 0x0F0F0F0Fu) | (((C[i] >> 2) & 0x03030303u) << 4);
+            v[2][i] = ((A[i] >> 4) & 0x0F0F0F0Fu) | (((C[i] >> 4) & 0x03030303u) << 4);
+            v[3][i] = ((B[i] >> 4) & 0x0F0F0F0Fu) | (((C[i] >> 6) & 0x03030303u) << 4);
         }
+        // scales of the half: bytes 8h .. 8h+7 of the block's 16; group k of this lane uses byte t + 2k
         const int sc[4] = {
-            (int) (int8_t) (r.s0 >> (8 * is)), (int) (int8_t) (r.s0 >> (8 * (is + 2))),
-            (int) (int8_t) (r.s1 >> (8 * is)), (int) (int8_t) (r.s1 >> (8 * (is + 2))),
+            (int) (int8_t) (r.s.x >> (8 * t)), (int) (int8_t) (r.s.x >> (8 * (t + 2))),
+            (int) (int8_t) (r.s.y >> (8 * t)), (int) (int8_t) (r.s.y >> (8 * (t + 2))),
         };
 #pragma unroll
         for (int col = 0; col < NC; ++col) {
@@ -165,12 +170,13 @@ struct T_Q6K {
             int isum = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint2 yk = *(const uint2 *) (yb->qs + 128 * h + 32 * k + 8 * t);
-                // sum (q - 32) * y = dot(q, y) - 32 * sum(y)
+                const uint4 yk = *(const uint4 *) (yb->qs + 128 * h + 32 * k + 16 * t);
+                // sum (q - 32) * y = dot(q, y) - 32 * sum(y); sum(y) over these 16 values = bsums[8h + 2k + t] (an exact f16 integer)
                 int s = dot4((int) v[k][0], (int) yk.x, 0);
                 s = dot4((int) v[k][1], (int) yk.y, s);
-                int ys = dot4(0x01010101, (int) yk.x, 0);
-                ys = dot4(0x01010101, (int) yk.y, ys);
+                s = dot4((int) v[k][2], (int) yk.z, s);
+                s = dot4((int) v[k][3], (int) yk.w, s);
+                const int ys = (int) h2f(yb->bsums[8 * h + 2 * k + t]);
                 isum += __mul24(sc[k], s - 32 * ys);
             }
             acc[col] += yb->d * d * (float) isum;
