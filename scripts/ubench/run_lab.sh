@@ -18,3 +18,7 @@ if [ "${PROBE:-0}" = "1" ]; then
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DGGML_MAX_NAME=128 -Iinclude scripts/ubench/prologue_probe.hip -o /tmp/prologue_probe
 timeout 120 /tmp/prologue_probe 2>&1 | tee gpurun_out/prologue_probe.txt
 fi
+if [ "${CHAIN:-0}" = "1" ]; then
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DGGML_MAX_NAME=128 -Iinclude scripts/ubench/chain_probe.hip -o /tmp/chain_probe
+timeout 60 /tmp/chain_probe 2>&1 | tee gpurun_out/chain_probe.txt
+fi
