@@ -302,6 +302,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_QKV")) c->opt.qkv = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_MIN_COLS")) c->opt.mmq_min_cols = atoi(e);
     if (const char * e = getenv("GGML_MI355X_FA_SPLITS")) c->opt.fa_splits = atoi(e);
+    if (const char * e = getenv("GGML_MI355X_FA_WO")) c->opt.fa_wo = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_SMALL_UPLOADS")) c->opt.small_uploads = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_I8")) c->opt.mmq_i8 = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MM_MERGE")) c->opt.mm_merge = atoi(e) != 0;
@@ -365,6 +366,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "mm_merge") c->opt.mm_merge = v != 0;
     else if (k == "mmq_bn") c->opt.mmq_bn = v;
     else if (k == "fa_splits") c->opt.fa_splits = v;
+    else if (k == "fa_wo") c->opt.fa_wo = v != 0;
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;
     else if (k == "timing") c->opt.timing = v != 0;
     else return -1;

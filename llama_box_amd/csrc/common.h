@@ -74,6 +74,9 @@ struct options {
     bool mm_merge = true;      // batches: sibling mat-muls over the same activations (wq/wk/wv, gate/up) as one launch
     int mmq_bn = 0;            // force the weight-panel height of mmq_i8 (64 / 128); 0 = pick by grid size
     int fa_splits = 0;         // 0 = auto
+    bool fa_wo = false;        // decode: attention as few fat splits whose merge is the wo mat-vec's prologue (no combine launch).  Correct and
+                               // tested, OFF by default: a KV trip of the lane-parallel kernel is a ~4 us dependent chain, so 9 splits of 2
+                               // trips (12.0 us) + the merging prologue (wo 6.8 -> 10.4 us) lose to 36 one-trip splits + combine (13.6 + 6.8)
     bool small_uploads = true; // set_tensor_async of <= 64 KiB: pinned ring + copy kernel instead of a blit
     bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)
 };

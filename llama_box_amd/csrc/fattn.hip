@@ -12,6 +12,8 @@
 // instruction moves 8 (D=64) or 4 (D=128) whole rows = 1 KiB, fully coalesced.  Scores are finished with a
 // sub-wave butterfly; there is no LDS traffic in the KV loop.  Partial (m, l, acc) triples are merged across
 // sub-rows (shuffles), waves (LDS) and splits (second tiny kernel).
+#include <algorithm>
+
 #include "dev_util.h"
 #include "kernels.h"
 
@@ -19,6 +21,7 @@ namespace mi355x {
 
 struct fa_geom {
     int n_q, n_head, n_kv_head, n_kv, n_splits, has_mask;
+    int rec_stride;  // floats between the partial records of consecutive splits (D + 2; 132 for the records the wo prologue reads)
     float scale, softcap, max_bias, m0, m1;
     uint32_t n_head_log2;
 };
@@ -252,14 +255,18 @@ __device__ __forceinline__ float xrow_allmax(const float x) {
 // MODE 2 (LIST): the visible tiles of every query token were listed once per graph by k_fattn_tile_scan (the mask is the same
 // tensor in every layer); split s of token t walks its share of THAT list, so the work is proportional to what the token can
 // see, not to the size of the unified cache, and no workgroup is launched just to find out that it has nothing to do.
-template <int G, int MODE, bool Q8>
-__global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
+// WV = waves per workgroup: 4 (many thin splits + combine pass) or 8 (few fat splits whose partials the wo mat-vec prologue combines:
+// mmvq.hip PRO 3; 16 waves would cap the kernel at 128 VGPRs, and it needs ~200: the first 16-wave build spilled and ran 2x slower)
+template <int G, int MODE, bool Q8, int WV = 4>
+__global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
                                                       const tdesc dst, const fa_geom geo, float * __restrict__ ws, const int g_real,
                                                       const int * __restrict__ lists, const int list_stride) {
     constexpr bool SKIP = MODE == 1, LIST = MODE == 2;
     constexpr int D = 128, NG = 16 / G;
     constexpr float LOG2E = 1.4426950408889634f;
-    __shared__ float sh[4][G][D + 2];
+    constexpr int TRIP = NG * WV * 4;  // positions per trip
+    static_assert(WV == 4 || (MODE == 0 && !Q8), "the wide form serves plain decode over an f16 cache only");
+    __shared__ float sh[WV][G][D + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane >> 4, sl = lane & 15;
     const int ul = sl / G, gl = sl % G;  // the (row group, head) pair this lane owns in the lane-parallel part
@@ -321,11 +328,11 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
     uint4 kraw[NG], vraw[NG];
     float mvl = 0.0f;   // mask value / validity of THIS lane's pair (ul, sub)
     bool okl = false;
-    int p0 = LIST ? tl[ti] * (NG * 16) : kv0;
+    int p0 = LIST ? tl[ti] * TRIP : kv0;
 #define FA_LOAD_TRIP()                                                                  \
     {                                                                                   \
         _Pragma("unroll") for (int u = 0; u < NG; ++u) {                               \
-            const int pc = min(p0 + u * 16 + wave * 4 + sub, kv1 - 1);                  \
+            const int pc = min(p0 + u * (WV * 4) + wave * 4 + sub, kv1 - 1);                  \
             const char * kp_ = kbase + (int64_t) pc * k.nb[1];                          \
             const char * vp_ = vbase + (int64_t) pc * v.nb[1];                          \
             if constexpr (Q8) {  /* 8 quants (2-byte aligned) + the block's f16 scale */  \
@@ -336,19 +343,19 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
                 vraw[u] = *(const uint4 *) vp_;                                         \
             }                                                                           \
         }                                                                               \
-        const int pl = p0 + ul * 16 + wave * 4 + sub;                                   \
+        const int pl = p0 + ul * (WV * 4) + wave * 4 + sub;                             \
         okl = pl < kv1;                                                                 \
         mvl = mp ? h2f(mp[min(pl, kv1 - 1)]) : 0.0f;                                    \
     }
     uint32_t vis = 0xFFFFFFFFu;  // bit i: trip i has a position this wave can see
     if constexpr (SKIP) {
         vis = 0;
-        const int ntrips = (kv1 - kv0 + NG * 16 - 1) / (NG * 16);  // <= 32 (launcher bounds the split length)
+        const int ntrips = (kv1 - kv0 + TRIP - 1) / TRIP;  // <= 32 (launcher bounds the split length)
         for (int i0 = 0; i0 < ntrips; i0 += 8) {
             uint16_t mraw[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int pl = kv0 + (i0 + i) * NG * 16 + ul * 16 + wave * 4 + sub;
+                const int pl = kv0 + (i0 + i) * TRIP + ul * (WV * 4) + wave * 4 + sub;
                 mraw[i] = (i0 + i < ntrips && pl < kv1) ? (mp ? mp[pl] : (uint16_t) 0) : (uint16_t) 0xFC00;
             }
 #pragma unroll
@@ -405,10 +412,10 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
 
     for (int trip = 0; LIST ? ti < ti1 : p0 < kv1; ++trip) {
         // position of the next trip (LIST: next entry of the tile list; otherwise the next NG*16 positions of the split)
-        int p_next = p0 + NG * 16;
+        int p_next = p0 + TRIP;
         if constexpr (LIST) {
             ++ti;
-            p_next = ti < ti1 ? tl[ti] * (NG * 16) : kv1;
+            p_next = ti < ti1 ? tl[ti] * TRIP : kv1;
         }
         if constexpr (SKIP) {
             if (!((vis >> trip) & 1u)) {  // nothing visible: only keep the pipeline primed for the next trip
@@ -533,18 +540,34 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
         sh[wave][gl][D + 1] = l;
     }
     __syncthreads();
-    // ---- merge the four waves; one thread per (g, d)
-    for (int e = tid; e < g_real * D; e += 256) {
+    // ---- merge the waves; one thread per (g, d)
+    for (int e = tid; e < g_real * D; e += WV * 64) {
         const int g = e / D, dd = e % D;
-        const float m0 = sh[0][g][D], m1 = sh[1][g][D], m2 = sh[2][g][D], m3 = sh[3][g][D];
-        const float mt = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        const float mref = mt == -INFINITY ? 0.0f : mt;
-        const float c0 = fa_exp2(m0 - mref), c1 = fa_exp2(m1 - mref), c2 = fa_exp2(m2 - mref), c3 = fa_exp2(m3 - mref);
-        float a = ((sh[0][g][dd] * c0 + sh[1][g][dd] * c1) + sh[2][g][dd] * c2) + sh[3][g][dd] * c3;
-        float lt = ((sh[0][g][D + 1] * c0 + sh[1][g][D + 1] * c1) + sh[2][g][D + 1] * c2) + sh[3][g][D + 1] * c3;
+        float mt, a, lt;
+        if constexpr (WV == 4) {
+            const float m0 = sh[0][g][D], m1 = sh[1][g][D], m2 = sh[2][g][D], m3 = sh[3][g][D];
+            mt = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            const float mref = mt == -INFINITY ? 0.0f : mt;
+            const float c0 = fa_exp2(m0 - mref), c1 = fa_exp2(m1 - mref), c2 = fa_exp2(m2 - mref), c3 = fa_exp2(m3 - mref);
+            a = ((sh[0][g][dd] * c0 + sh[1][g][dd] * c1) + sh[2][g][dd] * c2) + sh[3][g][dd] * c3;
+            lt = ((sh[0][g][D + 1] * c0 + sh[1][g][D + 1] * c1) + sh[2][g][D + 1] * c2) + sh[3][g][D + 1] * c3;
+        } else {
+            mt = sh[0][g][D];
+#pragma unroll
+            for (int w = 1; w < WV; ++w) mt = fmaxf(mt, sh[w][g][D]);
+            const float mref = mt == -INFINITY ? 0.0f : mt;
+            a = 0.0f;
+            lt = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WV; ++w) {
+                const float c = fa_exp2(sh[w][g][D] - mref);
+                a += sh[w][g][dd] * c;
+                lt += sh[w][g][D + 1] * c;
+            }
+        }
         const int h = kvh * g_real + g;
         const float mt_e = mt * (1.0f / LOG2E);  // records and sinks use the natural-log domain of the generic kernel
-        if (geo.n_splits == 1) {
+        if (geo.n_splits == 1 && WV == 4) {  // (the wide form always leaves records: its reader is the wo prologue, also for one split)
             if (sinks) {
                 const float sk = sinks[h];
                 const float mn = fmaxf(mt_e, sk);
@@ -555,7 +578,7 @@ __global__ void __launch_bounds__(256) k_fattn_dec128(const tdesc q, const tdesc
             float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
             out[dd] = a * (1.0f / lt);
         } else {
-            float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits + split) * (D + 2);
+            float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits + split) * geo.rec_stride;
             rec[dd] = a;
             if (dd == 0) {
                 rec[D] = mt_e;
@@ -660,7 +683,25 @@ int fattn_pick_splits(const tdesc & q, const tdesc & k) {
 }
 static size_t fattn_partials_bytes(const tdesc & q, const tdesc & v, int n_splits) {
     if (n_splits <= 1) return 0;
-    return ((size_t) (q.ne[1] * q.ne[3] * q.ne[2]) * (size_t) n_splits * (size_t) (v.ne[0] + 2) * sizeof(float) + 255) & ~(size_t) 255;
+    return ((size_t) (q.ne[1] * q.ne[3] * q.ne[2]) * (size_t) std::max(n_splits, 16) * (size_t) (v.ne[0] + 4) * sizeof(float) + 255) & ~(size_t) 255;  // (covers the fat-split records too)
+}
+// Single-token decode at head_dim 128 whose result goes straight into a quantised mat-vec (wo): number of fat splits (<= 16) for
+// the 8-wave kernel, 0 if that form does not serve the case.  A workgroup trip covers 8 waves x 4 rows x NG positions; splits are
+// sized in whole trips so that no workgroup runs a nearly empty one, and there are at most 12 of them: the wo prologue fetches up
+// to 12 records per head in one round trip.
+int fattn_fat_splits(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const fattn_params & p) {
+    if (q.ne[1] != 1 || q.ne[3] != 1 || k.ne[0] != 128 || k.ne[3] != 1 || p.kv_type != GGML_TYPE_F16 || sinks || p.logit_softcap != 0.0f || p.max_bias != 0.0f) return 0;
+    if (q.ne[2] % k.ne[2] != 0 || (q.ne[2] % 2) != 0) return 0;
+    const int64_t G = q.ne[2] / k.ne[2];
+    if (!(G == 2 || G == 4 || G == 7 || G == 8) || (q.nb[1] % 16) != 0 || (q.nb[2] % 16) != 0 || ((uintptr_t) q.data & 15) != 0) return 0;
+    if (mask && (mask->type != GGML_TYPE_F16)) return 0;
+    const int64_t trip = 32 * (16 / (G == 7 ? 8 : G));
+    const int64_t trips = (k.ne[1] + trip - 1) / trip;
+    int64_t splits = std::min<int64_t>(12, trips);
+    // whole trips per split: e.g. 9 trips -> 9 splits of 1; 32 trips -> 16 splits of 2; 33 trips -> 11 splits of 3
+    const int64_t per = (trips + splits - 1) / splits;
+    splits = (trips + per - 1) / per;
+    return (int) splits;
 }
 // prompt batches over a block_q8_0 cache run the matrix-core kernel on an f16 image of the K and V views (below)
 static bool fattn_q8_via_f16(const tdesc & q, int kv_type) { return kv_type == GGML_TYPE_Q8_0 && q.ne[1] >= fattn_mma_min_q(); }
@@ -788,6 +829,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         abort();
     }
     fa_geom geo;
+    geo.rec_stride = (int) k.ne[0] + 2;
     geo.n_q = (int) q.ne[1];
     geo.n_head = (int) q.ne[2];
     geo.n_kv_head = (int) k.ne[2];
@@ -807,6 +849,15 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     if (D == 128 && p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 2 || G == 4 || G == 7 || G == 8) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 &&
         ((uintptr_t) q.data & 15) == 0) {
         dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, (unsigned) (geo.n_q * q.ne[3]));
+        if (p.fat) {
+            // one decode token, few fat splits on 8-wave workgroups; the partial records stay in the workspace for the wo prologue
+            if (q8 || geo.n_q != 1 || q.ne[3] != 1 || sinks != nullptr) { MI_ERR("launch_flash_attn: fat-split form requested for a case it does not serve"); abort(); }
+            geo.rec_stride = FA_REC;
+            if (G == 2) hipLaunchKernelGGL((k_fattn_dec128<2, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
+            else if (G == 4) hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
+            else hipLaunchKernelGGL((k_fattn_dec128<8, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
+            return;
+        }
         // several query tokens with a mask: skip the KV trips a token cannot see — needs splits of at most 32 trips
         const int per = ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64;
         static const bool skip_on = !getenv("GGML_MI355X_FA_SKIP") || atoi(getenv("GGML_MI355X_FA_SKIP")) != 0;

@@ -220,6 +220,8 @@ struct exec_state {
     // tile lists (fattn.hip) valid for this mask tensor / tile size during this execution of the graph
     const void * fa_list_mask = nullptr;
     int fa_list_tile = 0;
+    // decode attention left as fat-split partial records for the prologue of the mat-vec that reads it (wo): fattn.hip / mmvq.hip PRO 3
+    struct { const ggml_tensor * b = nullptr; const ggml_tensor * fa = nullptr; const float * part = nullptr; int splits = 0; } fa_wo;
     // a split-K mat-mul whose partial products are summed by the norm + quantise kernel that reads it next (no reduce pass)
     const ggml_tensor * sk_dst = nullptr;
     splitk_src sk{};
@@ -307,8 +309,13 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const bool kquant = w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K || (w->type == GGML_TYPE_Q8_0 && (K % 256) == 0);  // formats with the mat-vec prologue
     auto dn = st.deferred.find(b);
     const bool pro_norm = dn != st.deferred.end();
-    const bool pro_f32 = !pro_norm && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
-    if (pro_norm || pro_f32) {
+    const bool pro_fa = st.fa_wo.b == b && st.fa_wo.part != nullptr;  // (set by the FLASH_ATTN_EXT node after checking this very mat-vec)
+    const bool pro_f32 = !pro_norm && !pro_fa && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
+    if (pro_fa && (w2 || pro_norm || !kquant || M != 1)) {
+        MI_ERR("graph_compute: attention partials were left for a mat-vec that cannot merge them");
+        return false;
+    }
+    if (pro_norm || pro_f32 || pro_fa) {
         mmvq_args a{};
         a.W = (const uint8_t *) w->data;
         a.W2 = w2 ? (const uint8_t *) w2->data : nullptr;
@@ -321,14 +328,22 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         a.dst_stride = (int64_t) (dst->nb[1] / 4);
         a.add = add ? (const float *) add->data : nullptr;
         a.add2 = add2 ? (const float *) add2->data : nullptr;
-        a.x = pro_norm ? (const float *) dn->second.x->data : (const float *) b->data;
+        a.x = pro_norm ? (const float *) dn->second.x->data : (pro_fa ? nullptr : (const float *) b->data);
+        if (pro_fa) {
+            a.fa_part = st.fa_wo.part;
+            a.fa_splits = st.fa_wo.splits;
+            // the attention result itself stays a tensor of the graph: written on the way, unless this launch's result recycled its block
+            a.x_out = ranges_overlap(dst, st.fa_wo.fa) ? nullptr : (float *) st.fa_wo.fa->data;
+            st.fa_wo.b = nullptr;
+            st.fa_wo.part = nullptr;
+        }
         a.norm_w = pro_norm ? (const float *) dn->second.w->data : nullptr;
         a.eps = pro_norm ? dn->second.eps : 0.0f;
         // (the allocator may have given THIS result the block of the norm's MUL node, free after its last reader — then that node is
         // provably dead and is not written: the two stores would race inside one launch)
         a.norm_out = (pro_norm && !ranges_overlap(dst, dn->second.out)) ? (float *) dn->second.out->data : nullptr;
         char cls[64];
-        snprintf(cls, sizeof(cls), "mmvq_%s%s_%s", type_tag(w->type), w2 ? "_glu" : "", pro_norm ? "normpro" : "f32pro");
+        snprintf(cls, sizeof(cls), "mmvq_%s%s_%s", type_tag(w->type), w2 ? "_glu" : "", pro_norm ? "normpro" : (pro_fa ? "attnpro" : "f32pro"));
         timed_scope ts(c, cls, wbytes, true);
         launch_mmvq(c->stream, a, 1);
         c->st.kernel_launches++;
@@ -1198,6 +1213,37 @@ static int run_node(exec_state & st, int i) {
                         st.fa_list_tile = -1;
                     }
                     p.tile_vis = (const uint8_t *) c->fa_lists;
+                }
+            }
+            // one decode token whose attention result goes (through a reshape) straight into a quantised mat-vec — wo: few fat splits on
+            // 8-wave workgroups, and the merge of their partial records is that mat-vec's prologue; the combine launch disappears
+            if (fuse && c->opt.fa_wo && c->opt.prologue && c->opt.fa_splits == 0 && a->ne[1] == 1 && a->ne[3] == 1 && !p.lists && !p.tile_vis && use_count(st, n) == 1 &&
+                !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(n) && (((uintptr_t) n->data) & 15) == 0) {
+                const int S = fattn_fat_splits(qd, kd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, p);
+                int j = i + 1;
+                const ggml_tensor * view = nullptr;
+                while (j < g->n_nodes && (st.done[j] || is_view_op(g->nodes[j]))) {
+                    if (!st.done[j] && g->nodes[j]->src[0] == (view ? view : n) && g->nodes[j]->data == n->data) view = g->nodes[j];
+                    ++j;
+                }
+                const ggml_tensor * mm = j < g->n_nodes ? g->nodes[j] : nullptr;
+                const ggml_tensor * w = mm ? mm->src[0] : nullptr;
+                const bool kq = w && (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K || w->type == GGML_TYPE_Q8_0) && w->ne[2] == 1 && w->ne[3] == 1 &&
+                                rows_contig(w) && (w->ne[0] % 256) == 0;
+                if (S > 0 && view && mm && mm->op == GGML_OP_MUL_MAT && mm->src[1] == view && kq && w->ne[0] == n->ne[0] * n->ne[1] && ggml_abi_nelements(view) == w->ne[0] &&
+                    use_count(st, view) == 1 && !(view->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(mm) && mm->type == GGML_TYPE_F32 &&
+                    !(tp_active(c) && buffer_is_rowpar(w->view_src ? w->view_src->buffer : w->buffer))) {
+                    p.n_splits = S;
+                    p.fat = 1;
+                    timed_scope ts(c, "flash_attn_fat", (double) (k->ne[1] * k->ne[2] * k->ne[0] * 2 * 2));
+                    launch_flash_attn(s, qd, kd, vd, m ? &md : nullptr, nullptr, TD(n), p, (char *) c->ws + st.aux_off);
+                    st.fa_wo.b = view;
+                    st.fa_wo.fa = n;
+                    st.fa_wo.part = (const float *) ((char *) c->ws + st.aux_off);
+                    st.fa_wo.splits = S;
+                    c->st.kernel_launches++;
+                    c->st.fused_nodes++;
+                    return 1;
                 }
             }
             // a batch's attention result read only by quantised mat-muls (wo), through the usual reshape: the combine pass writes

@@ -48,10 +48,16 @@ struct mmvq_args {
     const float * x;
     const float * norm_w;
     float eps;
+    // fa_part != null (instead of x): the row is the merge of `fa_splits` attention partial records per head ([head][split],
+    // FA_REC floats apart: 128 values, max, sum — fattn.hip's 8-wave decode kernel); K = heads * 128.  x_out: optional f32 copy.
+    const float * fa_part;
+    int fa_splits;
+    float * x_out;
     float * norm_out;  // norm_w != null: where RMS_NORM(x) * norm_w itself belongs (the graph's MUL node); written by workgroup 0 so that
                        // the fusion never leaves a tensor of the graph unwritten (readers in another split, or the host, may exist)
     int balance_tail;  // set by the launcher: spread the last, partial pass of rows evenly over the workgroups
 };
+#define FA_REC 132  // floats per attention partial record in the fat-split form (128 values + max + sum, padded to 16 bytes)
 void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave);
 // bench timing pass: when armed, the next streaming mat-vec launch records the kernel's own begin / end timestamps into
 // (e0, e1) through hipExtLaunchKernelGGL instead of being bracketed by host-side hipEventRecord calls
@@ -166,6 +172,8 @@ void launch_soft_max(hipStream_t s, const tdesc & src, const tdesc * mask, const
 struct fattn_params {
     float scale, max_bias, logit_softcap;
     int n_splits;  // KV splits per (token, kv-head group)
+    int fat = 0;   // 1: single-token decode as a few fat splits on 8-wave workgroups, records FA_REC apart, NO combine pass (the wo
+                   // mat-vec prologue merges them: mmvq_args::fa_part); see fattn_fat_splits()
     int kv_type;   // GGML_TYPE_F16 or GGML_TYPE_Q8_0 (K and V alike)
     const int * lists = nullptr;  // per-token lists of visible tiles (launch_fattn_tile_scan), or nullptr
     void * q8_out = nullptr;  // the result's only readers are quantised mat-muls (wo of a batch): leave it as Q8_K blocks here — honoured by
@@ -181,6 +189,7 @@ size_t fattn_workspace_bytes(const tdesc & q, const tdesc & k, const tdesc & v, 
 int fattn_mma_min_q();  // query tokens from which the matrix-core attention kernel takes over (env GGML_MI355X_FA_MMA_MIN_Q)
 bool flash_attn_mma_applies(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);
 int fattn_pick_splits(const tdesc & q, const tdesc & k);
+int fattn_fat_splits(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const fattn_params & p);  // 0 = the fat-split form does not apply
 bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);  // will this launch end in the quantising combine?
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks,
                        const tdesc & dst, const fattn_params & p, void * workspace);

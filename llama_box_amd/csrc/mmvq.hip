@@ -268,11 +268,28 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     const int nchk = a.K / 256;
     float4 v[4], g[4];
     item cur;
-    if constexpr (PRO == 1) {
+    // PRO 3 (wo of a decode step): the activation row is the attention result, still in the form of its split partials
+    // (fattn.hip, 8-wave form: [head][split] records of 128 values + (max, sum), FA_REC floats apart) — this prologue is the
+    // combine pass, so that pass's launch (~4.5 us of a dependent launch for 16 KB of work) disappears.  Lane l of chunk b owns
+    // dims 4(l & 31) .. +3 of head 2b + (l >> 5).
+    float2 fml[PRO == 3 ? 16 : 1];
+    float4 fr[PRO == 3 ? 12 : 1];
+    if constexpr (PRO == 3) {
+        const int S = a.fa_splits;
+        const float * rec0 = a.fa_part + (size_t) (2 * min(wave, nchk - 1) + (lane >> 5)) * S * FA_REC;
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) fml[sidx] = *(const float2 *) (rec0 + (size_t) min(sidx, S - 1) * FA_REC + 128);
+#pragma unroll
+        for (int sidx = 0; sidx < 12; ++sidx) fr[sidx] = *(const float4 *) (rec0 + (size_t) min(sidx, S - 1) * FA_REC + 4 * (lane & 31));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (PRO == 1 || PRO == 3) {
+        if constexpr (PRO == 1) {
         const float4 * x4 = (const float4 *) a.x;
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = x4[min(wave + u * WAVES, nchk - 1) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);  // keep the weight loads below behind them
+        }
         const int rc = min(row, a.N - 1);
         const uint8_t * rp = a.W + (size_t) rc * a.w_nb1;
         const uint8_t * rp2 = GLU ? a.W2 + (size_t) rc * a.w_nb1 : nullptr;
@@ -312,6 +329,46 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
             for (int i = tid; i < nvec; i += NT) ((uint4 *) dst)[i] = ((const uint4 *) src)[i];
         } else {
             for (int i = tid; i < nwords; i += NT) dst[i] = src[i];
+        }
+    } else if constexpr (PRO == 3) {
+        act * yl = (act *) smem;
+        const int S = a.fa_splits, hsel = lane >> 5, d0 = 4 * (lane & 31);
+        constexpr float LOG2E = 1.4426950408889634f;
+        for (int b0 = wave; b0 < nchk; b0 += WAVES) {
+            const float * rec0 = a.fa_part + (size_t) (2 * b0 + hsel) * S * FA_REC;
+            if (b0 != wave) {
+#pragma unroll
+                for (int sidx = 0; sidx < 16; ++sidx) fml[sidx] = *(const float2 *) (rec0 + (size_t) min(sidx, S - 1) * FA_REC + 128);
+#pragma unroll
+                for (int sidx = 0; sidx < 12; ++sidx) fr[sidx] = *(const float4 *) (rec0 + (size_t) min(sidx, S - 1) * FA_REC + d0);
+            }
+            // softmax merge of the splits, in split order (k_fattn_combine's arithmetic; records are in the natural-log domain)
+            float mn = -INFINITY;
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx) if (sidx < S) mn = fmaxf(mn, fml[sidx].x);
+            float cs[16], lt = 0.0f;
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx) {
+                cs[sidx] = (sidx < S && fml[sidx].x != -INFINITY) ? __builtin_amdgcn_exp2f((fml[sidx].x - mn) * LOG2E) : 0.0f;
+                lt += sidx < S ? fml[sidx].y * cs[sidx] : 0.0f;
+            }
+            float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int sidx = 0; sidx < 12; ++sidx)
+                if (sidx < S && cs[sidx] != 0.0f) { acc4.x += fr[sidx].x * cs[sidx]; acc4.y += fr[sidx].y * cs[sidx]; acc4.z += fr[sidx].z * cs[sidx]; acc4.w += fr[sidx].w * cs[sidx]; }
+            if (S > 12) {  // (fattn_fat_splits() never asks for more than 12; kept for callers that pass their own count)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) fr[sidx] = *(const float4 *) (rec0 + (size_t) min(12 + sidx, S - 1) * FA_REC + d0);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx)
+                    if (12 + sidx < S && cs[12 + sidx] != 0.0f) { acc4.x += fr[sidx].x * cs[12 + sidx]; acc4.y += fr[sidx].y * cs[12 + sidx]; acc4.z += fr[sidx].z * cs[12 + sidx]; acc4.w += fr[sidx].w * cs[12 + sidx]; }
+            }
+            const float il = 1.0f / lt;
+            float t[4] = {acc4.x * il, acc4.y * il, acc4.z * il, acc4.w * il};
+            // the graph's FLASH_ATTN_EXT result itself, for any other reader (graph.cpp passes null when that tensor is provably dead)
+            if (a.x_out && blockIdx.x == 0) ((float4 *) a.x_out)[b0 * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+            if constexpr (BPC == 1) wave_quantize_q8_K(t, lane, yl + b0);
+            else wave_quantize_q8_0(t, lane, yl + (size_t) b0 * BPC);
         }
     } else {
         // one wave per 256-value chunk: a Q8_K block, or eight Q8_0 blocks (launcher guarantees K % 256 == 0)
@@ -431,10 +488,15 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
     mmvq_args a = a0;
     const int nblk = a.K / T::BLK;
     const bool glu = a.W2 != nullptr;
-    if (a0.x != nullptr) {
+    if (a0.x != nullptr || a0.fa_part != nullptr) {
         if ((a0.K % 256) != 0) {
             MI_ERR("launch_mmvq: the f32 prologue needs K %% 256 == 0 (K = %d)", a0.K);
             abort();
+        }
+        if (a0.fa_part) {
+            if (glu || a0.norm_w || a0.fa_splits < 1 || a0.fa_splits > 16) { MI_ERR("launch_mmvq: bad attention-partials prologue request"); abort(); }
+            launch_stream<T, false, 3>(s, a0);
+            return;
         }
         if (a0.norm_w) { if (glu) launch_stream<T, true, 2>(s, a0); else launch_stream<T, false, 2>(s, a0); }
         else           { if (glu) launch_stream<T, true, 1>(s, a0); else launch_stream<T, false, 1>(s, a0); }

@@ -135,5 +135,90 @@ int main(int argc, char ** argv) {
                us[0], mb / us[0] / 1e6, us[1], mb / us[1] / 1e6, bad, o.N, first);
         fflush(stdout);
     }
+    // ---- fused Q/K/V + rope + cache store (qkv.hip) and decode attention (fattn.hip) in the same kind of dependent chain
+    {
+        const int K = 4096, NQ = 4096, NKV = 1024, HD = 128, NCTX = 2304;
+        uint16_t * kc, * vc; CK(hipMalloc(&kc, (size_t) NCTX * NKV * 2)); CK(hipMalloc(&vc, (size_t) NCTX * NKV * 2));
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, (uint32_t *) kc, (size_t) NCTX * NKV / 2, 5u);
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, (uint32_t *) vc, (size_t) NCTX * NKV / 2, 6u);
+        int32_t hpos = 2100; int64_t hslot = 2100;
+        int32_t * dpos; int64_t * dslot; CK(hipMalloc(&dpos, 4)); CK(hipMalloc(&dslot, 8));
+        CK(hipMemcpy(dpos, &hpos, 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dslot, &hslot, 8, hipMemcpyHostToDevice));
+        for (int tv : {GGML_TYPE_Q4_K, GGML_TYPE_Q6_K}) {
+            const wt ta = WT(GGML_TYPE_Q4_K), tb = WT(tv);
+            const size_t bq = mat_bytes(GGML_TYPE_Q4_K, K, NQ), bk = mat_bytes(GGML_TYPE_Q4_K, K, NKV), bv = mat_bytes(tv, K, NKV);
+            const size_t mb = bq + bk + bv;
+            hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, s, (uint32_t *) pool, pool_bytes / 4, 31u + (uint32_t) tv);
+            hipLaunchKernelGGL(k_fix, dim3((unsigned) ((pool_bytes / ta.bytes + 255) / 256)), dim3(256), 0, s, pool, pool_bytes / ta.bytes, ta.bytes, ta.d_off, ta.dmin);
+            CK(hipStreamSynchronize(s));
+            const int chain = 32;
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            for (int i = 0; i < chain; ++i) {
+                qkv_args a{};
+                const uint8_t * base = pool + (size_t) i * mb;
+                a.seg[0] = {base, (int64_t) (K / 256) * ta.bytes, 0, NQ, nullptr, 1, 0, (char *) ((i & 1) ? xa : xb), 0};
+                a.seg[1] = {base + bq, (int64_t) (K / 256) * ta.bytes, 0, NKV, nullptr, 1, 1, (char *) kc, (int64_t) NKV * 2};
+                a.seg[2] = {base + bq + bk, (int64_t) (K / 256) * tb.bytes, tv == GGML_TYPE_Q4_K ? 0 : 1, NKV, nullptr, 0, 1, (char *) vc, (int64_t) NKV * 2};
+                a.nseg = 3; a.K = K; a.x = (i & 1) ? xb : xa; a.norm_w = nw; a.eps = 1e-5f; a.norm_out = nullptr;
+                a.head_dim = HD; a.neox = 0; a.pos = dpos; a.freq_factors = nullptr;
+                rope_params rp{HD, 0, 8192, 500000.0f, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f, {0, 0, 0, 0}};
+                rope_host_consts(rp, a.theta_scale, a.corr0, a.corr1);
+                a.freq_scale = 1.0f; a.ext_factor = 0.0f; a.attn_factor = 1.0f; a.slot = dslot;
+                launch_qkv(s, a, GGML_TYPE_Q4_K, tv);
+            }
+            CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+            CK(hipEventRecord(e0, s));
+            for (int r = 0; r < 10; ++r) CK(hipGraphLaunch(ge, s));
+            CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / 10 / chain;
+            printf("qkv+rope+store q4_K/%s 4096 -> 4096+1024+1024  %7.1f MB | %7.2f us %5.2f TB/s\n", tv == GGML_TYPE_Q4_K ? "q4_K" : "q6_K", mb / 1048576.0, us, mb / us / 1e6);
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+            hipLaunchKernelGGL(k_fillf, dim3((VMAX + 255) / 256), dim3(256), 0, s, xa, VMAX, 1u);
+            hipLaunchKernelGGL(k_fillf, dim3((VMAX + 255) / 256), dim3(256), 0, s, xb, VMAX, 2u);
+        }
+        // attention: q [128, 1, 32] f32 (written by the previous launch of the chain), K/V f16 views [128, n_kv, 8]
+        for (int n_kv : {2304, 8192}) {
+            uint16_t * kc2, * vc2; CK(hipMalloc(&kc2, (size_t) n_kv * NKV * 2 * 8)); CK(hipMalloc(&vc2, (size_t) n_kv * NKV * 2 * 8));
+            hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, (uint32_t *) kc2, (size_t) n_kv * NKV * 8 / 2, 7u);
+            hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, (uint32_t *) vc2, (size_t) n_kv * NKV * 8 / 2, 8u);
+            uint16_t * mask; CK(hipMalloc(&mask, (size_t) n_kv * 64 * 2)); CK(hipMemset(mask, 0, (size_t) n_kv * 64 * 2));
+            void * ws; CK(hipMalloc(&ws, 64u << 20));
+            for (int splits : {0, 16, 32, 64}) {
+                const int chain = 8;
+                hipGraph_t g; hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+                for (int i = 0; i < chain; ++i) {
+                    tdesc q{(char *) ((i & 1) ? xb : xa), {HD, 1, 32, 1}, {4, HD * 32 * 4, HD * 4, HD * 32 * 4}, GGML_TYPE_F32};
+                    tdesc k{(char *) (kc2 + (size_t) i * n_kv * NKV), {HD, n_kv, 8, 1}, {2, NKV * 2, HD * 2, (int64_t) n_kv * NKV * 2}, GGML_TYPE_F16};
+                    tdesc v{(char *) (vc2 + (size_t) i * n_kv * NKV), {HD, n_kv, 8, 1}, {2, NKV * 2, HD * 2, (int64_t) n_kv * NKV * 2}, GGML_TYPE_F16};
+                    tdesc m{(char *) mask, {n_kv, 64, 1, 1}, {2, (int64_t) n_kv * 2, (int64_t) n_kv * 128, (int64_t) n_kv * 128}, GGML_TYPE_F16};
+                    tdesc d{(char *) ((i & 1) ? xa : xb), {HD, 32, 1, 1}, {4, HD * 4, HD * 32 * 4, HD * 32 * 4}, GGML_TYPE_F32};
+                    fattn_params p{};
+                    p.scale = 0.0883883f; p.max_bias = 0.0f; p.logit_softcap = 0.0f; p.kv_type = GGML_TYPE_F16;
+                    p.n_splits = splits ? splits : fattn_pick_splits(q, k);
+                    launch_flash_attn(s, q, k, v, &m, nullptr, d, p, ws);
+                }
+                CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+                CK(hipEventRecord(e0, s));
+                for (int r = 0; r < 10; ++r) CK(hipGraphLaunch(ge, s));
+                CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                const double us = ms * 1e3 / 10 / chain, mbv = (double) n_kv * NKV * 2 * 2 / 1048576.0;
+                tdesc q0{(char *) xa, {HD, 1, 32, 1}, {4, HD * 32 * 4, HD * 4, HD * 32 * 4}, GGML_TYPE_F32};
+                tdesc k0{(char *) kc2, {HD, n_kv, 8, 1}, {2, NKV * 2, HD * 2, (int64_t) n_kv * NKV * 2}, GGML_TYPE_F16};
+                printf("attention d128 32/8 heads n_kv=%5d splits=%2d (split + combine launches)  %6.1f MB | %7.2f us %5.2f TB/s\n", n_kv, splits ? splits : fattn_pick_splits(q0, k0), mbv, us, mbv * 1.048576 / us);
+                CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+                hipLaunchKernelGGL(k_fillf, dim3((VMAX + 255) / 256), dim3(256), 0, s, xa, VMAX, 1u);
+                hipLaunchKernelGGL(k_fillf, dim3((VMAX + 255) / 256), dim3(256), 0, s, xb, VMAX, 2u);
+            }
+            CK(hipFree(kc2)); CK(hipFree(vc2)); CK(hipFree(mask)); CK(hipFree(ws));
+        }
+    }
     return 0;
 }

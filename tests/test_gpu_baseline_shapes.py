@@ -346,3 +346,59 @@ def test_deferred_norm_result_is_still_written(backend, H, plog):
     assert res[False][2] == 1, "norm was not folded into the mat-vec launch"
     T.compare("lm_head over deferred norm", res[False][0], res[True][0], max_nmse=1e-10, log=plog)
     T.compare("result_norm read behind the fused launch", res[False][1], res[True][1], max_nmse=1e-12, log=plog)
+
+
+# ------------------------------------------------------------------------------------------------ attention merged in wo's prologue
+@pytest.mark.parametrize("NH,NKV,n_kv,n_vis,wt", [(32, 8, 2304, 2100, L.Q4_K), (32, 8, 2304, 2304, L.Q6_K), (28, 4, 8192, 8000, L.Q5_K), (64, 8, 1280, 1031, L.Q4_K),
+                                                   (32, 8, 256, 17, L.Q4_K), (8, 4, 4352, 4300, L.Q8_0), (32, 8, 33 * 256, 8400, L.Q4_K)])
+def test_decode_attention_merged_in_wo_prologue(backend, H, plog, NH, NKV, n_kv, n_vis, wt):
+    """One decode token: FLASH_ATTN_EXT -> reshape -> wo MUL_MAT -> + residual, with option fa_wo = 1: the attention runs as a few
+    fat splits (8-wave workgroups) and the merge of their partial records is the prologue of the wo mat-vec: two launches, no
+    combine pass.  Gates: the
+    attention tensor itself (still written, for any other reader) like every FLASH_ATTN_EXT; the mat-vec result against the
+    oracle fed the ORACLE's attention within the f16-accumulation band of the CPU's attention, and against the unfused GPU path."""
+    rng = np.random.default_rng(_seed(NH, NKV, n_kv, wt))
+    HD, EK, E = 128, NKV * 128, NH * 128
+    q = rng.standard_normal((1, NH, HD)).astype(np.float32)
+    kc = (rng.standard_normal((n_kv, EK)) * 0.5).astype(np.float16)
+    vc = (rng.standard_normal((n_kv, EK)) * 0.5).astype(np.float16)
+    mask = np.full((64, n_kv), -np.inf, np.float16)
+    mask[0, :n_vis] = 0
+    wo = T.rand_weight(wt, E, E, rng)
+    res = rng.standard_normal((1, E)).astype(np.float32)
+
+    def build(g):
+        qq = H.ggml_permute(g.ctx, g.new(L.F32, [HD, NH, 1], q), 0, 2, 1, 3)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [EK, n_kv], kc), HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [EK, n_kv], vc), HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        fa = H.ggml_flash_attn_ext(g.ctx, qq, k, v, g.new(L.F16, [n_kv, 64], mask), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(fa, 10)
+        y = H.ggml_mul_mat(g.ctx, g.new(wt, [E, E], wo), H.ggml_reshape_2d(g.ctx, fa, E, 1))
+        return fa, H.ggml_add(g.ctx, y, g.new(L.F32, [E, 1], res))
+
+    def run(target):
+        g = T.G(target)
+        try:
+            fa, out = build(g)
+            k0 = backend.stat("kernel_launches")
+            r = g.compute([out], NT)
+            return r[0], g.read(fa), backend.stat("kernel_launches") - k0
+        finally:
+            g.free()
+
+    y_o, fa_o, _ = run("oracle")
+    y_u, fa_u, launches_u = run(backend)
+    backend.set_option("fa_wo", 1)  # (off by default: measured slower than thin splits + combine — DESIGN.md §4)
+    try:
+        y_g, fa_g, launches = run(backend)
+    finally:
+        backend.set_option("fa_wo", 0)
+    _log(plog, f"attention->wo heads={NH}/{NKV} n_kv={n_kv} visible={n_vis} wo={QNAME[wt]}: {launches} launches merged, {launches_u} unmerged")
+    assert launches == 2 and launches_u == 3
+    exact = _attention_f64(q[0], kc, vc, n_vis, NH, NKV, HD)
+    e_gpu, e_cpu = T.nmse(np.asarray(fa_g).reshape(NH, HD), exact), T.nmse(np.asarray(fa_o).reshape(NH, HD), exact)
+    assert e_gpu <= 1e-9 and e_gpu <= e_cpu  # the attention tensor left behind by the merged path
+    T.compare(f"attention->wo merged: attention tensor heads={NH}/{NKV} n_kv={n_kv}", fa_g, fa_u, max_nmse=1e-11, log=plog)
+    # mat-vec result: the merged and the unmerged GPU paths see attention values that differ by f32 summation order only
+    T.compare(f"attention->wo merged vs unmerged heads={NH}/{NKV} n_kv={n_kv} wo={QNAME[wt]}", y_g, y_u, max_nmse=1e-6, log=plog)
+    T.compare(f"attention->wo merged vs oracle heads={NH}/{NKV} n_kv={n_kv} wo={QNAME[wt]}", y_g, y_o, max_nmse=max(2e-4, 3.0 * e_cpu), log=plog)
