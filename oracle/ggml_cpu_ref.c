@@ -395,6 +395,141 @@ float oracle_vec_dot_q6_K_q8_K(int64_t n, const block_q6_K * x, const block_q8_K
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* FAST block dots — bench.py's cpu_baseline leg ONLY (oracle_set_fast(1)); never the checker.  */
+/* The generic routines above are what ggml-cpu computes on a machine without SIMD; a host of   */
+/* llama-box runs ggml-cpu's x86 kernels (arch/x86/quants.c), whose published AVX2 algorithm is  */
+/* restated here so that the CPU number beside the GPU's is a credible one: vpmaddubsw/vpmaddwd  */
+/* integer dots (the same integers: tests check the sums bit for bit on unit scales), eight       */
+/* float lanes accumulated with FMA and summed at the end (a different f32 order than generic).   */
+/* ------------------------------------------------------------------------------------------ */
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+static inline float hsum8(__m256 v) {
+    __m128 r = _mm_add_ps(_mm256_castps256_ps128(v), _mm256_extractf128_ps(v, 1));
+    r = _mm_add_ps(r, _mm_movehl_ps(r, r));
+    r = _mm_add_ss(r, _mm_movehdup_ps(r));
+    return _mm_cvtss_f32(r);
+}
+static inline __m256i bcast16(int i) { return _mm256_set1_epi16((short) (((2 * i + 1) << 8) | (2 * i))); } /* pshufb mask: word i everywhere */
+static float fast_vec_dot_k45(int64_t n, const uint8_t * xb, size_t xstride, int is5, const block_q8_K * y) {
+    const int64_t nb = n / QK_K;
+    const __m256i m4 = _mm256_set1_epi8(0xF);
+    __m256 acc = _mm256_setzero_ps();
+    __m128 acc_m = _mm_setzero_ps();
+    for (int64_t i = 0; i < nb; ++i) {
+        const uint8_t * blk = xb + (size_t) i * xstride;
+        ggml_fp16_t hd, hdmin;
+        memcpy(&hd, blk, 2);
+        memcpy(&hdmin, blk + 2, 2);
+        const float d = y[i].d * F16(hd), dmin = -y[i].d * F16(hdmin);
+        uint32_t ut[4];
+        memcpy(ut, blk + 4, 12);
+        ut[3] = ((ut[2] >> 4) & 0x0f0f0f0fu) | (((ut[1] >> 6) & 0x03030303u) << 4);
+        const uint32_t uaux = ut[1] & 0x3f3f3f3fu;
+        ut[1] = (ut[2] & 0x0f0f0f0fu) | (((ut[0] >> 6) & 0x03030303u) << 4);
+        ut[2] = uaux;
+        ut[0] &= 0x3f3f3f3fu; /* bytes 0..7: the eight scales, 8..15: the eight mins */
+        const __m256i ms = _mm256_cvtepu8_epi16(_mm_set_epi32((int) ut[3], (int) ut[2], (int) ut[1], (int) ut[0]));
+        const __m256i q8sums = _mm256_loadu_si256((const __m256i *) y[i].bsums);
+        const __m128i q8s = _mm_hadd_epi16(_mm256_extracti128_si256(q8sums, 0), _mm256_extracti128_si256(q8sums, 1));
+        const __m128i prod = _mm_madd_epi16(_mm256_extracti128_si256(ms, 1), q8s);
+        acc_m = _mm_fmadd_ps(_mm_set1_ps(dmin), _mm_cvtepi32_ps(prod), acc_m);
+        const __m128i sc128 = _mm256_extracti128_si256(ms, 0);
+        const __m256i scales = _mm256_set_m128i(sc128, sc128);
+        const uint8_t * q4 = is5 ? blk + 48 : blk + 16;
+        const __m256i hbits = is5 ? _mm256_loadu_si256((const __m256i *) (blk + 16)) : _mm256_setzero_si256();
+        const int8_t * q8 = y[i].qs;
+        __m256i sumi = _mm256_setzero_si256();
+        for (int j = 0; j < QK_K / 64; ++j) {
+            const __m256i scale_l = _mm256_shuffle_epi8(scales, bcast16(2 * j)), scale_h = _mm256_shuffle_epi8(scales, bcast16(2 * j + 1));
+            const __m256i q4bits = _mm256_loadu_si256((const __m256i *) q4);
+            q4 += 32;
+            __m256i ql = _mm256_and_si256(q4bits, m4), qh = _mm256_and_si256(_mm256_srli_epi16(q4bits, 4), m4);
+            if (is5) {
+                const __m256i one = _mm256_set1_epi8(1);
+                ql = _mm256_or_si256(ql, _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(hbits, 2 * j), one), 4));
+                qh = _mm256_or_si256(qh, _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(hbits, 2 * j + 1), one), 4));
+            }
+            const __m256i q8l = _mm256_loadu_si256((const __m256i *) q8), q8h = _mm256_loadu_si256((const __m256i *) (q8 + 32));
+            q8 += 64;
+            const __m256i pl = _mm256_madd_epi16(scale_l, _mm256_maddubs_epi16(ql, q8l));
+            const __m256i ph = _mm256_madd_epi16(scale_h, _mm256_maddubs_epi16(qh, q8h));
+            sumi = _mm256_add_epi32(sumi, _mm256_add_epi32(pl, ph));
+        }
+        acc = _mm256_fmadd_ps(_mm256_set1_ps(d), _mm256_cvtepi32_ps(sumi), acc);
+    }
+    acc_m = _mm_add_ps(acc_m, _mm_movehl_ps(acc_m, acc_m));
+    acc_m = _mm_add_ss(acc_m, _mm_movehdup_ps(acc_m));
+    return hsum8(acc) + _mm_cvtss_f32(acc_m);
+}
+static float fast_vec_dot_q6_K_q8_K(int64_t n, const block_q6_K * x, const block_q8_K * y) {
+    const int64_t nb = n / QK_K;
+    const __m256i m4 = _mm256_set1_epi8(0xF), m2 = _mm256_set1_epi8(3);
+    __m256 acc = _mm256_setzero_ps();
+    for (int64_t i = 0; i < nb; ++i) {
+        const float d = y[i].d * F16(x[i].d);
+        const uint8_t * q4 = x[i].ql;
+        const uint8_t * qh = x[i].qh;
+        const int8_t * q8 = y[i].qs;
+        /* sum (q - 32) y = sum q y - 32 sum y: the second term from the 16-value sums of the activation block */
+        const __m256i sc16 = _mm256_cvtepi8_epi16(_mm_loadu_si128((const __m128i *) x[i].scales));
+        const __m256i off = _mm256_madd_epi16(sc16, _mm256_loadu_si256((const __m256i *) y[i].bsums));
+        __m256i sumi = _mm256_setzero_si256();
+        for (int j = 0; j < QK_K / 128; ++j) {
+            const __m256i b1 = _mm256_loadu_si256((const __m256i *) q4), b2 = _mm256_loadu_si256((const __m256i *) (q4 + 32)), bh = _mm256_loadu_si256((const __m256i *) qh);
+            q4 += 64;
+            qh += 32;
+            const __m256i q[4] = {
+                _mm256_or_si256(_mm256_and_si256(b1, m4), _mm256_slli_epi16(_mm256_and_si256(bh, m2), 4)),
+                _mm256_or_si256(_mm256_and_si256(b2, m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(bh, 2), m2), 4)),
+                _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(b1, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(bh, 4), m2), 4)),
+                _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(b2, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(bh, 6), m2), 4)),
+            };
+            for (int k = 0; k < 4; ++k) {
+                /* 32 values: scale 8j + 2k for the first 16, 8j + 2k + 1 for the next 16 (words 0..7 / 8..15 after vpmaddubsw) */
+                const int is = 8 * j + 2 * k;
+                const __m256i sc = _mm256_set_m128i(_mm_set1_epi16(x[i].scales[is + 1]), _mm_set1_epi16(x[i].scales[is]));
+                const __m256i p = _mm256_maddubs_epi16(q[k], _mm256_loadu_si256((const __m256i *) q8));
+                q8 += 32;
+                sumi = _mm256_add_epi32(sumi, _mm256_madd_epi16(sc, p));
+            }
+        }
+        sumi = _mm256_sub_epi32(sumi, _mm256_slli_epi32(off, 5));
+        acc = _mm256_fmadd_ps(_mm256_set1_ps(d), _mm256_cvtepi32_ps(sumi), acc);
+    }
+    return hsum8(acc);
+}
+static float fast_vec_dot_q8_0_q8_0(int64_t n, const block_q8_0 * x, const block_q8_0 * y) {
+    const int64_t nb = n / QK8_0;
+    __m256 acc = _mm256_setzero_ps();
+    const __m256i ones = _mm256_set1_epi16(1);
+    for (int64_t i = 0; i < nb; ++i) {
+        const __m256i qx = _mm256_loadu_si256((const __m256i *) x[i].qs), qy = _mm256_loadu_si256((const __m256i *) y[i].qs);
+        const __m256i p = _mm256_madd_epi16(ones, _mm256_maddubs_epi16(_mm256_sign_epi8(qx, qx), _mm256_sign_epi8(qy, qx)));
+        acc = _mm256_fmadd_ps(_mm256_set1_ps(F16(x[i].d) * F16(y[i].d)), _mm256_cvtepi32_ps(p), acc);
+    }
+    return hsum8(acc);
+}
+#define ORACLE_HAVE_FAST 1
+#else
+#define ORACLE_HAVE_FAST 0
+#endif
+static int g_fast = 0;
+int oracle_set_fast(int on) { g_fast = (on && ORACLE_HAVE_FAST) ? 1 : 0; return g_fast; }
+float oracle_fast_vec_dot(enum ggml_type type, int64_t n, const void * x, const void * y) {
+#if ORACLE_HAVE_FAST
+    switch (type) {
+        case GGML_TYPE_Q4_K: return fast_vec_dot_k45(n, (const uint8_t *) x, sizeof(block_q4_K), 0, (const block_q8_K *) y);
+        case GGML_TYPE_Q5_K: return fast_vec_dot_k45(n, (const uint8_t *) x, sizeof(block_q5_K), 1, (const block_q8_K *) y);
+        case GGML_TYPE_Q6_K: return fast_vec_dot_q6_K_q8_K(n, (const block_q6_K *) x, (const block_q8_K *) y);
+        case GGML_TYPE_Q8_0: return fast_vec_dot_q8_0_q8_0(n, (const block_q8_0 *) x, (const block_q8_0 *) y);
+        default: break;
+    }
+#endif
+    return NAN;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* helpers                                                                                      */
 /* ------------------------------------------------------------------------------------------ */
 #define TDATA(t) ((char *) (t)->data)
@@ -487,10 +622,13 @@ static enum ggml_status op_mul_mat(struct ggml_tensor * dst, int nth) {
                 for (int64_t i = 0; i < ne00; ++i) s += (ggml_float) (F16(x[i]) * F16(y[i]));
                 *d = (float) s;
             } break;
-            case GGML_TYPE_Q8_0: *d = oracle_vec_dot_q8_0_q8_0(ne00, (const block_q8_0 *) a, (const block_q8_0 *) w); break;
-            case GGML_TYPE_Q4_K: *d = oracle_vec_dot_q4_K_q8_K(ne00, (const block_q4_K *) a, (const block_q8_K *) w); break;
-            case GGML_TYPE_Q5_K: *d = oracle_vec_dot_q5_K_q8_K(ne00, (const block_q5_K *) a, (const block_q8_K *) w); break;
-            case GGML_TYPE_Q6_K: *d = oracle_vec_dot_q6_K_q8_K(ne00, (const block_q6_K *) a, (const block_q8_K *) w); break;
+            case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: case GGML_TYPE_Q6_K:
+                if (g_fast) { *d = oracle_fast_vec_dot(src0->type, ne00, a, w); break; }  /* (cpu_baseline timing leg only) */
+                if (src0->type == GGML_TYPE_Q8_0) *d = oracle_vec_dot_q8_0_q8_0(ne00, (const block_q8_0 *) a, (const block_q8_0 *) w);
+                else if (src0->type == GGML_TYPE_Q4_K) *d = oracle_vec_dot_q4_K_q8_K(ne00, (const block_q4_K *) a, (const block_q8_K *) w);
+                else if (src0->type == GGML_TYPE_Q5_K) *d = oracle_vec_dot_q5_K_q8_K(ne00, (const block_q5_K *) a, (const block_q8_K *) w);
+                else *d = oracle_vec_dot_q6_K_q8_K(ne00, (const block_q6_K *) a, (const block_q8_K *) w);
+                break;
             default: abort();
         }
     }

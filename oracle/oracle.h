@@ -41,6 +41,10 @@ int oracle_max_threads(void);
 /* 0 = generic ggml-cpu; 1 / 2 / 3 = one-ulp sensitivity probes for the tests (reversed block order, f32 RMS_NORM sum,
  * expf one ulp up / down) — see ggml_cpu_ref.c */
 void oracle_set_variant(int v);
+/* bench.py cpu_baseline ONLY: route the quantised block dots of MUL_MAT through the AVX2 restatement of ggml-cpu's x86 kernels
+ * (same integers, another f32 accumulation order).  Returns the state actually set (0 when built without AVX2+FMA). */
+int oracle_set_fast(int on);
+float oracle_fast_vec_dot(enum ggml_type type, int64_t n, const void * x, const void * y);
 
 #ifdef __cplusplus
 }

@@ -222,3 +222,50 @@ def test_quantize_q8_K_properties(built, x, scale):
     if d != 0.0:
         err = np.abs(xv.astype(np.float64) - float(d) * qs)
         assert np.all(err <= abs(float(d)) * (0.5 + 1e-6) + abs(float(d)) * (qs == 127))  # (a value rounding to 128 is clamped to 127)
+
+
+def test_fast_block_dots_compute_the_same_integers():
+    """bench.py's cpu_baseline leg times an AVX2 restatement of ggml-cpu's x86 block dots (oracle_set_fast).  It is never the
+    checker, but it must be the same computation: with unit scales every float involved is an exact integer, so the result must
+    EQUAL the generic routine's; with real scales it may differ by f32 accumulation order only."""
+    import ctypes as C
+
+    lib = T.oracle()
+    lib.oracle_fast_vec_dot.restype = C.c_float
+    lib.oracle_fast_vec_dot.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.oracle_set_fast.restype = C.c_int
+    if not lib.oracle_set_fast(1):
+        pytest.skip("oracle built without AVX2 + FMA")
+    lib.oracle_set_fast(0)
+    rng = np.random.default_rng(11)
+    one16 = np.array([1.0], np.float16).view(np.uint8)
+    for qt, name in ((L.Q4_K, "q4_K_q8_K"), (L.Q5_K, "q5_K_q8_K"), (L.Q6_K, "q6_K_q8_K"), (L.Q8_0, "q8_0_q8_0")):
+        gen = getattr(lib, "oracle_vec_dot_" + name)
+        for K in (256, 4096, 14336):
+            for unit in (True, False):
+                w = T.rand_weight(qt, K, 1, rng)[0].copy()
+                x = (rng.standard_normal(K) * 2).astype(np.float32)
+                if qt == L.Q8_0:
+                    y = np.zeros(K // 32 * 34, np.uint8)
+                    lib.oracle_quantize_row_q8_0(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), K)
+                else:
+                    y = np.zeros(K // 256 * 292, np.uint8)
+                    lib.oracle_quantize_row_q8_K(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), K)
+                if unit:
+                    wb = w.reshape(-1, L.TYPE_SIZE[qt])
+                    if qt in (L.Q4_K, L.Q5_K):
+                        wb[:, 0:2] = one16
+                        wb[:, 2:4] = one16
+                    elif qt == L.Q6_K:
+                        wb[:, 208:210] = one16
+                    else:
+                        wb[:, 0:2] = one16
+                        y.reshape(-1, 34)[:, 0:2] = one16
+                    if qt != L.Q8_0:
+                        y.reshape(-1, 292)[:, 0:4] = np.array([1.0], np.float32).view(np.uint8)
+                a = gen(K, w.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+                b = lib.oracle_fast_vec_dot(qt, K, w.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+                if unit and abs(a) < 2 ** 24:
+                    assert a == b, (name, K, a, b)
+                else:
+                    assert abs(a - b) <= 2e-6 * max(1.0, abs(a)) * np.sqrt(K / 256), (name, K, a, b)
