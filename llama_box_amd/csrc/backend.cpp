@@ -40,13 +40,20 @@ static std::once_flag g_reg_once;
 static ggml_guid g_guid = {0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x2d, 0x67, 0x67, 0x6d, 0x6c, 0x2d, 0x62, 0x6b, 0x6e, 0x64};
 
 static device_ctx * dctx(ggml_backend_dev_t dev) { return (device_ctx *) dev->context; }
+int logical_device_count() { return (int) g_reg_ctx.devices.size(); }
+int logical_device_ordinal(int i) { return dctx(g_reg_ctx.devices[(size_t) i])->device; }
+ggml_backend_dev_t logical_device(int i) { return g_reg_ctx.devices[(size_t) i]; }
 
 // ------------------------------------------------------------------------------------------------ buffers
 typedef ggml_backend_buffer_t (*buffer_init_fn)(ggml_backend_buffer_type_t, struct ggml_backend_buffer_i, void *, size_t);
 
 // libggml-base's ggml_backend_buffer_init when we are loaded by a ggml host; own allocation otherwise (the host
 // frees the object with `delete`, both sides share libstdc++'s allocator)
+ggml_backend_buffer_t make_backend_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * context, size_t size);
 static ggml_backend_buffer_t make_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * context, size_t size) {
+    return make_backend_buffer(buft, iface, context, size);
+}
+ggml_backend_buffer_t make_backend_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * context, size_t size) {
     static buffer_init_fn host_fn = (buffer_init_fn) dlsym(RTLD_DEFAULT, "ggml_backend_buffer_init");
     if (host_fn) return host_fn(buft, iface, context, size);
     return new ggml_backend_buffer{iface, buft, context, size, GGML_BACKEND_BUFFER_USAGE_ANY};
@@ -166,6 +173,7 @@ static void be_free(ggml_backend_t be) {
     HIP_CHECK(hipStreamSynchronize(c->stream));
     free_graph_cache(c);
     tp_free(c);
+    free_split_helpers(c);
     if (c->ws) HIP_CHECK(hipFree(c->ws));
     if (c->up_ring) HIP_CHECK(hipHostFree(c->up_ring));
     if (c->fa_lists) HIP_CHECK(hipFree(c->fa_lists));
@@ -313,6 +321,7 @@ static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { 
 static ggml_backend_buffer_type_t dev_get_host_buffer_type(ggml_backend_dev_t dev) { return &dctx(dev)->buft_host; }
 static bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) { return supports_op(op); }
 static bool dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    if (buft_is_split(buft)) return logical_device(split_buft_main_device(buft)) == dev;  // row-split weights: the MAIN device's backend computes on them
     if (buft->iface.get_name != buft_get_name) return false;
     return ((buft_ctx *) buft->context)->device == dctx(dev)->device;
 }
@@ -347,6 +356,8 @@ static int api_tp_init(ggml_backend_t be, int rank, int world, const void * uid,
     return tp_init((backend_ctx *) be->context, rank, world, uid, n);
 }
 static int api_tp_get_unique_id(void * out, size_t n) { return tp_get_unique_id(out, n); }
+static ggml_backend_buffer_type_t api_split_buffer_type(int main_device, const float * tensor_split) { return split_buffer_type(main_device, tensor_split); }
+static void api_split_rows(int64_t nrows, const float * tensor_split, int n_dev, int64_t * row0) { split_rows(nrows, tensor_split, n_dev, 64, row0); }
 static ggml_backend_buffer_type_t api_tp_rowpar_buft(int device) {
     if (device < 0 || device >= (int) g_reg_ctx.devices.size()) return nullptr;
     return &dctx(g_reg_ctx.devices[device])->buft_rowpar;
@@ -426,7 +437,9 @@ static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (n == "ggml_backend_mi355x_set_option") return (void *) api_set_option;
     if (n == "ggml_backend_mi355x_get_stat") return (void *) api_get_stat;
     if (n == "ggml_backend_mi355x_timing_report") return (void *) api_timing_report;
-    return nullptr;  // incl. "ggml_backend_split_buffer_type": hosts treat NULL as "row split unsupported"
+    if (n == "ggml_backend_split_buffer_type") return (void *) api_split_buffer_type;  // -sm row (split.cpp)
+    if (n == "ggml_backend_mi355x_split_rows") return (void *) api_split_rows;
+    return nullptr;
 }
 static const ggml_backend_reg_i k_reg_iface = {reg_get_name, reg_get_device_count, reg_get_device, reg_get_proc_address};
 
@@ -450,7 +463,10 @@ static void init_reg() {
         (void) hipGetLastError();
         n = 0;
     }
-    for (int i = 0; i < n && (int) g_reg_ctx.devices.size() < GGML_MI355X_MAX_DEVICES; ++i) {
+    // GGML_MI355X_FAKE_DEVICES=N: N logical devices per physical one (tests of the multi-device paths on a single-GPU box)
+    const int fake = getenv("GGML_MI355X_FAKE_DEVICES") ? std::max(1, atoi(getenv("GGML_MI355X_FAKE_DEVICES"))) : 1;
+    for (int ii = 0; ii < n * fake && (int) g_reg_ctx.devices.size() < GGML_MI355X_MAX_DEVICES; ++ii) {
+        const int i = ii / fake;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {

@@ -86,7 +86,8 @@ struct stats {
     int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)
 };
 
-struct tp_state;  // tp.cpp
+struct tp_state;      // tp.cpp
+struct split_helper;  // split.cpp
 
 struct cached_graph {
     hipGraph_t graph = nullptr;
@@ -120,6 +121,8 @@ struct backend_ctx {
     bool capturing = false;
     // tensor parallel
     tp_state * tp = nullptr;
+    // -sm row: per owning device a stream / scratch / event for the slices of row-split weights (split.cpp), created on first use
+    std::vector<split_helper *> split_helpers;
     // small host->device uploads (token ids, positions, cache indices, one mask row): staged in a pinned ring and moved by a
     // tiny kernel — a blit through hipMemcpyAsync costs ~25 us of stream time per copy, five of them per decode step
     char * up_ring = nullptr;
@@ -162,6 +165,27 @@ struct buffer_ctx {
 };
 bool buffer_is_ours(ggml_backend_buffer_t b);
 bool buffer_is_rowpar(ggml_backend_buffer_t b);
+ggml_backend_buffer_t make_backend_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * context, size_t size);
+int logical_device_count();                 // devices of the registration (GGML_MI355X_FAKE_DEVICES multiplies them for tests)
+int logical_device_ordinal(int i);          // HIP ordinal behind logical device i
+ggml_backend_dev_t logical_device(int i);
+
+// ---- row-split weight buffers, -sm row (split.cpp) ----
+struct split_tensor_info {
+    int n_dev;
+    int64_t row0[GGML_MI355X_MAX_DEVICES + 1];  // device d owns rows [row0[d], row0[d + 1])
+    void * slice[GGML_MI355X_MAX_DEVICES];      // its rows, GGUF bytes verbatim, in device d's memory
+    size_t row_bytes;
+};
+void split_rows(int64_t nrows, const float * tensor_split, int n_dev, int64_t granule, int64_t * row0);
+ggml_backend_buffer_type_t split_buffer_type(int main_device, const float * tensor_split);
+bool buft_is_split(ggml_backend_buffer_type_t buft);
+int split_buft_main_device(ggml_backend_buffer_type_t buft);
+bool buffer_is_split(ggml_backend_buffer_t b);
+const split_tensor_info * split_info(const ggml_tensor * t);
+bool split_mul_mat_supported(const ggml_tensor * op);
+bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor * b, ggml_tensor * dst);
+void free_split_helpers(backend_ctx * c);
 
 // ---- graph execution (graph.cpp) ----
 bool supports_op(const ggml_tensor * op);

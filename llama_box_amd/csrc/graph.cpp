@@ -34,6 +34,7 @@ bool supports_op(const ggml_tensor * op) {
             return true;
         case GGML_OP_MUL_MAT: {
             if (!a || !b || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(op)) return false;
+            if (buffer_is_split(a->buffer)) return split_mul_mat_supported(op);  // -sm row weights: every device computes its rows (split.cpp)
             if (is_quant(a->type)) {
                 return a->ne[2] == 1 && a->ne[3] == 1 && rows_contig(a) && b->nb[0] == 4 && a->ne[0] % ggml_abi_blck_size(a->type) == 0;
             }
@@ -1040,6 +1041,10 @@ static int run_node(exec_state & st, int i) {
                 c->st.kernel_launches++;
                 return 1;
             }
+            if (buffer_is_split(a->buffer)) {  // row-split weights (-sm row): broadcast, per-device rows, gather — no fusion with neighbours
+                if (!run_split_mul_mat(c, a, b, n)) return -1;
+                return 1;
+            }
             const bool rowpar = tp_active(c) && buffer_is_rowpar(a->view_src ? a->view_src->buffer : a->buffer);
             const int64_t M = b->ne[1] * b->ne[2] * b->ne[3];
             if (fuse && c->opt.qkv && !rowpar && M == 1 && try_fuse_qkv(st, i)) return 1;
@@ -1357,7 +1362,9 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     const ws_plan wp = plan_ws(c, g);
     if (!ensure_ws(c, wp.act_bytes + wp.aux_bytes + 256)) return GGML_STATUS_ALLOC_FAILED;
     c->tick++;
-    const bool want_graph = c->opt.graphs && !c->opt.timing && g->n_nodes >= 8;
+    bool has_split = false;  // multi-device launches + peer copies: executed eagerly (capture across devices is left for a box that has them)
+    for (int i = 0; i < g->n_nodes && !has_split; ++i) has_split = g->nodes[i]->op == GGML_OP_MUL_MAT && buffer_is_split(g->nodes[i]->src[0]->buffer);
+    const bool want_graph = c->opt.graphs && !c->opt.timing && g->n_nodes >= 8 && !has_split;
     if (!want_graph) {
         c->st.eager_graphs++;
         return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;

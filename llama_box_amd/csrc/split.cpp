@@ -1,0 +1,291 @@
+// split.cpp — "ggml_backend_split_buffer_type": the row-split weight buffer of `-sm row --tensor-split a,b,c,...`, one process
+// driving N MI355X.
+//
+// How it is reached: llama-box parses -sm row (/root/reference/llama-box/engine_param.hpp:902-916) and -ts
+// (:821-842) into llama.cpp's model params; llama.cpp then asks the backend registry of the main GPU for the proc address
+// "ggml_backend_split_buffer_type" and calls it with (main_device, tensor_split[]).  Mat-mul weights are allocated in the buffer
+// type it returns; every other tensor (activations, KV cache) stays in the main device's ordinary buffer, and the graph is
+// computed by the MAIN device's backend alone.  So the contract is upstream's row split, not a Megatron layout: a weight
+// [K, N] is cut by ROWS (output features) in the given proportions, device d owns rows [row0[d], row0[d+1]), and a MUL_MAT on
+// it is: broadcast the activations, every device computes its rows, the row ranges are gathered into the main device's dst.  No
+// reduction is involved (rows are independent), so results are bit-identical to the single-device kernels.
+//
+// MI355X-first choices: slices live in per-device hipMalloc allocations made at init_tensor time (GGUF bytes verbatim: the
+// kernels address a slice exactly like a whole tensor); the exchange is P2P over xGMI — hipMemcpyPeerAsync on the owning device's
+// stream, ordered by events against the main stream — 16 KB of activations out and N_d floats back per device for a decode token;
+// each device runs the same hand-written mat-vec kernels (mmvq.hip) on its slice.  Honest limit, stated in DESIGN.md §6: with the
+// KV cache and attention pinned to the main device by the host, this interface cannot reach the >= 3.5x decode target — the
+// one-process-per-GPU tensor-parallel form (tp.cpp: sharded heads, two all-reduces per layer) is the scaling path; this one
+// exists so that `-sm row` WORKS through the reference's own interface.
+// GGML_MI355X_FAKE_DEVICES=N registers N logical devices on every physical one: the tests exercise the whole split path (placement,
+// scatter/gather, multi-stream execution) on a single-GPU box.
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+// rows [row0[d], row0[d+1]) of an nrows-row tensor go to device d: cumulative proportions (all-zero or missing = even), boundaries
+// rounded down to `granule` rows (upstream rounds to its mat-mul tile height; here 64 keeps rotary pairs, heads' halves and the
+// 16-row work units of the mat-vec kernels together), the last device takes the remainder
+void split_rows(int64_t nrows, const float * tensor_split, int n_dev, int64_t granule, int64_t * row0) {
+    double total = 0.0;
+    for (int d = 0; d < n_dev; ++d) total += tensor_split ? std::max(0.0f, tensor_split[d]) : 0.0f;
+    double cum = 0.0;
+    for (int d = 0; d < n_dev; ++d) {
+        const double frac = total > 0.0 ? cum / total : (double) d / n_dev;
+        int64_t r = (int64_t) (frac * (double) nrows);
+        r -= r % granule;
+        row0[d] = std::min(std::max<int64_t>(r, d ? row0[d - 1] : 0), nrows);
+        cum += tensor_split && total > 0.0 ? std::max(0.0f, tensor_split[d]) : 0.0;
+    }
+    row0[0] = 0;
+    row0[n_dev] = nrows;
+}
+
+struct split_buft_ctx {
+    int main_device = 0;  // logical device index
+    int n_dev = 0;
+    float split[GGML_MI355X_MAX_DEVICES] = {0};
+    std::string name;
+};
+struct split_buffer_ctx {
+    split_buft_ctx * bt = nullptr;
+    std::unordered_map<const ggml_tensor *, split_tensor_info> tensors;
+};
+
+static void sbuf_free(ggml_backend_buffer_t b) {
+    split_buffer_ctx * c = (split_buffer_ctx *) b->context;
+    for (auto & kv : c->tensors)
+        for (int d = 0; d < kv.second.n_dev; ++d)
+            if (kv.second.slice[d]) {
+                HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+                HIP_CHECK(hipFree(kv.second.slice[d]));
+            }
+    delete c;
+}
+static void * sbuf_get_base(ggml_backend_buffer_t) { return (void *) 0x1000; }  // never dereferenced (as upstream's split buffer)
+static enum ggml_status sbuf_init_tensor(ggml_backend_buffer_t b, ggml_tensor * t) {
+    split_buffer_ctx * c = (split_buffer_ctx *) b->context;
+    if (t->view_src != nullptr || !ggml_abi_is_contiguous(t) || t->ne[2] != 1 || t->ne[3] != 1) {
+        MI_ERR("split buffer: tensor '%s' is a view / not a contiguous matrix", t->name);
+        return GGML_STATUS_FAILED;
+    }
+    split_tensor_info info{};
+    info.n_dev = c->bt->n_dev;
+    info.row_bytes = ggml_abi_row_size(t->type, t->ne[0]);
+    split_rows(t->ne[1], c->bt->split, info.n_dev, 64, info.row0);
+    for (int d = 0; d < info.n_dev; ++d) {
+        const int64_t rows = info.row0[d + 1] - info.row0[d];
+        if (rows <= 0) continue;
+        HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+        if (hipMalloc(&info.slice[d], (size_t) rows * info.row_bytes + 256) != hipSuccess) {
+            (void) hipGetLastError();
+            MI_ERR("split buffer: allocating %lld rows of '%s' on device %d failed", (long long) rows, t->name, d);
+            return GGML_STATUS_ALLOC_FAILED;
+        }
+    }
+    c->tensors[t] = info;
+    return GGML_STATUS_SUCCESS;
+}
+static const split_tensor_info * find(ggml_backend_buffer_t b, const ggml_tensor * t) {
+    split_buffer_ctx * c = (split_buffer_ctx *) b->context;
+    auto it = c->tensors.find(t);
+    return it == c->tensors.end() ? nullptr : &it->second;
+}
+// whole tensors only, like upstream's split buffer (the loader writes a tensor in one call)
+static void sbuf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t offset, size_t size) {
+    const split_tensor_info * info = find(b, t);
+    if (!info || offset != 0 || size != ggml_abi_nbytes(t)) {
+        MI_ERR("split buffer: set_tensor of '%s' must cover the whole tensor", t->name);
+        abort();
+    }
+    for (int d = 0; d < info->n_dev; ++d) {
+        const int64_t rows = info->row0[d + 1] - info->row0[d];
+        if (rows <= 0) continue;
+        HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+        HIP_CHECK(hipMemcpy(info->slice[d], (const char *) data + (size_t) info->row0[d] * info->row_bytes, (size_t) rows * info->row_bytes, hipMemcpyHostToDevice));
+    }
+}
+static void sbuf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t offset, size_t size) {
+    const split_tensor_info * info = find(b, t);
+    if (!info || offset != 0 || size != ggml_abi_nbytes(t)) {
+        MI_ERR("split buffer: get_tensor of '%s' must cover the whole tensor", t->name);
+        abort();
+    }
+    for (int d = 0; d < info->n_dev; ++d) {
+        const int64_t rows = info->row0[d + 1] - info->row0[d];
+        if (rows <= 0) continue;
+        HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+        HIP_CHECK(hipMemcpy((char *) data + (size_t) info->row0[d] * info->row_bytes, info->slice[d], (size_t) rows * info->row_bytes, hipMemcpyDeviceToHost));
+    }
+}
+static void sbuf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t value, size_t offset, size_t size) {
+    const split_tensor_info * info = find(b, t);
+    if (!info || offset != 0 || size != ggml_abi_nbytes(t)) { MI_ERR("split buffer: memset_tensor must cover the whole tensor"); abort(); }
+    for (int d = 0; d < info->n_dev; ++d) {
+        const int64_t rows = info->row0[d + 1] - info->row0[d];
+        if (rows <= 0) continue;
+        HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+        HIP_CHECK(hipMemset(info->slice[d], value, (size_t) rows * info->row_bytes));
+    }
+}
+static void sbuf_clear(ggml_backend_buffer_t, uint8_t) {}  // (slices are written whole by set_tensor; nothing to clear before that)
+static const ggml_backend_buffer_i k_split_buffer_iface = {sbuf_free, sbuf_get_base, sbuf_init_tensor, sbuf_memset_tensor, sbuf_set_tensor,
+                                                           sbuf_get_tensor, /* cpy_tensor */ nullptr, sbuf_clear, nullptr};
+
+bool buffer_is_split(ggml_backend_buffer_t b) { return b != nullptr && b->iface.free_buffer == sbuf_free; }
+const split_tensor_info * split_info(const ggml_tensor * t) { return buffer_is_split(t->buffer) ? find(t->buffer, t) : nullptr; }
+
+static const char * sbuft_name(ggml_backend_buffer_type_t buft) { return ((split_buft_ctx *) buft->context)->name.c_str(); }
+static ggml_backend_buffer_t sbuft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
+    split_buffer_ctx * c = new split_buffer_ctx();
+    c->bt = (split_buft_ctx *) buft->context;
+    return make_backend_buffer(buft, k_split_buffer_iface, c, size);
+}
+static size_t sbuft_alignment(ggml_backend_buffer_type_t) { return 128; }
+static size_t sbuft_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * t) { return (ggml_abi_nbytes(t) + 255) / 256 * 256; }
+static bool sbuft_is_host(ggml_backend_buffer_type_t) { return false; }
+static const ggml_backend_buffer_type_i k_split_buft_iface = {sbuft_name, sbuft_alloc, sbuft_alignment, /* max_size */ nullptr, sbuft_alloc_size, sbuft_is_host};
+
+bool buft_is_split(ggml_backend_buffer_type_t buft) { return buft != nullptr && buft->iface.get_name == sbuft_name; }
+int split_buft_main_device(ggml_backend_buffer_type_t buft) { return ((split_buft_ctx *) buft->context)->main_device; }
+
+// the proc address: ggml_backend_split_buffer_type_t(int main_device, const float * tensor_split).  One buffer type object per distinct
+// (main device, proportions); they live for the life of the process, like upstream's.
+ggml_backend_buffer_type_t split_buffer_type(int main_device, const float * tensor_split) {
+    static std::mutex mtx;
+    static std::vector<ggml_backend_buffer_type *> all;
+    const int n = logical_device_count();
+    if (main_device < 0 || main_device >= n) return nullptr;
+    std::lock_guard<std::mutex> lock(mtx);
+    for (auto * bt : all) {
+        split_buft_ctx * c = (split_buft_ctx *) bt->context;
+        bool same = c->main_device == main_device;
+        for (int d = 0; d < n && same; ++d) same = c->split[d] == (tensor_split ? tensor_split[d] : 0.0f);
+        if (same) return bt;
+    }
+    split_buft_ctx * c = new split_buft_ctx();
+    c->main_device = main_device;
+    c->n_dev = n;
+    for (int d = 0; d < n; ++d) c->split[d] = tensor_split ? tensor_split[d] : 0.0f;
+    c->name = std::string(GGML_MI355X_NAME) + "_Split";
+    ggml_backend_buffer_type * bt = new ggml_backend_buffer_type{k_split_buft_iface, logical_device(main_device), c};
+    all.push_back(bt);
+    return bt;
+}
+
+// ------------------------------------------------------------------------------------------------ execution
+// per owning device: a stream, scratch for the activation copy / the result rows, an event
+struct split_helper {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    char * ws = nullptr;
+    size_t ws_size = 0;
+};
+static split_helper * helper_for(backend_ctx * c, int d) {
+    if ((int) c->split_helpers.size() <= d) c->split_helpers.resize((size_t) d + 1, nullptr);
+    if (!c->split_helpers[d]) {
+        split_helper * h = new split_helper();
+        h->ordinal = logical_device_ordinal(d);
+        HIP_CHECK(hipSetDevice(h->ordinal));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+        if (h->ordinal != c->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, h->ordinal, c->device) == hipSuccess && can) {
+                if (hipDeviceEnablePeerAccess(c->device, 0) != hipSuccess) (void) hipGetLastError();  // (already enabled is fine)
+            }
+        }
+        HIP_CHECK(hipSetDevice(c->device));
+        c->split_helpers[d] = h;
+    }
+    return c->split_helpers[d];
+}
+void free_split_helpers(backend_ctx * c) {
+    for (split_helper * h : c->split_helpers) {
+        if (!h) continue;
+        HIP_CHECK(hipSetDevice(h->ordinal));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->ws) HIP_CHECK(hipFree(h->ws));
+        HIP_CHECK(hipEventDestroy(h->ev));
+        HIP_CHECK(hipStreamDestroy(h->stream));
+        delete h;
+    }
+    c->split_helpers.clear();
+    HIP_CHECK(hipSetDevice(c->device));
+}
+
+bool split_mul_mat_supported(const ggml_tensor * op) {
+    const ggml_tensor * w = op->src[0];
+    const ggml_tensor * b = op->src[1];
+    const bool quant = w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K || w->type == GGML_TYPE_Q8_0;
+    return quant && (w->ne[0] % 256) == 0 && w->ne[2] == 1 && w->ne[3] == 1 && b->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(b) && op->type == GGML_TYPE_F32 &&
+           ggml_abi_is_contiguous(op) && (((uintptr_t) b->data) & 15) == 0;
+}
+
+// dst[N, M] = W[K, N] (rows split over the devices) x b[K, M]; called with the main device current and returns with it current
+bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor * b, ggml_tensor * dst) {
+    const split_tensor_info * info = split_info(w);
+    if (!info) return false;
+    const int64_t K = w->ne[0], N = w->ne[1], M = b->ne[1] * b->ne[2] * b->ne[3];
+    const size_t x_bytes = ggml_abi_nbytes(b);
+    const int act_kind = w->type == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K;
+    hipEvent_t ready;  // the activations exist on the main stream from here on
+    HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ready, c->stream));
+    for (int d = 0; d < info->n_dev; ++d) {
+        const int64_t rows = info->row0[d + 1] - info->row0[d];
+        if (rows <= 0) continue;
+        split_helper * h = helper_for(c, d);
+        HIP_CHECK(hipSetDevice(h->ordinal));
+        const size_t q_bytes = quantized_act_bytes(act_kind, K, M);
+        const size_t need = ((x_bytes + 255) & ~(size_t) 255) + ((q_bytes + 255) & ~(size_t) 255) + (size_t) rows * M * sizeof(float) + 256;
+        if (need > h->ws_size) {
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+            if (h->ws) HIP_CHECK(hipFree(h->ws));
+            HIP_CHECK(hipMalloc((void **) &h->ws, need + (1u << 20)));
+            h->ws_size = need + (1u << 20);
+        }
+        float * xd = (float *) h->ws;
+        char * qd = h->ws + ((x_bytes + 255) & ~(size_t) 255);
+        float * yd = (float *) (qd + ((q_bytes + 255) & ~(size_t) 255));
+        HIP_CHECK(hipStreamWaitEvent(h->stream, ready, 0));
+        HIP_CHECK(hipMemcpyPeerAsync(xd, h->ordinal, b->data, c->device, x_bytes, h->stream));
+        mmvq_args a{};
+        a.W = (const uint8_t *) info->slice[d];
+        a.w_nb1 = (int64_t) info->row_bytes;
+        a.type = w->type;
+        a.K = (int) K;
+        a.N = (int) rows;
+        a.dst = yd;
+        a.dst_stride = rows;
+        if (M == 1) {
+            a.ncols = 1;
+            a.x = xd;  // f32 prologue: the mat-vec quantises the row itself (mmvq.hip PRO 1)
+            launch_mmvq(h->stream, a, 1);
+        } else {
+            tdesc xdsc{(char *) xd, {K, M, 1, 1}, {4, K * 4, K * M * 4, K * M * 4}, GGML_TYPE_F32};
+            launch_quantize_act(h->stream, act_kind, xdsc, qd);
+            a.ncols = (int) M;
+            a.act = qd;
+            launch_mmvq(h->stream, a, 1);  // (columns in chunks of 8: functional for prompt batches, not tuned — DESIGN.md §6)
+        }
+        // gather: rows [row0, row0 + rows) of every column of dst
+        HIP_CHECK(hipMemcpy2DAsync((float *) dst->data + info->row0[d], (size_t) N * sizeof(float), yd, (size_t) rows * sizeof(float), (size_t) rows * sizeof(float), (size_t) M,
+                                   hipMemcpyDeviceToDevice, h->stream));
+        HIP_CHECK(hipEventRecord(h->ev, h->stream));
+        c->st.kernel_launches += 1;
+    }
+    HIP_CHECK(hipSetDevice(c->device));
+    for (int d = 0; d < info->n_dev; ++d)
+        if (info->row0[d + 1] > info->row0[d]) HIP_CHECK(hipStreamWaitEvent(c->stream, c->split_helpers[d]->ev, 0));
+    HIP_CHECK(hipEventDestroy(ready));
+    return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace mi355x

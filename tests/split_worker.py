@@ -1,0 +1,65 @@
+"""Subprocess body of tests/test_gpu_split.py: the row-split buffer type (-sm row) exercised on ONE GPU by registering several logical
+devices on it (GGML_MI355X_FAKE_DEVICES, set by the parent before this process loads the backend).  Prints one JSON line."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import harness as T  # noqa: E402
+import llama_box_amd as L  # noqa: E402
+
+
+def main():
+    H = L.host()
+    be = L.Backend(0)
+    n_dev = H.ggml_backend_reg_dev_count(be.reg)
+    out = {"n_dev": int(n_dev), "cases": []}
+    split_fn = be.proc("ggml_backend_split_buffer_type", C.c_void_p, [C.c_int, C.POINTER(C.c_float)])
+    rows_fn = be.proc("ggml_backend_mi355x_split_rows", None, [C.c_int64, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int64)])
+    rng = np.random.default_rng(7)
+    for ts in ([3.0, 1.0, 2.0, 2.0], [0.0] * 4, [1.0, 0.0, 1.0, 0.0]):
+        arr = (C.c_float * 16)(*(ts + [0.0] * (16 - len(ts))))
+        buft = split_fn(0, arr)
+        assert buft, "ggml_backend_split_buffer_type returned NULL"
+        sup = [bool(H.ggml_backend_dev_supports_buft(H.ggml_backend_reg_dev_get(be.reg, d), buft)) for d in range(n_dev)]
+        for qt, K, N, M in ((L.Q4_K, 4096, 1024, 1), (L.Q6_K, 2048, 640, 1), (L.Q4_K, 1024, 512, 5), (L.Q8_0, 2048, 1100, 1), (L.Q5_K, 512, 384, 9)):
+            w = T.rand_weight(qt, K, N, rng)
+            x = rng.standard_normal((M, K)).astype(np.float32)
+            row0 = (C.c_int64 * 17)()
+            rows_fn(N, arr, n_dev, row0)
+            # weights in the split buffer type, everything else in the main device's buffer type
+            ctx_w = H.ggml_init(L.InitParams(0, None, True))
+            tw = H.ggml_new_tensor_4d(ctx_w, qt, K, N, 1, 1)
+            buf_w = H.ggml_backend_alloc_ctx_tensors_from_buft(ctx_w, buft)
+            assert buf_w
+            raw = np.ascontiguousarray(w)
+            H.ggml_backend_tensor_set(tw, raw.ctypes.data_as(C.c_void_p), 0, raw.nbytes)
+            back = np.empty(raw.nbytes, np.uint8)
+            H.ggml_backend_tensor_get(tw, back.ctypes.data_as(C.c_void_p), 0, raw.nbytes)
+            g = T.G(be)
+            tx = g.new(L.F32, [K, M], x)
+            y = H.ggml_mul_mat(g.ctx, tw, tx)
+            got = g.compute([y])[0]
+            g.free()
+
+            def build(go):
+                return H.ggml_mul_mat(go.ctx, go.new(qt, [K, N], w), go.new(L.F32, [K, M], x))
+
+            ref = T.run_case(build, "oracle")[0]
+            plain = T.run_case(build, be)[0]
+            out["cases"].append({"ts": ts, "qt": int(qt), "K": K, "N": N, "M": M, "supports_buft": sup, "row0": [int(row0[d]) for d in range(n_dev + 1)],
+                                 "roundtrip_equal": bool(np.array_equal(back, raw.view(np.uint8).ravel())), "nmse_vs_oracle": float(T.nmse(got, ref)),
+                                 "equal_to_unsplit_gpu": bool(np.array_equal(np.asarray(got).view(np.uint32), np.asarray(plain).view(np.uint32))) if M == 1 else None,
+                                 "nmse_vs_unsplit_gpu": float(T.nmse(got, plain))})
+            H.ggml_backend_buffer_free(buf_w)
+            H.ggml_free(ctx_w)
+    print("SPLIT_JSON " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

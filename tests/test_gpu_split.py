@@ -1,0 +1,66 @@
+"""-sm row --tensor-split through the reference's own interface: reg.get_proc_address("ggml_backend_split_buffer_type")(main_gpu,
+tensor_split) -> a buffer type whose tensors are cut by rows over the devices; MUL_MAT on them = broadcast, per-device rows, gather
+(csrc/split.cpp; /root/reference/llama-box/engine_param.hpp:821-842, :902-916).  The GPU box has ONE device, so the worker process
+registers four logical devices on it (GGML_MI355X_FAKE_DEVICES): placement, scatter/gather and the multi-stream execution are the
+real code; only the peer copies degenerate to same-device copies."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_row_split_buffer_type_on_four_logical_devices(plog):
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="4")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1]
+    res = json.loads(line[len("SPLIT_JSON "):])
+    assert res["n_dev"] == 4
+    for c in res["cases"]:
+        plog(f"[split] ts={c['ts']} type={c['qt']} K={c['K']} N={c['N']} M={c['M']}: rows {c['row0']} nmse vs oracle {c['nmse_vs_oracle']:.2e} vs unsplit gpu {c['nmse_vs_unsplit_gpu']:.2e}")
+        assert c["supports_buft"] == [True, False, False, False]  # only the main device's backend computes on split weights
+        assert c["roundtrip_equal"]  # set_tensor scatters, get_tensor gathers: the host sees GGUF bytes
+        assert c["nmse_vs_oracle"] <= 1e-10
+        if c["M"] == 1:
+            assert c["equal_to_unsplit_gpu"]  # rows are independent: the same kernel on a slice gives the same bits
+        r0, n = c["row0"], c["N"]
+        assert r0[0] == 0 and r0[-1] == n and all(a <= b for a, b in zip(r0[:-1], r0[1:]))
+        ts = c["ts"]
+        tot = sum(ts)
+        for d in range(4):  # proportions, up to the 64-row granule
+            want = n * (sum(ts[:d]) / tot if tot > 0 else d / 4)
+            assert abs(r0[d] - want) < 64, (d, r0, want)
+            assert r0[d] % 64 == 0 or r0[d] == n
+
+
+def test_split_rows_planning_without_a_device():
+    """The row plan is host arithmetic: reachable through the registration's proc address on a box without any GPU."""
+    import ctypes as C
+
+    import llama_box_amd as L
+
+    H = L.host()
+    lib = C.CDLL(L.BACKEND_SO)
+    lib.ggml_backend_mi355x_reg.restype = C.c_void_p
+    reg = lib.ggml_backend_mi355x_reg()
+    assert reg
+    addr = H.ggml_backend_reg_get_proc_address(reg, b"ggml_backend_mi355x_split_rows")
+    assert addr and H.ggml_backend_reg_get_proc_address(reg, b"ggml_backend_split_buffer_type")
+    fn = C.CFUNCTYPE(None, C.c_int64, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int64))(addr)
+    row0 = (C.c_int64 * 17)()
+    # Llama-3-70B ffn rows over eight devices, even split: 28672 / 8 = 3584 rows each
+    fn(28672, (C.c_float * 16)(*([1.0] * 8 + [0.0] * 8)), 8, row0)
+    assert [row0[d] for d in range(9)] == [3584 * d for d in range(9)]
+    # proportions 3:1 over two devices, 64-row granule
+    fn(4096, (C.c_float * 16)(3.0, 1.0), 2, row0)
+    assert [row0[d] for d in range(3)] == [0, 3072, 4096]
+    # all-zero proportions = even; a device with proportion 0 gets no rows
+    fn(1000, (C.c_float * 16)(), 4, row0)
+    assert [row0[d] for d in range(5)] == [0, 192, 448, 704, 1000]
+    fn(1024, (C.c_float * 16)(1.0, 0.0, 1.0), 3, row0)
+    assert [row0[d] for d in range(4)] == [0, 512, 512, 1024]
