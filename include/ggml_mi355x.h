@@ -41,9 +41,10 @@ ggml_backend_reg_t ggml_backend_mi355x_reg(void);
  * llama-box/engine_param.hpp:99-101, llama-box/rpcserver.hpp:402-403):
  *
  *   "ggml_backend_get_features"        ggml_backend_get_features_t
- *   "ggml_backend_split_buffer_type"   ggml_backend_split_buffer_type_t   (row-split hook of -sm row; NULL until the
- *                                      single-process split lands — the tensor-parallel path of this round is the
- *                                      one-process-per-GPU form below)
+ *   "ggml_backend_split_buffer_type"   ggml_backend_split_buffer_type_t   (row-split hook of -sm row: (main_device, tensor_split[]) ->
+ *                                      buffer type whose matrices are cut by rows over the devices; llama-box/engine_param.hpp
+ *                                      :821-842, :902-916; csrc/split.cpp)
+ *   "ggml_backend_mi355x_split_rows"   ggml_backend_mi355x_split_rows_t   (the row plan of that buffer type, host arithmetic)
  *   "ggml_backend_mi355x_tp_init"      ggml_backend_mi355x_tp_init_t
  *   "ggml_backend_mi355x_tp_rowpar_buffer_type"   ggml_backend_mi355x_tp_rowpar_buffer_type_t
  *   "ggml_backend_mi355x_set_option"   ggml_backend_mi355x_set_option_t
@@ -51,6 +52,13 @@ ggml_backend_reg_t ggml_backend_mi355x_reg(void);
  *   "ggml_backend_mi355x_timing_report" ggml_backend_mi355x_timing_report_t
  *   "ggml_backend_mi355x_tp_get_unique_id" ggml_backend_mi355x_tp_get_unique_id_t
  */
+
+/* Replaces: ggml_backend_cuda_split_buffer_type(int main_device, const float * tensor_split) of the stock GPU backends, as reached
+ * through get_proc_address (upstream ggml-backend.h: ggml_backend_split_buffer_type_t).  tensor_split holds one proportion per
+ * device of this registration (all zero = even).  Only the main device's backend supports_buft() the result. */
+/* (typedef ggml_backend_split_buffer_type_t: include/ggml_abi.h, as in upstream's ggml-backend.h) */
+/* row0[0 .. n_dev]: device d owns rows [row0[d], row0[d + 1]) of an nrows-row matrix (64-row granule). */
+typedef void (*ggml_backend_mi355x_split_rows_t)(int64_t nrows, const float * tensor_split, int n_dev, int64_t * row0);
 
 /* One-process-per-GPU tensor parallelism over RCCL/xGMI.  `unique_id` is the 128-byte ncclUniqueId produced by
  * rank 0 (ncclGetUniqueId) and distributed by the launcher (bench.py uses torch.distributed for that).  After a
@@ -62,9 +70,10 @@ typedef ggml_backend_buffer_type_t (*ggml_backend_mi355x_tp_rowpar_buffer_type_t
 
 /* Runtime options (string key/value); 0 = accepted, -1 = unknown key.  Keys (INTEGRATION.md 4b lists the defaults and the
  * environment variables that set the same things): "graphs", "fusion", "prologue", "qkv", "mm_merge", "mmq_i8", "mmq_bn",
- * "mmq_min_cols", "mmvq_max_cols", "fa_splits", "small_uploads", "timing". */
+ * "mmq_min_cols", "mmvq_max_cols", "fa_splits", "fa_wo", "small_uploads", "timing". */
 typedef int (*ggml_backend_mi355x_set_option_t)(ggml_backend_t backend, const char * key, const char * value);
-/* Counters for tests/bench: "graph_launches", "graph_captures", "eager_nodes", "kernel_launches", "fused_nodes". */
+/* Counters for tests/bench: "graph_launches", "graph_captures", "eager_graphs", "kernel_launches", "fused_nodes", "allreduces",
+ * "graph_launch_host_ns". */
 typedef int64_t (*ggml_backend_mi355x_get_stat_t)(ggml_backend_t backend, const char * key);
 /* Timing helper for bench.py (option "timing"="1": graphs off, every kernel class bracketed by hipEvents on the
  * backend's own stream — torch.cuda.Event cannot see that stream).  Writes lines "class count total_ms bytes". */

@@ -534,6 +534,7 @@ struct llm_context {
     // outputs
     std::vector<float> logits;
     float * logits_base = nullptr;  // where the last llm_decode's rows are: the pinned output area, or `logits`
+    std::vector<int32_t> output_ids;  // batch position -> output row of the last llm_decode (-1: no logits requested there)
     int n_outputs = 0;
     double timings[4] = {0, 0, 0, 0};
     // pinned host staging, as llama.cpp does it (inputs are uploaded with tensor_set_async out of host-buffer-type memory,
@@ -971,6 +972,9 @@ extern "C" int llm_decode(struct llm_context * c, int n_tokens, const int32_t * 
         c->logits_base = c->logits.data();
     }
     c->n_outputs = 0;
+    // batch position -> output row (llama.cpp's output_ids): what llama_get_logits_ith(ctx, i) resolves i >= 0 through
+    c->output_ids.assign((size_t) n_tokens, -1);
+    for (int i = 0, o = 0; i < n_tokens; ++i) if (!want_logits || want_logits[i]) c->output_ids[(size_t) i] = o++;
     for (int k = 0; k < 4; ++k) c->timings[k] = 0;
     for (int i0 = 0; i0 < n_tokens; i0 += c->p.n_ubatch) {
         const int n = std::min(c->p.n_ubatch, n_tokens - i0);
@@ -1003,9 +1007,43 @@ extern "C" int llm_decode_steps(struct llm_context * c, int n_steps, int n_par, 
 }
 extern "C" int llm_n_outputs(const struct llm_context * c) { return c->n_outputs; }
 extern "C" float * llm_get_logits(struct llm_context * c) { return c->logits_base; }
+// llama_get_logits_ith (include/llama.h; the reference reads through it at llama-box/httpserver.hpp:442 and inside
+// common_sampler_sample2 -> set_logits, patches/llama.cpp/sampling.patch:58-81): i >= 0 is a POSITION OF THE BATCH and must be one
+// whose logits were requested; i < 0 counts output rows from the end (-1 = the last one).  NULL for anything else.
 extern "C" float * llm_get_logits_ith(struct llm_context * c, int i) {
-    if (i < 0 || i >= c->n_outputs) return nullptr;
-    return c->logits_base + (size_t) i * c->model->n_vocab_l;
+    int row;
+    if (i < 0) row = c->n_outputs + i;
+    else if ((size_t) i < c->output_ids.size()) row = c->output_ids[(size_t) i];
+    else return nullptr;
+    if (row < 0 || row >= c->n_outputs) return nullptr;
+    return c->logits_base + (size_t) row * c->model->n_vocab_l;
+}
+// common_sampler_sample2 with the greedy chain llama-box builds for temperature 0 (llama_sampler_init_greedy: the FIRST maximal
+// logit wins): the host-side consumer of the logits rows the backend delivers.  -1 if position idx has no logits.
+extern "C" int32_t llm_sample_greedy(struct llm_context * c, int idx) {
+    const float * lg = llm_get_logits_ith(c, idx);
+    if (!lg) return -1;
+    const int nv = c->model->n_vocab_l;
+    int best = 0;
+    for (int t = 1; t < nv; ++t) if (lg[t] > lg[best]) best = t;
+    return best;
+}
+// get_token_probabilities (llama-box/httpserver.hpp:440-467): tokens sorted by logit, soft-max over the whole vocabulary; writes the
+// top_n leading (id, p) pairs.  Returns the number written, -1 if position idx has no logits.
+extern "C" int llm_token_probabilities(struct llm_context * c, int idx, int top_n, int32_t * ids, float * probs) {
+    const float * lg = llm_get_logits_ith(c, idx);
+    if (!lg) return -1;
+    const int nv = c->model->n_vocab_l;
+    std::vector<int32_t> order((size_t) nv);
+    for (int t = 0; t < nv; ++t) order[(size_t) t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return lg[a] > lg[b]; });
+    const float max_l = lg[order[0]];
+    float cum = 0.0f;
+    std::vector<float> p((size_t) nv);
+    for (int t = 0; t < nv; ++t) { p[(size_t) t] = expf(lg[order[(size_t) t]] - max_l); cum += p[(size_t) t]; }
+    const int n = std::min(top_n, nv);
+    for (int t = 0; t < n; ++t) { ids[t] = order[(size_t) t]; probs[t] = p[(size_t) t] / cum; }
+    return n;
 }
 extern "C" struct ggml_cgraph * llm_last_graph(struct llm_context * c) { return c->gf; }
 extern "C" void llm_last_timings(const struct llm_context * c, double out[4]) {

@@ -79,7 +79,11 @@ int llm_decode(struct llm_context * c, int n_tokens, const int32_t * tokens, con
 int llm_decode_steps(struct llm_context * c, int n_steps, int n_par, const int32_t * tokens, int pos0);
 int llm_n_outputs(const struct llm_context * c);
 float * llm_get_logits(struct llm_context * c);            /* [n_outputs][n_vocab], host memory */
-float * llm_get_logits_ith(struct llm_context * c, int i); /* i-th output row of the last llm_decode */
+/* llama_get_logits_ith semantics: i >= 0 = batch position (must have requested logits), i < 0 = output rows from the end; NULL otherwise */
+float * llm_get_logits_ith(struct llm_context * c, int i);
+/* host-side consumers of the logits: common_sampler_sample2 with a greedy chain, get_token_probabilities */
+int32_t llm_sample_greedy(struct llm_context * c, int idx);
+int llm_token_probabilities(struct llm_context * c, int idx, int top_n, int32_t * ids, float * probs);
 void llm_kv_clear(struct llm_context * c);
 int llm_kv_seq_rm(struct llm_context * c, int seq_id, int p0, int p1);
 /* llama_memory_seq_add + the K-shift graph it triggers (context shift, llama-box httpserver.hpp:3453-3537): positions

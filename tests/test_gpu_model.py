@@ -62,6 +62,36 @@ def _oracle_pair(H, name, fa, prompt, n_gen, seed=1234):
     return out
 
 
+def _oracle_yardstick(H, name, prompt, n_gen, seeds=(1234, 2001, 2002, 2003)):
+    """max |logit difference| of the oracle against ITSELF under one-ulp changes (variants 1-3 of oracle/ggml_cpu_ref.c), pooled over a
+    few model seeds: whether a given run crosses a rounding boundary is chance, how far a crossing moves the logits is a property of
+    the network — this is the deviation band any two correct implementations of it share."""
+    hp = preset(name)
+    worst = 0.0
+    for seed in seeds:
+        mc = Model(hp, seed, H.ggml_backend_cpu_buffer_type())
+        try:
+            c = Context(mc, compute=T.oracle_compute_fn(), flash_attn=0)
+            ids, rows = greedy(c, prompt, n_gen)
+            c.free()
+            rows = np.stack(rows)
+            for variant in (1, 2, 3):
+                T.oracle().oracle_set_variant(variant)
+                try:
+                    c = Context(mc, compute=T.oracle_compute_fn(), flash_attn=0)
+                    rc, lg = c.decode(prompt, range(len(prompt)), want=[0] * (len(prompt) - 1) + [1])
+                    rv = [lg[-1]]
+                    for i, t in enumerate(ids[:-1]):
+                        rv.append(c.decode([t], [len(prompt) + i])[1][0])
+                    c.free()
+                finally:
+                    T.oracle().oracle_set_variant(0)
+                worst = max(worst, float(np.max(np.abs(np.stack(rv) - rows))))
+        finally:
+            mc.free()
+    return worst
+
+
 @pytest.mark.parametrize("name", ["test-llama", "test-qwen2"])
 def test_logits_and_greedy_ids_softmax_path(backend, H, plog, name):
     (ref, ids_ref, rows_ref), (alt, ids_alt, rows_alt) = _oracle_pair(H, name, 0, PROMPT, 32)
@@ -93,9 +123,13 @@ def test_logits_and_greedy_ids_softmax_path(backend, H, plog, name):
         dmax = np.max(np.abs(rows_got - rows_ref), axis=1)
         plog(f"{name} teacher-forced decode x{len(ids_ref)}: nmse={e_dec:.3e} (oracle_rev floor {floor_dec:.3e}) max|d|={dmax.max():.3e} argmax agreement={int(agree.sum())}/{len(agree)} min margin={margins.min():.3e}; oracle_rev greedy ids equal oracle: {ids_alt == ids_ref}")
         assert e_dec <= 1e-3
-        # every step whose top-2 margin clears the observed deviation must pick the oracle's token: bit-exact ids under greedy
-        assert all(agree[i] for i in range(len(agree)) if margins[i] > 2.0 * dmax[i]), "greedy token differs where the margin is decisive"
-        assert agree.mean() >= 0.9
+        # greedy ids: equal to the oracle's wherever the top-2 margin exceeds how far the ORACLE moves under one-ulp changes of its
+        # own arithmetic (pooled over four seeds x three variants) — a yardstick the GPU has no part in (the earlier
+        # gate compared the margin with the GPU's own deviation)
+        yard = 2.0 * _oracle_yardstick(H, name, PROMPT, 32)
+        decisive = margins > yard
+        plog(f"{name}: oracle-vs-oracle yardstick {yard:.3e}; {int(decisive.sum())}/{len(margins)} decode positions decisive")
+        assert bool(np.all(agree[decisive])), "greedy token differs where the margin exceeds the oracle's own order sensitivity"
     finally:
         _free(cg, mg)
 
@@ -312,3 +346,35 @@ def test_kv_full_returns_1_and_bad_batch_minus_1(backend, H):
         assert rc == -1
     finally:
         c.free(); mg.free()
+
+
+def test_host_sampler_consumes_backend_logits(backend, H, plog):
+    """the rows the backend delivers (written straight into the pinned output area) are what the host-side
+    sampler reads through llama_get_logits_ith: greedy sampling and the top-n probabilities over the MI355X backend must match the
+    same consumers over the oracle, for a prompt batch with scattered logit requests and for decode steps."""
+    import ctypes as C
+
+    hp, mc, mg, cc, cg = _pair(H, backend, "test-qwen2", fa=1)
+    try:
+        toks = PROMPT[:12]
+        want = [0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+        assert cc.decode(toks, range(12), want=want)[0] == 0 and cg.decode(toks, range(12), want=want)[0] == 0
+        for pos in (2, 6, 11, -1, -3):
+            a, b = H.llm_sample_greedy(cc.c, pos), H.llm_sample_greedy(cg.c, pos)
+            ra = np.ctypeslib.as_array(H.llm_get_logits_ith(cc.c, pos), shape=(hp.n_vocab,))
+            top2 = np.sort(ra)[-2:]
+            dev = float(np.max(np.abs(ra - np.ctypeslib.as_array(H.llm_get_logits_ith(cg.c, pos), shape=(hp.n_vocab,)))))
+            plog(f"host sampler at batch position {pos}: oracle id {a}, backend id {b}, margin {top2[1] - top2[0]:.3e}, max|d| {dev:.3e}")
+            assert a == b or top2[1] - top2[0] <= 2 * dev
+        assert H.llm_sample_greedy(cg.c, 0) == -1 and not H.llm_get_logits_ith(cg.c, 3)
+        ids_c, ids_g = (C.c_int32 * 5)(), (C.c_int32 * 5)()
+        p_c, p_g = (C.c_float * 5)(), (C.c_float * 5)()
+        assert H.llm_token_probabilities(cc.c, -1, 5, ids_c, p_c) == 5 and H.llm_token_probabilities(cg.c, -1, 5, ids_g, p_g) == 5
+        assert np.allclose(np.array(list(p_c)), np.array(list(p_g)), atol=2e-3)
+        # greedy continuation driven entirely through the host sampler, teacher-forced with the oracle's choice
+        for i in range(8):
+            t = H.llm_sample_greedy(cc.c, -1)
+            assert cc.decode([t], [12 + i])[0] == 0 and cg.decode([t], [12 + i])[0] == 0
+            assert H.llm_get_logits_ith(cg.c, 0) and H.llm_get_logits_ith(cg.c, -1)
+    finally:
+        _free(cc, cg, mc, mg)

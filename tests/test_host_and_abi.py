@@ -295,3 +295,45 @@ def test_rope_multi_oracle_against_closed_form(H):
     # all-zero sections: upstream divides by zero there (llama-box only removed the assertion) -> refused, not guessed
     with pytest.raises(RuntimeError):
         _rope_multi_oracle(H, x, pos4, HD, [0, 0, 0, 0], L.ROPE_MROPE)
+
+
+def test_logits_ith_and_host_sampler_mirrors():
+    """llama_get_logits_ith semantics (batch position / negative = from the end / NULL without logits) and the two host-side
+    consumers the reference runs on those rows: common_sampler_sample2 with a greedy chain (sampling.patch:58-81, called at
+    httpserver.hpp:4294) and get_token_probabilities (httpserver.hpp:440-467) — here over the CPU oracle."""
+    import ctypes as C
+
+    import harness as T
+    from model_util import Context, Model, preset
+
+    H = L.host()
+    hp = preset("test-llama")
+    m = Model(hp, 77, H.ggml_backend_cpu_buffer_type())
+    c = Context(m, compute=T.oracle_compute_fn())
+    try:
+        toks = [3, 9, 27, 81, 243, 5]
+        rc, lg = c.decode(toks, range(6), want=[0, 1, 0, 0, 1, 1])
+        assert rc == 0 and lg.shape[0] == 3
+        nv = hp.n_vocab
+
+        def row(i):
+            p = H.llm_get_logits_ith(c.c, i)
+            return None if not p else np.ctypeslib.as_array(p, shape=(nv,)).copy()
+
+        assert row(0) is None and row(2) is None and row(6) is None and row(-4) is None  # no logits there / out of range
+        assert np.array_equal(row(1), lg[0]) and np.array_equal(row(4), lg[1]) and np.array_equal(row(5), lg[2])
+        assert np.array_equal(row(-1), lg[2]) and np.array_equal(row(-3), lg[0])
+        assert H.llm_sample_greedy(c.c, 0) == -1
+        for pos, r in ((1, 0), (4, 1), (-1, 2)):
+            assert H.llm_sample_greedy(c.c, pos) == int(np.argmax(lg[r]))  # first maximal logit
+        ids = (C.c_int32 * 8)()
+        pr = (C.c_float * 8)()
+        assert H.llm_token_probabilities(c.c, 5, 8, ids, pr) == 8
+        order = np.argsort(-lg[2], kind="stable")[:8]
+        p_ref = np.exp(lg[2].astype(np.float32) - lg[2].max())
+        p_ref = (p_ref / p_ref.sum(dtype=np.float32))[order]
+        assert list(ids) == order.tolist()
+        assert np.allclose(np.array(list(pr)), p_ref, rtol=1e-5)
+    finally:
+        c.free()
+        m.free()
