@@ -121,7 +121,8 @@ static ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t 
     buft_ctx * bc = (buft_ctx *) buft->context;
     HIP_CHECK(hipSetDevice(bc->device));
     void * p = nullptr;
-    hipError_t err = hipMalloc(&p, size > 0 ? size : 1);
+    // (+256: the skinny Q6_K fetch reads whole 256-byte windows of 210-byte blocks — up to 46 bytes past the last block of a tensor)
+    hipError_t err = hipMalloc(&p, size + 256);
     if (err != hipSuccess) {
         (void) hipGetLastError();
         MI_ERR("allocating %.2f MiB on device %d: hipMalloc failed: %s", size / 1024.0 / 1024.0, bc->device, hipGetErrorString(err));
@@ -315,6 +316,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_MMQ_I8")) c->opt.mmq_i8 = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MM_MERGE")) c->opt.mm_merge = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_BN")) c->opt.mmq_bn = atoi(e);
+    if (const char * e = getenv("GGML_MI355X_MMQ_SKINNY")) c->opt.mmq_skinny = atoi(e) != 0;
     return new ggml_backend{&g_guid, k_backend_iface, dev, c};
 }
 static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &dctx(dev)->buft; }
@@ -376,6 +378,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "mmq_i8") c->opt.mmq_i8 = v != 0;
     else if (k == "mm_merge") c->opt.mm_merge = v != 0;
     else if (k == "mmq_bn") c->opt.mmq_bn = v;
+    else if (k == "mmq_skinny") c->opt.mmq_skinny = v != 0;
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "fa_wo") c->opt.fa_wo = v != 0;
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;
@@ -396,6 +399,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "fused_nodes") return c->st.fused_nodes;
     if (k == "allreduces") return c->st.allreduces;
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
+    if (k == "skinny_launches") return c->st.skinny_launches;
     return -1;
 }
 static int api_timing_report(ggml_backend_t be, char * buf, size_t size, int reset) {

@@ -72,6 +72,7 @@ struct options {
     int mmq_min_cols = 3;      // batches at least this wide run on the matrix cores (measured, ms/step matrix cores vs multi-column mat-vec: 3 columns 4.1 / 4.4, 4: 3.9 / 4.2, 8: 4.4 / 5.7; 2 columns: 3.6 / 3.1)
     bool mmq_i8 = true;        // Q4_K/Q5_K batches on the int8 matrix cores (mmq_i8.hip) instead of the f16 variant (mmq.hip)
     bool mm_merge = true;      // batches: sibling mat-muls over the same activations (wq/wk/wv, gate/up) as one launch
+    bool mmq_skinny = true;    // 2..32 columns: weight-streaming matrix-core kernel (mmq_skinny.hip) instead of the tiled GEMM
     int mmq_bn = 0;            // force the weight-panel height of mmq_i8 (64 / 128); 0 = pick by grid size
     int fa_splits = 0;         // 0 = auto
     bool fa_wo = false;        // decode: attention as few fat splits whose merge is the wo mat-vec's prologue (no combine launch).  Correct and
@@ -83,6 +84,7 @@ struct options {
 
 struct stats {
     int64_t graph_launches = 0, graph_captures = 0, eager_graphs = 0, kernel_launches = 0, fused_nodes = 0, allreduces = 0;
+    int64_t skinny_launches = 0;       // mat-muls of 2..32 columns served by the weight-streaming matrix-core kernel
     int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)
 };
 

@@ -102,18 +102,22 @@ void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, con
 
 // ---- prefill: quantised weights x many columns through MFMA (mmq.hip)
 bool mmq_supported(int type, int64_t K, int64_t N, int64_t M);
-size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M);
+size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M, bool skinny);
 // int8-matrix-core variant for Q4_K / Q5_K (mmq_i8.hip); force_bn: 0 = auto, 64 / 128 = weight-panel height
 struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
 // up to three matrices of one type against the same activations in one launch (wq/wk/wv, ffn_gate/ffn_up of a batch)
-void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce = true);
+void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce = true, bool skinny = false);
 void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * mats, const float * part, int ks, int M);  // the reduce pass of launch_mmq_i8_multi(reduce = false), later
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M);
 // ksplit > 1: the K range is split over that many workgroup rows, partials in `part` (mmq_workspace_bytes), summed in a fixed order
-int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M);
+int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M, bool skinny);
 void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride, bool reduce = true);
+                   int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride, bool reduce = true, bool skinny = false);
+// 2..32 columns (continuous-batching decode steps): the weight-streaming matrix-core kernel of mmq_skinny.hip, reached through
+// launch_mmq_i8[_multi](skinny = true); the caller's activation area must hold 32 columns' worth of bytes (read, never used)
+bool mmq_skinny_supported(int type, int64_t K, int64_t N, int64_t M, int64_t w_nb1);
+int mmq_skinny_ksplit(int64_t K, int64_t n_total);
 // Q8_0 weights x Q8_0 activations, one int8 MFMA per 32-value block + immediate f32 scale-accumulate (mmq_q80.hip)
 bool mmq_q80_supported(int type, int64_t K, int64_t N, int64_t M);
 void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);

@@ -23,6 +23,7 @@
 
 #include "dev_util.h"
 #include "kernels.h"
+#include "mmq_args.h"
 
 namespace mi355x {
 
@@ -30,28 +31,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef int int16v __attribute__((ext_vector_type(16)));
-
-// Up to three weight matrices of one type that multiply the SAME activations (wq / wk / wv, ffn_gate / ffn_up) share a launch:
-// their row panels form one list (matrix i owns panels [panel0_i, panel0_{i+1})), which fills the chip where each of them
-// alone needed a K split — and a second kernel — to do so.
-struct mmq8_mat {
-    const uint8_t * W;
-    int64_t w_nb1;
-    int N, panel0;
-    float * dst;
-    int64_t dst_stride;
-    float * part;        // ksplit > 1: partial [ksplit][M][N] results of this matrix (summed in a fixed order by k_splitk_reduce)
-    const float * add;   // optional epilogue: + add[m * add_stride + n] (bias row: stride 0, residual: stride N)
-    int64_t add_stride;
-};
-struct mmq8_args {
-    mmq8_mat mat[3];
-    int n_mat;
-    int K, M;
-    const q8k_dev * act;  // [M][K/256]
-    int n_panels, m_tiles;
-    int ksplit;          // > 1: blockIdx.y owns a contiguous range of super-blocks and writes its partial result
-};
 
 constexpr int MI_BM = 128;
 constexpr int MI_MS = (16 + 8) * 2;  // row stride of the 16-wide f16 mins / bsums tiles (48 B)
@@ -444,7 +423,8 @@ template <int QT, int BN, int BM = 128> static void launch_mmq8_t(hipStream_t s,
 
 // few activation columns (continuous-batching decode, M <= 64) leave N/64 x 1 workgroups — far fewer than 256 CUs — so
 // the K range is split over blockIdx.y and the partial products are summed in a fixed order by a second tiny kernel
-int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M) {
+int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M, bool skinny) {
+    if (skinny && M >= 2 && M <= 32 && (N % 32) == 0) return mmq_skinny_ksplit(K, N);
     const int64_t wgs = ((N + 63) / 64) * ((M + 127) / 128), nblk = K / 256;
     static const int ks_target = getenv("GGML_MI355X_MMQ_KS_TARGET") ? atoi(getenv("GGML_MI355X_MMQ_KS_TARGET")) : 512;
     if (M <= 64) return (int) std::max<int64_t>(1, std::min<int64_t>(nblk, ks_target / std::max<int64_t>(1, wgs)));
@@ -508,7 +488,7 @@ void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int 
 }
 
 // n_mat (1..3) matrices of one type against the same activations; `part` holds ksplit * M * sum(N) floats when ksplit > 1
-void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce) {
+void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce, bool skinny) {
     mmq8_args a{};
     a.n_mat = n_mat;
     a.K = K;
@@ -528,6 +508,13 @@ void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc 
         a.mat[i].part = pp;
         pp += (size_t) a.ksplit * M * mats[i].N;
         panels128 += (mats[i].N + 127) / 128;
+        skinny = skinny && mmq_skinny_supported(type, K, mats[i].N, M, mats[i].w_nb1);
+    }
+    skinny = skinny && (a.ksplit & (a.ksplit - 1)) == 0;  // (its K split is a power of two: mmq_skinny_ksplit)
+    if (skinny) {  // a decode step of a continuous batch: stream the weights once (mmq_skinny.hip)
+        launch_mmq_skinny(s, type, a);
+        if (a.ksplit > 1 && reduce) launch_splitk_reduce_multi(s, a);
+        return;
     }
     // 128-row panels unless that leaves CUs idle (256 CUs, one 8-wave workgroup each)
     const int64_t wg128 = panels128 * ((M + MI_BM - 1) / MI_BM);
@@ -577,9 +564,9 @@ void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * ma
     launch_splitk_reduce_multi(s, a);
 }
 void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part, const float * add, int64_t add_stride, bool reduce) {
+                   int ksplit, float * part, const float * add, int64_t add_stride, bool reduce, bool skinny) {
     const mmq_mat_desc m{W, w_nb1, N, dst, dst_stride, add, add_stride};
-    launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part, reduce);
+    launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part, reduce, skinny);
 }
 
 }  // namespace mi355x

@@ -1,0 +1,364 @@
+// mmq_skinny.hip — quantised weights x 2..32 activation columns (the decode step of a continuous batch, `-np` > 1; SURVEY.md
+// §8a row a6 at small M) as a WEIGHT-STREAMING kernel on the integer matrix cores.
+//
+// The prompt-batch GEMM (mmq_i8.hip) tiles N x M and re-stages the weights per column tile; at M <= 32 there is one column
+// tile, every weight byte is used exactly once, and the launch is an HBM stream like the mat-vec — only with 32 dot products
+// per weight instead of one, which v_dot4 cannot keep up with (35 us for the 66 MB gate/up pair = 1.9 TB/s).
+//
+//   * work unit = (32 weight rows) x (one 256-value super-block) — 4.6 KB of Q4_K.  A workgroup (8 waves) owns one 32-row
+//     tile and a range of super-blocks; wave w takes units w, w+8, ..  and the eight partial 32x32 results meet in LDS at the
+//     end (fixed order).  The grid is one workgroup per CU walking the tiles with a stride: the first units of the next tile
+//     are already being fetched while the current one is reduced and stored (with one short-lived workgroup per tile the
+//     memory latency was exposed once per tile: 30 us for the 66 MB gate/up pair).  No K split across workgroups unless the matrix alone cannot fill the chip (then blockIdx.y splits K
+//     and the partial results go to the same [ksplit][M][N] workspace mmq_i8.hip uses — its consumers sum them).
+//   * both operands are fetched as ROW-CONTIGUOUS 16-byte pieces (runs of 9..20 lanes; scripts/ubench/ta_probe.hip: 23-34
+//     clocks per wave-instruction, against 65 when every lane sits in another row, which the MFMA operand layout would ask for)
+//     into a wave-private LDS area, and read back in the operand layout with conflict-free ds_read_b128 (row strides of
+//     4 * odd dwords).  The next unit's global loads are issued into registers before the current unit is multiplied; the LDS
+//     area is private to the wave, so the loop has no barrier at all.
+//   * the WEIGHTS are the matrix-core B operand and the activations the A operand: a lane's 16 accumulators are then 16
+//     tokens of ONE weight row, and that row's sub-block scale — a value the lane decoded from its own row header — folds the
+//     int32 block sum with one v_mad_i32_i24 per accumulator (the reverse assignment needs a per-register scale, i.e. an LDS
+//     read or a digit decomposition per MFMA).  sum_j sc_j * (q . y)_j is the integer ggml-cpu computes (ggml_vec_dot_q4_K_q8_K,
+//     /root/reference/llama.cpp/ggml/src/ggml-cpu/quants.c), exact in int32.
+//   * mins (Q4_K / Q5_K) and the -32 offset of Q6_K are sum_j m_j * bsum_j over the activation block's 16-value sums — one
+//     f16 MFMA per unit on the f16 bsums the quantisers store (exact: |.| < 2^24), as in mmq_i8.hip.
+//   * Q6_K blocks are 210 bytes at 2-byte alignment: the unit is fetched as 4-byte-aligned 16-byte pieces (dwordx4 only needs
+//     dword alignment) and shifted by 0 / 2 bytes on the way into LDS (v_alignbyte + the neighbour lane's first dword).
+#include <algorithm>
+
+#include "dev_util.h"
+#include "kernels.h"
+#include "mmq_args.h"
+#include "mmvq_types.h"
+
+namespace mi355x {
+
+typedef _Float16 half8s __attribute__((ext_vector_type(8)));
+typedef float float16s __attribute__((ext_vector_type(16)));
+typedef int int4s __attribute__((ext_vector_type(4)));
+typedef int int2s __attribute__((ext_vector_type(2)));
+typedef int int16s __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+
+constexpr int SK_NW = 8;            // waves per workgroup
+constexpr int SK_BTOK = 304;        // LDS bytes per token of the activation unit: 256 qs + 32 bsums (f16) + 16 pad (76 dwords = 4 * 19)
+constexpr int SK_B_BYTES = 32 * SK_BTOK;
+template <int QT> struct sk_fmt;
+template <> struct sk_fmt<4> { static constexpr int BYTES = 144, PIECES = 9, ROW = 144; };   // 36 dwords = 4 * 9
+template <> struct sk_fmt<5> { static constexpr int BYTES = 176, PIECES = 11, ROW = 176; };  // 44 dwords = 4 * 11
+template <> struct sk_fmt<6> { static constexpr int BYTES = 210, PIECES = 14, ROW = 240; };  // 14 pieces + 16 pad: 60 dwords = 4 * 15
+template <int QT> constexpr int sk_wave_lds() { return 32 * sk_fmt<QT>::ROW + SK_B_BYTES + 128; }
+
+__device__ __forceinline__ uint32_t sk_pack_h2(const float a, const float b) {
+    typedef _Float16 half2s __attribute__((ext_vector_type(2)));
+    const half2s h = {(_Float16) a, (_Float16) b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+template <int QT>
+__global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef sk_fmt<QT> F;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 31, g = lane >> 5;
+    const int nblk = a.K / 256;
+    // work items = (32-row tile, K slice); workgroup j serves items j, j + gridDim.x, ..  (one resident workgroup per CU: the loads
+    // of an item's first units are in flight while the previous item is reduced and stored)
+    const int ksl = 31 - __builtin_clz((unsigned) a.ksplit);  // ksplit is a power of two (launcher)
+    const int n_items = a.n_panels << ksl;
+    const int w_nb1 = (int) a.mat[0].w_nb1;  // the same for every matrix of the launch (checked by the launcher)
+
+    char * const As = smem + wave * sk_wave_lds<QT>();
+    char * const Bs = As + 32 * F::ROW;
+    float * const dAs = (float *) (Bs + SK_B_BYTES);
+
+    // ---- fetch roles.  Every offset is linear in the fetch index u, so a handful of registers address the whole unit:
+    //   weights, last 8 pieces of a row (Q4_K / Q5_K: the 128 qs bytes): u = 0..3, row = (lane >> 3) + 8 u, piece = HEAD + (lane & 7)
+    //   weights, first HEAD pieces of a row (header, Q5_K: + qh): piece index lane + 64 u over 32 * HEAD
+    //   Q6_K: a 256-byte window per row (16 pieces; the block is 210 bytes, the tail belongs to the next block): u = 0..7,
+    //         row = (lane >> 4) + 4 u, piece = lane & 15
+    //   activations: qs u = 0..7, token = (lane >> 4) + 4 u, piece = lane & 15; bsums: token = lane >> 1, piece 16 + (lane & 1)
+    // Tokens >= M are fetched like the others (the caller's activation area holds 32 tokens' worth of bytes) and never stored.
+    constexpr int HEAD = QT == 6 ? 0 : F::PIECES - 8;
+    constexpr int NLT = QT == 6 ? 8 : 4;
+    constexpr int NLH = (32 * HEAD + 63) / 64;
+    constexpr int NLA = NLT + NLH;
+    const int at_off = QT == 6 ? (lane >> 4) * w_nb1 + (lane & 15) * 16 : (lane >> 3) * w_nb1 + (HEAD + (lane & 7)) * 16;
+    const int at_lds = QT == 6 ? (lane >> 4) * F::ROW + (lane & 15) * 16 : (lane >> 3) * F::ROW + (HEAD + (lane & 7)) * 16;
+    const int at_step = (QT == 6 ? 4 : 8) * w_nb1;
+    constexpr int at_lstep = (QT == 6 ? 4 : 8) * F::ROW;
+    int ah_off[NLH > 0 ? NLH : 1], ah_lds[NLH > 0 ? NLH : 1];
+#pragma unroll
+    for (int u = 0; u < NLH; ++u) {
+        const int pi = min(lane + 64 * u, 32 * HEAD - 1);
+        const int r = pi / (HEAD > 0 ? HEAD : 1), pc = pi - r * HEAD;
+        ah_off[u] = r * w_nb1 + pc * 16;
+        ah_lds[u] = r * F::ROW + pc * 16;
+    }
+    const bool ah_last_live = ((32 * HEAD) % 64) == 0 || lane < ((32 * HEAD) % 64);
+    const char * const act_base = (const char *) a.act;
+    const int tok_bytes = nblk * (int) sizeof(q8k_dev);
+    const int bq_off = (lane >> 4) * tok_bytes + (lane & 15) * 16, bq_lds = (lane >> 4) * SK_BTOK + (lane & 15) * 16;
+    const int bq_step = 4 * tok_bytes;
+    const int bs_off = (lane >> 1) * tok_bytes + 256 + (lane & 1) * 16, bs_lds = (lane >> 1) * SK_BTOK + 256 + (lane & 1) * 16;
+    const int d_off = row * tok_bytes + 304;  // q8k_dev::d
+
+    const int16s zeroi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float16s zerof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+#define MAT_OF(t) ((a.n_mat > 2 && (t) >= a.mat[2].panel0) ? 2 : ((a.n_mat > 1 && (t) >= a.mat[1].panel0) ? 1 : 0))
+#define MAT_SEL(mi, f) ((mi) == 0 ? a.mat[0].f : ((mi) == 1 ? a.mat[1].f : a.mat[2].f))
+    // first row of the tile of an item (wave-uniform: scalar registers)
+    auto item_rows = [&](const int item) -> const uint8_t * {
+        const int tile = item >> ksl, mi = MAT_OF(tile);
+        return MAT_SEL(mi, W) + (size_t) (tile - MAT_SEL(mi, panel0)) * 32 * (size_t) w_nb1;
+    };
+    auto item_lo = [&](const int item) { return ((item & (a.ksplit - 1)) * nblk) >> ksl; };
+    auto item_hi = [&](const int item) { return (((item & (a.ksplit - 1)) + 1) * nblk) >> ksl; };
+
+    u32x4s ga[NLA], gb[9];
+    float gd = 0.0f;
+    // (a straight-line macro, not a lambda: register arrays captured by reference end up in scratch memory)
+#define SK_ISSUE(rows, sb)                                                                                              \
+    {                                                                                                                   \
+        const uint8_t * wb = (rows) + (QT == 6 ? (size_t) (sb) * 210 - 2 * ((sb) & 1) : (size_t) (sb) * F::BYTES);      \
+        _Pragma("unroll") for (int u = 0; u < NLT; ++u) ga[u] = *(const u32x4s *) (wb + at_off + u * at_step);          \
+        _Pragma("unroll") for (int u = 0; u < NLH; ++u) ga[NLT + u] = *(const u32x4s *) (wb + ah_off[u]);               \
+        const char * ab = act_base + (size_t) (sb) * sizeof(q8k_dev);                                                   \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) gb[u] = *(const u32x4s *) (ab + bq_off + u * bq_step);            \
+        gb[8] = *(const u32x4s *) (ab + bs_off);                                                                        \
+        gd = *(const float *) (ab + d_off);                                                                             \
+    }
+    // the unit whose loads are in flight: (nx_item, nx_sb); wave w takes super-blocks lo + w, lo + w + 8, .. of every item
+    int nx_item = blockIdx.x, nx_sb = 0;
+#define SK_NORMALISE()                                                                 \
+    while (nx_item < n_items && nx_sb >= item_hi(nx_item)) {                           \
+        nx_item += gridDim.x;                                                          \
+        if (nx_item < n_items) nx_sb = item_lo(nx_item) + wave;                        \
+    }
+    if (nx_item < n_items) nx_sb = item_lo(nx_item) + wave;
+    SK_NORMALISE()
+    if (nx_item < n_items) SK_ISSUE(item_rows(nx_item), nx_sb)
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        while (nx_item == item) {
+            const int sb = nx_sb;
+            // ---- registers -> the wave's LDS area
+            if constexpr (QT == 6) {
+                const int sh = 2 * (sb & 1);  // the block starts `sh` bytes into the fetched window
+#pragma unroll
+                for (int u = 0; u < NLT; ++u) {
+                    const uint32_t nx = (uint32_t) __shfl_down((int) ga[u].x, 1);  // first dword of the row's next piece
+                    u32x4s o;
+                    o.x = __builtin_amdgcn_alignbyte(ga[u].y, ga[u].x, sh);
+                    o.y = __builtin_amdgcn_alignbyte(ga[u].z, ga[u].y, sh);
+                    o.z = __builtin_amdgcn_alignbyte(ga[u].w, ga[u].z, sh);
+                    o.w = __builtin_amdgcn_alignbyte(nx, ga[u].w, sh);
+                    if ((lane & 15) < 14) *(u32x4s *) (As + at_lds + u * at_lstep) = o;  // 14 pieces cover the 210 bytes
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NLT; ++u) *(u32x4s *) (As + at_lds + u * at_lstep) = ga[u];
+#pragma unroll
+                for (int u = 0; u < NLH; ++u)
+                    if (u + 1 < NLH || ah_last_live) *(u32x4s *) (As + ah_lds[u]) = ga[NLT + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) *(u32x4s *) (Bs + bq_lds + u * 4 * SK_BTOK) = gb[u];
+            *(u32x4s *) (Bs + bs_lds) = gb[8];
+            if (g == 0) dAs[row] = gd;
+            // ---- the next unit's loads (of this item or of the workgroup's next one) fly while this one is multiplied
+            nx_sb += SK_NW;
+            SK_NORMALISE()
+            if (nx_item < n_items) SK_ISSUE(item_rows(nx_item), nx_sb)
+
+            const char * const arow = As + row * F::ROW;   // this lane's weight row (B operand: n = row)
+            const char * const btok = Bs + row * SK_BTOK;  // this lane's token (A operand: m = token)
+            int16s isum = zeroi, isum2 = zeroi;
+            float16s ms;
+            float d, dmin = 0.0f;
+            if constexpr (QT == 4 || QT == 5) {
+                const uint4 hdr = *(const uint4 *) arow;
+                d = h2f((uint16_t) (hdr.x & 0xFFFF));
+                dmin = h2f((uint16_t) (hdr.x >> 16));
+                int sc[8], mn[8];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) k4_scale_pair(hdr.y, hdr.z, hdr.w, p, sc[2 * p], sc[2 * p + 1], mn[2 * p], mn[2 * p + 1]);
+                uint4 qh = make_uint4(0, 0, 0, 0);
+                if constexpr (QT == 5) qh = *(const uint4 *) (arow + 16 + 16 * g);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const uint4 raw = *(const uint4 *) (arow + (QT == 5 ? 48 : 16) + 32 * p + 16 * g);
+                    int4s wlo, whi;
+                    wlo[0] = (int) (raw.x & 0x0F0F0F0Fu); wlo[1] = (int) (raw.y & 0x0F0F0F0Fu); wlo[2] = (int) (raw.z & 0x0F0F0F0Fu); wlo[3] = (int) (raw.w & 0x0F0F0F0Fu);
+                    whi[0] = (int) ((raw.x >> 4) & 0x0F0F0F0Fu); whi[1] = (int) ((raw.y >> 4) & 0x0F0F0F0Fu);
+                    whi[2] = (int) ((raw.z >> 4) & 0x0F0F0F0Fu); whi[3] = (int) ((raw.w >> 4) & 0x0F0F0F0Fu);
+                    if constexpr (QT == 5) {
+                        const uint32_t h4[4] = {qh.x, qh.y, qh.z, qh.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            wlo[k] |= (int) (((h4[k] >> (2 * p)) & 0x01010101u) << 4);
+                            whi[k] |= (int) (((h4[k] >> (2 * p + 1)) & 0x01010101u) << 4);
+                        }
+                    }
+                    const int4s y0 = *(const int4s *) (btok + 64 * p + 16 * g);
+                    const int4s y1 = *(const int4s *) (btok + 64 * p + 32 + 16 * g);
+                    const int16s t0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(y0, wlo, zeroi, 0, 0, 0);
+                    const int16s t1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(y1, whi, zeroi, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {  // (two accumulators: one v_mad_i32_i24 per product; summed into one the compiler
+                        isum[i] += __mul24(t0[i], sc[2 * p]);      // emits two multiplies and a three-operand add instead)
+                        isum2[i] += __mul24(t1[i], sc[2 * p + 1]);
+                    }
+                }
+                // mins: sum_j m_j * (sum of the 32 activations of sub-block j) = sum over the sixteen 16-value bsums with m_{k/2}
+                const half8s bsf = *(const half8s *) (btok + 256 + 16 * g);
+                const int m0 = g ? mn[4] : mn[0], m1 = g ? mn[5] : mn[1], m2 = g ? mn[6] : mn[2], m3 = g ? mn[7] : mn[3];
+                const uint4 mfu = make_uint4(sk_pack_h2((float) m0, (float) m0), sk_pack_h2((float) m1, (float) m1), sk_pack_h2((float) m2, (float) m2), sk_pack_h2((float) m3, (float) m3));
+                ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, __builtin_bit_cast(half8s, mfu), zerof, 0, 0, 0);
+            } else {
+                const uint4 scb = *(const uint4 *) (arow + 192);
+                d = h2f(*(const uint16_t *) (arow + 208));
+                const uint32_t scw[4] = {scb.x, scb.y, scb.z, scb.w};
+                int sc[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) sc[s] = (int) (int8_t) (scw[s >> 2] >> (8 * (s & 3)));
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        // l = 16 t + 8 g .. + 7 of half h: ql[64h + l], ql[64h + 32 + l], qh[32h + l] carry the four sub-blocks 8h + 2k + t
+                        const uint2 qa = *(const uint2 *) (arow + 64 * h + 16 * t + 8 * g);
+                        const uint2 qb = *(const uint2 *) (arow + 64 * h + 32 + 16 * t + 8 * g);
+                        const uint2 qc = *(const uint2 *) (arow + 128 + 32 * h + 16 * t + 8 * g);
+                        int2s v[4];
+                        v[0][0] = (int) ((qa.x & 0x0F0F0F0Fu) | ((qc.x << 4) & 0x30303030u));
+                        v[0][1] = (int) ((qa.y & 0x0F0F0F0Fu) | ((qc.y << 4) & 0x30303030u));
+                        v[1][0] = (int) ((qb.x & 0x0F0F0F0Fu) | ((qc.x << 2) & 0x30303030u));
+                        v[1][1] = (int) ((qb.y & 0x0F0F0F0Fu) | ((qc.y << 2) & 0x30303030u));
+                        v[2][0] = (int) (((qa.x >> 4) & 0x0F0F0F0Fu) | (qc.x & 0x30303030u));
+                        v[2][1] = (int) (((qa.y >> 4) & 0x0F0F0F0Fu) | (qc.y & 0x30303030u));
+                        v[3][0] = (int) (((qb.x >> 4) & 0x0F0F0F0Fu) | ((qc.x >> 2) & 0x30303030u));
+                        v[3][1] = (int) (((qb.y >> 4) & 0x0F0F0F0Fu) | ((qc.y >> 2) & 0x30303030u));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int s = 8 * h + 2 * k + t;
+                            const int2s y = *(const int2s *) (btok + 16 * s + 8 * g);
+                            const int16s tk = __builtin_amdgcn_mfma_i32_32x32x16_i8(__builtin_bit_cast(long, y), __builtin_bit_cast(long, v[k]), zeroi, 0, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) isum[i] += __mul24(tk[i], sc[s]);
+                        }
+                    }
+                // the codes are q + 32: subtract 32 * sum_s sc_s * bsum_s (one f16 MFMA, exact integers)
+                const half8s bsf = *(const half8s *) (btok + 256 + 16 * g);
+                uint4 sfu;
+                sfu.x = g ? sk_pack_h2((float) sc[8], (float) sc[9]) : sk_pack_h2((float) sc[0], (float) sc[1]);
+                sfu.y = g ? sk_pack_h2((float) sc[10], (float) sc[11]) : sk_pack_h2((float) sc[2], (float) sc[3]);
+                sfu.z = g ? sk_pack_h2((float) sc[12], (float) sc[13]) : sk_pack_h2((float) sc[4], (float) sc[5]);
+                sfu.w = g ? sk_pack_h2((float) sc[14], (float) sc[15]) : sk_pack_h2((float) sc[6], (float) sc[7]);
+                ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, __builtin_bit_cast(half8s, sfu), zerof, 0, 0, 0);
+            }
+            // ---- fold the unit: tokens of register i are (i & 3) + 8 (i >> 2) + 4 g
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 dy = *(const float4 *) (dAs + 8 * q + 4 * g);
+                const float dyv[4] = {dy.x, dy.y, dy.z, dy.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * q + r;
+                    float v;
+                    if constexpr (QT == 6) v = d * (float) (isum[i] - 32 * (int) ms[i]);
+                    else v = __builtin_fmaf(-dmin, ms[i], d * (float) (isum[i] + isum2[i]));
+                    acc[i] = __builtin_fmaf(dyv[r], v, acc[i]);
+                }
+            }
+        }
+
+        // ---- the eight K slices of the tile meet in LDS: each wave leaves its 32 x 32 partial [token][row] at the start of its
+        // own area (no other wave touches that), then every thread sums two outputs over the waves in a fixed order
+        float * const own = (float *) As;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) own[((i & 3) + 8 * (i >> 2) + 4 * g) * 32 + row] = acc[i];
+        __syncthreads();
+        const int tile = item >> ksl, ky = item & (a.ksplit - 1), mi = MAT_OF(tile);
+        const int mN = MAT_SEL(mi, N);
+        const int n0 = (tile - MAT_SEL(mi, panel0)) * 32;
+        float * const m_part = MAT_SEL(mi, part);
+        float * const m_dst = MAT_SEL(mi, dst);
+        const int64_t m_dst_stride = MAT_SEL(mi, dst_stride);
+        const float * const m_add = MAT_SEL(mi, add);
+        const int64_t m_add_stride = MAT_SEL(mi, add_stride);
+#pragma unroll
+        for (int q = 0; q < 1024 / (SK_NW * 64); ++q) {
+            const int o = tid + q * SK_NW * 64;
+            const int tok = o >> 5, n = n0 + (o & 31);
+            float v = *(const float *) (smem + o * 4);
+#pragma unroll
+            for (int w = 1; w < SK_NW; ++w) v += *(const float *) (smem + w * sk_wave_lds<QT>() + o * 4);
+            if (tok >= a.M) continue;
+            if (a.ksplit > 1) m_part[((size_t) ky * a.M + tok) * mN + n] = v;
+            else {
+                if (m_add) v += m_add[(size_t) tok * m_add_stride + n];
+                m_dst[(size_t) tok * m_dst_stride + n] = v;
+            }
+        }
+        __syncthreads();  // the areas are free for the next item's units
+    }
+#undef SK_ISSUE
+#undef SK_NORMALISE
+#undef MAT_SEL
+#undef MAT_OF
+}
+
+bool mmq_skinny_supported(int type, int64_t K, int64_t N, int64_t M, int64_t w_nb1) {
+    if (M < 2 || M > 32 || (K % 256) != 0 || (N % 32) != 0) return false;  // whole 32-row tiles (every model dimension is one)
+    // rows packed back to back (then every matrix of a launch has the same row stride)
+    if (type == GGML_TYPE_Q4_K) return w_nb1 == (K / 256) * 144;
+    if (type == GGML_TYPE_Q5_K) return w_nb1 == (K / 256) * 176;
+    if (type == GGML_TYPE_Q6_K) return w_nb1 == (K / 256) * 210 && (w_nb1 % 4) == 0;  // dword-aligned rows: the 0 / 2-byte shift of a super-block is the same in every row
+    return false;
+}
+
+// workgroups = 32-row tiles x ksplit: split K only while the tiles alone leave CUs without a workgroup
+int mmq_skinny_ksplit(int64_t K, int64_t n_total) {
+    const int64_t tiles = (n_total + 31) / 32, nblk = K / 256;
+    int ks = 1;
+    while (tiles * ks < 200 && ks * 2 <= 8 && nblk / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
+
+template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
+    const size_t lds = (size_t) SK_NW * sk_wave_lds<QT>();
+    static std::atomic<uint32_t> lds_raised{0};
+    (void) ensure_dyn_lds((const void *) k_mmq_skinny<QT>, lds, lds_raised);
+    a.n_panels = 0;
+    for (int i = 0; i < a.n_mat; ++i) {
+        a.mat[i].panel0 = a.n_panels;
+        a.n_panels += a.mat[i].N / 32;
+    }
+    a.m_tiles = 1;
+    // one workgroup per CU (its LDS areas fill the CU), walking the (tile, K slice) items with a stride of the grid
+    int dev = 0;
+    static std::atomic<int> n_cu{0};
+    if (n_cu.load(std::memory_order_relaxed) == 0) {
+        int v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        n_cu.store(v > 0 ? v : 256, std::memory_order_relaxed);
+    }
+    const int items = a.n_panels * a.ksplit;
+    hipLaunchKernelGGL((k_mmq_skinny<QT>), dim3((unsigned) std::min(items, n_cu.load(std::memory_order_relaxed))), dim3(SK_NW * 64), lds, s, a);
+}
+
+void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a) {
+    if (type == GGML_TYPE_Q4_K) launch_skinny_t<4>(s, a);
+    else if (type == GGML_TYPE_Q5_K) launch_skinny_t<5>(s, a);
+    else launch_skinny_t<6>(s, a);
+}
+
+}  // namespace mi355x

@@ -133,6 +133,45 @@ def test_sibling_mul_mats_share_a_launch(backend, H, plog, qt, M, bias):
         T.compare(f"sibling mat-muls {QNAME[qt]} M={M} bias={bias} {name} vs one by one", a, c, max_nmse=1e-12, log=plog)
 
 
+@pytest.mark.parametrize("qt", [L.Q4_K, L.Q5_K, L.Q6_K])
+@pytest.mark.parametrize("K,N,M,epi", [
+    (512, 32, 3, "none"), (512, 64, 32, "bias"), (1024, 96, 9, "res"), (4096, 512, 32, "res"), (4096, 512, 17, "none"),
+    (14336, 128, 32, "res"), (2048, 4096, 32, "bias"), (2048, 4096, 5, "none"), (3584, 608, 31, "res"), (8192, 256, 32, "none"),
+])
+def test_mul_mat_q_skinny_batches(backend, H, plog, qt, K, N, M, epi):
+    """2..32 columns (a decode step of `-np` parallel sequences): the weight-streaming matrix-core kernel (mmq_skinny.hip) —
+    one workgroup per 32-row tile, eight waves over the super-blocks, K split across workgroups when the tiles alone do not
+    fill the chip (N = 4096 at K = 2048: two K halves, summed by the reduce pass).  Same integer block sums as ggml-cpu's
+    vec_dot_q*_K_q8_K; the gate is the per-op one.  Also against the tiled GEMM it replaces (mmq_skinny = 0)."""
+    rng = np.random.default_rng(K * 31 + N * 7 + M + qt)
+    w = T.rand_weight(qt, K, N, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    x[M - 1, :256] = 0.0
+    addend = rng.standard_normal((M, N) if epi == "res" else (N,)).astype(np.float32)
+
+    def build(g):
+        r = H.ggml_mul_mat(g.ctx, g.new(qt, [K, N], w), g.new(L.F32, [K, M], x))
+        if epi == "bias":
+            r = H.ggml_add(g.ctx, r, g.new(L.F32, [N], addend))
+        elif epi == "res":
+            r = H.ggml_add(g.ctx, r, g.new(L.F32, [N, M], addend))
+        return r
+
+    ref = T.run_case(build, "oracle")
+    s0 = backend.stat("skinny_launches")
+    got = T.run_case(build, backend)
+    served = backend.stat("skinny_launches") - s0
+    expect = 0 if (qt == L.Q6_K and (K // 256) % 2) else 1  # Q6_K rows of an odd number of 210-byte blocks are not dword-aligned
+    assert served == expect, f"skinny kernel served {served} launches, expected {expect}"
+    T.compare(f"mul_mat skinny {QNAME[qt]} K={K} N={N} M={M} {epi}", got[0], ref[0], max_nmse=1e-10, log=plog)
+    backend.set_option("mmq_skinny", 0)
+    try:
+        tiled = T.run_case(build, backend)
+    finally:
+        backend.set_option("mmq_skinny", 1)
+    T.compare(f"mul_mat skinny {QNAME[qt]} K={K} N={N} M={M} {epi} vs tiled GEMM", got[0], tiled[0], max_nmse=1e-12, log=plog)
+
+
 def _random_mm_shapes():
     rng = np.random.default_rng(2024)
     out = []
