@@ -303,7 +303,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     c->device = d->device;
     c->name = d->name;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->fa_lists_bytes = (size_t) 1 << 20;
+    c->fa_lists_bytes = (size_t) 8 << 20;  // visible-position lists of a small batch: (n_kv + 1) ints per query token
     if (hipMalloc((void **) &c->fa_lists, c->fa_lists_bytes) != hipSuccess) { (void) hipGetLastError(); c->fa_lists = nullptr; c->fa_lists_bytes = 0; }
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->opt.graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->opt.fusion = atoi(e) != 0;

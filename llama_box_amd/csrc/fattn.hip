@@ -252,9 +252,11 @@ __device__ __forceinline__ float xrow_allmax(const float x) {
 // Q8 = true: K and V rows are block_q8_0 (quantised KV cache, -ctk/-ctv q8_0).  As in ggml-cpu the query is quantised to Q8_0
 // too (K's vec_dot_type), a score is sum over the four 32-value blocks of sumi * (d_k * d_q) with an integer block sum, and a
 // V row is de-quantised (q * d) and accumulated in f32.  A lane still owns 8 dims: 8 int8 of one block (lanes 4b..4b+3 = block b).
-// MODE 2 (LIST): the visible tiles of every query token were listed once per graph by k_fattn_tile_scan (the mask is the same
-// tensor in every layer); split s of token t walks its share of THAT list, so the work is proportional to what the token can
-// see, not to the size of the unified cache, and no workgroup is launched just to find out that it has nothing to do.
+// MODE 2 (LIST): the visible POSITIONS of every query token were listed once per graph by k_fattn_pos_scan (the mask is the same
+// tensor in every layer); split s of token t walks its share of THAT list, a trip = the next NG*16 listed positions, so the work
+// is proportional to what the token can see, not to the size of the unified cache nor to how its cells are scattered in it (the
+// decode cells of `-np 32` sequences interleave: every 64-cell tile of that region holds two cells of each sequence, and a list
+// of visible TILES — round 1 — made every token walk all of them: 10 us at the first step, 24 us sixty steps later).
 // WV = waves per workgroup: 4 (many thin splits + combine pass) or 8 (few fat splits whose partials the wo mat-vec prologue combines:
 // mmvq.hip PRO 3; 16 waves would cap the kernel at 128 VGPRs, and it needs ~200: the first 16-wave build spilled and ran 2x slower)
 template <int G, int MODE, bool Q8, int WV = 4>
@@ -276,15 +278,17 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     // if not: of the 64 x 32 (split, token) pairs of a -np 32 decode step only ~1/16 touch K/V at all
     const int tok = (int) blockIdx.z % geo.n_q, bat = (int) blockIdx.z / geo.n_q;
     const int per = SKIP ? ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64 : (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
-    const int kv0 = LIST ? 0 : min(split * per, geo.n_kv), kv1 = LIST ? geo.n_kv : min(geo.n_kv, kv0 + per);
-    const int * tl = nullptr;  // LIST: this token's visible tiles (tile = the NG*16 positions of one trip), entries [ti, ti1) are ours
-    int ti = 0, ti1 = 0;
+    const int kv0 = LIST ? 0 : min(split * per, geo.n_kv);
+    int kv1 = LIST ? 0 : min(geo.n_kv, kv0 + per);  // LIST: positions are list ENTRIES, [0, cnt)
+    const int * tl = nullptr;  // LIST: this token's visible positions, ascending; trips [ti, ti1) of TRIP entries each are ours
+    int ti = 0, ti1 = 0, cnt = 0;
     if constexpr (LIST) {
         const int * lt = lists + (int64_t) tok * list_stride;
-        const int cnt = lt[0], share = (cnt + geo.n_splits - 1) / geo.n_splits;
+        cnt = lt[0];
+        const int trips = (cnt + TRIP - 1) / TRIP, share = (trips + geo.n_splits - 1) / geo.n_splits;
         tl = lt + 1;
         ti = split * share;
-        ti1 = min(cnt, ti + share);
+        ti1 = min(trips, ti + share);
         if (ti >= ti1) {
             if (geo.n_splits == 1) {
                 // a token that sees nothing and no combine pass to say so: the CPU's result for such a row is 0 * (1 / 0) = NaN
@@ -299,6 +303,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             }
             return;
         }
+        kv1 = cnt;
     }
     const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
     if constexpr (SKIP) {
@@ -328,11 +333,12 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     uint4 kraw[NG], vraw[NG];
     float mvl = 0.0f;   // mask value / validity of THIS lane's pair (ul, sub)
     bool okl = false;
-    int p0 = LIST ? tl[ti] * TRIP : kv0;
+    int p0 = LIST ? ti * TRIP : kv0;
 #define FA_LOAD_TRIP()                                                                  \
     {                                                                                   \
         _Pragma("unroll") for (int u = 0; u < NG; ++u) {                               \
-            const int pc = min(p0 + u * (WV * 4) + wave * 4 + sub, kv1 - 1);                  \
+            const int pe_ = min(p0 + u * (WV * 4) + wave * 4 + sub, kv1 - 1);           \
+            const int pc = LIST ? tl[pe_] : pe_;                                        \
             const char * kp_ = kbase + (int64_t) pc * k.nb[1];                          \
             const char * vp_ = vbase + (int64_t) pc * v.nb[1];                          \
             if constexpr (Q8) {  /* 8 quants (2-byte aligned) + the block's f16 scale */  \
@@ -345,7 +351,8 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         }                                                                               \
         const int pl = p0 + ul * (WV * 4) + wave * 4 + sub;                             \
         okl = pl < kv1;                                                                 \
-        mvl = mp ? h2f(mp[min(pl, kv1 - 1)]) : 0.0f;                                    \
+        const int plc_ = min(pl, kv1 - 1);                                              \
+        mvl = mp ? h2f(mp[LIST ? tl[plc_] : plc_]) : 0.0f;                              \
     }
     uint32_t vis = 0xFFFFFFFFu;  // bit i: trip i has a position this wave can see
     if constexpr (SKIP) {
@@ -415,7 +422,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         int p_next = p0 + TRIP;
         if constexpr (LIST) {
             ++ti;
-            p_next = ti < ti1 ? tl[ti] * TRIP : kv1;
+            p_next = ti < ti1 ? ti * TRIP : kv1;
         }
         if constexpr (SKIP) {
             if (!((vis >> trip) & 1u)) {  // nothing visible: only keep the pipeline primed for the next trip
@@ -739,44 +746,46 @@ template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, co
     }
 }
 
-// ---- tile lists: for every query token, the tiles (runs of `tile` cache cells) in which its mask row has anything but -inf, in
-// ascending order; lists[t * stride] = count, entries follow.  One workgroup per token; ordered compaction by ballots.
-__global__ void __launch_bounds__(256) k_fattn_tile_scan(const tdesc mask, const int n_kv, const int tile, int * __restrict__ lists, const int stride) {
+// ---- position lists: for every query token, the cache cells at which its mask row holds anything but -inf, in ascending order;
+// lists[t * stride] = count, entries follow (stride = n_kv + 1).  One workgroup per token, four cells per thread and pass,
+// ordered compaction by a wave prefix sum over the per-thread counts.
+__global__ void __launch_bounds__(256) k_fattn_pos_scan(const tdesc mask, const int n_kv, int * __restrict__ lists, const int stride) {
     __shared__ int wcnt[4];
     const int tok = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1]);
-    int * out = lists + (int64_t) tok * stride;
-    const int n_tiles = (n_kv + tile - 1) / tile;
+    int * out = lists + (int64_t) tok * stride + 1;
     int base = 0;
-    for (int t0 = 0; t0 < n_tiles; t0 += 256) {
-        const int t = t0 + tid;
-        bool vis = false;
-        if (t < n_tiles) {
-            for (int c = 0; c < tile; c += 4) {
-                const int pp = t * tile + c;
-                if (pp < n_kv) {  // n_kv is a multiple of 4 (launcher): the four cells are in range together
-                    const uint2 w = *(const uint2 *) (mrow + pp);
-                    vis = vis || w.x != 0xFC00FC00u || w.y != 0xFC00FC00u;
-                }
-            }
+    for (int c0 = 0; c0 < n_kv; c0 += 1024) {
+        const int pp = c0 + 4 * tid;
+        uint2 w = make_uint2(0xFC00FC00u, 0xFC00FC00u);
+        if (pp < n_kv) w = *(const uint2 *) (mrow + pp);  // n_kv is a multiple of 4 (checked by fattn_list_tile): the four cells are in range together
+        const bool v0 = (w.x & 0xFFFFu) != 0xFC00u, v1 = (w.x >> 16) != 0xFC00u, v2 = (w.y & 0xFFFFu) != 0xFC00u, v3 = (w.y >> 16) != 0xFC00u;
+        const int mine = (int) v0 + (int) v1 + (int) v2 + (int) v3;
+        int incl = mine;  // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
         }
-        const unsigned long long bal = __ballot(vis);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wcnt[wave] = __popcll(bal);
+        if (lane == 63) wcnt[wave] = incl;
         __syncthreads();
         int woff = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            woff += w < wave ? wcnt[w] : 0;
-            tot += wcnt[w];
+        for (int wv = 0; wv < 4; ++wv) {
+            woff += wv < wave ? wcnt[wv] : 0;
+            tot += wcnt[wv];
         }
-        if (vis) out[1 + base + woff + before] = t;
+        int o = base + woff + incl - mine;
+        if (v0) out[o++] = pp;
+        if (v1) out[o++] = pp + 1;
+        if (v2) out[o++] = pp + 2;
+        if (v3) out[o++] = pp + 3;
         base += tot;
         __syncthreads();
     }
-    if (tid == 0) out[0] = base;
+    if (tid == 0) out[-1] = base;
 }
-// tile size of the list kernel for this attention shape, or 0 when it does not apply (then `lists` is not used)
+// does the position-list kernel apply to this attention shape?  Returns 1 (the scan granule: single cells) or 0 (`lists` is not used)
 int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const fattn_params & p, size_t lists_bytes) {
     const int64_t n_q = q.ne[1];
     const int G = k.ne[2] > 0 ? (int) (q.ne[2] / k.ne[2]) : 0;
@@ -784,14 +793,12 @@ int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const 
     if (!on || n_q < 2 || n_q >= fattn_mma_min_q() || !mask || q.ne[3] != 1 || mask->ne[3] != 1 || k.ne[0] != 128) return 0;
     if (p.logit_softcap != 0.0f || p.max_bias != 0.0f || !(G == 2 || G == 4 || G == 7 || G == 8) || p.n_splits < 1) return 0;
     if ((k.ne[1] % 4) != 0 || (mask->nb[1] % 8) != 0 || ((uintptr_t) mask->data & 7) != 0 || mask->type != GGML_TYPE_F16) return 0;
-    const int tile = 16 * (16 / (G == 7 ? 8 : G));
-    const int64_t stride = (k.ne[1] + tile - 1) / tile + 1;
-    if ((size_t) (n_q * stride) * sizeof(int) > lists_bytes) return 0;
-    return tile;
+    if ((size_t) (n_q * (k.ne[1] + 1)) * sizeof(int) > lists_bytes) return 0;
+    return 1;
 }
 void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, int tile, int * lists) {
-    const int stride = (n_kv + tile - 1) / tile + 1;
-    hipLaunchKernelGGL(k_fattn_tile_scan, dim3((unsigned) n_q), dim3(256), 0, s, mask, n_kv, tile, lists, stride);
+    (void) tile;
+    hipLaunchKernelGGL(k_fattn_pos_scan, dim3((unsigned) n_q), dim3(256), 0, s, mask, n_kv, lists, n_kv + 1);
 }
 
 // will launch_flash_attn end in the quantising combine pass for these arguments? (mirrors its dispatch)
@@ -861,9 +868,9 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         // several query tokens with a mask: skip the KV trips a token cannot see — needs splits of at most 32 trips
         const int per = ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64;
         static const bool skip_on = !getenv("GGML_MI355X_FA_SKIP") || atoi(getenv("GGML_MI355X_FA_SKIP")) != 0;
-        // p.lists set: the caller has run (or re-used) k_fattn_tile_scan for this mask with the tile size fattn_list_tile() gave
+        // p.lists set: the caller has run (or re-used) k_fattn_pos_scan for this mask (fattn_list_tile() said the list form applies)
         const bool list = p.lists != nullptr;
-        const int lstride = (geo.n_kv + 16 * (16 / (G == 7 ? 8 : G)) - 1) / (16 * (16 / (G == 7 ? 8 : G))) + 1;
+        const int lstride = geo.n_kv + 1;
         const bool skip = !list && skip_on && geo.n_q > 1 && (geo.n_q <= 64 || q8) && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
                           (mask->nb[3] % 8) == 0 && ((uintptr_t) mask->data & 7) == 0 && geo.n_splits > 1;
 #define FA_DEC(GG)                                                                                                                          \

@@ -179,7 +179,7 @@ struct fattn_params {
     int fat = 0;   // 1: single-token decode as a few fat splits on 8-wave workgroups, records FA_REC apart, NO combine pass (the wo
                    // mat-vec prologue merges them: mmvq_args::fa_part); see fattn_fat_splits()
     int kv_type;   // GGML_TYPE_F16 or GGML_TYPE_Q8_0 (K and V alike)
-    const int * lists = nullptr;  // per-token lists of visible tiles (launch_fattn_tile_scan), or nullptr
+    const int * lists = nullptr;  // per-token lists of visible cache positions (launch_fattn_tile_scan), or nullptr
     void * q8_out = nullptr;  // the result's only readers are quantised mat-muls (wo of a batch): leave it as Q8_K blocks here — honoured by
                               // the combine pass of the head_dim-128 kernels (n_splits > 1), see fattn_q8_out_ok()
     const uint8_t * tile_vis = nullptr;  // matrix-core kernel: [q tile of 32][kv tile of 64] visibility bytes (launch_fattn_vis_scan), or nullptr
