@@ -178,6 +178,7 @@ static void be_free(ggml_backend_t be) {
     if (c->ws) HIP_CHECK(hipFree(c->ws));
     if (c->up_ring) HIP_CHECK(hipHostFree(c->up_ring));
     if (c->fa_lists) HIP_CHECK(hipFree(c->fa_lists));
+    if (c->fa_arrive) HIP_CHECK(hipFree(c->fa_arrive));
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c;
     delete be;
@@ -305,6 +306,10 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->fa_lists_bytes = (size_t) 8 << 20;  // visible-position lists of a small batch: (n_kv + 1) ints per query token
     if (hipMalloc((void **) &c->fa_lists, c->fa_lists_bytes) != hipSuccess) { (void) hipGetLastError(); c->fa_lists = nullptr; c->fa_lists_bytes = 0; }
+    if (hipMalloc((void **) &c->fa_arrive, backend_ctx::fa_arrive_slots * sizeof(unsigned)) != hipSuccess || hipMemset(c->fa_arrive, 0, backend_ctx::fa_arrive_slots * sizeof(unsigned)) != hipSuccess) {
+        (void) hipGetLastError();
+        c->fa_arrive = nullptr;
+    }
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->opt.graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->opt.fusion = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_PROLOGUE")) c->opt.prologue = atoi(e) != 0;
@@ -317,6 +322,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_MM_MERGE")) c->opt.mm_merge = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_BN")) c->opt.mmq_bn = atoi(e);
     if (const char * e = getenv("GGML_MI355X_MMQ_SKINNY")) c->opt.mmq_skinny = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_FA_SELF_MERGE")) c->opt.fa_self_merge = atoi(e) != 0;
     return new ggml_backend{&g_guid, k_backend_iface, dev, c};
 }
 static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &dctx(dev)->buft; }
@@ -379,6 +385,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "mm_merge") c->opt.mm_merge = v != 0;
     else if (k == "mmq_bn") c->opt.mmq_bn = v;
     else if (k == "mmq_skinny") c->opt.mmq_skinny = v != 0;
+    else if (k == "fa_self_merge") c->opt.fa_self_merge = v != 0;
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "fa_wo") c->opt.fa_wo = v != 0;
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;

@@ -72,6 +72,9 @@ struct options {
     int mmq_min_cols = 3;      // batches at least this wide run on the matrix cores (measured, ms/step matrix cores vs multi-column mat-vec: 3 columns 4.1 / 4.4, 4: 3.9 / 4.2, 8: 4.4 / 5.7; 2 columns: 3.6 / 3.1)
     bool mmq_i8 = true;        // Q4_K/Q5_K batches on the int8 matrix cores (mmq_i8.hip) instead of the f16 variant (mmq.hip)
     bool mm_merge = true;      // batches: sibling mat-muls over the same activations (wq/wk/wv, gate/up) as one launch
+    bool fa_self_merge = false; // split attention (decode): the last split workgroup merges the partial records, no combine launch.  Off: measured
+                               // one token, n_kv 2100: 16.5 us against 7.6 + 5.0 for split + combine (record write-through, counter and re-read are a longer
+                               // dependent chain than a launch); -np 32: 18.3 against 19.6 us per layer (4.45 vs 4.49 ms per step)
     bool mmq_skinny = true;    // 2..32 columns: weight-streaming matrix-core kernel (mmq_skinny.hip) instead of the tiled GEMM
     int mmq_bn = 0;            // force the weight-panel height of mmq_i8 (64 / 128); 0 = pick by grid size
     int fa_splits = 0;         // 0 = auto
@@ -132,6 +135,8 @@ struct backend_ctx {
     upload_batch up_pending{};  // staged in the ring, not yet launched: flushed as ONE kernel before anything else enters the stream
     // attention over a unified cache with a few query tokens: per-token lists of visible tiles (fattn.hip, k_fattn_tile_scan),
     // built once per graph execution and shared by the attention nodes of all layers
+    unsigned * fa_arrive = nullptr;  // arrival counters of the self-merging attention splits (zero between launches)
+    static constexpr int fa_arrive_slots = 16384;
     int * fa_lists = nullptr;
     size_t fa_lists_bytes = 0;
     // per-class kernel timing (bench)

@@ -24,6 +24,9 @@ struct fa_geom {
     int rec_stride;  // floats between the partial records of consecutive splits (D + 2; 132 for the records the wo prologue reads)
     float scale, softcap, max_bias, m0, m1;
     uint32_t n_head_log2;
+    unsigned * arrive;  // != null (lane-parallel decode kernel, n_splits > 1): one counter per (batch, token, kv head); the LAST split workgroup to
+                        // arrive merges the partial records itself — no combine launch (the counter is left at zero again)
+    void * q8;          // with `arrive`: leave the merged result as Q8_K blocks here instead of f32 in dst (see fattn_params::q8_out)
 };
 
 // element-wise all-reduce over the four 16-lane DPP rows of a wave (lane l ends with x[l&15] + x[16+(l&15)] + ...):
@@ -247,6 +250,70 @@ __device__ __forceinline__ float xrow_allmax(const float x) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return fmaxf(a, b);
 }
+// records that another workgroup will read in the SAME launch: agent-scope (sc1, write-through / L1-bypassing) accesses on both sides
+// instead of release / acquire fences — a fence per split workgroup writes the whole L2 back and made the launch 3-5x slower
+__device__ __forceinline__ void st_agent(float * p, const float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Merge of the partial records of `g_real` consecutive heads (head_dim 128) by ONE 4-wave workgroup — what k_fattn_combine does
+// per head in its own launch: wave w takes heads w, w + 4, ..; lane s owns split s for the (max, sum) pairs, every lane two of
+// the 128 values; coefficients come out of their lanes through v_readlane.  q8 != null: the result leaves as Q8_K blocks (two
+// heads each) through `vals` (LDS, g_real * 128 floats), else as f32 rows of dst.
+__device__ __forceinline__ void fa_merge_heads(const float * __restrict__ base0, const int h0, const int g_real, const int n_splits, const float * __restrict__ sinks, const tdesc & dst,
+                                               const int tok, const int bat, q8k_dev * __restrict__ q8, float * __restrict__ vals) {
+    constexpr int D = 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (q8) __syncthreads();  // `vals` aliases the wave-merge buffer: everyone is done reading it
+    for (int g = wave; g < g_real; g += 4) {
+        const float * __restrict__ base = base0 + (int64_t) g * n_splits * (D + 2);
+        const bool has = lane < n_splits;
+        const float ms = has ? ld_agent(base + (int64_t) lane * (D + 2) + D) : -INFINITY;
+        const float ls = has ? ld_agent(base + (int64_t) lane * (D + 2) + D + 1) : 0.0f;
+        float mn = wave_max(ms);
+        float sink_term = 0.0f;
+        if (sinks) {
+            mn = fmaxf(mn, sinks[h0 + g]);
+            sink_term = expf(sinks[h0 + g] - mn);
+        }
+        const float cs = ms == -INFINITY ? 0.0f : expf(ms - mn);
+        const float lt = wave_sum(ls * cs) + sink_term;
+        float a0 = 0.0f, a1 = 0.0f;
+        // (a split that left an empty record — coefficient 0 — may hold anything in its values: select, not multiply)
+        for (int u0 = 0; u0 < n_splits; u0 += 8) {  // eight records in flight per lane
+            float r0[8], r1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int u = min(u0 + k, n_splits - 1);
+                r0[k] = ld_agent(base + (int64_t) u * (D + 2) + lane);
+                r1[k] = ld_agent(base + (int64_t) u * (D + 2) + 64 + lane);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float c = u0 + k < n_splits ? readlane_f32(cs, min(u0 + k, 63)) : 0.0f;
+                a0 += c != 0.0f ? r0[k] * c : 0.0f;
+                a1 += c != 0.0f ? r1[k] * c : 0.0f;
+            }
+        }
+        const float inv = 1.0f / lt;
+        if (q8) {
+            vals[g * D + lane] = a0 * inv;
+            vals[g * D + 64 + lane] = a1 * inv;
+        } else {
+            float * out = (float *) (dst.data + (int64_t) (h0 + g) * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+            out[lane] = a0 * inv;
+            out[64 + lane] = a1 * inv;
+        }
+    }
+    if (q8) {
+        __syncthreads();
+        if (wave < g_real / 2) {  // quantize_row_q8_K of the block (two heads), as k_quantize_q8_K does it
+            const float4 t4 = ((const float4 *) (vals + wave * 256))[lane];
+            const float t[4] = {t4.x, t4.y, t4.z, t4.w};
+            wave_quantize_q8_K(t, lane, q8 + wave);
+        }
+    }
+}
+
 // SKIP = true (several query tokens, e.g. -np 32 decode over a unified cache where each token sees ~1/32 of the cells): the mask
 // of the whole split is read first — one round trip — and trips without a visible position for this wave load no K/V at all.
 // Q8 = true: K and V rows are block_q8_0 (quantised KV cache, -ctk/-ctv q8_0).  As in ggml-cpu the query is quantised to Q8_0
@@ -282,6 +349,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     int kv1 = LIST ? 0 : min(geo.n_kv, kv0 + per);  // LIST: positions are list ENTRIES, [0, cnt)
     const int * tl = nullptr;  // LIST: this token's visible positions, ascending; trips [ti, ti1) of TRIP entries each are ours
     int ti = 0, ti1 = 0, cnt = 0;
+    bool empty = false;
     if constexpr (LIST) {
         const int * lt = lists + (int64_t) tok * list_stride;
         cnt = lt[0];
@@ -298,10 +366,11 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
                 }
             } else if (tid < g_real) {
                 float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + kvh * g_real + tid) * geo.n_splits + split) * (128 + 2);
-                rec[128] = -INFINITY;
-                rec[129] = 0.0f;
+                if (geo.arrive) { st_agent(rec + 128, -INFINITY); st_agent(rec + 129, 0.0f); }
+                else { rec[128] = -INFINITY; rec[129] = 0.0f; }
             }
-            return;
+            if (geo.n_splits == 1 || !geo.arrive) return;
+            empty = true;  // (still has to arrive: it may be the workgroup that merges the records)
         }
         kv1 = cnt;
     }
@@ -319,12 +388,14 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         if (!__any(any)) {  // every wave reaches the same verdict: no barrier has been passed yet
             if (tid < g_real) {
                 float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + kvh * g_real + tid) * geo.n_splits + split) * (D + 2);
-                rec[D] = -INFINITY;
-                rec[D + 1] = 0.0f;
+                if (geo.arrive) { st_agent(rec + D, -INFINITY); st_agent(rec + D + 1, 0.0f); }
+                else { rec[D] = -INFINITY; rec[D + 1] = 0.0f; }
             }
-            return;
+            if (!geo.arrive) return;
+            empty = true;
         }
     }
+    if (!empty) {
     const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
     const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + (Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
     const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + (Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
@@ -586,11 +657,38 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             out[dd] = a * (1.0f / lt);
         } else {
             float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits + split) * geo.rec_stride;
-            rec[dd] = a;
-            if (dd == 0) {
-                rec[D] = mt_e;
-                rec[D + 1] = lt;
+            if (WV == 4 && geo.arrive) {
+                st_agent(rec + dd, a);
+                if (dd == 0) { st_agent(rec + D, mt_e); st_agent(rec + D + 1, lt); }
+            } else {
+                rec[dd] = a;
+                if (dd == 0) {
+                    rec[D] = mt_e;
+                    rec[D + 1] = lt;
+                }
             }
+        }
+    }
+    }  // !empty
+    if constexpr (WV == 4) {
+        if (geo.n_splits > 1 && geo.arrive) {
+            // ---- the last split workgroup of this (token, kv head) to get here merges all records.  Our record went out with agent-scope
+            // stores; once they have completed (vmcnt 0) the arrival is counted, and the workgroup that finds n_splits - 1 arrivals before
+            // it reads the others' records with agent-scope loads (MI355X_MICROARCH.md "inter-workgroup visibility": sc1 stores AND
+            // sc1 loads need no fence)
+            __shared__ int s_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                unsigned * cnt_p = geo.arrive + ((int64_t) bat * geo.n_q + tok) * geo.n_kv_head + kvh;
+                const unsigned old = __hip_atomic_fetch_add(cnt_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = old == (unsigned) geo.n_splits - 1u;
+                if (s_last) __hip_atomic_store(cnt_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+            __syncthreads();
+            if (!s_last) return;
+            fa_merge_heads((const float *) ws + (((int64_t) bat * geo.n_q + tok) * geo.n_head + kvh * g_real) * geo.n_splits * (D + 2), kvh * g_real, g_real, geo.n_splits, sinks, dst,
+                           tok, bat, geo.q8 ? (q8k_dev *) geo.q8 + ((int64_t) bat * geo.n_q + tok) * (geo.n_head * D / 256) + (kvh * g_real) / 2 : nullptr, &sh[0][0][0]);
         }
     }
 }
@@ -885,9 +983,14 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
             else hipLaunchKernelGGL((k_fattn_dec128<GG, 0, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);                \
         }                                                                                                                                   \
     }
+        // n_splits > 1: the last split workgroup of a (token, kv head) merges the records itself when the caller gave arrival counters
+        // (one launch instead of two); Q8_K output needs whole head pairs inside a kv group
+        const bool self_merge = geo.n_splits > 1 && p.arrive != nullptr && (int64_t) geo.n_q * q.ne[3] * geo.n_kv_head <= (int64_t) p.arrive_slots && !(p.q8_out && (G & 1));
+        geo.arrive = self_merge ? p.arrive : nullptr;
+        geo.q8 = self_merge ? p.q8_out : nullptr;
         if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
 #undef FA_DEC
-        if (geo.n_splits > 1) launch_flash_attn_combine(s, 128, ws, sinks, dst, geo.n_q, geo.n_head, (int) q.ne[3], geo.n_splits, p.q8_out);
+        if (geo.n_splits > 1 && !self_merge) launch_flash_attn_combine(s, 128, ws, sinks, dst, geo.n_q, geo.n_head, (int) q.ne[3], geo.n_splits, p.q8_out);
         return;
     }
     if (q8) {

@@ -1201,6 +1201,10 @@ static int run_node(exec_state & st, int i) {
             const tdesc qd = TD(a), kd = TD(k), vd = TD(v);
             p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd));
             p.kv_type = k->type;
+            if (c->opt.fa_self_merge && c->fa_arrive) {
+                p.arrive = c->fa_arrive;
+                p.arrive_slots = backend_ctx::fa_arrive_slots;
+            }
             const tdesc md = m ? TD(m) : qd;
             timed_scope ts(c, "flash_attn", (double) (k->ne[1] * k->ne[2] * k->ne[0] * 2 * 2));
             if (c->fa_lists) {

@@ -182,6 +182,8 @@ struct fattn_params {
     const int * lists = nullptr;  // per-token lists of visible cache positions (launch_fattn_tile_scan), or nullptr
     void * q8_out = nullptr;  // the result's only readers are quantised mat-muls (wo of a batch): leave it as Q8_K blocks here — honoured by
                               // the combine pass of the head_dim-128 kernels (n_splits > 1), see fattn_q8_out_ok()
+    unsigned * arrive = nullptr;  // zeroed counters (arrive_slots of them): lets the split kernel of the head_dim-128 decode path merge its own
+    int arrive_slots = 0;         // partial records (last workgroup to arrive) instead of a second launch; the kernel leaves them at zero
     const uint8_t * tile_vis = nullptr;  // matrix-core kernel: [q tile of 32][kv tile of 64] visibility bytes (launch_fattn_vis_scan), or nullptr
 };
 size_t fattn_vis_bytes(const tdesc & q, const tdesc & k);

@@ -821,6 +821,50 @@ def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq
     T.compare(f"flash_attn block-diagonal D={HD} H={NH}/{NKV} nseq={nseq} per_seq={per_seq}", got[0], ref[0], max_nmse=1e-4, log=plog)
 
 
+@pytest.mark.parametrize("nseq,per_seq,nkv_dec", [(32, 64, 0), (5, 300, 0), (1, 0, 2100), (1, 0, 8192)])
+def test_flash_attn_self_merging_splits(backend, H, plog, nseq, per_seq, nkv_dec):
+    """Option fa_self_merge (off by default — measured slower for one token, +1 % for -np 32): the last split workgroup of a
+    (token, kv head) merges the partial records itself (arrival counter, agent-scope record stores / loads) instead of a combine
+    launch.  Same result as the two-launch form, the counters are back at zero afterwards (the second run checks that)."""
+    HD, NH, NKV = 128, 32, 8
+    rng = np.random.default_rng(nseq * 7 + per_seq + nkv_dec)
+    nkv = nkv_dec if nseq == 1 else (nseq * per_seq + 255) // 256 * 256
+    q = rng.standard_normal((NH, nseq, HD)).astype(np.float32)
+    kc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    vc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    MR = (nseq + 63) // 64 * 64
+    mask = np.full((MR, nkv), -np.inf, np.float16)
+    for t in range(nseq):
+        if nseq == 1:
+            mask[0, : nkv - 37] = 0
+        else:
+            mask[t, t * per_seq: t * per_seq + per_seq - (t % 7)] = 0
+
+    def build(g):
+        tq = g.new(L.F32, [HD, nseq, NH], q)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], kc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], vc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        r = H.ggml_flash_attn_ext(g.ctx, tq, k, v, g.new(L.F16, [nkv, MR], mask), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(r, 10)
+        return r
+
+    ref = T.run_case(build, "oracle")
+    two = T.run_case(build, backend)
+    backend.set_option("fa_self_merge", 1)
+    try:
+        k0 = backend.stat("kernel_launches")
+        one = T.run_case(build, backend)
+        launches = backend.stat("kernel_launches") - k0
+        again = T.run_case(build, backend)
+    finally:
+        backend.set_option("fa_self_merge", 0)
+    # (8192 cells: the CPU's f16 accumulation of V alone is ~1.7e-4 away from exact attention — test_flash_attn_head_dim_128_at_8192)
+    T.compare(f"flash_attn self-merging splits nseq={nseq} nkv={nkv}", one[0], ref[0], max_nmse=1e-4 if nkv <= 4096 else 3e-4, log=plog)
+    T.compare(f"flash_attn self-merging splits nseq={nseq} nkv={nkv} vs combine launch", one[0], two[0], max_nmse=1e-12, log=plog)
+    assert np.array_equal(one[0], again[0])
+    plog(f"    self-merging attention nseq={nseq} nkv={nkv}: {launches} launches")
+
+
 # ------------------------------------------------------------------------------------------------ fused Q/K/V
 @pytest.mark.parametrize("tq,tv,bias", [(L.Q4_K, L.Q4_K, False), (L.Q4_K, L.Q6_K, False), (L.Q5_K, L.Q6_K, True), (L.Q6_K, L.Q6_K, True), (L.Q4_K, L.Q5_K, False), (L.Q8_0, L.Q8_0, False), (L.Q8_0, L.Q8_0, True)])
 @pytest.mark.parametrize("kvt", [L.F16, L.Q8_0])
