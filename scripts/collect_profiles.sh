@@ -18,3 +18,9 @@ PMC_GROUPS="FETCH_SIZE;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
   BENCH_ARGS="--steps 16 --warmup 2 --prefill 2048 --timing-steps 0 --no-cpu-baseline --pmc-traffic 0" TOPN=40 bash scripts/prof_pmc.sh > $O/pmc_passes.txt 2>&1
 for i in 0 1 2; do cp gpurun_out/pmc_$i.summary.txt $O/pmc_pass$i.csv 2>/dev/null; done
 head -n 6 $O/pmc_pass0.csv | cut -c1-160
+# the -np 32 configuration: kernel stats of its decode steps (the skinny matrix-core kernel, position-list attention)
+rm -rf gpurun_out/prof_np
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_np -o np32 -- python bench.py --preset llama3-8b-q4_k_m --np 32 --prefill 128 --steps 64 --no-cpu-baseline --timing-steps 0 > $O/np32_bench_under_rocprof.json 2> $O/np32_prof.err; echo "np32 rocprof rc=$?"
+python scripts/prof_summary.py gpurun_out/prof_np/np32_results.db > $O/np32_kernel_stats.csv; head -n 8 $O/np32_kernel_stats.csv | cut -c1-150
+find gpurun_out/prof_np -size +20M -delete
+bash scripts/configs.sh > $O/configs.log 2>&1; cp gpurun_out/configs.jsonl $O/configs.jsonl
