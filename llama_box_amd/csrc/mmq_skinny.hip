@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
     //   Q6_K: a 256-byte window per row (16 pieces; the block is 210 bytes, the tail belongs to the next block): u = 0..7,
     //         row = (lane >> 4) + 4 u, piece = lane & 15
     //   activations: qs u = 0..7, token = (lane >> 4) + 4 u, piece = lane & 15; bsums: token = lane >> 1, piece 16 + (lane & 1)
-    // Tokens >= M are fetched like the others (the caller's activation area holds 32 tokens' worth of bytes) and never stored.
+    // Token groups of four beyond M are not fetched at all; within the last group tokens >= M are fetched like the others (the caller's
+    // activation area holds 32 tokens' worth of bytes) and their results never stored.
     constexpr int HEAD = QT == 6 ? 0 : F::PIECES - 8;
     constexpr int NLT = QT == 6 ? 8 : 4;
     constexpr int NLH = (32 * HEAD + 63) / 64;
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
     auto item_lo = [&](const int item) { return ((item & (a.ksplit - 1)) * nblk) >> ksl; };
     auto item_hi = [&](const int item) { return (((item & (a.ksplit - 1)) + 1) * nblk) >> ksl; };
 
-    u32x4s ga[NLA], gb[9];
+    u32x4s ga[NLA], gb[9] = {};
     float gd = 0.0f;
     // (a straight-line macro, not a lambda: register arrays captured by reference end up in scratch memory)
 #define SK_ISSUE(rows, sb)                                                                                              \
@@ -128,7 +129,8 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
         _Pragma("unroll") for (int u = 0; u < NLT; ++u) ga[u] = *(const u32x4s *) (wb + at_off + u * at_step);          \
         _Pragma("unroll") for (int u = 0; u < NLH; ++u) ga[NLT + u] = *(const u32x4s *) (wb + ah_off[u]);               \
         const char * ab = act_base + (size_t) (sb) * sizeof(q8k_dev);                                                   \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) gb[u] = *(const u32x4s *) (ab + bq_off + u * bq_step);            \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                                   \
+            if (4 * u < a.M) gb[u] = *(const u32x4s *) (ab + bq_off + u * bq_step); /* tokens 4u .. 4u+3: skipped beyond M */ \
         gb[8] = *(const u32x4s *) (ab + bs_off);                                                                        \
         gd = *(const float *) (ab + d_off);                                                                             \
     }
@@ -170,7 +172,8 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
                     if (u + 1 < NLH || ah_last_live) *(u32x4s *) (As + ah_lds[u]) = ga[NLT + u];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) *(u32x4s *) (Bs + bq_lds + u * 4 * SK_BTOK) = gb[u];
+            for (int u = 0; u < 8; ++u)
+                if (4 * u < a.M) *(u32x4s *) (Bs + bq_lds + u * 4 * SK_BTOK) = gb[u];
             *(u32x4s *) (Bs + bs_lds) = gb[8];
             if (g == 0) dAs[row] = gd;
             // ---- the next unit's loads (of this item or of the workgroup's next one) fly while this one is multiplied

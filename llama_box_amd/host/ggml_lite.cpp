@@ -872,7 +872,7 @@ static alloc_plan plan_graph(ggml_gallocr_t ga, ggml_cgraph * g) {
     for (int i = 0; i < g->n_nodes; ++i) {
         ggml_tensor * n = g->nodes[i];
         bool placed_inplace = false;
-        if (needs_alloc(n) && can_inplace(n) && !no_inplace) {
+        if (needs_alloc(n) && can_inplace(n) && !no_inplace && !ggml_lite_no_reuse()) {  // (no-reuse keeps EVERY node's own result readable afterwards)
             for (int s = 0; s < GGML_MAX_SRC && !placed_inplace; ++s) {
                 ggml_tensor * p = n->src[s];
                 if (!p || !same_layout(n, p)) continue;
