@@ -315,6 +315,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_PROLOGUE")) c->opt.prologue = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_QKV")) c->opt.qkv = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_MIN_COLS")) c->opt.mmq_min_cols = atoi(e);
+    if (const char * e = getenv("GGML_MI355X_MMVQ_MAX_COLS")) c->opt.mmvq_max_cols = atoi(e);
     if (const char * e = getenv("GGML_MI355X_FA_SPLITS")) c->opt.fa_splits = atoi(e);
     if (const char * e = getenv("GGML_MI355X_FA_WO")) c->opt.fa_wo = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_SMALL_UPLOADS")) c->opt.small_uploads = atoi(e) != 0;

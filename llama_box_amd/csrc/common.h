@@ -68,7 +68,8 @@ struct options {
     bool fusion = true;        // node fusion (norm+mul, mul_mat+add, ...)
     bool prologue = true;      // fold RMS_NORM / activation quantisation into the mat-vec prologue
     bool qkv = true;           // fused Q/K/V + rope + cache store launch
-    int mmvq_max_cols = 8;     // widest single launch of the bandwidth-bound matvec kernels
+    int mmvq_max_cols = 2;     // widest batch that takes the mat-vec fusions (gate/up/SwiGLU, +bias +residual in one launch); from three columns on the
+                               // skinny matrix-core kernel + its separate SwiGLU launch is faster (-np 8 step 4.06 -> 3.45 ms, -np 3 3.77 -> 3.35)
     int mmq_min_cols = 3;      // batches at least this wide run on the matrix cores (measured, ms/step matrix cores vs multi-column mat-vec: 3 columns 4.1 / 4.4, 4: 3.9 / 4.2, 8: 4.4 / 5.7; 2 columns: 3.6 / 3.1)
     bool mmq_i8 = true;        // Q4_K/Q5_K batches on the int8 matrix cores (mmq_i8.hip) instead of the f16 variant (mmq.hip)
     bool mm_merge = true;      // batches: sibling mat-muls over the same activations (wq/wk/wv, gate/up) as one launch

@@ -57,6 +57,107 @@ __device__ __forceinline__ uint32_t sk_pack_h2(const float a, const float b) {
     return __builtin_bit_cast(uint32_t, h);
 }
 
+// four bytes of a dword times a small digit with ONE v_pk_mul_lo_u16 (every byte product stays below 256: no carry crosses a byte)
+__device__ __forceinline__ uint32_t sk_pk_mul(const uint32_t a, const uint32_t b) {
+    typedef unsigned short ushort2s __attribute__((ext_vector_type(2)));
+    const ushort2s r = __builtin_bit_cast(ushort2s, a) * __builtin_bit_cast(ushort2s, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+// byte K of w replicated into both 16-bit lanes: 0x00bb00bb
+template <int K> __device__ __forceinline__ uint32_t sk_rep_byte(const uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c000c00u | (uint32_t) K | ((uint32_t) K << 16)); }
+
+// One unit (32 weight rows x one super-block x 32 tokens) of Q4_K / Q5_K: arow = this lane's row in the staged weight unit ([row][block
+// bytes]), btok = this lane's token in the staged activation unit ([token][256 qs | 32 bsums f16 | ..]), dAs = the 32 activation block
+// scales; g = lane >> 5 (the k-group of the MFMA operands).  Adds the unit's contribution to acc (register i: token (i & 3) + 8 (i >> 2) + 4 g).
+// The 6-bit sub-block scale cannot ride in an int8 operand (sc * q reaches 945), and folding each MFMA's int32 result with the
+// lane's scale costs 16 v_mul_i32_i24 per MFMA — measured at ~6.8 clocks each where an fp32 fma issues in 2
+// (scripts/ubench/valu_probe.hip): 128 of them were half of a unit's time.  So the scale is split into digits, sc = 8 s1 + s0 (Q4_K:
+// q <= 15, digits <= 7, products <= 105) or 16 s2 + 4 s1 + s0 (Q5_K: q <= 31, digits <= 3, products <= 93), one int8 weight operand per
+// digit (four nibbles x digit = ONE v_pk_mul_lo_u16), and the digit planes accumulate over all eight sub-blocks INSIDE the matrix
+// cores (C operand): sum_j sc_j (q . y)_j = 8 P1 + P0, the same integers ggml-cpu computes, with no per-sub-block fold at all.
+template <int QT> __device__ __forceinline__ void sk_unit_k45(const char * __restrict__ arow, const char * __restrict__ btok, const float * __restrict__ dAs, const int g, float (&acc)[16]) {
+    constexpr int NP = QT == 4 ? 2 : 3;              // digit planes
+    constexpr uint32_t DM = QT == 4 ? 0x07070707u : 0x03030303u;
+    constexpr int DS = QT == 4 ? 3 : 2;              // bits per digit
+    const int16s zeroi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float16s zerof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint4 hdr = *(const uint4 *) arow;
+    const float d = h2f((uint16_t) (hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (hdr.x >> 16));
+    // the 12 packed bytes: scales 0..3 / 4..7 and mins 0..3 / 4..7 as one byte each
+    const uint32_t slo = hdr.y & 0x3F3F3F3Fu, shi = (hdr.w & 0x0F0F0F0Fu) | ((hdr.y >> 2) & 0x30303030u);
+    const uint32_t mlo = hdr.z & 0x3F3F3F3Fu, mhi = ((hdr.w >> 4) & 0x0F0F0F0Fu) | ((hdr.z >> 2) & 0x30303030u);
+    // mins: sum_j m_j * (sum of the 32 activations of sub-block j) = sum over the sixteen 16-value bsums with m_{k/2}; this lane's k-group
+    // covers bsums 8g .. 8g+7, i.e. mins 4g .. 4g+3, each twice: 0x6400 | n == 1024 + n in f16, minus 1024
+    float16s ms;
+    {
+        typedef _Float16 half2s __attribute__((ext_vector_type(2)));
+        const uint32_t msrc = g ? mhi : mlo;
+        const half2s k1024 = {(_Float16) 1024.0f, (_Float16) 1024.0f};
+        uint4 mfu;
+        mfu.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2s, sk_rep_byte<0>(msrc) | 0x64006400u) - k1024);
+        mfu.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2s, sk_rep_byte<1>(msrc) | 0x64006400u) - k1024);
+        mfu.z = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2s, sk_rep_byte<2>(msrc) | 0x64006400u) - k1024);
+        mfu.w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2s, sk_rep_byte<3>(msrc) | 0x64006400u) - k1024);
+        const half8s bsf = *(const half8s *) (btok + 256 + 16 * g);
+        ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, __builtin_bit_cast(half8s, mfu), zerof, 0, 0, 0);
+    }
+    // digit dwords: plane n of scales 0..3 / 4..7
+    uint32_t dlo[NP], dhi[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        dlo[n] = (slo >> (DS * n)) & DM;
+        dhi[n] = (shi >> (DS * n)) & DM;
+    }
+    uint4 qh = make_uint4(0, 0, 0, 0);
+    if constexpr (QT == 5) qh = *(const uint4 *) (arow + 16 + 16 * g);
+    int16s pl[NP];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint4 raw = *(const uint4 *) (arow + (QT == 5 ? 48 : 16) + 32 * p + 16 * g);
+        uint32_t wlo[4] = {raw.x & 0x0F0F0F0Fu, raw.y & 0x0F0F0F0Fu, raw.z & 0x0F0F0F0Fu, raw.w & 0x0F0F0F0Fu};
+        uint32_t whi[4] = {(raw.x >> 4) & 0x0F0F0F0Fu, (raw.y >> 4) & 0x0F0F0F0Fu, (raw.z >> 4) & 0x0F0F0F0Fu, (raw.w >> 4) & 0x0F0F0F0Fu};
+        if constexpr (QT == 5) {
+            const uint32_t h4[4] = {qh.x, qh.y, qh.z, qh.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wlo[k] |= ((h4[k] >> (2 * p)) & 0x01010101u) << 4;
+                whi[k] |= ((h4[k] >> (2 * p + 1)) & 0x01010101u) << 4;
+            }
+        }
+        const int4s y0 = *(const int4s *) (btok + 64 * p + 16 * g);
+        const int4s y1 = *(const int4s *) (btok + 64 * p + 32 + 16 * g);
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            // sub-blocks 2p (low nibbles) and 2p + 1 (high nibbles): their digit n, replicated into both 16-bit lanes
+            const uint32_t src = p < 2 ? dlo[n] : dhi[n];
+            const uint32_t e0 = (p & 1) ? sk_rep_byte<2>(src) : sk_rep_byte<0>(src), e1 = (p & 1) ? sk_rep_byte<3>(src) : sk_rep_byte<1>(src);
+            int4s a0, a1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a0[k] = (int) sk_pk_mul(wlo[k], e0);
+                a1[k] = (int) sk_pk_mul(whi[k], e1);
+            }
+            pl[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(y0, a0, p == 0 ? zeroi : pl[n], 0, 0, 0);
+            pl[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(y1, a1, pl[n], 0, 0, 0);
+        }
+    }
+    // ---- fold the unit
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 dy = *(const float4 *) (dAs + 8 * q + 4 * g);
+        const float dyv[4] = {dy.x, dy.y, dy.z, dy.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            int isum;
+            if constexpr (QT == 4) isum = (pl[1][i] << 3) + pl[0][i];
+            else isum = (pl[2][i] << 4) + (pl[1][i] << 2) + pl[0][i];
+            const float v = __builtin_fmaf(-dmin, ms[i], d * (float) isum);
+            acc[i] = __builtin_fmaf(dyv[r], v, acc[i]);
+        }
+    }
+}
+
 template <int QT>
 __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -183,49 +284,14 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
 
             const char * const arow = As + row * F::ROW;   // this lane's weight row (B operand: n = row)
             const char * const btok = Bs + row * SK_BTOK;  // this lane's token (A operand: m = token)
-            int16s isum = zeroi, isum2 = zeroi;
-            float16s ms;
-            float d, dmin = 0.0f;
             if constexpr (QT == 4 || QT == 5) {
-                const uint4 hdr = *(const uint4 *) arow;
-                d = h2f((uint16_t) (hdr.x & 0xFFFF));
-                dmin = h2f((uint16_t) (hdr.x >> 16));
-                int sc[8], mn[8];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) k4_scale_pair(hdr.y, hdr.z, hdr.w, p, sc[2 * p], sc[2 * p + 1], mn[2 * p], mn[2 * p + 1]);
-                uint4 qh = make_uint4(0, 0, 0, 0);
-                if constexpr (QT == 5) qh = *(const uint4 *) (arow + 16 + 16 * g);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const uint4 raw = *(const uint4 *) (arow + (QT == 5 ? 48 : 16) + 32 * p + 16 * g);
-                    int4s wlo, whi;
-                    wlo[0] = (int) (raw.x & 0x0F0F0F0Fu); wlo[1] = (int) (raw.y & 0x0F0F0F0Fu); wlo[2] = (int) (raw.z & 0x0F0F0F0Fu); wlo[3] = (int) (raw.w & 0x0F0F0F0Fu);
-                    whi[0] = (int) ((raw.x >> 4) & 0x0F0F0F0Fu); whi[1] = (int) ((raw.y >> 4) & 0x0F0F0F0Fu);
-                    whi[2] = (int) ((raw.z >> 4) & 0x0F0F0F0Fu); whi[3] = (int) ((raw.w >> 4) & 0x0F0F0F0Fu);
-                    if constexpr (QT == 5) {
-                        const uint32_t h4[4] = {qh.x, qh.y, qh.z, qh.w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            wlo[k] |= (int) (((h4[k] >> (2 * p)) & 0x01010101u) << 4);
-                            whi[k] |= (int) (((h4[k] >> (2 * p + 1)) & 0x01010101u) << 4);
-                        }
-                    }
-                    const int4s y0 = *(const int4s *) (btok + 64 * p + 16 * g);
-                    const int4s y1 = *(const int4s *) (btok + 64 * p + 32 + 16 * g);
-                    const int16s t0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(y0, wlo, zeroi, 0, 0, 0);
-                    const int16s t1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(y1, whi, zeroi, 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {  // (two accumulators: one v_mad_i32_i24 per product; summed into one the compiler
-                        isum[i] += __mul24(t0[i], sc[2 * p]);      // emits two multiplies and a three-operand add instead)
-                        isum2[i] += __mul24(t1[i], sc[2 * p + 1]);
-                    }
-                }
-                // mins: sum_j m_j * (sum of the 32 activations of sub-block j) = sum over the sixteen 16-value bsums with m_{k/2}
-                const half8s bsf = *(const half8s *) (btok + 256 + 16 * g);
-                const int m0 = g ? mn[4] : mn[0], m1 = g ? mn[5] : mn[1], m2 = g ? mn[6] : mn[2], m3 = g ? mn[7] : mn[3];
-                const uint4 mfu = make_uint4(sk_pack_h2((float) m0, (float) m0), sk_pack_h2((float) m1, (float) m1), sk_pack_h2((float) m2, (float) m2), sk_pack_h2((float) m3, (float) m3));
-                ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, __builtin_bit_cast(half8s, mfu), zerof, 0, 0, 0);
+                sk_unit_k45<QT>(arow, btok, dAs, g, acc);
             } else {
+                // (the fold stays on v_mad_i32_i24 here although it issues at ~6.8 clocks (scripts/ubench/valu_probe.hip): the fp32 form of it —
+                // cvt + fma, 2 clocks each — was built and made the compiler park the prefetched unit in scratch (156 bytes per lane))
+                int16s isum = zeroi;
+                float16s ms;
+                float d;
                 const uint4 scb = *(const uint4 *) (arow + 192);
                 d = h2f(*(const uint16_t *) (arow + 208));
                 const uint32_t scw[4] = {scb.x, scb.y, scb.z, scb.w};
@@ -266,19 +332,17 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
                 sfu.z = g ? sk_pack_h2((float) sc[12], (float) sc[13]) : sk_pack_h2((float) sc[4], (float) sc[5]);
                 sfu.w = g ? sk_pack_h2((float) sc[14], (float) sc[15]) : sk_pack_h2((float) sc[6], (float) sc[7]);
                 ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, __builtin_bit_cast(half8s, sfu), zerof, 0, 0, 0);
-            }
-            // ---- fold the unit: tokens of register i are (i & 3) + 8 (i >> 2) + 4 g
+                // fold the unit: tokens of register i are (i & 3) + 8 (i >> 2) + 4 g
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 dy = *(const float4 *) (dAs + 8 * q + 4 * g);
-                const float dyv[4] = {dy.x, dy.y, dy.z, dy.w};
+                for (int q = 0; q < 4; ++q) {
+                    const float4 dy = *(const float4 *) (dAs + 8 * q + 4 * g);
+                    const float dyv[4] = {dy.x, dy.y, dy.z, dy.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 4 * q + r;
-                    float v;
-                    if constexpr (QT == 6) v = d * (float) (isum[i] - 32 * (int) ms[i]);
-                    else v = __builtin_fmaf(-dmin, ms[i], d * (float) (isum[i] + isum2[i]));
-                    acc[i] = __builtin_fmaf(dyv[r], v, acc[i]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * q + r;
+                        const float v = d * (float) (isum[i] - 32 * (int) ms[i]);
+                        acc[i] = __builtin_fmaf(dyv[r], v, acc[i]);
+                    }
                 }
             }
         }
@@ -319,6 +383,155 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
 #undef MAT_OF
 }
 
+// ------------------------------------------------------------------------------------------------ tile-parallel form (large N)
+// The loop above keeps ONE unit per wave in flight: the next unit's loads sit in registers while the current one is multiplied, and a
+// memory round trip under load (~3 us) is longer than a unit's arithmetic — the 66 MB gate/up pair streamed at 2.6 TB/s.  More
+// units in flight need LDS, and the 9.7 KB activation unit is what fills it; so when a matrix has enough 128-row groups to occupy
+// the chip, four waves take FOUR TILES of the SAME super-block and share its activations:
+//   * a workgroup = 4 waves = 4 tiles (128 rows) x the whole K range; step j = super-block j; no partial sums anywhere — a wave
+//     owns its tile's results from the first block to the last, and stores them itself;
+//   * everything arrives by LDS-DMA (global_load_lds_dwordx4: lane-linear 1 KB pieces, so the LDS image is the [row][piece] /
+//     [token][piece] order of the fetch) into rings of TP_NS stages: the activations of step j + TP_NS - 1 (each wave a quarter) and
+//     every wave's own weight unit of that step are requested while step j is multiplied — TP_NS - 1 units per wave in flight
+//     (three stages, two in flight, were still latency-bound: 25.9 us for the gate/up pair), no staging registers, no ds_write;
+//   * one barrier per step: after a wave's own vmcnt says its pieces of step j have landed, the barrier says everybody's have (and
+//     that everybody is done reading step j - 1, whose stage the next requests then overwrite).
+// hipcc does not count inline-asm memory operations, and in-order vmcnt is the reason for the ring: whatever a wave consumes must be
+// older than everything it keeps in flight, so the activations are requested with their step's weights, two steps ahead.
+constexpr int TP_NW = 4, TP_NS = 3;  // (five stages measured no faster than three: 19.0 us either way with the arithmetic switched off)
+template <int QT> constexpr int tp_a_stage() { return 32 * sk_fmt<QT>::ROW; }
+template <int QT> constexpr int tp_lds_bytes() { return TP_NS * (SK_B_BYTES + 128) + TP_NW * TP_NS * tp_a_stage<QT>(); }
+
+// lane i's 16 (4) bytes at g land at LDS[lds + 16 (4) * i]; `lds` is wave-uniform (MI355X guide: M0 is written in the statement that uses it)
+__device__ __forceinline__ void tp_dma16(const void * g, const uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void tp_dma4(const void * g, const uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+// s_waitcnt vmcnt(N): the instruction takes an immediate (a run-time switch over the counts cost 270 clocks per step)
+template <int N> __device__ __forceinline__ void tp_wait_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int QT>
+__global__ void __launch_bounds__(TP_NW * 64, 2) k_mmq_skinny_tp(const mmq8_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef sk_fmt<QT> F;
+    constexpr int NPA = 32 * F::PIECES, NLA = (NPA + 63) / 64;  // weight pieces per unit and the wave-instructions fetching them
+    constexpr int NPB = 32 * 19 / TP_NW;                         // activation pieces per wave and step: 152 = 2 x 64 + 24
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane & 31, g = lane >> 5;
+    const int nblk = a.K / 256;
+    const int w_nb1 = (int) a.mat[0].w_nb1;
+    const int tok_bytes = nblk * (int) sizeof(q8k_dev);
+    const uint32_t lds0 = (uint32_t) (uintptr_t) smem;  // LDS byte address of the dynamic array
+    // LDS: [activation ring: NS x 9728][scale ring: NS x 128][weight rings: wave x NS x stage]
+    const uint32_t b_ring = lds0, d_ring = lds0 + TP_NS * SK_B_BYTES, a_ring = d_ring + TP_NS * 128 + wave * TP_NS * tp_a_stage<QT>();
+    char * const a_ring_p = smem + TP_NS * (SK_B_BYTES + 128) + wave * TP_NS * tp_a_stage<QT>();
+
+    // fetch roles (offsets from the unit's first byte)
+    int a_off[NLA];
+#pragma unroll
+    for (int u = 0; u < NLA; ++u) {
+        const int pi = min(lane + 64 * u, NPA - 1);
+        a_off[u] = (pi / F::PIECES) * w_nb1 + (pi % F::PIECES) * 16;
+    }
+    int b_off[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int pi = wave * NPB + min(lane + 64 * u, NPB - 1);
+        b_off[u] = (pi / 19) * tok_bytes + (pi % 19) * 16;
+    }
+    const int d_off = row * tok_bytes + 304;  // q8k_dev::d (lanes 0..31)
+    constexpr int n_ops = NLA + 4;  // vector-memory operations of one step, the same for every wave (all four request the 128 scale bytes)
+
+#define MAT_OF(t) ((a.n_mat > 2 && (t) >= a.mat[2].panel0) ? 2 : ((a.n_mat > 1 && (t) >= a.mat[1].panel0) ? 1 : 0))
+#define MAT_SEL(mi, f) ((mi) == 0 ? a.mat[0].f : ((mi) == 1 ? a.mat[1].f : a.mat[2].f))
+    // items = groups of four 32-row tiles (panel0 / n_panels count groups here); this workgroup serves group blockIdx.x, + gridDim.x, ..
+    const int n_items = a.n_panels;
+    const int my_items = n_items > (int) blockIdx.x ? (n_items - 1 - (int) blockIdx.x) / (int) gridDim.x + 1 : 0;
+    const int total = my_items * nblk;  // steps
+    auto issue = [&](const int item, const int sb, const int slot) {
+        const int mi = MAT_OF(item);
+        const uint8_t * wb = MAT_SEL(mi, W) + ((size_t) (item - MAT_SEL(mi, panel0)) * 128 + wave * 32) * (size_t) w_nb1 + (size_t) sb * F::BYTES;
+        const uint32_t al = a_ring + slot * tp_a_stage<QT>();
+#pragma unroll
+        for (int u = 0; u < NLA; ++u)
+            if (u + 1 < NLA || (NPA % 64) == 0 || lane < (NPA % 64)) tp_dma16(wb + a_off[u], al + u * 1024);
+        const char * ab = (const char *) a.act + (size_t) sb * sizeof(q8k_dev);
+        const uint32_t bl = b_ring + slot * SK_B_BYTES + wave * NPB * 16;
+        tp_dma16(ab + b_off[0], bl);
+        tp_dma16(ab + b_off[1], bl + 1024);
+        if (lane < NPB - 128) tp_dma16(ab + b_off[2], bl + 2048);
+        if (lane < 32) tp_dma4(ab + d_off, d_ring + slot * 128);  // (every wave: identical bytes to the same place, and one wait count for all)
+    };
+
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // request steps 0 and 1
+    int is_item = blockIdx.x, is_sb = 0, is_s = 0;  // the next step to be requested
+#define TP_ISSUE_NEXT()                                          \
+    {                                                            \
+        issue(is_item, is_sb, is_s % TP_NS);                     \
+        ++is_s;                                                  \
+        if (++is_sb == nblk) { is_sb = 0; is_item += gridDim.x; } \
+    }
+#pragma unroll
+    for (int k = 0; k < TP_NS - 1; ++k)
+        if (k < total) TP_ISSUE_NEXT()
+    int cu_item = blockIdx.x, cu_sb = 0;
+    for (int s = 0; s < total; ++s) {
+        // this wave's pieces of step s have landed (the later steps' may still fly)
+        if (total - 1 - s >= TP_NS - 2) tp_wait_c<(TP_NS - 2) * n_ops>();
+        else if (total - 1 - s == 1) tp_wait_c<n_ops>();
+        else tp_wait_c<0>();
+        __syncthreads();                                    // ... everybody's have, and nobody reads step s - 1 any more
+        if (s + TP_NS - 1 < total) TP_ISSUE_NEXT()
+        const int slot = s % TP_NS;
+        sk_unit_k45<QT>(a_ring_p + slot * tp_a_stage<QT>() + row * F::ROW, smem + slot * SK_B_BYTES + row * SK_BTOK, (const float *) (smem + TP_NS * SK_B_BYTES + slot * 128), g, acc);
+        if (++cu_sb == nblk) {
+            // ---- the tile is complete: lane = weight row, register i = token (i & 3) + 8 (i >> 2) + 4 g
+            const int mi = MAT_OF(cu_item);
+            const int n = (cu_item - MAT_SEL(mi, panel0)) * 128 + wave * 32 + row;
+            float * const m_dst = MAT_SEL(mi, dst);
+            const int64_t m_dst_stride = MAT_SEL(mi, dst_stride);
+            const float * const m_add = MAT_SEL(mi, add);
+            const int64_t m_add_stride = MAT_SEL(mi, add_stride);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int tok = (i & 3) + 8 * (i >> 2) + 4 * g;
+                if (tok < a.M) {
+                    float v = acc[i];
+                    if (m_add) v += m_add[(size_t) tok * m_add_stride + n];
+                    m_dst[(size_t) tok * m_dst_stride + n] = v;
+                }
+                acc[i] = 0.0f;
+            }
+            cu_sb = 0;
+            cu_item += gridDim.x;
+        }
+    }
+#undef TP_ISSUE_NEXT
+#undef MAT_SEL
+#undef MAT_OF
+}
+
+// the tile-parallel form serves a launch when every matrix is whole 128-row groups, there is no K split, and the groups alone
+// occupy most of the chip
+static bool skinny_tp_applies(int type, const mmq8_args & a, int n_cu) {
+    if (!(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K) || a.ksplit != 1) return false;
+    static const bool on = !getenv("GGML_MI355X_SKINNY_TP") || atoi(getenv("GGML_MI355X_SKINNY_TP")) != 0;
+    if (!on) return false;
+    int64_t groups = 0;
+    for (int i = 0; i < a.n_mat; ++i) {
+        if (a.mat[i].N % 128) return false;
+        groups += a.mat[i].N / 128;
+    }
+    return groups * 4 >= (int64_t) n_cu * 3;
+}
+
 bool mmq_skinny_supported(int type, int64_t K, int64_t N, int64_t M, int64_t w_nb1) {
     if (M < 2 || M > 32 || (K % 256) != 0 || (N % 32) != 0) return false;  // whole 32-row tiles (every model dimension is one)
     // rows packed back to back (then every matrix of a launch has the same row stride)
@@ -336,7 +549,32 @@ int mmq_skinny_ksplit(int64_t K, int64_t n_total) {
     return ks;
 }
 
+static int skinny_n_cu() {
+    static std::atomic<int> n_cu{0};
+    if (n_cu.load(std::memory_order_relaxed) == 0) {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        n_cu.store(v > 0 ? v : 256, std::memory_order_relaxed);
+    }
+    return n_cu.load(std::memory_order_relaxed);
+}
+
 template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
+    const int n_cu = skinny_n_cu();
+    a.m_tiles = 1;
+    if constexpr (QT == 4 || QT == 5) {
+        if (skinny_tp_applies(QT == 4 ? GGML_TYPE_Q4_K : GGML_TYPE_Q5_K, a, n_cu)) {
+            static std::atomic<uint32_t> lds_raised_tp{0};
+            (void) ensure_dyn_lds((const void *) k_mmq_skinny_tp<QT>, (size_t) tp_lds_bytes<QT>(), lds_raised_tp);
+            a.n_panels = 0;
+            for (int i = 0; i < a.n_mat; ++i) {
+                a.mat[i].panel0 = a.n_panels;
+                a.n_panels += a.mat[i].N / 128;
+            }
+            hipLaunchKernelGGL((k_mmq_skinny_tp<QT>), dim3((unsigned) std::min(a.n_panels, n_cu)), dim3(TP_NW * 64), (size_t) tp_lds_bytes<QT>(), s, a);
+            return;
+        }
+    }
     const size_t lds = (size_t) SK_NW * sk_wave_lds<QT>();
     static std::atomic<uint32_t> lds_raised{0};
     (void) ensure_dyn_lds((const void *) k_mmq_skinny<QT>, lds, lds_raised);
@@ -345,17 +583,9 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
         a.mat[i].panel0 = a.n_panels;
         a.n_panels += a.mat[i].N / 32;
     }
-    a.m_tiles = 1;
     // one workgroup per CU (its LDS areas fill the CU), walking the (tile, K slice) items with a stride of the grid
-    int dev = 0;
-    static std::atomic<int> n_cu{0};
-    if (n_cu.load(std::memory_order_relaxed) == 0) {
-        int v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        n_cu.store(v > 0 ? v : 256, std::memory_order_relaxed);
-    }
     const int items = a.n_panels * a.ksplit;
-    hipLaunchKernelGGL((k_mmq_skinny<QT>), dim3((unsigned) std::min(items, n_cu.load(std::memory_order_relaxed))), dim3(SK_NW * 64), lds, s, a);
+    hipLaunchKernelGGL((k_mmq_skinny<QT>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
 }
 
 void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a) {
