@@ -408,6 +408,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "allreduces") return c->st.allreduces;
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
     if (k == "skinny_launches") return c->st.skinny_launches;
+    if (k == "wide_launches") return c->st.wide_launches;
     return -1;
 }
 static int api_timing_report(ggml_backend_t be, char * buf, size_t size, int reset) {

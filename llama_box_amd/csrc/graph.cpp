@@ -149,7 +149,8 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             const ggml_tensor * b = n->src[1];
             const int64_t Mc = b->ne[1] * b->ne[2] * b->ne[3];
             // (2..32 columns: the skinny matrix-core kernel fetches 32 columns' worth of activation bytes whatever M is)
-            p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], (Mc >= 2 && Mc < 32) ? 32 : Mc));
+            // (and the wide form of the same unit fetches whole groups of 128 columns of a prompt batch)
+            p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], (Mc >= 2 && Mc < 32) ? 32 : (Mc >= 33 ? (Mc + 127) / 128 * 128 : Mc)));
             if (Mc >= c->opt.mmq_min_cols && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, 3 * mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc, c->opt.mmq_skinny));  // (x3: up to three sibling matrices share a launch)
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
@@ -363,7 +364,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const bool i8 = c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M);
     if (M >= c->opt.mmq_min_cols && !w2 && !add2 && (!add || i8) && (i8 || mmq_supported(w->type, K, N, M))) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
-        const int ks = (N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M, c->opt.mmq_skinny) : 1;
+        const int ks = (N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M, c->opt.mmq_skinny, w->type) : 1;
         float * part = (float *) ((char *) c->ws + st.aux_off);
         if (i8) {
             const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
@@ -385,9 +386,10 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
                     }
                 }
             }
-            launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn, ks, part,
-                          add ? (const float *) add->data : nullptr, add_stride, !defer, c->opt.mmq_skinny);
-            if (c->opt.mmq_skinny && (ks & (ks - 1)) == 0 && mmq_skinny_supported(w->type, K, N, M, (int64_t) w->nb[1])) c->st.skinny_launches++;
+            const int served = launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn, ks, part,
+                                             add ? (const float *) add->data : nullptr, add_stride, !defer, c->opt.mmq_skinny);
+            c->st.skinny_launches += served == 1;
+            c->st.wide_launches += served == 2;
             if (defer) {
                 st.sk_dst = dst;
                 st.sk = splitk_src{part, ks, (int64_t) M * N, add ? (const float *) add->data : nullptr, add_stride, (float *) dst->data, (int64_t) (dst->nb[1] / 4)};
@@ -806,7 +808,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         n_total += w->ne[1];
         wbytes += (double) ggml_abi_row_size(w->type, K) * (double) w->ne[1];
     }
-    const int ks = mmq_pick_ksplit(K, n_total, M, c->opt.mmq_skinny);
+    const int ks = mmq_pick_ksplit(K, n_total, M, c->opt.mmq_skinny, type);
     if ((size_t) ks * (size_t) M * (size_t) n_total * sizeof(float) > c->ws_size - st.aux_off && ks > 1) return 0;
     const void * act = quantized_src1(st, X, type);
     for (size_t q = 1; q < ms.size(); ++q)
@@ -836,10 +838,9 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     float * part = (float *) ((char *) c->ws + st.aux_off);
     {
         timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (ms.size() == 3 ? "_x3" : "_x2")).c_str(), wbytes);
-        launch_mmq_i8_multi(c->stream, type, (int) ms.size(), mats, (int) K, (int) M, act, c->opt.mmq_bn, ks, part, !defer, c->opt.mmq_skinny);
-        bool sk = c->opt.mmq_skinny && (ks & (ks - 1)) == 0;
-        for (size_t q = 0; q < ms.size(); ++q) sk = sk && mmq_skinny_supported(type, K, mats[q].N, M, mats[q].w_nb1);
-        if (sk) c->st.skinny_launches++;
+        const int served = launch_mmq_i8_multi(c->stream, type, (int) ms.size(), mats, (int) K, (int) M, act, c->opt.mmq_bn, ks, part, !defer, c->opt.mmq_skinny);
+        c->st.skinny_launches += served == 1;
+        c->st.wide_launches += served == 2;
     }
     c->st.kernel_launches += (ks > 1 && !defer) ? 2 : 1;
     c->st.fused_nodes += ms[0].n_nodes - 1;

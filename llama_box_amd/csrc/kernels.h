@@ -106,13 +106,14 @@ size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M, bool skinn
 // int8-matrix-core variant for Q4_K / Q5_K (mmq_i8.hip); force_bn: 0 = auto, 64 / 128 = weight-panel height
 struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
 // up to three matrices of one type against the same activations in one launch (wq/wk/wv, ffn_gate/ffn_up of a batch)
-void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce = true, bool skinny = false);
+// (both return which kernel served the launch: 0 the tiled GEMM of mmq_i8.hip, 1 the skinny weight-streaming kernel, 2 its wide form)
+int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce = true, bool skinny = false);
 void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * mats, const float * part, int ks, int M);  // the reduce pass of launch_mmq_i8_multi(reduce = false), later
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M);
 // ksplit > 1: the K range is split over that many workgroup rows, partials in `part` (mmq_workspace_bytes), summed in a fixed order
-int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M, bool skinny);
+int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M, bool skinny, int type);
 void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
-void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
+int launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
                    int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride, bool reduce = true, bool skinny = false);
 // 2..32 columns (continuous-batching decode steps): the weight-streaming matrix-core kernel of mmq_skinny.hip, reached through
 // launch_mmq_i8[_multi](skinny = true); the caller's activation area must hold 32 columns' worth of bytes (read, never used)

@@ -340,8 +340,8 @@ bool mmq_supported(int type, int64_t K, int64_t N, int64_t M) {
     (void) N;
     return (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K) && (K % 256) == 0 && M >= 9;
 }
-size_t mmq_workspace_bytes(int, int64_t K, int64_t N, int64_t M, bool skinny) {
-    const int ks = mmq_pick_ksplit(K, N, M, skinny);
+size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M, bool skinny) {
+    const int ks = mmq_pick_ksplit(K, N, M, skinny, type);
     return ks > 1 ? (size_t) ks * (size_t) M * (size_t) N * sizeof(float) : 0;
 }
 

@@ -28,6 +28,9 @@ struct mmq8_args {
     int ksplit;          // > 1: blockIdx.y owns a contiguous range of super-blocks and writes its partial result
 };
 
-void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a);  // mmq_skinny.hip; a.mat[].panel0 / n_panels are set by the launcher
+void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a);
+// prompt batches on the same unit (mmq_skinny.hip, wide form): token tiles per workgroup (4 / 2) when it applies, 0 when it does not
+int mmq_wide_tiles(int type, int64_t K, const int64_t * N, int n_mat, int64_t M, int64_t w_nb1, int ksplit);
+void launch_mmq_wide(hipStream_t s, int type, int tt, const mmq8_args & a);  // mmq_skinny.hip; a.mat[].panel0 / n_panels are set by the launcher
 
 }  // namespace mi355x

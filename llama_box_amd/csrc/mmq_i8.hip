@@ -423,8 +423,10 @@ template <int QT, int BN, int BM = 128> static void launch_mmq8_t(hipStream_t s,
 
 // few activation columns (continuous-batching decode, M <= 64) leave N/64 x 1 workgroups — far fewer than 256 CUs — so
 // the K range is split over blockIdx.y and the partial products are summed in a fixed order by a second tiny kernel
-int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M, bool skinny) {
+int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M, bool skinny, int type) {
     if (skinny && M >= 2 && M <= 32 && (N % 32) == 0) return mmq_skinny_ksplit(K, N);
+    // prompt batches the wide form of mmq_skinny.hip serves run without a K split (its grid fills the chip by token-tile groups)
+    if (skinny && mmq_wide_tiles(type, K, &N, 1, M, (K / 256) * (type == GGML_TYPE_Q4_K ? 144 : 176), 1) != 0) return 1;
     const int64_t wgs = ((N + 63) / 64) * ((M + 127) / 128), nblk = K / 256;
     static const int ks_target = getenv("GGML_MI355X_MMQ_KS_TARGET") ? atoi(getenv("GGML_MI355X_MMQ_KS_TARGET")) : 512;
     if (M <= 64) return (int) std::max<int64_t>(1, std::min<int64_t>(nblk, ks_target / std::max<int64_t>(1, wgs)));
@@ -488,7 +490,7 @@ void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int 
 }
 
 // n_mat (1..3) matrices of one type against the same activations; `part` holds ksplit * M * sum(N) floats when ksplit > 1
-void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce, bool skinny) {
+int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce, bool skinny) {
     mmq8_args a{};
     a.n_mat = n_mat;
     a.K = K;
@@ -496,6 +498,7 @@ void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc 
     a.act = (const q8k_dev *) act_q8k;
     a.ksplit = std::max(1, ksplit);
     int64_t panels128 = 0;
+    const bool skinny_opt = skinny;
     float * pp = part;
     for (int i = 0; i < n_mat; ++i) {
         a.mat[i].W = mats[i].W;
@@ -510,11 +513,24 @@ void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc 
         panels128 += (mats[i].N + 127) / 128;
         skinny = skinny && mmq_skinny_supported(type, K, mats[i].N, M, mats[i].w_nb1);
     }
+    if (skinny_opt && M >= 33) {  // prompt batches: the wide form of the skinny unit, where it applies
+        int64_t Ns[3] = {0, 0, 0};
+        bool same = true;
+        for (int i = 0; i < n_mat; ++i) {
+            Ns[i] = mats[i].N;
+            same = same && mats[i].w_nb1 == mats[0].w_nb1;
+        }
+        const int tt = same ? mmq_wide_tiles(type, K, Ns, n_mat, M, mats[0].w_nb1, a.ksplit) : 0;
+        if (tt) {
+            launch_mmq_wide(s, type, tt, a);
+            return 2;
+        }
+    }
     skinny = skinny && (a.ksplit & (a.ksplit - 1)) == 0;  // (its K split is a power of two: mmq_skinny_ksplit)
     if (skinny) {  // a decode step of a continuous batch: stream the weights once (mmq_skinny.hip)
         launch_mmq_skinny(s, type, a);
         if (a.ksplit > 1 && reduce) launch_splitk_reduce_multi(s, a);
-        return;
+        return 1;
     }
     // 128-row panels unless that leaves CUs idle (256 CUs, one 8-wave workgroup each)
     const int64_t wg128 = panels128 * ((M + MI_BM - 1) / MI_BM);
@@ -545,6 +561,7 @@ void launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc 
         else launch_mmq8_t<6, 64>(s, a);
     }
     if (a.ksplit > 1 && reduce) launch_splitk_reduce_multi(s, a);  // (!reduce: the caller's next kernel sums the partials itself)
+    return 0;
 }
 void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * mats, const float * part, int ks, int M) {
     mmq8_args a{};
@@ -563,10 +580,10 @@ void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * ma
     }
     launch_splitk_reduce_multi(s, a);
 }
-void launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
+int launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
                    int ksplit, float * part, const float * add, int64_t add_stride, bool reduce, bool skinny) {
     const mmq_mat_desc m{W, w_nb1, N, dst, dst_stride, add, add_stride};
-    launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part, reduce, skinny);
+    return launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part, reduce, skinny);
 }
 
 }  // namespace mi355x

@@ -532,6 +532,310 @@ static bool skinny_tp_applies(int type, const mmq8_args & a, int n_cu) {
     return groups * 4 >= (int64_t) n_cu * 3;
 }
 
+static int skinny_n_cu();
+
+// ------------------------------------------------------------------------------------------------ wide form (prompt batches)
+// The same unit for 33 .. thousands of columns: a workgroup = NW computing waves = NW row tiles x TT token tiles (32 TT columns)
+// x the whole K range (+ loader waves, below).  Per step (super-block) a wave converts ITS weight unit once, in registers — nibbles x scale digits = the
+// int8 B operands of all eight sub-blocks, 64 registers for Q4_K — and multiplies it with TT token tiles whose activations sit in
+// LDS exactly as the quantisers wrote them ([token][256 qs | bsums]: LDS-DMA, no conversion, no ds_write anywhere in the kernel).
+// mmq_i8.hip, which this replaces where it applies, stages both operands through registers into LDS every 128 values of K and
+// runs at 24 % of the matrix pipe with its components adding up serially (fragment reads 4.0, conversion + LDS writes
+// 2.6, global loads 2.0 ms of a 13 ms prefill GEMM budget); here an MFMA operand costs one LDS read per TT/1 use on the weight
+// side and one per use on the activation side, and a step is 17 TT MFMAs against ~180 + 80 TT VALU.
+//   rings: weights 3 stages per wave (requested two steps ahead), activations 2 stages per workgroup (one step ahead: they come from
+//   L2); request order per step [activations of s+1, weights of s+2] so that what step s+1 consumes is older than what stays in flight
+//   (in-order vmcnt).  Items (128-row group, token tile group) of one weight group run on the same XCD at the same time: its L2
+//   serves the weight bytes to all of them.
+template <int QT, int TT, int NW> constexpr int wd_lds_bytes() { return 2 * TT * (SK_B_BYTES + 128) + NW * 3 * tp_a_stage<QT>(); }
+constexpr int WD_NL = 2;  // loader waves per workgroup
+
+// NW computing waves (one 32-row tile each) + WD_NL loader waves.  In-kernel timestamps of the first version, where every wave
+// requested its own operands: per step and wave 1 050 clocks issuing 9 LDS-DMA instructions (each waits for room in the CU's one
+// address pipeline), 1 650 at the barrier (for the slowest issuer), 430 converting the weight unit, 2 700 in the 34 MFMAs of its two
+// token tiles — the matrix pipe busy 37 %.  The loaders take the first two off the computing waves: they request, wait (vmcnt) and
+// meet the others at the step's barrier; the computing waves only convert and multiply.
+template <int QT, int TT, int NW>
+__global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef sk_fmt<QT> F;
+    constexpr int NP = QT == 4 ? 2 : 3;
+    constexpr uint32_t DM = QT == 4 ? 0x07070707u : 0x03030303u;
+    constexpr int DS = QT == 4 ? 3 : 2;
+    constexpr int NPA = 32 * F::PIECES, NLA = (NPA + 63) / 64;
+    constexpr int NPB = TT * 32 * 19 / WD_NL, NLB = (NPB + 63) / 64;  // activation pieces per loader and step, and the instructions fetching them
+    constexpr int TPL = NW / WD_NL;                                    // weight tiles per loader
+    constexpr int DCNT = (TT + WD_NL - 1) / WD_NL;                     // scale requests per loader and step
+    constexpr int B_STAGE = TT * SK_B_BYTES, A_STAGE = tp_a_stage<QT>();
+    static_assert(NW % WD_NL == 0 && (TT * 32 * 19) % WD_NL == 0, "loader roles");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= NW;
+    const int ld = wave - NW;  // loader index
+    const int row = lane & 31, g = lane >> 5;
+    const int nblk = a.K / 256;
+    const int w_nb1 = (int) a.mat[0].w_nb1;
+    const int tok_bytes = nblk * (int) sizeof(q8k_dev);
+    const uint32_t lds0 = (uint32_t) (uintptr_t) smem;
+    // LDS: [activation ring 2 x TT x 9728][scale ring 2 x TT x 128][weight rings: tile x 3 x stage]
+    const uint32_t b_ring = lds0, d_ring = lds0 + 2 * B_STAGE, a_rings = d_ring + 2 * TT * 128;
+    const char * const b_ring_p = smem;
+    const char * const d_ring_p = smem + 2 * B_STAGE;
+    const char * const a_ring_p = smem + 2 * B_STAGE + 2 * TT * 128 + (loader ? 0 : wave) * 3 * A_STAGE;
+
+    // loader fetch roles (offsets from the unit's first byte)
+    int a_off[NLA];
+#pragma unroll
+    for (int u = 0; u < NLA; ++u) {
+        const int pi = min(lane + 64 * u, NPA - 1);
+        a_off[u] = (pi / F::PIECES) * w_nb1 + (pi % F::PIECES) * 16;
+    }
+    int b_off[NLB];
+#pragma unroll
+    for (int u = 0; u < NLB; ++u) {
+        const int pi = max(ld, 0) * NPB + min(lane + 64 * u, NPB - 1);
+        b_off[u] = (pi / 19) * tok_bytes + (pi % 19) * 16;
+    }
+    const int d_off = row * tok_bytes + 304;  // q8k_dev::d of token `row` of a token tile
+    constexpr int n_ops_a = TPL * NLA;        // a loader's weight requests of one step
+
+#define MAT_OF(t) ((a.n_mat > 2 && (t) >= a.mat[2].panel0) ? 2 : ((a.n_mat > 1 && (t) >= a.mat[1].panel0) ? 1 : 0))
+#define MAT_SEL(mi, f) ((mi) == 0 ? a.mat[0].f : ((mi) == 1 ? a.mat[1].f : a.mat[2].f))
+    // virtual items v = blockIdx.x + gridDim.x r: XCD v % 8 (workgroups go round the XCDs) serves groups xcd, xcd + 8, ..; the token-tile
+    // groups of one weight group are consecutive there
+    const int n_groups = a.n_panels, m_tiles = a.m_tiles;
+    const int n_virtual = ((n_groups + 7) / 8) * 8 * m_tiles;
+    auto decode = [&](const int v, int & group, int & mt) {
+        const int xcd = v & 7, q = v >> 3;
+        group = (q / m_tiles) * 8 + xcd;
+        mt = q - (q / m_tiles) * m_tiles;
+    };
+    auto next_valid = [&](int v) {
+        for (; v < n_virtual; v += gridDim.x) {
+            int gr, mt;
+            decode(v, gr, mt);
+            if (gr < n_groups) return v;
+        }
+        return n_virtual;
+    };
+    int total = 0;  // steps of this workgroup (the same number in every wave: one barrier each)
+    for (int v = next_valid(blockIdx.x); v < n_virtual; v = next_valid(v + gridDim.x)) total += nblk;
+
+    auto issue_a = [&](const int v, const int sb, const int slot) {
+        int gr, mt;
+        decode(v, gr, mt);
+        const int mi = MAT_OF(gr);
+        const uint8_t * wg = MAT_SEL(mi, W) + (size_t) (gr - MAT_SEL(mi, panel0)) * (32 * NW) * (size_t) w_nb1 + (size_t) sb * F::BYTES;
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+            const int t = ld * TPL + k;
+            const uint8_t * wb = wg + (size_t) t * 32 * (size_t) w_nb1;
+            const uint32_t al = a_rings + (t * 3 + slot) * A_STAGE;
+#pragma unroll
+            for (int u = 0; u < NLA; ++u)
+                if (u + 1 < NLA || (NPA % 64) == 0 || lane < (NPA % 64)) tp_dma16(wb + a_off[u], al + u * 1024);
+        }
+    };
+    auto issue_b = [&](const int v, const int sb, const int slot) {
+        int gr, mt;
+        decode(v, gr, mt);
+        const char * ab = (const char *) a.act + (size_t) mt * (32 * TT) * (size_t) tok_bytes + (size_t) sb * sizeof(q8k_dev);
+        const uint32_t bl = b_ring + slot * B_STAGE + ld * NPB * 16;
+#pragma unroll
+        for (int u = 0; u < NLB; ++u)
+            if (u + 1 < NLB || (NPB % 64) == 0 || lane < (NPB % 64)) tp_dma16(ab + b_off[u], bl + u * 1024);
+        // the block scales of token tile tt: loader tt % WD_NL — every loader issues DCNT of these instructions (a duplicate when it has
+        // no tile of its own), so that the wait counts are the same compile-time constants for all
+#pragma unroll
+        for (int t = 0; t < DCNT; ++t) {
+            const int tt = min(ld + t * WD_NL, TT - 1);
+            if (lane < 32) tp_dma4(ab + (size_t) tt * 32 * (size_t) tok_bytes + d_off, d_ring + slot * TT * 128 + tt * 128);
+        }
+    };
+
+    float acc[TT][16];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    // request cursors (loaders): weights run two steps ahead, activations one
+    int va = next_valid(blockIdx.x), sa = 0, na = 0;  // next weight step to request (virtual item, super-block, running step number)
+    int vb = va, sbb = 0, nb = 0;
+    int vc = va, sc_ = 0;                             // the step being multiplied (computing waves)
+#define WD_ADV(v, sb) { if (++(sb) == nblk) { (sb) = 0; (v) = next_valid((v) + gridDim.x); } }
+    if (loader) {
+        if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+        if (vb < n_virtual) { issue_b(vb, sbb, nb % 2); ++nb; WD_ADV(vb, sbb) }
+        if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+    }
+    const int16s zeroi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float16s zerof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < total; ++s) {
+        if (loader) {
+            // this loader's pieces of step s (weights requested two steps ago, activations one) have landed; only its weight requests of
+            // step s + 1 may still fly
+            if (na > s + 1) tp_wait_c<n_ops_a>();
+            else tp_wait_c<0>();
+        }
+        __syncthreads();  // everything of step s is in LDS, and nobody reads step s - 1 any more
+        if (loader) {
+            if (vb < n_virtual) { issue_b(vb, sbb, nb % 2); ++nb; WD_ADV(vb, sbb) }
+            if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+            continue;
+        }
+
+        // ---- this wave's weight unit -> digit-plane operands, once per step
+        const char * const arow = a_ring_p + (s % 3) * A_STAGE + row * F::ROW;
+        const uint4 hdr = *(const uint4 *) arow;
+        const float d = h2f((uint16_t) (hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (hdr.x >> 16));
+        const uint32_t slo = hdr.y & 0x3F3F3F3Fu, shi = (hdr.w & 0x0F0F0F0Fu) | ((hdr.y >> 2) & 0x30303030u);
+        const uint32_t mlo = hdr.z & 0x3F3F3F3Fu, mhi = ((hdr.w >> 4) & 0x0F0F0F0Fu) | ((hdr.z >> 2) & 0x30303030u);
+        uint4 mfu;
+        {
+            typedef _Float16 half2s __attribute__((ext_vector_type(2)));
+            const uint32_t msrc = g ? mhi : mlo;
+            const half2s k1024 = {(_Float16) 1024.0f, (_Float16) 1024.0f};
+            mfu.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2s, sk_rep_byte<0>(msrc) | 0x64006400u) - k1024);
+            mfu.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2s, sk_rep_byte<1>(msrc) | 0x64006400u) - k1024);
+            mfu.z = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2s, sk_rep_byte<2>(msrc) | 0x64006400u) - k1024);
+            mfu.w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2s, sk_rep_byte<3>(msrc) | 0x64006400u) - k1024);
+        }
+        uint32_t dlo[NP], dhi[NP];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            dlo[n] = (slo >> (DS * n)) & DM;
+            dhi[n] = (shi >> (DS * n)) & DM;
+        }
+        uint4 qh = make_uint4(0, 0, 0, 0);
+        if constexpr (QT == 5) qh = *(const uint4 *) (arow + 16 + 16 * g);
+        int4s W0[4][NP], W1[4][NP];  // pair p, digit plane n: sub-block 2p (low nibbles) / 2p + 1 (high nibbles)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint4 raw = *(const uint4 *) (arow + (QT == 5 ? 48 : 16) + 32 * p + 16 * g);
+            uint32_t wlo[4] = {raw.x & 0x0F0F0F0Fu, raw.y & 0x0F0F0F0Fu, raw.z & 0x0F0F0F0Fu, raw.w & 0x0F0F0F0Fu};
+            uint32_t whi[4] = {(raw.x >> 4) & 0x0F0F0F0Fu, (raw.y >> 4) & 0x0F0F0F0Fu, (raw.z >> 4) & 0x0F0F0F0Fu, (raw.w >> 4) & 0x0F0F0F0Fu};
+            if constexpr (QT == 5) {
+                const uint32_t h4[4] = {qh.x, qh.y, qh.z, qh.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    wlo[k] |= ((h4[k] >> (2 * p)) & 0x01010101u) << 4;
+                    whi[k] |= ((h4[k] >> (2 * p + 1)) & 0x01010101u) << 4;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NP; ++n) {
+                const uint32_t src = p < 2 ? dlo[n] : dhi[n];
+                const uint32_t e0 = (p & 1) ? sk_rep_byte<2>(src) : sk_rep_byte<0>(src), e1 = (p & 1) ? sk_rep_byte<3>(src) : sk_rep_byte<1>(src);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    W0[p][n][k] = (int) sk_pk_mul(wlo[k], e0);
+                    W1[p][n][k] = (int) sk_pk_mul(whi[k], e1);
+                }
+            }
+        }
+        // ---- TT token tiles against it
+        const char * const bst = b_ring_p + (s % 2) * B_STAGE;
+        const float * const dst_ = (const float *) (d_ring_p + (s % 2) * TT * 128);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const char * const btok = bst + (t * 32 + row) * SK_BTOK;
+            int16s pl[NP];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int4s y0 = *(const int4s *) (btok + 64 * p + 16 * g);
+                const int4s y1 = *(const int4s *) (btok + 64 * p + 32 + 16 * g);
+#pragma unroll
+                for (int n = 0; n < NP; ++n) pl[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(y0, W0[p][n], p == 0 ? zeroi : pl[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NP; ++n) pl[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(y1, W1[p][n], pl[n], 0, 0, 0);
+            }
+            const half8s bsf = *(const half8s *) (btok + 256 + 16 * g);
+            const float16s ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, __builtin_bit_cast(half8s, mfu), zerof, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 dy = *(const float4 *) (dst_ + t * 32 + 8 * q + 4 * g);
+                const float dyv[4] = {dy.x, dy.y, dy.z, dy.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * q + r;
+                    int isum;
+                    if constexpr (QT == 4) isum = (pl[1][i] << 3) + pl[0][i];
+                    else isum = (pl[2][i] << 4) + (pl[1][i] << 2) + pl[0][i];
+                    const float v = __builtin_fmaf(-dmin, ms[i], d * (float) isum);
+                    acc[t][i] = __builtin_fmaf(dyv[r], v, acc[t][i]);
+                }
+            }
+        }
+        if (++sc_ == nblk) {
+            // ---- the tiles are complete: lane = weight row, register i = token (i & 3) + 8 (i >> 2) + 4 g of token tile t
+            int gr, mt;
+            decode(vc, gr, mt);
+            const int mi = MAT_OF(gr);
+            const int n = (gr - MAT_SEL(mi, panel0)) * (32 * NW) + wave * 32 + row;
+            float * const m_dst = MAT_SEL(mi, dst);
+            const int64_t m_dst_stride = MAT_SEL(mi, dst_stride);
+            const float * const m_add = MAT_SEL(mi, add);
+            const int64_t m_add_stride = MAT_SEL(mi, add_stride);
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int tok = mt * 32 * TT + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+                    if (tok < a.M) {
+                        float v = acc[t][i];
+                        if (m_add) v += m_add[(size_t) tok * m_add_stride + n];
+                        m_dst[(size_t) tok * m_dst_stride + n] = v;
+                    }
+                    acc[t][i] = 0.0f;
+                }
+            sc_ = 0;
+            vc = next_valid(vc + gridDim.x);
+        }
+    }
+#undef WD_ADV
+#undef MAT_SEL
+#undef MAT_OF
+}
+
+// Prompt batches (33 columns and up) take the wide form when every matrix is whole 128-row groups of Q4_K / Q5_K, there is no K
+// split and (row groups x 64-column groups) can occupy the chip.  One workgroup shape is in use — 4 computing waves (128 rows) x 2
+// token tiles (64 columns) + 2 loaders; measured on the 512-token prefill of Llama-3-8B Q4_K_M against the tiled GEMM at 28.9 k tok/s:
+// this shape 30.5 k; 8 computing waves x 2 tiles, everyone requesting its own operands, 28.7 k; the same with 2 / 4 loaders 26.1 /
+// 28.9 k (one address pipeline per CU: 52 LDS-DMA instructions per step); 4 waves x 4 tiles 20.2 k (spills at the 256-register cap
+// of six waves).  Qwen2-7B Q5_K_M (three digit planes: the tiled GEMM spills there) 20.5 -> 25.3 k.  Returns the shape code
+// NW * 16 + TT, or 0.  The caller's activation area must hold whole 128-column groups (columns beyond M are fetched, never stored).
+int mmq_wide_tiles(int type, int64_t K, const int64_t * N, int n_mat, int64_t M, int64_t w_nb1, int ksplit) {
+    static const bool on = !getenv("GGML_MI355X_MMQ_WIDE") || atoi(getenv("GGML_MI355X_MMQ_WIDE")) != 0;
+    if (!on || !(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K) || ksplit != 1 || M < 33 || (K % 256) != 0) return 0;
+    if (w_nb1 != (K / 256) * (type == GGML_TYPE_Q4_K ? 144 : 176)) return 0;
+    int64_t g128 = 0;
+    for (int i = 0; i < n_mat; ++i) {
+        if (N[i] % 128) return 0;
+        g128 += N[i] / 128;
+    }
+    return g128 * ((M + 63) / 64) * 2 >= skinny_n_cu() ? 4 * 16 + 2 : 0;
+}
+
+template <int QT, int TT, int NW> static void launch_wide_t(hipStream_t s, mmq8_args a) {
+    static std::atomic<uint32_t> lds_raised{0};
+    const void * fn = (const void *) k_mmq_wide<QT, TT, NW>;
+    const size_t lds = (size_t) wd_lds_bytes<QT, TT, NW>();
+    (void) ensure_dyn_lds(fn, lds, lds_raised);
+    a.n_panels = 0;
+    for (int i = 0; i < a.n_mat; ++i) {
+        a.mat[i].panel0 = a.n_panels;
+        a.n_panels += a.mat[i].N / (32 * NW);
+    }
+    a.m_tiles = (a.M + 32 * TT - 1) / (32 * TT);
+    const int n_virtual = ((a.n_panels + 7) / 8) * 8 * a.m_tiles;
+    hipLaunchKernelGGL((k_mmq_wide<QT, TT, NW>), dim3((unsigned) std::min(n_virtual, skinny_n_cu())), dim3((NW + WD_NL) * 64), lds, s, a);
+}
+void launch_mmq_wide(hipStream_t s, int type, int shape, const mmq8_args & a) {
+    (void) shape;  // (one shape in use: 4 computing waves x 2 token tiles)
+    if (type == GGML_TYPE_Q4_K) launch_wide_t<4, 2, 4>(s, a);
+    else launch_wide_t<5, 2, 4>(s, a);
+}
+
 bool mmq_skinny_supported(int type, int64_t K, int64_t N, int64_t M, int64_t w_nb1) {
     if (M < 2 || M > 32 || (K % 256) != 0 || (N % 32) != 0) return false;  // whole 32-row tiles (every model dimension is one)
     // rows packed back to back (then every matrix of a launch has the same row stride)

@@ -174,6 +174,44 @@ def test_mul_mat_q_skinny_batches(backend, H, plog, qt, K, N, M, epi):
     T.compare(f"mul_mat skinny {QNAME[qt]} K={K} N={N} M={M} {epi} vs tiled GEMM", got[0], tiled[0], max_nmse=1e-12, log=plog)
 
 
+@pytest.mark.parametrize("qt", [L.Q4_K, L.Q5_K])
+@pytest.mark.parametrize("K,N,M,epi,served", [
+    (512, 4096, 512, "res", 1), (1024, 8192, 300, "bias", 1), (256, 12288, 130, "none", 1), (2048, 16384, 33, "none", 1), (4096, 16384, 64, "res", 1),
+    (512, 28672, 128, "none", 1), (1024, 16384, 200, "bias", 1),  # many row groups, ragged columns
+    (2048, 4096, 100, "none", 0),  # too few (row group, token tile) pairs to fill the chip: the tiled GEMM keeps it
+])
+def test_mul_mat_q_wide_batches(backend, H, plog, qt, K, N, M, epi, served):
+    """Prompt batches (33 columns and up) on the wide form of the skinny unit (mmq_skinny.hip, k_mmq_wide): four row tiles x two
+    token tiles per workgroup + two loader waves, weights converted once per super-block in registers, both operands by LDS-DMA.  Ragged column
+    counts (the last token-tile group is fetched whole and stored partly), residual / bias in the store; same integers as
+    ggml-cpu's vec_dot_q*_K_q8_K.  Also against the tiled GEMM it replaces (mmq_skinny = 0)."""
+    rng = np.random.default_rng(K * 31 + N * 7 + M + qt)
+    w = T.rand_weight(qt, K, N, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    x[M - 1, :256] = 0.0
+    addend = rng.standard_normal((M, N) if epi == "res" else (N,)).astype(np.float32)
+
+    def build(g):
+        r = H.ggml_mul_mat(g.ctx, g.new(qt, [K, N], w), g.new(L.F32, [K, M], x))
+        if epi == "bias":
+            r = H.ggml_add(g.ctx, r, g.new(L.F32, [N], addend))
+        elif epi == "res":
+            r = H.ggml_add(g.ctx, r, g.new(L.F32, [N, M], addend))
+        return r
+
+    ref = T.run_case(build, "oracle", T.host_threads(32))
+    s0 = backend.stat("wide_launches")
+    got = T.run_case(build, backend)
+    assert backend.stat("wide_launches") - s0 == served
+    T.compare(f"mul_mat wide {QNAME[qt]} K={K} N={N} M={M} {epi}", got[0], ref[0], max_nmse=1e-10, log=plog)
+    backend.set_option("mmq_skinny", 0)
+    try:
+        tiled = T.run_case(build, backend)
+    finally:
+        backend.set_option("mmq_skinny", 1)
+    T.compare(f"mul_mat wide {QNAME[qt]} K={K} N={N} M={M} {epi} vs tiled GEMM", got[0], tiled[0], max_nmse=1e-12, log=plog)
+
+
 def _random_mm_shapes():
     rng = np.random.default_rng(2024)
     out = []
