@@ -336,6 +336,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     constexpr int TRIP = NG * WV * 4;  // positions per trip
     static_assert(WV == 4 || (MODE == 0 && !Q8), "the wide form serves plain decode over an f16 cache only");
     __shared__ float sh[WV][G][D + 2];
+    __shared__ float qv[WV == 4 ? G * D : 1];  // one pass, Q8_K output: the normalised heads of this kv group before quantisation
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane >> 4, sl = lane & 15;
     const int ul = sl / G, gl = sl % G;  // the (row group, head) pair this lane owns in the lane-parallel part
@@ -653,8 +654,11 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
                 a *= c;
                 lt = lt * c + expf(sk - mn);
             }
-            float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
-            out[dd] = a * (1.0f / lt);
+            if (WV == 4 && geo.q8) qv[g * D + dd] = a * (1.0f / lt);  // (quantised below, two heads per Q8_K block)
+            else {
+                float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+                out[dd] = a * (1.0f / lt);
+            }
         } else {
             float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits + split) * geo.rec_stride;
             if (WV == 4 && geo.arrive) {
@@ -671,6 +675,15 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     }
     }  // !empty
     if constexpr (WV == 4) {
+        if (geo.n_splits == 1 && geo.q8) {
+            // one pass and the readers are quantised mat-muls: quantize_row_q8_K of head pairs, as k_quantize_q8_K does it
+            __syncthreads();
+            if (wave < g_real / 2) {
+                const float4 t4 = ((const float4 *) (qv + wave * 256))[lane];
+                const float t[4] = {t4.x, t4.y, t4.z, t4.w};
+                wave_quantize_q8_K(t, lane, (q8k_dev *) geo.q8 + ((int64_t) bat * geo.n_q + tok) * (geo.n_head * D / 256) + (kvh * g_real) / 2 + wave);
+            }
+        }
         if (geo.n_splits > 1 && geo.arrive) {
             // ---- the last split workgroup of this (token, kv head) to get here merges all records.  Our record went out with agent-scope
             // stores; once they have completed (vmcnt 0) the arrival is counted, and the workgroup that finds n_splits - 1 arrivals before
@@ -772,9 +785,12 @@ int fattn_pick_splits(const tdesc & q, const tdesc & k) {
         // a few tokens at head_dim 128 (continuous-batching decode, speculative batches): the tile-list kernel — every split takes a
         // share of the token's VISIBLE tiles, so the count follows the number of (token, kv head) groups, not the cache size
         const int64_t groups = k.ne[2] * q.ne[1];
-        // (one pass without a combine was tried for -np 32 — 256 groups fill the chip by themselves — and lost: a trip of this
-        // kernel is a ~4 us dependent chain, three of them in sequence cost more than split + combine)
-        return (int) std::max<int64_t>(2, std::min<int64_t>(16, (768 + groups - 1) / groups));
+        // position lists make a token's work its own visible cells (~n_kv / n_q of a shared cache), 64 per trip: split only when a
+        // workgroup would otherwise walk more than ~8 trips, or when the (token, kv head) groups alone leave most CUs idle.  -np 32 at a
+        // few hundred cells per sequence: ONE pass, which also writes the Q8_K blocks the wo mat-mul reads (4.35 -> 4.30 ms per step)
+        const int64_t trips = std::max<int64_t>(1, (n_kv / q.ne[1] + 63) / 64);
+        const int64_t by_len = (trips + 7) / 8, by_occ = std::min<int64_t>(trips, (256 + groups - 1) / groups);
+        return (int) std::max<int64_t>(1, std::min<int64_t>(16, std::max(by_len, by_occ)));
     }
     if (q.ne[1] > 1) {  // a few tokens, other head sizes: short splits
         const int64_t by_len = (n_kv + 255) / 256;
@@ -901,10 +917,11 @@ void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv
 
 // will launch_flash_attn end in the quantising combine pass for these arguments? (mirrors its dispatch)
 bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p) {
-    if (k.ne[0] != 128 || (q.ne[2] % 2) != 0 || p.n_splits < 2 || q.ne[3] != 1 || k.ne[2] <= 0) return false;
+    if (k.ne[0] != 128 || (q.ne[2] % 2) != 0 || p.n_splits < 1 || q.ne[3] != 1 || k.ne[2] <= 0) return false;
     const bool q8 = p.kv_type == GGML_TYPE_Q8_0;
-    if ((!q8 || (fattn_q8_via_f16(q, p.kv_type) && k.ne[3] == 1)) && flash_attn_mma_applies(q, k, mask, sinks, dst, p)) return true;
+    if (p.n_splits >= 2 && (!q8 || (fattn_q8_via_f16(q, p.kv_type) && k.ne[3] == 1)) && flash_attn_mma_applies(q, k, mask, sinks, dst, p)) return true;
     const int G = (int) (q.ne[2] / k.ne[2]);
+    if (p.n_splits == 1 && ((G & 1) || p.fat || flash_attn_mma_applies(q, k, mask, sinks, dst, p))) return false;  // one pass: the lane-parallel kernel quantises whole head pairs of a kv group
     return p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 2 || G == 4 || G == 7 || G == 8) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 && ((uintptr_t) q.data & 15) == 0;
 }
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
@@ -987,7 +1004,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         // (one launch instead of two); Q8_K output needs whole head pairs inside a kv group
         const bool self_merge = geo.n_splits > 1 && p.arrive != nullptr && (int64_t) geo.n_q * q.ne[3] * geo.n_kv_head <= (int64_t) p.arrive_slots && !(p.q8_out && (G & 1));
         geo.arrive = self_merge ? p.arrive : nullptr;
-        geo.q8 = self_merge ? p.q8_out : nullptr;
+        geo.q8 = (self_merge || (geo.n_splits == 1 && !(G & 1))) ? p.q8_out : nullptr;
         if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
 #undef FA_DEC
         if (geo.n_splits > 1 && !self_merge) launch_flash_attn_combine(s, 128, ws, sinks, dst, geo.n_q, geo.n_head, (int) q.ne[3], geo.n_splits, p.q8_out);

@@ -905,6 +905,45 @@ def test_flash_attn_self_merging_splits(backend, H, plog, nseq, per_seq, nkv_dec
     plog(f"    self-merging attention nseq={nseq} nkv={nkv}: {launches} launches")
 
 
+@pytest.mark.parametrize("nseq,per_seq,splits", [(32, 64, 0), (32, 192, 1), (32, 192, 3), (12, 100, 0), (5, 700, 0)])
+def test_flash_attn_feeds_quantised_wo(backend, H, plog, nseq, per_seq, splits):
+    """-np decode: attention over a unified cache whose only reader is the quantised wo mat-mul.  The attention kernel leaves Q8_K
+    blocks (two heads each) instead of f32 — from its single pass when the position lists are short (no combine launch), from the
+    combine pass otherwise — and the skinny mat-mul reads them.  Equal to the oracle's f32 attention -> quantise -> mat-mul within
+    the attention gate (the quantisation sees values a few 1e-7 apart: a Q8 code may flip, worth ~1e-5 of the mat-mul's output)."""
+    HD, NH, NKV, E = 128, 32, 8, 4096
+    rng = np.random.default_rng(nseq * 13 + per_seq + splits)
+    nkv = (nseq * per_seq + 255) // 256 * 256
+    q = rng.standard_normal((NH, nseq, HD)).astype(np.float32)
+    kc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    vc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    MR = (nseq + 63) // 64 * 64
+    mask = np.full((MR, nkv), -np.inf, np.float16)
+    for t in range(nseq):
+        cells = rng.choice(nkv, per_seq - (t % 7), replace=False)  # scattered, as the decode cells of interleaved sequences are
+        mask[t, cells] = 0
+    wo = T.rand_weight(L.Q4_K, E, 512, rng)
+
+    def build(g):
+        tq = g.new(L.F32, [HD, nseq, NH], q)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], kc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], vc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        r = H.ggml_flash_attn_ext(g.ctx, tq, k, v, g.new(L.F16, [nkv, MR], mask), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(r, 10)
+        return H.ggml_mul_mat(g.ctx, g.new(L.Q4_K, [E, 512], wo), H.ggml_reshape_2d(g.ctx, r, E, nseq))
+
+    ref = T.run_case(build, "oracle", T.host_threads(16))
+    backend.set_option("fa_splits", splits)
+    try:
+        k0 = backend.stat("kernel_launches")
+        got = T.run_case(build, backend)
+        launches = backend.stat("kernel_launches") - k0
+    finally:
+        backend.set_option("fa_splits", 0)
+    plog(f"    attention -> wo nseq={nseq} per_seq={per_seq} splits={splits}: {launches} launches")
+    T.compare(f"flash_attn -> q8 -> wo nseq={nseq} per_seq={per_seq} splits={splits}", got[0], ref[0], max_nmse=1e-4, log=plog)
+
+
 # ------------------------------------------------------------------------------------------------ fused Q/K/V
 @pytest.mark.parametrize("tq,tv,bias", [(L.Q4_K, L.Q4_K, False), (L.Q4_K, L.Q6_K, False), (L.Q5_K, L.Q6_K, True), (L.Q6_K, L.Q6_K, True), (L.Q4_K, L.Q5_K, False), (L.Q8_0, L.Q8_0, False), (L.Q8_0, L.Q8_0, True)])
 @pytest.mark.parametrize("kvt", [L.F16, L.Q8_0])
