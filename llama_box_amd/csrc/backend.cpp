@@ -323,6 +323,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_MM_MERGE")) c->opt.mm_merge = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_BN")) c->opt.mmq_bn = atoi(e);
     if (const char * e = getenv("GGML_MI355X_MMQ_SKINNY")) c->opt.mmq_skinny = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_SKINNY_ROPE")) c->opt.skinny_rope = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FA_SELF_MERGE")) c->opt.fa_self_merge = atoi(e) != 0;
     return new ggml_backend{&g_guid, k_backend_iface, dev, c};
 }
@@ -386,6 +387,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "mm_merge") c->opt.mm_merge = v != 0;
     else if (k == "mmq_bn") c->opt.mmq_bn = v;
     else if (k == "mmq_skinny") c->opt.mmq_skinny = v != 0;
+    else if (k == "skinny_rope") c->opt.skinny_rope = v != 0;
     else if (k == "fa_self_merge") c->opt.fa_self_merge = v != 0;
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "fa_wo") c->opt.fa_wo = v != 0;
@@ -409,6 +411,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
     if (k == "skinny_launches") return c->st.skinny_launches;
     if (k == "wide_launches") return c->st.wide_launches;
+    if (k == "rope_epilogues") return c->st.rope_epilogues;
     return -1;
 }
 static int api_timing_report(ggml_backend_t be, char * buf, size_t size, int reset) {

@@ -76,6 +76,7 @@ struct options {
     bool fa_self_merge = false; // split attention (decode): the last split workgroup merges the partial records, no combine launch.  Off: measured
                                // one token, n_kv 2100: 16.5 us against 7.6 + 5.0 for split + combine (record write-through, counter and re-read are a longer
                                // dependent chain than a launch); -np 32: 18.3 against 19.6 us per layer (4.45 vs 4.49 ms per step)
+    bool skinny_rope = true;   // -np decode steps: ROPE(q), ROPE(k) and both KV-cache stores in the epilogue of the skinny QKV launch(es)
     bool mmq_skinny = true;    // 2..32 columns: weight-streaming matrix-core kernel (mmq_skinny.hip) instead of the tiled GEMM
     int mmq_bn = 0;            // force the weight-panel height of mmq_i8 (64 / 128); 0 = pick by grid size
     int fa_splits = 0;         // 0 = auto
@@ -90,6 +91,7 @@ struct stats {
     int64_t graph_launches = 0, graph_captures = 0, eager_graphs = 0, kernel_launches = 0, fused_nodes = 0, allreduces = 0;
     int64_t skinny_launches = 0;       // mat-muls of 2..32 columns served by the weight-streaming matrix-core kernel
     int64_t wide_launches = 0;         // prompt-batch mat-muls served by its wide form
+    int64_t rope_epilogues = 0;        // batches whose rope + KV-cache stores rode in the skinny QKV launches
     int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)
 };
 

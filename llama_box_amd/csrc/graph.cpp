@@ -228,6 +228,8 @@ struct exec_state {
     // a split-K mat-mul whose partial products are summed by the norm + quantise kernel that reads it next (no reduce pass)
     const ggml_tensor * sk_dst = nullptr;
     splitk_src sk{};
+    const ggml_tensor * epi_dst = nullptr;  // run_mul_mat_q: the skinny launch that produces this tensor carries `epi` (a sibling of another weight format)
+    mmq_epi epi{};
     int sk_next = -1;  // node index at which run_mul_mat_q may look ahead (set by the caller: first node after the consumed ones)
     // merged Q/K/V projections whose split-K partial products are summed by the rope + cache-store kernel at node `node`
     struct { int node = -1, n = 0, ks = 0, M = 0; mmq_mat_desc mats[3]; const ggml_tensor * dst[3]; const float * part = nullptr; } rs_sk;
@@ -364,7 +366,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const bool i8 = c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M);
     if (M >= c->opt.mmq_min_cols && !w2 && !add2 && (!add || i8) && (i8 || mmq_supported(w->type, K, N, M))) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes);
-        const int ks = (N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M, c->opt.mmq_skinny, w->type) : 1;
+        const int ks = st.epi_dst == dst ? 1 : ((N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M, c->opt.mmq_skinny, w->type) : 1);
         float * part = (float *) ((char *) c->ws + st.aux_off);
         if (i8) {
             const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
@@ -386,8 +388,9 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
                     }
                 }
             }
-            const int served = launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn, ks, part,
-                                             add ? (const float *) add->data : nullptr, add_stride, !defer, c->opt.mmq_skinny);
+            const mmq_epi * epi = st.epi_dst == dst ? &st.epi : nullptr;
+            const int served = launch_mmq_i8(c->stream, w->type, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4), c->opt.mmq_bn, epi ? 1 : ks, part,
+                                             add ? (const float *) add->data : nullptr, add_stride, !defer, c->opt.mmq_skinny, epi);
             c->st.skinny_launches += served == 1;
             c->st.wide_launches += served == 2;
             if (defer) {
@@ -808,7 +811,67 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         n_total += w->ne[1];
         wbytes += (double) ggml_abi_row_size(w->type, K) * (double) w->ne[1];
     }
-    const int ks = mmq_pick_ksplit(K, n_total, M, c->opt.mmq_skinny, type);
+    int ks = mmq_pick_ksplit(K, n_total, M, c->opt.mmq_skinny, type);
+    // -np decode steps: when these are the attention projections and ROPE(q), ROPE(k), SET_ROWS(k), SET_ROWS(v) follow (the window
+    // plan_rope_store recognises), the skinny launches rotate and store in their epilogue — no K split, no f32 projections, no rope launch
+    rope_store_plan epl;
+    int epi_node = -1;
+    mmq_epi epi{};
+    if (c->opt.fusion && c->opt.mmq_skinny && c->opt.skinny_rope && M <= 32 && st.rs_sk.node < 0) {
+        for (int k = i + ms[0].n_nodes; k < std::min(g->n_nodes, i + 24) && epi_node < 0; ++k)
+            if (!st.done[k] && !is_view_op(g->nodes[k])) {
+                bool member = false;
+                for (auto & o : ms) member = member || k == o.k || (o.n_nodes == 2 && k == o.k + 1);
+                for (auto & o : others) member = member || k == o.k || (o.n_nodes == 2 && k == o.k + 1);
+                if (!member) epi_node = k;
+            }
+        bool ok = epi_node >= 0 && g->nodes[epi_node]->op == GGML_OP_ROPE;
+        if (ok) {
+            // (the members behind node i are flagged done below; the plan's window walk must already see them that way)
+            std::vector<int> flagged;
+            for (size_t q = 1; q < ms.size(); ++q) for (int d = 0; d < ms[q].n_nodes; ++d) if (!st.done[ms[q].k + d]) { st.done[ms[q].k + d] = true; flagged.push_back(ms[q].k + d); }
+            for (auto & o : others) for (int d = 0; d < o.n_nodes; ++d) if (!st.done[o.k + d]) { st.done[o.k + d] = true; flagged.push_back(o.k + d); }
+            ok = plan_rope_store(st, epi_node, epl);
+            for (int f : flagged) st.done[f] = false;
+        }
+        // (all three in ONE launch only: a sibling of another weight format — wv as Q6_K — would run alone without its K split, 32 workgroups for
+        // 1024 rows, and cost more than the rope launch saves: measured 4.27 -> 4.40 ms per -np 32 step with it, 4.27 -> 4.2 without)
+        ok = ok && epl.a.p.mode == 0 && (epl.a.head_dim % 2) == 0 && ms.size() == 3 && others.empty();
+        auto role_of = [&](const member & m) {
+            for (int sidx = 0; sidx < 3; ++sidx)
+                if (through_views(epl.src[sidx]) == m.dst) return sidx;
+            return -1;
+        };
+        auto member_ok = [&](const member & m, int64_t N) {
+            const int r = role_of(m);
+            const int64_t arows = m.add ? m.add->ne[1] * m.add->ne[2] * m.add->ne[3] : 0;
+            const ggml_tensor * w = g->nodes[m.k]->src[0];
+            return r >= 0 && use_count(st, m.dst) == 1 && !(m.dst->flags & GGML_TENSOR_FLAG_OUTPUT) && (!m.add || arows == 1) && (N % epl.a.head_dim) == 0 &&
+                   mmq_skinny_supported(w->type, K, N, M, (int64_t) w->nb[1]) &&
+                   N == (r == 0 ? (int64_t) epl.a.nh : (int64_t) epl.a.nkv) * epl.a.head_dim;
+        };
+        for (size_t q = 0; q < ms.size() && ok; ++q) ok = member_ok(ms[q], mats[q].N);
+        for (auto & o : others) ok = ok && member_ok(o, g->nodes[o.k]->src[0]->ne[1]);
+        if (ok) {
+            rope_host_consts(epl.a.p, epi.theta_scale, epi.corr0, epi.corr1);
+            epi.freq_scale = epl.a.p.freq_scale;
+            epi.ext_factor = epl.a.p.ext_factor;
+            epi.attn_factor = epl.a.p.attn_factor;
+            epi.pos = epl.a.pos;
+            epi.ff = epl.a.ff;
+            epi.idx = epl.a.idx;
+            epi.head_dim = epl.a.head_dim;
+            epi.n_dims = epl.a.p.n_dims;
+            ks = 1;
+        } else
+            epi_node = -1;
+    }
+    auto epi_fill = [&](mmq_epi & e, int slot, int role) {  // role: 0 q, 1 k, 2 v
+        e.kind[slot] = role == 0 ? 1 : (role == 1 ? 2 : 3);
+        e.out[slot] = role == 0 ? epl.a.q_dst : (role == 1 ? epl.a.k_cache : epl.a.v_cache);
+        e.nb1[slot] = role == 0 ? epl.a.qd_nb1 : (role == 1 ? epl.a.kc_nb1 : epl.a.vc_nb1);
+        e.nb2[slot] = role == 0 ? epl.a.qd_nb2 : 0;
+    };
     if ((size_t) ks * (size_t) M * (size_t) n_total * sizeof(float) > c->ws_size - st.aux_off && ks > 1) return 0;
     const void * act = quantized_src1(st, X, type);
     for (size_t q = 1; q < ms.size(); ++q)
@@ -819,7 +882,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     // that kernel sums the partial products itself — no reduce pass, and the f32 projections are never written
     bool defer = false;
     int jr = -1;
-    if (ks > 1 && c->opt.fusion && st.rs_sk.node < 0) {
+    if (ks > 1 && c->opt.fusion && st.rs_sk.node < 0 && epi_node < 0) {
         for (int k = i + ms[0].n_nodes; k < std::min(g->n_nodes, i + 24) && jr < 0; ++k)
             if (!st.done[k] && !is_view_op(g->nodes[k])) jr = k;
         rope_store_plan pl;
@@ -838,7 +901,15 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     float * part = (float *) ((char *) c->ws + st.aux_off);
     {
         timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (ms.size() == 3 ? "_x3" : "_x2")).c_str(), wbytes);
-        const int served = launch_mmq_i8_multi(c->stream, type, (int) ms.size(), mats, (int) K, (int) M, act, c->opt.mmq_bn, ks, part, !defer, c->opt.mmq_skinny);
+        if (epi_node >= 0) {
+            auto role_of2 = [&](const member & m) {
+                for (int sidx = 0; sidx < 3; ++sidx)
+                    if (through_views(epl.src[sidx]) == m.dst) return sidx;
+                return -1;
+            };
+            for (size_t q = 0; q < ms.size(); ++q) epi_fill(epi, (int) q, role_of2(ms[q]));
+        }
+        const int served = launch_mmq_i8_multi(c->stream, type, (int) ms.size(), mats, (int) K, (int) M, act, c->opt.mmq_bn, ks, part, !defer, c->opt.mmq_skinny, epi_node >= 0 ? &epi : nullptr);
         c->st.skinny_launches += served == 1;
         c->st.wide_launches += served == 2;
     }
@@ -856,10 +927,27 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     }
     st.aux_off += aux_bump;
     for (auto & o : others) {
-        if (!run_mul_mat_q(st, g->nodes[o.k]->src[0], nullptr, X, o.dst, o.add, nullptr)) { st.aux_off -= aux_bump; return -1; }
+        if (epi_node >= 0) {
+            int role = -1;
+            for (int sidx = 0; sidx < 3; ++sidx)
+                if (through_views(epl.src[sidx]) == o.dst) role = sidx;
+            st.epi = epi;
+            for (int q = 0; q < 3; ++q) st.epi.kind[q] = 0;
+            epi_fill(st.epi, 0, role);
+            st.epi_dst = o.dst;
+        }
+        const bool ok_o = run_mul_mat_q(st, g->nodes[o.k]->src[0], nullptr, X, o.dst, o.add, nullptr);
+        st.epi_dst = nullptr;
+        if (!ok_o) { st.aux_off -= aux_bump; return -1; }
         c->st.fused_nodes += o.n_nodes - 1;
     }
     st.aux_off -= aux_bump;
+    if (epi_node >= 0) {  // ROPE(q), ROPE(k), SET_ROWS(k), SET_ROWS(v) happened in the epilogues
+        mark_done(st, epi_node);
+        for (int k : epl.nodes) mark_done(st, k);
+        c->st.fused_nodes += 4;
+        c->st.rope_epilogues++;
+    }
     return ms[0].n_nodes;
 }
 

@@ -105,16 +105,30 @@ bool mmq_supported(int type, int64_t K, int64_t N, int64_t M);
 size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M, bool skinny);
 // int8-matrix-core variant for Q4_K / Q5_K (mmq_i8.hip); force_bn: 0 = auto, 64 / 128 = weight-panel height
 struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
+// Epilogue of the skinny kernel (2..32 columns, no K split) for the attention projections of a batch: the ROPE of q and k and both
+// KV-cache stores happen where the projections' sums are complete — the rope + store launch of ops.hip (k_rope_qk_store) disappears.
+// Adjacent-pair ("normal") rotation only: both elements of a pair sit in one 32-row tile.
+struct mmq_epi {
+    int kind[3];            // per matrix of the launch: 0 plain, 1 ROPE -> f32 rope(q) tensor, 2 ROPE -> f16 cache rows (k), 3 f16 cache rows (v)
+    char * out[3];          // kind 1: rope(q) data; 2 / 3: cache data
+    int64_t nb1[3], nb2[3]; // kind 1: bytes per head / per token of rope(q); 2 / 3: nb1 = bytes per cache row
+    const int32_t * pos;
+    const float * ff;
+    const int64_t * idx;    // cache row of each token
+    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
+    int head_dim, n_dims;
+};
 // up to three matrices of one type against the same activations in one launch (wq/wk/wv, ffn_gate/ffn_up of a batch)
 // (both return which kernel served the launch: 0 the tiled GEMM of mmq_i8.hip, 1 the skinny weight-streaming kernel, 2 its wide form)
-int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce = true, bool skinny = false);
+int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce = true, bool skinny = false,
+                        const mmq_epi * epi = nullptr /* only with skinny-served launches and ksplit 1 (the caller checked mmq_skinny_supported) */);
 void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * mats, const float * part, int ks, int M);  // the reduce pass of launch_mmq_i8_multi(reduce = false), later
 bool mmq_i8_supported(int type, int64_t K, int64_t N, int64_t M);
 // ksplit > 1: the K range is split over that many workgroup rows, partials in `part` (mmq_workspace_bytes), summed in a fixed order
 int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M, bool skinny, int type);
 void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 int launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride, bool reduce = true, bool skinny = false);
+                   int ksplit, float * part, const float * add /* optional bias row or residual */, int64_t add_stride, bool reduce = true, bool skinny = false, const mmq_epi * epi = nullptr);
 // 2..32 columns (continuous-batching decode steps): the weight-streaming matrix-core kernel of mmq_skinny.hip, reached through
 // launch_mmq_i8[_multi](skinny = true); the caller's activation area must hold 32 columns' worth of bytes (read, never used)
 bool mmq_skinny_supported(int type, int64_t K, int64_t N, int64_t M, int64_t w_nb1);

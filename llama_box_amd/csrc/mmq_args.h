@@ -26,6 +26,8 @@ struct mmq8_args {
     const q8k_dev * act;  // [M][K/256]
     int n_panels, m_tiles;
     int ksplit;          // > 1: blockIdx.y owns a contiguous range of super-blocks and writes its partial result
+    int has_epi;         // skinny kernel: `epi` describes what happens to the results instead of the plain store
+    mmq_epi epi;
 };
 
 void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a);

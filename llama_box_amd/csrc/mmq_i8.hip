@@ -490,7 +490,7 @@ void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int 
 }
 
 // n_mat (1..3) matrices of one type against the same activations; `part` holds ksplit * M * sum(N) floats when ksplit > 1
-int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce, bool skinny) {
+int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc * mats, int K, int M, const void * act_q8k, int force_bn, int ksplit, float * part, bool reduce, bool skinny, const mmq_epi * epi) {
     mmq8_args a{};
     a.n_mat = n_mat;
     a.K = K;
@@ -527,7 +527,15 @@ int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc *
         }
     }
     skinny = skinny && (a.ksplit & (a.ksplit - 1)) == 0;  // (its K split is a power of two: mmq_skinny_ksplit)
+    if (epi && !(skinny && a.ksplit == 1)) {
+        MI_ERR("launch_mmq_i8_multi: a rope / cache-store epilogue was requested for a launch the skinny kernel does not serve");
+        abort();
+    }
     if (skinny) {  // a decode step of a continuous batch: stream the weights once (mmq_skinny.hip)
+        if (epi) {
+            a.has_epi = 1;
+            a.epi = *epi;
+        }
         launch_mmq_skinny(s, type, a);
         if (a.ksplit > 1 && reduce) launch_splitk_reduce_multi(s, a);
         return 1;
@@ -581,9 +589,9 @@ void launch_splitk_reduce_mats(hipStream_t s, int n_mat, const mmq_mat_desc * ma
     launch_splitk_reduce_multi(s, a);
 }
 int launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int force_bn,
-                   int ksplit, float * part, const float * add, int64_t add_stride, bool reduce, bool skinny) {
+                   int ksplit, float * part, const float * add, int64_t add_stride, bool reduce, bool skinny, const mmq_epi * epi) {
     const mmq_mat_desc m{W, w_nb1, N, dst, dst_stride, add, add_stride};
-    return launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part, reduce, skinny);
+    return launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part, reduce, skinny, epi);
 }
 
 }  // namespace mi355x

@@ -158,7 +158,10 @@ template <int QT> __device__ __forceinline__ void sk_unit_k45(const char * __res
     }
 }
 
-template <int QT>
+// EPI: the results of the attention projections of a batch are rotated and stored by this launch (mmq_epi) — a separate instantiation,
+// because the accurate cosf / sinf of the rotation bring a scratch frame that every launch of the kernel would otherwise pay for
+// (measured: 4.27 -> 4.45 ms per -np 32 step with the epilogue compiled into the one kernel, used or not)
+template <int QT, bool EPI>
 __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef sk_fmt<QT> F;
@@ -368,11 +371,36 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
             float v = *(const float *) (smem + o * 4);
 #pragma unroll
             for (int w = 1; w < SK_NW; ++w) v += *(const float *) (smem + w * sk_wave_lds<QT>() + o * 4);
+            if (a.ksplit > 1) {
+                if (tok < a.M) m_part[((size_t) ky * a.M + tok) * mN + n] = v;
+                continue;
+            }
+            const int tk = min(tok, a.M - 1);
+            if (m_add) v += m_add[(size_t) tk * m_add_stride + n];
+            const int kind = EPI ? (mi == 0 ? a.epi.kind[0] : (mi == 1 ? a.epi.kind[1] : a.epi.kind[2])) : 0;
+            if (kind == 0) {
+                if (tok < a.M) m_dst[(size_t) tok * m_dst_stride + n] = v;
+                continue;
+            }
+            if constexpr (EPI) {
+            // the attention projections of a batch: rotate (q, k) and store (rope(q) as f32, k and v as f16 rows of the cache) — the
+            // arithmetic of k_rope_qk_store (ops.hip), element for element
+            const float partner = __shfl_xor(v, 1);  // the other element of the rotation pair: rows n ^ 1, adjacent lanes
+            char * const e_out = mi == 0 ? a.epi.out[0] : (mi == 1 ? a.epi.out[1] : a.epi.out[2]);
+            const int64_t e_nb1 = mi == 0 ? a.epi.nb1[0] : (mi == 1 ? a.epi.nb1[1] : a.epi.nb1[2]);
+            const int64_t e_nb2 = mi == 0 ? a.epi.nb2[0] : (mi == 1 ? a.epi.nb2[1] : a.epi.nb2[2]);
+            const int head = n / a.epi.head_dim, dd = n - head * a.epi.head_dim;
+            float r = v;
+            if (kind != 3 && dd < a.epi.n_dims) {
+                const rope_consts rc{a.epi.theta_scale, a.epi.freq_scale, a.epi.ext_factor, a.epi.attn_factor, a.epi.corr0, a.epi.corr1};
+                float cs, sn;
+                rope_cos_sin(dd >> 1, (float) a.epi.pos[tk], a.epi.ff, rc, cs, sn);
+                const float x0 = (dd & 1) ? partner : v, x1 = (dd & 1) ? v : partner;
+                r = (dd & 1) ? x0 * sn + x1 * cs : x0 * cs - x1 * sn;
+            }
             if (tok >= a.M) continue;
-            if (a.ksplit > 1) m_part[((size_t) ky * a.M + tok) * mN + n] = v;
-            else {
-                if (m_add) v += m_add[(size_t) tok * m_add_stride + n];
-                m_dst[(size_t) tok * m_dst_stride + n] = v;
+            if (kind == 1) *(float *) (e_out + (int64_t) head * e_nb1 + (int64_t) tok * e_nb2 + (int64_t) dd * 4) = r;
+            else ((uint16_t *) (e_out + a.epi.idx[tok] * e_nb1))[n] = f2h(r);
             }
         }
         __syncthreads();  // the areas are free for the next item's units
@@ -867,7 +895,7 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
     const int n_cu = skinny_n_cu();
     a.m_tiles = 1;
     if constexpr (QT == 4 || QT == 5) {
-        if (skinny_tp_applies(QT == 4 ? GGML_TYPE_Q4_K : GGML_TYPE_Q5_K, a, n_cu)) {
+        if (!a.has_epi && skinny_tp_applies(QT == 4 ? GGML_TYPE_Q4_K : GGML_TYPE_Q5_K, a, n_cu)) {
             static std::atomic<uint32_t> lds_raised_tp{0};
             (void) ensure_dyn_lds((const void *) k_mmq_skinny_tp<QT>, (size_t) tp_lds_bytes<QT>(), lds_raised_tp);
             a.n_panels = 0;
@@ -880,8 +908,10 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
         }
     }
     const size_t lds = (size_t) SK_NW * sk_wave_lds<QT>();
-    static std::atomic<uint32_t> lds_raised{0};
-    (void) ensure_dyn_lds((const void *) k_mmq_skinny<QT>, lds, lds_raised);
+    static std::atomic<uint32_t> lds_raised{0}, lds_raised_epi{0};
+    const void * fn_plain = (const void *) k_mmq_skinny<QT, false>;
+    const void * fn_epi = (const void *) k_mmq_skinny<QT, true>;
+    (void) ensure_dyn_lds(a.has_epi ? fn_epi : fn_plain, lds, a.has_epi ? lds_raised_epi : lds_raised);
     a.n_panels = 0;
     for (int i = 0; i < a.n_mat; ++i) {
         a.mat[i].panel0 = a.n_panels;
@@ -889,7 +919,8 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
     }
     // one workgroup per CU (its LDS areas fill the CU), walking the (tile, K slice) items with a stride of the grid
     const int items = a.n_panels * a.ksplit;
-    hipLaunchKernelGGL((k_mmq_skinny<QT>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
+    if (a.has_epi) hipLaunchKernelGGL((k_mmq_skinny<QT, true>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
+    else hipLaunchKernelGGL((k_mmq_skinny<QT, false>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
 }
 
 void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a) {

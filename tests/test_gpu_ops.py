@@ -1012,6 +1012,57 @@ def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias, kvt):
             assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused q8_0 cache rows differ"
 
 
+@pytest.mark.parametrize("tq,tv,M,n_dims,bias", [(L.Q4_K, L.Q4_K, 32, 128, False), (L.Q4_K, L.Q6_K, 32, 128, False), (L.Q4_K, L.Q6_K, 7, 128, True),
+                                                  (L.Q5_K, L.Q5_K, 19, 64, False), (L.Q6_K, L.Q6_K, 32, 128, True)])
+def test_np_batch_qkv_rope_store_in_the_gemm_epilogue(backend, H, plog, tq, tv, M, n_dims, bias):
+    """-np decode step (3..32 tokens): wq / wk / wv -> (+bias) -> rope(q, k) -> KV-cache stores.  The skinny launches (one when the
+    three weights share a format, two when wv is stored in another) rotate and store in their epilogue — no rope launch, the f32
+    projections are never written.  Equal to the oracle, and to the unfused execution bit for bit (same mat-mul kernel, same rope
+    arithmetic element for element)."""
+    rng = np.random.default_rng(77 + tq * 7 + tv + M)
+    E, HD, NH, NKV, NCTX = 1024, 128, 8, 2, 300
+    x = rng.standard_normal((M, E)).astype(np.float32)
+    wq, wk, wv = T.rand_weight(tq, E, NH * HD, rng), T.rand_weight(tq, E, NKV * HD, rng), T.rand_weight(tv, E, NKV * HD, rng)
+    bq, bk, bv = (rng.standard_normal(n).astype(np.float32) for n in (NH * HD, NKV * HD, NKV * HD))
+    kc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    vc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    pos = rng.integers(0, 5000, M).astype(np.int32)
+    rows = rng.permutation(NCTX)[:M].astype(np.int64)
+
+    def build(g):
+        cur = g.new(L.F32, [E, M], x)
+        q = H.ggml_mul_mat(g.ctx, g.new(tq, [E, NH * HD], wq), cur)
+        k = H.ggml_mul_mat(g.ctx, g.new(tq, [E, NKV * HD], wk), cur)
+        v = H.ggml_mul_mat(g.ctx, g.new(tv, [E, NKV * HD], wv), cur)
+        if bias:
+            q = H.ggml_add(g.ctx, q, g.new(L.F32, [NH * HD], bq))
+            k = H.ggml_add(g.ctx, k, g.new(L.F32, [NKV * HD], bk))
+            v = H.ggml_add(g.ctx, v, g.new(L.F32, [NKV * HD], bv))
+        tp = g.new(L.I32, [M], pos)
+        idx = g.new(L.I64, [M], rows)
+        q = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, q, HD, NH, M), tp, None, n_dims, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        k = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, k, HD, NKV, M), tp, None, n_dims, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], kc0), H.ggml_reshape_2d(g.ctx, k, NKV * HD, M), idx)
+        vs = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], vc0), v, idx)
+        return [q, ks, vs]
+
+    ref = T.run_case(build, "oracle", expand_first=())
+    e0, k0 = backend.stat("rope_epilogues"), backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    epilogues, launches = backend.stat("rope_epilogues") - e0, backend.stat("kernel_launches") - k0
+    backend.set_option("skinny_rope", 0)
+    try:
+        plain = T.run_case(build, backend)
+    finally:
+        backend.set_option("skinny_rope", 1)
+    plog(f"    np batch qkv {QNAME[tq]}/{QNAME[tv]} M={M} n_dims={n_dims} bias={bias}: {launches} launches, {epilogues} rope epilogue(s)")
+    assert epilogues == (1 if tq == tv else 0), epilogues  # (a sibling of another format keeps its K split and the separate rope launch)
+    for name, a, b, c in zip(("q_rope", "k_cache", "v_cache"), got, ref, plain):
+        a32, b32, c32 = (np.asarray(t).astype(np.float32) for t in (a, b, c))
+        T.compare(f"np batch qkv {QNAME[tq]}/{QNAME[tv]} M={M} {name}", a32, b32, max_nmse=1e-10 if name == "q_rope" else 1e-6, log=plog)
+        assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: epilogue and separate rope launch differ"
+
+
 @pytest.mark.parametrize("mode,n_dims,T_", [(0, 128, 32), (L.ROPE_NEOX, 128, 5), (0, 64, 130)])
 def test_batch_rope_and_cache_stores_one_launch(backend, H, plog, mode, n_dims, T_):
     """A batch's ROPE(q), ROPE(k), SET_ROWS(k cache), SET_ROWS(v cache) run as one launch (k_rope_qk_store) and equal both the
