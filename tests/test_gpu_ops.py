@@ -266,7 +266,9 @@ def test_mul_mat_q_3d_src1(backend, H, plog, qt):
 
 # ------------------------------------------------------------------------------------------------ MUL_MAT (f16/f32)
 @pytest.mark.parametrize("wt", [L.F16, L.F32])
-@pytest.mark.parametrize("K,N,M,B0,B1", [(128, 96, 1, 2, 8), (64, 33, 3, 1, 4), (200, 17, 2, 1, 1), (2048, 128, 1, 2, 4), (7, 5, 2, 1, 1)])
+@pytest.mark.parametrize("K,N,M,B0,B1", [(128, 96, 1, 2, 8), (64, 33, 3, 1, 4), (200, 17, 2, 1, 1), (2048, 128, 1, 2, 4), (7, 5, 2, 1, 1),
+                                          # batches of columns (a prompt chunk on the non-flash path): the f16 matrix-core kernel, ragged tiles, K = 8 mod 16
+                                          (128, 96, 40, 2, 8), (64, 130, 33, 1, 4), (200, 70, 16, 1, 1), (2048, 128, 100, 2, 4), (136, 50, 64, 1, 2), (128, 512, 512, 8, 32)])
 def test_mul_mat_f(backend, H, plog, wt, K, N, M, B0, B1):
     rng = np.random.default_rng(K + N + M)
     w = rng.standard_normal((B0, N, K)).astype(np.float16 if wt == L.F16 else np.float32)
