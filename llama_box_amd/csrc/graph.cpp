@@ -528,6 +528,7 @@ struct qkv_chain {
     const ggml_tensor * bias = nullptr;
     const ggml_tensor * rope = nullptr;
     const ggml_tensor * store = nullptr;    // SET_ROWS node (f16 cache rows)
+    bool scatter = false;                   // ... whose rows are single elements (transposed V cache): one index per value
     const ggml_tensor * out_f32 = nullptr;  // otherwise: last materialised f32 tensor of the chain
     std::vector<int> nodes;
 };
@@ -571,6 +572,16 @@ static bool follow_qkv_chain(const exec_state & st, int start, int limit, qkv_ch
             c->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(c->src[1]) == 1 &&
             ((c->type == GGML_TYPE_F16 && c->nb[0] == 2) || (c->type == GGML_TYPE_Q8_0 && (N % 32) == 0))) {
             ch.store = c;
+            ch.nodes.push_back(j);
+            return true;
+        }
+        // the non-flash path keeps V transposed: the projection is viewed as N rows of one element and each goes to its own cache row
+        // (llama.cpp's v_idxs: element j of the token -> j * n_ctx + cell)
+        if (c->op == GGML_OP_SET_ROWS && c->src[0] == cur && cur->ne[0] == 1 && c->ne[0] == 1 && ggml_abi_nelements(cur) == N &&
+            c->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(c->src[1]) == N && ggml_abi_is_contiguous(c->src[1]) &&
+            c->type == GGML_TYPE_F16 && c->nb[0] == 2 && c->nb[1] == 2) {
+            ch.store = c;
+            ch.scatter = true;
             ch.nodes.push_back(j);
             return true;
         }
@@ -635,7 +646,7 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             if (rope0 && (memcmp(rope0->op_params, r->op_params, sizeof(r->op_params)) != 0 || rope0->src[1] != r->src[1] || rope0->src[2] != r->src[2] || rope0->ne[0] != r->ne[0])) return false;
             rope0 = r;
         }
-        if (ch.store) {
+        if (ch.store && !ch.scatter) {
             if (idx0 && idx0->data != ch.store->src[1]->data) return false;
             idx0 = ch.store->src[1];
         }
@@ -708,7 +719,8 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             sg.N = (int) w->ne[1];
             sg.bias = ch.bias ? (const float *) ch.bias->data : nullptr;
             sg.rope = ch.rope ? 1 : 0;
-            sg.store = !ch.store ? 0 : (ch.store->type == GGML_TYPE_Q8_0 ? 2 : 1);
+            sg.store = !ch.store ? 0 : ch.scatter ? 3 : (ch.store->type == GGML_TYPE_Q8_0 ? 2 : 1);
+            sg.idx = ch.scatter ? (const int64_t *) ch.store->src[1]->data : nullptr;
             sg.out = ch.store ? (char *) ch.store->data : (char *) ch.out_f32->data;
             sg.row_stride = ch.store ? (int64_t) ch.store->nb[1] : 0;
             bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];
@@ -1256,6 +1268,31 @@ static int run_node(exec_state & st, int i) {
         }
         case GGML_OP_SOFT_MAX: {
             const tdesc md = b ? TD(b) : TD(a);
+            // a decode step on the non-flash path: the probabilities have one reader, MUL_MAT(V^T view, p) — made inside that product
+            if (fuse && c->opt.softmax_mm && n->ne[1] == 1 && !n->src[2] && ggml_abi_op_param_f32(n, 1) == 0.0f && a->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(a) &&
+                single_use(st, n)) {
+                int j = -1;
+                for (int k = i + 1; k < std::min(g->n_nodes, i + 8) && j < 0; ++k) {
+                    if (st.done[k]) continue;
+                    const ggml_tensor * t = g->nodes[k];
+                    if (t->op == GGML_OP_MUL_MAT && t->src[1] == n) j = k;
+                    else if (!is_view_op(t)) break;
+                }
+                if (j >= 0) {
+                    const ggml_tensor * mm = g->nodes[j];
+                    const ggml_tensor * v = mm->src[0];
+                    // workgroups store rows of the product while others still read the logits: no recycled memory between the two
+                    if (v->type == GGML_TYPE_F16 && !buffer_is_split(v->buffer) && ggml_abi_is_contiguous(mm) && !ranges_overlap(mm, a) && !(b && ranges_overlap(mm, b))) {
+                        timed_scope ts(c, "soft_max_mul_mat_f", (double) ggml_abi_nbytes(v) + (double) ggml_abi_nbytes(n));
+                        if (launch_soft_max_mul_mat_f16(s, TD(v), TD(a), b ? &md : nullptr, TD(mm), ggml_abi_op_param_f32(n, 0))) {
+                            mark_done(st, j);
+                            c->st.kernel_launches++;
+                            c->st.fused_nodes++;
+                            return 1;
+                        }
+                    }
+                }
+            }
             timed_scope ts(c, "soft_max", (double) ggml_abi_nbytes(n) * 2);
             launch_soft_max(s, TD(a), b ? &md : nullptr, n->src[2] ? (const float *) n->src[2]->data : nullptr, TD(n), ggml_abi_op_param_f32(n, 0), ggml_abi_op_param_f32(n, 1));
             c->st.kernel_launches++;

@@ -75,9 +75,11 @@ struct qkv_seg {
     int alt, N;           // alt: 0 = first weight format of the launch, 1 = second
     const float * bias;   // optional [N]
     int rope;             // rotate pairs of this segment
-    int store;            // 0: f32 at out; 1: f16 / 2: block_q8_0 into row `slot` of a cache tensor (out + slot*row_stride)
+    int store;            // 0: f32 at out; 1: f16 / 2: block_q8_0 into row `slot` of a cache tensor (out + slot*row_stride);
+                          // 3: f16 element j at out + 2 idx[j] (the transposed V cache of the non-flash path: one row index per element)
     char * out;
     int64_t row_stride;
+    const int64_t * idx;  // store == 3
 };
 struct qkv_args {
     qkv_seg seg[3];
@@ -99,6 +101,7 @@ void launch_qkv(hipStream_t s, const qkv_args & a, int type_a, int type_b);
 // ---- f16 / f32 weights (K cache, V cache, small dense) (mmf.hip): dst = src0 · src1 with ggml broadcasting;
 // src1 rounded to f16 first when src0 is f16 (ggml-cpu vec_dot_type semantics)
 void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, const tdesc & dst);
+bool launch_soft_max_mul_mat_f16(hipStream_t s, const tdesc & a, const tdesc & kq, const tdesc * mask, const tdesc & d, float scale);  // decode: SOFT_MAX folded into V^T.p (mmf.hip)
 
 // ---- prefill: quantised weights x many columns through MFMA (mmq.hip)
 bool mmq_supported(int type, int64_t K, int64_t N, int64_t M);

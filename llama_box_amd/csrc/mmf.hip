@@ -105,6 +105,372 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mma(const tdesc a, const td
     }
 }
 
+// ---- one column against an f16 src0 that G heads of src1 share (K.q and V^T.p of a decode step on the non-flash path with grouped
+// queries: a.ne[2] KV heads, b.ne[2] = G a.ne[2] query heads).  The dot kernel above runs one workgroup per (rows, query head): every
+// src0 row is fetched G times and each wave waits out one or two dependent loads — 10 us per call at 2k cells, for 4.7 MB.  Here a
+// row owner fetches its slice of the row ONCE and feeds G accumulators (src1 is rounded to f16 first, as from_float does), with
+// several rows' loads in flight:
+//   short rows (K <= 512, K.q: rows = cells): LPR lanes own a row, 4 rows per owner, 64 x 4 / LPR rows per wave;
+//   long rows (V^T.p: K = cells): a wave owns 4 rows, the 4 waves of the workgroup take K in interleaved 512-element slices and
+//   add up through LDS.
+// f32 accumulation in a different order than the dot kernel (and the CPU); same NMSE gate (tests/test_gpu_ops.py::test_mul_mat_f).
+__device__ __forceinline__ void mmf_w8(const char * p, float (&w)[8]) {
+    const uint4 t = *(const uint4 *) p;
+    const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w[2 * i] = h2f((uint16_t) (u[i] & 0xFFFF));
+        w[2 * i + 1] = h2f((uint16_t) (u[i] >> 16));
+    }
+}
+__device__ __forceinline__ void mmf_x8(const char * p, float (&x)[8]) {
+    const float4 x0 = *(const float4 *) p, x1 = *(const float4 *) (p + 16);
+    const float t[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = h2f(f2h(t[i]));
+}
+// sum over each group of LPR consecutive lanes, on the DPP path (the 64 ds_bpermute a shuffle butterfly needs here — 16 sums, 4
+// dependent steps each — were 3.7 of the kernel's 7.8 us: scripts/ubench/attn_probe.hip)
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+    if (LPR == 64) return wave_sum(v);
+    if (LPR >= 16) {
+        v = row16_sum(v);
+        if (LPR == 32) v += __shfl_xor(v, 16, 64);
+        return v;
+    }
+    v += dpp_f32<MI_DPP_QUAD_XOR1>(v);
+    v += dpp_f32<MI_DPP_QUAD_XOR2>(v);
+    v += dpp_f32<MI_DPP_HALF_MIRROR>(v);
+    return v;
+}
+template <int G, int LPR>
+__global__ void __launch_bounds__(256) k_mul_mat_f16_gqa_short(const tdesc a, const tdesc b, const tdesc d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int lpr = LPR;
+    const int rpw = 64 / lpr, sub = lane / lpr, sl = lane % lpr;
+    const int64_t i02 = blockIdx.y, K = a.ne[0];
+    const int64_t base = (int64_t) blockIdx.x * 16 * rpw + wave * rpw + sub;  // owner's rows: base + 4 rpw r
+    const bool kin = (int64_t) sl * 8 < K;
+    float x[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (kin) mmf_x8(b.data + (i02 * G + g) * b.nb[2] + (int64_t) sl * 32, x[g]);
+        else
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[g][i] = 0.0f;
+    }
+    float w[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = std::min<int64_t>(base + 4 * rpw * r, a.ne[1] - 1);
+        if (kin) mmf_w8(a.data + row * a.nb[1] + i02 * a.nb[2] + (int64_t) sl * 16, w[r]);
+        else
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[r][i] = 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = base + 4 * rpw * r;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = fmaf(w[r][i], x[g][i], acc);
+            acc = group_sum<LPR>(acc);
+            if (sl == 0 && row < a.ne[1]) *(float *) (d.data + row * d.nb[0] + (i02 * G + g) * d.nb[2]) = acc;
+        }
+    }
+}
+template <int G>
+__global__ void __launch_bounds__(256) k_mul_mat_f16_gqa_long(const tdesc a, const tdesc b, const tdesc d) {
+    __shared__ float part[4][4 * G];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i02 = blockIdx.y, K = a.ne[0], row0 = (int64_t) blockIdx.x * 4;
+    const char * wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wr[r] = a.data + std::min<int64_t>(row0 + r, a.ne[1] - 1) * a.nb[1] + i02 * a.nb[2];
+    float acc[4][G];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[r][g] = 0.0f;
+    for (int64_t k = (int64_t) wave * 512 + lane * 8; k < K; k += 2048) {
+        float w[4][8], x[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mmf_w8(wr[r] + k * 2, w[r]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            mmf_x8(b.data + (i02 * G + g) * b.nb[2] + k * 4, x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[r][g] = fmaf(w[r][i], x[i], acc[r][g]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float v = wave_sum(acc[r][g]);
+            if (lane == 0) part[wave][r * G + g] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * G) {
+        const int r = threadIdx.x / G, g = threadIdx.x % G;
+        const float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        if (row0 + r < a.ne[1]) *(float *) (d.data + (row0 + r) * d.nb[0] + (i02 * G + g) * d.nb[2]) = v;
+    }
+}
+// ---- SOFT_MAX(K.q) folded into V^T.p (a decode step on the non-flash path): the long-row layout above with 8 waves, whose 512 threads
+// x 8 cells tile the whole row.  The workgroup first turns its slices of the G logit rows into probabilities —
+// ggml_compute_forward_soft_max_f32 as ops.hip restates it: w = x scale + mask, max, e = expf(w - max), sum in double, llama-box's
+// zero-sum guard, p = e (1 / sum) — and feeds them (rounded to f16, as from_float would) to the products.  One launch and one round
+// trip of the probabilities less; every row group of a KV head repeats the G rows' exponentials (32 x for 128 dims / 4), so the work
+// per thread is kept to one or two 8-cell slices, the logits / exponentials stay in registers between the passes when the row is
+// short enough (NIT slices of 4096 cells; NIT = 0: re-read and recomputed), and the V^T slices are requested before the statistics
+// are made.  The per-thread partial sums cover other cells than soft_max's own kernel; they are doubles, the float reciprocal is
+// the same in all but freak cases.  scripts/ubench/attn_probe.hip: 6.7 + 5.6 us as two launches at 2304 cells.
+#define SMM_NW 8
+template <int G, int NIT>
+__global__ void __launch_bounds__(64 * SMM_NW) k_soft_max_mul_mat_f16(const tdesc a, const tdesc kq, const tdesc m, const int has_mask, const tdesc d, const float scale) {
+    __shared__ float shm[SMM_NW][G];
+    __shared__ double shs[SMM_NW][G];
+    __shared__ float part[SMM_NW][4 * G];
+    constexpr int64_t STEP = 512 * SMM_NW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i02 = blockIdx.y, K = a.ne[0], row0 = (int64_t) blockIdx.x * 4;
+    const bool m16 = m.type == GGML_TYPE_F16;
+    const int64_t k0 = (int64_t) wave * 512 + lane * 8;
+    auto logits = [&](const int g, const int64_t k, float (&w)[8]) {
+        const int64_t h = i02 * G + g;
+        const char * xp = kq.data + h * kq.nb[2] + k * 4;
+        const float4 x0 = *(const float4 *) xp, x1 = *(const float4 *) (xp + 16);
+        const float t[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        if (has_mask) {
+            const char * mp = m.data + (h % m.ne[2]) * m.nb[2];
+            float mv[8];
+            if (m16) mmf_w8(mp + k * 2, mv);
+            else {
+                const float4 m0 = *(const float4 *) (mp + k * 4), m1 = *(const float4 *) (mp + k * 4 + 16);
+                mv[0] = m0.x; mv[1] = m0.y; mv[2] = m0.z; mv[3] = m0.w; mv[4] = m1.x; mv[5] = m1.y; mv[6] = m1.z; mv[7] = m1.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = t[i] * scale;
+                v += mv[i];
+                w[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = t[i] * scale;
+        }
+    };
+    const char * wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wr[r] = a.data + std::min<int64_t>(row0 + r, a.ne[1] - 1) * a.nb[1] + i02 * a.nb[2];
+    constexpr int NC = NIT > 0 ? NIT : 1;
+    uint4 vq[NC][4];  // this thread's slices of the 4 V^T rows (NIT > 0)
+    if (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NC; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vq[it][r] = k0 + STEP * it < K ? *(const uint4 *) (wr[r] + (k0 + STEP * it) * 2) : make_uint4(0, 0, 0, 0);
+    }
+    float e[NC][G][8];  // logits, then exponentials (NIT > 0)
+    float mx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+    if (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NC; ++it)
+            if (k0 + STEP * it < K)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    logits(g, k0 + STEP * it, e[it][g]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) mx[g] = fmaxf(mx[g], e[it][g][i]);
+                }
+    } else {
+        for (int64_t k = k0; k < K; k += STEP)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float w[8];
+                logits(g, k, w);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mx[g] = fmaxf(mx[g], w[i]);
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float v = wave_max(mx[g]);
+        if (lane == 0) shm[wave][g] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float v = shm[0][g];
+#pragma unroll
+        for (int w = 1; w < SMM_NW; ++w) v = fmaxf(v, shm[w][g]);
+        mx[g] = v;
+    }
+    double sum[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) sum[g] = 0.0;
+    if (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NC; ++it)
+            if (k0 + STEP * it < K)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        e[it][g][i] = expf(e[it][g][i] - mx[g]);
+                        sum[g] += (double) e[it][g][i];
+                    }
+    } else {
+        for (int64_t k = k0; k < K; k += STEP)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float w[8];
+                logits(g, k, w);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum[g] += (double) expf(w[i] - mx[g]);
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const double v = wave_sum_d(sum[g]);
+        if (lane == 0) shs[wave][g] = v;
+    }
+    __syncthreads();
+    float inv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        double t = shs[0][g];
+#pragma unroll
+        for (int w = 1; w < SMM_NW; ++w) t += shs[w][g];
+        if (isnan(t) || t == 0.0) t = -INFINITY;
+        inv[g] = (float) (1.0 / t);
+    }
+    float acc[4][G];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[r][g] = 0.0f;
+    auto product = [&](const int64_t k, const int it) {
+        float w[4][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (NIT > 0) {
+                const uint32_t u[4] = {vq[it][r].x, vq[it][r].y, vq[it][r].z, vq[it][r].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w[r][2 * i] = h2f((uint16_t) (u[i] & 0xFFFF));
+                    w[r][2 * i + 1] = h2f((uint16_t) (u[i] >> 16));
+                }
+            } else mmf_w8(wr[r] + k * 2, w[r]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float x[8];
+            if (NIT > 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = h2f(f2h(e[it][g][i] * inv[g]));
+            } else {
+                logits(g, k, x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = h2f(f2h(expf(x[i] - mx[g]) * inv[g]));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[r][g] = fmaf(w[r][i], x[i], acc[r][g]);
+        }
+    };
+    if (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NC; ++it)
+            if (k0 + STEP * it < K) product(k0 + STEP * it, it);
+    } else {
+        for (int64_t k = k0; k < K; k += STEP) product(k, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float v = wave_sum(acc[r][g]);
+            if (lane == 0) part[wave][r * G + g] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * G) {
+        const int r = threadIdx.x / G, g = threadIdx.x % G;
+        float v = part[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < SMM_NW; ++w) v += part[w][threadIdx.x];
+        if (row0 + r < a.ne[1]) *(float *) (d.data + (row0 + r) * d.nb[0] + (i02 * G + g) * d.nb[2]) = v;
+    }
+}
+template <int G, int MAXC>
+static void launch_smm_t(hipStream_t s, dim3 grid, int nit, const tdesc & a, const tdesc & kq, const tdesc & md, int has_mask, const tdesc & d, float scale) {
+#define SMM(NIT_) hipLaunchKernelGGL((k_soft_max_mul_mat_f16<G, NIT_>), grid, dim3(64 * SMM_NW), 0, s, a, kq, md, has_mask, d, scale)
+    if (nit == 1) { SMM(1); return; }
+    if constexpr (MAXC >= 2) if (nit == 2) { SMM(2); return; }
+    if constexpr (MAXC >= 4) if (nit <= 4) { SMM(4); return; }
+    SMM(0);
+#undef SMM
+}
+static bool mmf_vec_ok(const tdesc & a, const tdesc & b) {
+    const int64_t K = a.ne[0];
+    bool ok = a.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 4 && (K % 8) == 0 && (((uintptr_t) a.data) & 15) == 0 && (((uintptr_t) b.data) & 15) == 0;
+    for (int i = 1; i < 4; ++i) ok = ok && (a.nb[i] % 16) == 0 && (b.nb[i] % 16) == 0;
+    return ok;
+}
+// a = the f16 matrix (V^T view), kq = the logits SOFT_MAX reads, d = the product; false: shapes this kernel does not serve (the caller
+// runs SOFT_MAX and MUL_MAT on their own)
+bool launch_soft_max_mul_mat_f16(hipStream_t s, const tdesc & a, const tdesc & kq, const tdesc * mask, const tdesc & d, const float scale) {
+    const int64_t K = a.ne[0];
+    if (!mmf_vec_ok(a, kq) || kq.ne[0] != K || kq.ne[1] != 1 || kq.ne[3] != 1 || a.ne[3] != 1 || kq.ne[2] % a.ne[2] != 0 || d.nb[0] != 4) return false;
+    if (mask) {
+        const int esz = mask->type == GGML_TYPE_F16 ? 2 : 4;
+        if ((mask->type != GGML_TYPE_F16 && mask->type != GGML_TYPE_F32) || mask->nb[0] != esz || mask->ne[0] < K || mask->ne[3] != 1 || (((uintptr_t) mask->data) & 15) || (mask->nb[2] % 16)) return false;
+    }
+    const int G = (int) (kq.ne[2] / a.ne[2]);
+    const int nit = (int) ((K + 512 * SMM_NW - 1) / (512 * SMM_NW));
+    const tdesc md = mask ? *mask : kq;
+    dim3 grid((unsigned) ((a.ne[1] + 3) / 4), (unsigned) a.ne[2]);
+    switch (G) {  // cached logits / exponentials: at most 64 registers
+        case 1: launch_smm_t<1, 4>(s, grid, nit, a, kq, md, mask ? 1 : 0, d, scale); return true;
+        case 2: launch_smm_t<2, 4>(s, grid, nit, a, kq, md, mask ? 1 : 0, d, scale); return true;
+        case 3: launch_smm_t<3, 2>(s, grid, nit, a, kq, md, mask ? 1 : 0, d, scale); return true;
+        case 4: launch_smm_t<4, 2>(s, grid, nit, a, kq, md, mask ? 1 : 0, d, scale); return true;
+        case 5: launch_smm_t<5, 1>(s, grid, nit, a, kq, md, mask ? 1 : 0, d, scale); return true;
+        case 6: launch_smm_t<6, 1>(s, grid, nit, a, kq, md, mask ? 1 : 0, d, scale); return true;
+        case 7: launch_smm_t<7, 1>(s, grid, nit, a, kq, md, mask ? 1 : 0, d, scale); return true;
+        case 8: launch_smm_t<8, 1>(s, grid, nit, a, kq, md, mask ? 1 : 0, d, scale); return true;
+        default: break;
+    }
+    return false;
+}
+
+template <int G> static void launch_gqa_t(hipStream_t s, const tdesc & a, const tdesc & b, const tdesc & d) {
+    const int64_t K = a.ne[0];
+    if (K <= 512) {
+        int lpr = 64;
+        while (lpr > 8 && (int64_t) (lpr / 2) * 8 >= K) lpr >>= 1;
+        const int rows_per_block = 16 * (64 / lpr);
+        dim3 grid((unsigned) ((a.ne[1] + rows_per_block - 1) / rows_per_block), (unsigned) a.ne[2]);
+        switch (lpr) {
+            case 8: hipLaunchKernelGGL((k_mul_mat_f16_gqa_short<G, 8>), grid, dim3(256), 0, s, a, b, d); break;
+            case 16: hipLaunchKernelGGL((k_mul_mat_f16_gqa_short<G, 16>), grid, dim3(256), 0, s, a, b, d); break;
+            case 32: hipLaunchKernelGGL((k_mul_mat_f16_gqa_short<G, 32>), grid, dim3(256), 0, s, a, b, d); break;
+            default: hipLaunchKernelGGL((k_mul_mat_f16_gqa_short<G, 64>), grid, dim3(256), 0, s, a, b, d); break;
+        }
+    } else {
+        dim3 grid((unsigned) ((a.ne[1] + 3) / 4), (unsigned) a.ne[2]);
+        hipLaunchKernelGGL(k_mul_mat_f16_gqa_long<G>, grid, dim3(256), 0, s, a, b, d);
+    }
+}
+
 void launch_mul_mat_f(hipStream_t s, const tdesc & a, const tdesc & b, const tdesc & d) {
     const int64_t K = a.ne[0];
     const bool w16 = a.type == GGML_TYPE_F16;
@@ -116,6 +482,19 @@ void launch_mul_mat_f(hipStream_t s, const tdesc & a, const tdesc & b, const tde
         dim3 grid((unsigned) ((a.ne[1] + 63) / 64), (unsigned) ((b.ne[1] + 63) / 64), (unsigned) (b.ne[2] * b.ne[3]));
         hipLaunchKernelGGL(k_mul_mat_f16_mma, grid, dim3(256), 0, s, a, b, d);
         return;
+    }
+    if (w16 && vec_ok && b.ne[1] == 1 && a.ne[3] == 1 && b.ne[3] == 1 && b.ne[2] % a.ne[2] == 0 && a.ne[1] >= 64) {  // a decode step's K.q / V^T.p
+        switch (b.ne[2] / a.ne[2]) {
+            case 1: launch_gqa_t<1>(s, a, b, d); return;
+            case 2: launch_gqa_t<2>(s, a, b, d); return;
+            case 3: launch_gqa_t<3>(s, a, b, d); return;
+            case 4: launch_gqa_t<4>(s, a, b, d); return;
+            case 5: launch_gqa_t<5>(s, a, b, d); return;
+            case 6: launch_gqa_t<6>(s, a, b, d); return;
+            case 7: launch_gqa_t<7>(s, a, b, d); return;
+            case 8: launch_gqa_t<8>(s, a, b, d); return;
+            default: break;
+        }
     }
     int lpr = 64;
     if (vec_ok) {

@@ -586,6 +586,56 @@ __global__ void __launch_bounds__(256) k_soft_max(const tdesc a, const tdesc m, 
     const float inv = (float) (1.0 / sum);
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) y[i] *= inv;
 }
+// Rows of up to 256 NR values stay in registers between the three passes: one read, one write (the kernel above goes through the
+// output row three times, each pass waiting for the one before — 13 us per call on the 32 rows x 2k cells of a decode step).  Same
+// arithmetic in the same order (thread-strided partial sums in double, then the block tree), so the results are bit-identical.
+template <int NR>
+__global__ void __launch_bounds__(256) k_soft_max_reg(const tdesc a, const tdesc m, const int has_mask, const float * __restrict__ sinks, const tdesc d,
+                                                      const float scale, const float max_bias, const float m0, const float m1, const uint32_t n_head_log2) {
+    __shared__ double shd[4];
+    __shared__ float shf[4];
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % a.ne[1], i2 = (row / a.ne[1]) % a.ne[2], i3 = row / (a.ne[1] * a.ne[2]);
+    const float * x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    float * y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const char * mp = has_mask ? m.data + i1 * m.nb[1] + (i2 % m.ne[2]) * m.nb[2] + (i3 % m.ne[3]) * m.nb[3] : nullptr;
+    const uint32_t h = (uint32_t) i2;
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const int n = (int) a.ne[0];
+    const bool m16 = m.type == GGML_TYPE_F16;
+    float w[NR];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        w[j] = -INFINITY;
+        if (i < n) {
+            float v = x[i] * scale;
+            if (mp) v += slope * (m16 ? h2f(((const uint16_t *) mp)[i]) : ((const float *) mp)[i]);
+            w[j] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = block_max_f(mx, shf);
+    if (sinks) mx = fmaxf(mx, sinks[i2]);
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        if ((int) threadIdx.x + 256 * j < n) {
+            w[j] = expf(w[j] - mx);
+            sum += (double) w[j];
+        }
+    }
+    sum = block_sum_d(sum, shd);
+    if (sinks) sum += (double) expf(sinks[i2] - mx);
+    if (isnan(sum) || sum == 0.0) sum = -INFINITY;
+    const float inv = (float) (1.0 / sum);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < n) y[i] = w[j] * inv;
+    }
+}
 void launch_soft_max(hipStream_t s, const tdesc & a, const tdesc * mask, const float * sinks, const tdesc & d, float scale, float max_bias) {
     const uint32_t n_head = (uint32_t) a.ne[2];
     const uint32_t n_head_log2 = 1u << (uint32_t) floor(log2((double) n_head));
@@ -593,6 +643,14 @@ void launch_soft_max(hipStream_t s, const tdesc & a, const tdesc * mask, const f
     const float m1 = powf(2.0f, -(max_bias / 2.0f) / (float) n_head_log2);
     const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
     tdesc dummy = a;
+#define SM_REG(NR) hipLaunchKernelGGL(k_soft_max_reg<NR>, dim3((unsigned) rows), dim3(256), 0, s, a, mask ? *mask : dummy, mask ? 1 : 0, sinks, d, scale, max_bias, m0, m1, n_head_log2)
+    if (a.nb[0] == 4 && d.nb[0] == 4 && a.ne[0] <= 256 * 32) {
+        if (a.ne[0] <= 256 * 4) SM_REG(4);
+        else if (a.ne[0] <= 256 * 12) SM_REG(12);
+        else SM_REG(32);
+        return;
+    }
+#undef SM_REG
     hipLaunchKernelGGL(k_soft_max, dim3((unsigned) rows), dim3(256), 0, s, a, mask ? *mask : dummy, mask ? 1 : 0, sinks, d, scale, max_bias, m0, m1, n_head_log2);
 }
 

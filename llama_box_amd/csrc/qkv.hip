@@ -197,6 +197,10 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
                 uint16_t * o = (uint16_t *) (sg.out + slot * sg.row_stride);
                 o[r0] = f2h(v0);
                 o[r1] = f2h(v1);
+            } else if (sg.store == 3) {
+                uint16_t * o = (uint16_t *) sg.out;
+                o[sg.idx[r0]] = f2h(v0);
+                o[sg.idx[r1]] = f2h(v1);
             } else {
                 float * o = (float *) sg.out;
                 o[r0] = v0;

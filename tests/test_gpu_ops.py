@@ -268,6 +268,8 @@ def test_mul_mat_q_3d_src1(backend, H, plog, qt):
 @pytest.mark.parametrize("wt", [L.F16, L.F32])
 @pytest.mark.parametrize("K,N,M,B0,B1", [(128, 96, 1, 2, 8), (64, 33, 3, 1, 4), (200, 17, 2, 1, 1), (2048, 128, 1, 2, 4), (7, 5, 2, 1, 1),
                                           # batches of columns (a prompt chunk on the non-flash path): the f16 matrix-core kernel, ragged tiles, K = 8 mod 16
+                                          # one column, grouped heads (a decode step on the non-flash path): short rows (K.q) and long rows (V^T.p), ragged
+                                          (128, 300, 1, 2, 8), (64, 1000, 1, 4, 4), (80, 77, 1, 1, 8), (512, 65, 1, 3, 6), (2304, 128, 1, 8, 32), (1000, 66, 1, 1, 2), (520, 64, 1, 2, 2),
                                           (128, 96, 40, 2, 8), (64, 130, 33, 1, 4), (200, 70, 16, 1, 1), (2048, 128, 100, 2, 4), (136, 50, 64, 1, 2), (128, 512, 512, 8, 32)])
 def test_mul_mat_f(backend, H, plog, wt, K, N, M, B0, B1):
     rng = np.random.default_rng(K + N + M)
@@ -304,6 +306,67 @@ def test_mul_mat_f16_kv_views(backend, H, plog):
     ref, got = both(build, backend)
     T.compare("kq (strided K view x permuted Q)", got[0], ref[0], max_nmse=1e-11, log=plog)
     T.compare("kqv (transposed V view x P)", got[1], ref[1], max_nmse=1e-11, log=plog)
+
+
+@pytest.mark.parametrize("NKVLEN", [256, 2304])
+def test_mul_mat_f16_kv_views_decode(backend, H, plog, NKVLEN):
+    """One token against the cache views with 4 query heads per KV head: the grouped-head mat-vec kernels."""
+    rng = np.random.default_rng(5 + NKVLEN)
+    HD, NKV, NH, NCTX = 128, 2, 8, 4096
+    kc = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    vc = rng.standard_normal((NKV * HD, NCTX)).astype(np.float16)
+    q = rng.standard_normal((1, NH, HD)).astype(np.float32)
+    p = rng.uniform(0, 1, (NH, 1, NKVLEN)).astype(np.float32)
+
+    def build(g):
+        k_cache = g.new(L.F16, [NKV * HD, NCTX], kc)
+        v_cache = g.new(L.F16, [NCTX, NKV * HD], vc)
+        tq = g.new(L.F32, [HD, NH, 1], q)
+        tp = g.new(L.F32, [NKVLEN, 1, NH], p)
+        qp = H.ggml_permute(g.ctx, tq, 0, 2, 1, 3)
+        k = H.ggml_view_3d(g.ctx, k_cache, HD, NKVLEN, NKV, NKV * HD * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, v_cache, NKVLEN, HD, NKV, NCTX * 2, NCTX * 2 * HD, 0)
+        return [H.ggml_mul_mat(g.ctx, k, qp), H.ggml_mul_mat(g.ctx, v, tp)]
+
+    ref, got = both(build, backend)
+    T.compare(f"kq decode n_kv={NKVLEN}", got[0], ref[0], max_nmse=1e-11, log=plog)
+    T.compare(f"kqv decode n_kv={NKVLEN}", got[1], ref[1], max_nmse=1e-11, log=plog)
+
+
+@pytest.mark.parametrize("NH,NKV,NKVLEN,mask_t", [(8, 2, 256, L.F16), (8, 2, 2304, L.F16), (32, 8, 2304, L.F32), (4, 4, 4104, L.F16), (7, 1, 1000, L.F16),
+                                                  (16, 2, 5000, None), (6, 2, 9000, L.F16), (8, 8, 64, L.F32)])
+def test_soft_max_folded_into_vt_p(backend, H, plog, NH, NKV, NKVLEN, mask_t):
+    """Decode on the non-flash path: SOFT_MAX(K.q, mask, scale) -> MUL_MAT(V^T view, p) runs as one launch (mmf.hip) and equals the oracle and the two
+    separate launches (the probabilities and their f16 rounding are the same numbers; only the partition of the double sum differs)."""
+    rng = np.random.default_rng(11 + NKVLEN + NH)
+    HD, NCTX = 128, ((NKVLEN + 255) // 256) * 256
+    vc = rng.standard_normal((NKV * HD, NCTX)).astype(np.float16)
+    kq = (rng.standard_normal((NH, 1, NKVLEN)) * 20).astype(np.float32)
+    mask = np.zeros((64, NKVLEN), np.float32)
+    mask[:, int(NKVLEN * 0.8):] = -np.inf  # the cells past this sequence
+    mask[:, 3] = -np.inf
+
+    def build(g):
+        v_cache = g.new(L.F16, [NCTX, NKV * HD], vc)
+        tkq = g.new(L.F32, [NKVLEN, 1, NH], kq)
+        tm = None if mask_t is None else g.new(mask_t, [NKVLEN, 64], mask.astype(np.float16) if mask_t == L.F16 else mask)
+        p = H.ggml_soft_max_ext(g.ctx, tkq, tm, 0.0883883, 0.0)
+        v = H.ggml_view_3d(g.ctx, v_cache, NKVLEN, HD, NKV, NCTX * 2, NCTX * 2 * HD, 0)
+        return [H.ggml_mul_mat(g.ctx, v, p)]
+
+    ref = T.run_case(build, "oracle")
+    f0, k0 = backend.stat("fused_nodes"), backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    fused, launches = backend.stat("fused_nodes") - f0, backend.stat("kernel_launches") - k0
+    backend.set_option("softmax_mm", 0)
+    try:
+        plain = T.run_case(build, backend)
+    finally:
+        backend.set_option("softmax_mm", 1)
+    assert fused == 1 and launches == 1, (fused, launches)
+    T.compare(f"soft_max+V^T.p NH={NH} NKV={NKV} n_kv={NKVLEN} mask={mask_t}", got[0], ref[0], max_nmse=1e-11, log=plog)
+    # the separate soft_max splits the double sum over threads differently and its mat-vec adds in another order: f32 rounding level
+    assert T.nmse(got[0], plain[0]) < 1e-11
 
 
 # ------------------------------------------------------------------------------------------------ element-wise & norm
@@ -579,7 +642,7 @@ def test_rope_f16_kshift(backend, H, plog):
 
 # ------------------------------------------------------------------------------------------------ SOFT_MAX
 @pytest.mark.parametrize("mask_t", [None, L.F16, L.F32])
-@pytest.mark.parametrize("n,rows,heads", [(256, 3, 4), (1000, 1, 8), (8192, 2, 2), (33, 5, 12)])
+@pytest.mark.parametrize("n,rows,heads", [(256, 3, 4), (1000, 1, 8), (8192, 2, 2), (33, 5, 12), (2304, 1, 32), (3000, 2, 2), (8200, 1, 3)])
 def test_soft_max(backend, H, plog, mask_t, n, rows, heads):
     rng = np.random.default_rng(n + rows)
     x = (rng.standard_normal((heads, rows, n)) * 5).astype(np.float32)
@@ -1012,6 +1075,54 @@ def test_fused_qkv_rope_store(backend, H, plog, tq, tv, bias, kvt):
         T.compare(f"fused qkv {QNAME[tq]}/{QNAME[tv]} {name} vs unfused", a32, c32, max_nmse=tol_cache if name != "q_rope" else 1e-10, log=plog)
         if kvt == L.Q8_0 and name != "q_rope":
             assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused q8_0 cache rows differ"
+
+
+@pytest.mark.parametrize("tq,tv", [(L.Q4_K, L.Q4_K), (L.Q4_K, L.Q6_K), (L.Q5_K, L.Q6_K)])
+def test_fused_qkv_transposed_v_store(backend, H, plog, tq, tv):
+    """The non-flash path keeps V transposed: llama.cpp views the projection as n_embd_v rows of ONE element and scatters them with an
+    index per element (j * n_ctx + cell).  The fused decode launch does that scatter in its epilogue: still one launch, same bytes."""
+    rng = np.random.default_rng(9 + tq * 7 + tv)
+    E, HD, NH, NKV, NCTX, slot, pos = 1024, 128, 8, 2, 64, 37, 7
+    x = rng.standard_normal((1, E)).astype(np.float32)
+    nw = rng.uniform(0.5, 1.5, E).astype(np.float32)
+    wq, wk, wv = T.rand_weight(tq, E, NH * HD, rng), T.rand_weight(tq, E, NKV * HD, rng), T.rand_weight(tv, E, NKV * HD, rng)
+    kc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    vc0 = rng.standard_normal((NKV * HD, NCTX)).astype(np.float16)
+    v_idx = (np.arange(NKV * HD, dtype=np.int64) * NCTX + slot)
+
+    def build(g):
+        cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, g.new(L.F32, [E, 1], x), 1e-5), g.new(L.F32, [E], nw))
+        q = H.ggml_mul_mat(g.ctx, g.new(tq, [E, NH * HD], wq), cur)
+        k = H.ggml_mul_mat(g.ctx, g.new(tq, [E, NKV * HD], wk), cur)
+        v = H.ggml_mul_mat(g.ctx, g.new(tv, [E, NKV * HD], wv), cur)
+        tp = g.new(L.I32, [1], np.array([pos], np.int32))
+        idx = g.new(L.I64, [1], np.array([slot], np.int64))
+        vidx = g.new(L.I64, [NKV * HD], v_idx)
+        q = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, q, HD, NH, 1), tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        k = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, k, HD, NKV, 1), tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        v = H.ggml_reshape_3d(g.ctx, v, HD, NKV, 1)
+        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], kc0), H.ggml_reshape_2d(g.ctx, k, NKV * HD, 1), idx)
+        v_view = H.ggml_reshape_2d(g.ctx, g.new(L.F16, [NCTX, NKV * HD], vc0), 1, NCTX * NKV * HD)
+        vs = H.ggml_set_rows(g.ctx, v_view, H.ggml_reshape_2d(g.ctx, v, 1, NKV * HD), vidx)
+        return [q, ks, vs]
+
+    ref = T.run_case(build, "oracle")
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    backend.set_option("fusion", 0)
+    try:
+        plain = T.run_case(build, backend)
+    finally:
+        backend.set_option("fusion", 1)
+    plog(f"    fused qkv {QNAME[tq]}/{QNAME[tv]} with the transposed V cache: {launches} kernel launch(es)")
+    assert launches == 1, launches
+    for name, a, b, c in zip(("q_rope", "k_cache", "v_cache_T"), got, ref, plain):
+        a32, b32, c32 = (np.asarray(t).astype(np.float32) for t in (a, b, c))
+        T.compare(f"fused qkv {QNAME[tq]}/{QNAME[tv]} transposed V: {name}", a32, b32, max_nmse=1e-10 if name == "q_rope" else 1e-6, log=plog)
+        assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and node-by-node execution differ"
+    vt = np.asarray(got[2]).reshape(NKV * HD, NCTX)
+    assert np.array_equal(np.delete(vt, slot, axis=1), np.delete(vc0, slot, axis=1)), "cells of other tokens were touched"
 
 
 @pytest.mark.parametrize("tq,tv,M,n_dims,bias", [(L.Q4_K, L.Q4_K, 32, 128, False), (L.Q4_K, L.Q6_K, 32, 128, False), (L.Q4_K, L.Q6_K, 7, 128, True),
