@@ -848,7 +848,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         }
         // (all three in ONE launch only: a sibling of another weight format — wv as Q6_K — would run alone without its K split, 32 workgroups for
         // 1024 rows, and cost more than the rope launch saves: measured 4.27 -> 4.40 ms per -np 32 step with it, 4.27 -> 4.2 without)
-        ok = ok && epl.a.p.mode == 0 && (epl.a.head_dim % 2) == 0 && ms.size() == 3 && others.empty();
+        ok = ok && epl.a.p.mode == 0 && (epl.a.head_dim % 2) == 0 && ms.size() == 3 && others.empty() && !epl.a.v_idx;  // (the epilogue stores V as cache rows only)
         auto role_of = [&](const member & m) {
             for (int sidx = 0; sidx < 3; ++sidx)
                 if (through_views(epl.src[sidx]) == m.dst) return sidx;
@@ -1004,7 +1004,11 @@ static bool plan_rope_store(const exec_state & st, int i, rope_store_plan & pl) 
         return sr->type == GGML_TYPE_F16 && sr->nb[0] == 2 && sr->ne[0] == NKV * HD && src->ne[0] == NKV * HD && ggml_abi_nelements(src) == NKV * HD * T &&
                sr->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(sr->src[1]) == T && ggml_abi_is_contiguous(sr->src[1]);
     };
-    if (!store_ok(ks, ks->src[0]) || !store_ok(vs, vsrc) || ks->src[1]->data != vs->src[1]->data) return false;
+    // ... or, on the non-flash path, V transposed: the projection viewed as rows of ONE element, an index per element
+    const bool v_scatter = vs->type == GGML_TYPE_F16 && vs->ne[0] == 1 && vs->nb[0] == 2 && vs->nb[1] == 2 && vsrc->ne[0] == 1 && ggml_abi_nelements(vsrc) == NKV * HD * T &&
+                           vs->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(vs->src[1]) == NKV * HD * T && ggml_abi_is_contiguous(vs->src[1]);
+    if (!store_ok(ks, ks->src[0])) return false;
+    if (!v_scatter && (!store_ok(vs, vsrc) || ks->src[1]->data != vs->src[1]->data)) return false;
     if (vsrc->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(vsrc) || !ggml_abi_is_contiguous(ksrc) || ksrc->ne[0] != HD || ksrc->ne[1] != NKV) return false;
     if ((rq->op_params[1] % 2) != 0 || rq->op_params[1] > HD) return false;
     rope_store_args a{};
@@ -1019,6 +1023,7 @@ static bool plan_rope_store(const exec_state & st, int i, rope_store_plan & pl) 
     a.k_cache = (char *) ks->data; a.v_cache = (char *) vs->data;
     a.kc_nb1 = (int64_t) ks->nb[1]; a.vc_nb1 = (int64_t) vs->nb[1];
     a.idx = (const int64_t *) ks->src[1]->data;
+    a.v_idx = v_scatter ? (const int64_t *) vs->src[1]->data : nullptr;
     a.pos = (const int32_t *) rq->src[1]->data;
     a.ff = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
     a.p.n_dims = rq->op_params[1];

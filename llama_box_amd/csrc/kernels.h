@@ -176,6 +176,7 @@ struct rope_store_args {
     char * k_cache; char * v_cache;
     int64_t kc_nb1, vc_nb1;
     const int64_t * idx;
+    const int64_t * v_idx;  // transposed V cache (non-flash path): one index per ELEMENT, [token][nkv * head_dim]; value j of the token -> f16 element v_idx[..] of v_cache
     const int32_t * pos;
     const float * ff;
     rope_params p;

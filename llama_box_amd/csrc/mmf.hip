@@ -84,15 +84,30 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mma(const tdesc a, const td
     const char * wrow = a.data + std::min<int64_t>(row0 + r32, a.ne[1] - 1) * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3] + g * 16;  // this lane's src0 row, its k-group
     const char * xcol = b.data + std::min<int64_t>(col0 + r32, b.ne[1] - 1) * b.nb[1] + i12 * b.nb[2] + i13 * b.nb[3] + g * 32;  // this lane's src1 column
     mmf_float16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t k = 0; k < K; k += 16) {
-        // k-group g of the step: elements k + 8g .. k + 8g + 7 (the last step of a K that is 8 mod 16 has no second group)
-        mmf_half8 w = {0, 0, 0, 0, 0, 0, 0, 0}, x = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (k + 8 * g < K) {
-            w = *(const mmf_half8 *) (wrow + k * 2);
-            const float4 x0 = *(const float4 *) (xcol + k * 4), x1 = *(const float4 *) (xcol + k * 4 + 16);
-            x = (mmf_half8){(_Float16) x0.x, (_Float16) x0.y, (_Float16) x0.z, (_Float16) x0.w, (_Float16) x1.x, (_Float16) x1.y, (_Float16) x1.z, (_Float16) x1.w};
+    for (int64_t k = 0; k < K; k += 64) {  // 4 steps of 16 per trip, their loads in flight together
+        // k-group g of a step: elements kk + 8g .. kk + 8g + 7; past the end (the last step of a K that is 8 mod 16 has no second group): the
+        // row's first group is fetched instead — no branch between the loads — and masked to zeros
+        uint4 w[4], x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t kk = k + 16 * u;
+            const bool in = kk + 8 * g < K;
+            const int64_t kc = in ? kk : -8 * g;
+            const uint32_t keep = in ? 0xFFFFFFFFu : 0u;
+            w[u] = *(const uint4 *) (wrow + kc * 2);
+            x0[u] = *(const uint4 *) (xcol + kc * 4);
+            x1[u] = *(const uint4 *) (xcol + kc * 4 + 16);
+            w[u].x &= keep; w[u].y &= keep; w[u].z &= keep; w[u].w &= keep;
+            x0[u].x &= keep; x0[u].y &= keep; x0[u].z &= keep; x0[u].w &= keep;
+            x1[u].x &= keep; x1[u].y &= keep; x1[u].z &= keep; x1[u].w &= keep;
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const mmf_half8 x = {(_Float16) __builtin_bit_cast(float, x0[u].x), (_Float16) __builtin_bit_cast(float, x0[u].y), (_Float16) __builtin_bit_cast(float, x0[u].z),
+                                 (_Float16) __builtin_bit_cast(float, x0[u].w), (_Float16) __builtin_bit_cast(float, x1[u].x), (_Float16) __builtin_bit_cast(float, x1[u].y),
+                                 (_Float16) __builtin_bit_cast(float, x1[u].z), (_Float16) __builtin_bit_cast(float, x1[u].w)};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, __builtin_bit_cast(mmf_half8, w[u]), acc, 0, 0, 0);
+        }
     }
     // lane: src0 row row0 + r32; register i: src1 column col0 + (i & 3) + 8 (i >> 2) + 4 g
     const int64_t row = row0 + r32;
@@ -101,6 +116,62 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mma(const tdesc a, const td
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int64_t col = col0 + (i & 3) + 8 * (i >> 2) + 4 * g;
+        if (col < b.ne[1]) *(float *) (out + col * d.nb[1]) = acc[i];
+    }
+}
+
+// ---- the same contract for few output tiles and long rows (V^T.p of a -np decode batch on the non-flash path: 128 x 32 results per head
+// over thousands of cells — 128 waves of the kernel above, each walking all of K, took 170 us), and for 2..15 columns: 16 x 16 tiles
+// on v_mfma_f32_16x16x32_f16 (A: src1 column m = lane & 15, B: src0 row n = lane & 15, k-group lane >> 4), the NWK waves of a
+// workgroup take the K steps of ONE tile in turn and add up through LDS in wave order (deterministic).
+typedef float mmf_float4 __attribute__((ext_vector_type(4)));
+template <int NWK>
+__global__ void __launch_bounds__(64 * NWK) k_mul_mat_f16_mma16(const tdesc a, const tdesc b, const tdesc d) {
+    __shared__ mmf_float4 red[NWK][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int64_t row0 = (int64_t) blockIdx.x * 16, col0 = (int64_t) blockIdx.y * 16;
+    const int64_t i12 = blockIdx.z % b.ne[2], i13 = blockIdx.z / b.ne[2];
+    const int64_t i02 = i12 / (b.ne[2] / a.ne[2]), i03 = i13 / (b.ne[3] / a.ne[3]);
+    const int64_t K = a.ne[0];
+    const char * wrow = a.data + std::min<int64_t>(row0 + r16, a.ne[1] - 1) * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3] + kg * 16;
+    const char * xcol = b.data + std::min<int64_t>(col0 + r16, b.ne[1] - 1) * b.nb[1] + i12 * b.nb[2] + i13 * b.nb[3] + kg * 32;
+    mmf_float4 acc = {0, 0, 0, 0};
+    for (int64_t k = (int64_t) wave * 32; k < K; k += 32 * NWK * 4) {  // 4 steps' loads in flight
+        uint4 w[4], x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t kk = k + (int64_t) u * 32 * NWK;
+            const bool in = kk + 8 * kg < K;  // past the end: fetch the row's first group instead (no branch between the loads) and mask it to zeros
+            const int64_t kc = in ? kk : -8 * kg;
+            const uint32_t keep = in ? 0xFFFFFFFFu : 0u;
+            w[u] = *(const uint4 *) (wrow + kc * 2);
+            x0[u] = *(const uint4 *) (xcol + kc * 4);
+            x1[u] = *(const uint4 *) (xcol + kc * 4 + 16);
+            w[u].x &= keep; w[u].y &= keep; w[u].z &= keep; w[u].w &= keep;
+            x0[u].x &= keep; x0[u].y &= keep; x0[u].z &= keep; x0[u].w &= keep;
+            x1[u].x &= keep; x1[u].y &= keep; x1[u].z &= keep; x1[u].w &= keep;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const mmf_half8 x = {(_Float16) __builtin_bit_cast(float, x0[u].x), (_Float16) __builtin_bit_cast(float, x0[u].y), (_Float16) __builtin_bit_cast(float, x0[u].z),
+                                 (_Float16) __builtin_bit_cast(float, x0[u].w), (_Float16) __builtin_bit_cast(float, x1[u].x), (_Float16) __builtin_bit_cast(float, x1[u].y),
+                                 (_Float16) __builtin_bit_cast(float, x1[u].z), (_Float16) __builtin_bit_cast(float, x1[u].w)};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, __builtin_bit_cast(mmf_half8, w[u]), acc, 0, 0, 0);
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < NWK; ++w) acc += red[w][lane];
+    // lane: src0 row row0 + r16; register i: src1 column col0 + 4 kg + i
+    const int64_t row = row0 + r16;
+    if (row >= a.ne[1]) return;
+    char * out = d.data + row * d.nb[0] + i12 * d.nb[2] + i13 * d.nb[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t col = col0 + 4 * kg + i;
         if (col < b.ne[1]) *(float *) (out + col * d.nb[1]) = acc[i];
     }
 }
@@ -478,6 +549,15 @@ void launch_mul_mat_f(hipStream_t s, const tdesc & a, const tdesc & b, const tde
     // 16-byte vector path: contiguous dim 0 on both sides, K multiple of 8, every row start 16-byte aligned
     bool vec_ok = a.nb[0] == esz && b.nb[0] == 4 && (K % 8) == 0 && (((uintptr_t) a.data) & 15) == 0 && (((uintptr_t) b.data) & 15) == 0;
     for (int i = 1; i < 4; ++i) vec_ok = vec_ok && (a.nb[i] % 16) == 0 && (b.nb[i] % 16) == 0;
+    if (w16 && vec_ok && b.ne[1] >= 2) {
+        const int64_t waves32 = ((a.ne[1] + 31) / 32) * ((b.ne[1] + 31) / 32) * b.ne[2] * b.ne[3];
+        if (b.ne[1] < 16 || (K >= 1024 && waves32 < 2048)) {  // few tiles, long rows (or a handful of columns): split K inside the workgroup
+            dim3 grid((unsigned) ((a.ne[1] + 15) / 16), (unsigned) ((b.ne[1] + 15) / 16), (unsigned) (b.ne[2] * b.ne[3]));
+            if (K >= 4096) hipLaunchKernelGGL(k_mul_mat_f16_mma16<16>, grid, dim3(1024), 0, s, a, b, d);
+            else hipLaunchKernelGGL(k_mul_mat_f16_mma16<8>, grid, dim3(512), 0, s, a, b, d);
+            return;
+        }
+    }
     if (w16 && vec_ok && b.ne[1] >= 16) {  // a batch of columns: the matrix cores
         dim3 grid((unsigned) ((a.ne[1] + 63) / 64), (unsigned) ((b.ne[1] + 63) / 64), (unsigned) (b.ne[2] * b.ne[3]));
         hipLaunchKernelGGL(k_mul_mat_f16_mma, grid, dim3(256), 0, s, a, b, d);

@@ -523,8 +523,13 @@ __global__ void __launch_bounds__(256) k_rope_qk_store(const rope_store_args a) 
         } else {
             const int h = slot - a.nh - a.nkv;
             const float * src = (const float *) (a.v_src + h * a.v_nb1 + t * a.v_nb2);
-            uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * a.head_dim;
-            for (int i0 = lane; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(ld(2, src, h, i0));
+            if (a.v_idx) {
+                const int64_t * ix = a.v_idx + ((int64_t) t * a.nkv + h) * a.head_dim;
+                for (int i0 = lane; i0 < a.head_dim; i0 += 64) ((uint16_t *) a.v_cache)[ix[i0]] = f2h(ld(2, src, h, i0));
+            } else {
+                uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * a.head_dim;
+                for (int i0 = lane; i0 < a.head_dim; i0 += 64) dst[i0] = f2h(ld(2, src, h, i0));
+            }
         }
     }
 }

@@ -270,6 +270,8 @@ def test_mul_mat_q_3d_src1(backend, H, plog, qt):
                                           # batches of columns (a prompt chunk on the non-flash path): the f16 matrix-core kernel, ragged tiles, K = 8 mod 16
                                           # one column, grouped heads (a decode step on the non-flash path): short rows (K.q) and long rows (V^T.p), ragged
                                           (128, 300, 1, 2, 8), (64, 1000, 1, 4, 4), (80, 77, 1, 1, 8), (512, 65, 1, 3, 6), (2304, 128, 1, 8, 32), (1000, 66, 1, 1, 2), (520, 64, 1, 2, 2),
+                                          # few tiles over long rows (V^T.p of a -np decode batch) and 2..15 columns: 16x16 tiles, K split over the workgroup's waves
+                                          (7304, 128, 32, 2, 8), (3000, 40, 20, 1, 2), (128, 300, 8, 2, 8), (1032, 16, 5, 1, 3),
                                           (128, 96, 40, 2, 8), (64, 130, 33, 1, 4), (200, 70, 16, 1, 1), (2048, 128, 100, 2, 4), (136, 50, 64, 1, 2), (128, 512, 512, 8, 32)])
 def test_mul_mat_f(backend, H, plog, wt, K, N, M, B0, B1):
     rng = np.random.default_rng(K + N + M)
@@ -1215,6 +1217,49 @@ def test_batch_rope_and_cache_stores_one_launch(backend, H, plog, mode, n_dims, 
     for name, a, b, c in zip(("q_rope", "k_cache", "v_cache"), got, ref, plain):
         assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused differ"
         T.compare(f"batch rope+store T={T_} mode={mode} n_dims={n_dims} {name}", np.asarray(a).astype(np.float32), np.asarray(b).astype(np.float32),
+                  max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
+
+
+@pytest.mark.parametrize("T_", [32, 130])
+def test_batch_rope_and_transposed_v_store_one_launch(backend, H, plog, T_):
+    """The same window on the non-flash path: the V store is a scatter of single elements into the transposed cache (an index per element)."""
+    rng = np.random.default_rng(43 + T_)
+    HD, NH, NKV, NCTX = 128, 8, 2, 300
+    q = rng.standard_normal((T_, NH, HD)).astype(np.float32)
+    k = rng.standard_normal((T_, NKV, HD)).astype(np.float32)
+    v = rng.standard_normal((T_, NKV * HD)).astype(np.float32)
+    pos = rng.integers(0, 5000, T_).astype(np.int32)
+    rows = rng.permutation(NCTX)[:T_].astype(np.int64)
+    kc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    vc0 = rng.standard_normal((NKV * HD, NCTX)).astype(np.float16)
+    v_idx = (np.arange(NKV * HD, dtype=np.int64)[None, :] * NCTX + rows[:, None]).reshape(-1)
+
+    def build(g):
+        tp = g.new(L.I32, [T_], pos)
+        idx = g.new(L.I64, [T_], rows)
+        vidx = g.new(L.I64, [T_ * NKV * HD], v_idx)
+        q3 = H.ggml_reshape_3d(g.ctx, g.new(L.F32, [NH * HD, T_], q), HD, NH, T_)
+        k3 = H.ggml_reshape_3d(g.ctx, g.new(L.F32, [NKV * HD, T_], k), HD, NKV, T_)
+        qr = H.ggml_rope_ext(g.ctx, q3, tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        kr = H.ggml_rope_ext(g.ctx, k3, tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], kc0), H.ggml_reshape_2d(g.ctx, kr, NKV * HD, T_), idx)
+        v_view = H.ggml_reshape_2d(g.ctx, g.new(L.F16, [NCTX, NKV * HD], vc0), 1, NCTX * NKV * HD)
+        vs = H.ggml_set_rows(g.ctx, v_view, H.ggml_reshape_2d(g.ctx, g.new(L.F32, [NKV * HD, T_], v), 1, T_ * NKV * HD), vidx)
+        return [qr, ks, vs]
+
+    ref = T.run_case(build, "oracle")
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    backend.set_option("fusion", 0)
+    try:
+        plain = T.run_case(build, backend)
+    finally:
+        backend.set_option("fusion", 1)
+    assert launches == 1, launches
+    for name, a, b, c in zip(("q_rope", "k_cache", "v_cache_T"), got, ref, plain):
+        assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused differ"
+        T.compare(f"batch rope + transposed V store T={T_} {name}", np.asarray(a).astype(np.float32), np.asarray(b).astype(np.float32),
                   max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
 
 
