@@ -152,6 +152,8 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             // (and the wide form of the same unit fetches whole groups of 128 columns of a prompt batch)
             p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], (Mc >= 2 && Mc < 32) ? 32 : (Mc >= 33 ? (Mc + 127) / 128 * 128 : Mc)));
             if (Mc >= c->opt.mmq_min_cols && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, 3 * mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc, c->opt.mmq_skinny));  // (x3: up to three sibling matrices share a launch)
+        } else if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_F16) {
+            p.aux_bytes = std::max(p.aux_bytes, mul_mat_f_workspace_bytes(TD(n->src[0]), TD(n->src[1])));
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
             const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k));
@@ -1148,7 +1150,7 @@ static int run_node(exec_state & st, int i) {
         case GGML_OP_MUL_MAT: {
             if (!is_quant(a->type)) {
                 timed_scope ts(c, "mul_mat_f", (double) ggml_abi_nbytes(a));
-                launch_mul_mat_f(s, TD(a), TD(b), TD(n));
+                launch_mul_mat_f(s, TD(a), TD(b), TD(n), (float *) ((char *) c->ws + st.aux_off), c->ws ? c->ws_size - st.aux_off : 0);
                 c->st.kernel_launches++;
                 return 1;
             }

@@ -100,7 +100,8 @@ void launch_qkv(hipStream_t s, const qkv_args & a, int type_a, int type_b);
 
 // ---- f16 / f32 weights (K cache, V cache, small dense) (mmf.hip): dst = src0 · src1 with ggml broadcasting;
 // src1 rounded to f16 first when src0 is f16 (ggml-cpu vec_dot_type semantics)
-void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, const tdesc & dst);
+void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, const tdesc & dst, float * ws = nullptr, size_t ws_bytes = 0);  // ws: scratch for K-split partial tiles
+size_t mul_mat_f_workspace_bytes(const tdesc & src0, const tdesc & src1);
 bool launch_soft_max_mul_mat_f16(hipStream_t s, const tdesc & a, const tdesc & kq, const tdesc * mask, const tdesc & d, float scale);  // decode: SOFT_MAX folded into V^T.p (mmf.hip)
 
 // ---- prefill: quantised weights x many columns through MFMA (mmq.hip)

@@ -120,6 +120,81 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mma(const tdesc a, const td
     }
 }
 
+// ---- short rows against a batch (K.Q on the non-flash path: K = head size, rows = cells): the tile kernel above fetches 16 KB of src1
+// and 8 KB of src0 per 32 x 32 tile — 205 MB through the L2 for the 32 x 32 x 7300 logits of a -np 32 step, 39 us.  Here a wave
+// keeps its 32 columns of GH heads that share the src0 rows (grouped queries) in registers as f16 A operands — the whole K, at most
+// 16 NK — and walks RT row tiles: 8 KB of src0 per tile feed GH x NK MFMAs, the next tile's rows are requested before the current
+// one is multiplied.
+template <int GH, int NK>
+__global__ void __launch_bounds__(256) k_mul_mat_f16_mma_xres(const tdesc a, const tdesc b, const tdesc d, const int RT) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r32 = lane & 31, g = lane >> 5;
+    const int64_t K = a.ne[0], col0 = (int64_t) blockIdx.y * 32;
+    const int64_t hg = blockIdx.z % (b.ne[2] / GH), i13 = blockIdx.z / (b.ne[2] / GH);  // group of GH src1 heads with one src0 head
+    const int64_t i02 = hg * GH / (b.ne[2] / a.ne[2]), i03 = i13 / (b.ne[3] / a.ne[3]);
+    const int64_t tile0 = ((int64_t) blockIdx.x * 4 + wave) * RT, n_tiles = (a.ne[1] + 31) / 32;
+    if (tile0 >= n_tiles) return;
+    // k-group g of step s: elements 16 s + 8 g ..; past K: the first group is fetched instead and masked to zeros
+    mmf_half8 xs[GH][NK];
+#pragma unroll
+    for (int h = 0; h < GH; ++h) {
+        const char * xcol = b.data + std::min<int64_t>(col0 + r32, b.ne[1] - 1) * b.nb[1] + (hg * GH + h) * b.nb[2] + i13 * b.nb[3];
+#pragma unroll
+        for (int st = 0; st < NK; ++st) {
+            const int64_t kk = 16 * st + 8 * g;
+            const bool in = kk < K;
+            const uint32_t keep = in ? 0xFFFFFFFFu : 0u;
+            uint4 p0 = *(const uint4 *) (xcol + (in ? kk : 0) * 4), p1 = *(const uint4 *) (xcol + (in ? kk : 0) * 4 + 16);
+            p0.x &= keep; p0.y &= keep; p0.z &= keep; p0.w &= keep; p1.x &= keep; p1.y &= keep; p1.z &= keep; p1.w &= keep;
+            xs[h][st] = (mmf_half8){(_Float16) __builtin_bit_cast(float, p0.x), (_Float16) __builtin_bit_cast(float, p0.y), (_Float16) __builtin_bit_cast(float, p0.z),
+                                    (_Float16) __builtin_bit_cast(float, p0.w), (_Float16) __builtin_bit_cast(float, p1.x), (_Float16) __builtin_bit_cast(float, p1.y),
+                                    (_Float16) __builtin_bit_cast(float, p1.z), (_Float16) __builtin_bit_cast(float, p1.w)};
+        }
+    }
+    const char * abase = a.data + i02 * a.nb[2] + i03 * a.nb[3];
+    auto fetch = [&](const int64_t tile, uint4 (&w)[NK]) {
+        const char * wrow = abase + std::min<int64_t>(tile * 32 + r32, a.ne[1] - 1) * a.nb[1];
+#pragma unroll
+        for (int st = 0; st < NK; ++st) {
+            const int64_t kk = 16 * st + 8 * g;
+            const bool in = kk < K;
+            const uint32_t keep = in ? 0xFFFFFFFFu : 0u;
+            w[st] = *(const uint4 *) (wrow + (in ? kk : 0) * 2);
+            w[st].x &= keep; w[st].y &= keep; w[st].z &= keep; w[st].w &= keep;
+        }
+    };
+    uint4 w[NK], wn[NK];
+    fetch(tile0, w);
+    const int64_t tile_end = std::min<int64_t>(n_tiles, tile0 + RT);
+    for (int64_t tile = tile0; tile < tile_end; ++tile) {
+        if (tile + 1 < tile_end) fetch(tile + 1, wn);
+        const int64_t row = tile * 32 + r32;
+#pragma unroll
+        for (int h = 0; h < GH; ++h) {
+            mmf_float16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < NK; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xs[h][st], __builtin_bit_cast(mmf_half8, w[st]), acc, 0, 0, 0);
+            if (row < a.ne[1]) {
+                char * out = d.data + row * d.nb[0] + (hg * GH + h) * d.nb[2] + i13 * d.nb[3];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t col = col0 + (i & 3) + 8 * (i >> 2) + 4 * g;
+                    if (col < b.ne[1]) *(float *) (out + col * d.nb[1]) = acc[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < NK; ++st) w[st] = wn[st];
+    }
+}
+template <int GH> static void launch_xres_t(hipStream_t s, const tdesc & a, const tdesc & b, const tdesc & d) {
+    const int64_t n_tiles = (a.ne[1] + 31) / 32, ct = (b.ne[1] + 31) / 32, nz = (b.ne[2] / GH) * b.ne[3];
+    const int RT = (int) std::max<int64_t>(1, std::min<int64_t>(8, n_tiles * ct * nz / 512));
+    dim3 grid((unsigned) ((n_tiles + 4 * RT - 1) / (4 * RT)), (unsigned) ct, (unsigned) nz);
+    if (a.ne[0] <= 64) hipLaunchKernelGGL((k_mul_mat_f16_mma_xres<GH, 4>), grid, dim3(256), 0, s, a, b, d, RT);
+    else hipLaunchKernelGGL((k_mul_mat_f16_mma_xres<GH, 8>), grid, dim3(256), 0, s, a, b, d, RT);
+}
+
 // ---- the same contract for few output tiles and long rows (V^T.p of a -np decode batch on the non-flash path: 128 x 32 results per head
 // over thousands of cells — 128 waves of the kernel above, each walking all of K, took 170 us), and for 2..15 columns: 16 x 16 tiles
 // on v_mfma_f32_16x16x32_f16 (A: src1 column m = lane & 15, B: src0 row n = lane & 15, k-group lane >> 4), the NWK waves of a
@@ -174,6 +249,81 @@ __global__ void __launch_bounds__(64 * NWK) k_mul_mat_f16_mma16(const tdesc a, c
         const int64_t col = col0 + 4 * kg + i;
         if (col < b.ne[1]) *(float *) (out + col * d.nb[1]) = acc[i];
     }
+}
+
+// ---- ... and when scratch is at hand (few columns, at most 128 rows, long rows — V^T.p of a -np decode batch): 16 x 16 tiles fetch
+// every probability 8 times and every V^T element twice — 360 MB through the L2 for a 15 MB cache, 45 us.  Here a workgroup's four
+// waves cover ALL rows (32 each) of one head over a slice of K, so the probabilities of the slice cross the L2 once (the waves read
+// the same lines together), K is cut over workgroups, the partial tiles go to scratch ([slice][batch][column][row]) and
+// launch_splitk_reduce adds them in slice order.
+template <int NCT>
+__global__ void __launch_bounds__(256) k_mul_mat_f16_mma_ksplit(const tdesc a, const tdesc b, float * __restrict__ part, const int64_t Kc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r32 = lane & 31, g = lane >> 5;
+    const int64_t row0 = (int64_t) wave * 32;
+    if (row0 >= a.ne[1]) return;
+    const int64_t i12 = blockIdx.y % b.ne[2], i13 = blockIdx.y / b.ne[2];
+    const int64_t i02 = i12 / (b.ne[2] / a.ne[2]), i03 = i13 / (b.ne[3] / a.ne[3]);
+    const int64_t kb = (int64_t) blockIdx.x * Kc, ke = std::min<int64_t>(a.ne[0], kb + Kc);
+    const char * wrow = a.data + std::min<int64_t>(row0 + r32, a.ne[1] - 1) * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3] + g * 16;
+    const char * xcol[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) xcol[ct] = b.data + std::min<int64_t>(ct * 32 + r32, b.ne[1] - 1) * b.nb[1] + i12 * b.nb[2] + i13 * b.nb[3] + g * 32;
+    mmf_float16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = (mmf_float16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t k = kb; k < ke; k += 64) {
+        uint4 w[4], x0[4][NCT], x1[4][NCT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t kk = k + 16 * u;
+            const bool in = kk + 8 * g < ke;
+            const int64_t kc = in ? kk : -8 * g;
+            const uint32_t keep = in ? 0xFFFFFFFFu : 0u;
+            w[u] = *(const uint4 *) (wrow + kc * 2);
+            w[u].x &= keep; w[u].y &= keep; w[u].z &= keep; w[u].w &= keep;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                x0[u][ct] = *(const uint4 *) (xcol[ct] + kc * 4);
+                x1[u][ct] = *(const uint4 *) (xcol[ct] + kc * 4 + 16);
+                x0[u][ct].x &= keep; x0[u][ct].y &= keep; x0[u][ct].z &= keep; x0[u][ct].w &= keep;
+                x1[u][ct].x &= keep; x1[u][ct].y &= keep; x1[u][ct].z &= keep; x1[u][ct].w &= keep;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const uint4 p0 = x0[u][ct], p1 = x1[u][ct];
+                const mmf_half8 x = {(_Float16) __builtin_bit_cast(float, p0.x), (_Float16) __builtin_bit_cast(float, p0.y), (_Float16) __builtin_bit_cast(float, p0.z),
+                                     (_Float16) __builtin_bit_cast(float, p0.w), (_Float16) __builtin_bit_cast(float, p1.x), (_Float16) __builtin_bit_cast(float, p1.y),
+                                     (_Float16) __builtin_bit_cast(float, p1.z), (_Float16) __builtin_bit_cast(float, p1.w)};
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, __builtin_bit_cast(mmf_half8, w[u]), acc[ct], 0, 0, 0);
+            }
+    }
+    const int64_t row = row0 + r32;
+    if (row >= a.ne[1]) return;
+    float * out = part + ((int64_t) blockIdx.x * gridDim.y + blockIdx.y) * b.ne[1] * a.ne[1] + row;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t col = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+            if (col < b.ne[1]) out[col * a.ne[1]] = acc[ct][i];
+        }
+}
+// slices of K for the form above (0: the form does not apply)
+static int mmf_ksplit_slices(const tdesc & a, const tdesc & b, int64_t * Kc_out) {
+    const int64_t K = a.ne[0], nbatch = b.ne[2] * b.ne[3];
+    if (a.type != GGML_TYPE_F16 || b.ne[1] < 2 || b.ne[1] > 64 || a.ne[1] > 128 || (a.ne[1] % 4) != 0 || K < 2048 || b.ne[2] % a.ne[2] != 0 || b.ne[3] % a.ne[3] != 0) return 0;
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(K / 256, 512 / std::max<int64_t>(1, nbatch)));
+    const int64_t Kc = ((K + want - 1) / want + 63) / 64 * 64;
+    if (Kc_out) *Kc_out = Kc;
+    return (int) ((K + Kc - 1) / Kc);
+}
+size_t mul_mat_f_workspace_bytes(const tdesc & a, const tdesc & b) {
+    const int ks = mmf_ksplit_slices(a, b, nullptr);
+    return ks <= 1 ? 0 : (size_t) ks * (size_t) (b.ne[2] * b.ne[3] * b.ne[1] * a.ne[1]) * sizeof(float);
 }
 
 // ---- one column against an f16 src0 that G heads of src1 share (K.q and V^T.p of a decode step on the non-flash path with grouped
@@ -542,13 +692,25 @@ template <int G> static void launch_gqa_t(hipStream_t s, const tdesc & a, const 
     }
 }
 
-void launch_mul_mat_f(hipStream_t s, const tdesc & a, const tdesc & b, const tdesc & d) {
+void launch_mul_mat_f(hipStream_t s, const tdesc & a, const tdesc & b, const tdesc & d, float * ws, size_t ws_bytes) {
     const int64_t K = a.ne[0];
     const bool w16 = a.type == GGML_TYPE_F16;
     const int esz = w16 ? 2 : 4;
     // 16-byte vector path: contiguous dim 0 on both sides, K multiple of 8, every row start 16-byte aligned
     bool vec_ok = a.nb[0] == esz && b.nb[0] == 4 && (K % 8) == 0 && (((uintptr_t) a.data) & 15) == 0 && (((uintptr_t) b.data) & 15) == 0;
     for (int i = 1; i < 4; ++i) vec_ok = vec_ok && (a.nb[i] % 16) == 0 && (b.nb[i] % 16) == 0;
+    if (w16 && vec_ok && ws && d.nb[0] == 4 && d.nb[1] == d.ne[0] * 4 && d.nb[2] == d.nb[1] * d.ne[1] && d.nb[3] == d.nb[2] * d.ne[2]) {
+        int64_t Kc = 0;
+        const int ks = mmf_ksplit_slices(a, b, &Kc);
+        if (ks > 1 && mul_mat_f_workspace_bytes(a, b) <= ws_bytes) {
+            const int64_t nbatch = b.ne[2] * b.ne[3];
+            dim3 grid((unsigned) ks, (unsigned) nbatch);
+            if (b.ne[1] <= 32) hipLaunchKernelGGL(k_mul_mat_f16_mma_ksplit<1>, grid, dim3(256), 0, s, a, b, ws, Kc);
+            else hipLaunchKernelGGL(k_mul_mat_f16_mma_ksplit<2>, grid, dim3(256), 0, s, a, b, ws, Kc);
+            launch_splitk_reduce(s, ws, ks, (int) (nbatch * b.ne[1]), (int) a.ne[1], (float *) d.data, a.ne[1], nullptr, 0);
+            return;
+        }
+    }
     if (w16 && vec_ok && b.ne[1] >= 2) {
         const int64_t waves32 = ((a.ne[1] + 31) / 32) * ((b.ne[1] + 31) / 32) * b.ne[2] * b.ne[3];
         if (b.ne[1] < 16 || (K >= 1024 && waves32 < 2048)) {  // few tiles, long rows (or a handful of columns): split K inside the workgroup
@@ -557,6 +719,13 @@ void launch_mul_mat_f(hipStream_t s, const tdesc & a, const tdesc & b, const tde
             else hipLaunchKernelGGL(k_mul_mat_f16_mma16<8>, grid, dim3(512), 0, s, a, b, d);
             return;
         }
+    }
+    if (w16 && vec_ok && b.ne[1] >= 16 && K <= 128 && a.ne[1] >= 256 && b.ne[2] % a.ne[2] == 0) {  // short rows, many of them (K.Q): columns resident
+        const int64_t gq = b.ne[2] / a.ne[2];
+        if (gq % 4 == 0) launch_xres_t<4>(s, a, b, d);
+        else if (gq % 2 == 0) launch_xres_t<2>(s, a, b, d);
+        else launch_xres_t<1>(s, a, b, d);
+        return;
     }
     if (w16 && vec_ok && b.ne[1] >= 16) {  // a batch of columns: the matrix cores
         dim3 grid((unsigned) ((a.ne[1] + 63) / 64), (unsigned) ((b.ne[1] + 63) / 64), (unsigned) (b.ne[2] * b.ne[3]));

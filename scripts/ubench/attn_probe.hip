@@ -8,7 +8,24 @@
 #include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
-namespace mi355x { int log_level() { return 0; } }
+namespace mi355x {
+int log_level() { return 0; }
+// (stand-in for mmq_i8.hip's reduce pass, same access pattern: float4 slots, partials added in slice order)
+__global__ void __launch_bounds__(256) p_reduce(const float * part, int ks, int64_t mn, float * dst) {
+    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= mn) return;
+    float4 acc = *(const float4 *) (part + e);
+    for (int k = 1; k < ks; ++k) {
+        const float4 v = *(const float4 *) (part + (int64_t) k * mn + e);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *(float4 *) (dst + e) = acc;
+}
+void launch_splitk_reduce(hipStream_t s, const float * part, int ks, int M, int N, float * dst, int64_t, const float *, int64_t) {
+    const int64_t mn = (int64_t) M * N;
+    hipLaunchKernelGGL(p_reduce, dim3((unsigned) ((mn / 4 + 255) / 256)), dim3(256), 0, s, part, ks, mn, dst);
+}
+}
 using namespace mi355x;
 
 // copies of the shipped kernels with knock-outs
@@ -160,5 +177,29 @@ int main() {
     timeit("soft_max without expf", [&] { p_soft<3><<<NH, 256>>>(tkq, tm, tp, 0.088f); });
     timeit("soft_max without stores", [&] { p_soft<4><<<NH, 256>>>(tkq, tm, tp, 0.088f); });
     timeit("soft_max without block reductions", [&] { p_soft<5><<<NH, 256>>>(tkq, tm, tp, 0.088f); });
+    // ---- a -np 32 decode batch on the non-flash path: 32 tokens against 7296 cells
+    {
+        const int T = 32, ncell = 7296;
+        char *kc2, *vc2, *q2, *kq2, *p2, *out2, *ws2;
+        CK(hipMalloc(&kc2, (size_t) ncell * NKV * HD * 2)); CK(hipMalloc(&vc2, (size_t) ncell * NKV * HD * 2));
+        CK(hipMalloc(&q2, (size_t) T * NH * HD * 4)); CK(hipMalloc(&kq2, (size_t) ncell * T * NH * 4)); CK(hipMalloc(&p2, (size_t) ncell * T * NH * 4));
+        CK(hipMalloc(&out2, (size_t) T * NH * HD * 4)); CK(hipMalloc(&ws2, 64u << 20));
+        CK(hipMemset(kc2, 0x11, (size_t) ncell * NKV * HD * 2)); CK(hipMemset(vc2, 0x11, (size_t) ncell * NKV * HD * 2));
+        CK(hipMemset(q2, 0, (size_t) T * NH * HD * 4)); CK(hipMemset(kq2, 0, (size_t) ncell * T * NH * 4)); CK(hipMemset(p2, 0, (size_t) ncell * T * NH * 4));
+        const tdesc k2 = mk(kc2, GGML_TYPE_F16, HD, ncell, NKV, 2, NKV * HD * 2, HD * 2);
+        const tdesc v2 = mk(vc2, GGML_TYPE_F16, ncell, HD, NKV, 2, ncell * 2, (int64_t) ncell * 2 * HD);
+        const tdesc tq2 = mk(q2, GGML_TYPE_F32, HD, T, NH, 4, HD * NH * 4, HD * 4);
+        const tdesc tkq2 = mk(kq2, GGML_TYPE_F32, ncell, T, NH, 4, ncell * 4, (int64_t) ncell * 4 * T);
+        const tdesc tp2 = mk(p2, GGML_TYPE_F32, ncell, T, NH, 4, ncell * 4, (int64_t) ncell * 4 * T);
+        const tdesc to2 = mk(out2, GGML_TYPE_F32, HD, T, NH, 4, HD * 4, HD * 4 * T);
+        const tdesc tm2 = mk(mask, GGML_TYPE_F16, n_kv, 64, 1, 2, n_kv * 2, n_kv * 2 * 64);
+        (void) tm2;
+        timeit("batch 32 x 7296: K.Q (launch_mul_mat_f)", [&] { launch_mul_mat_f(0, k2, tq2, tkq2); });
+        timeit("batch 32 x 7296: K.Q tile kernel (no resident columns)", [&] { dim3 grid((ncell + 63) / 64, 1, NH); hipLaunchKernelGGL(k_mul_mat_f16_mma, grid, dim3(256), 0, 0, k2, tq2, tkq2); });
+        timeit("batch 32 x 7296: soft_max (no mask)", [&] { launch_soft_max(0, tkq2, nullptr, nullptr, tp2, 0.088f, 0.0f); });
+        timeit("batch 32 x 7296: V^T.p with scratch (K cut over workgroups + reduce)", [&] { launch_mul_mat_f(0, v2, tp2, to2, (float *) ws2, 64u << 20); });
+        timeit("batch 32 x 7296: V^T.p without scratch (16 x 16 tiles, K over waves)", [&] { launch_mul_mat_f(0, v2, tp2, to2); });
+        timeit("batch 32 x 7296: fill of the logits' size (30 MB memset)", [&] { CK(hipMemsetAsync(kq2, 0, (size_t) ncell * T * NH * 4, 0)); });
+    }
     return 0;
 }
