@@ -7,6 +7,27 @@
 
 namespace mi355x {
 
+// Non-temporal weight loads (the `nt` bit; MI355X_MICROARCH.md "nt-weights" reports -5..-10 % per decode layer for a bf16 stream of
+// whole 128-byte lines).  Measured here, round 2: 480 -> 415 tok/s (gate/up 15.2 -> 18.9 us, output 83 -> 141 us).  A 144 / 176 /
+// 210-byte super-block is not line-aligned and a lane's header, low and high quants are three instructions that touch the same
+// lines: without L2 residency every one of them goes back to memory.  Kept as a build switch, off.
+#ifndef MI_NT_WEIGHTS
+#define MI_NT_WEIGHTS 0
+#endif
+typedef uint32_t mi_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t mi_u32x2 __attribute__((ext_vector_type(2)));
+typedef mi_u32x4 mi_u32x4_a2 __attribute__((aligned(2)));
+typedef mi_u32x2 mi_u32x2_a2 __attribute__((aligned(2)));
+template <typename V, typename N> __device__ __forceinline__ V ld_stream_as(const V * p) {
+#if MI_NT_WEIGHTS
+    const N v = __builtin_nontemporal_load((const N *) p);
+    return __builtin_bit_cast(V, v);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint4 ld_stream(const uint4 * p) { return ld_stream_as<uint4, mi_u32x4>(p); }
+
 // sc/m pair extraction for K-quants' 12 packed bytes, for sub-blocks (2j, 2j+1); hy/hz/hw = bytes 0-3 / 4-7 / 8-11
 __device__ __forceinline__ void k4_scale_pair(uint32_t hy, uint32_t hz, uint32_t hw, int j, int & sc0, int & sc1, int & m0, int & m1) {
     const int sh = 16 * (j & 1);
@@ -38,9 +59,9 @@ struct T_Q4K {
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
         const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         raw r;
-        r.hdr = *(const uint4 *) blk;
-        r.q0 = *(const uint4 *) (blk + 16 + 32 * (p & 3));
-        r.q1 = *(const uint4 *) (blk + 32 + 32 * (p & 3));
+        r.hdr = ld_stream((const uint4 *) blk);
+        r.q0 = ld_stream((const uint4 *) (blk + 16 + 32 * (p & 3)));
+        r.q1 = ld_stream((const uint4 *) (blk + 32 + 32 * (p & 3)));
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
@@ -80,11 +101,11 @@ struct T_Q5K {
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
         const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         raw r;
-        r.hdr = *(const uint4 *) blk;
-        r.h0 = *(const uint4 *) (blk + 16);
-        r.h1 = *(const uint4 *) (blk + 32);
-        r.q0 = *(const uint4 *) (blk + 48 + 32 * (p & 3));
-        r.q1 = *(const uint4 *) (blk + 64 + 32 * (p & 3));
+        r.hdr = ld_stream((const uint4 *) blk);
+        r.h0 = ld_stream((const uint4 *) (blk + 16));
+        r.h1 = ld_stream((const uint4 *) (blk + 32));
+        r.q0 = ld_stream((const uint4 *) (blk + 48 + 32 * (p & 3)));
+        r.q1 = ld_stream((const uint4 *) (blk + 64 + 32 * (p & 3)));
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
@@ -131,6 +152,8 @@ struct T_Q5K {
 // 16-value sums (bsums) instead of a second dot product.
 struct __attribute__((packed, aligned(2))) u128_a2 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(2))) u64_a2 { uint32_t x, y; };
+__device__ __forceinline__ u128_a2 ld_stream(const u128_a2 * p) { return ld_stream_as<u128_a2, mi_u32x4_a2>(p); }
+__device__ __forceinline__ u64_a2 ld_stream(const u64_a2 * p) { return ld_stream_as<u64_a2, mi_u32x2_a2>(p); }
 struct T_Q6K {
     typedef q8k_dev act;
     static constexpr int BLK = 256, BYTES = 210, PPB = 4;
@@ -140,10 +163,10 @@ struct T_Q6K {
         const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         const int h = (p >> 1) & 1, t = p & 1;
         raw r;
-        r.a = *(const u128_a2 *) (blk + 64 * h + 16 * t);
-        r.b = *(const u128_a2 *) (blk + 64 * h + 32 + 16 * t);
-        r.c = *(const u128_a2 *) (blk + 128 + 32 * h + 16 * t);
-        r.s = *(const u64_a2 *) (blk + 192 + 8 * h);
+        r.a = ld_stream((const u128_a2 *) (blk + 64 * h + 16 * t));
+        r.b = ld_stream((const u128_a2 *) (blk + 64 * h + 32 + 16 * t));
+        r.c = ld_stream((const u128_a2 *) (blk + 128 + 32 * h + 16 * t));
+        r.s = ld_stream((const u64_a2 *) (blk + 192 + 8 * h));
         r.d = ld16(blk + 208);
         return r;
     }
