@@ -34,7 +34,7 @@ struct fam_geom {
 
 // NW waves of 32 queries each share one staged K/V tile (NW = 4: 128 queries per workgroup, half the staging work per query)
 template <int D, int NW>
-__global__ void __launch_bounds__(NW * 64) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo, float * __restrict__ ws,
+__global__ void __launch_bounds__(NW * 64, 2) k_fattn_mma(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const fam_geom geo, float * __restrict__ ws,
                                                        const uint8_t * __restrict__ vis) {
     constexpr int BKV = 64;
     constexpr int KS = (D + 8) * 2;    // K tile row stride (bytes): odd multiple of 16 -> conflict-free ds_read_b128
