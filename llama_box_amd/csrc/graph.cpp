@@ -722,9 +722,8 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             sg.bias = ch.bias ? (const float *) ch.bias->data : nullptr;
             sg.rope = ch.rope ? 1 : 0;
             sg.store = !ch.store ? 0 : ch.scatter ? 3 : (ch.store->type == GGML_TYPE_Q8_0 ? 2 : 1);
-            sg.idx = ch.scatter ? (const int64_t *) ch.store->src[1]->data : nullptr;
             sg.out = ch.store ? (char *) ch.store->data : (char *) ch.out_f32->data;
-            sg.row_stride = ch.store ? (int64_t) ch.store->nb[1] : 0;
+            sg.row_stride = !ch.store ? 0 : ch.scatter ? (int64_t) (uintptr_t) ch.store->src[1]->data : (int64_t) ch.store->nb[1];
             bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];
         }
         char cls[64];

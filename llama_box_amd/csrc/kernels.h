@@ -72,14 +72,16 @@ extern thread_local launch_probe g_launch_probe;
 struct qkv_seg {
     const uint8_t * W;
     int64_t w_nb1;
-    int alt, N;           // alt: 0 = first weight format of the launch, 1 = second
-    const float * bias;   // optional [N]
-    int rope;             // rotate pairs of this segment
-    int store;            // 0: f32 at out; 1: f16 / 2: block_q8_0 into row `slot` of a cache tensor (out + slot*row_stride);
+    int N;
+    uint8_t alt;          // 0 = first weight format of the launch, 1 = second      (alt / rope / store share one dword: see row_stride)
+    uint8_t rope;         // rotate pairs of this segment
+    uint8_t store;        // 0: f32 at out; 1: f16 / 2: block_q8_0 into row `slot` of a cache tensor (out + slot*row_stride);
                           // 3: f16 element j at out + 2 idx[j] (the transposed V cache of the non-flash path: one row index per element)
+    uint8_t pad_;
+    const float * bias;   // optional [N]
     char * out;
-    int64_t row_stride;
-    const int64_t * idx;  // store == 3
+    int64_t row_stride;   // store == 3: the address of the int64 index vector instead (no extra field: the struct travels in SGPRs,
+                          // and the two-format launch is at its register limit — one more pointer cost 12 bytes of spills)
 };
 struct qkv_args {
     qkv_seg seg[3];

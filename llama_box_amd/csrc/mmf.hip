@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mma(const tdesc a, const td
 // 16 NK — and walks RT row tiles: 8 KB of src0 per tile feed GH x NK MFMAs, the next tile's rows are requested before the current
 // one is multiplied.
 template <int GH, int NK>
-__global__ void __launch_bounds__(256) k_mul_mat_f16_mma_xres(const tdesc a, const tdesc b, const tdesc d, const int RT) {
+__global__ void __launch_bounds__(256, 2) k_mul_mat_f16_mma_xres(const tdesc a, const tdesc b, const tdesc d, const int RT) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r32 = lane & 31, g = lane >> 5;
     const int64_t K = a.ne[0], col0 = (int64_t) blockIdx.y * 32;
@@ -722,8 +722,7 @@ void launch_mul_mat_f(hipStream_t s, const tdesc & a, const tdesc & b, const tde
     }
     if (w16 && vec_ok && b.ne[1] >= 16 && K <= 128 && a.ne[1] >= 256 && b.ne[2] % a.ne[2] == 0) {  // short rows, many of them (K.Q): columns resident
         const int64_t gq = b.ne[2] / a.ne[2];
-        if (gq % 4 == 0) launch_xres_t<4>(s, a, b, d);
-        else if (gq % 2 == 0) launch_xres_t<2>(s, a, b, d);
+        if (gq % 2 == 0) launch_xres_t<2>(s, a, b, d);  // (4 heads' columns = 128 registers: with the row buffers past 256, one wave per SIMD, or spills)
         else launch_xres_t<1>(s, a, b, d);
         return;
     }

@@ -199,8 +199,9 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
                 o[r1] = f2h(v1);
             } else if (sg.store == 3) {
                 uint16_t * o = (uint16_t *) sg.out;
-                o[sg.idx[r0]] = f2h(v0);
-                o[sg.idx[r1]] = f2h(v1);
+                const int64_t * ix = (const int64_t *) (uintptr_t) sg.row_stride;
+                o[ix[r0]] = f2h(v0);
+                o[ix[r1]] = f2h(v1);
             } else {
                 float * o = (float *) sg.out;
                 o[r0] = v0;
