@@ -272,6 +272,7 @@ def test_mul_mat_q_3d_src1(backend, H, plog, qt):
                                           (128, 300, 1, 2, 8), (64, 1000, 1, 4, 4), (80, 77, 1, 1, 8), (512, 65, 1, 3, 6), (2304, 128, 1, 8, 32), (1000, 66, 1, 1, 2), (520, 64, 1, 2, 2),
                                           # few tiles over long rows (V^T.p of a -np decode batch) and 2..15 columns: 16x16 tiles, K split over the workgroup's waves
                                           (7304, 128, 32, 2, 8), (3000, 40, 20, 1, 2), (128, 300, 8, 2, 8), (1032, 16, 5, 1, 3),
+                                          (4096, 96, 40, 2, 4), (2056, 128, 64, 1, 3), (4104, 160, 8, 1, 2),
                                           # short rows, many of them, against a batch (K.Q): columns of 4 / 2 / 1 grouped heads resident in registers
                                           (128, 3000, 32, 2, 8), (128, 700, 70, 2, 4), (64, 513, 16, 3, 3), (120, 300, 33, 1, 2), (72, 260, 20, 2, 14),
                                           (128, 96, 40, 2, 8), (64, 130, 33, 1, 4), (200, 70, 16, 1, 1), (2048, 128, 100, 2, 4), (136, 50, 64, 1, 2), (128, 512, 512, 8, 32)])
