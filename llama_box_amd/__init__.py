@@ -17,7 +17,9 @@ import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_DIR)
-BACKEND_SO = os.path.join(_DIR, "libggml-mi355x.so")
+# (GGML_BACKEND_PATH: the variable the reference's loader honours for an out-of-tree backend library, pure_cpu.patch:101-102 — here it
+# lets the harness run an A/B build of the same library)
+BACKEND_SO = os.environ.get("GGML_BACKEND_PATH") or os.path.join(_DIR, "libggml-mi355x.so")
 HOST_SO = os.path.join(_DIR, "libmi355x_host.so")
 
 # ggml enums (include/ggml_abi.h)

@@ -575,7 +575,13 @@ static int skinny_n_cu();
 //   L2); request order per step [activations of s+1, weights of s+2] so that what step s+1 consumes is older than what stays in flight
 //   (in-order vmcnt).  Items (128-row group, token tile group) of one weight group run on the same XCD at the same time: its L2
 //   serves the weight bytes to all of them.
-template <int QT, int TT, int NW> constexpr int wd_lds_bytes() { return 2 * TT * (SK_B_BYTES + 128) + NW * 3 * tp_a_stage<QT>(); }
+#ifndef WD_KO
+#define WD_KO 0  // timing-only knock-outs of the wide kernel (wrong results): 1 no MFMAs, 2 no weight conversion, 3 no requests after the prologue
+#endif
+#ifndef WD_NB
+#define WD_NB 2  // stages of the activation ring (3 = requested two steps ahead, like the weights: measured equal, A/B on one box)
+#endif
+template <int QT, int TT, int NW> constexpr int wd_lds_bytes() { return WD_NB * TT * (SK_B_BYTES + 128) + NW * 3 * tp_a_stage<QT>(); }
 constexpr int WD_NL = 2;  // loader waves per workgroup
 
 // NW computing waves (one 32-row tile each) + WD_NL loader waves.  In-kernel timestamps of the first version, where every wave
@@ -605,10 +611,10 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
     const int tok_bytes = nblk * (int) sizeof(q8k_dev);
     const uint32_t lds0 = (uint32_t) (uintptr_t) smem;
     // LDS: [activation ring 2 x TT x 9728][scale ring 2 x TT x 128][weight rings: tile x 3 x stage]
-    const uint32_t b_ring = lds0, d_ring = lds0 + 2 * B_STAGE, a_rings = d_ring + 2 * TT * 128;
+    const uint32_t b_ring = lds0, d_ring = lds0 + WD_NB * B_STAGE, a_rings = d_ring + WD_NB * TT * 128;
     const char * const b_ring_p = smem;
-    const char * const d_ring_p = smem + 2 * B_STAGE;
-    const char * const a_ring_p = smem + 2 * B_STAGE + 2 * TT * 128 + (loader ? 0 : wave) * 3 * A_STAGE;
+    const char * const d_ring_p = smem + WD_NB * B_STAGE;
+    const char * const a_ring_p = smem + WD_NB * B_STAGE + WD_NB * TT * 128 + (loader ? 0 : wave) * 3 * A_STAGE;
 
     // loader fetch roles (offsets from the unit's first byte)
     int a_off[NLA];
@@ -693,8 +699,9 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
 #define WD_ADV(v, sb) { if (++(sb) == nblk) { (sb) = 0; (v) = next_valid((v) + gridDim.x); } }
     if (loader) {
         if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
-        if (vb < n_virtual) { issue_b(vb, sbb, nb % 2); ++nb; WD_ADV(vb, sbb) }
+        if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
         if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+        if (WD_NB == 3 && vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
     }
     const int16s zeroi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float16s zerof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -702,13 +709,19 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
         if (loader) {
             // this loader's pieces of step s (weights requested two steps ago, activations one) have landed; only its weight requests of
             // step s + 1 may still fly
-            if (na > s + 1) tp_wait_c<n_ops_a>();
+            // (WD_NB == 3: the activations run two steps ahead as well; what may still fly is step s + 1 of both kinds, requested together)
+            if (na > s + 1) tp_wait_c<WD_NB == 3 ? n_ops_a + NLB + DCNT : n_ops_a>();
             else tp_wait_c<0>();
         }
         __syncthreads();  // everything of step s is in LDS, and nobody reads step s - 1 any more
         if (loader) {
-            if (vb < n_virtual) { issue_b(vb, sbb, nb % 2); ++nb; WD_ADV(vb, sbb) }
+#if WD_KO != 3
+            if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
             if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+#else
+            if (vb < n_virtual) { ++nb; WD_ADV(vb, sbb) }
+            if (va < n_virtual) { ++na; WD_ADV(va, sa) }
+#endif
             continue;
         }
 
@@ -756,26 +769,46 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
                 const uint32_t e0 = (p & 1) ? sk_rep_byte<2>(src) : sk_rep_byte<0>(src), e1 = (p & 1) ? sk_rep_byte<3>(src) : sk_rep_byte<1>(src);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+#if WD_KO == 2
+                    W0[p][n][k] = (int) (hdr.y + k + n);
+                    W1[p][n][k] = (int) (hdr.z + k + p);
+#else
                     W0[p][n][k] = (int) sk_pk_mul(wlo[k], e0);
                     W1[p][n][k] = (int) sk_pk_mul(whi[k], e1);
+#endif
                 }
             }
         }
         // ---- TT token tiles against it
-        const char * const bst = b_ring_p + (s % 2) * B_STAGE;
-        const float * const dst_ = (const float *) (d_ring_p + (s % 2) * TT * 128);
+        const char * const bst = b_ring_p + (s % WD_NB) * B_STAGE;
+        const float * const dst_ = (const float *) (d_ring_p + (s % WD_NB) * TT * 128);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const char * const btok = bst + (t * 32 + row) * SK_BTOK;
             int16s pl[NP];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
+#if WD_KO == 4
+                const int4s y0 = {(int) hdr.x + p, (int) hdr.y, (int) hdr.z + t, (int) hdr.w}, y1 = {(int) hdr.y + p, (int) hdr.x, (int) hdr.w + t, (int) hdr.z};
+#else
                 const int4s y0 = *(const int4s *) (btok + 64 * p + 16 * g);
                 const int4s y1 = *(const int4s *) (btok + 64 * p + 32 + 16 * g);
+#endif
 #pragma unroll
+#if WD_KO == 1
+                for (int n = 0; n < NP; ++n) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pl[n][e] = (p == 0 ? 0 : pl[n][e]) + y0[e] + W0[p][n][e] + y1[e] + W1[p][n][e];
+                    if (p == 0) {
+#pragma unroll
+                        for (int e = 4; e < 16; ++e) pl[n][e] = 0;
+                    }
+                }
+#else
                 for (int n = 0; n < NP; ++n) pl[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(y0, W0[p][n], p == 0 ? zeroi : pl[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NP; ++n) pl[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(y1, W1[p][n], pl[n], 0, 0, 0);
+#endif
             }
             const half8s bsf = *(const half8s *) (btok + 256 + 16 * g);
             const float16s ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, __builtin_bit_cast(half8s, mfu), zerof, 0, 0, 0);
@@ -789,8 +822,12 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
                     int isum;
                     if constexpr (QT == 4) isum = (pl[1][i] << 3) + pl[0][i];
                     else isum = (pl[2][i] << 4) + (pl[1][i] << 2) + pl[0][i];
+#if WD_KO == 5
+                    acc[t][i] += __builtin_bit_cast(float, isum) + ms[i] + dyv[r];
+#else
                     const float v = __builtin_fmaf(-dmin, ms[i], d * (float) isum);
                     acc[t][i] = __builtin_fmaf(dyv[r], v, acc[t][i]);
+#endif
                 }
             }
         }
@@ -804,16 +841,24 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
             const int64_t m_dst_stride = MAT_SEL(mi, dst_stride);
             const float * const m_add = MAT_SEL(mi, add);
             const int64_t m_add_stride = MAT_SEL(mi, add_stride);
+            // (addends first, all of them in flight, then nothing but stores: with the optional load inside the store loop the compiler
+            // waited vmcnt(0) before every store — stores count in vmcnt on this ISA, so each of the 32 waited for its predecessor's
+            // write acknowledgement, ~16k clocks per item)
+            if (m_add) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int tok = min(mt * 32 * TT + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * g, a.M - 1);
+                        acc[t][i] += m_add[(size_t) tok * m_add_stride + n];
+                    }
+            }
 #pragma unroll
             for (int t = 0; t < TT; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int tok = mt * 32 * TT + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
-                    if (tok < a.M) {
-                        float v = acc[t][i];
-                        if (m_add) v += m_add[(size_t) tok * m_add_stride + n];
-                        m_dst[(size_t) tok * m_dst_stride + n] = v;
-                    }
+                    if (tok < a.M) m_dst[(size_t) tok * m_dst_stride + n] = acc[t][i];
                     acc[t][i] = 0.0f;
                 }
             sc_ = 0;
