@@ -527,14 +527,14 @@ __global__ void __launch_bounds__(TP_NW * 64, 2) k_mmq_skinny_tp(const mmq8_args
             const int64_t m_dst_stride = MAT_SEL(mi, dst_stride);
             const float * const m_add = MAT_SEL(mi, add);
             const int64_t m_add_stride = MAT_SEL(mi, add_stride);
+            if (m_add) {  // (addends first, then nothing but stores: see k_mmq_wide)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += m_add[(size_t) min((i & 3) + 8 * (i >> 2) + 4 * g, a.M - 1) * m_add_stride + n];
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int tok = (i & 3) + 8 * (i >> 2) + 4 * g;
-                if (tok < a.M) {
-                    float v = acc[i];
-                    if (m_add) v += m_add[(size_t) tok * m_add_stride + n];
-                    m_dst[(size_t) tok * m_dst_stride + n] = v;
-                }
+                if (tok < a.M) m_dst[(size_t) tok * m_dst_stride + n] = acc[i];
                 acc[i] = 0.0f;
             }
             cu_sb = 0;
