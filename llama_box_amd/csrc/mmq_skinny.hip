@@ -589,22 +589,28 @@ constexpr int WD_NL = 2;  // loader waves per workgroup
 // address pipeline), 1 650 at the barrier (for the slowest issuer), 430 converting the weight unit, 2 700 in the 34 MFMAs of its two
 // token tiles — the matrix pipe busy 37 %.  The loaders take the first two off the computing waves: they request, wait (vmcnt) and
 // meet the others at the step's barrier; the computing waves only convert and multiply.
-template <int QT, int TT, int NW>
-__global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_args a) {
+// NL = 0: no loader waves — every computing wave requests its own weight tile and its share of the activations (NW waves = one per
+// SIMD: 512 registers each, accumulators in AGPRs, room for 4 token tiles per converted weight unit).  Measured (A/B, 2048-token
+// prefill): 23.2 k tok/s against 31.6 k for 4 + 2 waves x 2 tiles — the requests' issue stalls sit in the computing waves' own
+// instruction streams again.  Kept behind GGML_MI355X_MMQ_WIDE_SELF=1 (correct: the wide tests pass with it).
+template <int QT, int TT, int NW, int NL>
+__global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args a) {
+    constexpr bool SELF = NL == 0;
+    constexpr int NLD = SELF ? NW : NL;  // waves that request
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef sk_fmt<QT> F;
     constexpr int NP = QT == 4 ? 2 : 3;
     constexpr uint32_t DM = QT == 4 ? 0x07070707u : 0x03030303u;
     constexpr int DS = QT == 4 ? 3 : 2;
     constexpr int NPA = 32 * F::PIECES, NLA = (NPA + 63) / 64;
-    constexpr int NPB = TT * 32 * 19 / WD_NL, NLB = (NPB + 63) / 64;  // activation pieces per loader and step, and the instructions fetching them
-    constexpr int TPL = NW / WD_NL;                                    // weight tiles per loader
-    constexpr int DCNT = (TT + WD_NL - 1) / WD_NL;                     // scale requests per loader and step
+    constexpr int NPB = TT * 32 * 19 / NLD, NLB = (NPB + 63) / 64;  // activation pieces per loader and step, and the instructions fetching them
+    constexpr int TPL = NW / NLD;                                    // weight tiles per loader
+    constexpr int DCNT = (TT + NLD - 1) / NLD;                       // scale requests per loader and step
     constexpr int B_STAGE = TT * SK_B_BYTES, A_STAGE = tp_a_stage<QT>();
-    static_assert(NW % WD_NL == 0 && (TT * 32 * 19) % WD_NL == 0, "loader roles");
+    static_assert(NW % NLD == 0 && (TT * 32 * 19) % NLD == 0, "loader roles");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= NW;
-    const int ld = wave - NW;  // loader index
+    const bool loader = !SELF && wave >= NW;
+    const int ld = SELF ? wave : wave - NW;  // loader index
     const int row = lane & 31, g = lane >> 5;
     const int nblk = a.K / 256;
     const int w_nb1 = (int) a.mat[0].w_nb1;
@@ -681,7 +687,7 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
         // no tile of its own), so that the wait counts are the same compile-time constants for all
 #pragma unroll
         for (int t = 0; t < DCNT; ++t) {
-            const int tt = min(ld + t * WD_NL, TT - 1);
+            const int tt = min(ld + t * NLD, TT - 1);
             if (lane < 32) tp_dma4(ab + (size_t) tt * 32 * (size_t) tok_bytes + d_off, d_ring + slot * TT * 128 + tt * 128);
         }
     };
@@ -697,7 +703,7 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
     int vb = va, sbb = 0, nb = 0;
     int vc = va, sc_ = 0;                             // the step being multiplied (computing waves)
 #define WD_ADV(v, sb) { if (++(sb) == nblk) { (sb) = 0; (v) = next_valid((v) + gridDim.x); } }
-    if (loader) {
+    if (loader || SELF) {
         if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
         if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
         if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
@@ -706,7 +712,7 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
     const int16s zeroi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float16s zerof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int s = 0; s < total; ++s) {
-        if (loader) {
+        if (loader || SELF) {
             // this loader's pieces of step s (weights requested two steps ago, activations one) have landed; only its weight requests of
             // step s + 1 may still fly
             // (WD_NB == 3: the activations run two steps ahead as well; what may still fly is step s + 1 of both kinds, requested together)
@@ -714,7 +720,7 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
             else tp_wait_c<0>();
         }
         __syncthreads();  // everything of step s is in LDS, and nobody reads step s - 1 any more
-        if (loader) {
+        if (loader || SELF) {
 #if WD_KO != 3
             if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
             if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
@@ -722,7 +728,7 @@ __global__ void __launch_bounds__((NW + WD_NL) * 64, 1) k_mmq_wide(const mmq8_ar
             if (vb < n_virtual) { ++nb; WD_ADV(vb, sbb) }
             if (va < n_virtual) { ++na; WD_ADV(va, sa) }
 #endif
-            continue;
+            if (!SELF) continue;
         }
 
         // ---- this wave's weight unit -> digit-plane operands, once per step
@@ -889,9 +895,9 @@ int mmq_wide_tiles(int type, int64_t K, const int64_t * N, int n_mat, int64_t M,
     return g128 * ((M + 63) / 64) * 2 >= skinny_n_cu() ? 4 * 16 + 2 : 0;
 }
 
-template <int QT, int TT, int NW> static void launch_wide_t(hipStream_t s, mmq8_args a) {
+template <int QT, int TT, int NW, int NL> static void launch_wide_t(hipStream_t s, mmq8_args a) {
     static std::atomic<uint32_t> lds_raised{0};
-    const void * fn = (const void *) k_mmq_wide<QT, TT, NW>;
+    const void * fn = (const void *) k_mmq_wide<QT, TT, NW, NL>;
     const size_t lds = (size_t) wd_lds_bytes<QT, TT, NW>();
     (void) ensure_dyn_lds(fn, lds, lds_raised);
     a.n_panels = 0;
@@ -901,12 +907,14 @@ template <int QT, int TT, int NW> static void launch_wide_t(hipStream_t s, mmq8_
     }
     a.m_tiles = (a.M + 32 * TT - 1) / (32 * TT);
     const int n_virtual = ((a.n_panels + 7) / 8) * 8 * a.m_tiles;
-    hipLaunchKernelGGL((k_mmq_wide<QT, TT, NW>), dim3((unsigned) std::min(n_virtual, skinny_n_cu())), dim3((NW + WD_NL) * 64), lds, s, a);
+    hipLaunchKernelGGL((k_mmq_wide<QT, TT, NW, NL>), dim3((unsigned) std::min(n_virtual, skinny_n_cu())), dim3((NW + NL) * 64), lds, s, a);
 }
 void launch_mmq_wide(hipStream_t s, int type, int shape, const mmq8_args & a) {
-    (void) shape;  // (one shape in use: 4 computing waves x 2 token tiles)
-    if (type == GGML_TYPE_Q4_K) launch_wide_t<4, 2, 4>(s, a);
-    else launch_wide_t<5, 2, 4>(s, a);
+    static const int self4 = getenv("GGML_MI355X_MMQ_WIDE_SELF") ? atoi(getenv("GGML_MI355X_MMQ_WIDE_SELF")) : 0;  // experiment: 4 waves x 4 token tiles, no loaders
+    (void) shape;
+    if (self4 && type == GGML_TYPE_Q4_K) { launch_wide_t<4, 4, 4, 0>(s, a); return; }
+    if (type == GGML_TYPE_Q4_K) launch_wide_t<4, 2, 4, WD_NL>(s, a);
+    else launch_wide_t<5, 2, 4, WD_NL>(s, a);
 }
 
 bool mmq_skinny_supported(int type, int64_t K, int64_t N, int64_t M, int64_t w_nb1) {
