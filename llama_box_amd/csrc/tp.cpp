@@ -82,8 +82,11 @@ int tp_init(backend_ctx * c, int rank, int world, const void * uid, size_t uid_s
         return -2;
     }
     c->tp = t;
-    // collectives inside a captured graph are opt-in until validated on multi-GPU hardware
-    if (!getenv("GGML_MI355X_TP_GRAPHS")) c->opt.graphs = false;
+    // The all-reduces are enqueued on the backend's stream like every kernel, so a decode step with a communicator attached is captured
+    // and replayed as ONE hipGraph like a single-GPU step (RCCL supports stream capture; the first sighting of a topology runs eagerly,
+    // which also lets RCCL finish its lazy connection set-up outside a capture, and a failed capture falls back to eager execution:
+    // graph.cpp).  Not yet exercised on multi-GPU hardware — GGML_MI355X_TP_GRAPHS=0 keeps the steps eager.
+    if (const char * e = getenv("GGML_MI355X_TP_GRAPHS")) { if (atoi(e) == 0) c->opt.graphs = false; }
     return 0;
 }
 
