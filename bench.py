@@ -156,10 +156,11 @@ def main():
     model = Model(hp, 0x5EED, be.buft, tp_rank=tp_rank, tp_size=tp_size, rowpar_buft=be.rowpar_buft() if tp_size > 1 else None)
     t_load = time.time() - t_load
     kvt = L.Q8_0 if args.ctkv == "q8_0" else 0
-    n_ctx = (args.np * (args.prefill + args.warmup + args.steps + args.timing_steps + 64) + 255) // 256 * 256
+    extra_leg = (args.warmup + args.steps) if (world > 1 or os.environ.get("BENCH_FORCE_TWO_LEGS") == "1") else 0  # tensor-split runs time the decode steps twice (eager, then graph replay)
+    n_ctx = (args.np * (args.prefill + args.warmup + args.steps + extra_leg + args.timing_steps + 64) + 255) // 256 * 256
     ctx = Context(model, backend=be, n_ctx=n_ctx, n_ubatch=args.ubatch, flash_attn=args.fa, graph_reuse=1, type_k=kvt, type_v=kvt)
     rng = np.random.default_rng(1 + 0 * rank)
-    toks = rng.integers(0, hp.n_vocab, args.np * (args.prefill + args.warmup + args.steps + args.timing_steps + 8))
+    toks = rng.integers(0, hp.n_vocab, args.np * (args.prefill + args.warmup + args.steps + extra_leg + args.timing_steps + 8))
 
     def sync():
         if dist is not None:
@@ -204,25 +205,74 @@ def main():
         rc = ctx.decode_steps(rows, args.np, pos)
         assert rc == 0, f"decode failed rc={rc}"
 
-    steps(args.warmup)
-    pos += args.warmup
-    g0 = be.stat("graph_launches")
-    gl0 = be.stat("graph_launch_host_ns")
-    sync()
-    t0 = time.perf_counter()
-    steps(args.steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    pos += args.steps
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    graph_steps = be.stat("graph_launches") - g0
-    graph_launch_host_us = (be.stat("graph_launch_host_ns") - gl0) / 1e3 / max(1, graph_steps)
+    def leg():  # W untimed warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks
+        nonlocal pos
+        steps(args.warmup)
+        pos += args.warmup
+        g0 = be.stat("graph_launches")
+        gl0 = be.stat("graph_launch_host_ns")
+        sync()
+        t0 = time.perf_counter()
+        steps(args.steps)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t1 = time.perf_counter()
+        pos += args.steps
+        el = t1 - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+        gs = be.stat("graph_launches") - g0
+        return el, gs, (be.stat("graph_launch_host_ns") - gl0) / 1e3 / max(1, gs)
+
+    def headline(el, extra_note=""):  # the contract's fields for a K-step time (everything else is added to it below)
+        st = 1 if tp_size > 1 or world == 1 else world
+        return {
+            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M" if args.preset == "llama3-8b-q4_k_m" and args.np == 1 else
+                      f"decode tokens/sec ({'batch-1' if args.np == 1 else f'-np {args.np} aggregate'}) + prefill tok/s, {args.preset} [secondary configuration, not the headline metric]",
+            "value": round(st * args.np * args.steps / el, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None,
+            "dtype": ("q8_0 weights x q8_0 activations" if "q8_0" in args.preset else ("q5_K/q6_K" if "q5_k" in args.preset else "q4_K/q6_K") + " weights x q8_K activations") + " (int8 dot, f32 accumulate)",
+            "data": "synthetic (GGUF-exact tensor set, directly sampled quant blocks, random token ids)",
+            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode, flash_attn={args.fa}, kv_cache={args.ctkv}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
+                       "parallelism": parallelism + extra_note},
+        }
+
+    tp_legs = None
+    two_legs = tp_size > 1 or os.environ.get("BENCH_FORCE_TWO_LEGS") == "1"  # (the variable: exercise this branch on one GPU)
+    if two_legs:
+        # Tensor split: the K steps are timed twice — eager launches first (the form that needs nothing of RCCL but stream order), then the
+        # same steps captured and replayed as hipGraphs with the all-reduces inside (never yet run on multi-GPU hardware).  The faster leg
+        # is `value`; if the graph leg does not come back, a watchdog prints the eager line and ends the process instead of hanging the job.
+        import threading
+        be.set_option("graphs", 0)
+        el_eager, _, _ = leg()
+        deadline = max(60.0, 30.0 * el_eager * (1.0 + args.warmup / max(1, args.steps)))
+
+        def give_up():
+            if rank == 0:
+                out = headline(el_eager, " [graph-replay leg timed out: eager launches]")
+                out["prefill_tok_s"] = round(prefill_tok_s, 1) if prefill_tok_s else None
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(deadline, give_up)
+        dog.daemon = True
+        dog.start()
+        be.set_option("graphs", 1)
+        try:
+            el_graph, graph_steps, graph_launch_host_us = leg()
+        except AssertionError as e:  # a failed replay: keep the eager number
+            el_graph, graph_steps, graph_launch_host_us = float("inf"), 0, 0.0
+            parallelism += f" [graph-replay leg failed: {e}]"
+        dog.cancel()
+        tp_legs = {"eager_ms_per_step": round(el_eager / args.steps * 1e3, 4), "graph_replay_ms_per_step": round(el_graph / args.steps * 1e3, 4) if el_graph != float("inf") else None}
+        elapsed = min(el_eager, el_graph)
+    else:
+        elapsed, graph_steps, graph_launch_host_us = leg()
     streams = 1 if tp_size > 1 or world == 1 else world
     tok_s = streams * args.np * args.steps / elapsed
     host_split = [x / max(1, args.steps) for x in ctx.timings()]
@@ -285,7 +335,7 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
             ctx_r.free(); model_r.free()
             replicas = {"value": round(world * args.steps / float(el[0]), 2), "unit": "tokens/s", "scaling": "weak",
-                        "note": f"{world} independent batch-1 decodes, one full model per GPU, same barrier / max-over-ranks timing (eager launches: graph replay is off while a communicator is attached)"}
+                        "note": f"{world} independent batch-1 decodes, one full model per GPU, same barrier / max-over-ranks timing"}
         except Exception as e:
             replicas = {"error": str(e)}
 
@@ -350,16 +400,10 @@ def main():
         kv_per_tok = int(2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * (34 / 32 if args.ctkv == "q8_0" else 2))
         n_past = args.prefill + args.warmup + args.steps // 2
         job_bytes = (w_bytes + args.np * kv_per_tok * n_past) * (tok_s / streams / args.np)
-        out = {
-            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M" if args.preset == "llama3-8b-q4_k_m" and args.np == 1 else
-                      f"decode tokens/sec ({'batch-1' if args.np == 1 else f'-np {args.np} aggregate'}) + prefill tok/s, {args.preset} [secondary configuration, not the headline metric]",
-            "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None,
-            "dtype": ("q8_0 weights x q8_0 activations" if "q8_0" in args.preset else ("q5_K/q6_K" if "q5_k" in args.preset else "q4_K/q6_K") + " weights x q8_K activations") + " (int8 dot, f32 accumulate)",
-            "data": "synthetic (GGUF-exact tensor set, directly sampled quant blocks, random token ids)",
-            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode, flash_attn={args.fa}, kv_cache={args.ctkv}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
-                       "parallelism": parallelism, "n_past_mid": n_past, "weight_bytes_per_token_per_gpu": w_bytes, "kv_bytes_per_token_per_gpu": kv_per_tok * n_past},
+        out = headline(elapsed)
+        out["config"].update({"n_past_mid": n_past, "weight_bytes_per_token_per_gpu": w_bytes, "kv_bytes_per_token_per_gpu": kv_per_tok * n_past})
+        out.update({
+            "tensor_split_legs": tp_legs,
             "prefill_tok_s": round(prefill_tok_s, 1) if prefill_tok_s else None,
             "prefill_host_us": {"build": round(prefill_host_split[0], 1), "inputs": round(prefill_host_split[1], 1), "compute+sync": round(prefill_host_split[2], 1), "logits_d2h": round(prefill_host_split[3], 1)} if prefill_tok_s else None,
             "prefill_roofline": prefill_roofline,
@@ -370,7 +414,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernel_classes_us": {k: round(v[1] * 1e3 / max(1, v[0]), 2) for k, v in sorted(classes.items())},
             "model_load_s": round(t_load, 1),
-        }
+        })
         print(json.dumps(out))
     if ctx is not None:
         ctx.free()
