@@ -284,6 +284,47 @@ def test_flash_attn_head_dim_128_at_8192(backend, H, plog, NH, NKV, n_kv, n_vis)
     T.compare(f"flash_attn d=128 heads={NH}/{NKV} n_kv={n_kv} visible={n_vis}", got[0], ref[0], max_nmse=max(1e-4, 1.5 * e_cpu), log=plog)
 
 
+# ------------------------------------------------------------------------------------------------ the non-flash attention chain at real shapes
+# llama-box runs with -fa off unless asked (engine_param.hpp:772-779): K view . q -> SOFT_MAX(mask, scale) -> V^T view . p -> CONT, exactly as
+# llama_lite / llm_build_llama build it.  Decode: two launches (grouped-head K.q, SOFT_MAX folded into V^T.p); a prompt chunk: the f16
+# matrix-core kernels and the register-resident soft-max.  Gates are the per-op ones (the products are exact in f32, sums differ in order).
+@pytest.mark.parametrize("NH,NKV,n_kv,n_vis,T_", [(32, 8, 2304, 2100, 1), (28, 4, 8192, 8000, 1), (64, 8, 4096, 4096, 1), (32, 8, 2304, 2304, 512), (32, 8, 7296, 7296, 32)])
+def test_non_flash_attention_chain(backend, H, plog, NH, NKV, n_kv, n_vis, T_):
+    rng = np.random.default_rng(NH * 17 + n_kv + T_)
+    HD, EK = 128, NKV * 128
+    q = rng.standard_normal((T_, NH, HD)).astype(np.float32)
+    kc = (rng.standard_normal((n_kv, EK)) * 0.5).astype(np.float16)
+    vt = (rng.standard_normal((EK, n_kv)) * 0.5).astype(np.float16)  # transposed V cache: [n_embd_v][n_ctx]
+    TP = (T_ + 63) // 64 * 64
+    mask = np.full((TP, n_kv), -np.inf, np.float16)
+    if T_ == 1:
+        mask[0, :n_vis] = 0
+    elif T_ == 32:  # a -np batch: token t sees the cells of its own sequence (every 32nd)
+        for t in range(T_):
+            mask[t, t::32] = 0
+    else:  # a prompt chunk at the end of the context: causal
+        for t in range(T_):
+            mask[t, :n_kv - T_ + t + 1] = 0
+
+    def build(g):
+        qq = H.ggml_permute(g.ctx, g.new(L.F32, [HD, NH, T_], q), 0, 2, 1, 3)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [EK, n_kv], kc), HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [n_kv, EK], vt), n_kv, HD, NKV, n_kv * 2, n_kv * 2 * HD, 0)
+        kq = H.ggml_mul_mat(g.ctx, k, qq)
+        p = H.ggml_soft_max_ext(g.ctx, kq, g.new(L.F16, [n_kv, TP], mask), 1.0 / np.sqrt(HD), 0.0)
+        kqv = H.ggml_mul_mat(g.ctx, v, p)
+        return H.ggml_cont_2d(g.ctx, H.ggml_permute(g.ctx, kqv, 0, 2, 1, 3), HD * NH, T_)
+
+    ref = T.run_case(build, "oracle", NT)
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    _log(plog, f"non-flash attention heads={NH}/{NKV} n_kv={n_kv} tokens={T_}: {launches} launches")
+    T.compare(f"non-flash attention heads={NH}/{NKV} n_kv={n_kv} tokens={T_}", got[0], ref[0], max_nmse=1e-10, log=plog)
+    if T_ == 1:
+        assert launches <= 3, launches  # K.q, SOFT_MAX + V^T.p, (CONT: a no-op copy for one token unless the allocator moved it)
+
+
 # ------------------------------------------------------------------------------------------------ split graphs
 def test_split_graph_keeps_tensors_read_by_another_split(backend, H, plog):
     """ggml_backend_sched hands a backend ONE split (a ggml_graph_view).  A tensor whose other reader sits in the next split
