@@ -71,7 +71,11 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
     using T = decltype(tag);
     constexpr int MAXW = 16, QB = 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
     const int WAVES = (int) blockDim.x >> 6;  // 8..16 waves: the launcher sizes the workgroup so that units/WAVES ~ 256 workgroups
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform, and the compiler must know it: the unit a wave works on — its segment descriptor, row numbers, pointers — then lives
+    // in SGPRs instead of every lane's VGPRs (two-format launch: 128 VGPRs + 20 bytes of scratch -> 120 and none; a launch with a
+    // scratch frame pays for it at every dispatch)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef typename T::act act;            // Q8_K blocks for the K-quants, Q8_0 blocks (8 per 256-value chunk) for Q8_0 weights
     constexpr int BPC = 256 / T::BLK;
     const int nchk = a.K / 256, nblk = nchk * BPC;
