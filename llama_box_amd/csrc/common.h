@@ -76,6 +76,7 @@ struct options {
     bool fa_self_merge = false; // split attention (decode): the last split workgroup merges the partial records, no combine launch.  Off: measured
                                // one token, n_kv 2100: 16.5 us against 7.6 + 5.0 for split + combine (record write-through, counter and re-read are a longer
                                // dependent chain than a launch); -np 32: 18.3 against 19.6 us per layer (4.45 vs 4.49 ms per step)
+    bool attn_nf = true;       // -np decode steps on the non-flash path: K.q -> SOFT_MAX -> V^T.p as one launch over the tokens' visible-cell lists (attn_nf.hip)
     bool softmax_mm = true;    // decode on the non-flash path: SOFT_MAX folded into the V^T.p product that reads it (mmf.hip)
     bool skinny_rope = true;   // -np decode steps: ROPE(q), ROPE(k) and both KV-cache stores in the epilogue of the skinny QKV launch(es)
     bool mmq_skinny = true;    // 2..32 columns: weight-streaming matrix-core kernel (mmq_skinny.hip) instead of the tiled GEMM

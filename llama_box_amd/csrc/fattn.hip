@@ -863,6 +863,8 @@ template <int D, int G> static void launch_fa(hipStream_t s, const tdesc & q, co
 // ---- position lists: for every query token, the cache cells at which its mask row holds anything but -inf, in ascending order;
 // lists[t * stride] = count, entries follow (stride = n_kv + 1).  One workgroup per token, four cells per thread and pass,
 // ordered compaction by a wave prefix sum over the per-thread counts.
+// (M32: an f32 mask — what llama.cpp builds when flash attention is off; rows 16-byte aligned)
+template <bool M32>
 __global__ void __launch_bounds__(256) k_fattn_pos_scan(const tdesc mask, const int n_kv, int * __restrict__ lists, const int stride) {
     __shared__ int wcnt[4];
     const int tok = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -871,9 +873,17 @@ __global__ void __launch_bounds__(256) k_fattn_pos_scan(const tdesc mask, const 
     int base = 0;
     for (int c0 = 0; c0 < n_kv; c0 += 1024) {
         const int pp = c0 + 4 * tid;
-        uint2 w = make_uint2(0xFC00FC00u, 0xFC00FC00u);
-        if (pp < n_kv) w = *(const uint2 *) (mrow + pp);  // n_kv is a multiple of 4 (checked by fattn_list_tile): the four cells are in range together
-        const bool v0 = (w.x & 0xFFFFu) != 0xFC00u, v1 = (w.x >> 16) != 0xFC00u, v2 = (w.y & 0xFFFFu) != 0xFC00u, v3 = (w.y >> 16) != 0xFC00u;
+        bool v0 = false, v1 = false, v2 = false, v3 = false;
+        if (M32) {
+            if (pp < n_kv) {
+                const uint4 w = *(const uint4 *) ((const float *) mrow + pp);
+                v0 = w.x != 0xFF800000u; v1 = w.y != 0xFF800000u; v2 = w.z != 0xFF800000u; v3 = w.w != 0xFF800000u;
+            }
+        } else {
+            uint2 w = make_uint2(0xFC00FC00u, 0xFC00FC00u);
+            if (pp < n_kv) w = *(const uint2 *) (mrow + pp);  // n_kv is a multiple of 4 (checked by fattn_list_tile): the four cells are in range together
+            v0 = (w.x & 0xFFFFu) != 0xFC00u; v1 = (w.x >> 16) != 0xFC00u; v2 = (w.y & 0xFFFFu) != 0xFC00u; v3 = (w.y >> 16) != 0xFC00u;
+        }
         const int mine = (int) v0 + (int) v1 + (int) v2 + (int) v3;
         int incl = mine;  // inclusive prefix sum over the wave
 #pragma unroll
@@ -912,7 +922,8 @@ int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const 
 }
 void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, int tile, int * lists) {
     (void) tile;
-    hipLaunchKernelGGL(k_fattn_pos_scan, dim3((unsigned) n_q), dim3(256), 0, s, mask, n_kv, lists, n_kv + 1);
+    if (mask.type == GGML_TYPE_F32) hipLaunchKernelGGL(k_fattn_pos_scan<true>, dim3((unsigned) n_q), dim3(256), 0, s, mask, n_kv, lists, n_kv + 1);
+    else hipLaunchKernelGGL(k_fattn_pos_scan<false>, dim3((unsigned) n_q), dim3(256), 0, s, mask, n_kv, lists, n_kv + 1);
 }
 
 // will launch_flash_attn end in the quantising combine pass for these arguments? (mirrors its dispatch)

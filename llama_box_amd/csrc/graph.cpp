@@ -154,6 +154,7 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             if (Mc >= c->opt.mmq_min_cols && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, 3 * mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc, c->opt.mmq_skinny));  // (x3: up to three sibling matrices share a launch)
         } else if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_F16) {
             p.aux_bytes = std::max(p.aux_bytes, mul_mat_f_workspace_bytes(TD(n->src[0]), TD(n->src[1])));
+            if (c->opt.attn_nf) p.aux_bytes = std::max(p.aux_bytes, attn_nf_list_scratch_bytes(TD(n->src[1]), TD(n->src[0]), nullptr));
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
             const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k));
@@ -1091,6 +1092,62 @@ static void flush_deferred_splitk(exec_state & st) {
 }
 
 // executes node i (possibly fusing followers); returns number of nodes consumed, or -1 on failure
+// ------------------------------------------------------------------------------------------------ non-flash attention of a small batch
+// kq = MUL_MAT(K view, q) -> SOFT_MAX(kq, mask, scale) -> MUL_MAT(V^T view, p) for 2..32 tokens (llama-box's default path, -fa off, in a
+// `-np` decode step): one launch over the tokens' lists of visible cells (attn_nf.hip) instead of three dense ones.  At node i = kq.
+static bool try_fuse_attn_nf(exec_state & st, int i) {
+    backend_ctx * c = st.c;
+    ggml_cgraph * g = st.g;
+    const ggml_tensor * kq = g->nodes[i];
+    const ggml_tensor * K = kq->src[0], * Q = kq->src[1];
+    if (!c->fa_lists || K->type != GGML_TYPE_F16 || Q->type != GGML_TYPE_F32 || Q->ne[1] < 2 || Q->ne[1] > 32 || !single_use(st, kq)) return false;
+    if (buffer_is_split(K->buffer)) return false;
+    auto next_real = [&](int from) {
+        for (int k = from; k < std::min(g->n_nodes, from + 6); ++k) {
+            if (st.done[k] || is_view_op(g->nodes[k])) continue;
+            return k;
+        }
+        return -1;
+    };
+    const int js = next_real(i + 1);
+    if (js < 0) return false;
+    const ggml_tensor * sm = g->nodes[js];
+    if (sm->op != GGML_OP_SOFT_MAX || sm->src[0] != kq || !sm->src[1] || sm->src[2] || ggml_abi_op_param_f32(sm, 1) != 0.0f || !single_use(st, sm)) return false;
+    const int jv = next_real(js + 1);
+    if (jv < 0) return false;
+    const ggml_tensor * kqv = g->nodes[jv];
+    if (kqv->op != GGML_OP_MUL_MAT || kqv->src[1] != sm || kqv->src[0]->type != GGML_TYPE_F16 || kqv->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(kqv)) return false;
+    const ggml_tensor * V = kqv->src[0], * M = sm->src[1];
+    if (buffer_is_split(V->buffer)) return false;
+    // the position lists come from the mask (fattn.hip: k_fattn_pos_scan reads four cells per thread); llama.cpp's mask is f32 when flash
+    // attention is off
+    const int malign = M->type == GGML_TYPE_F32 ? 16 : 8;
+    if ((M->type != GGML_TYPE_F16 && M->type != GGML_TYPE_F32) || (K->ne[1] % 4) != 0 || (M->nb[1] % malign) != 0 || ((uintptr_t) M->data & (malign - 1)) != 0 ||
+        M->ne[0] < K->ne[1] || M->ne[1] < Q->ne[1] || M->ne[2] != 1 || M->ne[3] != 1)
+        return false;
+    if ((size_t) (Q->ne[1] * (K->ne[1] + 1)) * sizeof(int) > c->fa_lists_bytes) return false;
+    // workgroups store rows of the result while others still read q: the result's block must not be q's recycled one
+    if (ranges_overlap(kqv, Q)) return false;
+    const tdesc qd = TD(Q), kd = TD(K), vd = TD(V), md = TD(M);
+    float * scratch = c->ws ? (float *) ((char *) c->ws + st.aux_off) : nullptr;
+    const size_t scratch_bytes = c->ws ? c->ws_size - st.aux_off : 0;
+    const size_t need = attn_nf_list_scratch_bytes(qd, kd, nullptr);
+    if (need == 0 || need > scratch_bytes) return false;
+    if (st.fa_list_mask != M->data || st.fa_list_tile != 1) {  // first attention of this graph run: list every token's visible cells
+        launch_fattn_tile_scan(c->stream, md, (int) Q->ne[1], (int) K->ne[1], 1, c->fa_lists);
+        c->st.kernel_launches++;
+        st.fa_list_mask = M->data;
+        st.fa_list_tile = 1;
+    }
+    timed_scope ts(c, "attn_nf_list", (double) ggml_abi_nbytes(kqv));
+    if (!launch_attn_nf_list(c->stream, qd, kd, vd, md, TD(kqv), c->fa_lists, (int) K->ne[1] + 1, scratch, scratch_bytes, ggml_abi_op_param_f32(sm, 0))) return false;
+    c->st.kernel_launches++;
+    mark_done(st, js);
+    mark_done(st, jv);
+    c->st.fused_nodes += 2;
+    return true;
+}
+
 static int run_node(exec_state & st, int i) {
     backend_ctx * c = st.c;
     ggml_cgraph * g = st.g;
@@ -1147,6 +1204,7 @@ static int run_node(exec_state & st, int i) {
         }
 
         case GGML_OP_MUL_MAT: {
+            if (!is_quant(a->type) && fuse && c->opt.attn_nf && try_fuse_attn_nf(st, i)) return 1;
             if (!is_quant(a->type)) {
                 timed_scope ts(c, "mul_mat_f", (double) ggml_abi_nbytes(a));
                 launch_mul_mat_f(s, TD(a), TD(b), TD(n), (float *) ((char *) c->ws + st.aux_off), c->ws ? c->ws_size - st.aux_off : 0);

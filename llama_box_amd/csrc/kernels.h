@@ -104,6 +104,10 @@ void launch_qkv(hipStream_t s, const qkv_args & a, int type_a, int type_b);
 // src1 rounded to f16 first when src0 is f16 (ggml-cpu vec_dot_type semantics)
 void launch_mul_mat_f(hipStream_t s, const tdesc & src0, const tdesc & src1, const tdesc & dst, float * ws = nullptr, size_t ws_bytes = 0);  // ws: scratch for K-split partial tiles
 size_t mul_mat_f_workspace_bytes(const tdesc & src0, const tdesc & src1);
+// ---- non-flash attention chain of a small batch over position lists (attn_nf.hip)
+size_t attn_nf_list_scratch_bytes(const tdesc & q, const tdesc & k, int * dq_out);
+bool launch_attn_nf_list(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc & mask, const tdesc & dst, const int * lists, int list_stride,
+                         float * scratch, size_t scratch_bytes, float scale);
 bool launch_soft_max_mul_mat_f16(hipStream_t s, const tdesc & a, const tdesc & kq, const tdesc * mask, const tdesc & d, float scale);  // decode: SOFT_MAX folded into V^T.p (mmf.hip)
 
 // ---- prefill: quantised weights x many columns through MFMA (mmq.hip)
