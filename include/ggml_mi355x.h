@@ -70,7 +70,7 @@ typedef ggml_backend_buffer_type_t (*ggml_backend_mi355x_tp_rowpar_buffer_type_t
 
 /* Runtime options (string key/value); 0 = accepted, -1 = unknown key.  Keys (INTEGRATION.md 4b lists the defaults and the
  * environment variables that set the same things): "graphs", "fusion", "prologue", "qkv", "mm_merge", "mmq_i8", "mmq_bn",
- * "mmq_skinny", "skinny_rope", "softmax_mm", "mmq_min_cols", "mmvq_max_cols", "fa_splits", "fa_wo", "fa_self_merge", "small_uploads", "timing". */
+ * "mmq_skinny", "skinny_rope", "softmax_mm", "attn_nf", "mmq_min_cols", "mmvq_max_cols", "fa_splits", "fa_wo", "fa_self_merge", "small_uploads", "timing". */
 typedef int (*ggml_backend_mi355x_set_option_t)(ggml_backend_t backend, const char * key, const char * value);
 /* Counters for tests/bench: "graph_launches", "graph_captures", "eager_graphs", "kernel_launches", "fused_nodes", "allreduces",
  * "graph_launch_host_ns", "skinny_launches", "wide_launches", "rope_epilogues". */

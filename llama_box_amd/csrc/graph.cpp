@@ -1129,6 +1129,26 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
     // workgroups store rows of the result while others still read q: the result's block must not be q's recycled one
     if (ranges_overlap(kqv, Q)) return false;
     const tdesc qd = TD(Q), kd = TD(K), vd = TD(V), md = TD(M);
+    // llm_build_* continues with CONT(PERMUTE(kqv, 0, 2, 1, 3)) -> [D * NH, T]: when that copy is the result's only reader, the rows go
+    // straight to its memory in that order (one launch less)
+    tdesc od = TD(kqv);
+    int jc = -1;
+    if (single_use(st, kqv)) {
+        const int jn = next_real(jv + 1);
+        if (jn >= 0) {
+            const ggml_tensor * ct = g->nodes[jn];
+            const ggml_tensor * pv = ct->src[0];
+            if (ct->op == GGML_OP_CONT && pv && pv->op == GGML_OP_PERMUTE && pv->src[0] == kqv && pv->data == kqv->data && ct->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(ct) &&
+                pv->ne[0] == kqv->ne[0] && pv->ne[1] == kqv->ne[2] && pv->ne[2] == kqv->ne[1] && pv->ne[3] == 1 && ggml_abi_nelements(ct) == ggml_abi_nelements(kqv) &&
+                !ranges_overlap(ct, Q) && !ranges_overlap(ct, kqv)) {
+                jc = jn;
+                od.data = (char *) ct->data;
+                od.nb[0] = 4;
+                od.nb[1] = (int64_t) kqv->ne[0] * kqv->ne[2] * 4;  // token
+                od.nb[2] = (int64_t) kqv->ne[0] * 4;               // head
+            }
+        }
+    }
     float * scratch = c->ws ? (float *) ((char *) c->ws + st.aux_off) : nullptr;
     const size_t scratch_bytes = c->ws ? c->ws_size - st.aux_off : 0;
     const size_t need = attn_nf_list_scratch_bytes(qd, kd, nullptr);
@@ -1140,11 +1160,15 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
         st.fa_list_tile = 1;
     }
     timed_scope ts(c, "attn_nf_list", (double) ggml_abi_nbytes(kqv));
-    if (!launch_attn_nf_list(c->stream, qd, kd, vd, md, TD(kqv), c->fa_lists, (int) K->ne[1] + 1, scratch, scratch_bytes, ggml_abi_op_param_f32(sm, 0))) return false;
+    if (!launch_attn_nf_list(c->stream, qd, kd, vd, md, od, c->fa_lists, (int) K->ne[1] + 1, scratch, scratch_bytes, ggml_abi_op_param_f32(sm, 0))) return false;
     c->st.kernel_launches++;
     mark_done(st, js);
     mark_done(st, jv);
     c->st.fused_nodes += 2;
+    if (jc >= 0) {
+        mark_done(st, jc);
+        c->st.fused_nodes++;
+    }
     return true;
 }
 
