@@ -15,6 +15,7 @@
 // A workgroup is (token, KV head, slice of the head dimensions); slices exist so that a handful of tokens still fill the chip, and
 // each repeats steps 1-2 for itself (cheap next to step 3).  Sums run in another order than the dense kernels' (and the CPU's).
 #include <algorithm>
+#include <type_traits>
 
 #include "dev_util.h"
 #include "kernels.h"
@@ -134,7 +135,8 @@ __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc
         // 3. V^T.p: lanes take cells (4 per lane and group of 256), a wave takes RB rows of the transposed cache at a time — all RB x 4 two-byte
         // loads of a block are requested before the first is used (one row pair at a time, each trip waited for its own loads: 16 round
         // trips per wave were 30 of the launch's 52 us)
-        constexpr int RB = G <= 4 ? 16 : 8;
+        auto vtp = [&](auto rb_tag) {
+        constexpr int RB = decltype(rb_tag)::value;
         for (int r0 = wave * RB; r0 < rows_per; r0 += 4 * RB) {
             float acc[RB][G];
 #pragma unroll
@@ -177,6 +179,11 @@ __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc
                     if (lane == 0 && r0 + r < rows_per) *out_ptr(g, d0 + r0 + r) = t;
                 }
         }
+        };
+        // rows per wave and block: as many as keep all four waves busy with this workgroup's slice of the head dimensions
+        if (G <= 4 && rows_per >= 64) vtp(std::integral_constant<int, 16>{});
+        else if (rows_per >= 32) vtp(std::integral_constant<int, 8>{});
+        else vtp(std::integral_constant<int, 4>{});
         return;
     }
     // ---- longer lists (a token that sees thousands of cells): the same three steps through scratch memory
