@@ -1126,9 +1126,9 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
         M->ne[0] < K->ne[1] || M->ne[1] < Q->ne[1] || M->ne[2] != 1 || M->ne[3] != 1)
         return false;
     if ((size_t) (Q->ne[1] * (K->ne[1] + 1)) * sizeof(int) > c->fa_lists_bytes) return false;
-    // workgroups store rows of the result while others still read q: the result's block must not be q's recycled one
-    if (ranges_overlap(kqv, Q)) return false;
     const tdesc qd = TD(Q), kd = TD(K), vd = TD(V), md = TD(M);
+    int dq_n = 1;
+    (void) attn_nf_list_scratch_bytes(qd, kd, &dq_n);
     // llm_build_* continues with CONT(PERMUTE(kqv, 0, 2, 1, 3)) -> [D * NH, T]: when that copy is the result's only reader, the rows go
     // straight to its memory in that order (one launch less)
     tdesc od = TD(kqv);
@@ -1139,16 +1139,24 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
             const ggml_tensor * ct = g->nodes[jn];
             const ggml_tensor * pv = ct->src[0];
             if (ct->op == GGML_OP_CONT && pv && pv->op == GGML_OP_PERMUTE && pv->src[0] == kqv && pv->data == kqv->data && ct->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(ct) &&
-                pv->ne[0] == kqv->ne[0] && pv->ne[1] == kqv->ne[2] && pv->ne[2] == kqv->ne[1] && pv->ne[3] == 1 && ggml_abi_nelements(ct) == ggml_abi_nelements(kqv) &&
-                !ranges_overlap(ct, Q) && !ranges_overlap(ct, kqv)) {
-                jc = jn;
-                od.data = (char *) ct->data;
-                od.nb[0] = 4;
-                od.nb[1] = (int64_t) kqv->ne[0] * kqv->ne[2] * 4;  // token
-                od.nb[2] = (int64_t) kqv->ne[0] * 4;               // head
+                pv->ne[0] == kqv->ne[0] && pv->ne[1] == kqv->ne[2] && pv->ne[2] == kqv->ne[1] && pv->ne[3] == 1 && ggml_abi_nelements(ct) == ggml_abi_nelements(kqv)) {
+                const int64_t tok_nb = (int64_t) kqv->ne[0] * kqv->ne[2] * 4, head_nb = (int64_t) kqv->ne[0] * 4;
+                // The copy's block is usually q's recycled one (same size, q dies at K.q).  That is safe exactly when it is the SAME rows:
+                // a workgroup (token, KV head) then overwrites only the q rows it alone reads, after it has read them — which needs one
+                // workgroup per (token, KV head), i.e. no slices of the head dimensions.
+                const bool same_rows = ct->data == Q->data && Q->nb[0] == 4 && (int64_t) Q->nb[1] == tok_nb && (int64_t) Q->nb[2] == head_nb && dq_n == 1;
+                if (!ranges_overlap(ct, Q) || same_rows) {
+                    jc = jn;
+                    od.data = (char *) ct->data;
+                    od.nb[0] = 4;
+                    od.nb[1] = tok_nb;
+                    od.nb[2] = head_nb;
+                }
             }
         }
     }
+    // workgroups store rows of the result while others still read q: written to its own tensor, the result must not sit in q's recycled block
+    if (jc < 0 && ranges_overlap(kqv, Q)) return false;
     float * scratch = c->ws ? (float *) ((char *) c->ws + st.aux_off) : nullptr;
     const size_t scratch_bytes = c->ws ? c->ws_size - st.aux_off : 0;
     const size_t need = attn_nf_list_scratch_bytes(qd, kd, nullptr);
