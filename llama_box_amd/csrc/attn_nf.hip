@@ -281,6 +281,11 @@ size_t attn_nf_list_scratch_bytes(const tdesc & q, const tdesc & k, int * dq_out
     if (T < 2 || T > 32 || NKV <= 0 || NH % NKV != 0 || q.ne[3] != 1 || k.ne[3] != 1 || k.ne[0] != 128 || q.ne[0] != 128) return 0;
     const int64_t G = NH / NKV;
     if (G < 1 || G > 8) return 0;
+    // The lists live on the device, so the host cannot know how many cells a token sees; it knows the average.  Tokens beyond NF_CAP cells
+    // take the scratch-memory path of the kernel, which is correct but slow (one dependent load pair per trip): the chain is only fused
+    // when the cache holds at most NF_CAP cells per token of the batch — the decode steps of many sequences — and a few tokens over
+    // long contexts stay on the dense kernels.
+    if (n_kv > (int64_t) NF_CAP * T) return 0;
     int dq = 1;
     while (dq < 8 && T * NKV * dq < 192) dq *= 2;  // slices of the head dimensions: enough workgroups for the chip when the tokens are few
     if (dq_out) *dq_out = dq;
