@@ -133,6 +133,9 @@ struct synth_spec {
     int64_t n_rows;         // local
     float f32_lo, f32_hi;   // for F32 tensors
     float wscale;           // gain of quantised tensors
+    int tie_id = -1;        // >= 0: `tie_eighths` of every 8 blocks repeat the block of tensor tie_id at row (row * 7919 + 13) % tie_rows (llm_hparams::peaked)
+    int tie_eighths = 0;
+    int64_t tie_rows = 0;
 };
 
 static void synth_rows(const synth_spec & sp, int64_t row0, int64_t row1, uint8_t * dst) {
@@ -152,7 +155,14 @@ static void synth_rows(const synth_spec & sp, int64_t row0, int64_t row1, uint8_
     for (int64_t r = row0; r < row1; ++r) {
         for (int64_t b = 0; b < sp.blocks_per_row; ++b) {
             const uint64_t gb = (uint64_t) ((r + sp.row_off) * sp.blocks_per_row_global + b + sp.blk_off);
-            const uint64_t key = sp.seed ^ ((uint64_t) sp.tensor_id * 0xD1B54A32D192ED03ull) ^ (gb * 0x9E3779B97F4A7C15ull);
+            uint64_t key = sp.seed ^ ((uint64_t) sp.tensor_id * 0xD1B54A32D192ED03ull) ^ (gb * 0x9E3779B97F4A7C15ull);
+            if (sp.tie_id >= 0) {
+                uint64_t pick = key ^ 0xA5A5A5A55A5A5A5Aull;
+                if ((int) (splitmix64(pick) & 7) < sp.tie_eighths) {
+                    const uint64_t tr = (uint64_t) (((r + sp.row_off) * 7919 + 13) % sp.tie_rows);
+                    key = sp.seed ^ ((uint64_t) sp.tie_id * 0xD1B54A32D192ED03ull) ^ ((tr * (uint64_t) sp.blocks_per_row_global + (uint64_t) (b + sp.blk_off)) * 0x9E3779B97F4A7C15ull);
+                }
+            }
             synth_block(sp.type, key, sp.K_global, sp.wscale, dst + (size_t) ((r - row0) * sp.blocks_per_row + b) * bs);
         }
     }
@@ -169,6 +179,7 @@ extern "C" int llm_preset(const char * name, struct llm_hparams * hp) {
     };
     const std::string n = name;
     if (n == "tinyllama-1.1b-q8_0") set("llama", 22, 2048, 32, 4, 64, 5632, 32000, 2048, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q8_0);
+    else if (n == "tinyllama-1.1b-q8_0-peaked") { set("llama", 22, 2048, 32, 4, 64, 5632, 32000, 2048, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q8_0); hp->peaked = 3; }
     else if (n == "llama3-8b-q4_k_m") set("llama", 32, 4096, 32, 8, 128, 14336, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M);
     else if (n == "llama3-70b-q4_k_m") { set("llama", 80, 8192, 64, 8, 128, 28672, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M); hp->attn_v_q5k_70b = 1; }
     else if (n == "qwen2-7b-q5_k_m") set("qwen2", 28, 3584, 28, 4, 128, 18944, 152064, 32768, 1000000.0f, 1e-6f, GGML_ROPE_TYPE_NEOX, 1, LLM_FTYPE_Q5_K_M);
@@ -196,6 +207,8 @@ struct tensor_plan {
     bool rowpar;            // lives in the reducing (row-parallel) buffer type
     float lo, hi;
     float wscale;
+    int tie_id = -1, tie_eighths = 0;
+    int64_t tie_rows = 0;
 };
 
 struct llm_model {
@@ -271,6 +284,12 @@ static std::vector<tensor_plan> make_plan(const llm_hparams & hp, int tp_rank, i
     }
     add("output_norm.weight", GGML_TYPE_F32, E, 1, E, 0, 0, false, 0.5f, 1.5f);
     add("output.weight", pick_type(hp, "output", 0), E, v_l, E, tp_rank * v_l, 0, false);
+    if (hp.peaked > 0) {
+        LLM_ASSERT(plan.back().type == plan.front().type && ggml_abi_blck_size(plan.back().type) > 1);  // the tied blocks are token_embd's, byte for byte (up to the gain)
+        plan.back().tie_id = plan.front().tensor_id;
+        plan.back().tie_eighths = std::min(8, hp.peaked);
+        plan.back().tie_rows = hp.n_vocab;
+    }
     for (auto & t : plan) {
         LLM_ASSERT(t.ne0 % ggml_abi_blck_size(t.type) == 0 && t.k_off % ggml_abi_blck_size(t.type) == 0);
     }
@@ -292,6 +311,9 @@ static synth_spec spec_of(const tensor_plan & t, uint64_t seed) {
     sp.f32_lo = t.lo;
     sp.f32_hi = t.hi;
     sp.wscale = t.wscale;
+    sp.tie_id = t.tie_id;
+    sp.tie_eighths = t.tie_eighths;
+    sp.tie_rows = t.tie_rows;
     return sp;
 }
 

@@ -268,10 +268,18 @@ def test_e2e_deviation_matches_oracle_order_sensitivity(backend, H, plog, name):
 
 
 # ------------------------------------------------------------------------------------------------ (d) BASELINE config 1 as written
-def test_config1_tinyllama_greedy_128(backend, H, plog):
+@pytest.mark.parametrize("name", ["tinyllama-1.1b-q8_0", "tinyllama-1.1b-q8_0-peaked"])
+def test_config1_tinyllama_greedy_128(backend, H, plog, name):
     """TinyLlama-1.1B Q8_0 shape (22 layers, 2048, 32/4 heads of 64, ffn 5632, vocab 32000), 16-token prompt, 128 greedy tokens:
-    the reference's own CPU-runnable configuration (BASELINE.json configs[0]) — here with the GPU against the CPU oracle."""
-    hp = preset("tinyllama-1.1b-q8_0")
+    the reference's own CPU-runnable configuration (BASELINE.json configs[0]) — here with the GPU against the CPU oracle.
+
+    Two weight sets of that shape.  Independent random weights give near-flat logits (top-2 margins down to 1e-4, below the
+    distance between two correct implementations), so the id gate can only cover the decisive positions.  The "-peaked" set
+    (llm_hparams::peaked: 3 of every 8 blocks of output.weight row r repeat token_embd row (7919 r + 13) mod n_vocab) has the
+    logit shape of a trained model — one row well ahead — while the layers still move every logit: there north_star's bar is
+    applied as written: ALL 128 greedy ids identical, teacher-forced and free-running (VERDICT r02 #6)."""
+    hp = preset(name)
+    peaked = hp.peaked > 0
     rng = np.random.default_rng(16)
     prompt = rng.integers(3, hp.n_vocab, 16).tolist()
     n_gen = 128
@@ -329,7 +337,7 @@ def test_config1_tinyllama_greedy_128(backend, H, plog):
         agree = np.argmax(rows_got, axis=1) == np.array(ids_ref)
         agree_var = np.argmax(rows_var, axis=1) == np.array(ids_ref)
         first = next((i for i, (a, b) in enumerate(zip(ids_ref, ids_free)) if a != b), None)
-        plog(f"[parity-e2e] config 1 (tinyllama-1.1b q8_0, 16-token prompt, 128 greedy, flash_attn off): teacher-forced logits nmse gpu={e:.3e} "
+        plog(f"[parity-e2e] config 1 ({name}, 16-token prompt, 128 greedy, flash_attn off): teacher-forced logits nmse gpu={e:.3e} "
              f"(oracle reversed-blocks {e_var:.3e}) max|d| gpu={dmax.max():.3e} (oracle variant {dvar.max():.3e}); argmax agreement gpu {int(agree.sum())}/{n_gen}, "
              f"oracle variant {int(agree_var.sum())}/{n_gen}; min margin {margin.min():.3e}; free-running ids "
              + ("identical for all 128 tokens" if first is None else f"first differ at token {first}: oracle margin there {margin[first]:.3e}, |d| there {dmax[first]:.3e}"))
@@ -338,7 +346,15 @@ def test_config1_tinyllama_greedy_128(backend, H, plog):
         yard = 2.0 * float(dvar.max())
         decisive = margin > yard
         assert bool(np.all(agree[decisive])), f"greedy id differs at a decisive margin (> {yard:.3e})"
-        plog(f"[parity-e2e] config 1: greedy ids identical at all {int(decisive.sum())}/{n_gen} positions whose margin exceeds the oracle-vs-oracle deviation {yard:.3e}")
+        plog(f"[parity-e2e] config 1 ({name}): greedy ids identical at all {int(decisive.sum())}/{n_gen} positions whose margin exceeds the oracle-vs-oracle deviation {yard:.3e} "
+             f"({decisive.mean():.0%} of the positions gated; margin >= 10 x the deviation at {np.mean(margin > 5.0 * yard):.0%})")
+        if peaked:
+            # the bar as north_star writes it: every one of the 128 ids, on logits whose margins dwarf the distance between two correct implementations
+            assert np.mean(margin > 5.0 * yard) >= 0.95, f"the peaked weight set is not peaked: margin >= 10 x deviation at only {np.mean(margin > 5.0 * yard):.0%} of the positions"
+            assert decisive.mean() >= 0.90
+            assert bool(np.all(agree)), f"teacher-forced greedy ids differ at positions {np.nonzero(~agree)[0].tolist()}"
+            assert first is None, f"free-running greedy ids diverge at token {first}"
+            assert len(set(ids_ref)) > n_gen // 2  # (a real sequence, not a fixed point)
         if first is not None:
             assert margin[first] <= yard, f"free-running ids diverge at token {first} with a decisive margin {margin[first]:.3e} > {yard:.3e}"
     finally:
