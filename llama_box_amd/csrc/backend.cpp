@@ -6,7 +6,10 @@
 // overlap), buffers are plain hipMalloc arenas sized for 288 GB parts, repeated graphs are replayed as hipGraphs.
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 #include "kernels.h"
@@ -59,9 +62,11 @@ ggml_backend_buffer_t make_backend_buffer(ggml_backend_buffer_type_t buft, const
     return new ggml_backend_buffer{iface, buft, context, size, GGML_BACKEND_BUFFER_USAGE_ANY};
 }
 
+static void uploader_drain(int device);
 static void buf_free(ggml_backend_buffer_t b) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     HIP_CHECK(hipSetDevice(c->device));
+    uploader_drain(c->device);  // a staged upload may still be writing into this arena
     HIP_CHECK(hipFree(c->base));
     delete c;
 }
@@ -70,17 +75,144 @@ static enum ggml_status buf_init_tensor(ggml_backend_buffer_t, ggml_tensor *) { 
 static void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t value, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     HIP_CHECK(hipSetDevice(c->device));
+    uploader_drain(c->device);
     HIP_CHECK(hipMemset((char *) t->data + offset, value, size));
     HIP_CHECK(hipDeviceSynchronize());
 }
+// ---- the loader's fast path: set_tensor of a weight
+// llama.cpp's loader calls buffer.set_tensor once per tensor with pageable memory (the mmap'd GGUF, or a read buffer with --no-mmap:
+// /root/reference/llama-box/engine_param.hpp:403); 42 GB for the 70B model.  A hipMemcpy from pageable memory is staged by the runtime
+// through its own bounce buffer on the calling thread, copy and DMA taking turns.  Here uploads above 1 MiB go through a per-device
+// engine: a ring of pinned slots, the host copy into a slot spread over a few threads, hipMemcpyAsync out of the slot on a dedicated
+// stream — the DMA of slot i overlaps the host copy of slot i+1, ACROSS set_tensor calls too: the call returns once its bytes sit in
+// pinned memory (the caller may reuse `data`), the last DMAs still in flight.  Everything else that can observe the device memory
+// waits for the engine first: the buffer vtable through uploader_drain(), a backend's stream through an event (uploader_join()).
+// No repack: the bytes land verbatim.  Any failure inside falls back to the plain synchronous copy.
+struct uploader {
+    int device = -1;
+    bool failed = false;
+    hipStream_t stream = nullptr;
+    static constexpr int NSLOT = 3;
+    char * slot[NSLOT] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr};
+    bool busy[NSLOT] = {false, false, false};
+    size_t slot_bytes = 0;
+    int next = 0;
+    hipEvent_t last = nullptr;  // recorded behind the newest DMA
+    bool in_flight = false;
+    int n_threads = 1;
+    std::mutex mtx;  // set_tensor may come from several host threads (RPC connections share the backend: SURVEY.md §8b "Threading")
+    uint64_t bytes = 0;
+    double seconds = 0;
+};
+static uploader g_uploaders[GGML_MI355X_MAX_DEVICES];
+
+static void par_memcpy(char * dst, const char * src, size_t n, int n_threads) {
+    if (n_threads <= 1 || n < ((size_t) 4 << 20)) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((n / (size_t) n_threads) + 4095) & ~(size_t) 4095;
+    for (int t = 1; t < n_threads; ++t) {
+        const size_t o = (size_t) t * per;
+        if (o >= n) break;
+        th.emplace_back([=] { memcpy(dst + o, src + o, std::min(per, n - o)); });
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (auto & x : th) x.join();
+}
+static uploader * uploader_for(int device) {
+    if (device < 0 || device >= GGML_MI355X_MAX_DEVICES) return nullptr;
+    uploader * u = &g_uploaders[device];
+    if (u->failed) return nullptr;
+    if (u->device == device) return u;
+    static const int enabled = [] { const char * e = getenv("GGML_MI355X_STAGED_UPLOAD"); return e ? atoi(e) : 1; }();
+    if (!enabled) { u->failed = true; return nullptr; }
+    const char * e_mb = getenv("GGML_MI355X_UPLOAD_SLOT_MIB");
+    const char * e_th = getenv("GGML_MI355X_UPLOAD_THREADS");
+    u->slot_bytes = (size_t) std::max(1, e_mb ? atoi(e_mb) : 32) << 20;
+    u->n_threads = std::max(1, std::min(16, e_th ? atoi(e_th) : 4));
+    bool ok = hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&u->last, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < uploader::NSLOT && ok; ++i)
+        ok = hipHostMalloc((void **) &u->slot[i], u->slot_bytes, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&u->ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {  // (pinned memory is a limited resource: the loader keeps working on the synchronous path)
+        (void) hipGetLastError();
+        MI_INFO("staged uploads unavailable on device %d (pinned allocation failed): set_tensor falls back to hipMemcpy", device);
+        for (int i = 0; i < uploader::NSLOT; ++i) {
+            if (u->slot[i]) (void) hipHostFree(u->slot[i]);
+            if (u->ev[i]) (void) hipEventDestroy(u->ev[i]);
+            u->slot[i] = nullptr;
+            u->ev[i] = nullptr;
+        }
+        if (u->last) (void) hipEventDestroy(u->last);
+        if (u->stream) (void) hipStreamDestroy(u->stream);
+        u->failed = true;
+        return nullptr;
+    }
+    u->device = device;
+    return u;
+}
+// host-side wait for every staged upload to this device (callers hold no lock)
+static void uploader_drain(int device) {
+    if (device < 0 || device >= GGML_MI355X_MAX_DEVICES) return;
+    uploader * u = &g_uploaders[device];
+    if (u->device != device) return;
+    std::lock_guard<std::mutex> lock(u->mtx);
+    if (!u->in_flight) return;
+    HIP_CHECK(hipStreamSynchronize(u->stream));
+    for (bool & b : u->busy) b = false;
+    u->in_flight = false;
+}
+// device-side: `s` (a backend's stream on this device) waits for the newest staged upload
+static void uploader_join(int device, hipStream_t s) {
+    if (device < 0 || device >= GGML_MI355X_MAX_DEVICES) return;
+    uploader * u = &g_uploaders[device];
+    if (u->device != device || !u->in_flight) return;
+    std::lock_guard<std::mutex> lock(u->mtx);
+    if (!u->in_flight) return;
+    if (hipEventQuery(u->last) == hipSuccess) {  // long done (every decode step passes here): nothing to wait for any more
+        for (bool & b : u->busy) b = false;
+        u->in_flight = false;
+        return;
+    }
+    (void) hipGetLastError();  // (hipErrorNotReady)
+    HIP_CHECK(hipStreamWaitEvent(s, u->last, 0));
+}
+static bool staged_upload(int device, char * dst, const char * src, size_t size) {
+    uploader * u = uploader_for(device);
+    if (!u) return false;
+    std::lock_guard<std::mutex> lock(u->mtx);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t o = 0; o < size; o += u->slot_bytes) {
+        const size_t n = std::min(u->slot_bytes, size - o);
+        const int k = u->next;
+        u->next = (k + 1) % uploader::NSLOT;
+        if (u->busy[k] && hipEventSynchronize(u->ev[k]) != hipSuccess) return false;
+        par_memcpy(u->slot[k], src + o, n, u->n_threads);
+        if (hipMemcpyAsync(dst + o, u->slot[k], n, hipMemcpyHostToDevice, u->stream) != hipSuccess || hipEventRecord(u->ev[k], u->stream) != hipSuccess) {
+            (void) hipGetLastError();
+            (void) hipStreamSynchronize(u->stream);
+            u->failed = true;  // the caller repeats the whole tensor on the synchronous path
+            return false;
+        }
+        u->busy[k] = true;
+        u->in_flight = true;
+    }
+    if (hipEventRecord(u->last, u->stream) != hipSuccess) { (void) hipGetLastError(); (void) hipStreamSynchronize(u->stream); }
+    u->bytes += size;
+    u->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
 static void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     HIP_CHECK(hipSetDevice(c->device));
+    if (size > ((size_t) 1 << 20) && staged_upload(c->device, (char *) t->data + offset, (const char *) data, size)) return;
+    uploader_drain(c->device);  // (keeps the writes of one tensor ordered: a small piece behind a staged one)
     HIP_CHECK(hipMemcpy((char *) t->data + offset, data, size, hipMemcpyHostToDevice));
 }
 static void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     HIP_CHECK(hipSetDevice(c->device));
+    uploader_drain(c->device);
     HIP_CHECK(hipMemcpy(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost));
 }
 static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst) {
@@ -89,6 +221,8 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggm
     buffer_ctx * sc = (buffer_ctx *) sb->context;
     buffer_ctx * dc = (buffer_ctx *) b->context;
     const size_t n = ggml_abi_nbytes(src);
+    uploader_drain(sc->device);
+    if (dc->device != sc->device) uploader_drain(dc->device);
     if (sc->device == dc->device) {
         HIP_CHECK(hipSetDevice(dc->device));
         HIP_CHECK(hipMemcpy(dst->data, src->data, n, hipMemcpyDeviceToDevice));
@@ -101,6 +235,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggm
 static void buf_clear(ggml_backend_buffer_t b, uint8_t value) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     HIP_CHECK(hipSetDevice(c->device));
+    uploader_drain(c->device);
     HIP_CHECK(hipMemset(c->base, value, c->size));
     HIP_CHECK(hipDeviceSynchronize());
 }
@@ -214,12 +349,14 @@ static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void *
         }
     }
     flush_uploads(c);
+    uploader_join(c->device, c->stream);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_tensor_async(ggml_backend_t be, const ggml_tensor * t, void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
     HIP_CHECK(hipSetDevice(c->device));
     flush_uploads(c);
+    uploader_join(c->device, c->stream);
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
 }
 static bool be_is_ours(ggml_backend_t be);
@@ -233,6 +370,8 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
     flush_uploads(cs);
     if (cd != cs) flush_uploads(cd);
     const size_t n = ggml_abi_nbytes(src);
+    uploader_join(cs->device, cs->stream);
+    if (cd->device != cs->device) uploader_drain(cd->device);
     if (cs->device == cd->device) {
         HIP_CHECK(hipSetDevice(cs->device));
         HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, cs->stream));
@@ -254,12 +393,14 @@ static void be_synchronize(ggml_backend_t be) {
     backend_ctx * c = (backend_ctx *) be->context;
     HIP_CHECK(hipSetDevice(c->device));
     flush_uploads(c);
+    uploader_drain(c->device);
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 static enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph * g) {
     backend_ctx * c = (backend_ctx *) be->context;
     if (hipSetDevice(c->device) != hipSuccess) return GGML_STATUS_FAILED;
     flush_uploads(c);
+    uploader_join(c->device, c->stream);  // weights staged by set_tensor are complete before the first kernel reads them
     return graph_compute(c, g);
 }
 static void be_event_record(ggml_backend_t be, ggml_backend_event_t ev) {
@@ -415,7 +556,11 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
     if (k == "skinny_launches") return c->st.skinny_launches;
     if (k == "wide_launches") return c->st.wide_launches;
+    if (k == "tiled_launches") return c->st.tiled_launches;
+    if (k == "shadow_launches") return c->st.shadow_launches;
     if (k == "rope_epilogues") return c->st.rope_epilogues;
+    if (k == "staged_upload_bytes") return (int64_t) g_uploaders[c->device].bytes;
+    if (k == "staged_upload_us") return (int64_t) (g_uploaders[c->device].seconds * 1e6);
     return -1;
 }
 static int api_timing_report(ggml_backend_t be, char * buf, size_t size, int reset) {

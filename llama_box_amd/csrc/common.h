@@ -35,6 +35,18 @@
         }                                                                                                       \
     } while (0)
 
+// inside graph execution a HIP failure must fail ONE llama_decode (GGML_STATUS_FAILED -> rc -2, llama-box/httpserver.hpp:3541-3545),
+// not the whole llama-box process: log, clear the sticky error, hand `ret` to the caller
+#define HIP_TRY(expr, ret)                                                                                      \
+    do {                                                                                                        \
+        hipError_t err_ = (expr);                                                                               \
+        if (err_ != hipSuccess) {                                                                               \
+            (void) hipGetLastError();                                                                           \
+            fprintf(stderr, "ggml-mi355x: HIP error %d (%s) at %s:%d: %s\n", (int) err_, hipGetErrorString(err_), __FILE__, __LINE__, #expr); \
+            return ret;                                                                                         \
+        }                                                                                                       \
+    } while (0)
+
 namespace mi355x {
 
 int log_level();
@@ -93,6 +105,8 @@ struct stats {
     int64_t graph_launches = 0, graph_captures = 0, eager_graphs = 0, kernel_launches = 0, fused_nodes = 0, allreduces = 0;
     int64_t skinny_launches = 0;       // mat-muls of 2..32 columns served by the weight-streaming matrix-core kernel
     int64_t wide_launches = 0;         // prompt-batch mat-muls served by its wide form
+    int64_t shadow_launches = 0;       // prompt-batch mat-muls served by the plain int8 GEMM over the pre-expanded shadow planes (mmq_shadow.hip)
+    int64_t tiled_launches = 0;        // batch mat-muls served by the LDS-tiled int8 GEMM (mmq_i8.hip)
     int64_t rope_epilogues = 0;        // batches whose rope + KV-cache stores rode in the skinny QKV launches
     int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)
 };
@@ -134,6 +148,7 @@ struct backend_ctx {
     tp_state * tp = nullptr;
     // -sm row: per owning device a stream / scratch / event for the slices of row-split weights (split.cpp), created on first use
     std::vector<split_helper *> split_helpers;
+    hipEvent_t split_ready = nullptr;  // "the activations of this split mat-mul exist on the main stream"
     // small host->device uploads (token ids, positions, cache indices, one mask row): staged in a pinned ring and moved by a
     // tiny kernel — a blit through hipMemcpyAsync costs ~25 us of stream time per copy, five of them per decode step
     char * up_ring = nullptr;

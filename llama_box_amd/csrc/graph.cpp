@@ -29,6 +29,13 @@ static bool same_shape(const ggml_tensor * a, const ggml_tensor * b) {
 bool supports_op(const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0];
     const ggml_tensor * b = op->src[1];
+    // A tensor in a row-split buffer (-sm row) has no dereferenceable ->data (split.cpp: its bytes are per-device slices behind a map), so
+    // the one op that may read it is a MUL_MAT taking it as src0.  llama.cpp's loader probes EVERY weight against the split buffer type
+    // first (weight_buft_supported builds MUL / ADD / ROPE / GET_ROWS probes with w->buffer set to a dummy split buffer): answering true
+    // there would put norm weights, biases, rope_freqs and token_embd behind the fake base address (as ggml-cuda refuses them).
+    for (int s = 0; s < GGML_MAX_SRC; ++s)
+        if (op->src[s] && buffer_is_split(op->src[s]->buffer) && !(op->op == GGML_OP_MUL_MAT && s == 0)) return false;
+    if (buffer_is_split(op->buffer)) return false;
     switch (op->op) {
         case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             return true;
@@ -396,6 +403,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
                                              add ? (const float *) add->data : nullptr, add_stride, !defer, c->opt.mmq_skinny, epi);
             c->st.skinny_launches += served == 1;
             c->st.wide_launches += served == 2;
+            c->st.tiled_launches += served == 0;
             if (defer) {
                 st.sk_dst = dst;
                 st.sk = splitk_src{part, ks, (int64_t) M * N, add ? (const float *) add->data : nullptr, add_stride, (float *) dst->data, (int64_t) (dst->nb[1] / 4)};
@@ -926,6 +934,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         const int served = launch_mmq_i8_multi(c->stream, type, (int) ms.size(), mats, (int) K, (int) M, act, c->opt.mmq_bn, ks, part, !defer, c->opt.mmq_skinny, epi_node >= 0 ? &epi : nullptr);
         c->st.skinny_launches += served == 1;
         c->st.wide_launches += served == 2;
+            c->st.tiled_launches += served == 0;
     }
     c->st.kernel_launches += (ks > 1 && !defer) ? 2 : 1;
     c->st.fused_nodes += ms[0].n_nodes - 1;
@@ -1190,6 +1199,11 @@ static int run_node(exec_state & st, int i) {
     const bool fuse = c->opt.fusion;
     auto next = [&](int k) -> ggml_tensor * { return i + k < g->n_nodes ? g->nodes[i + k] : nullptr; };
 
+    for (int sidx = 0; sidx < GGML_MAX_SRC; ++sidx)
+        if (n->src[sidx] && buffer_is_split(n->src[sidx]->buffer) && !(n->op == GGML_OP_MUL_MAT && sidx == 0)) {
+            MI_ERR("graph_compute: node %d '%s' (op %d) reads '%s' from a row-split buffer: only MUL_MAT weights may live there", i, n->name, (int) n->op, n->src[sidx]->name);
+            return -1;
+        }
     if (st.sk_dst && !is_view_op(n) && !(n->op == GGML_OP_RMS_NORM && a == st.sk_dst)) flush_deferred_splitk(st);
     if (st.rs_sk.node >= 0 && st.rs_sk.node != i && !is_view_op(n)) flush_deferred_qkv(st);
     switch (n->op) {

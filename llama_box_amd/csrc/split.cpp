@@ -74,6 +74,15 @@ static enum ggml_status sbuf_init_tensor(ggml_backend_buffer_t b, ggml_tensor * 
         MI_ERR("split buffer: tensor '%s' is a view / not a contiguous matrix", t->name);
         return GGML_STATUS_FAILED;
     }
+    auto old = c->tensors.find(t);
+    if (old != c->tensors.end()) {  // re-initialised (a host may call init_tensor again after a reset): the previous slices go first
+        for (int d = 0; d < old->second.n_dev; ++d)
+            if (old->second.slice[d]) {
+                HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+                HIP_CHECK(hipFree(old->second.slice[d]));
+            }
+        c->tensors.erase(old);
+    }
     split_tensor_info info{};
     info.n_dev = c->bt->n_dev;
     info.row_bytes = ggml_abi_row_size(t->type, t->ne[0]);
@@ -192,16 +201,22 @@ static split_helper * helper_for(backend_ctx * c, int d) {
     if (!c->split_helpers[d]) {
         split_helper * h = new split_helper();
         h->ordinal = logical_device_ordinal(d);
-        HIP_CHECK(hipSetDevice(h->ordinal));
-        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+        if (hipSetDevice(h->ordinal) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) {
+            (void) hipGetLastError();
+            MI_ERR("split buffer: no stream / event on device %d", h->ordinal);
+            if (h->stream) (void) hipStreamDestroy(h->stream);
+            delete h;
+            (void) hipSetDevice(c->device);
+            return nullptr;
+        }
         if (h->ordinal != c->device) {
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, h->ordinal, c->device) == hipSuccess && can) {
                 if (hipDeviceEnablePeerAccess(c->device, 0) != hipSuccess) (void) hipGetLastError();  // (already enabled is fine)
             }
         }
-        HIP_CHECK(hipSetDevice(c->device));
+        (void) hipSetDevice(c->device);
         c->split_helpers[d] = h;
     }
     return c->split_helpers[d];
@@ -218,6 +233,10 @@ void free_split_helpers(backend_ctx * c) {
     }
     c->split_helpers.clear();
     HIP_CHECK(hipSetDevice(c->device));
+    if (c->split_ready) {
+        HIP_CHECK(hipEventDestroy(c->split_ready));
+        c->split_ready = nullptr;
+    }
 }
 
 bool split_mul_mat_supported(const ggml_tensor * op) {
@@ -235,27 +254,36 @@ bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor
     const int64_t K = w->ne[0], N = w->ne[1], M = b->ne[1] * b->ne[2] * b->ne[3];
     const size_t x_bytes = ggml_abi_nbytes(b);
     const int act_kind = w->type == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K;
-    hipEvent_t ready;  // the activations exist on the main stream from here on
-    HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(ready, c->stream));
+    if (!c->split_ready) HIP_TRY(hipEventCreateWithFlags(&c->split_ready, hipEventDisableTiming), false);  // one per backend, re-recorded per mat-mul
+    hipEvent_t ready = c->split_ready;  // the activations exist on the main stream from here on
+    HIP_TRY(hipEventRecord(ready, c->stream), false);
     for (int d = 0; d < info->n_dev; ++d) {
         const int64_t rows = info->row0[d + 1] - info->row0[d];
         if (rows <= 0) continue;
         split_helper * h = helper_for(c, d);
-        HIP_CHECK(hipSetDevice(h->ordinal));
+        if (!h) return false;
+        HIP_TRY(hipSetDevice(h->ordinal), false);
         const size_t q_bytes = quantized_act_bytes(act_kind, K, M);
         const size_t need = ((x_bytes + 255) & ~(size_t) 255) + ((q_bytes + 255) & ~(size_t) 255) + (size_t) rows * M * sizeof(float) + 256;
         if (need > h->ws_size) {
-            HIP_CHECK(hipStreamSynchronize(h->stream));
-            if (h->ws) HIP_CHECK(hipFree(h->ws));
-            HIP_CHECK(hipMalloc((void **) &h->ws, need + (1u << 20)));
+            if (c->capturing) { (void) hipSetDevice(c->device); return false; }  // (sized on the eager first sighting of a topology; never inside a capture)
+            HIP_TRY(hipStreamSynchronize(h->stream), false);
+            if (h->ws) (void) hipFree(h->ws);
+            h->ws = nullptr;
+            h->ws_size = 0;
+            if (hipMalloc((void **) &h->ws, need + (1u << 20)) != hipSuccess) {
+                (void) hipGetLastError();
+                MI_ERR("split buffer: %.1f MiB of scratch on device %d failed", (need + (1u << 20)) / 1048576.0, h->ordinal);
+                (void) hipSetDevice(c->device);
+                return false;  // -> GGML_STATUS_FAILED for this llama_decode, not abort()
+            }
             h->ws_size = need + (1u << 20);
         }
         float * xd = (float *) h->ws;
         char * qd = h->ws + ((x_bytes + 255) & ~(size_t) 255);
         float * yd = (float *) (qd + ((q_bytes + 255) & ~(size_t) 255));
-        HIP_CHECK(hipStreamWaitEvent(h->stream, ready, 0));
-        HIP_CHECK(hipMemcpyPeerAsync(xd, h->ordinal, b->data, c->device, x_bytes, h->stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream, ready, 0), false);
+        HIP_TRY(hipMemcpyPeerAsync(xd, h->ordinal, b->data, c->device, x_bytes, h->stream), false);
         mmvq_args a{};
         a.W = (const uint8_t *) info->slice[d];
         a.w_nb1 = (int64_t) info->row_bytes;
@@ -276,15 +304,14 @@ bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor
             launch_mmvq(h->stream, a, 1);  // (columns in chunks of 8: functional for prompt batches, not tuned — DESIGN.md §6)
         }
         // gather: rows [row0, row0 + rows) of every column of dst
-        HIP_CHECK(hipMemcpy2DAsync((float *) dst->data + info->row0[d], (size_t) N * sizeof(float), yd, (size_t) rows * sizeof(float), (size_t) rows * sizeof(float), (size_t) M,
-                                   hipMemcpyDeviceToDevice, h->stream));
-        HIP_CHECK(hipEventRecord(h->ev, h->stream));
+        HIP_TRY(hipMemcpy2DAsync((float *) dst->data + info->row0[d], (size_t) N * sizeof(float), yd, (size_t) rows * sizeof(float), (size_t) rows * sizeof(float), (size_t) M,
+                                 hipMemcpyDeviceToDevice, h->stream), false);
+        HIP_TRY(hipEventRecord(h->ev, h->stream), false);
         c->st.kernel_launches += 1;
     }
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_TRY(hipSetDevice(c->device), false);
     for (int d = 0; d < info->n_dev; ++d)
-        if (info->row0[d + 1] > info->row0[d]) HIP_CHECK(hipStreamWaitEvent(c->stream, c->split_helpers[d]->ev, 0));
-    HIP_CHECK(hipEventDestroy(ready));
+        if (info->row0[d + 1] > info->row0[d]) HIP_TRY(hipStreamWaitEvent(c->stream, c->split_helpers[d]->ev, 0), false);
     return hipGetLastError() == hipSuccess;
 }
 

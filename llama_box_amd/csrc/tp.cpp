@@ -82,11 +82,14 @@ int tp_init(backend_ctx * c, int rank, int world, const void * uid, size_t uid_s
         return -2;
     }
     c->tp = t;
-    // The all-reduces are enqueued on the backend's stream like every kernel, so a decode step with a communicator attached is captured
-    // and replayed as ONE hipGraph like a single-GPU step (RCCL supports stream capture; the first sighting of a topology runs eagerly,
-    // which also lets RCCL finish its lazy connection set-up outside a capture, and a failed capture falls back to eager execution:
-    // graph.cpp).  Not yet exercised on multi-GPU hardware — GGML_MI355X_TP_GRAPHS=0 keeps the steps eager.
-    if (const char * e = getenv("GGML_MI355X_TP_GRAPHS")) { if (atoi(e) == 0) c->opt.graphs = false; }
+    // The all-reduces are enqueued on the backend's stream like every kernel, so a decode step with a communicator attached CAN be
+    // captured and replayed as one hipGraph like a single-GPU step (RCCL supports stream capture; the first sighting of a topology runs
+    // eagerly, which lets RCCL finish its lazy connection set-up outside a capture, and a failed capture falls back to eager execution:
+    // graph.cpp).  A replay that hangs has no fallback, though, and this path has not run on multi-GPU hardware yet: with a communicator
+    // attached, graphs are OPT-IN — GGML_MI355X_TP_GRAPHS=1, or the host's explicit set_option("graphs", 1) after tp_init (bench.py does
+    // that for its second, watchdog-guarded leg).  ADVICE r02.
+    const char * e = getenv("GGML_MI355X_TP_GRAPHS");
+    c->opt.graphs = e != nullptr && atoi(e) != 0;
     return 0;
 }
 

@@ -58,6 +58,34 @@ def main():
                                  "nmse_vs_unsplit_gpu": float(T.nmse(got, plain))})
             H.ggml_backend_buffer_free(buf_w)
             H.ggml_free(ctx_w)
+    # llama.cpp's loader asks, weight by weight, whether the device can run the op that will read the weight with the weight living in a
+    # (dummy, zero-size) buffer of the split type — weight_buft_supported.  Only MUL_MAT may say yes: anything else would dereference the
+    # split buffer's fake base address (ADVICE r02 / graph.cpp supports_op)
+    arr = (C.c_float * 16)(*([1.0] * 4 + [0.0] * 12))
+    buft = split_fn(0, arr)
+    dummy = H.ggml_backend_buft_alloc_buffer(buft, 0)
+    ctx_p = H.ggml_init(L.InitParams(0, None, True))
+    K, N, M, HD, NH = 1024, 512, 3, 64, 4
+    x = H.ggml_new_tensor_4d(ctx_p, L.F32, K, M, 1, 1)
+    x3 = H.ggml_new_tensor_4d(ctx_p, L.F32, HD, NH, M, 1)
+    pos = H.ggml_new_tensor_4d(ctx_p, L.I32, M, 1, 1, 1)
+    ids = H.ggml_new_tensor_4d(ctx_p, L.I32, M, 1, 1, 1)
+
+    def weight(qt, *ne):
+        w = H.ggml_new_tensor_4d(ctx_p, qt, *(list(ne) + [1] * (4 - len(ne))))
+        w.contents.buffer = dummy
+        return w
+
+    probes = {
+        "MUL_MAT": H.ggml_mul_mat(ctx_p, weight(L.Q4_K, K, N), x),
+        "MUL": H.ggml_mul(ctx_p, x, weight(L.F32, K)),
+        "ADD": H.ggml_add(ctx_p, x, weight(L.F32, K)),
+        "ROPE": H.ggml_rope_ext(ctx_p, x3, pos, weight(L.F32, HD // 2), HD, 0, 8192, 10000.0, 1.0, 0.0, 1.0, 32.0, 1.0),
+        "GET_ROWS": H.ggml_get_rows(ctx_p, weight(L.Q4_K, K, N), ids),
+    }
+    out["weight_probes"] = {k: bool(H.ggml_backend_dev_supports_op(be.dev, v)) for k, v in probes.items()}
+    H.ggml_free(ctx_p)
+    H.ggml_backend_buffer_free(dummy)
     print("SPLIT_JSON " + json.dumps(out))
 
 

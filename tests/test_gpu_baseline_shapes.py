@@ -452,3 +452,266 @@ def test_decode_attention_merged_in_wo_prologue(backend, H, plog, NH, NKV, n_kv,
     # mat-vec result: the merged and the unmerged GPU paths see attention values that differ by f32 summation order only
     T.compare(f"attention->wo merged vs unmerged heads={NH}/{NKV} n_kv={n_kv} wo={QNAME[wt]}", y_g, y_u, max_nmse=1e-6, log=plog)
     T.compare(f"attention->wo merged vs oracle heads={NH}/{NKV} n_kv={n_kv} wo={QNAME[wt]}", y_g, y_o, max_nmse=max(2e-4, 3.0 * e_cpu), log=plog)
+
+
+# ------------------------------------------------------------------------------------------------ (d) one real layer on a BATCH, teacher-forced
+# VERDICT r02 "What's missing" #1: the kernels the -np 32 and prefill bench lines time (k_mmq_skinny[_tp], k_mmq_wide, k_mmq_i8,
+# k_rope_qk_store / the rope epilogue, k_swiglu_q8_K, list attention, k_fattn_mma) ran in tests only at small shapes.  Here every node
+# group of a REAL layer is evaluated on a batch — 32 sequences of a continuous-batching decode step over a unified cache (config 3;
+# reference call site httpserver.hpp:3539-3623: one llama_decode over every slot's next token), and a 512-token prompt micro-batch
+# (config 2, -b/-ub: engine_param.hpp:1181,:1190) — each group fed the ORACLE's inputs, same gates as the one-token test above, and
+# which kernel served each mat-mul is asserted from the backend's counters.
+def _np32_layout(M, R, D):
+    """Unified cache of a -np step: sequence s owns prompt cells [s*R, (s+1)*R) and the decode cells M*R + d*M + s (d < D); the token
+    of this step goes into its d = D-1 cell.  Returns (n_kv, slot[M], pos[M], visible[M, n_kv])."""
+    n_kv = M * R + D * M
+    slot = np.array([M * R + (D - 1) * M + s for s in range(M)], np.int64)
+    pos = np.full(M, R + D - 1, np.int32)
+    vis = np.zeros((M, n_kv), bool)
+    for s in range(M):
+        vis[s, s * R:(s + 1) * R] = True
+        vis[s, M * R + s::M] = True
+    return n_kv, slot, pos, vis
+
+
+def _prefill_layout(M, n_past):
+    n_kv = n_past + M
+    slot = np.arange(n_past, n_past + M, dtype=np.int64)
+    pos = np.arange(n_past, n_past + M, dtype=np.int32)
+    vis = np.tril(np.ones((M, n_kv), bool), n_past)
+    return n_kv, slot, pos, vis
+
+
+BATCH_CASES = [
+    # (layer spec index, mode, flash attention)
+    (0, "np32", 1), (0, "np32", 0), (1, "np32", 1), (2, "np32", 1), (2, "np32", 0),
+    (0, "pf512", 1), (0, "pf512", 0), (1, "pf512", 1), (2, "pf512", 1),
+]
+
+
+@pytest.mark.parametrize("li,mode,fa", BATCH_CASES, ids=[f"{LAYERS[li].name.replace(' ', '_')}-{m}-fa{f}" for li, m, f in BATCH_CASES])
+def test_layer_teacher_forced_batch(backend, H, plog, li, mode, fa):
+    sp = LAYERS[li]
+    rng = np.random.default_rng(_seed(sp.name, mode, fa))
+    E, FF, NH, NKV, HD = sp.E, sp.FF, sp.NH, sp.NKV, sp.HD
+    EK = NKV * HD
+    if mode == "np32":
+        M = 32
+        n_kv, slot, pos, vis = _np32_layout(M, 64, 8)  # 2304 cells
+    else:
+        M = 512
+        n_kv, slot, pos, vis = _prefill_layout(M, 1792)  # 2304 cells, the last micro-batch of a 2304-token context
+    assert n_kv % 256 == 0
+    n_ctx = n_kv
+    MP = (M + 63) // 64 * 64
+    rope_mode = L.ROPE_NEOX if sp.neox else 0
+    W = dict(wq=T.rand_weight(sp.t_qk, E, NH * HD, rng), wk=T.rand_weight(sp.t_qk, E, EK, rng), wv=T.rand_weight(sp.t_v, E, EK, rng),
+             wo=T.rand_weight(sp.t_o, NH * HD, E, rng), wg=T.rand_weight(sp.t_gu, E, FF, rng), wu=T.rand_weight(sp.t_gu, E, FF, rng),
+             wd=T.rand_weight(sp.t_d, FF, E, rng))
+    nw1, nw2 = rng.uniform(0.5, 1.5, E).astype(np.float32), rng.uniform(0.5, 1.5, E).astype(np.float32)
+    bq, bk, bv = (rng.standard_normal(n).astype(np.float32) * 0.1 for n in (NH * HD, EK, EK))
+    x0 = (rng.standard_normal((M, E)) * rng.uniform(0.5, 2.0, (M, 1))).astype(np.float32)
+    kc0 = (rng.standard_normal((n_ctx, EK)) * 0.5).astype(np.float16)
+    vc0 = (rng.standard_normal((n_ctx, EK)) * 0.5).astype(np.float16)  # row-major [cell][EK]; the non-flash graph holds its transpose
+    mask16 = np.full((MP, n_kv), -np.inf, np.float16)
+    mask16[:M][vis] = 0
+    v_idx = (np.arange(EK, dtype=np.int64)[None, :] * n_ctx + slot[:, None]).reshape(-1)  # llama.cpp's v_idxs: element j of token t -> j * n_ctx + cell
+
+    def rope(g, t, nh, tp):
+        return H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, t, HD, nh, M), tp, None, HD, rope_mode, sp.n_ctx_train, sp.base, 1.0, 0.0, 1.0, 32.0, 1.0)
+
+    def v_cache_tensor(g, vc):  # [n_ctx, EK] values -> the graph's cache tensor
+        if fa:
+            return g.new(L.F16, [EK, n_ctx], vc)
+        return g.new(L.F16, [n_ctx, EK], np.ascontiguousarray(vc.T))
+
+    def seg_qkv(g, inp):
+        x = g.new(L.F32, [E, M], inp["x"])
+        cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, x, sp.eps), g.new(L.F32, [E], nw1))
+        q = H.ggml_mul_mat(g.ctx, g.new(sp.t_qk, [E, NH * HD], W["wq"]), cur)
+        if sp.bias:
+            q = H.ggml_add(g.ctx, q, g.new(L.F32, [NH * HD], bq))
+        k = H.ggml_mul_mat(g.ctx, g.new(sp.t_qk, [E, EK], W["wk"]), cur)
+        if sp.bias:
+            k = H.ggml_add(g.ctx, k, g.new(L.F32, [EK], bk))
+        v = H.ggml_mul_mat(g.ctx, g.new(sp.t_v, [E, EK], W["wv"]), cur)
+        if sp.bias:
+            v = H.ggml_add(g.ctx, v, g.new(L.F32, [EK], bv))
+        tp = g.new(L.I32, [M], pos)
+        idx = g.new(L.I64, [M], slot)
+        qr, kr = rope(g, q, NH, tp), rope(g, k, NKV, tp)
+        v3 = H.ggml_reshape_3d(g.ctx, v, HD, NKV, M)
+        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [EK, n_ctx], inp["kc"]), H.ggml_reshape_2d(g.ctx, kr, EK, M), idx)
+        vct = v_cache_tensor(g, inp["vc"])
+        if fa:
+            vs = H.ggml_set_rows(g.ctx, vct, H.ggml_reshape_2d(g.ctx, v3, EK, M), idx)
+        else:
+            vs = H.ggml_set_rows(g.ctx, H.ggml_reshape_2d(g.ctx, vct, 1, n_ctx * EK), H.ggml_reshape_2d(g.ctx, v3, 1, M * EK), g.new(L.I64, [M * EK], v_idx))
+        return dict(outs=[qr, ks, vs], first=[qr, kr, v3])
+
+    def seg_attn(g, inp):
+        qr = g.new(L.F32, [HD, NH, M], inp["q_rope"])
+        kc = g.new(L.F16, [EK, n_ctx], inp["kc"])
+        vct = v_cache_tensor(g, inp["vc"])
+        q = H.ggml_permute(g.ctx, qr, 0, 2, 1, 3)
+        k = H.ggml_view_3d(g.ctx, kc, HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        if fa:
+            v = H.ggml_view_3d(g.ctx, vct, HD, n_kv, NKV, EK * 2, HD * 2, 0)
+            out = H.ggml_flash_attn_ext(g.ctx, q, k, v, g.new(L.F16, [n_kv, MP], mask16), 1.0 / np.sqrt(HD), 0.0, 0.0)
+            H.ggml_flash_attn_ext_set_prec(out, 10)
+            out = H.ggml_reshape_2d(g.ctx, out, HD * NH, M)
+        else:
+            v = H.ggml_view_3d(g.ctx, vct, n_kv, HD, NKV, n_ctx * 2, n_ctx * 2 * HD, 0)
+            kq = H.ggml_mul_mat(g.ctx, k, q)
+            p = H.ggml_soft_max_ext(g.ctx, kq, g.new(L.F32, [n_kv, MP], mask16.astype(np.float32)), 1.0 / np.sqrt(HD), 0.0)
+            kqv = H.ggml_mul_mat(g.ctx, v, p)
+            out = H.ggml_cont_2d(g.ctx, H.ggml_permute(g.ctx, kqv, 0, 2, 1, 3), HD * NH, M)
+        return dict(outs=[out], first=[])
+
+    def seg_wo(g, inp):
+        a = g.new(L.F32, [NH * HD, M], inp["attn"])
+        y = H.ggml_mul_mat(g.ctx, g.new(sp.t_o, [NH * HD, E], W["wo"]), a)
+        return dict(outs=[H.ggml_add(g.ctx, y, g.new(L.F32, [E, M], inp["x"]))], first=[])
+
+    def seg_ffn(g, inp):
+        f = g.new(L.F32, [E, M], inp["ffn_inp"])
+        cur = H.ggml_mul(g.ctx, H.ggml_rms_norm(g.ctx, f, sp.eps), g.new(L.F32, [E], nw2))
+        gate = H.ggml_mul_mat(g.ctx, g.new(sp.t_gu, [E, FF], W["wg"]), cur)
+        up = H.ggml_mul_mat(g.ctx, g.new(sp.t_gu, [E, FF], W["wu"]), cur)
+        return dict(outs=[H.ggml_swiglu_split(g.ctx, gate, up)], first=[])
+
+    def seg_down(g, inp):
+        a = g.new(L.F32, [FF, M], inp["act"])
+        y = H.ggml_mul_mat(g.ctx, g.new(sp.t_d, [FF, E], W["wd"]), a)
+        return dict(outs=[H.ggml_add(g.ctx, y, g.new(L.F32, [E, M], inp["ffn_inp"]))], first=[])
+
+    COUNTERS = ("kernel_launches", "skinny_launches", "wide_launches", "tiled_launches", "shadow_launches", "rope_epilogues")
+
+    def run(seg, target, inp):
+        g = T.G(target)
+        try:
+            b = seg(g, inp)
+            c0 = {k: backend.stat(k) for k in COUNTERS} if target != "oracle" else None
+            r = g.compute(b["outs"], NT, expand_first=b["first"])
+            return r, ({k: backend.stat(k) - c0[k] for k in COUNTERS} if c0 else None)
+        finally:
+            g.free()
+
+    def served(cnt, wtypes, group):
+        """which kernel ran the group's quantised mat-muls: asserted, so that a silent fall-back to a slower (or untested) kernel fails here"""
+        _log(plog, f"{sp.name} {mode} fa={fa}: {group}: {cnt}")
+        if cnt is None:  # (the oracle target has no counters)
+            return
+        if M <= 32:
+            assert cnt["skinny_launches"] >= 1 and cnt["wide_launches"] == 0 and cnt["tiled_launches"] == 0, (group, cnt)
+        else:
+            kq = [t for t in wtypes if t in (L.Q4_K, L.Q5_K)]
+            if kq:
+                assert cnt["wide_launches"] + cnt["shadow_launches"] >= 1, (group, cnt)
+            if L.Q6_K in wtypes:
+                assert cnt["tiled_launches"] + cnt["shadow_launches"] >= 1, (group, cnt)
+            assert cnt["skinny_launches"] == 0, (group, cnt)
+
+    tag = f"{sp.name} [{mode}, {M} tokens, n_kv {n_kv}, fa={fa}]"
+    vals = {"x": x0, "kc": kc0, "vc": vc0}
+    (q_o, kc_o, vc_o), _ = run(seg_qkv, "oracle", vals)
+    (q_g, kc_g, vc_g), c1 = run(seg_qkv, backend, vals)
+    served(c1, (sp.t_qk, sp.t_v), "qkv + rope + stores")
+    T.compare(f"{tag}: q_rope", q_g, q_o, max_nmse=1e-10, log=plog)
+
+    def cache_rows(a, transposed):  # -> float32 [n_ctx, EK]
+        a = np.asarray(a)
+        return (a.reshape(EK, n_ctx).T if transposed else a.reshape(n_ctx, EK)).astype(np.float32)
+
+    other = np.ones(n_ctx, bool)
+    other[slot] = False
+    for nm, a, b, c0_, tr in (("k_cache", kc_g, kc_o, kc0, False), ("v_cache", vc_g, vc_o, vc0, not fa)):
+        a32, b32 = cache_rows(a, tr), cache_rows(b, tr)
+        T.compare(f"{tag}: {nm} new rows", a32[slot], b32[slot], max_nmse=1e-6, log=plog)
+        assert np.array_equal(a32[other], c0_.astype(np.float32)[other]), f"{nm}: cells other than the batch's were touched"
+
+    kc_n = cache_rows(kc_o, False).astype(np.float16)
+    vc_n = cache_rows(vc_o, not fa).astype(np.float16)
+    vals.update(q_rope=q_o, kc=kc_n, vc=vc_n)
+    (at_o,), _ = run(seg_attn, "oracle", vals)
+    (at_g,), c2 = run(seg_attn, backend, vals)
+    _log(plog, f"{tag}: attention: {c2}")
+    # exact attention in float64 over each token's visible cells (q rounded to f16 as both implementations do)
+    qf = np.asarray(q_o).reshape(M, NH, HD).astype(np.float16).astype(np.float64)
+    kf, vf = kc_n.astype(np.float64).reshape(n_ctx, NKV, HD), vc_n.astype(np.float64).reshape(n_ctx, NKV, HD)
+    grp = NH // NKV
+    exact = np.empty((M, NH, HD))
+    for t in range(M):
+        cells = np.nonzero(vis[t])[0]
+        for h in range(NH):
+            s_ = kf[cells, h // grp, :] @ qf[t, h] / np.sqrt(HD)
+            p_ = np.exp(s_ - s_.max())
+            exact[t, h] = (p_ / p_.sum()) @ vf[cells, h // grp, :]
+    e_gpu, e_cpu = T.nmse(np.asarray(at_g).reshape(M, NH, HD), exact), T.nmse(np.asarray(at_o).reshape(M, NH, HD), exact)
+    _log(plog, f"{tag}: attention vs float64: gpu nmse={e_gpu:.3e}, cpu oracle nmse={e_cpu:.3e}")
+    if fa:
+        assert e_gpu <= 1e-9 and e_gpu <= e_cpu * 1.01 + 1e-12
+        T.compare(f"{tag}: flash_attn", at_g, at_o, max_nmse=max(1e-4, 1.5 * e_cpu), log=plog)
+    else:
+        T.compare(f"{tag}: K.q -> soft_max -> V^T.p -> cont", at_g, at_o, max_nmse=1e-9, log=plog)
+
+    vals.update(attn=np.asarray(at_o).reshape(M, NH * HD))
+    (fi_o,), _ = run(seg_wo, "oracle", vals)
+    (fi_g,), c3 = run(seg_wo, backend, vals)
+    served(c3, (sp.t_o,), "wo + residual")
+    T.compare(f"{tag}: wo + residual (ffn_inp)", fi_g, fi_o, max_nmse=1e-10, log=plog)
+
+    vals.update(ffn_inp=np.asarray(fi_o).reshape(M, E))
+    (act_o,), _ = run(seg_ffn, "oracle", vals)
+    (act_g,), c4 = run(seg_ffn, backend, vals)
+    served(c4, (sp.t_gu,), "norm -> gate/up -> swiglu")
+    T.compare(f"{tag}: norm -> gate/up -> swiglu", act_g, act_o, max_nmse=1e-10, log=plog)
+
+    vals.update(act=np.asarray(act_o).reshape(M, FF))
+    (lo_o,), _ = run(seg_down, "oracle", vals)
+    (lo_g,), c5 = run(seg_down, backend, vals)
+    served(c5, (sp.t_d,), "ffn_down + residual")
+    T.compare(f"{tag}: ffn_down + residual (l_out)", lo_g, lo_o, max_nmse=1e-10, log=plog)
+
+
+# ------------------------------------------------------------------------------------------------ (e) config 2's prefill, end to end
+def test_prefill_2048_in_four_micro_batches(backend, H, plog):
+    """BASELINE config 2's prefill as llama-box drives it (-b 2048 -ub 512: four micro-batches of 512 tokens through one llama_decode), on a
+    model with Llama-3-8B's layer shapes and Q4_K_M type map cut to four layers (two plain, two "more bits"), flash attention on:
+    last-token logits against the oracle, judged beside the oracle's own order sensitivity (its block dots summed in reverse)."""
+    from model_util import Context, Model, preset
+    hp = preset("llama3-8b-q4_k_m", n_layer=4)
+    rng = np.random.default_rng(2048)
+    prompt = rng.integers(3, hp.n_vocab, 2048).tolist()
+    want = [0] * 2047 + [1]
+    mc = Model(hp, 7, H.ggml_backend_cpu_buffer_type())
+    mg = Model(hp, 7, backend.buft)
+    ctxs = []
+    try:
+        def last_logits(model, **kw):
+            c = Context(model, n_ctx=2304, n_ubatch=512, flash_attn=1, **kw)
+            ctxs.append(c)
+            rc, lg = c.decode(prompt, range(2048), want=want)
+            assert rc == 0
+            return lg[-1].copy()
+
+        ref = last_logits(mc, compute=T.oracle_compute_fn(NT))
+        T.oracle().oracle_set_variant(1)
+        try:
+            var = last_logits(mc, compute=T.oracle_compute_fn(NT))
+        finally:
+            T.oracle().oracle_set_variant(0)
+        c0 = {k: backend.stat(k) for k in ("wide_launches", "tiled_launches", "shadow_launches", "skinny_launches", "kernel_launches")}
+        got = last_logits(mg, backend=backend)
+        cnt = {k: backend.stat(k) - v for k, v in c0.items()}
+        e, e_var = T.nmse(got, ref), T.nmse(var, ref)
+        top2 = np.sort(ref)
+        _log(plog, f"prefill 2048 tokens in 4 micro-batches (llama3-8b shapes, 4 layers, q4_k_m): last-token logits nmse gpu={e:.3e} (oracle reversed-blocks {e_var:.3e}) "
+                   f"max|d| gpu={np.max(np.abs(got - ref)):.3e} (variant {np.max(np.abs(var - ref)):.3e}); argmax gpu={int(np.argmax(got))} oracle={int(np.argmax(ref))} margin={top2[-1] - top2[-2]:.3e}; kernels {cnt}")
+        assert cnt["wide_launches"] + cnt["shadow_launches"] >= 4 * 4 * 3 and cnt["skinny_launches"] == 0, cnt  # 4 micro-batches x 4 layers x (qkv, wo, gate/up [, down])
+        assert e <= 1e-3 and e <= max(10.0 * e_var, 1e-10)
+        if top2[-1] - top2[-2] > 2.0 * float(np.max(np.abs(var - ref))):
+            assert int(np.argmax(got)) == int(np.argmax(ref))
+    finally:
+        for o in ctxs + [mc, mg]:
+            o.free()

@@ -8,6 +8,7 @@ f32 summation order occasionally flips a rounding, and the flip (1/127 of a bloc
 it.  So the e2e gate is RELATIVE to the oracle's own sensitivity to summation order (oracle variant 1), plus an
 absolute NMSE cap of 1e-3, and greedy ids must match wherever the top-2 margin exceeds the observed deviation.
 The FLASH_ATTN_EXT path is gated against the CPU's own FA-vs-softmax gap (ggml-cpu accumulates V in f16 there)."""
+import ctypes as C
 import os
 import tempfile
 
@@ -378,3 +379,53 @@ def test_host_sampler_consumes_backend_logits(backend, H, plog):
             assert H.llm_get_logits_ith(cg.c, 0) and H.llm_get_logits_ith(cg.c, -1)
     finally:
         _free(cc, cg, mc, mg)
+
+
+# ------------------------------------------------------------------------------------------------ loader: errors and the staged upload path
+def test_alloc_buffer_beyond_device_memory_returns_null(backend, H, plog):
+    """Hosts handle a NULL buffer (llama-box/rpcserver.hpp:1068-1080: "device memory allocation failed" -> the request fails, the server
+    lives on).  The backend must hand back NULL — not abort() — and stay usable."""
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    H.ggml_backend_dev_memory(backend.dev, C.byref(free), C.byref(total))
+    assert 0 < free.value <= total.value
+    buf = H.ggml_backend_buft_alloc_buffer(backend.buft, total.value + (1 << 30))
+    assert not buf, "an allocation larger than the device's memory returned a buffer"
+    plog(f"[loader] alloc_buffer({(total.value + (1 << 30)) / 2**30:.1f} GiB) on a {total.value / 2**30:.1f} GiB device -> NULL")
+    # the device is still usable: a small graph runs
+    rng = np.random.default_rng(3)
+    w = T.rand_weight(L.Q4_K, 512, 256, rng)
+    x = rng.standard_normal((1, 512)).astype(np.float32)
+    build = lambda g: H.ggml_mul_mat(g.ctx, g.new(L.Q4_K, [512, 256], w), g.new(L.F32, [512, 1], x))
+    T.compare("mat-vec after a failed allocation", T.run_case(build, backend)[0], T.run_case(build, "oracle")[0], max_nmse=1e-10, log=plog)
+
+
+def test_staged_upload_round_trips_and_orders(backend, H, plog):
+    """set_tensor above 1 MiB goes through the pinned staging ring (backend.cpp: uploader) and returns with DMAs still in flight; every
+    reader must see the bytes: get_tensor right behind it, a small synchronous set_tensor into the same tensor, and a graph launched on the
+    backend's stream.  Sizes straddle the slot size (32 MiB) and are not multiples of anything."""
+    rng = np.random.default_rng(11)
+    b0 = backend.stat("staged_upload_bytes")
+    for n in (1 << 20, (1 << 20) + 4096 + 17, (32 << 20) - 1, (32 << 20) + 1, (70 << 20) + 12345):
+        ctx = H.ggml_init(L.InitParams(0, None, True))
+        t = H.ggml_new_tensor_4d(ctx, L.I32, (n + 3) // 4, 1, 1, 1)
+        buf = H.ggml_backend_alloc_ctx_tensors_from_buft(ctx, backend.buft)
+        assert buf
+        src = rng.integers(0, 256, n, dtype=np.uint8)
+        H.ggml_backend_tensor_set(t, src.ctypes.data_as(C.c_void_p), 0, n)
+        patch = rng.integers(0, 256, 1000, dtype=np.uint8)  # small piece right behind the staged one: must land AFTER it
+        H.ggml_backend_tensor_set(t, patch.ctypes.data_as(C.c_void_p), 4096, 1000)
+        src[4096:5096] = patch
+        back = np.empty(n, np.uint8)
+        H.ggml_backend_tensor_get(t, back.ctypes.data_as(C.c_void_p), 0, n)
+        assert np.array_equal(back, src), f"staged upload of {n} bytes did not round-trip"
+        H.ggml_backend_buffer_free(buf)
+        H.ggml_free(ctx)
+    assert backend.stat("staged_upload_bytes") - b0 >= (70 << 20), "the uploads did not take the staged path"
+    # a weight uploaded through the ring is complete when the first kernel reads it (graph_compute joins the upload stream)
+    K, N = 4096, 4096  # 9.4 MB of Q4_K
+    w = T.rand_weight(L.Q4_K, K, N, rng)
+    x = rng.standard_normal((1, K)).astype(np.float32)
+    build = lambda g: H.ggml_mul_mat(g.ctx, g.new(L.Q4_K, [K, N], w), g.new(L.F32, [K, 1], x))
+    ref = T.run_case(build, "oracle", T.host_threads())[0]
+    for _ in range(3):
+        T.compare("mat-vec on a weight uploaded through the staging ring", T.run_case(build, backend)[0], ref, max_nmse=1e-10, log=plog)

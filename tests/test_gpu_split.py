@@ -21,6 +21,8 @@ def test_row_split_buffer_type_on_four_logical_devices(plog):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1]
     res = json.loads(line[len("SPLIT_JSON "):])
     assert res["n_dev"] == 4
+    # only mat-mul weights may be placed in the split buffer type (llama.cpp's weight_buft_supported probes)
+    assert res["weight_probes"] == {"MUL_MAT": True, "MUL": False, "ADD": False, "ROPE": False, "GET_ROWS": False}, res["weight_probes"]
     for c in res["cases"]:
         plog(f"[split] ts={c['ts']} type={c['qt']} K={c['K']} N={c['N']} M={c['M']}: rows {c['row0']} nmse vs oracle {c['nmse_vs_oracle']:.2e} vs unsplit gpu {c['nmse_vs_unsplit_gpu']:.2e}")
         assert c["supports_buft"] == [True, False, False, False]  # only the main device's backend computes on split weights
