@@ -29,8 +29,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 # kernel-class tag (graph.cpp timed_scope) -> substring of the kernel symbol rocprofv3 reports
-def _class_to_symbol(cls):
+def _class_to_symbol(cls, n_par=1):
     parts = cls.split("_")
+    if parts[0] == "mmq" and 2 <= n_par <= 32:
+        # -np decode steps: the weight-streaming matrix-core kernel; the gate/up pair takes its tile-parallel form (mmq_skinny.hip)
+        qt = {"q4": "4", "q5": "5", "q6": "6"}.get(parts[1])
+        if qt is None:
+            return None
+        return f"k_mmq_skinny_tp<{qt}>" if cls.endswith("_x2") else f"k_mmq_skinny<{qt}, "
     if parts[0] != "mmvq":
         return None
     ty = {"q4": "T_Q4K", "q5": "T_Q5K", "q6": "T_Q6K", "q8": "T_Q80"}.get(parts[1])
@@ -55,7 +61,7 @@ def pmc_traffic(symbol, args):
     out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_CHILD="1")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", out, "-o", "pmc", "--output-format", "csv", "--",
-           sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--prefill", "256", "--timing-steps", "0", "--no-cpu-baseline",
+           sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--prefill", "256" if args.np == 1 else "64", "--timing-steps", "0", "--no-cpu-baseline",
            "--pmc-traffic", "0", "--preset", args.preset, "--fa", str(args.fa), "--np", str(args.np)]
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
@@ -302,7 +308,7 @@ def main():
     except Exception as e:
         roofline = {"error": str(e)}
     if roofline and "kernel" in roofline and args.pmc_traffic and rank == 0 and world == 1 and not os.environ.get("BENCH_PMC_CHILD"):
-        sym = _class_to_symbol(roofline["kernel"])
+        sym = _class_to_symbol(roofline["kernel"], args.np)
         if sym:
             torch.cuda.synchronize()
             tr, how = pmc_traffic(sym, args)
@@ -354,7 +360,7 @@ def main():
             nmax = lib.oracle_max_threads()
             # thread count: the best of a short probe (a 2-socket host is not fastest with every logical CPU spinning on one weight stream)
             best = (0.0, nmax)
-            for nth in sorted({nmax, max(1, nmax // 2), min(nmax, 64), min(nmax, 32)}, reverse=True):
+            for nth in sorted({nmax, max(1, nmax // 2), min(nmax, 96), min(nmax, 64), min(nmax, 32)}, reverse=True):
                 cc = Context(mc, compute=T.oracle_compute_fn(nth), n_ctx=256, flash_attn=args.fa, n_threads=nth)
                 cc.decode([int(toks[0])], [0])  # touch the weights / wake the pool
                 tp0 = time.perf_counter()
@@ -376,9 +382,11 @@ def main():
             lib.oracle_set_fast(0)
             found = [b for b in ("llama-box", "llama-bench", "llama-cli") if shutil.which(b)]
             cpu_baseline = {"value": round(args.cpu_steps / tc, 3), "unit": "tokens/s", "cores": nth, "kind": "port",
+                            "effective_GBps": round(mc.stream_bytes() * args.cpu_steps / tc / 1e9, 1),  # weight bytes one token streams x tokens/s: what the host's DRAM delivered
+                            "numa_nodes": len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]) if os.path.isdir("/sys/devices/system/node") else 1,
                             "sample": f"{args.cpu_steps} warm batch-1 decode steps at n_past 5..{4 + args.cpu_steps} of the same synthetic {args.preset} model; CPU restatement of ggml-cpu (oracle/): "
                                       + ("AVX2 block dots as ggml-cpu's x86 kernels compute them (same integers, FMA lane accumulation)" if fast else "generic scalar block dots (no AVX2 build)")
-                                      + f", OpenMP pool of {nth} threads (best of a probe over thread counts up to {nmax}); NOT llama-box's binary"
+                                      + f", OpenMP pool of {nth} threads (best of a probe over thread counts up to {nmax}), weight pages interleaved over the NUMA nodes / first-touched by many threads (ggml_lite.cpp spread_pages); NOT llama-box's binary"
                                       + (f" — binaries found on this host: {found}" if found else " (no llama-box / llama-bench / llama-cli on this host)"),
                             "setup_s": round(time.time() - t_c - tc, 1)}
             cc.free()

@@ -1,6 +1,7 @@
 // common.h — internal declarations shared by the backend's translation units (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>

@@ -66,6 +66,16 @@ struct launch_probe {
     bool armed = false, used = false;
 };
 extern thread_local launch_probe g_launch_probe;
+// launch through the armed probe (once) or plainly: every launcher of a kernel class bench.py may quote in `roofline` goes through this
+#define MI_LAUNCH_PROBED(kernel, grid, block, lds, stream, ...)                                                                  \
+    do {                                                                                                                         \
+        if (g_launch_probe.armed && !g_launch_probe.used) {                                                                      \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_launch_probe.e0, g_launch_probe.e1, 0, __VA_ARGS__);       \
+            g_launch_probe.used = true;                                                                                          \
+        } else {                                                                                                                 \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                   \
+        }                                                                                                                        \
+    } while (0)
 
 // ---- fused Q/K/V projection for one token (qkv.hip): up to three K-quant mat-vecs that share their input, with the
 // activation prologue of mmvq (f32 or RMS_NORM*w), optional bias, rotary embedding and the KV-cache store in the epilogue

@@ -418,7 +418,7 @@ template <int QT, int BN, int BM = 128> static void launch_mmq8_t(hipStream_t s,
     }
     a.m_tiles = (a.M + BM - 1) / BM;
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
-    hipLaunchKernelGGL((k_mmq_i8<QT, BN, BM>), dim3(grid, (unsigned) a.ksplit), dim3(BN * 4), lds, s, a);
+    MI_LAUNCH_PROBED((k_mmq_i8<QT, BN, BM>), dim3(grid, (unsigned) a.ksplit), dim3(BN * 4), lds, s, a);
 }
 
 // few activation columns (continuous-batching decode, M <= 64) leave N/64 x 1 workgroups — far fewer than 256 CUs — so

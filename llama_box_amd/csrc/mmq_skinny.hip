@@ -907,7 +907,7 @@ template <int QT, int TT, int NW, int NL> static void launch_wide_t(hipStream_t 
     }
     a.m_tiles = (a.M + 32 * TT - 1) / (32 * TT);
     const int n_virtual = ((a.n_panels + 7) / 8) * 8 * a.m_tiles;
-    hipLaunchKernelGGL((k_mmq_wide<QT, TT, NW, NL>), dim3((unsigned) std::min(n_virtual, skinny_n_cu())), dim3((NW + NL) * 64), lds, s, a);
+    MI_LAUNCH_PROBED((k_mmq_wide<QT, TT, NW, NL>), dim3((unsigned) std::min(n_virtual, skinny_n_cu())), dim3((NW + NL) * 64), lds, s, a);
 }
 void launch_mmq_wide(hipStream_t s, int type, int shape, const mmq8_args & a) {
     static const int self4 = getenv("GGML_MI355X_MMQ_WIDE_SELF") ? atoi(getenv("GGML_MI355X_MMQ_WIDE_SELF")) : 0;  // experiment: 4 waves x 4 token tiles, no loaders
@@ -956,7 +956,7 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
                 a.mat[i].panel0 = a.n_panels;
                 a.n_panels += a.mat[i].N / 128;
             }
-            hipLaunchKernelGGL((k_mmq_skinny_tp<QT>), dim3((unsigned) std::min(a.n_panels, n_cu)), dim3(TP_NW * 64), (size_t) tp_lds_bytes<QT>(), s, a);
+            MI_LAUNCH_PROBED((k_mmq_skinny_tp<QT>), dim3((unsigned) std::min(a.n_panels, n_cu)), dim3(TP_NW * 64), (size_t) tp_lds_bytes<QT>(), s, a);
             return;
         }
     }
@@ -972,8 +972,8 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
     }
     // one workgroup per CU (its LDS areas fill the CU), walking the (tile, K slice) items with a stride of the grid
     const int items = a.n_panels * a.ksplit;
-    if (a.has_epi) hipLaunchKernelGGL((k_mmq_skinny<QT, true>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
-    else hipLaunchKernelGGL((k_mmq_skinny<QT, false>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
+    if (a.has_epi) MI_LAUNCH_PROBED((k_mmq_skinny<QT, true>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
+    else MI_LAUNCH_PROBED((k_mmq_skinny<QT, false>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
 }
 
 void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a) {

@@ -5,6 +5,9 @@
 #include "ggml_lite.h"
 
 #include <dlfcn.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <thread>
 
 #include <algorithm>
 #include <cstdarg>
@@ -721,9 +724,42 @@ static void cpu_buf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, si
 static void cpu_buf_set(ggml_backend_buffer_t, ggml_tensor * t, const void * d, size_t off, size_t sz) { memcpy((char *) t->data + off, d, sz); }
 static void cpu_buf_get(ggml_backend_buffer_t, const ggml_tensor * t, void * d, size_t off, size_t sz) { memcpy(d, (const char *) t->data + off, sz); }
 static void cpu_buf_clear(ggml_backend_buffer_t b, uint8_t v) { memset(b->context, v, b->size); }
+// Large host buffers (the CPU copy of a model: bench.py's cpu_baseline, the oracle side of the model tests) are spread over the host's
+// memory controllers before anything is written: MPOL_INTERLEAVE over every online NUMA node where the kernel lets us (mbind by raw
+// syscall: no libnuma in the image), and in any case a first touch of the pages by many threads at once — striped 2 MiB apart — instead of
+// by the one thread that later fills the weights.  A model whose pages all sit on the loading thread's node is read through ONE socket's
+// memory channels whatever the thread count (53 GB/s on a host with > 400 GB/s).
+static void spread_pages(char * p, size_t size) {
+    if (size < ((size_t) 64 << 20)) return;
+    unsigned long mask[16] = {0};
+    int n_nodes = 0;
+    for (int nd = 0; nd < 1024; ++nd) {
+        char path[64];
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d", nd);
+        if (access(path, F_OK) != 0) break;
+        mask[nd / (8 * sizeof(unsigned long))] |= 1ul << (nd % (8 * sizeof(unsigned long)));
+        n_nodes++;
+    }
+#if defined(SYS_mbind)
+    if (n_nodes > 1) {
+        char * a = (char *) (((uintptr_t) p + 4095) & ~(uintptr_t) 4095);
+        (void) syscall(SYS_mbind, a, (size - (size_t) (a - p)) & ~(size_t) 4095, 3 /* MPOL_INTERLEAVE */, mask, sizeof(mask) * 8, 0);  // (refused under some seccomp profiles: the touch below still spreads)
+    }
+#endif
+    const unsigned T = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const size_t stripe = (size_t) 2 << 20;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([=] {
+            for (size_t s0 = (size_t) t * stripe; s0 < size; s0 += (size_t) T * stripe)
+                for (size_t o = s0; o < std::min(size, s0 + stripe); o += 4096) ((volatile char *) p)[o] = 0;
+        });
+    for (auto & x : th) x.join();
+}
 static ggml_backend_buffer_t cpu_buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
     void * p = nullptr;
     if (posix_memalign(&p, 64, size + 64) != 0) return nullptr;
+    spread_pages((char *) p, size + 64);
     ggml_backend_buffer_i iface = {cpu_buf_free, cpu_buf_base, nullptr, cpu_buf_memset, cpu_buf_set, cpu_buf_get, nullptr, cpu_buf_clear, nullptr};
     return ggml_backend_buffer_init(buft, iface, p, size);
 }
