@@ -36,7 +36,9 @@ def _class_to_symbol(cls, n_par=1):
         qt = {"q4": "4", "q5": "5", "q6": "6"}.get(parts[1])
         if qt is None:
             return None
-        return f"k_mmq_skinny_tp<{qt}>" if cls.endswith("_x2") else f"k_mmq_skinny<{qt}, "
+        n_total = next((int(x[1:]) for x in parts if x.startswith("n") and x[1:].isdigit()), 0)
+        tile_parallel = "x2" in parts and qt in ("4", "5") and n_total >= 192 * 128  # (mmq_skinny.hip skinny_tp_applies: >= 192 groups of 128 rows, no K split — the gate/up pair)
+        return f"k_mmq_skinny_tp<{qt}>" if tile_parallel else f"k_mmq_skinny<{qt}, "
     if parts[0] != "mmvq":
         return None
     ty = {"q4": "T_Q4K", "q5": "T_Q5K", "q6": "T_Q6K", "q8": "T_Q80"}.get(parts[1])

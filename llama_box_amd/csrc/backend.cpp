@@ -106,6 +106,11 @@ struct uploader {
     double seconds = 0;
 };
 static uploader g_uploaders[GGML_MI355X_MAX_DEVICES];
+// OFF by default.  Measured on the MI355X box (profiles/r03_upload_bench.jsonl, 6 GiB in 256 MiB tensors from pageable memory): plain hipMemcpy
+// 56.5 GB/s, this engine 55.5 (4 or 8 copy threads; 33 with one) — ROCm 7.2's own pageable path already runs at the PCIe Gen5 rate, a
+// 42.5 GB model is 0.8 s of copying either way.  What the engine still buys is the early return (the loader's next read overlaps the DMA);
+// GGML_MI355X_STAGED_UPLOAD=1 / set_option("staged_upload", 1) turns it on.
+static std::atomic<int> g_staged_upload{[] { const char * e = getenv("GGML_MI355X_STAGED_UPLOAD"); return e ? atoi(e) : 0; }()};
 
 static void par_memcpy(char * dst, const char * src, size_t n, int n_threads) {
     if (n_threads <= 1 || n < ((size_t) 4 << 20)) { memcpy(dst, src, n); return; }
@@ -124,8 +129,7 @@ static uploader * uploader_for(int device) {
     uploader * u = &g_uploaders[device];
     if (u->failed) return nullptr;
     if (u->device == device) return u;
-    static const int enabled = [] { const char * e = getenv("GGML_MI355X_STAGED_UPLOAD"); return e ? atoi(e) : 1; }();
-    if (!enabled) { u->failed = true; return nullptr; }
+    if (!g_staged_upload.load(std::memory_order_relaxed)) return nullptr;
     const char * e_mb = getenv("GGML_MI355X_UPLOAD_SLOT_MIB");
     const char * e_th = getenv("GGML_MI355X_UPLOAD_THREADS");
     u->slot_bytes = (size_t) std::max(1, e_mb ? atoi(e_mb) : 32) << 20;
@@ -538,6 +542,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "fa_wo") c->opt.fa_wo = v != 0;
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;
     else if (k == "timing") c->opt.timing = v != 0;
+    else if (k == "staged_upload") g_staged_upload.store(v != 0);
     else return -1;
     HIP_CHECK(hipStreamSynchronize(c->stream));
     free_graph_cache(c);

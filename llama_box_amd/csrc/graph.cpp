@@ -375,7 +375,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     }
     const bool i8 = c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M);
     if (M >= c->opt.mmq_min_cols && !w2 && !add2 && (!add || i8) && (i8 || mmq_supported(w->type, K, N, M))) {
-        timed_scope ts(c, (std::string("mmq_") + type_tag(w->type)).c_str(), wbytes, i8);
+        timed_scope ts(c, (std::string("mmq_") + type_tag(w->type) + "_n" + std::to_string(N) + "_k" + std::to_string(K)).c_str(), wbytes, i8);
         const int ks = st.epi_dst == dst ? 1 : ((N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M, c->opt.mmq_skinny, w->type) : 1);
         float * part = (float *) ((char *) c->ws + st.aux_off);
         if (i8) {
@@ -922,7 +922,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     }
     float * part = (float *) ((char *) c->ws + st.aux_off);
     {
-        timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (ms.size() == 3 ? "_x3" : "_x2")).c_str(), wbytes, true);
+        timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (ms.size() == 3 ? "_x3" : "_x2") + "_n" + std::to_string(n_total) + "_k" + std::to_string(K)).c_str(), wbytes, true);
         if (epi_node >= 0) {
             auto role_of2 = [&](const member & m) {
                 for (int sidx = 0; sidx < 3; ++sidx)

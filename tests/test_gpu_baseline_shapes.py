@@ -650,7 +650,9 @@ def test_layer_teacher_forced_batch(backend, H, plog, li, mode, fa):
     e_gpu, e_cpu = T.nmse(np.asarray(at_g).reshape(M, NH, HD), exact), T.nmse(np.asarray(at_o).reshape(M, NH, HD), exact)
     _log(plog, f"{tag}: attention vs float64: gpu nmse={e_gpu:.3e}, cpu oracle nmse={e_cpu:.3e}")
     if fa:
-        assert e_gpu <= 1e-9 and e_gpu <= e_cpu * 1.01 + 1e-12
+        # (prompt chunks run on the f16 matrix cores: the probabilities are rounded to f16 for the P.V product, ~1e-9 of the result; the
+        # lane-parallel decode kernel keeps them in f32.  Either way the kernel must be closer to exact attention than the CPU's f16 V sum.)
+        assert e_gpu <= (1e-9 if M <= 32 else 1e-8) and e_gpu <= e_cpu * 1.01 + 1e-12
         T.compare(f"{tag}: flash_attn", at_g, at_o, max_nmse=max(1e-4, 1.5 * e_cpu), log=plog)
     else:
         T.compare(f"{tag}: K.q -> soft_max -> V^T.p -> cont", at_g, at_o, max_nmse=1e-9, log=plog)

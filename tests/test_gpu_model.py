@@ -405,6 +405,14 @@ def test_staged_upload_round_trips_and_orders(backend, H, plog):
     backend's stream.  Sizes straddle the slot size (32 MiB) and are not multiples of anything."""
     rng = np.random.default_rng(11)
     b0 = backend.stat("staged_upload_bytes")
+    backend.set_option("staged_upload", 1)  # (off by default: measured equal to the runtime's pageable copy on this host — backend.cpp)
+    try:
+        _staged_upload_cases(backend, H, plog, rng, b0)
+    finally:
+        backend.set_option("staged_upload", 0)
+
+
+def _staged_upload_cases(backend, H, plog, rng, b0):
     for n in (1 << 20, (1 << 20) + 4096 + 17, (32 << 20) - 1, (32 << 20) + 1, (70 << 20) + 12345):
         ctx = H.ggml_init(L.InitParams(0, None, True))
         t = H.ggml_new_tensor_4d(ctx, L.I32, (n + 3) // 4, 1, 1, 1)
