@@ -684,4 +684,210 @@ __global__ void __launch_bounds__(SH_NW * 64, 2) k_mmq_shadow_pp(const shadow_ar
 #undef MAT_SEL
 }
 
+
+// ------------------------------------------------------------------------------------------------ the GEMM, third form: two independent workgroups per CU
+// 4 waves = 128 tokens x 128 rows (wave (wm, wn): tokens [64 wm, +64) x rows [64 wn, +64), the same 2 x 2 tiles per wave), 75 KB of LDS, so
+// that TWO workgroups share a CU: the two waves of a SIMD belong to different workgroups, meet at no common barrier and drift apart by
+// themselves — one's requests / fragment reads / fold beside the other's MFMAs without any hand-made schedule.  Price: 24 KB per step for
+// half the MACs of the 256 x 128 tile (1.5 x the bytes per MAC).  One barrier per step as in the first form; mins pre-pass and lean fold as
+// in the second.
+constexpr int SH3_BM = 128, SH3_NW = 4, SH3_NS = 3;
+constexpr int SH3_STAGE = SH3_BM * 64 + SH_BN * 64 * 2;          // 24 576
+constexpr int SH3_LDS_DY = SH3_NS * SH3_STAGE;                    // token scales [128] f32
+constexpr int SH3_LDS_DD = SH3_LDS_DY + SH3_BM * 4;               // weight (d, dmin) [4 panels][32 rows] float2
+constexpr int SH3_LDS_BYTES = SH3_LDS_DD + 4 * 256;               // 75 264
+
+template <bool MINS>
+__global__ void __launch_bounds__(SH3_NW * 64, 2) k_mmq_shadow3(const shadow_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int OPS = 6;  // requests per wave and step: 2 token pieces + its panel's 4 weight pieces
+    constexpr int NM = 2;   // + per super-block: token scales, weight (d, dmin)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, kg = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int group = (qb / a.m_tiles) * 8 + xcd, mt = qb % a.m_tiles;  // (m_tiles counts 128-token tiles for this kernel)
+    if (group >= a.n_groups) return;
+    const int mi = (a.n_mat > 2 && group >= a.mat[2].group0) ? 2 : ((a.n_mat > 1 && group >= a.mat[1].group0) ? 1 : 0);
+#define MAT_SEL(f) (mi == 0 ? a.mat[0].f : (mi == 1 ? a.mat[1].f : a.mat[2].f))
+    const int gl = group - MAT_SEL(group0);
+    const int nblk = a.K / 256;
+    const int m0 = mt * SH3_BM;
+    const int tok_bytes = nblk * (int) sizeof(q8k_dev);
+    const uint32_t lds0 = (uint32_t) (uintptr_t) smem;
+    const char * const act_b = (const char *) a.act;
+    const char * const wsrc_b = MAT_SEL(planes) + (size_t) (gl * 4 + wave) * nblk * SH_PANEL_SB;
+    const char * const msrc_wb = MAT_SEL(meta) + (size_t) (gl * 4 + wave) * nblk * SH_META;
+    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+
+    auto issue_stage = [&](const int sb, const int q, const int buf) {
+        const uint32_t tb = lds0 + buf * SH3_STAGE;
+        const int l = opaque_lane();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 16 * (2 * wave + i) + (l >> 2);
+            const uint32_t toff = (uint32_t) min(m0 + row, a.M - 1) * (uint32_t) tok_bytes + (((l & 3) ^ ((row >> 2) & 3)) << 4);
+            sh_dma16s(toff, act_b + (size_t) sb * sizeof(q8k_dev) + q * 64, tb + (2 * wave + i) * 1024);
+        }
+        const char * ws = wsrc_b + ((size_t) sb * 4 + q) * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sh_dma16s((uint32_t) l * 16u, ws + i * 1024, tb + SH3_BM * 64 + wave * 4096 + i * 1024);
+    };
+    auto issue_meta = [&](const int sb) {  // token scales (waves w and w + 2 both request piece w & 1) + this wave's panel (d, dmin)
+        const int l = opaque_lane();
+        sh_dma4s((uint32_t) min(m0 + 64 * (wave & 1) + l, a.M - 1) * (uint32_t) tok_bytes + 304, act_b + (size_t) sb * sizeof(q8k_dev), lds0 + SH3_LDS_DY + (wave & 1) * 256);
+        if (l < 16) sh_dma16s((uint32_t) l * 16u, msrc_wb + (size_t) sb * SH_META + 1024, lds0 + SH3_LDS_DD + wave * 256);
+    };
+
+    sh_f16v C[2][2];
+    sh_i16v acc[2][2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                C[rt][ta][r] = 0.0f;
+                acc[0][rt][ta][r] = 0;
+                acc[1][rt][ta][r] = 0;
+            }
+    const sh_f16v zerof = C[0][0];
+    const sh_i16v zeroi = acc[0][0][0];
+
+    const int sb_lo = (int) (((int64_t) blockIdx.y * nblk) / a.ksplit), sb_hi = (int) (((int64_t) (blockIdx.y + 1) * nblk) / a.ksplit);
+    const int g_lo = sb_lo * 4, g_last = sb_hi * 4 - 1;
+    if constexpr (MINS) {
+        // ---- mins pre-pass: C = - sum_sb dy dmin (sum_j m_j bsum_j).  The stage ring is still empty: two buffers of [token bsums 128 x 32 B |
+        // token scales 512 B | weight metadata 4 x 1280 B] = 9.5 KB live at its start
+        constexpr int MB = SH3_BM * 32 + SH3_BM * 4 + 4 * SH_META;
+        auto issue_mins = [&](const int sb) {
+            const uint32_t mb = lds0 + (sb & 1) * MB;
+            const int l = opaque_lane();
+            const char * ab = act_b + (size_t) sb * sizeof(q8k_dev);
+            sh_dma16s((uint32_t) min(m0 + 32 * wave + (l >> 1), a.M - 1) * (uint32_t) tok_bytes + 256 + (l & 1) * 16, ab, mb + wave * 1024);
+            sh_dma4s((uint32_t) min(m0 + 64 * (wave & 1) + l, a.M - 1) * (uint32_t) tok_bytes + 304, ab, mb + SH3_BM * 32 + (wave & 1) * 256);
+            const char * ms = msrc_wb + (size_t) sb * SH_META;
+            sh_dma16s((uint32_t) l * 16u, ms, mb + SH3_BM * 32 + SH3_BM * 4 + wave * SH_META);
+            if (l < 16) sh_dma16s((uint32_t) l * 16u, ms + 1024, mb + SH3_BM * 32 + SH3_BM * 4 + wave * SH_META + 1024);
+        };
+        issue_mins(sb_lo);
+        for (int sb = sb_lo; sb < sb_hi; ++sb) {
+            issue_mins(min(sb + 1, sb_hi - 1));
+            sh_wait<4>();
+            __syncthreads();
+            const char * mbase = smem + (sb & 1) * MB;
+            const char * wmeta = mbase + SH3_BM * 32 + SH3_BM * 4 + (2 * wn) * SH_META;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const float dmin = *(const float *) (wmeta + rt * SH_META + 1024 + fr * 8 + 4);
+                const sh_half8 fbm = *(const sh_half8 *) (wmeta + rt * SH_META + fr * 32 + kg * 16);
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) {
+                    const sh_half8 fam = *(const sh_half8 *) (mbase + (64 * wm + 32 * ta + fr) * 32 + kg * 16);
+                    const sh_f16v am = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fbm, zerof, 0, 0, 0);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 t = *(const float4 *) (mbase + SH3_BM * 32 + (64 * wm + 32 * ta + 8 * g4 + 4 * kg) * 4);
+                        const float dy[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) C[rt][ta][4 * g4 + e] = __builtin_fmaf(-dy[e], dmin * am[4 * g4 + e], C[rt][ta][4 * g4 + e]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        sh_wait<0>();
+        __syncthreads();
+    }
+
+    const int swz = (fr >> 2) & 3;
+    const int co0 = ((0 + kg) ^ swz) << 4, co1 = ((2 + kg) ^ swz) << 4;
+    const char * const tfrag = smem + (64 * wm + fr) * 64;
+    const char * const wfrag = smem + SH3_BM * 64 + (2 * wn) * 4096 + fr * 64;
+    // prologue: steps 0 and 1 (three stages, requested two steps ahead)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) issue_stage(min(g_lo + g, g_last) >> 2, min(g_lo + g, g_last) & 3, g);
+    int buf = 0;  // stage of the current step (steps are not a multiple of three: a running index)
+    for (int sb = sb_lo; sb < sb_hi; ++sb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // this wave's pieces of step (sb, q) have landed: requested since are the next step's (+ this super-block's metadata at q = 1:
+            // it was requested at q = 0 behind the barrier, in front of that step's stage)
+            if (q == 1) sh_wait<OPS + NM>(); else sh_wait<OPS>();
+            __syncthreads();
+            if (q == 0) issue_meta(sb);
+            {
+                const int g2 = min(sb * 4 + q + 2, g_last);
+                int nb = buf + 2;
+                nb = nb >= 3 ? nb - 3 : nb;
+                issue_stage(g2 >> 2, g2 & 3, nb);
+            }
+            const char * tb = tfrag + buf * SH3_STAGE;
+            const char * wb = wfrag + buf * SH3_STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int co = kk == 0 ? co0 : co1;
+                sh_i4v fa[2], fb[2][2];
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) fa[ta] = *(const sh_i4v *) (tb + ta * 2048 + co);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) fb[rt][p] = *(const sh_i4v *) (wb + rt * 4096 + p * 2048 + co);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            acc[p][rt][ta] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ta], fb[rt][p], (q == 0 && kk == 0) ? zeroi : acc[p][rt][ta], 0, 0, 0);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        // ---- fold (metadata of sb: requested at q = 0, older than the stage waited for at q = 2, visible since that step's barrier)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const float d = *(const float *) (smem + SH3_LDS_DD + (2 * wn + rt) * 256 + fr * 8);
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 t = *(const float4 *) (smem + SH3_LDS_DY + (64 * wm + 32 * ta + 8 * g4 + 4 * kg) * 4);
+                    const float dy[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        const int is = (acc[1][rt][ta][r] << 7) + acc[0][rt][ta][r];
+                        C[rt][ta][r] = __builtin_fmaf(dy[e], d * (float) is, C[rt][ta][r]);
+                    }
+                }
+            }
+        }
+    }
+    sh_wait<0>();
+    const int mN = MAT_SEL(N);
+    float * const m_dst = a.ksplit > 1 ? MAT_SEL(part) + (size_t) blockIdx.y * a.M * mN : MAT_SEL(dst);
+    const int64_t m_dst_stride = a.ksplit > 1 ? (int64_t) mN : MAT_SEL(dst_stride);
+    const float * const m_add = a.ksplit > 1 ? nullptr : MAT_SEL(add);
+    const int64_t m_add_stride = MAT_SEL(add_stride);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int n = gl * SH_BN + 64 * wn + 32 * rt + fr;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta) {
+            const int mb = m0 + 64 * wm + 32 * ta + 4 * kg;
+            if (m_add) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) C[rt][ta][r] += m_add[(size_t) min(mb + (r & 3) + 8 * (r >> 2), a.M - 1) * m_add_stride + n];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) m_dst[(size_t) m * m_dst_stride + n] = C[rt][ta][r];
+            }
+        }
+    }
+#undef MAT_SEL
+}
+
 }  // namespace mi355x

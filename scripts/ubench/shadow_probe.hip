@@ -78,6 +78,8 @@ int main(int argc, char ** argv) {
     std::mt19937_64 rng(1234);
     CK(hipFuncSetAttribute((const void *) k_mmq_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
     CK(hipFuncSetAttribute((const void *) k_mmq_shadow<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void *) k_mmq_shadow3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SH3_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void *) k_mmq_shadow3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SH3_LDS_BYTES));
     CK(hipFuncSetAttribute((const void *) k_mmq_shadow_pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SH2_LDS_BYTES));
     CK(hipFuncSetAttribute((const void *) k_mmq_shadow_pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SH2_LDS_BYTES));
     for (const shape & sh : shapes) {
@@ -131,7 +133,7 @@ int main(int argc, char ** argv) {
         a.K = sh.K; a.M = sh.M; a.act = dA;
         a.mat[0] = {planes, meta, sh.N, 0, dst, (int64_t) sh.N, nullptr, 0, part};
         a.n_groups = sh.N / 128;
-        a.m_tiles = (sh.M + SH_BM - 1) / SH_BM;
+        a.m_tiles = (sh.M + (SH_FORM == 3 ? SH3_BM : SH_BM) - 1) / (SH_FORM == 3 ? SH3_BM : SH_BM);
         a.ksplit = sh.ks;
         unsigned long long * d_st = nullptr;
 #if SH_STAMP
@@ -141,7 +143,10 @@ int main(int argc, char ** argv) {
 #endif
         const dim3 grid((unsigned) (((a.n_groups + 7) / 8) * 8 * a.m_tiles), (unsigned) sh.ks);
         auto launch = [&]() {
-#if SH_FORM == 2
+#if SH_FORM == 3
+            if (sh.qt == 6) hipLaunchKernelGGL(k_mmq_shadow3<false>, grid, dim3(SH3_NW * 64), SH3_LDS_BYTES, 0, a);
+            else hipLaunchKernelGGL(k_mmq_shadow3<true>, grid, dim3(SH3_NW * 64), SH3_LDS_BYTES, 0, a);
+#elif SH_FORM == 2
             if (sh.qt == 6) hipLaunchKernelGGL(k_mmq_shadow_pp<false>, grid, dim3(SH_NW * 64), SH2_LDS_BYTES, 0, a);
             else hipLaunchKernelGGL(k_mmq_shadow_pp<true>, grid, dim3(SH_NW * 64), SH2_LDS_BYTES, 0, a);
 #else
