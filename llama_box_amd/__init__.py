@@ -148,7 +148,7 @@ _SIGS = {
     "ggml_gallocr_alloc_graph": (_B, [_P, C.POINTER(CGraph)]), "ggml_gallocr_get_buffer_size": (_SZ, [_P, _I]),
     # llama_lite
     "llm_preset": (_I, [_S, C.POINTER(HParams)]),
-    "llm_model_synth": (_P, [C.POINTER(HParams), C.c_uint64, _P, _I, _I, _P]), "llm_synth_gguf": (_I, [C.POINTER(HParams), C.c_uint64, _S]),
+    "llm_model_synth": (_P, [C.POINTER(HParams), C.c_uint64, _P, _I, _I, _P]), "llm_model_synth_split": (_P, [C.POINTER(HParams), C.c_uint64, _P, _P]), "llm_synth_gguf": (_I, [C.POINTER(HParams), C.c_uint64, _S]),
     "llm_model_load": (_P, [_S, _P]), "llm_model_free": (None, [_P]), "llm_model_hparams": (C.POINTER(HParams), [_P]),
     "llm_model_stream_bytes": (C.c_uint64, [_P]), "llm_model_total_bytes": (C.c_uint64, [_P]), "llm_model_tensor": (TP, [_P, _S]),
     "llm_context_new": (_P, [_P, _P, COMPUTE_FN, C.POINTER(ContextParams)]), "llm_context_free": (None, [_P]),

@@ -514,7 +514,7 @@ static int api_tp_init(ggml_backend_t be, int rank, int world, const void * uid,
 }
 static int api_tp_get_unique_id(void * out, size_t n) { return tp_get_unique_id(out, n); }
 static ggml_backend_buffer_type_t api_split_buffer_type(int main_device, const float * tensor_split) { return split_buffer_type(main_device, tensor_split); }
-static void api_split_rows(int64_t nrows, const float * tensor_split, int n_dev, int64_t * row0) { split_rows(nrows, tensor_split, n_dev, 64, row0); }
+static void api_split_rows(int64_t nrows, const float * tensor_split, int n_dev, int64_t * row0) { split_rows(nrows, tensor_split, n_dev, nrows % 256 == 0 ? 256 : 64, row0); }  // (the granule sbuf_init_tensor uses)
 static ggml_backend_buffer_type_t api_tp_rowpar_buft(int device) {
     if (device < 0 || device >= (int) g_reg_ctx.devices.size()) return nullptr;
     return &dctx(g_reg_ctx.devices[device])->buft_rowpar;

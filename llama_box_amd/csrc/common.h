@@ -120,6 +120,7 @@ struct cached_graph {
     hipGraphExec_t exec = nullptr;
     int seen = 0;
     uint64_t last_use = 0;
+    int64_t allreduces = 0;  // reductions / collectives recorded in the graph (counted again at every replay: stats::allreduces)
 };
 
 struct timing_slot {
@@ -202,9 +203,13 @@ ggml_backend_dev_t logical_device(int i);
 // ---- row-split weight buffers, -sm row (split.cpp) ----
 struct split_tensor_info {
     int n_dev;
-    int64_t row0[GGML_MI355X_MAX_DEVICES + 1];  // device d owns rows [row0[d], row0[d + 1])
-    void * slice[GGML_MI355X_MAX_DEVICES];      // its rows, GGUF bytes verbatim, in device d's memory
-    size_t row_bytes;
+    int kind;                                   // 0: cut by ROWS (output features: wq / wk / wv / ffn_gate / ffn_up / output — "column-parallel"),
+                                                // 1: cut along K (input features, whole 256-value super-blocks: attn_output / ffn_down — "row-parallel":
+                                                //    every device holds all rows of its K range and produces a partial sum)
+    int64_t row0[GGML_MI355X_MAX_DEVICES + 1];  // kind 0: device d owns rows [row0[d], row0[d + 1]); kind 1: VALUES [row0[d], row0[d + 1]) of every row
+    void * slice[GGML_MI355X_MAX_DEVICES];      // its part, GGUF bytes verbatim (kind 1: rows of (row0[d+1] - row0[d]) / blck blocks), in device d's memory
+    size_t row_bytes;                           // bytes of a FULL row
+    size_t slice_row_bytes[GGML_MI355X_MAX_DEVICES];  // bytes of a row of device d's slice (kind 0: = row_bytes)
 };
 void split_rows(int64_t nrows, const float * tensor_split, int n_dev, int64_t granule, int64_t * row0);
 ggml_backend_buffer_type_t split_buffer_type(int main_device, const float * tensor_split);
@@ -214,6 +219,11 @@ bool buffer_is_split(ggml_backend_buffer_t b);
 const split_tensor_info * split_info(const ggml_tensor * t);
 bool split_mul_mat_supported(const ggml_tensor * op);
 bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor * b, ggml_tensor * dst);
+// row-parallel weight (kind 1): scatter b's K ranges, per-device partial products, in-stream sum on the main device (+ optional addend)
+bool run_split_rowpar(backend_ctx * c, const ggml_tensor * w, const ggml_tensor * b, ggml_tensor * dst, const ggml_tensor * add);
+// the whole FFN on sharded weights: broadcast x once, gate / up / SwiGLU / down on every device's own rows of the hidden layer, ONE sum
+bool split_ffn_applies(const ggml_tensor * wg, const ggml_tensor * wu, const ggml_tensor * wd);
+bool run_split_ffn(backend_ctx * c, const ggml_tensor * wg, const ggml_tensor * wu, const ggml_tensor * wd, const ggml_tensor * x, ggml_tensor * dst, const ggml_tensor * add);
 void free_split_helpers(backend_ctx * c);
 
 // ---- graph execution (graph.cpp) ----

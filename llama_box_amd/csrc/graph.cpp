@@ -477,6 +477,7 @@ static bool quant_consumers_only(const exec_state & st, int at, const ggml_tenso
             if (u->src[s] != t) continue;
             const ggml_tensor * wt = u->src[0];
             if (!(u->op == GGML_OP_MUL_MAT && s == 1 && (wt->type == GGML_TYPE_Q4_K || wt->type == GGML_TYPE_Q5_K || wt->type == GGML_TYPE_Q6_K))) return false;
+            if (buffer_is_split(wt->buffer)) return false;  // (split weights read the f32 activations on other devices: the tensor itself must exist)
             last = j;
             n_cons++;
         }
@@ -510,7 +511,8 @@ static bool can_defer_norm(const exec_state & st, int i, const ggml_tensor * n, 
             if (t->src[s] != m) continue;
             const ggml_tensor * wt = t->src[0];
             const bool ok = t->op == GGML_OP_MUL_MAT && s == 1 && (wt->type == GGML_TYPE_Q4_K || wt->type == GGML_TYPE_Q5_K || wt->type == GGML_TYPE_Q6_K || wt->type == GGML_TYPE_Q8_0) &&
-                            wt->ne[2] == 1 && wt->ne[3] == 1 && ggml_abi_is_contiguous(t) && !(st.c->tp && buffer_is_rowpar(wt->view_src ? wt->view_src->buffer : wt->buffer));
+                            wt->ne[2] == 1 && wt->ne[3] == 1 && ggml_abi_is_contiguous(t) && !(st.c->tp && buffer_is_rowpar(wt->view_src ? wt->view_src->buffer : wt->buffer)) &&
+                            !buffer_is_split(wt->buffer);  // (a split weight's devices are sent the f32 row: it has to be written)
             if (!ok) return false;
             last = j;
             n_cons++;
@@ -1257,8 +1259,38 @@ static int run_node(exec_state & st, int i) {
                 c->st.kernel_launches++;
                 return 1;
             }
-            if (buffer_is_split(a->buffer)) {  // row-split weights (-sm row): broadcast, per-device rows, gather — no fusion with neighbours
-                if (!run_split_mul_mat(c, a, b, n)) return -1;
+            if (buffer_is_split(a->buffer)) {  // weights in the split buffer type (-sm row): split.cpp
+                const split_tensor_info * si = split_info(a);
+                if (!si) return -1;
+                // the FFN on sharded weights: MUL_MAT(gate) MUL_MAT(up) GLU MUL_MAT(down) [ADD residual] as one sharded chain with ONE sum
+                ggml_tensor * n2 = next(1), * n3 = next(2), * n4 = next(3);
+                if (fuse && si->kind == 0 && n2 && n3 && n4 && n2->op == GGML_OP_MUL_MAT && n2->src[1] == b && buffer_is_split(n2->src[0]->buffer) &&
+                    n3->op == GGML_OP_GLU && n3->op_params[0] == GGML_GLU_OP_SWIGLU && n3->op_params[1] == 0 && n3->src[0] == n && n3->src[1] == n2 &&
+                    n4->op == GGML_OP_MUL_MAT && n4->src[1] == n3 && buffer_is_split(n4->src[0]->buffer) && single_use(st, n) && single_use(st, n2) && single_use(st, n3) &&
+                    split_mul_mat_supported(n2) && ggml_abi_is_contiguous(n3) && ggml_abi_is_contiguous(n4) && n4->type == GGML_TYPE_F32 && split_ffn_applies(a, n2->src[0], n4->src[0])) {
+                    ggml_tensor * a5 = next(4);
+                    const ggml_tensor * o5 = (a5 && single_use(st, n4)) ? add_partner(a5, n4) : nullptr;
+                    if (o5 && same_shape(o5, n4)) {
+                        if (!run_split_ffn(c, a, n2->src[0], n4->src[0], b, a5, o5)) return -1;
+                        c->st.fused_nodes += 4;
+                        return 5;
+                    }
+                    if (!run_split_ffn(c, a, n2->src[0], n4->src[0], b, n4, nullptr)) return -1;
+                    c->st.fused_nodes += 3;
+                    return 4;
+                }
+                if (si->kind == 1) {  // row-parallel (attn_output, or ffn_down outside the chain above): K ranges out, partial sums back, + residual
+                    ggml_tensor * a1 = next(1);
+                    const ggml_tensor * o1 = (fuse && a1 && single_use(st, n)) ? add_partner(a1, n) : nullptr;
+                    if (o1 && same_shape(o1, n)) {
+                        if (!run_split_rowpar(c, a, b, a1, o1)) return -1;
+                        c->st.fused_nodes += 1;
+                        return 2;
+                    }
+                    if (!run_split_rowpar(c, a, b, n, nullptr)) return -1;
+                    return 1;
+                }
+                if (!run_split_mul_mat(c, a, b, n)) return -1;  // column-parallel: broadcast, per-device rows, gather
                 return 1;
             }
             const bool rowpar = tp_active(c) && buffer_is_rowpar(a->view_src ? a->view_src->buffer : a->buffer);
@@ -1479,7 +1511,7 @@ static int run_node(exec_state & st, int i) {
                 const ggml_tensor * mm = j < g->n_nodes ? g->nodes[j] : nullptr;
                 const ggml_tensor * w = mm ? mm->src[0] : nullptr;
                 const bool kq = w && (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K || w->type == GGML_TYPE_Q8_0) && w->ne[2] == 1 && w->ne[3] == 1 &&
-                                rows_contig(w) && (w->ne[0] % 256) == 0;
+                                rows_contig(w) && (w->ne[0] % 256) == 0 && !buffer_is_split(w->buffer);
                 if (S > 0 && view && mm && mm->op == GGML_OP_MUL_MAT && mm->src[1] == view && kq && w->ne[0] == n->ne[0] * n->ne[1] && ggml_abi_nelements(view) == w->ne[0] &&
                     use_count(st, view) == 1 && !(view->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(mm) && mm->type == GGML_TYPE_F32 &&
                     !(tp_active(c) && buffer_is_rowpar(w->view_src ? w->view_src->buffer : w->buffer))) {
@@ -1609,7 +1641,10 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     c->tick++;
     bool has_split = false;  // multi-device launches + peer copies: executed eagerly (capture across devices is left for a box that has them)
     for (int i = 0; i < g->n_nodes && !has_split; ++i) has_split = g->nodes[i]->op == GGML_OP_MUL_MAT && buffer_is_split(g->nodes[i]->src[0]->buffer);
-    const bool want_graph = c->opt.graphs && !c->opt.timing && g->n_nodes >= 8 && !has_split;
+    // (graphs that launch on several devices' streams: captured only on request — GGML_MI355X_SPLIT_GRAPHS=1 — until that has run on a box
+    // with more than one GPU; the fork / join over events is capturable and is exercised on logical devices by tests/test_gpu_split.py)
+    static const bool split_graphs = getenv("GGML_MI355X_SPLIT_GRAPHS") && atoi(getenv("GGML_MI355X_SPLIT_GRAPHS")) != 0;
+    const bool want_graph = c->opt.graphs && !c->opt.timing && g->n_nodes >= 8 && (!has_split || split_graphs);
     if (!want_graph) {
         c->st.eager_graphs++;
         return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
@@ -1626,6 +1661,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         }
         c->st.graph_launch_host_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         c->st.graph_launches++;
+        c->st.allreduces += cg.allreduces;
         return GGML_STATUS_SUCCESS;
     }
     if (cg.seen < 2 || cg.seen > 1000000) {  // first sighting: run eagerly (one-off prefill graphs never pay for capture)
@@ -1651,8 +1687,10 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
     }
     c->capturing = true;
+    const int64_t red0 = c->st.allreduces;
     const bool ok = run_nodes(c, g, wp);
     c->capturing = false;
+    const int64_t red_captured = c->st.allreduces - red0;
     hipGraph_t graph = nullptr;
     const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
     if (!ok || e_end != hipSuccess || graph == nullptr) {
@@ -1673,6 +1711,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     }
     cg.graph = graph;
     cg.exec = exec;
+    cg.allreduces = red_captured;
     c->st.graph_captures++;
     if (hipGraphLaunch(cg.exec, c->stream) != hipSuccess) {
         (void) hipGetLastError();

@@ -123,6 +123,21 @@ __global__ void __launch_bounds__(256) k_binary(const int op, const tdesc a, con
         *(float *) (pd + i0 * d.nb[0]) = r;
     }
 }
+__global__ void __launch_bounds__(256) k_reduce_parts(const reduce_parts p, const float * __restrict__ add, float * __restrict__ dst, const int64_t n4) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = add ? ((const float4 *) add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int d = 0; d < p.n; ++d) {
+        const float4 v = ((const float4 *) p.part[d])[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    ((float4 *) dst)[i] = acc;
+}
+void launch_reduce_parts(hipStream_t s, const reduce_parts & p, const float * add, float * dst, int64_t n) {
+    const int64_t n4 = n / 4;  // (row lengths are multiples of 4: checked by the caller)
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned) ((n4 + 255) / 256)), dim3(256), 0, s, p, add, dst, n4);
+}
+
 void launch_binary(hipStream_t s, int op, const tdesc & a, const tdesc & b, const tdesc & d) {
     const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
     hipLaunchKernelGGL(k_binary, dim3((unsigned) rows), dim3(256), 0, s, op, a, b, d);

@@ -10,6 +10,17 @@
 // it is: broadcast the activations, every device computes its rows, the row ranges are gathered into the main device's dst.  No
 // reduction is involved (rows are independent), so results are bit-identical to the single-device kernels.
 //
+// Round 3: the TENSOR-PARALLEL layout north_star asks for is reachable through this interface.  A weight whose name says it consumes a
+// sharded activation — attn_output, ffn_down — is cut along K instead (whole 256-value super-blocks: "row-parallel"), in the same
+// proportions (256-row granules) as the rows of the weights that produce that activation.  Then
+//   * the FFN runs sharded end to end (run_split_ffn): x is broadcast once, every device computes gate / up / SwiGLU for ITS rows of the
+//     hidden layer and multiplies them with ITS K range of ffn_down; the only exchange is the sum of the n_dev partial rows — one
+//     in-stream reduction by the main device (a kernel that reads the partials out of the peers' memory over xGMI, device order, then the
+//     residual), no gather of the 2 x n_ff hidden values;
+//   * attn_output takes the K ranges of the attention result (scatter instead of broadcast) and ends in the same reduction:
+//     two reductions per layer, `allreduces` counts them.  Attention itself and the KV cache stay on the main device — the host
+//     allocates them there (llama.cpp keeps KV and non-matmul tensors in the main GPU's buffer under -sm row).
+//
 // MI355X-first choices: slices live in per-device hipMalloc allocations made at init_tensor time (GGUF bytes verbatim: the
 // kernels address a slice exactly like a whole tensor); the exchange is P2P over xGMI — hipMemcpyPeerAsync on the owning device's
 // stream, ordered by events against the main stream — 16 KB of activations out and N_d floats back per device for a decode token;
@@ -86,14 +97,22 @@ static enum ggml_status sbuf_init_tensor(ggml_backend_buffer_t b, ggml_tensor * 
     split_tensor_info info{};
     info.n_dev = c->bt->n_dev;
     info.row_bytes = ggml_abi_row_size(t->type, t->ne[0]);
-    split_rows(t->ne[1], c->bt->split, info.n_dev, 64, info.row0);
+    const int64_t blck = ggml_abi_blck_size(t->type);
+    // row-parallel weights by their GGUF names (llama.cpp's tensor names: model.patch:20-30 corroborates the style); needs whole
+    // 256-value super-blocks per device and a quantised type; anything else is cut by rows
+    const bool by_k = (strstr(t->name, "attn_output") || strstr(t->name, "ffn_down")) && blck > 1 && (t->ne[0] % 256) == 0 && !getenv("GGML_MI355X_SPLIT_ROWS_ONLY");
+    info.kind = by_k ? 1 : 0;
+    if (by_k) split_rows(t->ne[0], c->bt->split, info.n_dev, 256, info.row0);
+    else split_rows(t->ne[1], c->bt->split, info.n_dev, t->ne[1] % 256 == 0 ? 256 : 64, info.row0);  // (256-row granules where the rows can become another weight's K range)
     for (int d = 0; d < info.n_dev; ++d) {
-        const int64_t rows = info.row0[d + 1] - info.row0[d];
-        if (rows <= 0) continue;
+        const int64_t part = info.row0[d + 1] - info.row0[d];
+        info.slice_row_bytes[d] = by_k ? (size_t) (part / blck) * ggml_abi_type_size(t->type) : info.row_bytes;
+        if (part <= 0) continue;
+        const size_t bytes = by_k ? (size_t) t->ne[1] * info.slice_row_bytes[d] : (size_t) part * info.row_bytes;
         HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
-        if (hipMalloc(&info.slice[d], (size_t) rows * info.row_bytes + 256) != hipSuccess) {
+        if (hipMalloc(&info.slice[d], bytes + 256) != hipSuccess) {
             (void) hipGetLastError();
-            MI_ERR("split buffer: allocating %lld rows of '%s' on device %d failed", (long long) rows, t->name, d);
+            MI_ERR("split buffer: allocating %.1f MiB of '%s' on device %d failed", bytes / 1048576.0, t->name, d);
             return GGML_STATUS_ALLOC_FAILED;
         }
     }
@@ -112,11 +131,15 @@ static void sbuf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void
         MI_ERR("split buffer: set_tensor of '%s' must cover the whole tensor", t->name);
         abort();
     }
+    const size_t ts = ggml_abi_type_size(t->type), blck = (size_t) ggml_abi_blck_size(t->type);
     for (int d = 0; d < info->n_dev; ++d) {
         const int64_t rows = info->row0[d + 1] - info->row0[d];
         if (rows <= 0) continue;
         HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
-        HIP_CHECK(hipMemcpy(info->slice[d], (const char *) data + (size_t) info->row0[d] * info->row_bytes, (size_t) rows * info->row_bytes, hipMemcpyHostToDevice));
+        if (info->kind == 1)  // device d's K range of every row
+            HIP_CHECK(hipMemcpy2D(info->slice[d], info->slice_row_bytes[d], (const char *) data + (size_t) info->row0[d] / blck * ts, info->row_bytes, info->slice_row_bytes[d], (size_t) t->ne[1], hipMemcpyHostToDevice));
+        else
+            HIP_CHECK(hipMemcpy(info->slice[d], (const char *) data + (size_t) info->row0[d] * info->row_bytes, (size_t) rows * info->row_bytes, hipMemcpyHostToDevice));
     }
 }
 static void sbuf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t offset, size_t size) {
@@ -125,11 +148,15 @@ static void sbuf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void
         MI_ERR("split buffer: get_tensor of '%s' must cover the whole tensor", t->name);
         abort();
     }
+    const size_t ts = ggml_abi_type_size(t->type), blck = (size_t) ggml_abi_blck_size(t->type);
     for (int d = 0; d < info->n_dev; ++d) {
         const int64_t rows = info->row0[d + 1] - info->row0[d];
         if (rows <= 0) continue;
         HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
-        HIP_CHECK(hipMemcpy((char *) data + (size_t) info->row0[d] * info->row_bytes, info->slice[d], (size_t) rows * info->row_bytes, hipMemcpyDeviceToHost));
+        if (info->kind == 1)
+            HIP_CHECK(hipMemcpy2D((char *) data + (size_t) info->row0[d] / blck * ts, info->row_bytes, info->slice[d], info->slice_row_bytes[d], info->slice_row_bytes[d], (size_t) t->ne[1], hipMemcpyDeviceToHost));
+        else
+            HIP_CHECK(hipMemcpy((char *) data + (size_t) info->row0[d] * info->row_bytes, info->slice[d], (size_t) rows * info->row_bytes, hipMemcpyDeviceToHost));
     }
 }
 static void sbuf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t value, size_t offset, size_t size) {
@@ -139,7 +166,7 @@ static void sbuf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t
         const int64_t rows = info->row0[d + 1] - info->row0[d];
         if (rows <= 0) continue;
         HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
-        HIP_CHECK(hipMemset(info->slice[d], value, (size_t) rows * info->row_bytes));
+        HIP_CHECK(hipMemset(info->slice[d], value, info->kind == 1 ? (size_t) t->ne[1] * info->slice_row_bytes[d] : (size_t) rows * info->row_bytes));
     }
 }
 static void sbuf_clear(ggml_backend_buffer_t, uint8_t) {}  // (slices are written whole by set_tensor; nothing to clear before that)
@@ -215,6 +242,11 @@ static split_helper * helper_for(backend_ctx * c, int d) {
             if (hipDeviceCanAccessPeer(&can, h->ordinal, c->device) == hipSuccess && can) {
                 if (hipDeviceEnablePeerAccess(c->device, 0) != hipSuccess) (void) hipGetLastError();  // (already enabled is fine)
             }
+            // ... and the main device reads the helpers' partial products in its reduction kernel (launch_reduce_parts)
+            (void) hipSetDevice(c->device);
+            if (hipDeviceCanAccessPeer(&can, c->device, h->ordinal) == hipSuccess && can) {
+                if (hipDeviceEnablePeerAccess(h->ordinal, 0) != hipSuccess) (void) hipGetLastError();
+            }
         }
         (void) hipSetDevice(c->device);
         c->split_helpers[d] = h;
@@ -251,6 +283,7 @@ bool split_mul_mat_supported(const ggml_tensor * op) {
 bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor * b, ggml_tensor * dst) {
     const split_tensor_info * info = split_info(w);
     if (!info) return false;
+    if (info->kind == 1) return run_split_rowpar(c, w, b, dst, nullptr);
     const int64_t K = w->ne[0], N = w->ne[1], M = b->ne[1] * b->ne[2] * b->ne[3];
     const size_t x_bytes = ggml_abi_nbytes(b);
     const int act_kind = w->type == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K;
@@ -283,7 +316,8 @@ bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor
         char * qd = h->ws + ((x_bytes + 255) & ~(size_t) 255);
         float * yd = (float *) (qd + ((q_bytes + 255) & ~(size_t) 255));
         HIP_TRY(hipStreamWaitEvent(h->stream, ready, 0), false);
-        HIP_TRY(hipMemcpyPeerAsync(xd, h->ordinal, b->data, c->device, x_bytes, h->stream), false);
+        if (h->ordinal == c->device) HIP_TRY(hipMemcpyAsync(xd, b->data, x_bytes, hipMemcpyDeviceToDevice, h->stream), false);
+        else HIP_TRY(hipMemcpyPeerAsync(xd, h->ordinal, b->data, c->device, x_bytes, h->stream), false);
         mmvq_args a{};
         a.W = (const uint8_t *) info->slice[d];
         a.w_nb1 = (int64_t) info->row_bytes;
@@ -304,8 +338,9 @@ bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor
             launch_mmvq(h->stream, a, 1);  // (columns in chunks of 8: functional for prompt batches, not tuned — DESIGN.md §6)
         }
         // gather: rows [row0, row0 + rows) of every column of dst
-        HIP_TRY(hipMemcpy2DAsync((float *) dst->data + info->row0[d], (size_t) N * sizeof(float), yd, (size_t) rows * sizeof(float), (size_t) rows * sizeof(float), (size_t) M,
-                                 hipMemcpyDeviceToDevice, h->stream), false);
+        if (M == 1) HIP_TRY(hipMemcpyAsync((float *) dst->data + info->row0[d], yd, (size_t) rows * sizeof(float), hipMemcpyDeviceToDevice, h->stream), false);
+        else HIP_TRY(hipMemcpy2DAsync((float *) dst->data + info->row0[d], (size_t) N * sizeof(float), yd, (size_t) rows * sizeof(float), (size_t) rows * sizeof(float), (size_t) M,
+                                      hipMemcpyDeviceToDevice, h->stream), false);
         HIP_TRY(hipEventRecord(h->ev, h->stream), false);
         c->st.kernel_launches += 1;
     }
@@ -313,6 +348,135 @@ bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor
     for (int d = 0; d < info->n_dev; ++d)
         if (info->row0[d + 1] > info->row0[d]) HIP_TRY(hipStreamWaitEvent(c->stream, c->split_helpers[d]->ev, 0), false);
     return hipGetLastError() == hipSuccess;
+}
+
+
+// ------------------------------------------------------------------------------------------------ tensor-parallel forms
+static bool helper_ws(backend_ctx * c, split_helper * h, size_t need) {
+    if (need <= h->ws_size) return true;
+    if (c->capturing) return false;  // (sized on the eager first sighting of a topology; never inside a capture)
+    HIP_TRY(hipStreamSynchronize(h->stream), false);
+    if (h->ws) (void) hipFree(h->ws);
+    h->ws = nullptr;
+    h->ws_size = 0;
+    if (hipMalloc((void **) &h->ws, need + (1u << 20)) != hipSuccess) {
+        (void) hipGetLastError();
+        MI_ERR("split buffer: %.1f MiB of scratch on device %d failed", (need + (1u << 20)) / 1048576.0, h->ordinal);
+        return false;
+    }
+    h->ws_size = need + (1u << 20);
+    return true;
+}
+static size_t al256(size_t n) { return (n + 255) & ~(size_t) 255; }
+// columns of `M` f32 values each at `x` (row stride K): one mat-vec (M = 1: f32 prologue inside the kernel) or quantise + multi-column kernel
+static void slice_matmul(hipStream_t s, int type, const void * W, const void * W2, int64_t w_nb1, int64_t K, int64_t N, int64_t M, const float * x, char * q8, float * out) {
+    mmvq_args a{};
+    a.W = (const uint8_t *) W;
+    a.W2 = (const uint8_t *) W2;
+    a.w_nb1 = w_nb1;
+    a.type = type;
+    a.K = (int) K;
+    a.N = (int) N;
+    a.dst = out;
+    a.dst_stride = N;
+    if (M == 1) {
+        a.ncols = 1;
+        a.x = x;
+    } else {
+        const int kind = type == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K;
+        tdesc xd{(char *) x, {K, M, 1, 1}, {4, K * 4, K * M * 4, K * M * 4}, GGML_TYPE_F32};
+        launch_quantize_act(s, kind, xd, q8);
+        a.ncols = (int) M;
+        a.act = q8;
+    }
+    launch_mmvq(s, a, 1);
+}
+
+static bool join_and_reduce(backend_ctx * c, const split_tensor_info * info, float * const * parts, const ggml_tensor * add, ggml_tensor * dst) {
+    HIP_TRY(hipSetDevice(c->device), false);
+    reduce_parts rp{};
+    for (int d = 0; d < info->n_dev; ++d) {
+        if (info->row0[d + 1] <= info->row0[d]) continue;
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->split_helpers[d]->ev, 0), false);
+        rp.part[rp.n++] = parts[d];
+    }
+    launch_reduce_parts(c->stream, rp, add ? (const float *) add->data : nullptr, (float *) dst->data, ggml_abi_nelements(dst));
+    c->st.kernel_launches++;
+    c->st.allreduces++;
+    return hipGetLastError() == hipSuccess;
+}
+
+bool run_split_rowpar(backend_ctx * c, const ggml_tensor * w, const ggml_tensor * b, ggml_tensor * dst, const ggml_tensor * add) {
+    const split_tensor_info * info = split_info(w);
+    if (!info || info->kind != 1 || (ggml_abi_nelements(dst) % 4) != 0) return false;
+    const int64_t K = w->ne[0], N = w->ne[1], M = b->ne[1] * b->ne[2] * b->ne[3];
+    if (!c->split_ready) HIP_TRY(hipEventCreateWithFlags(&c->split_ready, hipEventDisableTiming), false);
+    HIP_TRY(hipEventRecord(c->split_ready, c->stream), false);
+    float * parts[GGML_MI355X_MAX_DEVICES] = {nullptr};
+    for (int d = 0; d < info->n_dev; ++d) {
+        const int64_t kd = info->row0[d + 1] - info->row0[d];
+        if (kd <= 0) continue;
+        split_helper * h = helper_for(c, d);
+        if (!h) return false;
+        HIP_TRY(hipSetDevice(h->ordinal), false);
+        const size_t x_b = al256((size_t) kd * M * 4), q_b = al256(quantized_act_bytes(w->type == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K, kd, M)), p_b = al256((size_t) N * M * 4);
+        if (!helper_ws(c, h, x_b + q_b + p_b + 256)) { (void) hipSetDevice(c->device); return false; }
+        float * xd = (float *) h->ws;
+        char * qd = h->ws + x_b;
+        float * pd = (float *) (h->ws + x_b + q_b);
+        HIP_TRY(hipStreamWaitEvent(h->stream, c->split_ready, 0), false);
+        // this device's K range of every column of b
+        if (M == 1 || kd == K) HIP_TRY(hipMemcpyAsync(xd, (const float *) b->data + info->row0[d], (size_t) kd * M * 4, hipMemcpyDeviceToDevice, h->stream), false);
+        else HIP_TRY(hipMemcpy2DAsync(xd, (size_t) kd * 4, (const float *) b->data + info->row0[d], (size_t) K * 4, (size_t) kd * 4, (size_t) M, hipMemcpyDeviceToDevice, h->stream), false);
+        slice_matmul(h->stream, w->type, info->slice[d], nullptr, (int64_t) info->slice_row_bytes[d], kd, N, M, xd, qd, pd);
+        HIP_TRY(hipEventRecord(h->ev, h->stream), false);
+        c->st.kernel_launches += 1;
+        parts[d] = pd;
+    }
+    return join_and_reduce(c, info, parts, add, dst);
+}
+
+bool split_ffn_applies(const ggml_tensor * wg, const ggml_tensor * wu, const ggml_tensor * wd) {
+    const split_tensor_info * ig = split_info(wg), * iu = split_info(wu), * id = split_info(wd);
+    if (!ig || !iu || !id || ig->kind != 0 || iu->kind != 0 || id->kind != 1) return false;
+    if (wg->type != wu->type || wg->ne[0] != wu->ne[0] || wg->ne[1] != wu->ne[1] || wd->ne[0] != wg->ne[1] || wg->nb[1] != wu->nb[1]) return false;
+    if ((wg->ne[0] % 256) != 0 || (wd->ne[1] % 4) != 0) return false;
+    for (int d = 0; d <= ig->n_dev; ++d)
+        if (ig->row0[d] != iu->row0[d] || ig->row0[d] != id->row0[d]) return false;  // a device's rows of the hidden layer ARE its K range of ffn_down
+    return true;
+}
+
+bool run_split_ffn(backend_ctx * c, const ggml_tensor * wg, const ggml_tensor * wu, const ggml_tensor * wd, const ggml_tensor * x, ggml_tensor * dst, const ggml_tensor * add) {
+    const split_tensor_info * ig = split_info(wg), * iu = split_info(wu), * id = split_info(wd);
+    const int64_t E = wg->ne[0], N = wd->ne[1], M = x->ne[1] * x->ne[2] * x->ne[3];
+    if (!c->split_ready) HIP_TRY(hipEventCreateWithFlags(&c->split_ready, hipEventDisableTiming), false);
+    HIP_TRY(hipEventRecord(c->split_ready, c->stream), false);
+    float * parts[GGML_MI355X_MAX_DEVICES] = {nullptr};
+    for (int d = 0; d < ig->n_dev; ++d) {
+        const int64_t fd = ig->row0[d + 1] - ig->row0[d];
+        if (fd <= 0) continue;
+        split_helper * h = helper_for(c, d);
+        if (!h) return false;
+        HIP_TRY(hipSetDevice(h->ordinal), false);
+        const int kg = wg->type == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K, kdn = wd->type == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K;
+        const size_t x_b = al256((size_t) E * M * 4), q1_b = al256(quantized_act_bytes(kg, E, M)), a_b = al256((size_t) fd * M * 4), q2_b = al256(quantized_act_bytes(kdn, fd, M)), p_b = al256((size_t) N * M * 4);
+        if (!helper_ws(c, h, x_b + q1_b + a_b + q2_b + p_b + 256)) { (void) hipSetDevice(c->device); return false; }
+        float * xd = (float *) h->ws;
+        char * q1 = h->ws + x_b;
+        float * ad = (float *) (h->ws + x_b + q1_b);
+        char * q2 = h->ws + x_b + q1_b + a_b;
+        float * pd = (float *) (h->ws + x_b + q1_b + a_b + q2_b);
+        HIP_TRY(hipStreamWaitEvent(h->stream, c->split_ready, 0), false);
+        if (h->ordinal == c->device) HIP_TRY(hipMemcpyAsync(xd, x->data, (size_t) E * M * 4, hipMemcpyDeviceToDevice, h->stream), false);
+        else HIP_TRY(hipMemcpyPeerAsync(xd, h->ordinal, x->data, c->device, (size_t) E * M * 4, h->stream), false);
+        // silu(Wg x) * (Wu x) for this device's rows of the hidden layer, then its K range of ffn_down: nothing leaves the device in between
+        slice_matmul(h->stream, wg->type, ig->slice[d], iu->slice[d], (int64_t) ig->row_bytes, E, fd, M, xd, q1, ad);
+        slice_matmul(h->stream, wd->type, id->slice[d], nullptr, (int64_t) id->slice_row_bytes[d], fd, N, M, ad, q2, pd);
+        HIP_TRY(hipEventRecord(h->ev, h->stream), false);
+        c->st.kernel_launches += 2;
+        parts[d] = pd;
+    }
+    return join_and_reduce(c, id, parts, add, dst);
 }
 
 }  // namespace mi355x

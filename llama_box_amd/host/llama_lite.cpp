@@ -250,7 +250,7 @@ static ggml_type pick_type(const llm_hparams & hp, const char * what, int il) {
     }
 }
 
-static std::vector<tensor_plan> make_plan(const llm_hparams & hp, int tp_rank, int tp_size) {
+static std::vector<tensor_plan> make_plan(const llm_hparams & hp, int tp_rank, int tp_size, bool split_mm = false) {
     std::vector<tensor_plan> plan;
     int id = 0;
     const int64_t E = hp.n_embd, HD = hp.n_embd_head;
@@ -290,6 +290,12 @@ static std::vector<tensor_plan> make_plan(const llm_hparams & hp, int tp_rank, i
         plan.back().tie_eighths = std::min(8, hp.peaked);
         plan.back().tie_rows = hp.n_vocab;
     }
+    if (split_mm)  // -sm row: llama.cpp allocates the layers' mat-mul weights and the output matrix in the split buffer type, everything else in the main GPU's
+        for (auto & t : plan) {
+            const bool mm = t.name.find("attn_q.weight") != std::string::npos || t.name.find("attn_k.weight") != std::string::npos || t.name.find("attn_v.weight") != std::string::npos ||
+                            t.name.find("attn_output.weight") != std::string::npos || t.name.find("ffn_") != std::string::npos || t.name == "output.weight";
+            t.rowpar = mm && t.name.find("norm") == std::string::npos && ggml_abi_blck_size(t.type) > 1;
+        }
     for (auto & t : plan) {
         LLM_ASSERT(t.ne0 % ggml_abi_blck_size(t.type) == 0 && t.k_off % ggml_abi_blck_size(t.type) == 0);
     }
@@ -347,16 +353,27 @@ static void bind_tensors(llm_model * m) {
     }
 }
 
+static llm_model * model_synth_impl(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, int tp_rank, int tp_size,
+                                    ggml_backend_buffer_type_t rowpar_buft, bool split_mm);
 extern "C" struct llm_model * llm_model_synth(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, int tp_rank, int tp_size,
                                               ggml_backend_buffer_type_t rowpar_buft) {
+    return model_synth_impl(hp, seed, buft, tp_rank, tp_size, rowpar_buft, false);
+}
+// -sm row (llama-box/engine_param.hpp:902-916): one process, every mat-mul weight in `split_buft` — what the backend registry's
+// "ggml_backend_split_buffer_type" proc address returned for (main_gpu, tensor_split) — and the rest in the main device's buffer type
+extern "C" struct llm_model * llm_model_synth_split(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, ggml_backend_buffer_type_t split_buft) {
+    return model_synth_impl(hp, seed, buft, 0, 1, split_buft, true);
+}
+static llm_model * model_synth_impl(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, int tp_rank, int tp_size,
+                                    ggml_backend_buffer_type_t rowpar_buft, bool split_mm) {
     llm_model * m = new llm_model();
     m->hp = *hp;
     m->tp_rank = tp_rank;
     m->tp_size = tp_size;
     m->ctx = ggml_init({0, nullptr, true});
-    std::vector<tensor_plan> plan = make_plan(*hp, tp_rank, tp_size);
+    std::vector<tensor_plan> plan = make_plan(*hp, tp_rank, tp_size, split_mm);
     // two allocation groups: ordinary weights, and row-parallel weights (in the backend's reducing buffer type)
-    ggml_context * ctx_rp = (tp_size > 1 && rowpar_buft) ? ggml_init({0, nullptr, true}) : nullptr;
+    ggml_context * ctx_rp = nullptr;
     std::vector<ggml_tensor *> ts;
     for (auto & t : plan) {
         // tensors are created in m->ctx for lookup; row-parallel ones are allocated separately below
@@ -394,7 +411,11 @@ extern "C" struct llm_model * llm_model_synth(const struct llm_hparams * hp, uin
             o = (o + align - 1) / align * align;
             ts[i]->data = (char *) ggml_backend_buffer_get_base(b) + o;
             ts[i]->buffer = b;
-            if (b->iface.init_tensor) b->iface.init_tensor(b, ts[i]);
+            if (b->iface.init_tensor && b->iface.init_tensor(b, ts[i]) != GGML_STATUS_SUCCESS) {
+                fprintf(stderr, "llm_model_synth: init_tensor failed for %s\n", plan[i].name.c_str());
+                llm_model_free(m);
+                return nullptr;
+            }
             o += ggml_backend_buft_get_alloc_size(buft, ts[i]);
         }
     }
@@ -404,7 +425,8 @@ extern "C" struct llm_model * llm_model_synth(const struct llm_hparams * hp, uin
     for (size_t i = 0; i < plan.size(); ++i) {
         const synth_spec sp = spec_of(plan[i], seed);
         const size_t row_bytes = ggml_row_size(plan[i].type, plan[i].ne0);
-        const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t) ((64u << 20) / row_bytes));
+        // (a split buffer takes whole tensors only, like upstream's: the loader writes a tensor in one call)
+        const int64_t rows_per_chunk = (split_mm && plan[i].rowpar) ? plan[i].ne1 : std::max<int64_t>(1, (int64_t) ((64u << 20) / row_bytes));
         for (int64_t r0 = 0; r0 < plan[i].ne1; r0 += rows_per_chunk) {
             const int64_t r1 = std::min<int64_t>(plan[i].ne1, r0 + rows_per_chunk);
             stage.resize((size_t) (r1 - r0) * row_bytes);

@@ -48,6 +48,8 @@ struct llm_model;
  * row-parallel wo/down).  rowpar_buft (may be NULL when tp_size==1) is the backend's reducing buffer type. */
 struct llm_model * llm_model_synth(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, int tp_rank, int tp_size,
                                    ggml_backend_buffer_type_t rowpar_buft);
+/* -sm row: mat-mul weights in `split_buft` (the registry's "ggml_backend_split_buffer_type" result), everything else in `buft` */
+struct llm_model * llm_model_synth_split(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, ggml_backend_buffer_type_t split_buft);
 int llm_synth_gguf(const struct llm_hparams * hp, uint64_t seed, const char * path);
 struct llm_model * llm_model_load(const char * path, ggml_backend_buffer_type_t buft);
 void llm_model_free(struct llm_model * m);

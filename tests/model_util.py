@@ -16,11 +16,13 @@ def preset(name, **over):
 
 
 class Model:
-    def __init__(self, hp=None, seed=1234, buft=None, path=None, tp_rank=0, tp_size=1, rowpar_buft=None):
+    def __init__(self, hp=None, seed=1234, buft=None, path=None, tp_rank=0, tp_size=1, rowpar_buft=None, split_buft=None):
         H = L.host()
         self.H = H
         if path is not None:
             self.m = H.llm_model_load(path.encode(), buft)
+        elif split_buft is not None:  # -sm row: mat-mul weights in the split buffer type
+            self.m = H.llm_model_synth_split(C.byref(hp), seed, buft, split_buft)
         else:
             self.m = H.llm_model_synth(C.byref(hp), seed, buft, tp_rank, tp_size, rowpar_buft)
         if not self.m:

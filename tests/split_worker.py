@@ -89,5 +89,59 @@ def main():
     print("SPLIT_JSON " + json.dumps(out))
 
 
+def model_main():
+    """A whole model under -sm row on two logical devices: mat-mul weights in the split buffer type (attn_output / ffn_down cut along K, the
+    rest by rows), everything else on the main device — prompt batch + decode steps against the CPU oracle and against the same model on
+    one device; the reductions per graph are counted."""
+    from model_util import Context, Model, preset
+
+    H = L.host()
+    be = L.Backend(0)
+    split_fn = be.proc("ggml_backend_split_buffer_type", C.c_void_p, [C.c_int, C.POINTER(C.c_float)])
+    out = {"n_dev": int(H.ggml_backend_reg_dev_count(be.reg)), "graphs_env": os.environ.get("GGML_MI355X_SPLIT_GRAPHS", "0"), "cases": []}
+    prompt = [1, 5, 9, 300, 17, 42, 99, 7, 250, 3]
+    for name, ftype, ts in (("test-llama-tp", 1, [1.0, 1.0]), ("test-llama-tp", 5, [1.0, 1.0]), ("test-llama-tp", 1, [3.0, 1.0]), ("test-qwen2", 5, [1.0, 1.0])):
+        hp = preset(name)
+        hp.ftype = ftype  # 1 = Q4_K_M type map (gate / up share a type: the sharded FFN chain), 5 = mixed (every kernel; gate / up differ: separate paths)
+        arr = (C.c_float * 16)(*(ts + [0.0] * (16 - len(ts))))
+        buft = split_fn(0, arr)
+        ms = Model(hp, 77, be.buft, split_buft=buft)
+        mg = Model(hp, 77, be.buft)
+        mc = Model(hp, 77, H.ggml_backend_cpu_buffer_type())
+        cs = Context(ms, backend=be, flash_attn=1)
+        cg = Context(mg, backend=be, flash_attn=1)
+        cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=1)
+
+        def run(ctx, count=False):
+            rows, reds = [], []
+            a0 = be.stat("allreduces")
+            rc, lg = ctx.decode(prompt, range(len(prompt)), want=[0] * (len(prompt) - 1) + [1])
+            assert rc == 0
+            reds.append(be.stat("allreduces") - a0)
+            rows.append(lg[-1])
+            for i, t in enumerate((11, 12, 13, 14, 15, 16)):
+                a0 = be.stat("allreduces")
+                rc, l1 = ctx.decode([t], [len(prompt) + i])
+                assert rc == 0
+                reds.append(be.stat("allreduces") - a0)
+                rows.append(l1[0])
+            return np.stack(rows), reds
+
+        g0 = be.stat("graph_launches")
+        r_s, reds = run(cs, True)
+        replays = be.stat("graph_launches") - g0
+        r_g, _ = run(cg)
+        r_c, _ = run(cc)
+        out["cases"].append({"model": name, "ftype": ftype, "ts": ts, "n_layer": int(hp.n_layer), "reductions_per_graph": [int(r) for r in reds], "graph_replays": int(replays),
+                             "nmse_vs_oracle": float(T.nmse(r_s, r_c)), "nmse_one_device_vs_oracle": float(T.nmse(r_g, r_c)), "nmse_vs_one_device": float(T.nmse(r_s, r_g)),
+                             "argmax_equal_one_device": bool(np.array_equal(np.argmax(r_s, 1), np.argmax(r_g, 1)))})
+        for o in (cs, cg, cc, ms, mg, mc):
+            o.free()
+    print("SPLIT_JSON " + json.dumps(out))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "model":
+        model_main()
+    else:
+        main()

@@ -36,8 +36,30 @@ def test_row_split_buffer_type_on_four_logical_devices(plog):
         tot = sum(ts)
         for d in range(4):  # proportions, up to the 64-row granule
             want = n * (sum(ts[:d]) / tot if tot > 0 else d / 4)
-            assert abs(r0[d] - want) < 64, (d, r0, want)
-            assert r0[d] % 64 == 0 or r0[d] == n
+            gran = 256 if n % 256 == 0 else 64  # (rows that can become another weight's K range are cut at super-block granules)
+            assert abs(r0[d] - want) < gran, (d, r0, want)
+            assert r0[d] % gran == 0 or r0[d] == n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphs", ["0", "1"])
+def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs):
+    """-sm row as a tensor-parallel layout (llama-box/engine_param.hpp:821-842, :902-916): attn_output / ffn_down cut along K,
+    the FFN sharded end to end, TWO in-stream reductions per layer.  graphs = 1: the multi-stream step captured and replayed as a hipGraph."""
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="2", GGML_MI355X_SPLIT_GRAPHS=graphs)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py"), "model"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1][len("SPLIT_JSON "):])
+    assert res["n_dev"] == 2
+    for c in res["cases"]:
+        plog(f"[split-tp] graphs={graphs} {c['model']} ftype={c['ftype']} ts={c['ts']}: reductions per graph {c['reductions_per_graph']} (2 x {c['n_layer']} layers), graph replays {c['graph_replays']}, "
+             f"logits nmse vs oracle {c['nmse_vs_oracle']:.2e} (one device {c['nmse_one_device_vs_oracle']:.2e}), vs one device {c['nmse_vs_one_device']:.2e}")
+        assert all(r_ == 2 * c["n_layer"] for r_ in c["reductions_per_graph"]), c  # wo and ffn_down: one sum each, nothing else crosses devices as a sum
+        # the gates of tests/test_tp_gloo.py: the sharded sums differ from the one-device run in f32 summation order only
+        assert c["nmse_vs_oracle"] <= 1e-3 and c["nmse_vs_oracle"] <= 10.0 * max(c["nmse_one_device_vs_oracle"], 1e-7)
+        assert c["nmse_vs_one_device"] <= 1e-3
+        if graphs == "1":
+            assert c["graph_replays"] >= 3, "the decode steps of the split model were not replayed as hipGraphs"
 
 
 def test_split_rows_planning_without_a_device():
@@ -58,11 +80,14 @@ def test_split_rows_planning_without_a_device():
     # Llama-3-70B ffn rows over eight devices, even split: 28672 / 8 = 3584 rows each
     fn(28672, (C.c_float * 16)(*([1.0] * 8 + [0.0] * 8)), 8, row0)
     assert [row0[d] for d in range(9)] == [3584 * d for d in range(9)]
-    # proportions 3:1 over two devices, 64-row granule
+    # proportions 3:1 over two devices
     fn(4096, (C.c_float * 16)(3.0, 1.0), 2, row0)
     assert [row0[d] for d in range(3)] == [0, 3072, 4096]
-    # all-zero proportions = even; a device with proportion 0 gets no rows
+    # all-zero proportions = even; 64-row granules when the row count is not a multiple of 256
     fn(1000, (C.c_float * 16)(), 4, row0)
     assert [row0[d] for d in range(5)] == [0, 192, 448, 704, 1000]
+    # a device with proportion 0 gets no rows; 256-row granules otherwise (a device's rows of ffn_gate / ffn_up ARE its K range of ffn_down)
     fn(1024, (C.c_float * 16)(1.0, 0.0, 1.0), 3, row0)
     assert [row0[d] for d in range(4)] == [0, 512, 512, 1024]
+    fn(14336, (C.c_float * 16)(*([1.0] * 8)), 8, row0)
+    assert [row0[d] for d in range(9)] == [1792 * d for d in range(9)]
