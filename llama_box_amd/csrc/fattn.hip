@@ -351,11 +351,20 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     const int * tl = nullptr;  // LIST: this token's visible positions, ascending; trips [ti, ti1) of TRIP entries each are ours
     int ti = 0, ti1 = 0, cnt = 0;
     bool empty = false;
+    // LIST: the list entries of the NEXT trip to be loaded (one per row group u), requested a round trip before its K/V rows are — for one
+    // split together with the count itself, so that neither the count nor the entries sit in the chain count -> entries -> rows that
+    // every trip used to walk (entries past the count are stale: they are replaced by the first entry, a visible cell, before use)
+    int nidx[NG];
+    int first = 0;
+#define FA_LIST_AHEAD(base)                                                                                         \
+    _Pragma("unroll") for (int u = 0; u < NG; ++u) nidx[u] = tl[min((base) + u * (WV * 4) + wave * 4 + sub, geo.n_kv - 1)];
     if constexpr (LIST) {
         const int * lt = lists + (int64_t) tok * list_stride;
-        cnt = lt[0];
-        const int trips = (cnt + TRIP - 1) / TRIP, share = (trips + geo.n_splits - 1) / geo.n_splits;
         tl = lt + 1;
+        cnt = lt[0];
+        first = lt[1];
+        if (geo.n_splits == 1) FA_LIST_AHEAD(0)
+        const int trips = (cnt + TRIP - 1) / TRIP, share = (trips + geo.n_splits - 1) / geo.n_splits;
         ti = split * share;
         ti1 = min(trips, ti + share);
         if (ti >= ti1) {
@@ -374,6 +383,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             empty = true;  // (still has to arrive: it may be the workgroup that merges the records)
         }
         kv1 = cnt;
+        if (geo.n_splits != 1 && !empty) FA_LIST_AHEAD(ti * TRIP)
     }
     const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
     if constexpr (SKIP) {
@@ -409,8 +419,8 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
 #define FA_LOAD_TRIP()                                                                  \
     {                                                                                   \
         _Pragma("unroll") for (int u = 0; u < NG; ++u) {                               \
-            const int pe_ = min(p0 + u * (WV * 4) + wave * 4 + sub, kv1 - 1);           \
-            const int pc = LIST ? tl[pe_] : pe_;                                        \
+            const int pr_ = p0 + u * (WV * 4) + wave * 4 + sub;                         \
+            const int pc = LIST ? (pr_ < kv1 ? nidx[u] : first) : min(pr_, kv1 - 1);    \
             const char * kp_ = kbase + (int64_t) pc * k.nb[1];                          \
             const char * vp_ = vbase + (int64_t) pc * v.nb[1];                          \
             if constexpr (Q8) {  /* 8 quants (2-byte aligned) + the block's f16 scale */  \
@@ -423,8 +433,14 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         }                                                                               \
         const int pl = p0 + ul * (WV * 4) + wave * 4 + sub;                             \
         okl = pl < kv1;                                                                 \
-        const int plc_ = min(pl, kv1 - 1);                                              \
-        mvl = mp ? h2f(mp[LIST ? tl[plc_] : plc_]) : 0.0f;                              \
+        int plc_ = min(pl, kv1 - 1);                                                    \
+        if constexpr (LIST) {                                                           \
+            plc_ = nidx[0];                                                             \
+            _Pragma("unroll") for (int u = 1; u < NG; ++u) plc_ = ul == u ? nidx[u] : plc_; \
+            plc_ = okl ? plc_ : first;                                                  \
+        }                                                                               \
+        mvl = mp ? h2f(mp[plc_]) : 0.0f;                                                \
+        if constexpr (LIST) FA_LIST_AHEAD(p0 + TRIP)                                    \
     }
     uint32_t vis = 0xFFFFFFFFu;  // bit i: trip i has a position this wave can see
     if constexpr (SKIP) {
@@ -599,6 +615,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
 #undef FA_PAIR
     }
 #undef FA_LOAD_TRIP
+#undef FA_LIST_AHEAD
     // ---- sum of head gl over the row groups (lanes gl, gl+G, ...) and the four rows
     if constexpr (G <= 2) l += dpp_f32<MI_DPP_ROR2>(l);
     if constexpr (G <= 4) l += dpp_f32<MI_DPP_ROR4>(l);

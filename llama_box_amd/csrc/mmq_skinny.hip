@@ -546,6 +546,147 @@ __global__ void __launch_bounds__(TP_NW * 64, 2) k_mmq_skinny_tp(const mmq8_args
 #undef MAT_OF
 }
 
+// ------------------------------------------------------------------------------------------------ tile-parallel form, eight waves
+// The four-wave form above keeps ONE wave on a SIMD, and a wave's step is a serial instruction stream: 13 requests (each an M0 write
+// and a wait for room in the CU's address pipeline), ~270 VALU, 17 MFMAs, the barrier — profiles/r03_np32_pmc_pass1.csv: its waves
+// execute an instruction in 50 % of their cycles and wait for memory in 19 %, while the same bytes stream at 4.8 TB/s through four waves
+// per CU that do nothing else (scripts/ubench/stride_probe.hip, any walking order).  The launch is bound by that stream of
+// instructions, not by HBM.  Here every tile gets TWO waves — wave t and wave t + 4 take the even and the odd super-blocks of tile t —
+// so that each SIMD has a second instruction stream to issue from while the first waits for the matrix pipe or the address pipeline;
+// a step = two consecutive super-blocks, whose activation blocks are neighbours in memory and land in one stage.  LDS (Q4_K):
+// weights 8 waves x 3 stages x 4.5 KB + activations 2 stages x 2 blocks x 9.5 KB = 146.5 KB — the activations (L2 hits) run one step
+// ahead, the weights two.  The halves of a tile meet once, at the end: wave t + 4 leaves its sums in the weight stage it consumed last.
+// (Q5_K's 5.5 KB units do not fit that way: it stays on the four-wave form.)
+constexpr int TP8_NW = 8, TP8_NSA = 3, TP8_NSB = 2;
+constexpr int TP8_B_STAGE = 2 * SK_B_BYTES, TP8_D_STAGE = 256;
+template <int QT> constexpr int tp8_lds_bytes() { return TP8_NSB * (TP8_B_STAGE + TP8_D_STAGE) + TP8_NW * TP8_NSA * tp_a_stage<QT>(); }
+
+template <int QT>
+__global__ void __launch_bounds__(TP8_NW * 64, 1) k_mmq_skinny_tp8(const mmq8_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef sk_fmt<QT> F;
+    constexpr int NPA = 32 * F::PIECES, NLA = (NPA + 63) / 64;  // weight pieces per unit and the wave-instructions fetching them
+    constexpr int NPB = 2 * 32 * 19 / TP8_NW;                    // activation pieces per wave and step: 152 = 2 x 64 + 24
+    constexpr int A_STAGE = tp_a_stage<QT>();
+    static_assert(tp8_lds_bytes<QT>() <= 160 * 1024, "LDS");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = wave & 3, kh = wave >> 2;  // this wave's tile of the group and its parity of super-blocks
+    const int row = lane & 31, g = lane >> 5;
+    const int nst = a.K / 512;  // steps per item
+    const int w_nb1 = (int) a.mat[0].w_nb1;
+    const int tok_bytes = (a.K / 256) * (int) sizeof(q8k_dev);
+    const uint32_t lds0 = (uint32_t) (uintptr_t) smem;
+    // LDS: [activation ring: 2 x (2 blocks x 9728)][scale ring: 2 x 256][weight rings: wave x 3 x stage]
+    constexpr int A_RINGS = TP8_NSB * (TP8_B_STAGE + TP8_D_STAGE);
+    const uint32_t b_ring = lds0, d_ring = lds0 + TP8_NSB * TP8_B_STAGE, a_ring = lds0 + A_RINGS + wave * TP8_NSA * A_STAGE;
+    char * const a_ring_p = smem + A_RINGS + wave * TP8_NSA * A_STAGE;
+
+    int a_off[NLA];
+#pragma unroll
+    for (int u = 0; u < NLA; ++u) {
+        const int pi = min(lane + 64 * u, NPA - 1);
+        a_off[u] = (pi / F::PIECES) * w_nb1 + (pi % F::PIECES) * 16;
+    }
+    // the stage's 1216 activation pieces in LDS order [block][token][19 pieces]; this wave requests 152 consecutive ones
+    int b_off[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int pi = wave * NPB + min(lane + 64 * u, NPB - 1);
+        const int blk = pi / 608, rem = pi - blk * 608;
+        b_off[u] = (rem / 19) * tok_bytes + blk * (int) sizeof(q8k_dev) + (rem % 19) * 16;
+    }
+    const int d_off = row * tok_bytes + g * (int) sizeof(q8k_dev) + 304;  // q8k_dev::d of (block g, token row): 64 lanes
+    constexpr int n_ops_a = NLA;
+
+#define MAT_OF(t) ((a.n_mat > 2 && (t) >= a.mat[2].panel0) ? 2 : ((a.n_mat > 1 && (t) >= a.mat[1].panel0) ? 1 : 0))
+#define MAT_SEL(mi, f) ((mi) == 0 ? a.mat[0].f : ((mi) == 1 ? a.mat[1].f : a.mat[2].f))
+    const int n_items = a.n_panels;
+    const int my_items = n_items > (int) blockIdx.x ? (n_items - 1 - (int) blockIdx.x) / (int) gridDim.x + 1 : 0;
+    const int total = my_items * nst;  // steps
+    auto issue_a = [&](const int item, const int j, const int slot) {
+        const int mi = MAT_OF(item);
+        const uint8_t * wb = MAT_SEL(mi, W) + ((size_t) (item - MAT_SEL(mi, panel0)) * 128 + tile * 32) * (size_t) w_nb1 + (size_t) (2 * j + kh) * F::BYTES;
+        const uint32_t al = a_ring + slot * A_STAGE;
+#pragma unroll
+        for (int u = 0; u < NLA; ++u)
+            if (u + 1 < NLA || (NPA % 64) == 0 || lane < (NPA % 64)) tp_dma16(wb + a_off[u], al + u * 1024);
+    };
+    auto issue_b = [&](const int j, const int slot) {
+        const char * ab = (const char *) a.act + (size_t) (2 * j) * sizeof(q8k_dev);
+        const uint32_t bl = b_ring + slot * TP8_B_STAGE + wave * NPB * 16;
+        tp_dma16(ab + b_off[0], bl);
+        tp_dma16(ab + b_off[1], bl + 1024);
+        if (lane < NPB - 128) tp_dma16(ab + b_off[2], bl + 2048);
+        tp_dma4(ab + d_off, d_ring + slot * TP8_D_STAGE);  // (every wave: identical bytes to the same place, and one wait count for all)
+    };
+
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // request cursors: weights run two steps ahead, activations one; queue order per step [activations s + 1, weights s + 2] — what
+    // step s + 1 consumes is then older than the one thing that may still fly when it starts (in-order vmcnt)
+    int ia_item = blockIdx.x, ia_j = 0, na = 0, sa = 0;  // next weight step to request (item, step of the item, running number, slot)
+    int ib_j = 0, nb = 0, sb_ = 0;
+#define TP8_ISSUE_A() { issue_a(ia_item, ia_j, sa); ++na; sa = sa == TP8_NSA - 1 ? 0 : sa + 1; if (++ia_j == nst) { ia_j = 0; ia_item += gridDim.x; } }
+#define TP8_ISSUE_B() { issue_b(ib_j, sb_); ++nb; sb_ ^= 1; if (++ib_j == nst) ib_j = 0; }
+    if (na < total) TP8_ISSUE_A()
+    if (nb < total) TP8_ISSUE_B()
+    if (na < total) TP8_ISSUE_A()
+    int cu_item = blockIdx.x, cu_j = 0, ca = 0, cb = 0;  // the step being multiplied and its slots
+    for (int s = 0; s < total; ++s) {
+        if (na > s + 1) tp_wait_c<n_ops_a>();
+        else tp_wait_c<0>();
+        __syncthreads();  // everything of step s is in LDS, and nobody reads step s - 1 any more
+        if (nb < total) TP8_ISSUE_B()
+        if (na < total) TP8_ISSUE_A()
+        sk_unit_k45<QT>(a_ring_p + ca * A_STAGE + row * F::ROW, smem + cb * TP8_B_STAGE + kh * SK_B_BYTES + row * SK_BTOK,
+                        (const float *) (smem + TP8_NSB * TP8_B_STAGE + cb * TP8_D_STAGE + kh * 128), g, acc);
+        if (++cu_j == nst) {
+            // ---- the tile is complete: the odd half's sums cross over through the weight stage that wave has just consumed (its next
+            // request goes out after the next step's barrier); lane = weight row, register i = token (i & 3) + 8 (i >> 2) + 4 g
+            if (kh) {
+                float * const own = (float *) (a_ring_p + ca * A_STAGE);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) own[i * 64 + lane] = acc[i];
+            }
+            __syncthreads();
+            if (!kh) {
+                const float * const other = (const float *) (a_ring_p + 4 * TP8_NSA * A_STAGE + ca * A_STAGE);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += other[i * 64 + lane];
+                const int mi = MAT_OF(cu_item);
+                const int n = (cu_item - MAT_SEL(mi, panel0)) * 128 + tile * 32 + row;
+                float * const m_dst = MAT_SEL(mi, dst);
+                const int64_t m_dst_stride = MAT_SEL(mi, dst_stride);
+                const float * const m_add = MAT_SEL(mi, add);
+                const int64_t m_add_stride = MAT_SEL(mi, add_stride);
+                if (m_add) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] += m_add[(size_t) min((i & 3) + 8 * (i >> 2) + 4 * g, a.M - 1) * m_add_stride + n];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int tok = (i & 3) + 8 * (i >> 2) + 4 * g;
+                    if (tok < a.M) m_dst[(size_t) tok * m_dst_stride + n] = acc[i];
+                }
+                // stores count in vmcnt and are not ordered with the requests in flight: drain once per item, so that the counted waits
+                // of the next item's steps see requests only
+                if (s + 1 < total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            cu_j = 0;
+            cu_item += gridDim.x;
+        }
+        ca = ca == TP8_NSA - 1 ? 0 : ca + 1;
+        cb ^= 1;
+    }
+#undef TP8_ISSUE_A
+#undef TP8_ISSUE_B
+#undef MAT_SEL
+#undef MAT_OF
+}
+
 // the tile-parallel form serves a launch when every matrix is whole 128-row groups, there is no K split, and the groups alone
 // occupy most of the chip
 static bool skinny_tp_applies(int type, const mmq8_args & a, int n_cu) {
@@ -949,13 +1090,23 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
     a.m_tiles = 1;
     if constexpr (QT == 4 || QT == 5) {
         if (!a.has_epi && skinny_tp_applies(QT == 4 ? GGML_TYPE_Q4_K : GGML_TYPE_Q5_K, a, n_cu)) {
-            static std::atomic<uint32_t> lds_raised_tp{0};
-            (void) ensure_dyn_lds((const void *) k_mmq_skinny_tp<QT>, (size_t) tp_lds_bytes<QT>(), lds_raised_tp);
             a.n_panels = 0;
             for (int i = 0; i < a.n_mat; ++i) {
                 a.mat[i].panel0 = a.n_panels;
                 a.n_panels += a.mat[i].N / 128;
             }
+            if constexpr (QT == 4) {
+                // two waves per tile (GGML_MI355X_SKINNY_TP=1: the four-wave form)
+                static const bool tp8 = !getenv("GGML_MI355X_SKINNY_TP") || atoi(getenv("GGML_MI355X_SKINNY_TP")) != 1;
+                if (tp8 && (a.K % 512) == 0) {
+                    static std::atomic<uint32_t> lds_raised_tp8{0};
+                    (void) ensure_dyn_lds((const void *) k_mmq_skinny_tp8<QT>, (size_t) tp8_lds_bytes<QT>(), lds_raised_tp8);
+                    MI_LAUNCH_PROBED((k_mmq_skinny_tp8<QT>), dim3((unsigned) std::min(a.n_panels, n_cu)), dim3(TP8_NW * 64), (size_t) tp8_lds_bytes<QT>(), s, a);
+                    return;
+                }
+            }
+            static std::atomic<uint32_t> lds_raised_tp{0};
+            (void) ensure_dyn_lds((const void *) k_mmq_skinny_tp<QT>, (size_t) tp_lds_bytes<QT>(), lds_raised_tp);
             MI_LAUNCH_PROBED((k_mmq_skinny_tp<QT>), dim3((unsigned) std::min(a.n_panels, n_cu)), dim3(TP_NW * 64), (size_t) tp_lds_bytes<QT>(), s, a);
             return;
         }

@@ -139,6 +139,9 @@ def test_sibling_mul_mats_share_a_launch(backend, H, plog, qt, M, bias):
     (14336, 128, 32, "res"), (2048, 4096, 32, "bias"), (2048, 4096, 5, "none"), (3584, 608, 31, "res"), (8192, 256, 32, "none"),
     # enough 128-row groups to occupy the chip: the tile-parallel form (four tiles of a super-block share its activations, LDS-DMA rings)
     (512, 24576, 32, "res"), (1024, 28672, 7, "none"), (256, 32768, 19, "bias"), (2048, 24704, 32, "none"),
+    # more groups than CUs: workgroups serve two items (the request rings run across the item boundary); Q4_K with K % 512 == 0 takes
+    # the eight-wave form (two waves per tile, even / odd super-blocks)
+    (1024, 49152, 32, "res"), (1536, 40960, 13, "none"),
 ])
 def test_mul_mat_q_skinny_batches(backend, H, plog, qt, K, N, M, epi):
     """2..32 columns (a decode step of `-np` parallel sequences): the weight-streaming matrix-core kernel (mmq_skinny.hip) —
