@@ -38,7 +38,12 @@ def _class_to_symbol(cls, n_par=1):
             return None
         n_total = next((int(x[1:]) for x in parts if x.startswith("n") and x[1:].isdigit()), 0)
         tile_parallel = "x2" in parts and qt in ("4", "5") and n_total >= 192 * 128  # (mmq_skinny.hip skinny_tp_applies: >= 192 groups of 128 rows, no K split — the gate/up pair)
-        return f"k_mmq_skinny_tp<{qt}>" if tile_parallel else f"k_mmq_skinny<{qt}, "
+        if tile_parallel:  # Q4_K: two waves per tile (k_mmq_skinny_tp8) unless GGML_MI355X_SKINNY_TP=1; Q5_K: the four-wave form
+            return "k_mmq_skinny_tp8<4>" if qt == "4" and os.environ.get("GGML_MI355X_SKINNY_TP", "2") != "1" else f"k_mmq_skinny_tp<{qt}>"
+        if "+" in parts[2]:  # two formats in one launch (mmq_q4_K+q6_K_x3_..): k_mmq_skinny<4, 6, ..>
+            other = {"K+q4": "4", "K+q5": "5", "K+q6": "6"}.get(parts[2])
+            return f"k_mmq_skinny<{qt}, {other}, " if other else None
+        return f"k_mmq_skinny<{qt}, {qt}, "
     if parts[0] != "mmvq":
         return None
     ty = {"q4": "T_Q4K", "q5": "T_Q5K", "q6": "T_Q6K", "q8": "T_Q80"}.get(parts[1])

@@ -469,6 +469,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_MMQ_BN")) c->opt.mmq_bn = atoi(e);
     if (const char * e = getenv("GGML_MI355X_MMQ_SKINNY")) c->opt.mmq_skinny = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_SKINNY_ROPE")) c->opt.skinny_rope = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_SKINNY_MIX")) c->opt.skinny_mix = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_SOFTMAX_MM")) c->opt.softmax_mm = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_ATTN_NF")) c->opt.attn_nf = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FA_SELF_MERGE")) c->opt.fa_self_merge = atoi(e) != 0;
@@ -535,6 +536,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "mmq_bn") c->opt.mmq_bn = v;
     else if (k == "mmq_skinny") c->opt.mmq_skinny = v != 0;
     else if (k == "skinny_rope") c->opt.skinny_rope = v != 0;
+    else if (k == "skinny_mix") c->opt.skinny_mix = v != 0;
     else if (k == "softmax_mm") c->opt.softmax_mm = v != 0;
     else if (k == "attn_nf") c->opt.attn_nf = v != 0;
     else if (k == "fa_self_merge") c->opt.fa_self_merge = v != 0;

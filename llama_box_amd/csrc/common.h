@@ -92,6 +92,7 @@ struct options {
     bool attn_nf = true;       // -np decode steps on the non-flash path: K.q -> SOFT_MAX -> V^T.p as one launch over the tokens' visible-cell lists (attn_nf.hip)
     bool softmax_mm = true;    // decode on the non-flash path: SOFT_MAX folded into the V^T.p product that reads it (mmf.hip)
     bool skinny_rope = true;   // -np decode steps: ROPE(q), ROPE(k) and both KV-cache stores in the epilogue of the skinny QKV launch(es)
+    bool skinny_mix = true;    // -np decode steps: sibling mat-muls stored in two K-quant formats (Q4_K wq / wk + Q6_K wv) share one skinny launch
     bool mmq_skinny = true;    // 2..32 columns: weight-streaming matrix-core kernel (mmq_skinny.hip) instead of the tiled GEMM
     int mmq_bn = 0;            // force the weight-panel height of mmq_i8 (64 / 128); 0 = pick by grid size
     int fa_splits = 0;         // 0 = auto

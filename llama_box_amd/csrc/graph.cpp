@@ -821,6 +821,25 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         if (ok && m.add && ranges_overlap(m.dst, m.add) && m.add->data != m.dst->data) ok = false;
         if (ok) (same ? ms : others).push_back(m);
     }
+    // a decode step of a continuous batch: the sibling stored in another K-quant format (Q4_K_M keeps wv as Q6_K in half the layers) joins
+    // the launch — the skinny kernel serves two formats in two passes — instead of running alone on 32 workgroups behind it
+    bool mixed = false;
+    if (c->opt.mmq_skinny && c->opt.skinny_mix && M >= 2 && M <= 32 && ms.size() == 2 && others.size() == 1) {
+        int ty[3];
+        int64_t Ns[3], nb[3];
+        const member * all[3] = {&ms[0], &ms[1], &others[0]};
+        for (int q = 0; q < 3; ++q) {
+            const ggml_tensor * w = g->nodes[all[q]->k]->src[0];
+            ty[q] = w->type;
+            Ns[q] = w->ne[1];
+            nb[q] = (int64_t) w->nb[1];
+        }
+        if (mmq_skinny_mix_ok(ty, Ns, nb, 3, K, M)) {
+            ms.push_back(others[0]);
+            others.clear();
+            mixed = true;
+        }
+    }
     if (ms.size() < 2) return 0;
     int64_t n_total = 0;
     mmq_mat_desc mats[3];
@@ -831,7 +850,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
         if ((ms[q].dst->nb[1] % 16) != 0) return 0;
         mats[q] = {(const uint8_t *) w->data, (int64_t) w->nb[1], (int) w->ne[1], (float *) ms[q].dst->data, (int64_t) (ms[q].dst->nb[1] / 4),
-                   add ? (const float *) add->data : nullptr, (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4)};
+                   add ? (const float *) add->data : nullptr, (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4), (int) w->type == type ? 0 : (int) w->type};
         n_total += w->ne[1];
         wbytes += (double) ggml_abi_row_size(w->type, K) * (double) w->ne[1];
     }
@@ -924,7 +943,8 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     }
     float * part = (float *) ((char *) c->ws + st.aux_off);
     {
-        timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (ms.size() == 3 ? "_x3" : "_x2") + "_n" + std::to_string(n_total) + "_k" + std::to_string(K)).c_str(), wbytes, true);
+        timed_scope ts(c, (std::string("mmq_") + type_tag(type) + (mixed ? std::string("+") + type_tag(g->nodes[ms.back().k]->src[0]->type) : std::string()) + (ms.size() == 3 ? "_x3" : "_x2") + "_n" +
+                           std::to_string(n_total) + "_k" + std::to_string(K)).c_str(), wbytes, true);
         if (epi_node >= 0) {
             auto role_of2 = [&](const member & m) {
                 for (int sidx = 0; sidx < 3; ++sidx)

@@ -124,7 +124,9 @@ bool launch_soft_max_mul_mat_f16(hipStream_t s, const tdesc & a, const tdesc & k
 bool mmq_supported(int type, int64_t K, int64_t N, int64_t M);
 size_t mmq_workspace_bytes(int type, int64_t K, int64_t N, int64_t M, bool skinny);
 // int8-matrix-core variant for Q4_K / Q5_K (mmq_i8.hip); force_bn: 0 = auto, 64 / 128 = weight-panel height
-struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
+bool mmq_skinny_mix_ok(const int * types, const int64_t * N, const int64_t * w_nb1, int n, int64_t K, int64_t M);
+struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride;
+                      int type = 0; };  // type: 0 = the launch's; another K-quant type makes it a two-format launch (2..32 columns only)
 // Epilogue of the skinny kernel (2..32 columns, no K split) for the attention projections of a batch: the ROPE of q and k and both
 // KV-cache stores happen where the projections' sums are complete — the rope + store launch of ops.hip (k_rope_qk_store) disappears.
 // Adjacent-pair ("normal") rotation only: both elements of a pair sit in one 32-row tile.

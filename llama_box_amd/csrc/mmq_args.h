@@ -18,6 +18,7 @@ struct mmq8_mat {
     float * part;        // ksplit > 1: partial [ksplit][M][N] results of this matrix (summed in a fixed order by k_splitk_reduce)
     const float * add;   // optional epilogue: + add[m * add_stride + n] (bias row: stride 0, residual: stride N)
     int64_t add_stride;
+    int qt;              // two-format launches of the skinny kernel: 4 / 5 / 6 = how THIS matrix is stored (0 otherwise)
 };
 struct mmq8_args {
     mmq8_mat mat[3];
@@ -31,6 +32,8 @@ struct mmq8_args {
 };
 
 void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a);
+// matrices of two K-quant formats in one launch (a.mat[].qt set); false: this pair of formats is not built
+bool launch_mmq_skinny_mixed(hipStream_t s, const mmq8_args & a);
 // prompt batches on the same unit (mmq_skinny.hip, wide form): token tiles per workgroup (4 / 2) when it applies, 0 when it does not
 int mmq_wide_tiles(int type, int64_t K, const int64_t * N, int n_mat, int64_t M, int64_t w_nb1, int ksplit);
 void launch_mmq_wide(hipStream_t s, int type, int tt, const mmq8_args & a);  // mmq_skinny.hip; a.mat[].panel0 / n_panels are set by the launcher

@@ -436,6 +436,17 @@ int mmq_pick_ksplit(int64_t K, int64_t N, int64_t M, bool skinny, int type) {
     if (wgs == 256 && nblk >= 32) return 2;
     return 1;
 }
+// can matrices of these K-quant types (same K, same activations) share one launch of 2..32 columns?
+bool mmq_skinny_mix_ok(const int * types, const int64_t * N, const int64_t * w_nb1, int n, int64_t K, int64_t M) {
+    bool has4 = false, has5 = false, has6 = false;
+    for (int i = 0; i < n; ++i) {
+        if (!mmq_skinny_supported(types[i], K, N[i], M, w_nb1[i])) return false;
+        has4 = has4 || types[i] == GGML_TYPE_Q4_K;
+        has5 = has5 || types[i] == GGML_TYPE_Q5_K;
+        has6 = has6 || types[i] == GGML_TYPE_Q6_K;
+    }
+    return has6 && (has4 != has5);
+}
 struct splitk_mat { const float * part; int64_t mn; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
 struct splitk_args { splitk_mat mat[3]; int n_mat, ks; int64_t e1, e2; };  // matrix i owns float4 slots [e_i, e_{i+1}) (e0 = 0)
 __global__ void __launch_bounds__(256) k_splitk_reduce(const splitk_args a) {
@@ -499,6 +510,7 @@ int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc *
     a.ksplit = std::max(1, ksplit);
     int64_t panels128 = 0;
     const bool skinny_opt = skinny;
+    bool mixed = false;
     float * pp = part;
     for (int i = 0; i < n_mat; ++i) {
         a.mat[i].W = mats[i].W;
@@ -511,8 +523,19 @@ int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc *
         a.mat[i].part = pp;
         pp += (size_t) a.ksplit * M * mats[i].N;
         panels128 += (mats[i].N + 127) / 128;
-        skinny = skinny && mmq_skinny_supported(type, K, mats[i].N, M, mats[i].w_nb1);
+        const int ti = mats[i].type ? mats[i].type : type;
+        mixed = mixed || ti != type;
+        a.mat[i].qt = ti == GGML_TYPE_Q4_K ? 4 : (ti == GGML_TYPE_Q5_K ? 5 : 6);
+        skinny = skinny && mmq_skinny_supported(ti, K, mats[i].N, M, mats[i].w_nb1);
     }
+    if (mixed) {  // two formats: the skinny kernel's two-pass form only (the caller asked mmq_skinny_mix_ok first)
+        if (!skinny || (a.ksplit & (a.ksplit - 1)) != 0 || (epi && a.ksplit != 1)) { MI_ERR("launch_mmq_i8_multi: a two-format launch the skinny kernel does not serve"); abort(); }
+        if (epi) { a.has_epi = 1; a.epi = *epi; }
+        if (!launch_mmq_skinny_mixed(s, a)) { MI_ERR("launch_mmq_i8_multi: this pair of formats has no two-format kernel"); abort(); }
+        if (a.ksplit > 1 && reduce) launch_splitk_reduce_multi(s, a);
+        return 1;
+    }
+    for (int i = 0; i < n_mat; ++i) a.mat[i].qt = 0;
     if (skinny_opt && M >= 33) {  // prompt batches: the wide form of the skinny unit, where it applies
         int64_t Ns[3] = {0, 0, 0};
         bool same = true;

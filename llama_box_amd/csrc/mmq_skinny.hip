@@ -26,6 +26,7 @@
 //   * Q6_K blocks are 210 bytes at 2-byte alignment: the unit is fetched as 4-byte-aligned 16-byte pieces (dwordx4 only needs
 //     dword alignment) and shifted by 0 / 2 bytes on the way into LDS (v_alignbyte + the neighbour lane's first dword).
 #include <algorithm>
+#include <type_traits>
 
 #include "dev_util.h"
 #include "kernels.h"
@@ -161,9 +162,16 @@ template <int QT> __device__ __forceinline__ void sk_unit_k45(const char * __res
 // EPI: the results of the attention projections of a batch are rotated and stored by this launch (mmq_epi) — a separate instantiation,
 // because the accurate cosf / sinf of the rotation bring a scratch frame that every launch of the kernel would otherwise pay for
 // (measured: 4.27 -> 4.45 ms per -np 32 step with the epilogue compiled into the one kernel, used or not)
-template <int QT, bool EPI>
+// MIXED: the matrices of the launch are stored in two formats (wq / wk as Q4_K next to a Q6_K wv: what Q4_K_M does to half the layers) —
+// this pass serves the items whose matrix is stored as QT and walks past the others (k_mmq_skinny_mix runs one pass per format)
+// (the pass is a lambda INSIDE the kernel: as a device function taking the argument block, by value or by reference, it made the compiler
+// copy the block into scratch memory — 408 bytes per lane — and read every pointer of the launch from there)
+template <int QA, int QB, bool EPI>
 __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool MIXED = QA != QB;
+    auto pass = [&](auto qt_tag) __attribute__((always_inline)) {
+    constexpr int QT = decltype(qt_tag)::value;
     typedef sk_fmt<QT> F;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -173,7 +181,8 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
     // of an item's first units are in flight while the previous item is reduced and stored)
     const int ksl = 31 - __builtin_clz((unsigned) a.ksplit);  // ksplit is a power of two (launcher)
     const int n_items = a.n_panels << ksl;
-    const int w_nb1 = (int) a.mat[0].w_nb1;  // the same for every matrix of the launch (checked by the launcher)
+    // the row stride is the same for every matrix of one format (checked by the launcher)
+    const int w_nb1 = !MIXED || a.mat[0].qt == QT ? (int) a.mat[0].w_nb1 : (a.mat[1].qt == QT ? (int) a.mat[1].w_nb1 : (int) a.mat[2].w_nb1);
 
     char * const As = smem + wave * sk_wave_lds<QT>();
     char * const Bs = As + 32 * F::ROW;
@@ -223,6 +232,11 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
     };
     auto item_lo = [&](const int item) { return ((item & (a.ksplit - 1)) * nblk) >> ksl; };
     auto item_hi = [&](const int item) { return (((item & (a.ksplit - 1)) + 1) * nblk) >> ksl; };
+    auto mine = [&](const int item) {  // (MIXED) is this item's matrix stored as QT?
+        if constexpr (!MIXED) return true;
+        const int mi = MAT_OF(item >> ksl);
+        return MAT_SEL(mi, qt) == QT;
+    };
 
     u32x4s ga[NLA], gb[9] = {};
     float gd = 0.0f;
@@ -241,7 +255,7 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
     // the unit whose loads are in flight: (nx_item, nx_sb); wave w takes super-blocks lo + w, lo + w + 8, .. of every item
     int nx_item = blockIdx.x, nx_sb = 0;
 #define SK_NORMALISE()                                                                 \
-    while (nx_item < n_items && nx_sb >= item_hi(nx_item)) {                           \
+    while (nx_item < n_items && (nx_sb >= item_hi(nx_item) || !mine(nx_item))) {       \
         nx_item += gridDim.x;                                                          \
         if (nx_item < n_items) nx_sb = item_lo(nx_item) + wave;                        \
     }
@@ -250,6 +264,7 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
     if (nx_item < n_items) SK_ISSUE(item_rows(nx_item), nx_sb)
 
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        if (!mine(item)) continue;
         float acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -409,6 +424,11 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
 #undef SK_NORMALISE
 #undef MAT_SEL
 #undef MAT_OF
+    };  // pass
+    // two formats in one launch: a workgroup's items of the first format, then its items of the second (the wave areas are laid out per
+    // format in the same LDS; every served item ends with a barrier, so the second pass's staging cannot overtake the first's last reduction)
+    pass(std::integral_constant<int, QA>{});
+    if constexpr (MIXED) pass(std::integral_constant<int, QB>{});
 }
 
 // ------------------------------------------------------------------------------------------------ tile-parallel form (large N)
@@ -1113,8 +1133,8 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
     }
     const size_t lds = (size_t) SK_NW * sk_wave_lds<QT>();
     static std::atomic<uint32_t> lds_raised{0}, lds_raised_epi{0};
-    const void * fn_plain = (const void *) k_mmq_skinny<QT, false>;
-    const void * fn_epi = (const void *) k_mmq_skinny<QT, true>;
+    const void * fn_plain = (const void *) k_mmq_skinny<QT, QT, false>;
+    const void * fn_epi = (const void *) k_mmq_skinny<QT, QT, true>;
     (void) ensure_dyn_lds(a.has_epi ? fn_epi : fn_plain, lds, a.has_epi ? lds_raised_epi : lds_raised);
     a.n_panels = 0;
     for (int i = 0; i < a.n_mat; ++i) {
@@ -1123,8 +1143,34 @@ template <int QT> static void launch_skinny_t(hipStream_t s, mmq8_args a) {
     }
     // one workgroup per CU (its LDS areas fill the CU), walking the (tile, K slice) items with a stride of the grid
     const int items = a.n_panels * a.ksplit;
-    if (a.has_epi) MI_LAUNCH_PROBED((k_mmq_skinny<QT, true>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
-    else MI_LAUNCH_PROBED((k_mmq_skinny<QT, false>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
+    if (a.has_epi) MI_LAUNCH_PROBED((k_mmq_skinny<QT, QT, true>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
+    else MI_LAUNCH_PROBED((k_mmq_skinny<QT, QT, false>), dim3((unsigned) std::min(items, n_cu)), dim3(SK_NW * 64), lds, s, a);
+}
+
+template <int QA, int QB> static void launch_skinny_mix_t(hipStream_t s, mmq8_args a) {
+    constexpr size_t lds = (size_t) SK_NW * (size_t) std::max(sk_wave_lds<QA>(), sk_wave_lds<QB>());
+    static std::atomic<uint32_t> lds_raised{0}, lds_raised_epi{0};
+    const void * fn = a.has_epi ? (const void *) k_mmq_skinny<QA, QB, true> : (const void *) k_mmq_skinny<QA, QB, false>;
+    (void) ensure_dyn_lds(fn, lds, a.has_epi ? lds_raised_epi : lds_raised);
+    a.m_tiles = 1;
+    a.n_panels = 0;
+    for (int i = 0; i < a.n_mat; ++i) {
+        a.mat[i].panel0 = a.n_panels;
+        a.n_panels += a.mat[i].N / 32;
+    }
+    const int items = a.n_panels * a.ksplit;
+    if (a.has_epi) MI_LAUNCH_PROBED((k_mmq_skinny<QA, QB, true>), dim3((unsigned) std::min(items, skinny_n_cu())), dim3(SK_NW * 64), lds, s, a);
+    else MI_LAUNCH_PROBED((k_mmq_skinny<QA, QB, false>), dim3((unsigned) std::min(items, skinny_n_cu())), dim3(SK_NW * 64), lds, s, a);
+}
+bool launch_mmq_skinny_mixed(hipStream_t s, const mmq8_args & a) {
+    bool has[7] = {};
+    for (int i = 0; i < a.n_mat; ++i) {
+        if (a.mat[i].qt < 4 || a.mat[i].qt > 6) return false;
+        has[a.mat[i].qt] = true;
+    }
+    if (has[4] && has[6] && !has[5]) { launch_skinny_mix_t<4, 6>(s, a); return true; }
+    if (has[5] && has[6] && !has[4]) { launch_skinny_mix_t<5, 6>(s, a); return true; }
+    return false;
 }
 
 void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a) {

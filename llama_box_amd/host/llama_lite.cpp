@@ -546,6 +546,28 @@ extern "C" uint64_t llm_model_total_bytes(const struct llm_model * m) { return m
 extern "C" struct ggml_tensor * llm_model_tensor(struct llm_model * m, const char * name) { return ggml_get_tensor(m->ctx, name); }
 
 // ---------------------------------------------------------------------------------------------- context
+// one row of the attention mask: `vis` where the cell holds a position of sequence s that is not after p, `hid` elsewhere (written to
+// vectorise — no short-circuit — and compiled at -O3: the library is built at -O2, where this compiler does not try)
+#pragma GCC push_options
+#pragma GCC optimize("O3")
+static void mask_row(uint16_t * __restrict__ row, const int n_kv, const int32_t * __restrict__ cpos, const int32_t * __restrict__ cseq, const int32_t s, const int32_t p,
+                     const uint16_t vis, const uint16_t hid) {
+    const uint32_t pu = (uint32_t) p;
+    for (int j = 0; j < n_kv; ++j) {
+        const bool v = (cseq[j] == s) & ((uint32_t) cpos[j] <= pu);
+        row[j] = v ? vis : hid;
+    }
+}
+static void mask_row(float * __restrict__ row, const int n_kv, const int32_t * __restrict__ cpos, const int32_t * __restrict__ cseq, const int32_t s, const int32_t p,
+                     const float vis, const float hid) {
+    const uint32_t pu = (uint32_t) p;
+    for (int j = 0; j < n_kv; ++j) {
+        const bool v = (cseq[j] == s) & ((uint32_t) cpos[j] <= pu);
+        row[j] = v ? vis : hid;
+    }
+}
+#pragma GCC pop_options
+
 struct kv_cell {
     int32_t pos = -1;
     int32_t seq = -1;
@@ -567,6 +589,7 @@ struct llm_context {
     ggml_backend_buffer_t buf_kv = nullptr;
     std::vector<ggml_tensor *> k_l, v_l;
     std::vector<kv_cell> cells;
+    std::vector<int32_t> mask_cpos, mask_cseq;  // the cells' fields as arrays (mask rows are filled from them)
     int kv_head = 0;
     // compute graph
     ggml_gallocr_t galloc = nullptr;
@@ -942,25 +965,27 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
         const int64_t n_tok_pad = c->inp_mask->ne[1];
         const int64_t rows = rebuilt ? n_tok_pad : n_tokens;
         const uint16_t NEG_INF_H = 0xFC00;
+        // cell j is visible to token i iff it holds a position (>= 0) of i's sequence that is not after i's — the condition llama.cpp's
+        // set_input_kq_mask evaluates per (token, cell); the cells' fields are gathered once per step so that the row loops vectorise
+        // (an empty cell's position -1 compares as the largest unsigned value: never visible)
+        std::vector<int32_t> & cpos = c->mask_cpos, & cseq = c->mask_cseq;
+        cpos.resize((size_t) n_kv);
+        cseq.resize((size_t) n_kv);
+        for (int j = 0; j < n_kv; ++j) {
+            cpos[j] = c->cells[j].pos;
+            cseq[j] = c->cells[j].seq;
+        }
         if (fa) {
             upload(c->inp_mask, (size_t) n_kv * rows * 2, [&](char * d) {
                 uint16_t * mask = (uint16_t *) d;
-                for (size_t e = 0; e < (size_t) n_kv * rows; ++e) mask[e] = NEG_INF_H;
-                for (int i = 0; i < n_tokens; ++i) {
-                    const int s = seq_id ? seq_id[i] : 0;
-                    for (int j = 0; j < n_kv; ++j)
-                        if (c->cells[j].pos >= 0 && c->cells[j].seq == s && c->cells[j].pos <= pos[i]) mask[(size_t) i * n_kv + j] = 0;
-                }
+                for (size_t e = (size_t) n_kv * n_tokens; e < (size_t) n_kv * rows; ++e) mask[e] = NEG_INF_H;
+                for (int i = 0; i < n_tokens; ++i) mask_row(mask + (size_t) i * n_kv, n_kv, cpos.data(), cseq.data(), seq_id ? seq_id[i] : 0, pos[i], (uint16_t) 0, NEG_INF_H);
             });
         } else {
             upload(c->inp_mask, (size_t) n_kv * rows * 4, [&](char * d) {
                 float * mask = (float *) d;
-                for (size_t e = 0; e < (size_t) n_kv * rows; ++e) mask[e] = -INFINITY;
-                for (int i = 0; i < n_tokens; ++i) {
-                    const int s = seq_id ? seq_id[i] : 0;
-                    for (int j = 0; j < n_kv; ++j)
-                        if (c->cells[j].pos >= 0 && c->cells[j].seq == s && c->cells[j].pos <= pos[i]) mask[(size_t) i * n_kv + j] = 0.0f;
-                }
+                for (size_t e = (size_t) n_kv * n_tokens; e < (size_t) n_kv * rows; ++e) mask[e] = -INFINITY;
+                for (int i = 0; i < n_tokens; ++i) mask_row(mask + (size_t) i * n_kv, n_kv, cpos.data(), cseq.data(), seq_id ? seq_id[i] : 0, pos[i], 0.0f, -INFINITY);
             });
         }
     }

@@ -1136,10 +1136,10 @@ def test_fused_qkv_transposed_v_store(backend, H, plog, tq, tv):
 @pytest.mark.parametrize("tq,tv,M,n_dims,bias", [(L.Q4_K, L.Q4_K, 32, 128, False), (L.Q4_K, L.Q6_K, 32, 128, False), (L.Q4_K, L.Q6_K, 7, 128, True),
                                                   (L.Q5_K, L.Q5_K, 19, 64, False), (L.Q6_K, L.Q6_K, 32, 128, True)])
 def test_np_batch_qkv_rope_store_in_the_gemm_epilogue(backend, H, plog, tq, tv, M, n_dims, bias):
-    """-np decode step (3..32 tokens): wq / wk / wv -> (+bias) -> rope(q, k) -> KV-cache stores.  The skinny launches (one when the
-    three weights share a format, two when wv is stored in another) rotate and store in their epilogue — no rope launch, the f32
-    projections are never written.  Equal to the oracle, and to the unfused execution bit for bit (same mat-mul kernel, same rope
-    arithmetic element for element)."""
+    """-np decode step (3..32 tokens): wq / wk / wv -> (+bias) -> rope(q, k) -> KV-cache stores.  ONE skinny launch — also when wv is
+    stored in another K-quant format than wq / wk (Q4_K_M: Q6_K in half the layers; the kernel serves two formats in two passes) —
+    rotates and stores in its epilogue: no rope launch, the f32 projections are never written.  Equal to the oracle, and to the
+    unfused execution bit for bit (same mat-mul arithmetic per tile, same rope arithmetic element for element)."""
     rng = np.random.default_rng(77 + tq * 7 + tv + M)
     E, HD, NH, NKV, NCTX = 1024, 128, 8, 2, 300
     x = rng.standard_normal((M, E)).astype(np.float32)
@@ -1177,7 +1177,19 @@ def test_np_batch_qkv_rope_store_in_the_gemm_epilogue(backend, H, plog, tq, tv, 
     finally:
         backend.set_option("skinny_rope", 1)
     plog(f"    np batch qkv {QNAME[tq]}/{QNAME[tv]} M={M} n_dims={n_dims} bias={bias}: {launches} launches, {epilogues} rope epilogue(s)")
-    assert epilogues == (1 if tq == tv else 0), epilogues  # (a sibling of another format keeps its K split and the separate rope launch)
+    assert epilogues == 1, epilogues
+    assert launches == 2, launches  # the activations' quantiser + the one mat-mul launch
+    if tq != tv:  # the two-format launch against the one-format launches it replaces (wq / wk together, wv alone, rope + stores)
+        backend.set_option("skinny_mix", 0)
+        try:
+            k1 = backend.stat("kernel_launches")
+            apart = T.run_case(build, backend)
+            launches_apart = backend.stat("kernel_launches") - k1
+        finally:
+            backend.set_option("skinny_mix", 1)
+        assert launches_apart > launches, (launches_apart, launches)
+        for name, a, c in zip(("q_rope", "k_cache", "v_cache"), got, apart):
+            assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: two-format launch and separate launches differ"
     for name, a, b, c in zip(("q_rope", "k_cache", "v_cache"), got, ref, plain):
         a32, b32, c32 = (np.asarray(t).astype(np.float32) for t in (a, b, c))
         T.compare(f"np batch qkv {QNAME[tq]}/{QNAME[tv]} M={M} {name}", a32, b32, max_nmse=1e-10 if name == "q_rope" else 1e-6, log=plog)
