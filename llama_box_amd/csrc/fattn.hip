@@ -334,9 +334,11 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     constexpr int D = 128, NG = 16 / G;
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr int TRIP = NG * WV * 4;  // positions per trip
-    static_assert(WV == 4 || (MODE == 0 && !Q8), "the wide form serves plain decode over an f16 cache only");
+    static_assert(WV == 4 || !Q8, "the eight-wave forms serve an f16 cache only");
+    // FAT: one decode token, a few fat splits whose records the wo mat-vec's prologue merges (records also for ONE split, no Q8_K output)
+    constexpr bool FAT = WV == 8 && MODE == 0;
     __shared__ float sh[WV][G][D + 2];
-    __shared__ float qv[WV == 4 ? G * D : 1];  // one pass, Q8_K output: the normalised heads of this kv group before quantisation
+    __shared__ float qv[FAT ? 1 : G * D];  // one pass, Q8_K output: the normalised heads of this kv group before quantisation
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane >> 4, sl = lane & 15;
     const int ul = sl / G, gl = sl % G;  // the (row group, head) pair this lane owns in the lane-parallel part
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         if (ti >= ti1) {
             if (geo.n_splits == 1) {
                 // a token that sees nothing and no combine pass to say so: the CPU's result for such a row is 0 * (1 / 0) = NaN
-                for (int e = tid; e < g_real * 128; e += 256) {
+                for (int e = tid; e < g_real * 128; e += WV * 64) {
                     float * out = (float *) (dst.data + (int64_t) (kvh * g_real + e / 128) * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
                     out[e % 128] = __builtin_nanf("");
                 }
@@ -663,7 +665,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         }
         const int h = kvh * g_real + g;
         const float mt_e = mt * (1.0f / LOG2E);  // records and sinks use the natural-log domain of the generic kernel
-        if (geo.n_splits == 1 && WV == 4) {  // (the wide form always leaves records: its reader is the wo prologue, also for one split)
+        if (geo.n_splits == 1 && (!FAT || geo.rec_stride == D + 2)) {  // (the fat form always leaves records: its reader is the wo prologue, also for one split)
             if (sinks) {
                 const float sk = sinks[h];
                 const float mn = fmaxf(mt_e, sk);
@@ -671,7 +673,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
                 a *= c;
                 lt = lt * c + expf(sk - mn);
             }
-            if (WV == 4 && geo.q8) qv[g * D + dd] = a * (1.0f / lt);  // (quantised below, two heads per Q8_K block)
+            if (!FAT && geo.q8) qv[g * D + dd] = a * (1.0f / lt);  // (quantised below, two heads per Q8_K block)
             else {
                 float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
                 out[dd] = a * (1.0f / lt);
@@ -691,7 +693,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         }
     }
     }  // !empty
-    if constexpr (WV == 4) {
+    if constexpr (!FAT) {
         if (geo.n_splits == 1 && geo.q8) {
             // one pass and the readers are quantised mat-muls: quantize_row_q8_K of head pairs, as k_quantize_q8_K does it
             __syncthreads();
@@ -701,6 +703,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
                 wave_quantize_q8_K(t, lane, (q8k_dev *) geo.q8 + ((int64_t) bat * geo.n_q + tok) * (geo.n_head * D / 256) + (kvh * g_real) / 2 + wave);
             }
         }
+        if constexpr (WV == 4)
         if (geo.n_splits > 1 && geo.arrive) {
             // ---- the last split workgroup of this (token, kv head) to get here merges all records.  Our record went out with agent-scope
             // stores; once they have completed (vmcnt 0) the arrival is counted, and the workgroup that finds n_splits - 1 arrivals before
@@ -1016,9 +1019,17 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         const int lstride = geo.n_kv + 1;
         const bool skip = !list && skip_on && geo.n_q > 1 && (geo.n_q <= 64 || q8) && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
                           (mask->nb[3] % 8) == 0 && ((uintptr_t) mask->data & 7) == 0 && geo.n_splits > 1;
+        // one decode token over an f16 cache: eight waves per workgroup (a trip covers 128 cells: splits of up to 128 cells are ONE trip)
+        // (measured, 2048-token context, 24 splits: 13.45 -> 12.6 us per layer for both launches, 480.7 -> 488.5 tok/s; profiles/r03_decode_ab_fa_wv8.txt)
+        static const int wv8 = getenv("GGML_MI355X_FA_WV8") ? atoi(getenv("GGML_MI355X_FA_WV8")) : 1;
+        static const int list_wv8 = getenv("GGML_MI355X_FA_LIST_WV8") ? atoi(getenv("GGML_MI355X_FA_LIST_WV8")) : 0;
+        const bool list8 = list_wv8 && list && !q8 && !p.arrive;
+        const bool wide8 = wv8 && !q8 && !list && !skip && geo.n_q == 1 && geo.n_splits > 1 && !p.arrive;
 #define FA_DEC(GG)                                                                                                                          \
     {                                                                                                                                       \
-        if (q8) {                                                                                                                           \
+        if (wide8) hipLaunchKernelGGL((k_fattn_dec128<GG, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);           \
+        else if (list8) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride); \
+        else if (q8) {                                                                                                                           \
             if (list) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride);      \
             else if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, 1, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);       \
             else hipLaunchKernelGGL((k_fattn_dec128<GG, 0, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);                 \
