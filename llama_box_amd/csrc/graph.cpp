@@ -1176,7 +1176,10 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
                 // a workgroup (token, KV head) then overwrites only the q rows it alone reads, after it has read them — which needs one
                 // workgroup per (token, KV head), i.e. no slices of the head dimensions.
                 const bool same_rows = ct->data == Q->data && Q->nb[0] == 4 && (int64_t) Q->nb[1] == tok_nb && (int64_t) Q->nb[2] == head_nb && dq_n == 1;
-                if (!ranges_overlap(ct, Q) || same_rows) {
+                // ct's block is written at node i, before the allocator's lifetime for it begins (node jn): besides q, the launch reads the
+                // mask and the K / V views — it must alias none of them (kq, the soft-max and kqv themselves are never materialised here)
+                const bool clear_of_inputs = !ranges_overlap(ct, M) && !ranges_overlap(ct, K) && !ranges_overlap(ct, V);
+                if (clear_of_inputs && (!ranges_overlap(ct, Q) || same_rows)) {
                     jc = jn;
                     od.data = (char *) ct->data;
                     od.nb[0] = 4;
