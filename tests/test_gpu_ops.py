@@ -133,6 +133,47 @@ def test_sibling_mul_mats_share_a_launch(backend, H, plog, qt, M, bias):
         T.compare(f"sibling mat-muls {QNAME[qt]} M={M} bias={bias} {name} vs one by one", a, c, max_nmse=1e-12, log=plog)
 
 
+@pytest.mark.parametrize("tq,tv", [(L.Q4_K, L.Q6_K), (L.Q5_K, L.Q6_K)])
+@pytest.mark.parametrize("M,K,bias", [(32, 4096, False), (5, 4096, True), (17, 1024, False)])
+def test_sibling_mul_mats_of_two_formats_share_a_launch(backend, H, plog, tq, tv, M, K, bias):
+    """2..32 columns: wq / wk in one K-quant format and wv in another (Q4_K_M / Q5_K_M keep wv as Q6_K in half the layers) multiply the
+    same activations in ONE skinny launch — a pass per format over the workgroup's items — here WITHOUT the rope epilogue (the results
+    are graph outputs), so also with a K split and its reduce pass where the tiles alone do not fill the chip (K = 4096: four K slices).
+    Equal to the oracle; against the separate launches (skinny_mix = 0) only the order of the K slices' partial sums may differ."""
+    rng = np.random.default_rng(M * 11 + tq + K)
+    NQ, NK = 1024, 256
+    wq, wk, wv = T.rand_weight(tq, K, NQ, rng), T.rand_weight(tq, K, NK, rng), T.rand_weight(tv, K, NK, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    bq, bk, bv = (rng.standard_normal(n).astype(np.float32) for n in (NQ, NK, NK))
+
+    def build(g):
+        cur = g.new(L.F32, [K, M], x)
+        outs = []
+        for t, w, n, b in ((tq, wq, NQ, bq), (tq, wk, NK, bk), (tv, wv, NK, bv)):
+            r = H.ggml_mul_mat(g.ctx, g.new(t, [K, n], w), cur)
+            if bias:
+                r = H.ggml_add(g.ctx, r, g.new(L.F32, [n], b))
+            outs.append(r)
+        return outs
+
+    ref = T.run_case(build, "oracle")
+    k0, s0 = backend.stat("kernel_launches"), backend.stat("skinny_launches")
+    got = T.run_case(build, backend)
+    launches, served = backend.stat("kernel_launches") - k0, backend.stat("skinny_launches") - s0
+    backend.set_option("skinny_mix", 0)
+    try:
+        k1 = backend.stat("kernel_launches")
+        apart = T.run_case(build, backend)
+        launches_apart = backend.stat("kernel_launches") - k1
+    finally:
+        backend.set_option("skinny_mix", 1)
+    plog(f"    sibling mat-muls {QNAME[tq]}/{QNAME[tv]} M={M} K={K} bias={bias}: {launches} launches in two formats at once, {launches_apart} apart")
+    assert served == 1 and launches <= 3 and launches < launches_apart, (served, launches, launches_apart)  # quantise + mat-mul (+ split-K pass)
+    for name, a, b, c in zip("qkv", got, ref, apart):
+        T.compare(f"two-format siblings {QNAME[tq]}/{QNAME[tv]} M={M} K={K} bias={bias} {name}", a, b, max_nmse=1e-10, log=plog)
+        T.compare(f"two-format siblings {QNAME[tq]}/{QNAME[tv]} M={M} K={K} bias={bias} {name} vs apart", a, c, max_nmse=1e-12, log=plog)
+
+
 @pytest.mark.parametrize("qt", [L.Q4_K, L.Q5_K, L.Q6_K])
 @pytest.mark.parametrize("K,N,M,epi", [
     (512, 32, 3, "none"), (512, 64, 32, "bias"), (1024, 96, 9, "res"), (4096, 512, 32, "res"), (4096, 512, 17, "none"),
