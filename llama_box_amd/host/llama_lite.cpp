@@ -591,6 +591,7 @@ struct llm_context {
     std::vector<kv_cell> cells;
     std::vector<int32_t> mask_cpos, mask_cseq;  // the cells' fields as arrays (mask rows are filled from them)
     int kv_head = 0;
+    int used_max = 0;           // one past the highest occupied cell; < 0: unknown (cells were freed), recounted by the next batch
     // compute graph
     ggml_gallocr_t galloc = nullptr;
     ggml_context * ctx_compute = nullptr;
@@ -773,6 +774,7 @@ extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backe
     }
     ggml_backend_buffer_clear(c->buf_kv, 0);
     c->cells.assign(c->p.n_ctx, kv_cell());
+    c->used_max = 0;
     c->galloc = ggml_gallocr_new(c->buft);
     // reserve the worst-case graph (full micro-batch over the full cache) so later graphs re-use one buffer
     build_graph(c, std::min(c->p.n_ubatch, c->p.n_ctx), c->p.n_ctx, std::min(c->p.n_ubatch, c->p.n_ctx));
@@ -813,13 +815,14 @@ extern "C" void llm_context_free(struct llm_context * c) {
 
 extern "C" void llm_kv_clear(struct llm_context * c) {
     for (auto & x : c->cells) x = kv_cell();
+    c->used_max = 0;
     c->kv_head = 0;
 }
 extern "C" int llm_kv_seq_rm(struct llm_context * c, int seq_id, int p0, int p1) {
     if (p0 < 0) p0 = 0;
     if (p1 < 0) p1 = INT32_MAX;
     for (auto & x : c->cells)
-        if (x.pos >= p0 && x.pos < p1 && (seq_id < 0 || x.seq == seq_id)) x = kv_cell();
+        if (x.pos >= p0 && x.pos < p1 && (seq_id < 0 || x.seq == seq_id)) { x = kv_cell(); c->used_max = -1; }
     c->kv_head = 0;
     return 1;
 }
@@ -875,7 +878,7 @@ extern "C" int llm_kv_seq_add(struct llm_context * c, int seq_id, int p0, int p1
             x.pos += delta;
             d[i] = delta;
             any = true;
-            if (x.pos < 0) x = kv_cell();  // shifted out of the sequence (llama.cpp frees such cells too)
+            if (x.pos < 0) { x = kv_cell(); c->used_max = -1; }  // shifted out of the sequence (llama.cpp frees such cells too)
         }
     }
     return any ? kv_apply_shift(c, d) : 0;
@@ -897,8 +900,13 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
         c->cells[slots[i]].seq = seq_id ? seq_id[i] : 0;
     }
     c->kv_head = (slots.back() + 1) % n_ctx;
-    int used_max = 0;
-    for (int i = 0; i < n_ctx; ++i) if (c->cells[i].pos >= 0) used_max = i + 1;
+    // (kept up to date by the allocations; a full recount only after cells were freed)
+    if (c->used_max < 0) {
+        c->used_max = 0;
+        for (int i = 0; i < n_ctx; ++i) if (c->cells[i].pos >= 0) c->used_max = i + 1;
+    }
+    for (int i = 0; i < n_tokens; ++i) c->used_max = std::max(c->used_max, slots[i] + 1);
+    const int used_max = c->used_max;
     const int n_kv = std::min(n_ctx, (used_max + 255) / 256 * 256);
     std::vector<int32_t> out_ids;
     for (int i = 0; i < n_tokens; ++i) if (!want || want[i]) out_ids.push_back(i);
@@ -1011,6 +1019,7 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     const double t3 = now_us();
     if (st != GGML_STATUS_SUCCESS) {
         for (int i = 0; i < n_tokens; ++i) c->cells[slots[i]] = kv_cell();  // roll the slots back
+        c->used_max = -1;
         return -2;
     }
     if (n_outputs > 0) {
