@@ -317,6 +317,7 @@ static void be_free(ggml_backend_t be) {
     if (c->ws) HIP_CHECK(hipFree(c->ws));
     if (c->up_ring) HIP_CHECK(hipHostFree(c->up_ring));
     if (c->fa_lists) HIP_CHECK(hipFree(c->fa_lists));
+    if (c->rope_tab) HIP_CHECK(hipFree(c->rope_tab));
     if (c->fa_arrive) HIP_CHECK(hipFree(c->fa_arrive));
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c;
@@ -451,6 +452,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->fa_lists_bytes = (size_t) 8 << 20;  // visible-position lists of a small batch: (n_kv + 1) ints per query token
     if (hipMalloc((void **) &c->fa_lists, c->fa_lists_bytes) != hipSuccess) { (void) hipGetLastError(); c->fa_lists = nullptr; c->fa_lists_bytes = 0; }
+    if (hipMalloc((void **) &c->rope_tab, backend_ctx::rope_tab_floats * sizeof(float)) != hipSuccess) { (void) hipGetLastError(); c->rope_tab = nullptr; }
     if (hipMalloc((void **) &c->fa_arrive, backend_ctx::fa_arrive_slots * sizeof(unsigned)) != hipSuccess || hipMemset(c->fa_arrive, 0, backend_ctx::fa_arrive_slots * sizeof(unsigned)) != hipSuccess) {
         (void) hipGetLastError();
         c->fa_arrive = nullptr;

@@ -161,6 +161,8 @@ struct backend_ctx {
     // built once per graph execution and shared by the attention nodes of all layers
     unsigned * fa_arrive = nullptr;  // arrival counters of the self-merging attention splits (zero between launches)
     static constexpr int fa_arrive_slots = 16384;
+    float * rope_tab = nullptr;   // (cos, sin) per (token, rotation pair) of a small batch: written once per graph run, read by every layer's QKV epilogue
+    static constexpr int rope_tab_floats = 32 * 256 * 2;
     int * fa_lists = nullptr;
     size_t fa_lists_bytes = 0;
     // per-class kernel timing (bench)

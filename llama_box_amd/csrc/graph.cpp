@@ -240,6 +240,11 @@ struct exec_state {
     splitk_src sk{};
     const ggml_tensor * epi_dst = nullptr;  // run_mul_mat_q: the skinny launch that produces this tensor carries `epi` (a sibling of another weight format)
     mmq_epi epi{};
+    // the (cos, sin) table of the QKV epilogues (ops.hip: k_rope_table) is valid for these positions / parameters during this execution of the graph
+    const void * rope_tab_pos = nullptr;
+    const void * rope_tab_ff = nullptr;
+    rope_params rope_tab_p{};
+    int rope_tab_m = 0;
     int sk_next = -1;  // node index at which run_mul_mat_q may look ahead (set by the caller: first node after the consumed ones)
     // merged Q/K/V projections whose split-K partial products are summed by the rope + cache-store kernel at node `node`
     struct { int node = -1, n = 0, ks = 0, M = 0; mmq_mat_desc mats[3]; const ggml_tensor * dst[3]; const float * part = nullptr; } rs_sk;
@@ -895,7 +900,18 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         };
         for (size_t q = 0; q < ms.size() && ok; ++q) ok = member_ok(ms[q], mats[q].N);
         for (auto & o : others) ok = ok && member_ok(o, g->nodes[o.k]->src[0]->ne[1]);
+        ok = ok && c->rope_tab && (int64_t) M * epl.a.p.n_dims <= (int64_t) backend_ctx::rope_tab_floats;
         if (ok) {
+            // the rotation's (cos, sin) per (token, pair): the same for every layer of this graph run — computed once, by the first epilogue
+            if (st.rope_tab_pos != (const void *) epl.a.pos || st.rope_tab_ff != (const void *) epl.a.ff || st.rope_tab_m != (int) M || memcmp(&st.rope_tab_p, &epl.a.p, sizeof(rope_params)) != 0) {
+                launch_rope_table(c->stream, epl.a.pos, epl.a.ff, epl.a.p, (int) M, c->rope_tab);
+                c->st.kernel_launches++;
+                st.rope_tab_pos = epl.a.pos;
+                st.rope_tab_ff = epl.a.ff;
+                st.rope_tab_p = epl.a.p;
+                st.rope_tab_m = (int) M;
+            }
+            epi.tab = c->rope_tab;
             rope_host_consts(epl.a.p, epi.theta_scale, epi.corr0, epi.corr1);
             epi.freq_scale = epl.a.p.freq_scale;
             epi.ext_factor = epl.a.p.ext_factor;

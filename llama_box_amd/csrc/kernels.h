@@ -137,6 +137,7 @@ struct mmq_epi {
     const int32_t * pos;
     const float * ff;
     const int64_t * idx;    // cache row of each token
+    const float * tab;      // [token][n_dims / 2][cos, sin]: launch_rope_table's output for these positions and parameters
     float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
     int head_dim, n_dims;
 };
@@ -192,6 +193,8 @@ struct rope_params {
     int sections[4];  // ggml_rope_multi (mode & GGML_ROPE_TYPE_MROPE): pairs per position stream (time, height, width, extra)
 };
 void rope_host_consts(const rope_params & p, float & theta_scale, float & corr0, float & corr1);
+// (cos, sin) of every (token, rotation pair) of a small batch — rope_cos_sin's arithmetic, once per graph run instead of once per layer and element
+void launch_rope_table(hipStream_t s, const int32_t * pos, const float * ff, const rope_params & p, int n_tok, float * tab);
 // batches: ROPE(q) + ROPE(k) + SET_ROWS(k) + SET_ROWS(v) in one launch (f32 sources [head_dim, heads, tokens], f16 cache rows)
 struct rope_store_args {
     const char * q_src; char * q_dst; const char * k_src; const char * v_src;

@@ -407,9 +407,10 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
             const int head = n / a.epi.head_dim, dd = n - head * a.epi.head_dim;
             float r = v;
             if (kind != 3 && dd < a.epi.n_dims) {
-                const rope_consts rc{a.epi.theta_scale, a.epi.freq_scale, a.epi.ext_factor, a.epi.attn_factor, a.epi.corr0, a.epi.corr1};
-                float cs, sn;
-                rope_cos_sin(dd >> 1, (float) a.epi.pos[tk], a.epi.ff, rc, cs, sn);
+                // (cos, sin) of (token, pair): the table launch_rope_table wrote for this graph run — the chain of multiplies and the accurate
+                // cosf / sinf of rope_cos_sin once per step, not once per layer and element (and no scratch frame in this kernel)
+                const float2 cssn = *(const float2 *) (a.epi.tab + ((size_t) tk * (a.epi.n_dims >> 1) + (dd >> 1)) * 2);
+                const float cs = cssn.x, sn = cssn.y;
                 const float x0 = (dd & 1) ? partner : v, x1 = (dd & 1) ? v : partner;
                 r = (dd & 1) ? x0 * sn + x1 * cs : x0 * cs - x1 * sn;
             }

@@ -463,12 +463,28 @@ template <bool F16IO> __global__ void __launch_bounds__(64) k_rope_multi(const t
         }
     }
 }
+__global__ void __launch_bounds__(256) k_rope_table(const int32_t * __restrict__ pos, const float * __restrict__ ff, const rope_consts rc, const int half, float * __restrict__ tab) {
+    const int tok = blockIdx.x, ip = threadIdx.x;
+    if (ip >= half) return;
+    float cs, sn;
+    rope_cos_sin(ip, (float) pos[tok], ff, rc, cs, sn);
+    *(float2 *) (tab + ((size_t) tok * half + ip) * 2) = make_float2(cs, sn);
+}
 void rope_host_consts(const rope_params & p, float & theta_scale, float & c0, float & c1) {
     theta_scale = powf(p.freq_base, -2.0f / (float) p.n_dims);
     // ggml_rope_yarn_corr_dims
     auto corr_dim = [&](float n_rot) { return (float) p.n_dims * logf((float) p.n_ctx_orig / (n_rot * 2.0f * (float) M_PI)) / (2.0f * logf(p.freq_base)); };
     c0 = fmaxf(0.0f, floorf(corr_dim(p.beta_fast)));
     c1 = fminf((float) (p.n_dims - 1), ceilf(corr_dim(p.beta_slow)));
+}
+void launch_rope_table(hipStream_t s, const int32_t * pos, const float * ff, const rope_params & p, int n_tok, float * tab) {
+    rope_consts rc{};
+    rope_host_consts(p, rc.theta_scale, rc.corr0, rc.corr1);
+    rc.freq_scale = p.freq_scale;
+    rc.ext_factor = p.ext_factor;
+    rc.attn_factor = p.attn_factor;
+    const int half = p.n_dims / 2;
+    hipLaunchKernelGGL(k_rope_table, dim3((unsigned) n_tok), dim3((unsigned) ((half + 63) / 64 * 64)), 0, s, pos, ff, rc, half, tab);
 }
 // Batches: ROPE(q), ROPE(k) -> SET_ROWS(k cache), SET_ROWS(v cache) as ONE launch (four nodes of every layer; at a few
 // dozen tokens each of them sits at the dependent-launch floor).  Query heads are rotated f32 -> f32 (in place when the allocator

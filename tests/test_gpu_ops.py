@@ -1219,7 +1219,7 @@ def test_np_batch_qkv_rope_store_in_the_gemm_epilogue(backend, H, plog, tq, tv, 
         backend.set_option("skinny_rope", 1)
     plog(f"    np batch qkv {QNAME[tq]}/{QNAME[tv]} M={M} n_dims={n_dims} bias={bias}: {launches} launches, {epilogues} rope epilogue(s)")
     assert epilogues == 1, epilogues
-    assert launches == 2, launches  # the activations' quantiser + the one mat-mul launch
+    assert launches == 3, launches  # the activations' quantiser + the (cos, sin) table of the batch (once per graph run) + the one mat-mul launch
     if tq != tv:  # the two-format launch against the one-format launches it replaces (wq / wk together, wv alone, rope + stores)
         backend.set_option("skinny_mix", 0)
         try:
