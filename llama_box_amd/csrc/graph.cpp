@@ -269,6 +269,22 @@ static int graph_use_count(const ggml_cgraph * g, const ggml_tensor * t) {
     }
     return -1;
 }
+// (cos, sin) per (token, rotation pair) of the batch at `pos` (ops.hip: k_rope_table), valid for this execution of the graph: every
+// layer rotates with the same positions and parameters, so the chain of multiplies and the accurate cosf / sinf run once per graph run
+static const float * ensure_rope_table(exec_state & st, const int32_t * pos, const float * ff, const rope_params & p, int M) {
+    backend_ctx * c = st.c;
+    static const bool on = !getenv("GGML_MI355X_ROPE_TABLE") || atoi(getenv("GGML_MI355X_ROPE_TABLE")) != 0;
+    if (!on || !c->rope_tab || M < 1 || (int64_t) M * p.n_dims > (int64_t) backend_ctx::rope_tab_floats) return nullptr;
+    if (st.rope_tab_pos != (const void *) pos || st.rope_tab_ff != (const void *) ff || st.rope_tab_m != M || memcmp(&st.rope_tab_p, &p, sizeof(rope_params)) != 0) {
+        launch_rope_table(c->stream, pos, ff, p, M, c->rope_tab);
+        c->st.kernel_launches++;
+        st.rope_tab_pos = pos;
+        st.rope_tab_ff = ff;
+        st.rope_tab_p = p;
+        st.rope_tab_m = M;
+    }
+    return c->rope_tab;
+}
 static void mark_done(exec_state & st, int k) {
     st.done[k] = 1;
     st.ooo.push_back(k);
@@ -706,6 +722,8 @@ static bool try_fuse_qkv(exec_state & st, int i) {
         base.freq_scale = p.freq_scale;
         base.ext_factor = p.ext_factor;
         base.attn_factor = p.attn_factor;
+        memset(p.sections, 0, sizeof(p.sections));
+        base.rope_tab = ensure_rope_table(st, base.pos, base.freq_factors, p, 1);
     } else {
         base.head_dim = 2;
         base.pos = nullptr;
@@ -900,18 +918,12 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         };
         for (size_t q = 0; q < ms.size() && ok; ++q) ok = member_ok(ms[q], mats[q].N);
         for (auto & o : others) ok = ok && member_ok(o, g->nodes[o.k]->src[0]->ne[1]);
-        ok = ok && c->rope_tab && (int64_t) M * epl.a.p.n_dims <= (int64_t) backend_ctx::rope_tab_floats;
+        // the rotation's (cos, sin) per (token, pair): the same for every layer of this graph run — computed once, by the first epilogue
         if (ok) {
-            // the rotation's (cos, sin) per (token, pair): the same for every layer of this graph run — computed once, by the first epilogue
-            if (st.rope_tab_pos != (const void *) epl.a.pos || st.rope_tab_ff != (const void *) epl.a.ff || st.rope_tab_m != (int) M || memcmp(&st.rope_tab_p, &epl.a.p, sizeof(rope_params)) != 0) {
-                launch_rope_table(c->stream, epl.a.pos, epl.a.ff, epl.a.p, (int) M, c->rope_tab);
-                c->st.kernel_launches++;
-                st.rope_tab_pos = epl.a.pos;
-                st.rope_tab_ff = epl.a.ff;
-                st.rope_tab_p = epl.a.p;
-                st.rope_tab_m = (int) M;
-            }
-            epi.tab = c->rope_tab;
+            epi.tab = ensure_rope_table(st, epl.a.pos, epl.a.ff, epl.a.p, (int) M);
+            ok = epi.tab != nullptr;
+        }
+        if (ok) {
             rope_host_consts(epl.a.p, epi.theta_scale, epi.corr0, epi.corr1);
             epi.freq_scale = epl.a.p.freq_scale;
             epi.ext_factor = epl.a.p.ext_factor;

@@ -105,6 +105,7 @@ struct qkv_args {
     const float * freq_factors;
     float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
     const int64_t * slot;
+    const float * rope_tab;  // optional: [head_dim / 2][cos, sin] for this token (launch_rope_table) instead of computing them in every workgroup's prologue
     int wg_a;  // set by launch_qkv: workgroups [0, wg_a) serve the alt == 0 segments, the rest the alt == 1 segments
 };
 bool qkv_types_supported(int type_a, int type_b);

@@ -116,7 +116,12 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
     // ---- prologue A: rotary table for this token (threads 0 .. head_dim/2-1)
     if (tid < half && a.pos != nullptr) {
         float cs, sn;
-        rope_cos_sin(tid, (float) a.pos[0], a.freq_factors, rope_consts{a.theta_scale, a.freq_scale, a.ext_factor, a.attn_factor, a.corr0, a.corr1}, cs, sn);
+        if (a.rope_tab) {  // written once per graph run: the multiply chain + accurate cosf / sinf are ~1 us in the prologue of this workgroup's first wave
+            const float2 t2 = ((const float2 *) a.rope_tab)[tid];
+            cs = t2.x;
+            sn = t2.y;
+        } else
+            rope_cos_sin(tid, (float) a.pos[0], a.freq_factors, rope_consts{a.theta_scale, a.freq_scale, a.ext_factor, a.attn_factor, a.corr0, a.corr1}, cs, sn);
         cs_tab[2 * tid] = cs;
         cs_tab[2 * tid + 1] = sn;
     }
