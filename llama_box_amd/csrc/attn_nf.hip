@@ -25,7 +25,9 @@ namespace mi355x {
 #define NF_CAP 1024  // visible cells per token served from registers and LDS
 template <int G>
 __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const int * __restrict__ lists,
-                                                      const int list_stride, float * __restrict__ scratch, const float scale, const int dq_n) {
+                                                      const int list_stride, float * __restrict__ scratch, const float scale, const int dq_n, q8k_dev * __restrict__ q8) {
+    // q8 != null (only with dq_n == 1 and an even G): the result's only readers are quantised mat-muls (wo) — it leaves the kernel as the
+    // Q8_K blocks quantize_row_q8_K builds of the token's row (a block = two heads), through the q area of the LDS, and not as f32
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) float nf_smem[];  // q [G][128] | positions [NF_CAP] | probabilities [G][NF_CAP]
     __shared__ float shf[4];
@@ -39,8 +41,22 @@ __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc
     float * sc = scratch + (((int64_t) tok * nkv_heads + kvh) * dq_n + dq) * (int64_t) G * n_kv;  // [G][n_kv], the first cnt of each row in use
     const int rows_per = D / dq_n, d0 = dq * rows_per;
     auto out_ptr = [&](const int g, const int d) { return (float *) (dst.data + (int64_t) d * dst.nb[0] + (int64_t) tok * dst.nb[1] + (int64_t) (kvh * G + g) * dst.nb[2]); };
+    auto put = [&](const int g, const int d, const float t) {
+        if (q8) nf_smem[g * D + d] = t;
+        else *out_ptr(g, d) = t;
+    };
+    auto finish = [&]() {  // (q8) every wave has stored its rows: quantise head pairs
+        if (!q8) return;
+        __syncthreads();
+        if (wave < G / 2) {
+            const float4 t4 = ((const float4 *) (nf_smem + wave * 256))[lane];
+            const float t[4] = {t4.x, t4.y, t4.z, t4.w};
+            wave_quantize_q8_K(t, lane, q8 + (int64_t) tok * (nkv_heads * G * D / 256) + (kvh * G) / 2 + wave);
+        }
+    };
     if (cnt == 0) {  // a token that sees nothing: the CPU's row is expf(-inf - -inf) = NaN throughout
-        for (int e = tid; e < G * rows_per; e += 256) *out_ptr(e / rows_per, d0 + e % rows_per) = __builtin_nanf("");
+        for (int e = tid; e < G * rows_per; e += 256) put(e / rows_per, d0 + e % rows_per, __builtin_nanf(""));
+        finish();
         return;
     }
     const char * mrow = mask.data + (int64_t) tok * mask.nb[1];
@@ -176,7 +192,7 @@ __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const float t = wave_sum(acc[r][g]);
-                    if (lane == 0 && r0 + r < rows_per) *out_ptr(g, d0 + r0 + r) = t;
+                    if (lane == 0 && r0 + r < rows_per) put(g, d0 + r0 + r, t);
                 }
         }
         };
@@ -184,6 +200,7 @@ __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc
         if (G <= 4 && rows_per >= 64) vtp(std::integral_constant<int, 16>{});
         else if (rows_per >= 32) vtp(std::integral_constant<int, 8>{});
         else vtp(std::integral_constant<int, 4>{});
+        finish();
         return;
     }
     // ---- longer lists (a token that sees thousands of cells): the same three steps through scratch memory
@@ -270,9 +287,10 @@ __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float t = wave_sum(acc[g]);
-            if (lane == 0) *out_ptr(g, d) = t;
+            if (lane == 0) put(g, d, t);
         }
     }
+    finish();
 }
 
 // scratch floats the launch needs (0: the shape is not served)
@@ -294,7 +312,7 @@ size_t attn_nf_list_scratch_bytes(const tdesc & q, const tdesc & k, int * dq_out
 // q: the permuted view [D, T, NH] MUL_MAT reads as src1; k: [D, n_kv, NKV] f16; v: the transposed view [n_kv, D, NKV] f16; dst: the
 // second MUL_MAT's result [D, T, NH] f32.  false: not served (the caller runs the three nodes one by one)
 bool launch_attn_nf_list(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc & mask, const tdesc & dst, const int * lists, int list_stride,
-                         float * scratch, size_t scratch_bytes, float scale) {
+                         float * scratch, size_t scratch_bytes, float scale, void * q8_out) {
     int dq = 1;
     const size_t need = attn_nf_list_scratch_bytes(q, k, &dq);
     if (need == 0 || need > scratch_bytes || !scratch || !lists) return false;
@@ -303,8 +321,9 @@ bool launch_attn_nf_list(hipStream_t s, const tdesc & q, const tdesc & k, const 
     if ((k.nb[1] % 16) || (k.nb[2] % 16) || (((uintptr_t) k.data) & 15) || (q.nb[1] % 16) || (q.nb[2] % 16) || (((uintptr_t) q.data) & 15)) return false;
     if ((mask.type != GGML_TYPE_F16 && mask.type != GGML_TYPE_F32) || mask.ne[0] < k.ne[1] || mask.ne[1] < q.ne[1] || mask.ne[2] != 1 || mask.ne[3] != 1) return false;
     const int G = (int) (q.ne[2] / k.ne[2]);
+    if (q8_out && (dq != 1 || (G & 1))) return false;  // Q8_K blocks are head pairs of whole rows
     dim3 grid((unsigned) q.ne[1], (unsigned) k.ne[2], (unsigned) dq);
-#define NF(G_) case G_: hipLaunchKernelGGL(k_attn_nf_list<G_>, grid, dim3(256), (size_t) (G_ * 128 + NF_CAP + G_ * NF_CAP) * 4, s, q, k, v, mask, dst, lists, list_stride, scratch, scale, dq); return true;
+#define NF(G_) case G_: hipLaunchKernelGGL(k_attn_nf_list<G_>, grid, dim3(256), (size_t) (G_ * 128 + NF_CAP + G_ * NF_CAP) * 4, s, q, k, v, mask, dst, lists, list_stride, scratch, scale, dq, (q8k_dev *) q8_out); return true;
     switch (G) { NF(1) NF(2) NF(3) NF(4) NF(5) NF(6) NF(7) NF(8) default: break; }
 #undef NF
     return false;

@@ -902,7 +902,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
         }
         // (all three in ONE launch only: a sibling of another weight format — wv as Q6_K — would run alone without its K split, 32 workgroups for
         // 1024 rows, and cost more than the rope launch saves: measured 4.27 -> 4.40 ms per -np 32 step with it, 4.27 -> 4.2 without)
-        ok = ok && epl.a.p.mode == 0 && (epl.a.head_dim % 2) == 0 && ms.size() == 3 && others.empty() && !epl.a.v_idx;  // (the epilogue stores V as cache rows only)
+        ok = ok && epl.a.p.mode == 0 && (epl.a.head_dim % 2) == 0 && ms.size() == 3 && others.empty();  // (V: cache rows, or — non-flash path — the elements of the transposed cache)
         auto role_of = [&](const member & m) {
             for (int sidx = 0; sidx < 3; ++sidx)
                 if (through_views(epl.src[sidx]) == m.dst) return sidx;
@@ -931,6 +931,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
             epi.pos = epl.a.pos;
             epi.ff = epl.a.ff;
             epi.idx = epl.a.idx;
+            epi.v_idx = epl.a.v_idx;
             epi.head_dim = epl.a.head_dim;
             epi.n_dims = epl.a.p.n_dims;
             ks = 1;
@@ -938,7 +939,7 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
             epi_node = -1;
     }
     auto epi_fill = [&](mmq_epi & e, int slot, int role) {  // role: 0 q, 1 k, 2 v
-        e.kind[slot] = role == 0 ? 1 : (role == 1 ? 2 : 3);
+        e.kind[slot] = role == 0 ? 1 : (role == 1 ? 2 : (epl.a.v_idx ? 4 : 3));
         e.out[slot] = role == 0 ? epl.a.q_dst : (role == 1 ? epl.a.k_cache : epl.a.v_cache);
         e.nb1[slot] = role == 0 ? epl.a.qd_nb1 : (role == 1 ? epl.a.kc_nb1 : epl.a.vc_nb1);
         e.nb2[slot] = role == 0 ? epl.a.qd_nb2 : 0;
@@ -1229,8 +1230,16 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
         st.fa_list_mask = M->data;
         st.fa_list_tile = 1;
     }
+    // the copy is read only by quantised mat-muls (wo): the rows leave the launch as Q8_K blocks in the activation scratch (no f32, no quantiser launch)
+    void * q8_out = nullptr;
+    if (jc >= 0 && dq_n == 1 && (Q->ne[2] / K->ne[2]) % 2 == 0 && c->opt.prologue && !(g->nodes[jc]->flags & GGML_TENSOR_FLAG_OUTPUT) && quant_consumers_only(st, jc, g->nodes[jc]))
+        q8_out = (char *) c->ws + st.act_off;
     timed_scope ts(c, "attn_nf_list", (double) ggml_abi_nbytes(kqv));
-    if (!launch_attn_nf_list(c->stream, qd, kd, vd, md, od, c->fa_lists, (int) K->ne[1] + 1, scratch, scratch_bytes, ggml_abi_op_param_f32(sm, 0))) return false;
+    if (!launch_attn_nf_list(c->stream, qd, kd, vd, md, od, c->fa_lists, (int) K->ne[1] + 1, scratch, scratch_bytes, ggml_abi_op_param_f32(sm, 0), q8_out)) return false;
+    if (q8_out) {
+        mark_q8_cache(st, g->nodes[jc]);
+        c->st.fused_nodes++;
+    }
     c->st.kernel_launches++;
     mark_done(st, js);
     mark_done(st, jv);

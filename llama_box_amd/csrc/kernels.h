@@ -118,7 +118,7 @@ size_t mul_mat_f_workspace_bytes(const tdesc & src0, const tdesc & src1);
 // ---- non-flash attention chain of a small batch over position lists (attn_nf.hip)
 size_t attn_nf_list_scratch_bytes(const tdesc & q, const tdesc & k, int * dq_out);
 bool launch_attn_nf_list(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc & mask, const tdesc & dst, const int * lists, int list_stride,
-                         float * scratch, size_t scratch_bytes, float scale);
+                         float * scratch, size_t scratch_bytes, float scale, void * q8_out = nullptr /* Q8_K blocks of the rows instead of f32 (one head-dimension slice, even group size) */);
 bool launch_soft_max_mul_mat_f16(hipStream_t s, const tdesc & a, const tdesc & kq, const tdesc * mask, const tdesc & d, float scale);  // decode: SOFT_MAX folded into V^T.p (mmf.hip)
 
 // ---- prefill: quantised weights x many columns through MFMA (mmq.hip)
@@ -132,12 +132,14 @@ struct mmq_mat_desc { const uint8_t * W; int64_t w_nb1; int N; float * dst; int6
 // KV-cache stores happen where the projections' sums are complete — the rope + store launch of ops.hip (k_rope_qk_store) disappears.
 // Adjacent-pair ("normal") rotation only: both elements of a pair sit in one 32-row tile.
 struct mmq_epi {
-    int kind[3];            // per matrix of the launch: 0 plain, 1 ROPE -> f32 rope(q) tensor, 2 ROPE -> f16 cache rows (k), 3 f16 cache rows (v)
+    int kind[3];            // per matrix of the launch: 0 plain, 1 ROPE -> f32 rope(q) tensor, 2 ROPE -> f16 cache rows (k), 3 f16 cache rows (v),
+                            // 4 f16 elements of the TRANSPOSED V cache (non-flash path): value n of token t -> element v_idx[t * N + n]
     char * out[3];          // kind 1: rope(q) data; 2 / 3: cache data
     int64_t nb1[3], nb2[3]; // kind 1: bytes per head / per token of rope(q); 2 / 3: nb1 = bytes per cache row
     const int32_t * pos;
     const float * ff;
     const int64_t * idx;    // cache row of each token
+    const int64_t * v_idx;  // kind 4: one cache element index per (token, value)
     const float * tab;      // [token][n_dims / 2][cos, sin]: launch_rope_table's output for these positions and parameters
     float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
     int head_dim, n_dims;

@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
             const int64_t e_nb2 = mi == 0 ? a.epi.nb2[0] : (mi == 1 ? a.epi.nb2[1] : a.epi.nb2[2]);
             const int head = n / a.epi.head_dim, dd = n - head * a.epi.head_dim;
             float r = v;
-            if (kind != 3 && dd < a.epi.n_dims) {
+            if (kind < 3 && dd < a.epi.n_dims) {
                 // (cos, sin) of (token, pair): the table launch_rope_table wrote for this graph run — the chain of multiplies and the accurate
                 // cosf / sinf of rope_cos_sin once per step, not once per layer and element (and no scratch frame in this kernel)
                 const float2 cssn = *(const float2 *) (a.epi.tab + ((size_t) tk * (a.epi.n_dims >> 1) + (dd >> 1)) * 2);
@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(SK_NW * 64, 1) k_mmq_skinny(const mmq8_args a)
             }
             if (tok >= a.M) continue;
             if (kind == 1) *(float *) (e_out + (int64_t) head * e_nb1 + (int64_t) tok * e_nb2 + (int64_t) dd * 4) = r;
+            else if (kind == 4) ((uint16_t *) e_out)[a.epi.v_idx[(int64_t) tok * mN + n]] = f2h(r);
             else ((uint16_t *) (e_out + a.epi.idx[tok] * e_nb1))[n] = f2h(r);
             }
         }

@@ -335,6 +335,57 @@ def test_non_flash_attention_chain(backend, H, plog, NH, NKV, n_kv, n_vis, T_):
         assert launches <= 3, launches  # list scan, the fused chain, CONT
 
 
+@pytest.mark.parametrize("NH,NKV,n_kv,T_,wt", [(32, 8, 7296, 32, L.Q4_K), (32, 8, 512, 16, L.Q6_K), (32, 8, 1024, 24, L.Q6_K), (28, 4, 2048, 32, L.Q5_K)])
+def test_non_flash_attention_chain_into_wo(backend, H, plog, NH, NKV, n_kv, T_, wt):
+    """The -np decode step of llama-box's default (non-flash) path up to the attention output projection: K.q -> SOFT_MAX -> V^T.p -> CONT ->
+    wo.  When the copy is read only by quantised mat-muls, the list kernel leaves the rows as Q8_K blocks (two heads per block) in the
+    activation scratch: no f32 rows, no quantiser launch.  Equal to the oracle within the mat-mul gate, and to the execution with the
+    f32 rows + quantiser launch (prologue = 0) bit for bit — same sums, same quantiser arithmetic."""
+    rng = np.random.default_rng(NH * 19 + n_kv + T_ + wt)
+    HD, EK, E = 128, NKV * 128, NH * 128
+    q = rng.standard_normal((T_, NH, HD)).astype(np.float32)
+    kc = (rng.standard_normal((n_kv, EK)) * 0.5).astype(np.float16)
+    vt = (rng.standard_normal((EK, n_kv)) * 0.5).astype(np.float16)
+    wo = T.rand_weight(wt, E, 512, rng)
+    TP = (T_ + 63) // 64 * 64
+    mask = np.full((TP, n_kv), -np.inf, np.float32)
+    run_ = (n_kv // 2) // T_ // 4 * 4
+    for t in range(T_):
+        mask[t, t * run_:(t + 1) * run_] = 0
+        mask[t, T_ * run_ + t::T_] = 0
+
+    def build(g):
+        qq = H.ggml_permute(g.ctx, g.new(L.F32, [HD, NH, T_], q), 0, 2, 1, 3)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [EK, n_kv], kc), HD, n_kv, NKV, EK * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [n_kv, EK], vt), n_kv, HD, NKV, n_kv * 2, n_kv * 2 * HD, 0)
+        kq = H.ggml_mul_mat(g.ctx, k, qq)
+        p = H.ggml_soft_max_ext(g.ctx, kq, g.new(L.F32, [n_kv, TP], mask), 1.0 / np.sqrt(HD), 0.0)
+        kqv = H.ggml_mul_mat(g.ctx, v, p)
+        cur = H.ggml_cont_2d(g.ctx, H.ggml_permute(g.ctx, kqv, 0, 2, 1, 3), HD * NH, T_)
+        return H.ggml_mul_mat(g.ctx, g.new(wt, [E, 512], wo), cur)
+
+    ref = T.run_case(build, "oracle", NT)
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    backend.set_option("prologue", 0)
+    try:
+        k1 = backend.stat("kernel_launches")
+        plain = T.run_case(build, backend)
+        launches_plain = backend.stat("kernel_launches") - k1
+    finally:
+        backend.set_option("prologue", 1)
+    _log(plog, f"non-flash attention -> wo heads={NH}/{NKV} n_kv={n_kv} tokens={T_} wo={QNAME[wt]}: {launches} launches, {launches_plain} with the f32 rows + quantiser")
+    G = NH // NKV
+    # (Q8_K blocks are head pairs of whole rows: an even group size, and one workgroup per (token, KV head) — with fewer than 192 of those
+    # the kernel slices the head dimensions to fill the chip and the rows leave as f32)
+    handed_over = G % 2 == 0 and T_ * NKV >= 192
+    assert launches == launches_plain - (1 if handed_over else 0), (launches, launches_plain)
+    # (the attention's own rounding flips — see test_non_flash_attention_chain — pass through the 8-bit activation quantiser: ~1e-6 of the output)
+    T.compare(f"non-flash attention -> wo heads={NH}/{NKV} n_kv={n_kv} tokens={T_} wo={QNAME[wt]}", got[0], ref[0], max_nmse=5e-6, log=plog)
+    assert np.array_equal(np.asarray(got[0]), np.asarray(plain[0])), "Q8_K hand-off and f32 rows + quantiser differ"
+
+
 # ------------------------------------------------------------------------------------------------ split graphs (ADVICE r01 #1)
 def test_split_graph_keeps_tensors_read_by_another_split(backend, H, plog):
     """ggml_backend_sched hands a backend ONE split (a ggml_graph_view).  A tensor whose other reader sits in the next split

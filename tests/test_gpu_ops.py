@@ -1175,7 +1175,7 @@ def test_fused_qkv_transposed_v_store(backend, H, plog, tq, tv):
 
 
 @pytest.mark.parametrize("tq,tv,M,n_dims,bias", [(L.Q4_K, L.Q4_K, 32, 128, False), (L.Q4_K, L.Q6_K, 32, 128, False), (L.Q4_K, L.Q6_K, 7, 128, True),
-                                                  (L.Q5_K, L.Q5_K, 19, 64, False), (L.Q6_K, L.Q6_K, 32, 128, True)])
+                                                  (L.Q5_K, L.Q5_K, 19, 64, False), (L.Q6_K, L.Q6_K, 32, 128, True), (L.Q5_K, L.Q6_K, 32, 128, False), (L.Q5_K, L.Q6_K, 3, 64, True)])
 def test_np_batch_qkv_rope_store_in_the_gemm_epilogue(backend, H, plog, tq, tv, M, n_dims, bias):
     """-np decode step (3..32 tokens): wq / wk / wv -> (+bias) -> rope(q, k) -> KV-cache stores.  ONE skinny launch — also when wv is
     stored in another K-quant format than wq / wk (Q4_K_M: Q6_K in half the layers; the kernel serves two formats in two passes) —
@@ -1320,6 +1320,54 @@ def test_batch_rope_and_transposed_v_store_one_launch(backend, H, plog, T_):
         assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused differ"
         T.compare(f"batch rope + transposed V store T={T_} {name}", np.asarray(a).astype(np.float32), np.asarray(b).astype(np.float32),
                   max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
+
+
+@pytest.mark.parametrize("tq,tv,M", [(L.Q4_K, L.Q4_K, 32), (L.Q4_K, L.Q6_K, 32), (L.Q4_K, L.Q6_K, 5)])
+def test_np_batch_qkv_rope_store_epilogue_with_the_transposed_v_cache(backend, H, plog, tq, tv, M):
+    """The same step on the NON-flash path (llama-box's default): V lives transposed in its cache, llama.cpp stores it with one index per
+    ELEMENT.  The skinny launch's epilogue scatters the V values there itself (kind 4) — no rope + store launch on this path either.
+    Equal to the oracle and bit for bit to the execution with the separate launch."""
+    rng = np.random.default_rng(311 + tq + tv + M)
+    E, HD, NH, NKV, NCTX = 1024, 128, 8, 2, 300
+    x = rng.standard_normal((M, E)).astype(np.float32)
+    wq, wk, wv = T.rand_weight(tq, E, NH * HD, rng), T.rand_weight(tq, E, NKV * HD, rng), T.rand_weight(tv, E, NKV * HD, rng)
+    kc0 = rng.standard_normal((NCTX, NKV * HD)).astype(np.float16)
+    vc0 = rng.standard_normal((NKV * HD, NCTX)).astype(np.float16)
+    pos = rng.integers(0, 5000, M).astype(np.int32)
+    rows = rng.permutation(NCTX)[:M].astype(np.int64)
+    v_idx = (np.arange(NKV * HD, dtype=np.int64)[None, :] * NCTX + rows[:, None]).reshape(-1)
+
+    def build(g):
+        cur = g.new(L.F32, [E, M], x)
+        q = H.ggml_mul_mat(g.ctx, g.new(tq, [E, NH * HD], wq), cur)
+        k = H.ggml_mul_mat(g.ctx, g.new(tq, [E, NKV * HD], wk), cur)
+        v = H.ggml_mul_mat(g.ctx, g.new(tv, [E, NKV * HD], wv), cur)
+        tp = g.new(L.I32, [M], pos)
+        idx = g.new(L.I64, [M], rows)
+        vidx = g.new(L.I64, [M * NKV * HD], v_idx)
+        q = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, q, HD, NH, M), tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        k = H.ggml_rope_ext(g.ctx, H.ggml_reshape_3d(g.ctx, k, HD, NKV, M), tp, None, HD, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        ks = H.ggml_set_rows(g.ctx, g.new(L.F16, [NKV * HD, NCTX], kc0), H.ggml_reshape_2d(g.ctx, k, NKV * HD, M), idx)
+        v_view = H.ggml_reshape_2d(g.ctx, g.new(L.F16, [NCTX, NKV * HD], vc0), 1, NCTX * NKV * HD)
+        vs = H.ggml_set_rows(g.ctx, v_view, H.ggml_reshape_2d(g.ctx, v, 1, M * NKV * HD), vidx)
+        return [q, ks, vs]
+
+    ref = T.run_case(build, "oracle", expand_first=())
+    e0 = backend.stat("rope_epilogues")
+    got = T.run_case(build, backend)
+    epilogues = backend.stat("rope_epilogues") - e0
+    backend.set_option("skinny_rope", 0)
+    try:
+        plain = T.run_case(build, backend)
+    finally:
+        backend.set_option("skinny_rope", 1)
+    assert epilogues == 1, epilogues
+    for name, a, b, c in zip(("q_rope", "k_cache", "v_cache_T"), got, ref, plain):
+        a32, b32 = (np.asarray(t).astype(np.float32) for t in (a, b))
+        T.compare(f"np batch qkv (transposed V) {QNAME[tq]}/{QNAME[tv]} M={M} {name}", a32, b32, max_nmse=1e-10 if name == "q_rope" else 1e-6, log=plog)
+        assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: epilogue and separate rope launch differ"
+    vt = np.asarray(got[2]).reshape(NKV * HD, NCTX)
+    assert np.array_equal(np.delete(vt, rows, axis=1), np.delete(vc0, rows, axis=1)), "cells of other tokens were touched"
 
 
 # ------------------------------------------------------------------------------------------------ fused chains
