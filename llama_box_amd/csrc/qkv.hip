@@ -278,7 +278,10 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     // needs the whole activation row in one batch of 2 blocks per wave
     static const int force_nw = getenv("GGML_MI355X_QKV_WAVES") ? atoi(getenv("GGML_MI355X_QKV_WAVES")) : 0;
     int nw = std::min(16, std::max((nblk + 1) / 2, 8));
-    while (nw < 16 && (units[0] + nw - 1) / nw + (units[1] + nw - 1) / nw > 256) ++nw;  // smallest workgroup that still gives every wave one unit
+    // smallest workgroup that still gives every wave one unit — counted over both formats together: two formats at 12 waves need 257
+    // workgroups for Llama-3-8B (the 256 are then shared by bytes, a few waves take two units), which measures 12.5 us against 13.2 us for
+    // 13-wave workgroups that fit (profiles/r03_decode_lab.txt #6)
+    while (nw < 16 && (units[0] + units[1] + nw - 1) / nw > 256) ++nw;
     if (force_nw) nw = force_nw;
     if (q8_store) nw = 16;  // a workgroup trip = 16 row pairs = one block_q8_0 of the cache row (caller checked the alignment)
     const dim3 block((unsigned) nw * 64);
