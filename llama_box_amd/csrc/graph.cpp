@@ -900,8 +900,9 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
             ok = plan_rope_store(st, epi_node, epl);
             for (int f : flagged) st.done[f] = false;
         }
-        // (all three in ONE launch only: a sibling of another weight format — wv as Q6_K — would run alone without its K split, 32 workgroups for
-        // 1024 rows, and cost more than the rope launch saves: measured 4.27 -> 4.40 ms per -np 32 step with it, 4.27 -> 4.2 without)
+        // (all three in ONE launch only — a wv stored in another K-quant format has joined it above (skinny_mix).  A sibling left outside would run
+        // alone without its K split, 32 workgroups for 1024 rows, and cost more than the rope launch saves: measured 4.27 -> 4.40 ms per
+        // -np 32 step in round 2)
         ok = ok && epl.a.p.mode == 0 && (epl.a.head_dim % 2) == 0 && ms.size() == 3 && others.empty();  // (V: cache rows, or — non-flash path — the elements of the transposed cache)
         auto role_of = [&](const member & m) {
             for (int sidx = 0; sidx < 3; ++sidx)

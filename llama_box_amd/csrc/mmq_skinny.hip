@@ -25,6 +25,9 @@
 //     f16 MFMA per unit on the f16 bsums the quantisers store (exact: |.| < 2^24), as in mmq_i8.hip.
 //   * Q6_K blocks are 210 bytes at 2-byte alignment: the unit is fetched as 4-byte-aligned 16-byte pieces (dwordx4 only needs
 //     dword alignment) and shifted by 0 / 2 bytes on the way into LDS (v_alignbyte + the neighbour lane's first dword).
+// Forms in this file: the K-parallel kernel above for any shape (k_mmq_skinny<QA, QB, EPI>; QA != QB: matrices of two formats in one
+// launch, one pass per format; EPI: rope + KV-cache stores in the epilogue), the tile-parallel LDS-DMA kernels for the gate/up pair
+// (k_mmq_skinny_tp, four waves; k_mmq_skinny_tp8, two waves per tile: round 3), and the same unit turned towards prompt batches (k_mmq_wide).
 #include <algorithm>
 #include <type_traits>
 
