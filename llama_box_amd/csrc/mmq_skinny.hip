@@ -1088,7 +1088,9 @@ bool mmq_skinny_supported(int type, int64_t K, int64_t N, int64_t M, int64_t w_n
     // rows packed back to back (then every matrix of a launch has the same row stride)
     if (type == GGML_TYPE_Q4_K) return w_nb1 == (K / 256) * 144;
     if (type == GGML_TYPE_Q5_K) return w_nb1 == (K / 256) * 176;
-    if (type == GGML_TYPE_Q6_K) return w_nb1 == (K / 256) * 210 && (w_nb1 % 4) == 0;  // dword-aligned rows: the 0 / 2-byte shift of a super-block is the same in every row
+    // (a Q6_K matrix of 64 k rows and more — the output matrix — stays on the tiled GEMM: 144 us against 170 us here for 128256 x 4096 at
+    // 32 columns, profiles/r03_np32_ab_q6_tiled.txt; this kernel's Q6_K unit is bound by its integer VALU, the tiled one converts once per 64 columns)
+    if (type == GGML_TYPE_Q6_K) return N < 65536 && w_nb1 == (K / 256) * 210 && (w_nb1 % 4) == 0;  // dword-aligned rows: the 0 / 2-byte shift of a super-block is the same in every row
     return false;
 }
 
