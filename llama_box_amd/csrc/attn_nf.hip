@@ -23,12 +23,14 @@
 namespace mi355x {
 
 #define NF_CAP 1024  // visible cells per token served from registers and LDS
+struct __attribute__((aligned(4))) u32x4a { uint32_t x, y, z, w; };  // a 16-byte load that only promises dword alignment
 template <int G>
 __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const tdesc dst, const int * __restrict__ lists,
-                                                      const int list_stride, float * __restrict__ scratch, const float scale, const int dq_n, q8k_dev * __restrict__ q8) {
+                                                      const int list_stride, float * __restrict__ scratch, const float scale, const int dq_n, q8k_dev * __restrict__ q8, const int nf_groups_on) {
     // q8 != null (only with dq_n == 1 and an even G): the result's only readers are quantised mat-muls (wo) — it leaves the kernel as the
     // Q8_K blocks quantize_row_q8_K builds of the token's row (a block = two heads), through the q area of the LDS, and not as f32
     constexpr int D = 128;
+    const bool nf_groups = nf_groups_on;
     extern __shared__ __attribute__((aligned(16))) float nf_smem[];  // q [G][128] | positions [NF_CAP] | probabilities [G][NF_CAP]
     __shared__ float shf[4];
     __shared__ double shd[4];
@@ -197,6 +199,90 @@ __global__ void __launch_bounds__(256) k_attn_nf_list(const tdesc q, const tdesc
         }
         };
         // rows per wave and block: as many as keep all four waves busy with this workgroup's slice of the head dimensions
+        // 3'. The same product with LANES on the rows of V^T and the list walked in GROUPS of eight entries.  A token's prompt is a run of
+        // consecutive cells (the unified cache hands cells out first-fit): eight consecutive cells of a row are ONE 16-byte load, and only
+        // the scattered rest — the decode cells of interleaved sequences — is gathered two bytes at a time.  The launch is bound by the
+        // address pipeline (every lane of these loads sits in another cache line: ~65 clocks per wave-instruction), so the count of load
+        // instructions is what matters: at 128 + 72 cells a wave issues 8 + 36 of them instead of 128, and a lane owns its row's sums (no
+        // 64-lane reductions).  Waves 0 / 1 take the even groups of rows 0..63 / 64..127, waves 2 / 3 the odd groups; the halves meet in LDS.
+        // One slice of the head dimensions and at most 512 cells (64 groups: one ballot); the form above serves the rest.
+        if (dq_n == 1 && cnt <= 512 && nf_groups) {
+            const int ngr = (cnt + 7) / 8, gi_l = lane;
+            const bool in = gi_l < ngr;
+            const int p_first = pos_s[min(8 * gi_l, cnt - 1)], p_last = pos_s[min(8 * gi_l + 7, cnt - 1)];
+            const bool is_run = in && 8 * gi_l + 7 < cnt && p_last == p_first + 7 && (p_first & 1) == 0;  // ascending list: consecutive; even start: dword-aligned
+            const int wv = __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform for the compiler too: the masks and group indices below are scalars)
+            const unsigned long long par = (wv >> 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+            unsigned long long m_run = __ballot(is_run) & par, m_sc = __ballot(in && !is_run) & par;
+            const int row = 64 * (wv & 1) + lane;
+            const char * vr = vbase + (int64_t) row * v.nb[1];
+            float acc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = 0.0f;
+            auto take = [](unsigned long long & m) { const int i = __builtin_ctzll(m); m &= m - 1; return i; };
+            // runs: up to eight 16-byte loads in flight
+            while (m_run) {
+                int gi[8];
+                u32x4a x[8];
+                int n = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    gi[u] = m_run ? take(m_run) : -1;
+                    if (gi[u] >= 0) { x[u] = *(const u32x4a *) (vr + (int64_t) pos_s[8 * gi[u]] * 2); n = u + 1; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u >= n) break;
+                    const uint32_t w4[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                    float xf[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { xf[2 * k] = h2f((uint16_t) (w4[k] & 0xFFFF)); xf[2 * k + 1] = h2f((uint16_t) (w4[k] >> 16)); }
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float4 pa = *(const float4 *) (p_s + g * NF_CAP + 8 * gi[u]), pb = *(const float4 *) (p_s + g * NF_CAP + 8 * gi[u] + 4);
+                        const float pv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[g] = fmaf(xf[k], pv[k], acc[g]);
+                    }
+                }
+            }
+            // scattered groups: the gathers of up to five groups (40 two-byte loads) in flight together
+            while (m_sc) {
+                int gi[5];
+                uint16_t xs[5][8];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    gi[u] = m_sc ? take(m_sc) : -1;
+                    if (gi[u] >= 0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) xs[u][k] = *(const uint16_t *) (vr + (int64_t) pos_s[min(8 * gi[u] + k, cnt - 1)] * 2);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    if (gi[u] < 0) break;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (8 * gi[u] + k >= cnt) break;
+                        const float xv = h2f(xs[u][k]);
+#pragma unroll
+                        for (int g = 0; g < G; ++g) acc[g] = fmaf(xv, p_s[g * NF_CAP + 8 * gi[u] + k], acc[g]);
+                    }
+                }
+            }
+            __syncthreads();  // every wave is done with the probabilities: their area carries the odd groups' sums over
+            if (wv >> 1) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) p_s[g * D + row] = acc[g];
+            }
+            __syncthreads();
+            if (!(wv >> 1)) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) put(g, row, acc[g] + p_s[g * D + row]);
+            }
+            finish();
+            return;
+        }
         if (G <= 4 && rows_per >= 64) vtp(std::integral_constant<int, 16>{});
         else if (rows_per >= 32) vtp(std::integral_constant<int, 8>{});
         else vtp(std::integral_constant<int, 4>{});
@@ -322,8 +408,9 @@ bool launch_attn_nf_list(hipStream_t s, const tdesc & q, const tdesc & k, const 
     if ((mask.type != GGML_TYPE_F16 && mask.type != GGML_TYPE_F32) || mask.ne[0] < k.ne[1] || mask.ne[1] < q.ne[1] || mask.ne[2] != 1 || mask.ne[3] != 1) return false;
     const int G = (int) (q.ne[2] / k.ne[2]);
     if (q8_out && (dq != 1 || (G & 1))) return false;  // Q8_K blocks are head pairs of whole rows
+    static const int groups_on = !getenv("GGML_MI355X_NF_GROUPS") || atoi(getenv("GGML_MI355X_NF_GROUPS")) != 0;
     dim3 grid((unsigned) q.ne[1], (unsigned) k.ne[2], (unsigned) dq);
-#define NF(G_) case G_: hipLaunchKernelGGL(k_attn_nf_list<G_>, grid, dim3(256), (size_t) (G_ * 128 + NF_CAP + G_ * NF_CAP) * 4, s, q, k, v, mask, dst, lists, list_stride, scratch, scale, dq, (q8k_dev *) q8_out); return true;
+#define NF(G_) case G_: hipLaunchKernelGGL(k_attn_nf_list<G_>, grid, dim3(256), (size_t) (G_ * 128 + NF_CAP + G_ * NF_CAP) * 4, s, q, k, v, mask, dst, lists, list_stride, scratch, scale, dq, (q8k_dev *) q8_out, groups_on); return true;
     switch (G) { NF(1) NF(2) NF(3) NF(4) NF(5) NF(6) NF(7) NF(8) default: break; }
 #undef NF
     return false;
