@@ -89,8 +89,10 @@ static void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t 
 // waits for the engine first: the buffer vtable through uploader_drain(), a backend's stream through an event (uploader_join()).
 // No repack: the bytes land verbatim.  Any failure inside falls back to the plain synchronous copy.
 struct uploader {
-    int device = -1;
-    bool failed = false;
+    // device / failed / in_flight are read without the mutex on the fast paths (every decode step passes uploader_join): atomics.
+    // Initialisation happens once, under mtx (two RPC connections may issue their first set_tensor concurrently — ADVICE r03).
+    std::atomic<int> device{-1};
+    std::atomic<bool> failed{false};
     hipStream_t stream = nullptr;
     static constexpr int NSLOT = 3;
     char * slot[NSLOT] = {nullptr, nullptr, nullptr};
@@ -99,7 +101,7 @@ struct uploader {
     size_t slot_bytes = 0;
     int next = 0;
     hipEvent_t last = nullptr;  // recorded behind the newest DMA
-    bool in_flight = false;
+    std::atomic<bool> in_flight{false};
     int n_threads = 1;
     std::mutex mtx;  // set_tensor may come from several host threads (RPC connections share the backend: SURVEY.md §8b "Threading")
     uint64_t bytes = 0;
@@ -130,6 +132,9 @@ static uploader * uploader_for(int device) {
     if (u->failed) return nullptr;
     if (u->device == device) return u;
     if (!g_staged_upload.load(std::memory_order_relaxed)) return nullptr;
+    std::lock_guard<std::mutex> init_lock(u->mtx);
+    if (u->failed) return nullptr;
+    if (u->device == device) return u;  // another thread initialised it while this one waited
     const char * e_mb = getenv("GGML_MI355X_UPLOAD_SLOT_MIB");
     const char * e_th = getenv("GGML_MI355X_UPLOAD_THREADS");
     u->slot_bytes = (size_t) std::max(1, e_mb ? atoi(e_mb) : 32) << 20;
@@ -566,7 +571,6 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "skinny_launches") return c->st.skinny_launches;
     if (k == "wide_launches") return c->st.wide_launches;
     if (k == "tiled_launches") return c->st.tiled_launches;
-    if (k == "shadow_launches") return c->st.shadow_launches;
     if (k == "rope_epilogues") return c->st.rope_epilogues;
     if (k == "staged_upload_bytes") return (int64_t) g_uploaders[c->device].bytes;
     if (k == "staged_upload_us") return (int64_t) (g_uploaders[c->device].seconds * 1e6);

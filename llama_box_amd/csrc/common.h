@@ -107,7 +107,6 @@ struct stats {
     int64_t graph_launches = 0, graph_captures = 0, eager_graphs = 0, kernel_launches = 0, fused_nodes = 0, allreduces = 0;
     int64_t skinny_launches = 0;       // mat-muls of 2..32 columns served by the weight-streaming matrix-core kernel
     int64_t wide_launches = 0;         // prompt-batch mat-muls served by its wide form
-    int64_t shadow_launches = 0;       // prompt-batch mat-muls served by the plain int8 GEMM over the pre-expanded shadow planes (mmq_shadow.hip)
     int64_t tiled_launches = 0;        // batch mat-muls served by the LDS-tiled int8 GEMM (mmq_i8.hip)
     int64_t rope_epilogues = 0;        // batches whose rope + KV-cache stores rode in the skinny QKV launches
     int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)

@@ -741,12 +741,7 @@ static int skinny_n_cu();
 //   L2); request order per step [activations of s+1, weights of s+2] so that what step s+1 consumes is older than what stays in flight
 //   (in-order vmcnt).  Items (128-row group, token tile group) of one weight group run on the same XCD at the same time: its L2
 //   serves the weight bytes to all of them.
-#ifndef WD_KO
-#define WD_KO 0  // timing-only knock-outs of the wide kernel (wrong results): 1 no MFMAs, 2 no weight conversion, 3 no requests after the prologue
-#endif
-#ifndef WD_NB
-#define WD_NB 2  // stages of the activation ring (3 = requested two steps ahead, like the weights: measured equal, A/B on one box)
-#endif
+constexpr int WD_NB = 2;  // stages of the activation ring (3 = requested two steps ahead, like the weights: measured equal, A/B on one box)
 template <int QT, int TT, int NW> constexpr int wd_lds_bytes() { return WD_NB * TT * (SK_B_BYTES + 128) + NW * 3 * tp_a_stage<QT>(); }
 constexpr int WD_NL = 2;  // loader waves per workgroup
 
@@ -887,13 +882,8 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
         }
         __syncthreads();  // everything of step s is in LDS, and nobody reads step s - 1 any more
         if (loader || SELF) {
-#if WD_KO != 3
             if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
             if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
-#else
-            if (vb < n_virtual) { ++nb; WD_ADV(vb, sbb) }
-            if (va < n_virtual) { ++na; WD_ADV(va, sa) }
-#endif
             if (!SELF) continue;
         }
 
@@ -941,13 +931,8 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
                 const uint32_t e0 = (p & 1) ? sk_rep_byte<2>(src) : sk_rep_byte<0>(src), e1 = (p & 1) ? sk_rep_byte<3>(src) : sk_rep_byte<1>(src);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-#if WD_KO == 2
-                    W0[p][n][k] = (int) (hdr.y + k + n);
-                    W1[p][n][k] = (int) (hdr.z + k + p);
-#else
                     W0[p][n][k] = (int) sk_pk_mul(wlo[k], e0);
                     W1[p][n][k] = (int) sk_pk_mul(whi[k], e1);
-#endif
                 }
             }
         }
@@ -960,27 +945,12 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
             int16s pl[NP];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-#if WD_KO == 4
-                const int4s y0 = {(int) hdr.x + p, (int) hdr.y, (int) hdr.z + t, (int) hdr.w}, y1 = {(int) hdr.y + p, (int) hdr.x, (int) hdr.w + t, (int) hdr.z};
-#else
                 const int4s y0 = *(const int4s *) (btok + 64 * p + 16 * g);
                 const int4s y1 = *(const int4s *) (btok + 64 * p + 32 + 16 * g);
-#endif
 #pragma unroll
-#if WD_KO == 1
-                for (int n = 0; n < NP; ++n) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pl[n][e] = (p == 0 ? 0 : pl[n][e]) + y0[e] + W0[p][n][e] + y1[e] + W1[p][n][e];
-                    if (p == 0) {
-#pragma unroll
-                        for (int e = 4; e < 16; ++e) pl[n][e] = 0;
-                    }
-                }
-#else
                 for (int n = 0; n < NP; ++n) pl[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(y0, W0[p][n], p == 0 ? zeroi : pl[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NP; ++n) pl[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(y1, W1[p][n], pl[n], 0, 0, 0);
-#endif
             }
             const half8s bsf = *(const half8s *) (btok + 256 + 16 * g);
             const float16s ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, __builtin_bit_cast(half8s, mfu), zerof, 0, 0, 0);
@@ -994,12 +964,8 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
                     int isum;
                     if constexpr (QT == 4) isum = (pl[1][i] << 3) + pl[0][i];
                     else isum = (pl[2][i] << 4) + (pl[1][i] << 2) + pl[0][i];
-#if WD_KO == 5
-                    acc[t][i] += __builtin_bit_cast(float, isum) + ms[i] + dyv[r];
-#else
                     const float v = __builtin_fmaf(-dmin, ms[i], d * (float) isum);
                     acc[t][i] = __builtin_fmaf(dyv[r], v, acc[t][i]);
-#endif
                 }
             }
         }

@@ -253,6 +253,27 @@ static split_helper * helper_for(backend_ctx * c, int d) {
     }
     return c->split_helpers[d];
 }
+// Called with the helper's device current, before its workspace is freed and regrown.  hipFree() waits for the allocation's OWN
+// device only, but since round 3 the main device's k_reduce_parts reads the partial products out of this workspace over peer access
+// on c->stream: wait for both streams, so that no reader — local or remote — can still be queued.
+static bool quiesce_readers(backend_ctx * c, split_helper * h) {
+    HIP_TRY(hipStreamSynchronize(h->stream), false);
+    HIP_TRY(hipSetDevice(c->device), false);
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (hipSetDevice(h->ordinal) != hipSuccess || e != hipSuccess) {
+        (void) hipGetLastError();
+        MI_ERR("split buffer: waiting for the main stream before a workspace regrow failed");
+        return false;
+    }
+    return true;
+}
+// run_split_* are called with the main device current and return with it current on EVERY path: the early returns of HIP_TRY
+// inside their per-device loops used to leave a helper's device current for graph_compute's failure path.
+struct main_device_guard {
+    int device;
+    explicit main_device_guard(const backend_ctx * c) : device(c->device) {}
+    ~main_device_guard() { if (hipSetDevice(device) != hipSuccess) (void) hipGetLastError(); }
+};
 void free_split_helpers(backend_ctx * c) {
     for (split_helper * h : c->split_helpers) {
         if (!h) continue;
@@ -281,6 +302,7 @@ bool split_mul_mat_supported(const ggml_tensor * op) {
 
 // dst[N, M] = W[K, N] (rows split over the devices) x b[K, M]; called with the main device current and returns with it current
 bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor * b, ggml_tensor * dst) {
+    const main_device_guard restore_device(c);
     const split_tensor_info * info = split_info(w);
     if (!info) return false;
     if (info->kind == 1) return run_split_rowpar(c, w, b, dst, nullptr);
@@ -300,7 +322,7 @@ bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor
         const size_t need = ((x_bytes + 255) & ~(size_t) 255) + ((q_bytes + 255) & ~(size_t) 255) + (size_t) rows * M * sizeof(float) + 256;
         if (need > h->ws_size) {
             if (c->capturing) { (void) hipSetDevice(c->device); return false; }  // (sized on the eager first sighting of a topology; never inside a capture)
-            HIP_TRY(hipStreamSynchronize(h->stream), false);
+            if (!quiesce_readers(c, h)) { (void) hipSetDevice(c->device); return false; }
             if (h->ws) (void) hipFree(h->ws);
             h->ws = nullptr;
             h->ws_size = 0;
@@ -355,7 +377,7 @@ bool run_split_mul_mat(backend_ctx * c, const ggml_tensor * w, const ggml_tensor
 static bool helper_ws(backend_ctx * c, split_helper * h, size_t need) {
     if (need <= h->ws_size) return true;
     if (c->capturing) return false;  // (sized on the eager first sighting of a topology; never inside a capture)
-    HIP_TRY(hipStreamSynchronize(h->stream), false);
+    if (!quiesce_readers(c, h)) return false;
     if (h->ws) (void) hipFree(h->ws);
     h->ws = nullptr;
     h->ws_size = 0;
@@ -407,6 +429,7 @@ static bool join_and_reduce(backend_ctx * c, const split_tensor_info * info, flo
 }
 
 bool run_split_rowpar(backend_ctx * c, const ggml_tensor * w, const ggml_tensor * b, ggml_tensor * dst, const ggml_tensor * add) {
+    const main_device_guard restore_device(c);
     const split_tensor_info * info = split_info(w);
     if (!info || info->kind != 1 || (ggml_abi_nelements(dst) % 4) != 0) return false;
     const int64_t K = w->ne[0], N = w->ne[1], M = b->ne[1] * b->ne[2] * b->ne[3];
@@ -447,6 +470,7 @@ bool split_ffn_applies(const ggml_tensor * wg, const ggml_tensor * wu, const ggm
 }
 
 bool run_split_ffn(backend_ctx * c, const ggml_tensor * wg, const ggml_tensor * wu, const ggml_tensor * wd, const ggml_tensor * x, ggml_tensor * dst, const ggml_tensor * add) {
+    const main_device_guard restore_device(c);
     const split_tensor_info * ig = split_info(wg), * iu = split_info(wu), * id = split_info(wd);
     const int64_t E = wg->ne[0], N = wd->ne[1], M = x->ne[1] * x->ne[2] * x->ne[3];
     if (!c->split_ready) HIP_TRY(hipEventCreateWithFlags(&c->split_ready, hipEventDisableTiming), false);

@@ -88,8 +88,12 @@ int tp_init(backend_ctx * c, int rank, int world, const void * uid, size_t uid_s
     // graph.cpp).  A replay that hangs has no fallback, though, and this path has not run on multi-GPU hardware yet: with a communicator
     // attached, graphs are OPT-IN — GGML_MI355X_TP_GRAPHS=1, or the host's explicit set_option("graphs", 1) after tp_init (bench.py does
     // that for its second, watchdog-guarded leg).  ADVICE r02.
+    // Only ever LOWERED here: a host that switched graphs off before tp_init keeps them off whatever the environment says.
     const char * e = getenv("GGML_MI355X_TP_GRAPHS");
-    c->opt.graphs = e != nullptr && atoi(e) != 0;
+    const bool env_on = e != nullptr && atoi(e) != 0;
+    c->opt.graphs = c->opt.graphs && env_on;
+    MI_INFO("tensor parallel rank %d / %d: hipGraph replay of steps with all-reduces is %s (GGML_MI355X_TP_GRAPHS=%s; set_option(\"graphs\", 1) after tp_init turns it on)",
+            rank, world, c->opt.graphs ? "ON" : "off", e ? e : "unset");
     return 0;
 }
 

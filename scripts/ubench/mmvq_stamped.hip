@@ -1,3 +1,4 @@
+// LAB COPY of llama_box_amd/csrc/mmvq.hip (round 3 state) with in-kernel wall-clock stamps (-DMI_LAB_STAMPS); built only by scripts/ubench/run_lab.sh.
 // mmvq.hip — decode mat-vec for GGUF-quantised weights: y[N] (x up to 8 columns) = W[N x K] · x[K].
 //
 // This is THE bandwidth-bound kernel of the hot path (~95 % of decode time is weight streaming, SURVEY.md §8a
@@ -24,6 +25,17 @@
 #include "mmvq_types.h"
 
 namespace mi355x {
+
+// scripts/ubench/decode_lab.hip builds a private copy of this file with -DMI_LAB_STAMPS: wave 0 of every workgroup records the
+// 100 MHz wall clock at a few points of k_mmvq_stream (where does a launch's fixed cost go?).  Nothing of it exists in the product.
+#ifdef MI_LAB_STAMPS
+__device__ unsigned long long * g_lab_stamps = nullptr;
+// (the launch's slot in the stamp buffer rides in a.dst_stride, which the single-column kernel does not read)
+#define MI_STAMP(k) do { if (g_lab_stamps && threadIdx.x == 0) g_lab_stamps[((size_t) a.dst_stride * 256 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+void lab_set_stamps(unsigned long long * p) { (void) hipMemcpyToSymbol(HIP_SYMBOL(g_lab_stamps), &p, sizeof(p)); }
+#else
+#define MI_STAMP(k) do { } while (0)
+#endif
 
 thread_local launch_probe g_launch_probe;
 
@@ -244,6 +256,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
             }
         }
     };
+    MI_STAMP(0);
     // Order of the first requests (scripts/ubench/decode_lab.hip, stamp_lab.hip, prologue_probe.hip — DESIGN.md §4):
     //   f32 prologue (PRO 1: wo, ffn_down): the activation row FIRST, then the first weights, both unconditionally (clamped
     //     addresses): wo 6.0 -> 5.4 us, ffn_down Q4_K 11.7 -> 10.3, Q6_K 15.8 -> 14.7.  A load under `if (...)` makes hipcc's
@@ -305,6 +318,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
             }
         }
     }
+    MI_STAMP(1);
 
     // ---- activation prologue
     if constexpr (PRO == 0) {
@@ -379,6 +393,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ss += (double) (v[u].x * v[u].x) + (double) (v[u].y * v[u].y) + (double) (v[u].z * v[u].z) + (double) (v[u].w * v[u].w);
                 ss = wave_sum_d(ss);
+                MI_STAMP(2);
                 if (lane == 0) red[wave] = ss;
                 __syncthreads();  // reached exactly once by every wave: the loop condition admits b0 == wave
                 double tot = 0.0;
@@ -407,9 +422,11 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         }
     }
     __syncthreads();
+    MI_STAMP(3);
     const act * y = (const act *) smem;
 
     float acc = 0.0f, acc2 = 0.0f;
+    int lab_first = 1;
     while (have) {
         int nrow = row, nch = ch + 1;
         if (nch == nchunks) { nch = 0; nrow = next_row(row); }
@@ -442,7 +459,9 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         row = nrow;
         ch = nch;
         have = nhave;
+        if (lab_first) { MI_STAMP(4); lab_first = 0; }
     }
+    MI_STAMP(5);
 }
 
 template <typename T, bool GLU, int PRO> static void launch_stream(hipStream_t s, const mmvq_args & a) {

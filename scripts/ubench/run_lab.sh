@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 for d in ${DEPTHS:-4}; do echo "== GGML_MI355X_DMA_DEPTH=$d" | tee -a gpurun_out/decode_lab.txt; GGML_MI355X_DMA_DEPTH=$d timeout 300 /tmp/decode_lab 2>&1 | tee -a gpurun_out/decode_lab.txt; done
 if [ "${STAMPS:-0}" = "1" ]; then
 F="--offload-arch=gfx950 -fvisibility=hidden -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DGGML_MAX_NAME=128 -Iinclude"
-/opt/rocm/bin/hipcc $F -DMI_LAB_STAMPS -c llama_box_amd/csrc/mmvq.hip -o /tmp/mmvq_st.o
+/opt/rocm/bin/hipcc $F -DMI_LAB_STAMPS -c -I llama_box_amd/csrc scripts/ubench/mmvq_stamped.hip -o /tmp/mmvq_st.o
 /opt/rocm/bin/hipcc $F -DMI_LAB_STAMPS -c scripts/ubench/stamp_lab.hip -o /tmp/stamp_lab.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/stamp_lab.o /tmp/mmvq_st.o -o /tmp/stamp_lab
 timeout 300 /tmp/stamp_lab 2>&1 | tee gpurun_out/stamp_lab.txt

@@ -1,5 +1,5 @@
-// shadow_probe.hip — stand-alone check + timing of the shadow-plane GEMM (llama_box_amd/csrc/mmq_shadow_dev.h).
-//   build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I llama_box_amd/csrc -I include -DGGML_MAX_NAME=128 [-DSH_KO=n] scripts/ubench/shadow_probe.hip -o scripts/ubench/shadow_probe.bin
+// shadow_probe.hip — stand-alone check + timing of the shadow-plane GEMM (scripts/ubench/mmq_shadow_dev.h; lab code, not part of libggml-mi355x.so).
+//   build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I scripts/ubench -I llama_box_amd/csrc -I include -DGGML_MAX_NAME=128 [-DSH_KO=n] scripts/ubench/shadow_probe.hip -o scripts/ubench/shadow_probe.bin
 //   run:    scripts/ubench/shadow_probe.bin            (prints one line per shape: max relative error of sampled outputs vs a CPU restatement, us, TFLOP/s)
 // The CPU side restates the contract the kernel serves (ggml-cpu's vec_dot_q{4,6}_K_q8_K: integer block sums, one f32 scale-accumulate per
 // super-block) in double precision on a sample of the outputs.
