@@ -69,7 +69,7 @@ def pmc_traffic(symbol, args):
     env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_CHILD="1")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", out, "-o", "pmc", "--output-format", "csv", "--",
            sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--prefill", "256" if args.np == 1 else "64", "--timing-steps", "0", "--no-cpu-baseline",
-           "--pmc-traffic", "0", "--preset", args.preset, "--fa", str(args.fa), "--np", str(args.np)]
+           "--pmc-traffic", "0", "--preset", args.preset, "--fa", str(args.fa), "--np", str(args.np), "--draft", str(args.draft)]
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
         files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--prefill", type=int, default=2048)
     ap.add_argument("--fa", type=int, default=1)
     ap.add_argument("--np", type=int, default=1, help="parallel sequences decoded per step (llama-box -np continuous batching)")
+    ap.add_argument("--draft", type=int, default=0, help="speculative decoding: every step is one llama_decode over np x (1 + draft) tokens with logits at every position, then the "
+                                                          "drafts are dropped from the cache (worst case of the verification; llama-box httpserver.hpp:4042-4069, :4696-4768)")
     ap.add_argument("--ubatch", type=int, default=512)
     ap.add_argument("--n-batch", type=int, default=2048, dest="n_batch", help="prompt tokens per llama_decode call (llama-box -b); several slots' prompts share a call")
     ap.add_argument("--ctkv", default="f16", choices=["f16", "q8_0"], help="KV cache type (llama-box --cache-type-k / --cache-type-v); the headline metric is quoted on f16")
@@ -110,17 +112,41 @@ def main():
     ap.add_argument("--pmc-traffic", type=int, default=1, help="1: re-run a short decode under rocprofv3 --pmc FETCH_SIZE (own pass) for roofline.traffic")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks ourselves, exactly as the driver's multi-GPU line does (one process
+        # per GPU under torch.distributed.run, rendezvous on 127.0.0.1), and hand its exit code on.  A plain invocation used to run
+        # ONE rank silently and print "n_gpus": 1.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        # the ranks that came up are not the GPUs that were asked for: no line at all is better than a line about another job
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run (launch with --nproc-per-node {args.gpus}, or plain `python bench.py --gpus {args.gpus}`)", file=sys.stderr)
+        sys.exit(2)
 
     import numpy as np
     import torch  # first: one HIP runtime per process (torch's and /opt/rocm's share the SONAME)
 
-    n_dev = max(1, torch.cuda.device_count())
-    local_rank %= n_dev  # (more ranks than GPUs only happens in the single-GPU dry run of the multi-rank path)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (world > n_dev and os.environ.get("BENCH_ALLOW_SHARED_GPU") != "1"):
+        # one rank per GPU or nothing (BENCH_ALLOW_SHARED_GPU=1: the dry run of the multi-rank path on a one-GPU box, tests/test_gpu_model.py)
+        if rank == 0:
+            print(f"bench.py: {world} rank(s) but {n_dev} GPU(s) visible: refusing to run", file=sys.stderr)
+        sys.exit(3)
+    shared_gpu = world > n_dev
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -170,10 +196,11 @@ def main():
     t_load = time.time() - t_load
     kvt = L.Q8_0 if args.ctkv == "q8_0" else 0
     extra_leg = (args.warmup + args.steps) if (world > 1 or os.environ.get("BENCH_FORCE_TWO_LEGS") == "1") else 0  # tensor-split runs time the decode steps twice (eager, then graph replay)
-    n_ctx = (args.np * (args.prefill + args.warmup + args.steps + extra_leg + args.timing_steps + 64) + 255) // 256 * 256
+    n_ctx = (args.np * (args.prefill + args.warmup + args.steps + extra_leg + args.timing_steps + 64 + args.draft) + 255) // 256 * 256
     ctx = Context(model, backend=be, n_ctx=n_ctx, n_ubatch=args.ubatch, flash_attn=args.fa, graph_reuse=1, type_k=kvt, type_v=kvt)
     rng = np.random.default_rng(1 + 0 * rank)
-    toks = rng.integers(0, hp.n_vocab, args.np * (args.prefill + args.warmup + args.steps + extra_leg + args.timing_steps + 8))
+    T1 = 1 + args.draft  # tokens per sequence and step
+    toks = rng.integers(0, hp.n_vocab, args.np * T1 * (args.prefill + args.warmup + args.steps + extra_leg + args.timing_steps + 8))
 
     def sync():
         if dist is not None:
@@ -209,13 +236,16 @@ def main():
     seq_ids = list(range(args.np))
 
     def step(i):
+        if args.draft:
+            return steps(1, pos + i)
         rc, lg = ctx.decode([int(toks[(pos + i) * args.np + sq]) for sq in range(args.np)], [pos + i] * args.np, seq=seq_ids, copy_logits=False)
         assert rc == 0, f"decode failed rc={rc}"
         return lg
 
-    def steps(n):  # n consecutive llama_decode calls issued by the host library itself (llama-box's loop is C++, not Python)
-        rows = [[int(toks[(pos + i) * args.np + sq]) for sq in range(args.np)] for i in range(n)]
-        rc = ctx.decode_steps(rows, args.np, pos)
+    def steps(n, at=None):  # n consecutive llama_decode calls issued by the host library itself (llama-box's loop is C++, not Python)
+        p0 = pos if at is None else at
+        rows = [[int(toks[(p0 + i) * args.np * T1 + k]) for k in range(args.np * T1)] for i in range(n)]
+        rc = ctx.verify_steps(rows, args.np, args.draft, p0) if args.draft else ctx.decode_steps(rows, args.np, p0)
         assert rc == 0, f"decode failed rc={rc}"
 
     def leg():  # W untimed warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks
@@ -242,16 +272,18 @@ def main():
 
     def headline(el, extra_note=""):  # the contract's fields for a K-step time (everything else is added to it below)
         st = 1 if tp_size > 1 or world == 1 else world
+        draft_note = f" with {args.draft} drafts per sequence (speculative-decoding batch shape, M = {args.np * T1})" if args.draft else ""
         return {
-            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M" if args.preset == "llama3-8b-q4_k_m" and args.np == 1 else
-                      f"decode tokens/sec ({'batch-1' if args.np == 1 else f'-np {args.np} aggregate'}) + prefill tok/s, {args.preset} [secondary configuration, not the headline metric]",
-            "value": round(st * args.np * args.steps / el, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M" if args.preset == "llama3-8b-q4_k_m" and args.np == 1 and args.draft == 0 else
+                      f"decode tokens/sec ({'batch-1' if args.np == 1 else f'-np {args.np} aggregate'}" + (f", {T1} positions per sequence and step verified: 1 sampled + {args.draft} drafts, all rejected" if args.draft else "")
+                      + f") + prefill tok/s, {args.preset} [secondary configuration, not the headline metric]",
+            "value": round(st * args.np * T1 * args.steps / el, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None,
             "dtype": ("q8_0 weights x q8_0 activations" if "q8_0" in args.preset else ("q5_K/q6_K" if "q5_k" in args.preset else "q4_K/q6_K") + " weights x q8_K activations") + " (int8 dot, f32 accumulate)",
             "data": "synthetic (GGUF-exact tensor set, directly sampled quant blocks, random token ids)",
-            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode, flash_attn={args.fa}, kv_cache={args.ctkv}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
-                       "parallelism": parallelism + extra_note},
+            "config": {"workload": f"{args.preset}: {args.prefill}-token prefill then {'batch-1' if args.np == 1 else f'-np {args.np} continuous-batching'} decode{draft_note}, flash_attn={args.fa}, kv_cache={args.ctkv}, n_ctx={n_ctx}, n_ubatch={args.ubatch}" + (f" [DEBUG n_layer={args.layers}]" if args.layers else ""),
+                       "parallelism": parallelism + extra_note + (" [DRY RUN: the ranks share one GPU]" if shared_gpu else "")},
         }
 
     tp_legs = None
@@ -287,7 +319,7 @@ def main():
     else:
         elapsed, graph_steps, graph_launch_host_us = leg()
     streams = 1 if tp_size > 1 or world == 1 else world
-    tok_s = streams * args.np * args.steps / elapsed
+    tok_s = streams * args.np * args.steps / elapsed  # (sequence-steps per second: what the byte accounting below multiplies by)
     host_split = [x / max(1, args.steps) for x in ctx.timings()]
 
     # ---- per-kernel-class timing pass (eager, hipEvents on the backend's stream)

@@ -1083,6 +1083,30 @@ extern "C" int llm_decode_steps(struct llm_context * c, int n_steps, int n_par, 
     for (int k = 0; k < 4; ++k) c->timings[k] = acc[k];
     return 0;
 }
+// Speculative decoding as llama-box drives it (httpserver.hpp:4042-4069: every slot's sampled token plus its drafts go into ONE batch, logits
+// requested at every position; :4696-4768: the drafts are verified against them and the rejected tail is removed from the cache with
+// llama_memory_seq_rm).  One step here = one llama_decode over n_par x (1 + n_draft) tokens — sequence s at positions p .. p + n_draft —
+// followed by the WORST case of the verification: every draft rejected (seq_rm of p + 1 ..), so the next step starts at p + 1.
+// tokens: [n_steps][n_par][1 + n_draft].
+extern "C" int llm_verify_steps(struct llm_context * c, int n_steps, int n_par, int n_draft, const int32_t * tokens, int pos0) {
+    if (n_steps <= 0 || n_par <= 0 || n_draft < 0 || !tokens) return -1;
+    const int T1 = 1 + n_draft, n = n_par * T1;
+    std::vector<int32_t> pos((size_t) n), seq((size_t) n);
+    for (int s = 0; s < n_par; ++s)
+        for (int j = 0; j < T1; ++j) seq[(size_t) s * T1 + j] = s;
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n_steps; ++i) {
+        for (int s = 0; s < n_par; ++s)
+            for (int j = 0; j < T1; ++j) pos[(size_t) s * T1 + j] = pos0 + i + j;
+        const int rc = llm_decode(c, n, tokens + (size_t) i * n, pos.data(), seq.data(), nullptr);
+        if (rc != 0) return rc;
+        for (int k = 0; k < 4; ++k) acc[k] += c->timings[k];
+        if (n_draft > 0)
+            for (int s = 0; s < n_par; ++s) llm_kv_seq_rm(c, s, pos0 + i + 1, -1);
+    }
+    for (int k = 0; k < 4; ++k) c->timings[k] = acc[k];
+    return 0;
+}
 extern "C" int llm_n_outputs(const struct llm_context * c) { return c->n_outputs; }
 extern "C" float * llm_get_logits(struct llm_context * c) { return c->logits_base; }
 // llama_get_logits_ith (include/llama.h; the reference reads through it at llama-box/httpserver.hpp:442 and inside

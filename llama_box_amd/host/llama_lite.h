@@ -82,6 +82,9 @@ int llm_decode(struct llm_context * c, int n_tokens, const int32_t * tokens, con
    are fetched to the host exactly as llm_decode does; after the call they hold the last step's.  llm_last_timings then
    reports the sums over all steps.  Returns 0 or the first failing llm_decode's code. */
 int llm_decode_steps(struct llm_context * c, int n_steps, int n_par, const int32_t * tokens, int pos0);
+// one step = llama_decode over n_par x (1 + n_draft) tokens (a slot's sampled token + its drafts, logits at every position), then the rejected
+// drafts leave the cache (llama_memory_seq_rm): llama-box's speculative-decoding batch shape (httpserver.hpp:4042-4069, :4696-4768)
+int llm_verify_steps(struct llm_context * c, int n_steps, int n_par, int n_draft, const int32_t * tokens, int pos0);
 int llm_n_outputs(const struct llm_context * c);
 float * llm_get_logits(struct llm_context * c);            /* [n_outputs][n_vocab], host memory */
 /* llama_get_logits_ith semantics: i >= 0 = batch position (must have requested logits), i < 0 = output rows from the end; NULL otherwise */

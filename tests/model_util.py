@@ -72,6 +72,13 @@ class Context:
         arr = (C.c_int32 * len(flat))(*flat)
         return self.H.llm_decode_steps(self.c, len(tokens), n_par, arr, int(pos0))
 
+    def verify_steps(self, tokens, n_par, n_draft, pos0):
+        """n_steps speculative-decoding steps inside the host library (tokens: [n_steps][n_par * (1 + n_draft)] ints): every step
+        decodes each sequence's sampled token + n_draft drafts with logits at every position, then drops the drafts' cells; returns rc."""
+        flat = [int(t) for row in tokens for t in row]
+        arr = (C.c_int32 * len(flat))(*flat)
+        return self.H.llm_verify_steps(self.c, len(tokens), n_par, n_draft, arr, int(pos0))
+
     def clear(self):
         self.H.llm_kv_clear(self.c)
 

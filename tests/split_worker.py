@@ -100,8 +100,16 @@ def model_main():
     split_fn = be.proc("ggml_backend_split_buffer_type", C.c_void_p, [C.c_int, C.POINTER(C.c_float)])
     out = {"n_dev": int(H.ggml_backend_reg_dev_count(be.reg)), "graphs_env": os.environ.get("GGML_MI355X_SPLIT_GRAPHS", "0"), "cases": []}
     prompt = [1, 5, 9, 300, 17, 42, 99, 7, 250, 3]
-    for name, ftype, ts in (("test-llama-tp", 1, [1.0, 1.0]), ("test-llama-tp", 5, [1.0, 1.0]), ("test-llama-tp", 1, [3.0, 1.0]), ("test-qwen2", 5, [1.0, 1.0])):
+    cases = (("test-llama-tp", 1, [1.0, 1.0], 0), ("test-llama-tp", 5, [1.0, 1.0], 0), ("test-llama-tp", 1, [3.0, 1.0], 0), ("test-qwen2", 5, [1.0, 1.0], 0))
+    if len(sys.argv) > 2 and sys.argv[2] == "70b":
+        # BASELINE config 4 at its real shard shapes: Llama-3-70B's layer (8192 / 28672, 64 heads on 8 KV heads, Q4_K_M type
+        # map with Q5_K attn_v) cut to two layers, --tensor-split 1,1,1,1,1,1,1,1 over eight logical devices: every device holds 1024 / 128 /
+        # 128 rows of wq / wk / wv, the 1024-value K slice of attn_output, 3584 rows of gate / up and the 3584-value K slice of ffn_down
+        cases = (("llama3-70b-q4_k_m", 1, [1.0] * 8, 2),)
+    for name, ftype, ts, n_layer in cases:
         hp = preset(name)
+        if n_layer:
+            hp.n_layer = n_layer
         hp.ftype = ftype  # 1 = Q4_K_M type map (gate / up share a type: the sharded FFN chain), 5 = mixed (every kernel; gate / up differ: separate paths)
         arr = (C.c_float * 16)(*(ts + [0.0] * (16 - len(ts))))
         buft = split_fn(0, arr)

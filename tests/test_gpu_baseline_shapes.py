@@ -108,6 +108,12 @@ LAYERS = [
     Spec("llama3-70b q4_k_m layer", 8192, 28672, 64, 8, 128, L.Q4_K, L.Q5_K, L.Q4_K, L.Q4_K, L.Q6_K, False, False, 500000.0, 1e-5, 1030, 8192),
     # TinyLlama-1.1B Q8_0 (config 1's model): head_dim 64
     Spec("tinyllama-1.1b q8_0 layer", 2048, 5632, 32, 4, 64, L.Q8_0, L.Q8_0, L.Q8_0, L.Q8_0, L.Q8_0, False, False, 10000.0, 1e-5, 143, 2048),
+    # ONE RANK of Llama-3-70B under --tensor-split 1,1,1,1,1,1,1,1 (BASELINE config 4; engine_param.hpp:821-842, :902-916):
+    # 8 Q heads on 1 KV head, wq 1024 x 8192, wk / wv 128 x 8192, wo's K slice 8192 x 1024, gate / up 3584 x 8192, ffn_down's K slice
+    # 8192 x 3584 (14 super-blocks per row).  A rank's partial products carry the residual here, as the single-rank graph does; the
+    # sum over ranks is tests/test_tp_* 's business.  Plain layers keep attn_v in Q5_K, the "more bits" layers have attn_v / ffn_down in Q6_K.
+    Spec("llama3-70b q4_k_m TP8 rank shard (plain)", 8192, 3584, 8, 1, 128, L.Q4_K, L.Q5_K, L.Q4_K, L.Q4_K, L.Q4_K, False, False, 500000.0, 1e-5, 2063, 8192),
+    Spec("llama3-70b q4_k_m TP8 rank shard (more bits)", 8192, 3584, 8, 1, 128, L.Q4_K, L.Q6_K, L.Q4_K, L.Q4_K, L.Q6_K, False, False, 500000.0, 1e-5, 2063, 8192),
 ]
 
 
@@ -534,10 +540,46 @@ def _prefill_layout(M, n_past):
     return n_kv, slot, pos, vis
 
 
+def _draft_layout(S, R, D, n_draft):
+    """A step that verifies drafts (llama-box speculative decoding: httpserver.hpp:4042-4069 batches every slot's sampled token plus its
+    n_draft draft tokens, :4696-4768 verifies them): S sequences, each with R prompt cells and D - 1 earlier decode cells (interleaved as
+    continuous batching leaves them), and 1 + n_draft NEW consecutive tokens per sequence in this batch; token j of a sequence sees the
+    sequence's older cells and the batch's tokens 0..j of the same sequence.  Returns (n_kv, slot[M], pos[M], visible[M, n_kv])."""
+    T1 = 1 + n_draft
+    M = S * T1
+    base = S * R + (D - 1) * S
+    n_kv = (base + M + 255) // 256 * 256
+    slot = np.array([base + s * T1 + j for s in range(S) for j in range(T1)], np.int64)
+    pos = np.array([R + D - 1 + j for s in range(S) for j in range(T1)], np.int32)
+    vis = np.zeros((M, n_kv), bool)
+    for s in range(S):
+        for j in range(T1):
+            t = s * T1 + j
+            vis[t, s * R:(s + 1) * R] = True
+            vis[t, S * R + s:base:S] = True
+            vis[t, base + s * T1:base + s * T1 + j + 1] = True
+    return n_kv, slot, pos, vis
+
+
+# mode -> (M, layout): "np32" / "pf512" are BASELINE configs 3 / 2; the rest are the speculative-decoding shapes of SURVEY §8 f4
+# (VERDICT r03 #6): a -np 32 step with 1 / 4 drafts per slot (M = 64 / 160 — between the skinny kernels' 32 columns and the 512 the
+# wide form was tuned on) and ONE sequence verifying 8 / 16 drafts (M = 9 / 17)
+BATCH_MODES = {
+    "np32": lambda: (32,) + _np32_layout(32, 64, 8),            # 2304 cells
+    "pf512": lambda: (512,) + _prefill_layout(512, 1792),       # 2304 cells, the last micro-batch of a 2304-token context
+    "np32d1": lambda: (64,) + _draft_layout(32, 64, 7, 1),      # 2304 cells
+    "np32d4": lambda: (160,) + _draft_layout(32, 64, 4, 4),     # 2304 cells
+    "sd8": lambda: (9,) + _draft_layout(1, 2288, 8, 8),         # 2304 cells
+    "sd16": lambda: (17,) + _draft_layout(1, 2280, 8, 16),      # 2304 cells
+}
 BATCH_CASES = [
     # (layer spec index, mode, flash attention)
     (0, "np32", 1), (0, "np32", 0), (1, "np32", 1), (2, "np32", 1), (2, "np32", 0),
     (0, "pf512", 1), (0, "pf512", 0), (1, "pf512", 1), (2, "pf512", 1),
+    # config 4: one TP8 rank of Llama-3-70B at M = 32 and M = 512 (M = 1 is test_layer_teacher_forced)
+    (5, "np32", 1), (6, "np32", 1), (5, "pf512", 1), (6, "pf512", 1), (6, "np32", 0),
+    # speculative-decoding shapes: Llama-3-8B plain / more-bits layers, flash and non-flash, and a TP8 rank
+    (0, "np32d1", 1), (1, "np32d4", 1), (0, "np32d4", 0), (0, "sd8", 1), (1, "sd16", 1), (1, "sd8", 0), (6, "np32d4", 1), (5, "sd16", 1),
 ]
 
 
@@ -547,12 +589,7 @@ def test_layer_teacher_forced_batch(backend, H, plog, li, mode, fa):
     rng = np.random.default_rng(_seed(sp.name, mode, fa))
     E, FF, NH, NKV, HD = sp.E, sp.FF, sp.NH, sp.NKV, sp.HD
     EK = NKV * HD
-    if mode == "np32":
-        M = 32
-        n_kv, slot, pos, vis = _np32_layout(M, 64, 8)  # 2304 cells
-    else:
-        M = 512
-        n_kv, slot, pos, vis = _prefill_layout(M, 1792)  # 2304 cells, the last micro-batch of a 2304-token context
+    M, n_kv, slot, pos, vis = BATCH_MODES[mode]()
     assert n_kv % 256 == 0
     n_ctx = n_kv
     MP = (M + 63) // 64 * 64
@@ -656,13 +693,21 @@ def test_layer_teacher_forced_batch(backend, H, plog, li, mode, fa):
             return
         if M <= 32:
             assert cnt["skinny_launches"] >= 1 and cnt["wide_launches"] == 0 and cnt["tiled_launches"] == 0, (group, cnt)
-        else:
+        elif mode == "pf512" and li < 5:
             kq = [t for t in wtypes if t in (L.Q4_K, L.Q5_K)]
             if kq:
                 assert cnt["wide_launches"] >= 1, (group, cnt)
             if L.Q6_K in wtypes:
                 assert cnt["tiled_launches"] >= 1, (group, cnt)
             assert cnt["skinny_launches"] == 0, (group, cnt)
+        else:
+            # 33 .. 160 columns, or a rank's narrow shards: the wide form where its grid fills the chip (mmq_wide_tiles), the tiled int8 GEMM
+            # otherwise — never the 32-column skinny kernel, never a column-by-column mat-vec fall-back (one launch per matrix group at most,
+            # + split-K reduce / quantiser launches)
+            assert cnt["skinny_launches"] == 0 and cnt["wide_launches"] + cnt["tiled_launches"] >= 1, (group, cnt)
+            if L.Q6_K in wtypes:
+                assert cnt["tiled_launches"] >= 1, (group, cnt)
+            assert cnt["kernel_launches"] <= 12, (group, cnt)
 
     tag = f"{sp.name} [{mode}, {M} tokens, n_kv {n_kv}, fa={fa}]"
     vals = {"x": x0, "kc": kc0, "vc": vc0}

@@ -437,3 +437,25 @@ def _staged_upload_cases(backend, H, plog, rng, b0):
     ref = T.run_case(build, "oracle", T.host_threads())[0]
     for _ in range(3):
         T.compare("mat-vec on a weight uploaded through the staging ring", T.run_case(build, backend)[0], ref, max_nmse=1e-10, log=plog)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_dry_run_on_one_gpu(plog):
+    """`python bench.py --gpus 2` with nothing around it: the script starts its two ranks itself (torch.distributed.run, 127.0.0.1) and
+    rank 0 prints ONE line with "n_gpus": 2.  On the one-GPU box both ranks share device 0 (BENCH_ALLOW_SHARED_GPU=1: a dry run of the
+    multi-rank path — rendezvous, sharded model, in-stream reductions, barrier + max-over-ranks timing — not a measurement)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_ALLOW_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--prefill", "64", "--layers", "2", "--no-cpu-baseline",
+                        "--pmc-traffic", "0", "--timing-steps", "0", "--replica-leg", "0"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    plog(f"[bench --gpus 2, one GPU shared] value={out['value']} tok/s ms_per_step={out['ms_per_step']} parallelism={out['config']['parallelism']} legs={out.get('tensor_split_legs')}")
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["value"] > 0
+    assert "DRY RUN" in out["config"]["parallelism"]

@@ -62,6 +62,24 @@ def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs):
             assert c["graph_replays"] >= 3, "the decode steps of the split model were not replayed as hipGraphs"
 
 
+@pytest.mark.gpu
+def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog):
+    """BASELINE config 4 (Llama-3-70B Q4_K_M, --tensor-split 1,1,1,1,1,1,1,1; llama-box/engine_param.hpp:821-842, :902-916) at its REAL per-device
+    shard shapes, through "ggml_backend_split_buffer_type" on eight logical devices of the one GPU: two layers of the 70B layer shape, prompt
+    batch + decode steps; reductions == 2 x n_layer per graph, logits against the CPU oracle and against the same model on one device."""
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="8", GGML_MI355X_SPLIT_GRAPHS="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py"), "model", "70b"], capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1][len("SPLIT_JSON "):])
+    assert res["n_dev"] == 8
+    (c,) = res["cases"]
+    plog(f"[split-tp 70b shards] {c['model']} n_layer={c['n_layer']} ts={c['ts']}: reductions per graph {c['reductions_per_graph']}, "
+         f"logits nmse vs oracle {c['nmse_vs_oracle']:.2e} (one device {c['nmse_one_device_vs_oracle']:.2e}), vs one device {c['nmse_vs_one_device']:.2e}")
+    assert all(r_ == 2 * c["n_layer"] for r_ in c["reductions_per_graph"]), c
+    assert c["nmse_vs_oracle"] <= 1e-3 and c["nmse_vs_oracle"] <= 10.0 * max(c["nmse_one_device_vs_oracle"], 1e-7)
+    assert c["nmse_vs_one_device"] <= 1e-3
+
+
 def test_split_rows_planning_without_a_device():
     """The row plan is host arithmetic: reachable through the registration's proc address on a box without any GPU."""
     import ctypes as C

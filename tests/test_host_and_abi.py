@@ -337,3 +337,32 @@ def test_logits_ith_and_host_sampler_mirrors():
     finally:
         c.free()
         m.free()
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's multi-GPU entry point
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([_sys.executable, os.path.join(repo, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_refuses_a_rank_count_other_than_gpus():
+    """`--gpus N` under a launcher that started another number of ranks prints NO line and exits non-zero (VERDICT r03 #6)."""
+    r = _run_bench(["--gpus", "4", "--steps", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "{" not in r.stdout
+
+
+def test_bench_gpus_n_starts_n_ranks_itself_and_fails_without_gpus():
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run with two ranks; on a box
+    without two GPUs every rank refuses, the exit code is non-zero and no JSON line appears (it used to run one rank and print n_gpus 1)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs here: the real run is the driver's SCALE leg")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--prefill", "0", "--layers", "1"], timeout=300)
+    assert r.returncode != 0, r.stdout[-500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln], r.stdout[-500:]
+    assert "refusing to run" in r.stderr  # came from the ranks torch.distributed.run started, not from the parent
