@@ -324,6 +324,7 @@ static void be_free(ggml_backend_t be) {
     if (c->fa_lists) HIP_CHECK(hipFree(c->fa_lists));
     if (c->rope_tab) HIP_CHECK(hipFree(c->rope_tab));
     if (c->fa_arrive) HIP_CHECK(hipFree(c->fa_arrive));
+    if (c->ss_buf) HIP_CHECK(hipFree(c->ss_buf));
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c;
     delete be;
@@ -480,6 +481,11 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_SOFTMAX_MM")) c->opt.softmax_mm = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_ATTN_NF")) c->opt.attn_nf = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FA_SELF_MERGE")) c->opt.fa_self_merge = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_SS_PARTIALS")) c->opt.ss_partials = atoi(e) != 0;
+    if (hipMalloc((void **) &c->ss_buf, 256 * sizeof(double)) != hipSuccess) {  // (optional: without it every norm prologue sums its own row)
+        (void) hipGetLastError();
+        c->ss_buf = nullptr;
+    }
     return new ggml_backend{&g_guid, k_backend_iface, dev, c};
 }
 static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &dctx(dev)->buft; }
@@ -547,6 +553,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "softmax_mm") c->opt.softmax_mm = v != 0;
     else if (k == "attn_nf") c->opt.attn_nf = v != 0;
     else if (k == "fa_self_merge") c->opt.fa_self_merge = v != 0;
+    else if (k == "ss_partials") c->opt.ss_partials = v != 0;
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "fa_wo") c->opt.fa_wo = v != 0;
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;
@@ -567,6 +574,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "kernel_launches") return c->st.kernel_launches;
     if (k == "fused_nodes") return c->st.fused_nodes;
     if (k == "allreduces") return c->st.allreduces;
+    if (k == "ss_handoffs") return c->st.ss_handoffs;
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
     if (k == "skinny_launches") return c->st.skinny_launches;
     if (k == "wide_launches") return c->st.wide_launches;

@@ -86,6 +86,7 @@ struct options {
     int mmq_min_cols = 3;      // batches at least this wide run on the matrix cores (measured, ms/step matrix cores vs multi-column mat-vec: 3 columns 4.1 / 4.4, 4: 3.9 / 4.2, 8: 4.4 / 5.7; 2 columns: 3.6 / 3.1)
     bool mmq_i8 = true;        // Q4_K/Q5_K batches on the int8 matrix cores (mmq_i8.hip) instead of the f16 variant (mmq.hip)
     bool mm_merge = true;      // batches: sibling mat-muls over the same activations (wq/wk/wv, gate/up) as one launch
+    bool ss_partials = true;    // residual-stream mat-vecs leave the sum of squares of their result for the next RMS_NORM prologue (GGML_MI355X_SS_PARTIALS=0: off)
     bool fa_self_merge = false; // split attention (decode): the last split workgroup merges the partial records, no combine launch.  Off: measured
                                // one token, n_kv 2100: 16.5 us against 7.6 + 5.0 for split + combine (record write-through, counter and re-read are a longer
                                // dependent chain than a launch); -np 32: 18.3 against 19.6 us per layer (4.45 vs 4.49 ms per step)
@@ -105,6 +106,7 @@ struct options {
 
 struct stats {
     int64_t graph_launches = 0, graph_captures = 0, eager_graphs = 0, kernel_launches = 0, fused_nodes = 0, allreduces = 0;
+    int64_t ss_handoffs = 0;           // RMS_NORM prologues that took the sum of squares from the producing mat-vec's partial sums
     int64_t skinny_launches = 0;       // mat-muls of 2..32 columns served by the weight-streaming matrix-core kernel
     int64_t wide_launches = 0;         // prompt-batch mat-muls served by its wide form
     int64_t tiled_launches = 0;        // batch mat-muls served by the LDS-tiled int8 GEMM (mmq_i8.hip)
@@ -158,6 +160,7 @@ struct backend_ctx {
     upload_batch up_pending{};  // staged in the ring, not yet launched: flushed as ONE kernel before anything else enters the stream
     // attention over a unified cache with a few query tokens: per-token lists of visible tiles (fattn.hip, k_fattn_tile_scan),
     // built once per graph execution and shared by the attention nodes of all layers
+    double * ss_buf = nullptr;       // 256 partial sums of squares: from the mat-vec that writes a residual stream to the norm prologue that reads it (mmvq_args::ss_out)
     unsigned * fa_arrive = nullptr;  // arrival counters of the self-merging attention splits (zero between launches)
     static constexpr int fa_arrive_slots = 16384;
     float * rope_tab = nullptr;   // (cos, sin) per (token, rotation pair) of a small batch: written once per graph run, read by every layer's QKV epilogue

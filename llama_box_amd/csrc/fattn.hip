@@ -27,6 +27,8 @@ struct fa_geom {
     unsigned * arrive;  // != null (lane-parallel decode kernel, n_splits > 1): one counter per (batch, token, kv head); the LAST split workgroup to
                         // arrive merges the partial records itself — no combine launch (the counter is left at zero again)
     void * q8;          // with `arrive`: leave the merged result as Q8_K blocks here instead of f32 in dst (see fattn_params::q8_out)
+    int merge2;         // with `arrive` (round 4): records [kv head][split][head of the group][132] written with 8-byte agent-scope stores, merged by
+                        // the last workgroup to arrive in ONE round trip of 8-byte agent-scope loads (MODE 0, f32 output, <= 32 splits, any wave count)
 };
 
 // element-wise all-reduce over the four 16-lane DPP rows of a wave (lane l ends with x[l&15] + x[16+(l&15)] + ...):
@@ -254,6 +256,56 @@ __device__ __forceinline__ float xrow_allmax(const float x) {
 // instead of release / acquire fences — a fence per split workgroup writes the whole L2 back and made the launch 3-5x slower
 __device__ __forceinline__ void st_agent(float * p, const float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// two floats as ONE naturally aligned 8-byte agent-scope access (global_store_dwordx2 / global_load_dwordx2 ... sc1): a 4-byte sc1 store is
+// one fabric write each and costs ~6x the time per byte of a wide one (MI355X_MICROARCH.md, stores of each flavour)
+__device__ __forceinline__ void st_agent2(float * p, const float a, const float b) {
+    const unsigned long long v = (unsigned long long) __builtin_bit_cast(unsigned, a) | ((unsigned long long) __builtin_bit_cast(unsigned, b) << 32);
+    __hip_atomic_store((unsigned long long *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_agent2(const float * p) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, (unsigned) v), __builtin_bit_cast(float, (unsigned) (v >> 32)));
+}
+#define FA_M2_REC 132  // floats per (split, head) record of the merge2 layout: 128 values, max (natural-log domain), sum, 2 pad
+
+// merge2 (round 4): the LAST workgroup of a (token, kv head) to arrive merges the n_splits x g_real records.  Two waves per head and trip
+// (a thread per output dim, as k_fattn_combine); lane s of every wave owns split s for the (max, sum) pairs and ALL loads of a trip — the
+// pair and up to 32 values per thread — go out together: one memory round trip per trip of WV / 2 heads, where round 2's merge walked the
+// records in four dependent trips (16.5 us against 12.6 us for split + combine launches).  Kept SMALL on purpose: this code runs once per
+// (token, kv head) on a cold instruction cache — the first version of this merge, 32 records x 3 share counts fully unrolled (~24 KB of
+// straight-line code), cost 6 us more than the combine launch it replaced.  n_splits <= 32.
+__device__ __forceinline__ void fa_merge2(const float * __restrict__ hb, const int h0, const int g_real, const int n_splits, const float * __restrict__ sinks, const tdesc & dst,
+                                          const int tok, const int bat, const int n_threads) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t ss = (int64_t) g_real * FA_M2_REC;  // floats between the records of consecutive splits
+#pragma unroll 1
+    for (int g = tid >> 7; g < g_real; g += n_threads >> 7) {
+        const int dd = tid & 127;
+        const float * __restrict__ base = hb + (int64_t) g * FA_M2_REC;
+        const float2 ml = ld_agent2(base + (int64_t) min(lane, n_splits - 1) * ss + 128);
+        float r[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) r[u] = ld_agent(base + (int64_t) min(u, n_splits - 1) * ss + dd);
+        const float ms = lane < n_splits ? ml.x : -INFINITY, ls = lane < n_splits ? ml.y : 0.0f;
+        float mn = wave_max(ms);
+        float sink_term = 0.0f;
+        if (sinks) {
+            mn = fmaxf(mn, sinks[h0 + g]);
+            sink_term = expf(sinks[h0 + g] - mn);
+        }
+        const float cs = ms == -INFINITY ? 0.0f : expf(ms - mn);
+        const float lt = wave_sum(ls * cs) + sink_term;
+        // (a split that left an empty record — coefficient 0 — may hold anything in its values: select, not multiply)
+        float a = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const float c = readlane_f32(cs, u);
+            a += c != 0.0f ? r[u] * c : 0.0f;
+        }
+        float * out = (float *) (dst.data + (int64_t) (h0 + g) * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+        out[dd] = a * (1.0f / lt);
+    }
+}
 
 // Merge of the partial records of `g_real` consecutive heads (head_dim 128) by ONE 4-wave workgroup — what k_fattn_combine does
 // per head in its own launch: wave w takes heads w, w + 4, ..; lane s owns split s for the (max, sum) pairs, every lane two of
@@ -680,7 +732,14 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             }
         } else {
             float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + h) * geo.n_splits + split) * geo.rec_stride;
-            if (WV == 4 && geo.arrive) {
+            if (geo.merge2) {
+                // merge2 layout; the two dims of a column travel as one 8-byte agent-scope store: even dims pick up their odd neighbour's
+                // value from the next lane (e = tid + k * WV * 64 and D are even-aligned: dd and dd + 1 sit in neighbouring lanes)
+                float * r2 = ws + (((((int64_t) bat * geo.n_q + tok) * geo.n_kv_head + kvh) * geo.n_splits + split) * g_real + g) * FA_M2_REC;
+                const float nb = dpp_f32<0xF5>(a);  // quad_perm [1, 1, 3, 3]: lane 2i reads lane 2i + 1
+                if ((dd & 1) == 0) st_agent2(r2 + dd, a, nb);
+                if (dd == 0) st_agent2(r2 + D, mt_e, lt);
+            } else if (WV == 4 && geo.arrive) {
                 st_agent(rec + dd, a);
                 if (dd == 0) { st_agent(rec + D, mt_e); st_agent(rec + D + 1, lt); }
             } else {
@@ -693,6 +752,26 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         }
     }
     }  // !empty
+    if (geo.merge2) {
+        // ---- merge2: our record went out with 8-byte agent-scope (write-through) stores; once they have completed (vmcnt 0 in every storing
+        // wave, then the barrier) the arrival is counted, and the workgroup that finds n_splits - 1 arrivals before it merges all records
+        // with agent-scope loads — sc1 stores AND sc1 loads need no fence (MI355X_MICROARCH.md "inter-workgroup visibility") and the result
+        // does not depend on where the workgroups ran
+        __shared__ int s_last2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned * cnt_p = geo.arrive + ((int64_t) bat * geo.n_q + tok) * geo.n_kv_head + kvh;
+            const unsigned old = __hip_atomic_fetch_add(cnt_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last2 = old == (unsigned) geo.n_splits - 1u;
+            if (s_last2) __hip_atomic_store(cnt_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+        __syncthreads();
+        if (!s_last2) return;
+        fa_merge2(ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_kv_head + kvh) * geo.n_splits) * (int64_t) (g_real * FA_M2_REC), kvh * g_real, g_real, geo.n_splits, sinks, dst, tok, bat,
+                  WV * 64);
+        return;
+    }
     if constexpr (!FAT) {
         if (geo.n_splits == 1 && geo.q8) {
             // one pass and the readers are quantised mat-muls: quantize_row_q8_K of head pairs, as k_quantize_q8_K does it
@@ -981,7 +1060,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         MI_ERR("launch_flash_attn: the matrix-core kernel refused a batch flash_attn_mma_applies accepted");
         abort();
     }
-    fa_geom geo;
+    fa_geom geo{};
     geo.rec_stride = (int) k.ne[0] + 2;
     geo.n_q = (int) q.ne[1];
     geo.n_head = (int) q.ne[2];
@@ -1023,8 +1102,13 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         // (measured, 2048-token context, 24 splits: 13.45 -> 12.6 us per layer for both launches, 480.7 -> 488.5 tok/s; profiles/r03_decode_ab_fa_wv8.txt)
         static const int wv8 = getenv("GGML_MI355X_FA_WV8") ? atoi(getenv("GGML_MI355X_FA_WV8")) : 1;
         static const int list_wv8 = getenv("GGML_MI355X_FA_LIST_WV8") ? atoi(getenv("GGML_MI355X_FA_LIST_WV8")) : 0;
+        // n_splits > 1: the last split workgroup of a (token, kv head) merges the records itself when the caller gave arrival counters
+        // (one launch instead of two); Q8_K output needs whole head pairs inside a kv group.  merge2 (round 4): the one-round-trip merge,
+        // for the plain form (no lists, no trip skipping) with f32 output and at most 32 splits, on four or eight waves
+        const bool self_merge = geo.n_splits > 1 && p.arrive != nullptr && (int64_t) geo.n_q * q.ne[3] * geo.n_kv_head <= (int64_t) p.arrive_slots && !(p.q8_out && (G & 1));
+        const bool merge2 = self_merge && !list && !skip && !q8 && p.q8_out == nullptr && geo.n_splits <= 32;
         const bool list8 = list_wv8 && list && !q8 && !p.arrive;
-        const bool wide8 = wv8 && !q8 && !list && !skip && geo.n_q == 1 && geo.n_splits > 1 && !p.arrive;
+        const bool wide8 = wv8 && !q8 && !list && !skip && geo.n_q == 1 && geo.n_splits > 1 && (!p.arrive || merge2);
 #define FA_DEC(GG)                                                                                                                          \
     {                                                                                                                                       \
         if (wide8) hipLaunchKernelGGL((k_fattn_dec128<GG, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);           \
@@ -1039,10 +1123,8 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
             else hipLaunchKernelGGL((k_fattn_dec128<GG, 0, false>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);                \
         }                                                                                                                                   \
     }
-        // n_splits > 1: the last split workgroup of a (token, kv head) merges the records itself when the caller gave arrival counters
-        // (one launch instead of two); Q8_K output needs whole head pairs inside a kv group
-        const bool self_merge = geo.n_splits > 1 && p.arrive != nullptr && (int64_t) geo.n_q * q.ne[3] * geo.n_kv_head <= (int64_t) p.arrive_slots && !(p.q8_out && (G & 1));
         geo.arrive = self_merge ? p.arrive : nullptr;
+        geo.merge2 = merge2 ? 1 : 0;
         geo.q8 = (self_merge || (geo.n_splits == 1 && !(G & 1))) ? p.q8_out : nullptr;
         if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
 #undef FA_DEC

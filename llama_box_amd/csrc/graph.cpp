@@ -246,6 +246,10 @@ struct exec_state {
     rope_params rope_tab_p{};
     int rope_tab_m = 0;
     int sk_next = -1;  // node index at which run_mul_mat_q may look ahead (set by the caller: first node after the consumed ones)
+    // the tensor whose sum of squares sits in c->ss_buf as ss_n partial sums (written by the mat-vec launch that produced the tensor: mmvq_args::ss_out),
+    // for the RMS_NORM prologue that reads it next; reset when any other node writes into its memory
+    const ggml_tensor * ss_tensor = nullptr;
+    int ss_n = 0;
     // merged Q/K/V projections whose split-K partial products are summed by the rope + cache-store kernel at node `node`
     struct { int node = -1, n = 0, ks = 0, M = 0; mmq_mat_desc mats[3]; const ggml_tensor * dst[3]; const float * part = nullptr; } rs_sk;
 };
@@ -378,6 +382,18 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         // (the allocator may have given THIS result the block of the norm's MUL node, free after its last reader — then that node is
         // provably dead and is not written: the two stores would race inside one launch)
         a.norm_out = (pro_norm && !ranges_overlap(dst, dn->second.out)) ? (float *) dn->second.out->data : nullptr;
+        if (pro_norm && st.ss_tensor != nullptr && st.ss_tensor == dn->second.x) {  // x came out of a launch that left its sum of squares behind
+            a.ss_in = c->ss_buf;
+            a.ss_n = st.ss_n;
+            c->st.ss_handoffs++;
+        }
+        if (st.ss_tensor != nullptr && ranges_overlap(dst, st.ss_tensor)) st.ss_tensor = nullptr;  // (this result recycles that tensor's block)
+        if (c->opt.ss_partials && c->ss_buf != nullptr && (add || add2) && !w2 && launch_mmvq_ss_count(a) > 0) {
+            // a residual stream leaves this launch (wo + residual, ffn_down + residual): the RMS_NORM that reads it next takes the sum of squares from here
+            a.ss_out = c->ss_buf;
+            st.ss_tensor = dst;
+            st.ss_n = launch_mmvq_ss_count(a);
+        }
         char cls[64];
         snprintf(cls, sizeof(cls), "mmvq_%s%s_%s", type_tag(w->type), w2 ? "_glu" : "", pro_norm ? "normpro" : (pro_fa ? "attnpro" : "f32pro"));
         timed_scope ts(c, cls, wbytes, true);
@@ -699,6 +715,11 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     base.norm_w = norm ? (const float *) dn->second.w->data : nullptr;
     base.eps = norm ? dn->second.eps : 0.0f;
     base.norm_out = norm ? (float *) dn->second.out->data : nullptr;
+    if (norm && st.ss_tensor != nullptr && st.ss_tensor == dn->second.x) {
+        base.ss_in = c->ss_buf;
+        base.ss_n = st.ss_n;
+        c->st.ss_handoffs++;
+    }
     if (norm)  // a chain tensor that recycled the MUL node's block proves that node dead after this launch: do not write it (race)
         for (auto & ch : chains)
             for (int k : ch.nodes)
@@ -1267,6 +1288,8 @@ static int run_node(exec_state & st, int i) {
             MI_ERR("graph_compute: node %d '%s' (op %d) reads '%s' from a row-split buffer: only MUL_MAT weights may live there", i, n->name, (int) n->op, n->src[sidx]->name);
             return -1;
         }
+    // (a node that writes into the memory of the tensor whose sum of squares is on record — an in-place op — makes that record stale)
+    if (st.ss_tensor && n != st.ss_tensor && !is_view_op(n) && ranges_overlap(n, st.ss_tensor)) st.ss_tensor = nullptr;
     if (st.sk_dst && !is_view_op(n) && !(n->op == GGML_OP_RMS_NORM && a == st.sk_dst)) flush_deferred_splitk(st);
     if (st.rs_sk.node >= 0 && st.rs_sk.node != i && !is_view_op(n)) flush_deferred_qkv(st);
     switch (n->op) {

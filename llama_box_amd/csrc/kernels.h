@@ -56,7 +56,16 @@ struct mmvq_args {
     float * norm_out;  // norm_w != null: where RMS_NORM(x) * norm_w itself belongs (the graph's MUL node); written by workgroup 0 so that
                        // the fusion never leaves a tensor of the graph unwritten (readers in another split, or the host, may exist)
     int balance_tail;  // set by the launcher: spread the last, partial pass of rows evenly over the workgroups
+    // sum of squares of the result row, handed from the mat-vec that WRITES a residual stream to the RMS_NORM prologue that READS it (round 4):
+    //   ss_out != null (single column, f32 result, no SwiGLU): workgroup b writes the sum of (double) (v * v) over the rows it produced to ss_out[b];
+    //     launch_mmvq_ss_count() tells how many workgroups that is
+    //   ss_in != null (norm prologue): sum of squares of x = the ss_n partial sums in ss_in, added in a fixed order — the prologue then needs
+    //     neither its pass over x nor the workgroup barrier of its own reduction (knock-out: gate/up 16.0 -> 14.8 us)
+    double * ss_out;
+    const double * ss_in;
+    int ss_n;
 };
+int launch_mmvq_ss_count(const mmvq_args & a);  // workgroups (= partial sums) a launch with ss_out will write; 0 if this launch cannot publish them
 #define FA_REC 132  // floats per attention partial record in the fat-split form (128 values + max + sum, padded to 16 bytes)
 void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave);
 // bench timing pass: when armed, the next streaming mat-vec launch records the kernel's own begin / end timestamps into
@@ -107,6 +116,8 @@ struct qkv_args {
     const int64_t * slot;
     const float * rope_tab;  // optional: [head_dim / 2][cos, sin] for this token (launch_rope_table) instead of computing them in every workgroup's prologue
     int wg_a;  // set by launch_qkv: workgroups [0, wg_a) serve the alt == 0 segments, the rest the alt == 1 segments
+    const double * ss_in;  // as mmvq_args::ss_in / ss_n (norm prologue)
+    int ss_n;
 };
 bool qkv_types_supported(int type_a, int type_b);
 void launch_qkv(hipStream_t s, const qkv_args & a, int type_a, int type_b);

@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
         qkv_load<T>(sg.W + (size_t) r0 * sg.w_nb1, sg.W + (size_t) r1 * sg.w_nb1, 0, lane, nblk * T::PPB, ra);
     }
 
+    const int64_t slot = a.slot ? a.slot[0] : 0;  // (requested here: after the prologue it was one more dependent round trip in front of the cache-row stores)
     // ---- prologue A: rotary table for this token (threads 0 .. head_dim/2-1)
     if (tid < half && a.pos != nullptr) {
         float cs, sn;
@@ -145,15 +146,23 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
             }
             float scale = 1.0f;
             if (norm) {  // caller guarantees nblk <= QB*WAVES (K <= 8192): the whole row is in this one batch
-                double ss = 0.0;
-#pragma unroll
-                for (int q = 0; q < QB; ++q) ss += (double) (v[q].x * v[q].x) + (double) (v[q].y * v[q].y) + (double) (v[q].z * v[q].z) + (double) (v[q].w * v[q].w);
-                ss = wave_sum_d(ss);
-                if (lane == 0) red[wave] = ss;
-                __syncthreads();
                 double tot = 0.0;
+                if (a.ss_in) {
+                    // the mat-vec that wrote x left its sum of squares as partial sums (mmvq.hip, ss_out): no pass over x, no barrier
+                    double p4[4];
 #pragma unroll
-                for (int i = 0; i < MAXW; ++i) tot += i < WAVES ? red[i] : 0.0;
+                    for (int q = 0; q < 4; ++q) p4[q] = lane + 64 * q < a.ss_n ? a.ss_in[lane + 64 * q] : 0.0;
+                    tot = wave_sum_d(((p4[0] + p4[1]) + p4[2]) + p4[3]);
+                } else {
+                    double ss = 0.0;
+#pragma unroll
+                    for (int q = 0; q < QB; ++q) ss += (double) (v[q].x * v[q].x) + (double) (v[q].y * v[q].y) + (double) (v[q].z * v[q].z) + (double) (v[q].w * v[q].w);
+                    ss = wave_sum_d(ss);
+                    if (lane == 0) red[wave] = ss;
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < MAXW; ++i) tot += i < WAVES ? red[i] : 0.0;
+                }
                 const float mean = (float) (tot / (double) a.K);
                 scale = 1.0f / sqrtf(mean + a.eps);
             }
@@ -178,7 +187,6 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
     }
     __syncthreads();
 
-    const int64_t slot = a.slot ? a.slot[0] : 0;
     while (have) {
         float acc0 = 0.0f, acc1 = 0.0f;
         {

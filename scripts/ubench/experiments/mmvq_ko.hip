@@ -1,3 +1,6 @@
+// LAB: knock-out copy of llama_box_amd/csrc/mmvq.hip (timing only, WRONG results for KO != 0): KO 1 = no activation prologue at all,
+// KO 2 = norm prologue without the sum-of-squares exchange (one barrier less), KO 3 = no quantisation arithmetic,
+// KO 4 = the weights consumed by an XOR instead of the dot products, KO 5 = KO 4 + Q4_K rows fetched as three contiguous aligned wave-loads.  Built by run_lab2.sh.
 // mmvq.hip — decode mat-vec for GGUF-quantised weights: y[N] (x up to 8 columns) = W[N x K] · x[K].
 //
 // This is THE bandwidth-bound kernel of the hot path (~95 % of decode time is weight streaming, SURVEY.md §8a
@@ -21,11 +24,16 @@
 
 #include <algorithm>
 
-#include "mmvq_types.h"
+#include "../../../llama_box_amd/csrc/mmvq_types.h"
+#ifndef KO
+#define KO 0
+#endif
+#ifndef LAB_WAVES
+#define LAB_WAVES 16
+#endif
 
 namespace mi355x {
 
-thread_local launch_probe g_launch_probe;
 
 
 // ------------------------------------------------------------------------------------------------ kernel
@@ -37,7 +45,7 @@ thread_local launch_probe g_launch_probe;
 //      [RMS_NORM -> MUL -> quantise -> MUL_MAT] is ONE launch; arithmetic per element is identical to the unfused
 //      kernels (sum of squares in double, (x*scale)*w with two roundings, CPU-identical Q8_K rounding)
 template <typename T, int NC, int R, bool GLU, int PRO, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
+__global__ void __launch_bounds__(WAVES * 64) k_mmvq_ko(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::act act;
     constexpr int NT = WAVES * 64;
@@ -201,12 +209,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
 //   * the prologue (PRO as above) runs once per workgroup with 1024 threads: one L2 round trip for x (and w), the
 //     RMS-norm reduction, CPU-identical Q8_K quantisation straight into LDS.
 template <typename T, bool GLU, int PRO>
-__global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
+__global__ void __launch_bounds__(1024) k_mmvq_stream_ko(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::act act;
     // pairs per item: ~16 dwords of weights per lane per matrix (8 for the two-matrix GLU form).  Measured on MI355X:
     // doubling this (128 KiB per CU in flight) made every variant 5-25 % SLOWER — the launch is not in-flight-bound
-    constexpr int WAVES = 16, NT = 1024, UB = (GLU ? 8 : 16) / T::DW, U = UB < 1 ? 1 : (UB > 4 ? 4 : UB);
+    constexpr int WAVES = LAB_WAVES, NT = 64 * LAB_WAVES, UB = (GLU ? 8 : 16) / T::DW, U = UB < 1 ? 1 : (UB > 4 ? 4 : UB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = a.K / T::BLK;
     const int npairs = nblk * T::PPB;
@@ -224,6 +232,31 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         const int rr = full + (int) blockIdx.x * rem_per + wave;
         return (wave < rem_per && rr < a.N) ? rr : a.N;
     };
+#if KO == 9
+    {   // the ideal stream of scripts/ubench/ubench.hip over this launch's bytes (one matrix after the other), x read at the end
+        const size_t Tn = (size_t) gridDim.x * 1024;
+        uint4 accv = make_uint4(0, 0, 0, 0);
+        for (int m = 0; m < (GLU ? 2 : 1); ++m) {
+            const uint4 * Wv = (const uint4 *) (m ? a.W2 : a.W);
+            const size_t n16 = (size_t) a.N * a.w_nb1 / 16;
+            size_t i = (size_t) blockIdx.x * 1024 + threadIdx.x;
+            uint4 vv = i < n16 ? Wv[i] : make_uint4(0, 0, 0, 0);
+            for (;;) {
+                const size_t ni = i + Tn;
+                const bool more = ni < n16;
+                uint4 nv = make_uint4(0, 0, 0, 0);
+                if (more) nv = Wv[ni];
+                accv.x ^= vv.x; accv.y += vv.y; accv.z ^= vv.z; accv.w += vv.w;
+                if (!more) break;
+                vv = nv; i = ni;
+            }
+        }
+        const float xv = a.x ? a.x[threadIdx.x] : 0.0f;
+        if (blockIdx.x == 0) a.dst[threadIdx.x] = xv + (float) ((accv.x ^ accv.y ^ accv.z ^ accv.w) & 1);
+        else if ((accv.x ^ accv.y ^ accv.z ^ accv.w) == 0x12345678u) a.dst[threadIdx.x] = xv;
+        return;
+    }
+#endif
     int row = blockIdx.x * WAVES + wave, ch = 0;
     if (full == 0) row = (wave < rem_per && (int) blockIdx.x * rem_per + wave < a.N) ? (int) blockIdx.x * rem_per + wave : a.N;
     bool have = row < a.N;
@@ -255,7 +288,6 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     constexpr int BPC = PRO == 0 ? 1 : 256 / T::BLK;  // activation blocks per 256-value chunk
     const int nchk = a.K / 256;
     float4 v[4], g[4];
-    double ssp[4] = {0.0, 0.0, 0.0, 0.0};
     item cur;
     // PRO 3 (wo of a decode step): the activation row is the attention result, still in the form of its split partials
     // (fattn.hip, 8-wave form: [head][split] records of 128 values + (max, sum), FA_REC floats apart) — this prologue is the
@@ -291,10 +323,6 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     } else {
         if (have) load_item(row, 0, cur);
         if constexpr (PRO == 2) {
-            if (a.ss_in) {  // (uniform) the producer of x left its sum of squares as partial sums: one more load in this round trip
-#pragma unroll
-                for (int u = 0; u < 4; ++u) ssp[u] = lane + 64 * u < a.ss_n ? a.ss_in[lane + 64 * u] : 0.0;
-            }
             const float4 * x4 = (const float4 *) a.x;
             const float4 * w4 = (const float4 *) a.norm_w;
 #pragma unroll
@@ -311,6 +339,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         }
     }
 
+#if KO != 1 && KO != 6
     // ---- activation prologue
     if constexpr (PRO == 0) {
         const int nwords = (int) ((size_t) nblk * sizeof(act) / 4);
@@ -379,12 +408,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
             }
             float scale = 1.0f;
             if constexpr (PRO == 2) {
-              double tot = 0.0;
-              if (a.ss_in) {
-                // partial sums in a fixed order (lane-strided, then the wave tree): every wave of every workgroup gets the same bits,
-                // and nobody waits for anybody
-                tot = wave_sum_d(((ssp[0] + ssp[1]) + ssp[2]) + ssp[3]);
-              } else {
+#if KO != 2
                 double * red = (double *) (smem + (size_t) nblk * sizeof(act));
                 double ss = 0.0;
 #pragma unroll
@@ -392,11 +416,14 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
                 ss = wave_sum_d(ss);
                 if (lane == 0) red[wave] = ss;
                 __syncthreads();  // reached exactly once by every wave: the loop condition admits b0 == wave
+                double tot = 0.0;
 #pragma unroll
                 for (int i = 0; i < WAVES; ++i) tot += red[i];
-              }
                 const float mean = (float) (tot / (double) a.K);
                 scale = 1.0f / sqrtf(mean + a.eps);
+#else
+                scale = a.eps * 1000.0f;
+#endif
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -410,18 +437,22 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
                         t[3] = (t[3] * scale) * g[u].w;
                         if (a.norm_out && blockIdx.x == 0) ((float4 *) a.norm_out)[b * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
                     }
+#if KO != 3
                     if constexpr (BPC == 1) wave_quantize_q8_K(t, lane, yl + b);
                     else wave_quantize_q8_0(t, lane, yl + (size_t) b * BPC);
+#else
+                    if (t[0] == 123.456f) ((float *) yl)[b] = t[1] + t[2] + t[3];
+#endif
                 }
             }
             if constexpr (PRO == 2) break;  // single batch by construction
         }
     }
+#endif
     __syncthreads();
     const act * y = (const act *) smem;
 
     float acc = 0.0f, acc2 = 0.0f;
-    double ssw = 0.0;  // lane 0: sum of squares of the rows this wave produced
     while (have) {
         int nrow = row, nch = ch + 1;
         if (nch == nchunks) { nch = 0; nrow = next_row(row); }
@@ -432,8 +463,17 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         for (int u = 0; u < U; ++u) {
             const int p = (ch * U + u) * 64 + lane;
             if (p < npairs) {
+#if KO == 4 || KO == 5 || KO == 6
+                { const uint32_t * wq = (const uint32_t *) &cur.w[u]; uint32_t xx = 0;
+                  for (int q = 0; q < (int) (sizeof(cur.w[u]) / 4); ++q) xx ^= wq[q];
+                  acc += __builtin_bit_cast(float, xx & 0x3F800000u); }
+                if (GLU) { const uint32_t * wq = (const uint32_t *) &cur.w2[u]; uint32_t xx = 0;
+                  for (int q = 0; q < (int) (sizeof(cur.w2[u]) / 4); ++q) xx ^= wq[q];
+                  acc2 += __builtin_bit_cast(float, xx & 0x3F800000u); }
+#else
                 T::template dot<1>(cur.w[u], p, y, nblk, &acc);
                 if (GLU) T::template dot<1>(cur.w2[u], p, y, nblk, &acc2);
+#endif
             }
         }
         if (ch == nchunks - 1) {
@@ -446,7 +486,6 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
                 if (a.add) v += a.add[row];
                 if (a.add2) v += a.add2[row];
                 a.dst[row] = v;
-                ssw += (double) (v * v);  // (as ggml-cpu's rms_norm: the f32 product, summed in double)
             }
             acc = 0.0f;
             acc2 = 0.0f;
@@ -455,18 +494,6 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         row = nrow;
         ch = nch;
         have = nhave;
-    }
-    if (a.ss_out) {  // (uniform) this launch writes a residual stream an RMS_NORM prologue reads next: leave its sum of squares, one partial per workgroup
-        double * red = (double *) (smem + (size_t) nblk * sizeof(act));
-        if constexpr (PRO == 2) __syncthreads();  // (the norm prologue's own exchange used this area)
-        if (lane == 0) red[wave] = ssw;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int i = 0; i < WAVES; ++i) t += red[i];
-            a.ss_out[blockIdx.x] = t;
-        }
     }
 }
 
@@ -478,19 +505,31 @@ template <typename T, bool GLU, int PRO> static void launch_stream(hipStream_t s
     mmvq_args a2 = a;
     a2.balance_tail = bal;
     if (g_launch_probe.armed && !g_launch_probe.used) {
-        hipExtLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, g_launch_probe.e0, g_launch_probe.e1, 0, a2);
+        hipExtLaunchKernelGGL((k_mmvq_stream_ko<T, GLU, PRO>), dim3(grid), dim3(64 * LAB_WAVES), lds, s, g_launch_probe.e0, g_launch_probe.e1, 0, a2);
         g_launch_probe.used = true;
     } else {
-        hipLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, a2);
+        hipLaunchKernelGGL((k_mmvq_stream_ko<T, GLU, PRO>), dim3(grid), dim3(64 * LAB_WAVES), lds, s, a2);
     }
 }
 
 template <typename T, int NC, int R, bool GLU, int PRO, int WAVES> static void launch_one(hipStream_t s, const mmvq_args & a, size_t lds) {
     const int rows_per_block = WAVES * R;
     const unsigned grid = (unsigned) ((a.N + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((k_mmvq<T, NC, R, GLU, PRO, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
+    hipLaunchKernelGGL((k_mmvq_ko<T, NC, R, GLU, PRO, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
 }
 
+#if KO == 5 || KO == 6
+struct T_Q4K_lin : T_Q4K {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
+        const uint4 * q = (const uint4 *) row + (size_t) (p >> 6) * 144;
+        raw r;
+        r.hdr = q[p & 63];
+        r.q0 = q[64 + (p & 63)];
+        r.q1 = q[128 + (p & 15)];
+        return r;
+    }
+};
+#endif
 template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a0, int rows_per_wave) {
     mmvq_args a = a0;
     const int nblk = a.K / T::BLK;
@@ -543,20 +582,20 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
     }
 }
 
-int launch_mmvq_ss_count(const mmvq_args & a) {
-    // the streaming kernel with an f32 / norm prologue (launch_type): one column, K-quant or Q8_0 rows of whole 256-value chunks, no SwiGLU
-    if (a.ncols != 1 || a.W2 != nullptr || a.fa_part != nullptr || a.x == nullptr || (a.K % 256) != 0) return 0;
-    return (int) std::min<int64_t>(256, ((int64_t) a.N + 15) / 16);
-}
-
-void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave) {
+static void launch_mmvq_ko(hipStream_t s, const mmvq_args & a, int rows_per_wave) {
     switch (a.type) {
+#if KO == 5 || KO == 6
+        case GGML_TYPE_Q4_K: launch_type<T_Q4K_lin>(s, a, rows_per_wave); break;
+#else
         case GGML_TYPE_Q4_K: launch_type<T_Q4K>(s, a, rows_per_wave); break;
+#endif
         case GGML_TYPE_Q5_K: launch_type<T_Q5K>(s, a, rows_per_wave); break;
         case GGML_TYPE_Q6_K: launch_type<T_Q6K>(s, a, rows_per_wave); break;
         case GGML_TYPE_Q8_0: launch_type<T_Q80>(s, a, rows_per_wave); break;
         default: MI_ERR("launch_mmvq: unsupported weight type %d", a.type); abort();
     }
 }
+
+bool launch_mmvq_v2(hipStream_t s, const mmvq_args & a) { launch_mmvq_ko(s, a, 1); return true; }
 
 }  // namespace mi355x

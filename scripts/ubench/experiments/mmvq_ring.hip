@@ -1,3 +1,4 @@
+// LAB copy of llama_box_amd/csrc/mmvq.hip with the static register ring in k_mmvq_stream (round 4); built by run_lab2.sh (RINGS=...).
 // mmvq.hip — decode mat-vec for GGUF-quantised weights: y[N] (x up to 8 columns) = W[N x K] · x[K].
 //
 // This is THE bandwidth-bound kernel of the hot path (~95 % of decode time is weight streaming, SURVEY.md §8a
@@ -21,11 +22,10 @@
 
 #include <algorithm>
 
-#include "mmvq_types.h"
+#include "../../../llama_box_amd/csrc/mmvq_types.h"
 
 namespace mi355x {
 
-thread_local launch_probe g_launch_probe;
 
 
 // ------------------------------------------------------------------------------------------------ kernel
@@ -37,7 +37,7 @@ thread_local launch_probe g_launch_probe;
 //      [RMS_NORM -> MUL -> quantise -> MUL_MAT] is ONE launch; arithmetic per element is identical to the unfused
 //      kernels (sum of squares in double, (x*scale)*w with two roundings, CPU-identical Q8_K rounding)
 template <typename T, int NC, int R, bool GLU, int PRO, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
+__global__ void __launch_bounds__(WAVES * 64) k_mmvq_ring(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::act act;
     constexpr int NT = WAVES * 64;
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
 //   * the prologue (PRO as above) runs once per workgroup with 1024 threads: one L2 round trip for x (and w), the
 //     RMS-norm reduction, CPU-identical Q8_K quantisation straight into LDS.
 template <typename T, bool GLU, int PRO>
-__global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
+__global__ void __launch_bounds__(1024) k_mmvq_stream_ring(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::act act;
     // pairs per item: ~16 dwords of weights per lane per matrix (8 for the two-matrix GLU form).  Measured on MI355X:
@@ -232,18 +232,43 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         typename T::raw w[U];
         typename T::raw w2[U];
     };
-    auto load_item = [&](const int r, const int c, item & it) {
+    // The wave walks its items (row, chunk) through a STATIC ring of D register sets (round 4): while item i is multiplied, items
+    // i + 1 .. i + D - 1 are in flight.  The round-1..3 loop held `cur` and `nxt` and ended every trip with `cur = nxt` — a register
+    // copy, which needs nxt's DATA: hipcc put s_waitcnt vmcnt(0) in front of it, so a wave never had more than the one item in
+    // flight that it was about to need, and every trip paid the full memory latency behind its dot products (knock-out builds,
+    // scripts/ubench/experiments/mmvq_ko.hip: without the dot products the 66 MB gate/up launch dropped 15.1 -> 13.4 us although
+    // the kernel is nowhere near VALU-bound).  Every request is UNCONDITIONAL (addresses clamped to the wave's last item; a wave
+    // past its end re-requests lines it already holds): only then can hipcc count how many newer requests may stay in flight at
+    // each use (vmcnt(n) instead of vmcnt(0)).
+#ifndef RING_D
+#define RING_D 3
+#endif
+    constexpr int D = (RING_D == 3 && U * T::DW * (GLU ? 2 : 1) <= 24) ? 3 : 2;
+    struct ipos { int row, ch; bool have; };
+    auto advance = [&](const ipos q) {
+        if (!q.have) return q;
+        ipos n{q.row, q.ch + 1, true};
+        if (n.ch == nchunks) {
+            const int nr = next_row(q.row);
+            if (nr >= a.N) return ipos{q.row, q.ch, false};  // past the end: keep pointing at the last item (its lines are in L1 / L2)
+            n.row = nr;
+            n.ch = 0;
+        }
+        return n;
+    };
+    auto load_item = [&](const ipos q, item & it) {
+        const int r = min(q.row, a.N - 1);
         const uint8_t * rp = a.W + (size_t) r * a.w_nb1;
         const uint8_t * rp2 = GLU ? a.W2 + (size_t) r * a.w_nb1 : nullptr;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = (c * U + u) * 64 + lane;
-            if (p < npairs) {
-                it.w[u] = T::load(rp, p);
-                if (GLU) it.w2[u] = T::load(rp2, p);
-            }
+            const int p = min((q.ch * U + u) * 64 + lane, npairs - 1);
+            it.w[u] = T::load(rp, p);
+            if (GLU) it.w2[u] = T::load(rp2, p);
         }
     };
+    ipos p0{min(row, a.N - 1), 0, have}, p1 = advance(p0), p2 = advance(p1);
+    item r0, r1, r2;
     // Order of the first requests (scripts/ubench/decode_lab.hip, stamp_lab.hip, prologue_probe.hip — DESIGN.md §4):
     //   f32 prologue (PRO 1: wo, ffn_down): the activation row FIRST, then the first weights, both unconditionally (clamped
     //     addresses): wo 6.0 -> 5.4 us, ffn_down Q4_K 11.7 -> 10.3, Q6_K 15.8 -> 14.7.  A load under `if (...)` makes hipcc's
@@ -255,8 +280,6 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     constexpr int BPC = PRO == 0 ? 1 : 256 / T::BLK;  // activation blocks per 256-value chunk
     const int nchk = a.K / 256;
     float4 v[4], g[4];
-    double ssp[4] = {0.0, 0.0, 0.0, 0.0};
-    item cur;
     // PRO 3 (wo of a decode step): the activation row is the attention result, still in the form of its split partials
     // (fattn.hip, 8-wave form: [head][split] records of 128 values + (max, sum), FA_REC floats apart) — this prologue is the
     // combine pass, so that pass's launch (~4.5 us of a dependent launch for 16 KB of work) disappears.  Lane l of chunk b owns
@@ -272,44 +295,25 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         for (int sidx = 0; sidx < 12; ++sidx) fr[sidx] = *(const float4 *) (rec0 + (size_t) min(sidx, S - 1) * FA_REC + 4 * (lane & 31));
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (PRO == 1 || PRO == 3) {
-        if constexpr (PRO == 1) {
+    if constexpr (PRO == 1) {
         const float4 * x4 = (const float4 *) a.x;
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = x4[min(wave + u * WAVES, nchk - 1) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);  // keep the weight loads below behind them
-        }
-        const int rc = min(row, a.N - 1);
-        const uint8_t * rp = a.W + (size_t) rc * a.w_nb1;
-        const uint8_t * rp2 = GLU ? a.W2 + (size_t) rc * a.w_nb1 : nullptr;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = min(u * 64 + lane, npairs - 1);
-            cur.w[u] = T::load(rp, p);
-            if (GLU) cur.w2[u] = T::load(rp2, p);
-        }
-    } else {
-        if (have) load_item(row, 0, cur);
-        if constexpr (PRO == 2) {
-            if (a.ss_in) {  // (uniform) the producer of x left its sum of squares as partial sums: one more load in this round trip
-#pragma unroll
-                for (int u = 0; u < 4; ++u) ssp[u] = lane + 64 * u < a.ss_n ? a.ss_in[lane + 64 * u] : 0.0;
-            }
-            const float4 * x4 = (const float4 *) a.x;
-            const float4 * w4 = (const float4 *) a.norm_w;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int b = wave + u * WAVES;
-                if (b < nchk) {
-                    v[u] = x4[b * 64 + lane];
-                    g[u] = w4[b * 64 + lane];
-                } else {
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    g[u] = v[u];
-                }
-            }
-        }
     }
+    load_item(p0, r0);
+    if constexpr (PRO == 2) {
+        const float4 * x4 = (const float4 *) a.x;
+        const float4 * w4 = (const float4 *) a.norm_w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = min(wave + u * WAVES, nchk - 1);
+            v[u] = x4[b * 64 + lane];
+            g[u] = w4[b * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (D == 3) load_item(p1, r1);  // the second item goes out before the prologue as well: HBM keeps streaming underneath it
 
     // ---- activation prologue
     if constexpr (PRO == 0) {
@@ -379,12 +383,6 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
             }
             float scale = 1.0f;
             if constexpr (PRO == 2) {
-              double tot = 0.0;
-              if (a.ss_in) {
-                // partial sums in a fixed order (lane-strided, then the wave tree): every wave of every workgroup gets the same bits,
-                // and nobody waits for anybody
-                tot = wave_sum_d(((ssp[0] + ssp[1]) + ssp[2]) + ssp[3]);
-              } else {
                 double * red = (double *) (smem + (size_t) nblk * sizeof(act));
                 double ss = 0.0;
 #pragma unroll
@@ -392,9 +390,9 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
                 ss = wave_sum_d(ss);
                 if (lane == 0) red[wave] = ss;
                 __syncthreads();  // reached exactly once by every wave: the loop condition admits b0 == wave
+                double tot = 0.0;
 #pragma unroll
                 for (int i = 0; i < WAVES; ++i) tot += red[i];
-              }
                 const float mean = (float) (tot / (double) a.K);
                 scale = 1.0f / sqrtf(mean + a.eps);
             }
@@ -421,51 +419,55 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
     const act * y = (const act *) smem;
 
     float acc = 0.0f, acc2 = 0.0f;
-    double ssw = 0.0;  // lane 0: sum of squares of the rows this wave produced
-    while (have) {
-        int nrow = row, nch = ch + 1;
-        if (nch == nchunks) { nch = 0; nrow = next_row(row); }
-        const bool nhave = nrow < a.N;
-        item nxt;
-        if (nhave) load_item(nrow, nch, nxt);
+    auto compute = [&](const item & it, const ipos q) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = (ch * U + u) * 64 + lane;
+            const int p = (q.ch * U + u) * 64 + lane;
             if (p < npairs) {
-                T::template dot<1>(cur.w[u], p, y, nblk, &acc);
-                if (GLU) T::template dot<1>(cur.w2[u], p, y, nblk, &acc2);
+                T::template dot<1>(it.w[u], p, y, nblk, &acc);
+                if (GLU) T::template dot<1>(it.w2[u], p, y, nblk, &acc2);
             }
         }
-        if (ch == nchunks - 1) {
+        if (q.ch == nchunks - 1) {
             float v = wave_sum(acc);
             if (GLU) {
                 const float g = wave_sum(acc2);
                 v = silu_f(v) * g;
             }
             if (lane == 0) {
-                if (a.add) v += a.add[row];
-                if (a.add2) v += a.add2[row];
-                a.dst[row] = v;
-                ssw += (double) (v * v);  // (as ggml-cpu's rms_norm: the f32 product, summed in double)
+                if (a.add) v += a.add[q.row];
+                if (a.add2) v += a.add2[q.row];
+                a.dst[q.row] = v;
             }
             acc = 0.0f;
             acc2 = 0.0f;
         }
-        cur = nxt;
-        row = nrow;
-        ch = nch;
-        have = nhave;
-    }
-    if (a.ss_out) {  // (uniform) this launch writes a residual stream an RMS_NORM prologue reads next: leave its sum of squares, one partial per workgroup
-        double * red = (double *) (smem + (size_t) nblk * sizeof(act));
-        if constexpr (PRO == 2) __syncthreads();  // (the norm prologue's own exchange used this area)
-        if (lane == 0) red[wave] = ssw;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int i = 0; i < WAVES; ++i) t += red[i];
-            a.ss_out[blockIdx.x] = t;
+    };
+    if constexpr (D == 3) {
+        for (;;) {
+            load_item(p2, r2);
+            if (!p0.have) break;
+            compute(r0, p0);
+            p0 = advance(p2);
+            load_item(p0, r0);
+            if (!p1.have) break;
+            compute(r1, p1);
+            p1 = advance(p0);
+            load_item(p1, r1);
+            if (!p2.have) break;
+            compute(r2, p2);
+            p2 = advance(p1);
+        }
+    } else {
+        for (;;) {
+            load_item(p1, r1);
+            if (!p0.have) break;
+            compute(r0, p0);
+            p0 = advance(p1);
+            load_item(p0, r0);
+            if (!p1.have) break;
+            compute(r1, p1);
+            p1 = advance(p0);
         }
     }
 }
@@ -478,17 +480,17 @@ template <typename T, bool GLU, int PRO> static void launch_stream(hipStream_t s
     mmvq_args a2 = a;
     a2.balance_tail = bal;
     if (g_launch_probe.armed && !g_launch_probe.used) {
-        hipExtLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, g_launch_probe.e0, g_launch_probe.e1, 0, a2);
+        hipExtLaunchKernelGGL((k_mmvq_stream_ring<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, g_launch_probe.e0, g_launch_probe.e1, 0, a2);
         g_launch_probe.used = true;
     } else {
-        hipLaunchKernelGGL((k_mmvq_stream<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, a2);
+        hipLaunchKernelGGL((k_mmvq_stream_ring<T, GLU, PRO>), dim3(grid), dim3(1024), lds, s, a2);
     }
 }
 
 template <typename T, int NC, int R, bool GLU, int PRO, int WAVES> static void launch_one(hipStream_t s, const mmvq_args & a, size_t lds) {
     const int rows_per_block = WAVES * R;
     const unsigned grid = (unsigned) ((a.N + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((k_mmvq<T, NC, R, GLU, PRO, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
+    hipLaunchKernelGGL((k_mmvq_ring<T, NC, R, GLU, PRO, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
 }
 
 template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a0, int rows_per_wave) {
@@ -543,13 +545,7 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
     }
 }
 
-int launch_mmvq_ss_count(const mmvq_args & a) {
-    // the streaming kernel with an f32 / norm prologue (launch_type): one column, K-quant or Q8_0 rows of whole 256-value chunks, no SwiGLU
-    if (a.ncols != 1 || a.W2 != nullptr || a.fa_part != nullptr || a.x == nullptr || (a.K % 256) != 0) return 0;
-    return (int) std::min<int64_t>(256, ((int64_t) a.N + 15) / 16);
-}
-
-void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave) {
+static void launch_mmvq_ring(hipStream_t s, const mmvq_args & a, int rows_per_wave) {
     switch (a.type) {
         case GGML_TYPE_Q4_K: launch_type<T_Q4K>(s, a, rows_per_wave); break;
         case GGML_TYPE_Q5_K: launch_type<T_Q5K>(s, a, rows_per_wave); break;
@@ -558,5 +554,7 @@ void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave) {
         default: MI_ERR("launch_mmvq: unsupported weight type %d", a.type); abort();
     }
 }
+
+bool launch_mmvq_v2(hipStream_t s, const mmvq_args & a) { launch_mmvq_ring(s, a, 1); return true; }
 
 }  // namespace mi355x

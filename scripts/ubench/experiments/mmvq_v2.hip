@@ -19,6 +19,12 @@
 
 namespace mi355x {
 
+#ifndef V2_VARIANT
+#define V2_VARIANT 0
+#endif
+// lab variants: 0 = one item requested before the prologue (+ one more inside the loop, as k_mmvq_stream); 1 = two before the prologue
+#define V2_DEPTH (V2_VARIANT == 1 ? 2 : 1)
+
 template <typename T, bool GLU, int PRO>
 __global__ void __launch_bounds__(1024) k_mmvq_cols(const mmvq_args a, const int rg_shift) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,7 +59,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_cols(const mmvq_args a, const int
     auto load_item = [&](const int t, const int ci, item & it) {
         bool valid;
         const int row = min(row_of(t, valid), a.N - 1);
-        const int p = (wcol + ci * CW) * 4 + j;
+        const int p = min(wcol + ci * CW, nblk - 1) * 4 + j;  // (clamped: a wave beyond the last column still issues its first, unused request)
         it.w = T::load(a.W + (size_t) row * a.w_nb1, p);
         if (GLU) it.w2 = T::load(a.W2 + (size_t) row * a.w_nb1, p);
     };
@@ -73,11 +79,28 @@ __global__ void __launch_bounds__(1024) k_mmvq_cols(const mmvq_args a, const int
         if constexpr (PRO == 2) g[u] = g4[b * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
-    int t = 0, ci = 0;
-    bool have = ncol > 0 && n_pass > 0 && wave_active(0);
+    // item iterator: (pass, column index) in the order the wave walks them
+    struct pos { int t, ci; bool have; };
+    auto advance = [&](const pos q) {
+        pos n{q.t, q.ci + 1, false};
+        if (n.ci >= ncol) { n.ci = 0; n.t = q.t + 1; }
+        n.have = q.have && n.t < n_pass && wave_active(n.t);
+        return n;
+    };
+    pos at{0, 0, ncol > 0 && n_pass > 0 && wave_active(0)};
     // (a wave without work in pass 0 has none in the tail either when n_full == 0; with n_full > 0 pass 0 is a full one)
-    item cur;
-    load_item(0, 0, cur);
+    constexpr int D = V2_DEPTH;  // items requested before the prologue
+    item ring[D];
+    pos rp[D];
+    {
+        pos q = at;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            rp[d] = q;
+            if (d == 0 || q.have) load_item(q.have ? q.t : 0, q.have ? q.ci : 0, ring[d]);
+            q = advance(q);
+        }
+    }
 
     // ---- activation prologue: this wave's columns only
     float scale = 1.0f;
@@ -85,10 +108,17 @@ __global__ void __launch_bounds__(1024) k_mmvq_cols(const mmvq_args a, const int
         // the norm's sum of squares is the one thing every wave needs from every other: the row is shared out over ALL 16 waves here
         // (wave w sums 256-value chunks w, w + 16, ...), whatever the column map
         double ss = 0.0;
-        const int nchk = nblk;
-        for (int b0 = wave; b0 < nchk; b0 += WAVES) {
-            const float4 q = (CW == WAVES && b0 < 4 * CW) ? v[(b0 - wave) / WAVES] : x4[b0 * 64 + lane];
-            ss += (double) (q.x * q.x) + (double) (q.y * q.y) + (double) (q.z * q.z) + (double) (q.w * q.w);
+        float4 sq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // (K <= 16384: four chunks per wave at most; with CW == 16 they ARE the wave's columns, already requested)
+            const int b0 = wave + u * WAVES;
+            if (CW == WAVES) sq[u] = v[u];
+            else sq[u] = x4[min(b0, nblk - 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 q = sq[u];
+            if (wave + u * WAVES < nblk) ss += (double) (q.x * q.x) + (double) (q.y * q.y) + (double) (q.z * q.z) + (double) (q.w * q.w);
         }
         ss = wave_sum_d(ss);
         if (lane == 0) red_ss[wave] = ss;
@@ -127,15 +157,14 @@ __global__ void __launch_bounds__(1024) k_mmvq_cols(const mmvq_args a, const int
     // (no barrier: a wave reads back only the blocks it wrote itself, and a wave's LDS operations complete in order)
 
     float acc = 0.0f, acc2 = 0.0f;
-    while (have) {
-        int nt = t, nci = ci + 1;
-        if (nci == ncol) { nci = 0; nt = t + 1; }
-        const bool nhave = nt < n_pass && wave_active(nt);
+    pos nq = advance(rp[D - 1]);  // the next item to request
+    while (rp[0].have) {
         item nxt;
-        if (nhave) load_item(nt, nci, nxt);
+        if (nq.have) load_item(nq.t, nq.ci, nxt);
+        const int t = rp[0].t, ci = rp[0].ci;
         const int p = (wcol + ci * CW) * 4 + j;
-        T::template dot<1>(cur.w, p, yl, nblk, &acc);
-        if (GLU) T::template dot<1>(cur.w2, p, yl, nblk, &acc2);
+        T::template dot<1>(ring[0].w, p, yl, nblk, &acc);
+        if (GLU) T::template dot<1>(ring[0].w2, p, yl, nblk, &acc2);
         if (ci == ncol - 1) {
             // the quad's four lanes hold one row's partial over this wave's columns
             float s = acc;
@@ -155,10 +184,11 @@ __global__ void __launch_bounds__(1024) k_mmvq_cols(const mmvq_args a, const int
             acc = 0.0f;
             acc2 = 0.0f;
         }
-        cur = nxt;
-        t = nt;
-        ci = nci;
-        have = nhave;
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d) { ring[d] = ring[d + 1]; rp[d] = rp[d + 1]; }
+        ring[D - 1] = nxt;
+        rp[D - 1] = nq;
+        nq = advance(nq);
     }
     __syncthreads();
     // ---- rows of the workgroup: fixed-order sum over the column waves, epilogue

@@ -242,6 +242,43 @@ def test_hipgraph_replay_is_bit_identical_to_eager(backend, H, plog):
     assert np.array_equal(outs[1][1].view(np.uint32), outs[0][1].view(np.uint32))
 
 
+@pytest.mark.parametrize("name", ["test-llama", "test-qwen2"])
+def test_sum_of_squares_handed_from_the_residual_mat_vecs_to_the_norm_prologues(backend, H, plog, name):
+    """Option ss_partials (on by default, round 4): the mat-vec launches that write a residual stream (wo + residual, ffn_down + residual) leave
+    the sum of squares of their result row as one partial sum per workgroup, and the RMS_NORM prologue of the launch that reads the row next
+    (gate / up of the same layer, the fused Q/K/V of the next layer, the output matrix) adds those instead of walking the row behind a
+    workgroup barrier.  Same numbers as without (the double-precision sum only changes its order), and the hand-offs are counted: per decode
+    step n_layer (ffn norms) + n_layer - 1 (attention norms of layers 1..) [+ 1: the output norm, when it is deferred into a K-quant mat-vec]."""
+    hp = preset(name)
+    mg = Model(hp, 4321, backend.buft)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            backend.set_option("ss_partials", mode)
+            backend.set_option("graphs", 0)  # (count per executed graph, not per capture)
+            c = Context(mg, backend=backend, flash_attn=1)
+            rc, _ = c.decode(PROMPT, range(len(PROMPT)))
+            assert rc == 0
+            h0 = backend.stat("ss_handoffs")
+            rows = []
+            for i in range(6):
+                rc, lg = c.decode([11 + i], [len(PROMPT) + i])
+                assert rc == 0
+                rows.append(lg[0])
+            outs[mode] = (np.stack(rows), backend.stat("ss_handoffs") - h0)
+            c.free()
+    finally:
+        backend.set_option("ss_partials", 1)
+        backend.set_option("graphs", 1)
+        mg.free()
+    e = T.nmse(outs[1][0], outs[0][0])
+    plog(f"[ss_partials] {name}: hand-offs per decode step {outs[1][1] / 6:.1f} (n_layer {hp.n_layer}), logits nmse on vs off {e:.2e}, bit-equal {np.array_equal(outs[1][0], outs[0][0])}")
+    assert outs[0][1] == 0
+    # (the output matrix takes part when its norm is deferred into a K-quant mat-vec prologue; the test models keep it in another format)
+    assert outs[1][1] in (6 * (2 * hp.n_layer - 1), 6 * 2 * hp.n_layer), (outs[1][1], hp.n_layer)
+    assert e <= 1e-9
+
+
 def test_gguf_file_path_equals_in_memory_model(backend, H, plog):
     hp = preset("test-qwen2")
     with tempfile.TemporaryDirectory() as d:
