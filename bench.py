@@ -171,24 +171,47 @@ def main():
     if world > 1:
         # every step of the set-up is agreed on by all ranks over gloo, so that a rank that cannot load RCCL (or cannot create
         # the communicator) never leaves the others blocked in a collective: any failure -> every rank runs a full replica
-        uid, err = [None], ""
-        if rank == 0:
+        def agree(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t[0]) == 1
+
+        # (1) the one-shot peer-to-peer all-reduce (csrc/tp_p2p.hip): IPC-mapped mailboxes, the handles go round over gloo.  Serves the
+        # latency-bound sums of decode; needs no RCCL and works with several ranks on one GPU (the dry run)
+        err, handle = "", None
+        try:
+            if os.environ.get("BENCH_TP_P2P", "1") != "0":
+                handle = be.tp_p2p_export(rank, world)
+        except Exception as e:
+            err = f"p2p export: {e}"
+        handles = [None] * world
+        dist.all_gather_object(handles, handle)
+        p2p_ok = all(h is not None for h in handles)
+        if p2p_ok:
+            try:
+                be.tp_p2p_attach(handles)
+            except Exception as e:
+                p2p_ok, err = False, f"p2p attach: {e}"
+        p2p_ok = agree(p2p_ok)
+        # (2) RCCL for the long messages of prompt batches (one communicator over xGMI); impossible when ranks share a GPU
+        uid = [None]
+        if rank == 0 and not shared_gpu and os.environ.get("BENCH_TP_RCCL", "1") != "0":
             try:
                 uid[0] = be.tp_unique_id()
             except Exception as e:
                 err = f"unique id: {e}"
         dist.broadcast_object_list(uid, src=0)
-        ok = 1 if uid[0] is not None else 0
-        if ok:
+        rccl_ok = uid[0] is not None
+        if rccl_ok:
             try:
                 be.tp_init(rank, world, uid[0])
             except Exception as e:
-                ok, err = 0, f"comm init: {e}"
-        agreed = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        if int(agreed[0]) == 1:
+                rccl_ok, err = False, f"comm init: {e}"
+        rccl_ok = agree(rccl_ok)
+        if p2p_ok or rccl_ok:
             tp_size, tp_rank = world, rank
-            parallelism = f"tp{world} (row/column tensor-split, RCCL all-reduce x{2 * hp.n_layer}/token)"
+            how = "one-shot P2P all-reduce over IPC-mapped mailboxes" + (" + RCCL for messages > 256 KiB" if rccl_ok else " (no RCCL communicator)") if p2p_ok else "RCCL all-reduce"
+            parallelism = f"tp{world} (row/column tensor-split, {how}, x{2 * hp.n_layer}/token)"
         else:
             parallelism = f"replicas x{world} (tensor-split set-up failed on some rank{': ' + err if err else ''})"
     t_load = time.time()
@@ -456,6 +479,7 @@ def main():
             "prefill_roofline": prefill_roofline,
             "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),
             "replicas_on_the_same_gpus": replicas,
+            "tp_stats": {"allreduces": int(be.stat("allreduces")), "p2p_launches_issued": int(be.stat("p2p_allreduces")), "p2p_timeouts": int(be.stat("p2p_timeouts"))} if tp_size > 1 else None,
             "graph_replayed_steps": int(graph_steps), "hipGraphLaunch_host_us": round(graph_launch_host_us, 1),
             "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -51,6 +51,8 @@ ggml_backend_reg_t ggml_backend_mi355x_reg(void);
  *   "ggml_backend_mi355x_get_stat"     ggml_backend_mi355x_get_stat_t
  *   "ggml_backend_mi355x_timing_report" ggml_backend_mi355x_timing_report_t
  *   "ggml_backend_mi355x_tp_get_unique_id" ggml_backend_mi355x_tp_get_unique_id_t
+ *   "ggml_backend_mi355x_tp_p2p_export"   ggml_backend_mi355x_tp_p2p_export_t
+ *   "ggml_backend_mi355x_tp_p2p_attach"   ggml_backend_mi355x_tp_p2p_attach_t
  */
 
 /* Replaces: ggml_backend_cuda_split_buffer_type(int main_device, const float * tensor_split) of the stock GPU backends, as reached
@@ -65,6 +67,14 @@ typedef void (*ggml_backend_mi355x_split_rows_t)(int64_t nrows, const float * te
  * successful call, MUL_MAT nodes whose src0 lives in the "rowpar" buffer type are followed by an in-stream
  * all-reduce(sum) of their f32 result across ranks.  Returns 0 on success. */
 typedef int (*ggml_backend_mi355x_tp_init_t)(ggml_backend_t backend, int rank, int world_size, const void * unique_id, size_t unique_id_size);
+/* One-shot peer-to-peer all-reduce for the latency-bound sums of tensor-parallel decode (csrc/tp_p2p.hip; no reference counterpart: llama.cpp
+ * has no collective — SURVEY.md §2.5, §8e).  Two steps, both on every rank: export() allocates this rank's mailbox and returns its
+ * hipIpcMemHandle_t (64 bytes) in handle_out; the launcher's control plane gathers the `world_size` handles in rank order; attach() maps the
+ * peers' mailboxes.  From then on row-parallel sums of up to 256 KiB run as ONE launch that writes the partial into every peer's memory over
+ * xGMI and adds the world_size mailboxes in rank order (bit-identical on all ranks); longer ones use RCCL when tp_init() has also been called,
+ * else they go through the mailboxes in chunks.  Works without RCCL, and with several ranks on one GPU.  Return 0 on success. */
+typedef int (*ggml_backend_mi355x_tp_p2p_export_t)(ggml_backend_t backend, int rank, int world_size, void * handle_out, size_t handle_size);
+typedef int (*ggml_backend_mi355x_tp_p2p_attach_t)(ggml_backend_t backend, const void * handles, size_t handles_size);
 typedef int (*ggml_backend_mi355x_tp_get_unique_id_t)(void * unique_id_out, size_t unique_id_size);
 typedef ggml_backend_buffer_type_t (*ggml_backend_mi355x_tp_rowpar_buffer_type_t)(int device);
 

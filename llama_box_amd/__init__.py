@@ -245,6 +245,23 @@ class Backend:
         if rc != 0:
             raise RuntimeError(f"ggml-mi355x: tp_init failed ({rc})")
 
+    def tp_p2p_export(self, rank, world):
+        """Step 1 of the one-shot peer-to-peer all-reduce (csrc/tp_p2p.hip): this rank's mailbox as a 64-byte IPC handle."""
+        fn = self.proc("ggml_backend_mi355x_tp_p2p_export", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t])
+        buf = C.create_string_buffer(64)
+        rc = fn(self.backend, rank, world, buf, 64)
+        if rc != 0:
+            raise RuntimeError(f"ggml-mi355x: tp_p2p_export failed ({rc})")
+        return buf.raw
+
+    def tp_p2p_attach(self, handles):
+        """Step 2: `handles` = the world's 64-byte handles in rank order (bytes, or a list of bytes)."""
+        blob = b"".join(handles) if isinstance(handles, (list, tuple)) else handles
+        fn = self.proc("ggml_backend_mi355x_tp_p2p_attach", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t])
+        rc = fn(self.backend, blob, len(blob))
+        if rc != 0:
+            raise RuntimeError(f"ggml-mi355x: tp_p2p_attach failed ({rc})")
+
     def synchronize(self):
         host().ggml_backend_synchronize(self.backend)
 

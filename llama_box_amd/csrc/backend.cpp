@@ -527,6 +527,14 @@ static int api_tp_init(ggml_backend_t be, int rank, int world, const void * uid,
     return tp_init((backend_ctx *) be->context, rank, world, uid, n);
 }
 static int api_tp_get_unique_id(void * out, size_t n) { return tp_get_unique_id(out, n); }
+static int api_tp_p2p_export(ggml_backend_t be, int rank, int world, void * handle_out, size_t n) {
+    if (!be_is_ours(be)) return -1;
+    return tp_p2p_export((backend_ctx *) be->context, rank, world, handle_out, n);
+}
+static int api_tp_p2p_attach(ggml_backend_t be, const void * handles, size_t n) {
+    if (!be_is_ours(be)) return -1;
+    return tp_p2p_attach((backend_ctx *) be->context, handles, n);
+}
 static ggml_backend_buffer_type_t api_split_buffer_type(int main_device, const float * tensor_split) { return split_buffer_type(main_device, tensor_split); }
 static void api_split_rows(int64_t nrows, const float * tensor_split, int n_dev, int64_t * row0) { split_rows(nrows, tensor_split, n_dev, nrows % 256 == 0 ? 256 : 64, row0); }  // (the granule sbuf_init_tensor uses)
 static ggml_backend_buffer_type_t api_tp_rowpar_buft(int device) {
@@ -575,6 +583,8 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "fused_nodes") return c->st.fused_nodes;
     if (k == "allreduces") return c->st.allreduces;
     if (k == "ss_handoffs") return c->st.ss_handoffs;
+    if (k == "p2p_allreduces") return c->st.p2p_allreduces;
+    if (k == "p2p_timeouts") return tp_p2p_timeouts(c);
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
     if (k == "skinny_launches") return c->st.skinny_launches;
     if (k == "wide_launches") return c->st.wide_launches;
@@ -619,6 +629,8 @@ static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (n == "ggml_backend_get_features") return (void *) get_features;
     if (n == "ggml_backend_mi355x_tp_init") return (void *) api_tp_init;
     if (n == "ggml_backend_mi355x_tp_get_unique_id") return (void *) api_tp_get_unique_id;
+    if (n == "ggml_backend_mi355x_tp_p2p_export") return (void *) api_tp_p2p_export;
+    if (n == "ggml_backend_mi355x_tp_p2p_attach") return (void *) api_tp_p2p_attach;
     if (n == "ggml_backend_mi355x_tp_rowpar_buffer_type") return (void *) api_tp_rowpar_buft;
     if (n == "ggml_backend_mi355x_set_option") return (void *) api_set_option;
     if (n == "ggml_backend_mi355x_get_stat") return (void *) api_get_stat;

@@ -106,6 +106,7 @@ struct options {
 
 struct stats {
     int64_t graph_launches = 0, graph_captures = 0, eager_graphs = 0, kernel_launches = 0, fused_nodes = 0, allreduces = 0;
+    int64_t p2p_allreduces = 0;        // row-parallel sums served by the one-shot peer-to-peer kernel (tp_p2p.hip) instead of RCCL
     int64_t ss_handoffs = 0;           // RMS_NORM prologues that took the sum of squares from the producing mat-vec's partial sums
     int64_t skinny_launches = 0;       // mat-muls of 2..32 columns served by the weight-streaming matrix-core kernel
     int64_t wide_launches = 0;         // prompt-batch mat-muls served by its wide form
@@ -240,6 +241,9 @@ void free_graph_cache(backend_ctx * ctx);
 int tp_init(backend_ctx * ctx, int rank, int world, const void * uid, size_t uid_size);
 int tp_get_unique_id(void * out, size_t size);
 bool tp_active(const backend_ctx * ctx);
+int tp_p2p_export(backend_ctx * ctx, int rank, int world, void * handle_out, size_t size);  // -> this rank's mailbox as a hipIpcMemHandle_t (64 bytes)
+int tp_p2p_attach(backend_ctx * ctx, const void * handles, size_t size);                    // world handles in rank order, own slot ignored
+int64_t tp_p2p_timeouts(backend_ctx * ctx);
 // in-stream sum all-reduce of n floats at ptr (capturable)
 bool tp_all_reduce(backend_ctx * ctx, float * ptr, size_t n);
 void tp_free(backend_ctx * ctx);

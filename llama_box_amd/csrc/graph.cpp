@@ -1430,6 +1430,7 @@ static int run_node(exec_state & st, int i) {
             st.sk_next = -1;
             if (!ok_mm) return -1;
             if (rowpar) {
+                timed_scope ts(c, "tp_all_reduce", (double) ggml_abi_nbytes(n));
                 if (!tp_all_reduce(c, (float *) n->data, (size_t) ggml_abi_nelements(n))) return -1;
                 c->st.allreduces++;
             }

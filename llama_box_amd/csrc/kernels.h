@@ -119,6 +119,19 @@ struct qkv_args {
     const double * ss_in;  // as mmvq_args::ss_in / ss_n (norm prologue)
     int ss_n;
 };
+// ---- one-shot peer-to-peer all-reduce (tp_p2p.hip)
+#define P2P_SLOT_FLOATS 65536  // values per (parity, source rank) mailbox: 256 KiB of f32 = 8 columns of Llama-3-70B's residual stream
+#define P2P_MAX_BLOCKS 32
+#define P2P_MAX_RANKS 16
+struct p2p_args {
+    float * data;                     // in: this rank's partial; out: the sum over ranks (in rank order)
+    int n;                            // <= P2P_SLOT_FLOATS
+    int rank, world;
+    char * mbox[P2P_MAX_RANKS];       // every rank's mailbox as mapped HERE: [2 parities][world sources][P2P_SLOT_FLOATS] 8-byte granules
+    unsigned * state;                 // device: [0] epoch of the last finished all-reduce, [1] arrivals of the running one, [2] time-outs
+    unsigned max_spins;
+};
+void launch_p2p_all_reduce(hipStream_t s, const p2p_args & a);
 bool qkv_types_supported(int type_a, int type_b);
 void launch_qkv(hipStream_t s, const qkv_args & a, int type_a, int type_b);
 

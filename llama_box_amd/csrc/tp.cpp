@@ -11,7 +11,11 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <cstring>
+
 #include "common.h"
+#include "kernels.h"
 
 namespace mi355x {
 
@@ -52,9 +56,16 @@ static rccl_api * load_rccl() {
 }
 
 struct tp_state {
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;  // optional since round 4: a peer-to-peer-only group has none
     int rank = 0, world = 1;
+    // one-shot peer-to-peer all-reduce (tp_p2p.hip): this rank's mailbox, every rank's mailbox as mapped here, the device-side state words
+    char * mbox_local = nullptr;
+    char * mbox[P2P_MAX_RANKS] = {nullptr};
+    unsigned * p2p_state = nullptr;
+    bool p2p = false;
+    int p2p_max_cols_bytes = 0;  // messages up to this many bytes take the one-shot path when RCCL is there too
 };
+static size_t mbox_bytes(int world) { return (size_t) 2 * (size_t) world * P2P_SLOT_FLOATS * 8; }
 
 int tp_get_unique_id(void * out, size_t size) {
     rccl_api * api = load_rccl();
@@ -71,14 +82,14 @@ int tp_init(backend_ctx * c, int rank, int world, const void * uid, size_t uid_s
     if (!api || uid_size < sizeof(ncclUniqueId)) return -1;
     ncclUniqueId id;
     memcpy(&id, uid, sizeof(id));
-    tp_state * t = new tp_state();
+    tp_state * t = c->tp ? c->tp : new tp_state();  // (a peer-to-peer group may already be attached)
     t->rank = rank;
     t->world = world;
     HIP_CHECK(hipSetDevice(c->device));
     ncclResult_t r = api->CommInitRank(&t->comm, world, id, rank);
     if (r != ncclSuccess) {
         MI_ERR("ncclCommInitRank failed: %s", api->GetErrorString ? api->GetErrorString(r) : "?");
-        delete t;
+        if (!c->tp) delete t;
         return -2;
     }
     c->tp = t;
@@ -97,10 +108,103 @@ int tp_init(backend_ctx * c, int rank, int world, const void * uid, size_t uid_s
     return 0;
 }
 
-bool tp_active(const backend_ctx * c) { return c->tp != nullptr && c->tp->world > 1; }
+// ---- peer-to-peer group (no RCCL needed).  Step 1, every rank: allocate the mailbox and hand out its IPC handle ...
+int tp_p2p_export(backend_ctx * c, int rank, int world, void * handle_out, size_t size) {
+    if (world < 2 || world > P2P_MAX_RANKS || rank < 0 || rank >= world || size < sizeof(hipIpcMemHandle_t)) return -1;
+    HIP_TRY(hipSetDevice(c->device), -2);
+    tp_state * t = c->tp ? c->tp : new tp_state();
+    if (c->tp && (t->rank != rank || t->world != world)) { MI_ERR("tp_p2p_export: rank / world differ from the RCCL communicator's"); return -3; }
+    t->rank = rank;
+    t->world = world;
+    if (!t->mbox_local) {
+        // uncached (fine-grained) device memory: peers write it over xGMI / from another process while this rank's kernel polls it
+        hipError_t e = hipExtMallocWithFlags((void **) &t->mbox_local, mbox_bytes(world), hipDeviceMallocUncached);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            e = hipExtMallocWithFlags((void **) &t->mbox_local, mbox_bytes(world), hipDeviceMallocFinegrained);
+        }
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            MI_ERR("tp_p2p_export: cannot allocate %.1f MiB of uncached mailbox memory (%s)", mbox_bytes(world) / 1048576.0, hipGetErrorString(e));
+            if (!c->tp) delete t;
+            return -4;
+        }
+        HIP_TRY(hipMemset(t->mbox_local, 0, mbox_bytes(world)), -5);  // tag 0 never matches: epochs start at 1
+        HIP_TRY(hipMalloc((void **) &t->p2p_state, 64), -5);
+        HIP_TRY(hipMemset(t->p2p_state, 0, 64), -5);
+        HIP_TRY(hipDeviceSynchronize(), -5);
+    }
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, t->mbox_local);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        MI_ERR("tp_p2p_export: hipIpcGetMemHandle failed (%s) — HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver", hipGetErrorString(e));
+        if (!c->tp) { (void) hipFree(t->mbox_local); (void) hipFree(t->p2p_state); delete t; }
+        return -6;
+    }
+    memcpy(handle_out, &h, sizeof(h));
+    c->tp = t;
+    return 0;
+}
+// ... step 2, every rank, after the handles went round (the caller's control plane: gloo in bench.py / the tests): map the peers' mailboxes
+int tp_p2p_attach(backend_ctx * c, const void * handles, size_t size) {
+    tp_state * t = c->tp;
+    if (!t || !t->mbox_local || size < (size_t) t->world * sizeof(hipIpcMemHandle_t)) return -1;
+    HIP_TRY(hipSetDevice(c->device), -2);
+    for (int r = 0; r < t->world; ++r) {
+        if (r == t->rank) { t->mbox[r] = t->mbox_local; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *) handles + (size_t) r * sizeof(h), sizeof(h));
+        void * p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            MI_ERR("tp_p2p_attach: hipIpcOpenMemHandle of rank %d's mailbox failed (%s)", r, hipGetErrorString(e));
+            return -3;
+        }
+        t->mbox[r] = (char *) p;
+    }
+    t->p2p = true;
+    const char * e = getenv("GGML_MI355X_P2P_MAX_BYTES");
+    t->p2p_max_cols_bytes = e ? atoi(e) : 8 * 8192 * 4;  // up to eight columns of a 70B residual stream; longer messages prefer RCCL's ring when there is one
+    // as with a communicator: replayed graphs containing cross-rank waits are opt-in (a replay that hangs has no fallback; the kernel's spins are bounded)
+    const char * g = getenv("GGML_MI355X_TP_GRAPHS");
+    const bool env_on = g != nullptr && atoi(g) != 0;
+    if (!t->comm) c->opt.graphs = c->opt.graphs && env_on;
+    MI_INFO("tensor parallel rank %d / %d: one-shot peer-to-peer all-reduce attached (mailbox %.1f MiB per rank%s)", t->rank, t->world, mbox_bytes(t->world) / 1048576.0,
+            t->comm ? ", RCCL for longer messages" : ", no RCCL communicator");
+    return 0;
+}
+int64_t tp_p2p_timeouts(backend_ctx * c) {
+    if (!c->tp || !c->tp->p2p_state) return 0;
+    unsigned st[3] = {0, 0, 0};
+    if (hipMemcpy(st, c->tp->p2p_state, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) { (void) hipGetLastError(); return -1; }
+    return (int64_t) st[2];
+}
+
+bool tp_active(const backend_ctx * c) { return c->tp != nullptr && c->tp->world > 1 && (c->tp->comm != nullptr || c->tp->p2p); }
 
 bool tp_all_reduce(backend_ctx * c, float * ptr, size_t n) {
     if (!tp_active(c)) return true;
+    tp_state * t = c->tp;
+    if (t->p2p && (t->comm == nullptr || n * sizeof(float) <= (size_t) t->p2p_max_cols_bytes)) {
+        // one launch per mailbox-full (decode: ONE launch; a prompt batch without RCCL goes through in chunks)
+        static const unsigned max_spins = getenv("GGML_MI355X_P2P_MAX_SPINS") ? (unsigned) atoll(getenv("GGML_MI355X_P2P_MAX_SPINS")) : 4000000u;  // ~ seconds
+        for (size_t o = 0; o < n; o += P2P_SLOT_FLOATS) {
+            p2p_args a{};
+            a.data = ptr + o;
+            a.n = (int) std::min<size_t>(P2P_SLOT_FLOATS, n - o);
+            a.rank = t->rank;
+            a.world = t->world;
+            for (int r = 0; r < t->world; ++r) a.mbox[r] = t->mbox[r];
+            a.state = t->p2p_state;
+            a.max_spins = max_spins;
+            launch_p2p_all_reduce(c->stream, a);
+            c->st.kernel_launches++;
+            c->st.p2p_allreduces++;
+        }
+        return hipGetLastError() == hipSuccess;
+    }
     rccl_api * api = load_rccl();
     ncclResult_t r = api->AllReduce(ptr, ptr, n, ncclFloat32, ncclSum, c->tp->comm, c->stream);
     if (r != ncclSuccess) {
@@ -112,8 +216,12 @@ bool tp_all_reduce(backend_ctx * c, float * ptr, size_t n) {
 
 void tp_free(backend_ctx * c) {
     if (!c->tp) return;
-    rccl_api * api = load_rccl();
+    rccl_api * api = c->tp->comm ? load_rccl() : nullptr;
     if (api && c->tp->comm) api->CommDestroy(c->tp->comm);
+    for (int r = 0; r < c->tp->world && r < P2P_MAX_RANKS; ++r)
+        if (c->tp->mbox[r] && c->tp->mbox[r] != c->tp->mbox_local && hipIpcCloseMemHandle(c->tp->mbox[r]) != hipSuccess) (void) hipGetLastError();
+    if (c->tp->mbox_local && hipFree(c->tp->mbox_local) != hipSuccess) (void) hipGetLastError();
+    if (c->tp->p2p_state && hipFree(c->tp->p2p_state) != hipSuccess) (void) hipGetLastError();
     delete c->tp;
     c->tp = nullptr;
 }

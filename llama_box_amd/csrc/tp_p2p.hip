@@ -1,0 +1,92 @@
+// tp_p2p.hip — one-shot peer-to-peer all-reduce for the latency-bound messages of tensor-parallel decode (round 4).
+//
+// What it serves: the two sums per layer of a --tensor-split run (llama-box/engine_param.hpp:821-842): n_embd x M f32
+// partial products, 16 KiB (8B) / 32 KiB (70B) at batch 1.  A ring collective pays 2 (N - 1) hops for them; xGMI is point to point and
+// every GPU reaches every other directly, so here each rank WRITES its partial straight into a mailbox in every peer's memory and then
+// sums the N mailboxes of its own memory in rank order — one hop, one launch, and every rank adds the same numbers in the same order
+// (the result is bit-identical on all ranks and from run to run).
+//
+// Protocol (MI355X_MICROARCH.md, "handoff-1to1" / Guideline 16 R2: the data IS the flag):
+//   * a value travels as ONE naturally aligned 8-byte granule {f32 value, u32 tag}, written with one system-scope store (untorn);
+//     tag = the epoch of this all-reduce, so a reader polling a granule knows the value is the one it waits for — no flag, no fence;
+//   * mailboxes are double-buffered by epoch parity: a rank can be at most one all-reduce ahead of a peer (it cannot finish all-reduce
+//     k + 1 without the peer's contribution to it, which the peer sends only after it has finished reading all-reduce k);
+//   * the epoch lives in DEVICE memory and is advanced by the kernel itself (the last workgroup to finish writes it; the next launch on the
+//     stream starts after this one has ended): a hipGraph replay re-runs the same kernel nodes with frozen arguments, so nothing per-launch
+//     may come from the host;
+//   * every spin is bounded: on a time-out the kernel raises an error word and returns (the host reports it, nothing hangs).
+// The mailbox memory is allocated uncached / fine-grained and exported with hipIpcGetMemHandle; peers map it with hipIpcOpenMemHandle
+// (tp.cpp).  Two ranks on ONE GPU work the same way (that is how the tests run it on a one-GPU box).
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+// values per (parity, source) mailbox; messages up to this size are one launch, longer ones go in chunks
+static_assert(P2P_SLOT_FLOATS % 256 == 0, "slot size");
+
+__device__ __forceinline__ void st_sys(unsigned long long * p, const unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// grid: up to P2P_MAX_BLOCKS workgroups of 256 threads; thread t of block b owns values b * 256 + t, + grid * 256, ...
+__global__ void __launch_bounds__(256) k_p2p_all_reduce(const p2p_args a) {
+    const int tid = threadIdx.x;
+    __shared__ unsigned s_epoch;
+    if (tid == 0) s_epoch = a.state[0] + 1u;  // (written by the previous all-reduce launch of this stream, which has ended)
+    __syncthreads();
+    const unsigned epoch = s_epoch;
+    const unsigned par = epoch & 1u;
+    const size_t slot = (size_t) P2P_SLOT_FLOATS;
+    // ---- send: my partial into slot [par][rank] of every rank's mailbox (my own included)
+    for (int i = (int) blockIdx.x * 256 + tid; i < a.n; i += (int) gridDim.x * 256) {
+        const unsigned long long g = ((unsigned long long) epoch << 32) | (unsigned long long) __builtin_bit_cast(unsigned, a.data[i]);
+#pragma unroll 1
+        for (int p = 0; p < a.world; ++p) {
+            unsigned long long * mb = (unsigned long long *) a.mbox[p] + ((size_t) par * a.world + a.rank) * slot;
+            st_sys(mb + i, g);
+        }
+    }
+    // ---- receive: the N contributions to my values, summed in rank order.  All N granules are requested together and only the
+    // late ones again: one memory round trip when the peers are on time, not N dependent ones
+    bool failed = false;
+    for (int i = (int) blockIdx.x * 256 + tid; i < a.n; i += (int) gridDim.x * 256) {
+        const unsigned long long * mb = (const unsigned long long *) a.mbox[a.rank] + (size_t) par * a.world * slot + i;
+        unsigned long long g[P2P_MAX_RANKS];
+#pragma unroll
+        for (int s = 0; s < P2P_MAX_RANKS; ++s) g[s] = s < a.world ? ld_sys(mb + (size_t) s * slot) : ((unsigned long long) epoch << 32);
+        unsigned spins = 0;
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int s = 0; s < P2P_MAX_RANKS; ++s) all = all && (unsigned) (g[s] >> 32) == epoch;
+            if (all) break;
+            if (++spins > a.max_spins) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int s = 0; s < P2P_MAX_RANKS; ++s)
+                if (s < a.world && (unsigned) (g[s] >> 32) != epoch) g[s] = ld_sys(mb + (size_t) s * slot);
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int s = 0; s < P2P_MAX_RANKS; ++s) sum += s < a.world ? __builtin_bit_cast(float, (unsigned) g[s]) : 0.0f;
+        a.data[i] = sum;
+    }
+    if (failed) atomicAdd(a.state + 2, 1u);
+    __syncthreads();
+    if (tid == 0) {  // the last workgroup to get here publishes the epoch for the next launch
+        const unsigned done = __hip_atomic_fetch_add(a.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1u) {
+            __hip_atomic_store(a.state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.state, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+void launch_p2p_all_reduce(hipStream_t s, const p2p_args & a) {
+    const int blocks = std::max(1, std::min(P2P_MAX_BLOCKS, (a.n + 255) / 256));
+    hipLaunchKernelGGL(k_p2p_all_reduce, dim3((unsigned) blocks), dim3(256), 0, s, a);
+}
+
+}  // namespace mi355x

@@ -185,6 +185,8 @@ extern "C" int llm_preset(const char * name, struct llm_hparams * hp) {
     else if (n == "qwen2-7b-q5_k_m") set("qwen2", 28, 3584, 28, 4, 128, 18944, 152064, 32768, 1000000.0f, 1e-6f, GGML_ROPE_TYPE_NEOX, 1, LLM_FTYPE_Q5_K_M);
     else if (n == "test-llama") set("llama", 3, 256, 4, 2, 64, 512, 512, 512, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_MIXED);
     else if (n == "test-llama-tp") set("llama", 2, 512, 8, 4, 64, 1024, 512, 512, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_MIXED);
+    // four-way tensor split with head_dim 128: 8 heads on 4 KV heads (2 + 1 per rank), wo K slices of 256, ffn_down K slices of 512, 1024 vocab rows per rank
+    else if (n == "test-llama-tp4") set("llama", 2, 1024, 8, 4, 128, 2048, 4096, 512, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_MIXED);
     else if (n == "test-qwen2") set("qwen2", 2, 256, 4, 2, 64, 768, 768, 512, 1000000.0f, 1e-6f, GGML_ROPE_TYPE_NEOX, 1, LLM_FTYPE_MIXED);
     else return -1;
     return 0;

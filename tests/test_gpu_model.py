@@ -496,3 +496,7 @@ def test_bench_two_ranks_dry_run_on_one_gpu(plog):
     plog(f"[bench --gpus 2, one GPU shared] value={out['value']} tok/s ms_per_step={out['ms_per_step']} parallelism={out['config']['parallelism']} legs={out.get('tensor_split_legs')}")
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["value"] > 0
     assert "DRY RUN" in out["config"]["parallelism"]
+    # the ranks really ran tensor-split: two sums per layer and token through the one-shot peer-to-peer all-reduce (RCCL refuses a shared GPU)
+    assert out["config"]["parallelism"].startswith("tp2") and "P2P" in out["config"]["parallelism"], out["config"]["parallelism"]
+    assert out["scaling"] == "strong" and out["tp_stats"]["p2p_timeouts"] == 0 and out["tp_stats"]["allreduces"] >= 2 * 2 * 6, out["tp_stats"]
+    assert out["tensor_split_legs"]["eager_ms_per_step"] > 0
