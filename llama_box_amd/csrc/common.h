@@ -246,6 +246,9 @@ int tp_p2p_attach(backend_ctx * ctx, const void * handles, size_t size);        
 int64_t tp_p2p_timeouts(backend_ctx * ctx);
 // in-stream sum all-reduce of n floats at ptr (capturable)
 bool tp_all_reduce(backend_ctx * ctx, float * ptr, size_t n);
+// the same with the residual ADD that follows folded in: out[i] = sum_ranks(ptr[i]) + add[i] (add: n values), and the sum of squares of `out`
+// left as partial sums (ss_out, *ss_n of them) — served by ONE peer-to-peer launch; returns false (nothing done) when that form does not apply
+bool tp_all_reduce_fused(backend_ctx * ctx, float * ptr, size_t n, const float * add, float * out, double * ss_out, int * ss_n);
 void tp_free(backend_ctx * ctx);
 
 }  // namespace mi355x

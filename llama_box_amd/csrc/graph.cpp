@@ -1431,6 +1431,21 @@ static int run_node(exec_state & st, int i) {
             if (!ok_mm) return -1;
             if (rowpar) {
                 timed_scope ts(c, "tp_all_reduce", (double) ggml_abi_nbytes(n));
+                // sum over ranks -> + residual: the ADD that follows rides in the peer-to-peer launch (one decode token: its sum of squares too,
+                // for the RMS_NORM prologue that reads the residual stream next)
+                ggml_tensor * a1 = next(1);
+                const ggml_tensor * o1 = (fuse && a1 && single_use(st, n)) ? add_partner(a1, n) : nullptr;
+                if (o1 && same_shape(o1, n)) {  // (the ADD may recycle the block of either operand: every thread reads its own elements before it writes them)
+                    int ssn = 0;
+                    const bool want_ss = c->opt.ss_partials && c->ss_buf != nullptr && M == 1;
+                    if (st.ss_tensor != nullptr && ranges_overlap(a1, st.ss_tensor)) st.ss_tensor = nullptr;
+                    if (tp_all_reduce_fused(c, (float *) n->data, (size_t) ggml_abi_nelements(n), (const float *) o1->data, (float *) a1->data, want_ss ? c->ss_buf : nullptr, &ssn)) {
+                        c->st.allreduces++;
+                        c->st.fused_nodes += 1;
+                        if (want_ss) { st.ss_tensor = a1; st.ss_n = ssn; }
+                        return 2;
+                    }
+                }
                 if (!tp_all_reduce(c, (float *) n->data, (size_t) ggml_abi_nelements(n))) return -1;
                 c->st.allreduces++;
             }

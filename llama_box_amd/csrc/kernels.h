@@ -130,8 +130,14 @@ struct p2p_args {
     char * mbox[P2P_MAX_RANKS];       // every rank's mailbox as mapped HERE: [2 parities][world sources][P2P_SLOT_FLOATS] 8-byte granules
     unsigned * state;                 // device: [0] epoch of the last finished all-reduce, [1] arrivals of the running one, [2] time-outs
     unsigned max_spins;
+    // fused epilogue (one launch of n <= P2P_SLOT_FLOATS only): out[i] = sum + add[i] (the residual ADD that follows a row-parallel mat-mul:
+    // `add` rows of n values, or null) and, for ss_out != null, one partial sum of squares of `out` per workgroup (mmvq_args::ss_in's producer)
+    const float * add;
+    float * out;                      // null: in place
+    double * ss_out;
 };
 void launch_p2p_all_reduce(hipStream_t s, const p2p_args & a);
+int p2p_all_reduce_blocks(int n);  // workgroups (= ss_out partials) of a launch over n values
 bool qkv_types_supported(int type_a, int type_b);
 void launch_qkv(hipStream_t s, const qkv_args & a, int type_a, int type_b);
 

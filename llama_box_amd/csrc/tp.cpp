@@ -214,6 +214,29 @@ bool tp_all_reduce(backend_ctx * c, float * ptr, size_t n) {
     return true;
 }
 
+bool tp_all_reduce_fused(backend_ctx * c, float * ptr, size_t n, const float * add, float * out, double * ss_out, int * ss_n) {
+    if (!tp_active(c)) return false;
+    tp_state * t = c->tp;
+    if (!t->p2p || n > P2P_SLOT_FLOATS || (t->comm != nullptr && n * sizeof(float) > (size_t) t->p2p_max_cols_bytes)) return false;
+    static const unsigned max_spins = getenv("GGML_MI355X_P2P_MAX_SPINS") ? (unsigned) atoll(getenv("GGML_MI355X_P2P_MAX_SPINS")) : 4000000u;
+    p2p_args a{};
+    a.data = ptr;
+    a.n = (int) n;
+    a.rank = t->rank;
+    a.world = t->world;
+    for (int r = 0; r < t->world; ++r) a.mbox[r] = t->mbox[r];
+    a.state = t->p2p_state;
+    a.max_spins = max_spins;
+    a.add = add;
+    a.out = out;
+    a.ss_out = ss_out;
+    if (ss_n) *ss_n = p2p_all_reduce_blocks(a.n);
+    launch_p2p_all_reduce(c->stream, a);
+    c->st.kernel_launches++;
+    c->st.p2p_allreduces++;
+    return hipGetLastError() == hipSuccess;
+}
+
 void tp_free(backend_ctx * c) {
     if (!c->tp) return;
     rccl_api * api = c->tp->comm ? load_rccl() : nullptr;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "dev_util.h"
 #include "kernels.h"
 
 namespace mi355x {
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(256) k_p2p_all_reduce(const p2p_args a) {
     // ---- receive: the N contributions to my values, summed in rank order.  All N granules are requested together and only the
     // late ones again: one memory round trip when the peers are on time, not N dependent ones
     bool failed = false;
+    double ssq = 0.0;
     for (int i = (int) blockIdx.x * 256 + tid; i < a.n; i += (int) gridDim.x * 256) {
         const unsigned long long * mb = (const unsigned long long *) a.mbox[a.rank] + (size_t) par * a.world * slot + i;
         unsigned long long g[P2P_MAX_RANKS];
@@ -71,7 +73,16 @@ __global__ void __launch_bounds__(256) k_p2p_all_reduce(const p2p_args a) {
         float sum = 0.0f;
 #pragma unroll
         for (int s = 0; s < P2P_MAX_RANKS; ++s) sum += s < a.world ? __builtin_bit_cast(float, (unsigned) g[s]) : 0.0f;
-        a.data[i] = sum;
+        if (a.add) sum += a.add[i];
+        (a.out ? a.out : a.data)[i] = sum;
+        ssq += (double) (sum * sum);
+    }
+    if (a.ss_out) {  // (uniform) the row's sum of squares for the RMS_NORM prologue that reads it next: one partial per workgroup
+        __shared__ double s_ss[4];
+        ssq = wave_sum_d(ssq);
+        if ((tid & 63) == 0) s_ss[tid >> 6] = ssq;
+        __syncthreads();
+        if (tid == 0) a.ss_out[blockIdx.x] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
     }
     if (failed) atomicAdd(a.state + 2, 1u);
     __syncthreads();
@@ -84,9 +95,9 @@ __global__ void __launch_bounds__(256) k_p2p_all_reduce(const p2p_args a) {
     }
 }
 
+int p2p_all_reduce_blocks(int n) { return std::max(1, std::min(P2P_MAX_BLOCKS, (n + 255) / 256)); }
 void launch_p2p_all_reduce(hipStream_t s, const p2p_args & a) {
-    const int blocks = std::max(1, std::min(P2P_MAX_BLOCKS, (a.n + 255) / 256));
-    hipLaunchKernelGGL(k_p2p_all_reduce, dim3((unsigned) blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_p2p_all_reduce, dim3((unsigned) p2p_all_reduce_blocks(a.n)), dim3(256), 0, s, a);
 }
 
 }  // namespace mi355x

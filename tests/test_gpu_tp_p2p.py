@@ -45,6 +45,9 @@ def test_tensor_parallel_decode_over_the_p2p_all_reduce(plog, world, graphs):
         assert all(n == 2 * c["n_layer"] for n in c["per_decode_step"]), c
         assert c["allreduces"] == 2 * c["n_layer"] * 9, c
         if not graphs:
+            # the residual ADD rides in the all-reduce launch, and at one token its sum of squares goes on to the next RMS_NORM prologue:
+            # per decode step n_layer ffn norms + (n_layer - 1) attention norms of the layers behind the first
+            assert c["ss_handoffs"] >= 8 * (2 * c["n_layer"] - 1), c
             assert c["p2p_allreduces"] == c["allreduces"], c  # (launches are counted when issued; a replayed graph re-runs them uncounted)
         else:
             assert c["p2p_allreduces"] >= 2 * c["n_layer"], c

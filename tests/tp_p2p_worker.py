@@ -39,7 +39,7 @@ def main():
         hp.ftype = ftype
         m = Model(hp, 2024, be.buft, tp_rank=rank, tp_size=world, rowpar_buft=be.rowpar_buft())
         c = Context(m, backend=be, flash_attn=1)
-        a0, p0, k0, g0 = be.stat("allreduces"), be.stat("p2p_allreduces"), be.stat("kernel_launches"), be.stat("graph_launches")
+        a0, p0, k0, g0, h0 = be.stat("allreduces"), be.stat("p2p_allreduces"), be.stat("kernel_launches"), be.stat("graph_launches"), be.stat("ss_handoffs")
         rc, lg = c.decode(prompt, range(len(prompt)))
         assert rc == 0
         rows = [lg]
@@ -53,6 +53,7 @@ def main():
         local = np.concatenate(rows)  # [9 + 8, n_vocab / world]
         n_ar, n_p2p = int(be.stat("allreduces") - a0), int(be.stat("p2p_allreduces") - p0)
         replays = int(be.stat("graph_launches") - g0)
+        handoffs = int(be.stat("ss_handoffs") - h0)
         gathered = [torch.zeros(local.shape, dtype=torch.float32) for _ in range(world)]
         dist.all_gather(gathered, torch.from_numpy(np.ascontiguousarray(local)))
         c.free()
@@ -82,7 +83,7 @@ def main():
             mg.free()
             mf.free()
             out["cases"].append({"model": name, "ftype": ftype, "n_layer": int(hp.n_layer), "allreduces": n_ar, "p2p_allreduces": n_p2p, "per_decode_step": per_step,
-                                 "graph_replays": replays, "nmse_vs_oracle": float(T.nmse(full, ref)), "nmse_one_device_vs_oracle": float(T.nmse(one, ref)),
+                                 "graph_replays": replays, "ss_handoffs": handoffs, "nmse_vs_oracle": float(T.nmse(full, ref)), "nmse_one_device_vs_oracle": float(T.nmse(one, ref)),
                                  "nmse_vs_one_device": float(T.nmse(full, one)), "argmax_equal": bool(np.array_equal(np.argmax(full, 1), np.argmax(ref, 1)))})
         dist.barrier()
     out["p2p_timeouts"] = int(be.stat("p2p_timeouts"))
