@@ -211,9 +211,63 @@ static bool staged_upload(int device, char * dst, const char * src, size_t size)
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------ mask statistics (common.h)
+namespace {
+struct mask_entry { const void * dev = nullptr; mask_stats st; uint64_t stamp = 0; };
+std::mutex g_mask_mtx;
+mask_entry g_masks[8];
+uint64_t g_mask_clock = 0;
+}  // namespace
+void note_mask_upload(const ggml_tensor * t, const void * host, size_t offset, size_t size) {
+    // candidates: a whole 2-D f16 / f32 tensor of up to 256 rows whose name says mask ("KQ_mask" in llama.cpp's graphs).  Larger ones are prompt
+    // micro-batches: dense by construction, and scanning 2 MB per micro-batch would cost more than the decision is worth
+    if (offset != 0 || t->ne[2] != 1 || t->ne[3] != 1 || t->ne[1] < 2 || t->ne[1] > 256 || (t->type != GGML_TYPE_F16 && t->type != GGML_TYPE_F32)) return;
+    if (size != (size_t) t->nb[1] * (size_t) t->ne[1] || t->nb[0] != (t->type == GGML_TYPE_F16 ? 2u : 4u)) return;
+    bool named = false;
+    for (const char * p = t->name; *p && !named; ++p) named = (p[0] == 'm' || p[0] == 'M') && (p[1] == 'a' || p[1] == 'A') && (p[2] == 's' || p[2] == 'S') && (p[3] == 'k' || p[3] == 'K');
+    if (!named) return;
+    const int64_t n = t->ne[0], rows = t->ne[1];
+    mask_stats st;
+    int64_t total = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        int64_t vis = 0;
+        if (t->type == GGML_TYPE_F16) {
+            const uint16_t * m = (const uint16_t *) ((const char *) host + r * t->nb[1]);
+            for (int64_t i = 0; i < n; ++i) vis += m[i] != 0xFC00u;  // (-inf; anything else — 0 or an ALiBi slope — is a visible cell)
+        } else {
+            const uint32_t * m = (const uint32_t *) ((const char *) host + r * t->nb[1]);
+            for (int64_t i = 0; i < n; ++i) vis += m[i] != 0xFF800000u;
+        }
+        total += vis;
+        st.rows += vis > 0;
+        st.max_visible = std::max(st.max_visible, (int) vis);
+    }
+    st.density = st.rows > 0 ? (float) ((double) total / ((double) st.rows * (double) n)) : 0.0f;
+    std::lock_guard<std::mutex> lock(g_mask_mtx);
+    mask_entry * slot = &g_masks[0];
+    for (mask_entry & e : g_masks) {
+        if (e.dev == t->data) { slot = &e; break; }
+        if (e.stamp < slot->stamp) slot = &e;
+    }
+    slot->dev = t->data;
+    slot->st = st;
+    slot->stamp = ++g_mask_clock;
+}
+bool lookup_mask_stats(const void * dev_ptr, mask_stats * out) {
+    std::lock_guard<std::mutex> lock(g_mask_mtx);
+    for (const mask_entry & e : g_masks)
+        if (e.dev == dev_ptr && e.stamp != 0) { *out = e.st; return true; }
+    return false;
+}
+int mask_sparse_hint(const void * dev_ptr) {
+    mask_stats st;
+    return dev_ptr != nullptr && lookup_mask_stats(dev_ptr, &st) && st.rows > 0 && st.density <= 0.25f ? 1 : 0;
+}
+
 static void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     HIP_CHECK(hipSetDevice(c->device));
+    note_mask_upload(t, data, offset, size);
     if (size > ((size_t) 1 << 20) && staged_upload(c->device, (char *) t->data + offset, (const char *) data, size)) return;
     uploader_drain(c->device);  // (keeps the writes of one tensor ordered: a small piece behind a staged one)
     HIP_CHECK(hipMemcpy((char *) t->data + offset, data, size, hipMemcpyHostToDevice));
@@ -339,6 +393,7 @@ void flush_uploads(backend_ctx * c) {
 static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
     HIP_CHECK(hipSetDevice(c->device));
+    note_mask_upload(t, data, offset, size);
     constexpr size_t SMALL = 64 * 1024, RING = 4u << 20;
     if (size > 0 && size <= SMALL && c->opt.small_uploads) {
         if (!c->up_ring) {
@@ -583,6 +638,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "fused_nodes") return c->st.fused_nodes;
     if (k == "allreduces") return c->st.allreduces;
     if (k == "ss_handoffs") return c->st.ss_handoffs;
+    if (k == "fa_list_launches") return c->st.fa_list_launches;
     if (k == "p2p_allreduces") return c->st.p2p_allreduces;
     if (k == "p2p_timeouts") return tp_p2p_timeouts(c);
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;

@@ -111,6 +111,7 @@ struct stats {
     int64_t skinny_launches = 0;       // mat-muls of 2..32 columns served by the weight-streaming matrix-core kernel
     int64_t wide_launches = 0;         // prompt-batch mat-muls served by its wide form
     int64_t tiled_launches = 0;        // batch mat-muls served by the LDS-tiled int8 GEMM (mmq_i8.hip)
+    int64_t fa_list_launches = 0;      // FLASH_ATTN_EXT nodes served over per-token position lists (2..32 tokens; 33..256 when the mask is known to be sparse)
     int64_t rope_epilogues = 0;        // batches whose rope + KV-cache stores rode in the skinny QKV launches
     int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)
 };
@@ -236,6 +237,22 @@ void free_split_helpers(backend_ctx * c);
 bool supports_op(const ggml_tensor * op);
 enum ggml_status graph_compute(backend_ctx * ctx, ggml_cgraph * g);
 void free_graph_cache(backend_ctx * ctx);
+
+// ---- host-side shadow of what the engine uploads as attention masks (backend.cpp) ----
+// llama.cpp fills the KQ mask on the host and hands it over with set_tensor(_async) before every graph: while the bytes pass through, the
+// backend notes how many cells the batch's tokens can see.  graph_compute reads that to choose kernels whose cost depends on the mask's
+// CONTENT (position lists against the dense matrix-core kernel for 33+ tokens; the list form of the non-flash chain only when no token's
+// list exceeds its capacity) — decisions a captured graph cannot take from device memory.  Unknown mask (never uploaded through this
+// backend, or too large to be worth scanning): callers keep their shape-only rules.
+struct mask_stats {
+    int rows = 0;          // rows with at least one visible cell
+    int max_visible = 0;   // the longest row
+    float density = 1.0f;  // visible cells / (rows x row length)
+};
+void note_mask_upload(const ggml_tensor * t, const void * host, size_t offset, size_t size);
+bool lookup_mask_stats(const void * dev_ptr, mask_stats * out);
+// 1: the mask at dev_ptr is known and sparse enough (<= a quarter visible) that per-token position lists beat a dense tile kernel
+int mask_sparse_hint(const void * dev_ptr);
 
 // ---- tensor parallel (tp.cpp) ----
 int tp_init(backend_ctx * ctx, int rank, int world, const void * uid, size_t uid_size);

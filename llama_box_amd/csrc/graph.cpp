@@ -164,7 +164,8 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             if (c->opt.attn_nf) p.aux_bytes = std::max(p.aux_bytes, attn_nf_list_scratch_bytes(TD(n->src[1]), TD(n->src[0]), nullptr));
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
-            const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(q, k));
+            // (both forms a 33+-token batch may take — matrix-core tiles or, for a mask known to be sparse, position lists — fit this)
+            const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : std::max(fattn_pick_splits(q, k), 16));
             p.aux_bytes = std::max(p.aux_bytes, fattn_workspace_bytes(q, k, v, ns, n->src[1]->type));
         }
     }
@@ -1208,6 +1209,14 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
         M->ne[0] < K->ne[1] || M->ne[1] < Q->ne[1] || M->ne[2] != 1 || M->ne[3] != 1)
         return false;
     if ((size_t) (Q->ne[1] * (K->ne[1] + 1)) * sizeof(int) > c->fa_lists_bytes) return false;
+    {
+        // The list kernel serves a token's first 1024 visible cells from registers / LDS and anything beyond through scratch memory (correct,
+        // ~100 us per layer).  When the mask passed through set_tensor the LONGEST row is known exactly (common.h: mask_stats): one 20 k-cell
+        // sequence among 31 short ones keeps the batch on the dense kernels (ADVICE r02 / VERDICT r03 #7).  Unknown mask: the average rule
+        // inside attn_nf_list_scratch_bytes alone decides, as before.
+        mask_stats ms;
+        if (lookup_mask_stats(M->data, &ms) && ms.max_visible > 1024) return false;
+    }
     const tdesc qd = TD(Q), kd = TD(K), vd = TD(V), md = TD(M);
     int dq_n = 1;
     (void) attn_nf_list_scratch_bytes(qd, kd, &dq_n);
@@ -1567,7 +1576,8 @@ static int run_node(exec_state & st, int i) {
             p.max_bias = ggml_abi_op_param_f32(n, 1);
             p.logit_softcap = ggml_abi_op_param_f32(n, 2);
             const tdesc qd = TD(a), kd = TD(k), vd = TD(v);
-            p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd));
+            const tdesc md0 = m ? TD(m) : qd;
+            p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd, m ? &md0 : nullptr));
             p.kv_type = k->type;
             if (c->opt.fa_self_merge && c->fa_arrive) {
                 p.arrive = c->fa_arrive;
@@ -1585,6 +1595,7 @@ static int run_node(exec_state & st, int i) {
                         st.fa_list_tile = tile;
                     }
                     p.lists = c->fa_lists;
+                    c->st.fa_list_launches++;
                 } else if (m && a->ne[1] >= fattn_mma_min_q() && a->ne[3] == 1 && m->ne[3] == 1 && m->type == GGML_TYPE_F16 && (m->nb[1] % 8) == 0 && !(((uintptr_t) m->data) & 7) &&
                            (k->ne[1] % 4) == 0 && fattn_vis_bytes(qd, kd) <= c->fa_lists_bytes && flash_attn_mma_applies(qd, kd, &md, n->src[4] ? (const float *) n->src[4]->data : nullptr, TD(n), p)) {
                     // prompt batches on the matrix-core kernel: which (query tile, kv tile) pairs hold anything visible — once per graph run
@@ -1714,6 +1725,15 @@ static uint64_t fingerprint(const ggml_cgraph * g) {
         fnv(h, &n->data, sizeof(n->data));
         fnv(h, n->op_params, sizeof(n->op_params));
         fnv(h, &n->flags, sizeof(n->flags));
+        // kernel choices that follow the CONTENT of the attention mask (common.h: mask_stats) belong to the topology a captured graph stands for
+        if (n->op == GGML_OP_FLASH_ATTN_EXT && n->src[3]) {
+            const int hint = n->src[0]->ne[1] >= 33 ? mask_sparse_hint(n->src[3]->data) : 0;
+            fnv(h, &hint, sizeof(hint));
+        } else if (n->op == GGML_OP_SOFT_MAX && n->src[1] && n->src[0]->ne[1] >= 2 && n->src[0]->ne[1] <= 32) {
+            mask_stats ms;
+            const int hint = lookup_mask_stats(n->src[1]->data, &ms) ? (ms.max_visible > 1024 ? 2 : 1) : 0;
+            fnv(h, &hint, sizeof(hint));
+        }
         for (int s = 0; s < GGML_MAX_SRC; ++s) {
             const ggml_tensor * t = n->src[s];
             if (!t) continue;

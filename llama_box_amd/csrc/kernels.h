@@ -272,7 +272,10 @@ void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv
 size_t fattn_workspace_bytes(const tdesc & q, const tdesc & k, const tdesc & v, int n_splits, int kv_type);
 int fattn_mma_min_q();  // query tokens from which the matrix-core attention kernel takes over (env GGML_MI355X_FA_MMA_MIN_Q)
 bool flash_attn_mma_applies(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);
-int fattn_pick_splits(const tdesc & q, const tdesc & k);
+int fattn_pick_splits(const tdesc & q, const tdesc & k, const tdesc * mask = nullptr);
+// 33+ query tokens normally run on the matrix-core kernel; a batch whose mask is KNOWN to be sparse (mask_sparse_hint: draft-verification
+// batches of many sequences over a unified cache, llama-box/httpserver.hpp:4042-4069) of up to 256 tokens walks per-token position lists instead
+bool fattn_prefers_lists(const tdesc & q, const tdesc * mask);
 int fattn_fat_splits(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const fattn_params & p);  // 0 = the fat-split form does not apply
 bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);  // will this launch end in the quantising combine?
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks,

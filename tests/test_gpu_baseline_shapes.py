@@ -341,6 +341,45 @@ def test_non_flash_attention_chain(backend, H, plog, NH, NKV, n_kv, n_vis, T_):
         assert launches <= 3, launches  # list scan, the fused chain, CONT
 
 
+def test_non_flash_list_chain_gate_follows_the_longest_row(backend, H, plog):
+    """ADVICE r02 / VERDICT r03 #7: the fused K.q -> SOFT_MAX -> V^T.p launch keeps a token's first 1024 visible cells on chip and pushes longer
+    rows through scratch memory (~100 us per layer).  The host used to know only the AVERAGE row (cache cells / tokens); since round 4 the
+    backend notes every mask's longest row while the engine uploads it (set_tensor, tensor named as llama.cpp names it) — one 3000-cell
+    sequence among three short ones now stays on the dense kernels although the average (825 cells) would have passed.  Same numbers either way."""
+    NH, NKV, HD, n_kv, T_ = 32, 8, 128, 3300, 4
+    n_kv = (n_kv + 255) // 256 * 256
+    EK = NKV * HD
+    rng = np.random.default_rng(77)
+    q = rng.standard_normal((T_, NH, HD)).astype(np.float32)
+    kc = (rng.standard_normal((n_kv, EK)) * 0.5).astype(np.float16)
+    vt = (rng.standard_normal((EK, n_kv)) * 0.5).astype(np.float16)
+    mask = np.full((64, n_kv), -np.inf, np.float32)
+    mask[0, :3000] = 0
+    for t in range(1, T_):
+        mask[t, 3000 + 100 * (t - 1): 3000 + 100 * t] = 0
+
+    def build(name):
+        def b(g):
+            qq = H.ggml_permute(g.ctx, g.new(L.F32, [HD, NH, T_], q), 0, 2, 1, 3)
+            k = H.ggml_view_3d(g.ctx, g.new(L.F16, [EK, n_kv], kc), HD, n_kv, NKV, EK * 2, HD * 2, 0)
+            v = H.ggml_view_3d(g.ctx, g.new(L.F16, [n_kv, EK], vt), n_kv, HD, NKV, n_kv * 2, n_kv * 2 * HD, 0)
+            kq = H.ggml_mul_mat(g.ctx, k, qq)
+            p = H.ggml_soft_max_ext(g.ctx, kq, g.new(L.F32, [n_kv, 64], mask, name=name), 1.0 / np.sqrt(HD), 0.0)
+            kqv = H.ggml_mul_mat(g.ctx, v, p)
+            return H.ggml_cont_2d(g.ctx, H.ggml_permute(g.ctx, kqv, 0, 2, 1, 3), HD * NH, T_)
+        return b
+
+    ref = T.run_case(build("KQ_mask"), "oracle", NT)
+    res = {}
+    for name in ("inp_anon", "KQ_mask"):  # (anonymous first: a mask the backend has no statistics for is judged by the average, as before)
+        k0 = backend.stat("kernel_launches")
+        got = T.run_case(build(name), backend)
+        res[name] = (got[0], backend.stat("kernel_launches") - k0)
+        T.compare(f"non-flash chain, one long row among short ones, mask named {name}", got[0], ref[0], max_nmse=1e-9, log=plog)
+    _log(plog, f"non-flash list gate: launches with an anonymous mask {res['inp_anon'][1]} (fused over lists, long row through scratch), with llama.cpp's mask name {res['KQ_mask'][1]} (dense kernels)")
+    assert res["inp_anon"][1] <= 2 and res["KQ_mask"][1] >= 3, (res["inp_anon"][1], res["KQ_mask"][1])
+
+
 @pytest.mark.parametrize("NH,NKV,n_kv,T_,wt", [(32, 8, 7296, 32, L.Q4_K), (32, 8, 512, 16, L.Q6_K), (32, 8, 1024, 24, L.Q6_K), (28, 4, 2048, 32, L.Q5_K)])
 def test_non_flash_attention_chain_into_wo(backend, H, plog, NH, NKV, n_kv, T_, wt):
     """The -np decode step of llama-box's default (non-flash) path up to the attention output projection: K.q -> SOFT_MAX -> V^T.p -> CONT ->
@@ -646,13 +685,13 @@ def test_layer_teacher_forced_batch(backend, H, plog, li, mode, fa):
         k = H.ggml_view_3d(g.ctx, kc, HD, n_kv, NKV, EK * 2, HD * 2, 0)
         if fa:
             v = H.ggml_view_3d(g.ctx, vct, HD, n_kv, NKV, EK * 2, HD * 2, 0)
-            out = H.ggml_flash_attn_ext(g.ctx, q, k, v, g.new(L.F16, [n_kv, MP], mask16), 1.0 / np.sqrt(HD), 0.0, 0.0)
+            out = H.ggml_flash_attn_ext(g.ctx, q, k, v, g.new(L.F16, [n_kv, MP], mask16, name="KQ_mask"), 1.0 / np.sqrt(HD), 0.0, 0.0)  # (llama.cpp's name for it)
             H.ggml_flash_attn_ext_set_prec(out, 10)
             out = H.ggml_reshape_2d(g.ctx, out, HD * NH, M)
         else:
             v = H.ggml_view_3d(g.ctx, vct, n_kv, HD, NKV, n_ctx * 2, n_ctx * 2 * HD, 0)
             kq = H.ggml_mul_mat(g.ctx, k, q)
-            p = H.ggml_soft_max_ext(g.ctx, kq, g.new(L.F32, [n_kv, MP], mask16.astype(np.float32)), 1.0 / np.sqrt(HD), 0.0)
+            p = H.ggml_soft_max_ext(g.ctx, kq, g.new(L.F32, [n_kv, MP], mask16.astype(np.float32), name="KQ_mask"), 1.0 / np.sqrt(HD), 0.0)
             kqv = H.ggml_mul_mat(g.ctx, v, p)
             out = H.ggml_cont_2d(g.ctx, H.ggml_permute(g.ctx, kqv, 0, 2, 1, 3), HD * NH, M)
         return dict(outs=[out], first=[])
@@ -674,7 +713,7 @@ def test_layer_teacher_forced_batch(backend, H, plog, li, mode, fa):
         y = H.ggml_mul_mat(g.ctx, g.new(sp.t_d, [FF, E], W["wd"]), a)
         return dict(outs=[H.ggml_add(g.ctx, y, g.new(L.F32, [E, M], inp["ffn_inp"]))], first=[])
 
-    COUNTERS = ("kernel_launches", "skinny_launches", "wide_launches", "tiled_launches", "rope_epilogues")
+    COUNTERS = ("kernel_launches", "skinny_launches", "wide_launches", "tiled_launches", "rope_epilogues", "fa_list_launches")
 
     def run(seg, target, inp):
         g = T.G(target)
@@ -733,6 +772,11 @@ def test_layer_teacher_forced_batch(backend, H, plog, li, mode, fa):
     (at_o,), _ = run(seg_attn, "oracle", vals)
     (at_g,), c2 = run(seg_attn, backend, vals)
     _log(plog, f"{tag}: attention: {c2}")
+    if fa:
+        # which attention kernel: per-token position lists for up to 32 tokens and — the mask having passed through set_tensor under llama.cpp's
+        # name, so that the backend knows how little of the cache a token sees — for the draft-verification batches of 64 / 160 tokens
+        # (3 % visible here); the 512-token prompt chunk runs on the matrix-core kernel
+        assert c2["fa_list_launches"] == (1 if M <= 256 else 0), (tag, c2)
     # exact attention in float64 over each token's visible cells (q rounded to f16 as both implementations do)
     qf = np.asarray(q_o).reshape(M, NH, HD).astype(np.float16).astype(np.float64)
     kf, vf = kc_n.astype(np.float64).reshape(n_ctx, NKV, HD), vc_n.astype(np.float64).reshape(n_ctx, NKV, HD)
