@@ -65,19 +65,19 @@ ggml_backend_buffer_t make_backend_buffer(ggml_backend_buffer_type_t buft, const
 static void uploader_drain(int device);
 static void buf_free(ggml_backend_buffer_t b) {
     buffer_ctx * c = (buffer_ctx *) b->context;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);  // a staged upload may still be writing into this arena
-    HIP_CHECK(hipFree(c->base));
+    HIP_SOFT(hipFree(c->base));
     delete c;
 }
 static void * buf_get_base(ggml_backend_buffer_t b) { return ((buffer_ctx *) b->context)->base; }
 static enum ggml_status buf_init_tensor(ggml_backend_buffer_t, ggml_tensor *) { return GGML_STATUS_SUCCESS; }
 static void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t value, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);
-    HIP_CHECK(hipMemset((char *) t->data + offset, value, size));
-    HIP_CHECK(hipDeviceSynchronize());
+    HIP_SOFT(hipMemset((char *) t->data + offset, value, size));
+    HIP_SOFT(hipDeviceSynchronize());
 }
 // ---- the loader's fast path: set_tensor of a weight
 // llama.cpp's loader calls buffer.set_tensor once per tensor with pageable memory (the mmap'd GGUF, or a read buffer with --no-mmap:
@@ -166,7 +166,7 @@ static void uploader_drain(int device) {
     if (u->device != device) return;
     std::lock_guard<std::mutex> lock(u->mtx);
     if (!u->in_flight) return;
-    HIP_CHECK(hipStreamSynchronize(u->stream));
+    HIP_SOFT(hipStreamSynchronize(u->stream));
     for (bool & b : u->busy) b = false;
     u->in_flight = false;
 }
@@ -183,7 +183,7 @@ static void uploader_join(int device, hipStream_t s) {
         return;
     }
     (void) hipGetLastError();  // (hipErrorNotReady)
-    HIP_CHECK(hipStreamWaitEvent(s, u->last, 0));
+    HIP_SOFT(hipStreamWaitEvent(s, u->last, 0));
 }
 static bool staged_upload(int device, char * dst, const char * src, size_t size) {
     uploader * u = uploader_for(device);
@@ -210,6 +210,10 @@ static bool staged_upload(int device, char * dst, const char * src, size_t size)
     u->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return true;
 }
+
+static std::atomic<int> g_hip_failed{0};
+void note_hip_failure() { g_hip_failed.store(1, std::memory_order_relaxed); }
+bool hip_failed() { return g_hip_failed.load(std::memory_order_relaxed) != 0; }
 
 // ------------------------------------------------------------------------------------------------ mask statistics (common.h)
 namespace {
@@ -266,17 +270,17 @@ int mask_sparse_hint(const void * dev_ptr) {
 
 static void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     note_mask_upload(t, data, offset, size);
     if (size > ((size_t) 1 << 20) && staged_upload(c->device, (char *) t->data + offset, (const char *) data, size)) return;
     uploader_drain(c->device);  // (keeps the writes of one tensor ordered: a small piece behind a staged one)
-    HIP_CHECK(hipMemcpy((char *) t->data + offset, data, size, hipMemcpyHostToDevice));
+    HIP_SOFT(hipMemcpy((char *) t->data + offset, data, size, hipMemcpyHostToDevice));
 }
 static void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);
-    HIP_CHECK(hipMemcpy(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost));
+    HIP_SOFT(hipMemcpy(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost));
 }
 static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst) {
     ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
@@ -287,20 +291,20 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggm
     uploader_drain(sc->device);
     if (dc->device != sc->device) uploader_drain(dc->device);
     if (sc->device == dc->device) {
-        HIP_CHECK(hipSetDevice(dc->device));
-        HIP_CHECK(hipMemcpy(dst->data, src->data, n, hipMemcpyDeviceToDevice));
+        HIP_SOFT(hipSetDevice(dc->device));
+        HIP_SOFT(hipMemcpy(dst->data, src->data, n, hipMemcpyDeviceToDevice));
     } else {
-        HIP_CHECK(hipMemcpyPeer(dst->data, dc->device, src->data, sc->device, n));
+        HIP_SOFT(hipMemcpyPeer(dst->data, dc->device, src->data, sc->device, n));
     }
-    HIP_CHECK(hipDeviceSynchronize());
+    HIP_SOFT(hipDeviceSynchronize());
     return true;
 }
 static void buf_clear(ggml_backend_buffer_t b, uint8_t value) {
     buffer_ctx * c = (buffer_ctx *) b->context;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);
-    HIP_CHECK(hipMemset(c->base, value, c->size));
-    HIP_CHECK(hipDeviceSynchronize());
+    HIP_SOFT(hipMemset(c->base, value, c->size));
+    HIP_SOFT(hipDeviceSynchronize());
 }
 static const ggml_backend_buffer_i k_buffer_iface = {buf_free, buf_get_base, buf_init_tensor, buf_memset_tensor, buf_set_tensor,
                                                      buf_get_tensor, buf_cpy_tensor, buf_clear, nullptr};
@@ -317,7 +321,7 @@ struct buft_ctx {
 static const char * buft_get_name(ggml_backend_buffer_type_t buft) { return ((buft_ctx *) buft->context)->name.c_str(); }
 static ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
     buft_ctx * bc = (buft_ctx *) buft->context;
-    HIP_CHECK(hipSetDevice(bc->device));
+    HIP_SOFT(hipSetDevice(bc->device));
     void * p = nullptr;
     // (+256: the skinny Q6_K fetch reads whole 256-byte windows of 210-byte blocks — up to 46 bytes past the last block of a tensor)
     hipError_t err = hipMalloc(&p, size + 256);
@@ -333,7 +337,7 @@ static size_t buft_alignment(ggml_backend_buffer_type_t) { return 256; }
 static size_t buft_max_size(ggml_backend_buffer_type_t buft) {
     buft_ctx * bc = (buft_ctx *) buft->context;
     hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDeviceProperties(&prop, bc->device));
+    HIP_SOFT(hipGetDeviceProperties(&prop, bc->device));
     return prop.totalGlobalMem;
 }
 static size_t buft_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * t) {
@@ -344,7 +348,7 @@ static bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
 static const ggml_backend_buffer_type_i k_buft_iface = {buft_get_name, buft_alloc, buft_alignment, buft_max_size, buft_alloc_size, buft_is_host};
 
 // ---- pinned host buffer type (uploads at PCIe rate; llama.cpp asks for it via get_host_buffer_type)
-static void hbuf_free(ggml_backend_buffer_t b) { HIP_CHECK(hipHostFree(b->context)); }
+static void hbuf_free(ggml_backend_buffer_t b) { HIP_SOFT(hipHostFree(b->context)); }
 static void * hbuf_base(ggml_backend_buffer_t b) { return b->context; }
 static void hbuf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, size_t off, size_t sz) { memset((char *) t->data + off, v, sz); }
 static void hbuf_set(ggml_backend_buffer_t, ggml_tensor * t, const void * d, size_t off, size_t sz) { memcpy((char *) t->data + off, d, sz); }
@@ -368,18 +372,18 @@ static bool hbuft_is_host(ggml_backend_buffer_type_t) { return true; }
 static const char * be_get_name(ggml_backend_t be) { return ((backend_ctx *) be->context)->name.c_str(); }
 static void be_free(ggml_backend_t be) {
     backend_ctx * c = (backend_ctx *) be->context;
-    HIP_CHECK(hipSetDevice(c->device));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_SOFT(hipSetDevice(c->device));
+    HIP_SOFT(hipStreamSynchronize(c->stream));
     free_graph_cache(c);
     tp_free(c);
     free_split_helpers(c);
-    if (c->ws) HIP_CHECK(hipFree(c->ws));
-    if (c->up_ring) HIP_CHECK(hipHostFree(c->up_ring));
-    if (c->fa_lists) HIP_CHECK(hipFree(c->fa_lists));
-    if (c->rope_tab) HIP_CHECK(hipFree(c->rope_tab));
-    if (c->fa_arrive) HIP_CHECK(hipFree(c->fa_arrive));
-    if (c->ss_buf) HIP_CHECK(hipFree(c->ss_buf));
-    HIP_CHECK(hipStreamDestroy(c->stream));
+    if (c->ws) HIP_SOFT(hipFree(c->ws));
+    if (c->up_ring) HIP_SOFT(hipHostFree(c->up_ring));
+    if (c->fa_lists) HIP_SOFT(hipFree(c->fa_lists));
+    if (c->rope_tab) HIP_SOFT(hipFree(c->rope_tab));
+    if (c->fa_arrive) HIP_SOFT(hipFree(c->fa_arrive));
+    if (c->ss_buf) HIP_SOFT(hipFree(c->ss_buf));
+    HIP_SOFT(hipStreamDestroy(c->stream));
     delete c;
     delete be;
 }
@@ -392,7 +396,7 @@ void flush_uploads(backend_ctx * c) {
 }
 static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     note_mask_upload(t, data, offset, size);
     constexpr size_t SMALL = 64 * 1024, RING = 4u << 20;
     if (size > 0 && size <= SMALL && c->opt.small_uploads) {
@@ -404,7 +408,7 @@ static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void *
             size_t at = (c->up_head + 255) & ~(size_t) 255;
             if (at + size > c->up_cap) {  // wrap: everything staged so far must have been consumed
                 flush_uploads(c);
-                HIP_CHECK(hipStreamSynchronize(c->stream));
+                HIP_SOFT(hipStreamSynchronize(c->stream));
                 at = 0;
             }
             memcpy(c->up_ring + at, data, size);
@@ -416,14 +420,14 @@ static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void *
     }
     flush_uploads(c);
     uploader_join(c->device, c->stream);
-    HIP_CHECK(hipMemcpyAsync((char *) t->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
+    HIP_SOFT(hipMemcpyAsync((char *) t->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_tensor_async(ggml_backend_t be, const ggml_tensor * t, void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     flush_uploads(c);
     uploader_join(c->device, c->stream);
-    HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
+    HIP_SOFT(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
 }
 static bool be_is_ours(ggml_backend_t be);
 static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, const ggml_tensor * src, ggml_tensor * dst) {
@@ -439,28 +443,28 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
     uploader_join(cs->device, cs->stream);
     if (cd->device != cs->device) uploader_drain(cd->device);
     if (cs->device == cd->device) {
-        HIP_CHECK(hipSetDevice(cs->device));
-        HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, cs->stream));
+        HIP_SOFT(hipSetDevice(cs->device));
+        HIP_SOFT(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, cs->stream));
     } else {
-        HIP_CHECK(hipSetDevice(cs->device));
-        HIP_CHECK(hipMemcpyPeerAsync(dst->data, cd->device, src->data, cs->device, n, cs->stream));
+        HIP_SOFT(hipSetDevice(cs->device));
+        HIP_SOFT(hipMemcpyPeerAsync(dst->data, cd->device, src->data, cs->device, n, cs->stream));
     }
     if (be_src != be_dst) {  // make the destination stream wait for the copy
         hipEvent_t ev;
-        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(ev, cs->stream));
-        HIP_CHECK(hipSetDevice(cd->device));
-        HIP_CHECK(hipStreamWaitEvent(cd->stream, ev, 0));
-        HIP_CHECK(hipEventDestroy(ev));
+        HIP_SOFT(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_SOFT(hipEventRecord(ev, cs->stream));
+        HIP_SOFT(hipSetDevice(cd->device));
+        HIP_SOFT(hipStreamWaitEvent(cd->stream, ev, 0));
+        HIP_SOFT(hipEventDestroy(ev));
     }
     return true;
 }
 static void be_synchronize(ggml_backend_t be) {
     backend_ctx * c = (backend_ctx *) be->context;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     flush_uploads(c);
     uploader_drain(c->device);
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_SOFT(hipStreamSynchronize(c->stream));
 }
 static enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph * g) {
     backend_ctx * c = (backend_ctx *) be->context;
@@ -472,12 +476,12 @@ static enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph * g) {
 static void be_event_record(ggml_backend_t be, ggml_backend_event_t ev) {
     backend_ctx * c = (backend_ctx *) be->context;
     flush_uploads(c);
-    HIP_CHECK(hipEventRecord((hipEvent_t) ev->context, c->stream));
+    HIP_SOFT(hipEventRecord((hipEvent_t) ev->context, c->stream));
 }
 static void be_event_wait(ggml_backend_t be, ggml_backend_event_t ev) {
     backend_ctx * c = (backend_ctx *) be->context;
     flush_uploads(c);
-    HIP_CHECK(hipStreamWaitEvent(c->stream, (hipEvent_t) ev->context, 0));
+    HIP_SOFT(hipStreamWaitEvent(c->stream, (hipEvent_t) ev->context, 0));
 }
 static const ggml_backend_i k_backend_iface = {
     be_get_name, be_free, be_set_tensor_async, be_get_tensor_async, be_cpy_tensor_async, be_synchronize,
@@ -493,8 +497,8 @@ static bool be_is_ours(ggml_backend_t be) { return be != nullptr && be->iface.ge
 static const char * dev_get_name(ggml_backend_dev_t dev) { return dctx(dev)->name.c_str(); }
 static const char * dev_get_description(ggml_backend_dev_t dev) { return dctx(dev)->description.c_str(); }
 static void dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
-    HIP_CHECK(hipSetDevice(dctx(dev)->device));
-    HIP_CHECK(hipMemGetInfo(free, total));
+    HIP_SOFT(hipSetDevice(dctx(dev)->device));
+    HIP_SOFT(hipMemGetInfo(free, total));
 }
 static enum ggml_backend_dev_type dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
 static void dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props * props) {
@@ -506,11 +510,17 @@ static void dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props * props
 }
 static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     device_ctx * d = dctx(dev);
-    HIP_CHECK(hipSetDevice(d->device));
+    // (init_backend HAS a way to say no: NULL — ggml_backend_dev_init's callers check it)
+    if (hipSetDevice(d->device) != hipSuccess) { (void) hipGetLastError(); MI_ERR("init_backend: device %d cannot be made current", d->device); return nullptr; }
     backend_ctx * c = new backend_ctx();
     c->device = d->device;
     c->name = d->name;
-    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void) hipGetLastError();
+        MI_ERR("init_backend: no stream on device %d", d->device);
+        delete c;
+        return nullptr;
+    }
     c->fa_lists_bytes = (size_t) 8 << 20;  // visible-position lists of a small batch: (n_kv + 1) ints per query token
     if (hipMalloc((void **) &c->fa_lists, c->fa_lists_bytes) != hipSuccess) { (void) hipGetLastError(); c->fa_lists = nullptr; c->fa_lists_bytes = 0; }
     if (hipMalloc((void **) &c->rope_tab, backend_ctx::rope_tab_floats * sizeof(float)) != hipSuccess) { (void) hipGetLastError(); c->rope_tab = nullptr; }
@@ -557,16 +567,19 @@ static bool dev_offload_op(ggml_backend_dev_t, const ggml_tensor * op) {
     return batch >= 32;
 }
 static ggml_backend_event_t dev_event_new(ggml_backend_dev_t dev) {
-    HIP_CHECK(hipSetDevice(dctx(dev)->device));
+    HIP_SOFT(hipSetDevice(dctx(dev)->device));
     hipEvent_t ev;
-    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {  // (event_new may return NULL: the scheduler then runs without events)
+        (void) hipGetLastError();
+        return nullptr;
+    }
     return new ggml_backend_event{dev, ev};
 }
 static void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t ev) {
-    HIP_CHECK(hipEventDestroy((hipEvent_t) ev->context));
+    HIP_SOFT(hipEventDestroy((hipEvent_t) ev->context));
     delete ev;
 }
-static void dev_event_synchronize(ggml_backend_dev_t, ggml_backend_event_t ev) { HIP_CHECK(hipEventSynchronize((hipEvent_t) ev->context)); }
+static void dev_event_synchronize(ggml_backend_dev_t, ggml_backend_event_t ev) { HIP_SOFT(hipEventSynchronize((hipEvent_t) ev->context)); }
 static const ggml_backend_device_i k_device_iface = {
     dev_get_name, dev_get_description, dev_get_memory, dev_get_type, dev_get_props, dev_init_backend, dev_get_buffer_type,
     dev_get_host_buffer_type, /* buffer_from_host_ptr */ nullptr, dev_supports_op, dev_supports_buft, dev_offload_op,
@@ -623,7 +636,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "timing") c->opt.timing = v != 0;
     else if (k == "staged_upload") g_staged_upload.store(v != 0);
     else return -1;
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_SOFT(hipStreamSynchronize(c->stream));
     free_graph_cache(c);
     return 0;
 }
@@ -653,14 +666,14 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
 static int api_timing_report(ggml_backend_t be, char * buf, size_t size, int reset) {
     if (!be_is_ours(be) || !buf || size == 0) return -1;
     backend_ctx * c = (backend_ctx *) be->context;
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_SOFT(hipStreamSynchronize(c->stream));
     for (auto & pe : c->pending_events) {
         float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
+        HIP_SOFT(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
         c->timing[pe.first].total_ms += ms;
         c->timing[pe.first].count += 1;
-        HIP_CHECK(hipEventDestroy(pe.second.first));
-        HIP_CHECK(hipEventDestroy(pe.second.second));
+        HIP_SOFT(hipEventDestroy(pe.second.first));
+        HIP_SOFT(hipEventDestroy(pe.second.second));
     }
     c->pending_events.clear();
     std::string out;

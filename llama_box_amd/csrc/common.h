@@ -36,6 +36,21 @@
         }                                                                                                       \
     } while (0)
 
+// Entry points of the ggml interface that return no status (set_tensor, get_tensor, memset, cpy, clear, synchronize, events, free): upstream's
+// backends abort() there.  llama-box is a server: a failed copy must not take every other request down with it.  The failure is logged,
+// cleared and REMEMBERED (mi355x::hip_failed()): from then on every graph_compute of this process's backends returns GGML_STATUS_FAILED ->
+// llama_decode rc < 0 -> the engine fails the affected requests (llama-box/httpserver.hpp:3541-3545) and the operator sees the log.
+#define HIP_SOFT(expr)                                                                                          \
+    do {                                                                                                        \
+        hipError_t err_ = (expr);                                                                               \
+        if (err_ != hipSuccess) {                                                                               \
+            (void) hipGetLastError();                                                                           \
+            fprintf(stderr, "ggml-mi355x: HIP error %d (%s) at %s:%d: %s — graph_compute will report failure from here on\n", (int) err_, \
+                    hipGetErrorString(err_), __FILE__, __LINE__, #expr);                                        \
+            mi355x::note_hip_failure();                                                                         \
+        }                                                                                                       \
+    } while (0)
+
 // inside graph execution a HIP failure must fail ONE llama_decode (GGML_STATUS_FAILED -> rc -2, llama-box/httpserver.hpp:3541-3545),
 // not the whole llama-box process: log, clear the sticky error, hand `ret` to the caller
 #define HIP_TRY(expr, ret)                                                                                      \
@@ -51,6 +66,8 @@
 namespace mi355x {
 
 int log_level();
+void note_hip_failure();  // backend.cpp: a data-path HIP call failed outside graph execution (HIP_SOFT)
+bool hip_failed();
 
 // device-side layout of a Q8_K-quantised activation block (the ggml block_q8_K fields, 16-byte aligned:
 // qs | bsums | d) — produced by quantize kernels, consumed by the K-quant matvec / GEMM kernels

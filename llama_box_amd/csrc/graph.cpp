@@ -127,8 +127,8 @@ bool supports_op(const ggml_tensor * op) {
 static bool ensure_ws(backend_ctx * c, size_t need) {
     if (need <= c->ws_size) return true;
     if (c->capturing) return false;
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->ws) HIP_CHECK(hipFree(c->ws));
+    HIP_SOFT(hipStreamSynchronize(c->stream));
+    if (c->ws) HIP_SOFT(hipFree(c->ws));
     c->ws = nullptr;
     c->ws_size = 0;
     const size_t sz = (need + (size_t) (8u << 20)) & ~(size_t) 255;
@@ -182,15 +182,15 @@ struct timed_scope {
     // probe = true: the class is ONE streaming mat-vec launch whose launcher can time the kernel itself (launch_probe)
     timed_scope(backend_ctx * c_, const char * cls_, double bytes, bool probe_ = false) : c(c_), cls(cls_), probe(probe_) {
         if (!c->opt.timing || c->capturing) return;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
+        HIP_SOFT(hipEventCreate(&e0));
+        HIP_SOFT(hipEventCreate(&e1));
         if (probe) {
             g_launch_probe.e0 = e0;
             g_launch_probe.e1 = e1;
             g_launch_probe.armed = true;
             g_launch_probe.used = false;
         } else {
-            HIP_CHECK(hipEventRecord(e0, c->stream));
+            HIP_SOFT(hipEventRecord(e0, c->stream));
         }
         c->timing[cls].total_ms += 0;  // create slot
         c->timing["bytes:" + cls].total_ms += bytes;
@@ -201,12 +201,12 @@ struct timed_scope {
             const bool used = g_launch_probe.used;
             g_launch_probe = launch_probe();
             if (!used) {  // the launcher took a path without the probe: nothing was recorded
-                HIP_CHECK(hipEventDestroy(e0));
-                HIP_CHECK(hipEventDestroy(e1));
+                HIP_SOFT(hipEventDestroy(e0));
+                HIP_SOFT(hipEventDestroy(e1));
                 return;
             }
         } else {
-            HIP_CHECK(hipEventRecord(e1, c->stream));
+            HIP_SOFT(hipEventRecord(e1, c->stream));
         }
         c->pending_events.push_back({cls, {e0, e1}});
     }
@@ -1756,6 +1756,10 @@ void free_graph_cache(backend_ctx * c) {
 
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
+    if (hip_failed()) {  // a set_tensor / get_tensor / copy / synchronize of this process failed earlier (HIP_SOFT): the inputs of this graph cannot be trusted
+        MI_ERR("graph_compute: refused — an earlier HIP call of the data path failed (see the log above)");
+        return GGML_STATUS_FAILED;
+    }
     const ws_plan wp = plan_ws(c, g);
     if (!ensure_ws(c, wp.act_bytes + wp.aux_bytes + 256)) return GGML_STATUS_ALLOC_FAILED;
     c->tick++;

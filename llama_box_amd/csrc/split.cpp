@@ -73,8 +73,8 @@ static void sbuf_free(ggml_backend_buffer_t b) {
     for (auto & kv : c->tensors)
         for (int d = 0; d < kv.second.n_dev; ++d)
             if (kv.second.slice[d]) {
-                HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
-                HIP_CHECK(hipFree(kv.second.slice[d]));
+                HIP_SOFT(hipSetDevice(logical_device_ordinal(d)));
+                HIP_SOFT(hipFree(kv.second.slice[d]));
             }
     delete c;
 }
@@ -89,8 +89,8 @@ static enum ggml_status sbuf_init_tensor(ggml_backend_buffer_t b, ggml_tensor * 
     if (old != c->tensors.end()) {  // re-initialised (a host may call init_tensor again after a reset): the previous slices go first
         for (int d = 0; d < old->second.n_dev; ++d)
             if (old->second.slice[d]) {
-                HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
-                HIP_CHECK(hipFree(old->second.slice[d]));
+                HIP_SOFT(hipSetDevice(logical_device_ordinal(d)));
+                HIP_SOFT(hipFree(old->second.slice[d]));
             }
         c->tensors.erase(old);
     }
@@ -109,7 +109,7 @@ static enum ggml_status sbuf_init_tensor(ggml_backend_buffer_t b, ggml_tensor * 
         info.slice_row_bytes[d] = by_k ? (size_t) (part / blck) * ggml_abi_type_size(t->type) : info.row_bytes;
         if (part <= 0) continue;
         const size_t bytes = by_k ? (size_t) t->ne[1] * info.slice_row_bytes[d] : (size_t) part * info.row_bytes;
-        HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+        HIP_SOFT(hipSetDevice(logical_device_ordinal(d)));
         if (hipMalloc(&info.slice[d], bytes + 256) != hipSuccess) {
             (void) hipGetLastError();
             MI_ERR("split buffer: allocating %.1f MiB of '%s' on device %d failed", bytes / 1048576.0, t->name, d);
@@ -135,11 +135,11 @@ static void sbuf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void
     for (int d = 0; d < info->n_dev; ++d) {
         const int64_t rows = info->row0[d + 1] - info->row0[d];
         if (rows <= 0) continue;
-        HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+        HIP_SOFT(hipSetDevice(logical_device_ordinal(d)));
         if (info->kind == 1)  // device d's K range of every row
-            HIP_CHECK(hipMemcpy2D(info->slice[d], info->slice_row_bytes[d], (const char *) data + (size_t) info->row0[d] / blck * ts, info->row_bytes, info->slice_row_bytes[d], (size_t) t->ne[1], hipMemcpyHostToDevice));
+            HIP_SOFT(hipMemcpy2D(info->slice[d], info->slice_row_bytes[d], (const char *) data + (size_t) info->row0[d] / blck * ts, info->row_bytes, info->slice_row_bytes[d], (size_t) t->ne[1], hipMemcpyHostToDevice));
         else
-            HIP_CHECK(hipMemcpy(info->slice[d], (const char *) data + (size_t) info->row0[d] * info->row_bytes, (size_t) rows * info->row_bytes, hipMemcpyHostToDevice));
+            HIP_SOFT(hipMemcpy(info->slice[d], (const char *) data + (size_t) info->row0[d] * info->row_bytes, (size_t) rows * info->row_bytes, hipMemcpyHostToDevice));
     }
 }
 static void sbuf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t offset, size_t size) {
@@ -152,11 +152,11 @@ static void sbuf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void
     for (int d = 0; d < info->n_dev; ++d) {
         const int64_t rows = info->row0[d + 1] - info->row0[d];
         if (rows <= 0) continue;
-        HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
+        HIP_SOFT(hipSetDevice(logical_device_ordinal(d)));
         if (info->kind == 1)
-            HIP_CHECK(hipMemcpy2D((char *) data + (size_t) info->row0[d] / blck * ts, info->row_bytes, info->slice[d], info->slice_row_bytes[d], info->slice_row_bytes[d], (size_t) t->ne[1], hipMemcpyDeviceToHost));
+            HIP_SOFT(hipMemcpy2D((char *) data + (size_t) info->row0[d] / blck * ts, info->row_bytes, info->slice[d], info->slice_row_bytes[d], info->slice_row_bytes[d], (size_t) t->ne[1], hipMemcpyDeviceToHost));
         else
-            HIP_CHECK(hipMemcpy((char *) data + (size_t) info->row0[d] * info->row_bytes, info->slice[d], (size_t) rows * info->row_bytes, hipMemcpyDeviceToHost));
+            HIP_SOFT(hipMemcpy((char *) data + (size_t) info->row0[d] * info->row_bytes, info->slice[d], (size_t) rows * info->row_bytes, hipMemcpyDeviceToHost));
     }
 }
 static void sbuf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t value, size_t offset, size_t size) {
@@ -165,8 +165,8 @@ static void sbuf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t
     for (int d = 0; d < info->n_dev; ++d) {
         const int64_t rows = info->row0[d + 1] - info->row0[d];
         if (rows <= 0) continue;
-        HIP_CHECK(hipSetDevice(logical_device_ordinal(d)));
-        HIP_CHECK(hipMemset(info->slice[d], value, info->kind == 1 ? (size_t) t->ne[1] * info->slice_row_bytes[d] : (size_t) rows * info->row_bytes));
+        HIP_SOFT(hipSetDevice(logical_device_ordinal(d)));
+        HIP_SOFT(hipMemset(info->slice[d], value, info->kind == 1 ? (size_t) t->ne[1] * info->slice_row_bytes[d] : (size_t) rows * info->row_bytes));
     }
 }
 static void sbuf_clear(ggml_backend_buffer_t, uint8_t) {}  // (slices are written whole by set_tensor; nothing to clear before that)
@@ -277,17 +277,17 @@ struct main_device_guard {
 void free_split_helpers(backend_ctx * c) {
     for (split_helper * h : c->split_helpers) {
         if (!h) continue;
-        HIP_CHECK(hipSetDevice(h->ordinal));
-        HIP_CHECK(hipStreamSynchronize(h->stream));
-        if (h->ws) HIP_CHECK(hipFree(h->ws));
-        HIP_CHECK(hipEventDestroy(h->ev));
-        HIP_CHECK(hipStreamDestroy(h->stream));
+        HIP_SOFT(hipSetDevice(h->ordinal));
+        HIP_SOFT(hipStreamSynchronize(h->stream));
+        if (h->ws) HIP_SOFT(hipFree(h->ws));
+        HIP_SOFT(hipEventDestroy(h->ev));
+        HIP_SOFT(hipStreamDestroy(h->stream));
         delete h;
     }
     c->split_helpers.clear();
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_SOFT(hipSetDevice(c->device));
     if (c->split_ready) {
-        HIP_CHECK(hipEventDestroy(c->split_ready));
+        HIP_SOFT(hipEventDestroy(c->split_ready));
         c->split_ready = nullptr;
     }
 }

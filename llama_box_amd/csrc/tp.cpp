@@ -85,7 +85,7 @@ int tp_init(backend_ctx * c, int rank, int world, const void * uid, size_t uid_s
     tp_state * t = c->tp ? c->tp : new tp_state();  // (a peer-to-peer group may already be attached)
     t->rank = rank;
     t->world = world;
-    HIP_CHECK(hipSetDevice(c->device));
+    HIP_TRY(hipSetDevice(c->device), -2);
     ncclResult_t r = api->CommInitRank(&t->comm, world, id, rank);
     if (r != ncclSuccess) {
         MI_ERR("ncclCommInitRank failed: %s", api->GetErrorString ? api->GetErrorString(r) : "?");
