@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--np", type=int, default=1, help="parallel sequences decoded per step (llama-box -np continuous batching)")
     ap.add_argument("--draft", type=int, default=0, help="speculative decoding: every step is one llama_decode over np x (1 + draft) tokens with logits at every position, then the "
                                                           "drafts are dropped from the cache (worst case of the verification; llama-box httpserver.hpp:4042-4069, :4696-4768)")
+    ap.add_argument("--emulate-tp", type=int, default=0, dest="emulate_tp", help="ONE GPU: build and time rank 0's shard of an N-way tensor split WITHOUT any collective (the row-parallel "
+                                                                                   "sums are simply not taken): the per-rank compute time of a --tensor-split run, for the time budget of DESIGN.md §6; not a throughput")
     ap.add_argument("--ubatch", type=int, default=512)
     ap.add_argument("--n-batch", type=int, default=2048, dest="n_batch", help="prompt tokens per llama_decode call (llama-box -b); several slots' prompts share a call")
     ap.add_argument("--ctkv", default="f16", choices=["f16", "q8_0"], help="KV cache type (llama-box --cache-type-k / --cache-type-v); the headline metric is quoted on f16")
@@ -214,6 +216,10 @@ def main():
             parallelism = f"tp{world} (row/column tensor-split, {how}, x{2 * hp.n_layer}/token)"
         else:
             parallelism = f"replicas x{world} (tensor-split set-up failed on some rank{': ' + err if err else ''})"
+    emulated = world == 1 and args.emulate_tp > 1
+    if emulated:
+        tp_size, tp_rank = args.emulate_tp, 0
+        parallelism = f"rank 0's shard of a tp{tp_size} split ALONE on one GPU, no collectives (per-rank compute time only)"
     t_load = time.time()
     model = Model(hp, 0x5EED, be.buft, tp_rank=tp_rank, tp_size=tp_size, rowpar_buft=be.rowpar_buft() if tp_size > 1 else None)
     t_load = time.time() - t_load
@@ -230,6 +236,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if dist is not None:
+        dist.barrier()  # every rank has its model: the first cross-rank sum is not met by a rank that is still uploading weights
     # ---- prefill (reported beside the headline; v1 path = column chunks of the bandwidth kernel)
     pos = 0
     prefill_tok_s = None
@@ -297,9 +305,9 @@ def main():
         st = 1 if tp_size > 1 or world == 1 else world
         draft_note = f" with {args.draft} drafts per sequence (speculative-decoding batch shape, M = {args.np * T1})" if args.draft else ""
         return {
-            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M" if args.preset == "llama3-8b-q4_k_m" and args.np == 1 and args.draft == 0 else
+            "metric": "decode tokens/sec (batch-1) + prefill tok/s, Llama-3-8B Q4_K_M" if args.preset == "llama3-8b-q4_k_m" and args.np == 1 and args.draft == 0 and not emulated else
                       f"decode tokens/sec ({'batch-1' if args.np == 1 else f'-np {args.np} aggregate'}" + (f", {T1} positions per sequence and step verified: 1 sampled + {args.draft} drafts, all rejected" if args.draft else "")
-                      + f") + prefill tok/s, {args.preset} [secondary configuration, not the headline metric]",
+                      + f") + prefill tok/s, {args.preset} [secondary configuration, not the headline metric]" + (" [ONE RANK'S SHARE OF A TENSOR SPLIT, NO COLLECTIVES: a time budget input, not a throughput]" if emulated else ""),
             "value": round(st * args.np * T1 * args.steps / el, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if tp_size > 1 else "weak", "vs_baseline": None,
@@ -310,7 +318,7 @@ def main():
         }
 
     tp_legs = None
-    two_legs = tp_size > 1 or os.environ.get("BENCH_FORCE_TWO_LEGS") == "1"  # (the variable: exercise this branch on one GPU)
+    two_legs = (tp_size > 1 and not emulated) or os.environ.get("BENCH_FORCE_TWO_LEGS") == "1"  # (the variable: exercise this branch on one GPU)
     if two_legs:
         # Tensor split: the K steps are timed twice — eager launches first (the form that needs nothing of RCCL but stream order), then the
         # same steps captured and replayed as hipGraphs with the all-reduces inside (never yet run on multi-GPU hardware).  The faster leg
@@ -318,6 +326,20 @@ def main():
         import threading
         be.set_option("graphs", 0)
         el_eager, _, _ = leg()
+        if tp_size > 1:
+            tmo = torch.tensor([int(be.stat("p2p_timeouts"))], dtype=torch.int64)
+            dist.all_reduce(tmo, op=dist.ReduceOp.MAX)
+            if int(tmo[0]) > 0:
+                # the one-shot all-reduce timed out somewhere (never seen on the boxes of the build; its spins are bounded so that this can be
+                # reported instead of hanging): its sums are garbage -> with a communicator, switch it off everywhere and time the leg again
+                if rccl_ok:
+                    be.set_option("tp_p2p", 0)
+                    parallelism += " [peer-to-peer all-reduce timed out: RCCL only]"
+                    el_eager, _, _ = leg()
+                else:
+                    if rank == 0:
+                        print("bench.py: the peer-to-peer all-reduce timed out and there is no RCCL communicator to fall back to", file=sys.stderr)
+                    sys.exit(4)
         deadline = max(60.0, 30.0 * el_eager * (1.0 + args.warmup / max(1, args.steps)))
 
         def give_up():
@@ -382,7 +404,7 @@ def main():
     # are worth as N data-parallel engines is the other half of the picture.  Informational: `value` stays the tensor-split number.
     w_bytes = model.stream_bytes()
     replicas = None
-    if (tp_size > 1 and args.replica_leg) or (world > 1 and args.replica_leg == 2):  # (2: exercise the leg in the single-GPU dry run)
+    if (tp_size > 1 and not emulated and args.replica_leg) or (world > 1 and args.replica_leg == 2):  # (2: exercise the leg in the single-GPU dry run)
         try:
             ctx.free(); model.free()
             ctx = model = None
@@ -479,7 +501,7 @@ def main():
             "prefill_roofline": prefill_roofline,
             "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),
             "replicas_on_the_same_gpus": replicas,
-            "tp_stats": {"allreduces": int(be.stat("allreduces")), "p2p_launches_issued": int(be.stat("p2p_allreduces")), "p2p_timeouts": int(be.stat("p2p_timeouts"))} if tp_size > 1 else None,
+            "tp_stats": {"allreduces": int(be.stat("allreduces")), "p2p_launches_issued": int(be.stat("p2p_allreduces")), "p2p_timeouts": int(be.stat("p2p_timeouts"))} if tp_size > 1 and not emulated else None,
             "graph_replayed_steps": int(graph_steps), "hipGraphLaunch_host_us": round(graph_launch_host_us, 1),
             "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -630,6 +630,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "attn_nf") c->opt.attn_nf = v != 0;
     else if (k == "fa_self_merge") c->opt.fa_self_merge = v != 0;
     else if (k == "ss_partials") c->opt.ss_partials = v != 0;
+    else if (k == "tp_p2p") tp_p2p_enable(c, v != 0);
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "fa_wo") c->opt.fa_wo = v != 0;
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;

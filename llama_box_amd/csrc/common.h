@@ -278,6 +278,7 @@ bool tp_active(const backend_ctx * ctx);
 int tp_p2p_export(backend_ctx * ctx, int rank, int world, void * handle_out, size_t size);  // -> this rank's mailbox as a hipIpcMemHandle_t (64 bytes)
 int tp_p2p_attach(backend_ctx * ctx, const void * handles, size_t size);                    // world handles in rank order, own slot ignored
 int64_t tp_p2p_timeouts(backend_ctx * ctx);
+void tp_p2p_enable(backend_ctx * ctx, bool on);
 // in-stream sum all-reduce of n floats at ptr (capturable)
 bool tp_all_reduce(backend_ctx * ctx, float * ptr, size_t n);
 // the same with the residual ADD that follows folded in: out[i] = sum_ranks(ptr[i]) + add[i] (add: n values), and the sum of squares of `out`

@@ -46,14 +46,30 @@ template <typename T> __device__ __forceinline__ void qkv_dot(const qkv_regs<T> 
     }
 }
 // all trips of one unit; trip 0 is already in `r`
-template <typename T> __device__ __forceinline__ void qkv_unit(qkv_regs<T> & r, const uint8_t * row0, const uint8_t * row1, const int lane, const int nblk,
-                                                               const typename T::act * __restrict__ y, float & acc0, float & acc1) {
+template <typename T, bool PIPE> __device__ __forceinline__ void qkv_unit(qkv_regs<T> & r, const uint8_t * row0, const uint8_t * row1, const int lane, const int nblk,
+                                                                          const typename T::act * __restrict__ y, float & acc0, float & acc1) {
     const int npairs = nblk * T::PPB;
     constexpr int per_chunk = 64 * qkv_u<T>::U;
     const int nch = (npairs + per_chunk - 1) / per_chunk;
-    for (int c = 0; c < nch; ++c) {
-        if (c > 0) qkv_load<T>(row0, row1, c, lane, npairs, r);
+    // K > 4096: the unit has several trips.  The next trip's weights are requested BEFORE the current one is multiplied (a second register set,
+    // statically named: no copy, so hipcc keeps them in flight) — a trip used to be requested only after the previous one's dot products, one
+    // dependent memory round trip per 4096 values of K (Llama-3-70B: K = 8192; a tensor-split rank's fused QKV launch 14-15 us for 5.9 MB)
+    if constexpr (!PIPE) {
+        for (int c = 0; c < nch; ++c) {
+            if (c > 0) qkv_load<T>(row0, row1, c, lane, npairs, r);
+            qkv_dot<T>(r, c, lane, npairs, y, nblk, acc0, acc1);
+        }
+        return;
+    }
+    // (PIPE: the K > 4096 instantiation, 8 waves per workgroup so that the second register set fits without scratch)
+    qkv_regs<T> r2;
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) qkv_load<T>(row0, row1, c + 1, lane, npairs, r2);
         qkv_dot<T>(r, c, lane, npairs, y, nblk, acc0, acc1);
+        if (c + 1 < nch) {
+            if (c + 2 < nch) qkv_load<T>(row0, row1, c + 2, lane, npairs, r);
+            qkv_dot<T>(r2, c + 1, lane, npairs, y, nblk, acc0, acc1);
+        }
     }
 }
 
@@ -63,13 +79,13 @@ template <typename T> __device__ __forceinline__ void qkv_unit(qkv_regs<T> & r, 
 // the two, not the sum — holding both register sets in one code path spilled weight registers to scratch memory.
 // Q8S: the launch stores into a block_q8_0 KV cache (a separate instantiation: the block assembly costs registers the default
 // f16-cache kernel does not have to spare)
-template <typename TA, typename TB, bool Q8S>
-__global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
+template <typename TA, typename TB, bool Q8S, bool PIPE = false>
+__global__ void __launch_bounds__(PIPE ? 512 : 1024) k_qkv_stream2(const qkv_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (a generic lambda, not a device function: passing the kernel-argument struct to a function copies it to scratch)
     auto body = [&](auto tag, const int alt, const int wg, const int nwg) {
     using T = decltype(tag);
-    constexpr int MAXW = 16, QB = 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
+    constexpr int MAXW = 16, QB = PIPE ? 4 : 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
     const int WAVES = (int) blockDim.x >> 6;  // 8..16 waves: the launcher sizes the workgroup so that units/WAVES ~ 256 workgroups
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform, and the compiler must know it: the unit a wave works on — its segment descriptor, row numbers, pointers — then lives
@@ -192,7 +208,7 @@ __global__ void __launch_bounds__(1024) k_qkv_stream2(const qkv_args a) {
         {
             const uint8_t * row0 = sg.W + (size_t) r0 * sg.w_nb1;
             const uint8_t * row1 = sg.W + (size_t) r1 * sg.w_nb1;
-            qkv_unit<T>(ra, row0, row1, lane, nblk, yl, acc0, acc1);
+            qkv_unit<T, PIPE>(ra, row0, row1, lane, nblk, yl, acc0, acc1);
         }
         float v0 = wave_sum(acc0), v1 = wave_sum(acc1);
         if (lane == 0) {
@@ -285,17 +301,25 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     // 12 waves x 256 workgroups; with fixed 16-wave workgroups a quarter of the CUs had nothing to do); the norm prologue
     // needs the whole activation row in one batch of 2 blocks per wave
     static const int force_nw = getenv("GGML_MI355X_QKV_WAVES") ? atoi(getenv("GGML_MI355X_QKV_WAVES")) : 0;
-    int nw = std::min(16, std::max((nblk + 1) / 2, 8));
+    // K > 4096 (a unit has several trips) on an f16 cache: the pipelined instantiation — the next trip in flight under the current one's dot
+    // products, four activation blocks per wave in the prologue, 8 waves (256 registers each: the Q5_K / Q6_K register sets spill at 12)
+    static const bool pipe_on = !getenv("GGML_MI355X_QKV_PIPE") || atoi(getenv("GGML_MI355X_QKV_PIPE")) != 0;
+    // ... where 16-wave workgroups would leave half the chip without one (a tensor-split rank's 640 row pairs: 40 workgroups -> 80; measured
+    // 13.9 -> 11.9 and 15.8 -> 12.9 us per launch, profiles/r04_ab_qkv_pipe.txt); the unsharded 70B launch (5120 row pairs) measures the same either way
+    const bool pipe = pipe_on && nblk > 16 && nblk <= 32 && !q8_store && type_a != GGML_TYPE_Q8_0 && (units[0] + units[1] + 15) / 16 < 128;
+    int nw = pipe ? 8 : std::min(16, std::max((nblk + 1) / 2, 8));
+    const int nw_cap = pipe ? 8 : 16;
     // smallest workgroup that still gives every wave one unit — counted over both formats together: two formats at 12 waves need 257
     // workgroups for Llama-3-8B (the 256 are then shared by bytes, a few waves take two units), which measures 12.5 us against 13.2 us for
     // 13-wave workgroups that fit (profiles/r03_decode_lab.txt #6)
-    while (nw < 16 && (units[0] + units[1] + nw - 1) / nw > 256) ++nw;
+    while (nw < nw_cap && (units[0] + units[1] + nw - 1) / nw > 256) ++nw;
     if (force_nw) nw = force_nw;
     if (q8_store) nw = 16;  // a workgroup trip = 16 row pairs = one block_q8_0 of the cache row (caller checked the alignment)
     const dim3 block((unsigned) nw * 64);
 #define QKV_LAUNCH(TA, TB, GRID)                                                                              \
     do {                                                                                                      \
         if (q8_store) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, true>), GRID, block, lds, s, a);              \
+        else if (pipe) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false, true>), GRID, block, lds, s, a);      \
         else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                      \
     } while (0)
     if (type_a == type_b || units[1] == 0) {

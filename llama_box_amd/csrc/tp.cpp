@@ -175,6 +175,10 @@ int tp_p2p_attach(backend_ctx * c, const void * handles, size_t size) {
             t->comm ? ", RCCL for longer messages" : ", no RCCL communicator");
     return 0;
 }
+// set_option("tp_p2p", 0 / 1): stop / resume serving sums through the mailboxes (a launcher that saw time-outs falls back to RCCL)
+void tp_p2p_enable(backend_ctx * c, bool on) {
+    if (c->tp && c->tp->mbox_local && c->tp->mbox[c->tp->rank]) c->tp->p2p = on;
+}
 int64_t tp_p2p_timeouts(backend_ctx * c) {
     if (!c->tp || !c->tp->p2p_state) return 0;
     unsigned st[3] = {0, 0, 0};
@@ -189,7 +193,7 @@ bool tp_all_reduce(backend_ctx * c, float * ptr, size_t n) {
     tp_state * t = c->tp;
     if (t->p2p && (t->comm == nullptr || n * sizeof(float) <= (size_t) t->p2p_max_cols_bytes)) {
         // one launch per mailbox-full (decode: ONE launch; a prompt batch without RCCL goes through in chunks)
-        static const unsigned max_spins = getenv("GGML_MI355X_P2P_MAX_SPINS") ? (unsigned) atoll(getenv("GGML_MI355X_P2P_MAX_SPINS")) : 4000000u;  // ~ seconds
+        static const unsigned max_spins = getenv("GGML_MI355X_P2P_MAX_SPINS") ? (unsigned) atoll(getenv("GGML_MI355X_P2P_MAX_SPINS")) : 2000000u;  // seconds of polling before the group is declared broken (ranks enter their first all-reduce after a barrier of the launcher)
         for (size_t o = 0; o < n; o += P2P_SLOT_FLOATS) {
             p2p_args a{};
             a.data = ptr + o;
@@ -218,7 +222,7 @@ bool tp_all_reduce_fused(backend_ctx * c, float * ptr, size_t n, const float * a
     if (!tp_active(c)) return false;
     tp_state * t = c->tp;
     if (!t->p2p || n > P2P_SLOT_FLOATS || (t->comm != nullptr && n * sizeof(float) > (size_t) t->p2p_max_cols_bytes)) return false;
-    static const unsigned max_spins = getenv("GGML_MI355X_P2P_MAX_SPINS") ? (unsigned) atoll(getenv("GGML_MI355X_P2P_MAX_SPINS")) : 4000000u;
+    static const unsigned max_spins = getenv("GGML_MI355X_P2P_MAX_SPINS") ? (unsigned) atoll(getenv("GGML_MI355X_P2P_MAX_SPINS")) : 2000000u;
     p2p_args a{};
     a.data = ptr;
     a.n = (int) n;

@@ -35,9 +35,14 @@ __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long * 
 __global__ void __launch_bounds__(256) k_p2p_all_reduce(const p2p_args a) {
     const int tid = threadIdx.x;
     __shared__ unsigned s_epoch;
-    if (tid == 0) s_epoch = a.state[0] + 1u;  // (written by the previous all-reduce launch of this stream, which has ended)
+    __shared__ unsigned s_dead;
+    if (tid == 0) {
+        s_epoch = a.state[0] + 1u;  // (written by the previous all-reduce launch of this stream, which has ended)
+        s_dead = a.state[2];        // an earlier all-reduce of this group timed out: the group is broken, nobody waits any more (the host
+    }                               // reads the word — stat "p2p_timeouts" — and falls back; waiting again would cost seconds per launch)
     __syncthreads();
     const unsigned epoch = s_epoch;
+    const unsigned max_spins = s_dead ? 0u : a.max_spins;
     const unsigned par = epoch & 1u;
     const size_t slot = (size_t) P2P_SLOT_FLOATS;
     // ---- send: my partial into slot [par][rank] of every rank's mailbox (my own included)
@@ -64,7 +69,7 @@ __global__ void __launch_bounds__(256) k_p2p_all_reduce(const p2p_args a) {
 #pragma unroll
             for (int s = 0; s < P2P_MAX_RANKS; ++s) all = all && (unsigned) (g[s] >> 32) == epoch;
             if (all) break;
-            if (++spins > a.max_spins) { failed = true; break; }
+            if (++spins > max_spins) { failed = true; break; }
             __builtin_amdgcn_s_sleep(1);
 #pragma unroll
             for (int s = 0; s < P2P_MAX_RANKS; ++s)

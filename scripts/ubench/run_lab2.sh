@@ -19,6 +19,10 @@ for d in ${RINGS:-}; do
   /opt/rocm/bin/hipcc $F -fvisibility=hidden -DRING_D=$d -c scripts/ubench/experiments/mmvq_ring.hip -o /tmp/mmvq_ring_$d.o
   run "RING_D=$d" /tmp/mmvq_ring_$d.o
 done
+for q in ${PRIOS:-}; do
+  /opt/rocm/bin/hipcc $F -fvisibility=hidden -DLAB_PRIO=$q -c scripts/ubench/experiments/mmvq_prio.hip -o /tmp/mmvq_prio_$q.o
+  run "LAB_PRIO=$q" /tmp/mmvq_prio_$q.o
+done
 for k in ${KOS:-}; do
   /opt/rocm/bin/hipcc $F -fvisibility=hidden -DKO=$k ${KO_DEFS:-} -c scripts/ubench/experiments/mmvq_ko.hip -o /tmp/mmvq_ko_$k.o
   run "KO=$k ${KO_DEFS:-}" /tmp/mmvq_ko_$k.o

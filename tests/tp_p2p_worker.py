@@ -39,6 +39,7 @@ def main():
         hp.ftype = ftype
         m = Model(hp, 2024, be.buft, tp_rank=rank, tp_size=world, rowpar_buft=be.rowpar_buft())
         c = Context(m, backend=be, flash_attn=1)
+        dist.barrier()  # (every rank has its shard: nobody's first sum waits for a peer that is still loading)
         a0, p0, k0, g0, h0 = be.stat("allreduces"), be.stat("p2p_allreduces"), be.stat("kernel_launches"), be.stat("graph_launches"), be.stat("ss_handoffs")
         rc, lg = c.decode(prompt, range(len(prompt)))
         assert rc == 0
