@@ -225,11 +225,18 @@ uint64_t g_mask_clock = 0;
 void note_mask_upload(const ggml_tensor * t, const void * host, size_t offset, size_t size) {
     // candidates: a whole 2-D f16 / f32 tensor of up to 256 rows whose name says mask ("KQ_mask" in llama.cpp's graphs).  Larger ones are prompt
     // micro-batches: dense by construction, and scanning 2 MB per micro-batch would cost more than the decision is worth
-    if (offset != 0 || t->ne[2] != 1 || t->ne[3] != 1 || t->ne[1] < 2 || t->ne[1] > 256 || (t->type != GGML_TYPE_F16 && t->type != GGML_TYPE_F32)) return;
-    if (size != (size_t) t->nb[1] * (size_t) t->ne[1] || t->nb[0] != (t->type == GGML_TYPE_F16 ? 2u : 4u)) return;
+    // anything else written to a tensor on record makes the record stale (a partial update, another tensor recycling the address)
+    auto forget = [&]() {
+        std::lock_guard<std::mutex> lock(g_mask_mtx);
+        for (mask_entry & e : g_masks)
+            if (e.dev == t->data) { e.dev = nullptr; e.stamp = 0; }
+    };
     bool named = false;
     for (const char * p = t->name; *p && !named; ++p) named = (p[0] == 'm' || p[0] == 'M') && (p[1] == 'a' || p[1] == 'A') && (p[2] == 's' || p[2] == 'S') && (p[3] == 'k' || p[3] == 'K');
-    if (!named) return;
+    const bool whole = offset == 0 && t->ne[2] == 1 && t->ne[3] == 1 && (t->type == GGML_TYPE_F16 || t->type == GGML_TYPE_F32) && size == (size_t) t->nb[1] * (size_t) t->ne[1] &&
+                       t->nb[0] == (t->type == GGML_TYPE_F16 ? 2u : 4u);
+    // (2 MiB: a 160-token draft batch over a 6 k-cell cache; beyond that the scan itself would show in the step — such a mask is judged by shape)
+    if (!named || !whole || t->ne[1] < 2 || t->ne[1] > 256 || size > ((size_t) 2 << 20)) { forget(); return; }
     const int64_t n = t->ne[0], rows = t->ne[1];
     mask_stats st;
     int64_t total = 0;
