@@ -210,6 +210,30 @@ def main():
             except Exception as e:
                 rccl_ok, err = False, f"comm init: {e}"
         rccl_ok = agree(rccl_ok)
+        def group_check(tag):
+            """Every rank sums a known vector through the backend's own collective (the path graph_compute takes) and compares: a group that
+            cannot add is switched off here, before any number depends on it."""
+            ok = True
+            try:
+                for n in (4096, 8192 * 8 + 256):  # one launch of the one-shot kernel / past its message limit (RCCL or chunks)
+                    x = torch.full((n,), float(rank + 1), dtype=torch.float32, device=f"cuda:{local_rank}")
+                    x[::7] += 0.5 * rank
+                    dist.barrier()
+                    be.tp_all_reduce(x.data_ptr(), n)
+                    be.synchronize()
+                    want = torch.full((n,), world * (world + 1) / 2.0, dtype=torch.float32)
+                    want[::7] += 0.5 * world * (world - 1) / 2.0
+                    ok = ok and bool(torch.equal(x.cpu(), want)) and int(be.stat("p2p_timeouts")) == 0
+            except Exception as e:
+                ok = False
+                print(f"bench.py: rank {rank}: {tag} group check raised {e}", file=sys.stderr)
+            return agree(ok)
+
+        if p2p_ok and not group_check("peer-to-peer"):
+            # (the mailboxes are there but do not add up on this node: leave them alone; RCCL alone carries the sums if it is there)
+            be.set_option("tp_p2p", 0)
+            p2p_ok = False
+            err = "the peer-to-peer all-reduce failed its self-check"
         if p2p_ok or rccl_ok:
             tp_size, tp_rank = world, rank
             how = "one-shot P2P all-reduce over IPC-mapped mailboxes" + (" + RCCL for messages > 256 KiB" if rccl_ok else " (no RCCL communicator)") if p2p_ok else "RCCL all-reduce"

@@ -53,6 +53,7 @@ ggml_backend_reg_t ggml_backend_mi355x_reg(void);
  *   "ggml_backend_mi355x_tp_get_unique_id" ggml_backend_mi355x_tp_get_unique_id_t
  *   "ggml_backend_mi355x_tp_p2p_export"   ggml_backend_mi355x_tp_p2p_export_t
  *   "ggml_backend_mi355x_tp_p2p_attach"   ggml_backend_mi355x_tp_p2p_attach_t
+ *   "ggml_backend_mi355x_tp_all_reduce"   ggml_backend_mi355x_tp_all_reduce_t
  */
 
 /* Replaces: ggml_backend_cuda_split_buffer_type(int main_device, const float * tensor_split) of the stock GPU backends, as reached
@@ -75,6 +76,10 @@ typedef int (*ggml_backend_mi355x_tp_init_t)(ggml_backend_t backend, int rank, i
  * else they go through the mailboxes in chunks.  Works without RCCL, and with several ranks on one GPU.  Return 0 on success. */
 typedef int (*ggml_backend_mi355x_tp_p2p_export_t)(ggml_backend_t backend, int rank, int world_size, void * handle_out, size_t handle_size);
 typedef int (*ggml_backend_mi355x_tp_p2p_attach_t)(ggml_backend_t backend, const void * handles, size_t handles_size);
+/* The collective itself, for a launcher that wants to check its group before trusting it: in-place sum over the ranks of n f32 values at
+ * device_ptr, enqueued in the backend's stream (ggml_backend_synchronize to wait) — exactly what graph_compute issues behind a row-parallel
+ * mat-mul.  0 on success. */
+typedef int (*ggml_backend_mi355x_tp_all_reduce_t)(ggml_backend_t backend, float * device_ptr, size_t n);
 typedef int (*ggml_backend_mi355x_tp_get_unique_id_t)(void * unique_id_out, size_t unique_id_size);
 typedef ggml_backend_buffer_type_t (*ggml_backend_mi355x_tp_rowpar_buffer_type_t)(int device);
 

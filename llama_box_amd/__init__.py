@@ -262,6 +262,13 @@ class Backend:
         if rc != 0:
             raise RuntimeError(f"ggml-mi355x: tp_p2p_attach failed ({rc})")
 
+    def tp_all_reduce(self, device_ptr, n):
+        """In-place sum over the ranks of n f32 values at device_ptr, in the backend's stream (synchronize() to wait)."""
+        fn = self.proc("ggml_backend_mi355x_tp_all_reduce", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t])
+        rc = fn(self.backend, C.c_void_p(device_ptr), n)
+        if rc != 0:
+            raise RuntimeError(f"ggml-mi355x: tp_all_reduce failed ({rc})")
+
     def synchronize(self):
         host().ggml_backend_synchronize(self.backend)
 

@@ -606,6 +606,15 @@ static int api_tp_p2p_export(ggml_backend_t be, int rank, int world, void * hand
     if (!be_is_ours(be)) return -1;
     return tp_p2p_export((backend_ctx *) be->context, rank, world, handle_out, n);
 }
+// in-place sum over the ranks of n f32 values in device memory, in the backend's stream (what graph_compute issues behind a row-parallel mat-mul);
+// exported so that a launcher can check its group before it trusts it
+static int api_tp_all_reduce(ggml_backend_t be, float * device_ptr, size_t n) {
+    if (!be_is_ours(be)) return -1;
+    backend_ctx * c = (backend_ctx *) be->context;
+    if (!tp_active(c)) return -2;
+    HIP_TRY(hipSetDevice(c->device), -3);
+    return tp_all_reduce(c, device_ptr, n) ? 0 : -4;
+}
 static int api_tp_p2p_attach(ggml_backend_t be, const void * handles, size_t n) {
     if (!be_is_ours(be)) return -1;
     return tp_p2p_attach((backend_ctx *) be->context, handles, n);
@@ -708,6 +717,7 @@ static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (n == "ggml_backend_mi355x_tp_get_unique_id") return (void *) api_tp_get_unique_id;
     if (n == "ggml_backend_mi355x_tp_p2p_export") return (void *) api_tp_p2p_export;
     if (n == "ggml_backend_mi355x_tp_p2p_attach") return (void *) api_tp_p2p_attach;
+    if (n == "ggml_backend_mi355x_tp_all_reduce") return (void *) api_tp_all_reduce;
     if (n == "ggml_backend_mi355x_tp_rowpar_buffer_type") return (void *) api_tp_rowpar_buft;
     if (n == "ggml_backend_mi355x_set_option") return (void *) api_set_option;
     if (n == "ggml_backend_mi355x_get_stat") return (void *) api_get_stat;
