@@ -95,12 +95,38 @@ __device__ __forceinline__ float eat_item(const item & it, const q8k_dev * y, co
 }
 
 // one phase for this workgroup.  `first` was requested by the caller (before the barrier in the persistent variant).
-template <bool COHERENT>
-__device__ __forceinline__ void run_phase(const phase & ph, const float * x, const float * nw, float * out, char * smem, item first) {
+// GRAN (round 4, VERDICT r02 / r03 "(d)"): no barrier at all between the phases.  A wave's result leaves as ONE naturally aligned 8-byte granule
+// {value, tag = index of the phase that reads it} written with an agent-scope (sc1, write-through) store; the next phase's prologue polls the
+// granules of its 256-value chunk (4 per lane, all requested together, only the late ones again) — Guideline 16 R2, "the data IS the flag".  The
+// vectors are double-buffered by phase parity (a workgroup cannot publish phase k + 2 before it has gathered every workgroup's phase k + 1, and
+// those were published after their owners had finished reading phase k).  gin: granules this phase reads (tag `tag`), gout: those it writes (tag + 1).
+#ifndef GRAN_SLEEP
+#define GRAN_SLEEP 1
+#endif
+__device__ __forceinline__ unsigned long long ld_gran(const unsigned long long * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool COHERENT, bool GRAN = false>
+__device__ __forceinline__ void run_phase(const phase & ph, const float * x, const float * nw, float * out, char * smem, item first,
+                                          const unsigned long long * gin = nullptr, unsigned long long * gout = nullptr, const unsigned tag = 0, unsigned * fail = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- prologue: RMS_NORM * w -> Q8_K (K = 4096: one 256-value chunk per wave)
     float4 v, g;
-    if (COHERENT) {  // written by other workgroups of THIS launch: L2-coherent loads (the acquire fence of the barrier invalidated L1)
+    if (GRAN) {
+        const unsigned long long * gp = gin + (size_t) (wave * 64 + lane) * 4;
+        unsigned long long q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = ld_gran(gp + i);
+        for (int spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ok = ok && (unsigned) (q[i] >> 32) == tag;
+            if (__all(ok)) break;
+            if (spins > 4000000) { if (fail) *fail = 7; break; }
+            __builtin_amdgcn_s_sleep(GRAN_SLEEP);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if ((unsigned) (q[i] >> 32) != tag) q[i] = ld_gran(gp + i);
+        }
+        v = make_float4(__builtin_bit_cast(float, (unsigned) q[0]), __builtin_bit_cast(float, (unsigned) q[1]), __builtin_bit_cast(float, (unsigned) q[2]), __builtin_bit_cast(float, (unsigned) q[3]));
+    } else if (COHERENT) {  // written by other workgroups of THIS launch: L2-coherent loads (the acquire fence of the barrier invalidated L1)
         v = ((const float4 *) x)[wave * 64 + lane];
     } else v = ((const float4 *) x)[wave * 64 + lane];
     g = ((const float4 *) nw)[wave * 64 + lane];
@@ -132,7 +158,10 @@ __device__ __forceinline__ void run_phase(const phase & ph, const float * x, con
     }
     const float r = wave_sum(acc);
     __syncthreads();  // (LDS activations are rewritten by the next phase)
-    if (lane == 0) out[blockIdx.x * 16 + wave] = r * 1e-6f + (float) (blockIdx.x & 3);
+    const float res = r * 1e-6f + (float) (blockIdx.x & 3);
+    if (GRAN) {
+        if (lane == 0) __hip_atomic_store(gout + blockIdx.x * 16 + wave, ((unsigned long long) (tag + 1) << 32) | __builtin_bit_cast(unsigned, res), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (lane == 0) out[blockIdx.x * 16 + wave] = res;
 }
 
 __global__ void __launch_bounds__(1024) k_phase(const phase ph, const float * x, const float * nw, float * out) {
@@ -166,6 +195,15 @@ template <int MODE> __global__ void __launch_bounds__(1024) k_persist(const prog
     for (int l = 0; l < n_layers; ++l) {
         for (int p = 0; p < 5; ++p, ++k) {
             const phase ph = progs[l].ph[p];
+            if (MODE == 5) {
+                // granule vectors live behind the two activation buffers' first 32 KB each (4096 x 8 bytes), zeroed by the memset node: tag 0 = phase 0's input
+                unsigned long long * ga = (unsigned long long *) (xa + 16384), * gb = (unsigned long long *) (xb + 16384);
+                run_phase<true, true>(ph, nullptr, nw, nullptr, smem, first, (k & 1) ? gb : ga, (k & 1) ? ga : gb, (unsigned) k, &sa->fail);
+                const bool last5 = l == n_layers - 1 && p == 4;
+                const phase nx5 = last5 ? ph : (p < 4 ? progs[l].ph[p + 1] : progs[l + 1].ph[0]);
+                if (!last5) load_item(nx5.W, nx5.n16, my, first);  // the next phase's weights are requested before its prologue polls for its activations
+                continue;
+            }
             run_phase<true>(ph, (k & 1) ? xb : xa, nw, (k & 1) ? xa : xb, smem, first);
             // request the next phase's first item, THEN arrive: the weights stream while the barrier and the next prologue run
             const bool last = l == n_layers - 1 && p == 4;
@@ -191,7 +229,7 @@ int main() {
     for (int l = 0; l < LAYERS; ++l) for (int p = 0; p < 5; ++p) { hp[l].ph[p].W = W + off; off += hp[l].ph[p].n16; }
     (void) unit;
     prog * dp; CK(hipMalloc(&dp, sizeof(prog) * LAYERS)); CK(hipMemcpy(dp, hp.data(), sizeof(prog) * LAYERS, hipMemcpyHostToDevice));
-    float *xa, *xb, *nw; CK(hipMalloc(&xa, 65536)); CK(hipMalloc(&xb, 65536)); CK(hipMalloc(&nw, 65536));
+    float *xa, *xb, *nw; CK(hipMalloc(&xa, 65536 + 32768)); CK(hipMalloc(&xb, 65536 + 32768)); CK(hipMalloc(&nw, 65536));
     std::vector<float> h(16384);
     for (int i = 0; i < 16384; ++i) h[i] = (float) ((i * 7919) % 1000) / 500.0f - 1.0f;
     CK(hipMemcpy(xa, h.data(), 65536, hipMemcpyHostToDevice)); CK(hipMemcpy(xb, h.data(), 65536, hipMemcpyHostToDevice)); CK(hipMemcpy(nw, h.data(), 65536, hipMemcpyHostToDevice));
@@ -217,11 +255,13 @@ int main() {
         const double us = time_graph(ge, 10);
         printf("L  five launches per layer        : %7.2f us/layer  (%.1f MB/layer -> %.2f TB/s)\n", us / LAYERS, layer_bytes / 1048576.0, layer_bytes * LAYERS / us / 1e6);
     }
-    for (int mode = 0; mode < 5; ++mode) {
+    for (int mode = 0; mode < 6; ++mode) {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
         CK(hipMemsetAsync(sa, 0, sizeof(sync_area), s));
-        if (mode == 0) hipLaunchKernelGGL(k_persist<0>, dim3(256), dim3(1024), lds, s, dp, LAYERS, xa, xb, nw, sa, wt);
+        if (mode == 5) { CK(hipMemsetAsync(xa + 16384, 0, 32768, s)); CK(hipMemsetAsync(xb + 16384, 0, 32768, s)); }
+        if (mode == 5) hipLaunchKernelGGL(k_persist<5>, dim3(256), dim3(1024), lds, s, dp, LAYERS, xa, xb, nw, sa, wt);
+        else if (mode == 0) hipLaunchKernelGGL(k_persist<0>, dim3(256), dim3(1024), lds, s, dp, LAYERS, xa, xb, nw, sa, wt);
         else if (mode == 1) hipLaunchKernelGGL(k_persist<1>, dim3(256), dim3(1024), lds, s, dp, LAYERS, xa, xb, nw, sa, wt);
         else if (mode == 2) hipLaunchKernelGGL(k_persist<2>, dim3(256), dim3(1024), lds, s, dp, LAYERS, xa, xb, nw, sa, wt);
         else if (mode == 3) hipLaunchKernelGGL(k_persist<3>, dim3(256), dim3(1024), lds, s, dp, LAYERS, xa, xb, nw, sa, wt);
@@ -232,7 +272,7 @@ int main() {
         std::vector<unsigned long long> hw(256); CK(hipMemcpy(hw.data(), wt, 256 * 8, hipMemcpyDeviceToHost));
         std::sort(hw.begin(), hw.end());
         printf("P%d persistent, %s barrier : %7.2f us/layer  (%.2f TB/s); time in barrier per phase: min %.2f median %.2f max %.2f us; fail=%u xcd populations %u %u %u %u %u %u %u %u\n", mode,
-               mode == 1 ? "XCD-hierarchical" : mode == 0 ? "flat counter    " : mode == 2 ? "flat, NO fences " : mode == 3 ? "NO barrier      " : "flat, no prefetch", us / LAYERS, layer_bytes * LAYERS / us / 1e6, hw[0] / 100.0 / (5 * LAYERS - 1), hw[128] / 100.0 / (5 * LAYERS - 1),
+               mode == 1 ? "XCD-hierarchical" : mode == 0 ? "flat counter    " : mode == 2 ? "flat, NO fences " : mode == 3 ? "NO barrier      " : mode == 5 ? "GRANULE hand-off (no barrier)" : "flat, no prefetch", us / LAYERS, layer_bytes * LAYERS / us / 1e6, hw[0] / 100.0 / (5 * LAYERS - 1), hw[128] / 100.0 / (5 * LAYERS - 1),
                hw[255] / 100.0 / (5 * LAYERS - 1), hs.fail, hs.pop[0], hs.pop[1], hs.pop[2], hs.pop[3], hs.pop[4], hs.pop[5], hs.pop[6], hs.pop[7]);
     }
     return 0;
