@@ -416,4 +416,6 @@ bool launch_attn_nf_list(hipStream_t s, const tdesc & q, const tdesc & k, const 
     return false;
 }
 
+MI_TU_TOUCH(attn_nf)
+
 }  // namespace mi355x

@@ -528,6 +528,17 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
         delete c;
         return nullptr;
     }
+    {   // every kernel file's code object onto this device now, not in front of the first prompt (kernels.h: MI_TU_TOUCH)
+        static const bool preload = !getenv("GGML_MI355X_PRELOAD") || atoi(getenv("GGML_MI355X_PRELOAD")) != 0;
+        static std::mutex pre_mtx;
+        static bool preloaded[64] = {false};
+        std::lock_guard<std::mutex> lk(pre_mtx);
+        if (preload && d->device >= 0 && d->device < 64 && !preloaded[d->device]) {
+            preload_kernel_files(c->stream);
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { (void) hipGetLastError(); MI_ERR("init_backend: kernel preload failed on device %d", d->device); }
+            preloaded[d->device] = true;
+        }
+    }
     c->fa_lists_bytes = (size_t) 8 << 20;  // visible-position lists of a small batch: (n_kv + 1) ints per query token
     if (hipMalloc((void **) &c->fa_lists, c->fa_lists_bytes) != hipSuccess) { (void) hipGetLastError(); c->fa_lists = nullptr; c->fa_lists_bytes = 0; }
     if (hipMalloc((void **) &c->rope_tab, backend_ctx::rope_tab_floats * sizeof(float)) != hipSuccess) { (void) hipGetLastError(); c->rope_tab = nullptr; }

@@ -1148,4 +1148,6 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     abort();
 }
 
+MI_TU_TOUCH(fattn)
+
 }  // namespace mi355x

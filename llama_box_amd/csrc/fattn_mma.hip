@@ -304,4 +304,6 @@ bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, cons
     return true;
 }
 
+MI_TU_TOUCH(fattn_mma)
+
 }  // namespace mi355x

@@ -756,4 +756,6 @@ void launch_mul_mat_f(hipStream_t s, const tdesc & a, const tdesc & b, const tde
     else hipLaunchKernelGGL(k_mul_mat_f<false>, grid, dim3(256), 0, s, a, b, d, lpr, vec_ok ? 1 : 0);
 }
 
+MI_TU_TOUCH(mmf)
+
 }  // namespace mi355x

@@ -374,4 +374,6 @@ void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K
     if (a.ksplit > 1) launch_splitk_reduce(s, part, a.ksplit, M, N, dst, dst_stride, nullptr, 0);
 }
 
+MI_TU_TOUCH(mmq)
+
 }  // namespace mi355x

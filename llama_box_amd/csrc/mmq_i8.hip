@@ -617,4 +617,6 @@ int launch_mmq_i8(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int
     return launch_mmq_i8_multi(s, type, 1, &m, K, M, act_q8k, force_bn, ksplit, part, reduce, skinny, epi);
 }
 
+MI_TU_TOUCH(mmq_i8)
+
 }  // namespace mi355x

@@ -170,4 +170,6 @@ void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int 
     hipLaunchKernelGGL(k_mmq_q80, dim3(grid), dim3(512), lds, s, a);
 }
 
+MI_TU_TOUCH(mmq_q80)
+
 }  // namespace mi355x

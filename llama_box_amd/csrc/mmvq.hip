@@ -559,4 +559,6 @@ void launch_mmvq(hipStream_t s, const mmvq_args & a, int rows_per_wave) {
     }
 }
 
+MI_TU_TOUCH(mmvq)
+
 }  // namespace mi355x

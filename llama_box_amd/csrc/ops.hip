@@ -806,4 +806,6 @@ void launch_upload_multi(hipStream_t s, const upload_batch & b) {
     hipLaunchKernelGGL(k_upload_multi, dim3(gx, (unsigned) b.n), dim3(256), 0, s, b);
 }
 
+MI_TU_TOUCH(ops)
+
 }  // namespace mi355x

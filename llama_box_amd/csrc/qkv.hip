@@ -346,4 +346,6 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     else { MI_ERR("launch_qkv: unsupported weight format pair %d/%d", type_a, type_b); abort(); }
 }
 
+MI_TU_TOUCH(qkv)
+
 }  // namespace mi355x

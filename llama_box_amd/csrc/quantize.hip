@@ -172,4 +172,6 @@ void launch_quantize_act(hipStream_t s, int kind, const tdesc & src, void * dst)
     }
 }
 
+MI_TU_TOUCH(quantize)
+
 }  // namespace mi355x

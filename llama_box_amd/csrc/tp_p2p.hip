@@ -105,4 +105,6 @@ void launch_p2p_all_reduce(hipStream_t s, const p2p_args & a) {
     hipLaunchKernelGGL(k_p2p_all_reduce, dim3((unsigned) p2p_all_reduce_blocks(a.n)), dim3(256), 0, s, a);
 }
 
+MI_TU_TOUCH(tp_p2p)
+
 }  // namespace mi355x

@@ -742,8 +742,11 @@ static int skinny_n_cu();
 //   (in-order vmcnt).  Items (128-row group, token tile group) of one weight group run on the same XCD at the same time: its L2
 //   serves the weight bytes to all of them.
 constexpr int WD_NB = 2;  // stages of the activation ring (3 = requested two steps ahead, like the weights: measured equal, A/B on one box)
-template <int QT, int TT, int NW> constexpr int wd_lds_bytes() { return WD_NB * TT * (SK_B_BYTES + 128) + NW * 3 * tp_a_stage<QT>(); }
+template <int QT, int TT, int NW, int NA = 3, int KH = 1> constexpr int wd_lds_bytes() { return WD_NB * KH * TT * (SK_B_BYTES + 128) + NW * KH * NA * tp_a_stage<QT>(); }
 constexpr int WD_NL = 2;  // loader waves per workgroup
+// timing-only knock-outs (GGML_MI355X_MMQ_WIDE_KO; results are wrong): 1 = the loaders request nothing after the prologue, 2 = the computing
+// waves only meet the barriers.  Which side of the workgroup bounds a step?
+__device__ int g_wd_ko = 0;
 
 // NW computing waves (one 32-row tile each) + WD_NL loader waves.  In-kernel timestamps of the first version, where every wave
 // requested its own operands: per step and wave 1 050 clocks issuing 9 LDS-DMA instructions (each waits for room in the CU's one
@@ -754,34 +757,50 @@ constexpr int WD_NL = 2;  // loader waves per workgroup
 // SIMD: 512 registers each, accumulators in AGPRs, room for 4 token tiles per converted weight unit).  Measured (A/B, 2048-token
 // prefill): 23.2 k tok/s against 31.6 k for 4 + 2 waves x 2 tiles — the requests' issue stalls sit in the computing waves' own
 // instruction streams again.  Kept behind GGML_MI355X_MMQ_WIDE_SELF=1 (correct: the wide tests pass with it).
-template <int QT, int TT, int NW, int NL>
-__global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args a) {
+// NA = stages of a weight ring.  NA = 2 (weights requested ONE step ahead, like the activations) brings the workgroup to 76 KB of LDS, so
+// that TWO workgroups share a CU (12 waves, 168 registers each): the second one runs while the first waits at its barrier, for an LDS
+// read or for the matrix pipe — the latency hiding a single computing wave per SIMD does not have (round 4).
+// KH = 2 (round 4): TWO computing waves per row tile and SIMD — wave (tile, kh) takes super-blocks 2 s + kh of step s, so a step is two
+// super-blocks and a SIMD always has one wave converting / folding (VALU) while the other multiplies (matrix pipe); PMC of the KH = 1 form:
+// its single computing wave per SIMD is busy 85 % of the time with VALU and MFMA one after the other.  Both waves of a pair hold f32 tiles; at the
+// end of an item the kh = 1 wave hands its tile over through the activation stage that was just consumed (two more barriers per item) and the
+// kh = 0 wave adds and stores: sum over even super-blocks + sum over odd ones.  (Two workgroups per CU do not do this: a workgroup of 5 or 6 waves
+// at 168 registers is never co-resident with a second one — scripts/ubench/occupancy_probe.hip — and without loader waves, 4 + 4 co-resident
+// waves run at 25 k tok/s against 30.5 k.)
+template <int QT, int TT, int NW, int NL, int NA, int KH>
+__global__ void __launch_bounds__((NW * KH + NL) * 64, (NA == 2 || KH == 2) ? 3 : 1) k_mmq_wide(const mmq8_args a) {
     constexpr bool SELF = NL == 0;
-    constexpr int NLD = SELF ? NW : NL;  // waves that request
+    constexpr int NCW = NW * KH;           // computing waves
+    constexpr int NLD = SELF ? NCW : NL;   // waves that request
+    static_assert(KH == 1 || (KH == 2 && NL > 0), "the K-paired form has loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef sk_fmt<QT> F;
     constexpr int NP = QT == 4 ? 2 : 3;
     constexpr uint32_t DM = QT == 4 ? 0x07070707u : 0x03030303u;
     constexpr int DS = QT == 4 ? 3 : 2;
     constexpr int NPA = 32 * F::PIECES, NLA = (NPA + 63) / 64;
-    constexpr int NPB = TT * 32 * 19 / NLD, NLB = (NPB + 63) / 64;  // activation pieces per loader and step, and the instructions fetching them
-    constexpr int TPL = NW / NLD;                                    // weight tiles per loader
-    constexpr int DCNT = (TT + NLD - 1) / NLD;                       // scale requests per loader and step
-    constexpr int B_STAGE = TT * SK_B_BYTES, A_STAGE = tp_a_stage<QT>();
-    static_assert(NW % NLD == 0 && (TT * 32 * 19) % NLD == 0, "loader roles");
+    constexpr int NPB = KH * TT * 32 * 19 / NLD, NLB = (NPB + 63) / 64;  // activation pieces per loader and step, and the instructions fetching them
+    constexpr int TPL = NCW / NLD;                                        // weight units per loader
+    constexpr int DCNT = (KH * TT + NLD - 1) / NLD;                       // scale requests per loader and step
+    constexpr int B_STAGE = KH * TT * SK_B_BYTES, A_STAGE = tp_a_stage<QT>();  // an activation stage: [kh][token tile][token]
+    constexpr int D_STAGE = KH * TT * 128;
+    static_assert(NCW % NLD == 0 && (KH * TT * 32 * 19) % NLD == 0, "loader roles");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = !SELF && wave >= NW;
-    const int ld = SELF ? wave : wave - NW;  // loader index
+    const int ko = __builtin_amdgcn_readfirstlane(g_wd_ko);
+    const bool loader = !SELF && wave >= NCW;
+    const int ld = SELF ? wave : wave - NCW;  // loader index
+    const int tile = wave % NW, kh = KH == 1 ? 0 : (wave / NW) & 1;  // (computing waves)
     const int row = lane & 31, g = lane >> 5;
     const int nblk = a.K / 256;
+    const int nsteps = nblk / KH;  // steps of an item
     const int w_nb1 = (int) a.mat[0].w_nb1;
     const int tok_bytes = nblk * (int) sizeof(q8k_dev);
     const uint32_t lds0 = (uint32_t) (uintptr_t) smem;
-    // LDS: [activation ring 2 x TT x 9728][scale ring 2 x TT x 128][weight rings: tile x 3 x stage]
-    const uint32_t b_ring = lds0, d_ring = lds0 + WD_NB * B_STAGE, a_rings = d_ring + WD_NB * TT * 128;
-    const char * const b_ring_p = smem;
+    // LDS: [activation ring 2 x KH x TT x 9728][scale ring 2 x KH x TT x 128][weight rings: computing wave x NA x stage]
+    const uint32_t b_ring = lds0, d_ring = lds0 + WD_NB * B_STAGE, a_rings = d_ring + WD_NB * D_STAGE;
+    char * const b_ring_p = smem;
     const char * const d_ring_p = smem + WD_NB * B_STAGE;
-    const char * const a_ring_p = smem + WD_NB * B_STAGE + WD_NB * TT * 128 + (loader ? 0 : wave) * 3 * A_STAGE;
+    const char * const a_ring_p = smem + WD_NB * B_STAGE + WD_NB * D_STAGE + (loader ? 0 : wave) * NA * A_STAGE;
 
     // loader fetch roles (offsets from the unit's first byte)
     int a_off[NLA];
@@ -794,7 +813,8 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
 #pragma unroll
     for (int u = 0; u < NLB; ++u) {
         const int pi = max(ld, 0) * NPB + min(lane + 64 * u, NPB - 1);
-        b_off[u] = (pi / 19) * tok_bytes + (pi % 19) * 16;
+        const int q = pi / 19;  // [kh][token of the TT tiles]
+        b_off[u] = (q % (TT * 32)) * tok_bytes + (q / (TT * 32)) * (int) sizeof(q8k_dev) + (pi % 19) * 16;
     }
     const int d_off = row * tok_bytes + 304;  // q8k_dev::d of token `row` of a token tile
     constexpr int n_ops_a = TPL * NLA;        // a loader's weight requests of one step
@@ -819,18 +839,18 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
         return n_virtual;
     };
     int total = 0;  // steps of this workgroup (the same number in every wave: one barrier each)
-    for (int v = next_valid(blockIdx.x); v < n_virtual; v = next_valid(v + gridDim.x)) total += nblk;
+    for (int v = next_valid(blockIdx.x); v < n_virtual; v = next_valid(v + gridDim.x)) total += nsteps;
 
     auto issue_a = [&](const int v, const int sb, const int slot) {
         int gr, mt;
         decode(v, gr, mt);
         const int mi = MAT_OF(gr);
-        const uint8_t * wg = MAT_SEL(mi, W) + (size_t) (gr - MAT_SEL(mi, panel0)) * (32 * NW) * (size_t) w_nb1 + (size_t) sb * F::BYTES;
+        const uint8_t * wg = MAT_SEL(mi, W) + (size_t) (gr - MAT_SEL(mi, panel0)) * (32 * NW) * (size_t) w_nb1 + (size_t) sb * KH * F::BYTES;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
-            const int t = ld * TPL + k;
-            const uint8_t * wb = wg + (size_t) t * 32 * (size_t) w_nb1;
-            const uint32_t al = a_rings + (t * 3 + slot) * A_STAGE;
+            const int t = ld * TPL + k;  // computing wave (tile t % NW, K half t / NW)
+            const uint8_t * wb = wg + (size_t) (t % NW) * 32 * (size_t) w_nb1 + (t / NW) * F::BYTES;
+            const uint32_t al = a_rings + (t * NA + slot) * A_STAGE;
 #pragma unroll
             for (int u = 0; u < NLA; ++u)
                 if (u + 1 < NLA || (NPA % 64) == 0 || lane < (NPA % 64)) tp_dma16(wb + a_off[u], al + u * 1024);
@@ -839,7 +859,7 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
     auto issue_b = [&](const int v, const int sb, const int slot) {
         int gr, mt;
         decode(v, gr, mt);
-        const char * ab = (const char *) a.act + (size_t) mt * (32 * TT) * (size_t) tok_bytes + (size_t) sb * sizeof(q8k_dev);
+        const char * ab = (const char *) a.act + (size_t) mt * (32 * TT) * (size_t) tok_bytes + (size_t) sb * KH * sizeof(q8k_dev);
         const uint32_t bl = b_ring + slot * B_STAGE + ld * NPB * 16;
 #pragma unroll
         for (int u = 0; u < NLB; ++u)
@@ -848,8 +868,8 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
         // no tile of its own), so that the wait counts are the same compile-time constants for all
 #pragma unroll
         for (int t = 0; t < DCNT; ++t) {
-            const int tt = min(ld + t * NLD, TT - 1);
-            if (lane < 32) tp_dma4(ab + (size_t) tt * 32 * (size_t) tok_bytes + d_off, d_ring + slot * TT * 128 + tt * 128);
+            const int tt = min(ld + t * NLD, KH * TT - 1);  // [kh][token tile]
+            if (lane < 32) tp_dma4(ab + (size_t) (tt % TT) * 32 * (size_t) tok_bytes + (tt / TT) * sizeof(q8k_dev) + d_off, d_ring + slot * D_STAGE + tt * 128);
         }
     };
 
@@ -863,45 +883,53 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
     int va = next_valid(blockIdx.x), sa = 0, na = 0;  // next weight step to request (virtual item, super-block, running step number)
     int vb = va, sbb = 0, nb = 0;
     int vc = va, sc_ = 0;                             // the step being multiplied (computing waves)
-#define WD_ADV(v, sb) { if (++(sb) == nblk) { (sb) = 0; (v) = next_valid((v) + gridDim.x); } }
+#define WD_ADV(v, sb) { if (++(sb) == nsteps) { (sb) = 0; (v) = next_valid((v) + gridDim.x); } }
     if (loader || SELF) {
-        if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+        if (va < n_virtual) { issue_a(va, sa, na % NA); ++na; WD_ADV(va, sa) }
         if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
-        if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+        if (NA == 3 && va < n_virtual) { issue_a(va, sa, na % NA); ++na; WD_ADV(va, sa) }
         if (WD_NB == 3 && vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
     }
     const int16s zeroi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float16s zerof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (!SELF) {
         // the loaders' loop, apart from the computing waves' (one barrier per step in both): its address registers are not live in the
-        // multiply loop and the operands are not live here (239 -> 183 registers for Q4_K)
+        // multiply loop and the operands are not live here
         if (loader) {
             for (int s = 0; s < total; ++s) {
                 // this loader's pieces of step s (weights requested two steps ago, activations one) have landed; only its weight requests of
                 // step s + 1 may still fly
                 // (WD_NB == 3: the activations run two steps ahead as well; what may still fly is step s + 1 of both kinds, requested together)
-                if (na > s + 1) tp_wait_c<WD_NB == 3 ? n_ops_a + NLB + DCNT : n_ops_a>();
+                if (NA == 3 && na > s + 1) tp_wait_c<WD_NB == 3 ? n_ops_a + NLB + DCNT : n_ops_a>();
                 else tp_wait_c<0>();
                 __syncthreads();  // everything of step s is in LDS, and nobody reads step s - 1 any more
-                if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
-                if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+                if (!(ko & 1)) {
+                    if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
+                    if (va < n_virtual) { issue_a(va, sa, na % NA); ++na; WD_ADV(va, sa) }
+                }
+                if (KH == 2 && ++sc_ == nsteps) {  // the pairs' hand-over at the end of an item (below): two barriers
+                    __syncthreads();
+                    __syncthreads();
+                    sc_ = 0;
+                }
             }
             return;
         }
     }
     for (int s = 0; s < total; ++s) {
         if (SELF) {
-            if (na > s + 1) tp_wait_c<WD_NB == 3 ? n_ops_a + NLB + DCNT : n_ops_a>();
+            if (NA == 3 && na > s + 1) tp_wait_c<WD_NB == 3 ? n_ops_a + NLB + DCNT : n_ops_a>();
             else tp_wait_c<0>();
         }
         __syncthreads();  // everything of step s is in LDS, and nobody reads step s - 1 any more
         if (SELF) {
             if (vb < n_virtual) { issue_b(vb, sbb, nb % WD_NB); ++nb; WD_ADV(vb, sbb) }
-            if (va < n_virtual) { issue_a(va, sa, na % 3); ++na; WD_ADV(va, sa) }
+            if (va < n_virtual) { issue_a(va, sa, na % NA); ++na; WD_ADV(va, sa) }
         }
 
+        if (ko & 2) continue;
         // ---- this wave's weight unit -> digit-plane operands, once per step
-        const char * const arow = a_ring_p + (s % 3) * A_STAGE + row * F::ROW;
+        const char * const arow = a_ring_p + (s % NA) * A_STAGE + row * F::ROW;
         const uint4 hdr = *(const uint4 *) arow;
         const float d = h2f((uint16_t) (hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (hdr.x >> 16));
         const uint32_t slo = hdr.y & 0x3F3F3F3Fu, shi = (hdr.w & 0x0F0F0F0Fu) | ((hdr.y >> 2) & 0x30303030u);
@@ -950,8 +978,8 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
             }
         }
         // ---- TT token tiles against it
-        const char * const bst = b_ring_p + (s % WD_NB) * B_STAGE;
-        const float * const dst_ = (const float *) (d_ring_p + (s % WD_NB) * TT * 128);
+        const char * const bst = b_ring_p + (s % WD_NB) * B_STAGE + kh * TT * SK_B_BYTES;
+        const float * const dst_ = (const float *) (d_ring_p + (s % WD_NB) * D_STAGE + kh * TT * 128);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const char * const btok = bst + (t * 32 + row) * SK_BTOK;
@@ -982,12 +1010,35 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
                 }
             }
         }
-        if (++sc_ == nblk) {
+        if (++sc_ == nsteps) {
             // ---- the tiles are complete: lane = weight row, register i = token (i & 3) + 8 (i >> 2) + 4 g of token tile t
+            if constexpr (KH == 2) {
+                // the odd super-blocks' tile goes to the wave of the even ones through the activation stage of this step (nobody reads it
+                // after the first barrier; the loaders write it again only after the NEXT step's barrier)
+                float * const xch = (float *) (b_ring_p + (s % WD_NB) * B_STAGE) + tile * (TT * 16 * 64) + lane;
+                static_assert(NW * TT * 16 * 64 * 4 <= B_STAGE, "hand-over area");
+                __syncthreads();
+                if (kh == 1) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            xch[(t * 16 + i) * 64] = acc[t][i];
+                            acc[t][i] = 0.0f;
+                        }
+                }
+                __syncthreads();
+                if (kh == 0) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[t][i] += xch[(t * 16 + i) * 64];
+                }
+            }
             int gr, mt;
             decode(vc, gr, mt);
             const int mi = MAT_OF(gr);
-            const int n = (gr - MAT_SEL(mi, panel0)) * (32 * NW) + wave * 32 + row;
+            const int n = (gr - MAT_SEL(mi, panel0)) * (32 * NW) + tile * 32 + row;
             float * const m_dst = MAT_SEL(mi, dst);
             const int64_t m_dst_stride = MAT_SEL(mi, dst_stride);
             const float * const m_add = MAT_SEL(mi, add);
@@ -995,23 +1046,25 @@ __global__ void __launch_bounds__((NW + NL) * 64, 1) k_mmq_wide(const mmq8_args 
             // (addends first, all of them in flight, then nothing but stores: with the optional load inside the store loop the compiler
             // waited vmcnt(0) before every store — stores count in vmcnt on this ISA, so each of the 32 waited for its predecessor's
             // write acknowledgement, ~16k clocks per item)
-            if (m_add) {
+            if (KH == 1 || kh == 0) {
+                if (m_add) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int tok = min(mt * 32 * TT + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * g, a.M - 1);
+                            acc[t][i] += m_add[(size_t) tok * m_add_stride + n];
+                        }
+                }
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const int tok = min(mt * 32 * TT + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * g, a.M - 1);
-                        acc[t][i] += m_add[(size_t) tok * m_add_stride + n];
+                        const int tok = mt * 32 * TT + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+                        if (tok < a.M) m_dst[(size_t) tok * m_dst_stride + n] = acc[t][i];
+                        acc[t][i] = 0.0f;
                     }
             }
-#pragma unroll
-            for (int t = 0; t < TT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int tok = mt * 32 * TT + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
-                    if (tok < a.M) m_dst[(size_t) tok * m_dst_stride + n] = acc[t][i];
-                    acc[t][i] = 0.0f;
-                }
             sc_ = 0;
             vc = next_valid(vc + gridDim.x);
         }
@@ -1040,11 +1093,28 @@ int mmq_wide_tiles(int type, int64_t K, const int64_t * N, int n_mat, int64_t M,
     return g128 * ((M + 63) / 64) * 2 >= skinny_n_cu() ? 4 * 16 + 2 : 0;
 }
 
-template <int QT, int TT, int NW, int NL> static void launch_wide_t(hipStream_t s, mmq8_args a) {
+template <int QT, int TT, int NW, int NL, int NA = 3, int KH = 1> static void launch_wide_t(hipStream_t s, mmq8_args a, const int per_cu = 1) {
     static std::atomic<uint32_t> lds_raised{0};
-    const void * fn = (const void *) k_mmq_wide<QT, TT, NW, NL>;
-    const size_t lds = (size_t) wd_lds_bytes<QT, TT, NW>();
+    const void * fn = (const void *) k_mmq_wide<QT, TT, NW, NL, NA, KH>;
+    const size_t lds = (size_t) wd_lds_bytes<QT, TT, NW, NA, KH>();
     (void) ensure_dyn_lds(fn, lds, lds_raised);
+    static const bool occ_log = getenv("GGML_MI355X_OCC_LOG") != nullptr;
+    if (occ_log) {
+        static std::atomic<int> once{0};
+        if (!once.exchange(1)) {
+            int nb = -1;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (NW * KH + NL) * 64, lds);
+            hipFuncAttributes fa{};
+            (void) hipFuncGetAttributes(&fa, fn);
+            fprintf(stderr, "[mi355x] k_mmq_wide<%d,%d,%d,%d,%d,%d>: %d blocks/CU by the occupancy API (err %d), lds %zu, regs %d, static lds %zu, max dyn lds %d\n", QT, TT, NW, NL, NA, KH, nb, (int) e, lds,
+                    fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+        }
+    }
+    static const int ko_env = getenv("GGML_MI355X_MMQ_WIDE_KO") ? atoi(getenv("GGML_MI355X_MMQ_WIDE_KO")) : 0;
+    if (ko_env) {
+        static std::atomic<int> ko_set{0};
+        if (!ko_set.exchange(1)) (void) hipMemcpyToSymbol(HIP_SYMBOL(g_wd_ko), &ko_env, sizeof(int));
+    }
     a.n_panels = 0;
     for (int i = 0; i < a.n_mat; ++i) {
         a.mat[i].panel0 = a.n_panels;
@@ -1052,12 +1122,26 @@ template <int QT, int TT, int NW, int NL> static void launch_wide_t(hipStream_t 
     }
     a.m_tiles = (a.M + 32 * TT - 1) / (32 * TT);
     const int n_virtual = ((a.n_panels + 7) / 8) * 8 * a.m_tiles;
-    MI_LAUNCH_PROBED((k_mmq_wide<QT, TT, NW, NL>), dim3((unsigned) std::min(n_virtual, skinny_n_cu())), dim3((NW + NL) * 64), lds, s, a);
+    MI_LAUNCH_PROBED((k_mmq_wide<QT, TT, NW, NL, NA, KH>), dim3((unsigned) std::min(n_virtual, skinny_n_cu() * per_cu)), dim3((NW * KH + NL) * 64), lds, s, a);
 }
 void launch_mmq_wide(hipStream_t s, int type, int shape, const mmq8_args & a) {
     static const int self4 = getenv("GGML_MI355X_MMQ_WIDE_SELF") ? atoi(getenv("GGML_MI355X_MMQ_WIDE_SELF")) : 0;  // experiment: 4 waves x 4 token tiles, no loaders
     (void) shape;
     if (self4 && type == GGML_TYPE_Q4_K) { launch_wide_t<4, 4, 4, 0>(s, a); return; }
+    static const int wg2 = getenv("GGML_MI355X_MMQ_WIDE_WG2") ? atoi(getenv("GGML_MI355X_MMQ_WIDE_WG2")) : 0;  // two workgroups per CU (weight ring of two stages)
+    static const int kh2 = getenv("GGML_MI355X_MMQ_WIDE_KH") ? atoi(getenv("GGML_MI355X_MMQ_WIDE_KH")) : 0;  // two computing waves per row tile (even / odd super-blocks)
+    if (kh2 && type == GGML_TYPE_Q4_K && (a.K / 256) % 2 == 0) {
+        if (kh2 == 4) launch_wide_t<4, 2, 4, 4, 2, 2>(s, a);
+        else launch_wide_t<4, 2, 4, 2, 2, 2>(s, a);
+        return;
+    }
+    if (wg2) {
+        if (type == GGML_TYPE_Q4_K && wg2 >= 5) launch_wide_t<4, 2, 4, 0, 2>(s, a, wg2 == 6 ? 1 : 2);  // no loaders: 4 waves, one per SIMD and workgroup
+        else if (type == GGML_TYPE_Q4_K && wg2 >= 3) launch_wide_t<4, 2, 4, 1, 2>(s, a, wg2 == 4 ? 1 : 2);  // one loader: 5 waves
+        else if (type == GGML_TYPE_Q4_K) launch_wide_t<4, 2, 4, WD_NL, 2>(s, a, wg2 == 2 ? 1 : 2);
+        else launch_wide_t<5, 2, 4, WD_NL, 2>(s, a, wg2 == 2 ? 1 : 2);
+        return;
+    }
     if (type == GGML_TYPE_Q4_K) launch_wide_t<4, 2, 4, WD_NL>(s, a);
     else launch_wide_t<5, 2, 4, WD_NL>(s, a);
 }
@@ -1164,7 +1248,5 @@ void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a) {
     else if (type == GGML_TYPE_Q5_K) launch_skinny_t<5>(s, a);
     else launch_skinny_t<6>(s, a);
 }
-
-MI_TU_TOUCH(mmq_skinny)
 
 }  // namespace mi355x
