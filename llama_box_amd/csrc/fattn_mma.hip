@@ -82,45 +82,112 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn_mma(const tdesc q, const t
     const float16v zero = O[0];
     float m = -INFINITY, l = 0.0f;
 
-    // staging roles: thread -> KV row and its slice of the head dimension (NW parts)
+    // staging roles.  K: thread -> KV row and its slice of the head dimension (NW parts).  V (round 4): thread -> a block of 4 KV rows x 8 head
+    // dims, transposed in registers (16 v_perm) and written as 8 ds_write_b64 of V^T — the first version wrote V^T with 32 ds_write_b16 per thread.
+    constexpr int T = NW * 64;
     const int srow = tid / NW, spart = tid % NW;
     constexpr int CH = D / (8 * NW);  // 16-byte chunks per thread per tile
+    constexpr int NBLK = 16 * (D / 8), VB = (NBLK + T - 1) / T;
 
-    // vis (k_fattn_vis_scan, once per graph run — the mask is the same tensor in every layer): byte [q tile of 32][kv tile of 64] says
-    // whether ANY of the 32 queries can see ANY of the 64 cells.  A causal prompt chunk skips the tiles above its diagonal; a
-    // continuous batch's prompt chunks (each sequence sees only its own cells of the unified cache) skip almost everything.
-    const uint8_t * visrow = vis ? vis + (int64_t) (blockIdx.x * NW) * tiles : nullptr;
+    // vis (k_fattn_vis_scan, once per graph run — the mask is the same tensor in every layer): byte [q tile of 32][kv tile of 64]:
+    // 0 = none of the 32 queries sees any of the 64 cells, 2 = every mask value of the tile is +0.0 (all visible, no bias: the kernel does
+    // not read the mask at all), 1 = anything else.  A causal prompt chunk skips the tiles above its diagonal and reads the mask only ON the
+    // diagonal; a continuous batch's prompt chunks (each sequence sees only its own cells of the unified cache) skip almost everything.
     const int n_qt = (geo.n_q + 31) / 32;
-    for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
-        if (visrow) {  // workgroup-uniform: every thread evaluates the same NW bytes
-            const int kt = kv0 / BKV;
-            bool any = false;
+    const int kt_begin = kv_begin / BKV, kt_end = (kv_end + BKV - 1) / BKV;
+    // the states of this split's tiles, all NW query tiles packed into one byte (2 bits each), copied to LDS once: the walk below decides
+    // from LDS (a global byte load per decision put one L2 round trip per tile in front of the next tile's requests)
+    uint8_t * const vt = (uint8_t *) (smem + BKV * KS + D * VS);
+    if (vis) {
+        const uint8_t * visrow = vis + (int64_t) (blockIdx.x * NW) * tiles;
+        for (int i = kt_begin + tid; i < kt_end; i += T) {
+            uint32_t b = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) any = any || ((int) blockIdx.x * NW + w < n_qt && visrow[(int64_t) w * tiles + kt] != 0);
-            if (!any) continue;
+            for (int w = 0; w < NW; ++w)
+                if ((int) blockIdx.x * NW + w < n_qt) b |= (uint32_t) (visrow[(int64_t) w * tiles + i] & 3) << (2 * w);
+            vt[i - kt_begin] = (uint8_t) b;
         }
         __syncthreads();
+    }
+    auto next_tile = [&](int kt) __attribute__((always_inline)) {
+        if (vis)
+            while (kt < kt_end && __builtin_amdgcn_readfirstlane((int) vt[kt - kt_begin]) == 0) ++kt;  // (readfirstlane: the tile index stays in an SGPR)
+        return kt;
+    };
+    // K / V of a tile travel global -> registers -> LDS; the NEXT visible tile's loads are issued as soon as this tile's registers have been
+    // written to LDS, so they fly during the two GEMMs and the softmax (the first version loaded, waited and wrote inside the two barriers:
+    // one exposed L2 / HBM round trip per tile, ~15 k clocks per tile and wave against 1 k of matrix pipe)
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));  // (a struct uint4 copied whole to LDS keeps the array in scratch)
+    u32x4v kr[CH];
+    uint4 vr[VB][4];
+    auto load_tile = [&](const int kt) __attribute__((always_inline)) {
+        const int kv0 = kt * BKV;
         {
             const int pos = min(kv0 + srow, geo.n_kv - 1);
-            const uint4 * kp = (const uint4 *) (kbase + (int64_t) pos * k.nb[1]) + spart * CH;
-            const uint4 * vp = (const uint4 *) (vbase + (int64_t) pos * v.nb[1]) + spart * CH;
-            uint4 kr[CH], vr[CH];
+            const u32x4v * kp = (const u32x4v *) (kbase + (int64_t) pos * k.nb[1]) + spart * CH;
 #pragma unroll
-            for (int i = 0; i < CH; ++i) { kr[i] = kp[i]; vr[i] = vp[i]; }
+            for (int i = 0; i < CH; ++i) kr[i] = kp[i];
+        }
 #pragma unroll
-            for (int i = 0; i < CH; ++i) *(uint4 *) (Kt + srow * KS + (spart * CH + i) * 16) = kr[i];
+        for (int j = 0; j < VB; ++j) {
+            const int b = min(tid + j * T, NBLK - 1), kvq = b / (D / 8), dch = b % (D / 8);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int d0 = (spart * CH + i) * 8;
-                const uint32_t w[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    *(uint16_t *) (Vt + (d0 + 2 * e) * VS + srow * 2) = (uint16_t) (w[e] & 0xFFFF);
-                    *(uint16_t *) (Vt + (d0 + 2 * e + 1) * VS + srow * 2) = (uint16_t) (w[e] >> 16);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int pos = min(kv0 + 4 * kvq + r, geo.n_kv - 1);
+                vr[j][r] = *((const uint4 *) (vbase + (int64_t) pos * v.nb[1]) + dch);
             }
         }
-        __syncthreads();
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) *(u32x4v *) (Kt + srow * KS + (spart * CH + i) * 16) = kr[i];
+#pragma unroll
+        for (int j = 0; j < VB; ++j) {
+            const int b = tid + j * T;
+            if (VB * T != NBLK && b >= NBLK) break;
+            const int kvq = b / (D / 8), dch = b % (D / 8);
+            const uint32_t r0[4] = {vr[j][0].x, vr[j][0].y, vr[j][0].z, vr[j][0].w}, r1[4] = {vr[j][1].x, vr[j][1].y, vr[j][1].z, vr[j][1].w};
+            const uint32_t r2[4] = {vr[j][2].x, vr[j][2].y, vr[j][2].z, vr[j][2].w}, r3[4] = {vr[j][3].x, vr[j][3].y, vr[j][3].z, vr[j][3].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // dword e of a row holds head dims 2e, 2e + 1
+                uint2 lo, hi;
+                lo.x = __builtin_amdgcn_perm(r1[e], r0[e], 0x05040100u);  // {row0.lo16, row1.lo16}
+                lo.y = __builtin_amdgcn_perm(r3[e], r2[e], 0x05040100u);
+                hi.x = __builtin_amdgcn_perm(r1[e], r0[e], 0x07060302u);  // {row0.hi16, row1.hi16}
+                hi.y = __builtin_amdgcn_perm(r3[e], r2[e], 0x07060302u);
+                // (groups of 4 KV positions XOR-swizzled by the row's 32-dim tile: the 16 lanes that write one KV group — rows 8 dims apart,
+                // 16 banks apart mod 64 — would hit 4 bank pairs; the readers' tile index dt is a compile-time constant)
+                const int kvs = 8 * (kvq ^ (2 * (dch >> 2)));
+                *(uint2 *) (Vt + (8 * dch + 2 * e) * VS + kvs) = lo;
+                *(uint2 *) (Vt + (8 * dch + 2 * e + 1) * VS + kvs) = hi;
+            }
+        }
+    };
+
+    int kt = next_tile(kt_begin);
+    if (kt < kt_end) load_tile(kt);
+    while (kt < kt_end) {
+        const int kv0 = kt * BKV;
+        const int mine = !vis ? 1 : (int) __builtin_amdgcn_readfirstlane((vt[kt - kt_begin] >> (2 * wave)) & 3);
+        const bool tail = kv0 + BKV > geo.n_kv;
+        __syncthreads();  // nobody reads the previous tile any more
+        store_tile();
+        // the mask words of this tile (only where the tile is neither hidden nor plainly visible), requested BEFORE the next tile's K / V:
+        // vmcnt retires in order, so waiting for them later leaves the younger K / V requests in flight
+        uint2 mw[2][4] = {};
+        const bool use_mask = geo.has_mask != 0 && mine == 1;  // (wave-uniform)
+        if (use_mask) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) mw[t][g4] = *(const uint2 *) (mrow + min(kv0 + 32 * t + 8 * g4 + 4 * kg, geo.n_kv - 4));
+        }
+        const int kt_next = next_tile(kt + 1);
+        if (kt_next < kt_end) load_tile(kt_next);
+        // (a bare barrier behind the LDS writes: __syncthreads() would also wait vmcnt(0), i.e. for the loads just issued)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        kt = kt_next;
+        if (mine == 0) continue;  // none of this wave's queries sees the tile (the barriers are at the loop top)
 
         // ---- S^T = K·Q^T for the two 32-position halves of the tile
         float16v S[2];
@@ -135,25 +202,35 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn_mma(const tdesc q, const t
         }
         // ---- scale, mask, online softmax (lane = one query; registers = 32 of the tile's 64 KV positions)
         float mx = -INFINITY;
+        if (use_mask || tail) {  // (wave-uniform) a tile on the diagonal / with a bias / at the end of the cache
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int p0 = kv0 + 32 * t + 8 * g4 + 4 * kg;  // four consecutive KV positions: registers 4*g4 .. 4*g4+3
-                float mv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (mrow) {
-                    const uint2 mw = *(const uint2 *) (mrow + min(p0, geo.n_kv - 4));
-                    mv[0] = h2f((uint16_t) (mw.x & 0xFFFF)); mv[1] = h2f((uint16_t) (mw.x >> 16));
-                    mv[2] = h2f((uint16_t) (mw.y & 0xFFFF)); mv[3] = h2f((uint16_t) (mw.y >> 16));
-                }
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int p0 = kv0 + 32 * t + 8 * g4 + 4 * kg;  // four consecutive KV positions: registers 4*g4 .. 4*g4+3
+                    float mv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (use_mask) {
+                        mv[0] = h2f((uint16_t) (mw[t][g4].x & 0xFFFF)); mv[1] = h2f((uint16_t) (mw[t][g4].x >> 16));
+                        mv[2] = h2f((uint16_t) (mw[t][g4].y & 0xFFFF)); mv[3] = h2f((uint16_t) (mw[t][g4].y >> 16));
+                    }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float sv = fmaf(S[t][4 * g4 + e], sc2, mv[e] * LOG2E);  // log2 domain: p = 2^(s - m) is ONE v_exp_f32
-                    if (p0 + e >= geo.n_kv) sv = -INFINITY;
-                    S[t][4 * g4 + e] = sv;
-                    mx = fmaxf(mx, sv);
+                    for (int e = 0; e < 4; ++e) {
+                        float sv = fmaf(S[t][4 * g4 + e], sc2, mv[e] * LOG2E);  // log2 domain: p = 2^(s - m) is ONE v_exp_f32
+                        if (p0 + e >= geo.n_kv) sv = -INFINITY;
+                        S[t][4 * g4 + e] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
                 }
             }
+        } else {  // every cell visible to every query, no bias: one multiply per score
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sv = S[t][r] * sc2;  // (= fmaf(s, sc2, +0.0), what the masked path computes for a visible cell)
+                    S[t][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx);
@@ -173,10 +250,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn_mma(const tdesc q, const t
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
         m = m_new;
+        if (!__all(alpha == 1.0f)) {  // (wave-uniform; once the running maxima have settled — most tiles of a long row — nothing is rescaled)
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+        }
         // ---- O^T += V^T·P^T
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -185,11 +264,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn_mma(const tdesc q, const t
                 half8 pb;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) pb[u] = (_Float16) S[t][8 * s2 + u];
-                const int kvo = (32 * t + 16 * s2 + 4 * kg) * 2;  // byte offset of this half's first run inside a V^T row
+                const int kvg = 8 * t + 4 * s2 + kg;  // this half's first group of 4 KV positions inside a V^T row (the second: + 2)
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt) {
-                    const char * vrow = Vt + (32 * dt + fr) * VS + kvo;
-                    const half4v a0 = *(const half4v *) vrow, a1 = *(const half4v *) (vrow + 16);
+                    const char * vrow = Vt + (32 * dt + fr) * VS;
+                    const half4v a0 = *(const half4v *) (vrow + 8 * (kvg ^ (2 * dt))), a1 = *(const half4v *) (vrow + 8 * ((kvg + 2) ^ (2 * dt)));
                     const half8 a = (half8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, O[dt], 0, 0, 0);
                 }
@@ -234,33 +313,34 @@ int fattn_mma_pick_splits(const tdesc & q, const tdesc & k) {
     want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, tiles / 4)));
     return (int) want;
 }
-// one workgroup per 32-query tile; thread t looks at kv tile t, t + 256, ...: 32 mask rows x 64 cells (f16) each
+// a wave per (32-query tile, 64-cell tile): lane = (mask row, half of the 64 cells), 64 bytes each — coalesced, where the first version
+// walked 32 rows per THREAD (86 us per micro-batch of 512 x 2048).  Result: 0 = nothing visible, 2 = every value +0.0, 1 = otherwise.
 __global__ void __launch_bounds__(256) k_fattn_vis_scan(const tdesc mask, const int n_q, const int n_kv, uint8_t * __restrict__ vis) {
     const int qt = blockIdx.x, tiles = (n_kv + 63) / 64;
-    for (int kt = threadIdx.x; kt < tiles; kt += 256) {
-        bool any = false;
-        for (int r = 0; r < 32 && !any; ++r) {
-            const int qi = qt * 32 + r;
-            if (qi >= n_q) break;
-            const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) qi * mask.nb[1]) + kt * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane >> 1, half = lane & 1;
+    const int qi = qt * 32 + r;
+    for (int kt = blockIdx.y * 4 + wave; kt < tiles; kt += gridDim.y * 4) {
+        bool any = false, zero = true;
+        if (qi < n_q) {
+            const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) qi * mask.nb[1]) + kt * 64 + half * 32;
 #pragma unroll
-            for (int c = 0; c < 64; c += 8) {
-                if (kt * 64 + c < n_kv) {  // n_kv % 4 == 0 and rows 8-byte aligned (launcher); a tail of 4 cells is read as 8 only when in range
-                    const uint2 w0 = *(const uint2 *) (mrow + c);
-                    any = any || w0.x != 0xFC00FC00u || w0.y != 0xFC00FC00u;
-                    if (kt * 64 + c + 4 < n_kv) {
-                        const uint2 w1 = *(const uint2 *) (mrow + c + 4);
-                        any = any || w1.x != 0xFC00FC00u || w1.y != 0xFC00FC00u;
-                    }
+            for (int c = 0; c < 32; c += 4) {  // n_kv % 4 == 0 and rows 8-byte aligned (launcher)
+                if (kt * 64 + half * 32 + c < n_kv) {
+                    const uint2 w = *(const uint2 *) (mrow + c);
+                    any = any || w.x != 0xFC00FC00u || w.y != 0xFC00FC00u;
+                    zero = zero && (w.x | w.y) == 0u;
                 }
             }
         }
-        vis[(int64_t) qt * tiles + kt] = any ? 1 : 0;
+        const bool w_any = __any(any), w_zero = __all(zero) && (kt + 1) * 64 <= n_kv;
+        if (lane == 0) vis[(int64_t) qt * tiles + kt] = !w_any ? 0 : (w_zero ? 2 : 1);
     }
 }
 size_t fattn_vis_bytes(const tdesc & q, const tdesc & k) { return (size_t) ((q.ne[1] + 31) / 32) * (size_t) ((k.ne[1] + 63) / 64); }
 void launch_fattn_vis_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, uint8_t * vis) {
-    hipLaunchKernelGGL(k_fattn_vis_scan, dim3((unsigned) ((n_q + 31) / 32)), dim3(256), 0, s, mask, n_q, n_kv, vis);
+    const int tiles = (n_kv + 63) / 64;
+    hipLaunchKernelGGL(k_fattn_vis_scan, dim3((unsigned) ((n_q + 31) / 32), (unsigned) std::min(64, (tiles + 3) / 4)), dim3(256), 0, s, mask, n_q, n_kv, vis);
 }
 int fattn_mma_min_q() {
     // up to 32 query tokens are served per token (tile-list / lane-parallel kernels): a -np 32 decode step has 32 tokens that
@@ -291,14 +371,17 @@ bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, cons
     float * ws = (float *) workspace;
     const int nw = geo.n_q >= 256 ? 4 : 2;  // 128-query workgroups when there are enough queries to keep the grid full
     dim3 grid((unsigned) ((geo.n_q + nw * 32 - 1) / (nw * 32)), (unsigned) geo.n_head, (unsigned) (q.ne[3] * geo.n_splits));
+    const int tiles_all = (geo.n_kv + 63) / 64, tps = (tiles_all + geo.n_splits - 1) / geo.n_splits;
+    const uint8_t * const tile_vis = tps <= 16384 ? p.tile_vis : nullptr;  // (without the states every tile is multiplied and reads its mask: correct, slower)
+    const size_t vt_bytes = tile_vis ? (size_t) ((tps + 15) & ~15) : 0;  // the split's tile states (a byte per tile)
     if (D == 128) {
-        const size_t lds = 64 * (128 + 8) * 2 + 128 * (64 + 4) * 2;
-        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<128, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
-        else hipLaunchKernelGGL((k_fattn_mma<128, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
+        const size_t lds = 64 * (128 + 8) * 2 + 128 * (64 + 4) * 2 + vt_bytes;
+        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<128, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws, tile_vis);
+        else hipLaunchKernelGGL((k_fattn_mma<128, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws, tile_vis);
     } else {
-        const size_t lds = 64 * (64 + 8) * 2 + 64 * (64 + 4) * 2;
-        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<64, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
-        else hipLaunchKernelGGL((k_fattn_mma<64, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws, p.tile_vis);
+        const size_t lds = 64 * (64 + 8) * 2 + 64 * (64 + 4) * 2 + vt_bytes;
+        if (nw == 4) hipLaunchKernelGGL((k_fattn_mma<64, 4>), grid, dim3(256), lds, s, q, k, v, mk, dst, geo, ws, tile_vis);
+        else hipLaunchKernelGGL((k_fattn_mma<64, 2>), grid, dim3(128), lds, s, q, k, v, mk, dst, geo, ws, tile_vis);
     }
     if (geo.n_splits > 1) launch_flash_attn_combine(s, (int) k.ne[0], ws, sinks, dst, (int) q.ne[1], (int) q.ne[2], (int) q.ne[3], geo.n_splits, p.q8_out);
     return true;
