@@ -268,9 +268,10 @@ struct ggml_tensor * ggml_transpose(struct ggml_context * ctx, struct ggml_tenso
 }
 
 // ------------------------------------------------------------------------------------------------ ops
-static bool can_repeat(const ggml_tensor * b, const ggml_tensor * a) {  // b broadcastable to a
+static bool can_repeat(const ggml_tensor * b, const ggml_tensor * a) {  // b broadcastable to a (ggml_can_repeat: an empty b only to an empty a)
+    if (ggml_nelements(b) == 0) return ggml_nelements(a) == 0;
     for (int i = 0; i < GGML_MAX_DIMS; ++i)
-        if (b->ne[i] == 0 || a->ne[i] % b->ne[i] != 0) return false;
+        if (a->ne[i] % b->ne[i] != 0) return false;
     return true;
 }
 static void set_f32(ggml_tensor * t, int i, float v) { memcpy(&t->op_params[i], &v, 4); }

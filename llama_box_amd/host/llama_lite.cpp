@@ -913,8 +913,9 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     std::vector<int32_t> out_ids;
     for (int i = 0; i < n_tokens; ++i) if (!want || want[i]) out_ids.push_back(i);
     const int n_outputs = (int) out_ids.size();
-    if (n_outputs == 0) out_ids.push_back(n_tokens - 1);  // keep the graph shape valid; result discarded
-    const int n_out_graph = std::max(1, n_outputs);
+    // a micro-batch nobody wants logits from (every chunk of a prompt but the last): llama.cpp builds the graph with an EMPTY out_ids — the last
+    // layer's tensors behind get_rows and the output head have zero rows and are skipped by the backends (ggml_is_empty)
+    const int n_out_graph = n_outputs;
 
     graph_key key{n_tokens, n_kv, n_out_graph};
     bool rebuilt = false;

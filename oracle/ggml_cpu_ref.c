@@ -1176,6 +1176,9 @@ int oracle_supports_op(const struct ggml_tensor * node) {
 
 enum ggml_status oracle_compute_node(struct ggml_tensor * node, int n_threads) {
     int nth = n_threads > 0 ? n_threads : oracle_max_threads();
+    /* ggml-cpu skips tensors without elements (ggml_compute_forward: `if (tensor->op == GGML_OP_NONE || ggml_is_empty(tensor)) return;`):
+       llama.cpp relies on it for micro-batches nobody wants logits from — out_ids is empty and everything behind the last layer's get_rows has 0 rows */
+    if (node->ne[0] == 0 || node->ne[1] == 0 || node->ne[2] == 0 || node->ne[3] == 0) return GGML_STATUS_SUCCESS;
     switch (node->op) {
         case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             return GGML_STATUS_SUCCESS;

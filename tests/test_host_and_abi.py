@@ -175,9 +175,18 @@ def test_driver_on_oracle_determinism_reuse_and_batching(H):
         assert rc == 0 and T.nmse(lk, lf) < 2e-2
         with pytest.raises(RuntimeError):
             Context(m, compute=fn, flash_attn=0, type_v=L.Q8_0)
+        # a prompt in micro-batches, logits wanted for its last token only: the chunks before the last have ZERO outputs — out_ids is empty, the
+        # last layer's tensors behind get_rows and the output head have no rows and are skipped (ggml_is_empty), the cache is filled all the same
+        long_prompt = [(7 * i + 3) % hp.n_vocab for i in range(20)]
+        want = [0] * 19 + [1]
+        c6 = Context(m, compute=fn, flash_attn=1, n_ubatch=8)
+        c7 = Context(m, compute=fn, flash_attn=1, n_ubatch=32)
+        rc6, l6 = c6.decode(long_prompt, range(20), want=want)
+        rc7, l7 = c7.decode(long_prompt, range(20), want=want)
+        assert rc6 == 0 and rc7 == 0 and l6.shape == (1, hp.n_vocab) and np.array_equal(l6, l7)
         # return codes
         assert c3.decode([hp.n_vocab], [0])[0] == -1
-        for c in (c1, c2, c3, c4, c5):
+        for c in (c1, c2, c3, c4, c5, c6, c7):
             c.free()
     finally:
         m.free()
