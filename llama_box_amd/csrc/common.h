@@ -183,7 +183,7 @@ struct backend_ctx {
     unsigned * fa_arrive = nullptr;  // arrival counters of the self-merging attention splits (zero between launches)
     static constexpr int fa_arrive_slots = 16384;
     float * rope_tab = nullptr;   // (cos, sin) per (token, rotation pair) of a small batch: written once per graph run, read by every layer's QKV epilogue
-    static constexpr int rope_tab_floats = 32 * 256 * 2;
+    static constexpr int rope_tab_floats = 4096 * 256;  // (cos, sin) of up to 4096 tokens x 128 pairs (round 4: prompt micro-batches use the table too)
     int * fa_lists = nullptr;
     size_t fa_lists_bytes = 0;
     // per-class kernel timing (bench)

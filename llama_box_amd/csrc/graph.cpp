@@ -1153,7 +1153,9 @@ static bool try_fuse_rope_store(exec_state & st, int i) {
         st.rs_sk.node = -1;
     }
     timed_scope ts(c, "rope_qk_store", (double) ggml_abi_nbytes(st.g->nodes[i]) * 2);
-    launch_rope_qk_store(c->stream, pl.a, pl.T);
+    const float * tab = rope_qk_store_vec_ok(pl.a, pl.T) ? ensure_rope_table(st, pl.a.pos, pl.a.ff, pl.a.p, pl.T) : nullptr;
+    if (tab) launch_rope_qk_store_vec(c->stream, pl.a, pl.T, tab);
+    else launch_rope_qk_store(c->stream, pl.a, pl.T);
     c->st.kernel_launches++;
     for (int k : pl.nodes) { mark_done(st, k); c->st.fused_nodes++; }
     return true;

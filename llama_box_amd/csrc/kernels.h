@@ -247,6 +247,9 @@ struct rope_store_args {
     int ks;
 };
 void launch_rope_qk_store(hipStream_t s, rope_store_args a, int n_tokens);
+// prompt micro-batches: the vectorised form over the per-run (cos, sin) table (ops.hip: k_rope_qk_store_vec)
+bool rope_qk_store_vec_ok(const rope_store_args & a, int n_tokens);
+void launch_rope_qk_store_vec(hipStream_t s, const rope_store_args & a, int n_tokens, const float * tab);
 void launch_rope(hipStream_t s, const tdesc & src, const tdesc & pos, const float * freq_factors, const tdesc & dst, const rope_params & p);
 void launch_soft_max(hipStream_t s, const tdesc & src, const tdesc * mask, const float * sinks, const tdesc & dst, float scale, float max_bias);
 

@@ -564,6 +564,85 @@ __global__ void __launch_bounds__(256) k_rope_qk_store(const rope_store_args a) 
         }
     }
 }
+// The same work for a prompt micro-batch, vectorised (round 4): a workgroup per token, a thread per CHUNK — 4 consecutive head dims ("normal"
+// rotation: two adjacent pairs) or 4 + 4 dims half a head apart (NeoX) — of every query / key / value head; ALL of a thread's loads are
+// requested first (the per-slot loop above waits one L2 round trip per head slot: 14 us for 512 tokens of Llama-3-8B against 23 MB of traffic),
+// and (cos, sin) come from the per-graph-run table of k_rope_table (the chain of multiplies and the accurate cosf / sinf once per run, not once
+// per layer).  Requires: whole heads rotated (n_dims == head_dim), head_dim % 8 == 0, projections in memory (no split-K partials), row-major V cache.
+// The arithmetic per element is that of k_rope_qk_store (x0 cs - x1 sn, x0 sn + x1 cs; f2h for the cache rows).
+template <bool NEOX>
+__global__ void __launch_bounds__(256) k_rope_qk_store_vec(const rope_store_args a, const float * __restrict__ tab) {
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x, hd = a.head_dim, half = hd >> 1;
+    const int64_t row = a.idx[t];
+    const int cph = NEOX ? hd / 8 : hd / 4;            // chunks per head
+    const int n_rot = (a.nh + a.nkv) * cph, n_v = a.nkv * (hd / 4);
+    constexpr int MAXC = 6;                            // chunks per thread and pass (Llama-3-8B: 1280 rotated chunks -> 5, + 1 value chunk)
+    for (int c0 = 0; c0 < n_rot + n_v; c0 += 256 * MAXC) {
+        float4 lo[MAXC], hi[MAXC], cs[MAXC], cs2[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            const int c = c0 + tid + 256 * k;
+            if (c < n_rot) {
+                const int slot = c / cph, j = c - slot * cph;
+                const float * src = slot < a.nh ? (const float *) (a.q_src + (int64_t) slot * a.q_nb1 + t * a.q_nb2) : (const float *) (a.k_src + (int64_t) (slot - a.nh) * a.k_nb1 + t * a.k_nb2);
+                lo[k] = *(const float4 *) (src + 4 * j);
+                if (NEOX) {
+                    hi[k] = *(const float4 *) (src + half + 4 * j);
+                    cs[k] = *(const float4 *) (tab + ((size_t) t * half + 4 * j) * 2);       // pairs 4j, 4j + 1
+                    cs2[k] = *(const float4 *) (tab + ((size_t) t * half + 4 * j + 2) * 2);  // pairs 4j + 2, 4j + 3
+                } else {
+                    cs[k] = *(const float4 *) (tab + ((size_t) t * half + 2 * j) * 2);       // pairs 2j, 2j + 1
+                }
+            } else if (c < n_rot + n_v) {
+                const int cv = c - n_rot, h = cv / (hd / 4), j = cv - h * (hd / 4);
+                lo[k] = *(const float4 *) ((const float *) (a.v_src + (int64_t) h * a.v_nb1 + t * a.v_nb2) + 4 * j);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            const int c = c0 + tid + 256 * k;
+            if (c < n_rot) {
+                const int slot = c / cph, j = c - slot * cph;
+                float4 o0, o1;
+                if (NEOX) {  // element i pairs with i + half: (cos, sin) of pair i
+                    o0 = make_float4(lo[k].x * cs[k].x - hi[k].x * cs[k].y, lo[k].y * cs[k].z - hi[k].y * cs[k].w, lo[k].z * cs2[k].x - hi[k].z * cs2[k].y, lo[k].w * cs2[k].z - hi[k].w * cs2[k].w);
+                    o1 = make_float4(lo[k].x * cs[k].y + hi[k].x * cs[k].x, lo[k].y * cs[k].w + hi[k].y * cs[k].z, lo[k].z * cs2[k].y + hi[k].z * cs2[k].x, lo[k].w * cs2[k].w + hi[k].w * cs2[k].z);
+                } else {     // elements (2i, 2i + 1)
+                    o0 = make_float4(lo[k].x * cs[k].x - lo[k].y * cs[k].y, lo[k].x * cs[k].y + lo[k].y * cs[k].x, lo[k].z * cs[k].z - lo[k].w * cs[k].w, lo[k].z * cs[k].w + lo[k].w * cs[k].z);
+                    o1 = o0;
+                }
+                if (slot < a.nh) {
+                    float * dst = (float *) (a.q_dst + (int64_t) slot * a.qd_nb1 + t * a.qd_nb2);
+                    *(float4 *) (dst + 4 * j) = o0;
+                    if (NEOX) *(float4 *) (dst + half + 4 * j) = o1;
+                } else {
+                    uint16_t * dst = (uint16_t *) (a.k_cache + row * a.kc_nb1) + (int64_t) (slot - a.nh) * hd;
+                    *(uint2 *) (dst + 4 * j) = make_uint2((uint32_t) f2h(o0.x) | ((uint32_t) f2h(o0.y) << 16), (uint32_t) f2h(o0.z) | ((uint32_t) f2h(o0.w) << 16));
+                    if (NEOX) *(uint2 *) (dst + half + 4 * j) = make_uint2((uint32_t) f2h(o1.x) | ((uint32_t) f2h(o1.y) << 16), (uint32_t) f2h(o1.z) | ((uint32_t) f2h(o1.w) << 16));
+                }
+            } else if (c < n_rot + n_v) {
+                const int cv = c - n_rot, h = cv / (hd / 4), j = cv - h * (hd / 4);
+                uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * hd;
+                *(uint2 *) (dst + 4 * j) = make_uint2((uint32_t) f2h(lo[k].x) | ((uint32_t) f2h(lo[k].y) << 16), (uint32_t) f2h(lo[k].z) | ((uint32_t) f2h(lo[k].w) << 16));
+            }
+        }
+    }
+}
+bool rope_qk_store_vec_ok(const rope_store_args & a, int n_tokens) {
+    static const bool on = !getenv("GGML_MI355X_ROPE_VEC") || atoi(getenv("GGML_MI355X_ROPE_VEC")) != 0;
+    if (!on || n_tokens < 33 || a.v_idx != nullptr || a.ks > 1 || a.sk[0].part || a.sk[1].part || a.sk[2].part) return false;
+    if ((a.p.mode & ~GGML_ROPE_TYPE_NEOX) != 0 || a.p.n_dims != a.head_dim || (a.head_dim % 8) != 0) return false;
+    auto al16 = [](const void * p) { return (((uintptr_t) p) & 15) == 0; };
+    if (!al16(a.q_src) || !al16(a.q_dst) || !al16(a.k_src) || !al16(a.v_src) || !al16(a.k_cache) || !al16(a.v_cache)) return false;
+    for (int64_t v : {a.q_nb1, a.q_nb2, a.qd_nb1, a.qd_nb2, a.k_nb1, a.k_nb2, a.v_nb1, a.v_nb2})
+        if (v % 16) return false;
+    return (a.kc_nb1 % 8) == 0 && (a.vc_nb1 % 8) == 0;
+}
+void launch_rope_qk_store_vec(hipStream_t s, const rope_store_args & a, int n_tokens, const float * tab) {
+    if (a.p.mode & GGML_ROPE_TYPE_NEOX) hipLaunchKernelGGL(k_rope_qk_store_vec<true>, dim3((unsigned) n_tokens), dim3(256), 0, s, a, tab);
+    else hipLaunchKernelGGL(k_rope_qk_store_vec<false>, dim3((unsigned) n_tokens), dim3(256), 0, s, a, tab);
+}
 void launch_rope_qk_store(hipStream_t s, rope_store_args a, int n_tokens) {
     rope_host_consts(a.p, a.theta_scale, a.corr0, a.corr1);
     const int n_all = a.nh + 2 * a.nkv;
