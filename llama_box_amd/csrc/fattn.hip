@@ -863,11 +863,61 @@ template <int D, bool Q8OUT = false> __global__ void __launch_bounds__(Q8OUT ? 2
     }
 }
 
+// Few splits, many (token, head) rows — the combine pass behind the matrix-core kernel of a prompt micro-batch (512 tokens x 32 heads x 4 splits:
+// 16 384 rows): a thread per 4-dim chunk of a row, 8 rows per workgroup, every load of the thread (S float4 + S (m, l) pairs) requested at once.
+// The arithmetic is k_fattn_combine's: coefficients exp(m_s - max), values selected (not multiplied) where the coefficient is 0, sum in split order.
+template <int D, int S>
+__global__ void __launch_bounds__(256) k_fattn_combine_rows(const float * __restrict__ ws, const tdesc dst, const fa_geom geo, const int n_rows) {
+    constexpr int CPR = D / 4;            // chunks (threads) per row
+    constexpr int RPB = 256 / CPR;        // rows per workgroup
+    const int r = (int) blockIdx.x * RPB + (int) threadIdx.x / CPR, j = (int) threadIdx.x % CPR;
+    if (r >= n_rows) return;
+    // row r = ((bat * n_q + tok) * n_head + h): the record layout of the split kernels
+    const int h = r % geo.n_head, tok = (r / geo.n_head) % geo.n_q, bat = r / (geo.n_head * geo.n_q);
+    const float * __restrict__ base = ws + (int64_t) r * geo.n_splits * (D + 2);
+    float4 v[S];
+    float2 ml[S];
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int uu = min(u, geo.n_splits - 1);
+        // (records are D + 2 floats apart: 8-byte aligned, not 16)
+        const float2 v0 = *(const float2 *) (base + (int64_t) uu * (D + 2) + 4 * j), v1 = *(const float2 *) (base + (int64_t) uu * (D + 2) + 4 * j + 2);
+        v[u] = make_float4(v0.x, v0.y, v1.x, v1.y);
+        ml[u] = *(const float2 *) (base + (int64_t) uu * (D + 2) + D);
+    }
+    float mn = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < S; ++u) mn = fmaxf(mn, u < geo.n_splits ? ml[u].x : -INFINITY);
+    float lt = 0.0f;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const float c = (u < geo.n_splits && ml[u].x != -INFINITY) ? expf(ml[u].x - mn) : 0.0f;
+        lt += (u < geo.n_splits ? ml[u].y : 0.0f) * c;
+        a.x += c != 0.0f ? v[u].x * c : 0.0f;
+        a.y += c != 0.0f ? v[u].y * c : 0.0f;
+        a.z += c != 0.0f ? v[u].z * c : 0.0f;
+        a.w += c != 0.0f ? v[u].w * c : 0.0f;
+    }
+    const float inv = 1.0f / lt;
+    float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+    *(float4 *) (out + 4 * j) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+}
+
 void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits, void * q8_out) {
     fa_geom geo{};
     geo.n_q = n_q;
     geo.n_head = n_head;
     geo.n_splits = n_splits;
+    static const bool rows_on = !getenv("GGML_MI355X_FA_COMBINE_ROWS") || atoi(getenv("GGML_MI355X_FA_COMBINE_ROWS")) != 0;
+    const int64_t n_rows = (int64_t) n_batch * n_q * n_head;
+    if (rows_on && !q8_out && !sinks && D == 128 && n_splits <= 8 && n_rows >= 2048 && n_rows < (1 << 30) && (dst.nb[1] % 16) == 0 && (dst.nb[2] % 16) == 0 && (dst.nb[3] % 16) == 0 &&
+        (((uintptr_t) dst.data) & 15) == 0 && (((uintptr_t) ws) & 7) == 0) {
+        const unsigned blocks = (unsigned) ((n_rows + 7) / 8);
+        if (n_splits <= 4) hipLaunchKernelGGL((k_fattn_combine_rows<128, 4>), dim3(blocks), dim3(256), 0, s, ws, dst, geo, (int) n_rows);
+        else hipLaunchKernelGGL((k_fattn_combine_rows<128, 8>), dim3(blocks), dim3(256), 0, s, ws, dst, geo, (int) n_rows);
+        return;
+    }
     dim3 g2((unsigned) n_head, (unsigned) n_q, (unsigned) n_batch);
     if (q8_out && D == 128) {
         hipLaunchKernelGGL((k_fattn_combine<128, true>), dim3((unsigned) (n_head / 2), (unsigned) n_q, (unsigned) n_batch), dim3(256), 0, s, ws, sinks, dst, geo, (q8k_dev *) q8_out);

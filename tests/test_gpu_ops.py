@@ -755,6 +755,9 @@ FA_CASES = [  # (HD, NH, NKV, n_q, n_kv, splits, softcap, alibi, sinks)
     (128, 8, 2, 40, 1024, 0, 0.0, 0.0, False),
     (64, 4, 2, 96, 512, 3, 0.0, 0.0, False),
     (128, 16, 4, 33, 1100, 5, 0.0, 0.0, False),
+    # ... with >= 2048 (token, head) rows: the row-parallel combine pass of prompt micro-batches (k_fattn_combine_rows, 4- and 8-split forms)
+    (128, 32, 8, 64, 1024, 4, 0.0, 0.0, False),
+    (128, 32, 4, 80, 768, 6, 0.0, 0.0, False),
 ]
 
 
