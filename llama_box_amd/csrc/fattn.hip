@@ -866,8 +866,10 @@ template <int D, bool Q8OUT = false> __global__ void __launch_bounds__(Q8OUT ? 2
 // Few splits, many (token, head) rows — the combine pass behind the matrix-core kernel of a prompt micro-batch (512 tokens x 32 heads x 4 splits:
 // 16 384 rows): a thread per 4-dim chunk of a row, 8 rows per workgroup, every load of the thread (S float4 + S (m, l) pairs) requested at once.
 // The arithmetic is k_fattn_combine's: coefficients exp(m_s - max), values selected (not multiplied) where the coefficient is 0, sum in split order.
-template <int D, int S>
-__global__ void __launch_bounds__(256) k_fattn_combine_rows(const float * __restrict__ ws, const tdesc dst, const fa_geom geo, const int n_rows) {
+// Q8OUT: the rows' only readers are quantised mat-muls (wo): a wave holds two adjacent heads of a token = one Q8_K block, lane l its values
+// 4 l .. 4 l + 3 — the block is quantised in registers (wave_quantize_q8_K, the arithmetic of k_quantize_q8_K) and no f32 row is written.
+template <int D, int S, bool Q8OUT = false>
+__global__ void __launch_bounds__(256) k_fattn_combine_rows(const float * __restrict__ ws, const tdesc dst, const fa_geom geo, const int n_rows, q8k_dev * __restrict__ q8 = nullptr) {
     constexpr int CPR = D / 4;            // chunks (threads) per row
     constexpr int RPB = 256 / CPR;        // rows per workgroup
     const int r = (int) blockIdx.x * RPB + (int) threadIdx.x / CPR, j = (int) threadIdx.x % CPR;
@@ -900,22 +902,38 @@ __global__ void __launch_bounds__(256) k_fattn_combine_rows(const float * __rest
         a.w += c != 0.0f ? v[u].w * c : 0.0f;
     }
     const float inv = 1.0f / lt;
-    float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
-    *(float4 *) (out + 4 * j) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    if constexpr (Q8OUT) {
+        static_assert(D == 128, "two heads of 128 = one block");
+        const float t[4] = {a.x * inv, a.y * inv, a.z * inv, a.w * inv};
+        wave_quantize_q8_K(t, (int) threadIdx.x & 63, q8 + (r >> 1));  // (n_head and n_rows are even: the launcher checked)
+    } else {
+        float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+        *(float4 *) (out + 4 * j) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
 }
 
+// is the combine pass of this shape served by the row-parallel kernel (which also quantises for free)?
+bool fattn_combine_rows_applies(int D, int64_t n_q, int64_t n_head, int64_t n_batch, int n_splits, const float * sinks) {
+    static const bool rows_on = !getenv("GGML_MI355X_FA_COMBINE_ROWS") || atoi(getenv("GGML_MI355X_FA_COMBINE_ROWS")) != 0;
+    const int64_t n_rows = n_batch * n_q * n_head;
+    return rows_on && !sinks && D == 128 && n_splits >= 2 && n_splits <= 8 && n_rows >= 2048 && n_rows < (1 << 30);
+}
 void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits, void * q8_out) {
     fa_geom geo{};
     geo.n_q = n_q;
     geo.n_head = n_head;
     geo.n_splits = n_splits;
-    static const bool rows_on = !getenv("GGML_MI355X_FA_COMBINE_ROWS") || atoi(getenv("GGML_MI355X_FA_COMBINE_ROWS")) != 0;
     const int64_t n_rows = (int64_t) n_batch * n_q * n_head;
-    if (rows_on && !q8_out && !sinks && D == 128 && n_splits <= 8 && n_rows >= 2048 && n_rows < (1 << 30) && (dst.nb[1] % 16) == 0 && (dst.nb[2] % 16) == 0 && (dst.nb[3] % 16) == 0 &&
-        (((uintptr_t) dst.data) & 15) == 0 && (((uintptr_t) ws) & 7) == 0) {
+    if (fattn_combine_rows_applies(D, n_q, n_head, n_batch, n_splits, sinks) && (((uintptr_t) ws) & 7) == 0 &&
+        (q8_out ? (n_head % 2) == 0 : ((dst.nb[1] % 16) == 0 && (dst.nb[2] % 16) == 0 && (dst.nb[3] % 16) == 0 && (((uintptr_t) dst.data) & 15) == 0))) {
         const unsigned blocks = (unsigned) ((n_rows + 7) / 8);
-        if (n_splits <= 4) hipLaunchKernelGGL((k_fattn_combine_rows<128, 4>), dim3(blocks), dim3(256), 0, s, ws, dst, geo, (int) n_rows);
-        else hipLaunchKernelGGL((k_fattn_combine_rows<128, 8>), dim3(blocks), dim3(256), 0, s, ws, dst, geo, (int) n_rows);
+        if (q8_out) {
+            if (n_splits <= 4) hipLaunchKernelGGL((k_fattn_combine_rows<128, 4, true>), dim3(blocks), dim3(256), 0, s, ws, dst, geo, (int) n_rows, (q8k_dev *) q8_out);
+            else hipLaunchKernelGGL((k_fattn_combine_rows<128, 8, true>), dim3(blocks), dim3(256), 0, s, ws, dst, geo, (int) n_rows, (q8k_dev *) q8_out);
+        } else {
+            if (n_splits <= 4) hipLaunchKernelGGL((k_fattn_combine_rows<128, 4>), dim3(blocks), dim3(256), 0, s, ws, dst, geo, (int) n_rows, (q8k_dev *) nullptr);
+            else hipLaunchKernelGGL((k_fattn_combine_rows<128, 8>), dim3(blocks), dim3(256), 0, s, ws, dst, geo, (int) n_rows, (q8k_dev *) nullptr);
+        }
         return;
     }
     dim3 g2((unsigned) n_head, (unsigned) n_q, (unsigned) n_batch);

@@ -1644,7 +1644,11 @@ static int run_node(exec_state & st, int i) {
             // a batch's attention result read only by quantised mat-muls (wo), through the usual reshape: the combine pass writes
             // Q8_K blocks into the activation scratch instead of f32 (one launch less per layer)
             const ggml_tensor * q8_reader = nullptr;
-            if (fuse && c->opt.prologue && a->ne[1] > 1 && a->ne[1] <= 128 /* (launch-bound sizes: at 512 tokens the quantising combine is the slower pair) */ && use_count(st, n) == 1 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(n)) {
+            // (up to 128 tokens — launch-bound sizes — through the quantising form of the head-pair combine; bigger batches when the row-parallel
+            // combine serves them: it quantises in registers)
+            if (fuse && c->opt.prologue && a->ne[1] > 1 &&
+                (a->ne[1] <= 128 || (p.n_splits >= 2 && fattn_combine_rows_applies((int) k->ne[0], a->ne[1], a->ne[2], a->ne[3], p.n_splits, n->src[4] ? (const float *) n->src[4]->data : nullptr))) &&
+                use_count(st, n) == 1 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(n)) {
                 for (int k = i + 1; k < std::min(g->n_nodes, i + 4) && !q8_reader; ++k) {
                     const ggml_tensor * t = g->nodes[k];
                     if ((t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW) && t->src[0] == n && t->data == n->data && ggml_abi_is_contiguous(t) && t->ne[0] == n->ne[0] * n->ne[1] &&

@@ -267,6 +267,7 @@ struct fattn_params {
     int arrive_slots = 0;         // partial records (last workgroup to arrive) instead of a second launch; the kernel leaves them at zero
     const uint8_t * tile_vis = nullptr;  // matrix-core kernel: [q tile of 32][kv tile of 64] visibility bytes (launch_fattn_vis_scan), or nullptr
 };
+bool fattn_combine_rows_applies(int D, int64_t n_q, int64_t n_head, int64_t n_batch, int n_splits, const float * sinks);  // the row-parallel combine pass (prompt micro-batches)
 size_t fattn_vis_bytes(const tdesc & q, const tdesc & k);
 void launch_fattn_vis_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, uint8_t * vis);
 // few query tokens over a large unified cache (continuous batching): tile size for the tile-list attention kernel, 0 = not applicable
