@@ -233,14 +233,26 @@ void note_mask_upload(const ggml_tensor * t, const void * host, size_t offset, s
     };
     bool named = false;
     for (const char * p = t->name; *p && !named; ++p) named = (p[0] == 'm' || p[0] == 'M') && (p[1] == 'a' || p[1] == 'A') && (p[2] == 's' || p[2] == 'S') && (p[3] == 'k' || p[3] == 'K');
-    const bool whole = offset == 0 && t->ne[2] == 1 && t->ne[3] == 1 && (t->type == GGML_TYPE_F16 || t->type == GGML_TYPE_F32) && size == (size_t) t->nb[1] * (size_t) t->ne[1] &&
-                       t->nb[0] == (t->type == GGML_TYPE_F16 ? 2u : 4u);
-    // (2 MiB: a 160-token draft batch over a 6 k-cell cache; beyond that the scan itself would show in the step — such a mask is judged by shape)
-    if (!named || !whole || t->ne[1] < 2 || t->ne[1] > 256 || size > ((size_t) 2 << 20)) { forget(); return; }
-    const int64_t n = t->ne[0], rows = t->ne[1];
+    // whole rows from the first one on: the tensor, or its first n_tokens rows (the rows behind them are GGML_KQ_MASK_PAD padding that no kernel reads:
+    // a host that re-uses its graph uploads only the live rows every step — llama_lite.cpp does)
+    const bool whole = offset == 0 && t->ne[2] == 1 && t->ne[3] == 1 && (t->type == GGML_TYPE_F16 || t->type == GGML_TYPE_F32) && t->nb[1] > 0 && size % (size_t) t->nb[1] == 0 &&
+                       size <= (size_t) t->nb[1] * (size_t) t->ne[1] && t->nb[0] == (t->type == GGML_TYPE_F16 ? 2u : 4u);
+    // (16 MiB: a 160-token draft batch — 192 rows with padding — over a 40 k-cell cache; the 2 MiB of round 4's first cut lost the 10 k-cell cache of the
+    // bench's own `--np 32 --draft 4` line: 10.3 -> 12.1 ms per step on the dense kernel.  A sparse mask is read in full, ~0.1 ms per MiB on one host
+    // core; a dense one is given up as soon as a quarter of its cells have been seen visible)
+    if (!named || !whole || t->ne[1] < 2 || t->ne[1] > 256 || size > ((size_t) 16 << 20)) { forget(); return; }
+    const int64_t n = t->ne[0], rows = (int64_t) (size / (size_t) t->nb[1]);
+    if (rows < 2) { forget(); return; }
     mask_stats st;
     int64_t total = 0;
+    const int64_t dense_at = rows * n / 4 + 1;
     for (int64_t r = 0; r < rows; ++r) {
+        if (total >= dense_at) {  // dense whatever follows: density > 0.25 is all its readers ask (the longest row so far stands in for the rest)
+            st.rows = (int) rows;
+            st.max_visible = std::max(st.max_visible, (int) n);
+            total = rows * n;
+            break;
+        }
         int64_t vis = 0;
         if (t->type == GGML_TYPE_F16) {
             const uint16_t * m = (const uint16_t *) ((const char *) host + r * t->nb[1]);

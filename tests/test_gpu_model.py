@@ -371,6 +371,34 @@ def test_batch_shapes_head_dim_128(backend, H, plog, name, n_seq, n_tok):
         _free(cc, cg, mc, mg)
 
 
+def test_verification_batches_through_the_driver_walk_position_lists(backend, H, plog):
+    """Speculative-decoding steps as the DRIVER issues them (llm_verify_steps: 12 sequences x (1 + 3 drafts) = 48 positions per batch, the graph
+    re-used, only the live mask rows uploaded each step): the mask is sparse — a position sees its own sequence's cells of the unified cache —
+    and the backend must learn that from those partial uploads: every layer's attention of every step walks position lists (fa_list_launches),
+    not the dense matrix-core kernel.  (Round 4 lost this twice without a test noticing: a size cap, then the whole-tensor condition.)"""
+    hp = preset("test-llama", n_head=4, n_head_kv=2, n_embd=512, n_embd_head=128)
+    mg = Model(hp, 7, backend.buft)
+    n_par, n_draft, n_steps, n_prompt = 12, 3, 3, 40
+    cg = Context(mg, backend=backend, flash_attn=1, n_ctx=2048)
+    try:
+        rng = np.random.default_rng(5)
+        toks = rng.integers(1, hp.n_vocab, n_par * n_prompt).tolist()
+        rc, _ = cg.decode(toks, [i for _ in range(n_par) for i in range(n_prompt)], [k for k in range(n_par) for _ in range(n_prompt)], ([0] * (n_prompt - 1) + [1]) * n_par)
+        assert rc == 0
+        rows = [rng.integers(1, hp.n_vocab, n_par * (1 + n_draft)).tolist() for _ in range(n_steps)]
+        n0 = backend.stat("fa_list_launches")
+        backend.set_option("graphs", 0)  # (a replayed hipGraph runs the same kernels without passing the counters)
+        try:
+            assert cg.verify_steps(rows, n_par, n_draft, n_prompt) == 0
+        finally:
+            backend.set_option("graphs", 1)
+        n_list = backend.stat("fa_list_launches") - n0
+        plog(f"verification batches of {n_par} x {1 + n_draft} positions: {n_list} list-form attention launches in {n_steps} steps x {hp.n_layer} layers")
+        assert n_list == n_steps * hp.n_layer, n_list
+    finally:
+        _free(cg, mg)
+
+
 def test_kv_full_returns_1_and_bad_batch_minus_1(backend, H):
     hp = preset("test-llama")
     mg = Model(hp, 5, backend.buft)

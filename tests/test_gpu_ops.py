@@ -978,6 +978,38 @@ def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq
     T.compare(f"flash_attn block-diagonal D={HD} H={NH}/{NKV} nseq={nseq} per_seq={per_seq}", got[0], ref[0], max_nmse=1e-4, log=plog)
 
 
+def test_flash_attn_draft_batch_over_a_large_unified_cache_walks_position_lists(backend, H, plog):
+    """32 sequences x 5 positions (sampled token + 4 drafts: llama-box's verification batch) over a 10 k-cell unified cache: the mask — 192 rows
+    x 10 240 cells, 3.9 MB, named KQ_mask as in llama.cpp's graphs — is sparse, its statistics are taken when it is uploaded, and the batch
+    walks per-token position lists instead of multiplying every tile through the whole cache (round 4's first cut stopped looking at 2 MiB
+    and lost exactly the bench's `--np 32 --draft 4` line)."""
+    HD, NH, NKV, nseq, T1, per_seq = 128, 32, 8, 32, 5, 300
+    nq, nkv = nseq * T1, 10240
+    rng = np.random.default_rng(4242)
+    q = rng.standard_normal((NH, nq, HD)).astype(np.float32)
+    kc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    vc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
+    MR = (nq + 63) // 64 * 64
+    mask = np.full((MR, nkv), -np.inf, np.float16)
+    for sq in range(nseq):
+        for j in range(T1):
+            mask[sq * T1 + j, sq * per_seq: sq * per_seq + per_seq - 8 + j] = 0  # the sequence's cells up to this position
+    assert mask.nbytes > (2 << 20)
+
+    def build(g):
+        tq = g.new(L.F32, [HD, nq, NH], q)
+        k = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], kc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        v = H.ggml_view_3d(g.ctx, g.new(L.F16, [NKV * HD, nkv], vc), HD, nkv, NKV, NKV * HD * 2, HD * 2, 0)
+        r = H.ggml_flash_attn_ext(g.ctx, tq, k, v, g.new(L.F16, [nkv, MR], mask, name="KQ_mask"), 1.0 / np.sqrt(HD), 0.0, 0.0)
+        H.ggml_flash_attn_ext_set_prec(r, 10)
+        return r
+
+    n0 = backend.stat("fa_list_launches")
+    ref, got = both(build, backend)
+    assert backend.stat("fa_list_launches") == n0 + 1
+    T.compare("flash_attn draft batch 32 x 5 over 10240 cells", got[0], ref[0], max_nmse=1e-4, log=plog)
+
+
 @pytest.mark.parametrize("nseq,per_seq,nkv_dec", [(32, 64, 0), (5, 300, 0), (1, 0, 2100), (1, 0, 8192)])
 def test_flash_attn_self_merging_splits(backend, H, plog, nseq, per_seq, nkv_dec):
     """Option fa_self_merge (off by default — measured slower for one token, +1 % for -np 32): the last split workgroup of a
