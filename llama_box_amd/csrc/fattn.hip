@@ -821,11 +821,11 @@ template <int D, bool Q8OUT = false> __global__ void __launch_bounds__(Q8OUT ? 2
     // that left an empty record (coefficient 0) may hold anything there, so it is masked by a select, not by a multiply
     float r0[32], r1[32];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) r0[u] = u < geo.n_splits ? base[(int64_t) u * (D + 2) + dd] : 0.0f;
-    const bool second = geo.n_splits > 32;
+    for (int u = 0; u < 32; ++u) r0[u] = base[(int64_t) min(u, geo.n_splits - 1) * (D + 2) + dd];  // (clamped, not predicated: 32 branch-free requests; a split beyond
+    const bool second = geo.n_splits > 32;                                                        //  n_splits has coefficient 0 and is dropped by the select below)
     if (second) {
 #pragma unroll
-        for (int u = 0; u < 32; ++u) r1[u] = (32 + u) < geo.n_splits ? base[(int64_t) (32 + u) * (D + 2) + dd] : 0.0f;
+        for (int u = 0; u < 32; ++u) r1[u] = base[(int64_t) min(32 + u, geo.n_splits - 1) * (D + 2) + dd];
     }
     float mn = wave_max(ms);
     float sink_term = 0.0f;
