@@ -157,9 +157,9 @@ int main(int argc, char ** argv) {
             for (int i = 0; i < chain; ++i) {
                 qkv_args a{};
                 const uint8_t * base = pool + (size_t) i * mb;
-                a.seg[0] = {base, (int64_t) (K / 256) * ta.bytes, 0, NQ, nullptr, 1, 0, (char *) ((i & 1) ? xa : xb), 0};
-                a.seg[1] = {base + bq, (int64_t) (K / 256) * ta.bytes, 0, NKV, nullptr, 1, 1, (char *) kc, (int64_t) NKV * 2};
-                a.seg[2] = {base + bq + bk, (int64_t) (K / 256) * tb.bytes, tv == GGML_TYPE_Q4_K ? 0 : 1, NKV, nullptr, 0, 1, (char *) vc, (int64_t) NKV * 2};
+                a.seg[0] = {base, (int64_t) (K / 256) * ta.bytes, NQ, 0, 1, 0, 0, nullptr, (char *) ((i & 1) ? xa : xb), 0};
+                a.seg[1] = {base + bq, (int64_t) (K / 256) * ta.bytes, NKV, 0, 1, 1, 0, nullptr, (char *) kc, (int64_t) NKV * 2};
+                a.seg[2] = {base + bq + bk, (int64_t) (K / 256) * tb.bytes, NKV, (uint8_t) (tv == GGML_TYPE_Q4_K ? 0 : 1), 0, 1, 0, nullptr, (char *) vc, (int64_t) NKV * 2};
                 a.nseg = 3; a.K = K; a.x = (i & 1) ? xb : xa; a.norm_w = nw; a.eps = 1e-5f; a.norm_out = nullptr;
                 a.head_dim = HD; a.neox = 0; a.pos = dpos; a.freq_factors = nullptr;
                 rope_params rp{HD, 0, 8192, 500000.0f, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f, {0, 0, 0, 0}};
