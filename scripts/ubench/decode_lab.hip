@@ -9,7 +9,7 @@
 #include <string>
 #include "../../llama_box_amd/csrc/kernels.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
-namespace mi355x { int log_level() { return 1; } bool launch_mmvq_dma(hipStream_t s, const mmvq_args & a); /* scripts/ubench/experiments/mmvq_dma.hip */ }
+namespace mi355x { int log_level() { return 1; } int mask_sparse_hint(const void *) { return 0; } /* (backend.cpp's mask statistics: none in the lab) */ bool launch_mmvq_dma(hipStream_t s, const mmvq_args & a); /* scripts/ubench/experiments/mmvq_dma.hip */ }
 static int g_mode = 0;
 static void mmvq_set_dma(int on) { g_mode = on; }
 static void lab_launch(hipStream_t s, const mi355x::mmvq_args & a) { if (!g_mode || !mi355x::launch_mmvq_dma(s, a)) mi355x::launch_mmvq(s, a, 1); }
