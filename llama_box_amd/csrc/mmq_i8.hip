@@ -572,7 +572,9 @@ int launch_mmq_i8_multi(hipStream_t s, int type, int n_mat, const mmq_mat_desc *
     // panels (two independent 4-wave workgroups per CU, not behind one barrier) measure 2-3 % ahead on every prompt shape of the 8B
     // model; Q5_K (three pieces: the 64-row variant spills) and the 70B shapes measure 4-30 % ahead with 128
     const bool prefer128 = type == GGML_TYPE_Q5_K || K >= 8192;
-    const int bn = force_bn ? force_bn : (bm == 128 && wg128 >= 256 && a.ksplit == 1 && prefer128 ? 128 : 64);
+    // (with the K range split — ffn_down of a prompt micro-batch: 32 panels x 4 column tiles x 2 K halves — the splits count as workgroups too:
+    // Q6_K 14336 -> 4096 x 512 measures 102 -> 93-98 us on 128-row panels, round 4)
+    const int bn = force_bn ? force_bn : (bm == 128 && wg128 * std::max(1, a.ksplit) >= 256 && prefer128 ? 128 : 64);
     if (bm < 128 && bn == 64) {
 #define MMQ_SKINNY(QT)                                   \
     {                                                    \
