@@ -8,4 +8,10 @@ mkdir -p ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fvisibility=hidden -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DGGML_MAX_NAME=128 -I../include -Icsrc \
   -c ../scripts/ubench/experiments/mmq_skinny_wide_variants.hip -o /tmp/mmq_skinny_variants.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/wide_variants.so $(ls build/*.o | grep -v mmq_skinny.o) /tmp/mmq_skinny_variants.o -ldl -Wl,--no-undefined
+# (experiments/mmq_skinny_wide_async.hip — the barrier-free step loop, GGML_MI355X_MMQ_WIDE_ASYNC=1 — builds the same way: SRC=... below)
+if [ -n "${ASYNC:-}" ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fvisibility=hidden -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DGGML_MAX_NAME=128 -I../include -Icsrc \
+    -c ../scripts/ubench/experiments/mmq_skinny_wide_async.hip -o /tmp/mmq_skinny_async.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/wide_async.so $(ls build/*.o | grep -v mmq_skinny.o) /tmp/mmq_skinny_async.o -ldl -Wl,--no-undefined
+fi
 cp libggml-mi355x.so ab/a_product.so
