@@ -1249,4 +1249,6 @@ void launch_mmq_skinny(hipStream_t s, int type, const mmq8_args & a) {
     else launch_skinny_t<6>(s, a);
 }
 
+MI_TU_TOUCH(mmq_skinny)
+
 }  // namespace mi355x
