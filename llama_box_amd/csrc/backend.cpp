@@ -692,6 +692,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "allreduces") return c->st.allreduces;
     if (k == "ss_handoffs") return c->st.ss_handoffs;
     if (k == "fa_list_launches") return c->st.fa_list_launches;
+    if (k == "nf_mma_chains") return c->st.nf_mma_chains;
     if (k == "p2p_allreduces") return c->st.p2p_allreduces;
     if (k == "p2p_timeouts") return tp_p2p_timeouts(c);
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;

@@ -128,6 +128,7 @@ struct stats {
     int64_t skinny_launches = 0;       // mat-muls of 2..32 columns served by the weight-streaming matrix-core kernel
     int64_t wide_launches = 0;         // prompt-batch mat-muls served by its wide form
     int64_t tiled_launches = 0;        // batch mat-muls served by the LDS-tiled int8 GEMM (mmq_i8.hip)
+    int64_t nf_mma_chains = 0;         // non-flash K.q -> SOFT_MAX -> V^T.p chains of a prompt micro-batch served by the two-pass matrix-core kernel (round 4)
     int64_t fa_list_launches = 0;      // FLASH_ATTN_EXT nodes served over per-token position lists (2..32 tokens; 33..256 when the mask is known to be sparse)
     int64_t rope_epilogues = 0;        // batches whose rope + KV-cache stores rode in the skinny QKV launches
     int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)

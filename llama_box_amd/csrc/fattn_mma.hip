@@ -304,6 +304,254 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn_mma(const tdesc q, const t
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the NON-FLASH chain of a prompt micro-batch
+// llama-box runs with -fa off unless asked (engine_param.hpp:772-779): a prompt chunk then reaches the backend as
+//   kq = MUL_MAT(K view, q) -> p = SOFT_MAX(kq, mask f32, scale) -> MUL_MAT(V^T view, p)
+// — three dense launches over a [n_kv, tokens, heads] f32 score matrix (134 MB for 512 tokens x 2048 cells x 32 heads: 54 + 78 + 93 us per layer).
+// The same arithmetic on the tiling of k_fattn_mma, in two passes over the K tiles so that the softmax is ggml_compute_forward_soft_max_f32's and
+// not an online one: PASS 1 leaves (max, sum of e^(w - max)) per (query, head, KV split); PASS 2 combines those into the row's maximum and sum,
+// recomputes the scores, takes p = e^(w - max) * (1 / sum) — rounded to f16 where the CPU's second MUL_MAT rounds its src1 — and multiplies with
+// the TRANSPOSED V cache, whose rows need no transposition on the way into LDS.  Partial outputs of KV splits simply add (k_fattn_combine_rows
+// with coefficients 1).  llama-box's zero-sum guard (ggml-cpu.patch:5-15) and the NaN row of a query that sees nothing are kept.
+template <int D, int NW, int PASS>
+__global__ void __launch_bounds__(NW * 64, 2) k_attn_nf_mma(const tdesc q, const tdesc k, const tdesc vt, const tdesc mask, const tdesc dst, const fam_geom geo, float * __restrict__ stats,
+                                                         float * __restrict__ ws, const uint8_t * __restrict__ vis) {
+    constexpr int BKV = 64;
+    constexpr int KS = (D + 8) * 2, VS = (BKV + 4) * 2, NS = D / 16, ND = D / 32;
+    constexpr int T = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char * Kt = smem;
+    char * Vt = smem + BKV * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, kg = lane >> 5;
+    const int h = blockIdx.y, bat = blockIdx.z / geo.n_splits, split = blockIdx.z % geo.n_splits;
+    const int tiles = (geo.n_kv + BKV - 1) / BKV, tps = (tiles + geo.n_splits - 1) / geo.n_splits;
+    const int kv_begin = split * tps * BKV, kv_end = min(geo.n_kv, kv_begin + tps * BKV);
+    const int kvh = h / (geo.n_head / geo.n_kv_head);
+    const int qi = blockIdx.x * (NW * 32) + wave * 32 + fr;
+    const int qrow = min(qi, geo.n_q - 1);
+    const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / vt.ne[3]);
+    half8 qf[NS];
+    {
+        const float * qp = (const float *) (q.data + (int64_t) qrow * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a = *(const float4 *) (qp + 16 * s + 8 * kg), b = *(const float4 *) (qp + 16 * s + 8 * kg + 4);
+            qf[s] = (half8){(_Float16) a.x, (_Float16) a.y, (_Float16) a.z, (_Float16) a.w, (_Float16) b.x, (_Float16) b.y, (_Float16) b.z, (_Float16) b.w};
+        }
+    }
+    const float * mrow = (const float *) (mask.data + (int64_t) qrow * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]);
+    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3];
+    const char * vtbase = vt.data + (int64_t) kvh * vt.nb[2] + vb * vt.nb[3];  // row d of the head at + d * vt.nb[1], cells contiguous
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int64_t srow_id = ((int64_t) bat * geo.n_q + qrow) * geo.n_head + h;  // this lane's (query, head) row of the statistics / records
+
+    // PASS 2: the row's maximum and sum from the splits' statistics (ggml: max over the row, sum of expf(w - max), 1 / sum; zero-sum guard)
+    float m_g = -INFINITY, inv = 0.0f;
+    if constexpr (PASS == 2) {
+        const float * st = stats + srow_id * geo.n_splits * 2;
+        for (int u = 0; u < geo.n_splits; ++u) m_g = fmaxf(m_g, st[2 * u]);
+        double sum = 0.0;
+        for (int u = 0; u < geo.n_splits; ++u) {
+            const float mu = st[2 * u];
+            if (mu != -INFINITY) sum += (double) st[2 * u + 1] * (double) __builtin_amdgcn_exp2f((mu - m_g) * LOG2E);
+        }
+        if (m_g == -INFINITY) sum = __builtin_nan("");  // expf(-inf - -inf) in every cell
+        if (isnan(sum) || sum == 0.0) sum = -INFINITY;
+        inv = (float) (1.0 / sum);
+    }
+
+    float16v O[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] = 0.0f;
+    const float16v zero = O[0];
+    float m = -INFINITY, l = 0.0f;
+
+    const int srow = tid / NW, spart = tid % NW;
+    constexpr int CH = D / (8 * NW);
+    constexpr int VCH = D * 8 / T;  // 16-byte chunks of the V^T tile (D rows x 8 chunks of 8 cells) per thread
+    const int n_qt = (geo.n_q + 31) / 32;
+    const int kt_begin = kv_begin / BKV, kt_end = (kv_end + BKV - 1) / BKV;
+    uint8_t * const vst = (uint8_t *) (smem + BKV * KS + D * VS);
+    if (vis) {
+        const uint8_t * visrow = vis + (int64_t) (blockIdx.x * NW) * tiles;
+        for (int i = kt_begin + tid; i < kt_end; i += T) {
+            uint32_t b = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if ((int) blockIdx.x * NW + w < n_qt) b |= (uint32_t) (visrow[(int64_t) w * tiles + i] & 3) << (2 * w);
+            vst[i - kt_begin] = (uint8_t) b;
+        }
+        __syncthreads();
+    }
+    auto next_tile = [&](int kt) __attribute__((always_inline)) {
+        if (vis)
+            while (kt < kt_end && __builtin_amdgcn_readfirstlane((int) vst[kt - kt_begin]) == 0) ++kt;
+        return kt;
+    };
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v kr[CH];
+    u32x4v vr[PASS == 2 ? VCH : 1];
+    auto load_tile = [&](const int kt) __attribute__((always_inline)) {
+        const int kv0 = kt * BKV;
+        const int pos = min(kv0 + srow, geo.n_kv - 1);
+        const u32x4v * kp = (const u32x4v *) (kbase + (int64_t) pos * k.nb[1]) + spart * CH;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) kr[i] = kp[i];
+        if constexpr (PASS == 2) {
+#pragma unroll
+            for (int j = 0; j < VCH; ++j) {
+                const int c = tid + j * T, drow = c >> 3, kvc = c & 7;
+                // (cells past n_kv belong to the cache but not to this graph's view: they are given p = 0, and 0 x NaN must not happen)
+                const bool in = kv0 + 8 * kvc + 7 < geo.n_kv;
+                vr[j] = in ? *(const u32x4v *) (vtbase + (int64_t) drow * vt.nb[1] + (int64_t) (kv0 + 8 * kvc) * 2) : (u32x4v){0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) *(u32x4v *) (Kt + srow * KS + (spart * CH + i) * 16) = kr[i];
+        if constexpr (PASS == 2) {
+#pragma unroll
+            for (int j = 0; j < VCH; ++j) {
+                const int c = tid + j * T, drow = c >> 3, kvc = c & 7, sw = 2 * (drow >> 5);  // (the swizzle of k_fattn_mma's V^T image)
+                *(uint2 *) (Vt + drow * VS + 8 * ((2 * kvc) ^ sw)) = make_uint2(vr[j][0], vr[j][1]);
+                *(uint2 *) (Vt + drow * VS + 8 * ((2 * kvc + 1) ^ sw)) = make_uint2(vr[j][2], vr[j][3]);
+            }
+        }
+    };
+
+    int kt = next_tile(kt_begin);
+    if (kt < kt_end) load_tile(kt);
+    while (kt < kt_end) {
+        const int kv0 = kt * BKV;
+        const int mine = !vis ? 1 : (int) __builtin_amdgcn_readfirstlane((vst[kt - kt_begin] >> (2 * wave)) & 3);
+        const bool tail = kv0 + BKV > geo.n_kv;
+        __syncthreads();
+        store_tile();
+        float4 mw[2][4];
+        const bool use_mask = mine == 1;
+        if (use_mask) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) mw[t][g4] = *(const float4 *) (mrow + min(kv0 + 32 * t + 8 * g4 + 4 * kg, geo.n_kv - 4));
+        }
+        const int kt_next = next_tile(kt + 1);
+        if (kt_next < kt_end) load_tile(kt_next);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        kt = kt_next;
+        if (mine == 0) continue;
+        float16v S[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            S[t] = zero;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const half8 a = *(const half8 *) (Kt + (32 * t + fr) * KS + (16 * s + 8 * kg) * 2);
+                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
+            }
+        }
+        // w = kq * scale + mask (two roundings, as SOFT_MAX computes it)
+        if (use_mask || tail) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int p0 = kv0 + 32 * t + 8 * g4 + 4 * kg;
+                    const float mv[4] = {use_mask ? mw[t][g4].x : 0.0f, use_mask ? mw[t][g4].y : 0.0f, use_mask ? mw[t][g4].z : 0.0f, use_mask ? mw[t][g4].w : 0.0f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float w = S[t][4 * g4 + e] * geo.scale + mv[e];
+                        if (p0 + e >= geo.n_kv) w = -INFINITY;
+                        S[t][4 * g4 + e] = w;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[t][r] = S[t][r] * geo.scale;
+        }
+        if constexpr (PASS == 1) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            if (__all(m_new == -INFINITY)) continue;
+            const float mref = m_new == -INFINITY ? 0.0f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m - mref) * LOG2E);
+            float rs = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rs += __builtin_amdgcn_exp2f((S[t][r] - mref) * LOG2E);
+            rs += __shfl_xor(rs, 32, 64);
+            l = l * alpha + rs;
+            m = m_new;
+        } else {
+            if (__all(m_g == -INFINITY)) continue;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    half8 pb;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pb[u] = (_Float16) (__builtin_amdgcn_exp2f((S[t][8 * s2 + u] - m_g) * LOG2E) * inv);
+                    const int kvg = 8 * t + 4 * s2 + kg;
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) {
+                        const char * vrow = Vt + (32 * dt + fr) * VS;
+                        const half4v a0 = *(const half4v *) (vrow + 8 * (kvg ^ (2 * dt))), a1 = *(const half4v *) (vrow + 8 * ((kvg + 2) ^ (2 * dt)));
+                        const half8 a = (half8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                        O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, O[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (qi >= geo.n_q) return;
+    if constexpr (PASS == 1) {
+        if (kg == 0) {
+            float * st = stats + (srow_id * geo.n_splits + split) * 2;
+            st[0] = m;
+            st[1] = l;
+        }
+    } else {
+        const bool nan_row = m_g == -INFINITY;  // the query sees nothing: the CPU's row is NaN throughout
+        if (geo.n_splits == 1) {
+            float * out = (float *) (dst.data + (int64_t) h * dst.nb[1] + (int64_t) qi * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = 32 * dt + 8 * g4 + 4 * kg;
+                    const float nn = __builtin_nanf("");
+                    *(float4 *) (out + d0) = nan_row ? make_float4(nn, nn, nn, nn) : make_float4(O[dt][4 * g4], O[dt][4 * g4 + 1], O[dt][4 * g4 + 2], O[dt][4 * g4 + 3]);
+                }
+        } else {  // a record k_fattn_combine_rows adds to the other splits': coefficient e^(0 - 0) = 1 each, sum of the "l" fields = 1
+            float * rec = ws + (srow_id * geo.n_splits + split) * (D + 2);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = 32 * dt + 8 * g4 + 4 * kg;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rec[d0 + e] = nan_row ? __builtin_nanf("") : O[dt][4 * g4 + e];
+                }
+            if (kg == 0) {
+                rec[D] = 0.0f;
+                rec[D + 1] = split == 0 ? 1.0f : 0.0f;
+            }
+        }
+    }
+}
+
 // returns false when this variant does not apply (caller falls back to the split-KV kernel)
 int fattn_mma_pick_splits(const tdesc & q, const tdesc & k) {
     const int64_t qt = q.ne[1] >= 256 ? 128 : 64;
@@ -315,6 +563,7 @@ int fattn_mma_pick_splits(const tdesc & q, const tdesc & k) {
 }
 // a wave per (32-query tile, 64-cell tile): lane = (mask row, half of the 64 cells), 64 bytes each — coalesced, where the first version
 // walked 32 rows per THREAD (86 us per micro-batch of 512 x 2048).  Result: 0 = nothing visible, 2 = every value +0.0, 1 = otherwise.
+template <bool F32>  // (the mask of the non-flash path is f32: rows 16-byte aligned there)
 __global__ void __launch_bounds__(256) k_fattn_vis_scan(const tdesc mask, const int n_q, const int n_kv, uint8_t * __restrict__ vis) {
     const int qt = blockIdx.x, tiles = (n_kv + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -323,6 +572,17 @@ __global__ void __launch_bounds__(256) k_fattn_vis_scan(const tdesc mask, const 
     for (int kt = blockIdx.y * 4 + wave; kt < tiles; kt += gridDim.y * 4) {
         bool any = false, zero = true;
         if (qi < n_q) {
+            if constexpr (F32) {
+                const uint32_t * mrow = (const uint32_t *) (mask.data + (int64_t) qi * mask.nb[1]) + kt * 64 + half * 32;
+#pragma unroll
+                for (int c = 0; c < 32; c += 4) {
+                    if (kt * 64 + half * 32 + c < n_kv) {
+                        const uint4 w = *(const uint4 *) (mrow + c);
+                        any = any || w.x != 0xFF800000u || w.y != 0xFF800000u || w.z != 0xFF800000u || w.w != 0xFF800000u;
+                        zero = zero && (w.x | w.y | w.z | w.w) == 0u;
+                    }
+                }
+            } else {
             const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) qi * mask.nb[1]) + kt * 64 + half * 32;
 #pragma unroll
             for (int c = 0; c < 32; c += 4) {  // n_kv % 4 == 0 and rows 8-byte aligned (launcher)
@@ -332,6 +592,7 @@ __global__ void __launch_bounds__(256) k_fattn_vis_scan(const tdesc mask, const 
                     zero = zero && (w.x | w.y) == 0u;
                 }
             }
+            }
         }
         const bool w_any = __any(any), w_zero = __all(zero) && (kt + 1) * 64 <= n_kv;
         if (lane == 0) vis[(int64_t) qt * tiles + kt] = !w_any ? 0 : (w_zero ? 2 : 1);
@@ -340,7 +601,8 @@ __global__ void __launch_bounds__(256) k_fattn_vis_scan(const tdesc mask, const 
 size_t fattn_vis_bytes(const tdesc & q, const tdesc & k) { return (size_t) ((q.ne[1] + 31) / 32) * (size_t) ((k.ne[1] + 63) / 64); }
 void launch_fattn_vis_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, uint8_t * vis) {
     const int tiles = (n_kv + 63) / 64;
-    hipLaunchKernelGGL(k_fattn_vis_scan, dim3((unsigned) ((n_q + 31) / 32), (unsigned) std::min(64, (tiles + 3) / 4)), dim3(256), 0, s, mask, n_q, n_kv, vis);
+    if (mask.type == GGML_TYPE_F32) hipLaunchKernelGGL(k_fattn_vis_scan<true>, dim3((unsigned) ((n_q + 31) / 32), (unsigned) std::min(64, (tiles + 3) / 4)), dim3(256), 0, s, mask, n_q, n_kv, vis);
+    else hipLaunchKernelGGL(k_fattn_vis_scan<false>, dim3((unsigned) ((n_q + 31) / 32), (unsigned) std::min(64, (tiles + 3) / 4)), dim3(256), 0, s, mask, n_q, n_kv, vis);
 }
 int fattn_mma_min_q() {
     // up to 32 query tokens are served per token (tile-list / lane-parallel kernels): a -np 32 decode step has 32 tokens that
@@ -385,6 +647,50 @@ bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, cons
     }
     if (geo.n_splits > 1) launch_flash_attn_combine(s, (int) k.ne[0], ws, sinks, dst, (int) q.ne[1], (int) q.ne[2], (int) q.ne[3], geo.n_splits, p.q8_out);
     return true;
+}
+
+// ---- the non-flash chain of a prompt micro-batch (k_attn_nf_mma): applicability, workspace, launch
+bool attn_nf_mma_applies(const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask) {
+    static const bool on = !getenv("GGML_MI355X_ATTN_NF_MMA") || atoi(getenv("GGML_MI355X_ATTN_NF_MMA")) != 0;
+    const int64_t D = k.ne[0];
+    if (!on || D != 128 || q.ne[1] < fattn_mma_min_q() || q.ne[3] != 1 || k.ne[3] != 1 || vt.ne[3] != 1 || k.type != GGML_TYPE_F16 || vt.type != GGML_TYPE_F16 || q.type != GGML_TYPE_F32 ||
+        mask.type != GGML_TYPE_F32)
+        return false;
+    if (k.ne[2] <= 0 || q.ne[2] % k.ne[2] != 0 || vt.ne[2] != k.ne[2] || vt.ne[0] != k.ne[1] || vt.ne[1] != D || (k.ne[1] % 8) != 0) return false;
+    if ((q.nb[1] % 16) || (q.nb[2] % 16) || (((uintptr_t) q.data) & 15) || k.nb[0] != 2 || (k.nb[1] % 16) || (k.nb[2] % 16) || (((uintptr_t) k.data) & 15)) return false;
+    if (vt.nb[0] != 2 || (vt.nb[1] % 16) || (vt.nb[2] % 16) || (((uintptr_t) vt.data) & 15) || (mask.nb[1] % 16) || (((uintptr_t) mask.data) & 15) || mask.ne[0] < k.ne[1] || mask.ne[1] < q.ne[1]) return false;
+    return true;
+}
+size_t attn_nf_mma_ws_bytes(const tdesc & q, int n_splits) {  // [statistics: rows x splits x 2][records: rows x splits x (D + 2)]
+    const size_t rows = (size_t) q.ne[1] * (size_t) q.ne[2];
+    return ((rows * (size_t) n_splits * 2 * sizeof(float) + 255) & ~(size_t) 255) + (n_splits > 1 ? rows * (size_t) n_splits * (128 + 2) * sizeof(float) : 0);
+}
+// dst: the result as [D, head, token] strides in nb[1] (head) / nb[2] (token) — the caller passes kqv's or the CONT copy's layout that way
+void launch_attn_nf_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask, const tdesc & dst, float scale, int n_splits, const uint8_t * tile_vis, void * workspace) {
+    fam_geom geo;
+    geo.n_q = (int) q.ne[1];
+    geo.n_head = (int) q.ne[2];
+    geo.n_kv_head = (int) k.ne[2];
+    geo.n_kv = (int) k.ne[1];
+    geo.has_mask = 1;
+    geo.scale = scale;
+    geo.n_splits = std::max(1, n_splits);
+    const size_t rows = (size_t) q.ne[1] * (size_t) q.ne[2];
+    float * stats = (float *) workspace;
+    float * recs = (float *) ((char *) workspace + ((rows * (size_t) geo.n_splits * 2 * sizeof(float) + 255) & ~(size_t) 255));
+    const int tiles_all = (geo.n_kv + 63) / 64, tps = (tiles_all + geo.n_splits - 1) / geo.n_splits;
+    const uint8_t * const vis = tps <= 16384 ? tile_vis : nullptr;
+    const size_t lds = 64 * (128 + 8) * 2 + 128 * (64 + 4) * 2 + (vis ? (size_t) ((tps + 15) & ~15) : 0);
+    const int nw = geo.n_q >= 256 ? 4 : 2;
+    dim3 grid((unsigned) ((geo.n_q + nw * 32 - 1) / (nw * 32)), (unsigned) geo.n_head, (unsigned) geo.n_splits);
+    if (nw == 4) {
+        hipLaunchKernelGGL((k_attn_nf_mma<128, 4, 1>), grid, dim3(256), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
+        hipLaunchKernelGGL((k_attn_nf_mma<128, 4, 2>), grid, dim3(256), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
+    } else {
+        hipLaunchKernelGGL((k_attn_nf_mma<128, 2, 1>), grid, dim3(128), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
+        hipLaunchKernelGGL((k_attn_nf_mma<128, 2, 2>), grid, dim3(128), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
+    }
+    if (geo.n_splits > 1) launch_flash_attn_combine(s, 128, recs, nullptr, dst, geo.n_q, geo.n_head, 1, geo.n_splits, nullptr);
 }
 
 MI_TU_TOUCH(fattn_mma)

@@ -162,6 +162,9 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
         } else if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_F16) {
             p.aux_bytes = std::max(p.aux_bytes, mul_mat_f_workspace_bytes(TD(n->src[0]), TD(n->src[1])));
             if (c->opt.attn_nf) p.aux_bytes = std::max(p.aux_bytes, attn_nf_list_scratch_bytes(TD(n->src[1]), TD(n->src[0]), nullptr));
+            // (K.q of a prompt micro-batch on the non-flash path: statistics + partial records of the two-pass matrix-core form)
+            if (c->opt.attn_nf && n->src[1]->type == GGML_TYPE_F32 && n->src[1]->ne[1] >= 256 && n->src[0]->ne[0] == 128 && n->src[1]->ne[3] == 1)
+                p.aux_bytes = std::max(p.aux_bytes, attn_nf_mma_ws_bytes(TD(n->src[1]), fattn_mma_pick_splits(TD(n->src[1]), TD(n->src[0]))));
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
             // (both forms a 33+-token batch may take — matrix-core tiles or, for a mask known to be sparse, position lists — fit this)
@@ -1284,6 +1287,84 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
     return true;
 }
 
+// The same chain for a prompt micro-batch (256 tokens and more): two passes of the matrix-core kernel k_attn_nf_mma (fattn_mma.hip) — the row maxima
+// and sums, then p = e / sum and V^T.p — instead of three dense launches over the [n_kv, tokens, heads] score matrix (round 4).  At node i = kq.
+static bool try_fuse_attn_nf_mma(exec_state & st, int i) {
+    backend_ctx * c = st.c;
+    ggml_cgraph * g = st.g;
+    const ggml_tensor * kq = g->nodes[i];
+    const ggml_tensor * K = kq->src[0], * Q = kq->src[1];
+    if (!c->fa_lists || !c->ws || K->type != GGML_TYPE_F16 || Q->type != GGML_TYPE_F32 || Q->ne[1] < 256 || !single_use(st, kq)) return false;
+    if (buffer_is_split(K->buffer)) return false;
+    auto next_real = [&](int from) {
+        for (int k = from; k < std::min(g->n_nodes, from + 6); ++k) {
+            if (st.done[k] || is_view_op(g->nodes[k])) continue;
+            return k;
+        }
+        return -1;
+    };
+    const int js = next_real(i + 1);
+    if (js < 0) return false;
+    const ggml_tensor * sm = g->nodes[js];
+    if (sm->op != GGML_OP_SOFT_MAX || sm->src[0] != kq || !sm->src[1] || sm->src[2] || ggml_abi_op_param_f32(sm, 1) != 0.0f || !single_use(st, sm)) return false;
+    const int jv = next_real(js + 1);
+    if (jv < 0) return false;
+    const ggml_tensor * kqv = g->nodes[jv];
+    if (kqv->op != GGML_OP_MUL_MAT || kqv->src[1] != sm || kqv->src[0]->type != GGML_TYPE_F16 || kqv->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(kqv)) return false;
+    const ggml_tensor * V = kqv->src[0], * M = sm->src[1];
+    if (buffer_is_split(V->buffer) || M->ne[2] != 1 || M->ne[3] != 1) return false;
+    const tdesc qd = TD(Q), kd = TD(K), vd = TD(V), md = TD(M);
+    if (!attn_nf_mma_applies(qd, kd, vd, md) || fattn_vis_bytes(qd, kd) > c->fa_lists_bytes) return false;
+    // where the rows go: kqv [D, T, NH], or — when CONT(PERMUTE(kqv, 0, 2, 1, 3)) is its only reader — that copy [D * NH, T] (try_fuse_attn_nf has the
+    // aliasing argument: the copy is usually q's recycled block and holds the SAME rows; a workgroup reads its queries before anything is written)
+    tdesc od = TD(kqv);
+    od.nb[1] = kqv->nb[2];  // (the kernel's dst: nb[1] = head stride, nb[2] = token stride)
+    od.nb[2] = kqv->nb[1];
+    int jc = -1;
+    if (single_use(st, kqv)) {
+        const int jn = next_real(jv + 1);
+        if (jn >= 0) {
+            const ggml_tensor * ct = g->nodes[jn];
+            const ggml_tensor * pv = ct->src[0];
+            if (ct->op == GGML_OP_CONT && pv && pv->op == GGML_OP_PERMUTE && pv->src[0] == kqv && pv->data == kqv->data && ct->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(ct) &&
+                pv->ne[0] == kqv->ne[0] && pv->ne[1] == kqv->ne[2] && pv->ne[2] == kqv->ne[1] && pv->ne[3] == 1 && ggml_abi_nelements(ct) == ggml_abi_nelements(kqv)) {
+                const int64_t tok_nb = (int64_t) kqv->ne[0] * kqv->ne[2] * 4, head_nb = (int64_t) kqv->ne[0] * 4;
+                const bool same_rows = ct->data == Q->data && Q->nb[0] == 4 && (int64_t) Q->nb[1] == tok_nb && (int64_t) Q->nb[2] == head_nb;
+                const bool clear_of_inputs = !ranges_overlap(ct, M) && !ranges_overlap(ct, K) && !ranges_overlap(ct, V);
+                if (clear_of_inputs && (!ranges_overlap(ct, Q) || same_rows) && (((uintptr_t) ct->data) & 15) == 0) {
+                    jc = jn;
+                    od.data = (char *) ct->data;
+                    od.nb[0] = 4;
+                    od.nb[1] = head_nb;
+                    od.nb[2] = tok_nb;
+                }
+            }
+        }
+    }
+    if (jc < 0 && (ranges_overlap(kqv, Q) || (((uintptr_t) kqv->data) & 15) != 0)) return false;
+    const int n_splits = fattn_mma_pick_splits(qd, kd);
+    const size_t need = attn_nf_mma_ws_bytes(qd, n_splits);
+    if (need > c->ws_size - st.aux_off) return false;
+    if (st.fa_list_mask != M->data || st.fa_list_tile != -1) {  // first attention of this graph run: the (query tile, kv tile) states
+        launch_fattn_vis_scan(c->stream, md, (int) Q->ne[1], (int) K->ne[1], (uint8_t *) c->fa_lists);
+        c->st.kernel_launches++;
+        st.fa_list_mask = M->data;
+        st.fa_list_tile = -1;
+    }
+    timed_scope ts(c, "attn_nf_mma", (double) ggml_abi_nbytes(kqv));
+    launch_attn_nf_mma(c->stream, qd, kd, vd, md, od, ggml_abi_op_param_f32(sm, 0), n_splits, (const uint8_t *) c->fa_lists, (char *) c->ws + st.aux_off);
+    c->st.kernel_launches += n_splits > 1 ? 3 : 2;
+    c->st.nf_mma_chains++;
+    mark_done(st, js);
+    mark_done(st, jv);
+    c->st.fused_nodes += 2;
+    if (jc >= 0) {
+        mark_done(st, jc);
+        c->st.fused_nodes++;
+    }
+    return true;
+}
+
 static int run_node(exec_state & st, int i) {
     backend_ctx * c = st.c;
     ggml_cgraph * g = st.g;
@@ -1348,6 +1429,7 @@ static int run_node(exec_state & st, int i) {
 
         case GGML_OP_MUL_MAT: {
             if (!is_quant(a->type) && fuse && c->opt.attn_nf && try_fuse_attn_nf(st, i)) return 1;
+            if (!is_quant(a->type) && fuse && c->opt.attn_nf && try_fuse_attn_nf_mma(st, i)) return 1;
             if (!is_quant(a->type)) {
                 timed_scope ts(c, "mul_mat_f", (double) ggml_abi_nbytes(a));
                 launch_mul_mat_f(s, TD(a), TD(b), TD(n), (float *) ((char *) c->ws + st.aux_off), c->ws ? c->ws_size - st.aux_off : 0);
