@@ -666,7 +666,8 @@ size_t attn_nf_mma_ws_bytes(const tdesc & q, int n_splits) {  // [statistics: ro
     return ((rows * (size_t) n_splits * 2 * sizeof(float) + 255) & ~(size_t) 255) + (n_splits > 1 ? rows * (size_t) n_splits * (128 + 2) * sizeof(float) : 0);
 }
 // dst: the result as [D, head, token] strides in nb[1] (head) / nb[2] (token) — the caller passes kqv's or the CONT copy's layout that way
-void launch_attn_nf_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask, const tdesc & dst, float scale, int n_splits, const uint8_t * tile_vis, void * workspace) {
+void launch_attn_nf_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask, const tdesc & dst, float scale, int n_splits, const uint8_t * tile_vis, void * workspace,
+                        void * q8_out) {
     fam_geom geo;
     geo.n_q = (int) q.ne[1];
     geo.n_head = (int) q.ne[2];
@@ -690,7 +691,7 @@ void launch_attn_nf_mma(hipStream_t s, const tdesc & q, const tdesc & k, const t
         hipLaunchKernelGGL((k_attn_nf_mma<128, 2, 1>), grid, dim3(128), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
         hipLaunchKernelGGL((k_attn_nf_mma<128, 2, 2>), grid, dim3(128), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
     }
-    if (geo.n_splits > 1) launch_flash_attn_combine(s, 128, recs, nullptr, dst, geo.n_q, geo.n_head, 1, geo.n_splits, nullptr);
+    if (geo.n_splits > 1) launch_flash_attn_combine(s, 128, recs, nullptr, dst, geo.n_q, geo.n_head, 1, geo.n_splits, q8_out);  // (q8_out: only where the row-parallel form applies — the caller checked)
 }
 
 MI_TU_TOUCH(fattn_mma)

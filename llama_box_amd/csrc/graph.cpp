@@ -1351,8 +1351,17 @@ static bool try_fuse_attn_nf_mma(exec_state & st, int i) {
         st.fa_list_mask = M->data;
         st.fa_list_tile = -1;
     }
+    // the copy is read only by quantised mat-muls (wo) and the splits' sum is the row-parallel combine: it writes the Q8_K blocks itself
+    void * q8_out = nullptr;
+    if (jc >= 0 && n_splits > 1 && (Q->ne[2] % 2) == 0 && c->opt.prologue && !(g->nodes[jc]->flags & GGML_TENSOR_FLAG_OUTPUT) && quant_consumers_only(st, jc, g->nodes[jc]) &&
+        fattn_combine_rows_applies(128, Q->ne[1], Q->ne[2], 1, n_splits, nullptr))
+        q8_out = (char *) c->ws + st.act_off;
     timed_scope ts(c, "attn_nf_mma", (double) ggml_abi_nbytes(kqv));
-    launch_attn_nf_mma(c->stream, qd, kd, vd, md, od, ggml_abi_op_param_f32(sm, 0), n_splits, (const uint8_t *) c->fa_lists, (char *) c->ws + st.aux_off);
+    launch_attn_nf_mma(c->stream, qd, kd, vd, md, od, ggml_abi_op_param_f32(sm, 0), n_splits, (const uint8_t *) c->fa_lists, (char *) c->ws + st.aux_off, q8_out);
+    if (q8_out) {
+        mark_q8_cache(st, g->nodes[jc]);
+        c->st.fused_nodes++;
+    }
     c->st.kernel_launches += n_splits > 1 ? 3 : 2;
     c->st.nf_mma_chains++;
     mark_done(st, js);

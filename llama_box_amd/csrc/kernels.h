@@ -270,7 +270,8 @@ struct fattn_params {
 // the non-flash chain (K.q -> SOFT_MAX -> V^T.p) of a prompt micro-batch on the matrix cores, two passes (fattn_mma.hip: k_attn_nf_mma)
 bool attn_nf_mma_applies(const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask);
 size_t attn_nf_mma_ws_bytes(const tdesc & q, int n_splits);
-void launch_attn_nf_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask, const tdesc & dst, float scale, int n_splits, const uint8_t * tile_vis, void * workspace);
+void launch_attn_nf_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask, const tdesc & dst, float scale, int n_splits, const uint8_t * tile_vis, void * workspace,
+                        void * q8_out = nullptr);
 bool fattn_combine_rows_applies(int D, int64_t n_q, int64_t n_head, int64_t n_batch, int n_splits, const float * sinks);  // the row-parallel combine pass (prompt micro-batches)
 size_t fattn_vis_bytes(const tdesc & q, const tdesc & k);
 void launch_fattn_vis_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, uint8_t * vis);

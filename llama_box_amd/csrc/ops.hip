@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(256) k_rope_qk_store(const rope_store_args a) 
 // rotation: two adjacent pairs) or 4 + 4 dims half a head apart (NeoX) — of every query / key / value head; ALL of a thread's loads are
 // requested first (the per-slot loop above waits one L2 round trip per head slot: 14 us for 512 tokens of Llama-3-8B against 23 MB of traffic),
 // and (cos, sin) come from the per-graph-run table of k_rope_table (the chain of multiplies and the accurate cosf / sinf once per run, not once
-// per layer).  Requires: whole heads rotated (n_dims == head_dim), head_dim % 8 == 0, projections in memory (no split-K partials), row-major V cache.
+// per layer).  Requires: whole heads rotated (n_dims == head_dim), head_dim % 8 == 0, projections in memory (no split-K partials); the V cache row-major, or transposed with llama.cpp's per-element indices (non-flash path).
 // The arithmetic per element is that of k_rope_qk_store (x0 cs - x1 sn, x0 sn + x1 cs; f2h for the cache rows).
 template <bool NEOX>
 __global__ void __launch_bounds__(256) k_rope_qk_store_vec(const rope_store_args a, const float * __restrict__ tab) {
@@ -623,21 +623,31 @@ __global__ void __launch_bounds__(256) k_rope_qk_store_vec(const rope_store_args
                 }
             } else if (c < n_rot + n_v) {
                 const int cv = c - n_rot, h = cv / (hd / 4), j = cv - h * (hd / 4);
-                uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * hd;
-                *(uint2 *) (dst + 4 * j) = make_uint2((uint32_t) f2h(lo[k].x) | ((uint32_t) f2h(lo[k].y) << 16), (uint32_t) f2h(lo[k].z) | ((uint32_t) f2h(lo[k].w) << 16));
+                if (a.v_idx) {  // the transposed V cache of the non-flash path: one element index per value (llama.cpp's v_idxs)
+                    const int64_t * ix = a.v_idx + ((int64_t) t * a.nkv + h) * hd + 4 * j;
+                    const int64_t i0 = ix[0], i1 = ix[1], i2 = ix[2], i3 = ix[3];
+                    uint16_t * vc = (uint16_t *) a.v_cache;
+                    vc[i0] = f2h(lo[k].x);
+                    vc[i1] = f2h(lo[k].y);
+                    vc[i2] = f2h(lo[k].z);
+                    vc[i3] = f2h(lo[k].w);
+                } else {
+                    uint16_t * dst = (uint16_t *) (a.v_cache + row * a.vc_nb1) + (int64_t) h * hd;
+                    *(uint2 *) (dst + 4 * j) = make_uint2((uint32_t) f2h(lo[k].x) | ((uint32_t) f2h(lo[k].y) << 16), (uint32_t) f2h(lo[k].z) | ((uint32_t) f2h(lo[k].w) << 16));
+                }
             }
         }
     }
 }
 bool rope_qk_store_vec_ok(const rope_store_args & a, int n_tokens) {
     static const bool on = !getenv("GGML_MI355X_ROPE_VEC") || atoi(getenv("GGML_MI355X_ROPE_VEC")) != 0;
-    if (!on || n_tokens < 33 || a.v_idx != nullptr || a.ks > 1 || a.sk[0].part || a.sk[1].part || a.sk[2].part) return false;
+    if (!on || n_tokens < 33 || a.ks > 1 || a.sk[0].part || a.sk[1].part || a.sk[2].part) return false;
     if ((a.p.mode & ~GGML_ROPE_TYPE_NEOX) != 0 || a.p.n_dims != a.head_dim || (a.head_dim % 8) != 0) return false;
     auto al16 = [](const void * p) { return (((uintptr_t) p) & 15) == 0; };
     if (!al16(a.q_src) || !al16(a.q_dst) || !al16(a.k_src) || !al16(a.v_src) || !al16(a.k_cache) || !al16(a.v_cache)) return false;
     for (int64_t v : {a.q_nb1, a.q_nb2, a.qd_nb1, a.qd_nb2, a.k_nb1, a.k_nb2, a.v_nb1, a.v_nb2})
         if (v % 16) return false;
-    return (a.kc_nb1 % 8) == 0 && (a.vc_nb1 % 8) == 0;
+    return (a.kc_nb1 % 8) == 0 && (a.v_idx != nullptr || (a.vc_nb1 % 8) == 0);
 }
 void launch_rope_qk_store_vec(hipStream_t s, const rope_store_args & a, int n_tokens, const float * tab) {
     if (a.p.mode & GGML_ROPE_TYPE_NEOX) hipLaunchKernelGGL(k_rope_qk_store_vec<true>, dim3((unsigned) n_tokens), dim3(256), 0, s, a, tab);

@@ -1315,11 +1315,11 @@ def test_batch_rope_and_cache_stores_one_launch(backend, H, plog, mode, n_dims, 
                   max_nmse=1e-6 if name != "q_rope" else 1e-10, log=plog)
 
 
-@pytest.mark.parametrize("T_", [32, 130])
+@pytest.mark.parametrize("T_", [32, 130, 512])
 def test_batch_rope_and_transposed_v_store_one_launch(backend, H, plog, T_):
     """The same window on the non-flash path: the V store is a scatter of single elements into the transposed cache (an index per element)."""
     rng = np.random.default_rng(43 + T_)
-    HD, NH, NKV, NCTX = 128, 8, 2, 300
+    HD, NH, NKV, NCTX = 128, 8, 2, max(300, T_ + 40)
     q = rng.standard_normal((T_, NH, HD)).astype(np.float32)
     k = rng.standard_normal((T_, NKV, HD)).astype(np.float32)
     v = rng.standard_normal((T_, NKV * HD)).astype(np.float32)
@@ -1351,7 +1351,7 @@ def test_batch_rope_and_transposed_v_store_one_launch(backend, H, plog, T_):
         plain = T.run_case(build, backend)
     finally:
         backend.set_option("fusion", 1)
-    assert launches == 1, launches
+    assert launches == (2 if T_ >= 33 else 1), launches  # (from 33 tokens: the vectorised store + the (cos, sin) table's launch)
     for name, a, b, c in zip(("q_rope", "k_cache", "v_cache_T"), got, ref, plain):
         assert np.array_equal(np.asarray(a), np.asarray(c)), f"{name}: fused and unfused differ"
         T.compare(f"batch rope + transposed V store T={T_} {name}", np.asarray(a).astype(np.float32), np.asarray(b).astype(np.float32),
