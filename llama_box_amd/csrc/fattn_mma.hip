@@ -431,9 +431,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_nf_mma(const tdesc q, const
         const bool tail = kv0 + BKV > geo.n_kv;
         __syncthreads();
         store_tile();
+        // (64-query workgroups — batches below 256 tokens — hold twice the staging registers per thread: their mask words are read where they are used,
+        // behind the barrier, instead of a tile ahead)
+        constexpr bool MASK_EARLY = NW == 4;
         float4 mw[2][4];
         const bool use_mask = mine == 1;
-        if (use_mask) {
+        if (MASK_EARLY && use_mask) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -461,6 +464,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_nf_mma(const tdesc q, const
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int p0 = kv0 + 32 * t + 8 * g4 + 4 * kg;
+                    if (!MASK_EARLY && use_mask) mw[t][g4] = *(const float4 *) (mrow + min(p0, geo.n_kv - 4));
                     const float mv[4] = {use_mask ? mw[t][g4].x : 0.0f, use_mask ? mw[t][g4].y : 0.0f, use_mask ? mw[t][g4].z : 0.0f, use_mask ? mw[t][g4].w : 0.0f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -682,15 +686,12 @@ void launch_attn_nf_mma(hipStream_t s, const tdesc & q, const tdesc & k, const t
     const int tiles_all = (geo.n_kv + 63) / 64, tps = (tiles_all + geo.n_splits - 1) / geo.n_splits;
     const uint8_t * const vis = tps <= 16384 ? tile_vis : nullptr;
     const size_t lds = 64 * (128 + 8) * 2 + 128 * (64 + 4) * 2 + (vis ? (size_t) ((tps + 15) & ~15) : 0);
-    const int nw = geo.n_q >= 256 ? 4 : 2;
+    // (always 128-query workgroups: the 64-query form of pass 2 holds twice the staging registers per thread and spills 60 of them; a batch
+    // of 64 tokens leaves two of the four waves multiplying clamped duplicates instead)
+    constexpr int nw = 4;
     dim3 grid((unsigned) ((geo.n_q + nw * 32 - 1) / (nw * 32)), (unsigned) geo.n_head, (unsigned) geo.n_splits);
-    if (nw == 4) {
-        hipLaunchKernelGGL((k_attn_nf_mma<128, 4, 1>), grid, dim3(256), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
-        hipLaunchKernelGGL((k_attn_nf_mma<128, 4, 2>), grid, dim3(256), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
-    } else {
-        hipLaunchKernelGGL((k_attn_nf_mma<128, 2, 1>), grid, dim3(128), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
-        hipLaunchKernelGGL((k_attn_nf_mma<128, 2, 2>), grid, dim3(128), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
-    }
+    hipLaunchKernelGGL((k_attn_nf_mma<128, 4, 1>), grid, dim3(256), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
+    hipLaunchKernelGGL((k_attn_nf_mma<128, 4, 2>), grid, dim3(256), lds, s, q, k, vt, mask, dst, geo, stats, recs, vis);
     if (geo.n_splits > 1) launch_flash_attn_combine(s, 128, recs, nullptr, dst, geo.n_q, geo.n_head, 1, geo.n_splits, q8_out);  // (q8_out: only where the row-parallel form applies — the caller checked)
 }
 

@@ -163,7 +163,7 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             p.aux_bytes = std::max(p.aux_bytes, mul_mat_f_workspace_bytes(TD(n->src[0]), TD(n->src[1])));
             if (c->opt.attn_nf) p.aux_bytes = std::max(p.aux_bytes, attn_nf_list_scratch_bytes(TD(n->src[1]), TD(n->src[0]), nullptr));
             // (K.q of a prompt micro-batch on the non-flash path: statistics + partial records of the two-pass matrix-core form)
-            if (c->opt.attn_nf && n->src[1]->type == GGML_TYPE_F32 && n->src[1]->ne[1] >= 256 && n->src[0]->ne[0] == 128 && n->src[1]->ne[3] == 1)
+            if (c->opt.attn_nf && n->src[1]->type == GGML_TYPE_F32 && n->src[1]->ne[1] >= fattn_mma_min_q() && n->src[0]->ne[0] == 128 && n->src[1]->ne[3] == 1)
                 p.aux_bytes = std::max(p.aux_bytes, attn_nf_mma_ws_bytes(TD(n->src[1]), fattn_mma_pick_splits(TD(n->src[1]), TD(n->src[0]))));
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
@@ -1287,14 +1287,14 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
     return true;
 }
 
-// The same chain for a prompt micro-batch (256 tokens and more): two passes of the matrix-core kernel k_attn_nf_mma (fattn_mma.hip) — the row maxima
+// The same chain for a batch of 33 tokens and more (prompt micro-batches, speculative-decoding batches): two passes of the matrix-core kernel k_attn_nf_mma (fattn_mma.hip) — the row maxima
 // and sums, then p = e / sum and V^T.p — instead of three dense launches over the [n_kv, tokens, heads] score matrix (round 4).  At node i = kq.
 static bool try_fuse_attn_nf_mma(exec_state & st, int i) {
     backend_ctx * c = st.c;
     ggml_cgraph * g = st.g;
     const ggml_tensor * kq = g->nodes[i];
     const ggml_tensor * K = kq->src[0], * Q = kq->src[1];
-    if (!c->fa_lists || !c->ws || K->type != GGML_TYPE_F16 || Q->type != GGML_TYPE_F32 || Q->ne[1] < 256 || !single_use(st, kq)) return false;
+    if (!c->fa_lists || !c->ws || K->type != GGML_TYPE_F16 || Q->type != GGML_TYPE_F32 || Q->ne[1] < fattn_mma_min_q() || !single_use(st, kq)) return false;
     if (buffer_is_split(K->buffer)) return false;
     auto next_real = [&](int from) {
         for (int k = from; k < std::min(g->n_nodes, from + 6); ++k) {
