@@ -303,12 +303,15 @@ def main():
         rc = ctx.verify_steps(rows, args.np, args.draft, p0) if args.draft else ctx.decode_steps(rows, args.np, p0)
         assert rc == 0, f"decode failed rc={rc}"
 
+    host_graph = {}
+
     def leg():  # W untimed warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks
         nonlocal pos
         steps(args.warmup)
         pos += args.warmup
         g0 = be.stat("graph_launches")
         gl0 = be.stat("graph_launch_host_ns")
+        host0 = {k: be.stat(k) for k in ("graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits")}
         sync()
         t0 = time.perf_counter()
         steps(args.steps)
@@ -323,6 +326,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t[0])
         gs = be.stat("graph_launches") - g0
+        # host time inside graph_compute per timed step (the GPU idles while the host recognises the graph it is about to replay: VERDICT r04 #6)
+        host_graph.update({"graph_key_us": round((be.stat("graph_key_host_ns") - host0["graph_key_host_ns"]) / 1e3 / max(1, gs), 2),
+                           "graph_compute_us": round((be.stat("graph_compute_host_ns") - host0["graph_compute_host_ns"]) / 1e3 / max(1, args.steps), 2),
+                           "replays_recognised_in_place": int(be.stat("graph_key_fast_hits") - host0["graph_key_fast_hits"])})
         return el, gs, (be.stat("graph_launch_host_ns") - gl0) / 1e3 / max(1, gs)
 
     def headline(el, extra_note=""):  # the contract's fields for a K-step time (everything else is added to it below)
@@ -455,6 +462,7 @@ def main():
 
     # ---- CPU baseline: the oracle (restated ggml-cpu), same model shape, on this host's cores
     cpu_baseline = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             import ctypes as C
@@ -480,12 +488,12 @@ def main():
                     best = (rate, nth)
             nth = best[1]
             cc = Context(mc, compute=T.oracle_compute_fn(nth), n_ctx=256, flash_attn=args.fa, n_threads=nth)
-            cc.decode([int(toks[0])], [0])
+            cpu_rows = [cc.decode([int(toks[0])], [0])[1][0]]
             for i in range(4):  # warm
-                cc.decode([int(toks[1 + i])], [1 + i])
+                cpu_rows.append(cc.decode([int(toks[1 + i])], [1 + i])[1][0])
             tc0 = time.perf_counter()
             for i in range(args.cpu_steps):
-                cc.decode([int(toks[5 + i])], [5 + i])
+                cpu_rows.append(cc.decode([int(toks[5 + i])], [5 + i], copy_logits=True)[1][0])
             tc = time.perf_counter() - tc0
             lib.oracle_set_fast(0)
             found = [b for b in ("llama-box", "llama-bench", "llama-cli") if shutil.which(b)]
@@ -498,6 +506,34 @@ def main():
                                       + (f" — binaries found on this host: {found}" if found else " (no llama-box / llama-bench / llama-cli on this host)"),
                             "setup_s": round(time.time() - t_c - tc, 1)}
             cc.free()
+            # ---- parity of the timed model at full depth: the tokens the CPU leg just decoded (positions 0 .. 4 + cpu_steps, one
+            # llama_decode each) go through a FRESH context of the GPU backend; logits row by row against the CPU leg's.  The yardstick beside it: the
+            # oracle against itself — its generic scalar block dots against the x86 lane order the timed leg ran (same integers, another f32 order).
+            if model is not None and tp_size == 1:
+                try:
+                    cpu_rows = np.stack(cpu_rows)
+                    n_par_rows = len(cpu_rows)
+                    cgp = Context(model, backend=be, n_ctx=256, flash_attn=args.fa, graph_reuse=1, type_k=kvt, type_v=kvt)
+                    gpu_rows = np.stack([cgp.decode([int(toks[i])], [i])[1][0] for i in range(n_par_rows)])
+                    cgp.free()
+                    n_gen = min(n_par_rows, int(os.environ.get("BENCH_PARITY_GENERIC_STEPS", "16")))
+                    cgn = Context(mc, compute=T.oracle_compute_fn(nmax), n_ctx=256, flash_attn=args.fa, n_threads=nmax)
+                    gen_rows = np.stack([cgn.decode([int(toks[i])], [i])[1][0] for i in range(n_gen)])
+                    cgn.free()
+                    top2 = np.sort(cpu_rows, axis=1)
+                    margin = top2[:, -1] - top2[:, -2]
+                    agree = np.argmax(gpu_rows, axis=1) == np.argmax(cpu_rows, axis=1)
+                    d_oo = float(np.max(np.abs(gen_rows - cpu_rows[:n_gen])))
+                    decisive = margin > 2.0 * d_oo
+                    parity = {"nmse": float(T.nmse(gpu_rows, cpu_rows)), "max_abs": float(np.max(np.abs(gpu_rows - cpu_rows))),
+                              "argmax_agree": f"{int(agree.sum())}/{len(agree)}",
+                              "argmax_agree_where_margin_exceeds_2x_oracle_vs_oracle": f"{int((agree & decisive).sum())}/{int(decisive.sum())}",
+                              "oracle_vs_oracle_nmse": float(T.nmse(gen_rows, cpu_rows[:n_gen])), "oracle_vs_oracle_max_abs": d_oo,
+                              "rows": n_par_rows, "oracle_vs_oracle_rows": n_gen,
+                              "what": f"{args.preset}, all {hp.n_layer} layers: {n_par_rows} batch-1 llama_decode calls at n_past 0..{n_par_rows - 1} on a fresh GPU context vs the CPU leg's logits (oracle, x86 lane order); "
+                                      f"oracle-vs-oracle = the generic scalar oracle vs that leg on the first {n_gen} rows (same integer block sums, another f32 summation order)"}
+                except Exception as e:
+                    parity = {"error": str(e)}
             mc.free()
         except Exception as e:
             cpu_baseline = {"error": str(e)}
@@ -526,9 +562,9 @@ def main():
             "decode_hbm_frac_of_8TBs": round(job_bytes / 8e12, 4),
             "replicas_on_the_same_gpus": replicas,
             "tp_stats": {"allreduces": int(be.stat("allreduces")), "p2p_launches_issued": int(be.stat("p2p_allreduces")), "p2p_timeouts": int(be.stat("p2p_timeouts"))} if tp_size > 1 and not emulated else None,
-            "graph_replayed_steps": int(graph_steps), "hipGraphLaunch_host_us": round(graph_launch_host_us, 1),
+            "graph_replayed_steps": int(graph_steps), "hipGraphLaunch_host_us": round(graph_launch_host_us, 1), "graph_compute_host_us_per_step": host_graph,
             "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "kernel_classes_us": {k: round(v[1] * 1e3 / max(1, v[0]), 2) for k, v in sorted(classes.items())},
             "model_load_s": round(t_load, 1),
         })

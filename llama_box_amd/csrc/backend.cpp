@@ -367,7 +367,24 @@ static bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
 static const ggml_backend_buffer_type_i k_buft_iface = {buft_get_name, buft_alloc, buft_alignment, buft_max_size, buft_alloc_size, buft_is_host};
 
 // ---- pinned host buffer type (uploads at PCIe rate; llama.cpp asks for it via get_host_buffer_type)
-static void hbuf_free(ggml_backend_buffer_t b) { HIP_SOFT(hipHostFree(b->context)); }
+// The ranges handed out are remembered: memory of this type is mapped into the device's address space (hipHostMalloc), so a kernel can write
+// it — get_tensor_async uses that for the logits rows of a decode step (be_get_tensor_async).
+static std::mutex g_pinned_mtx;
+static std::vector<std::pair<const char *, size_t>> g_pinned;
+static bool is_pinned_range(const void * p, size_t n) {
+    std::lock_guard<std::mutex> lock(g_pinned_mtx);
+    for (const auto & r : g_pinned)
+        if ((const char *) p >= r.first && (const char *) p + n <= r.first + r.second) return true;
+    return false;
+}
+static void hbuf_free(ggml_backend_buffer_t b) {
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mtx);
+        for (size_t i = 0; i < g_pinned.size(); ++i)
+            if (g_pinned[i].first == (const char *) b->context) { g_pinned.erase(g_pinned.begin() + (long) i); break; }
+    }
+    HIP_SOFT(hipHostFree(b->context));
+}
 static void * hbuf_base(ggml_backend_buffer_t b) { return b->context; }
 static void hbuf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, size_t off, size_t sz) { memset((char *) t->data + off, v, sz); }
 static void hbuf_set(ggml_backend_buffer_t, ggml_tensor * t, const void * d, size_t off, size_t sz) { memcpy((char *) t->data + off, d, sz); }
@@ -376,12 +393,16 @@ static void hbuf_clear(ggml_backend_buffer_t b, uint8_t v) { memset(b->context, 
 static const char * hbuft_name(ggml_backend_buffer_type_t) { return GGML_MI355X_NAME "_Host"; }
 static ggml_backend_buffer_t hbuft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
     void * p = nullptr;
-    hipError_t err = hipHostMalloc(&p, size > 0 ? size : 1, hipHostMallocDefault);
+    hipError_t err = hipHostMalloc(&p, size > 0 ? size : 1, hipHostMallocPortable | hipHostMallocMapped);  // (every device of the process may read and write it)
     if (err != hipSuccess) {
         (void) hipGetLastError();
         return nullptr;
     }
     ggml_backend_buffer_i iface = {hbuf_free, hbuf_base, nullptr, hbuf_memset, hbuf_set, hbuf_get, nullptr, hbuf_clear, nullptr};
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mtx);
+        g_pinned.emplace_back((const char *) p, size > 0 ? size : 1);
+    }
     return make_buffer(buft, iface, p, size);
 }
 static size_t hbuft_alignment(ggml_backend_buffer_type_t) { return 64; }
@@ -446,6 +467,14 @@ static void be_get_tensor_async(ggml_backend_t be, const ggml_tensor * t, void *
     HIP_SOFT(hipSetDevice(c->device));
     flush_uploads(c);
     uploader_join(c->device, c->stream);
+    // The logits of a decode step (513 KB per sequence, llama.cpp's pinned output buffer): a blit through hipMemcpyAsync starts ~20 us after
+    // the graph's last kernel and takes 10 us (profiles/r05_decode_gaps_*.txt); a copy kernel writing the mapped pinned memory is an ordinary
+    // launch behind that kernel.  Only into memory of OUR host buffer type (known to be device-mapped), up to 8 MiB.
+    if (c->opt.small_downloads && size > 0 && size <= ((size_t) 8 << 20) && is_pinned_range(data, size)) {
+        launch_upload_small(c->stream, data, (const char *) t->data + offset, size);
+        c->st.kernel_downloads++;
+        return;
+    }
     HIP_SOFT(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
 }
 static bool be_is_ours(ggml_backend_t be);
@@ -567,6 +596,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     if (const char * e = getenv("GGML_MI355X_FA_SPLITS")) c->opt.fa_splits = atoi(e);
     if (const char * e = getenv("GGML_MI355X_FA_WO")) c->opt.fa_wo = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_SMALL_UPLOADS")) c->opt.small_uploads = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_SMALL_DOWNLOADS")) c->opt.small_downloads = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_I8")) c->opt.mmq_i8 = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MM_MERGE")) c->opt.mm_merge = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_MMQ_BN")) c->opt.mmq_bn = atoi(e);
@@ -673,6 +703,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "fa_wo") c->opt.fa_wo = v != 0;
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;
+    else if (k == "small_downloads") c->opt.small_downloads = v != 0;
     else if (k == "timing") c->opt.timing = v != 0;
     else if (k == "staged_upload") g_staged_upload.store(v != 0);
     else return -1;
@@ -696,6 +727,11 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "p2p_allreduces") return c->st.p2p_allreduces;
     if (k == "p2p_timeouts") return tp_p2p_timeouts(c);
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
+    if (k == "kernel_downloads") return c->st.kernel_downloads;
+    if (k == "graph_key_host_ns") return c->st.graph_key_host_ns;
+    if (k == "graph_compute_host_ns") return c->st.graph_compute_host_ns;
+    if (k == "graph_key_fast_hits") return c->st.graph_key_fast_hits;
+    if (k == "graph_key_collisions") return c->st.graph_key_collisions;
     if (k == "skinny_launches") return c->st.skinny_launches;
     if (k == "wide_launches") return c->st.wide_launches;
     if (k == "tiled_launches") return c->st.tiled_launches;

@@ -118,6 +118,7 @@ struct options {
                                // tested, OFF by default: a KV trip of the lane-parallel kernel is a ~4 us dependent chain, so 9 splits of 2
                                // trips (12.0 us) + the merging prologue (wo 6.8 -> 10.4 us) lose to 36 one-trip splits + combine (13.6 + 6.8)
     bool small_uploads = true; // set_tensor_async of <= 64 KiB: pinned ring + copy kernel instead of a blit
+    bool small_downloads = true; // get_tensor_async of <= 8 MiB into this backend's pinned host buffer type: a copy kernel instead of a blit
     bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)
 };
 
@@ -132,6 +133,11 @@ struct stats {
     int64_t fa_list_launches = 0;      // FLASH_ATTN_EXT nodes served over per-token position lists (2..32 tokens; 33..256 when the mask is known to be sparse)
     int64_t rope_epilogues = 0;        // batches whose rope + KV-cache stores rode in the skinny QKV launches
     int64_t graph_launch_host_ns = 0;  // host time spent inside hipGraphLaunch (replays only)
+    int64_t graph_key_host_ns = 0;     // replays only: host time from entering graph_compute to calling hipGraphLaunch (recognising the graph)
+    int64_t graph_compute_host_ns = 0; // host time inside graph_compute, all paths
+    int64_t graph_key_fast_hits = 0;   // replays recognised by comparing against the graph replayed last (no key built, no hash)
+    int64_t kernel_downloads = 0;      // get_tensor_async calls served by a copy kernel writing mapped pinned memory
+    int64_t graph_key_collisions = 0;  // two different graph keys with one hash (each keeps its own entry)
 };
 
 struct tp_state;      // tp.cpp
@@ -143,6 +149,7 @@ struct cached_graph {
     int seen = 0;
     uint64_t last_use = 0;
     int64_t allreduces = 0;  // reductions / collectives recorded in the graph (counted again at every replay: stats::allreduces)
+    std::vector<uint64_t> key;  // the graph this entry stands for, word by word (graph.cpp: walk_key) — an entry is used only when these are equal
 };
 
 struct timing_slot {
@@ -166,6 +173,8 @@ struct backend_ctx {
     uint64_t q8_epoch = 0;
     // hipGraph cache
     std::unordered_map<uint64_t, cached_graph> graphs;
+    cached_graph * last_graph = nullptr;  // the entry looked up last: compared first, in place (graph.cpp: key_equals)
+    std::vector<uint64_t> key_scratch;
     uint64_t tick = 0;
     bool capturing = false;
     // tensor parallel

@@ -945,12 +945,12 @@ void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const flo
     else hipLaunchKernelGGL((k_fattn_combine<64>), g2, dim3(64), 0, s, ws, sinks, dst, geo);
 }
 
-bool fattn_prefers_lists(const tdesc & q, const tdesc * mask) {
+bool fattn_prefers_lists(const tdesc & q, const tdesc * mask, int mask_sparse) {
     static const bool on = !getenv("GGML_MI355X_FA_SPARSE_LISTS") || atoi(getenv("GGML_MI355X_FA_SPARSE_LISTS")) != 0;
-    return on && mask != nullptr && q.ne[1] >= fattn_mma_min_q() && q.ne[1] <= 256 && mask_sparse_hint(mask->data) != 0;
+    return on && mask != nullptr && q.ne[1] >= fattn_mma_min_q() && q.ne[1] <= 256 && mask_sparse != 0;
 }
-int fattn_pick_splits(const tdesc & q, const tdesc & k, const tdesc * mask) {
-    if (q.ne[1] >= fattn_mma_min_q() && (k.ne[0] == 64 || k.ne[0] == 128) && !fattn_prefers_lists(q, mask)) return fattn_mma_pick_splits(q, k);  // (soft-capped / ALiBi batches fall back to the generic kernel with this count)
+int fattn_pick_splits(const tdesc & q, const tdesc & k, const tdesc * mask, int mask_sparse) {
+    if (q.ne[1] >= fattn_mma_min_q() && (k.ne[0] == 64 || k.ne[0] == 128) && !fattn_prefers_lists(q, mask, mask_sparse)) return fattn_mma_pick_splits(q, k);  // (soft-capped / ALiBi batches fall back to the generic kernel with this count)
     const int64_t n_kv = k.ne[1];
     if (q.ne[1] > 1 && k.ne[0] == 128 && q.ne[3] == 1) {
         // a few tokens at head_dim 128 (continuous-batching decode, speculative batches): the tile-list kernel — every split takes a
@@ -1085,7 +1085,7 @@ int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const 
     const int64_t n_q = q.ne[1];
     const int G = k.ne[2] > 0 ? (int) (q.ne[2] / k.ne[2]) : 0;
     static const bool on = !getenv("GGML_MI355X_FA_LIST") || atoi(getenv("GGML_MI355X_FA_LIST")) != 0;
-    if (!on || n_q < 2 || (n_q >= fattn_mma_min_q() && !fattn_prefers_lists(q, mask)) || !mask || q.ne[3] != 1 || mask->ne[3] != 1 || k.ne[0] != 128) return 0;
+    if (!on || n_q < 2 || (n_q >= fattn_mma_min_q() && !fattn_prefers_lists(q, mask, p.mask_sparse)) || !mask || q.ne[3] != 1 || mask->ne[3] != 1 || k.ne[0] != 128) return 0;
     if (p.logit_softcap != 0.0f || p.max_bias != 0.0f || !(G == 2 || G == 4 || G == 7 || G == 8) || p.n_splits < 1) return 0;
     if ((k.ne[1] % 4) != 0 || (mask->nb[1] % 8) != 0 || ((uintptr_t) mask->data & 7) != 0 || mask->type != GGML_TYPE_F16) return 0;
     if ((size_t) (n_q * (k.ne[1] + 1)) * sizeof(int) > lists_bytes) return 0;

@@ -176,6 +176,27 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
     return p;
 }
 
+// ------------------------------------------------------------------------------------------------ attention-mask content hints
+// the uploaded tensor behind an attention mask: llama.cpp hands FLASH_ATTN_EXT a ggml_cast(F16) of the F32 KQ_mask it fills on the host
+// (a CPY node whose src[0] is the input), possibly through views — the statistics of backend.cpp are keyed by the address that went
+// through set_tensor
+static const void * mask_upload_ptr(const ggml_tensor * m) {
+    for (int hop = 0; m && hop < 4; ++hop) {
+        const bool whole_view = (m->op == GGML_OP_VIEW || m->op == GGML_OP_RESHAPE) && m->src[0] && m->view_offs == 0 && ggml_abi_nelements(m) == ggml_abi_nelements(m->src[0]);
+        if (!((m->op == GGML_OP_CPY || m->op == GGML_OP_DUP || m->op == GGML_OP_CONT || whole_view) && m->src[0])) break;
+        m = m->src[0];
+    }
+    return m ? m->data : nullptr;
+}
+static int fa_mask_hint(const ggml_tensor * n) {  // kernel choices that follow the CONTENT of the attention mask (common.h: mask_stats)
+    if (n->op == GGML_OP_FLASH_ATTN_EXT && n->src[3]) return n->src[0]->ne[1] >= 33 ? mask_sparse_hint(mask_upload_ptr(n->src[3])) : 0;
+    if (n->op == GGML_OP_SOFT_MAX && n->src[1] && n->src[0]->ne[1] >= 2 && n->src[0]->ne[1] <= 32) {
+        mask_stats ms;
+        return lookup_mask_stats(mask_upload_ptr(n->src[1]), &ms) ? (ms.max_visible > 1024 ? 2 : 1) : 0;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ timing (bench)
 struct timed_scope {
     backend_ctx * c;
@@ -1220,7 +1241,7 @@ static bool try_fuse_attn_nf(exec_state & st, int i) {
         // sequence among 31 short ones keeps the batch on the dense kernels (ADVICE r02 / VERDICT r03 #7).  Unknown mask: the average rule
         // inside attn_nf_list_scratch_bytes alone decides, as before.
         mask_stats ms;
-        if (lookup_mask_stats(M->data, &ms) && ms.max_visible > 1024) return false;
+        if (lookup_mask_stats(mask_upload_ptr(M), &ms) && ms.max_visible > 1024) return false;
     }
     const tdesc qd = TD(Q), kd = TD(K), vd = TD(V), md = TD(M);
     int dq_n = 1;
@@ -1670,7 +1691,8 @@ static int run_node(exec_state & st, int i) {
             p.logit_softcap = ggml_abi_op_param_f32(n, 2);
             const tdesc qd = TD(a), kd = TD(k), vd = TD(v);
             const tdesc md0 = m ? TD(m) : qd;
-            p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd, m ? &md0 : nullptr));
+            p.mask_sparse = fa_mask_hint(n);
+            p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd, m ? &md0 : nullptr, p.mask_sparse));
             p.kv_type = k->type;
             if (c->opt.fa_self_merge && c->fa_arrive) {
                 p.arrive = c->fa_arrive;
@@ -1806,41 +1828,76 @@ static bool run_nodes(backend_ctx * c, ggml_cgraph * g, const ws_plan & wp) {
 }
 
 // ------------------------------------------------------------------------------------------------ hipGraph cache
-static inline void fnv(uint64_t & h, const void * p, size_t n) {
-    const uint8_t * b = (const uint8_t *) p;
-    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001B3ull; }
-}
-static uint64_t fingerprint(const ggml_cgraph * g) {
-    uint64_t h = 0xCBF29CE484222325ull;
-    fnv(h, &g->n_nodes, sizeof(int));
+// A captured hipGraph stands for one graph KEY: every property of the ggml graph that decides which kernels run on which addresses
+// with which arguments — per node {type, op, ne, nb, op_params, flags, buffer, data, which src slots are set, the mask-content hint}
+// and per src {type, buffer, ne, nb, data} — laid out as 8-byte words (~20 per node + 11 per src: ~270 KB for a 32-layer decode graph).
+// Round 4 hashed those bytes with a byte-serial FNV-1a before EVERY replay (4 cycles per byte on a dependent multiply chain: 100-370 us
+// of host time per step during which the GPU idles) and trusted the 64-bit hash alone.  Now: the key words of the graph
+// replayed last are compared in place (wide memcmp over the contiguous field runs of ggml_tensor, early exit at the first difference,
+// nothing built, nothing hashed); only on a miss are the words materialised, hashed eight bytes per multiply on four independent lanes,
+// and looked up — and a cached entry is used only if its stored words are EQUAL, so a hash collision can no longer replay another graph.
+static_assert(offsetof(ggml_tensor, ne) == offsetof(ggml_tensor, buffer) + 8 && offsetof(ggml_tensor, nb) == offsetof(ggml_tensor, ne) + 32 &&
+              offsetof(ggml_tensor, op) == offsetof(ggml_tensor, nb) + 32 && offsetof(ggml_tensor, op_params) == offsetof(ggml_tensor, op) + 4 &&
+              offsetof(ggml_tensor, flags) == offsetof(ggml_tensor, op_params) + 64 && offsetof(ggml_tensor, src) == offsetof(ggml_tensor, flags) + 4 &&
+              offsetof(ggml_tensor, buffer) % 8 == 0 && offsetof(ggml_tensor, src) % 8 == 0,
+              "graph key: {buffer, ne, nb, op, op_params, flags} must be one padding-free run of ggml_tensor");
+static constexpr size_t KEY_NODE_RUN = (offsetof(ggml_tensor, src) - offsetof(ggml_tensor, buffer)) / 8;  // buffer .. flags: 18 words
+static constexpr size_t KEY_SRC_RUN = (offsetof(ggml_tensor, op) - offsetof(ggml_tensor, buffer)) / 8;    // buffer, ne, nb: 9 words
+
+// walks the key words of `g` in their fixed order; `put(p, n)` receives runs of n words and returns false to stop
+template <class Put>
+static inline bool walk_key(const ggml_cgraph * g, Put && put) {
+    uint64_t w[2];
+    w[0] = (uint64_t) (uint32_t) g->n_nodes;
+    if (!put(w, 1)) return false;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
-        fnv(h, &n->op, sizeof(n->op));
-        fnv(h, &n->type, sizeof(n->type));
-        fnv(h, n->ne, sizeof(n->ne));
-        fnv(h, n->nb, sizeof(n->nb));
-        fnv(h, &n->data, sizeof(n->data));
-        fnv(h, n->op_params, sizeof(n->op_params));
-        fnv(h, &n->flags, sizeof(n->flags));
-        // kernel choices that follow the CONTENT of the attention mask (common.h: mask_stats) belong to the topology a captured graph stands for
-        if (n->op == GGML_OP_FLASH_ATTN_EXT && n->src[3]) {
-            const int hint = n->src[0]->ne[1] >= 33 ? mask_sparse_hint(n->src[3]->data) : 0;
-            fnv(h, &hint, sizeof(hint));
-        } else if (n->op == GGML_OP_SOFT_MAX && n->src[1] && n->src[0]->ne[1] >= 2 && n->src[0]->ne[1] <= 32) {
-            mask_stats ms;
-            const int hint = lookup_mask_stats(n->src[1]->data, &ms) ? (ms.max_visible > 1024 ? 2 : 1) : 0;
-            fnv(h, &hint, sizeof(hint));
-        }
+        uint32_t present = 0;
+        for (int s = 0; s < GGML_MAX_SRC; ++s) present |= n->src[s] ? 1u << s : 0u;
+        const bool hinted = n->op == GGML_OP_FLASH_ATTN_EXT || n->op == GGML_OP_SOFT_MAX;
+        w[0] = (uint64_t) (uint32_t) n->type | (uint64_t) present << 32 | (uint64_t) (hinted ? fa_mask_hint(n) : 0) << 48;
+        w[1] = (uint64_t) (uintptr_t) n->data;
+        if (!put(w, 2) || !put(&n->buffer, KEY_NODE_RUN)) return false;
         for (int s = 0; s < GGML_MAX_SRC; ++s) {
             const ggml_tensor * t = n->src[s];
             if (!t) continue;
-            fnv(h, &t->data, sizeof(t->data));
-            fnv(h, t->ne, sizeof(t->ne));
-            fnv(h, t->nb, sizeof(t->nb));
-            fnv(h, &t->type, sizeof(t->type));
+            w[0] = (uint64_t) (uint32_t) t->type;
+            w[1] = (uint64_t) (uintptr_t) t->data;
+            if (!put(w, 2) || !put(&t->buffer, KEY_SRC_RUN)) return false;
         }
     }
-    return h;
+    return true;
+}
+static bool key_equals(const ggml_cgraph * g, const std::vector<uint64_t> & key) {
+    const uint64_t * at = key.data(), * const end = at + key.size();
+    const bool same = walk_key(g, [&](const void * p, size_t n) {
+        if ((size_t) (end - at) < n || memcmp(at, p, n * 8) != 0) return false;
+        at += n;
+        return true;
+    });
+    return same && at == end;
+}
+static void key_build(const ggml_cgraph * g, std::vector<uint64_t> & key) {
+    key.clear();
+    key.reserve((size_t) g->n_nodes * 48);
+    walk_key(g, [&](const void * p, size_t n) {
+        const size_t at = key.size();
+        key.resize(at + n);
+        memcpy(key.data() + at, p, n * 8);
+        return true;
+    });
+}
+static uint64_t key_hash(const std::vector<uint64_t> & key) {  // four independent multiply-fold lanes over 8-byte words
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    auto fold = [](uint64_t a, uint64_t v) {
+        const unsigned __int128 m = (unsigned __int128) (a ^ v) * 0xD6E8FEB86659FD93ull;
+        return (uint64_t) m ^ (uint64_t) (m >> 64);
+    };
+    size_t i = 0;
+    for (; i + 4 <= key.size(); i += 4)
+        for (int l = 0; l < 4; ++l) h[l] = fold(h[l], key[i + l]);
+    for (; i < key.size(); ++i) h[0] = fold(h[0], key[i]);
+    return fold(fold(fold(h[0], h[1]), h[2]), h[3] ^ key.size());
 }
 
 void free_graph_cache(backend_ctx * c) {
@@ -1849,6 +1906,7 @@ void free_graph_cache(backend_ctx * c) {
         if (kv.second.graph) (void) hipGraphDestroy(kv.second.graph);
     }
     c->graphs.clear();
+    c->last_graph = nullptr;
 }
 
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
@@ -1857,25 +1915,18 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         MI_ERR("graph_compute: refused — an earlier HIP call of the data path failed (see the log above)");
         return GGML_STATUS_FAILED;
     }
-    const ws_plan wp = plan_ws(c, g);
-    if (!ensure_ws(c, wp.act_bytes + wp.aux_bytes + 256)) return GGML_STATUS_ALLOC_FAILED;
+    const auto t_enter = std::chrono::steady_clock::now();
+    struct host_clock {  // host time of this call (stats::graph_compute_host_ns: key comparison, planning, launches — the GPU may idle meanwhile)
+        backend_ctx * c;
+        std::chrono::steady_clock::time_point t0;
+        ~host_clock() { c->st.graph_compute_host_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    } clock{c, t_enter};
     c->tick++;
-    bool has_split = false;  // multi-device launches + peer copies: executed eagerly (capture across devices is left for a box that has them)
-    for (int i = 0; i < g->n_nodes && !has_split; ++i) has_split = g->nodes[i]->op == GGML_OP_MUL_MAT && buffer_is_split(g->nodes[i]->src[0]->buffer);
-    // (graphs that launch on several devices' streams: captured only on request — GGML_MI355X_SPLIT_GRAPHS=1 — until that has run on a box
-    // with more than one GPU; the fork / join over events is capturable and is exercised on logical devices by tests/test_gpu_split.py)
-    static const bool split_graphs = getenv("GGML_MI355X_SPLIT_GRAPHS") && atoi(getenv("GGML_MI355X_SPLIT_GRAPHS")) != 0;
-    const bool want_graph = c->opt.graphs && !c->opt.timing && g->n_nodes >= 8 && (!has_split || split_graphs);
-    if (!want_graph) {
-        c->st.eager_graphs++;
-        return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
-    }
-    const uint64_t fp = fingerprint(g);
-    cached_graph & cg = c->graphs[fp];
-    cg.last_use = c->tick;
-    cg.seen++;
-    if (cg.exec) {
+    auto replay = [&](cached_graph & cg) {
+        cg.last_use = c->tick;
+        cg.seen++;
         const auto t0 = std::chrono::steady_clock::now();
+        c->st.graph_key_host_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t0 - t_enter).count();
         if (hipGraphLaunch(cg.exec, c->stream) != hipSuccess) {
             (void) hipGetLastError();
             return GGML_STATUS_FAILED;
@@ -1884,7 +1935,43 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         c->st.graph_launches++;
         c->st.allreduces += cg.allreduces;
         return GGML_STATUS_SUCCESS;
+    };
+    // the step llama-box repeats: the same graph as last time.  Its key is compared in place; an instantiated graph implies that the scratch it was
+    // captured over is still the one in use (ensure_ws drops the cache when it regrows), so nothing else has to be planned for a replay.
+    const bool may_replay = c->opt.graphs && !c->opt.timing && g->n_nodes >= 8;
+    if (may_replay && c->last_graph && c->last_graph->exec && key_equals(g, c->last_graph->key)) {
+        c->st.graph_key_fast_hits++;
+        return replay(*c->last_graph);
     }
+    const ws_plan wp = plan_ws(c, g);
+    if (!ensure_ws(c, wp.act_bytes + wp.aux_bytes + 256)) return GGML_STATUS_ALLOC_FAILED;
+    bool has_split = false;  // multi-device launches + peer copies: executed eagerly (capture across devices is left for a box that has them)
+    for (int i = 0; i < g->n_nodes && !has_split; ++i) has_split = g->nodes[i]->op == GGML_OP_MUL_MAT && buffer_is_split(g->nodes[i]->src[0]->buffer);
+    // (graphs that launch on several devices' streams: captured only on request — GGML_MI355X_SPLIT_GRAPHS=1 — until that has run on a box
+    // with more than one GPU; the fork / join over events is capturable and is exercised on logical devices by tests/test_gpu_split.py)
+    static const bool split_graphs = getenv("GGML_MI355X_SPLIT_GRAPHS") && atoi(getenv("GGML_MI355X_SPLIT_GRAPHS")) != 0;
+    const bool want_graph = may_replay && (!has_split || split_graphs);
+    if (!want_graph) {
+        c->st.eager_graphs++;
+        return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+    }
+    key_build(g, c->key_scratch);
+    uint64_t fp = key_hash(c->key_scratch);
+    auto it = c->graphs.find(fp);
+    while (it != c->graphs.end() && it->second.key != c->key_scratch) {  // another graph with this hash (never seen): probe on
+        c->st.graph_key_collisions++;
+        fp = fp * 0x9E3779B97F4A7C15ull + 1;
+        it = c->graphs.find(fp);
+    }
+    if (it == c->graphs.end()) {
+        it = c->graphs.emplace(fp, cached_graph()).first;
+        it->second.key = c->key_scratch;
+    }
+    cached_graph & cg = it->second;
+    c->last_graph = &cg;  // (unordered_map nodes stay where they are until erased; every erase below resets this)
+    if (cg.exec) return replay(cg);
+    cg.last_use = c->tick;
+    cg.seen++;
     if (cg.seen < 2 || cg.seen > 1000000) {  // first sighting: run eagerly (one-off prefill graphs never pay for capture)
         c->st.eager_graphs++;
         const bool ok = run_nodes(c, g, wp);
@@ -1893,6 +1980,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
                 if (it->second.last_use + 256 < c->tick) {
                     if (it->second.exec) (void) hipGraphExecDestroy(it->second.exec);
                     if (it->second.graph) (void) hipGraphDestroy(it->second.graph);
+                    if (c->last_graph == &it->second) c->last_graph = nullptr;
                     it = c->graphs.erase(it);
                 } else {
                     ++it;

@@ -266,6 +266,8 @@ struct fattn_params {
     unsigned * arrive = nullptr;  // zeroed counters (arrive_slots of them): lets the split kernel of the head_dim-128 decode path merge its own
     int arrive_slots = 0;         // partial records (last workgroup to arrive) instead of a second launch; the kernel leaves them at zero
     const uint8_t * tile_vis = nullptr;  // matrix-core kernel: [q tile of 32][kv tile of 64] visibility bytes (launch_fattn_vis_scan), or nullptr
+    int mask_sparse = 0;  // 1: the mask's CONTENT is known (it passed through set_tensor, possibly behind the host's F32 -> F16 cast node) and at most a
+                          // quarter of its cells are visible (common.h: mask_sparse_hint, resolved by graph.cpp) — position lists beat dense tiles
 };
 // the non-flash chain (K.q -> SOFT_MAX -> V^T.p) of a prompt micro-batch on the matrix cores, two passes (fattn_mma.hip: k_attn_nf_mma)
 bool attn_nf_mma_applies(const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask);
@@ -281,10 +283,10 @@ void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv
 size_t fattn_workspace_bytes(const tdesc & q, const tdesc & k, const tdesc & v, int n_splits, int kv_type);
 int fattn_mma_min_q();  // query tokens from which the matrix-core attention kernel takes over (env GGML_MI355X_FA_MMA_MIN_Q)
 bool flash_attn_mma_applies(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);
-int fattn_pick_splits(const tdesc & q, const tdesc & k, const tdesc * mask = nullptr);
+int fattn_pick_splits(const tdesc & q, const tdesc & k, const tdesc * mask = nullptr, int mask_sparse = 0);
 // 33+ query tokens normally run on the matrix-core kernel; a batch whose mask is KNOWN to be sparse (mask_sparse_hint: draft-verification
 // batches of many sequences over a unified cache, llama-box/httpserver.hpp:4042-4069) of up to 256 tokens walks per-token position lists instead
-bool fattn_prefers_lists(const tdesc & q, const tdesc * mask);
+bool fattn_prefers_lists(const tdesc & q, const tdesc * mask, int mask_sparse);
 int fattn_fat_splits(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const fattn_params & p);  // 0 = the fat-split form does not apply
 bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p);  // will this launch end in the quantising combine?
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks,

@@ -19,6 +19,22 @@ tail = steps[-16:]
 for i, (s, e, busy, inner, n) in enumerate(tail):
     nxt = tail[i + 1][0] - e if i + 1 < len(tail) else 0
     print(f"step kernels={n} span={(e - s) / 1e3:8.1f} us busy={busy / 1e3:8.1f} inner_gaps={inner / 1e3:6.1f} gap_to_next_step={nxt / 1e3:6.1f}")
+# The host's turn between two steps: a step ends with the output mat-vec, then the logits' D2H copy (a blit kernel when the
+# target is pinned memory), then NOTHING runs until the host has synchronised, sampled, staged the next inputs, recognised the graph and called
+# hipGraphLaunch.  The cut above puts that idle time inside the next step's "inner gaps"; here it is on its own.
+turn = []
+for a in ends[-17:-1]:
+    nxt = rows[a + 1:a + 4]
+    if not nxt: continue
+    out_end = rows[a][1]
+    if "copyBuffer" in nxt[0][2] and len(nxt) > 1:
+        turn.append(((nxt[0][0] - out_end) / 1e3, (nxt[0][1] - nxt[0][0]) / 1e3, (nxt[1][0] - nxt[0][1]) / 1e3, nxt[1][2].split("(")[0][:40]))
+    else:
+        turn.append(((nxt[0][0] - out_end) / 1e3, 0.0, 0.0, nxt[0][2].split("(")[0][:40]))
+if turn:
+    n = len(turn)
+    print(f"between steps (mean of {n}): output mat-vec end -> D2H copy start {sum(t[0] for t in turn) / n:6.1f} us, copy {sum(t[1] for t in turn) / n:5.1f} us, "
+          f"copy end -> first kernel of the next step ({turn[-1][3]}) {sum(t[2] for t in turn) / n:6.1f} us  [host turnaround: sync + sampler + inputs + graph key + hipGraphLaunch]")
 big = {}
 st = rows[ends[-3] + 1:ends[-2] + 1]
 for i in range(len(st) - 1):
