@@ -474,9 +474,14 @@ def main():
             fast = int(lib.oracle_set_fast(1))  # AVX2 restatement of ggml-cpu's x86 block dots (oracle/ggml_cpu_ref.c): timing leg only
             mc = Model(hp, 0x5EED, H.ggml_backend_cpu_buffer_type())
             nmax = lib.oracle_max_threads()
-            # thread count: the best of a short probe (a 2-socket host is not fastest with every logical CPU spinning on one weight stream)
+            # what the host offers THIS container: the cgroup's CFS quota (16 CPUs on the GPU boxes of round 5, whose host shows 256 logical CPUs).  A team
+            # beyond it is descheduled by the kernel for most of its wall time — round 4's probe over {all, half, 96, 64, 32} never looked below 32 and
+            # reported 13 tok/s where 8 threads deliver twice that (profiles/r05_cpu_scaling.txt)
+            quota = T.cpu_quota()
+            nmax = max(1, min(nmax, quota))
+            # thread count: the best of a short probe around the quota
             best = (0.0, nmax)
-            for nth in sorted({nmax, max(1, nmax // 2), min(nmax, 96), min(nmax, 64), min(nmax, 32)}, reverse=True):
+            for nth in sorted({nmax, max(1, nmax - 1), max(1, nmax - 2), max(1, nmax - 4), max(1, nmax * 3 // 4), max(1, nmax // 2)}, reverse=True):
                 cc = Context(mc, compute=T.oracle_compute_fn(nth), n_ctx=256, flash_attn=args.fa, n_threads=nth)
                 cc.decode([int(toks[0])], [0])  # touch the weights / wake the pool
                 tp0 = time.perf_counter()
@@ -497,12 +502,12 @@ def main():
             tc = time.perf_counter() - tc0
             lib.oracle_set_fast(0)
             found = [b for b in ("llama-box", "llama-bench", "llama-cli") if shutil.which(b)]
-            cpu_baseline = {"value": round(args.cpu_steps / tc, 3), "unit": "tokens/s", "cores": nth, "kind": "port",
+            cpu_baseline = {"value": round(args.cpu_steps / tc, 3), "unit": "tokens/s", "cores": nth, "kind": "port", "cpu_quota_of_this_container": quota, "host_logical_cpus": os.cpu_count(),
                             "effective_GBps": round(mc.stream_bytes() * args.cpu_steps / tc / 1e9, 1),  # weight bytes one token streams x tokens/s: what the host's DRAM delivered
                             "numa_nodes": len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]) if os.path.isdir("/sys/devices/system/node") else 1,
                             "sample": f"{args.cpu_steps} warm batch-1 decode steps at n_past 5..{4 + args.cpu_steps} of the same synthetic {args.preset} model; CPU restatement of ggml-cpu (oracle/): "
                                       + ("AVX2 block dots as ggml-cpu's x86 kernels compute them (same integers, FMA lane accumulation)" if fast else "generic scalar block dots (no AVX2 build)")
-                                      + f", OpenMP pool of {nth} threads (best of a probe over thread counts up to {nmax}), weight pages interleaved over the NUMA nodes / first-touched by many threads (ggml_lite.cpp spread_pages); NOT llama-box's binary"
+                                      + f", OpenMP pool of {nth} threads (best of a probe over thread counts up to the container's CPU quota, {quota} of the host's {os.cpu_count()} logical CPUs), weight pages interleaved over the NUMA nodes / first-touched by many threads (ggml_lite.cpp spread_pages); NOT llama-box's binary"
                                       + (f" — binaries found on this host: {found}" if found else " (no llama-box / llama-bench / llama-cli on this host)"),
                             "setup_s": round(time.time() - t_c - tc, 1)}
             cc.free()

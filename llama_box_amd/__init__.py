@@ -149,6 +149,8 @@ _SIGS = {
     # llama_lite
     "llm_preset": (_I, [_S, C.POINTER(HParams)]),
     "llm_model_synth": (_P, [C.POINTER(HParams), C.c_uint64, _P, _I, _I, _P]), "llm_model_synth_split": (_P, [C.POINTER(HParams), C.c_uint64, _P, _P]), "llm_synth_gguf": (_I, [C.POINTER(HParams), C.c_uint64, _S]),
+    "llm_model_synth_layer_split": (_P, [C.POINTER(HParams), C.c_uint64, C.POINTER(_P), _I]),
+    "llm_context_new_layer_split": (_P, [_P, C.POINTER(_P), _I, C.POINTER(ContextParams)]), "llm_layer_split_stats": (None, [_P, C.POINTER(C.c_int64)]),
     "llm_model_load": (_P, [_S, _P]), "llm_model_free": (None, [_P]), "llm_model_hparams": (C.POINTER(HParams), [_P]),
     "llm_model_stream_bytes": (C.c_uint64, [_P]), "llm_model_total_bytes": (C.c_uint64, [_P]), "llm_model_tensor": (TP, [_P, _S]),
     "llm_context_new": (_P, [_P, _P, COMPUTE_FN, C.POINTER(ContextParams)]), "llm_context_free": (None, [_P]),
@@ -210,8 +212,9 @@ class Backend:
 
     def set_option(self, key, value):
         fn = self.proc("ggml_backend_mi355x_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p])
-        if fn(self.backend, key.encode(), str(value).encode()) != 0:
-            raise ValueError(f"unknown backend option {key}")
+        rc = fn(self.backend, key.encode(), str(value).encode())
+        if rc != 0:
+            raise ValueError(f"unknown backend option {key}" if rc == -1 else f"backend option {key}={value} refused ({rc})")
 
     def stat(self, key):
         fn = self.proc("ggml_backend_mi355x_get_stat", C.c_int64, [C.c_void_p, C.c_char_p])

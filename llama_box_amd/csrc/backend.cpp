@@ -67,7 +67,7 @@ static void buf_free(ggml_backend_buffer_t b) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);  // a staged upload may still be writing into this arena
-    HIP_SOFT(hipFree(c->base));
+    HIP_NOTE(hipFree(c->base));
     delete c;
 }
 static void * buf_get_base(ggml_backend_buffer_t b) { return ((buffer_ctx *) b->context)->base; }
@@ -214,13 +214,14 @@ static bool staged_upload(int device, char * dst, const char * src, size_t size)
 static std::atomic<int> g_hip_failed{0};
 void note_hip_failure() { g_hip_failed.store(1, std::memory_order_relaxed); }
 bool hip_failed() { return g_hip_failed.load(std::memory_order_relaxed) != 0; }
+void clear_hip_failure() { g_hip_failed.store(0, std::memory_order_relaxed); }
 
 // ------------------------------------------------------------------------------------------------ mask statistics (common.h)
 namespace {
 struct mask_entry { const void * dev = nullptr; mask_stats st; uint64_t stamp = 0; };
 std::mutex g_mask_mtx;
 mask_entry g_masks[8];
-uint64_t g_mask_clock = 0;
+std::atomic<uint64_t> g_mask_clock{0};
 }  // namespace
 void note_mask_upload(const ggml_tensor * t, const void * host, size_t offset, size_t size) {
     // candidates: a whole 2-D f16 / f32 tensor of up to 256 rows whose name says mask ("KQ_mask" in llama.cpp's graphs).  Larger ones are prompt
@@ -276,6 +277,14 @@ void note_mask_upload(const ggml_tensor * t, const void * host, size_t offset, s
     slot->st = st;
     slot->stamp = ++g_mask_clock;
 }
+// a device-side write (a graph node's output, a tensor copy) into memory on record makes the record stale: the statistics describe bytes that
+// came through set_tensor, nothing else
+void forget_mask_stats(const void * dev_ptr, size_t nbytes) {
+    if (g_mask_clock.load(std::memory_order_relaxed) == 0 || !dev_ptr) return;  // (nothing was ever recorded: the common case costs one load)
+    std::lock_guard<std::mutex> lock(g_mask_mtx);
+    for (mask_entry & e : g_masks)
+        if (e.stamp != 0 && (const char *) e.dev >= (const char *) dev_ptr && (const char *) e.dev < (const char *) dev_ptr + nbytes) { e.dev = nullptr; e.stamp = 0; }
+}
 bool lookup_mask_stats(const void * dev_ptr, mask_stats * out) {
     std::lock_guard<std::mutex> lock(g_mask_mtx);
     for (const mask_entry & e : g_masks)
@@ -307,6 +316,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggm
     buffer_ctx * sc = (buffer_ctx *) sb->context;
     buffer_ctx * dc = (buffer_ctx *) b->context;
     const size_t n = ggml_abi_nbytes(src);
+    forget_mask_stats(dst->data, n);
     uploader_drain(sc->device);
     if (dc->device != sc->device) uploader_drain(dc->device);
     if (sc->device == dc->device) {
@@ -355,8 +365,11 @@ static ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t 
 static size_t buft_alignment(ggml_backend_buffer_type_t) { return 256; }
 static size_t buft_max_size(ggml_backend_buffer_type_t buft) {
     buft_ctx * bc = (buft_ctx *) buft->context;
-    hipDeviceProp_t prop;
-    HIP_SOFT(hipGetDeviceProperties(&prop, bc->device));
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, bc->device) != hipSuccess) {
+        (void) hipGetLastError();
+        return SIZE_MAX;  // (what ggml assumes for a buffer type without get_max_size)
+    }
     return prop.totalGlobalMem;
 }
 static size_t buft_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * t) {
@@ -383,7 +396,7 @@ static void hbuf_free(ggml_backend_buffer_t b) {
         for (size_t i = 0; i < g_pinned.size(); ++i)
             if (g_pinned[i].first == (const char *) b->context) { g_pinned.erase(g_pinned.begin() + (long) i); break; }
     }
-    HIP_SOFT(hipHostFree(b->context));
+    HIP_NOTE(hipHostFree(b->context));
 }
 static void * hbuf_base(ggml_backend_buffer_t b) { return b->context; }
 static void hbuf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, size_t off, size_t sz) { memset((char *) t->data + off, v, sz); }
@@ -417,12 +430,12 @@ static void be_free(ggml_backend_t be) {
     free_graph_cache(c);
     tp_free(c);
     free_split_helpers(c);
-    if (c->ws) HIP_SOFT(hipFree(c->ws));
-    if (c->up_ring) HIP_SOFT(hipHostFree(c->up_ring));
-    if (c->fa_lists) HIP_SOFT(hipFree(c->fa_lists));
-    if (c->rope_tab) HIP_SOFT(hipFree(c->rope_tab));
-    if (c->fa_arrive) HIP_SOFT(hipFree(c->fa_arrive));
-    if (c->ss_buf) HIP_SOFT(hipFree(c->ss_buf));
+    if (c->ws) HIP_NOTE(hipFree(c->ws));
+    if (c->up_ring) HIP_NOTE(hipHostFree(c->up_ring));
+    if (c->fa_lists) HIP_NOTE(hipFree(c->fa_lists));
+    if (c->rope_tab) HIP_NOTE(hipFree(c->rope_tab));
+    if (c->fa_arrive) HIP_NOTE(hipFree(c->fa_arrive));
+    if (c->ss_buf) HIP_NOTE(hipFree(c->ss_buf));
     HIP_SOFT(hipStreamDestroy(c->stream));
     delete c;
     delete be;
@@ -488,6 +501,7 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
     flush_uploads(cs);
     if (cd != cs) flush_uploads(cd);
     const size_t n = ggml_abi_nbytes(src);
+    forget_mask_stats(dst->data, n);
     uploader_join(cs->device, cs->stream);
     if (cd->device != cs->device) uploader_drain(cd->device);
     if (cs->device == cd->device) {
@@ -499,11 +513,11 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
     }
     if (be_src != be_dst) {  // make the destination stream wait for the copy
         hipEvent_t ev;
-        HIP_SOFT(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_NOTE(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIP_SOFT(hipEventRecord(ev, cs->stream));
         HIP_SOFT(hipSetDevice(cd->device));
         HIP_SOFT(hipStreamWaitEvent(cd->stream, ev, 0));
-        HIP_SOFT(hipEventDestroy(ev));
+        HIP_NOTE(hipEventDestroy(ev));
     }
     return true;
 }
@@ -545,8 +559,10 @@ static bool be_is_ours(ggml_backend_t be) { return be != nullptr && be->iface.ge
 static const char * dev_get_name(ggml_backend_dev_t dev) { return dctx(dev)->name.c_str(); }
 static const char * dev_get_description(ggml_backend_dev_t dev) { return dctx(dev)->description.c_str(); }
 static void dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
-    HIP_SOFT(hipSetDevice(dctx(dev)->device));
-    HIP_SOFT(hipMemGetInfo(free, total));
+    *free = 0;  // (what a failed query reports: llama-box's /v1/models and --list-devices print these)
+    *total = 0;
+    HIP_NOTE(hipSetDevice(dctx(dev)->device));
+    HIP_NOTE(hipMemGetInfo(free, total));
 }
 static enum ggml_backend_dev_type dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
 static void dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props * props) {
@@ -636,7 +652,7 @@ static ggml_backend_event_t dev_event_new(ggml_backend_dev_t dev) {
     return new ggml_backend_event{dev, ev};
 }
 static void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t ev) {
-    HIP_SOFT(hipEventDestroy((hipEvent_t) ev->context));
+    HIP_NOTE(hipEventDestroy((hipEvent_t) ev->context));
     delete ev;
 }
 static void dev_event_synchronize(ggml_backend_dev_t, ggml_backend_event_t ev) { HIP_SOFT(hipEventSynchronize((hipEvent_t) ev->context)); }
@@ -699,12 +715,14 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "attn_nf") c->opt.attn_nf = v != 0;
     else if (k == "fa_self_merge") c->opt.fa_self_merge = v != 0;
     else if (k == "ss_partials") c->opt.ss_partials = v != 0;
-    else if (k == "tp_p2p") tp_p2p_enable(c, v != 0);
+    else if (k == "tp_p2p") { if (!tp_p2p_enable(c, v != 0)) return -2; }
+    else if (k == "tp_p2p_reset") { if (!tp_p2p_reset(c)) return -2; }
     else if (k == "fa_splits") c->opt.fa_splits = v;
     else if (k == "fa_wo") c->opt.fa_wo = v != 0;
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;
     else if (k == "small_downloads") c->opt.small_downloads = v != 0;
     else if (k == "timing") c->opt.timing = v != 0;
+    else if (k == "clear_failure") { if (v) clear_hip_failure(); }
     else if (k == "staged_upload") g_staged_upload.store(v != 0);
     else return -1;
     HIP_SOFT(hipStreamSynchronize(c->stream));
@@ -746,11 +764,11 @@ static int api_timing_report(ggml_backend_t be, char * buf, size_t size, int res
     HIP_SOFT(hipStreamSynchronize(c->stream));
     for (auto & pe : c->pending_events) {
         float ms = 0;
-        HIP_SOFT(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
+        HIP_NOTE(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
         c->timing[pe.first].total_ms += ms;
         c->timing[pe.first].count += 1;
-        HIP_SOFT(hipEventDestroy(pe.second.first));
-        HIP_SOFT(hipEventDestroy(pe.second.second));
+        HIP_NOTE(hipEventDestroy(pe.second.first));
+        HIP_NOTE(hipEventDestroy(pe.second.second));
     }
     c->pending_events.clear();
     std::string out;

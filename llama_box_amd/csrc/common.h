@@ -51,6 +51,17 @@
         }                                                                                                       \
     } while (0)
 
+// Bookkeeping calls that move no tensor data (event create / destroy / elapsed time of the bench's timing, frees in teardown, memory and property
+// queries): a failure there is logged and cleared and NOTHING else — it must not brick inference for the rest of the process.
+#define HIP_NOTE(expr)                                                                                          \
+    do {                                                                                                        \
+        hipError_t err_ = (expr);                                                                               \
+        if (err_ != hipSuccess) {                                                                               \
+            (void) hipGetLastError();                                                                           \
+            fprintf(stderr, "ggml-mi355x: HIP error %d (%s) at %s:%d: %s (ignored: no tensor data involved)\n", (int) err_, hipGetErrorString(err_), __FILE__, __LINE__, #expr); \
+        }                                                                                                       \
+    } while (0)
+
 // inside graph execution a HIP failure must fail ONE llama_decode (GGML_STATUS_FAILED -> rc -2, llama-box/httpserver.hpp:3541-3545),
 // not the whole llama-box process: log, clear the sticky error, hand `ret` to the caller
 #define HIP_TRY(expr, ret)                                                                                      \
@@ -68,6 +79,7 @@ namespace mi355x {
 int log_level();
 void note_hip_failure();  // backend.cpp: a data-path HIP call failed outside graph execution (HIP_SOFT)
 bool hip_failed();
+void clear_hip_failure();  // set_option("clear_failure", 1): the operator's way back without a restart (the log says what failed)
 
 // device-side layout of a Q8_K-quantised activation block (the ggml block_q8_K fields, 16-byte aligned:
 // qs | bsums | d) — produced by quantize kernels, consumed by the K-quant matvec / GEMM kernels
@@ -278,6 +290,7 @@ struct mask_stats {
 };
 void note_mask_upload(const ggml_tensor * t, const void * host, size_t offset, size_t size);
 bool lookup_mask_stats(const void * dev_ptr, mask_stats * out);
+void forget_mask_stats(const void * dev_ptr, size_t nbytes);  // a device-side write landed there
 // 1: the mask at dev_ptr is known and sparse enough (<= a quarter visible) that per-token position lists beat a dense tile kernel
 int mask_sparse_hint(const void * dev_ptr);
 
@@ -288,7 +301,9 @@ bool tp_active(const backend_ctx * ctx);
 int tp_p2p_export(backend_ctx * ctx, int rank, int world, void * handle_out, size_t size);  // -> this rank's mailbox as a hipIpcMemHandle_t (64 bytes)
 int tp_p2p_attach(backend_ctx * ctx, const void * handles, size_t size);                    // world handles in rank order, own slot ignored
 int64_t tp_p2p_timeouts(backend_ctx * ctx);
-void tp_p2p_enable(backend_ctx * ctx, bool on);
+bool tp_p2p_enable(backend_ctx * ctx, bool on);  // false: refused (switching the only transport of a group off)
+bool tp_p2p_reset(backend_ctx * ctx);           // forget a time-out (every rank, all idle)
+bool tp_check(backend_ctx * ctx);               // false: an all-reduce of an earlier graph timed out — the caller fails its graph_compute
 // in-stream sum all-reduce of n floats at ptr (capturable)
 bool tp_all_reduce(backend_ctx * ctx, float * ptr, size_t n);
 // the same with the residual ADD that follows folded in: out[i] = sum_ranks(ptr[i]) + add[i] (add: n values), and the sum of squares of `out`

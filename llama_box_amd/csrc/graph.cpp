@@ -128,7 +128,7 @@ static bool ensure_ws(backend_ctx * c, size_t need) {
     if (need <= c->ws_size) return true;
     if (c->capturing) return false;
     HIP_SOFT(hipStreamSynchronize(c->stream));
-    if (c->ws) HIP_SOFT(hipFree(c->ws));
+    if (c->ws) HIP_NOTE(hipFree(c->ws));
     c->ws = nullptr;
     c->ws_size = 0;
     const size_t sz = (need + (size_t) (8u << 20)) & ~(size_t) 255;
@@ -206,8 +206,8 @@ struct timed_scope {
     // probe = true: the class is ONE streaming mat-vec launch whose launcher can time the kernel itself (launch_probe)
     timed_scope(backend_ctx * c_, const char * cls_, double bytes, bool probe_ = false) : c(c_), cls(cls_), probe(probe_) {
         if (!c->opt.timing || c->capturing) return;
-        HIP_SOFT(hipEventCreate(&e0));
-        HIP_SOFT(hipEventCreate(&e1));
+        HIP_NOTE(hipEventCreate(&e0));
+        HIP_NOTE(hipEventCreate(&e1));
         if (probe) {
             g_launch_probe.e0 = e0;
             g_launch_probe.e1 = e1;
@@ -225,8 +225,8 @@ struct timed_scope {
             const bool used = g_launch_probe.used;
             g_launch_probe = launch_probe();
             if (!used) {  // the launcher took a path without the probe: nothing was recorded
-                HIP_SOFT(hipEventDestroy(e0));
-                HIP_SOFT(hipEventDestroy(e1));
+                HIP_NOTE(hipEventDestroy(e0));
+                HIP_NOTE(hipEventDestroy(e1));
                 return;
             }
         } else {
@@ -413,7 +413,9 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
             c->st.ss_handoffs++;
         }
         if (st.ss_tensor != nullptr && ranges_overlap(dst, st.ss_tensor)) st.ss_tensor = nullptr;  // (this result recycles that tensor's block)
-        if (c->opt.ss_partials && c->ss_buf != nullptr && (add || add2) && !w2 && launch_mmvq_ss_count(a) > 0) {
+        // (never from a launch that CONSUMES the record — a deferred-norm prologue with a bias or residual add, e.g. Qwen2's Q/K/V + bias when the fused
+        // QKV launch declines: a workgroup that finishes early would overwrite ss_buf[blockIdx.x] before a late one has read all ss_n partials)
+        if (c->opt.ss_partials && c->ss_buf != nullptr && (add || add2) && !w2 && !a.ss_in && launch_mmvq_ss_count(a) > 0) {
             // a residual stream leaves this launch (wo + residual, ffn_down + residual): the RMS_NORM that reads it next takes the sum of squares from here
             a.ss_out = c->ss_buf;
             st.ss_tensor = dst;
@@ -1809,6 +1811,8 @@ static bool run_nodes(backend_ctx * c, ggml_cgraph * g, const ws_plan & wp) {
         st.ooo.clear();
         const int used = run_node(st, i);
         if (used < 0) return false;
+        for (int k = 0; k < used; ++k)  // (mask statistics describe uploaded bytes only: common.h)
+            if (!is_view_op(g->nodes[i + k]) && g->nodes[i + k]->data) forget_mask_stats(g->nodes[i + k]->data, ggml_abi_nbytes(g->nodes[i + k]));
         if (!st.q8_fresh && c->q8_src) {
             const char * q0 = (const char *) c->q8_src, * q1 = q0 + c->q8_bytes;
             auto hits = [&](const ggml_tensor * t) {
@@ -1915,6 +1919,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         MI_ERR("graph_compute: refused — an earlier HIP call of the data path failed (see the log above)");
         return GGML_STATUS_FAILED;
     }
+    if (!tp_check(c)) return GGML_STATUS_FAILED;  // (one load of a host word; tp.cpp)
     const auto t_enter = std::chrono::steady_clock::now();
     struct host_clock {  // host time of this call (stats::graph_compute_host_ns: key comparison, planning, launches — the GPU may idle meanwhile)
         backend_ctx * c;

@@ -130,6 +130,8 @@ struct p2p_args {
     char * mbox[P2P_MAX_RANKS];       // every rank's mailbox as mapped HERE: [2 parities][world sources][P2P_SLOT_FLOATS] 8-byte granules
     unsigned * state;                 // device: [0] epoch of the last finished all-reduce, [1] arrivals of the running one, [2] time-outs
     unsigned max_spins;
+    unsigned * err_host;              // host-mapped word (or null): raised together with state[2] so that the HOST sees a time-out without a device read —
+                                      // graph_compute checks it on entry and reports GGML_STATUS_FAILED
     // fused epilogue (one launch of n <= P2P_SLOT_FLOATS only): out[i] = sum + add[i] (the residual ADD that follows a row-parallel mat-mul:
     // `add` rows of n values, or null) and, for ss_out != null, one partial sum of squares of `out` per workgroup (mmvq_args::ss_in's producer)
     const float * add;

@@ -74,7 +74,7 @@ static void sbuf_free(ggml_backend_buffer_t b) {
         for (int d = 0; d < kv.second.n_dev; ++d)
             if (kv.second.slice[d]) {
                 HIP_SOFT(hipSetDevice(logical_device_ordinal(d)));
-                HIP_SOFT(hipFree(kv.second.slice[d]));
+                HIP_NOTE(hipFree(kv.second.slice[d]));
             }
     delete c;
 }
@@ -90,7 +90,7 @@ static enum ggml_status sbuf_init_tensor(ggml_backend_buffer_t b, ggml_tensor * 
         for (int d = 0; d < old->second.n_dev; ++d)
             if (old->second.slice[d]) {
                 HIP_SOFT(hipSetDevice(logical_device_ordinal(d)));
-                HIP_SOFT(hipFree(old->second.slice[d]));
+                HIP_NOTE(hipFree(old->second.slice[d]));
             }
         c->tensors.erase(old);
     }
@@ -279,15 +279,15 @@ void free_split_helpers(backend_ctx * c) {
         if (!h) continue;
         HIP_SOFT(hipSetDevice(h->ordinal));
         HIP_SOFT(hipStreamSynchronize(h->stream));
-        if (h->ws) HIP_SOFT(hipFree(h->ws));
-        HIP_SOFT(hipEventDestroy(h->ev));
+        if (h->ws) HIP_NOTE(hipFree(h->ws));
+        HIP_NOTE(hipEventDestroy(h->ev));
         HIP_SOFT(hipStreamDestroy(h->stream));
         delete h;
     }
     c->split_helpers.clear();
     HIP_SOFT(hipSetDevice(c->device));
     if (c->split_ready) {
-        HIP_SOFT(hipEventDestroy(c->split_ready));
+        HIP_NOTE(hipEventDestroy(c->split_ready));
         c->split_ready = nullptr;
     }
 }

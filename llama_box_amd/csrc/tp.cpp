@@ -62,6 +62,7 @@ struct tp_state {
     char * mbox_local = nullptr;
     char * mbox[P2P_MAX_RANKS] = {nullptr};
     unsigned * p2p_state = nullptr;
+    unsigned * p2p_err_host = nullptr;  // pinned + mapped: raised by the kernel on a time-out, read by tp_check() without touching the device
     bool p2p = false;
     int p2p_max_cols_bytes = 0;  // messages up to this many bytes take the one-shot path when RCCL is there too
 };
@@ -132,6 +133,8 @@ int tp_p2p_export(backend_ctx * c, int rank, int world, void * handle_out, size_
         HIP_TRY(hipMemset(t->mbox_local, 0, mbox_bytes(world)), -5);  // tag 0 never matches: epochs start at 1
         HIP_TRY(hipMalloc((void **) &t->p2p_state, 64), -5);
         HIP_TRY(hipMemset(t->p2p_state, 0, 64), -5);
+        HIP_TRY(hipHostMalloc((void **) &t->p2p_err_host, 64, hipHostMallocMapped | hipHostMallocPortable), -5);
+        *t->p2p_err_host = 0;
         HIP_TRY(hipDeviceSynchronize(), -5);
     }
     hipIpcMemHandle_t h;
@@ -139,7 +142,7 @@ int tp_p2p_export(backend_ctx * c, int rank, int world, void * handle_out, size_
     if (e != hipSuccess) {
         (void) hipGetLastError();
         MI_ERR("tp_p2p_export: hipIpcGetMemHandle failed (%s) — HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver", hipGetErrorString(e));
-        if (!c->tp) { (void) hipFree(t->mbox_local); (void) hipFree(t->p2p_state); delete t; }
+        if (!c->tp) { (void) hipFree(t->mbox_local); (void) hipFree(t->p2p_state); (void) hipHostFree(t->p2p_err_host); delete t; }
         return -6;
     }
     memcpy(handle_out, &h, sizeof(h));
@@ -175,9 +178,40 @@ int tp_p2p_attach(backend_ctx * c, const void * handles, size_t size) {
             t->comm ? ", RCCL for longer messages" : ", no RCCL communicator");
     return 0;
 }
-// set_option("tp_p2p", 0 / 1): stop / resume serving sums through the mailboxes (a launcher that saw time-outs falls back to RCCL)
-void tp_p2p_enable(backend_ctx * c, bool on) {
-    if (c->tp && c->tp->mbox_local && c->tp->mbox[c->tp->rank]) c->tp->p2p = on;
+// set_option("tp_p2p", 0 / 1): stop / resume serving sums through the mailboxes (a launcher that saw time-outs falls back to RCCL).
+// Switching them OFF is refused in a group that has no RCCL communicator: nothing else could carry the sums, and a row-parallel mat-mul
+// without its reduction is a silently wrong model.
+bool tp_p2p_enable(backend_ctx * c, bool on) {
+    if (!(c->tp && c->tp->mbox_local && c->tp->mbox[c->tp->rank])) return !on;  // (no mailboxes attached: "off" is what it is)
+    if (!on && c->tp->comm == nullptr) {
+        MI_ERR("set_option(tp_p2p, 0) refused: this tensor-parallel group has no RCCL communicator, the mailboxes are its only transport");
+        return false;
+    }
+    c->tp->p2p = on;
+    if (!on && c->tp->p2p_err_host) *c->tp->p2p_err_host = 0;  // (the sums are RCCL's from here on: a time-out of the mailboxes is history)
+    return true;
+}
+// set_option("tp_p2p_reset", 1), on EVERY rank of the group with all of them idle (the host's control plane: a barrier before and after):
+// forgets a time-out — device word, host word, the mailboxes' tags and the epoch — so that the group can be used again
+bool tp_p2p_reset(backend_ctx * c) {
+    tp_state * t = c->tp;
+    if (!t || !t->mbox_local || !t->p2p_state) return false;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { (void) hipGetLastError(); return false; }
+    if (hipMemset(t->mbox_local, 0, mbox_bytes(t->world)) != hipSuccess || hipMemset(t->p2p_state, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void) hipGetLastError(); return false; }
+    if (t->p2p_err_host) *t->p2p_err_host = 0;
+    t->p2p = t->mbox[t->rank] != nullptr;
+    return true;
+}
+// graph_compute's entry check: a time-out of the one-shot all-reduce means the sums of the graph(s) before were wrong, and the group's ranks may
+// disagree about it.  Every graph_compute of this rank fails from then on until the HOST — which has a control plane over the ranks — either resets
+// the group (set_option("tp_p2p_reset", 1) on every rank) or, with a RCCL communicator attached, switches the mailboxes off on every rank
+// (set_option("tp_p2p", 0): bench.py does that after agreeing over gloo).  Never a silent wrong sum, never a rank-local change of transport.
+bool tp_check(backend_ctx * c) {
+    tp_state * t = c->tp;
+    if (!t || !t->p2p_err_host || *(volatile unsigned *) t->p2p_err_host == 0) return true;
+    MI_ERR("tensor parallel rank %d / %d: the peer-to-peer all-reduce timed out — results since then are invalid; graph_compute fails until the host resets the group "
+           "(set_option tp_p2p_reset) %s", t->rank, t->world, t->comm ? "or switches it to RCCL on every rank (set_option tp_p2p 0)" : "(no RCCL communicator is attached)");
+    return false;
 }
 int64_t tp_p2p_timeouts(backend_ctx * c) {
     if (!c->tp || !c->tp->p2p_state) return 0;
@@ -186,11 +220,17 @@ int64_t tp_p2p_timeouts(backend_ctx * c) {
     return (int64_t) st[2];
 }
 
-bool tp_active(const backend_ctx * c) { return c->tp != nullptr && c->tp->world > 1 && (c->tp->comm != nullptr || c->tp->p2p); }
+// membership, not transport: a rank of a group ALWAYS treats its row-parallel weights as partial sums — if no transport is left, the sum fails
+// loudly instead of being skipped
+bool tp_active(const backend_ctx * c) { return c->tp != nullptr && c->tp->world > 1; }
 
 bool tp_all_reduce(backend_ctx * c, float * ptr, size_t n) {
     if (!tp_active(c)) return true;
     tp_state * t = c->tp;
+    if (t->comm == nullptr && !t->p2p) {
+        MI_ERR("tensor parallel rank %d / %d: a row-parallel sum is due and no transport is available (no RCCL communicator, mailboxes off)", t->rank, t->world);
+        return false;
+    }
     if (t->p2p && (t->comm == nullptr || n * sizeof(float) <= (size_t) t->p2p_max_cols_bytes)) {
         // one launch per mailbox-full (decode: ONE launch; a prompt batch without RCCL goes through in chunks)
         static const unsigned max_spins = getenv("GGML_MI355X_P2P_MAX_SPINS") ? (unsigned) atoll(getenv("GGML_MI355X_P2P_MAX_SPINS")) : 2000000u;  // seconds of polling before the group is declared broken (ranks enter their first all-reduce after a barrier of the launcher)
@@ -202,6 +242,7 @@ bool tp_all_reduce(backend_ctx * c, float * ptr, size_t n) {
             a.world = t->world;
             for (int r = 0; r < t->world; ++r) a.mbox[r] = t->mbox[r];
             a.state = t->p2p_state;
+            a.err_host = t->p2p_err_host;
             a.max_spins = max_spins;
             launch_p2p_all_reduce(c->stream, a);
             c->st.kernel_launches++;
@@ -230,6 +271,7 @@ bool tp_all_reduce_fused(backend_ctx * c, float * ptr, size_t n, const float * a
     a.world = t->world;
     for (int r = 0; r < t->world; ++r) a.mbox[r] = t->mbox[r];
     a.state = t->p2p_state;
+    a.err_host = t->p2p_err_host;
     a.max_spins = max_spins;
     a.add = add;
     a.out = out;
@@ -249,6 +291,7 @@ void tp_free(backend_ctx * c) {
         if (c->tp->mbox[r] && c->tp->mbox[r] != c->tp->mbox_local && hipIpcCloseMemHandle(c->tp->mbox[r]) != hipSuccess) (void) hipGetLastError();
     if (c->tp->mbox_local && hipFree(c->tp->mbox_local) != hipSuccess) (void) hipGetLastError();
     if (c->tp->p2p_state && hipFree(c->tp->p2p_state) != hipSuccess) (void) hipGetLastError();
+    if (c->tp->p2p_err_host && hipHostFree(c->tp->p2p_err_host) != hipSuccess) (void) hipGetLastError();
     delete c->tp;
     c->tp = nullptr;
 }

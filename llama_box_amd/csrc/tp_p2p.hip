@@ -14,7 +14,10 @@
 //   * the epoch lives in DEVICE memory and is advanced by the kernel itself (the last workgroup to finish writes it; the next launch on the
 //     stream starts after this one has ended): a hipGraph replay re-runs the same kernel nodes with frozen arguments, so nothing per-launch
 //     may come from the host;
-//   * every spin is bounded: on a time-out the kernel raises an error word and returns (the host reports it, nothing hangs).
+//   * every spin is bounded: on a time-out the kernel raises an error word in device memory (later launches stop waiting) AND a host-mapped
+//     word: the sums of a broken group are garbage, so the next graph_compute of this backend returns GGML_STATUS_FAILED (tp.cpp: tp_check)
+//     until the host resets the group (set_option("tp_p2p_reset", 1) on every rank) or, with a RCCL communicator attached, from then on
+//     sums through RCCL.
 // The mailbox memory is allocated uncached / fine-grained and exported with hipIpcGetMemHandle; peers map it with hipIpcOpenMemHandle
 // (tp.cpp).  Two ranks on ONE GPU work the same way (that is how the tests run it on a one-GPU box).
 #include <hip/hip_runtime.h>
@@ -89,7 +92,10 @@ __global__ void __launch_bounds__(256) k_p2p_all_reduce(const p2p_args a) {
         __syncthreads();
         if (tid == 0) a.ss_out[blockIdx.x] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
     }
-    if (failed) atomicAdd(a.state + 2, 1u);
+    if (failed) {
+        atomicAdd(a.state + 2, 1u);
+        if (a.err_host) __hip_atomic_store(a.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
     if (tid == 0) {  // the last workgroup to get here publishes the epoch for the next launch
         const unsigned done = __hip_atomic_fetch_add(a.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

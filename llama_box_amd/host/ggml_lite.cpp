@@ -717,6 +717,62 @@ enum ggml_status ggml_backend_graph_compute(ggml_backend_t backend, struct ggml_
 }
 bool ggml_backend_supports_op(ggml_backend_t backend, const struct ggml_tensor * op) { return ggml_backend_dev_supports_op(backend->device, op); }
 
+// ---- tensor copies between backends and events, as ggml-backend.cpp implements them (what ggml_backend_sched issues between the devices of a
+// layer split: -sm layer, llama.cpp's default; /root/reference/llama-box/engine_param.hpp:900-916)
+static bool same_layout(const struct ggml_tensor * a, const struct ggml_tensor * b) {
+    if (a->type != b->type) return false;
+    for (int i = 0; i < GGML_MAX_DIMS; ++i)
+        if (a->ne[i] != b->ne[i] || a->nb[i] != b->nb[i]) return false;
+    return true;
+}
+void ggml_backend_tensor_copy(struct ggml_tensor * src, struct ggml_tensor * dst) {
+    LITE_ASSERT(same_layout(src, dst) && "cannot copy tensors with different layouts");
+    if (src == dst) return;
+    ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
+    ggml_backend_buffer_t db = dst->view_src ? dst->view_src->buffer : dst->buffer;
+    if (ggml_backend_buffer_is_host(sb)) {
+        ggml_backend_tensor_set(dst, src->data, 0, ggml_nbytes(src));
+    } else if (ggml_backend_buffer_is_host(db)) {
+        ggml_backend_tensor_get(src, dst->data, 0, ggml_nbytes(src));
+    } else if (!(db->iface.cpy_tensor && db->iface.cpy_tensor(db, src, dst))) {
+        const size_t n = ggml_nbytes(src);  // (the slow way, through host memory)
+        void * tmp = malloc(n);
+        LITE_ASSERT(tmp);
+        ggml_backend_tensor_get(src, tmp, 0, n);
+        ggml_backend_tensor_set(dst, tmp, 0, n);
+        free(tmp);
+    }
+}
+void ggml_backend_tensor_copy_async(ggml_backend_t backend_src, ggml_backend_t backend_dst, struct ggml_tensor * src, struct ggml_tensor * dst) {
+    LITE_ASSERT(same_layout(src, dst) && "cannot copy tensors with different layouts");
+    if (src == dst) return;
+    if (backend_dst->iface.cpy_tensor_async != nullptr && backend_dst->iface.cpy_tensor_async(backend_src, backend_dst, src, dst)) return;
+    // an async copy would happen after everything queued on both backends: synchronise both, then copy
+    ggml_backend_synchronize(backend_src);
+    ggml_backend_synchronize(backend_dst);
+    ggml_backend_tensor_copy(src, dst);
+}
+ggml_backend_event_t ggml_backend_event_new(ggml_backend_dev_t device) {
+    if (device == nullptr || device->iface.event_new == nullptr) return nullptr;  // (a device without events: the scheduler synchronises instead)
+    return device->iface.event_new(device);
+}
+void ggml_backend_event_free(ggml_backend_event_t event) {
+    if (event == nullptr) return;
+    event->device->iface.event_free(event->device, event);
+}
+void ggml_backend_event_record(ggml_backend_event_t event, ggml_backend_t backend) {
+    LITE_ASSERT(backend->iface.event_record != nullptr);
+    backend->iface.event_record(backend, event);
+}
+void ggml_backend_event_synchronize(ggml_backend_event_t event) {
+    LITE_ASSERT(event->device->iface.event_synchronize);
+    event->device->iface.event_synchronize(event->device, event);
+}
+void ggml_backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
+    LITE_ASSERT(backend->iface.event_wait != nullptr);
+    backend->iface.event_wait(backend, event);
+}
+
 // ---------------------------------------------------------------------------------- host (malloc) buffer type
 static const char * cpu_buft_name(ggml_backend_buffer_type_t) { return "CPU"; }
 static void cpu_buf_free(ggml_backend_buffer_t b) { free(b->context); }

@@ -159,6 +159,14 @@ void ggml_backend_synchronize(ggml_backend_t backend);
 enum ggml_status ggml_backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph);
 enum ggml_status ggml_backend_graph_compute_async(ggml_backend_t backend, struct ggml_cgraph * cgraph);
 bool ggml_backend_supports_op(ggml_backend_t backend, const struct ggml_tensor * op);
+/* copies between backends and events (ggml-backend.h): what ggml_backend_sched issues between the devices of a layer split */
+void ggml_backend_tensor_copy(struct ggml_tensor * src, struct ggml_tensor * dst);
+void ggml_backend_tensor_copy_async(ggml_backend_t backend_src, ggml_backend_t backend_dst, struct ggml_tensor * src, struct ggml_tensor * dst);
+ggml_backend_event_t ggml_backend_event_new(ggml_backend_dev_t device);
+void ggml_backend_event_free(ggml_backend_event_t event);
+void ggml_backend_event_record(ggml_backend_event_t event, ggml_backend_t backend);
+void ggml_backend_event_synchronize(ggml_backend_event_t event);
+void ggml_backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event);
 
 /* plain host-memory buffer type (the role ggml_backend_cpu_buffer_type() plays upstream) */
 ggml_backend_buffer_type_t ggml_backend_cpu_buffer_type(void);

@@ -222,6 +222,8 @@ struct llm_model {
     ggml_tensor *tok_embd = nullptr, *output_norm = nullptr, *output = nullptr;
     std::vector<llm_layer> layers;
     uint64_t stream_bytes = 0, total_bytes = 0;
+    int n_dev = 1;               // -sm layer: devices the layers are spread over (llm_model_synth_layer_split)
+    std::vector<int> layer_dev;  // ... and which of them holds layer il
 };
 
 static bool use_more_bits(int i, int n) { return i < n / 8 || i >= 7 * n / 8 || (i - n / 8) % 3 == 2; }
@@ -356,7 +358,7 @@ static void bind_tensors(llm_model * m) {
 }
 
 static llm_model * model_synth_impl(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, int tp_rank, int tp_size,
-                                    ggml_backend_buffer_type_t rowpar_buft, bool split_mm);
+                                    ggml_backend_buffer_type_t rowpar_buft, bool split_mm, const std::vector<ggml_backend_buffer_type_t> * layer_bufts = nullptr);
 extern "C" struct llm_model * llm_model_synth(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, int tp_rank, int tp_size,
                                               ggml_backend_buffer_type_t rowpar_buft) {
     return model_synth_impl(hp, seed, buft, tp_rank, tp_size, rowpar_buft, false);
@@ -366,59 +368,77 @@ extern "C" struct llm_model * llm_model_synth(const struct llm_hparams * hp, uin
 extern "C" struct llm_model * llm_model_synth_split(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, ggml_backend_buffer_type_t split_buft) {
     return model_synth_impl(hp, seed, buft, 0, 1, split_buft, true);
 }
+// -sm layer (llama.cpp's default with several devices; llama-box/engine_param.hpp:900-916): device d holds a contiguous range of layers in its own
+// buffer type, token_embd goes with layer 0, output_norm / output with the last layer
+static int layer_split_device(int il, int n_layer, int n_dev) { return std::min(n_dev - 1, il * n_dev / std::max(1, n_layer)); }
+extern "C" struct llm_model * llm_model_synth_layer_split(const struct llm_hparams * hp, uint64_t seed, const ggml_backend_buffer_type_t * bufts, int n_dev) {
+    if (n_dev < 1 || n_dev > hp->n_layer) return nullptr;
+    std::vector<ggml_backend_buffer_type_t> v(bufts, bufts + n_dev);
+    return model_synth_impl(hp, seed, bufts[0], 0, 1, nullptr, false, &v);
+}
 static llm_model * model_synth_impl(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, int tp_rank, int tp_size,
-                                    ggml_backend_buffer_type_t rowpar_buft, bool split_mm) {
+                                    ggml_backend_buffer_type_t rowpar_buft, bool split_mm, const std::vector<ggml_backend_buffer_type_t> * layer_bufts) {
     llm_model * m = new llm_model();
     m->hp = *hp;
     m->tp_rank = tp_rank;
     m->tp_size = tp_size;
     m->ctx = ggml_init({0, nullptr, true});
     std::vector<tensor_plan> plan = make_plan(*hp, tp_rank, tp_size, split_mm);
-    // two allocation groups: ordinary weights, and row-parallel weights (in the backend's reducing buffer type)
-    ggml_context * ctx_rp = nullptr;
     std::vector<ggml_tensor *> ts;
     for (auto & t : plan) {
-        // tensors are created in m->ctx for lookup; row-parallel ones are allocated separately below
         ggml_tensor * x = ggml_new_tensor_2d(m->ctx, t.type, t.ne0, t.ne1);
         ggml_set_name(x, t.name.c_str());
         ts.push_back(x);
     }
-    (void) ctx_rp;
-    // allocate: ordinary group first
+    // allocation groups: [0] ordinary weights, [1] row-parallel weights (the backend's reducing / split buffer type), or one group per device of a layer split
+    std::vector<ggml_backend_buffer_type_t> group_buft;
+    std::vector<int> group_of(plan.size(), 0);
+    if (layer_bufts) {
+        group_buft = *layer_bufts;
+        m->n_dev = (int) layer_bufts->size();
+        m->layer_dev.resize((size_t) hp->n_layer);
+        for (int il = 0; il < hp->n_layer; ++il) m->layer_dev[(size_t) il] = layer_split_device(il, hp->n_layer, m->n_dev);
+        for (size_t i = 0; i < plan.size(); ++i) {
+            int il = -1;
+            if (sscanf(plan[i].name.c_str(), "blk.%d.", &il) == 1) group_of[i] = m->layer_dev[(size_t) il];
+            else group_of[i] = plan[i].name == "token_embd.weight" ? 0 : m->n_dev - 1;
+        }
+    } else {
+        group_buft = {buft, rowpar_buft};
+        for (size_t i = 0; i < plan.size(); ++i) group_of[i] = (plan[i].rowpar && rowpar_buft) ? 1 : 0;
+    }
     {
-        const size_t align = ggml_backend_buft_get_alignment(buft);
-        size_t total = 0, total_rp = 0;
+        std::vector<size_t> total(group_buft.size(), 0), off(group_buft.size(), 0);
+        std::vector<ggml_backend_buffer_t> bufs(group_buft.size(), nullptr);
         for (size_t i = 0; i < plan.size(); ++i) {
-            size_t & acc = (plan[i].rowpar && rowpar_buft) ? total_rp : total;
-            acc = (acc + align - 1) / align * align + ggml_backend_buft_get_alloc_size(buft, ts[i]);
+            const int g = group_of[i];
+            const size_t align = ggml_backend_buft_get_alignment(group_buft[(size_t) g]);
+            total[(size_t) g] = (total[(size_t) g] + align - 1) / align * align + ggml_backend_buft_get_alloc_size(group_buft[(size_t) g], ts[i]);
         }
-        ggml_backend_buffer_t buf = ggml_backend_buft_alloc_buffer(buft, total + align);
-        ggml_backend_buffer_t buf_rp = (total_rp && rowpar_buft) ? ggml_backend_buft_alloc_buffer(rowpar_buft, total_rp + align) : nullptr;
-        if (!buf || (total_rp && rowpar_buft && !buf_rp)) {
-            fprintf(stderr, "llm_model_synth: failed to allocate %zu bytes of weights\n", total + total_rp);
-            llm_model_free(m);
-            return nullptr;
+        for (size_t g = 0; g < group_buft.size(); ++g) {
+            if (!total[g]) continue;
+            bufs[g] = ggml_backend_buft_alloc_buffer(group_buft[g], total[g] + ggml_backend_buft_get_alignment(group_buft[g]));
+            if (!bufs[g]) {
+                fprintf(stderr, "llm_model_synth: failed to allocate %zu bytes of weights\n", total[g]);
+                llm_model_free(m);
+                return nullptr;
+            }
+            ggml_backend_buffer_set_usage(bufs[g], GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+            m->buffers.push_back(bufs[g]);
         }
-        ggml_backend_buffer_set_usage(buf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
-        m->buffers.push_back(buf);
-        if (buf_rp) {
-            ggml_backend_buffer_set_usage(buf_rp, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
-            m->buffers.push_back(buf_rp);
-        }
-        size_t off = 0, off_rp = 0;
         for (size_t i = 0; i < plan.size(); ++i) {
-            const bool rp = plan[i].rowpar && rowpar_buft;
-            size_t & o = rp ? off_rp : off;
-            ggml_backend_buffer_t b = rp ? buf_rp : buf;
-            o = (o + align - 1) / align * align;
-            ts[i]->data = (char *) ggml_backend_buffer_get_base(b) + o;
-            ts[i]->buffer = b;
-            if (b->iface.init_tensor && b->iface.init_tensor(b, ts[i]) != GGML_STATUS_SUCCESS) {
+            const size_t g = (size_t) group_of[i];
+            const size_t align = ggml_backend_buft_get_alignment(group_buft[g]);
+            ggml_backend_buffer_t bb = bufs[g];
+            off[g] = (off[g] + align - 1) / align * align;
+            ts[i]->data = (char *) ggml_backend_buffer_get_base(bb) + off[g];
+            ts[i]->buffer = bb;
+            if (bb->iface.init_tensor && bb->iface.init_tensor(bb, ts[i]) != GGML_STATUS_SUCCESS) {
                 fprintf(stderr, "llm_model_synth: init_tensor failed for %s\n", plan[i].name.c_str());
                 llm_model_free(m);
                 return nullptr;
             }
-            o += ggml_backend_buft_get_alloc_size(buft, ts[i]);
+            off[g] += ggml_backend_buft_get_alloc_size(group_buft[g], ts[i]);
         }
     }
     // generate + upload in chunks of rows, generation multi-threaded (each block is independent)
@@ -552,14 +572,6 @@ extern "C" struct ggml_tensor * llm_model_tensor(struct llm_model * m, const cha
 // vectorise — no short-circuit — and compiled at -O3: the library is built at -O2, where this compiler does not try)
 #pragma GCC push_options
 #pragma GCC optimize("O3")
-static void mask_row(uint16_t * __restrict__ row, const int n_kv, const int32_t * __restrict__ cpos, const int32_t * __restrict__ cseq, const int32_t s, const int32_t p,
-                     const uint16_t vis, const uint16_t hid) {
-    const uint32_t pu = (uint32_t) p;
-    for (int j = 0; j < n_kv; ++j) {
-        const bool v = (cseq[j] == s) & ((uint32_t) cpos[j] <= pu);
-        row[j] = v ? vis : hid;
-    }
-}
 static void mask_row(float * __restrict__ row, const int n_kv, const int32_t * __restrict__ cpos, const int32_t * __restrict__ cseq, const int32_t s, const int32_t p,
                      const float vis, const float hid) {
     const uint32_t pu = (uint32_t) p;
@@ -573,6 +585,13 @@ static void mask_row(float * __restrict__ row, const int n_kv, const int32_t * _
 struct kv_cell {
     int32_t pos = -1;
     int32_t seq = -1;
+};
+
+// the inputs a graph segment reads and the tensor it ends in.  One segment = the whole model on one backend; with -sm layer one segment per device,
+// each with its own copies of the inputs and, from the second on, the residual stream of the previous device as an input (`resid`)
+struct seg_io {
+    ggml_tensor *tokens = nullptr, *pos = nullptr, *mask = nullptr, *k_idxs = nullptr, *v_idxs = nullptr, *out_ids = nullptr, *resid = nullptr;
+    ggml_tensor * out = nullptr;  // l_out of the segment's last layer, or the logits
 };
 
 struct graph_key {
@@ -618,6 +637,27 @@ struct llm_context {
     // in-flight micro-batch keeps its own input slot, so the host builds and stages batch i+1 while the GPU runs batch i
     static constexpr int PIN_SLOTS = 4;
     int pin_slot = 0, in_flight = 0;
+    // -sm layer (llm_context_new_layer_split): one graph segment per device, driven the way ggml_backend_sched drives the splits of a
+    // layer-split model — input copies in LS_COPIES slots per device, cpy_tensor_async of the residual stream between neighbouring
+    // devices, one event per (device, slot) recorded after the segment's graph and waited for before the slot is overwritten
+    static constexpr int LS_COPIES = 2;
+    struct ls_dev {
+        ggml_backend_t be = nullptr;
+        ggml_backend_buffer_type_t buft = nullptr;
+        ggml_gallocr_t galloc = nullptr;
+        int l0 = 0, l1 = 0;
+        ggml_context * ctx_kv = nullptr;
+        ggml_backend_buffer_t buf_kv = nullptr;
+        ggml_context * ctx_in = nullptr;       // the input copies of all slots (+ nothing else): allocated once per graph key, outside the graph allocator
+        ggml_backend_buffer_t buf_in = nullptr;
+        ggml_context * ctx[LS_COPIES] = {nullptr, nullptr};
+        ggml_cgraph * gf[LS_COPIES] = {nullptr, nullptr};
+        seg_io io[LS_COPIES];
+        ggml_backend_event_t ev[LS_COPIES] = {nullptr, nullptr};
+    };
+    std::vector<ls_dev> ls;
+    int ls_copy = 0;
+    int64_t ls_stats[4] = {0, 0, 0, 0};  // cpy_tensor_async calls between devices, blocking input copies, events recorded, events waited for
 };
 
 static ggml_tensor * named(ggml_tensor * t, const char * base, int il) {
@@ -627,40 +667,51 @@ static ggml_tensor * named(ggml_tensor * t, const char * base, int il) {
     return ggml_set_name(t, buf);
 }
 
-static void build_graph(llm_context * c, int n_tokens, int n_kv, int n_outputs) {
+// creates the input tensors of layers [l0, l1) (+ the output head if `head`) in `ctx`
+static void make_inputs(llm_context * c, ggml_context * ctx, int l0, int l1, bool head, int n_tokens, int n_kv, int n_outputs, seg_io & io) {
     llm_model * m = c->model;
     const llm_hparams & hp = m->hp;
-    if (c->ctx_compute) ggml_free(c->ctx_compute);
-    c->ctx_compute = ggml_init({0, nullptr, true});
-    ggml_context * ctx = c->ctx_compute;
-    ggml_cgraph * gf = ggml_new_graph_custom(ctx, 8192, false);
+    const bool fa = c->p.flash_attn != 0;
+    const int64_t n_embd_k = (int64_t) m->n_head_kv_l * hp.n_embd_head;
+    if (l0 == 0) {
+        io.tokens = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_tokens);
+        ggml_set_input(named(io.tokens, "inp_tokens", -1));
+    } else {
+        io.resid = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, hp.n_embd, n_tokens);
+        ggml_set_input(named(io.resid, "l_out_from_the_previous_device", -1));
+    }
+    io.pos = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_tokens);
+    ggml_set_input(named(io.pos, "inp_pos", -1));
+    const int64_t n_tok_pad = (n_tokens + 63) / 64 * 64;  // GGML_KQ_MASK_PAD
+    // llama.cpp's build_attn_inp_kv_unified: the mask is an F32 input filled on the host; with flash attention FLASH_ATTN_EXT is handed a
+    // ggml_cast(F16) of it (self_kq_mask_cnv) — a CPY node in the graph, not an F16 upload
+    io.mask = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, n_kv, n_tok_pad);
+    ggml_set_input(named(io.mask, "KQ_mask", -1));
+    io.k_idxs = ggml_new_tensor_1d(ctx, GGML_TYPE_I64, n_tokens);
+    ggml_set_input(named(io.k_idxs, "k_idxs", -1));
+    if (!fa) {
+        io.v_idxs = ggml_new_tensor_1d(ctx, GGML_TYPE_I64, (int64_t) n_tokens * n_embd_k);
+        ggml_set_input(named(io.v_idxs, "v_idxs", -1));
+    }
+    if (l1 == hp.n_layer && n_outputs < n_tokens) {
+        io.out_ids = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_outputs);
+        ggml_set_input(named(io.out_ids, "out_ids", -1));
+    }
+    (void) head;
+}
+
+// layers [l0, l1) (+ norm and output matrix if `head`) over the inputs `io`, appended to `gf`
+static void build_segment(llm_context * c, ggml_context * ctx, ggml_cgraph * gf, int l0, int l1, bool head, int n_tokens, int n_kv, seg_io & io) {
+    llm_model * m = c->model;
+    const llm_hparams & hp = m->hp;
     const int64_t HD = hp.n_embd_head, NH = m->n_head_l, NKV = m->n_head_kv_l;
     const int64_t n_embd_k = NKV * HD, n_ctx = c->p.n_ctx;
     const bool fa = c->p.flash_attn != 0;
     const float kq_scale = 1.0f / sqrtf((float) HD);
+    ggml_tensor * const mask_cnv = fa ? named(ggml_cast(ctx, io.mask, GGML_TYPE_F16), "KQ_mask_cnv", -1) : io.mask;
 
-    c->inp_tokens = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_tokens);
-    ggml_set_input(named(c->inp_tokens, "inp_tokens", -1));
-    c->inp_pos = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_tokens);
-    ggml_set_input(named(c->inp_pos, "inp_pos", -1));
-    const int64_t n_tok_pad = (n_tokens + 63) / 64 * 64;  // GGML_KQ_MASK_PAD
-    c->inp_mask = ggml_new_tensor_2d(ctx, fa ? GGML_TYPE_F16 : GGML_TYPE_F32, n_kv, n_tok_pad);
-    ggml_set_input(named(c->inp_mask, "KQ_mask", -1));
-    c->inp_k_idxs = ggml_new_tensor_1d(ctx, GGML_TYPE_I64, n_tokens);
-    ggml_set_input(named(c->inp_k_idxs, "k_idxs", -1));
-    c->inp_v_idxs = nullptr;
-    if (!fa) {
-        c->inp_v_idxs = ggml_new_tensor_1d(ctx, GGML_TYPE_I64, (int64_t) n_tokens * n_embd_k);
-        ggml_set_input(named(c->inp_v_idxs, "v_idxs", -1));
-    }
-    c->inp_out_ids = nullptr;
-    if (n_outputs < n_tokens) {
-        c->inp_out_ids = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_outputs);
-        ggml_set_input(named(c->inp_out_ids, "out_ids", -1));
-    }
-
-    ggml_tensor * inpL = named(ggml_get_rows(ctx, m->tok_embd, c->inp_tokens), "inp_embd", -1);
-    for (int il = 0; il < hp.n_layer; ++il) {
+    ggml_tensor * inpL = l0 == 0 ? named(ggml_get_rows(ctx, m->tok_embd, io.tokens), "inp_embd", -1) : io.resid;
+    for (int il = l0; il < l1; ++il) {
         const llm_layer & L = m->layers[il];
         ggml_tensor * inpSA = inpL;
         ggml_tensor * cur = named(ggml_rms_norm(ctx, inpL, hp.rms_eps), "norm", il);
@@ -674,8 +725,8 @@ static void build_graph(llm_context * c, int n_tokens, int n_kv, int n_outputs) 
         Qcur = ggml_reshape_3d(ctx, Qcur, HD, NH, n_tokens);
         Kcur = ggml_reshape_3d(ctx, Kcur, HD, NKV, n_tokens);
         Vcur = ggml_reshape_3d(ctx, Vcur, HD, NKV, n_tokens);
-        Qcur = named(ggml_rope_ext(ctx, Qcur, c->inp_pos, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f), "Qcur_rope", il);
-        Kcur = named(ggml_rope_ext(ctx, Kcur, c->inp_pos, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f), "Kcur_rope", il);
+        Qcur = named(ggml_rope_ext(ctx, Qcur, io.pos, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f), "Qcur_rope", il);
+        Kcur = named(ggml_rope_ext(ctx, Kcur, io.pos, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f), "Kcur_rope", il);
         // llama.cpp's build_attn adds q, k and v to the graph together before the cache stores ("so that they are not reordered")
         ggml_build_forward_expand(gf, Qcur);
         ggml_build_forward_expand(gf, Kcur);
@@ -683,20 +734,20 @@ static void build_graph(llm_context * c, int n_tokens, int n_kv, int n_outputs) 
         // store K/V into the cache at the slots chosen for this micro-batch
         ggml_tensor * k_cache = c->k_l[il];
         ggml_tensor * v_cache = c->v_l[il];
-        ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, k_cache, ggml_reshape_2d(ctx, Kcur, n_embd_k, n_tokens), c->inp_k_idxs), "k_store", il));
+        ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, k_cache, ggml_reshape_2d(ctx, Kcur, n_embd_k, n_tokens), io.k_idxs), "k_store", il));
         if (fa) {
-            ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, v_cache, ggml_reshape_2d(ctx, Vcur, n_embd_k, n_tokens), c->inp_k_idxs), "v_store", il));
+            ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, v_cache, ggml_reshape_2d(ctx, Vcur, n_embd_k, n_tokens), io.k_idxs), "v_store", il));
         } else {
             // transposed V cache: every element is its own row of length 1
             ggml_tensor * v_view = ggml_reshape_2d(ctx, v_cache, 1, n_ctx * n_embd_k);
             ggml_tensor * v_src = ggml_reshape_2d(ctx, Vcur, 1, (int64_t) n_tokens * n_embd_k);
-            ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, v_view, v_src, c->inp_v_idxs), "v_store", il));
+            ggml_build_forward_expand(gf, named(ggml_set_rows(ctx, v_view, v_src, io.v_idxs), "v_store", il));
         }
         ggml_tensor * q = ggml_permute(ctx, Qcur, 0, 2, 1, 3);  // [HD, n_tokens, NH]
         ggml_tensor * k = ggml_view_3d(ctx, k_cache, HD, n_kv, NKV, ggml_row_size(k_cache->type, n_embd_k), ggml_row_size(k_cache->type, HD), 0);
         if (fa) {
             ggml_tensor * v = ggml_view_3d(ctx, v_cache, HD, n_kv, NKV, ggml_row_size(v_cache->type, n_embd_k), ggml_row_size(v_cache->type, HD), 0);
-            cur = ggml_flash_attn_ext(ctx, q, k, v, c->inp_mask, kq_scale, 0.0f, 0.0f);
+            cur = ggml_flash_attn_ext(ctx, q, k, v, mask_cnv, kq_scale, 0.0f, 0.0f);
             ggml_flash_attn_ext_set_prec(cur, GGML_PREC_F32);
             named(cur, "fattn", il);
             cur = ggml_reshape_2d(ctx, cur, HD * NH, n_tokens);
@@ -704,15 +755,15 @@ static void build_graph(llm_context * c, int n_tokens, int n_kv, int n_outputs) 
             ggml_tensor * v = ggml_view_3d(ctx, v_cache, n_kv, HD, NKV, ggml_row_size(v_cache->type, n_ctx), ggml_row_size(v_cache->type, n_ctx) * HD, 0);
             ggml_tensor * kq = named(ggml_mul_mat(ctx, k, q), "kq", il);  // [n_kv, n_tokens, NH]
             ggml_mul_mat_set_prec(kq, GGML_PREC_F32);
-            kq = named(ggml_soft_max_ext(ctx, kq, c->inp_mask, kq_scale, 0.0f), "kq_soft_max", il);
+            kq = named(ggml_soft_max_ext(ctx, kq, mask_cnv, kq_scale, 0.0f), "kq_soft_max", il);
             ggml_tensor * kqv = named(ggml_mul_mat(ctx, v, kq), "kqv", il);  // [HD, n_tokens, NH]
             cur = ggml_permute(ctx, kqv, 0, 2, 1, 3);
             cur = named(ggml_cont_2d(ctx, cur, HD * NH, n_tokens), "kqv_out", il);
         }
         cur = named(ggml_mul_mat(ctx, L.wo, cur), "attn_out", il);
-        if (il == hp.n_layer - 1 && c->inp_out_ids) {
-            cur = ggml_get_rows(ctx, cur, c->inp_out_ids);
-            inpSA = ggml_get_rows(ctx, inpSA, c->inp_out_ids);
+        if (il == hp.n_layer - 1 && io.out_ids) {
+            cur = ggml_get_rows(ctx, cur, io.out_ids);
+            inpSA = ggml_get_rows(ctx, inpSA, io.out_ids);
         }
         ggml_tensor * ffn_inp = named(ggml_add(ctx, cur, inpSA), "ffn_inp", il);
         cur = named(ggml_rms_norm(ctx, ffn_inp, hp.rms_eps), "norm_ffn", il);
@@ -724,12 +775,31 @@ static void build_graph(llm_context * c, int n_tokens, int n_kv, int n_outputs) 
         cur = named(ggml_add(ctx, cur, ffn_inp), "l_out", il);
         inpL = cur;
     }
-    ggml_tensor * cur = named(ggml_rms_norm(ctx, inpL, hp.rms_eps), "norm_final", -1);
-    cur = named(ggml_mul(ctx, cur, m->output_norm), "result_norm", -1);
-    cur = named(ggml_mul_mat(ctx, m->output, cur), "result_output", -1);
+    ggml_tensor * cur = inpL;
+    if (head) {
+        cur = named(ggml_rms_norm(ctx, inpL, hp.rms_eps), "norm_final", -1);
+        cur = named(ggml_mul(ctx, cur, m->output_norm), "result_norm", -1);
+        cur = named(ggml_mul_mat(ctx, m->output, cur), "result_output", -1);
+    }
     ggml_set_output(cur);
     ggml_build_forward_expand(gf, cur);
-    c->t_logits = cur;
+    io.out = cur;
+}
+
+static void build_graph(llm_context * c, int n_tokens, int n_kv, int n_outputs) {
+    if (c->ctx_compute) ggml_free(c->ctx_compute);
+    c->ctx_compute = ggml_init({0, nullptr, true});
+    ggml_cgraph * gf = ggml_new_graph_custom(c->ctx_compute, 8192, false);
+    seg_io io;
+    make_inputs(c, c->ctx_compute, 0, c->model->hp.n_layer, true, n_tokens, n_kv, n_outputs, io);
+    build_segment(c, c->ctx_compute, gf, 0, c->model->hp.n_layer, true, n_tokens, n_kv, io);
+    c->inp_tokens = io.tokens;
+    c->inp_pos = io.pos;
+    c->inp_mask = io.mask;
+    c->inp_k_idxs = io.k_idxs;
+    c->inp_v_idxs = io.v_idxs;
+    c->inp_out_ids = io.out_ids;
+    c->t_logits = io.out;
     c->gf = gf;
 }
 
@@ -791,7 +861,7 @@ extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backe
         if (hbuft) {
             const size_t nub = (size_t) std::min(c->p.n_ubatch, c->p.n_ctx);
             const size_t n_tok_pad = (nub + 63) / 64 * 64;
-            size_t in_bytes = nub * (4 + 4 + 8 + 4) + n_tok_pad * (size_t) c->p.n_ctx * (c->p.flash_attn ? 2 : 4) + 256;
+            size_t in_bytes = nub * (4 + 4 + 8 + 4) + n_tok_pad * (size_t) c->p.n_ctx * 4 + 256;
             if (!c->p.flash_attn) in_bytes += nub * (size_t) n_embd_k * 8;
             in_bytes = (in_bytes + 255) / 256 * 256;
             c->pin_out_rows = 64;
@@ -807,6 +877,18 @@ extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backe
 
 extern "C" void llm_context_free(struct llm_context * c) {
     if (!c) return;
+    for (auto & d : c->ls) {
+        if (d.be) ggml_backend_synchronize(d.be);
+        for (int k = 0; k < llm_context::LS_COPIES; ++k) {
+            if (d.ctx[k]) ggml_free(d.ctx[k]);
+            if (d.ev[k]) ggml_backend_event_free(d.ev[k]);
+        }
+        if (d.galloc) ggml_gallocr_free(d.galloc);
+        if (d.buf_in) ggml_backend_buffer_free(d.buf_in);
+        if (d.ctx_in) ggml_free(d.ctx_in);
+        if (d.buf_kv) ggml_backend_buffer_free(d.buf_kv);
+        if (d.ctx_kv) ggml_free(d.ctx_kv);
+    }
     if (c->ctx_compute) ggml_free(c->ctx_compute);
     if (c->galloc) ggml_gallocr_free(c->galloc);
     if (c->buf_pin) ggml_backend_buffer_free(c->buf_pin);
@@ -869,6 +951,7 @@ static int kv_apply_shift(llm_context * c, const std::vector<int32_t> & delta) {
 // llama_memory_seq_add: positions [p0, p1) of a sequence move by `delta`; the cached K rows are re-rotated at once
 // (llama.cpp defers that to the next llama_decode's memory update — same result).  Returns 0, or -2 if the shift graph failed.
 extern "C" int llm_kv_seq_add(struct llm_context * c, int seq_id, int p0, int p1, int delta) {
+    if (!c->ls.empty()) return -2;  // (the K-shift graph is not cut over devices in this harness)
     if (p0 < 0) p0 = 0;
     if (p1 < 0) p1 = INT32_MAX;
     if (delta == 0) return 0;
@@ -884,6 +967,177 @@ extern "C" int llm_kv_seq_add(struct llm_context * c, int seq_id, int p0, int p1
         }
     }
     return any ? kv_apply_shift(c, d) : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ -sm layer
+// llama.cpp's default with several devices (llama-box/engine_param.hpp:900-916: split_mode stays LLAMA_SPLIT_MODE_LAYER unless -sm says
+// otherwise; patches/llama.cpp/max_devices.patch:5-10 raises the device limit): every device holds a range of layers and their KV cache,
+// ggml_backend_sched cuts the graph where the weights change device and moves the residual stream across with the destination backend's
+// cpy_tensor_async, ordering the re-use of its input copies with event_record / event_wait / event_synchronize.  This is that driver for
+// OUR devices (no scheduler exists in the snapshot): the calls a backend sees, in the order ggml_backend_sched_compute_splits issues them.
+extern "C" struct llm_context * llm_context_new_layer_split(struct llm_model * m, const ggml_backend_t * backends, int n_dev, const struct llm_context_params * p) {
+    if (n_dev < 1 || n_dev != m->n_dev || (int) m->layer_dev.size() != m->hp.n_layer) {
+        fprintf(stderr, "llm_context_new_layer_split: the model was not built by llm_model_synth_layer_split for %d devices\n", n_dev);
+        return nullptr;
+    }
+    llm_context * c = new llm_context();
+    c->model = m;
+    c->p = *p;
+    if (c->p.n_ubatch <= 0) c->p.n_ubatch = 512;
+    if (c->p.n_ctx <= 0) c->p.n_ctx = 512;
+    c->p.n_ctx = (c->p.n_ctx + 255) / 256 * 256;
+    const llm_hparams & hp = m->hp;
+    const int64_t n_embd_k = (int64_t) m->n_head_kv_l * hp.n_embd_head;
+    c->ls.resize((size_t) n_dev);
+    c->k_l.assign((size_t) hp.n_layer, nullptr);
+    c->v_l.assign((size_t) hp.n_layer, nullptr);
+    for (int d = 0; d < n_dev; ++d) {
+        llm_context::ls_dev & D = c->ls[(size_t) d];
+        D.be = backends[d];
+        D.buft = ggml_backend_dev_buffer_type(backends[d]->device);
+        D.l0 = hp.n_layer;
+        D.l1 = 0;
+        for (int il = 0; il < hp.n_layer; ++il)
+            if (m->layer_dev[(size_t) il] == d) { D.l0 = std::min(D.l0, il); D.l1 = std::max(D.l1, il + 1); }
+        LLM_ASSERT(D.l0 < D.l1);
+        D.ctx_kv = ggml_init({0, nullptr, true});
+        for (int il = D.l0; il < D.l1; ++il) {
+            ggml_tensor * k = ggml_new_tensor_2d(D.ctx_kv, GGML_TYPE_F16, n_embd_k, c->p.n_ctx);
+            ggml_tensor * v = c->p.flash_attn ? ggml_new_tensor_2d(D.ctx_kv, GGML_TYPE_F16, n_embd_k, c->p.n_ctx) : ggml_new_tensor_2d(D.ctx_kv, GGML_TYPE_F16, c->p.n_ctx, n_embd_k);
+            c->k_l[(size_t) il] = named(k, "cache_k_l", il);
+            c->v_l[(size_t) il] = named(v, "cache_v_l", il);
+        }
+        D.buf_kv = ggml_backend_alloc_ctx_tensors_from_buft(D.ctx_kv, D.buft);
+        if (!D.buf_kv) { llm_context_free(c); return nullptr; }
+        ggml_backend_buffer_clear(D.buf_kv, 0);
+        D.galloc = ggml_gallocr_new(D.buft);
+        for (int k = 0; k < llm_context::LS_COPIES; ++k) D.ev[k] = ggml_backend_event_new(backends[d]->device);
+        // reserve the worst-case segment so that later graphs re-use one buffer
+        const int nub = std::min(c->p.n_ubatch, c->p.n_ctx);
+        ggml_context * tmp = ggml_init({0, nullptr, true});
+        ggml_cgraph * gf = ggml_new_graph_custom(tmp, 8192, false);
+        seg_io io;
+        make_inputs(c, tmp, D.l0, D.l1, d == n_dev - 1, nub, c->p.n_ctx, nub, io);
+        build_segment(c, tmp, gf, D.l0, D.l1, d == n_dev - 1, nub, c->p.n_ctx, io);
+        const bool ok = ggml_gallocr_reserve(D.galloc, gf);
+        ggml_free(tmp);
+        if (!ok) { llm_context_free(c); return nullptr; }
+    }
+    c->cells.assign((size_t) c->p.n_ctx, kv_cell());
+    c->used_max = 0;
+    c->key = graph_key();
+    return c;
+}
+extern "C" void llm_layer_split_stats(const struct llm_context * c, int64_t out[4]) {
+    for (int k = 0; k < 4; ++k) out[k] = c->ls_stats[k];
+}
+
+static void ls_sync_all(llm_context * c) {
+    for (auto & d : c->ls) ggml_backend_synchronize(d.be);
+    c->ls_copy = 0;  // ggml_backend_sched_synchronize: "always use copy 0 after a synchronization" — a decode step sees the same graph every time
+    c->in_flight = 0;
+}
+
+static int decode_ubatch_ls(llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const std::vector<int> & slots,
+                            const std::vector<int32_t> & out_ids, int n_kv, float * logits_out, int * n_out_acc, bool defer_sync) {
+    llm_model * m = c->model;
+    const llm_hparams & hp = m->hp;
+    const int n_ctx = c->p.n_ctx, n_dev = (int) c->ls.size(), n_outputs = (int) out_ids.size();
+    const int64_t n_embd_k = (int64_t) m->n_head_kv_l * hp.n_embd_head;
+    graph_key key{n_tokens, n_kv, n_outputs};
+    if (!(key == c->key)) {
+        ls_sync_all(c);
+        for (int d = 0; d < n_dev; ++d) {
+            llm_context::ls_dev & D = c->ls[(size_t) d];
+            if (D.buf_in) ggml_backend_buffer_free(D.buf_in);
+            if (D.ctx_in) ggml_free(D.ctx_in);
+            D.ctx_in = ggml_init({0, nullptr, true});
+            for (int k = 0; k < llm_context::LS_COPIES; ++k) {
+                D.io[k] = seg_io();
+                make_inputs(c, D.ctx_in, D.l0, D.l1, d == n_dev - 1, n_tokens, n_kv, n_outputs, D.io[k]);
+            }
+            D.buf_in = ggml_backend_alloc_ctx_tensors_from_buft(D.ctx_in, D.buft);
+            if (!D.buf_in) return -2;
+            for (int k = 0; k < llm_context::LS_COPIES; ++k) {
+                if (D.ctx[k]) ggml_free(D.ctx[k]);
+                D.ctx[k] = ggml_init({0, nullptr, true});
+                D.gf[k] = ggml_new_graph_custom(D.ctx[k], 8192, false);
+                build_segment(c, D.ctx[k], D.gf[k], D.l0, D.l1, d == n_dev - 1, n_tokens, n_kv, D.io[k]);
+                if (!ggml_gallocr_alloc_graph(D.galloc, D.gf[k])) return -2;  // (same topology, same plan: both slots' graphs share the compute buffer — they run one after the other on the device's stream)
+            }
+            // the padding rows of the masks (GGML_KQ_MASK_PAD) are never read; written once so that the cast never converts uninitialised memory
+            for (int k = 0; k < llm_context::LS_COPIES; ++k) {
+                std::vector<float> pad((size_t) D.io[k].mask->ne[0] * (size_t) D.io[k].mask->ne[1], -INFINITY);
+                ggml_backend_tensor_set(D.io[k].mask, pad.data(), 0, pad.size() * 4);
+            }
+        }
+        c->key = key;
+    }
+    const int cur = c->ls_copy;
+    // host-side images of the user inputs
+    std::vector<int64_t> kidx((size_t) n_tokens), vidx;
+    for (int i = 0; i < n_tokens; ++i) kidx[(size_t) i] = slots[(size_t) i];
+    if (!c->p.flash_attn) {
+        vidx.resize((size_t) n_tokens * (size_t) n_embd_k);
+        for (int i = 0; i < n_tokens; ++i)
+            for (int64_t j = 0; j < n_embd_k; ++j) vidx[(size_t) i * n_embd_k + j] = j * n_ctx + slots[(size_t) i];
+    }
+    std::vector<int32_t> & cpos = c->mask_cpos, & cseq = c->mask_cseq;
+    cpos.resize((size_t) n_kv);
+    cseq.resize((size_t) n_kv);
+    for (int j = 0; j < n_kv; ++j) { cpos[(size_t) j] = c->cells[(size_t) j].pos; cseq[(size_t) j] = c->cells[(size_t) j].seq; }
+    std::vector<float> mask((size_t) n_kv * (size_t) n_tokens);
+    for (int i = 0; i < n_tokens; ++i) mask_row(mask.data() + (size_t) i * n_kv, n_kv, cpos.data(), cseq.data(), seq_id ? seq_id[i] : 0, pos[i], 0.0f, -INFINITY);
+
+    enum ggml_status st = GGML_STATUS_SUCCESS;
+    for (int d = 0; d < n_dev && st == GGML_STATUS_SUCCESS; ++d) {
+        llm_context::ls_dev & D = c->ls[(size_t) d];
+        seg_io & io = D.io[cur];
+        // --- user inputs (GGML_TENSOR_FLAG_INPUT): the split backend must have finished the graph that read this slot last, then a BLOCKING copy
+        if (D.ev[cur]) ggml_backend_event_synchronize(D.ev[cur]);
+        else ggml_backend_synchronize(D.be);
+        if (d == 0) {
+            // (llama.cpp fills its input tensors with ggml_backend_tensor_set — blocking — from host memory)
+            if (io.tokens) ggml_backend_tensor_set(io.tokens, tokens, 0, (size_t) n_tokens * 4);
+            ggml_backend_tensor_set(io.pos, pos, 0, (size_t) n_tokens * 4);
+            ggml_backend_tensor_set(io.k_idxs, kidx.data(), 0, kidx.size() * 8);
+            if (io.v_idxs) ggml_backend_tensor_set(io.v_idxs, vidx.data(), 0, vidx.size() * 8);
+            ggml_backend_tensor_set(io.mask, mask.data(), 0, mask.size() * 4);
+            if (io.out_ids) ggml_backend_tensor_set(io.out_ids, out_ids.data(), 0, out_ids.size() * 4);
+        } else {
+            // an input that lives on another device's backend: ggml_backend_tensor_copy -> the destination buffer's cpy_tensor
+            seg_io & src = c->ls[0].io[cur];
+            ggml_backend_tensor_copy(src.pos, io.pos);
+            ggml_backend_tensor_copy(src.k_idxs, io.k_idxs);
+            if (io.v_idxs) ggml_backend_tensor_copy(src.v_idxs, io.v_idxs);
+            ggml_backend_tensor_copy(src.mask, io.mask);
+            c->ls_stats[1] += 3 + (io.v_idxs ? 1 : 0);
+            if (io.out_ids) ggml_backend_tensor_set(io.out_ids, out_ids.data(), 0, out_ids.size() * 4);  // (only the last device reads it: its own input)
+            // --- the residual stream, produced by the previous device's graph: wait until this backend is done with the slot, then the async copy
+            llm_context::ls_dev & P = c->ls[(size_t) d - 1];
+            if (D.ev[cur]) { ggml_backend_event_wait(D.be, D.ev[cur]); c->ls_stats[3]++; }
+            else ggml_backend_synchronize(D.be);
+            // (harness addition, not in ggml_backend_sched: the copy is issued on the SOURCE stream — also order it behind the destination's last use of the slot)
+            if (D.ev[cur]) { ggml_backend_event_wait(P.be, D.ev[cur]); c->ls_stats[3]++; }
+            ggml_backend_tensor_copy_async(P.be, D.be, P.io[cur].out, io.resid);
+            c->ls_stats[0]++;
+        }
+        st = ggml_backend_graph_compute_async(D.be, D.gf[cur]);
+        if (D.ev[cur]) { ggml_backend_event_record(D.ev[cur], D.be); c->ls_stats[2]++; }
+    }
+    if (st != GGML_STATUS_SUCCESS) { ls_sync_all(c); return -2; }
+    if (n_outputs > 0 || !defer_sync) {
+        llm_context::ls_dev & Last = c->ls.back();
+        if (n_outputs > 0) ggml_backend_tensor_get_async(Last.be, Last.io[cur].out, logits_out, 0, (size_t) n_outputs * m->n_vocab_l * 4);
+        ls_sync_all(c);
+        *n_out_acc += n_outputs;
+        c->t_logits = Last.io[cur].out;
+        c->gf = Last.gf[cur];
+    } else {
+        c->ls_copy = (cur + 1) % llm_context::LS_COPIES;  // the next micro-batch takes the other slot while this one is in flight
+        c->in_flight++;
+    }
+    return 0;
 }
 
 static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const int8_t * want, float * logits_out, int * n_out_acc,
@@ -916,6 +1170,14 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
     // a micro-batch nobody wants logits from (every chunk of a prompt but the last): llama.cpp builds the graph with an EMPTY out_ids — the last
     // layer's tensors behind get_rows and the output head have zero rows and are skipped by the backends (ggml_is_empty)
     const int n_out_graph = n_outputs;
+    if (!c->ls.empty()) {
+        const int rc = decode_ubatch_ls(c, n_tokens, tokens, pos, seq_id, slots, out_ids, n_kv, logits_out, n_out_acc, defer_sync);
+        if (rc != 0) {
+            for (int i = 0; i < n_tokens; ++i) c->cells[slots[i]] = kv_cell();
+            c->used_max = -1;
+        }
+        return rc;
+    }
 
     graph_key key{n_tokens, n_kv, n_out_graph};
     bool rebuilt = false;
@@ -929,7 +1191,6 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
 
     // inputs: filled straight into the pinned staging area and uploaded asynchronously on the backend's stream (the copies
     // and the graph are stream-ordered); without a device backend (CPU oracle) the plain blocking setter is used
-    const bool fa = c->p.flash_attn != 0;
     const bool async_io = c->backend != nullptr && c->pin != nullptr;
     if (async_io && c->in_flight >= llm_context::PIN_SLOTS - 1) {  // the slot about to be re-used may still be in flight
         ggml_backend_synchronize(c->backend);
@@ -975,7 +1236,6 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
         // graph is (re)built and skipped on re-use, which keeps the per-step upload at n_tokens * n_kv entries
         const int64_t n_tok_pad = c->inp_mask->ne[1];
         const int64_t rows = rebuilt ? n_tok_pad : n_tokens;
-        const uint16_t NEG_INF_H = 0xFC00;
         // cell j is visible to token i iff it holds a position (>= 0) of i's sequence that is not after i's — the condition llama.cpp's
         // set_input_kq_mask evaluates per (token, cell); the cells' fields are gathered once per step so that the row loops vectorise
         // (an empty cell's position -1 compares as the largest unsigned value: never visible)
@@ -986,19 +1246,11 @@ static int decode_ubatch(llm_context * c, int n_tokens, const int32_t * tokens, 
             cpos[j] = c->cells[j].pos;
             cseq[j] = c->cells[j].seq;
         }
-        if (fa) {
-            upload(c->inp_mask, (size_t) n_kv * rows * 2, [&](char * d) {
-                uint16_t * mask = (uint16_t *) d;
-                for (size_t e = (size_t) n_kv * n_tokens; e < (size_t) n_kv * rows; ++e) mask[e] = NEG_INF_H;
-                for (int i = 0; i < n_tokens; ++i) mask_row(mask + (size_t) i * n_kv, n_kv, cpos.data(), cseq.data(), seq_id ? seq_id[i] : 0, pos[i], (uint16_t) 0, NEG_INF_H);
-            });
-        } else {
-            upload(c->inp_mask, (size_t) n_kv * rows * 4, [&](char * d) {
-                float * mask = (float *) d;
-                for (size_t e = (size_t) n_kv * n_tokens; e < (size_t) n_kv * rows; ++e) mask[e] = -INFINITY;
-                for (int i = 0; i < n_tokens; ++i) mask_row(mask + (size_t) i * n_kv, n_kv, cpos.data(), cseq.data(), seq_id ? seq_id[i] : 0, pos[i], 0.0f, -INFINITY);
-            });
-        }
+        upload(c->inp_mask, (size_t) n_kv * rows * 4, [&](char * d) {
+            float * mask = (float *) d;
+            for (size_t e = (size_t) n_kv * n_tokens; e < (size_t) n_kv * rows; ++e) mask[e] = -INFINITY;
+            for (int i = 0; i < n_tokens; ++i) mask_row(mask + (size_t) i * n_kv, n_kv, cpos.data(), cseq.data(), seq_id ? seq_id[i] : 0, pos[i], 0.0f, -INFINITY);
+        });
     }
     const double t2 = now_us();
     const size_t logit_bytes = (size_t) n_outputs * m->n_vocab_l * 4;
@@ -1063,9 +1315,11 @@ extern "C" int llm_decode(struct llm_context * c, int n_tokens, const int32_t * 
                                c->logits_base + (size_t) c->n_outputs * c->model->n_vocab_l, &c->n_outputs, /*defer_sync=*/i0 + n < n_tokens);
         if (rc != 0) {
             if (c->backend && c->in_flight) { ggml_backend_synchronize(c->backend); c->in_flight = 0; }
+            if (!c->ls.empty()) ls_sync_all(c);
             return rc;
         }
     }
+    if (!c->ls.empty() && c->in_flight) ls_sync_all(c);
     if (c->backend && c->in_flight) {  // the call returns with everything finished
         ggml_backend_synchronize(c->backend);
         c->in_flight = 0;

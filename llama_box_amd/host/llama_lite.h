@@ -50,6 +50,8 @@ struct llm_model * llm_model_synth(const struct llm_hparams * hp, uint64_t seed,
                                    ggml_backend_buffer_type_t rowpar_buft);
 /* -sm row: mat-mul weights in `split_buft` (the registry's "ggml_backend_split_buffer_type" result), everything else in `buft` */
 struct llm_model * llm_model_synth_split(const struct llm_hparams * hp, uint64_t seed, ggml_backend_buffer_type_t buft, ggml_backend_buffer_type_t split_buft);
+/* -sm layer (llama.cpp's default with several devices; llama-box/engine_param.hpp:900-916): device d's buffer type holds a contiguous range of layers */
+struct llm_model * llm_model_synth_layer_split(const struct llm_hparams * hp, uint64_t seed, const ggml_backend_buffer_type_t * bufts, int n_dev);
 int llm_synth_gguf(const struct llm_hparams * hp, uint64_t seed, const char * path);
 struct llm_model * llm_model_load(const char * path, ggml_backend_buffer_type_t buft);
 void llm_model_free(struct llm_model * m);
@@ -74,6 +76,11 @@ struct llm_context;
 /* exactly one of backend / compute must be set: backend -> ggml_backend_graph_compute, else the callback
  * (tests pass the CPU oracle's oracle_graph_compute here; the product never does) */
 struct llm_context * llm_context_new(struct llm_model * m, ggml_backend_t backend, llm_compute_fn compute, const struct llm_context_params * p);
+/* one backend per device of a layer-split model: the graph is cut at the device boundaries and driven as ggml_backend_sched drives its splits
+ * (blocking input copies, cpy_tensor_async of the residual stream, event_record / event_wait / event_synchronize per input-copy slot) */
+struct llm_context * llm_context_new_layer_split(struct llm_model * m, const ggml_backend_t * backends, int n_dev, const struct llm_context_params * p);
+/* [cpy_tensor_async calls between devices, blocking input copies between devices, events recorded, events waited for] since the context was made */
+void llm_layer_split_stats(const struct llm_context * c, int64_t out[4]);
 void llm_context_free(struct llm_context * c);
 /* return codes as llama_decode: 0 ok, 1 no KV slot, -1 invalid batch, -2 compute/alloc failure */
 int llm_decode(struct llm_context * c, int n_tokens, const int32_t * tokens, const int32_t * pos, const int32_t * seq_id, const int8_t * want_logits);

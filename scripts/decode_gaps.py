@@ -35,6 +35,12 @@ if turn:
     n = len(turn)
     print(f"between steps (mean of {n}): output mat-vec end -> D2H copy start {sum(t[0] for t in turn) / n:6.1f} us, copy {sum(t[1] for t in turn) / n:5.1f} us, "
           f"copy end -> first kernel of the next step ({turn[-1][3]}) {sum(t[2] for t in turn) / n:6.1f} us  [host turnaround: sync + sampler + inputs + graph key + hipGraphLaunch]")
+if "-v" in sys.argv:  # every launch of one step: start offset, duration, gap before it
+    stv = rows[ends[-3] + 1:ends[-2] + 1]
+    t0 = stv[0][0]
+    for i, (s_, e_, k_) in enumerate(stv):
+        g_ = (s_ - stv[i - 1][1]) / 1e3 if i else 0.0
+        print(f"  {(s_ - t0) / 1e3:9.2f} us  dur {(e_ - s_) / 1e3:7.2f}  gap {g_:6.2f}  {k_.replace('mi355x::', '').split('(')[0][:70]}")
 big = {}
 st = rows[ends[-3] + 1:ends[-2] + 1]
 for i in range(len(st) - 1):

@@ -215,9 +215,32 @@ def run_case(build, target, n_threads=4, **kw):
         g.free()
 
 
+def cpu_quota():
+    """CPUs this container may actually use: the cgroup's CFS quota (cpu.max: "1600000 100000" = 16 CPUs on the GPU boxes of round 5, whose
+    host shows 256 logical CPUs) or, without one, the logical CPU count.  An OpenMP team larger than the quota is throttled by the kernel — the
+    round-4 oracle runs with 64 / 128 threads spent most of their wall time descheduled (profiles/r05_cpu_scaling.txt: 8 threads 125 GB/s,
+    64 threads 42, 128 threads 10)."""
+    n = os.cpu_count() or 4
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def host_threads(cap=64):
-    """Threads for oracle runs at real model shapes (the GPU box has far more cores than this container)."""
-    return max(4, min(cap, os.cpu_count() or 4))
+    """Threads for oracle runs at real model shapes: what the host offers THIS container (cpu_quota), minus one for the driving thread."""
+    q = cpu_quota()
+    return max(2, min(cap, q - 1 if q > 4 else q))
 
 
 def nmse(a, b):

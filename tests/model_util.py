@@ -16,10 +16,13 @@ def preset(name, **over):
 
 
 class Model:
-    def __init__(self, hp=None, seed=1234, buft=None, path=None, tp_rank=0, tp_size=1, rowpar_buft=None, split_buft=None):
+    def __init__(self, hp=None, seed=1234, buft=None, path=None, tp_rank=0, tp_size=1, rowpar_buft=None, split_buft=None, layer_bufts=None):
         H = L.host()
         self.H = H
-        if path is not None:
+        if layer_bufts is not None:  # -sm layer: device d's buffer type holds a contiguous range of layers
+            arr = (C.c_void_p * len(layer_bufts))(*layer_bufts)
+            self.m = H.llm_model_synth_layer_split(C.byref(hp), seed, arr, len(layer_bufts))
+        elif path is not None:
             self.m = H.llm_model_load(path.encode(), buft)
         elif split_buft is not None:  # -sm row: mat-mul weights in the split buffer type
             self.m = H.llm_model_synth_split(C.byref(hp), seed, buft, split_buft)
@@ -40,13 +43,17 @@ class Model:
 
 
 class Context:
-    def __init__(self, model, backend=None, compute=None, n_ctx=512, n_ubatch=512, flash_attn=0, n_threads=0, graph_reuse=1, type_k=0, type_v=0):
+    def __init__(self, model, backend=None, compute=None, n_ctx=512, n_ubatch=512, flash_attn=0, n_threads=0, graph_reuse=1, type_k=0, type_v=0, backends=None):
         H = L.host()
         self.H = H
         self.model = model
         self._compute = compute if compute is not None else L.COMPUTE_FN()
         cp = L.ContextParams(n_ctx, n_ubatch, flash_attn, n_threads, graph_reuse, type_k, type_v)
-        self.c = H.llm_context_new(model.m, backend.backend if backend is not None else None, self._compute, C.byref(cp))
+        if backends is not None:  # -sm layer: one backend per device, the graph cut at the device boundaries
+            arr = (C.c_void_p * len(backends))(*[b.backend for b in backends])
+            self.c = H.llm_context_new_layer_split(model.m, arr, len(backends), C.byref(cp))
+        else:
+            self.c = H.llm_context_new(model.m, backend.backend if backend is not None else None, self._compute, C.byref(cp))
         if not self.c:
             raise RuntimeError("context creation failed")
 
@@ -88,6 +95,11 @@ class Context:
     def seq_add(self, seq_id, p0, p1, delta):
         """llama_memory_seq_add + K-shift (context shift)."""
         return self.H.llm_kv_seq_add(self.c, seq_id, p0, p1, delta)
+
+    def layer_split_stats(self):
+        out = (C.c_int64 * 4)()
+        self.H.llm_layer_split_stats(self.c, out)
+        return dict(zip(("cpy_tensor_async", "blocking_input_copies", "events_recorded", "events_waited"), [int(x) for x in out]))
 
     def timings(self):
         out = (C.c_double * 4)()

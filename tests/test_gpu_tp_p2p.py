@@ -56,3 +56,30 @@ def test_tensor_parallel_decode_over_the_p2p_all_reduce(plog, world, graphs):
         assert c["nmse_vs_one_device"] <= 1e-3, c
         if graphs:
             assert c["graph_replays"] >= 3, c
+
+
+@pytest.mark.gpu
+def test_a_timed_out_all_reduce_fails_the_next_graph_and_the_group_can_be_reset(plog):
+    """ADVICE r04 (tp_p2p.hip / tp.cpp): switching a peer-to-peer-only group's mailboxes off is refused; a sum that times out makes the rank's next
+    graph_compute return GGML_STATUS_FAILED (llama_decode rc -2: llama-box fails the requests, /root/reference/llama-box/httpserver.hpp:3541-3545) instead
+    of summing stale mailboxes with a success status; set_option("tp_p2p_reset", 1) on every rank brings the group back."""
+    world = 2
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TP_GRAPHS="0", GGML_MI355X_TP_GRAPHS="0", OMP_NUM_THREADS="4", TP_DRILL="1", GGML_MI355X_P2P_MAX_SPINS="200000")
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "tp_p2p_worker.py")], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert [p.returncode for p in procs] == [0] * world, "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    res = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("TP_P2P_JSON ")][-1][len("TP_P2P_JSON "):])["drill"]
+    plog(f"[tp-p2p drill] {res}")
+    for r in res:
+        assert r["off_refused"] and r["rc_healthy"] == 0 and r["sum_after_reset_ok"] and r["rc_after_reset"] == 0 and r["timeouts_after_reset"] == 0, r
+    assert res[0]["timeouts_after_lone_sum"] > 0 and res[0]["rc_after_timeout"] == -2, res[0]

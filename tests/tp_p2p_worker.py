@@ -19,6 +19,54 @@ import llama_box_amd as L  # noqa: E402
 from model_util import Context, Model, preset  # noqa: E402
 
 
+def drill(be, rank, world):
+    """(1) the only transport of a group cannot be switched off, (2) a time-out of the one-shot all-reduce is REPORTED — every later
+    graph_compute of the rank fails (llama_decode rc -2) instead of summing stale mailboxes for good — and (3) the host can reset the group."""
+    res = {"rank": rank}
+    try:
+        be.set_option("tp_p2p", 0)
+        res["off_refused"] = False
+    except ValueError:
+        res["off_refused"] = True
+    hp = preset("test-llama-tp")
+    m = Model(hp, 2024, be.buft, tp_rank=rank, tp_size=world, rowpar_buft=be.rowpar_buft())
+    c = Context(m, backend=be, flash_attn=1)
+    dist.barrier()
+    rc, _ = c.decode([1, 5, 9], range(3))
+    res["rc_healthy"] = rc
+    dist.barrier()
+    n = 4096
+    if rank == 0:  # a sum nobody else joins: the kernel's bounded spins run out (GGML_MI355X_P2P_MAX_SPINS is small in this process)
+        x = torch.ones(n, dtype=torch.float32, device="cuda:0")
+        be.tp_all_reduce(x.data_ptr(), n)
+        be.synchronize()
+        res["timeouts_after_lone_sum"] = int(be.stat("p2p_timeouts"))
+        rc, _ = c.decode([7], [3])
+        res["rc_after_timeout"] = rc
+    dist.barrier()
+    be.set_option("tp_p2p_reset", 1)  # every rank, all idle
+    dist.barrier()
+    x = torch.full((n,), float(rank + 1), dtype=torch.float32, device="cuda:0")
+    be.tp_all_reduce(x.data_ptr(), n)
+    be.synchronize()
+    res["sum_after_reset_ok"] = bool(torch.equal(x.cpu(), torch.full((n,), world * (world + 1) / 2.0)))
+    c.free()
+    c = Context(m, backend=be, flash_attn=1)
+    dist.barrier()
+    rc, _ = c.decode([1, 5, 9], range(3))
+    res["rc_after_reset"] = rc
+    res["timeouts_after_reset"] = int(be.stat("p2p_timeouts"))
+    c.free()
+    m.free()
+    allres = [None] * world
+    dist.all_gather_object(allres, res)
+    if rank == 0:
+        print("TP_P2P_JSON " + json.dumps({"drill": allres}), flush=True)
+    be.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,6 +81,8 @@ def main():
     graphs = int(os.environ.get("TP_GRAPHS", "0"))
     be.set_option("graphs", graphs)
     out = {"cases": []}
+    if os.environ.get("TP_DRILL") == "1":
+        return drill(be, rank, world)
     prompt = [1, 5, 9, 300, 17, 42, 99, 7, 250]
     for name, ftype in ((("test-llama-tp", 1), ("test-llama-tp", 5)) if world <= 2 else (("test-llama-tp4", 1), ("test-llama-tp4", 5))):
         hp = preset(name)
