@@ -311,7 +311,7 @@ def main():
         pos += args.warmup
         g0 = be.stat("graph_launches")
         gl0 = be.stat("graph_launch_host_ns")
-        host0 = {k: be.stat(k) for k in ("graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits")}
+        host0 = {k: be.stat(k) for k in ("graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs")}
         sync()
         t0 = time.perf_counter()
         steps(args.steps)
@@ -329,7 +329,11 @@ def main():
         # host time inside graph_compute per timed step (the GPU idles while the host recognises the graph it is about to replay: VERDICT r04 #6)
         host_graph.update({"graph_key_us": round((be.stat("graph_key_host_ns") - host0["graph_key_host_ns"]) / 1e3 / max(1, gs), 2),
                            "graph_compute_us": round((be.stat("graph_compute_host_ns") - host0["graph_compute_host_ns"]) / 1e3 / max(1, args.steps), 2),
-                           "replays_recognised_in_place": int(be.stat("graph_key_fast_hits") - host0["graph_key_fast_hits"])})
+                           "replays_recognised_in_place": int(be.stat("graph_key_fast_hits") - host0["graph_key_fast_hits"]),
+                           # steps that were NOT replays (a -np engine outgrows its 256-cell cache view every few steps): captured at first sighting / of those,
+                           # patched into the previous executable graph / run eagerly
+                           "captures": int(be.stat("graph_captures") - host0["graph_captures"]), "captures_at_first_sighting": int(be.stat("graph_early_captures") - host0["graph_early_captures"]),
+                           "executable_graph_updates": int(be.stat("graph_exec_updates") - host0["graph_exec_updates"]), "eager_steps": int(be.stat("eager_graphs") - host0["eager_graphs"])})
         return el, gs, (be.stat("graph_launch_host_ns") - gl0) / 1e3 / max(1, gs)
 
     def headline(el, extra_note=""):  # the contract's fields for a K-step time (everything else is added to it below)

@@ -750,6 +750,8 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "graph_compute_host_ns") return c->st.graph_compute_host_ns;
     if (k == "graph_key_fast_hits") return c->st.graph_key_fast_hits;
     if (k == "graph_key_collisions") return c->st.graph_key_collisions;
+    if (k == "graph_early_captures") return c->st.graph_early_captures;
+    if (k == "graph_exec_updates") return c->st.graph_exec_updates;
     if (k == "skinny_launches") return c->st.skinny_launches;
     if (k == "wide_launches") return c->st.wide_launches;
     if (k == "tiled_launches") return c->st.tiled_launches;

@@ -149,6 +149,8 @@ struct stats {
     int64_t graph_compute_host_ns = 0; // host time inside graph_compute, all paths
     int64_t graph_key_fast_hits = 0;   // replays recognised by comparing against the graph replayed last (no key built, no hash)
     int64_t kernel_downloads = 0;      // get_tensor_async calls served by a copy kernel writing mapped pinned memory
+    int64_t graph_early_captures = 0;  // graphs captured at their FIRST sighting (same step as the one replayed last, over a grown cache)
+    int64_t graph_exec_updates = 0;    // ... of them, served by patching the predecessor's executable graph (hipGraphExecUpdate) instead of instantiating
     int64_t graph_key_collisions = 0;  // two different graph keys with one hash (each keeps its own entry)
 };
 
@@ -161,6 +163,8 @@ struct cached_graph {
     int seen = 0;
     uint64_t last_use = 0;
     int64_t allreduces = 0;  // reductions / collectives recorded in the graph (counted again at every replay: stats::allreduces)
+    int n_nodes = 0;
+    bool early_failed = false;  // a capture at first sighting was tried and failed (graph.cpp)
     std::vector<uint64_t> key;  // the graph this entry stands for, word by word (graph.cpp: walk_key) — an entry is used only when these are equal
 };
 

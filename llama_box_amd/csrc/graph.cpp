@@ -1973,11 +1973,20 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         it->second.key = c->key_scratch;
     }
     cached_graph & cg = it->second;
+    // A graph seen for the first time whose predecessor — the graph replayed last — has the same number of nodes is the same step over a grown
+    // cache (n_kv moves to the next multiple of 256: every 8th step of a -np 32 engine, llama-box/httpserver.hpp:3539-3623): its kernels have
+    // all run before, so it is captured at once instead of after an eager run (profiles/r05_np32_ab_early_capture.txt).  Anything else keeps the
+    // rule "first sighting eager" — one-off prompt graphs never pay for a capture, and a kernel's first launch never happens inside one.
+    static const bool early_on = !getenv("GGML_MI355X_EARLY_CAPTURE") || atoi(getenv("GGML_MI355X_EARLY_CAPTURE")) != 0;
+    const bool early = early_on && cg.seen == 0 && !cg.early_failed && c->last_graph && c->last_graph != &cg && c->last_graph->exec && c->last_graph->n_nodes == g->n_nodes &&
+                       c->last_graph->last_use + 1 == c->tick && !has_split && !tp_active(c);
+    cached_graph * const prev = early ? c->last_graph : nullptr;
+    cg.n_nodes = g->n_nodes;
     c->last_graph = &cg;  // (unordered_map nodes stay where they are until erased; every erase below resets this)
     if (cg.exec) return replay(cg);
     cg.last_use = c->tick;
     cg.seen++;
-    if (cg.seen < 2 || cg.seen > 1000000) {  // first sighting: run eagerly (one-off prefill graphs never pay for capture)
+    if (!early && (cg.seen < 2 || cg.seen > 1000000)) {  // first sighting: run eagerly (one-off prefill graphs never pay for capture)
         c->st.eager_graphs++;
         const bool ok = run_nodes(c, g, wp);
         if (c->graphs.size() > 64) {  // bound the cache: drop everything that is not instantiated and old
@@ -2010,13 +2019,37 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (!ok || e_end != hipSuccess || graph == nullptr) {
         (void) hipGetLastError();
         if (graph) (void) hipGraphDestroy(graph);
+        if (early) {  // (the shortcut did not work for this graph: back to the ordinary rule, the next sighting tries again)
+            cg.early_failed = true;
+            c->st.eager_graphs++;
+            return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+        }
         MI_INFO("hipGraph capture failed (ok=%d, err=%d); running this topology eagerly from now on", (int) ok, (int) e_end);
         cg.seen = 1000001;  // never try again
         c->st.eager_graphs++;
         return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
     }
     hipGraphExec_t exec = nullptr;
-    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || exec == nullptr) {
+    // the same step over a grown cache: the predecessor's executable graph is PATCHED with this capture's kernel parameters (same kernels in the same
+    // order, other extents / grid sizes) and moves to this entry — instantiating ~300 kernel nodes anew is the larger half of a re-capture.  Any
+    // difference in topology (another attention kernel for the longer cache, another split count's combine pass) makes the update fail: then the
+    // ordinary instantiation below.  The predecessor's key is never seen again in a decode run (n_kv only grows); if it is, it is captured afresh.
+    static const bool update_on = !getenv("GGML_MI355X_EXEC_UPDATE") || atoi(getenv("GGML_MI355X_EXEC_UPDATE")) != 0;
+    if (early && update_on && prev && prev->exec) {
+        hipGraphNode_t err_node = nullptr;
+        hipGraphExecUpdateResult res = hipGraphExecUpdateError;
+        if (hipGraphExecUpdate(prev->exec, graph, &err_node, &res) == hipSuccess && res == hipGraphExecUpdateSuccess) {
+            exec = prev->exec;
+            prev->exec = nullptr;
+            if (prev->graph) (void) hipGraphDestroy(prev->graph);
+            prev->graph = nullptr;
+            prev->seen = 1;
+            c->st.graph_exec_updates++;
+        } else {
+            (void) hipGetLastError();
+        }
+    }
+    if (exec == nullptr && (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || exec == nullptr)) {
         (void) hipGetLastError();
         (void) hipGraphDestroy(graph);
         cg.seen = 1000001;
@@ -2027,6 +2060,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     cg.exec = exec;
     cg.allreduces = red_captured;
     c->st.graph_captures++;
+    c->st.graph_early_captures += early ? 1 : 0;
     if (hipGraphLaunch(cg.exec, c->stream) != hipSuccess) {
         (void) hipGetLastError();
         return GGML_STATUS_FAILED;

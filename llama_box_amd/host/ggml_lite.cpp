@@ -800,7 +800,15 @@ static void spread_pages(char * p, size_t size) {
 #if defined(SYS_mbind)
     if (n_nodes > 1) {
         char * a = (char *) (((uintptr_t) p + 4095) & ~(uintptr_t) 4095);
-        (void) syscall(SYS_mbind, a, (size - (size_t) (a - p)) & ~(size_t) 4095, 3 /* MPOL_INTERLEAVE */, mask, sizeof(mask) * 8, 0);  // (refused under some seccomp profiles: the touch below still spreads)
+        // GGML_LITE_NUMA_NODE=n: everything on node n instead (MPOL_PREFERRED) — for a reader team pinned to that node's cores (bench.py's CPU leg on a
+        // container whose CPU quota is a fraction of one socket: all-local reads instead of half of them crossing the socket link)
+        const char * one = getenv("GGML_LITE_NUMA_NODE");
+        if (one && atoi(one) >= 0 && atoi(one) < n_nodes) {
+            unsigned long m1[16] = {0};
+            m1[atoi(one) / (8 * sizeof(unsigned long))] = 1ul << (atoi(one) % (8 * sizeof(unsigned long)));
+            (void) syscall(SYS_mbind, a, (size - (size_t) (a - p)) & ~(size_t) 4095, 1 /* MPOL_PREFERRED */, m1, sizeof(m1) * 8, 0);
+        } else
+            (void) syscall(SYS_mbind, a, (size - (size_t) (a - p)) & ~(size_t) 4095, 3 /* MPOL_INTERLEAVE */, mask, sizeof(mask) * 8, 0);  // (refused under some seccomp profiles: the touch below still spreads)
     }
 #endif
     const unsigned T = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));

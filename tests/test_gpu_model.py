@@ -242,6 +242,43 @@ def test_hipgraph_replay_is_bit_identical_to_eager(backend, H, plog):
     assert np.array_equal(outs[1][1].view(np.uint32), outs[0][1].view(np.uint32))
 
 
+@pytest.mark.parametrize("fa", [1, 0])
+def test_a_grown_cache_is_captured_at_first_sighting_and_patched_into_the_previous_executable_graph(backend, H, plog, fa):
+    """Round 5: a continuous-batching engine (8 sequences here) moves to the next 256-cell step of its cache view every few decode steps; the graph of
+    the new extent is the same step as the one replayed last, so it is captured at its FIRST sighting (stat graph_early_captures) and, where the
+    kernels are the same, the predecessor's executable graph is patched with the new parameters instead of instantiated anew (graph_exec_updates).
+    Same logits, bit for bit, as eager execution across four such boundaries."""
+    hp = preset("test-llama", n_head=4, n_head_kv=2, n_embd=512, n_embd_head=128)
+    mg = Model(hp, 31, backend.buft)
+    n_par, n_steps, n_prompt = 8, 120, 24
+    rng = np.random.default_rng(8)
+    toks = rng.integers(1, hp.n_vocab, n_par * n_prompt).tolist()
+    rows = [rng.integers(1, hp.n_vocab, n_par).tolist() for _ in range(n_steps)]
+    outs = {}
+    try:
+        for mode in (1, 0):
+            backend.set_option("graphs", mode)
+            c = Context(mg, backend=backend, flash_attn=fa, n_ctx=2048)
+            rc, _ = c.decode(toks, [i for _ in range(n_par) for i in range(n_prompt)], [k for k in range(n_par) for _ in range(n_prompt)], ([0] * (n_prompt - 1) + [1]) * n_par)
+            assert rc == 0
+            s0 = {k: backend.stat(k) for k in ("graph_launches", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs")}
+            lg = []
+            for i in range(n_steps):
+                rc, l1 = c.decode(rows[i], [n_prompt + i] * n_par, seq=list(range(n_par)))
+                assert rc == 0
+                lg.append(l1)
+            outs[mode] = (np.stack(lg), {k: backend.stat(k) - v for k, v in s0.items()})
+            c.free()
+    finally:
+        backend.set_option("graphs", 1)
+        mg.free()
+    st = outs[1][1]
+    plog(f"grown-cache capture (fa={fa}): {n_steps} steps of {n_par} sequences: {st}")
+    # 8 cells per step from 192: the 256-cell view is outgrown after 8 steps, then every 32 steps: four new extents in 120 steps
+    assert st["graph_captures"] >= 4 and st["graph_early_captures"] >= 3 and st["eager_graphs"] <= 2, st
+    assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
+
+
 @pytest.mark.parametrize("name", ["test-llama", "test-qwen2"])
 def test_sum_of_squares_handed_from_the_residual_mat_vecs_to_the_norm_prologues(backend, H, plog, name):
     """Option ss_partials (on by default, round 4): the mat-vec launches that write a residual stream (wo + residual, ffn_down + residual) leave
