@@ -158,7 +158,7 @@ _SIGS = {
     "llm_decode_steps": (_I, [_P, _I, _I, C.POINTER(C.c_int32), _I]),
     "llm_verify_steps": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int32), _I]),
     "llm_n_outputs": (_I, [_P]), "llm_get_logits": (C.POINTER(C.c_float), [_P]), "llm_get_logits_ith": (C.POINTER(C.c_float), [_P, _I]),
-    "llm_kv_clear": (None, [_P]), "llm_kv_seq_rm": (_I, [_P, _I, _I, _I]), "llm_kv_seq_add": (_I, [_P, _I, _I, _I, _I]), "llm_last_graph": (C.POINTER(CGraph), [_P]),
+    "llm_kv_clear": (None, [_P]), "llm_kv_seq_rm": (_I, [_P, _I, _I, _I]), "llm_kv_seq_add": (_I, [_P, _I, _I, _I, _I]), "llm_last_graph": (C.POINTER(CGraph), [_P]), "llm_context_cache_tensor": (TP, [_P, _I, _I]),
     "llm_sample_greedy": (C.c_int32, [_P, _I]), "llm_token_probabilities": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "llm_last_timings": (None, [_P, C.POINTER(C.c_double)]),
 }

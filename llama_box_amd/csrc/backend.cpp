@@ -65,6 +65,7 @@ ggml_backend_buffer_t make_backend_buffer(ggml_backend_buffer_type_t buft, const
 static void uploader_drain(int device);
 static void buf_free(ggml_backend_buffer_t b) {
     buffer_ctx * c = (buffer_ctx *) b->context;
+    if (ip_any()) ip_host_buffer_freed(b);  // (tp_inproc.cpp mirrors host buffers on the other devices)
     HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);  // a staged upload may still be writing into this arena
     HIP_NOTE(hipFree(c->base));
@@ -74,6 +75,7 @@ static void * buf_get_base(ggml_backend_buffer_t b) { return ((buffer_ctx *) b->
 static enum ggml_status buf_init_tensor(ggml_backend_buffer_t, ggml_tensor *) { return GGML_STATUS_SUCCESS; }
 static void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t value, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
+    if (ip_any()) ip_host_access(b, true);
     HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);
     HIP_SOFT(hipMemset((char *) t->data + offset, value, size));
@@ -298,6 +300,7 @@ int mask_sparse_hint(const void * dev_ptr) {
 
 static void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
+    if (ip_any()) ip_host_access(b, true);  // (a cache buffer whose heads live sharded on several devices: tp_inproc.cpp)
     HIP_SOFT(hipSetDevice(c->device));
     note_mask_upload(t, data, offset, size);
     if (size > ((size_t) 1 << 20) && staged_upload(c->device, (char *) t->data + offset, (const char *) data, size)) return;
@@ -306,6 +309,7 @@ static void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void 
 }
 static void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t offset, size_t size) {
     buffer_ctx * c = (buffer_ctx *) b->context;
+    if (ip_any()) ip_host_access(b, false);
     HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);
     HIP_SOFT(hipMemcpy(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost));
@@ -317,6 +321,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggm
     buffer_ctx * dc = (buffer_ctx *) b->context;
     const size_t n = ggml_abi_nbytes(src);
     forget_mask_stats(dst->data, n);
+    if (ip_any()) { ip_host_access(sb, false); ip_host_access(b, true); }
     uploader_drain(sc->device);
     if (dc->device != sc->device) uploader_drain(dc->device);
     if (sc->device == dc->device) {
@@ -330,6 +335,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggm
 }
 static void buf_clear(ggml_backend_buffer_t b, uint8_t value) {
     buffer_ctx * c = (buffer_ctx *) b->context;
+    if (ip_any()) ip_host_access(b, true);
     HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);
     HIP_SOFT(hipMemset(c->base, value, c->size));
@@ -339,6 +345,14 @@ static const ggml_backend_buffer_i k_buffer_iface = {buf_free, buf_get_base, buf
                                                      buf_get_tensor, buf_cpy_tensor, buf_clear, nullptr};
 
 bool buffer_is_ours(ggml_backend_buffer_t b) { return b != nullptr && b->iface.free_buffer == buf_free; }
+// a buffer object that only TAGS tensors the backend creates itself (tp_inproc.cpp: the per-device shards of a rewritten graph): it owns no memory
+void make_internal_buffer(ggml_backend_buffer * out, buffer_ctx * bc, int device_ordinal, bool rowpar) {
+    bc->device = device_ordinal;
+    bc->base = nullptr;
+    bc->size = 0;
+    bc->rowpar = rowpar;
+    *out = ggml_backend_buffer{k_buffer_iface, nullptr, bc, 0, GGML_BACKEND_BUFFER_USAGE_COMPUTE};
+}
 bool buffer_is_rowpar(ggml_backend_buffer_t b) { return buffer_is_ours(b) && ((buffer_ctx *) b->context)->rowpar; }
 
 // ---- device buffer type
@@ -428,6 +442,7 @@ static void be_free(ggml_backend_t be) {
     HIP_SOFT(hipSetDevice(c->device));
     HIP_SOFT(hipStreamSynchronize(c->stream));
     free_graph_cache(c);
+    ip_free(c);
     tp_free(c);
     free_split_helpers(c);
     if (c->ws) HIP_NOTE(hipFree(c->ws));
@@ -449,6 +464,7 @@ void flush_uploads(backend_ctx * c) {
 }
 static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
+    if (ip_any()) ip_host_access(t->view_src ? t->view_src->buffer : t->buffer, true);
     HIP_SOFT(hipSetDevice(c->device));
     note_mask_upload(t, data, offset, size);
     constexpr size_t SMALL = 64 * 1024, RING = 4u << 20;
@@ -477,6 +493,7 @@ static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void *
 }
 static void be_get_tensor_async(ggml_backend_t be, const ggml_tensor * t, void * data, size_t offset, size_t size) {
     backend_ctx * c = (backend_ctx *) be->context;
+    if (ip_any()) ip_host_access(t->view_src ? t->view_src->buffer : t->buffer, false);
     HIP_SOFT(hipSetDevice(c->device));
     flush_uploads(c);
     uploader_join(c->device, c->stream);
@@ -502,6 +519,7 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
     if (cd != cs) flush_uploads(cd);
     const size_t n = ggml_abi_nbytes(src);
     forget_mask_stats(dst->data, n);
+    if (ip_any()) { ip_host_access(sb, false); ip_host_access(db, true); }
     uploader_join(cs->device, cs->stream);
     if (cd->device != cs->device) uploader_drain(cd->device);
     if (cs->device == cd->device) {
@@ -554,6 +572,11 @@ static const ggml_backend_i k_backend_iface = {
 #endif
 };
 static bool be_is_ours(ggml_backend_t be) { return be != nullptr && be->iface.get_name == be_get_name; }
+static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *);
+ggml_backend_t internal_backend(int logical) {
+    if (logical < 0 || logical >= logical_device_count()) return nullptr;
+    return dev_init_backend(logical_device(logical), nullptr);
+}
 
 // ------------------------------------------------------------------------------------------------ device iface
 static const char * dev_get_name(ggml_backend_dev_t dev) { return dctx(dev)->name.c_str(); }
@@ -756,6 +779,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "wide_launches") return c->st.wide_launches;
     if (k == "tiled_launches") return c->st.tiled_launches;
     if (k == "rope_epilogues") return c->st.rope_epilogues;
+    if (k.rfind("ip_", 0) == 0) return ip_stat(c, key);
     if (k == "staged_upload_bytes") return (int64_t) g_uploaders[c->device].bytes;
     if (k == "staged_upload_us") return (int64_t) (g_uploaders[c->device].seconds * 1e6);
     return -1;

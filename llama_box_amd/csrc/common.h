@@ -156,6 +156,7 @@ struct stats {
 
 struct tp_state;      // tp.cpp
 struct split_helper;  // split.cpp
+struct ip_engine;     // tp_inproc.cpp
 
 struct cached_graph {
     hipGraph_t graph = nullptr;
@@ -195,6 +196,7 @@ struct backend_ctx {
     bool capturing = false;
     // tensor parallel
     tp_state * tp = nullptr;
+    ip_engine * ip = nullptr;  // -sm row served as in-process tensor parallelism (tp_inproc.cpp); owned by the main device's backend
     // -sm row: per owning device a stream / scratch / event for the slices of row-split weights (split.cpp), created on first use
     std::vector<split_helper *> split_helpers;
     hipEvent_t split_ready = nullptr;  // "the activations of this split mat-mul exist on the main stream"
@@ -280,6 +282,25 @@ void free_split_helpers(backend_ctx * c);
 bool supports_op(const ggml_tensor * op);
 enum ggml_status graph_compute(backend_ctx * ctx, ggml_cgraph * g);
 void free_graph_cache(backend_ctx * ctx);
+bool graph_key_equals(const ggml_cgraph * g, const std::vector<uint64_t> & key);  // the graph-key words (graph.cpp: walk_key), compared in place ...
+void graph_key_build(const ggml_cgraph * g, std::vector<uint64_t> & key);         // ... or materialised
+
+// ---- in-process tensor parallel over the devices of a row-split model, -sm row (tp_inproc.cpp) ----
+struct ip_engine;
+// handled = false: the graph is not one the engine takes (no split weights, or a shape it declines): the caller goes on as before
+enum ggml_status ip_graph_compute(backend_ctx * ctx, ggml_cgraph * g, bool * handled);
+void ip_free(backend_ctx * ctx);
+int64_t ip_stat(const backend_ctx * ctx, const char * key);  // -1: unknown key
+// the host is about to read / has written memory of `b` behind the engine's back (get_tensor, set_tensor, copies, a graph the engine does not take):
+// the per-device KV shards are gathered into / re-scattered from the host's cache tensors lazily
+void ip_host_access(ggml_backend_buffer_t b, bool write);
+void ip_host_buffer_freed(ggml_backend_buffer_t b);  // the host frees a buffer the engine mirrors
+bool ip_any();
+
+// ---- internal buffer objects for tensors the backend creates itself (backend.cpp) ----
+struct buffer_ctx;
+void make_internal_buffer(ggml_backend_buffer * out, buffer_ctx * bc, int device_ordinal, bool rowpar);
+ggml_backend_t internal_backend(int logical_device);  // a second backend instance on a device of the registration (its own stream and scratch)
 
 // ---- host-side shadow of what the engine uploads as attention masks (backend.cpp) ----
 // llama.cpp fills the KQ mask on the host and hands it over with set_tensor(_async) before every graph: while the bytes pass through, the
@@ -305,6 +326,7 @@ bool tp_active(const backend_ctx * ctx);
 int tp_p2p_export(backend_ctx * ctx, int rank, int world, void * handle_out, size_t size);  // -> this rank's mailbox as a hipIpcMemHandle_t (64 bytes)
 int tp_p2p_attach(backend_ctx * ctx, const void * handles, size_t size);                    // world handles in rank order, own slot ignored
 int64_t tp_p2p_timeouts(backend_ctx * ctx);
+int tp_attach_local(backend_ctx * const * ctxs, int n);  // the devices of this process as one group (ranks = array order); 0 or < 0
 bool tp_p2p_enable(backend_ctx * ctx, bool on);  // false: refused (switching the only transport of a group off)
 bool tp_p2p_reset(backend_ctx * ctx);           // forget a time-out (every rank, all idle)
 bool tp_check(backend_ctx * ctx);               // false: an all-reduce of an earlier graph timed out — the caller fails its graph_compute

@@ -375,7 +375,8 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     auto dn = st.deferred.find(b);
     const bool pro_norm = dn != st.deferred.end();
     const bool pro_fa = st.fa_wo.b == b && st.fa_wo.part != nullptr;  // (set by the FLASH_ATTN_EXT node after checking this very mat-vec)
-    const bool pro_f32 = !pro_norm && !pro_fa && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
+    static const bool dbg_no_pro_f32 = getenv("GGML_MI355X_DBG_NO_PRO_F32") != nullptr;
+    const bool pro_f32 = !dbg_no_pro_f32 && !pro_norm && !pro_fa && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
     if (pro_fa && (w2 || pro_norm || !kquant || M != 1)) {
         MI_ERR("graph_compute: attention partials were left for a mat-vec that cannot merge them");
         return false;
@@ -406,7 +407,12 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         a.eps = pro_norm ? dn->second.eps : 0.0f;
         // (the allocator may have given THIS result the block of the norm's MUL node, free after its last reader — then that node is
         // provably dead and is not written: the two stores would race inside one launch)
-        a.norm_out = (pro_norm && !ranges_overlap(dst, dn->second.out)) ? (float *) dn->second.out->data : nullptr;
+        // ... and so is a MUL node that the allocator placed over the norm's INPUT x (RMS_NORM and MUL run in place when the norm is x's last reader — the
+        // final norm in front of the output matrix): workgroup 0 would replace x by norm(x) * w while the other workgroups' prologues still read x.  On
+        // one otherwise idle GPU all 256 workgroups start together and read x before workgroup 0 gets that far; with anything else on the GPU (a second
+        // rank or model, the logical devices of the tests) late workgroups read the overwritten row: logits 4e-2 off at random steps (round 5).  The
+        // node is dead by construction: can_defer_norm admitted the pair only because every reader of it takes the prologue.
+        a.norm_out = (pro_norm && !ranges_overlap(dst, dn->second.out) && !ranges_overlap(dn->second.x, dn->second.out)) ? (float *) dn->second.out->data : nullptr;
         if (pro_norm && st.ss_tensor != nullptr && st.ss_tensor == dn->second.x) {  // x came out of a launch that left its sum of squares behind
             a.ss_in = c->ss_buf;
             a.ss_n = st.ss_n;
@@ -741,7 +747,7 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     base.x = norm ? (const float *) dn->second.x->data : (const float *) X->data;
     base.norm_w = norm ? (const float *) dn->second.w->data : nullptr;
     base.eps = norm ? dn->second.eps : 0.0f;
-    base.norm_out = norm ? (float *) dn->second.out->data : nullptr;
+    base.norm_out = (norm && !ranges_overlap(dn->second.x, dn->second.out)) ? (float *) dn->second.out->data : nullptr;  // (never over the norm's own input: see run_mul_mat_q)
     if (norm && st.ss_tensor != nullptr && st.ss_tensor == dn->second.x) {
         base.ss_in = c->ss_buf;
         base.ss_n = st.ss_n;
@@ -1426,7 +1432,9 @@ static int run_node(exec_state & st, int i) {
             if (fuse && m && m->op == GGML_OP_MUL && single_use(st, n) && m->type == GGML_TYPE_F32 && m->nb[0] == 4) {
                 const ggml_tensor * w = m->src[0] == n ? m->src[1] : (m->src[1] == n ? m->src[0] : nullptr);
                 if (w && w->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(w) && w->ne[0] == n->ne[0] && ggml_abi_nelements(w) == w->ne[0] && same_shape(m, n)) {
-                    if (c->opt.prologue && can_defer_norm(st, i, n, m, a, w)) {
+                    static const bool dbg_no_defer = getenv("GGML_MI355X_DBG_NO_DEFER_NORM") != nullptr;
+                    static const char * dbg_only = getenv("GGML_MI355X_DBG_DEFER_ONLY");
+                    if (c->opt.prologue && !dbg_no_defer && (!dbg_only || strstr(m->name, dbg_only)) && can_defer_norm(st, i, n, m, a, w)) {
                         st.deferred[m] = {a, w, ggml_abi_op_param_f32(n, 0), m};
                         c->st.fused_nodes += 2;
                         return 2;
@@ -1560,7 +1568,8 @@ static int run_node(exec_state & st, int i) {
                 // for the RMS_NORM prologue that reads the residual stream next)
                 ggml_tensor * a1 = next(1);
                 const ggml_tensor * o1 = (fuse && a1 && single_use(st, n)) ? add_partner(a1, n) : nullptr;
-                if (o1 && same_shape(o1, n)) {  // (the ADD may recycle the block of either operand: every thread reads its own elements before it writes them)
+                static const bool dbg_no_ar_fused = getenv("GGML_MI355X_DBG_NO_AR_FUSED") != nullptr;
+                if (o1 && same_shape(o1, n) && !dbg_no_ar_fused) {  // (the ADD may recycle the block of either operand: every thread reads its own elements before it writes them)
                     int ssn = 0;
                     const bool want_ss = c->opt.ss_partials && c->ss_buf != nullptr && M == 1;
                     if (st.ss_tensor != nullptr && ranges_overlap(a1, st.ss_tensor)) st.ss_tensor = nullptr;
@@ -1891,6 +1900,8 @@ static void key_build(const ggml_cgraph * g, std::vector<uint64_t> & key) {
         return true;
     });
 }
+bool graph_key_equals(const ggml_cgraph * g, const std::vector<uint64_t> & key) { return key_equals(g, key); }
+void graph_key_build(const ggml_cgraph * g, std::vector<uint64_t> & key) { key_build(g, key); }
 static uint64_t key_hash(const std::vector<uint64_t> & key) {  // four independent multiply-fold lanes over 8-byte words
     uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
     auto fold = [](uint64_t a, uint64_t v) {
@@ -1947,6 +1958,13 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (may_replay && c->last_graph && c->last_graph->exec && key_equals(g, c->last_graph->key)) {
         c->st.graph_key_fast_hits++;
         return replay(*c->last_graph);
+    }
+    // -sm row: a graph over row-split weights runs as tensor parallelism over the process's devices where the engine takes it (tp_inproc.cpp); a
+    // backend that owns such an engine also tells it about every other graph (the K-shift works on the host's cache tensors)
+    {
+        bool handled = false;
+        const enum ggml_status st_ip = ip_graph_compute(c, g, &handled);
+        if (handled) return st_ip;
     }
     const ws_plan wp = plan_ws(c, g);
     if (!ensure_ws(c, wp.act_bytes + wp.aux_bytes + 256)) return GGML_STATUS_ALLOC_FAILED;

@@ -895,6 +895,37 @@ void launch_upload_multi(hipStream_t s, const upload_batch & b) {
     hipLaunchKernelGGL(k_upload_multi, dim3(gx, (unsigned) b.n), dim3(256), 0, s, b);
 }
 
+// rows of `width` bytes from one pitch to another; either side may be a peer device's memory (tp_inproc.cpp: the vocab shards of the logits into the
+// main device's tensor, the KV shards into / out of the host's cache tensors)
+__global__ void __launch_bounds__(256) k_copy2d(char * __restrict__ dst, const size_t dpitch, const char * __restrict__ src, const size_t spitch, const size_t width, const int vec) {
+    const size_t row = blockIdx.y;
+    char * d = dst + row * dpitch;
+    const char * s = src + row * spitch;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;; i += (size_t) gridDim.x * 256) {
+        if (vec == 16) {
+            if (i * 16 >= width) break;
+            ((uint4 *) d)[i] = ((const uint4 *) s)[i];
+        } else if (vec == 2) {
+            if (i * 2 >= width) break;
+            ((uint16_t *) d)[i] = ((const uint16_t *) s)[i];
+        } else {
+            if (i >= width) break;
+            d[i] = s[i];
+        }
+    }
+}
+void launch_copy2d(hipStream_t s, void * dst, size_t dpitch, const void * src, size_t spitch, size_t width, size_t height) {
+    if (width == 0 || height == 0) return;
+    const uintptr_t al = (uintptr_t) dst | (uintptr_t) src | (uintptr_t) dpitch | (uintptr_t) spitch | (uintptr_t) width;
+    const int vec = (al & 15) == 0 ? 16 : ((al & 1) == 0 ? 2 : 1);
+    const size_t items = (width + vec - 1) / vec;
+    const unsigned gx = (unsigned) std::min<size_t>(64, (items + 255) / 256);
+    for (size_t r0 = 0; r0 < height; r0 += 65535) {
+        const size_t h = std::min<size_t>(65535, height - r0);
+        hipLaunchKernelGGL(k_copy2d, dim3(gx, (unsigned) h), dim3(256), 0, s, (char *) dst + r0 * dpitch, dpitch, (const char *) src + r0 * spitch, spitch, width, vec);
+    }
+}
+
 MI_TU_TOUCH(ops)
 
 }  // namespace mi355x

@@ -102,8 +102,15 @@ static enum ggml_status sbuf_init_tensor(ggml_backend_buffer_t b, ggml_tensor * 
     // 256-value super-blocks per device and a quantised type; anything else is cut by rows
     const bool by_k = (strstr(t->name, "attn_output") || strstr(t->name, "ffn_down")) && blck > 1 && (t->ne[0] % 256) == 0 && !getenv("GGML_MI355X_SPLIT_ROWS_ONLY");
     info.kind = by_k ? 1 : 0;
-    if (by_k) split_rows(t->ne[0], c->bt->split, info.n_dev, 256, info.row0);
-    else split_rows(t->ne[1], c->bt->split, info.n_dev, t->ne[1] % 256 == 0 ? 256 : 64, info.row0);  // (256-row granules where the rows can become another weight's K range)
+    // The attention weights are cut at EIGHTHS of their rows (attn_output: of its K range): wq, wk, wv and attn_output then agree on which heads a
+    // device owns whatever their sizes — a device's rows of wk / wv are whole KV heads (8 of them in the Llama-3 family, 4 in Qwen2-7B: halves of
+    // the devices for -ts over 2 or 4), its rows of wq the query heads of exactly those groups, its K range of attn_output their outputs — which
+    // is what lets the attention and the KV cache be sharded with them (tp_inproc.cpp; it checks, and declines where a head would be cut).
+    const bool attn = strstr(t->name, "attn_q") || strstr(t->name, "attn_k") || strstr(t->name, "attn_v") || strstr(t->name, "attn_output");
+    const int64_t cut = by_k ? t->ne[0] : t->ne[1];
+    const int64_t eighth = attn && cut % 8 == 0 && (by_k ? (cut / 8) % 256 == 0 : (cut / 8) % 16 == 0) && !getenv("GGML_MI355X_SPLIT_LEGACY_ROWS") ? cut / 8 : 0;
+    if (by_k) split_rows(t->ne[0], c->bt->split, info.n_dev, eighth ? eighth : 256, info.row0);
+    else split_rows(t->ne[1], c->bt->split, info.n_dev, eighth ? eighth : (t->ne[1] % 256 == 0 ? 256 : 64), info.row0);  // (256-row granules where the rows can become another weight's K range)
     for (int d = 0; d < info.n_dev; ++d) {
         const int64_t part = info.row0[d + 1] - info.row0[d];
         info.slice_row_bytes[d] = by_k ? (size_t) (part / blck) * ggml_abi_type_size(t->type) : info.row_bytes;

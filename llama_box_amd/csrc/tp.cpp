@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -64,6 +65,7 @@ struct tp_state {
     unsigned * p2p_state = nullptr;
     unsigned * p2p_err_host = nullptr;  // pinned + mapped: raised by the kernel on a time-out, read by tp_check() without touching the device
     bool p2p = false;
+    bool local_group = false;  // the ranks are the devices of THIS process (tp_attach_local): the peers' mailboxes are not IPC mappings
     int p2p_max_cols_bytes = 0;  // messages up to this many bytes take the one-shot path when RCCL is there too
 };
 static size_t mbox_bytes(int world) { return (size_t) 2 * (size_t) world * P2P_SLOT_FLOATS * 8; }
@@ -178,6 +180,61 @@ int tp_p2p_attach(backend_ctx * c, const void * handles, size_t size) {
             t->comm ? ", RCCL for longer messages" : ", no RCCL communicator");
     return 0;
 }
+// ---- the same group inside ONE process (tp_inproc.cpp: llama-box drives all devices from one process, engine.cpp:87-95): every device's worker
+// context becomes a rank; the mailboxes are plain device allocations reached over peer access — no IPC handles, no control plane
+int tp_attach_local(backend_ctx * const * ctxs, int n) {
+    if (n < 2 || n > P2P_MAX_RANKS) return -1;
+    for (int r = 0; r < n; ++r)
+        if (ctxs[r]->tp) return -2;  // (already a rank of something else)
+    std::vector<tp_state *> ts((size_t) n, nullptr);
+    auto undo = [&]() {
+        for (int r = 0; r < n; ++r) {
+            if (!ts[(size_t) r]) continue;
+            (void) hipSetDevice(ctxs[r]->device);
+            if (ts[(size_t) r]->mbox_local) (void) hipFree(ts[(size_t) r]->mbox_local);
+            if (ts[(size_t) r]->p2p_state) (void) hipFree(ts[(size_t) r]->p2p_state);
+            if (ts[(size_t) r]->p2p_err_host) (void) hipHostFree(ts[(size_t) r]->p2p_err_host);
+            delete ts[(size_t) r];
+        }
+        (void) hipGetLastError();
+    };
+    for (int r = 0; r < n; ++r) {
+        tp_state * t = ts[(size_t) r] = new tp_state();
+        t->rank = r;
+        t->world = n;
+        if (hipSetDevice(ctxs[r]->device) != hipSuccess) { undo(); return -3; }
+        for (int q = 0; q < n; ++q) {  // every other device of the group may write this one's mailbox
+            if (ctxs[q]->device == ctxs[r]->device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, ctxs[r]->device, ctxs[q]->device) != hipSuccess || !can) { (void) hipGetLastError(); MI_ERR("tp_attach_local: device %d cannot reach device %d", ctxs[r]->device, ctxs[q]->device); undo(); return -4; }
+            if (hipDeviceEnablePeerAccess(ctxs[q]->device, 0) != hipSuccess) (void) hipGetLastError();  // (already enabled is fine)
+        }
+        hipError_t e = hipExtMallocWithFlags((void **) &t->mbox_local, mbox_bytes(n), hipDeviceMallocUncached);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            e = hipExtMallocWithFlags((void **) &t->mbox_local, mbox_bytes(n), hipDeviceMallocFinegrained);
+        }
+        if (e != hipSuccess || hipMemset(t->mbox_local, 0, mbox_bytes(n)) != hipSuccess || hipMalloc((void **) &t->p2p_state, 64) != hipSuccess || hipMemset(t->p2p_state, 0, 64) != hipSuccess ||
+            hipHostMalloc((void **) &t->p2p_err_host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void) hipGetLastError();
+            MI_ERR("tp_attach_local: mailbox of device %d failed", ctxs[r]->device);
+            undo();
+            return -5;
+        }
+        *t->p2p_err_host = 0;
+    }
+    const char * e = getenv("GGML_MI355X_P2P_MAX_BYTES");
+    for (int r = 0; r < n; ++r) {
+        tp_state * t = ts[(size_t) r];
+        for (int q = 0; q < n; ++q) t->mbox[q] = ts[(size_t) q]->mbox_local;
+        t->p2p = true;
+        t->local_group = true;
+        t->p2p_max_cols_bytes = e ? atoi(e) : 8 * 8192 * 4;
+        ctxs[r]->tp = t;
+    }
+    return 0;
+}
+
 // set_option("tp_p2p", 0 / 1): stop / resume serving sums through the mailboxes (a launcher that saw time-outs falls back to RCCL).
 // Switching them OFF is refused in a group that has no RCCL communicator: nothing else could carry the sums, and a row-parallel mat-mul
 // without its reduction is a silently wrong model.
@@ -287,7 +344,7 @@ void tp_free(backend_ctx * c) {
     if (!c->tp) return;
     rccl_api * api = c->tp->comm ? load_rccl() : nullptr;
     if (api && c->tp->comm) api->CommDestroy(c->tp->comm);
-    for (int r = 0; r < c->tp->world && r < P2P_MAX_RANKS; ++r)
+    for (int r = 0; r < c->tp->world && r < P2P_MAX_RANKS && !c->tp->local_group; ++r)
         if (c->tp->mbox[r] && c->tp->mbox[r] != c->tp->mbox_local && hipIpcCloseMemHandle(c->tp->mbox[r]) != hipSuccess) (void) hipGetLastError();
     if (c->tp->mbox_local && hipFree(c->tp->mbox_local) != hipSuccess) (void) hipGetLastError();
     if (c->tp->p2p_state && hipFree(c->tp->p2p_state) != hipSuccess) (void) hipGetLastError();

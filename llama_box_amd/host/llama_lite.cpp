@@ -1405,6 +1405,11 @@ extern "C" int llm_token_probabilities(struct llm_context * c, int idx, int top_
     return n;
 }
 extern "C" struct ggml_cgraph * llm_last_graph(struct llm_context * c) { return c->gf; }
+// the K (which = 0) or V (1) cache tensor of layer il: what llama.cpp's state save / slot save reads with ggml_backend_tensor_get
+extern "C" struct ggml_tensor * llm_context_cache_tensor(struct llm_context * c, int il, int which) {
+    if (il < 0 || il >= (int) c->k_l.size()) return nullptr;
+    return which ? c->v_l[(size_t) il] : c->k_l[(size_t) il];
+}
 extern "C" void llm_last_timings(const struct llm_context * c, double out[4]) {
     for (int k = 0; k < 4; ++k) out[k] = c->timings[k];
 }

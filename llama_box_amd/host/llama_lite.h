@@ -106,6 +106,7 @@ int llm_kv_seq_rm(struct llm_context * c, int seq_id, int p0, int p1);
 int llm_kv_seq_add(struct llm_context * c, int seq_id, int p0, int p1, int delta);
 /* the graph of the last micro-batch (for inspection / per-node comparison in tests) */
 struct ggml_cgraph * llm_last_graph(struct llm_context * c);
+struct ggml_tensor * llm_context_cache_tensor(struct llm_context * c, int il, int which); /* K (0) / V (1) cache tensor of layer il */
 /* host-side time split of the last llm_decode, microseconds: [build+alloc, set inputs, compute+sync, get logits] */
 void llm_last_timings(const struct llm_context * c, double out[4]);
 

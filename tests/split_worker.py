@@ -105,7 +105,7 @@ def model_main():
         # BASELINE config 4 at its real shard shapes: Llama-3-70B's layer (8192 / 28672, 64 heads on 8 KV heads, Q4_K_M type
         # map with Q5_K attn_v) cut to two layers, --tensor-split 1,1,1,1,1,1,1,1 over eight logical devices: every device holds 1024 / 128 /
         # 128 rows of wq / wk / wv, the 1024-value K slice of attn_output, 3584 rows of gate / up and the 3584-value K slice of ffn_down
-        cases = (("llama3-70b-q4_k_m", 1, [1.0] * 8, 2),)
+        cases = (("llama3-70b-q4_k_m", 1, [1.0] * int(os.environ.get("GGML_MI355X_FAKE_DEVICES", "8")), 2),)
     for name, ftype, ts, n_layer in cases:
         hp = preset(name)
         if n_layer:
@@ -136,13 +136,37 @@ def model_main():
             return np.stack(rows), reds
 
         g0 = be.stat("graph_launches")
+        ip0 = {k: be.stat(k) for k in ("ip_graphs", "ip_declined", "ip_input_copies", "ip_output_copies", "ip_kv_gathers", "ip_kv_scatters", "ip_worker_kernel_launches", "p2p_allreduces")}
         r_s, reds = run(cs, True)
         replays = be.stat("graph_launches") - g0
+        ip = {k: int(be.stat(k) - v) for k, v in ip0.items()}
+        ip["devices"] = int(be.stat("ip_devices"))
+        ip["p2p_timeouts"] = int(be.stat("p2p_timeouts"))
+        # the host reads a cache tensor back (a slot save): the shards come home — compare K of layer 0 with the one-device run's below
+        def cache_bytes(ctx_model, ctx):
+            t = H.llm_context_cache_tensor(ctx.c, 0, 0)
+            n = H.ggml_nbytes(t)
+            raw = np.empty(n, np.uint8)
+            H.ggml_backend_tensor_get(t, raw.ctypes.data_as(C.c_void_p), 0, n)
+            return raw
+        k_split = cache_bytes(ms, cs)
+        ip["kv_gathers_after_get_tensor"] = int(be.stat("ip_kv_gathers") - ip0["ip_kv_gathers"])
         r_g, _ = run(cg)
+        k_one = cache_bytes(mg, cg)
+        ip["cache_equal_to_one_device"] = bool(np.array_equal(k_split, k_one))
+        # (another mat-mul tiling over the narrower shards may sum in another order: an ulp in f32, now and then an f16 rounding of a cached value)
+        ip["cache_nmse_vs_one_device"] = float(T.nmse(k_split.view(np.float16).astype(np.float64), k_one.view(np.float16).astype(np.float64)))
+        # ... and decoding goes on after the host looked (and after it WROTE: the same bytes back — the shards are re-scattered)
+        H.ggml_backend_tensor_set(H.llm_context_cache_tensor(cs.c, 0, 0), k_split.ctypes.data_as(C.c_void_p), 0, k_split.nbytes)
+        rc_a, la = cs.decode([21], [len(prompt) + 6])
+        rc_b, lb = cg.decode([21], [len(prompt) + 6])
+        ip["nmse_after_host_write_vs_one_device"] = float(T.nmse(la[0], lb[0])) if rc_a == 0 and rc_b == 0 else -1.0
+        ip["kv_scatters_total"] = int(be.stat("ip_kv_scatters") - ip0["ip_kv_scatters"])
         r_c, _ = run(cc)
         out["cases"].append({"model": name, "ftype": ftype, "ts": ts, "n_layer": int(hp.n_layer), "reductions_per_graph": [int(r) for r in reds], "graph_replays": int(replays),
                              "nmse_vs_oracle": float(T.nmse(r_s, r_c)), "nmse_one_device_vs_oracle": float(T.nmse(r_g, r_c)), "nmse_vs_one_device": float(T.nmse(r_s, r_g)),
-                             "argmax_equal_one_device": bool(np.array_equal(np.argmax(r_s, 1), np.argmax(r_g, 1)))})
+                             "argmax_equal_one_device": bool(np.array_equal(np.argmax(r_s, 1), np.argmax(r_g, 1))), "ip": ip,
+                             "nmse_rows_vs_one_device": [float(T.nmse(r_s[i], r_g[i])) for i in range(len(r_s))]})
         for o in (cs, cg, cc, ms, mg, mc):
             o.free()
     print("SPLIT_JSON " + json.dumps(out))

@@ -46,7 +46,8 @@ def test_row_split_buffer_type_on_four_logical_devices(plog):
 def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs):
     """-sm row as a tensor-parallel layout (llama-box/engine_param.hpp:821-842, :902-916): attn_output / ffn_down cut along K,
     the FFN sharded end to end, TWO in-stream reductions per layer.  graphs = 1: the multi-stream step captured and replayed as a hipGraph."""
-    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="2", GGML_MI355X_SPLIT_GRAPHS=graphs)
+    # (GPU_MAX_HW_QUEUES: the logical devices' streams must not share a hardware queue of the one GPU — a device's all-reduce polls for its peers)
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="2", GGML_MI355X_SPLIT_GRAPHS=graphs, GPU_MAX_HW_QUEUES="8")
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py"), "model"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1][len("SPLIT_JSON "):])
@@ -60,6 +61,20 @@ def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs):
         assert c["nmse_vs_one_device"] <= 1e-3
         if graphs == "1":
             assert c["graph_replays"] >= 3, "the decode steps of the split model were not replayed as hipGraphs"
+        ip = c["ip"]
+        plog(f"[split-tp] graphs={graphs} {c['model']} ftype={c['ftype']} ts={c['ts']}: in-process tensor parallel {ip}")
+        assert ip["p2p_timeouts"] == 0, ip
+        if c["ts"][0] == c["ts"][1] and c["model"] == "test-llama-tp":
+            # an even split of a model whose heads divide: ALL seven graphs run as tensor parallelism over the two devices (round 5) — attention and the
+            # KV cache sharded by heads, the sums on the peer-to-peer all-reduce; per graph 5 input tensors copied to the other device and one
+            # vocab shard written back, NOTHING per layer
+            assert ip["devices"] == 2 and ip["ip_graphs"] == 7 and ip["ip_declined"] == 0, ip
+            assert ip["ip_input_copies"] <= 7 * 6 and ip["ip_output_copies"] == 7 * 2, ip
+            assert ip["ip_worker_kernel_launches"] > 0 and ip["p2p_allreduces"] > 0, ip
+            # the host's cache tensors: gathered when the host reads, re-scattered after it wrote
+            assert ip["kv_gathers_after_get_tensor"] == 1 and ip["cache_nmse_vs_one_device"] <= 1e-6, ip  # (gathered from eight devices' shards into the host's tensor)
+    assert 0.0 <= ip["nmse_after_host_write_vs_one_device"] <= 1e-3 and ip["kv_scatters_total"] == 2, ip
+            assert ip["kv_scatters_total"] == 2 and 0.0 <= ip["nmse_after_host_write_vs_one_device"] <= 1e-3, ip
 
 
 @pytest.mark.gpu
@@ -67,7 +82,7 @@ def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog):
     """BASELINE config 4 (Llama-3-70B Q4_K_M, --tensor-split 1,1,1,1,1,1,1,1; llama-box/engine_param.hpp:821-842, :902-916) at its REAL per-device
     shard shapes, through "ggml_backend_split_buffer_type" on eight logical devices of the one GPU: two layers of the 70B layer shape, prompt
     batch + decode steps; reductions == 2 x n_layer per graph, logits against the CPU oracle and against the same model on one device."""
-    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="8", GGML_MI355X_SPLIT_GRAPHS="0")
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="8", GGML_MI355X_SPLIT_GRAPHS=os.environ.get("TEST_70B_SPLIT_GRAPHS", "1"), GPU_MAX_HW_QUEUES="16")
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py"), "model", "70b"], capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1][len("SPLIT_JSON "):])
@@ -78,6 +93,15 @@ def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog):
     assert all(r_ == 2 * c["n_layer"] for r_ in c["reductions_per_graph"]), c
     assert c["nmse_vs_oracle"] <= 1e-3 and c["nmse_vs_oracle"] <= 10.0 * max(c["nmse_one_device_vs_oracle"], 1e-7)
     assert c["nmse_vs_one_device"] <= 1e-3
+    # round 5 (VERDICT r04 "next" #5): the 70B shard shapes run as in-process tensor parallelism over the eight devices — one KV head and eight query
+    # heads each, reductions == 2 x n_layer on the one-shot all-reduce, and NO gather / broadcast per layer: per graph the inputs go out (<= 6
+    # tensors x 7 devices) and the vocab shards come back (8), whatever the number of layers
+    ip = c["ip"]
+    plog(f"[split-tp 70b shards] in-process tensor parallel: {ip}; graph replays {c['graph_replays']}")
+    assert ip["devices"] == 8 and ip["ip_graphs"] == 7 and ip["ip_declined"] == 0 and ip["p2p_timeouts"] == 0, ip
+    assert ip["ip_input_copies"] <= 7 * 6 * 7 and ip["ip_output_copies"] == 7 * 8, ip
+    assert ip["kv_gathers_after_get_tensor"] == 1 and ip["cache_nmse_vs_one_device"] <= 1e-6, ip  # (gathered from eight devices' shards into the host's tensor)
+    assert 0.0 <= ip["nmse_after_host_write_vs_one_device"] <= 1e-3 and ip["kv_scatters_total"] == 2, ip
 
 
 def test_split_rows_planning_without_a_device():

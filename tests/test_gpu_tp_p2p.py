@@ -19,11 +19,16 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,graphs", [(2, 0), (4, 0), (2, 1)])
-def test_tensor_parallel_decode_over_the_p2p_all_reduce(plog, world, graphs):
+@pytest.mark.parametrize("world,graphs,real", [(2, 0, ""), (4, 0, ""), (2, 1, ""), (2, 0, "llama3-8b-q4_k_m"), (2, 0, "llama3-70b-q4_k_m")])
+def test_tensor_parallel_decode_over_the_p2p_all_reduce(plog, world, graphs, real):
+    """real: a rank's shard shapes of a real model (two layers of it).  Round 5 found the decode steps of exactly these 4e-2 off at random: the
+    deferred final norm's MUL node sits in the memory of the norm's own input (both run in place), workgroup 0 of the output mat-vec wrote it while
+    late workgroups — the ranks share the GPU here — still read the input (graph.cpp: norm_out)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0",
                TP_GRAPHS=str(graphs), GGML_MI355X_TP_GRAPHS=str(graphs), OMP_NUM_THREADS="4")
+    if real:
+        env.update(TP_PRESET=real, TP_LAYERS="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "tp_p2p_worker.py")], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
     outs = []
@@ -44,6 +49,9 @@ def test_tensor_parallel_decode_over_the_p2p_all_reduce(plog, world, graphs):
         # two sums per layer and graph, every one of them served by the peer-to-peer kernel (no RCCL communicator exists here)
         assert all(n == 2 * c["n_layer"] for n in c["per_decode_step"]), c
         assert c["allreduces"] == 2 * c["n_layer"] * 9, c
+        if real:  # (the prompt's sums exceed one mailbox slot and go through in chunks: more launches than sums)
+            assert c["nmse_vs_oracle"] <= 1e-3 and c["nmse_vs_one_device"] <= 1e-3, c
+            continue
         if not graphs:
             # the residual ADD rides in the all-reduce launch, and at one token its sum of squares goes on to the next RMS_NORM prologue:
             # per decode step n_layer ffn norms + (n_layer - 1) attention norms of the layers behind the first

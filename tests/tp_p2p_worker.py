@@ -84,9 +84,14 @@ def main():
     if os.environ.get("TP_DRILL") == "1":
         return drill(be, rank, world)
     prompt = [1, 5, 9, 300, 17, 42, 99, 7, 250]
-    for name, ftype in ((("test-llama-tp", 1), ("test-llama-tp", 5)) if world <= 2 else (("test-llama-tp4", 1), ("test-llama-tp4", 5))):
+    cases = (("test-llama-tp", 1), ("test-llama-tp", 5)) if world <= 2 else (("test-llama-tp4", 1), ("test-llama-tp4", 5))
+    if os.environ.get("TP_PRESET"):  # e.g. llama3-70b-q4_k_m cut to TP_LAYERS layers: a rank's real shard shapes
+        cases = ((os.environ["TP_PRESET"], 1),)
+    for name, ftype in cases:
         hp = preset(name)
         hp.ftype = ftype
+        if os.environ.get("TP_LAYERS"):
+            hp.n_layer = int(os.environ["TP_LAYERS"])
         m = Model(hp, 2024, be.buft, tp_rank=rank, tp_size=world, rowpar_buft=be.rowpar_buft())
         c = Context(m, backend=be, flash_attn=1)
         dist.barrier()  # (every rank has its shard: nobody's first sum waits for a peer that is still loading)
@@ -135,7 +140,8 @@ def main():
             mf.free()
             out["cases"].append({"model": name, "ftype": ftype, "n_layer": int(hp.n_layer), "allreduces": n_ar, "p2p_allreduces": n_p2p, "per_decode_step": per_step,
                                  "graph_replays": replays, "ss_handoffs": handoffs, "nmse_vs_oracle": float(T.nmse(full, ref)), "nmse_one_device_vs_oracle": float(T.nmse(one, ref)),
-                                 "nmse_vs_one_device": float(T.nmse(full, one)), "argmax_equal": bool(np.array_equal(np.argmax(full, 1), np.argmax(ref, 1)))})
+                                 "nmse_vs_one_device": float(T.nmse(full, one)), "argmax_equal": bool(np.array_equal(np.argmax(full, 1), np.argmax(ref, 1))),
+                                 "nmse_rows_vs_one_device": [float(T.nmse(full[i], one[i])) for i in range(len(full))]})
         dist.barrier()
     out["p2p_timeouts"] = int(be.stat("p2p_timeouts"))
     tmo = torch.tensor([out["p2p_timeouts"]], dtype=torch.int64)
