@@ -27,9 +27,11 @@
 // GGML_MI355X_SPLIT_TP=0 switches the engine off.  On ONE physical GPU (GGML_MI355X_FAKE_DEVICES) the devices' streams must not share a hardware
 // queue — a device's all-reduce polls for its peers' contributions — so the tests run with GPU_MAX_HW_QUEUES >= the number of logical devices.
 #include <algorithm>
+#include <condition_variable>
 #include <deque>
 #include <list>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 #include "common.h"
@@ -85,6 +87,17 @@ struct ip_plan {
     size_t stage_bytes = 0;
     uint64_t last_use = 0;
 };
+struct ip_plan;
+// one launcher thread per device other than the main one: a step's graphs are submitted to all devices AT ONCE (a replay is ~100 us of host time per
+// device — key comparison + hipGraphLaunch —: eight of them in a row would hold the last device back by most of a millisecond of a ~3 ms step)
+struct ip_worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    ip_plan * job = nullptr;  // set by the main thread, cleared by the worker when the submission is done
+    bool quit = false;
+    enum ggml_status result = GGML_STATUS_SUCCESS;
+};
 struct ip_engine {
     backend_ctx * main = nullptr;
     int n_dev = 0, main_dev = 0;
@@ -101,10 +114,19 @@ struct ip_engine {
     std::list<ip_plan> plans;
     ip_plan * last = nullptr;
     hipEvent_t ev_in = nullptr, ev_done[MAXD] = {nullptr};
+    // "the inputs are on the main device": recorded on a stream of its own behind the main stream — the other devices' streams wait for it while the
+    // main stream may already be CAPTURING its graph, and HIP refuses a wait on an event of a capturing stream from outside the capture (error 905)
+    hipStream_t fence = nullptr;
+    hipEvent_t ev_fence = nullptr;
     uint64_t tick = 0;
     options opt_seen;
     bool dead = false;
     bool running = false;
+    ip_worker * workers[MAXD] = {nullptr};
+    bool threaded = false;
+    std::mutex turn_m;
+    std::condition_variable turn_cv;
+    int turn = 0;
     // counters (ip_stat)
     int64_t graphs = 0, declined = 0, plans_built = 0, input_copies = 0, output_copies = 0, kv_gathers = 0, kv_scatters = 0, replica_bytes = 0;
 };
@@ -116,6 +138,7 @@ bool ip_any() { return !g_engines.empty(); }
 static size_t type_row_bytes(int type, int64_t n) { return (size_t) (n / ggml_abi_blck_size((ggml_type) type)) * ggml_abi_type_size((ggml_type) type); }
 
 // ------------------------------------------------------------------------------------------------ engine set-up
+static void worker_main(ip_engine * E, int d);
 static ip_engine * engine_new(backend_ctx * c, int n_dev, int main_dev) {
     if (n_dev < 2 || n_dev > MAXD || n_dev > P2P_MAX_RANKS) return nullptr;
     ip_engine * E = new ip_engine();
@@ -155,12 +178,27 @@ static ip_engine * engine_new(backend_ctx * c, int n_dev, int main_dev) {
         // the workers start from the main backend's options (a host that switched graphs or fusion off means all of it)
         if (ok && d != main_dev) E->ctx[d]->opt = c->opt;
     }
-    ok = ok && hipSetDevice(c->device) == hipSuccess && hipEventCreateWithFlags(&E->ev_in, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipSetDevice(c->device) == hipSuccess && hipEventCreateWithFlags(&E->ev_in, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&E->ev_fence, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&E->fence, hipStreamNonBlocking) == hipSuccess;
     (void) hipSetDevice(c->device);
     if (!ok) {
         (void) hipGetLastError();
         MI_ERR("in-process tensor parallel: set-up over %d devices failed; -sm row graphs run node by node on the main device (split.cpp)", n_dev);
         E->dead = true;
+    }
+    // OPT-IN (GGML_MI355X_SPLIT_THREADS=1).  On eight LOGICAL devices of one GPU, submitting the devices' graphs concurrently — or one after the other
+    // in DESCENDING device order from these threads (GGML_MI355X_DBG_SUBMIT_ORDER) — gives wrong results for the first graph on some boxes (the device
+    // that submits first ends with a zero logits shard; no all-reduce time-out is raised), while the ascending order of the one-thread form is
+    // bit-stable over every run (profiles/r05_inproc_tp_submit_order.txt).  The cause was not found in this round; whether it is an artefact of eight
+    // streams on one GPU's queues or a real ordering assumption can only be settled on a multi-GPU box, so the default stays the form that is verified.
+    static const bool threads_on = getenv("GGML_MI355X_SPLIT_THREADS") && atoi(getenv("GGML_MI355X_SPLIT_THREADS")) != 0;
+    if (ok && threads_on) {
+        for (int d = 0; d < n_dev; ++d) {
+            if (d == main_dev) continue;
+            E->workers[d] = new ip_worker();
+            E->workers[d]->th = std::thread(worker_main, E, d);
+        }
+        E->threaded = true;
     }
     E->opt_seen = c->opt;
     // (the split-graph capture gate of graph.cpp: replayed graphs with cross-device waits are opt-in until they have run on real multi-GPU hardware)
@@ -177,6 +215,18 @@ void ip_free(backend_ctx * c) {
         g_engines.erase(std::remove(g_engines.begin(), g_engines.end(), E), g_engines.end());
     }
     for (int d = 0; d < E->n_dev; ++d) {
+        if (ip_worker * W = E->workers[d]) {
+            {
+                std::lock_guard<std::mutex> lk(W->m);
+                W->quit = true;
+                W->cv.notify_all();
+            }
+            W->th.join();
+            delete W;
+            E->workers[d] = nullptr;
+        }
+    }
+    for (int d = 0; d < E->n_dev; ++d) {
         if (hipSetDevice(E->ordinal[d]) != hipSuccess) { (void) hipGetLastError(); continue; }
         if (E->ctx[d] && E->ctx[d]->stream) (void) hipStreamSynchronize(E->ctx[d]->stream);
     }
@@ -191,6 +241,8 @@ void ip_free(backend_ctx * c) {
     }
     (void) hipSetDevice(c->device);
     if (E->ev_in) (void) hipEventDestroy(E->ev_in);
+    if (E->ev_fence) (void) hipEventDestroy(E->ev_fence);
+    if (E->fence) (void) hipStreamDestroy(E->fence);
     (void) hipGetLastError();
     delete E;
     c->ip = nullptr;
@@ -212,6 +264,16 @@ int64_t ip_stat(const backend_ctx * c, const char * key) {
         for (int d = 0; E && d < E->n_dev; ++d)
             if (d != E->main_dev && E->ctx[d]) n += E->ctx[d]->st.kernel_launches;
         return n;
+    }
+    if (k == "ip_worker_p2p_timeouts") {  // time-outs of the all-reduce on the OTHER devices (stat "p2p_timeouts" is the main device's)
+        int64_t n = 0;
+        for (int d = 0; E && d < E->n_dev; ++d)
+            if (d != E->main_dev && E->ctx[d]) n += std::max<int64_t>(0, tp_p2p_timeouts(E->ctx[d]));
+        return n;
+    }
+    if (k.rfind("ip_dbg_timeouts_", 0) == 0) {  // ip_dbg_timeouts_<d>: the all-reduce time-outs of device d's context
+        const int d = atoi(key + 16);
+        return E && d >= 0 && d < E->n_dev && E->ctx[d] ? tp_p2p_timeouts(E->ctx[d]) : -2;
     }
     if (k == "ip_worker_graph_launches") {
         int64_t n = 0;
@@ -253,7 +315,9 @@ static bool mirror_ready(ip_engine * E, int mi, bool kv) {
             (void) hipSetDevice(E->main->device);
             return false;
         }
-        if (hipMemset(m.base[d], 0, m.size) != hipSuccess) (void) hipGetLastError();
+        // (on the device's OWN stream: a plain hipMemset runs on the null stream, which the devices' non-blocking streams do not wait for — it zeroed
+        // a device's mirror in the middle of its first graph whenever that device got going before the others)
+        if (hipMemsetAsync(m.base[d], 0, m.size, E->ctx[d]->stream) != hipSuccess) (void) hipGetLastError();
     }
     (void) hipSetDevice(E->main->device);
     return true;
@@ -820,6 +884,57 @@ static bool ensure_stage(ip_engine * E, size_t need) {
     return true;
 }
 
+// device d's part of a step, up to and including its graph (called with no assumption about the current device; leaves device d current)
+static enum ggml_status submit_device(ip_engine * E, ip_plan * P, int d) {
+    backend_ctx * c = E->main;
+    backend_ctx * w = E->ctx[d];
+    HIP_TRY(hipSetDevice(E->ordinal[d]), GGML_STATUS_FAILED);
+    if (d != E->main_dev) {
+        HIP_TRY(hipStreamWaitEvent(w->stream, E->ev_in, 0), GGML_STATUS_FAILED);
+        for (const ip_input & in : P->inputs) {
+            const ip_mirror & m = E->mirrors[(size_t) in.mirror];
+            if (E->ordinal[d] == c->device) HIP_TRY(hipMemcpyAsync(m.base[d] + in.off, m.host_base + in.off, in.bytes, hipMemcpyDeviceToDevice, w->stream), GGML_STATUS_FAILED);
+            else HIP_TRY(hipMemcpyPeerAsync(m.base[d] + in.off, E->ordinal[d], m.host_base + in.off, c->device, in.bytes, w->stream), GGML_STATUS_FAILED);
+        }
+    }
+    // replayed graphs with cross-device waits: on unless GGML_MI355X_SPLIT_GRAPHS=0 (the kernels' spins are bounded: a device that does not show
+    // up costs a failed llama_decode, not a hang)
+    static const bool graphs_ok = !getenv("GGML_MI355X_SPLIT_GRAPHS") || atoi(getenv("GGML_MI355X_SPLIT_GRAPHS")) != 0;
+    const bool graphs_was = w->opt.graphs;
+    w->opt.graphs = graphs_was && graphs_ok;
+    // debugging aid: GGML_MI355X_DBG_SUBMIT_ORDER=asc | desc — the devices' graphs are submitted one after the other in that order of device index
+    static const char * dbg_order = getenv("GGML_MI355X_DBG_SUBMIT_ORDER");
+    if (dbg_order) {
+        // asc: 0, 1, 2, ...; desc: n-1, ..., 0; mdesc: the main device first, then the others descending
+        const int my = dbg_order[0] == 'd' ? E->n_dev - 1 - d : (dbg_order[0] == 'm' ? (d == E->main_dev ? 0 : E->n_dev - d) : d);
+        std::unique_lock<std::mutex> lk(E->turn_m);
+        E->turn_cv.wait(lk, [&] { return E->turn == my; });
+    }
+    const enum ggml_status st = graph_compute(w, &P->graph[d]);
+    if (dbg_order) {
+        std::lock_guard<std::mutex> lk(E->turn_m);
+        E->turn++;
+        E->turn_cv.notify_all();
+    }
+    w->opt.graphs = graphs_was;
+    return st;
+}
+static void worker_main(ip_engine * E, int d) {
+    ip_worker * W = E->workers[d];
+    std::unique_lock<std::mutex> lk(W->m);
+    for (;;) {
+        W->cv.wait(lk, [&] { return W->job != nullptr || W->quit; });
+        if (W->quit) return;
+        ip_plan * P = W->job;
+        lk.unlock();
+        const enum ggml_status st = submit_device(E, P, d);
+        lk.lock();
+        W->result = st;
+        W->job = nullptr;
+        W->cv.notify_all();
+    }
+}
+
 static enum ggml_status run_plan(ip_engine * E, ip_plan * P, const ggml_cgraph * g) {
     backend_ctx * c = E->main;
     struct guard { int dev; ~guard() { if (hipSetDevice(dev) != hipSuccess) (void) hipGetLastError(); } } restore{c->device};
@@ -850,31 +965,35 @@ static enum ggml_status run_plan(ip_engine * E, ip_plan * P, const ggml_cgraph *
     }
     // the inputs exist on the main stream from here on
     HIP_TRY(hipSetDevice(c->device), GGML_STATUS_FAILED);
-    HIP_TRY(hipEventRecord(E->ev_in, c->stream), GGML_STATUS_FAILED);
+    HIP_TRY(hipEventRecord(E->ev_fence, c->stream), GGML_STATUS_FAILED);
+    HIP_TRY(hipStreamWaitEvent(E->fence, E->ev_fence, 0), GGML_STATUS_FAILED);
+    HIP_TRY(hipEventRecord(E->ev_in, E->fence), GGML_STATUS_FAILED);
     enum ggml_status st = GGML_STATUS_SUCCESS;
-    for (int d = 0; d < E->n_dev && st == GGML_STATUS_SUCCESS; ++d) {
-        backend_ctx * w = E->ctx[d];
-        HIP_TRY(hipSetDevice(E->ordinal[d]), GGML_STATUS_FAILED);
-        if (d != E->main_dev) {
-            HIP_TRY(hipStreamWaitEvent(w->stream, E->ev_in, 0), GGML_STATUS_FAILED);
-            for (const ip_input & in : P->inputs) {
-                const ip_mirror & m = E->mirrors[(size_t) in.mirror];
-                if (E->ordinal[d] == c->device) HIP_TRY(hipMemcpyAsync(m.base[d] + in.off, m.host_base + in.off, in.bytes, hipMemcpyDeviceToDevice, w->stream), GGML_STATUS_FAILED);
-                else HIP_TRY(hipMemcpyPeerAsync(m.base[d] + in.off, E->ordinal[d], m.host_base + in.off, c->device, in.bytes, w->stream), GGML_STATUS_FAILED);
-                E->input_copies++;
-            }
+    E->input_copies += (int64_t) P->inputs.size() * (E->n_dev - 1);
+    E->turn = 0;
+    if (E->threaded) {
+        for (int d = 0; d < E->n_dev; ++d) {
+            if (d == E->main_dev) continue;
+            ip_worker * W = E->workers[d];
+            std::lock_guard<std::mutex> lk(W->m);
+            W->job = P;
+            W->cv.notify_all();
         }
-        // replayed graphs with cross-device waits: on unless GGML_MI355X_SPLIT_GRAPHS=0 (the kernels' spins are bounded: a device that does not show
-        // up costs a failed llama_decode, not a hang)
-        static const bool graphs_ok = !getenv("GGML_MI355X_SPLIT_GRAPHS") || atoi(getenv("GGML_MI355X_SPLIT_GRAPHS")) != 0;
-        const bool graphs_was = w->opt.graphs;
-        w->opt.graphs = graphs_was && graphs_ok;
-        E->running = true;  // (the main device's context re-enters graph_compute with ITS graph: not a graph for the engine)
-        st = graph_compute(w, &P->graph[d]);
-        E->running = false;
-        w->opt.graphs = graphs_was;
-        if (st != GGML_STATUS_SUCCESS) break;
-        if (d == E->main_dev) HIP_TRY(hipEventRecord(E->ev_done[d], w->stream), GGML_STATUS_FAILED);  // "the main device is through with its graph"
+    }
+    E->running = true;  // (the main device's context re-enters graph_compute with ITS graph: not a graph for the engine)
+    st = submit_device(E, P, E->main_dev);
+    E->running = false;
+    if (st == GGML_STATUS_SUCCESS) HIP_TRY(hipEventRecord(E->ev_done[E->main_dev], c->stream), GGML_STATUS_FAILED);  // "the main device is through with its graph"
+    for (int d = 0; d < E->n_dev; ++d) {
+        if (d == E->main_dev) continue;
+        if (E->threaded) {
+            ip_worker * W = E->workers[d];
+            std::unique_lock<std::mutex> lk(W->m);
+            W->cv.wait(lk, [&] { return W->job == nullptr; });
+            if (W->result != GGML_STATUS_SUCCESS) st = W->result;
+        } else if (st == GGML_STATUS_SUCCESS) {
+            st = submit_device(E, P, d);
+        }
     }
     // Every device's rows of a sharded result go straight into the host's tensor on the main device — but only once the MAIN device's graph has
     // ended: the host's allocator gave that tensor a block its graph may use for intermediates until the last node (a device that finishes first

@@ -141,7 +141,8 @@ def model_main():
         replays = be.stat("graph_launches") - g0
         ip = {k: int(be.stat(k) - v) for k, v in ip0.items()}
         ip["devices"] = int(be.stat("ip_devices"))
-        ip["p2p_timeouts"] = int(be.stat("p2p_timeouts"))
+        ip["p2p_timeouts"] = int(be.stat("p2p_timeouts")) + int(be.stat("ip_worker_p2p_timeouts"))
+        ip["timeouts_by_device"] = [int(be.stat(f"ip_dbg_timeouts_{d}")) for d in range(int(be.stat("ip_devices")))]
         # the host reads a cache tensor back (a slot save): the shards come home — compare K of layer 0 with the one-device run's below
         def cache_bytes(ctx_model, ctx):
             t = H.llm_context_cache_tensor(ctx.c, 0, 0)
@@ -166,7 +167,9 @@ def model_main():
         out["cases"].append({"model": name, "ftype": ftype, "ts": ts, "n_layer": int(hp.n_layer), "reductions_per_graph": [int(r) for r in reds], "graph_replays": int(replays),
                              "nmse_vs_oracle": float(T.nmse(r_s, r_c)), "nmse_one_device_vs_oracle": float(T.nmse(r_g, r_c)), "nmse_vs_one_device": float(T.nmse(r_s, r_g)),
                              "argmax_equal_one_device": bool(np.array_equal(np.argmax(r_s, 1), np.argmax(r_g, 1))), "ip": ip,
-                             "nmse_rows_vs_one_device": [float(T.nmse(r_s[i], r_g[i])) for i in range(len(r_s))]})
+                             "nmse_rows_vs_one_device": [float(T.nmse(r_s[i], r_g[i])) for i in range(len(r_s))],
+                             "nmse_row0_by_vocab_eighth": [float(T.nmse(x, y)) for x, y in zip(np.array_split(r_s[0], 8), np.array_split(r_g[0], 8))],
+                             "nmse_row1_by_vocab_eighth": [float(T.nmse(x, y)) for x, y in zip(np.array_split(r_s[1], 8), np.array_split(r_g[1], 8))]})
         for o in (cs, cg, cc, ms, mg, mc):
             o.free()
     print("SPLIT_JSON " + json.dumps(out))

@@ -552,6 +552,9 @@ def test_bench_two_ranks_dry_run_on_one_gpu(plog):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["BENCH_ALLOW_SHARED_GPU"] = "1"
+    # (the in-process leg — one process driving both devices — needs two LOGICAL devices on the one GPU, whose streams must not share a hardware queue)
+    env["GGML_MI355X_FAKE_DEVICES"] = "2"
+    env["GPU_MAX_HW_QUEUES"] = "8"
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--prefill", "64", "--layers", "2", "--no-cpu-baseline",
                         "--pmc-traffic", "0", "--timing-steps", "0", "--replica-leg", "0"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
@@ -565,6 +568,11 @@ def test_bench_two_ranks_dry_run_on_one_gpu(plog):
     assert out["config"]["parallelism"].startswith("tp2") and "P2P" in out["config"]["parallelism"], out["config"]["parallelism"]
     assert out["scaling"] == "strong" and out["tp_stats"]["p2p_timeouts"] == 0 and out["tp_stats"]["allreduces"] >= 2 * 2 * 6, out["tp_stats"]
     assert out["tensor_split_legs"]["eager_ms_per_step"] > 0
+    # round 5: the same decode with ONE process driving the two (logical) devices through "ggml_backend_split_buffer_type" — what llama-box reaches
+    ip = out["in_process_tensor_split"]
+    plog(f"[bench --gpus 2, one GPU shared] in-process leg: {ip}")
+    assert ip and "error" not in ip and ip["value"] > 0 and ip["devices"] == 2 and ip["graphs_declined"] == 0 and ip["p2p_timeouts"] == 0, ip
+    assert ip["allreduces_per_step"] == 2 * 2, ip
 
 
 _SOFT_FAIL_WORKER = r'''
