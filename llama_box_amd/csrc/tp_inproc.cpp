@@ -95,6 +95,7 @@ struct ip_worker {
     std::mutex m;
     std::condition_variable cv;
     ip_plan * job = nullptr;  // set by the main thread, cleared by the worker when the submission is done
+    std::atomic<uint64_t> prepared{0};  // the engine epoch whose wait + input copies this device has issued
     bool quit = false;
     enum ggml_status result = GGML_STATUS_SUCCESS;
 };
@@ -114,10 +115,10 @@ struct ip_engine {
     std::list<ip_plan> plans;
     ip_plan * last = nullptr;
     hipEvent_t ev_in = nullptr, ev_done[MAXD] = {nullptr};
-    // "the inputs are on the main device": recorded on a stream of its own behind the main stream — the other devices' streams wait for it while the
-    // main stream may already be CAPTURING its graph, and HIP refuses a wait on an event of a capturing stream from outside the capture (error 905)
-    hipStream_t fence = nullptr;
-    hipEvent_t ev_fence = nullptr;
+    // "the inputs are on the main device" (ev_in) is an event of the main stream: every other device's stream must have been told to wait for it
+    // BEFORE the main stream starts capturing its graph — HIP refuses a wait on an event of a capturing stream from outside the capture (error 905) —
+    // so the main thread holds its own graph back until all devices have issued their waits and input copies (`prepared` below)
+    uint64_t epoch = 0;
     uint64_t tick = 0;
     options opt_seen;
     bool dead = false;
@@ -178,8 +179,7 @@ static ip_engine * engine_new(backend_ctx * c, int n_dev, int main_dev) {
         // the workers start from the main backend's options (a host that switched graphs or fusion off means all of it)
         if (ok && d != main_dev) E->ctx[d]->opt = c->opt;
     }
-    ok = ok && hipSetDevice(c->device) == hipSuccess && hipEventCreateWithFlags(&E->ev_in, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&E->ev_fence, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&E->fence, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipSetDevice(c->device) == hipSuccess && hipEventCreateWithFlags(&E->ev_in, hipEventDisableTiming) == hipSuccess;
     (void) hipSetDevice(c->device);
     if (!ok) {
         (void) hipGetLastError();
@@ -241,8 +241,6 @@ void ip_free(backend_ctx * c) {
     }
     (void) hipSetDevice(c->device);
     if (E->ev_in) (void) hipEventDestroy(E->ev_in);
-    if (E->ev_fence) (void) hipEventDestroy(E->ev_fence);
-    if (E->fence) (void) hipStreamDestroy(E->fence);
     (void) hipGetLastError();
     delete E;
     c->ip = nullptr;
@@ -884,34 +882,38 @@ static bool ensure_stage(ip_engine * E, size_t need) {
     return true;
 }
 
-// device d's part of a step, up to and including its graph (called with no assumption about the current device; leaves device d current)
-static enum ggml_status submit_device(ip_engine * E, ip_plan * P, int d) {
-    backend_ctx * c = E->main;
+// device d's part of a step, first half: its stream waits for the inputs and copies them over (leaves device d current)
+static enum ggml_status prepare_device(ip_engine * E, ip_plan * P, int d) {
     backend_ctx * w = E->ctx[d];
     HIP_TRY(hipSetDevice(E->ordinal[d]), GGML_STATUS_FAILED);
-    if (d != E->main_dev) {
-        HIP_TRY(hipStreamWaitEvent(w->stream, E->ev_in, 0), GGML_STATUS_FAILED);
-        for (const ip_input & in : P->inputs) {
-            const ip_mirror & m = E->mirrors[(size_t) in.mirror];
-            if (E->ordinal[d] == c->device) HIP_TRY(hipMemcpyAsync(m.base[d] + in.off, m.host_base + in.off, in.bytes, hipMemcpyDeviceToDevice, w->stream), GGML_STATUS_FAILED);
-            else HIP_TRY(hipMemcpyPeerAsync(m.base[d] + in.off, E->ordinal[d], m.host_base + in.off, c->device, in.bytes, w->stream), GGML_STATUS_FAILED);
-        }
+    if (d == E->main_dev) return GGML_STATUS_SUCCESS;
+    HIP_TRY(hipStreamWaitEvent(w->stream, E->ev_in, 0), GGML_STATUS_FAILED);
+    for (const ip_input & in : P->inputs) {
+        const ip_mirror & m = E->mirrors[(size_t) in.mirror];
+        // a copy KERNEL of this device reading the main device's memory over peer access: an ordinary launch of this stream, behind the event wait
+        // above by construction (an asynchronous device-to-device memcpy may take a DMA engine with an ordering of its own)
+        launch_copy2d(w->stream, m.base[d] + in.off, in.bytes, m.host_base + in.off, in.bytes, in.bytes, 1);
     }
+    return hipGetLastError() == hipSuccess ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+}
+// ... second half: its graph
+static enum ggml_status launch_device(ip_engine * E, ip_plan * P, int d) {
+    backend_ctx * w = E->ctx[d];
+    HIP_TRY(hipSetDevice(E->ordinal[d]), GGML_STATUS_FAILED);
     // replayed graphs with cross-device waits: on unless GGML_MI355X_SPLIT_GRAPHS=0 (the kernels' spins are bounded: a device that does not show
     // up costs a failed llama_decode, not a hang)
     static const bool graphs_ok = !getenv("GGML_MI355X_SPLIT_GRAPHS") || atoi(getenv("GGML_MI355X_SPLIT_GRAPHS")) != 0;
     const bool graphs_was = w->opt.graphs;
     w->opt.graphs = graphs_was && graphs_ok;
-    // debugging aid: GGML_MI355X_DBG_SUBMIT_ORDER=asc | desc — the devices' graphs are submitted one after the other in that order of device index
+    // debugging aid: GGML_MI355X_DBG_SUBMIT_ORDER=asc | desc | mdesc — the devices' graphs are submitted one after the other in that order
     static const char * dbg_order = getenv("GGML_MI355X_DBG_SUBMIT_ORDER");
-    if (dbg_order) {
-        // asc: 0, 1, 2, ...; desc: n-1, ..., 0; mdesc: the main device first, then the others descending
+    if (dbg_order && E->threaded) {
         const int my = dbg_order[0] == 'd' ? E->n_dev - 1 - d : (dbg_order[0] == 'm' ? (d == E->main_dev ? 0 : E->n_dev - d) : d);
         std::unique_lock<std::mutex> lk(E->turn_m);
         E->turn_cv.wait(lk, [&] { return E->turn == my; });
     }
     const enum ggml_status st = graph_compute(w, &P->graph[d]);
-    if (dbg_order) {
+    if (dbg_order && E->threaded) {
         std::lock_guard<std::mutex> lk(E->turn_m);
         E->turn++;
         E->turn_cv.notify_all();
@@ -927,7 +929,9 @@ static void worker_main(ip_engine * E, int d) {
         if (W->quit) return;
         ip_plan * P = W->job;
         lk.unlock();
-        const enum ggml_status st = submit_device(E, P, d);
+        enum ggml_status st = prepare_device(E, P, d);
+        W->prepared.store(E->epoch, std::memory_order_release);  // (the main thread starts its own graph — possibly a capture — only after this)
+        if (st == GGML_STATUS_SUCCESS) st = launch_device(E, P, d);
         lk.lock();
         W->result = st;
         W->job = nullptr;
@@ -965,10 +969,9 @@ static enum ggml_status run_plan(ip_engine * E, ip_plan * P, const ggml_cgraph *
     }
     // the inputs exist on the main stream from here on
     HIP_TRY(hipSetDevice(c->device), GGML_STATUS_FAILED);
-    HIP_TRY(hipEventRecord(E->ev_fence, c->stream), GGML_STATUS_FAILED);
-    HIP_TRY(hipStreamWaitEvent(E->fence, E->ev_fence, 0), GGML_STATUS_FAILED);
-    HIP_TRY(hipEventRecord(E->ev_in, E->fence), GGML_STATUS_FAILED);
+    HIP_TRY(hipEventRecord(E->ev_in, c->stream), GGML_STATUS_FAILED);
     enum ggml_status st = GGML_STATUS_SUCCESS;
+    E->epoch++;
     E->input_copies += (int64_t) P->inputs.size() * (E->n_dev - 1);
     E->turn = 0;
     if (E->threaded) {
@@ -980,9 +983,20 @@ static enum ggml_status run_plan(ip_engine * E, ip_plan * P, const ggml_cgraph *
             W->cv.notify_all();
         }
     }
-    E->running = true;  // (the main device's context re-enters graph_compute with ITS graph: not a graph for the engine)
-    st = submit_device(E, P, E->main_dev);
-    E->running = false;
+    // every device's stream is told to wait for the inputs before the main stream may start a capture
+    for (int d = 0; d < E->n_dev; ++d) {
+        if (d == E->main_dev) continue;
+        if (E->threaded) {
+            while (E->workers[d]->prepared.load(std::memory_order_acquire) != E->epoch) std::this_thread::yield();
+        } else if (st == GGML_STATUS_SUCCESS) {
+            st = prepare_device(E, P, d);
+        }
+    }
+    if (st == GGML_STATUS_SUCCESS) {
+        E->running = true;  // (the main device's context re-enters graph_compute with ITS graph: not a graph for the engine)
+        st = launch_device(E, P, E->main_dev);
+        E->running = false;
+    }
     if (st == GGML_STATUS_SUCCESS) HIP_TRY(hipEventRecord(E->ev_done[E->main_dev], c->stream), GGML_STATUS_FAILED);  // "the main device is through with its graph"
     for (int d = 0; d < E->n_dev; ++d) {
         if (d == E->main_dev) continue;
@@ -992,7 +1006,7 @@ static enum ggml_status run_plan(ip_engine * E, ip_plan * P, const ggml_cgraph *
             W->cv.wait(lk, [&] { return W->job == nullptr; });
             if (W->result != GGML_STATUS_SUCCESS) st = W->result;
         } else if (st == GGML_STATUS_SUCCESS) {
-            st = submit_device(E, P, d);
+            st = launch_device(E, P, d);
         }
     }
     // Every device's rows of a sharded result go straight into the host's tensor on the main device — but only once the MAIN device's graph has

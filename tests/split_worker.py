@@ -169,7 +169,9 @@ def model_main():
                              "argmax_equal_one_device": bool(np.array_equal(np.argmax(r_s, 1), np.argmax(r_g, 1))), "ip": ip,
                              "nmse_rows_vs_one_device": [float(T.nmse(r_s[i], r_g[i])) for i in range(len(r_s))],
                              "nmse_row0_by_vocab_eighth": [float(T.nmse(x, y)) for x, y in zip(np.array_split(r_s[0], 8), np.array_split(r_g[0], 8))],
-                             "nmse_row1_by_vocab_eighth": [float(T.nmse(x, y)) for x, y in zip(np.array_split(r_s[1], 8), np.array_split(r_g[1], 8))]})
+                             "nmse_row1_by_vocab_eighth": [float(T.nmse(x, y)) for x, y in zip(np.array_split(r_s[1], 8), np.array_split(r_g[1], 8))],
+                             "row0_absmean_by_vocab_eighth": [float(np.mean(np.abs(x))) for x in np.array_split(r_s[0], 8)],
+                             "row0_zero_fraction_by_vocab_eighth": [float(np.mean(x == 0)) for x in np.array_split(r_s[0], 8)]})
         for o in (cs, cg, cc, ms, mg, mc):
             o.free()
     print("SPLIT_JSON " + json.dumps(out))
