@@ -54,6 +54,7 @@ ggml_backend_reg_t ggml_backend_mi355x_reg(void);
  *   "ggml_backend_mi355x_tp_p2p_export"   ggml_backend_mi355x_tp_p2p_export_t
  *   "ggml_backend_mi355x_tp_p2p_attach"   ggml_backend_mi355x_tp_p2p_attach_t
  *   "ggml_backend_mi355x_tp_all_reduce"   ggml_backend_mi355x_tp_all_reduce_t
+ *   "ggml_backend_mi355x_graph_key_probe" ggml_backend_mi355x_graph_key_probe_t   (tests: is graph b the graph a captured hipGraph of a stands for?)
  */
 
 /* Replaces: ggml_backend_cuda_split_buffer_type(int main_device, const float * tensor_split) of the stock GPU backends, as reached
@@ -83,12 +84,21 @@ typedef int (*ggml_backend_mi355x_tp_all_reduce_t)(ggml_backend_t backend, float
 typedef int (*ggml_backend_mi355x_tp_get_unique_id_t)(void * unique_id_out, size_t unique_id_size);
 typedef ggml_backend_buffer_type_t (*ggml_backend_mi355x_tp_rowpar_buffer_type_t)(int device);
 
-/* Runtime options (string key/value); 0 = accepted, -1 = unknown key.  Keys (INTEGRATION.md 4b lists the defaults and the
+/* The graph key (csrc/graph.cpp: walk_key) of `a`, built, then compared IN PLACE with graph `b` exactly as graph_compute compares the graph of a
+ * llama_decode with the one it replayed last: 1 = same captured hipGraph serves both, 0 = not.  *n_words (may be NULL) = 8-byte words of the key.
+ * Host arithmetic: works without a device. */
+typedef int (*ggml_backend_mi355x_graph_key_probe_t)(const struct ggml_cgraph * a, const struct ggml_cgraph * b, int64_t * n_words);
+
+/* Runtime options (string key/value); 0 = accepted, -1 = unknown key, -2 = refused (e.g. "tp_p2p" = 0 in a group whose only transport the mailboxes are).  Keys (INTEGRATION.md 4b lists the defaults and the
  * environment variables that set the same things): "graphs", "fusion", "prologue", "qkv", "mm_merge", "mmq_i8", "mmq_bn",
- * "mmq_skinny", "skinny_rope", "softmax_mm", "attn_nf", "mmq_min_cols", "mmvq_max_cols", "fa_splits", "fa_wo", "fa_self_merge", "small_uploads", "timing". */
+ * "mmq_skinny", "skinny_rope", "softmax_mm", "attn_nf", "mmq_min_cols", "mmvq_max_cols", "fa_splits", "fa_wo", "fa_self_merge", "small_uploads", "small_downloads",
+ * "timing", "tp_p2p", "tp_p2p_reset" (forget an all-reduce time-out: every rank, all idle), "clear_failure" (forget a remembered HIP failure of a status-less entry point). */
 typedef int (*ggml_backend_mi355x_set_option_t)(ggml_backend_t backend, const char * key, const char * value);
-/* Counters for tests/bench: "graph_launches", "graph_captures", "eager_graphs", "kernel_launches", "fused_nodes", "allreduces",
- * "graph_launch_host_ns", "skinny_launches", "wide_launches", "rope_epilogues". */
+/* Counters for tests/bench: "graph_launches", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs", "kernel_launches", "fused_nodes",
+ * "allreduces", "p2p_allreduces", "p2p_timeouts", "graph_launch_host_ns", "graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits", "graph_key_collisions",
+ * "kernel_downloads", "skinny_launches", "wide_launches", "tiled_launches", "rope_epilogues", "fa_list_launches"; in-process tensor parallel (-sm row, csrc/tp_inproc.cpp):
+ * "ip_devices", "ip_graphs", "ip_declined", "ip_plans", "ip_input_copies", "ip_output_copies", "ip_kv_gathers", "ip_kv_scatters", "ip_worker_kernel_launches",
+ * "ip_worker_graph_launches", "ip_worker_p2p_timeouts". */
 typedef int64_t (*ggml_backend_mi355x_get_stat_t)(ggml_backend_t backend, const char * key);
 /* Timing helper for bench.py (option "timing"="1": graphs off, every kernel class bracketed by hipEvents on the
  * backend's own stream — torch.cuda.Event cannot see that stream).  Writes lines "class count total_ms bytes". */

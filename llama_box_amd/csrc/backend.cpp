@@ -717,6 +717,14 @@ static ggml_backend_buffer_type_t api_tp_rowpar_buft(int device) {
     if (device < 0 || device >= (int) g_reg_ctx.devices.size()) return nullptr;
     return &dctx(g_reg_ctx.devices[device])->buft_rowpar;
 }
+// the graph key of `a` compared in place with graph `b` (what decides "replay the captured hipGraph"): 1 equal, 0 different; *n_words = key length.
+// Host arithmetic only — tests reach it without a device.
+static int api_graph_key_probe(const ggml_cgraph * a, const ggml_cgraph * b, int64_t * n_words) {
+    std::vector<uint64_t> key;
+    graph_key_build(a, key);
+    if (n_words) *n_words = (int64_t) key.size();
+    return graph_key_equals(b, key) ? 1 : 0;
+}
 static int api_set_option(ggml_backend_t be, const char * key, const char * value) {
     if (!be_is_ours(be)) return -1;
     backend_ctx * c = (backend_ctx *) be->context;
@@ -828,6 +836,7 @@ static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (n == "ggml_backend_mi355x_timing_report") return (void *) api_timing_report;
     if (n == "ggml_backend_split_buffer_type") return (void *) api_split_buffer_type;  // -sm row (split.cpp)
     if (n == "ggml_backend_mi355x_split_rows") return (void *) api_split_rows;
+    if (n == "ggml_backend_mi355x_graph_key_probe") return (void *) api_graph_key_probe;
     return nullptr;
 }
 static const ggml_backend_reg_i k_reg_iface = {reg_get_name, reg_get_device_count, reg_get_device, reg_get_proc_address};

@@ -375,3 +375,57 @@ def test_bench_gpus_n_starts_n_ranks_itself_and_fails_without_gpus():
     assert r.returncode != 0, r.stdout[-500:]
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln], r.stdout[-500:]
     assert "refusing to run" in r.stderr  # came from the ranks torch.distributed.run started, not from the parent
+
+
+def test_graph_key_decides_what_a_captured_graph_stands_for():
+    """graph.cpp: a captured hipGraph is replayed for a graph whose KEY — per node {type, op, ne, nb, op_params, flags, buffer, data, which sources,
+    mask-content hint}, per source {type, buffer, ne, nb, data} — equals the one it was captured for; since round 5 the key of the graph replayed
+    last is compared in place (no hash: a collision cannot replay another graph, and no 240 KB byte-serial FNV before every step).  Host arithmetic,
+    probed through the registration's proc address without a device: a rebuilt identical graph matches; one more node, another op parameter, another
+    shape, another data address or another source do not."""
+    import ctypes as C
+
+    import numpy as np
+
+    import llama_box_amd as L
+
+    H = L.host()
+    lib = C.CDLL(L.BACKEND_SO)
+    lib.ggml_backend_mi355x_reg.restype = C.c_void_p
+    reg = lib.ggml_backend_mi355x_reg()
+    addr = H.ggml_backend_reg_get_proc_address(reg, b"ggml_backend_mi355x_graph_key_probe")
+    assert addr
+    probe = C.CFUNCTYPE(C.c_int, C.POINTER(L.CGraph), C.POINTER(L.CGraph), C.POINTER(C.c_int64))(addr)
+    keep = []
+
+    def build(scale=0.5, rows=8, extra=False, swap=False, shift=0):
+        ctx = H.ggml_init(L.InitParams(0, None, True))
+        keep.append(ctx)
+        x = H.ggml_new_tensor_4d(ctx, L.F32, 64, rows, 1, 1)
+        y = H.ggml_new_tensor_4d(ctx, L.F32, 64, rows, 1, 1)
+        w = H.ggml_new_tensor_4d(ctx, L.F32, 64, 1, 1, 1)
+        # (addresses are part of the key: the tensors get fixed fake ones — nothing is computed here)
+        for i, t in enumerate((x, y, w)):
+            t.contents.data = 0x10000 + 0x4000 * i + shift
+        a = H.ggml_add(ctx, x, y if not swap else x)
+        b = H.ggml_mul(ctx, H.ggml_rms_norm(ctx, a, 1e-5), w)
+        c = H.ggml_scale(ctx, b, scale)
+        if extra:
+            c = H.ggml_scale(ctx, c, 2.0)
+        gf = H.ggml_new_graph_custom(ctx, 64, False)
+        H.ggml_build_forward_expand(gf, c)
+        for i in range(gf.contents.n_nodes):
+            gf.contents.nodes[i].contents.data = 0x80000 + 0x4000 * i
+        return gf
+
+    n_words = C.c_int64(0)
+    g0 = build()
+    assert probe(g0, build(), C.byref(n_words)) == 1 and n_words.value > 0          # the same step, rebuilt by the host
+    assert n_words.value == 1 + 4 * 20 + 6 * 11                                       # 4 nodes x 20 words + 6 sources x 11 words + the node count
+    assert probe(g0, build(extra=True), None) == 0                                    # one more node
+    assert probe(g0, build(scale=0.25), None) == 0                                    # another op parameter
+    assert probe(g0, build(rows=16), None) == 0                                       # another shape (a grown batch / cache view)
+    assert probe(g0, build(shift=256), None) == 0                                     # another input address (the allocator moved a tensor)
+    assert probe(g0, build(swap=True), None) == 0                                     # another source tensor in one slot
+    for ctx in keep:
+        H.ggml_free(ctx)
