@@ -217,6 +217,7 @@ void launch_argmax(hipStream_t s, const tdesc & src, const tdesc & dst);
 void launch_upload_multi(hipStream_t s, const upload_batch & b);  // up to 8 pinned-host -> device copies in one launch
 void launch_upload_small(hipStream_t s, void * dst, const void * pinned_src, size_t n);
 void launch_copy2d(hipStream_t s, void * dst, size_t dpitch, const void * src, size_t spitch, size_t width, size_t height);  // either side may be peer memory
+void launch_rebase_row_index(hipStream_t s, int64_t * dst, const int64_t * src, int64_t n_tok, int64_t full, int64_t ext, int64_t o0, int64_t n_ctx);  // tp_inproc.cpp: transposed V cache
 // dst[i] = (add ? add[i] : 0) + part[0][i] + part[1][i] + ... in device order (the partial products of a row-parallel mat-mul; the parts may
 // live in peer devices' memory: read over xGMI by the main device's kernel)
 struct reduce_parts { const float * part[GGML_MI355X_MAX_DEVICES]; int n; };

@@ -926,6 +926,21 @@ void launch_copy2d(hipStream_t s, void * dst, size_t dpitch, const void * src, s
     }
 }
 
+// in-process tensor parallel, non-flash graphs: the host's per-element row indices of the transposed V cache (v_idxs[i * full + j] = j * n_ctx + slot_i)
+// cut down to one device's rows [o0, o0 + ext) of every token and rebased onto its shard of the cache: dst[i * ext + j'] = src[i * full + o0 + j'] - o0 * n_ctx
+__global__ void __launch_bounds__(256) k_rebase_row_index(int64_t * __restrict__ dst, const int64_t * __restrict__ src, const int64_t n_tok, const int64_t full, const int64_t ext,
+                                                         const int64_t o0, const int64_t n_ctx) {
+    const int64_t e = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_tok * ext) return;
+    const int64_t i = e / ext, j = e - i * ext;
+    dst[e] = src[i * full + o0 + j] - o0 * n_ctx;
+}
+void launch_rebase_row_index(hipStream_t s, int64_t * dst, const int64_t * src, int64_t n_tok, int64_t full, int64_t ext, int64_t o0, int64_t n_ctx) {
+    const int64_t n = n_tok * ext;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rebase_row_index, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, dst, src, n_tok, full, ext, o0, n_ctx);
+}
+
 MI_TU_TOUCH(ops)
 
 }  // namespace mi355x

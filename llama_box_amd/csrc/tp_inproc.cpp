@@ -22,8 +22,11 @@
 //   * per graph (not per layer) the inputs the host uploaded to the main device are copied to the other devices, and the vocab shards of the
 //     logits are written into the main device's result tensor.
 //
-// What it declines (the caller then runs the graph as before, split.cpp): graphs without flash attention (the transposed V cache is indexed per
-// element by a host-computed index tensor), shard boundaries that cut a head, a device without a share, ops outside the rules below.
+//   * graphs WITHOUT flash attention (llama-box's default, engine_param.hpp:772-779) store V transposed, one element per host-computed row index: the
+//     transposed cache is sharded by rows, and every device gets its own cut-down copy of the index tensor rebased onto its shard (k_rebase_row_index, once
+//     per graph); K.q, SOFT_MAX and V^T.p are batches over the heads a device owns.
+//
+// What it declines (the caller then runs the graph as before, split.cpp): shard boundaries that cut a head, a device without a share, ops outside the rules below.
 // GGML_MI355X_SPLIT_TP=0 switches the engine off.  On ONE physical GPU (GGML_MI355X_FAKE_DEVICES) the devices' streams must not share a hardware
 // queue — a device's all-reduce polls for its peers' contributions — so the tests run with GPU_MAX_HW_QUEUES >= the number of logical devices.
 #include <algorithm>
@@ -60,8 +63,10 @@ struct ip_mirror {  // a buffer of the host (compute buffer, KV cache buffer) an
     bool kv = false;                // holds sharded cache tensors: every device (the main one too) works on a shadow
     int state = 0;                  // kv: 0 host memory and shadows agree, 1 the shadows are newer, 2 the host's memory is newer
 };
-struct ip_kv_tensor {  // a cache tensor [ne0, rows] of the host, sharded along ne0
+struct ip_kv_tensor {  // a cache tensor of the host: [ne0, rows] sharded along ne0 (K, V: a device's heads of every cell), or — the TRANSPOSED V cache of graphs
+                       // without flash attention, [n_ctx, n_embd_kv] — sharded along dimension 1 (dim == 1: a device's rows are one contiguous block)
     char * host_ptr = nullptr;
+    int dim = 0;
     int type = 0;
     int64_t ne0 = 0, rows = 0;
     size_t host_row_bytes = 0;
@@ -76,9 +81,20 @@ struct ip_output {                                    // a sharded result the ho
     int64_t off[MAXD + 1];
     size_t stage_off;  // where every device's shard sits in its staging area
 };
+// graphs without flash attention store V transposed, one ELEMENT per row index: v_idxs[i * full + j] = j * n_ctx + slot_i (a host-computed input).  A device
+// stores its rows [off[d], off[d + 1]) of every token into its shard of the cache through its own copy of that tensor, cut down and rebased (k_rebase_row_index)
+struct ip_rebase {
+    int mirror;        // where the host's index tensor lives
+    size_t moff;
+    int64_t n_tok, full, n_ctx;
+    int64_t off[MAXD + 1];
+    size_t stage_off;  // the device's tensor in its staging area
+    std::vector<ggml_tensor *> clones[MAXD];
+};
 struct ip_plan {
     std::vector<uint64_t> key;
     bool declined = false;
+    std::vector<ip_rebase> rebases;
     std::deque<ggml_tensor> store[MAXD];
     std::vector<ggml_tensor *> nodes[MAXD];
     ggml_cgraph graph[MAXD];
@@ -346,6 +362,14 @@ static bool kv_move(ip_engine * E, int mi, bool to_host) {
             if (t.mirror != mi || !ok) continue;
             const int64_t ext = t.off[d + 1] - t.off[d];
             if (ext <= 0) continue;
+            if (t.dim == 1) {  // rows [off[d], off[d + 1]) of the transposed cache: one contiguous block on either side
+                char * hostb = t.host_ptr + (size_t) t.off[d] * t.host_row_bytes;
+                char * shardb = m.base[d] + (t.host_ptr - m.host_base);
+                const size_t nb = (size_t) ext * t.host_row_bytes;
+                if (to_host) launch_copy2d(s, hostb, nb, shardb, nb, nb, 1);
+                else launch_copy2d(s, shardb, nb, hostb, nb, nb, 1);
+                continue;
+            }
             char * host = t.host_ptr + type_row_bytes(t.type, t.off[d]);
             char * shard = m.base[d] + (t.host_ptr - m.host_base);
             const size_t w = type_row_bytes(t.type, ext);
@@ -444,6 +468,8 @@ struct analysis {
     int n;
     std::unordered_map<const ggml_tensor *, sdesc> d;
     std::unordered_map<const ggml_tensor *, int> node_index;
+    struct vidx_t { int64_t n_tok, full, n_ctx; int64_t off[MAXD + 1]; };
+    std::unordered_map<const ggml_tensor *, vidx_t> vidx;  // per-element row-index inputs of the transposed V cache (see ip_rebase)
     const char * why = "";
     const ggml_tensor * where = nullptr;
     bool fail(const char * w, const ggml_tensor * t) { why = w; where = t; return false; }
@@ -467,7 +493,7 @@ static bool leaf_desc(analysis & A, const ggml_tensor * t, sdesc & o) {
     for (const ip_kv_tensor & k : A.E->kv)  // a cache tensor sharded by an earlier graph stays sharded the same way
         if (k.host_ptr == (char *) t->data && t->view_src == nullptr) {
             o.kind = 1;
-            o.dim = 0;
+            o.dim = k.dim;
             for (int i = 0; i <= A.n; ++i) o.off[i] = k.off[i];
             return true;
         }
@@ -535,6 +561,16 @@ static bool analyse_node(analysis & A, const ggml_tensor * t) {
                 A.d[t] = o;
                 return true;
             }
+            if (a.kind == 1 && b.kind == 1 && a.dim == 2 && b.dim == 2) {
+                // graphs without flash attention: K.q and V^T.p — a batch of mat-muls over the head dimension, both operands sharded by heads
+                for (int i = 0; i <= A.n; ++i)
+                    if (b.off[i] * s0->ne[2] != a.off[i] * s1->ne[2]) return A.fail("query heads and KV heads are cut at different places", t);
+                o.kind = 1;
+                o.dim = 2;
+                for (int i = 0; i <= A.n; ++i) o.off[i] = b.off[i];
+                A.d[t] = o;
+                return true;
+            }
             if (a.kind != 0 || b.kind != 0) return A.fail("a mat-mul of sharded operands that is not a split weight's", t);
             A.d[t] = sdesc();
             return true;
@@ -566,7 +602,15 @@ static bool analyse_node(analysis & A, const ggml_tensor * t) {
         case GGML_OP_RESHAPE: {
             if (!get_desc(A, s0, a)) return false;
             if (a.kind == 0) { A.d[t] = sdesc(); return true; }
-            if (!reshape_shard(s0, a, t, o, A.n)) return A.fail("a reshape that does not keep the shard in one dimension", t);
+            if (!reshape_shard(s0, a, t, o, A.n)) {
+                // [head_dim, n_head_kv, n_tokens] -> [1, n_tokens * n_embd_kv] (the source rows of the transposed V store): in the HOST's order a device's
+                // elements are strided, in the device's own packed tensor they are simply all of it — a share of the rows, consumed only by SET_ROWS below
+                if (!(t->ne[0] == 1 && t->ne[2] == 1 && t->ne[3] == 1 && ggml_abi_nelements(t) % s0->ne[a.dim] == 0)) return A.fail("a reshape that does not keep the shard in one dimension", t);
+                const int64_t per = ggml_abi_nelements(t) / s0->ne[a.dim];
+                o.kind = 1;
+                o.dim = 1;
+                for (int i = 0; i <= A.n; ++i) o.off[i] = a.off[i] * per;
+            }
             A.d[t] = o;
             return true;
         }
@@ -598,6 +642,17 @@ static bool analyse_node(analysis & A, const ggml_tensor * t) {
                 A.d[t] = o;
                 return true;
             }
+            // ... on the TRANSPOSED V cache [n_ctx, n_embd_kv] (no flash attention): [n_kv, head_dim, n_head_kv], rows of the cache per dimension 1, one head of rows per step of dimension 2
+            if (s0->op == GGML_OP_NONE && a.dim == 1 && t->view_offs == 0 && t->nb[1] == s0->nb[1] && t->ne[1] * t->ne[2] == s0->ne[1] && t->nb[2] == t->nb[1] * (size_t) t->ne[1] && t->ne[3] == 1) {
+                o.kind = 1;
+                o.dim = 2;
+                for (int i = 0; i <= A.n; ++i) {
+                    if (a.off[i] % t->ne[1] != 0) return A.fail("a cache shard boundary inside a head", t);
+                    o.off[i] = a.off[i] / t->ne[1];
+                }
+                A.d[t] = o;
+                return true;
+            }
             return A.fail("a view of a sharded tensor that is not the attention's cache window", t);
         }
         case GGML_OP_ROPE: {
@@ -618,6 +673,28 @@ static bool analyse_node(analysis & A, const ggml_tensor * t) {
             if (a.kind == 0) {
                 if (cd.kind != 0) return A.fail("replicated rows into a sharded cache", t);
                 A.d[t] = sdesc();
+                return true;
+            }
+            if (t->ne[0] == 1 && a.dim == 1 && s0->ne[0] == 1 && dst->ne[2] == 1 && dst->ne[3] == 1 && s1->op == GGML_OP_NONE && s1->type == GGML_TYPE_I64 && ggml_abi_is_contiguous(s1) &&
+                ggml_abi_nelements(s1) == s0->ne[1] && s0->ne[1] % dst->ne[1] == 0) {
+                // the transposed V cache [n_ctx, n_embd_kv], one element per row index: a device's rows of the cache are its share of every token's values
+                const int64_t n_tok = s0->ne[1] / dst->ne[1];
+                sdesc leaf;
+                leaf.kind = 1;
+                leaf.dim = 1;
+                for (int i = 0; i <= A.n; ++i) {
+                    if (a.off[i] % n_tok != 0) return A.fail("the transposed V store's share is not whole rows per token", t);
+                    leaf.off[i] = a.off[i] / n_tok;
+                }
+                if (cd.kind == 1 && (cd.dim != 1 || !same_off(cd, leaf, A.n))) return A.fail("a cache tensor sharded differently by another graph", t);
+                analysis::vidx_t v{n_tok, dst->ne[1], dst->ne[0], {0}};
+                for (int i = 0; i <= A.n; ++i) v.off[i] = leaf.off[i];
+                A.vidx[s1] = v;
+                A.d[dst] = leaf;
+                o.kind = 1;
+                o.dim = 1;
+                for (int i = 0; i <= A.n; ++i) o.off[i] = leaf.off[i] * dst->ne[0];
+                A.d[t] = o;
                 return true;
             }
             if (a.dim != 0 || dst->ne[0] != s0->ne[0] || dst->ne[2] != 1 || dst->ne[3] != 1) return A.fail("rows sharded along another dimension than the cache row", t);
@@ -645,8 +722,23 @@ static bool analyse_node(analysis & A, const ggml_tensor * t) {
             A.d[t] = o;
             return true;
         }
-        case GGML_OP_GET_ROWS: case GGML_OP_RMS_NORM: case GGML_OP_SCALE: case GGML_OP_UNARY: case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT:
-        case GGML_OP_SOFT_MAX: case GGML_OP_ARGMAX:
+        case GGML_OP_SOFT_MAX: {
+            if (!get_desc(A, s0, a)) return false;
+            if (a.kind == 0) return all_replicated();
+            if (a.dim == 0) return A.fail("a soft-max across a shard boundary", t);
+            if (s1 && (!get_desc(A, s1, b) || b.kind != 0)) return A.fail("a sharded mask", t);
+            if (t->src[2]) { sdesc sk; if (!get_desc(A, t->src[2], sk) || sk.kind != 0) return A.fail("sharded sinks", t); }
+            A.d[t] = a;
+            return true;
+        }
+        case GGML_OP_CONT: {
+            if (!get_desc(A, s0, a)) return false;
+            if (a.kind == 0) return all_replicated();
+            if (!reshape_shard(s0, a, t, o, A.n)) return A.fail("a copy that does not keep the shard in one dimension", t);  // (cont_2d of the permuted attention result)
+            A.d[t] = o;
+            return true;
+        }
+        case GGML_OP_GET_ROWS: case GGML_OP_RMS_NORM: case GGML_OP_SCALE: case GGML_OP_UNARY: case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_ARGMAX:
             return all_replicated();
         default:
             return A.fail("an op the engine has no rule for", t);
@@ -660,6 +752,7 @@ struct rewriter {
     analysis * A;
     int dev;
     std::unordered_map<const ggml_tensor *, ggml_tensor *> done;
+    std::unordered_map<const ggml_tensor *, ggml_tensor *> vidx_done;  // this device's cut-down copies of per-element row-index inputs (ip_rebase)
     bool ok = true;
 };
 static void contiguous_strides(ggml_tensor * c) {
@@ -704,9 +797,9 @@ static ggml_tensor * clone_leaf(rewriter & R, const ggml_tensor * t) {
         c->data = info->slice[d];
         return c;
     }
-    if (sd.kind == 1) {  // a cache tensor: this device's heads of every cell, in the shadow of the host's cache buffer
+    if (sd.kind == 1) {  // a cache tensor: this device's heads of every cell (or its rows of the transposed V cache), in the shadow of the host's cache buffer
         const int64_t ext = sd.off[d + 1] - sd.off[d];
-        c->ne[0] = ext;
+        c->ne[sd.dim] = ext;
         contiguous_strides(c);
         c->data = mirror_addr(R, t, true);
         return c;
@@ -751,7 +844,7 @@ static ggml_tensor * clone_of(rewriter & R, const ggml_tensor * t) {
             c->data = c->src[0]->data;
             break;
         case GGML_OP_VIEW:
-            if (sd.kind == 1) {  // the attention's window on the sharded cache: this device's heads, the shard's row stride
+            if (sd.kind == 1) {  // the attention's window on the sharded cache: this device's heads, the shard's row stride (the transposed cache keeps n_ctx-long rows)
                 c->ne[2] = ext;
                 c->nb[1] = c->src[0]->nb[1];
                 c->nb[3] = c->nb[2] * (size_t) c->ne[2];
@@ -759,7 +852,24 @@ static ggml_tensor * clone_of(rewriter & R, const ggml_tensor * t) {
             c->data = (char *) (c->view_src ? c->view_src->data : c->src[0]->data) + t->view_offs;
             break;
         case GGML_OP_SET_ROWS:
-            for (int i = 0; i < 4; ++i) { c->ne[i] = c->view_src->ne[i]; c->nb[i] = c->view_src->nb[i]; }
+            if (t->ne[0] == 1 && sd.kind == 1) {  // the transposed V cache seen as rows of ONE element each: this device's [n_ctx, rows] block of it, flat
+                c->ne[1] = ext;
+                contiguous_strides(c);
+                auto vi = R.A->vidx.find(t->src[1]);
+                if (vi != R.A->vidx.end()) {
+                    ggml_tensor *& ix = R.vidx_done[t->src[1]];
+                    if (!ix) {
+                        ix = new_clone(R, t->src[1]);
+                        ix->ne[0] = vi->second.n_tok * (vi->second.off[d + 1] - vi->second.off[d]);
+                        ix->ne[1] = ix->ne[2] = ix->ne[3] = 1;
+                        contiguous_strides(ix);
+                        ix->data = nullptr;  // (its place in the staging area is set before every run)
+                    }
+                    c->src[1] = ix;
+                }
+            } else {
+                for (int i = 0; i < 4; ++i) { c->ne[i] = c->view_src->ne[i]; c->nb[i] = c->view_src->nb[i]; }
+            }
             c->data = c->view_src->data;
             break;
         default:
@@ -783,7 +893,10 @@ static ip_plan * build_plan(ip_engine * E, const ggml_cgraph * g) {
     ip_plan * P = &E->plans.back();
     graph_key_build(g, P->key);
     E->plans_built++;
-    analysis A{E, g, E->n_dev, {}, {}, "", nullptr};
+    analysis A;
+    A.E = E;
+    A.g = g;
+    A.n = E->n_dev;
     bool any_split = false;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * t = g->nodes[i];
@@ -806,6 +919,7 @@ static ip_plan * build_plan(ip_engine * E, const ggml_cgraph * g) {
         if (mi < 0) { P->declined = true; return P; }
         ip_kv_tensor k;
         k.host_ptr = (char *) t->data;
+        k.dim = kv.second.dim;
         k.type = t->type;
         k.ne0 = t->ne[0];
         k.rows = t->ne[1];
@@ -816,12 +930,40 @@ static ip_plan * build_plan(ip_engine * E, const ggml_cgraph * g) {
         if (E->mirrors[(size_t) mi].kv && E->mirrors[(size_t) mi].state == 0) E->mirrors[(size_t) mi].state = 2;  // (a tensor joins a live shadow: its rows come from the host's copy)
     }
     for (int d = 0; d < E->n_dev; ++d) {
-        rewriter R{E, P, &A, d, {}, true};
+        rewriter R;
+        R.E = E;
+        R.P = P;
+        R.A = &A;
+        R.dev = d;
         for (int i = 0; i < g->n_nodes && R.ok; ++i) P->nodes[d].push_back(clone_of(R, g->nodes[i]));
         if (!R.ok) {
             MI_ERR("in-process tensor parallel: building device %d's graph failed (memory for a mirror or a replica?)", E->ordinal[d]);
             P->declined = true;
             return P;
+        }
+        for (auto & vd : R.vidx_done) {  // this device's cut-down index tensors: one rebase per distinct host tensor
+            const analysis::vidx_t & v = A.vidx[vd.first];
+            ip_rebase * rb = nullptr;
+            const int mi = mirror_of(E, root_buffer(vd.first));
+            if (mi < 0) { P->declined = true; return P; }
+            const size_t moff = (size_t) ((char *) vd.first->data - E->mirrors[(size_t) mi].host_base);
+            for (ip_rebase & x : P->rebases)
+                if (x.mirror == mi && x.moff == moff) rb = &x;
+            if (!rb) {
+                P->rebases.emplace_back();
+                rb = &P->rebases.back();
+                rb->mirror = mi;
+                rb->moff = moff;
+                rb->n_tok = v.n_tok;
+                rb->full = v.full;
+                rb->n_ctx = v.n_ctx;
+                for (int k = 0; k <= E->n_dev; ++k) rb->off[k] = v.off[k];
+                int64_t widest = 0;
+                for (int k = 0; k < E->n_dev; ++k) widest = std::max(widest, v.off[k + 1] - v.off[k]);
+                rb->stage_off = P->stage_bytes;
+                P->stage_bytes += ((size_t) (v.n_tok * widest) * 8 + 255) & ~(size_t) 255;
+            }
+            rb->clones[d].push_back(vd.second);
         }
         ggml_cgraph & cg = P->graph[d];
         memset(&cg, 0, sizeof(cg));
@@ -886,13 +1028,19 @@ static bool ensure_stage(ip_engine * E, size_t need) {
 static enum ggml_status prepare_device(ip_engine * E, ip_plan * P, int d) {
     backend_ctx * w = E->ctx[d];
     HIP_TRY(hipSetDevice(E->ordinal[d]), GGML_STATUS_FAILED);
-    if (d == E->main_dev) return GGML_STATUS_SUCCESS;
-    HIP_TRY(hipStreamWaitEvent(w->stream, E->ev_in, 0), GGML_STATUS_FAILED);
-    for (const ip_input & in : P->inputs) {
-        const ip_mirror & m = E->mirrors[(size_t) in.mirror];
-        // a copy KERNEL of this device reading the main device's memory over peer access: an ordinary launch of this stream, behind the event wait
-        // above by construction (an asynchronous device-to-device memcpy may take a DMA engine with an ordering of its own)
-        launch_copy2d(w->stream, m.base[d] + in.off, in.bytes, m.host_base + in.off, in.bytes, in.bytes, 1);
+    if (d != E->main_dev) {
+        HIP_TRY(hipStreamWaitEvent(w->stream, E->ev_in, 0), GGML_STATUS_FAILED);
+        for (const ip_input & in : P->inputs) {
+            const ip_mirror & m = E->mirrors[(size_t) in.mirror];
+            // a copy KERNEL of this device reading the main device's memory over peer access: an ordinary launch of this stream, behind the event wait
+            // above by construction (an asynchronous device-to-device memcpy may take a DMA engine with an ordering of its own)
+            launch_copy2d(w->stream, m.base[d] + in.off, in.bytes, m.host_base + in.off, in.bytes, in.bytes, 1);
+        }
+    }
+    // graphs without flash attention: this device's share of the host's per-element V row indices, rebased onto its shard of the transposed cache
+    for (const ip_rebase & rb : P->rebases) {
+        const ip_mirror & m = E->mirrors[(size_t) rb.mirror];
+        launch_rebase_row_index(w->stream, (int64_t *) (E->stage[d] + rb.stage_off), (const int64_t *) (m.base[d] + rb.moff), rb.n_tok, rb.full, rb.off[d + 1] - rb.off[d], rb.off[d], rb.n_ctx);
     }
     return hipGetLastError() == hipSuccess ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
 }
@@ -957,6 +1105,9 @@ static enum ggml_status run_plan(ip_engine * E, ip_plan * P, const ggml_cgraph *
     (void) g;
     for (const ip_output & o : P->outputs)
         for (int d = 0; d < E->n_dev; ++d) P->nodes[d][(size_t) o.node]->data = E->stage[d] + o.stage_off;
+    for (const ip_rebase & rb : P->rebases)
+        for (int d = 0; d < E->n_dev; ++d)
+            for (ggml_tensor * ix : rb.clones[d]) ix->data = E->stage[d] + rb.stage_off;
     // the host's cache tensors were written behind the engine's back (or never sharded yet): hand every device its heads
     for (size_t mi = 0; mi < E->mirrors.size(); ++mi) {
         ip_mirror & m = E->mirrors[mi];
@@ -992,6 +1143,7 @@ static enum ggml_status run_plan(ip_engine * E, ip_plan * P, const ggml_cgraph *
             st = prepare_device(E, P, d);
         }
     }
+    if (st == GGML_STATUS_SUCCESS) st = prepare_device(E, P, E->main_dev);
     if (st == GGML_STATUS_SUCCESS) {
         E->running = true;  // (the main device's context re-enters graph_compute with ITS graph: not a graph for the engine)
         st = launch_device(E, P, E->main_dev);

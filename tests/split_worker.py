@@ -116,9 +116,10 @@ def model_main():
         ms = Model(hp, 77, be.buft, split_buft=buft)
         mg = Model(hp, 77, be.buft)
         mc = Model(hp, 77, H.ggml_backend_cpu_buffer_type())
-        cs = Context(ms, backend=be, flash_attn=1)
-        cg = Context(mg, backend=be, flash_attn=1)
-        cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=1)
+        fa = int(os.environ.get("SPLIT_FA", "1"))  # 0: llama-box's default attention path (K.q -> SOFT_MAX -> V^T.p over a transposed V cache)
+        cs = Context(ms, backend=be, flash_attn=fa)
+        cg = Context(mg, backend=be, flash_attn=fa)
+        cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=fa)
 
         def run(ctx, count=False):
             rows, reds = [], []
@@ -145,7 +146,7 @@ def model_main():
         ip["timeouts_by_device"] = [int(be.stat(f"ip_dbg_timeouts_{d}")) for d in range(int(be.stat("ip_devices")))]
         # the host reads a cache tensor back (a slot save): the shards come home — compare K of layer 0 with the one-device run's below
         def cache_bytes(ctx_model, ctx):
-            t = H.llm_context_cache_tensor(ctx.c, 0, 0)
+            t = H.llm_context_cache_tensor(ctx.c, 0, 0 if fa else 1)  # (without flash attention: the TRANSPOSED V cache, sharded by rows)
             n = H.ggml_nbytes(t)
             raw = np.empty(n, np.uint8)
             H.ggml_backend_tensor_get(t, raw.ctypes.data_as(C.c_void_p), 0, n)
@@ -158,7 +159,7 @@ def model_main():
         # (another mat-mul tiling over the narrower shards may sum in another order: an ulp in f32, now and then an f16 rounding of a cached value)
         ip["cache_nmse_vs_one_device"] = float(T.nmse(k_split.view(np.float16).astype(np.float64), k_one.view(np.float16).astype(np.float64)))
         # ... and decoding goes on after the host looked (and after it WROTE: the same bytes back — the shards are re-scattered)
-        H.ggml_backend_tensor_set(H.llm_context_cache_tensor(cs.c, 0, 0), k_split.ctypes.data_as(C.c_void_p), 0, k_split.nbytes)
+        H.ggml_backend_tensor_set(H.llm_context_cache_tensor(cs.c, 0, 0 if fa else 1), k_split.ctypes.data_as(C.c_void_p), 0, k_split.nbytes)
         rc_a, la = cs.decode([21], [len(prompt) + 6])
         rc_b, lb = cg.decode([21], [len(prompt) + 6])
         ip["nmse_after_host_write_vs_one_device"] = float(T.nmse(la[0], lb[0])) if rc_a == 0 and rc_b == 0 else -1.0

@@ -42,12 +42,14 @@ def test_row_split_buffer_type_on_four_logical_devices(plog):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("graphs", ["0", "1"])
-def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs):
+@pytest.mark.parametrize("graphs,fa", [("0", "1"), ("1", "1"), ("1", "0")])
+def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs, fa):
     """-sm row as a tensor-parallel layout (llama-box/engine_param.hpp:821-842, :902-916): attn_output / ffn_down cut along K,
     the FFN sharded end to end, TWO in-stream reductions per layer.  graphs = 1: the multi-stream step captured and replayed as a hipGraph."""
     # (GPU_MAX_HW_QUEUES: the logical devices' streams must not share a hardware queue of the one GPU — a device's all-reduce polls for its peers)
-    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="2", GGML_MI355X_SPLIT_GRAPHS=graphs, GPU_MAX_HW_QUEUES="8")
+    # fa = 0: llama-box's DEFAULT attention path (engine_param.hpp:772-779) — K.q -> SOFT_MAX -> V^T.p over a transposed V cache that the host indexes per element:
+    # the engine shards that cache by rows and gives every device its own cut-down, rebased copy of the index tensor
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="2", GGML_MI355X_SPLIT_GRAPHS=graphs, GPU_MAX_HW_QUEUES="8", SPLIT_FA=fa)
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py"), "model"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1][len("SPLIT_JSON "):])
@@ -62,7 +64,7 @@ def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs):
         if graphs == "1":
             assert c["graph_replays"] >= 3, "the decode steps of the split model were not replayed as hipGraphs"
         ip = c["ip"]
-        plog(f"[split-tp] graphs={graphs} {c['model']} ftype={c['ftype']} ts={c['ts']}: in-process tensor parallel {ip}")
+        plog(f"[split-tp] graphs={graphs} fa={fa} {c['model']} ftype={c['ftype']} ts={c['ts']}: in-process tensor parallel {ip}")
         assert ip["p2p_timeouts"] == 0, ip
         if c["ts"][0] == c["ts"][1] and c["model"] == "test-llama-tp":
             # an even split of a model whose heads divide: ALL seven graphs run as tensor parallelism over the two devices (round 5) — attention and the
@@ -77,11 +79,12 @@ def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs):
 
 
 @pytest.mark.gpu
-def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog):
+@pytest.mark.parametrize("fa", ["1", "0"])
+def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog, fa):
     """BASELINE config 4 (Llama-3-70B Q4_K_M, --tensor-split 1,1,1,1,1,1,1,1; llama-box/engine_param.hpp:821-842, :902-916) at its REAL per-device
     shard shapes, through "ggml_backend_split_buffer_type" on eight logical devices of the one GPU: two layers of the 70B layer shape, prompt
     batch + decode steps; reductions == 2 x n_layer per graph, logits against the CPU oracle and against the same model on one device."""
-    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="8", GGML_MI355X_SPLIT_GRAPHS=os.environ.get("TEST_70B_SPLIT_GRAPHS", "1"), GPU_MAX_HW_QUEUES="16")
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="8", GGML_MI355X_SPLIT_GRAPHS=os.environ.get("TEST_70B_SPLIT_GRAPHS", "1"), GPU_MAX_HW_QUEUES="16", SPLIT_FA=fa)
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py"), "model", "70b"], capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1][len("SPLIT_JSON "):])
@@ -96,7 +99,7 @@ def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog):
     # heads each, reductions == 2 x n_layer on the one-shot all-reduce, and NO gather / broadcast per layer: per graph the inputs go out (<= 6
     # tensors x 7 devices) and the vocab shards come back (8), whatever the number of layers
     ip = c["ip"]
-    plog(f"[split-tp 70b shards] in-process tensor parallel: {ip}; graph replays {c['graph_replays']}")
+    plog(f"[split-tp 70b shards] fa={fa} in-process tensor parallel: {ip}; graph replays {c['graph_replays']}")
     assert ip["devices"] == 8 and ip["ip_graphs"] == 7 and ip["ip_declined"] == 0 and ip["p2p_timeouts"] == 0, ip
     assert ip["ip_input_copies"] <= 7 * 6 * 7 and ip["ip_output_copies"] == 7 * 8, ip
     assert ip["kv_gathers_after_get_tensor"] == 1 and ip["cache_nmse_vs_one_device"] <= 1e-6, ip  # (gathered from eight devices' shards into the host's tensor)
