@@ -202,12 +202,12 @@ static ip_engine * engine_new(backend_ctx * c, int n_dev, int main_dev) {
         MI_ERR("in-process tensor parallel: set-up over %d devices failed; -sm row graphs run node by node on the main device (split.cpp)", n_dev);
         E->dead = true;
     }
-    // OPT-IN (GGML_MI355X_SPLIT_THREADS=1).  On eight LOGICAL devices of one GPU, submitting the devices' graphs concurrently — or one after the other
-    // in DESCENDING device order from these threads (GGML_MI355X_DBG_SUBMIT_ORDER) — gives wrong results for the first graph on some boxes (the device
-    // that submits first ends with a zero logits shard; no all-reduce time-out is raised), while the ascending order of the one-thread form is
-    // bit-stable over every run (profiles/r05_inproc_tp_submit_order.txt).  The cause was not found in this round; whether it is an artefact of eight
-    // streams on one GPU's queues or a real ordering assumption can only be settled on a multi-GPU box, so the default stays the form that is verified.
-    static const bool threads_on = getenv("GGML_MI355X_SPLIT_THREADS") && atoi(getenv("GGML_MI355X_SPLIT_THREADS")) != 0;
+    // One launcher thread per device (GGML_MI355X_SPLIT_THREADS=0: the main thread submits the devices one after the other, ascending).  Until late in
+    // round 5 this was opt-in: with the threads — or with any order in which a device other than the main one submits first — the first graph came out wrong
+    // on most boxes.  The cause was replica_of(): non-split weights were copied with a device-to-device hipMemcpy, which returns before the copy has run,
+    // and the early device read half-copied norm weights.  Same box, same binary, five alternating runs each: the copy as it was 8 of 10 wrong, the
+    // stream-ordered copy 10 of 10 equal to the one-device logits (profiles/r05_inproc_tp_submit_order.txt).
+    static const bool threads_on = !(getenv("GGML_MI355X_SPLIT_THREADS") && atoi(getenv("GGML_MI355X_SPLIT_THREADS")) == 0);
     if (ok && threads_on) {
         for (int d = 0; d < n_dev; ++d) {
             if (d == main_dev) continue;
@@ -217,7 +217,6 @@ static ip_engine * engine_new(backend_ctx * c, int n_dev, int main_dev) {
         E->threaded = true;
     }
     E->opt_seen = c->opt;
-    // (the split-graph capture gate of graph.cpp: replayed graphs with cross-device waits are opt-in until they have run on real multi-GPU hardware)
     std::lock_guard<std::mutex> lk(g_ip_mtx);
     g_engines.push_back(E);
     return E;
@@ -343,9 +342,15 @@ static void * replica_of(ip_engine * E, int d, const ggml_tensor * t) {
     const size_t n = ggml_abi_nbytes(t);
     void * p = nullptr;
     if (hipSetDevice(E->ordinal[d]) != hipSuccess || hipMalloc(&p, n + 256) != hipSuccess) { (void) hipGetLastError(); (void) hipSetDevice(E->main->device); return nullptr; }
-    hipError_t e = E->ordinal[d] == E->main->device ? hipMemcpy(p, t->data, n, hipMemcpyDeviceToDevice) : hipMemcpyPeer(p, E->ordinal[d], t->data, E->main->device, n);
+    // ON THE DEVICE'S OWN STREAM: a device-to-device hipMemcpy returns before the copy has run (it goes to the null stream, which the devices' non-blocking
+    // streams do not wait for) — a device that got going before the others read half-copied norm weights and embeddings in its first graph (the open question
+    // of profiles/r05_inproc_tp_submit_order.txt, answered late in round 5).  The main device's memory is read over peer access by a copy kernel.
+    static const bool dbg_null_stream = getenv("GGML_MI355X_DBG_REPLICA_MEMCPY") != nullptr;  // (the A/B of the evidence file: the copy as it was)
+    if (dbg_null_stream) (void) hipMemcpyPeer(p, E->ordinal[d], t->data, E->main->device, n);
+    else launch_copy2d(E->ctx[d]->stream, p, n, t->data, n, n, 1);
+    const hipError_t e = hipGetLastError();
     (void) hipSetDevice(E->main->device);
-    if (e != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    if (e != hipSuccess) return nullptr;
     E->replicas[d][t->data] = p;
     E->replica_bytes += (int64_t) n;
     return p;

@@ -105,7 +105,7 @@ def model_main():
         # BASELINE config 4 at its real shard shapes: Llama-3-70B's layer (8192 / 28672, 64 heads on 8 KV heads, Q4_K_M type
         # map with Q5_K attn_v) cut to two layers, --tensor-split 1,1,1,1,1,1,1,1 over eight logical devices: every device holds 1024 / 128 /
         # 128 rows of wq / wk / wv, the 1024-value K slice of attn_output, 3584 rows of gate / up and the 3584-value K slice of ffn_down
-        cases = (("llama3-70b-q4_k_m", 1, [1.0] * int(os.environ.get("GGML_MI355X_FAKE_DEVICES", "8")), 2),)
+        cases = (("llama3-70b-q4_k_m", 1, [1.0] * int(os.environ.get("GGML_MI355X_FAKE_DEVICES", "8")), int(os.environ.get("SPLIT_LAYERS", "2"))),)
     for name, ftype, ts, n_layer in cases:
         hp = preset(name)
         if n_layer:
@@ -173,6 +173,17 @@ def model_main():
                              "nmse_row1_by_vocab_eighth": [float(T.nmse(x, y)) for x, y in zip(np.array_split(r_s[1], 8), np.array_split(r_g[1], 8))],
                              "row0_absmean_by_vocab_eighth": [float(np.mean(np.abs(x))) for x in np.array_split(r_s[0], 8)],
                              "row0_zero_fraction_by_vocab_eighth": [float(np.mean(x == 0)) for x in np.array_split(r_s[0], 8)]})
+        if os.environ.get("SPLIT_TIME"):  # host view of a step: every decode reads its logits back (the sampler's synchronisation)
+            import time
+            for tag, ctx in (("split", cs), ("one_device", cg)):
+                p0 = len(prompt) + 7
+                for i in range(8):
+                    ctx.decode([31 + i], [p0 + i])
+                h0, t0 = be.stat("graph_compute_host_ns"), time.perf_counter()
+                n_t = int(os.environ["SPLIT_TIME"])
+                for i in range(n_t):
+                    ctx.decode([41 + i], [p0 + 8 + i])
+                out["cases"][-1][f"timed_{tag}"] = {"ms_per_step": (time.perf_counter() - t0) / n_t * 1e3, "graph_compute_host_us_per_step": (be.stat("graph_compute_host_ns") - h0) / n_t / 1e3}
         for o in (cs, cg, cc, ms, mg, mc):
             o.free()
     print("SPLIT_JSON " + json.dumps(out))

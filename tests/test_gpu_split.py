@@ -79,12 +79,18 @@ def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs, fa):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fa", ["1", "0"])
-def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog, fa):
+@pytest.mark.parametrize("fa,threads,order", [("1", "1", ""), ("0", "1", ""), ("1", "0", ""), ("1", "1", "desc")])
+def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog, fa, threads, order):
     """BASELINE config 4 (Llama-3-70B Q4_K_M, --tensor-split 1,1,1,1,1,1,1,1; llama-box/engine_param.hpp:821-842, :902-916) at its REAL per-device
     shard shapes, through "ggml_backend_split_buffer_type" on eight logical devices of the one GPU: two layers of the 70B layer shape, prompt
-    batch + decode steps; reductions == 2 x n_layer per graph, logits against the CPU oracle and against the same model on one device."""
-    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="8", GGML_MI355X_SPLIT_GRAPHS=os.environ.get("TEST_70B_SPLIT_GRAPHS", "1"), GPU_MAX_HW_QUEUES="16", SPLIT_FA=fa)
+    batch + decode steps; reductions == 2 x n_layer per graph, logits against the CPU oracle and against the same model on one device.
+    threads = 1: one launcher thread per device (the default); 0: the main thread submits the devices in ascending order.  order = desc: the launcher
+    threads pass a turnstile so that device 7 submits FIRST, eagerly — the order that exposed half-copied weight replicas (profiles/r05_inproc_tp_submit_order.txt):
+    a device must not depend on the main device having started before it."""
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="8", GGML_MI355X_SPLIT_GRAPHS=os.environ.get("TEST_70B_SPLIT_GRAPHS", "0" if order else "1"), GPU_MAX_HW_QUEUES="16", SPLIT_FA=fa,
+               GGML_MI355X_SPLIT_THREADS=threads)
+    if order:
+        env["GGML_MI355X_DBG_SUBMIT_ORDER"] = order
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py"), "model", "70b"], capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1][len("SPLIT_JSON "):])
@@ -99,7 +105,7 @@ def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog, fa):
     # heads each, reductions == 2 x n_layer on the one-shot all-reduce, and NO gather / broadcast per layer: per graph the inputs go out (<= 6
     # tensors x 7 devices) and the vocab shards come back (8), whatever the number of layers
     ip = c["ip"]
-    plog(f"[split-tp 70b shards] fa={fa} in-process tensor parallel: {ip}; graph replays {c['graph_replays']}")
+    plog(f"[split-tp 70b shards] fa={fa} threads={threads} order={order or 'free'} in-process tensor parallel: {ip}; graph replays {c['graph_replays']}")
     assert ip["devices"] == 8 and ip["ip_graphs"] == 7 and ip["ip_declined"] == 0 and ip["p2p_timeouts"] == 0, ip
     assert ip["ip_input_copies"] <= 7 * 6 * 7 and ip["ip_output_copies"] == 7 * 8, ip
     assert ip["kv_gathers_after_get_tensor"] == 1 and ip["cache_nmse_vs_one_device"] <= 1e-6, ip  # (gathered from eight devices' shards into the host's tensor)
