@@ -146,8 +146,8 @@ def main():
     n_dev = torch.cuda.device_count()
     if n_dev < 1 or (world > n_dev and os.environ.get("BENCH_ALLOW_SHARED_GPU") != "1"):
         # one rank per GPU or nothing (BENCH_ALLOW_SHARED_GPU=1: the dry run of the multi-rank path on a one-GPU box, tests/test_gpu_model.py)
-        if rank == 0:
-            print(f"bench.py: {world} rank(s) but {n_dev} GPU(s) visible: refusing to run", file=sys.stderr)
+        # (every rank says so: the launcher tears the others down as soon as the first one exits, and that one need not be rank 0)
+        print(f"bench.py[rank {rank}]: {world} rank(s) but {n_dev} GPU(s) visible: refusing to run", file=sys.stderr, flush=True)
         sys.exit(3)
     shared_gpu = world > n_dev
     local_rank %= n_dev
