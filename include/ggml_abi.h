@@ -443,6 +443,13 @@ typedef ggml_backend_buffer_type_t (*ggml_backend_split_buffer_type_t)(int main_
 
 #pragma pack(push, 1)
 typedef struct { ggml_fp16_t d; int8_t qs[QK8_0]; } block_q8_0;                                            /* 34 B */
+/* the legacy 32-value formats a KV cache may be kept in (-ctk / -ctv: llama-box/engine_param.hpp:51-54) and the Q8_1 activation block their dots take */
+typedef struct { ggml_fp16_t d; uint8_t qs[16]; } block_q4_0;                                              /* 18 B */
+typedef struct { ggml_fp16_t d; ggml_fp16_t m; uint8_t qs[16]; } block_q4_1;                               /* 20 B */
+typedef struct { ggml_fp16_t d; uint8_t qh[4]; uint8_t qs[16]; } block_q5_0;                               /* 22 B */
+typedef struct { ggml_fp16_t d; ggml_fp16_t m; uint8_t qh[4]; uint8_t qs[16]; } block_q5_1;                /* 24 B */
+typedef struct { ggml_fp16_t d; ggml_fp16_t s; int8_t qs[32]; } block_q8_1;                                /* 36 B: s = d * sum(qs) */
+typedef struct { ggml_fp16_t d; uint8_t qs[16]; } block_iq4_nl;                                            /* 18 B */
 typedef struct { ggml_fp16_t d; ggml_fp16_t dmin; uint8_t scales[K_SCALE_SIZE]; uint8_t qs[QK_K / 2]; } block_q4_K;   /* 144 B */
 typedef struct { ggml_fp16_t d; ggml_fp16_t dmin; uint8_t scales[K_SCALE_SIZE]; uint8_t qh[QK_K / 8]; uint8_t qs[QK_K / 2]; } block_q5_K; /* 176 B */
 typedef struct { uint8_t ql[QK_K / 2]; uint8_t qh[QK_K / 4]; int8_t scales[QK_K / 16]; ggml_fp16_t d; } block_q6_K;   /* 210 B */
@@ -451,6 +458,7 @@ typedef struct { float d; int8_t qs[QK_K]; int16_t bsums[QK_K / 16]; } block_q8_
 
 #ifdef __cplusplus
 static_assert(sizeof(block_q8_0) == 34, "q8_0");
+static_assert(sizeof(block_q4_0) == 18 && sizeof(block_q4_1) == 20 && sizeof(block_q5_0) == 22 && sizeof(block_q5_1) == 24 && sizeof(block_q8_1) == 36 && sizeof(block_iq4_nl) == 18, "legacy 32-value blocks");
 static_assert(sizeof(block_q4_K) == 144, "q4_K");
 static_assert(sizeof(block_q5_K) == 176, "q5_K");
 static_assert(sizeof(block_q6_K) == 210, "q6_K");
@@ -465,7 +473,7 @@ static_assert(sizeof(struct ggml_tensor) % GGML_MEM_ALIGN == 0, "ggml_tensor ali
 /* ------- small inline helpers every side needs (own implementations, not ggml's code) ------- */
 static inline int64_t ggml_abi_blck_size(enum ggml_type t) {
     switch (t) {
-        case GGML_TYPE_Q8_0: return 32;
+        case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_0: case GGML_TYPE_Q5_1: case GGML_TYPE_Q8_1: case GGML_TYPE_IQ4_NL: return 32;
         case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: case GGML_TYPE_Q6_K: case GGML_TYPE_Q8_K: return 256;
         default: return 1;
     }
@@ -477,6 +485,11 @@ static inline size_t ggml_abi_type_size(enum ggml_type t) {
         case GGML_TYPE_I8: return 1;
         case GGML_TYPE_I64: case GGML_TYPE_F64: return 8;
         case GGML_TYPE_Q8_0: return 34;
+        case GGML_TYPE_Q4_0: case GGML_TYPE_IQ4_NL: return 18;
+        case GGML_TYPE_Q4_1: return 20;
+        case GGML_TYPE_Q5_0: return 22;
+        case GGML_TYPE_Q5_1: return 24;
+        case GGML_TYPE_Q8_1: return 36;
         case GGML_TYPE_Q4_K: return 144;
         case GGML_TYPE_Q5_K: return 176;
         case GGML_TYPE_Q6_K: return 210;

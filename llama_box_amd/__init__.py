@@ -24,8 +24,10 @@ HOST_SO = os.path.join(_DIR, "libmi355x_host.so")
 
 # ggml enums (include/ggml_abi.h)
 F32, F16, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, I32, I64 = 0, 1, 8, 12, 13, 14, 15, 26, 27
-TYPE_BLCK = {F32: 1, F16: 1, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256, I32: 1, I64: 1}
-TYPE_SIZE = {F32: 4, F16: 2, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, I32: 4, I64: 8}
+Q4_0, Q4_1, Q5_0, Q5_1, Q8_1, IQ4_NL, BF16 = 2, 3, 6, 7, 9, 20, 30  # the other types a KV cache may be kept in (-ctk / -ctv) and the Q8_1 activation block
+TYPE_BLCK = {F32: 1, F16: 1, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256, I32: 1, I64: 1, Q4_0: 32, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q8_1: 32, IQ4_NL: 32, BF16: 1}
+TYPE_SIZE = {F32: 4, F16: 2, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, I32: 4, I64: 8, Q4_0: 18, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_1: 36, IQ4_NL: 18, BF16: 2}
+TYPE_NAME = {F32: "f32", F16: "f16", BF16: "bf16", Q8_0: "q8_0", Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", IQ4_NL: "iq4_nl"}
 GGML_MAX_NAME = 128
 ROPE_NEOX = 2
 ROPE_MROPE = 8    # ggml_rope_multi: four position streams over sections of the rotation pairs (Qwen2-VL)

@@ -26,6 +26,42 @@ static bool same_shape(const ggml_tensor * a, const ggml_tensor * b) {
 }
 
 // ------------------------------------------------------------------------------------------------ supports_op
+// which attention path serves this FLASH_ATTN_EXT node: 0 none (the host keeps it on the CPU backend), 1 the f16 kernels on the cache views in place,
+// 2 the lane-parallel kernel on block_q8_0 K / V, 3 the f16 kernels on an f16 IMAGE of whichever of K / V is kept in another type (kv_types.hip:
+// -ctk / -ctv q4_0, q4_1, q5_0, q5_1, iq4_nl, bf16, f32, mixed pairs, and q8_0 shapes route 2 does not take)
+static int fa_route(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0];
+    const ggml_tensor * k = op->src[1];
+    const ggml_tensor * v = op->src[2];
+    const ggml_tensor * m = op->src[3];
+    if (!a || !k || !v || a->type != GGML_TYPE_F32) return 0;
+    if (k->type == GGML_TYPE_Q8_0 && v->type == GGML_TYPE_Q8_0) {
+        // quantised KV cache: served by the lane-parallel kernel (head_dim 128, 2/4/7/8 query heads per KV head, no soft-capping / ALiBi)
+        const int64_t g = k->ne[2] ? a->ne[2] / k->ne[2] : 0;
+        const bool shape = k->ne[0] == 128 && v->ne[0] == 128 && a->nb[0] == 4 && !(a->nb[1] % 16) && !(a->nb[2] % 16) && a->ne[2] % k->ne[2] == 0 && k->ne[2] == v->ne[2] &&
+                           (g == 2 || g == 4 || g == 7 || g == 8) && ggml_abi_op_param_f32(op, 1) == 0.0f && ggml_abi_op_param_f32(op, 2) == 0.0f &&
+                           !(k->nb[1] % 2) && !(v->nb[1] % 2) && !(k->nb[2] % 2) && !(v->nb[2] % 2);
+        if (shape) return (!m || (m->type == GGML_TYPE_F16 && m->ne[2] == 1 && rows_contig(m))) ? 2 : 0;
+    }
+    const bool k16 = k->type == GGML_TYPE_F16, v16 = v->type == GGML_TYPE_F16;
+    if (!(k16 || kv_image_type(k->type)) || !(v16 || kv_image_type(v->type))) return 0;
+    if (k->ne[0] != v->ne[0] || (k->ne[0] != 64 && k->ne[0] != 128)) return 0;
+    if (a->nb[0] != 4) return 0;
+    for (const ggml_tensor * t : {k, v}) {
+        if (t->type == GGML_TYPE_F16) {
+            if (t->nb[0] != 2 || (t->nb[1] % 16) || (t->nb[2] % 16)) return 0;
+        } else {  // read block by block into the image: whole blocks per head row, element-aligned strides, one cache stream
+            const size_t al = t->type == GGML_TYPE_F32 ? 4 : 2;
+            if (t->nb[0] != ggml_abi_type_size(t->type) || (t->nb[1] % al) || (t->nb[2] % al) || t->ne[3] != 1) return 0;
+        }
+    }
+    if (m && (m->type != GGML_TYPE_F16 || m->ne[2] != 1 || !rows_contig(m))) return 0;
+    if (k->ne[2] <= 0 || a->ne[2] % k->ne[2] != 0 || k->ne[2] != v->ne[2]) return 0;
+    const int64_t g = a->ne[2] / k->ne[2];
+    if (k->ne[0] == 64 ? !(g == 1 || g == 2 || g == 4 || g == 8) : !(g == 1 || g == 2 || g == 4 || g == 7 || g == 8)) return 0;
+    return (k16 && v16) ? 1 : 3;
+}
+
 bool supports_op(const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0];
     const ggml_tensor * b = op->src[1];
@@ -68,12 +104,17 @@ bool supports_op(const ggml_tensor * op) {
             if (st == GGML_TYPE_I32 && dt == GGML_TYPE_I32) return true;
             if ((st == GGML_TYPE_Q8_0 && dt == GGML_TYPE_F32) || (st == GGML_TYPE_F32 && dt == GGML_TYPE_Q8_0))  // K-shift of a quantised cache
                 return ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(op) && (a->ne[0] % 32) == 0;
+            if ((kv_store_type(st) && dt == GGML_TYPE_F32) || (st == GGML_TYPE_F32 && kv_store_type(dt)))  // ... of a cache in one of the other types (kv_types.hip)
+                return ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(op) && (a->ne[0] % 32) == 0 && (((uintptr_t) a->data | (uintptr_t) op->data) & 15) == 0;
             return (st == GGML_TYPE_F32 || st == GGML_TYPE_F16) && (dt == GGML_TYPE_F32 || dt == GGML_TYPE_F16);
         }
         case GGML_OP_GET_ROWS:
             return b->type == GGML_TYPE_I32 && op->type == GGML_TYPE_F32 && rows_contig(a) && op->nb[0] == 4 &&
                    (is_quant(a->type) || a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32);
         case GGML_OP_SET_ROWS:
+            if (kv_store_type(op->type))  // a cache row in q4_0 / q4_1 / q5_0 / q5_1 / iq4_nl / bf16: the type's from_float per block of 32 (kv_types.hip)
+                return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_I64 && a->nb[0] == 4 && (a->ne[0] % 32) == 0 && (a->nb[1] % 16) == 0 && (a->nb[2] % 16) == 0 && (a->nb[3] % 16) == 0 &&
+                       op->nb[0] == ggml_abi_type_size(op->type);
             if (op->type == GGML_TYPE_Q8_0) return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_I64 && a->nb[0] == 4 && (a->ne[0] % 32) == 0 && (a->nb[1] % 16) == 0 && (a->nb[2] % 16) == 0 && (a->nb[3] % 16) == 0;
             return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_I64 && a->nb[0] == 4 && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) &&
                    op->nb[0] == ggml_abi_type_size(op->type);
@@ -93,29 +134,8 @@ bool supports_op(const ggml_tensor * op) {
             }
             return (a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16) && a->type == op->type && rows_contig(a) && rows_contig(op) && b->type == GGML_TYPE_I32;
         }
-        case GGML_OP_FLASH_ATTN_EXT: {
-            const ggml_tensor * k = op->src[1];
-            const ggml_tensor * v = op->src[2];
-            const ggml_tensor * m = op->src[3];
-            if (a->type != GGML_TYPE_F32) return false;
-            if (k->type == GGML_TYPE_Q8_0 && v->type == GGML_TYPE_Q8_0) {
-                // quantised KV cache: served by the lane-parallel kernel only (head_dim 128, 2/4/7/8 query heads per KV head, no
-                // soft-capping / ALiBi); anything else stays on the CPU backend
-                const int64_t g = k->ne[2] ? a->ne[2] / k->ne[2] : 0;
-                if (k->ne[0] != 128 || v->ne[0] != 128 || a->nb[0] != 4 || (a->nb[1] % 16) || (a->nb[2] % 16) || a->ne[2] % k->ne[2] != 0 || k->ne[2] != v->ne[2]) return false;
-                if (!(g == 2 || g == 4 || g == 7 || g == 8) || ggml_abi_op_param_f32(op, 1) != 0.0f || ggml_abi_op_param_f32(op, 2) != 0.0f) return false;
-                if ((k->nb[1] % 2) || (v->nb[1] % 2) || (k->nb[2] % 2) || (v->nb[2] % 2)) return false;
-                return !m || (m->type == GGML_TYPE_F16 && m->ne[2] == 1 && rows_contig(m));
-            }
-            if (k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return false;
-            if (k->ne[0] != v->ne[0] || (k->ne[0] != 64 && k->ne[0] != 128)) return false;
-            if (a->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || (k->nb[1] % 16) || (v->nb[1] % 16) || (k->nb[2] % 16) || (v->nb[2] % 16)) return false;
-            if (m && (m->type != GGML_TYPE_F16 || m->ne[2] != 1 || !rows_contig(m))) return false;
-            if (a->ne[2] % k->ne[2] != 0 || k->ne[2] != v->ne[2]) return false;
-            const int64_t g = a->ne[2] / k->ne[2];
-            if (k->ne[0] == 64) return g == 1 || g == 2 || g == 4 || g == 8;
-            return g == 1 || g == 2 || g == 4 || g == 7 || g == 8;
-        }
+        case GGML_OP_FLASH_ATTN_EXT:
+            return fa_route(op) != 0;
         case GGML_OP_ARGMAX:
             return a->type == GGML_TYPE_F32 && a->nb[0] == 4;
         default:
@@ -148,6 +168,7 @@ struct ws_plan {
     size_t aux_bytes = 0;  // region B: attention partials
 };
 
+static size_t fa_image_offset(const tdesc & q, const tdesc & k, const tdesc & v) { return (fattn_workspace_bytes(q, k, v, 64, GGML_TYPE_F16) + 255) & ~(size_t) 255; }
 static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
     ws_plan p;
     for (int i = 0; i < g->n_nodes; ++i) {
@@ -169,6 +190,10 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             const tdesc q = TD(n->src[0]), k = TD(n->src[1]), v = TD(n->src[2]);
             // (both forms a 33+-token batch may take — matrix-core tiles or, for a mask known to be sparse, position lists — fit this)
             const int ns = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : std::max(fattn_pick_splits(q, k), 16));
+            if (fa_route(n) == 3) {  // the f16 images of K / V behind the largest partial-record area the f16 kernels may ask for
+                p.aux_bytes = std::max(p.aux_bytes, fa_image_offset(q, k, v) + (k.type != GGML_TYPE_F16 ? kv_image_bytes(k) : 0) + (v.type != GGML_TYPE_F16 ? kv_image_bytes(v) : 0));
+                continue;
+            }
             p.aux_bytes = std::max(p.aux_bytes, fattn_workspace_bytes(q, k, v, ns, n->src[1]->type));
         }
     }
@@ -1622,6 +1647,9 @@ static int run_node(exec_state & st, int i) {
             } else if (a->type == GGML_TYPE_Q8_0 || n->type == GGML_TYPE_Q8_0) {
                 timed_scope ts(c, "cpy_q8_0", (double) ggml_abi_nbytes(n) + (double) ggml_abi_nbytes(a));
                 launch_cpy_q8_0(s, a->data, n->data, ggml_abi_nelements(a), n->type == GGML_TYPE_Q8_0);
+            } else if (kv_store_type(a->type) || kv_store_type(n->type)) {
+                timed_scope ts(c, "cpy_kv_type", (double) ggml_abi_nbytes(n) + (double) ggml_abi_nbytes(a));
+                launch_cpy_kv(s, kv_store_type(n->type) ? n->type : a->type, a->data, n->data, ggml_abi_nelements(a), kv_store_type(n->type));
             } else {
                 timed_scope ts(c, "cpy", (double) ggml_abi_nbytes(n) * 2);
                 launch_cpy(s, TD(a), TD(n));
@@ -1638,6 +1666,7 @@ static int run_node(exec_state & st, int i) {
         case GGML_OP_SET_ROWS: {
             timed_scope ts(c, "set_rows", (double) ggml_abi_nbytes(a));
             if (n->type == GGML_TYPE_Q8_0) launch_set_rows_q8_0(s, TD(a), TD(b), TD(n));
+            else if (kv_store_type(n->type)) launch_set_rows_kv(s, TD(a), TD(b), TD(n));
             else launch_set_rows(s, TD(a), TD(b), TD(n));
             c->st.kernel_launches++;
             return 1;
@@ -1700,11 +1729,29 @@ static int run_node(exec_state & st, int i) {
             p.scale = ggml_abi_op_param_f32(n, 0);
             p.max_bias = ggml_abi_op_param_f32(n, 1);
             p.logit_softcap = ggml_abi_op_param_f32(n, 2);
-            const tdesc qd = TD(a), kd = TD(k), vd = TD(v);
+            const tdesc qd = TD(a);
+            tdesc kd = TD(k), vd = TD(v);
+            const bool imaged = fa_route(n) == 3;
+            if (imaged) {
+                // K / V kept in another type: expand the views to f16 once (kv_types.hip) and let the f16 kernels read the image
+                char * img = (char *) c->ws + st.aux_off + fa_image_offset(qd, kd, vd);
+                timed_scope ts(c, "kv_image_f16", (double) (ggml_abi_nbytes(k) + ggml_abi_nbytes(v)));
+                if (k->type != GGML_TYPE_F16) {
+                    const size_t kb = kv_image_bytes(kd);
+                    kd = launch_kv_image_f16(s, kd, img);
+                    img += kb;
+                    c->st.kernel_launches++;
+                }
+                if (v->type != GGML_TYPE_F16) {
+                    vd = launch_kv_image_f16(s, vd, img);
+                    c->st.kernel_launches++;
+                }
+                c->st.kv_image_nodes++;
+            }
             const tdesc md0 = m ? TD(m) : qd;
             p.mask_sparse = fa_mask_hint(n);
             p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd, m ? &md0 : nullptr, p.mask_sparse));
-            p.kv_type = k->type;
+            p.kv_type = imaged ? (int) GGML_TYPE_F16 : (int) k->type;
             if (c->opt.fa_self_merge && c->fa_arrive) {
                 p.arrive = c->fa_arrive;
                 p.arrive_slots = backend_ctx::fa_arrive_slots;

@@ -213,6 +213,14 @@ void launch_get_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const 
 void launch_set_rows(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
 void launch_cpy_q8_0(hipStream_t s, const void * src, void * dst, int64_t n_values, bool to_q8);  // contiguous Q8_0 <-> F32 (K-shift of a quantised cache)
 void launch_set_rows_q8_0(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);  // f32 rows -> block_q8_0 rows (quantised KV cache)
+// kv_types.hip: a KV cache in one of the other types of -ctk / -ctv (q4_0, q4_1, q5_0, q5_1, iq4_nl, bf16; f32 for reading)
+bool kv_type_is_block(int type);
+bool kv_store_type(int type);  // SET_ROWS / CPY-from-f32 destination types served there
+bool kv_image_type(int type);  // FLASH_ATTN_EXT reads K / V of this type through an f16 image in scratch memory
+void launch_set_rows_kv(hipStream_t s, const tdesc & src, const tdesc & idx, const tdesc & dst);
+void launch_cpy_kv(hipStream_t s, int type, const void * src, void * dst, int64_t n_values, bool to_type);  // contiguous type <-> F32 (K-shift)
+size_t kv_image_bytes(const tdesc & t);
+tdesc launch_kv_image_f16(hipStream_t s, const tdesc & t, void * image);
 void launch_argmax(hipStream_t s, const tdesc & src, const tdesc & dst);
 void launch_upload_multi(hipStream_t s, const upload_batch & b);  // up to 8 pinned-host -> device copies in one launch
 void launch_upload_small(hipStream_t s, void * dst, const void * pinned_src, size_t n);
@@ -320,7 +328,9 @@ void tu_touch_ops(hipStream_t s);
 void tu_touch_fattn(hipStream_t s);
 void tu_touch_fattn_mma(hipStream_t s);
 void tu_touch_tp_p2p(hipStream_t s);
+void tu_touch_kv_types(hipStream_t s);
 inline void preload_kernel_files(hipStream_t s) {
+    tu_touch_kv_types(s);
     tu_touch_quantize(s);
     tu_touch_mmvq(s);
     tu_touch_qkv(s);

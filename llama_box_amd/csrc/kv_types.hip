@@ -1,0 +1,350 @@
+// kv_types.hip — a KV cache kept in one of the other types llama-box lets the user pick (-ctk / -ctv, llama-box/engine_param.hpp:51-54: f32, f16,
+// bf16, q8_0, q4_0, q4_1, iq4_nl, q5_0, q5_1).  f16 and q8_0 are the fast paths of qkv.hip / fattn.hip; everything here serves the rest so that
+// such a cache stays on the device instead of sending its SET_ROWS / FLASH_ATTN_EXT / K-shift nodes back to the CPU backend:
+//
+//   * SET_ROWS f32 -> type: the destination type's from_float, exactly as ggml's quantize_row_*_ref evaluates it (one f32 rounding per operation,
+//     the FIRST element of largest magnitude sets the sign of the scale, truncating conversions) — byte-identical blocks;
+//   * CPY type <-> f32 on contiguous tensors: the K-shift of such a cache (llama.cpp build_rope_shift: cast to f32 -> rope -> copy back);
+//   * FLASH_ATTN_EXT: the K / V views are expanded to an f16 image in scratch memory once per node (level * d in f32 — exact — then ONE rounding to
+//     f16) and the f16 attention kernels run on the image.  ggml-cpu instead quantises every query row to 8 bits (Q8_0 / Q8_1) and takes integer block
+//     dots: this path keeps the query in f16, which is closer to exact attention than the reference (the tests measure both distances).
+//
+// A block is 32 values; one thread handles one block (a cache row is 32 blocks per 1024 values: launch-bound work, not bandwidth-bound).
+#include "common.h"
+#include "dev_util.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+__device__ static const int8_t k_iq4nl_values[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
+
+__device__ __forceinline__ uint16_t f2bf(const float f) {  // ggml_compute_fp32_to_bf16: nearest even, NaN kept quiet
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t) ((u >> 16) | 64);
+    return (uint16_t) ((u + (0x7fffu + ((u >> 16) & 1u))) >> 16);
+}
+__device__ __forceinline__ void st16(char * p, const uint16_t v) { *(uint16_t *) p = v; }  // (blocks are 2-byte aligned, no more)
+
+__device__ __forceinline__ int iq4nl_best_index(const float x) {  // best_index_int8(16, kvalues_iq4nl, x)
+    if (x <= (float) k_iq4nl_values[0]) return 0;
+    if (x >= (float) k_iq4nl_values[15]) return 15;
+    int ml = 0, mu = 15;
+    while (mu - ml > 1) {
+        const int mav = (ml + mu) / 2;
+        if (x < (float) k_iq4nl_values[mav]) mu = mav;
+        else ml = mav;
+    }
+    return x - (float) k_iq4nl_values[mu - 1] < (float) k_iq4nl_values[mu] - x ? mu - 1 : mu;
+}
+
+// the element of largest magnitude with its sign, the first one on a tie (quantize_row_q4_0_ref: `if (amax < fabsf(v))`)
+__device__ __forceinline__ float signed_extreme(const float (&x)[32]) {
+    float amax = 0.0f, mx = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float v = x[j];
+        if (amax < fabsf(v)) {
+            amax = fabsf(v);
+            mx = v;
+        }
+    }
+    return mx;
+}
+
+// one block of 32 values -> its bytes at `out` (quantize_row_{q4_0,q4_1,q5_0,q5_1,iq4_nl}_ref)
+template <int TYPE> __device__ __forceinline__ void quantize_block(const float (&x)[32], char * out) {
+    if constexpr (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q5_0) {
+        constexpr bool Q5 = TYPE == GGML_TYPE_Q5_0;
+        const float d = signed_extreme(x) / (Q5 ? -16.0f : -8.0f);
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        // (an all-zero block: 0 / -8 = -0.0, stored as 0x8000 by the reference.  The compiler folds the scaling and the conversion into ONE
+        // v_fma_mixlo_f16 with a +0 addend, and (-0) + (+0) = +0 loses the sign — the zero is stored from its own bits)
+        st16(out, d == 0.0f ? (uint16_t) (__float_as_uint(d) >> 16) : f2h(d));
+        uint32_t qh = 0;
+        char * qs = out + (Q5 ? 6 : 2);
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            uint32_t pair = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float x0 = x[j + e] * id, x1 = x[16 + j + e] * id;
+                const int xi0 = min(Q5 ? 31 : 15, (int) (x0 + (Q5 ? 16.5f : 8.5f))), xi1 = min(Q5 ? 31 : 15, (int) (x1 + (Q5 ? 16.5f : 8.5f)));
+                pair |= (uint32_t) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4)) << (8 * e);
+                if (Q5) {
+                    qh |= (uint32_t) ((xi0 & 0x10) >> 4) << (j + e);
+                    qh |= (uint32_t) ((xi1 & 0x10) >> 4) << (j + e + 16);
+                }
+            }
+            st16(qs + j, (uint16_t) pair);
+        }
+        if (Q5) {
+            st16(out + 2, (uint16_t) (qh & 0xFFFF));
+            st16(out + 4, (uint16_t) (qh >> 16));
+        }
+    } else if constexpr (TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1) {
+        constexpr bool Q5 = TYPE == GGML_TYPE_Q5_1;
+        float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (x[j] < mn) mn = x[j];
+            if (x[j] > mx) mx = x[j];
+        }
+        const float d = (mx - mn) / (Q5 ? 31.0f : 15.0f);
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        st16(out, f2h(d));
+        st16(out + 2, f2h(mn));
+        uint32_t qh = 0;
+        char * qs = out + (Q5 ? 8 : 4);
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            uint32_t pair = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float x0 = (x[j + e] - mn) * id, x1 = (x[16 + j + e] - mn) * id;
+                // Q4_1: MIN(15, (int8_t)(x0 + 0.5f)); Q5_1: (uint8_t)(x0 + 0.5f) — x0 lies in [0, levels], so both conversions are the truncation
+                const int xi0 = Q5 ? (int) (x0 + 0.5f) : min(15, (int) (x0 + 0.5f)), xi1 = Q5 ? (int) (x1 + 0.5f) : min(15, (int) (x1 + 0.5f));
+                pair |= (uint32_t) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4)) << (8 * e);
+                if (Q5) {
+                    qh |= (uint32_t) ((xi0 & 0x10) >> 4) << (j + e);
+                    qh |= (uint32_t) ((xi1 & 0x10) >> 4) << (j + e + 16);
+                }
+            }
+            st16(qs + j, (uint16_t) pair);
+        }
+        if (Q5) {
+            st16(out + 4, (uint16_t) (qh & 0xFFFF));
+            st16(out + 6, (uint16_t) (qh >> 16));
+        }
+    } else {  // IQ4_NL: quantize_row_iq4_nl_impl(32, 32, ..., ntry = -1): levels against max / -127, then the least-squares scale under the weights x^2
+        float amax = 0.0f, mx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float ax = fabsf(x[j]);
+            if (ax > amax) {
+                amax = ax;
+                mx = x[j];
+            }
+        }
+        uint32_t lv[4] = {0, 0, 0, 0};  // 32 four-bit levels, element j in nibble j
+        float scale = 0.0f;
+        if (amax >= 1e-15f) {
+            const float d0 = mx / -127.0f;
+            const float id = 1.0f / d0;
+            float sumqx = 0.0f, sumq2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int l = iq4nl_best_index(id * x[j]);
+                lv[j >> 3] |= (uint32_t) l << (4 * (j & 7));
+                const float q = (float) k_iq4nl_values[l], w = x[j] * x[j];
+                sumqx += w * q * x[j];
+                sumq2 += w * q * q;
+            }
+            scale = sumqx / sumq2;
+        }
+        st16(out, f2h(scale));
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            uint32_t pair = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t lo = (lv[(j + e) >> 3] >> (4 * ((j + e) & 7))) & 15u, hi = (lv[(16 + j + e) >> 3] >> (4 * ((16 + j + e) & 7))) & 15u;
+                pair |= (lo | (hi << 4)) << (8 * e);
+            }
+            st16(out + 2 + j, (uint16_t) pair);
+        }
+    }
+}
+
+// one block -> 32 f32 values (dequantize_row_*): level * d (+ m), one rounding per operation
+template <int TYPE> __device__ __forceinline__ void dequantize_block(const char * blk, float (&y)[32]) {
+    if constexpr (TYPE == GGML_TYPE_F32) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) y[j] = ((const float *) blk)[j];
+    } else if constexpr (TYPE == GGML_TYPE_BF16) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) y[j] = __uint_as_float((uint32_t) ((const uint16_t *) blk)[j] << 16);
+    } else if constexpr (TYPE == GGML_TYPE_F16) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) y[j] = h2f(((const uint16_t *) blk)[j]);
+    } else if constexpr (TYPE == GGML_TYPE_Q8_0) {
+        const float d = h2f(ld16(blk));
+#pragma unroll
+        for (int j = 0; j < 32; j += 2) {
+            const uint16_t w = ld16(blk + 2 + j);
+            y[j] = d * (float) (int8_t) (w & 0xFF);
+            y[j + 1] = d * (float) (int8_t) (w >> 8);
+        }
+    } else {
+        constexpr bool OFFSET = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1;
+        constexpr bool FIVE = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
+        const float d = h2f(ld16(blk));
+        const float m = OFFSET ? h2f(ld16(blk + 2)) : 0.0f;
+        const int o = (OFFSET ? 4 : 2) + (FIVE ? 4 : 0);
+        uint32_t qh = 0;
+        if (FIVE) qh = (uint32_t) ld16(blk + o - 4) | ((uint32_t) ld16(blk + o - 2) << 16);
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const uint16_t w = ld16(blk + o + j);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int b = (w >> (8 * e)) & 0xFF;
+                int q0 = b & 0x0F, q1 = b >> 4;
+                if (FIVE) {
+                    q0 |= (int) ((qh >> (j + e)) & 1u) << 4;
+                    q1 |= (int) ((qh >> (j + e + 16)) & 1u) << 4;
+                }
+                if constexpr (TYPE == GGML_TYPE_IQ4_NL) {
+                    y[j + e] = d * (float) k_iq4nl_values[q0];
+                    y[j + e + 16] = d * (float) k_iq4nl_values[q1];
+                } else if constexpr (OFFSET) {
+                    y[j + e] = (float) q0 * d + m;
+                    y[j + e + 16] = (float) q1 * d + m;
+                } else {
+                    y[j + e] = (float) (q0 - (FIVE ? 16 : 8)) * d;
+                    y[j + e + 16] = (float) (q1 - (FIVE ? 16 : 8)) * d;
+                }
+            }
+        }
+    }
+}
+
+template <int TYPE> __device__ __forceinline__ constexpr int kv_block_bytes() {
+    return TYPE == GGML_TYPE_F32 ? 128 : (TYPE == GGML_TYPE_BF16 || TYPE == GGML_TYPE_F16) ? 64 : TYPE == GGML_TYPE_Q8_0 ? 34 : (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_IQ4_NL) ? 18 :
+           TYPE == GGML_TYPE_Q4_1 ? 20 : TYPE == GGML_TYPE_Q5_0 ? 22 : 24;
+}
+
+__device__ __forceinline__ void load_block_f32(const char * src, float (&x)[32]) {  // 32 f32 of a row (rows are 16-byte aligned: supports_op)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 v = ((const float4 *) src)[j];
+        x[4 * j] = v.x;
+        x[4 * j + 1] = v.y;
+        x[4 * j + 2] = v.z;
+        x[4 * j + 3] = v.w;
+    }
+}
+
+// ---- SET_ROWS: f32 rows [ne0, ne1, ne2, ne3] -> rows idx[i1] of a tensor of blocks (or bf16).  A thread per block of 32 values.
+template <int TYPE> __global__ void __launch_bounds__(64) k_set_rows_kv(const tdesc a, const tdesc idx, const tdesc d) {
+    const int64_t per_row = a.ne[0] / 32;
+    const int64_t gid = (int64_t) blockIdx.x * 64 + threadIdx.x;
+    if (gid >= per_row * a.ne[1] * a.ne[2] * a.ne[3]) return;
+    const int64_t row = gid / per_row, blk = gid - row * per_row;
+    const int64_t i01 = row % a.ne[1], i02 = (row / a.ne[1]) % a.ne[2], i03 = row / (a.ne[1] * a.ne[2]);
+    const int64_t i12 = i03 % idx.ne[2], i11 = i02 % idx.ne[1];
+    const int64_t r = *(const int64_t *) (idx.data + i01 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+    float x[32];
+    load_block_f32(a.data + i01 * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3] + blk * 128, x);
+    char * out = d.data + r * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3] + blk * kv_block_bytes<TYPE>();
+    if constexpr (TYPE == GGML_TYPE_BF16) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) st16(out + 2 * j, f2bf(x[j]));
+    } else {
+        quantize_block<TYPE>(x, out);
+    }
+}
+
+// ---- CPY between contiguous tensors: blocks -> f32 and f32 -> blocks (K-shift)
+template <int TYPE> __global__ void __launch_bounds__(64) k_cpy_kv_to_f32(const char * __restrict__ src, float * __restrict__ dst, const int64_t n_blocks) {
+    const int64_t i = (int64_t) blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_blocks) return;
+    float y[32];
+    dequantize_block<TYPE>(src + i * kv_block_bytes<TYPE>(), y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ((float4 *) (dst + i * 32))[j] = make_float4(y[4 * j], y[4 * j + 1], y[4 * j + 2], y[4 * j + 3]);
+}
+template <int TYPE> __global__ void __launch_bounds__(64) k_cpy_f32_to_kv(const float * __restrict__ src, char * __restrict__ dst, const int64_t n_blocks) {
+    const int64_t i = (int64_t) blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_blocks) return;
+    float x[32];
+    load_block_f32((const char *) (src + i * 32), x);
+    char * out = dst + i * kv_block_bytes<TYPE>();
+    if constexpr (TYPE == GGML_TYPE_BF16) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) st16(out + 2 * j, f2bf(x[j]));
+    } else {
+        quantize_block<TYPE>(x, out);
+    }
+}
+
+// ---- the f16 image of a K or V view [D, n_kv, n_kv_head] (any row / head strides) -> rows [n_kv][n_kv_head * D]
+template <int TYPE> __global__ void __launch_bounds__(64) k_kv_image_f16(const tdesc t, uint16_t * __restrict__ out) {
+    const int64_t per_head = t.ne[0] / 32, per_cell = per_head * t.ne[2];
+    const int64_t i = (int64_t) blockIdx.x * 64 + threadIdx.x;
+    if (i >= per_cell * t.ne[1]) return;
+    const int64_t cell = i / per_cell, rem = i - cell * per_cell, h = rem / per_head, b = rem - h * per_head;
+    float y[32];
+    dequantize_block<TYPE>(t.data + cell * t.nb[1] + h * t.nb[2] + b * kv_block_bytes<TYPE>(), y);
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = (uint32_t) f2h(y[2 * j]) | ((uint32_t) f2h(y[2 * j + 1]) << 16);
+    uint4 * o = (uint4 *) (out + (cell * t.ne[2] + h) * t.ne[0] + b * 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
+
+bool kv_type_is_block(int type) {
+    return type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_IQ4_NL;
+}
+// types whose cache rows this file stores (SET_ROWS / CPY from f32)
+bool kv_store_type(int type) { return kv_type_is_block(type) || type == GGML_TYPE_BF16; }
+// types FLASH_ATTN_EXT reads through the f16 image (f16 itself is read in place)
+bool kv_image_type(int type) { return kv_type_is_block(type) || type == GGML_TYPE_BF16 || type == GGML_TYPE_F32 || type == GGML_TYPE_Q8_0; }
+
+#define KV_DISPATCH_STORE(TYPE_, CALL)                                  \
+    switch (TYPE_) {                                                    \
+        case GGML_TYPE_Q4_0: { constexpr int T = GGML_TYPE_Q4_0; CALL; break; }   \
+        case GGML_TYPE_Q4_1: { constexpr int T = GGML_TYPE_Q4_1; CALL; break; }   \
+        case GGML_TYPE_Q5_0: { constexpr int T = GGML_TYPE_Q5_0; CALL; break; }   \
+        case GGML_TYPE_Q5_1: { constexpr int T = GGML_TYPE_Q5_1; CALL; break; }   \
+        case GGML_TYPE_IQ4_NL: { constexpr int T = GGML_TYPE_IQ4_NL; CALL; break; } \
+        case GGML_TYPE_BF16: { constexpr int T = GGML_TYPE_BF16; CALL; break; }   \
+        default: MI_ERR("kv_types: type %d has no store kernel", (int) (TYPE_)); abort(); \
+    }
+
+void launch_set_rows_kv(hipStream_t s, const tdesc & a, const tdesc & idx, const tdesc & d) {
+    const int64_t n = (a.ne[0] / 32) * a.ne[1] * a.ne[2] * a.ne[3];
+    if (n <= 0) return;
+    const dim3 grid((unsigned) ((n + 63) / 64));
+    KV_DISPATCH_STORE(d.type, hipLaunchKernelGGL((k_set_rows_kv<T>), grid, dim3(64), 0, s, a, idx, d))
+}
+void launch_cpy_kv(hipStream_t s, int type, const void * src, void * dst, int64_t n_values, bool to_type) {
+    const int64_t n = n_values / 32;
+    if (n <= 0) return;
+    const dim3 grid((unsigned) ((n + 63) / 64));
+    if (to_type) {
+        KV_DISPATCH_STORE(type, hipLaunchKernelGGL((k_cpy_f32_to_kv<T>), grid, dim3(64), 0, s, (const float *) src, (char *) dst, n))
+    } else {
+        KV_DISPATCH_STORE(type, hipLaunchKernelGGL((k_cpy_kv_to_f32<T>), grid, dim3(64), 0, s, (const char *) src, (float *) dst, n))
+    }
+}
+size_t kv_image_bytes(const tdesc & t) { return (((size_t) (t.ne[0] * t.ne[1] * t.ne[2]) * sizeof(uint16_t)) + 255) & ~(size_t) 255; }
+// writes the image and returns the descriptor of it (f16, rows [n_kv][n_kv_head * D])
+tdesc launch_kv_image_f16(hipStream_t s, const tdesc & t, void * image) {
+    const int64_t n = (t.ne[0] / 32) * t.ne[1] * t.ne[2];
+    const dim3 grid((unsigned) ((n + 63) / 64));
+    uint16_t * out = (uint16_t *) image;
+    switch (t.type) {
+        case GGML_TYPE_Q4_0: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q4_0>), grid, dim3(64), 0, s, t, out); break;
+        case GGML_TYPE_Q4_1: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q4_1>), grid, dim3(64), 0, s, t, out); break;
+        case GGML_TYPE_Q5_0: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q5_0>), grid, dim3(64), 0, s, t, out); break;
+        case GGML_TYPE_Q5_1: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q5_1>), grid, dim3(64), 0, s, t, out); break;
+        case GGML_TYPE_IQ4_NL: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_IQ4_NL>), grid, dim3(64), 0, s, t, out); break;
+        case GGML_TYPE_Q8_0: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q8_0>), grid, dim3(64), 0, s, t, out); break;
+        case GGML_TYPE_BF16: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_BF16>), grid, dim3(64), 0, s, t, out); break;
+        case GGML_TYPE_F32: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_F32>), grid, dim3(64), 0, s, t, out); break;
+        default: MI_ERR("kv_types: type %d has no f16 image", t.type); abort();
+    }
+    tdesc o = t;
+    o.data = (char *) image;
+    o.type = GGML_TYPE_F16;
+    o.nb[0] = 2;
+    o.nb[2] = t.ne[0] * 2;
+    o.nb[1] = t.ne[2] * o.nb[2];
+    o.nb[3] = t.ne[1] * o.nb[1];
+    return o;
+}
+
+MI_TU_TOUCH(kv_types)
+
+}  // namespace mi355x

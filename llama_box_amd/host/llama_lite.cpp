@@ -819,12 +819,19 @@ extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backe
     c->buft = backend ? ggml_backend_dev_buffer_type(backend->device) : ggml_backend_cpu_buffer_type();
     const llm_hparams & hp = m->hp;
     const int64_t n_embd_k = (int64_t) m->n_head_kv_l * hp.n_embd_head;
-    const ggml_type type_k = c->p.type_k == 0 ? GGML_TYPE_F16 : (ggml_type) c->p.type_k;
-    const ggml_type type_v = c->p.type_v == 0 ? GGML_TYPE_F16 : (ggml_type) c->p.type_v;
-    const bool quant_kv = type_k != GGML_TYPE_F16 || type_v != GGML_TYPE_F16;
-    if ((type_k != GGML_TYPE_F16 && type_k != GGML_TYPE_Q8_0) || (type_v != GGML_TYPE_F16 && type_v != GGML_TYPE_Q8_0) || (quant_kv && !c->p.flash_attn) ||
-        (quant_kv && (hp.n_embd_head % 32) != 0)) {
-        fprintf(stderr, "llm_context_new: unsupported KV cache types %d/%d (f16 or q8_0; quantised caches need flash_attn)\n", (int) type_k, (int) type_v);
+    // -ctk / -ctv (llama-box/engine_param.hpp:51-54): f32, f16, bf16, q8_0, q4_0, q4_1, iq4_nl, q5_0, q5_1.  0 = the default (f16); f32 is ggml type 0
+    // too, so it is asked for as LLM_KV_TYPE_F32 (-1)
+    auto kv_type_of = [](int32_t t) { return t == 0 ? GGML_TYPE_F16 : t == LLM_KV_TYPE_F32 ? GGML_TYPE_F32 : (ggml_type) t; };
+    auto kv_type_ok = [](ggml_type t) {
+        return t == GGML_TYPE_F32 || t == GGML_TYPE_F16 || t == GGML_TYPE_BF16 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_IQ4_NL ||
+               t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1;
+    };
+    const ggml_type type_k = kv_type_of(c->p.type_k), type_v = kv_type_of(c->p.type_v);
+    // (llama.cpp: a quantised V cache needs flash attention — the non-flash path keeps V transposed, one element per index; this harness asks the same
+    // of K, whose non-flash K.q would be a MUL_MAT over cache blocks)
+    const bool other_kv = type_k != GGML_TYPE_F16 || type_v != GGML_TYPE_F16;
+    if (!kv_type_ok(type_k) || !kv_type_ok(type_v) || (other_kv && !c->p.flash_attn) || (hp.n_embd_head % ggml_blck_size(type_k)) != 0 || (hp.n_embd_head % ggml_blck_size(type_v)) != 0) {
+        fprintf(stderr, "llm_context_new: unsupported KV cache types %d/%d (f32, f16, bf16, q8_0, q4_0, q4_1, iq4_nl, q5_0, q5_1; anything but f16 needs flash_attn)\n", (int) type_k, (int) type_v);
         delete c;
         return nullptr;
     }
@@ -927,7 +934,11 @@ static int kv_apply_shift(llm_context * c, const std::vector<int32_t> & delta) {
         ggml_tensor * kc = c->k_l[il];
         ggml_tensor * k = ggml_view_3d(ctx, kc, HD, NKV, n_ctx, ggml_row_size(kc->type, HD), ggml_row_size(kc->type, NKV * HD), 0);
         ggml_tensor * r;
-        if (kc->type != GGML_TYPE_F16) {
+        if (kc->type == GGML_TYPE_BF16) {  // (llama.cpp ropes a non-quantised cache in place, and ROPE has no bf16 form: no context shift on such a cache)
+            ggml_free(ctx);
+            return -2;
+        }
+        if (ggml_blck_size(kc->type) > 1) {  // ggml_is_quantized
             ggml_tensor * tmp = ggml_cast(ctx, k, GGML_TYPE_F32);
             tmp = ggml_rope_ext_inplace(ctx, tmp, shift, nullptr, (int) HD, hp.rope_type, hp.n_ctx_train, hp.rope_freq_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
             r = ggml_cpy(ctx, tmp, k);

@@ -28,7 +28,10 @@ typedef double ggml_float; /* ggml-cpu accumulates scalar reductions in double *
  *   1  block dots summed last block first (f32 summation order of the mat-muls)
  *   2  RMS_NORM sum of squares accumulated in f32 instead of double
  *   3  expf() results moved one ulp up or down, by a bit of the argument (what a different libm / a hardware exp is
- *      entitled to; a uniform shift would cancel in soft_max's ratio)                                              */
+ *      entitled to; a uniform shift would cancel in soft_max's ratio)
+ *   4  FLASH_ATTN_EXT over a block-format K (q8_0, q4_0, q4_1, q5_0, q5_1, iq4_nl): the logit K.q from the dequantised row and the
+ *      UNQUANTISED query — how far ggml-cpu's 8-bit query (Q8_0 / Q8_1) alone moves the result; an implementation that keeps the
+ *      query in f16 (csrc/kv_types.hip) sits on this side of that distance                                          */
 static int g_variant = 0;
 void oracle_set_variant(int v) { g_variant = v; }
 #define BLK_IDX(i, nb) (g_variant == 1 ? ((nb) - 1 - (i)) : (i))
@@ -199,11 +202,366 @@ static void dequantize_row_q6_K(const block_q6_K * x, float * y, int64_t k) {
     }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* The legacy 32-value formats a KV cache may be kept in (llama-box/engine_param.hpp:51-54: -ctk / -ctv f32, f16, bf16, q8_0, q4_0, */
+/* q4_1, iq4_nl, q5_0, q5_1): quantize_row_*_ref / dequantize_row_* of ggml-quants.c, ggml_compute_fp32_to_bf16 of ggml-impl.h.       */
+/* SET_ROWS stores a cache row through the destination type's from_float; FLASH_ATTN_EXT reads K through vec_dot and V through        */
+/* to_float (below).                                                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+static inline float bf16_to_fp32(uint16_t h) {
+    union { uint32_t u; float f; } v;
+    v.u = (uint32_t) h << 16;
+    return v.f;
+}
+static inline uint16_t fp32_to_bf16(float f) { /* ggml_compute_fp32_to_bf16: round to nearest even, NaNs kept quiet */
+    union { uint32_t u; float f; } v;
+    v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t) ((v.u >> 16) | 64);
+    return (uint16_t) ((v.u + (0x7fffu + ((v.u >> 16) & 1u))) >> 16);
+}
+uint16_t oracle_fp32_to_bf16(float f) { return fp32_to_bf16(f); }
+float oracle_bf16_to_fp32(uint16_t h) { return bf16_to_fp32(h); }
+
+static void quantize_row_q4_0_ref(const float * x, block_q4_0 * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        float amax = 0.0f, max = 0.0f; /* the value of largest magnitude, with its sign */
+        for (int j = 0; j < 32; j++) {
+            const float v = x[i * 32 + j];
+            if (amax < fabsf(v)) { amax = fabsf(v); max = v; }
+        }
+        const float d = max / -8;
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = oracle_fp32_to_fp16(d);
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = x[i * 32 + 0 + j] * id, x1 = x[i * 32 + 16 + j] * id;
+            const uint8_t xi0 = (uint8_t) ((int8_t) (x0 + 8.5f) < 15 ? (int8_t) (x0 + 8.5f) : 15); /* MIN(15, (int8_t)(x0 + 8.5f)) */
+            const uint8_t xi1 = (uint8_t) ((int8_t) (x1 + 8.5f) < 15 ? (int8_t) (x1 + 8.5f) : 15);
+            y[i].qs[j] = (uint8_t) (xi0 | (xi1 << 4));
+        }
+    }
+}
+static void dequantize_row_q4_0(const block_q4_0 * x, float * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = F16(x[i].d);
+        for (int j = 0; j < 16; ++j) {
+            const int x0 = (x[i].qs[j] & 0x0F) - 8, x1 = (x[i].qs[j] >> 4) - 8;
+            y[i * 32 + j] = x0 * d;
+            y[i * 32 + j + 16] = x1 * d;
+        }
+    }
+}
+static void quantize_row_q4_1_ref(const float * x, block_q4_1 * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        float min = 3.402823466e+38f, max = -3.402823466e+38f;
+        for (int j = 0; j < 32; j++) {
+            const float v = x[i * 32 + j];
+            if (v < min) min = v;
+            if (v > max) max = v;
+        }
+        const float d = (max - min) / ((1 << 4) - 1);
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = oracle_fp32_to_fp16(d);
+        y[i].m = oracle_fp32_to_fp16(min);
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = (x[i * 32 + 0 + j] - min) * id, x1 = (x[i * 32 + 16 + j] - min) * id;
+            const uint8_t xi0 = (uint8_t) ((int8_t) (x0 + 0.5f) < 15 ? (int8_t) (x0 + 0.5f) : 15);
+            const uint8_t xi1 = (uint8_t) ((int8_t) (x1 + 0.5f) < 15 ? (int8_t) (x1 + 0.5f) : 15);
+            y[i].qs[j] = (uint8_t) (xi0 | (xi1 << 4));
+        }
+    }
+}
+static void dequantize_row_q4_1(const block_q4_1 * x, float * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = F16(x[i].d), m = F16(x[i].m);
+        for (int j = 0; j < 16; ++j) {
+            const int x0 = (x[i].qs[j] & 0x0F), x1 = (x[i].qs[j] >> 4);
+            y[i * 32 + j] = x0 * d + m;
+            y[i * 32 + j + 16] = x1 * d + m;
+        }
+    }
+}
+static void quantize_row_q5_0_ref(const float * x, block_q5_0 * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        float amax = 0.0f, max = 0.0f;
+        for (int j = 0; j < 32; j++) {
+            const float v = x[i * 32 + j];
+            if (amax < fabsf(v)) { amax = fabsf(v); max = v; }
+        }
+        const float d = max / -16;
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = oracle_fp32_to_fp16(d);
+        uint32_t qh = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = x[i * 32 + 0 + j] * id, x1 = x[i * 32 + 16 + j] * id;
+            const uint8_t xi0 = (uint8_t) ((int8_t) (x0 + 16.5f) < 31 ? (int8_t) (x0 + 16.5f) : 31); /* MIN(31, (int8_t)(x0 + 16.5f)) */
+            const uint8_t xi1 = (uint8_t) ((int8_t) (x1 + 16.5f) < 31 ? (int8_t) (x1 + 16.5f) : 31);
+            y[i].qs[j] = (uint8_t) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+            qh |= ((xi0 & 0x10u) >> 4) << (j + 0); /* the fifth bits */
+            qh |= ((xi1 & 0x10u) >> 4) << (j + 16);
+        }
+        memcpy(&y[i].qh, &qh, sizeof(qh));
+    }
+}
+static void dequantize_row_q5_0(const block_q5_0 * x, float * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = F16(x[i].d);
+        uint32_t qh;
+        memcpy(&qh, x[i].qh, sizeof(qh));
+        for (int j = 0; j < 16; ++j) {
+            const uint8_t xh_0 = ((qh >> (j + 0)) << 4) & 0x10, xh_1 = ((qh >> (j + 12))) & 0x10;
+            const int32_t x0 = ((x[i].qs[j] & 0x0F) | xh_0) - 16, x1 = ((x[i].qs[j] >> 4) | xh_1) - 16;
+            y[i * 32 + j] = x0 * d;
+            y[i * 32 + j + 16] = x1 * d;
+        }
+    }
+}
+static void quantize_row_q5_1_ref(const float * x, block_q5_1 * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        float min = 3.402823466e+38f, max = -3.402823466e+38f;
+        for (int j = 0; j < 32; j++) {
+            const float v = x[i * 32 + j];
+            if (v < min) min = v;
+            if (v > max) max = v;
+        }
+        const float d = (max - min) / ((1 << 5) - 1);
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = oracle_fp32_to_fp16(d);
+        y[i].m = oracle_fp32_to_fp16(min);
+        uint32_t qh = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = (x[i * 32 + 0 + j] - min) * id, x1 = (x[i * 32 + 16 + j] - min) * id;
+            const uint8_t xi0 = (uint8_t) (x0 + 0.5f), xi1 = (uint8_t) (x1 + 0.5f);
+            y[i].qs[j] = (uint8_t) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+            qh |= ((xi0 & 0x10u) >> 4) << (j + 0);
+            qh |= ((xi1 & 0x10u) >> 4) << (j + 16);
+        }
+        memcpy(&y[i].qh, &qh, sizeof(qh));
+    }
+}
+static void dequantize_row_q5_1(const block_q5_1 * x, float * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = F16(x[i].d), m = F16(x[i].m);
+        uint32_t qh;
+        memcpy(&qh, x[i].qh, sizeof(qh));
+        for (int j = 0; j < 16; ++j) {
+            const uint8_t xh_0 = ((qh >> (j + 0)) << 4) & 0x10, xh_1 = ((qh >> (j + 12))) & 0x10;
+            const int x0 = (x[i].qs[j] & 0x0F) | xh_0, x1 = (x[i].qs[j] >> 4) | xh_1;
+            y[i * 32 + j] = x0 * d + m;
+            y[i * 32 + j + 16] = x1 * d + m;
+        }
+    }
+}
+/* IQ4_NL: 16 non-linear levels, one f16 scale per 32 values.  quantize_row_iq4_nl_ref -> quantize_row_iq4_nl_impl(super-block 32, block 32, no
+   importance weights, ntry = -1 — the run-time form; the offline quantiser searches 15 scales with ntry = 7): levels chosen against max / -127, then
+   the least-squares scale for those levels under the weights x^2.  (An all-zero block leaves upstream's level buffer as the previous block left
+   it; d = 0 there, so the values are 0 either way — the levels are written as 0 here.) */
+static const int8_t kvalues_iq4nl[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
+static inline int best_index_int8(int n, const int8_t * val, float x) {
+    if (x <= val[0]) return 0;
+    if (x >= val[n - 1]) return n - 1;
+    int ml = 0, mu = n - 1;
+    while (mu - ml > 1) {
+        const int mav = (ml + mu) / 2;
+        if (x < val[mav]) mu = mav; else ml = mav;
+    }
+    return x - val[mu - 1] < val[mu] - x ? mu - 1 : mu;
+}
+static void quantize_row_iq4_nl_ref(const float * x, block_iq4_nl * y, int64_t k) {
+    const int64_t nb = k / 32;
+    const int8_t * values = kvalues_iq4nl;
+    for (int64_t ib = 0; ib < nb; ++ib) {
+        const float * xb = x + ib * 32;
+        uint8_t L[32];
+        memset(L, 0, sizeof(L));
+        float amax = 0, max = 0;
+        for (int j = 0; j < 32; ++j) {
+            const float ax = fabsf(xb[j]);
+            if (ax > amax) { amax = ax; max = xb[j]; }
+        }
+        float scale = 0.0f;
+        if (amax >= 1e-15f) { /* GROUP_MAX_EPS */
+            float d = max / values[0];
+            const float id = 1 / d;
+            float sumqx = 0, sumq2 = 0;
+            for (int j = 0; j < 32; ++j) {
+                const float al = id * xb[j];
+                const int l = best_index_int8(16, values, al);
+                L[j] = (uint8_t) l;
+                const float q = values[l], w = xb[j] * xb[j];
+                sumqx += w * q * xb[j];
+                sumq2 += w * q * q;
+            }
+            d = sumqx / sumq2;
+            scale = d;
+        }
+        y[ib].d = oracle_fp32_to_fp16(scale);
+        for (int j = 0; j < 16; ++j) y[ib].qs[j] = (uint8_t) (L[j] | (L[16 + j] << 4));
+    }
+}
+static void dequantize_row_iq4_nl(const block_iq4_nl * x, float * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = F16(x[i].d);
+        for (int j = 0; j < 16; ++j) {
+            y[i * 32 + j] = d * kvalues_iq4nl[x[i].qs[j] & 0xf];
+            y[i * 32 + j + 16] = d * kvalues_iq4nl[x[i].qs[j] >> 4];
+        }
+    }
+}
+/* quantize_row_q8_1_ref: Q8_0 plus s = d * sum(qs), the term the offset formats (Q4_1, Q5_1) multiply their minimum by */
+static void quantize_row_q8_1_ref(const float * x, block_q8_1 * y, int64_t k) {
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < 32; j++) {
+            const float v = fabsf(x[i * 32 + j]);
+            if (v > amax) amax = v;
+        }
+        const float d = amax / ((1 << 7) - 1);
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = oracle_fp32_to_fp16(d);
+        int sum = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float v0 = x[i * 32 + j] * id, v1 = x[i * 32 + 16 + j] * id;
+            y[i].qs[j] = (int8_t) roundf(v0);
+            y[i].qs[16 + j] = (int8_t) roundf(v1);
+            sum += y[i].qs[j];
+            sum += y[i].qs[16 + j];
+        }
+        y[i].s = oracle_fp32_to_fp16(sum * d);
+    }
+}
+/* the generic ggml_vec_dot_{q4_0,q5_0,iq4_nl}_q8_0 and ggml_vec_dot_{q4_1,q5_1}_q8_1: integer sums per block, one f32 product per block */
+static float vec_dot_q4_0_q8_0(int64_t n, const block_q4_0 * x, const block_q8_0 * y) {
+    float sumf = 0;
+    for (int64_t ib = 0; ib < n / 32; ++ib) {
+        int sumi0 = 0, sumi1 = 0;
+        for (int j = 0; j < 16; ++j) {
+            const int v0 = (x[ib].qs[j] & 0x0F) - 8, v1 = (x[ib].qs[j] >> 4) - 8;
+            sumi0 += v0 * y[ib].qs[j];
+            sumi1 += v1 * y[ib].qs[j + 16];
+        }
+        sumf += (sumi0 + sumi1) * F16(x[ib].d) * F16(y[ib].d);
+    }
+    return sumf;
+}
+static float vec_dot_q4_1_q8_1(int64_t n, const block_q4_1 * x, const block_q8_1 * y) {
+    float sumf = 0;
+    for (int64_t ib = 0; ib < n / 32; ++ib) {
+        int sumi0 = 0, sumi1 = 0;
+        for (int j = 0; j < 16; ++j) {
+            const int v0 = (x[ib].qs[j] & 0x0F), v1 = (x[ib].qs[j] >> 4);
+            sumi0 += v0 * y[ib].qs[j];
+            sumi1 += v1 * y[ib].qs[j + 16];
+        }
+        sumf += (F16(x[ib].d) * F16(y[ib].d)) * (sumi0 + sumi1) + F16(x[ib].m) * F16(y[ib].s);
+    }
+    return sumf;
+}
+static float vec_dot_q5_0_q8_0(int64_t n, const block_q5_0 * x, const block_q8_0 * y) {
+    float sumf = 0;
+    for (int64_t ib = 0; ib < n / 32; ++ib) {
+        uint32_t qh;
+        memcpy(&qh, x[ib].qh, sizeof(qh));
+        int sumi0 = 0, sumi1 = 0;
+        for (int j = 0; j < 16; ++j) {
+            const uint8_t xh_0 = ((qh & (1u << (j + 0))) >> (j + 0)) << 4, xh_1 = ((qh & (1u << (j + 16))) >> (j + 12));
+            const int32_t x0 = (int8_t) (((x[ib].qs[j] & 0x0F) | xh_0) - 16), x1 = (int8_t) (((x[ib].qs[j] >> 4) | xh_1) - 16);
+            sumi0 += x0 * y[ib].qs[j];
+            sumi1 += x1 * y[ib].qs[j + 16];
+        }
+        sumf += (F16(x[ib].d) * F16(y[ib].d)) * (sumi0 + sumi1);
+    }
+    return sumf;
+}
+static float vec_dot_q5_1_q8_1(int64_t n, const block_q5_1 * x, const block_q8_1 * y) {
+    float sumf = 0;
+    for (int64_t ib = 0; ib < n / 32; ++ib) {
+        uint32_t qh;
+        memcpy(&qh, x[ib].qh, sizeof(qh));
+        int sumi0 = 0, sumi1 = 0;
+        for (int j = 0; j < 16; ++j) {
+            const uint8_t xh_0 = ((qh >> (j + 0)) << 4) & 0x10, xh_1 = ((qh >> (j + 12))) & 0x10;
+            const int32_t x0 = (x[ib].qs[j] & 0xF) | xh_0, x1 = (x[ib].qs[j] >> 4) | xh_1;
+            sumi0 += x0 * y[ib].qs[j];
+            sumi1 += x1 * y[ib].qs[j + 16];
+        }
+        sumf += (F16(x[ib].d) * F16(y[ib].d)) * (sumi0 + sumi1) + F16(x[ib].m) * F16(y[ib].s);
+    }
+    return sumf;
+}
+static float vec_dot_iq4_nl_q8_0(int64_t n, const block_iq4_nl * x, const block_q8_0 * y) {
+    float sumf = 0;
+    for (int64_t ib = 0; ib < n / 32; ++ib) {
+        const float d = F16(y[ib].d) * F16(x[ib].d);
+        int sumi1 = 0, sumi2 = 0;
+        for (int j = 0; j < 16; ++j) {
+            sumi1 += y[ib].qs[j + 0] * kvalues_iq4nl[x[ib].qs[j] & 0xf];
+            sumi2 += y[ib].qs[j + 16] * kvalues_iq4nl[x[ib].qs[j] >> 4];
+        }
+        sumf += d * (sumi1 + sumi2);
+    }
+    return sumf;
+}
+/* type_traits[type].from_float / type_traits_cpu[type].from_float for the types a cache row may be stored in; 0 when the type has none here */
+int oracle_quantize_row(enum ggml_type type, const float * x, void * y, int64_t k) {
+    switch (type) {
+        case GGML_TYPE_F32: memcpy(y, x, (size_t) k * 4); return 1;
+        case GGML_TYPE_F16: for (int64_t i = 0; i < k; ++i) ((ggml_fp16_t *) y)[i] = oracle_fp32_to_fp16(x[i]); return 1;
+        case GGML_TYPE_BF16: for (int64_t i = 0; i < k; ++i) ((uint16_t *) y)[i] = fp32_to_bf16(x[i]); return 1;
+        case GGML_TYPE_Q8_0: oracle_quantize_row_q8_0(x, (block_q8_0 *) y, k); return 1;
+        case GGML_TYPE_Q8_1: quantize_row_q8_1_ref(x, (block_q8_1 *) y, k); return 1;
+        case GGML_TYPE_Q4_0: quantize_row_q4_0_ref(x, (block_q4_0 *) y, k); return 1;
+        case GGML_TYPE_Q4_1: quantize_row_q4_1_ref(x, (block_q4_1 *) y, k); return 1;
+        case GGML_TYPE_Q5_0: quantize_row_q5_0_ref(x, (block_q5_0 *) y, k); return 1;
+        case GGML_TYPE_Q5_1: quantize_row_q5_1_ref(x, (block_q5_1 *) y, k); return 1;
+        case GGML_TYPE_IQ4_NL: quantize_row_iq4_nl_ref(x, (block_iq4_nl *) y, k); return 1;
+        default: return 0;
+    }
+}
+/* one K.q logit as FLASH_ATTN_EXT forms it for a block-format K row (tests: against the float64 golden value): the query through the
+   from_float of K's vec_dot_type, then K's vec_dot */
+float oracle_kq_dot(enum ggml_type kt, int64_t n, const void * krow, const float * q) {
+    block_q8_1 * a = (block_q8_1 *) malloc((size_t) (n / 32 + 1) * sizeof(block_q8_1));
+    if (!a) return NAN;
+    float s = NAN;
+    const int q81 = kt == GGML_TYPE_Q4_1 || kt == GGML_TYPE_Q5_1;
+    (void) oracle_quantize_row(q81 ? GGML_TYPE_Q8_1 : GGML_TYPE_Q8_0, q, a, n);
+    switch (kt) {
+        case GGML_TYPE_Q8_0: s = oracle_vec_dot_q8_0_q8_0(n, (const block_q8_0 *) krow, (const block_q8_0 *) a); break;
+        case GGML_TYPE_Q4_0: s = vec_dot_q4_0_q8_0(n, (const block_q4_0 *) krow, (const block_q8_0 *) a); break;
+        case GGML_TYPE_Q5_0: s = vec_dot_q5_0_q8_0(n, (const block_q5_0 *) krow, (const block_q8_0 *) a); break;
+        case GGML_TYPE_IQ4_NL: s = vec_dot_iq4_nl_q8_0(n, (const block_iq4_nl *) krow, (const block_q8_0 *) a); break;
+        case GGML_TYPE_Q4_1: s = vec_dot_q4_1_q8_1(n, (const block_q4_1 *) krow, a); break;
+        case GGML_TYPE_Q5_1: s = vec_dot_q5_1_q8_1(n, (const block_q5_1 *) krow, a); break;
+        default: break;
+    }
+    free(a);
+    return s;
+}
+static int is_cache_block_type(enum ggml_type t) {
+    return t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL;
+}
+
 void oracle_dequantize_row(enum ggml_type type, const void * x, float * y, int64_t k) {
     switch (type) {
         case GGML_TYPE_F32: memcpy(y, x, (size_t) k * 4); break;
         case GGML_TYPE_F16: for (int64_t i = 0; i < k; ++i) y[i] = F16(((const ggml_fp16_t *) x)[i]); break;
         case GGML_TYPE_Q8_0: dequantize_row_q8_0((const block_q8_0 *) x, y, k); break;
+        case GGML_TYPE_BF16: for (int64_t i = 0; i < k; ++i) y[i] = bf16_to_fp32(((const uint16_t *) x)[i]); break;
+        case GGML_TYPE_Q4_0: dequantize_row_q4_0((const block_q4_0 *) x, y, k); break;
+        case GGML_TYPE_Q4_1: dequantize_row_q4_1((const block_q4_1 *) x, y, k); break;
+        case GGML_TYPE_Q5_0: dequantize_row_q5_0((const block_q5_0 *) x, y, k); break;
+        case GGML_TYPE_Q5_1: dequantize_row_q5_1((const block_q5_1 *) x, y, k); break;
+        case GGML_TYPE_IQ4_NL: dequantize_row_iq4_nl((const block_iq4_nl *) x, y, k); break;
         case GGML_TYPE_Q4_K: dequantize_row_q4_K((const block_q4_K *) x, y, k); break;
         case GGML_TYPE_Q5_K: dequantize_row_q5_K((const block_q5_K *) x, y, k); break;
         case GGML_TYPE_Q6_K: dequantize_row_q6_K((const block_q6_K *) x, y, k); break;
@@ -776,9 +1134,9 @@ static enum ggml_status op_set_rows(struct ggml_tensor * dst) {
     const struct ggml_tensor * a = dst->src[0];
     const struct ggml_tensor * idx = dst->src[1];
     if (a->type != GGML_TYPE_F32 || idx->type != GGML_TYPE_I64) return GGML_STATUS_FAILED;
-    if (dst->type != GGML_TYPE_F32 && dst->type != GGML_TYPE_F16 && dst->type != GGML_TYPE_Q8_0) return GGML_STATUS_FAILED;
+    if (dst->type != GGML_TYPE_F32 && dst->type != GGML_TYPE_F16 && dst->type != GGML_TYPE_BF16 && !is_cache_block_type(dst->type)) return GGML_STATUS_FAILED;
     const int64_t nc = a->ne[0];
-    if (dst->type == GGML_TYPE_Q8_0 && (nc % 32) != 0) return GGML_STATUS_FAILED;
+    if (is_cache_block_type(dst->type) && (nc % 32) != 0) return GGML_STATUS_FAILED;
     for (int64_t i03 = 0; i03 < a->ne[3]; ++i03)
         for (int64_t i02 = 0; i02 < a->ne[2]; ++i02)
             for (int64_t i01 = 0; i01 < a->ne[1]; ++i01) {
@@ -788,8 +1146,7 @@ static enum ggml_status op_set_rows(struct ggml_tensor * dst) {
                 const float * s = (const float *) (TDATA(a) + i01 * a->nb[1] + i02 * a->nb[2] + i03 * a->nb[3]);
                 char * d = TDATA(dst) + i1 * dst->nb[1] + i02 * dst->nb[2] + i03 * dst->nb[3];
                 if (dst->type == GGML_TYPE_F32) memcpy(d, s, (size_t) nc * 4);
-                else if (dst->type == GGML_TYPE_Q8_0) oracle_quantize_row_q8_0(s, (block_q8_0 *) d, nc); /* from_float of the destination type (quantised KV cache) */
-                else for (int64_t i = 0; i < nc; ++i) ((ggml_fp16_t *) d)[i] = oracle_fp32_to_fp16(s[i]);
+                else (void) oracle_quantize_row(dst->type, s, d, nc); /* from_float of the destination type (f16 / bf16 / quantised KV cache) */
             }
     return GGML_STATUS_SUCCESS;
 }
@@ -806,12 +1163,13 @@ static enum ggml_status op_cpy(struct ggml_tensor * dst) {
     /* quantised KV cache, K-shift (llama.cpp build_rope_shift: cast to f32 -> rope -> cpy back): contiguous Q8_0 <-> F32
        — ggml_compute_forward_dup_from_q dequantises whole rows, ggml_compute_forward_dup_f32 with a contiguous quantised
        destination runs from_float (quantize_row_q8_0) over rows of ne00 values */
-    if (a->type == GGML_TYPE_Q8_0 && dst->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(dst)) {
-        dequantize_row_q8_0((const block_q8_0 *) TDATA(a), (float *) TDATA(dst), n);
+    if ((is_cache_block_type(a->type) || a->type == GGML_TYPE_BF16) && dst->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(dst)) {
+        oracle_dequantize_row(a->type, TDATA(a), (float *) TDATA(dst), n);
         return GGML_STATUS_SUCCESS;
     }
-    if (a->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_Q8_0 && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(dst) && (a->ne[0] % 32) == 0) {
-        oracle_quantize_row_q8_0((const float *) TDATA(a), (block_q8_0 *) TDATA(dst), n);
+    if (a->type == GGML_TYPE_F32 && (is_cache_block_type(dst->type) || dst->type == GGML_TYPE_BF16) && ggml_abi_is_contiguous(a) && ggml_abi_is_contiguous(dst) &&
+        (a->ne[0] % ggml_abi_blck_size(dst->type)) == 0) {
+        (void) oracle_quantize_row(dst->type, (const float *) TDATA(a), TDATA(dst), n);
         return GGML_STATUS_SUCCESS;
     }
     const int sf32 = a->type == GGML_TYPE_F32, sf16 = a->type == GGML_TYPE_F16;
@@ -1049,9 +1407,15 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
     const struct ggml_tensor * v = dst->src[2];
     const struct ggml_tensor * mask = dst->src[3];
     const struct ggml_tensor * sinks = dst->src[4];
-    if (q->type != GGML_TYPE_F32 || (k->type != GGML_TYPE_F16 && k->type != GGML_TYPE_Q8_0) || (v->type != GGML_TYPE_F16 && v->type != GGML_TYPE_Q8_0)) return GGML_STATUS_FAILED;
-    const int kq8 = k->type == GGML_TYPE_Q8_0, vq8 = v->type == GGML_TYPE_Q8_0;
-    if ((kq8 && (k->ne[0] % 32) != 0) || (vq8 && (v->ne[0] % 32) != 0)) return GGML_STATUS_FAILED;
+    /* K: vec_dot of its type against the query converted to that type's vec_dot_type (f16 -> f16, bf16 -> bf16, f32 -> f32, q8_0 / q4_0 / q5_0 /
+       iq4_nl -> q8_0, q4_1 / q5_1 -> q8_1); V: f16 rows accumulate in f16, every other type through to_float into an f32 accumulator */
+    const enum ggml_type kt = k->type, vt = v->type;
+    const int k_ok = kt == GGML_TYPE_F16 || kt == GGML_TYPE_BF16 || kt == GGML_TYPE_F32 || is_cache_block_type(kt);
+    const int v_ok = vt == GGML_TYPE_F16 || vt == GGML_TYPE_BF16 || vt == GGML_TYPE_F32 || is_cache_block_type(vt);
+    if (q->type != GGML_TYPE_F32 || !k_ok || !v_ok) return GGML_STATUS_FAILED;
+    const int kq8 = is_cache_block_type(kt), vq8 = vt != GGML_TYPE_F16;
+    const int kq81 = kt == GGML_TYPE_Q4_1 || kt == GGML_TYPE_Q5_1;
+    if ((kq8 && (k->ne[0] % 32) != 0) || (is_cache_block_type(vt) && (v->ne[0] % 32) != 0)) return GGML_STATUS_FAILED;
     if (mask && mask->type != GGML_TYPE_F16) return GGML_STATUS_FAILED;
     const int64_t DK = k->ne[0], DV = v->ne[0];
     const int64_t neq1 = q->ne[1], neq2 = q->ne[2], neq3 = q->ne[3];
@@ -1077,21 +1441,44 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
         float * VKQ32 = (float *) calloc((size_t) DV, 4);
         ggml_fp16_t * VKQ16 = (ggml_fp16_t *) calloc((size_t) DV, 2);
         ggml_fp16_t * Q16 = (ggml_fp16_t *) malloc((size_t) DK * 2);
-        block_q8_0 * Qq = (block_q8_0 *) malloc((size_t) (DK / 32 + 1) * sizeof(block_q8_0));
-        float * V32 = (float *) malloc((size_t) DV * 4);
+        block_q8_0 * Qq = (block_q8_0 *) malloc((size_t) (DK / 32 + 1) * sizeof(block_q8_1) + (size_t) DK * 4); /* (room for any vec_dot_type: q8_0, q8_1, bf16, f32) */
+        float * V32 = (float *) malloc((size_t) (DV + DK) * 4);
         if (!VKQ32 || !VKQ16 || !Q16 || !Qq || !V32) { fail = 1; free(VKQ32); free(VKQ16); free(Q16); free(Qq); free(V32); continue; }
+        float * V32k = V32 + DV;
         const ggml_fp16_t * mp = mask ? (const ggml_fp16_t *) (TDATA(mask) + iq1 * mask->nb[1] + (iq2 % mask->ne[2]) * mask->nb[2] + (iq3 % mask->ne[3]) * mask->nb[3]) : NULL;
         const int64_t ik3 = iq3 / rk3, ik2 = iq2 / rk2, iv3 = iq3 / rv3, iv2 = iq2 / rv2;
         const float * pq = (const float *) (TDATA(q) + iq1 * q->nb[1] + iq2 * q->nb[2] + iq3 * q->nb[3]);
-        if (kq8) oracle_quantize_row_q8_0(pq, Qq, DK);
+        if (kq8) (void) oracle_quantize_row(kq81 ? GGML_TYPE_Q8_1 : GGML_TYPE_Q8_0, pq, Qq, DK);
+        else if (kt == GGML_TYPE_BF16) for (int64_t i = 0; i < DK; ++i) ((uint16_t *) Qq)[i] = fp32_to_bf16(pq[i]);
+        else if (kt == GGML_TYPE_F32) memcpy(Qq, pq, (size_t) DK * 4);
         else for (int64_t i = 0; i < DK; ++i) Q16[i] = oracle_fp32_to_fp16(pq[i]);
         for (int64_t ic = 0; ic < nek1; ++ic) {
             const float mv = mp ? slope * F16(mp[ic]) : 0.0f;
             if (mv == -INFINITY) continue;
             const ggml_fp16_t * kd = (const ggml_fp16_t *) (TDATA(k) + ic * k->nb[1] + ik2 * k->nb[2] + ik3 * k->nb[3]);
             float s;
-            if (kq8) {
-                s = oracle_vec_dot_q8_0_q8_0(DK, (const block_q8_0 *) kd, Qq);
+            if (kq8 && g_variant == 4) { /* yardstick: the block-format K row against the UNQUANTISED query (see oracle_set_variant) */
+                oracle_dequantize_row(kt, kd, V32k, DK);
+                ggml_float acc = 0.0;
+                for (int64_t i = 0; i < DK; ++i) acc += (ggml_float) V32k[i] * (ggml_float) pq[i];
+                s = (float) acc;
+            } else if (kq8) {
+                switch (kt) {
+                    case GGML_TYPE_Q8_0: s = oracle_vec_dot_q8_0_q8_0(DK, (const block_q8_0 *) kd, Qq); break;
+                    case GGML_TYPE_Q4_0: s = vec_dot_q4_0_q8_0(DK, (const block_q4_0 *) kd, Qq); break;
+                    case GGML_TYPE_Q5_0: s = vec_dot_q5_0_q8_0(DK, (const block_q5_0 *) kd, Qq); break;
+                    case GGML_TYPE_IQ4_NL: s = vec_dot_iq4_nl_q8_0(DK, (const block_iq4_nl *) kd, Qq); break;
+                    case GGML_TYPE_Q4_1: s = vec_dot_q4_1_q8_1(DK, (const block_q4_1 *) kd, (const block_q8_1 *) Qq); break;
+                    default: s = vec_dot_q5_1_q8_1(DK, (const block_q5_1 *) kd, (const block_q8_1 *) Qq); break;
+                }
+            } else if (kt == GGML_TYPE_BF16) { /* ggml_vec_dot_bf16 */
+                ggml_float acc = 0.0;
+                for (int64_t i = 0; i < DK; ++i) acc += (ggml_float) (bf16_to_fp32(((const uint16_t *) kd)[i]) * bf16_to_fp32(((const uint16_t *) Qq)[i]));
+                s = (float) acc;
+            } else if (kt == GGML_TYPE_F32) { /* ggml_vec_dot_f32 */
+                ggml_float acc = 0.0;
+                for (int64_t i = 0; i < DK; ++i) acc += (ggml_float) (((const float *) kd)[i] * ((const float *) Qq)[i]);
+                s = (float) acc;
             } else {
                 ggml_float acc = 0.0;
                 for (int64_t i = 0; i < DK; ++i) acc += (ggml_float) (F16(kd[i]) * F16(Q16[i]));
@@ -1111,8 +1498,8 @@ static enum ggml_status op_flash_attn_ext(struct ggml_tensor * dst, int nth) {
             } else {
                 vs = oracle_expf(s - M);
             }
-            if (vq8) { /* v_to_float + ggml_vec_mad_f32 */
-                dequantize_row_q8_0((const block_q8_0 *) vd, V32, DV);
+            if (vq8) { /* v_to_float + ggml_vec_mad_f32 (an f32 V is read in place) */
+                oracle_dequantize_row(vt, vd, V32, DV);
                 for (int64_t i = 0; i < DV; ++i) VKQ32[i] += V32[i] * vs;
             } else {
                 for (int64_t i = 0; i < DV; ++i) { /* ggml_vec_mad_f16 */

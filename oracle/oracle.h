@@ -26,6 +26,11 @@ ggml_fp16_t oracle_fp32_to_fp16(float f);
 
 void oracle_dequantize_row(enum ggml_type type, const void * x, float * y, int64_t k);
 void oracle_quantize_row_q8_0(const float * x, block_q8_0 * y, int64_t k);
+/* from_float of the types a KV-cache row may be stored in (f32, f16, bf16, q8_0, q8_1, q4_0, q4_1, q5_0, q5_1, iq4_nl): 1 done, 0 no such type here */
+int oracle_quantize_row(enum ggml_type type, const float * x, void * y, int64_t k);
+float oracle_kq_dot(enum ggml_type kt, int64_t n, const void * krow, const float * q); /* a K.q logit of a block-format cache row, as FLASH_ATTN_EXT forms it */
+uint16_t oracle_fp32_to_bf16(float f);
+float oracle_bf16_to_fp32(uint16_t h);
 void oracle_quantize_row_q8_K(const float * x, block_q8_K * y, int64_t k);
 float oracle_vec_dot_q8_0_q8_0(int64_t n, const block_q8_0 * x, const block_q8_0 * y);
 float oracle_vec_dot_q4_K_q8_K(int64_t n, const block_q4_K * x, const block_q8_K * y);

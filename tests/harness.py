@@ -53,6 +53,14 @@ def oracle():
         lib.oracle_fp32_to_fp16.restype = C.c_uint16
         lib.oracle_fp32_to_fp16.argtypes = [C.c_float]
         lib.oracle_max_threads.restype = C.c_int
+        lib.oracle_quantize_row.restype = C.c_int
+        lib.oracle_quantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        lib.oracle_kq_dot.restype = C.c_float
+        lib.oracle_kq_dot.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.oracle_fp32_to_bf16.restype = C.c_uint16
+        lib.oracle_fp32_to_bf16.argtypes = [C.c_float]
+        lib.oracle_bf16_to_fp32.restype = C.c_float
+        lib.oracle_bf16_to_fp32.argtypes = [C.c_uint16]
         _oracle = lib
     return _oracle
 
