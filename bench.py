@@ -105,7 +105,7 @@ def main():
                                                                                    "sums are simply not taken): the per-rank compute time of a --tensor-split run, for the time budget of DESIGN.md §6; not a throughput")
     ap.add_argument("--ubatch", type=int, default=512)
     ap.add_argument("--n-batch", type=int, default=2048, dest="n_batch", help="prompt tokens per llama_decode call (llama-box -b); several slots' prompts share a call")
-    ap.add_argument("--ctkv", default="f16", choices=["f16", "q8_0"], help="KV cache type (llama-box --cache-type-k / --cache-type-v); the headline metric is quoted on f16")
+    ap.add_argument("--ctkv", default="f16", choices=["f16", "q8_0", "q4_0", "q4_1", "q5_0", "q5_1", "iq4_nl", "bf16", "f32"], help="KV cache type (llama-box --cache-type-k / --cache-type-v); the headline metric is quoted on f16")
     ap.add_argument("--layers", type=int, default=0, help="debug only: override n_layer (result is then NOT a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-process", type=int, default=1, dest="in_process", help="--gpus N > 1: ALSO time the same decode with ONE process driving the N devices (-sm row through "
@@ -249,7 +249,7 @@ def main():
     t_load = time.time()
     model = Model(hp, 0x5EED, be.buft, tp_rank=tp_rank, tp_size=tp_size, rowpar_buft=be.rowpar_buft() if tp_size > 1 else None)
     t_load = time.time() - t_load
-    kvt = L.Q8_0 if args.ctkv == "q8_0" else 0
+    kvt = {"f16": 0, "q8_0": L.Q8_0, "q4_0": L.Q4_0, "q4_1": L.Q4_1, "q5_0": L.Q5_0, "q5_1": L.Q5_1, "iq4_nl": L.IQ4_NL, "bf16": L.BF16, "f32": -1}[args.ctkv]
     extra_leg = (args.warmup + args.steps) if (world > 1 or os.environ.get("BENCH_FORCE_TWO_LEGS") == "1") else 0  # tensor-split runs time the decode steps twice (eager, then graph replay)
     n_ctx = (args.np * (args.prefill + args.warmup + args.steps + extra_leg + args.timing_steps + 64 + args.draft) + 255) // 256 * 256
     ctx = Context(model, backend=be, n_ctx=n_ctx, n_ubatch=args.ubatch, flash_attn=args.fa, graph_reuse=1, type_k=kvt, type_v=kvt)
@@ -621,7 +621,7 @@ def main():
         prefill_roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                             "flop_per_token": round(flop_tok), "note": "dense f16 MFMA peak; the GEMMs run on the int8 matrix cores (2x rate) with two digit passes per weight"}
     if rank == 0:
-        kv_per_tok = int(2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * (34 / 32 if args.ctkv == "q8_0" else 2))
+        kv_per_tok = int(2 * hp.n_layer * (hp.n_head_kv // tp_size) * hp.n_embd_head * {"f16": 2, "bf16": 2, "f32": 4, "q8_0": 34 / 32, "q4_0": 18 / 32, "iq4_nl": 18 / 32, "q4_1": 20 / 32, "q5_0": 22 / 32, "q5_1": 24 / 32}[args.ctkv])
         n_past = args.prefill + args.warmup + args.steps // 2
         job_bytes = (w_bytes + args.np * kv_per_tok * n_past) * (tok_s / streams / args.np)
         note_ip = ""

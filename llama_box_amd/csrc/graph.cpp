@@ -695,6 +695,11 @@ static bool follow_qkv_chain(const exec_state & st, int start, int limit, qkv_ch
         }
         break;
     }
+    // the chain ends in front of a consumer it cannot absorb (e.g. the SET_ROWS of a cache kept in another type, kv_types.hip): trailing views are not
+    // part of it — they do nothing, and counting them would stretch the fused window over nodes that sit between them (SET_ROWS(k) in front of
+    // V's reshape) and make try_fuse_qkv give up
+    while (ch.nodes.size() > 1 && is_view_op(g->nodes[ch.nodes.back()]) && g->nodes[ch.nodes.back()] != ch.rope) ch.nodes.pop_back();
+    cur = g->nodes[ch.nodes.back()];
     ch.out_f32 = cur;
     return ggml_abi_is_contiguous(cur) && cur->type == GGML_TYPE_F32;
 }
@@ -1666,7 +1671,20 @@ static int run_node(exec_state & st, int i) {
         case GGML_OP_SET_ROWS: {
             timed_scope ts(c, "set_rows", (double) ggml_abi_nbytes(a));
             if (n->type == GGML_TYPE_Q8_0) launch_set_rows_q8_0(s, TD(a), TD(b), TD(n));
-            else if (kv_store_type(n->type)) launch_set_rows_kv(s, TD(a), TD(b), TD(n));
+            else if (kv_store_type(n->type)) {
+                // K and V rows of a step go into their caches through the same indices: SET_ROWS(k), [views], SET_ROWS(v) as ONE launch
+                int j = i + 1;
+                while (j < g->n_nodes && (st.done[j] || is_view_op(g->nodes[j]))) ++j;
+                const ggml_tensor * n2 = j < g->n_nodes ? g->nodes[j] : nullptr;
+                if (fuse && n2 && n2->op == GGML_OP_SET_ROWS && kv_store_type(n2->type) && n2->src[0]->type == GGML_TYPE_F32 && n2->src[1]->type == GGML_TYPE_I64 &&
+                    n2->src[0] != n && !ranges_overlap(n2->src[0], n) && !ranges_overlap(n2, n) && supports_op(n2)) {
+                    launch_set_rows_kv_pair(s, TD(a), TD(b), TD(n), TD(n2->src[0]), TD(n2->src[1]), TD(n2));
+                    mark_done(st, j);
+                    c->st.fused_nodes++;
+                } else {
+                    launch_set_rows_kv(s, TD(a), TD(b), TD(n));
+                }
+            }
             else launch_set_rows(s, TD(a), TD(b), TD(n));
             c->st.kernel_launches++;
             return 1;
@@ -1736,16 +1754,8 @@ static int run_node(exec_state & st, int i) {
                 // K / V kept in another type: expand the views to f16 once (kv_types.hip) and let the f16 kernels read the image
                 char * img = (char *) c->ws + st.aux_off + fa_image_offset(qd, kd, vd);
                 timed_scope ts(c, "kv_image_f16", (double) (ggml_abi_nbytes(k) + ggml_abi_nbytes(v)));
-                if (k->type != GGML_TYPE_F16) {
-                    const size_t kb = kv_image_bytes(kd);
-                    kd = launch_kv_image_f16(s, kd, img);
-                    img += kb;
-                    c->st.kernel_launches++;
-                }
-                if (v->type != GGML_TYPE_F16) {
-                    vd = launch_kv_image_f16(s, vd, img);
-                    c->st.kernel_launches++;
-                }
+                launch_kv_images_f16(s, kd, vd, img);
+                c->st.kernel_launches++;
                 c->st.kv_image_nodes++;
             }
             const tdesc md0 = m ? TD(m) : qd;

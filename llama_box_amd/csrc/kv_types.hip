@@ -244,6 +244,35 @@ template <int TYPE> __global__ void __launch_bounds__(64) k_set_rows_kv(const td
     }
 }
 
+// ... two SET_ROWS in one launch (the K and the V rows of a step): grid.y picks the pair member, the destination type is a run-time switch
+__device__ __forceinline__ void set_rows_block_any(const tdesc & a, const tdesc & idx, const tdesc & d, const int64_t gid) {
+    const int64_t per_row = a.ne[0] / 32;
+    if (gid >= per_row * a.ne[1] * a.ne[2] * a.ne[3]) return;
+    const int64_t row = gid / per_row, blk = gid - row * per_row;
+    const int64_t i01 = row % a.ne[1], i02 = (row / a.ne[1]) % a.ne[2], i03 = row / (a.ne[1] * a.ne[2]);
+    const int64_t i12 = i03 % idx.ne[2], i11 = i02 % idx.ne[1];
+    const int64_t r = *(const int64_t *) (idx.data + i01 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+    float x[32];
+    load_block_f32(a.data + i01 * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3] + blk * 128, x);
+    char * row_out = d.data + r * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3];
+    switch (d.type) {
+        case GGML_TYPE_Q4_0: quantize_block<GGML_TYPE_Q4_0>(x, row_out + blk * 18); break;
+        case GGML_TYPE_Q4_1: quantize_block<GGML_TYPE_Q4_1>(x, row_out + blk * 20); break;
+        case GGML_TYPE_Q5_0: quantize_block<GGML_TYPE_Q5_0>(x, row_out + blk * 22); break;
+        case GGML_TYPE_Q5_1: quantize_block<GGML_TYPE_Q5_1>(x, row_out + blk * 24); break;
+        case GGML_TYPE_IQ4_NL: quantize_block<GGML_TYPE_IQ4_NL>(x, row_out + blk * 18); break;
+        default:  // BF16
+#pragma unroll
+            for (int j = 0; j < 32; ++j) st16(row_out + blk * 64 + 2 * j, f2bf(x[j]));
+            break;
+    }
+}
+__global__ void __launch_bounds__(64) k_set_rows_kv_pair(const tdesc a0, const tdesc i0, const tdesc d0, const tdesc a1, const tdesc i1, const tdesc d1) {
+    const int64_t gid = (int64_t) blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.y == 0) set_rows_block_any(a0, i0, d0, gid);
+    else set_rows_block_any(a1, i1, d1, gid);
+}
+
 // ---- CPY between contiguous tensors: blocks -> f32 and f32 -> blocks (K-shift)
 template <int TYPE> __global__ void __launch_bounds__(64) k_cpy_kv_to_f32(const char * __restrict__ src, float * __restrict__ dst, const int64_t n_blocks) {
     const int64_t i = (int64_t) blockIdx.x * 64 + threadIdx.x;
@@ -267,14 +296,34 @@ template <int TYPE> __global__ void __launch_bounds__(64) k_cpy_f32_to_kv(const 
     }
 }
 
-// ---- the f16 image of a K or V view [D, n_kv, n_kv_head] (any row / head strides) -> rows [n_kv][n_kv_head * D]
-template <int TYPE> __global__ void __launch_bounds__(64) k_kv_image_f16(const tdesc t, uint16_t * __restrict__ out) {
+// ---- the f16 image of a K and / or V view [D, n_kv, n_kv_head] (any row / head strides) -> rows [n_kv][n_kv_head * D].  ONE launch per attention node:
+// grid.y picks the tensor, the type is a run-time switch (uniform over the launch's half)
+__device__ __forceinline__ void dequantize_block_any(const int type, const char * blk, float (&y)[32]) {
+    switch (type) {
+        case GGML_TYPE_Q4_0: dequantize_block<GGML_TYPE_Q4_0>(blk, y); break;
+        case GGML_TYPE_Q4_1: dequantize_block<GGML_TYPE_Q4_1>(blk, y); break;
+        case GGML_TYPE_Q5_0: dequantize_block<GGML_TYPE_Q5_0>(blk, y); break;
+        case GGML_TYPE_Q5_1: dequantize_block<GGML_TYPE_Q5_1>(blk, y); break;
+        case GGML_TYPE_IQ4_NL: dequantize_block<GGML_TYPE_IQ4_NL>(blk, y); break;
+        case GGML_TYPE_Q8_0: dequantize_block<GGML_TYPE_Q8_0>(blk, y); break;
+        case GGML_TYPE_BF16: dequantize_block<GGML_TYPE_BF16>(blk, y); break;
+        default: dequantize_block<GGML_TYPE_F32>(blk, y); break;
+    }
+}
+__device__ __forceinline__ int kv_block_bytes_any(const int type) {
+    return type == GGML_TYPE_F32 ? 128 : type == GGML_TYPE_BF16 ? 64 : type == GGML_TYPE_Q8_0 ? 34 : (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_IQ4_NL) ? 18 : type == GGML_TYPE_Q4_1 ? 20 :
+           type == GGML_TYPE_Q5_0 ? 22 : 24;
+}
+__global__ void __launch_bounds__(64) k_kv_image_f16(const tdesc k, const tdesc v, uint16_t * __restrict__ ko, uint16_t * __restrict__ vo, const int first) {
+    const bool second = (int) blockIdx.y + first == 1;
+    const tdesc & t = second ? v : k;
+    uint16_t * out = second ? vo : ko;
     const int64_t per_head = t.ne[0] / 32, per_cell = per_head * t.ne[2];
     const int64_t i = (int64_t) blockIdx.x * 64 + threadIdx.x;
     if (i >= per_cell * t.ne[1]) return;
     const int64_t cell = i / per_cell, rem = i - cell * per_cell, h = rem / per_head, b = rem - h * per_head;
     float y[32];
-    dequantize_block<TYPE>(t.data + cell * t.nb[1] + h * t.nb[2] + b * kv_block_bytes<TYPE>(), y);
+    dequantize_block_any(t.type, t.data + cell * t.nb[1] + h * t.nb[2] + b * kv_block_bytes_any(t.type), y);
     uint32_t w[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) w[j] = (uint32_t) f2h(y[2 * j]) | ((uint32_t) f2h(y[2 * j + 1]) << 16);
@@ -308,6 +357,11 @@ void launch_set_rows_kv(hipStream_t s, const tdesc & a, const tdesc & idx, const
     const dim3 grid((unsigned) ((n + 63) / 64));
     KV_DISPATCH_STORE(d.type, hipLaunchKernelGGL((k_set_rows_kv<T>), grid, dim3(64), 0, s, a, idx, d))
 }
+void launch_set_rows_kv_pair(hipStream_t s, const tdesc & a0, const tdesc & i0, const tdesc & d0, const tdesc & a1, const tdesc & i1, const tdesc & d1) {
+    const int64_t n0 = (a0.ne[0] / 32) * a0.ne[1] * a0.ne[2] * a0.ne[3], n1 = (a1.ne[0] / 32) * a1.ne[1] * a1.ne[2] * a1.ne[3];
+    if (std::max(n0, n1) <= 0) return;
+    hipLaunchKernelGGL(k_set_rows_kv_pair, dim3((unsigned) ((std::max(n0, n1) + 63) / 64), 2), dim3(64), 0, s, a0, i0, d0, a1, i1, d1);
+}
 void launch_cpy_kv(hipStream_t s, int type, const void * src, void * dst, int64_t n_values, bool to_type) {
     const int64_t n = n_values / 32;
     if (n <= 0) return;
@@ -319,22 +373,7 @@ void launch_cpy_kv(hipStream_t s, int type, const void * src, void * dst, int64_
     }
 }
 size_t kv_image_bytes(const tdesc & t) { return (((size_t) (t.ne[0] * t.ne[1] * t.ne[2]) * sizeof(uint16_t)) + 255) & ~(size_t) 255; }
-// writes the image and returns the descriptor of it (f16, rows [n_kv][n_kv_head * D])
-tdesc launch_kv_image_f16(hipStream_t s, const tdesc & t, void * image) {
-    const int64_t n = (t.ne[0] / 32) * t.ne[1] * t.ne[2];
-    const dim3 grid((unsigned) ((n + 63) / 64));
-    uint16_t * out = (uint16_t *) image;
-    switch (t.type) {
-        case GGML_TYPE_Q4_0: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q4_0>), grid, dim3(64), 0, s, t, out); break;
-        case GGML_TYPE_Q4_1: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q4_1>), grid, dim3(64), 0, s, t, out); break;
-        case GGML_TYPE_Q5_0: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q5_0>), grid, dim3(64), 0, s, t, out); break;
-        case GGML_TYPE_Q5_1: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q5_1>), grid, dim3(64), 0, s, t, out); break;
-        case GGML_TYPE_IQ4_NL: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_IQ4_NL>), grid, dim3(64), 0, s, t, out); break;
-        case GGML_TYPE_Q8_0: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_Q8_0>), grid, dim3(64), 0, s, t, out); break;
-        case GGML_TYPE_BF16: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_BF16>), grid, dim3(64), 0, s, t, out); break;
-        case GGML_TYPE_F32: hipLaunchKernelGGL((k_kv_image_f16<GGML_TYPE_F32>), grid, dim3(64), 0, s, t, out); break;
-        default: MI_ERR("kv_types: type %d has no f16 image", t.type); abort();
-    }
+static tdesc image_desc(const tdesc & t, void * image) {
     tdesc o = t;
     o.data = (char *) image;
     o.type = GGML_TYPE_F16;
@@ -343,6 +382,18 @@ tdesc launch_kv_image_f16(hipStream_t s, const tdesc & t, void * image) {
     o.nb[1] = t.ne[2] * o.nb[2];
     o.nb[3] = t.ne[1] * o.nb[1];
     return o;
+}
+// expands whichever of K / V is not f16 into `image` (K's image first) in ONE launch and rewrites the descriptors to the f16 rows [n_kv][n_kv_head * D]
+void launch_kv_images_f16(hipStream_t s, tdesc & k, tdesc & v, void * image) {
+    const bool do_k = k.type != GGML_TYPE_F16, do_v = v.type != GGML_TYPE_F16;
+    if (!do_k && !do_v) return;
+    uint16_t * ko = (uint16_t *) image;
+    uint16_t * vo = (uint16_t *) ((char *) image + (do_k ? kv_image_bytes(k) : 0));
+    const int64_t nk = do_k ? (k.ne[0] / 32) * k.ne[1] * k.ne[2] : 0, nv = do_v ? (v.ne[0] / 32) * v.ne[1] * v.ne[2] : 0;
+    const dim3 grid((unsigned) ((std::max(nk, nv) + 63) / 64), (do_k && do_v) ? 2 : 1);
+    hipLaunchKernelGGL(k_kv_image_f16, grid, dim3(64), 0, s, k, v, ko, vo, do_k ? 0 : 1);
+    if (do_k) k = image_desc(k, ko);
+    if (do_v) v = image_desc(v, vo);
 }
 
 MI_TU_TOUCH(kv_types)
