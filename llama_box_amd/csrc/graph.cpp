@@ -26,6 +26,18 @@ static bool same_shape(const ggml_tensor * a, const ggml_tensor * b) {
 }
 
 // ------------------------------------------------------------------------------------------------ supports_op
+// MUL_MAT whose src0 is a KV-cache view kept in a block format or bf16 (K.q of the non-flash path with -ctk q8_0 / q4_0 / ...: llama.cpp asks flash
+// attention only of a quantised V): the view is expanded to f16 (kv_types.hip) and the f16 product runs on the image.  Weight matrices of the
+// mat-vec formats (2-D Q8_0 ...) keep their own kernels.
+static bool mm_cache_image_ok(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0];
+    const ggml_tensor * b = op->src[1];
+    if (!a || !b || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(op)) return false;
+    if (!(kv_type_is_block(a->type) || a->type == GGML_TYPE_BF16 || (a->type == GGML_TYPE_Q8_0 && (a->ne[2] > 1 || !rows_contig(a))))) return false;
+    if (a->nb[0] != ggml_abi_type_size(a->type) || (a->ne[0] % 32) != 0 || (a->nb[1] % 2) || (a->nb[2] % 2) || a->ne[3] != 1 || b->ne[3] != 1 || b->nb[0] != 4) return false;
+    return a->ne[2] > 0 && b->ne[2] % a->ne[2] == 0;
+}
+
 // which attention path serves this FLASH_ATTN_EXT node: 0 none (the host keeps it on the CPU backend), 1 the f16 kernels on the cache views in place,
 // 2 the lane-parallel kernel on block_q8_0 K / V, 3 the f16 kernels on an f16 IMAGE of whichever of K / V is kept in another type (kv_types.hip:
 // -ctk / -ctv q4_0, q4_1, q5_0, q5_1, iq4_nl, bf16, f32, mixed pairs, and q8_0 shapes route 2 does not take)
@@ -78,6 +90,7 @@ bool supports_op(const ggml_tensor * op) {
         case GGML_OP_MUL_MAT: {
             if (!a || !b || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(op)) return false;
             if (buffer_is_split(a->buffer)) return split_mul_mat_supported(op);  // -sm row weights: every device computes its rows (split.cpp)
+            if (mm_cache_image_ok(op)) return true;
             if (is_quant(a->type)) {
                 return a->ne[2] == 1 && a->ne[3] == 1 && rows_contig(a) && b->nb[0] == 4 && a->ne[0] % ggml_abi_blck_size(a->type) == 0;
             }
@@ -180,6 +193,9 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             // (and the wide form of the same unit fetches whole groups of 128 columns of a prompt batch)
             p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], (Mc >= 2 && Mc < 32) ? 32 : (Mc >= 33 ? (Mc + 127) / 128 * 128 : Mc)));
             if (Mc >= c->opt.mmq_min_cols && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, 3 * mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc, c->opt.mmq_skinny));  // (x3: up to three sibling matrices share a launch)
+        } else if (n->op == GGML_OP_MUL_MAT && mm_cache_image_ok(n) && !buffer_is_split(n->src[0]->buffer)) {
+            const tdesc a16 = kv_image_desc(TD(n->src[0]), nullptr);
+            p.aux_bytes = std::max(p.aux_bytes, ((mul_mat_f_workspace_bytes(a16, TD(n->src[1])) + 255) & ~(size_t) 255) + kv_image_bytes(a16));
         } else if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_F16) {
             p.aux_bytes = std::max(p.aux_bytes, mul_mat_f_workspace_bytes(TD(n->src[0]), TD(n->src[1])));
             if (c->opt.attn_nf) p.aux_bytes = std::max(p.aux_bytes, attn_nf_list_scratch_bytes(TD(n->src[1]), TD(n->src[0]), nullptr));
@@ -1498,6 +1514,18 @@ static int run_node(exec_state & st, int i) {
         }
 
         case GGML_OP_MUL_MAT: {
+            if (mm_cache_image_ok(n) && !buffer_is_split(a->buffer)) {
+                // K.q over a cache kept in a block format / bf16 (-fa off): the view goes through its f16 image, the product through the f16 kernel
+                tdesc a16 = TD(a), none = TD(a);
+                none.type = GGML_TYPE_F16;  // (launch_kv_images_f16 expands what is not f16: only `a16` here)
+                const size_t off = (mul_mat_f_workspace_bytes(kv_image_desc(a16, nullptr), TD(b)) + 255) & ~(size_t) 255;
+                timed_scope ts(c, "mul_mat_f_kv_image", (double) ggml_abi_nbytes(a));
+                launch_kv_images_f16(s, a16, none, (char *) c->ws + st.aux_off + off);
+                launch_mul_mat_f(s, a16, TD(b), TD(n), (float *) ((char *) c->ws + st.aux_off), off);
+                c->st.kernel_launches += 2;
+                c->st.kv_image_nodes++;
+                return 1;
+            }
             if (!is_quant(a->type) && fuse && c->opt.attn_nf && try_fuse_attn_nf(st, i)) return 1;
             if (!is_quant(a->type) && fuse && c->opt.attn_nf && try_fuse_attn_nf_mma(st, i)) return 1;
             if (!is_quant(a->type)) {

@@ -221,6 +221,7 @@ void launch_set_rows_kv(hipStream_t s, const tdesc & src, const tdesc & idx, con
 void launch_set_rows_kv_pair(hipStream_t s, const tdesc & a0, const tdesc & i0, const tdesc & d0, const tdesc & a1, const tdesc & i1, const tdesc & d1);  // SET_ROWS(k) + SET_ROWS(v), one launch
 void launch_cpy_kv(hipStream_t s, int type, const void * src, void * dst, int64_t n_values, bool to_type);  // contiguous type <-> F32 (K-shift)
 size_t kv_image_bytes(const tdesc & t);
+tdesc kv_image_desc(const tdesc & t, void * image);  // the f16 descriptor launch_kv_images_f16 leaves for this view (no launch)
 void launch_kv_images_f16(hipStream_t s, tdesc & k, tdesc & v, void * image);  // one launch; rewrites the descriptors of the expanded ones
 void launch_argmax(hipStream_t s, const tdesc & src, const tdesc & dst);
 void launch_upload_multi(hipStream_t s, const upload_batch & b);  // up to 8 pinned-host -> device copies in one launch

@@ -383,6 +383,7 @@ static tdesc image_desc(const tdesc & t, void * image) {
     o.nb[3] = t.ne[1] * o.nb[1];
     return o;
 }
+tdesc kv_image_desc(const tdesc & t, void * image) { return image_desc(t, image); }
 // expands whichever of K / V is not f16 into `image` (K's image first) in ONE launch and rewrites the descriptors to the f16 rows [n_kv][n_kv_head * D]
 void launch_kv_images_f16(hipStream_t s, tdesc & k, tdesc & v, void * image) {
     const bool do_k = k.type != GGML_TYPE_F16, do_v = v.type != GGML_TYPE_F16;

@@ -827,11 +827,10 @@ extern "C" struct llm_context * llm_context_new(struct llm_model * m, ggml_backe
                t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1;
     };
     const ggml_type type_k = kv_type_of(c->p.type_k), type_v = kv_type_of(c->p.type_v);
-    // (llama.cpp: a quantised V cache needs flash attention — the non-flash path keeps V transposed, one element per index; this harness asks the same
-    // of K, whose non-flash K.q would be a MUL_MAT over cache blocks)
-    const bool other_kv = type_k != GGML_TYPE_F16 || type_v != GGML_TYPE_F16;
-    if (!kv_type_ok(type_k) || !kv_type_ok(type_v) || (other_kv && !c->p.flash_attn) || (hp.n_embd_head % ggml_blck_size(type_k)) != 0 || (hp.n_embd_head % ggml_blck_size(type_v)) != 0) {
-        fprintf(stderr, "llm_context_new: unsupported KV cache types %d/%d (f32, f16, bf16, q8_0, q4_0, q4_1, iq4_nl, q5_0, q5_1; anything but f16 needs flash_attn)\n", (int) type_k, (int) type_v);
+    // (llama.cpp: a quantised V cache needs flash attention — the non-flash path keeps V transposed, one element per index; K may be of any type there:
+    // K.q is then a MUL_MAT over the cache's blocks)
+    if (!kv_type_ok(type_k) || !kv_type_ok(type_v) || (type_v != GGML_TYPE_F16 && !c->p.flash_attn) || (hp.n_embd_head % ggml_blck_size(type_k)) != 0 || (hp.n_embd_head % ggml_blck_size(type_v)) != 0) {
+        fprintf(stderr, "llm_context_new: unsupported KV cache types %d/%d (f32, f16, bf16, q8_0, q4_0, q4_1, iq4_nl, q5_0, q5_1; a V cache other than f16 needs flash_attn)\n", (int) type_k, (int) type_v);
         delete c;
         return nullptr;
     }

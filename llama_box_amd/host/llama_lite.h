@@ -71,7 +71,7 @@ struct llm_context_params {
     int32_t n_threads;  /* for the external compute function */
     int32_t graph_reuse; /* keep the built graph while the topology key is unchanged */
     int32_t type_k, type_v; /* ggml type of the K / V cache rows (llama-box -ctk / -ctv, engine_param.hpp:51-54): 0 or GGML_TYPE_F16 = f16; GGML_TYPE_Q8_0,
-                               Q4_0, Q4_1, IQ4_NL, Q5_0, Q5_1, BF16; LLM_KV_TYPE_F32 = f32 (anything but f16 needs flash_attn, as a quantised V does in llama.cpp) */
+                               Q4_0, Q4_1, IQ4_NL, Q5_0, Q5_1, BF16; LLM_KV_TYPE_F32 = f32 (a V cache other than f16 needs flash_attn, as in llama.cpp) */
 };
 struct llm_context;
 /* exactly one of backend / compute must be set: backend -> ggml_backend_graph_compute, else the callback

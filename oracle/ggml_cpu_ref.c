@@ -914,6 +914,9 @@ static enum ggml_type vec_dot_type(enum ggml_type t) {
         case GGML_TYPE_F16: return GGML_TYPE_F16;
         case GGML_TYPE_Q8_0: return GGML_TYPE_Q8_0;
         case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: case GGML_TYPE_Q6_K: return GGML_TYPE_Q8_K;
+        case GGML_TYPE_BF16: return GGML_TYPE_BF16;
+        case GGML_TYPE_Q4_0: case GGML_TYPE_Q5_0: case GGML_TYPE_IQ4_NL: return GGML_TYPE_Q8_0; /* (a K cache in these types, -fa off: K.q is a MUL_MAT over cache blocks) */
+        case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_1: return GGML_TYPE_Q8_1;
         default: return GGML_TYPE_COUNT;
     }
 }
@@ -949,6 +952,7 @@ static enum ggml_status op_mul_mat(struct ggml_tensor * dst, int nth) {
                 break;
             case GGML_TYPE_Q8_0: oracle_quantize_row_q8_0((const float *) s, (block_q8_0 *) w, ne10); break;
             case GGML_TYPE_Q8_K: oracle_quantize_row_q8_K((const float *) s, (block_q8_K *) w, ne10); break;
+            case GGML_TYPE_Q8_1: case GGML_TYPE_BF16: (void) oracle_quantize_row(vdt, (const float *) s, w, ne10); break;
             default: abort();
         }
     }
@@ -987,6 +991,16 @@ static enum ggml_status op_mul_mat(struct ggml_tensor * dst, int nth) {
                 else if (src0->type == GGML_TYPE_Q5_K) *d = oracle_vec_dot_q5_K_q8_K(ne00, (const block_q5_K *) a, (const block_q8_K *) w);
                 else *d = oracle_vec_dot_q6_K_q8_K(ne00, (const block_q6_K *) a, (const block_q8_K *) w);
                 break;
+            case GGML_TYPE_Q4_0: *d = vec_dot_q4_0_q8_0(ne00, (const block_q4_0 *) a, (const block_q8_0 *) w); break;
+            case GGML_TYPE_Q5_0: *d = vec_dot_q5_0_q8_0(ne00, (const block_q5_0 *) a, (const block_q8_0 *) w); break;
+            case GGML_TYPE_IQ4_NL: *d = vec_dot_iq4_nl_q8_0(ne00, (const block_iq4_nl *) a, (const block_q8_0 *) w); break;
+            case GGML_TYPE_Q4_1: *d = vec_dot_q4_1_q8_1(ne00, (const block_q4_1 *) a, (const block_q8_1 *) w); break;
+            case GGML_TYPE_Q5_1: *d = vec_dot_q5_1_q8_1(ne00, (const block_q5_1 *) a, (const block_q8_1 *) w); break;
+            case GGML_TYPE_BF16: { /* ggml_vec_dot_bf16 generic */
+                ggml_float s = 0.0;
+                for (int64_t i = 0; i < ne00; ++i) s += (ggml_float) (bf16_to_fp32(((const uint16_t *) a)[i]) * bf16_to_fp32(((const uint16_t *) w)[i]));
+                *d = (float) s;
+            } break;
             default: abort();
         }
     }

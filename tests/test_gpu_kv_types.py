@@ -344,3 +344,66 @@ def test_context_shift_on_kv_cache_types(backend, H, plog, t):
     finally:
         for o in (cc, cg, mc, mg):
             o.free()
+
+
+# ------------------------------------------------------------------------------------------------ -fa off: K.q as a MUL_MAT over cache blocks
+@pytest.mark.parametrize("t", [L.Q8_0, L.Q4_0, L.Q4_1, L.Q5_0, L.Q5_1, L.IQ4_NL, L.BF16])
+@pytest.mark.parametrize("HD,NH,NKV,nq,nkv", [(128, 32, 8, 1, 1024), (128, 28, 4, 5, 300), (64, 8, 2, 40, 512)])
+def test_mul_mat_over_a_k_cache_in_kv_types(backend, H, plog, t, HD, NH, NKV, nq, nkv):
+    """llama-box's default (-fa off) with -ctk <type>: llama.cpp asks flash attention only of a quantised V, so K.q is MUL_MAT(cache view [HD, n_kv, n_head_kv],
+    q [HD, n_q, n_head]).  ggml-cpu quantises q to Q8_0 / Q8_1 and takes block dots; the device expands the view to f16 and runs the f16 product (q rounded
+    to f16, f32 sums).  Against the float64 product over the dequantised cache the kernel must be no further away than the oracle."""
+    rng = np.random.default_rng(t * 17 + NH + nkv + nq)
+    NCTX = nkv + 32
+    q = rng.standard_normal((NH, nq, HD)).astype(np.float32)
+    kf = (rng.standard_normal((nkv, NKV * HD)) * rng.uniform(0.3, 2.0, (nkv, 1))).astype(np.float32)
+    kf[3, :64] = 0.0
+    img0 = backend.stat("kv_image_nodes")
+
+    def build(g):
+        ks = H.ggml_set_rows(g.ctx, g.new(t, [NKV * HD, NCTX]), g.new(L.F32, [NKV * HD, nkv], kf), g.new(L.I64, [nkv], np.arange(nkv, dtype=np.int64)))
+        k = H.ggml_view_3d(g.ctx, ks, HD, nkv, NKV, row_bytes(t, NKV * HD), row_bytes(t, HD), 0)
+        return [H.ggml_mul_mat(g.ctx, k, g.new(L.F32, [HD, nq, NH], q)), ks]
+
+    ref, got = both(build, backend)
+    assert np.array_equal(np.asarray(got[1]), np.asarray(ref[1]))
+    assert backend.stat("kv_image_nodes") == img0 + 1
+    T.compare(f"mul_mat K={NAME[t]} cache view hd={HD} H={NH}/{NKV} nq={nq} nkv={nkv}", got[0], ref[0], max_nmse=1e-3, log=plog)
+    kd = deq(t, ref[1], NCTX * NKV * HD).reshape(NCTX, NKV, HD)[:nkv]
+    exact = np.stack([q[h].astype(np.float64) @ kd[:, h // (NH // NKV)].T for h in range(NH)])  # [NH, nq, nkv]
+    e_gpu, e_cpu = T.nmse(np.asarray(got[0]).reshape(NH, nq, nkv), exact), T.nmse(np.asarray(ref[0]).reshape(NH, nq, nkv), exact)
+    plog(f"    vs the float64 product over the dequantised cache: kernel nmse={e_gpu:.3e}  cpu-oracle nmse={e_cpu:.3e}")
+    assert e_gpu <= 1e-6
+    if L.TYPE_BLCK[t] == 32:
+        assert e_gpu <= e_cpu * 1.01 + 1e-12
+
+
+@pytest.mark.parametrize("tk", [L.Q8_0, L.Q4_0, L.Q5_1, L.IQ4_NL, L.BF16])
+def test_model_logits_without_flash_attention_and_a_k_cache_in_kv_types(backend, H, plog, tk):
+    """-ctk <type> with llama-box's default attention path (-fa off; the V cache stays f16 and transposed): prompt + greedy steps against the oracle."""
+    hp = preset("test-llama", n_head=4, n_head_kv=2, n_embd_head=128)
+    mc = Model(hp, 1234, H.ggml_backend_cpu_buffer_type())
+    mg = Model(hp, 1234, backend.buft)
+    cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=0, type_k=tk, type_v=0)
+    cg = Context(mg, backend=backend, flash_attn=0, type_k=tk, type_v=0)
+    try:
+        rc, ref = cc.decode(PROMPT, range(len(PROMPT)))
+        rc2, got = cg.decode(PROMPT, range(len(PROMPT)))
+        assert rc == 0 and rc2 == 0
+        e = T.nmse(got, ref)
+        plog(f"-fa 0, K={kv_name(tk)} cache, prompt logits: nmse(gpu, cpu)={e:.3e}")
+        assert e <= 1e-3
+        cc.clear(); cg.clear()
+        ids_ref, rows_ref = greedy(cc, PROMPT, 10)
+        ids_got, rows_got = greedy(cg, PROMPT, 10)
+        plog(f"-fa 0, K={kv_name(tk)} greedy ids ref={ids_ref} got={ids_got}")
+        n_same = next((i for i, (a, b) in enumerate(zip(ids_ref, ids_got)) if a != b), len(ids_ref))
+        for i in range(min(n_same + 1, len(rows_ref))):
+            assert T.nmse(rows_got[i], rows_ref[i]) <= 1e-3
+        if n_same < len(ids_ref):
+            r = np.sort(rows_ref[n_same])[::-1]
+            dev = float(np.max(np.abs(rows_got[n_same] - rows_ref[n_same])))
+            assert r[0] - r[1] <= 2 * dev, f"greedy ids diverge at step {n_same} with margin {r[0] - r[1]:.3e} > deviation {dev:.3e}"
+    finally:
+        for o in (cc, cg, mc, mg):
+            o.free()
