@@ -169,10 +169,10 @@ template <int TYPE> __device__ __forceinline__ void dequantize_block(const char 
     } else if constexpr (TYPE == GGML_TYPE_Q8_0) {
         const float d = h2f(ld16(blk));
 #pragma unroll
-        for (int j = 0; j < 32; j += 2) {
-            const uint16_t w = ld16(blk + 2 + j);
-            y[j] = d * (float) (int8_t) (w & 0xFF);
-            y[j + 1] = d * (float) (int8_t) (w >> 8);
+        for (int j = 0; j < 32; j += 4) {
+            const uint32_t w = ld32_a2(blk + 2 + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[j + e] = d * (float) (int8_t) (w >> (8 * e));
         }
     } else {
         constexpr bool OFFSET = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1;
@@ -181,10 +181,12 @@ template <int TYPE> __device__ __forceinline__ void dequantize_block(const char 
         const float m = OFFSET ? h2f(ld16(blk + 2)) : 0.0f;
         const int o = (OFFSET ? 4 : 2) + (FIVE ? 4 : 0);
         uint32_t qh = 0;
-        if (FIVE) qh = (uint32_t) ld16(blk + o - 4) | ((uint32_t) ld16(blk + o - 2) << 16);
+        if (FIVE) qh = ld32_a2(blk + o - 4);
+        // (the 16 nibble bytes as four dwords: blocks are 2-byte aligned, the hardware takes the unaligned dword load)
+        const uint32_t qw[4] = {ld32_a2(blk + o), ld32_a2(blk + o + 4), ld32_a2(blk + o + 8), ld32_a2(blk + o + 12)};
 #pragma unroll
         for (int j = 0; j < 16; j += 2) {
-            const uint16_t w = ld16(blk + o + j);
+            const uint32_t w = (qw[j >> 2] >> (8 * (j & 3))) & 0xFFFFu;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int b = (w >> (8 * e)) & 0xFF;
@@ -298,38 +300,65 @@ template <int TYPE> __global__ void __launch_bounds__(64) k_cpy_f32_to_kv(const 
 
 // ---- the f16 image of a K and / or V view [D, n_kv, n_kv_head] (any row / head strides) -> rows [n_kv][n_kv_head * D].  ONE launch per attention node:
 // grid.y picks the tensor, the type is a run-time switch (uniform over the launch's half)
-__device__ __forceinline__ void dequantize_block_any(const int type, const char * blk, float (&y)[32]) {
-    switch (type) {
-        case GGML_TYPE_Q4_0: dequantize_block<GGML_TYPE_Q4_0>(blk, y); break;
-        case GGML_TYPE_Q4_1: dequantize_block<GGML_TYPE_Q4_1>(blk, y); break;
-        case GGML_TYPE_Q5_0: dequantize_block<GGML_TYPE_Q5_0>(blk, y); break;
-        case GGML_TYPE_Q5_1: dequantize_block<GGML_TYPE_Q5_1>(blk, y); break;
-        case GGML_TYPE_IQ4_NL: dequantize_block<GGML_TYPE_IQ4_NL>(blk, y); break;
-        case GGML_TYPE_Q8_0: dequantize_block<GGML_TYPE_Q8_0>(blk, y); break;
-        case GGML_TYPE_BF16: dequantize_block<GGML_TYPE_BF16>(blk, y); break;
-        default: dequantize_block<GGML_TYPE_F32>(blk, y); break;
-    }
-}
 __device__ __forceinline__ int kv_block_bytes_any(const int type) {
     return type == GGML_TYPE_F32 ? 128 : type == GGML_TYPE_BF16 ? 64 : type == GGML_TYPE_Q8_0 ? 34 : (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_IQ4_NL) ? 18 : type == GGML_TYPE_Q4_1 ? 20 :
            type == GGML_TYPE_Q5_0 ? 22 : 24;
 }
-__global__ void __launch_bounds__(64) k_kv_image_f16(const tdesc k, const tdesc v, uint16_t * __restrict__ ko, uint16_t * __restrict__ vo, const int first) {
+// eight consecutive values (octet o = 0 .. 3) of one block -> f32: what one lane of the image kernel expands (four lanes per block, so that a wave's
+// stores are 64 consecutive 16-byte pieces)
+__device__ __forceinline__ void dequantize_octet_any(const int type, const char * blk, const int o, float (&y)[8]) {
+    if (type == GGML_TYPE_F32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = ((const float *) blk)[8 * o + j];
+        return;
+    }
+    if (type == GGML_TYPE_BF16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = __uint_as_float((uint32_t) ((const uint16_t *) blk)[8 * o + j] << 16);
+        return;
+    }
+    const float d = h2f(ld16(blk));
+    if (type == GGML_TYPE_Q8_0) {
+        const uint32_t w0 = ld32_a2(blk + 2 + 8 * o), w1 = ld32_a2(blk + 6 + 8 * o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = d * (float) (int8_t) (w0 >> (8 * j));
+            y[4 + j] = d * (float) (int8_t) (w1 >> (8 * j));
+        }
+        return;
+    }
+    const bool offset = type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_1, five = type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1;
+    const float m = offset ? h2f(ld16(blk + 2)) : 0.0f;
+    const int qo = (offset ? 4 : 2) + (five ? 4 : 0);
+    const uint32_t qh = five ? ld32_a2(blk + qo - 4) : 0u;
+    // values 8 o .. 8 o + 7: the low (o < 2) or high nibbles of bytes 8 (o & 1) .. 8 (o & 1) + 7
+    const uint32_t w0 = ld32_a2(blk + qo + 8 * (o & 1)), w1 = ld32_a2(blk + qo + 8 * (o & 1) + 4);
+    const int sh = (o >> 1) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int q = (int) (((j < 4 ? w0 : w1) >> (8 * (j & 3) + sh)) & 0x0Fu);
+        if (five) q |= (int) ((qh >> (8 * o + j)) & 1u) << 4;
+        if (type == GGML_TYPE_IQ4_NL) y[j] = d * (float) k_iq4nl_values[q];
+        else if (offset) y[j] = (float) q * d + m;
+        else y[j] = (float) (q - (five ? 16 : 8)) * d;
+    }
+}
+__global__ void __launch_bounds__(256) k_kv_image_f16(const tdesc k, const tdesc v, uint16_t * __restrict__ ko, uint16_t * __restrict__ vo, const int first) {
     const bool second = (int) blockIdx.y + first == 1;
     const tdesc & t = second ? v : k;
     uint16_t * out = second ? vo : ko;
     const int64_t per_head = t.ne[0] / 32, per_cell = per_head * t.ne[2];
-    const int64_t i = (int64_t) blockIdx.x * 64 + threadIdx.x;
+    const int64_t gid = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = gid >> 2;
+    const int o = (int) (gid & 3);
     if (i >= per_cell * t.ne[1]) return;
     const int64_t cell = i / per_cell, rem = i - cell * per_cell, h = rem / per_head, b = rem - h * per_head;
-    float y[32];
-    dequantize_block_any(t.type, t.data + cell * t.nb[1] + h * t.nb[2] + b * kv_block_bytes_any(t.type), y);
-    uint32_t w[16];
+    float y[8];
+    dequantize_octet_any(t.type, t.data + cell * t.nb[1] + h * t.nb[2] + b * kv_block_bytes_any(t.type), o, y);
+    uint32_t w[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) w[j] = (uint32_t) f2h(y[2 * j]) | ((uint32_t) f2h(y[2 * j + 1]) << 16);
-    uint4 * o = (uint4 *) (out + (cell * t.ne[2] + h) * t.ne[0] + b * 32);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+    for (int j = 0; j < 4; ++j) w[j] = (uint32_t) f2h(y[2 * j]) | ((uint32_t) f2h(y[2 * j + 1]) << 16);
+    *(uint4 *) (out + (cell * t.ne[2] + h) * t.ne[0] + b * 32 + 8 * o) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 bool kv_type_is_block(int type) {
@@ -391,8 +420,8 @@ void launch_kv_images_f16(hipStream_t s, tdesc & k, tdesc & v, void * image) {
     uint16_t * ko = (uint16_t *) image;
     uint16_t * vo = (uint16_t *) ((char *) image + (do_k ? kv_image_bytes(k) : 0));
     const int64_t nk = do_k ? (k.ne[0] / 32) * k.ne[1] * k.ne[2] : 0, nv = do_v ? (v.ne[0] / 32) * v.ne[1] * v.ne[2] : 0;
-    const dim3 grid((unsigned) ((std::max(nk, nv) + 63) / 64), (do_k && do_v) ? 2 : 1);
-    hipLaunchKernelGGL(k_kv_image_f16, grid, dim3(64), 0, s, k, v, ko, vo, do_k ? 0 : 1);
+    const dim3 grid((unsigned) ((4 * std::max(nk, nv) + 255) / 256), (do_k && do_v) ? 2 : 1);  // four lanes per block of 32 values
+    hipLaunchKernelGGL(k_kv_image_f16, grid, dim3(256), 0, s, k, v, ko, vo, do_k ? 0 : 1);
     if (do_k) k = image_desc(k, ko);
     if (do_v) v = image_desc(v, vo);
 }
