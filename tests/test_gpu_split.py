@@ -79,6 +79,28 @@ def test_tensor_parallel_model_through_the_split_buffer_type(plog, graphs, fa):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kv,fa", [("q4_0", "1"), ("q5_1", "1"), ("q8_0", "0")])
+def test_tensor_parallel_model_with_a_kv_cache_in_another_type(plog, kv, fa):
+    """-sm row together with -ctk / -ctv <type> (csrc/kv_types.hip under csrc/tp_inproc.cpp): every device stores its heads' rows into its shard of the
+    cache in the block format and reads them through its own f16 image; the graphs still run as tensor parallelism (nothing declined), the logits
+    against the same model and cache type on one device."""
+    env = dict(os.environ, GGML_MI355X_FAKE_DEVICES="2", GGML_MI355X_SPLIT_GRAPHS="1", GPU_MAX_HW_QUEUES="8", SPLIT_FA=fa, SPLIT_KV=kv)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "split_worker.py"), "model"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("SPLIT_JSON ")][-1][len("SPLIT_JSON "):])
+    for c in res["cases"]:
+        ip = c["ip"]
+        plog(f"[split-tp kv={kv} fa={fa}] {c['model']} ftype={c['ftype']} ts={c['ts']}: logits nmse vs oracle {c['nmse_vs_oracle']:.2e} (one device {c['nmse_one_device_vs_oracle']:.2e}), vs one device "
+             f"{c['nmse_vs_one_device']:.2e}; graphs as tensor parallelism {ip['ip_graphs']}, declined {ip['ip_declined']}, cache bytes equal to one device {ip.get('cache_bytes_equal_fraction', 1.0):.4f}")
+        assert all(r_ == 2 * c["n_layer"] for r_ in c["reductions_per_graph"]), c
+        assert c["nmse_vs_oracle"] <= 2e-3 and c["nmse_vs_one_device"] <= 2e-3, c  # (a 4-bit cache re-quantises values that differ in the last bit: level flips, DESIGN.md section 2)
+        assert ip["p2p_timeouts"] == 0, ip
+        if c["ts"][0] == c["ts"][1] and c["model"] == "test-llama-tp":
+            assert ip["devices"] == 2 and ip["ip_graphs"] == 7 and ip["ip_declined"] == 0, ip
+            assert ip.get("cache_bytes_equal_fraction", 1.0) >= 0.97, ip
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fa,threads,order", [("1", "1", ""), ("0", "1", ""), ("1", "0", ""), ("1", "1", "desc")])
 def test_llama3_70b_shard_shapes_on_eight_logical_devices(plog, fa, threads, order):
     """BASELINE config 4 (Llama-3-70B Q4_K_M, --tensor-split 1,1,1,1,1,1,1,1; llama-box/engine_param.hpp:821-842, :902-916) at its REAL per-device
