@@ -96,7 +96,7 @@ typedef int (*ggml_backend_mi355x_graph_key_probe_t)(const struct ggml_cgraph * 
 typedef int (*ggml_backend_mi355x_set_option_t)(ggml_backend_t backend, const char * key, const char * value);
 /* Counters for tests/bench: "graph_launches", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs", "kernel_launches", "fused_nodes",
  * "allreduces", "p2p_allreduces", "p2p_timeouts", "graph_launch_host_ns", "graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits", "graph_key_collisions",
- * "kernel_downloads", "kv_image_nodes", "skinny_launches", "wide_launches", "tiled_launches", "rope_epilogues", "fa_list_launches"; in-process tensor parallel (-sm row, csrc/tp_inproc.cpp):
+ * "kernel_downloads", "kv_image_nodes", "kv_native_nodes", "skinny_launches", "wide_launches", "tiled_launches", "rope_epilogues", "fa_list_launches"; in-process tensor parallel (-sm row, csrc/tp_inproc.cpp):
  * "ip_devices", "ip_graphs", "ip_declined", "ip_plans", "ip_input_copies", "ip_output_copies", "ip_kv_gathers", "ip_kv_scatters", "ip_worker_kernel_launches",
  * "ip_worker_graph_launches", "ip_worker_p2p_timeouts". */
 typedef int64_t (*ggml_backend_mi355x_get_stat_t)(ggml_backend_t backend, const char * key);

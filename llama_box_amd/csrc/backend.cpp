@@ -778,6 +778,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
     if (k == "kernel_downloads") return c->st.kernel_downloads;
     if (k == "kv_image_nodes") return c->st.kv_image_nodes;
+    if (k == "kv_native_nodes") return c->st.kv_native_nodes;
     if (k == "graph_key_host_ns") return c->st.graph_key_host_ns;
     if (k == "graph_compute_host_ns") return c->st.graph_compute_host_ns;
     if (k == "graph_key_fast_hits") return c->st.graph_key_fast_hits;

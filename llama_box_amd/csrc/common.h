@@ -148,6 +148,7 @@ struct stats {
     int64_t graph_key_host_ns = 0;     // replays only: host time from entering graph_compute to calling hipGraphLaunch (recognising the graph)
     int64_t graph_compute_host_ns = 0; // host time inside graph_compute, all paths
     int64_t graph_key_fast_hits = 0;   // replays recognised by comparing against the graph replayed last (no key built, no hash)
+    int64_t kv_native_nodes = 0;       // ... and those whose K / V in such a type were read in place by the lane-parallel kernel's DQ form
     int64_t kv_image_nodes = 0;        // FLASH_ATTN_EXT nodes whose K / V (kept in q4_0, q4_1, q5_0, q5_1, iq4_nl, bf16, f32 ...) were read through an f16 image
     int64_t kernel_downloads = 0;      // get_tensor_async calls served by a copy kernel writing mapped pinned memory
     int64_t graph_early_captures = 0;  // graphs captured at their FIRST sighting (same step as the one replayed last, over a grown cache)

@@ -16,6 +16,7 @@
 
 #include "dev_util.h"
 #include "kernels.h"
+#include "kv_dequant.h"
 
 namespace mi355x {
 
@@ -378,7 +379,12 @@ __device__ __forceinline__ void fa_merge_heads(const float * __restrict__ base0,
 // of visible TILES — round 1 — made every token walk all of them: 10 us at the first step, 24 us sixty steps later).
 // WV = waves per workgroup: 4 (many thin splits + combine pass) or 8 (few fat splits whose partials the wo mat-vec prologue combines:
 // mmvq.hip PRO 3; 16 waves would cap the kernel at 128 VGPRs, and it needs ~200: the first 16-wave build spilled and ran 2x slower)
-template <int G, int MODE, bool Q8, int WV = 4>
+// KVT != 0 (round 5): K and V live in ANOTHER cache type, both the same one of q4_0, q4_1, q5_0, q5_1 (KVT = its ggml type): a lane fetches the raw bytes of
+// its eight dims of the row's block (kv_dequant.h: 8 nibble bytes + scale [+ minimum, fifth bits] — four dwords that stay in registers while the
+// loads fly) and expands them to packed f16 where the f16 cache's values are consumed (byte permutes + one packed subtract + one packed multiply);
+// everything else is the f16 path.  Same values as the f16 image of kv_types.hip (q4_0 / q5_0: bit for bit; the offset formats within half an ulp),
+// without its pass over the cache.  A first form with the type as a RUN-TIME switch (any pair of types) lost to the image: 29 us against 12.8 + 9.2.
+template <int G, int MODE, bool Q8, int WV = 4, int KVT = 0>
 __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
                                                       const tdesc dst, const fa_geom geo, float * __restrict__ ws, const int g_real,
                                                       const int * __restrict__ lists, const int list_stride) {
@@ -386,7 +392,9 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     constexpr int D = 128, NG = 16 / G;
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr int TRIP = NG * WV * 4;  // positions per trip
-    static_assert(WV == 4 || !Q8, "the eight-wave forms serve an f16 cache only");
+    constexpr bool DQ = KVT != 0;
+    static_assert(WV == 4 || (!Q8 && !DQ), "the eight-wave forms serve an f16 cache only");
+    static_assert(!(Q8 && DQ), "q8_0 has its own integer path");
     // FAT: one decode token, a few fat splits whose records the wo mat-vec's prologue merges (records also for ONE split, no Q8_K output)
     constexpr bool FAT = WV == 8 && MODE == 0;
     __shared__ float sh[WV][G][D + 2];
@@ -462,8 +470,8 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     }
     if (!empty) {
     const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
-    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + (Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
-    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + (Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
+    const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + (DQ ? (sl >> 2) * kv_block_bytes_t<KVT>() : Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
+    const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + (DQ ? (sl >> 2) * kv_block_bytes_t<KVT>() : Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
 
     // a trip covers NG*16 consecutive positions: position of (u, wave, sub) = p0 + u*16 + wave*4 + sub
     uint4 kraw[NG], vraw[NG];
@@ -477,7 +485,10 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             const int pc = LIST ? (pr_ < kv1 ? nidx[u] : first) : min(pr_, kv1 - 1);    \
             const char * kp_ = kbase + (int64_t) pc * k.nb[1];                          \
             const char * vp_ = vbase + (int64_t) pc * v.nb[1];                          \
-            if constexpr (Q8) {  /* 8 quants (2-byte aligned) + the block's f16 scale */  \
+            if constexpr (DQ) {  /* the raw octet of this lane's block, whatever the type */ \
+                kraw[u] = kv_load_octet_raw_t<KVT>(kp_, sl & 3);                        \
+                vraw[u] = kv_load_octet_raw_t<KVT>(vp_, sl & 3);                        \
+            } else if constexpr (Q8) {  /* 8 quants (2-byte aligned) + the block's f16 scale */  \
                 kraw[u] = make_uint4(ld32_a2(kp_), ld32_a2(kp_ + 4), (uint32_t) ld16(kp_ - 2 - (sl & 3) * 8), 0u);  \
                 vraw[u] = make_uint4(ld32_a2(vp_), ld32_a2(vp_ + 4), (uint32_t) ld16(vp_ - 2 - (sl & 3) * 8), 0u);  \
             } else {                                                                    \
@@ -581,7 +592,11 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         float vf[NG][8];
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
-            const uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
+            uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
+            if constexpr (DQ) {  // expand the raw octets to the f16 values an f16 cache would hold here
+                kv_octet_f16_t<KVT>(kraw[u], sl & 3, ku);
+                kv_octet_f16_t<KVT>(vraw[u], sl & 3, vu);
+            }
             if constexpr (Q8) {
                 const float dv = h2f((uint16_t) vu[2]), dk = h2f((uint16_t) ku[2]);
 #pragma unroll
@@ -1097,6 +1112,21 @@ void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv
     else hipLaunchKernelGGL(k_fattn_pos_scan<false>, dim3((unsigned) n_q), dim3(256), 0, s, mask, n_kv, lists, n_kv + 1);
 }
 
+// K / V kept in another cache type: can the lane-parallel kernel read them in place (its KVT form)?  The shapes of that kernel (head_dim 128, 2 / 4 / 7 / 8
+// query heads per KV head, no soft-capping / ALiBi, up to 32 query tokens — bigger batches go to the matrix cores over the f16 image), K and V in the same
+// one of the integer-level formats, 2-byte-aligned strides; everything else (iq4_nl, bf16, f32, mixed pairs, head_dim 64) goes through the image
+static bool dq_type_ok(int t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1; }
+bool fattn_native_kv_ok(const tdesc & q, const tdesc & k, const tdesc & v, const fattn_params & p) {
+    static const bool on = !getenv("GGML_MI355X_FA_NATIVE_KV") || atoi(getenv("GGML_MI355X_FA_NATIVE_KV")) != 0;
+    if (!on || !dq_type_ok(k.type) || v.type != k.type || k.ne[0] != 128 || v.ne[0] != 128 || k.ne[2] <= 0 || q.ne[2] % k.ne[2] != 0) return false;
+    const int G = (int) (q.ne[2] / k.ne[2]);
+    if (!(G == 2 || G == 4 || G == 7 || G == 8) || p.logit_softcap != 0.0f || p.max_bias != 0.0f || q.ne[1] > 32 || p.n_splits < 1) return false;
+    if ((q.nb[1] % 16) != 0 || (q.nb[2] % 16) != 0 || ((uintptr_t) q.data & 15) != 0) return false;
+    for (const tdesc * t : {&k, &v})
+        if ((t->nb[1] % 2) || (t->nb[2] % 2) || (t->nb[3] % 2) || ((uintptr_t) t->data % 2)) return false;
+    return true;
+}
+
 // will launch_flash_attn end in the quantising combine pass for these arguments? (mirrors its dispatch)
 bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const float * sinks, const tdesc & dst, const fattn_params & p) {
     if (k.ne[0] != 128 || (q.ne[2] % 2) != 0 || p.n_splits < 1 || q.ne[3] != 1 || k.ne[2] <= 0) return false;
@@ -1109,7 +1139,7 @@ bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
                        const fattn_params & p, void * workspace) {
     const bool q8 = p.kv_type == GGML_TYPE_Q8_0;
-    if (!q8 && !p.lists && launch_flash_attn_mma(s, q, k, v, mask, sinks, dst, p, workspace)) return;  // (lists set: the caller chose the position-list form)
+    if (!q8 && !p.dq && !p.lists && launch_flash_attn_mma(s, q, k, v, mask, sinks, dst, p, workspace)) return;  // (lists set: the caller chose the position-list form)
     if (fattn_q8_via_f16(q, p.kv_type) && k.ne[3] == 1 && v.ne[3] == 1 && flash_attn_mma_applies(q, k, mask, sinks, dst, p)) {
         // a prompt batch over the quantised cache: the CPU quantises each query row to Q8_0 and takes integer block dots; here
         // the cells are expanded to f16 once (exact up to the f16 rounding of d * q) and the f16 matrix-core kernel runs on
@@ -1155,7 +1185,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, (unsigned) (geo.n_q * q.ne[3]));
         if (p.fat) {
             // one decode token, few fat splits on 8-wave workgroups; the partial records stay in the workspace for the wo prologue
-            if (q8 || geo.n_q != 1 || q.ne[3] != 1 || sinks != nullptr) { MI_ERR("launch_flash_attn: fat-split form requested for a case it does not serve"); abort(); }
+            if (q8 || p.dq || geo.n_q != 1 || q.ne[3] != 1 || sinks != nullptr) { MI_ERR("launch_flash_attn: fat-split form requested for a case it does not serve"); abort(); }
             geo.rec_stride = FA_REC;
             if (G == 2) hipLaunchKernelGGL((k_fattn_dec128<2, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
             else if (G == 4) hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
@@ -1168,6 +1198,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         // p.lists set: the caller has run (or re-used) k_fattn_pos_scan for this mask (fattn_list_tile() said the list form applies)
         const bool list = p.lists != nullptr;
         const int lstride = geo.n_kv + 1;
+        const bool dq = p.dq != 0;
         const bool skip = !list && skip_on && geo.n_q > 1 && (geo.n_q <= 64 || q8) && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
                           (mask->nb[3] % 8) == 0 && ((uintptr_t) mask->data & 7) == 0 && geo.n_splits > 1;
         // one decode token over an f16 cache: eight waves per workgroup (a trip covers 128 cells: splits of up to 128 cells are ONE trip)
@@ -1178,14 +1209,23 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         // (one launch instead of two); Q8_K output needs whole head pairs inside a kv group.  merge2 (round 4): the one-round-trip merge,
         // for the plain form (no lists, no trip skipping) with f32 output and at most 32 splits, on four or eight waves
         const bool self_merge = geo.n_splits > 1 && p.arrive != nullptr && (int64_t) geo.n_q * q.ne[3] * geo.n_kv_head <= (int64_t) p.arrive_slots && !(p.q8_out && (G & 1));
-        const bool merge2 = self_merge && !list && !skip && !q8 && p.q8_out == nullptr && geo.n_splits <= 32;
-        const bool list8 = list_wv8 && list && !q8 && !p.arrive;
-        const bool wide8 = wv8 && !q8 && !list && !skip && geo.n_q == 1 && geo.n_splits > 1 && (!p.arrive || merge2);
+        const bool merge2 = self_merge && !list && !skip && !q8 && !dq && p.q8_out == nullptr && geo.n_splits <= 32;
+        const bool list8 = list_wv8 && list && !q8 && !dq && !p.arrive;
+        const bool wide8 = wv8 && !q8 && !dq && !list && !skip && geo.n_q == 1 && geo.n_splits > 1 && (!p.arrive || merge2);
+#define FA_DEC_T(GG, TT)                                                                                                                    \
+    {                                                                                                                                       \
+        if (list) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, false, 4, TT>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride);  \
+        else if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, 1, false, 4, TT>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);   \
+        else hipLaunchKernelGGL((k_fattn_dec128<GG, 0, false, 4, TT>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);             \
+    }
 #define FA_DEC(GG)                                                                                                                          \
     {                                                                                                                                       \
         if (wide8) hipLaunchKernelGGL((k_fattn_dec128<GG, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);           \
         else if (list8) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride); \
-        else if (q8) {                                                                                                                           \
+        else if (dq) {                                                                                                                           \
+            if (k.type == GGML_TYPE_Q4_0) FA_DEC_T(GG, GGML_TYPE_Q4_0) else if (k.type == GGML_TYPE_Q4_1) FA_DEC_T(GG, GGML_TYPE_Q4_1)               \
+            else if (k.type == GGML_TYPE_Q5_0) FA_DEC_T(GG, GGML_TYPE_Q5_0) else FA_DEC_T(GG, GGML_TYPE_Q5_1)                                        \
+        } else if (q8) {                                                                                                                         \
             if (list) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride);      \
             else if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, 1, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);       \
             else hipLaunchKernelGGL((k_fattn_dec128<GG, 0, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);                 \
@@ -1200,8 +1240,13 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         geo.q8 = (self_merge || (geo.n_splits == 1 && !(G & 1))) ? p.q8_out : nullptr;
         if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
 #undef FA_DEC
+#undef FA_DEC_T
         if (geo.n_splits > 1 && !self_merge) launch_flash_attn_combine(s, 128, ws, sinks, dst, geo.n_q, geo.n_head, (int) q.ne[3], geo.n_splits, p.q8_out);
         return;
+    }
+    if (p.dq) {
+        MI_ERR("launch_flash_attn: K / V in another cache type reached the generic kernel (head_dim %d, group %d) — fattn_native_kv_ok should have refused it", D, G);
+        abort();
     }
     if (q8) {
         MI_ERR("launch_flash_attn: q8_0 K/V reached the generic kernel (head_dim %d, group %d) — supports_op should have refused it", D, G);

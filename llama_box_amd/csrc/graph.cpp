@@ -1777,7 +1777,19 @@ static int run_node(exec_state & st, int i) {
             p.logit_softcap = ggml_abi_op_param_f32(n, 2);
             const tdesc qd = TD(a);
             tdesc kd = TD(k), vd = TD(v);
-            const bool imaged = fa_route(n) == 3;
+            bool imaged = fa_route(n) == 3;
+            bool native_kv = false;
+            if (imaged) {  // decode-sized batches at the lane-parallel kernel's shapes read the cache IN PLACE (fattn.hip: the DQ form); everything else through the image
+                fattn_params probe{};
+                probe.logit_softcap = ggml_abi_op_param_f32(n, 2);
+                probe.max_bias = ggml_abi_op_param_f32(n, 1);
+                probe.n_splits = 1;
+                native_kv = fattn_native_kv_ok(qd, kd, vd, probe);
+                if (native_kv) {
+                    imaged = false;
+                    c->st.kv_native_nodes++;
+                }
+            }
             if (imaged) {
                 // K / V kept in another type: expand the views to f16 once (kv_types.hip) and let the f16 kernels read the image
                 char * img = (char *) c->ws + st.aux_off + fa_image_offset(qd, kd, vd);
@@ -1789,7 +1801,8 @@ static int run_node(exec_state & st, int i) {
             const tdesc md0 = m ? TD(m) : qd;
             p.mask_sparse = fa_mask_hint(n);
             p.n_splits = std::min(64, c->opt.fa_splits > 0 ? c->opt.fa_splits : fattn_pick_splits(qd, kd, m ? &md0 : nullptr, p.mask_sparse));
-            p.kv_type = imaged ? (int) GGML_TYPE_F16 : (int) k->type;
+            p.kv_type = (imaged || native_kv) ? (int) GGML_TYPE_F16 : (int) k->type;
+            p.dq = native_kv ? 1 : 0;
             if (c->opt.fa_self_merge && c->fa_arrive) {
                 p.arrive = c->fa_arrive;
                 p.arrive_slots = backend_ctx::fa_arrive_slots;
@@ -1821,7 +1834,7 @@ static int run_node(exec_state & st, int i) {
             }
             // one decode token whose attention result goes (through a reshape) straight into a quantised mat-vec — wo: few fat splits on
             // 8-wave workgroups, and the merge of their partial records is that mat-vec's prologue; the combine launch disappears
-            if (fuse && c->opt.fa_wo && c->opt.prologue && c->opt.fa_splits == 0 && a->ne[1] == 1 && a->ne[3] == 1 && !p.lists && !p.tile_vis && use_count(st, n) == 1 &&
+            if (fuse && c->opt.fa_wo && !native_kv && c->opt.prologue && c->opt.fa_splits == 0 && a->ne[1] == 1 && a->ne[3] == 1 && !p.lists && !p.tile_vis && use_count(st, n) == 1 &&
                 !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(n) && (((uintptr_t) n->data) & 15) == 0) {
                 const int S = fattn_fat_splits(qd, kd, m ? &md : nullptr, n->src[4] ? (const float *) n->src[4]->data : nullptr, p);
                 int j = i + 1;

@@ -274,6 +274,8 @@ struct fattn_params {
     int fat = 0;   // 1: single-token decode as a few fat splits on 8-wave workgroups, records FA_REC apart, NO combine pass (the wo
                    // mat-vec prologue merges them: mmvq_args::fa_part); see fattn_fat_splits()
     int kv_type;   // GGML_TYPE_F16 or GGML_TYPE_Q8_0 (K and V alike)
+    int dq = 0;    // 1: K / V are read IN PLACE in another cache type (tdesc::type each: q4_0, q4_1, q5_0, q5_1, iq4_nl, bf16, q8_0, f16) by the lane-parallel kernel's
+                   // DQ form — the caller asked fattn_native_kv_ok() first; kv_type is GGML_TYPE_F16 then (everything but the fetch is the f16 path)
     const int * lists = nullptr;  // per-token lists of visible cache positions (launch_fattn_tile_scan), or nullptr
     void * q8_out = nullptr;  // the result's only readers are quantised mat-muls (wo of a batch): leave it as Q8_K blocks here — honoured by
                               // the combine pass of the head_dim-128 kernels (n_splits > 1), see fattn_q8_out_ok()
@@ -288,6 +290,7 @@ bool attn_nf_mma_applies(const tdesc & q, const tdesc & k, const tdesc & vt, con
 size_t attn_nf_mma_ws_bytes(const tdesc & q, int n_splits);
 void launch_attn_nf_mma(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & vt, const tdesc & mask, const tdesc & dst, float scale, int n_splits, const uint8_t * tile_vis, void * workspace,
                         void * q8_out = nullptr);
+bool fattn_native_kv_ok(const tdesc & q, const tdesc & k, const tdesc & v, const fattn_params & p);  // may launch_flash_attn read this K / V pair in place (p.dq = 1)?
 bool fattn_combine_rows_applies(int D, int64_t n_q, int64_t n_head, int64_t n_batch, int n_splits, const float * sinks);  // the row-parallel combine pass (prompt micro-batches)
 size_t fattn_vis_bytes(const tdesc & q, const tdesc & k);
 void launch_fattn_vis_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv, uint8_t * vis);

@@ -13,10 +13,9 @@
 #include "common.h"
 #include "dev_util.h"
 #include "kernels.h"
+#include "kv_dequant.h"
 
 namespace mi355x {
-
-__device__ static const int8_t k_iq4nl_values[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
 
 __device__ __forceinline__ uint16_t f2bf(const float f) {  // ggml_compute_fp32_to_bf16: nearest even, NaN kept quiet
     const uint32_t u = __float_as_uint(f);
@@ -300,49 +299,6 @@ template <int TYPE> __global__ void __launch_bounds__(64) k_cpy_f32_to_kv(const 
 
 // ---- the f16 image of a K and / or V view [D, n_kv, n_kv_head] (any row / head strides) -> rows [n_kv][n_kv_head * D].  ONE launch per attention node:
 // grid.y picks the tensor, the type is a run-time switch (uniform over the launch's half)
-__device__ __forceinline__ int kv_block_bytes_any(const int type) {
-    return type == GGML_TYPE_F32 ? 128 : type == GGML_TYPE_BF16 ? 64 : type == GGML_TYPE_Q8_0 ? 34 : (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_IQ4_NL) ? 18 : type == GGML_TYPE_Q4_1 ? 20 :
-           type == GGML_TYPE_Q5_0 ? 22 : 24;
-}
-// eight consecutive values (octet o = 0 .. 3) of one block -> f32: what one lane of the image kernel expands (four lanes per block, so that a wave's
-// stores are 64 consecutive 16-byte pieces)
-__device__ __forceinline__ void dequantize_octet_any(const int type, const char * blk, const int o, float (&y)[8]) {
-    if (type == GGML_TYPE_F32) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = ((const float *) blk)[8 * o + j];
-        return;
-    }
-    if (type == GGML_TYPE_BF16) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = __uint_as_float((uint32_t) ((const uint16_t *) blk)[8 * o + j] << 16);
-        return;
-    }
-    const float d = h2f(ld16(blk));
-    if (type == GGML_TYPE_Q8_0) {
-        const uint32_t w0 = ld32_a2(blk + 2 + 8 * o), w1 = ld32_a2(blk + 6 + 8 * o);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            y[j] = d * (float) (int8_t) (w0 >> (8 * j));
-            y[4 + j] = d * (float) (int8_t) (w1 >> (8 * j));
-        }
-        return;
-    }
-    const bool offset = type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_1, five = type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1;
-    const float m = offset ? h2f(ld16(blk + 2)) : 0.0f;
-    const int qo = (offset ? 4 : 2) + (five ? 4 : 0);
-    const uint32_t qh = five ? ld32_a2(blk + qo - 4) : 0u;
-    // values 8 o .. 8 o + 7: the low (o < 2) or high nibbles of bytes 8 (o & 1) .. 8 (o & 1) + 7
-    const uint32_t w0 = ld32_a2(blk + qo + 8 * (o & 1)), w1 = ld32_a2(blk + qo + 8 * (o & 1) + 4);
-    const int sh = (o >> 1) * 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        int q = (int) (((j < 4 ? w0 : w1) >> (8 * (j & 3) + sh)) & 0x0Fu);
-        if (five) q |= (int) ((qh >> (8 * o + j)) & 1u) << 4;
-        if (type == GGML_TYPE_IQ4_NL) y[j] = d * (float) k_iq4nl_values[q];
-        else if (offset) y[j] = (float) q * d + m;
-        else y[j] = (float) (q - (five ? 16 : 8)) * d;
-    }
-}
 __global__ void __launch_bounds__(256) k_kv_image_f16(const tdesc k, const tdesc v, uint16_t * __restrict__ ko, uint16_t * __restrict__ vo, const int first) {
     const bool second = (int) blockIdx.y + first == 1;
     const tdesc & t = second ? v : k;
@@ -353,11 +309,17 @@ __global__ void __launch_bounds__(256) k_kv_image_f16(const tdesc k, const tdesc
     const int o = (int) (gid & 3);
     if (i >= per_cell * t.ne[1]) return;
     const int64_t cell = i / per_cell, rem = i - cell * per_cell, h = rem / per_head, b = rem - h * per_head;
-    float y[8];
-    dequantize_octet_any(t.type, t.data + cell * t.nb[1] + h * t.nb[2] + b * kv_block_bytes_any(t.type), o, y);
+    const char * blk = t.data + cell * t.nb[1] + h * t.nb[2] + b * kv_block_bytes_any(t.type);
     uint32_t w[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = (uint32_t) f2h(y[2 * j]) | ((uint32_t) f2h(y[2 * j + 1]) << 16);
+    if (t.type == GGML_TYPE_F32) {  // (eight dwords: not an octet the shared helpers carry)
+        const float4 lo = ((const float4 *) blk)[2 * o], hi = ((const float4 *) blk)[2 * o + 1];
+        w[0] = (uint32_t) f2h(lo.x) | ((uint32_t) f2h(lo.y) << 16);
+        w[1] = (uint32_t) f2h(lo.z) | ((uint32_t) f2h(lo.w) << 16);
+        w[2] = (uint32_t) f2h(hi.x) | ((uint32_t) f2h(hi.y) << 16);
+        w[3] = (uint32_t) f2h(hi.z) | ((uint32_t) f2h(hi.w) << 16);
+    } else {
+        kv_octet_f16(t.type, kv_load_octet_raw(t.type, blk, o), o, w);
+    }
     *(uint4 *) (out + (cell * t.ne[2] + h) * t.ne[0] + b * 32 + 8 * o) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
