@@ -379,7 +379,7 @@ __device__ __forceinline__ void fa_merge_heads(const float * __restrict__ base0,
 // of visible TILES — round 1 — made every token walk all of them: 10 us at the first step, 24 us sixty steps later).
 // WV = waves per workgroup: 4 (many thin splits + combine pass) or 8 (few fat splits whose partials the wo mat-vec prologue combines:
 // mmvq.hip PRO 3; 16 waves would cap the kernel at 128 VGPRs, and it needs ~200: the first 16-wave build spilled and ran 2x slower)
-// KVT != 0 (round 5): K and V live in ANOTHER cache type, both the same one of q4_0, q4_1, q5_0, q5_1 (KVT = its ggml type): a lane fetches the raw bytes of
+// KVT != 0 (round 5): K and V live in ANOTHER cache type, both the same one of q4_0, q4_1, q5_0, q5_1, iq4_nl (KVT = its ggml type): a lane fetches the raw bytes of
 // its eight dims of the row's block (kv_dequant.h: 8 nibble bytes + scale [+ minimum, fifth bits] — four dwords that stay in registers while the
 // loads fly) and expands them to packed f16 where the f16 cache's values are consumed (byte permutes + one packed subtract + one packed multiply);
 // everything else is the f16 path.  Same values as the f16 image of kv_types.hip (q4_0 / q5_0: bit for bit; the offset formats within half an ulp),
@@ -1115,7 +1115,7 @@ void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv
 // K / V kept in another cache type: can the lane-parallel kernel read them in place (its KVT form)?  The shapes of that kernel (head_dim 128, 2 / 4 / 7 / 8
 // query heads per KV head, no soft-capping / ALiBi, up to 32 query tokens — bigger batches go to the matrix cores over the f16 image), K and V in the same
 // one of the integer-level formats, 2-byte-aligned strides; everything else (iq4_nl, bf16, f32, mixed pairs, head_dim 64) goes through the image
-static bool dq_type_ok(int t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1; }
+static bool dq_type_ok(int t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL; }
 bool fattn_native_kv_ok(const tdesc & q, const tdesc & k, const tdesc & v, const fattn_params & p) {
     static const bool on = !getenv("GGML_MI355X_FA_NATIVE_KV") || atoi(getenv("GGML_MI355X_FA_NATIVE_KV")) != 0;
     if (!on || !dq_type_ok(k.type) || v.type != k.type || k.ne[0] != 128 || v.ne[0] != 128 || k.ne[2] <= 0 || q.ne[2] % k.ne[2] != 0) return false;
@@ -1224,7 +1224,8 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         else if (list8) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride); \
         else if (dq) {                                                                                                                           \
             if (k.type == GGML_TYPE_Q4_0) FA_DEC_T(GG, GGML_TYPE_Q4_0) else if (k.type == GGML_TYPE_Q4_1) FA_DEC_T(GG, GGML_TYPE_Q4_1)               \
-            else if (k.type == GGML_TYPE_Q5_0) FA_DEC_T(GG, GGML_TYPE_Q5_0) else FA_DEC_T(GG, GGML_TYPE_Q5_1)                                        \
+            else if (k.type == GGML_TYPE_Q5_0) FA_DEC_T(GG, GGML_TYPE_Q5_0) else if (k.type == GGML_TYPE_Q5_1) FA_DEC_T(GG, GGML_TYPE_Q5_1)           \
+            else FA_DEC_T(GG, GGML_TYPE_IQ4_NL)                                                                                                  \
         } else if (q8) {                                                                                                                         \
             if (list) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride);      \
             else if (skip) hipLaunchKernelGGL((k_fattn_dec128<GG, 1, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);       \

@@ -71,18 +71,18 @@ __device__ __forceinline__ void kv_octet_f16(const int type, const uint4 raw, co
     for (int j = 0; j < 4; ++j) h[j] = (uint32_t) f2h(y[2 * j]) | ((uint32_t) f2h(y[2 * j + 1]) << 16);
 }
 
-// ---- compile-time forms for the decode attention kernel (fattn.hip, KVT): the formats whose levels are plain integers (q4_0, q4_1, q5_0, q5_1).
+// ---- compile-time forms for the decode attention kernel (fattn.hip, KVT): q4_0, q4_1, q5_0, q5_1 (levels are plain integers) and iq4_nl (a 16-entry table).
 // 0x6400 | n is the f16 number 1024 + n: the eight levels of an octet become packed f16 with two byte permutes per dword, one packed subtraction
 // (1024 + n - (1024 + 8) = n - 8, exact) and one packed multiply by the block's f16 scale — ONE rounding of the exact product, the number
 // f2h((float) level * d) is; the offset formats take a packed fma (level * d + m rounded once: within half an f16 ulp of the image's f32 sum).
 typedef _Float16 kv_half2 __attribute__((ext_vector_type(2)));
 template <int T> __device__ __forceinline__ uint4 kv_load_octet_raw_t(const char * blk, const int o) {
-    if constexpr (T == GGML_TYPE_Q4_0) return make_uint4(ld32_a2(blk + 2 + 8 * (o & 1)), ld32_a2(blk + 6 + 8 * (o & 1)), (uint32_t) ld16(blk), 0u);
+    if constexpr (T == GGML_TYPE_Q4_0 || T == GGML_TYPE_IQ4_NL) return make_uint4(ld32_a2(blk + 2 + 8 * (o & 1)), ld32_a2(blk + 6 + 8 * (o & 1)), (uint32_t) ld16(blk), 0u);
     else if constexpr (T == GGML_TYPE_Q4_1) return make_uint4(ld32_a2(blk + 4 + 8 * (o & 1)), ld32_a2(blk + 8 + 8 * (o & 1)), ld32_a2(blk), 0u);
     else if constexpr (T == GGML_TYPE_Q5_0) return make_uint4(ld32_a2(blk + 6 + 8 * (o & 1)), ld32_a2(blk + 10 + 8 * (o & 1)), (uint32_t) ld16(blk), ld32_a2(blk + 2));
     else return make_uint4(ld32_a2(blk + 8 + 8 * (o & 1)), ld32_a2(blk + 12 + 8 * (o & 1)), ld32_a2(blk), ld32_a2(blk + 4));  // Q5_1
 }
-template <int T> __device__ __forceinline__ constexpr int kv_block_bytes_t() { return T == GGML_TYPE_Q4_0 ? 18 : T == GGML_TYPE_Q4_1 ? 20 : T == GGML_TYPE_Q5_0 ? 22 : 24; }
+template <int T> __device__ __forceinline__ constexpr int kv_block_bytes_t() { return (T == GGML_TYPE_Q4_0 || T == GGML_TYPE_IQ4_NL) ? 18 : T == GGML_TYPE_Q4_1 ? 20 : T == GGML_TYPE_Q5_0 ? 22 : 24; }
 template <int T> __device__ __forceinline__ void kv_octet_f16_t(const uint4 raw, const int o, uint32_t (&h)[4]) {
     constexpr bool OFFSET = T == GGML_TYPE_Q4_1 || T == GGML_TYPE_Q5_1, FIVE = T == GGML_TYPE_Q5_0 || T == GGML_TYPE_Q5_1;
     const int sh = (o >> 1) * 4;
@@ -92,12 +92,21 @@ template <int T> __device__ __forceinline__ void kv_octet_f16_t(const uint4 raw,
         t0 |= (((b & 0xFu) * 0x00204081u) & 0x01010101u) << 4;
         t1 |= ((((b >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) << 4;
     }
+    if constexpr (T == GGML_TYPE_IQ4_NL) {
+        // the 16 non-linear levels through two 8-entry byte tables (level + 128, so that the byte is unsigned): a byte permute looks four nibbles up at once,
+        // bit 3 of each nibble picks the table; 1024 + (level + 128) - 1152 = level, exact
+        constexpr uint32_t A0 = 0x3F2D1801u, A1 = 0x766A5D4Fu, B0 = 0xA6998D81u, B1 = 0xF1D9C5B5u;  // {1, 24, 45, 63 | 79, 93, 106, 118 || 129, 141, 153, 166 | 181, 197, 217, 241}
+        const uint32_t s0 = t0 & 0x07070707u, s1 = t1 & 0x07070707u;
+        const uint32_t m0 = ((t0 >> 3) & 0x01010101u) * 0xFFu, m1 = ((t1 >> 3) & 0x01010101u) * 0xFFu;
+        t0 = (__builtin_amdgcn_perm(A1, A0, s0) & ~m0) | (__builtin_amdgcn_perm(B1, B0, s0) & m0);
+        t1 = (__builtin_amdgcn_perm(A1, A0, s1) & ~m1) | (__builtin_amdgcn_perm(B1, B0, s1) & m1);
+    }
     const uint32_t k64 = 0x64646464u;
     const uint32_t p[4] = {__builtin_amdgcn_perm(k64, t0, 0x05010400u), __builtin_amdgcn_perm(k64, t0, 0x07030602u), __builtin_amdgcn_perm(k64, t1, 0x05010400u),
                            __builtin_amdgcn_perm(k64, t1, 0x07030602u)};  // [n0, 0x64, n1, 0x64]: the halves 1024 + n
     const _Float16 d = __builtin_bit_cast(_Float16, (uint16_t) (raw.z & 0xFFFFu));
     const kv_half2 d2 = {d, d};
-    constexpr float zero = 1024.0f + (OFFSET ? 0.0f : FIVE ? 16.0f : 8.0f);
+    constexpr float zero = 1024.0f + (T == GGML_TYPE_IQ4_NL ? 128.0f : OFFSET ? 0.0f : FIVE ? 16.0f : 8.0f);
     const kv_half2 z2 = {(_Float16) zero, (_Float16) zero};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -24,16 +24,29 @@ __device__ __forceinline__ uint16_t f2bf(const float f) {  // ggml_compute_fp32_
 }
 __device__ __forceinline__ void st16(char * p, const uint16_t v) { *(uint16_t *) p = v; }  // (blocks are 2-byte aligned, no more)
 
-__device__ __forceinline__ int iq4nl_best_index(const float x) {  // best_index_int8(16, kvalues_iq4nl, x)
-    if (x <= (float) k_iq4nl_values[0]) return 0;
-    if (x >= (float) k_iq4nl_values[15]) return 15;
-    int ml = 0, mu = 15;
-    while (mu - ml > 1) {
-        const int mav = (ml + mu) / 2;
-        if (x < (float) k_iq4nl_values[mav]) mu = mav;
-        else ml = mav;
+__device__ __forceinline__ float iq4nl_level(const int l) {  // kvalues_iq4nl[l] from constants (two selects deep, no memory)
+    constexpr float V[16] = {-127.f, -104.f, -83.f, -65.f, -49.f, -35.f, -22.f, -10.f, 1.f, 13.f, 25.f, 38.f, 53.f, 69.f, 89.f, 113.f};
+    float r = V[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) r = l == k ? V[k] : r;
+    return r;
+}
+// best_index_int8(16, kvalues_iq4nl, x) without its table walk (a dependent chain of memory loads per value: SET_ROWS to iq4_nl ran at 25 us per layer):
+// the bracketing levels lo <= x < hi come out of 15 compares against constants, the choice between them is the reference's own expression
+__device__ __forceinline__ int iq4nl_best_index(const float x) {
+    constexpr float V[16] = {-127.f, -104.f, -83.f, -65.f, -49.f, -35.f, -22.f, -10.f, 1.f, 13.f, 25.f, 38.f, 53.f, 69.f, 89.f, 113.f};
+    if (x <= V[0]) return 0;
+    if (x >= V[15] || x != x) return 15;  // (a NaN fails every `x < val[mid]` of the reference's search and ends at the top)
+    int ml = 0;
+    float lo = V[0], hi = V[15];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const bool ge = x >= V[k];
+        ml += ge ? 1 : 0;
+        lo = ge ? V[k] : lo;             // the largest level <= x (levels ascend)
+        hi = (!ge && V[k] < hi) ? V[k] : hi;  // the smallest level > x
     }
-    return x - (float) k_iq4nl_values[mu - 1] < (float) k_iq4nl_values[mu] - x ? mu - 1 : mu;
+    return x - lo < hi - x ? ml : ml + 1;
 }
 
 // the element of largest magnitude with its sign, the first one on a tie (quantize_row_q4_0_ref: `if (amax < fabsf(v))`)
@@ -134,7 +147,7 @@ template <int TYPE> __device__ __forceinline__ void quantize_block(const float (
             for (int j = 0; j < 32; ++j) {
                 const int l = iq4nl_best_index(id * x[j]);
                 lv[j >> 3] |= (uint32_t) l << (4 * (j & 7));
-                const float q = (float) k_iq4nl_values[l], w = x[j] * x[j];
+                const float q = iq4nl_level(l), w = x[j] * x[j];
                 sumqx += w * q * x[j];
                 sumq2 += w * q * q;
             }
@@ -274,6 +287,59 @@ __global__ void __launch_bounds__(64) k_set_rows_kv_pair(const tdesc a0, const t
     else set_rows_block_any(a1, i1, d1, gid);
 }
 
+// ---- SET_ROWS into IQ4_NL, lane-parallel: the level search is ~90 VALU per value, 3 000 for a block on one thread (25 us per layer for the two rows of a decode
+// step).  One block per 32 lanes, a value per lane: the block's extreme by an index-aware butterfly (the FIRST largest magnitude, as the reference's scan finds
+// it), the level per lane, and the two weighted sums added in the reference's order — every lane walks j = 0 .. 31 over its block's products (the same 64
+// dependent adds the reference does, once per block instead of being the tail of 3 000 instructions): the bytes stay identical.
+__device__ __forceinline__ void iq4nl_set_block_lanes(const tdesc & a, const tdesc & idx, const tdesc & d, const int64_t blk_id, const int lane) {
+    const int64_t per_row = a.ne[0] / 32;
+    if (blk_id >= per_row * a.ne[1] * a.ne[2] * a.ne[3]) return;  // (whole half-waves: a block is 32 lanes)
+    const int l32 = lane & 31, base = lane & 32;
+    const int64_t row = blk_id / per_row, blk = blk_id - row * per_row;
+    const int64_t i01 = row % a.ne[1], i02 = (row / a.ne[1]) % a.ne[2], i03 = row / (a.ne[1] * a.ne[2]);
+    const int64_t i12 = i03 % idx.ne[2], i11 = i02 % idx.ne[1];
+    const int64_t r = *(const int64_t *) (idx.data + i01 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+    const float xv = ((const float *) (a.data + i01 * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3]))[blk * 32 + l32];
+    float ax = fabsf(xv);
+    int at = l32;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const float oax = __shfl_xor(ax, off);
+        const int oat = __shfl_xor(at, off);
+        const bool take = oax > ax || (oax == ax && oat < at);
+        ax = take ? oax : ax;
+        at = take ? oat : at;
+    }
+    const float mx = __shfl(xv, base + at);
+    int l = 0;
+    float scale = 0.0f;
+    if (ax >= 1e-15f) {
+        const float d0 = mx / -127.0f;
+        const float id = 1.0f / d0;
+        l = iq4nl_best_index(id * xv);
+        const float q = iq4nl_level(l), w = xv * xv;
+        const float pqx = w * q * xv, pq2 = w * q * q;
+        float sumqx = 0.0f, sumq2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            sumqx += __shfl(pqx, base + j);
+            sumq2 += __shfl(pq2, base + j);
+        }
+        scale = sumqx / sumq2;
+    }
+    char * out = d.data + r * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3] + blk * 18;
+    const int hi = __shfl(l, base + ((l32 + 16) & 31));  // value j + 16 shares byte j with value j
+    const uint32_t byte = (uint32_t) l | ((uint32_t) hi << 4);
+    const uint32_t next = (uint32_t) __shfl((int) byte, lane + 1);
+    if (l32 < 16 && (l32 & 1) == 0) st16(out + 2 + l32, (uint16_t) (byte | (next << 8)));
+    if (l32 == 0) st16(out, f2h(scale));
+}
+__global__ void __launch_bounds__(256) k_set_rows_iq4nl(const tdesc a0, const tdesc i0, const tdesc d0, const tdesc a1, const tdesc i1, const tdesc d1) {
+    const int64_t blk_id = ((int64_t) blockIdx.x * 256 + threadIdx.x) >> 5;
+    if (blockIdx.y == 0) iq4nl_set_block_lanes(a0, i0, d0, blk_id, (int) (threadIdx.x & 63));
+    else iq4nl_set_block_lanes(a1, i1, d1, blk_id, (int) (threadIdx.x & 63));
+}
+
 // ---- CPY between contiguous tensors: blocks -> f32 and f32 -> blocks (K-shift)
 template <int TYPE> __global__ void __launch_bounds__(64) k_cpy_kv_to_f32(const char * __restrict__ src, float * __restrict__ dst, const int64_t n_blocks) {
     const int64_t i = (int64_t) blockIdx.x * 64 + threadIdx.x;
@@ -345,12 +411,20 @@ bool kv_image_type(int type) { return kv_type_is_block(type) || type == GGML_TYP
 void launch_set_rows_kv(hipStream_t s, const tdesc & a, const tdesc & idx, const tdesc & d) {
     const int64_t n = (a.ne[0] / 32) * a.ne[1] * a.ne[2] * a.ne[3];
     if (n <= 0) return;
+    if (d.type == GGML_TYPE_IQ4_NL) {  // a lane per value
+        hipLaunchKernelGGL(k_set_rows_iq4nl, dim3((unsigned) ((n * 32 + 255) / 256), 1), dim3(256), 0, s, a, idx, d, a, idx, d);
+        return;
+    }
     const dim3 grid((unsigned) ((n + 63) / 64));
     KV_DISPATCH_STORE(d.type, hipLaunchKernelGGL((k_set_rows_kv<T>), grid, dim3(64), 0, s, a, idx, d))
 }
 void launch_set_rows_kv_pair(hipStream_t s, const tdesc & a0, const tdesc & i0, const tdesc & d0, const tdesc & a1, const tdesc & i1, const tdesc & d1) {
     const int64_t n0 = (a0.ne[0] / 32) * a0.ne[1] * a0.ne[2] * a0.ne[3], n1 = (a1.ne[0] / 32) * a1.ne[1] * a1.ne[2] * a1.ne[3];
     if (std::max(n0, n1) <= 0) return;
+    if (d0.type == GGML_TYPE_IQ4_NL && d1.type == GGML_TYPE_IQ4_NL) {
+        hipLaunchKernelGGL(k_set_rows_iq4nl, dim3((unsigned) ((std::max(n0, n1) * 32 + 255) / 256), 2), dim3(256), 0, s, a0, i0, d0, a1, i1, d1);
+        return;
+    }
     hipLaunchKernelGGL(k_set_rows_kv_pair, dim3((unsigned) ((std::max(n0, n1) + 63) / 64), 2), dim3(64), 0, s, a0, i0, d0, a1, i1, d1);
 }
 void launch_cpy_kv(hipStream_t s, int type, const void * src, void * dst, int64_t n_values, bool to_type) {

@@ -197,7 +197,7 @@ def test_flash_attn_over_kv_types(backend, H, plog, tk, tv, HD, NH, NKV, nq, nkv
     # served either through the f16 image or, where the lane-parallel kernel reads such a cache IN PLACE (fattn.hip: fattn_native_kv_ok), by that form:
     # exactly one of the two, and the in-place form only at its shapes (head_dim 128, at most 32 query tokens)
     d_nat, d_img = backend.stat("kv_native_nodes") - nat0, backend.stat("kv_image_nodes") - img0
-    in_place = HD == 128 and nq <= 32 and tk == tv and tk in (L.Q4_0, L.Q4_1, L.Q5_0, L.Q5_1)  # (fattn.hip: fattn_native_kv_ok)
+    in_place = HD == 128 and nq <= 32 and tk == tv and tk in (L.Q4_0, L.Q4_1, L.Q5_0, L.Q5_1, L.IQ4_NL)  # (fattn.hip: fattn_native_kv_ok)
     assert (d_nat, d_img) == ((1, 0) if in_place else (0, 1)), (d_nat, d_img)
     tag = f"flash_attn K={NAME[tk]} V={NAME[tv]} hd={HD} H={NH}/{NKV} nq={nq} nkv={nkv} splits={splits} sinks={sinks}"
     T.compare(tag, got[0], ref[0], max_nmse=1e-3, log=plog)
