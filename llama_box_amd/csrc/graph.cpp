@@ -33,7 +33,11 @@ static bool mm_cache_image_ok(const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0];
     const ggml_tensor * b = op->src[1];
     if (!a || !b || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !ggml_abi_is_contiguous(op)) return false;
-    if (!(kv_type_is_block(a->type) || a->type == GGML_TYPE_BF16 || (a->type == GGML_TYPE_Q8_0 && (a->ne[2] > 1 || !rows_contig(a))))) return false;
+    if (!(kv_type_is_block(a->type) || a->type == GGML_TYPE_BF16 || a->type == GGML_TYPE_Q8_0)) return false;
+    // a VIEW into a cache (or a batch of matrices), never a plain 2-D weight: llama.cpp's loader probes every weight type with a plain tensor, and a model stored
+    // in q4_0 / q5_1 / bf16 ... must get the same answer there as at graph time — its mat-muls stay where they were (the CPU backend), they do not take an
+    // image of a whole weight matrix per step
+    if (a->view_src == nullptr && a->ne[2] == 1) return false;
     if (a->nb[0] != ggml_abi_type_size(a->type) || (a->ne[0] % 32) != 0 || (a->nb[1] % 2) || (a->nb[2] % 2) || a->ne[3] != 1 || b->ne[3] != 1 || b->nb[0] != 4) return false;
     return a->ne[2] > 0 && b->ne[2] % a->ne[2] == 0;
 }
