@@ -18,7 +18,8 @@ KVALUES = np.array([-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53,
 
 
 def h2b(x):  # float32 [n] -> the two bytes of its f16 rounding [n, 2]
-    return x.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    with np.errstate(over="ignore"):  # (scales beyond 65504 round to infinity, as GGML_FP32_TO_FP16 does)
+        return x.astype(np.float16).view(np.uint8).reshape(-1, 2)
 
 
 def b2f(b):  # [n, 2] bytes of an f16 -> float32 [n]
@@ -28,7 +29,8 @@ def b2f(b):  # [n, 2] bytes of an f16 -> float32 [n]
 def signed_max(x):
     """the element of largest magnitude with its sign — the FIRST one on a tie (strict > while scanning)"""
     i = np.argmax(np.abs(x), axis=1)  # argmax returns the first maximum
-    return x[np.arange(x.shape[0]), i]
+    m = x[np.arange(x.shape[0]), i]
+    return np.where(m == 0, F(0.0), m).astype(F)  # (a block of zeros of either sign: the scan never moves off its initial +0.0)
 
 
 def inv(d):
@@ -61,7 +63,7 @@ def quantize(name, x):
         return np.concatenate([h2b(d), fifth_bits(q), pack_nibbles(q[:, :16] & 15, q[:, 16:] & 15)], axis=1)
     if name in ("q4_1", "q5_1"):
         levels = 15 if name == "q4_1" else 31
-        mn, mx = x.min(axis=1), x.max(axis=1)
+        mn, mx = x[np.arange(n), np.argmin(x, axis=1)], x[np.arange(n), np.argmax(x, axis=1)]  # (the FIRST element that attains the extreme: its sign if that is a zero)
         d = ((mx - mn).astype(F) / F(levels)).astype(F)
         t = ((x - mn[:, None]).astype(F) * inv(d)[:, None]).astype(F)
         q = np.trunc((t + F(0.5)).astype(F)).astype(np.int32)

@@ -54,6 +54,7 @@ def edge_rows(rng, n_rows, width):
     x[2, 40], x[2, 33] = -3.0, 3.0
     x[3, :32] = (np.arange(32, dtype=np.float32) - 15.5) * 0.25  # values that land on .5 before the truncation
     x[4, :32] = np.where(np.arange(32) % 2 == 0, 1e-20, -1e-20).astype(np.float32)  # under iq4_nl's group epsilon
+    x[5, :] = np.where(rng.integers(0, 2, width) == 0, 0.0, -0.0).astype(np.float32)  # zeros of both signs: which zero the scale / minimum inherits is part of the bytes
     return x
 
 

@@ -123,3 +123,25 @@ def test_known_answer_blocks(built):
     x[0], x[17] = 127.0, -127.0
     b = _quantize(L.Q8_1, x)[0]
     assert np.array_equal(b[0:4], np.array([1.0, 30.0], np.float16).view(np.uint8)) and b[4:].view(np.int8)[0] == 127 and b[4:].view(np.int8)[17] == -127
+
+
+@pytest.mark.parametrize("name,qt", BLOCK_TYPES + [("q8_1", L.Q8_1)])
+def test_quantize_matches_the_numpy_twin_on_random_blocks(built, name, qt):
+    """beyond the committed vectors: 4 000 seeded blocks over twelve decades of scale, with planted ties, zeros and exact half-way values, through the C oracle and
+    through the NumPy restatement (tests/golden/make_kv_golden.py) — byte for byte"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_kv_golden", os.path.join(os.path.dirname(__file__), "golden", "make_kv_golden.py"))
+    twin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(twin)
+    rng = np.random.default_rng(qt * 1000 + 7)
+    x = (rng.standard_normal((4000, 32)) * 10.0 ** rng.uniform(-6, 6, (4000, 1))).astype(np.float32)
+    x[::17, :] = np.round(x[::17, :] * 4) / 4          # coarse grids: many equal magnitudes and values that land on a .5 before the truncation
+    x[::29, rng.integers(0, 32)] = 0.0
+    k = rng.integers(0, 32, 4000)
+    x[np.arange(0, 4000, 13), k[::13][: len(range(0, 4000, 13))]] *= -1.0
+    x[5::41] = np.abs(x[5::41])                         # all-positive blocks (the offset formats' minimum is then > 0)
+    x[7::53, 1] = -x[7::53, 0]                          # an exact tie in magnitude between the first two elements
+    got = _quantize(qt, x)
+    ref = twin.quantize(name, x)
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, f"{name}: {bad.size} of 4000 blocks differ, first {bad[0]}: oracle {got[bad[0]].tolist()} twin {ref[bad[0]].tolist()} x {x[bad[0]].tolist()}"
