@@ -549,7 +549,7 @@ def main():
             # thread count: the best of a short probe around the quota
             best = (0.0, nmax)
             for nth in sorted({nmax, max(1, nmax - 1), max(1, nmax - 2), max(1, nmax - 4), max(1, nmax * 3 // 4), max(1, nmax // 2)}, reverse=True):
-                cc = Context(mc, compute=T.oracle_compute_fn(nth), n_ctx=256, flash_attn=args.fa, n_threads=nth)
+                cc = Context(mc, compute=T.oracle_compute_fn(nth), n_ctx=256, flash_attn=args.fa, n_threads=nth, type_k=kvt, type_v=kvt)
                 cc.decode([int(toks[0])], [0])  # touch the weights / wake the pool
                 tp0 = time.perf_counter()
                 for i in range(3):
@@ -559,7 +559,7 @@ def main():
                 if rate > best[0]:
                     best = (rate, nth)
             nth = best[1]
-            cc = Context(mc, compute=T.oracle_compute_fn(nth), n_ctx=256, flash_attn=args.fa, n_threads=nth)
+            cc = Context(mc, compute=T.oracle_compute_fn(nth), n_ctx=256, flash_attn=args.fa, n_threads=nth, type_k=kvt, type_v=kvt)
             cpu_rows = [cc.decode([int(toks[0])], [0])[1][0]]
             for i in range(4):  # warm
                 cpu_rows.append(cc.decode([int(toks[1 + i])], [1 + i])[1][0])
@@ -589,7 +589,7 @@ def main():
                     gpu_rows = np.stack([cgp.decode([int(toks[i])], [i])[1][0] for i in range(n_par_rows)])
                     cgp.free()
                     n_gen = min(n_par_rows, int(os.environ.get("BENCH_PARITY_GENERIC_STEPS", "16")))
-                    cgn = Context(mc, compute=T.oracle_compute_fn(nmax), n_ctx=256, flash_attn=args.fa, n_threads=nmax)
+                    cgn = Context(mc, compute=T.oracle_compute_fn(nmax), n_ctx=256, flash_attn=args.fa, n_threads=nmax, type_k=kvt, type_v=kvt)
                     gen_rows = np.stack([cgn.decode([int(toks[i])], [i])[1][0] for i in range(n_gen)])
                     cgn.free()
                     top2 = np.sort(cpu_rows, axis=1)
