@@ -85,7 +85,7 @@ class HParams(C.Structure):
     _fields_ = [("arch", C.c_char * 32), ("n_layer", C.c_int32), ("n_embd", C.c_int32), ("n_head", C.c_int32),
                 ("n_head_kv", C.c_int32), ("n_embd_head", C.c_int32), ("n_ff", C.c_int32), ("n_vocab", C.c_int32),
                 ("n_ctx_train", C.c_int32), ("rope_freq_base", C.c_float), ("rms_eps", C.c_float),
-                ("rope_type", C.c_int32), ("qkv_bias", C.c_int32), ("ftype", C.c_int32), ("attn_v_q5k_70b", C.c_int32), ("peaked", C.c_int32)]
+                ("rope_type", C.c_int32), ("qkv_bias", C.c_int32), ("ftype", C.c_int32), ("attn_v_q5k_70b", C.c_int32), ("peaked", C.c_int32), ("branch_gain", C.c_float)]
 
 
 class ContextParams(C.Structure):

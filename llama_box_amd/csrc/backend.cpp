@@ -753,6 +753,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "small_uploads") c->opt.small_uploads = v != 0;
     else if (k == "small_downloads") c->opt.small_downloads = v != 0;
     else if (k == "timing") c->opt.timing = v != 0;
+    else if (k == "exec_update") c->opt.exec_update = v;
     else if (k == "clear_failure") { if (v) clear_hip_failure(); }
     else if (k == "staged_upload") g_staged_upload.store(v != 0);
     else return -1;
@@ -775,6 +776,9 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "nf_mma_chains") return c->st.nf_mma_chains;
     if (k == "p2p_allreduces") return c->st.p2p_allreduces;
     if (k == "p2p_timeouts") return tp_p2p_timeouts(c);
+    if (k == "graph_exec_update_failures") return c->st.graph_exec_update_failures;
+    if (k == "graph_evictions") return c->st.graph_evictions;
+    if (k == "graph_cache_size") return (int64_t) c->graphs.size();
     if (k == "graph_launch_host_ns") return c->st.graph_launch_host_ns;
     if (k == "kernel_downloads") return c->st.kernel_downloads;
     if (k == "kv_image_nodes") return c->st.kv_image_nodes;

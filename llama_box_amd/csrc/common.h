@@ -132,6 +132,8 @@ struct options {
     bool small_uploads = true; // set_tensor_async of <= 64 KiB: pinned ring + copy kernel instead of a blit
     bool small_downloads = true; // get_tensor_async of <= 8 MiB into this backend's pinned host buffer type: a copy kernel instead of a blit
     bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)
+    int exec_update = [] { const char * e = getenv("GGML_MI355X_EXEC_UPDATE"); return e ? atoi(e) : 1; }();  // patch the predecessor's executable graph at a capture at
+                               // first sighting (graph.cpp); 2 = run the update and treat it as failed (tests)
 };
 
 struct stats {
@@ -153,6 +155,8 @@ struct stats {
     int64_t kernel_downloads = 0;      // get_tensor_async calls served by a copy kernel writing mapped pinned memory
     int64_t graph_early_captures = 0;  // graphs captured at their FIRST sighting (same step as the one replayed last, over a grown cache)
     int64_t graph_exec_updates = 0;    // ... of them, served by patching the predecessor's executable graph (hipGraphExecUpdate) instead of instantiating
+    int64_t graph_exec_update_failures = 0; // ... and updates that failed: the predecessor's (possibly half-patched) executable graph is destroyed, both entries start over
+    int64_t graph_evictions = 0;       // cache entries dropped because they had not been used for 256 graphs
     int64_t graph_key_collisions = 0;  // two different graph keys with one hash (each keeps its own entry)
 };
 

@@ -38,6 +38,10 @@ static bool mm_cache_image_ok(const ggml_tensor * op) {
     // in q4_0 / q5_1 / bf16 ... must get the same answer there as at graph time — its mat-muls stay where they were (the CPU backend), they do not take an
     // image of a whole weight matrix per step
     if (a->view_src == nullptr && a->ne[2] == 1) return false;
+    // ... nor a view of one: a 2-D view of a Q8_0 weight keeps the quantised mat-vec / mat-mul kernels (the integer-dot arithmetic of the reference), and
+    // weights in the other block formats stay where they were
+    const ggml_backend_buffer_t root = a->view_src && a->view_src->buffer ? a->view_src->buffer : a->buffer;
+    if (root && root->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS) return false;
     if (a->nb[0] != ggml_abi_type_size(a->type) || (a->ne[0] % 32) != 0 || (a->nb[1] % 2) || (a->nb[2] % 2) || a->ne[3] != 1 || b->ne[3] != 1 || b->nb[0] != 4) return false;
     return a->ne[2] > 0 && b->ne[2] % a->ne[2] == 0;
 }
@@ -2089,8 +2093,24 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         it = c->graphs.find(fp);
     }
     if (it == c->graphs.end()) {
+        // bound the cache wherever a new entry appears (eager first sightings and captures at first sighting alike): drop what has not been
+        // used for 256 graphs.  The entry replayed last (the predecessor a capture at first sighting patches) was used one tick ago and stays.
+        if (c->graphs.size() > 64) {
+            for (auto jt = c->graphs.begin(); jt != c->graphs.end();) {
+                if (jt->second.last_use + 256 < c->tick) {
+                    if (jt->second.exec) (void) hipGraphExecDestroy(jt->second.exec);
+                    if (jt->second.graph) (void) hipGraphDestroy(jt->second.graph);
+                    if (c->last_graph == &jt->second) c->last_graph = nullptr;
+                    jt = c->graphs.erase(jt);
+                    c->st.graph_evictions++;
+                } else {
+                    ++jt;
+                }
+            }
+        }
         it = c->graphs.emplace(fp, cached_graph()).first;
         it->second.key = c->key_scratch;
+        it->second.last_use = c->tick;
     }
     cached_graph & cg = it->second;
     // A graph seen for the first time whose predecessor — the graph replayed last — has the same number of nodes is the same step over a grown
@@ -2108,20 +2128,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     cg.seen++;
     if (!early && (cg.seen < 2 || cg.seen > 1000000)) {  // first sighting: run eagerly (one-off prefill graphs never pay for capture)
         c->st.eager_graphs++;
-        const bool ok = run_nodes(c, g, wp);
-        if (c->graphs.size() > 64) {  // bound the cache: drop everything that is not instantiated and old
-            for (auto it = c->graphs.begin(); it != c->graphs.end();) {
-                if (it->second.last_use + 256 < c->tick) {
-                    if (it->second.exec) (void) hipGraphExecDestroy(it->second.exec);
-                    if (it->second.graph) (void) hipGraphDestroy(it->second.graph);
-                    if (c->last_graph == &it->second) c->last_graph = nullptr;
-                    it = c->graphs.erase(it);
-                } else {
-                    ++it;
-                }
-            }
-        }
-        return ok ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+        return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
     }
     // second sighting: capture, instantiate, replay
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
@@ -2153,21 +2160,26 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     // the same step over a grown cache: the predecessor's executable graph is PATCHED with this capture's kernel parameters (same kernels in the same
     // order, other extents / grid sizes) and moves to this entry — instantiating ~300 kernel nodes anew is the larger half of a re-capture.  Any
     // difference in topology (another attention kernel for the longer cache, another split count's combine pass) makes the update fail: then the
-    // ordinary instantiation below.  The predecessor's key is never seen again in a decode run (n_kv only grows); if it is, it is captured afresh.
-    static const bool update_on = !getenv("GGML_MI355X_EXEC_UPDATE") || atoi(getenv("GGML_MI355X_EXEC_UPDATE")) != 0;
-    if (early && update_on && prev && prev->exec) {
+    // ordinary instantiation below.  Either way the predecessor gives its executable graph up: after a successful update it IS this entry's, after
+    // a failed one it may be half patched (the runtime rewrites kernel nodes one by one until it meets the mismatch) and must never be launched
+    // under the old key again — a -np 32 engine's n_kv shrinks when sequences finish, so that key does come back.  The predecessor's entry
+    // returns to "seen once" and is captured afresh at its next sighting.  (exec_update 2 = the test hook: the update runs, then counts as failed.)
+    if (early && c->opt.exec_update && prev && prev->exec) {
         hipGraphNode_t err_node = nullptr;
         hipGraphExecUpdateResult res = hipGraphExecUpdateError;
-        if (hipGraphExecUpdate(prev->exec, graph, &err_node, &res) == hipSuccess && res == hipGraphExecUpdateSuccess) {
+        const bool updated = hipGraphExecUpdate(prev->exec, graph, &err_node, &res) == hipSuccess && res == hipGraphExecUpdateSuccess && c->opt.exec_update != 2;
+        if (updated) {
             exec = prev->exec;
-            prev->exec = nullptr;
-            if (prev->graph) (void) hipGraphDestroy(prev->graph);
-            prev->graph = nullptr;
-            prev->seen = 1;
             c->st.graph_exec_updates++;
         } else {
             (void) hipGetLastError();
+            (void) hipGraphExecDestroy(prev->exec);
+            c->st.graph_exec_update_failures++;
         }
+        prev->exec = nullptr;
+        if (prev->graph) (void) hipGraphDestroy(prev->graph);
+        prev->graph = nullptr;
+        prev->seen = 1;
     }
     if (exec == nullptr && (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || exec == nullptr)) {
         (void) hipGetLastError();

@@ -399,7 +399,10 @@ void ip_host_access(ggml_backend_buffer_t b, bool write) {
             if (m.state == 1) {  // the shards are newer than the host's tensors: bring them home first (a write may cover only part of them)
                 (void) hipSetDevice(E->main->device);
                 (void) hipStreamSynchronize(E->main->stream);
-                kv_move(E, (int) i, true);
+                if (!kv_move(E, (int) i, true)) {  // the host's tensors stay stale: the shards remain the newer copy, and everything after this fails loudly
+                    note_hip_failure();
+                    continue;
+                }
                 m.state = 0;
             }
             if (write) m.state = 2;
@@ -721,6 +724,10 @@ static bool analyse_node(analysis & A, const ggml_tensor * t) {
             if (a.kind != 1 || k.kind != 1 || v.kind != 1 || a.dim != 2 || k.dim != 2 || v.dim != 2 || !same_off(k, v, A.n)) return A.fail("attention over operands not sharded by heads", t);
             for (int i = 0; i <= A.n; ++i)  // a device's query heads are exactly the groups of its KV heads
                 if (a.off[i] * s1->ne[2] != k.off[i] * s0->ne[2]) return A.fail("query heads and KV heads are cut at different places", t);
+            // the kernels derive ALiBi slopes (n_head_log2, m0 / m1) and sinks[h] from the head count and head index of the tensor they are given: a
+            // device's share would get the slopes / sinks of heads 0..n_local-1.  Declined — such graphs run node by node (attention on the main device)
+            if (ggml_abi_op_param_f32(t, 1) != 0.0f) return A.fail("attention with ALiBi slopes (max_bias) sharded by heads", t);
+            if (t->src[4]) return A.fail("attention with per-head sinks sharded by heads", t);
             o.kind = 1;
             o.dim = 1;  // result: [head_dim, n_head, n_tokens]
             for (int i = 0; i <= A.n; ++i) o.off[i] = a.off[i];
@@ -733,6 +740,10 @@ static bool analyse_node(analysis & A, const ggml_tensor * t) {
             if (a.dim == 0) return A.fail("a soft-max across a shard boundary", t);
             if (s1 && (!get_desc(A, s1, b) || b.kind != 0)) return A.fail("a sharded mask", t);
             if (t->src[2]) { sdesc sk; if (!get_desc(A, t->src[2], sk) || sk.kind != 0) return A.fail("sharded sinks", t); }
+            if (a.dim >= 2) {  // rows of [n_kv, n_tokens, n_head, ...] sharded by heads: the same two per-head quantities as in FLASH_ATTN_EXT above
+                if (ggml_abi_op_param_f32(t, 1) != 0.0f) return A.fail("a soft-max with ALiBi slopes (max_bias) sharded by heads", t);
+                if (t->src[2]) return A.fail("a soft-max with per-head sinks sharded by heads", t);
+            }
             A.d[t] = a;
             return true;
         }

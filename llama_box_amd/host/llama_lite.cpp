@@ -121,6 +121,103 @@ static void synth_block(ggml_type type, uint64_t key, int64_t K, float wscale, u
     }
 }
 
+// f16 -> f32 (harness-side: the tied output rows below are re-encoded from token_embd's dequantised values)
+static float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t) (h & 0x8000) << 16, e = (h >> 10) & 31, man = h & 0x3FF;
+    uint32_t x;
+    if (e == 0) {
+        if (!man) x = sign;
+        else {
+            int sh = 0;
+            uint32_t m = man;
+            while (!(m & 0x400)) { m <<= 1; ++sh; }
+            x = sign | (uint32_t) (127 - 15 - sh + 1) << 23 | (m & 0x3FF) << 13;
+        }
+    } else if (e == 31) x = sign | 0x7F800000u | man << 13;
+    else x = sign | (e + 112) << 23 | man << 13;
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+// the 256 values a synthetic K-quant super-block stands for (block layouts: SURVEY.md Appendix A.1 / A.2)
+static void block_values(ggml_type type, const uint8_t * p, float * y) {
+    auto scale_min = [](int j, const uint8_t * q, int & sc, int & mn) {
+        if (j < 4) { sc = q[j] & 63; mn = q[j + 4] & 63; }
+        else { sc = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); mn = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+    };
+    switch (type) {
+        case GGML_TYPE_Q4_K:
+        case GGML_TYPE_Q5_K: {
+            const bool q5 = type == GGML_TYPE_Q5_K;
+            uint16_t hd, hm;
+            memcpy(&hd, p, 2);
+            memcpy(&hm, p + 2, 2);
+            const float d = f16_to_f32(hd), dmin = f16_to_f32(hm);
+            const uint8_t * scales = p + 4, * qh = p + 16, * ql = p + (q5 ? 16 + 32 : 16);
+            for (int j = 0; j < 4; ++j) {
+                int s1, m1, s2, m2;
+                scale_min(2 * j, scales, s1, m1);
+                scale_min(2 * j + 1, scales, s2, m2);
+                for (int l = 0; l < 32; ++l) {
+                    const int lo = (ql[32 * j + l] & 0xF) + (q5 && (qh[l] >> (2 * j) & 1) ? 16 : 0);
+                    const int hi = (ql[32 * j + l] >> 4) + (q5 && (qh[l] >> (2 * j + 1) & 1) ? 16 : 0);
+                    y[64 * j + l] = d * (float) s1 * (float) lo - dmin * (float) m1;
+                    y[64 * j + 32 + l] = d * (float) s2 * (float) hi - dmin * (float) m2;
+                }
+            }
+        } break;
+        case GGML_TYPE_Q6_K: {
+            const block_q6_K * b = (const block_q6_K *) p;
+            const float d = f16_to_f32(b->d);
+            for (int n = 0; n < 2; ++n) {
+                const uint8_t * ql = b->ql + 64 * n, * qh = b->qh + 32 * n;
+                const int8_t * sc = b->scales + 8 * n;
+                for (int l = 0; l < 32; ++l) {
+                    const int is = l / 16;
+                    const int q1 = (int) ((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32, q2 = (int) ((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                    const int q3 = (int) ((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32, q4 = (int) ((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                    y[128 * n + l] = d * (float) sc[is] * (float) q1;
+                    y[128 * n + l + 32] = d * (float) sc[is + 2] * (float) q2;
+                    y[128 * n + l + 64] = d * (float) sc[is + 4] * (float) q3;
+                    y[128 * n + l + 96] = d * (float) sc[is + 6] * (float) q4;
+                }
+            }
+        } break;
+        default: LLM_ASSERT(!"block_values: unsupported type");
+    }
+}
+
+// 256 values -> one Q6_K super-block (a plain absmax encoder: any valid block will do for a synthetic weight set — this is the model
+// generator, not a restatement of ggml's quantize_row_q6_K)
+static void pack_q6_K(const float * x, uint8_t * out) {
+    block_q6_K * b = (block_q6_K *) out;
+    float sub[16], smax = 0.0f;
+    for (int j = 0; j < 16; ++j) {
+        float a = 0.0f;
+        for (int l = 0; l < 16; ++l) a = std::max(a, fabsf(x[16 * j + l]));
+        sub[j] = a / 31.0f;
+        smax = std::max(smax, sub[j]);
+    }
+    memset(b, 0, sizeof(*b));
+    if (smax == 0.0f) return;
+    const float d = f16_to_f32(f32_to_f16(smax / 127.0f));
+    b->d = f32_to_f16(smax / 127.0f);
+    int q[256];
+    for (int j = 0; j < 16; ++j) {
+        const int sc = std::max(1, std::min(127, (int) lrintf(sub[j] / d)));
+        b->scales[j] = (int8_t) sc;
+        for (int l = 0; l < 16; ++l) q[16 * j + l] = std::max(-32, std::min(31, (int) lrintf(x[16 * j + l] / (d * (float) sc)))) + 32;
+    }
+    for (int n = 0; n < 2; ++n)
+        for (int l = 0; l < 32; ++l) {
+            const int q1 = q[128 * n + l], q2 = q[128 * n + l + 32], q3 = q[128 * n + l + 64], q4 = q[128 * n + l + 96];
+            b->ql[64 * n + l] = (uint8_t) ((q1 & 0xF) | ((q3 & 0xF) << 4));
+            b->ql[64 * n + l + 32] = (uint8_t) ((q2 & 0xF) | ((q4 & 0xF) << 4));
+            b->qh[32 * n + l] = (uint8_t) ((q1 >> 4) | ((q2 >> 4) << 2) | ((q3 >> 4) << 4) | ((q4 >> 4) << 6));
+        }
+}
+
 struct synth_spec {
     uint64_t seed;
     int tensor_id;
@@ -136,6 +233,9 @@ struct synth_spec {
     int tie_id = -1;        // >= 0: `tie_eighths` of every 8 blocks repeat the block of tensor tie_id at row (row * 7919 + 13) % tie_rows (llm_hparams::peaked)
     int tie_eighths = 0;
     int64_t tie_rows = 0;
+    ggml_type tie_type = GGML_TYPE_F32;  // the tied tensor's block format; when it is not `type`, its values are re-encoded (Q6_K)
+    float tie_wscale = 1.0f;             // ... at the tied tensor's own gain, times tie_gain
+    float tie_gain = 1.0f;
 };
 
 static void synth_rows(const synth_spec & sp, int64_t row0, int64_t row1, uint8_t * dst) {
@@ -161,6 +261,16 @@ static void synth_rows(const synth_spec & sp, int64_t row0, int64_t row1, uint8_
                 if ((int) (splitmix64(pick) & 7) < sp.tie_eighths) {
                     const uint64_t tr = (uint64_t) (((r + sp.row_off) * 7919 + 13) % sp.tie_rows);
                     key = sp.seed ^ ((uint64_t) sp.tie_id * 0xD1B54A32D192ED03ull) ^ ((tr * (uint64_t) sp.blocks_per_row_global + (uint64_t) (b + sp.blk_off)) * 0x9E3779B97F4A7C15ull);
+                    if (sp.tie_type != sp.type) {  // Q4_K_M / Q5_K_M: token_embd is Q4_K / Q5_K, output.weight Q6_K — the tied block is token_embd's VALUES in Q6_K
+                        LLM_ASSERT(sp.type == GGML_TYPE_Q6_K && ggml_abi_blck_size(sp.tie_type) == 256);
+                        uint8_t src[256];
+                        float v[256];
+                        synth_block(sp.tie_type, key, sp.K_global, sp.tie_wscale, src);
+                        block_values(sp.tie_type, src, v);
+                        for (float & f : v) f *= sp.tie_gain;
+                        pack_q6_K(v, dst + (size_t) ((r - row0) * sp.blocks_per_row + b) * bs);
+                        continue;
+                    }
                 }
             }
             synth_block(sp.type, key, sp.K_global, sp.wscale, dst + (size_t) ((r - row0) * sp.blocks_per_row + b) * bs);
@@ -177,7 +287,20 @@ extern "C" int llm_preset(const char * name, struct llm_hparams * hp) {
         hp->n_vocab = V; hp->n_ctx_train = CTX; hp->rope_freq_base = base; hp->rms_eps = eps; hp->rope_type = rope;
         hp->qkv_bias = bias; hp->ftype = ft;
     };
-    const std::string n = name;
+    std::string n = name;
+    // "<preset>-damped": the same architecture and quantisation recipe with the two properties of a TRAINED network that independent random
+    // weights lack — small residual branches (gain 0.08 / sqrt(2 n_layer): a flipped 8-bit activation rounding injects 1/127 of a block's range
+    // however small the difference that caused it, and with branches of gain 0.25 every later quantiser re-amplifies it; measured on the oracle
+    // against itself, Llama-3-8B: logits NMSE 3.1e-4 at gain 1/8, 4.4e-5 at 0.03, 9.9e-6 at 0.01 — scripts/lab/damped_probe.py) and an output matrix
+    // tied to the embeddings (one logit far ahead of the rest): the weight sets north_star's 1e-3 / exact-id bar is testable on
+    const bool damped = n.size() > 7 && n.compare(n.size() - 7, 7, "-damped") == 0;
+    if (damped) {
+        n.resize(n.size() - 7);
+        if (llm_preset(n.c_str(), hp) != 0) return -1;
+        hp->peaked = 3;
+        hp->branch_gain = 0.08f / sqrtf(2.0f * (float) hp->n_layer);
+        return 0;
+    }
     if (n == "tinyllama-1.1b-q8_0") set("llama", 22, 2048, 32, 4, 64, 5632, 32000, 2048, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q8_0);
     else if (n == "tinyllama-1.1b-q8_0-peaked") { set("llama", 22, 2048, 32, 4, 64, 5632, 32000, 2048, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q8_0); hp->peaked = 3; }
     else if (n == "llama3-8b-q4_k_m") set("llama", 32, 4096, 32, 8, 128, 14336, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M);
@@ -211,6 +334,8 @@ struct tensor_plan {
     float wscale;
     int tie_id = -1, tie_eighths = 0;
     int64_t tie_rows = 0;
+    ggml_type tie_type = GGML_TYPE_F32;
+    float tie_wscale = 1.0f;
 };
 
 struct llm_model {
@@ -265,7 +390,9 @@ static std::vector<tensor_plan> make_plan(const llm_hparams & hp, int tp_rank, i
         // residual-branch output projections get a small gain, as in trained transformers: the residual stream stays
         // dominated by its own history, so one-ulp differences are not chaotically amplified layer over layer
         const bool branch_out = name.find("attn_output") != std::string::npos || name.find("ffn_down") != std::string::npos;
-        const float gain = name == "token_embd.weight" ? sqrtf((float) hp.n_embd) : (branch_out ? 0.25f : 1.0f);  // embeddings ~N(0,1)
+        // (llm_hparams::branch_gain: the "-damped" sets use ~1/sqrt(2 n_layer), the depth scaling trained residual networks are initialised with)
+        const float bgain = hp.branch_gain > 0.0f ? hp.branch_gain : 0.25f;
+        const float gain = name == "token_embd.weight" ? sqrtf((float) hp.n_embd) : (branch_out ? bgain : 1.0f);  // embeddings ~N(0,1)
         plan.push_back({name, type, ne0, ne1, Kg, row_off, k_off, id++, rowpar, lo, hi, gain});
     };
     add("token_embd.weight", pick_type(hp, "token_embd", 0), E, hp.n_vocab, E, 0, 0, false);
@@ -289,7 +416,10 @@ static std::vector<tensor_plan> make_plan(const llm_hparams & hp, int tp_rank, i
     add("output_norm.weight", GGML_TYPE_F32, E, 1, E, 0, 0, false, 0.5f, 1.5f);
     add("output.weight", pick_type(hp, "output", 0), E, v_l, E, tp_rank * v_l, 0, false);
     if (hp.peaked > 0) {
-        LLM_ASSERT(plan.back().type == plan.front().type && ggml_abi_blck_size(plan.back().type) > 1);  // the tied blocks are token_embd's, byte for byte (up to the gain)
+        // the tied blocks are token_embd's: byte for byte (up to the gain) when the two tensors share a format, else its values re-encoded as Q6_K
+        LLM_ASSERT(ggml_abi_blck_size(plan.back().type) > 1 && (plan.back().type == plan.front().type || (plan.back().type == GGML_TYPE_Q6_K && ggml_abi_blck_size(plan.front().type) == 256)));
+        plan.back().tie_type = plan.front().type;
+        plan.back().tie_wscale = plan.front().wscale;
         plan.back().tie_id = plan.front().tensor_id;
         plan.back().tie_eighths = std::min(8, hp.peaked);
         plan.back().tie_rows = hp.n_vocab;
@@ -324,6 +454,9 @@ static synth_spec spec_of(const tensor_plan & t, uint64_t seed) {
     sp.tie_id = t.tie_id;
     sp.tie_eighths = t.tie_eighths;
     sp.tie_rows = t.tie_rows;
+    sp.tie_type = t.tie_id >= 0 ? t.tie_type : t.type;
+    sp.tie_wscale = t.tie_wscale;
+    sp.tie_gain = t.tie_id >= 0 ? t.wscale / t.tie_wscale : 1.0f;
     return sp;
 }
 

@@ -37,10 +37,14 @@ struct llm_hparams {
     int32_t attn_v_q5k_70b; /* 70B recipe: attn_v Q4_K -> Q5_K */
     int32_t peaked;         /* 0..8: that many eighths of the blocks of output.weight row r repeat the blocks of token_embd row
                                (r * 7919 + 13) mod n_vocab — the logits get a trained model's shape (one row far ahead of the rest, the
-                               rest still decided by the layers) instead of the near-flat ones of independent random weights */
+                               rest still decided by the layers) instead of the near-flat ones of independent random weights.  When the two
+                               tensors differ in format (Q4_K_M / Q5_K_M: Q4_K / Q5_K embeddings, Q6_K output) the tied blocks are token_embd's
+                               VALUES re-encoded as Q6_K */
+    float branch_gain;      /* gain of attn_output / ffn_down (the residual branches); 0 = the default 0.25.  "-damped" presets: 0.08 / sqrt(2 n_layer) */
 };
 
-/* presets: "tinyllama-1.1b-q8_0", "tinyllama-1.1b-q8_0-peaked", "llama3-8b-q4_k_m", "llama3-70b-q4_k_m", "qwen2-7b-q5_k_m", "test-llama", "test-qwen2" */
+/* presets: "tinyllama-1.1b-q8_0", "tinyllama-1.1b-q8_0-peaked", "llama3-8b-q4_k_m", "llama3-70b-q4_k_m", "qwen2-7b-q5_k_m", "test-llama", "test-qwen2";
+   any of them + "-damped" = peaked 3 + branch_gain 0.08 / sqrt(2 n_layer) */
 int llm_preset(const char * name, struct llm_hparams * hp);
 
 struct llm_model;

@@ -279,6 +279,46 @@ def test_a_grown_cache_is_captured_at_first_sighting_and_patched_into_the_previo
     assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
 
 
+def test_a_failed_executable_graph_update_retires_the_predecessor(backend, H, plog):
+    """when hipGraphExecUpdate fails, the predecessor's executable graph may be half patched with the new step's extents; it is destroyed and its
+    entry starts over, so a key that comes BACK (a -np engine's n_kv shrinks when sequences finish; here: the cache is cleared and the same steps run
+    again) is captured afresh instead of replaying a corrupted graph.  Option exec_update 2 runs the update and treats it as failed.  Bit-equal to
+    eager execution over both passes, and the failures are counted."""
+    hp = preset("test-llama", n_head=4, n_head_kv=2, n_embd=512, n_embd_head=128)
+    mg = Model(hp, 31, backend.buft)
+    n_par, n_steps, n_prompt = 8, 24, 24
+    rng = np.random.default_rng(9)
+    toks = rng.integers(1, hp.n_vocab, n_par * n_prompt).tolist()
+    rows = [rng.integers(1, hp.n_vocab, n_par).tolist() for _ in range(n_steps)]
+    outs = {}
+    try:
+        for mode in (1, 0):
+            backend.set_option("graphs", mode)
+            backend.set_option("exec_update", 2)
+            c = Context(mg, backend=backend, flash_attn=1, n_ctx=2048)
+            s0 = {k: backend.stat(k) for k in ("graph_captures", "graph_early_captures", "graph_exec_updates", "graph_exec_update_failures")}
+            lg = []
+            for _ in range(2):  # the second pass meets the keys of the first again, the small extent after the large one
+                c.clear()
+                rc, _ = c.decode(toks, [i for _ in range(n_par) for i in range(n_prompt)], [k for k in range(n_par) for _ in range(n_prompt)], ([0] * (n_prompt - 1) + [1]) * n_par)
+                assert rc == 0
+                for i in range(n_steps):
+                    rc, l1 = c.decode(rows[i], [n_prompt + i] * n_par, seq=list(range(n_par)))
+                    assert rc == 0
+                    lg.append(l1)
+            outs[mode] = (np.stack(lg), {k: backend.stat(k) - v for k, v in s0.items()})
+            c.free()
+    finally:
+        backend.set_option("exec_update", 1)
+        backend.set_option("graphs", 1)
+        mg.free()
+    st = outs[1][1]
+    plog(f"failed exec update: 2 x {n_steps} steps of {n_par} sequences: {st}")
+    assert st["graph_exec_update_failures"] >= 1 and st["graph_exec_updates"] == 0, st
+    assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
+    assert np.array_equal(outs[1][0][:n_steps].view(np.uint32), outs[1][0][n_steps:].view(np.uint32))  # the two passes are the same computation
+
+
 @pytest.mark.parametrize("name", ["test-llama", "test-qwen2"])
 def test_sum_of_squares_handed_from_the_residual_mat_vecs_to_the_norm_prologues(backend, H, plog, name):
     """Option ss_partials (on by default, round 4): the mat-vec launches that write a residual stream (wo + residual, ffn_down + residual) leave
