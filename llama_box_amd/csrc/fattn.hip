@@ -530,13 +530,15 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     fa_half2 qh[G][4];    // f16 cache: the query as packed f16
     int qq[G][2];         // q8_0 cache: the query's 8 int8 of this lane's block ...
     float dq[G];          // ... and the block scale (through f16, as block_q8_0.d)
+    int qsb[G];           // the other block formats: the sum of the block's 32 quants ...
+    float sq[G];          // ... and block_q8_1.s (q4_1 / q5_1: multiplies K's minimum)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int h = kvh * g_real + min(g, g_real - 1);
         const float4 * qp = (const float4 *) ((const float *) (q.data + (int64_t) tok * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]) + sl * 8);
         const float4 qa = qp[0], qb = qp[1];
         const float z = g < g_real ? 1.0f : 0.0f;
-        if constexpr (Q8) {  // quantize_row_q8_0 of the query: a block = the 4 lanes of a quad
+        if constexpr (Q8 || DQ) {  // quantize_row_q8_0 / _q8_1 of the query (the vec_dot_type of K's format): a block = the 4 lanes of a quad
             const float xv[8] = {qa.x * z, qa.y * z, qa.z * z, qa.w * z, qb.x * z, qb.y * z, qb.z * z, qb.w * z};
             float amax = 0.0f;
 #pragma unroll
@@ -554,6 +556,13 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             qq[g][0] = (int) w0;
             qq[g][1] = (int) w1;
             dq[g] = h2f(f2h(d));
+            if constexpr (DQ) {  // the block's sum of quants: the "- 8" / "- 16" of q4_0 / q5_0 on the integer sum; block_q8_1.s = f16(sum * d) for q4_1 / q5_1
+                int qs_ = dot4((int) w0, 0x01010101, dot4((int) w1, 0x01010101, 0));
+                qs_ += dpp_i32<MI_DPP_QUAD_XOR1>(qs_);
+                qs_ += dpp_i32<MI_DPP_QUAD_XOR2>(qs_);
+                qsb[g] = qs_;
+                sq[g] = h2f(f2h((float) qs_ * d));
+            }
         } else {
             qh[g][0] = (fa_half2){(_Float16) (qa.x * z), (_Float16) (qa.y * z)};  // q_to_vec_dot: Q -> f16 (round to nearest even)
             qh[g][1] = (fa_half2){(_Float16) (qa.z * z), (_Float16) (qa.w * z)};
@@ -593,11 +602,28 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             uint32_t ku[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vu[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
-            if constexpr (DQ) {  // expand the raw octets to the f16 values an f16 cache would hold here
-                kv_octet_f16_t<KVT>(kraw[u], sl & 3, ku);
-                kv_octet_f16_t<KVT>(vraw[u], sl & 3, vu);
-            }
-            if constexpr (Q8) {
+            if constexpr (DQ) {
+                // ggml-cpu's arithmetic for a block-format cache (round 6): integer block dots of K's levels with the Q8_0 / Q8_1 query, one f32 term per
+                // block in the reference's operation order (ggml_vec_dot_{q4_0,q5_0,iq4_nl}_q8_0, _{q4_1,q5_1}_q8_1); V de-quantised to f32 (to_float)
+                constexpr bool OFFSET = KVT == GGML_TYPE_Q4_1 || KVT == GGML_TYPE_Q5_1;
+                uint32_t k0, k1;
+                kv_octet_levels_t<KVT, true>(kraw[u], sl & 3, k0, k1);
+                const float dk = h2f((uint16_t) (ku[2] & 0xFFFFu));
+                const float mk = OFFSET ? h2f((uint16_t) (ku[2] >> 16)) : 0.0f;
+                kv_octet_f32_t<KVT>(vraw[u], sl & 3, vf[u]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    int isum = dot4((int) k0, qq[g][0], dot4((int) k1, qq[g][1], 0));
+                    isum += dpp_i32<MI_DPP_QUAD_XOR1>(isum);
+                    isum += dpp_i32<MI_DPP_QUAD_XOR2>(isum);
+                    float term;
+                    if constexpr (KVT == GGML_TYPE_Q4_0) term = ((float) (isum - 8 * qsb[g]) * dk) * dq[g];
+                    else if constexpr (KVT == GGML_TYPE_Q5_0) term = (dk * dq[g]) * (float) (isum - 16 * qsb[g]);
+                    else if constexpr (KVT == GGML_TYPE_IQ4_NL) term = (dq[g] * dk) * (float) isum;
+                    else term = (dk * dq[g]) * (float) isum + mk * sq[g];
+                    t[u * G + g] = (sl & 3) == 0 ? term : 0.0f;
+                }
+            } else if constexpr (Q8) {
                 const float dv = h2f((uint16_t) vu[2]), dk = h2f((uint16_t) ku[2]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {  // dequantize_row_q8_0: q * d

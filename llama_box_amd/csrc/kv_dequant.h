@@ -82,6 +82,54 @@ template <int T> __device__ __forceinline__ uint4 kv_load_octet_raw_t(const char
     else if constexpr (T == GGML_TYPE_Q5_0) return make_uint4(ld32_a2(blk + 6 + 8 * (o & 1)), ld32_a2(blk + 10 + 8 * (o & 1)), (uint32_t) ld16(blk), ld32_a2(blk + 2));
     else return make_uint4(ld32_a2(blk + 8 + 8 * (o & 1)), ld32_a2(blk + 12 + 8 * (o & 1)), ld32_a2(blk), ld32_a2(blk + 4));  // Q5_1
 }
+// the eight integer LEVELS of an octet as the bytes of two dwords — what the reference's integer block dots multiply (ggml_vec_dot_q4_0_q8_0 ...:
+// oracle/ggml_cpu_ref.c restates them) and what dequantize_row_* scales.  q4_0 / q4_1: the nibble 0..15; q5_0 / q5_1: nibble | fifth bit << 4 = 0..31 (the
+// "- 8" / "- 16" of the symmetric formats is applied to the block's integer sum by the caller: sum((n - 8) q) = sum(n q) - 8 sum(q));
+// iq4_nl: the table value itself as a SIGNED byte (SIGNED = true: the dot's operand) or + 128 as an unsigned one (the V side: cvt_f32_ubyte, then - 128 d).
+template <int T, bool SIGNED> __device__ __forceinline__ void kv_octet_levels_t(const uint4 raw, const int o, uint32_t & t0, uint32_t & t1) {
+    constexpr bool FIVE = T == GGML_TYPE_Q5_0 || T == GGML_TYPE_Q5_1;
+    const int sh = (o >> 1) * 4;
+    t0 = (raw.x >> sh) & 0x0F0F0F0Fu;
+    t1 = (raw.y >> sh) & 0x0F0F0F0Fu;
+    if constexpr (FIVE) {
+        const uint32_t b = raw.w >> (8 * o);
+        t0 |= (((b & 0xFu) * 0x00204081u) & 0x01010101u) << 4;
+        t1 |= ((((b >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) << 4;
+    }
+    if constexpr (T == GGML_TYPE_IQ4_NL) {
+        // {-127, -104, -83, -65 | -49, -35, -22, -10 || 1, 13, 25, 38 | 53, 69, 89, 113} as two's-complement bytes, or + 128
+        constexpr uint32_t A0 = SIGNED ? 0xBFAD9881u : 0x3F2D1801u, A1 = SIGNED ? 0xF6EADDCFu : 0x766A5D4Fu, B0 = SIGNED ? 0x26190D01u : 0xA6998D81u, B1 = SIGNED ? 0x71594535u : 0xF1D9C5B5u;
+        const uint32_t s0 = t0 & 0x07070707u, s1 = t1 & 0x07070707u;
+        const uint32_t m0 = ((t0 >> 3) & 0x01010101u) * 0xFFu, m1 = ((t1 >> 3) & 0x01010101u) * 0xFFu;
+        t0 = (__builtin_amdgcn_perm(A1, A0, s0) & ~m0) | (__builtin_amdgcn_perm(B1, B0, s0) & m0);
+        t1 = (__builtin_amdgcn_perm(A1, A0, s1) & ~m1) | (__builtin_amdgcn_perm(B1, B0, s1) & m1);
+    }
+}
+// ... and the eight VALUES in f32 exactly as dequantize_row_* leaves them (v_to_float of ggml-cpu's flash attention: a block-format V row is accumulated in f32):
+// symmetric formats (level - z) * d — computed as fma(level, d, -z d): z d is exact, the fma rounds the exact product once, the same number; offset formats
+// level * d, rounded, + m, rounded (the reference is compiled without contraction, and so is this file)
+template <int T> __device__ __forceinline__ void kv_octet_f32_t(const uint4 raw, const int o, float (&y)[8]) {
+    constexpr bool OFFSET = T == GGML_TYPE_Q4_1 || T == GGML_TYPE_Q5_1, FIVE = T == GGML_TYPE_Q5_0 || T == GGML_TYPE_Q5_1;
+    uint32_t t0, t1;
+    kv_octet_levels_t<T, false>(raw, o, t0, t1);
+    const float d = h2f((uint16_t) (raw.z & 0xFFFFu));
+    if constexpr (OFFSET) {
+        const float m = h2f((uint16_t) (raw.z >> 16));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            y[i] = (float) ((t0 >> (8 * i)) & 0xFFu) * d + m;
+            y[4 + i] = (float) ((t1 >> (8 * i)) & 0xFFu) * d + m;
+        }
+    } else {
+        constexpr float Z = T == GGML_TYPE_IQ4_NL ? 128.0f : FIVE ? 16.0f : 8.0f;
+        const float zd = -Z * d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            y[i] = __builtin_fmaf((float) ((t0 >> (8 * i)) & 0xFFu), d, zd);
+            y[4 + i] = __builtin_fmaf((float) ((t1 >> (8 * i)) & 0xFFu), d, zd);
+        }
+    }
+}
 template <int T> __device__ __forceinline__ constexpr int kv_block_bytes_t() { return (T == GGML_TYPE_Q4_0 || T == GGML_TYPE_IQ4_NL) ? 18 : T == GGML_TYPE_Q4_1 ? 20 : T == GGML_TYPE_Q5_0 ? 22 : 24; }
 template <int T> __device__ __forceinline__ void kv_octet_f16_t(const uint4 raw, const int o, uint32_t (&h)[4]) {
     constexpr bool OFFSET = T == GGML_TYPE_Q4_1 || T == GGML_TYPE_Q5_1, FIVE = T == GGML_TYPE_Q5_0 || T == GGML_TYPE_Q5_1;

@@ -3,11 +3,12 @@ iq4_nl, q5_0, q5_1; f16 and q8_0 are the fast paths tested elsewhere).  csrc/kv_
 
   * SET_ROWS f32 -> type ............ the type's from_float per block of 32: BYTE-exact against the oracle (integer / byte work)
   * CPY type <-> f32 (K-shift) ...... cast bit-exact, the copy back byte-exact
-  * FLASH_ATTN_EXT .................. K / V expanded to f16 — in the decode kernel's registers where K and V share an integer-level format (q4_0, q4_1, q5_0, q5_1;
-                                     head_dim 128, up to 32 query tokens), else into an f16 image in scratch — then the f16 kernels' arithmetic.  ggml-cpu quantises every QUERY row to 8 bits (Q8_0 / Q8_1) for
-                                     the block formats; here the query stays f16.  Gates: NMSE <= 1e-3 against the oracle (north_star's band; the two differ by
-                                     the CPU's query quantisation), and against float64 attention over the dequantised cache the kernel must be no further
-                                     away than the oracle is (<= 1e-6 for the float types, where the oracle is exact).
+  * FLASH_ATTN_EXT .................. where K and V share one of q4_0, q4_1, q5_0, q5_1, iq4_nl (head_dim 128, up to 32 query tokens) the decode kernel reads the cache IN
+                                     PLACE with ggml-cpu's arithmetic (round 6): the query row quantised to Q8_0 / Q8_1, integer block dots with K's levels, one f32 term
+                                     per block in the reference's operation order, V de-quantised to f32 — gate NMSE <= 1e-6 against the oracle, as for q8_0.
+                                     Everything else (prompt batches, mixed pairs, bf16 / f32, head_dim 64) is expanded into an f16 image in scratch and runs the f16
+                                     kernels with the query in f16: gate 1e-3 against the oracle (the two differ by the CPU's query quantisation), and against float64
+                                     attention over the dequantised cache the kernel must be no further away than the oracle is (<= 1e-6 for the float types).
   * whole models .................... prompt + greedy steps with every cache type against the oracle; context shift on block-format caches
 """
 import ctypes as C
@@ -201,7 +202,9 @@ def test_flash_attn_over_kv_types(backend, H, plog, tk, tv, HD, NH, NKV, nq, nkv
     in_place = HD == 128 and nq <= 32 and tk == tv and tk in (L.Q4_0, L.Q4_1, L.Q5_0, L.Q5_1, L.IQ4_NL)  # (fattn.hip: fattn_native_kv_ok)
     assert (d_nat, d_img) == ((1, 0) if in_place else (0, 1)), (d_nat, d_img)
     tag = f"flash_attn K={NAME[tk]} V={NAME[tv]} hd={HD} H={NH}/{NKV} nq={nq} nkv={nkv} splits={splits} sinks={sinks}"
-    T.compare(tag, got[0], ref[0], max_nmse=1e-3, log=plog)
+    # in place (round 6): ggml-cpu's own arithmetic — the query row quantised to Q8_0 / Q8_1, integer block dots, V de-quantised to f32 — so the gate is the
+    # one every other integer-dot path of the repo has; through the image (prompt batches, mixed pairs, float types) the query stays f16: north_star's band
+    T.compare(tag, got[0], ref[0], max_nmse=1e-6 if in_place else 1e-3, log=plog)
     if sinks:
         return
     n = NCTX * NKV * HD
@@ -215,6 +218,9 @@ def test_flash_attn_over_kv_types(backend, H, plog, tk, tv, HD, NH, NKV, nq, nkv
         exact[:, h] = (pr @ vh) / pr.sum(axis=1, keepdims=True)
     e_gpu, e_cpu = T.nmse(got[0].reshape(nq, NH, HD), exact), T.nmse(ref[0].reshape(nq, NH, HD), exact)
     plog(f"    vs float64 attention over the dequantised cache: kernel nmse={e_gpu:.3e}  cpu-oracle nmse={e_cpu:.3e}")
+    if in_place:  # the same approximation as the oracle's (its 8-bit query), to the summation order
+        assert e_gpu <= e_cpu * 1.05 + 1e-9
+        return
     assert e_gpu <= 1e-6
     if L.TYPE_BLCK[tk] == 32:  # the oracle's 8-bit query is the larger approximation
         assert e_gpu <= e_cpu * 1.01 + 1e-12
