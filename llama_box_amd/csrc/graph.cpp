@@ -664,6 +664,11 @@ struct qkv_chain {
     const ggml_tensor * out_f32 = nullptr;  // otherwise: last materialised f32 tensor of the chain
     std::vector<int> nodes;
 };
+// the block-format / bf16 cache-row stores ride in the fused Q/K/V launch (round 6); GGML_MI355X_QKV_KV_STORE=0: the separate SET_ROWS launch of round 5 (A/B)
+static bool qkv_kv_store_on() {
+    static const bool on = !getenv("GGML_MI355X_QKV_KV_STORE") || atoi(getenv("GGML_MI355X_QKV_KV_STORE")) != 0;
+    return on;
+}
 // follows mm -> [ADD bias] -> (RESHAPE)* -> [ROPE] -> (RESHAPE)* -> [SET_ROWS]; stops at the first consumer it cannot absorb
 static bool follow_qkv_chain(const exec_state & st, int start, int limit, qkv_chain & ch) {
     const ggml_cgraph * g = st.g;
@@ -702,7 +707,8 @@ static bool follow_qkv_chain(const exec_state & st, int start, int limit, qkv_ch
         }
         if (c->op == GGML_OP_SET_ROWS && c->src[0] == cur && c->ne[0] == N && cur->ne[0] == N && ggml_abi_nelements(cur) == N &&
             c->src[1]->type == GGML_TYPE_I64 && ggml_abi_nelements(c->src[1]) == 1 &&
-            ((c->type == GGML_TYPE_F16 && c->nb[0] == 2) || (c->type == GGML_TYPE_Q8_0 && (N % 32) == 0))) {
+            ((c->type == GGML_TYPE_F16 && c->nb[0] == 2) || (c->type == GGML_TYPE_BF16 && c->nb[0] == 2 && qkv_kv_store_on()) ||
+             ((c->type == GGML_TYPE_Q8_0 || (kv_type_is_block(c->type) && qkv_kv_store_on())) && (N % 32) == 0))) {
             ch.store = c;
             ch.nodes.push_back(j);
             return true;
@@ -753,6 +759,22 @@ static bool try_fuse_qkv(exec_state & st, int i) {
         chains.push_back(ch);
     }
     if (chains.size() < 2) return false;
+    {
+        // a block-format cache row is assembled from 16 consecutive row PAIRS of a workgroup trip: the NeoX layout pairs rows (i, i + d/2) of two different
+        // blocks.  Such a model keeps round 5's form for those caches — the chains end in f32 in front of their SET_ROWS, one more launch stores both rows —
+        // instead of losing the whole fused launch (q8_0 did and does: its SET_ROWS was always part of the chain)
+        bool neox = false;
+        for (auto & ch : chains) neox = neox || (ch.rope && ((ch.rope->op_params[2] & GGML_ROPE_TYPE_NEOX) || (ch.rope->ne[0] % 32) != 0)) || (ch.mm->ne[0] % 32) != 0;
+        if (neox)
+            for (auto & ch : chains)
+                if (ch.store && !ch.scatter && kv_type_is_block(ch.store->type)) {
+                    ch.store = nullptr;
+                    ch.nodes.pop_back();
+                    while (ch.nodes.size() > 1 && is_view_op(g->nodes[ch.nodes.back()]) && g->nodes[ch.nodes.back()] != ch.rope) ch.nodes.pop_back();
+                    ch.out_f32 = g->nodes[ch.nodes.back()];
+                    if (!ggml_abi_is_contiguous(ch.out_f32) || ch.out_f32->type != GGML_TYPE_F32) return false;
+                }
+    }
     bool attn = false;  // only attention projections (something rotates or lands in the KV cache); gate/up siblings have their own fusion
     for (auto & ch : chains) attn = attn || ch.rope || ch.store;
     if (!attn) return false;
@@ -765,8 +787,8 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     // rope / store consistency
     const ggml_tensor * rope0 = nullptr;
     const ggml_tensor * idx0 = nullptr;
-    bool q8_store = false;
-    for (auto & ch : chains) q8_store = q8_store || (ch.store && ch.store->type == GGML_TYPE_Q8_0);
+    bool q8_store = false;  // a cache row in a block format (q8_0, or q4_0 / q4_1 / q5_0 / q5_1 / iq4_nl: kv_quant.h): assembled per block by the launch's workgroups
+    for (auto & ch : chains) q8_store = q8_store || (ch.store && !ch.scatter && (ch.store->type == GGML_TYPE_Q8_0 || kv_type_is_block(ch.store->type)));
     for (auto & ch : chains) {
         if (q8_store) {
             // quantised KV cache: a workgroup trip (16 row pairs) must be exactly one block_q8_0 of the cache row, which the
@@ -863,7 +885,8 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             sg.N = (int) w->ne[1];
             sg.bias = ch.bias ? (const float *) ch.bias->data : nullptr;
             sg.rope = ch.rope ? 1 : 0;
-            sg.store = !ch.store ? 0 : ch.scatter ? 3 : (ch.store->type == GGML_TYPE_Q8_0 ? 2 : 1);
+            sg.store = !ch.store ? 0 : ch.scatter ? 3 : (ch.store->type == GGML_TYPE_F16 ? 1 : ch.store->type == GGML_TYPE_BF16 ? 4 : 2);
+            sg.kvt = (uint8_t) (ch.store && sg.store == 2 ? ch.store->type : 0);
             sg.out = ch.store ? (char *) ch.store->data : (char *) ch.out_f32->data;
             sg.row_stride = !ch.store ? 0 : ch.scatter ? (int64_t) (uintptr_t) ch.store->src[1]->data : (int64_t) ch.store->nb[1];
             bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];

@@ -94,9 +94,9 @@ struct qkv_seg {
     int N;
     uint8_t alt;          // 0 = first weight format of the launch, 1 = second      (alt / rope / store share one dword: see row_stride)
     uint8_t rope;         // rotate pairs of this segment
-    uint8_t store;        // 0: f32 at out; 1: f16 / 2: block_q8_0 into row `slot` of a cache tensor (out + slot*row_stride);
+    uint8_t store;        // 0: f32 at out; 1: f16 / 2: blocks of type `kvt` / 4: bf16 into row `slot` of a cache tensor (out + slot*row_stride);
                           // 3: f16 element j at out + 2 idx[j] (the transposed V cache of the non-flash path: one row index per element)
-    uint8_t pad_;
+    uint8_t kvt;          // store == 2: the cache's block format (GGML_TYPE_Q8_0, Q4_0, Q4_1, Q5_0, Q5_1, IQ4_NL)
     const float * bias;   // optional [N]
     char * out;
     int64_t row_stride;   // store == 3: the address of the int64 index vector instead (no extra field: the struct travels in SGPRs,

@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "mmvq_types.h"
+#include "kv_quant.h"
 
 namespace mi355x {
 
@@ -230,6 +231,10 @@ __global__ void __launch_bounds__(PIPE ? 512 : 1024) k_qkv_stream2(const qkv_arg
                 uint16_t * o = (uint16_t *) (sg.out + slot * sg.row_stride);
                 o[r0] = f2h(v0);
                 o[r1] = f2h(v1);
+            } else if (sg.store == 4) {  // a bf16 cache (-ctk / -ctv bf16)
+                uint16_t * o = (uint16_t *) (sg.out + slot * sg.row_stride);
+                o[r0] = f2bf(v0);
+                o[r1] = f2bf(v1);
             } else if (sg.store == 3) {
                 uint16_t * o = (uint16_t *) sg.out;
                 const int64_t * ix = (const int64_t *) (uintptr_t) sg.row_stride;
@@ -246,7 +251,20 @@ __global__ void __launch_bounds__(PIPE ? 512 : 1024) k_qkv_stream2(const qkv_arg
             // aligns the units; segment and trip count are workgroup-uniform) = one block_q8_0, quantised as
             // quantize_row_q8_0_ref does: d = amax / 127 (stored f16), q = roundf(x * (1 / d))
             __syncthreads();
-            if (wave == 0) {
+            if (wave == 0 && sg.kvt != GGML_TYPE_Q8_0) {
+                // the other block formats of -ctk / -ctv (round 6: their rows used to leave as f32 and a second launch stored them — 7 us per layer): the
+                // type's quantize_row_*_ref with a lane per value (kv_quant.h), byte for byte; the type is uniform over the segment
+                const float x = stash[lane & 31];
+                char * row = sg.out + slot * sg.row_stride;
+                const size_t b = (size_t) ((r0 & ~31) >> 5);
+                switch (sg.kvt) {
+                    case GGML_TYPE_Q4_0: quantize_block_lanes<GGML_TYPE_Q4_0>(x, lane, row + b * 18, lane < 32); break;
+                    case GGML_TYPE_Q4_1: quantize_block_lanes<GGML_TYPE_Q4_1>(x, lane, row + b * 20, lane < 32); break;
+                    case GGML_TYPE_Q5_0: quantize_block_lanes<GGML_TYPE_Q5_0>(x, lane, row + b * 22, lane < 32); break;
+                    case GGML_TYPE_Q5_1: quantize_block_lanes<GGML_TYPE_Q5_1>(x, lane, row + b * 24, lane < 32); break;
+                    default: quantize_block_lanes<GGML_TYPE_IQ4_NL>(x, lane, row + b * 18, lane < 32); break;
+                }
+            } else if (wave == 0) {
                 const float x = stash[lane & 31];
                 float amax = fabsf(x);
 #pragma unroll

@@ -49,3 +49,13 @@ for i in range(len(st) - 1):
     a = big.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += g
 for k, (n, g) in sorted(big.items(), key=lambda kv: -kv[1][1])[:8]:
     print(f"  gap before {k:50s}: {n:3d} x {g / n:5.2f} us")
+# round 6: WHERE the sporadic inner gaps sit — every gap > 1.5 us of the last 8 steps with its index in the step and the kernels either side
+if "-w" in sys.argv:
+    for si in range(-10, -2):
+        stw = rows[ends[si] + 1:ends[si + 1] + 1]
+        out = []
+        for i in range(1, len(stw)):
+            g_ = (stw[i][0] - stw[i - 1][1]) / 1e3
+            if g_ > 1.5:
+                out.append(f"#{i}:{g_:.1f}us[{stw[i - 1][2].replace('mi355x::', '').split('(')[0][5:28]}->{stw[i][2].replace('mi355x::', '').split('(')[0][5:28]}]")
+        print(f"  step {si}: " + " ".join(out))

@@ -312,6 +312,47 @@ def test_model_logits_with_kv_cache_types(backend, H, plog, tk, tv):
             o.free()
 
 
+@pytest.mark.parametrize("tk,tv", [(L.Q4_0, L.Q4_0), (L.Q4_1, L.Q4_1), (L.Q5_0, L.Q5_0), (L.Q5_1, L.Q5_1), (L.IQ4_NL, L.IQ4_NL), (L.BF16, L.BF16), (L.Q8_0, L.Q4_0), (0, L.Q5_1)])
+def test_decode_cache_rows_stored_by_the_fused_qkv_launch_are_byte_exact(backend, H, plog, tk, tv):
+    """Round 6: a decode step's K / V rows of a block-format (or bf16) cache leave the fused Q/K/V launch already in the cache's format (qkv.hip epilogue +
+    kv_quant.h: a lane per value) instead of as f32 rows that one more launch stored (7 us per layer).  Same bytes in every layer's K and V cache, and the
+    same logits bit for bit, as with the fused launch switched off (option qkv 0: the projections, ROPE and SET_ROWS run as separate kernels — the SET_ROWS
+    whose bytes test_set_rows_into_kv_types_is_byte_exact pins on the oracle)."""
+    hp = preset("test-llama", n_head=4, n_head_kv=2, n_embd_head=128)
+    mg = Model(hp, 77, backend.buft)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            backend.set_option("qkv", mode)
+            cg = Context(mg, backend=backend, flash_attn=1, type_k=tk, type_v=tv)
+            k0 = backend.stat("kernel_launches")
+            rc, _ = cg.decode(PROMPT, range(len(PROMPT)), want=[0] * (len(PROMPT) - 1) + [1])
+            assert rc == 0
+            rows = []
+            for i in range(6):
+                rc, lg = cg.decode([3 + 5 * i], [len(PROMPT) + i])
+                assert rc == 0
+                rows.append(lg[0])
+            launches = backend.stat("kernel_launches") - k0
+            caches = []
+            for il in range(hp.n_layer):
+                for which in (0, 1):
+                    t = H.llm_context_cache_tensor(cg.c, il, which)
+                    n = H.ggml_nbytes(t)
+                    raw = np.empty(n, np.uint8)
+                    H.ggml_backend_tensor_get(t, raw.ctypes.data_as(C.c_void_p), 0, n)
+                    caches.append(raw)
+            outs[mode] = (np.stack(rows), caches, launches)
+            cg.free()
+    finally:
+        backend.set_option("qkv", 1)
+        mg.free()
+    plog(f"K={kv_name(tk)} V={kv_name(tv)}: kernel launches for the prompt + 6 decode steps: fused {outs[1][2]}, unfused {outs[0][2]}")
+    for a, b in zip(outs[1][1], outs[0][1]):
+        assert np.array_equal(a, b), "cache bytes differ between the fused launch's epilogue stores and SET_ROWS"
+    assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
+
+
 @pytest.mark.parametrize("t", [L.Q4_0, L.Q5_1, L.IQ4_NL, -1])
 def test_context_shift_on_kv_cache_types(backend, H, plog, t):
     """llama-box context shift (httpserver.hpp:3453-3537) on such a cache: seq_rm + seq_add, K re-rotated on the device through cast -> rope -> cpy (block
