@@ -425,7 +425,9 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const bool pro_norm = dn != st.deferred.end();
     const bool pro_fa = st.fa_wo.b == b && st.fa_wo.part != nullptr;  // (set by the FLASH_ATTN_EXT node after checking this very mat-vec)
     static const bool dbg_no_pro_f32 = getenv("GGML_MI355X_DBG_NO_PRO_F32") != nullptr;
-    const bool pro_f32 = !dbg_no_pro_f32 && !pro_norm && !pro_fa && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
+    // (the producer left b as Q8_K blocks in the activation scratch — the attention combine pass in front of wo, option fa_q8_b1: nothing to quantise here)
+    const bool held_q8 = c->q8_src == b->data && c->q8_kind == act_kind(w->type) && c->q8_bytes == ggml_abi_nbytes(b);
+    const bool pro_f32 = !dbg_no_pro_f32 && !pro_norm && !pro_fa && !held_q8 && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
     if (pro_fa && (w2 || pro_norm || !kquant || M != 1)) {
         MI_ERR("graph_compute: attention partials were left for a mat-vec that cannot merge them");
         return false;
@@ -557,6 +559,12 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     };
     addend(add, a.add, a.add_stride);
     addend(add2, a.add2, a.add2_stride);
+    if (st.ss_tensor != nullptr && ranges_overlap(dst, st.ss_tensor)) st.ss_tensor = nullptr;
+    if (M == 1 && held_q8 && c->opt.ss_partials && c->ss_buf != nullptr && (add || add2) && !w2 && launch_mmvq_ss_count(a) > 0) {
+        a.ss_out = c->ss_buf;  // (wo + residual over pre-quantised activations: the sum of squares for the next norm prologue, as the prologue forms leave it)
+        st.ss_tensor = dst;
+        st.ss_n = launch_mmvq_ss_count(a);
+    }
     const int rpw = (M == 1 && N >= 2048) ? 2 : 1;
     char cls[64];
     snprintf(cls, sizeof(cls), "mmvq_%s%s_nc%d", type_tag(w->type), w2 ? "_glu" : "", (int) std::min<int64_t>(M, 8));
@@ -761,13 +769,13 @@ static bool try_fuse_qkv(exec_state & st, int i) {
     if (chains.size() < 2) return false;
     {
         // a block-format cache row is assembled from 16 consecutive row PAIRS of a workgroup trip: the NeoX layout pairs rows (i, i + d/2) of two different
-        // blocks.  Such a model keeps round 5's form for those caches — the chains end in f32 in front of their SET_ROWS, one more launch stores both rows —
-        // instead of losing the whole fused launch (q8_0 did and does: its SET_ROWS was always part of the chain)
+        // blocks.  Such a model keeps round 5's form for those caches — the chains end in f32 in front of their SET_ROWS, which run as their own launches —
+        // instead of losing the whole fused launch (as a q8_0 cache did until round 6: Qwen2-7B at 8 k context 356 tok/s with -ctk q8_0 against 481 with f16)
         bool neox = false;
         for (auto & ch : chains) neox = neox || (ch.rope && ((ch.rope->op_params[2] & GGML_ROPE_TYPE_NEOX) || (ch.rope->ne[0] % 32) != 0)) || (ch.mm->ne[0] % 32) != 0;
         if (neox)
             for (auto & ch : chains)
-                if (ch.store && !ch.scatter && kv_type_is_block(ch.store->type)) {
+                if (ch.store && !ch.scatter && (kv_type_is_block(ch.store->type) || ch.store->type == GGML_TYPE_Q8_0)) {
                     ch.store = nullptr;
                     ch.nodes.pop_back();
                     while (ch.nodes.size() > 1 && is_view_op(g->nodes[ch.nodes.back()]) && g->nodes[ch.nodes.back()] != ch.rope) ch.nodes.pop_back();
@@ -1899,7 +1907,8 @@ static int run_node(exec_state & st, int i) {
             const ggml_tensor * q8_reader = nullptr;
             // (up to 128 tokens — launch-bound sizes — through the quantising form of the head-pair combine; bigger batches when the row-parallel
             // combine serves them: it quantises in registers)
-            if (fuse && c->opt.prologue && a->ne[1] > 1 &&
+            static const bool fa_q8_b1 = getenv("GGML_MI355X_FA_Q8_B1") && atoi(getenv("GGML_MI355X_FA_Q8_B1")) != 0;  // one decode token too (lab, round 6)
+            if (fuse && c->opt.prologue && (a->ne[1] > 1 || (fa_q8_b1 && a->ne[3] == 1 && !tp_active(c))) &&
                 (a->ne[1] <= 128 || (p.n_splits >= 2 && fattn_combine_rows_applies((int) k->ne[0], a->ne[1], a->ne[2], a->ne[3], p.n_splits, n->src[4] ? (const float *) n->src[4]->data : nullptr))) &&
                 use_count(st, n) == 1 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(n)) {
                 for (int k = i + 1; k < std::min(g->n_nodes, i + 4) && !q8_reader; ++k) {

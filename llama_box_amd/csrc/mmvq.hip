@@ -60,8 +60,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
     if (p < npairs) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            w[r] = T::load(rows[r], p);
-            if (GLU) w2[r] = T::load(rows2[r], p);
+            w[r] = T::load(rows[r], p, nblk);
+            if (GLU) w2[r] = T::load(rows2[r], p, nblk);
         }
     }
 
@@ -152,8 +152,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_mmvq(const mmvq_args a) {
         if (pn < npairs) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                nw[r] = T::load(rows[r], pn);
-                if (GLU) nw2[r] = T::load(rows2[r], pn);
+                nw[r] = T::load(rows[r], pn, nblk);
+                if (GLU) nw2[r] = T::load(rows2[r], pn, nblk);
             }
         }
 #pragma unroll
@@ -239,8 +239,8 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
         for (int u = 0; u < U; ++u) {
             const int p = (c * U + u) * 64 + lane;
             if (p < npairs) {
-                it.w[u] = T::load(rp, p);
-                if (GLU) it.w2[u] = T::load(rp2, p);
+                it.w[u] = T::load(rp, p, nblk);
+                if (GLU) it.w2[u] = T::load(rp2, p, nblk);
             }
         }
     };
@@ -285,8 +285,8 @@ __global__ void __launch_bounds__(1024) k_mmvq_stream(const mmvq_args a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = min(u * 64 + lane, npairs - 1);
-            cur.w[u] = T::load(rp, p);
-            if (GLU) cur.w2[u] = T::load(rp2, p);
+            cur.w[u] = T::load(rp, p, nblk);
+            if (GLU) cur.w2[u] = T::load(rp2, p, nblk);
         }
     } else {
         if (have) load_item(row, 0, cur);
@@ -545,7 +545,11 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
 
 int launch_mmvq_ss_count(const mmvq_args & a) {
     // the streaming kernel with an f32 / norm prologue (launch_type): one column, K-quant or Q8_0 rows of whole 256-value chunks, no SwiGLU
-    if (a.ncols != 1 || a.W2 != nullptr || a.fa_part != nullptr || a.x == nullptr || (a.K % 256) != 0) return 0;
+    if (a.ncols != 1 || a.W2 != nullptr || a.fa_part != nullptr || (a.K % 256) != 0) return 0;
+    if (a.x == nullptr) {  // pre-quantised activations: the streaming form only (launch_type)
+        const size_t blk = a.type == GGML_TYPE_Q8_0 ? 8 * sizeof(q80_dev) : sizeof(q8k_dev);
+        if (a.act == nullptr || (size_t) (a.K / 256) * blk > 60 * 1024) return 0;
+    }
     return (int) std::min<int64_t>(256, ((int64_t) a.N + 15) / 16);
 }
 

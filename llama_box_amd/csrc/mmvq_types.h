@@ -14,6 +14,13 @@ namespace mi355x {
 #ifndef MI_NT_WEIGHTS
 #define MI_NT_WEIGHTS 0
 #endif
+// LAB ONLY (round 6; scripts/lab/build_ab.sh): MI_LAB_PLANES = 1 makes T_Q4K / T_Q6K::load fetch THE SAME NUMBER OF BYTES from the addresses a
+// line-aligned plane repack of the row would have (Q4_K: groups of 8 super-blocks as [8 x 16 B headers | 32 lanes x 16 B q0 | 32 lanes x 16 B q1] = 9 lines;
+// Q6_K: groups of 8 as [A | B | C planes of 512 B] = 12 lines, the scales and d of the whole row behind the groups) — every 128-byte line is touched by exactly
+// one wave-instruction.  The bytes found there are NOT the weights (nothing was repacked): results are wrong, only the timing means anything.
+#ifndef MI_LAB_PLANES
+#define MI_LAB_PLANES 0
+#endif
 typedef uint32_t mi_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t mi_u32x2 __attribute__((ext_vector_type(2)));
 typedef mi_u32x4 mi_u32x4_a2 __attribute__((aligned(2)));
@@ -56,12 +63,20 @@ struct T_Q4K {
     static constexpr int BLK = 256, BYTES = 144, PPB = 4;
     struct raw { uint4 hdr, q0, q1; };
     static constexpr int DW = 12;
-    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
-        const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk = 0) {
+        (void) nblk;
         raw r;
+#if MI_LAB_PLANES
+        const uint8_t * grp = row + (size_t) (p >> 5) * (8 * BYTES);  // 8 super-blocks = 32 lanes = 1152 B = 9 lines
+        r.hdr = ld_stream((const uint4 *) (grp + 16 * ((p >> 2) & 7)));
+        r.q0 = ld_stream((const uint4 *) (grp + 128 + 16 * (p & 31)));
+        r.q1 = ld_stream((const uint4 *) (grp + 128 + 512 + 16 * (p & 31)));
+#else
+        const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         r.hdr = ld_stream((const uint4 *) blk);
         r.q0 = ld_stream((const uint4 *) (blk + 16 + 32 * (p & 3)));
         r.q1 = ld_stream((const uint4 *) (blk + 32 + 32 * (p & 3)));
+#endif
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
@@ -98,7 +113,7 @@ struct T_Q5K {
     static constexpr int BLK = 256, BYTES = 176, PPB = 4;
     struct raw { uint4 hdr, h0, h1, q0, q1; };
     static constexpr int DW = 20;
-    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int = 0) {
         const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         raw r;
         r.hdr = ld_stream((const uint4 *) blk);
@@ -159,10 +174,24 @@ struct T_Q6K {
     static constexpr int BLK = 256, BYTES = 210, PPB = 4;
     struct raw { u128_a2 a, b, c; u64_a2 s; uint16_t d; };
     static constexpr int DW = 15;
-    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk = 0) {
         const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         const int h = (p >> 1) & 1, t = p & 1;
         raw r;
+#if MI_LAB_PLANES
+        {
+            const uint8_t * grp = row + (size_t) (p >> 5) * 1536;  // 8 super-blocks: three planes of 32 lanes x 16 B = 12 lines
+            const uint8_t * tail = row + (size_t) (nblk >> 3) * 1536 + (size_t) (p >> 2) * 16;  // scales: 16 B per super-block behind the groups, then the d's
+            r.a = __builtin_bit_cast(u128_a2, ld_stream((const uint4 *) (grp + 16 * (p & 31))));
+            r.b = __builtin_bit_cast(u128_a2, ld_stream((const uint4 *) (grp + 512 + 16 * (p & 31))));
+            r.c = __builtin_bit_cast(u128_a2, ld_stream((const uint4 *) (grp + 1024 + 16 * (p & 31))));
+            r.s = ld_stream((const u64_a2 *) (tail + 8 * h));
+            r.d = ld16(row + (size_t) (nblk >> 3) * 1536 + (size_t) nblk * 16 + (size_t) (p >> 2) * 2);
+            (void) blk; (void) t;
+            return r;
+        }
+#endif
+        (void) nblk;
         r.a = ld_stream((const u128_a2 *) (blk + 64 * h + 16 * t));
         r.b = ld_stream((const u128_a2 *) (blk + 64 * h + 32 + 16 * t));
         r.c = ld_stream((const u128_a2 *) (blk + 128 + 32 * h + 16 * t));
@@ -213,7 +242,7 @@ struct T_Q80 {
     static constexpr int BLK = 32, BYTES = 34, PPB = 1;
     struct raw { uint32_t q[8]; uint16_t d; };
     static constexpr int DW = 9;
-    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p) {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int = 0) {
         const uint8_t * blk = row + (size_t) p * BYTES;
         raw r;
         r.d = ld16(blk);

@@ -29,8 +29,8 @@ template <typename T> __device__ __forceinline__ void qkv_load(const uint8_t * _
     for (int u = 0; u < U; ++u) {
         const int p = (c * U + u) * 64 + lane;
         if (p < npairs) {
-            r.w[0][u] = T::load(row0, p);
-            r.w[1][u] = T::load(row1, p);
+            r.w[0][u] = T::load(row0, p, npairs / T::PPB);
+            r.w[1][u] = T::load(row1, p, npairs / T::PPB);
         }
     }
 }
