@@ -776,6 +776,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "nf_mma_chains") return c->st.nf_mma_chains;
     if (k == "p2p_allreduces") return c->st.p2p_allreduces;
     if (k == "p2p_timeouts") return tp_p2p_timeouts(c);
+    if (k == "step_heads") return c->st.step_heads;
     if (k == "graph_exec_update_failures") return c->st.graph_exec_update_failures;
     if (k == "graph_evictions") return c->st.graph_evictions;
     if (k == "graph_cache_size") return (int64_t) c->graphs.size();

@@ -155,6 +155,7 @@ struct stats {
     int64_t kernel_downloads = 0;      // get_tensor_async calls served by a copy kernel writing mapped pinned memory
     int64_t graph_early_captures = 0;  // graphs captured at their FIRST sighting (same step as the one replayed last, over a grown cache)
     int64_t graph_exec_updates = 0;    // ... of them, served by patching the predecessor's executable graph (hipGraphExecUpdate) instead of instantiating
+    int64_t step_heads = 0;            // decode-step heads served by one launch: GET_ROWS + mask cast + rotary table (ops.hip: k_step_head)
     int64_t graph_exec_update_failures = 0; // ... and updates that failed: the predecessor's (possibly half-patched) executable graph is destroyed, both entries start over
     int64_t graph_evictions = 0;       // cache entries dropped because they had not been used for 256 graphs
     int64_t graph_key_collisions = 0;  // two different graph keys with one hash (each keeps its own entry)

@@ -425,9 +425,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     const bool pro_norm = dn != st.deferred.end();
     const bool pro_fa = st.fa_wo.b == b && st.fa_wo.part != nullptr;  // (set by the FLASH_ATTN_EXT node after checking this very mat-vec)
     static const bool dbg_no_pro_f32 = getenv("GGML_MI355X_DBG_NO_PRO_F32") != nullptr;
-    // (the producer left b as Q8_K blocks in the activation scratch — the attention combine pass in front of wo, option fa_q8_b1: nothing to quantise here)
-    const bool held_q8 = c->q8_src == b->data && c->q8_kind == act_kind(w->type) && c->q8_bytes == ggml_abi_nbytes(b);
-    const bool pro_f32 = !dbg_no_pro_f32 && !pro_norm && !pro_fa && !held_q8 && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
+    const bool pro_f32 = !dbg_no_pro_f32 && !pro_norm && !pro_fa && c->opt.fusion && c->opt.prologue && kquant && M == 1 && b->type == GGML_TYPE_F32 && b->nb[0] == 4 && (((uintptr_t) b->data) & 15) == 0;
     if (pro_fa && (w2 || pro_norm || !kquant || M != 1)) {
         MI_ERR("graph_compute: attention partials were left for a mat-vec that cannot merge them");
         return false;
@@ -559,12 +557,6 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     };
     addend(add, a.add, a.add_stride);
     addend(add2, a.add2, a.add2_stride);
-    if (st.ss_tensor != nullptr && ranges_overlap(dst, st.ss_tensor)) st.ss_tensor = nullptr;
-    if (M == 1 && held_q8 && c->opt.ss_partials && c->ss_buf != nullptr && (add || add2) && !w2 && launch_mmvq_ss_count(a) > 0) {
-        a.ss_out = c->ss_buf;  // (wo + residual over pre-quantised activations: the sum of squares for the next norm prologue, as the prologue forms leave it)
-        st.ss_tensor = dst;
-        st.ss_n = launch_mmvq_ss_count(a);
-    }
     const int rpw = (M == 1 && N >= 2048) ? 2 : 1;
     char cls[64];
     snprintf(cls, sizeof(cls), "mmvq_%s%s_nc%d", type_tag(w->type), w2 ? "_glu" : "", (int) std::min<int64_t>(M, 8));
@@ -1730,6 +1722,68 @@ static int run_node(exec_state & st, int i) {
             return 1;
         }
         case GGML_OP_GET_ROWS: {
+            // the head of a decode step (round 6): the token embeddings' GET_ROWS, the mask's F32 -> F16 cast (an input leaf cast once per graph) and the (cos, sin) table
+            // the fused Q/K/V launches of every layer read are independent of each other — one launch instead of three at the dependent-launch floor.  The cast is
+            // hoisted over the nodes between only when its result's memory is not touched by any of them; the table is the one ensure_rope_table would build at the
+            // first fused Q/K/V launch (same positions, parameters, token count: it then finds it valid), and is simply rebuilt there if the guess was wrong
+            static const bool head_on = !getenv("GGML_MI355X_STEP_HEAD") || atoi(getenv("GGML_MI355X_STEP_HEAD")) != 0;
+            const int64_t n_rows = b->ne[0] * b->ne[1] * b->ne[2];
+            if (head_on && fuse && !c->opt.timing && n_rows <= 64) {
+                const ggml_tensor * cast = nullptr;
+                int cast_at = -1;
+                const ggml_tensor * rope = nullptr;
+                const int lim = std::min(g->n_nodes, i + 48);
+                for (int k = i + 1; k < lim && (!cast || !rope); ++k) {
+                    const ggml_tensor * t = g->nodes[k];
+                    if (st.done[k]) continue;
+                    if (!cast && t->op == GGML_OP_CPY && t->src[0]->type == GGML_TYPE_F32 && t->type == GGML_TYPE_F16 && t->src[0]->op == GGML_OP_NONE &&
+                        ggml_abi_is_contiguous(t->src[0]) && ggml_abi_is_contiguous(t) && same_shape(t->src[0], t) && ggml_abi_nelements(t) <= (int64_t) 1 << 22) {
+                        bool clean = !ranges_overlap(t, n) && !ranges_overlap(t, a) && !ranges_overlap(t, b);
+                        for (int m = i + 1; m < k && clean; ++m) {
+                            const ggml_tensor * u = g->nodes[m];
+                            clean = !ranges_overlap(t, u);
+                            for (int q = 0; q < GGML_MAX_SRC && clean; ++q)
+                                if (u->src[q]) clean = !ranges_overlap(t, u->src[q]);
+                        }
+                        if (clean) { cast = t; cast_at = k; }
+                    }
+                    if (!rope && t->op == GGML_OP_ROPE && t->type == GGML_TYPE_F32 && !(t->op_params[2] & GGML_ROPE_TYPE_MROPE) && t->src[1] && t->src[1]->op == GGML_OP_NONE &&
+                        t->src[1]->type == GGML_TYPE_I32 && (!t->src[2] || t->src[2]->op == GGML_OP_NONE))
+                        rope = t;
+                }
+                rope_params rp{};
+                int rope_m = 0;
+                if (rope && c->rope_tab) {
+                    rp.n_dims = rope->op_params[1];
+                    rp.mode = rope->op_params[2];
+                    rp.n_ctx_orig = rope->op_params[4];
+                    rp.freq_base = ggml_abi_op_param_f32(rope, 5);
+                    rp.freq_scale = ggml_abi_op_param_f32(rope, 6);
+                    rp.ext_factor = ggml_abi_op_param_f32(rope, 7);
+                    rp.attn_factor = ggml_abi_op_param_f32(rope, 8);
+                    rp.beta_fast = ggml_abi_op_param_f32(rope, 9);
+                    rp.beta_slow = ggml_abi_op_param_f32(rope, 10);
+                    memset(rp.sections, 0, sizeof(rp.sections));
+                    rope_m = (int) rope->ne[2];
+                    static const bool tab_on = !getenv("GGML_MI355X_ROPE_TABLE") || atoi(getenv("GGML_MI355X_ROPE_TABLE")) != 0;
+                    if (!tab_on || rope_m < 1 || rope_m > 64 || rp.n_dims < 2 || rp.n_dims > 256 || (int64_t) rope_m * rp.n_dims > (int64_t) backend_ctx::rope_tab_floats) rope_m = 0;
+                }
+                if (cast || rope_m > 0) {
+                    const tdesc ta = TD(a), tb = TD(b), tn = TD(n);
+                    launch_step_head(s, &ta, &tb, &tn, cast ? (const float *) cast->src[0]->data : nullptr, cast ? cast->data : nullptr, cast ? ggml_abi_nelements(cast) : 0,
+                                     rope_m > 0 ? (const int32_t *) rope->src[1]->data : nullptr, rope_m > 0 && rope->src[2] ? (const float *) rope->src[2]->data : nullptr, &rp, rope_m, c->rope_tab);
+                    c->st.kernel_launches++;
+                    c->st.step_heads++;
+                    if (cast) { mark_done(st, cast_at); c->st.fused_nodes++; }
+                    if (rope_m > 0) {
+                        st.rope_tab_pos = rope->src[1]->data;
+                        st.rope_tab_ff = rope->src[2] ? rope->src[2]->data : nullptr;
+                        st.rope_tab_p = rp;
+                        st.rope_tab_m = rope_m;
+                    }
+                    return 1;
+                }
+            }
             timed_scope ts(c, "get_rows", (double) ggml_abi_nbytes(n));
             launch_get_rows(s, TD(a), TD(b), TD(n));
             c->st.kernel_launches++;
@@ -1907,8 +1961,9 @@ static int run_node(exec_state & st, int i) {
             const ggml_tensor * q8_reader = nullptr;
             // (up to 128 tokens — launch-bound sizes — through the quantising form of the head-pair combine; bigger batches when the row-parallel
             // combine serves them: it quantises in registers)
-            static const bool fa_q8_b1 = getenv("GGML_MI355X_FA_Q8_B1") && atoi(getenv("GGML_MI355X_FA_Q8_B1")) != 0;  // one decode token too (lab, round 6)
-            if (fuse && c->opt.prologue && (a->ne[1] > 1 || (fa_q8_b1 && a->ne[3] == 1 && !tp_active(c))) &&
+            // (one decode token: measured in round 6 — the combine pass leaving Q8_K blocks and wo without a prologue is no faster: the quantising combine +0.3 us,
+            // wo on pre-quantised blocks 7.2 us against ~5.6 with its f32 prologue; profiles/r06_lab_combine_q8k_to_wo_batch1.txt)
+            if (fuse && c->opt.prologue && a->ne[1] > 1 &&
                 (a->ne[1] <= 128 || (p.n_splits >= 2 && fattn_combine_rows_applies((int) k->ne[0], a->ne[1], a->ne[2], a->ne[3], p.n_splits, n->src[4] ? (const float *) n->src[4]->data : nullptr))) &&
                 use_count(st, n) == 1 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_abi_is_contiguous(n)) {
                 for (int k = i + 1; k < std::min(g->n_nodes, i + 4) && !q8_reader; ++k) {

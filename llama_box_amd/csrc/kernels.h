@@ -242,6 +242,9 @@ struct rope_params {
 void rope_host_consts(const rope_params & p, float & theta_scale, float & corr0, float & corr1);
 // (cos, sin) of every (token, rotation pair) of a small batch — rope_cos_sin's arithmetic, once per graph run instead of once per layer and element
 void launch_rope_table(hipStream_t s, const int32_t * pos, const float * ff, const rope_params & p, int n_tok, float * tab);
+// GET_ROWS + the mask's F32 -> F16 cast + the rotary (cos, sin) table of a decode step in one launch (ops.hip: k_step_head); absent parts: a == nullptr / cp_n == 0 / n_tok == 0
+void launch_step_head(hipStream_t s, const tdesc * a, const tdesc * idx, const tdesc * d, const float * cp_src, void * cp_dst, int64_t cp_n,
+                      const int32_t * pos, const float * ff, const rope_params * p, int n_tok, float * tab);
 // batches: ROPE(q) + ROPE(k) + SET_ROWS(k) + SET_ROWS(v) in one launch (f32 sources [head_dim, heads, tokens], f16 cache rows)
 struct rope_store_args {
     const char * q_src; char * q_dst; const char * k_src; const char * v_src;

@@ -545,11 +545,7 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
 
 int launch_mmvq_ss_count(const mmvq_args & a) {
     // the streaming kernel with an f32 / norm prologue (launch_type): one column, K-quant or Q8_0 rows of whole 256-value chunks, no SwiGLU
-    if (a.ncols != 1 || a.W2 != nullptr || a.fa_part != nullptr || (a.K % 256) != 0) return 0;
-    if (a.x == nullptr) {  // pre-quantised activations: the streaming form only (launch_type)
-        const size_t blk = a.type == GGML_TYPE_Q8_0 ? 8 * sizeof(q80_dev) : sizeof(q8k_dev);
-        if (a.act == nullptr || (size_t) (a.K / 256) * blk > 60 * 1024) return 0;
-    }
+    if (a.ncols != 1 || a.W2 != nullptr || a.fa_part != nullptr || a.x == nullptr || (a.K % 256) != 0) return 0;
     return (int) std::min<int64_t>(256, ((int64_t) a.N + 15) / 16);
 }
 

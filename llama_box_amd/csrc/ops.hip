@@ -470,6 +470,79 @@ __global__ void __launch_bounds__(256) k_rope_table(const int32_t * __restrict__
     rope_cos_sin(ip, (float) pos[tok], ff, rc, cs, sn);
     *(float2 *) (tab + ((size_t) tok * half + ip) * 2) = make_float2(cs, sn);
 }
+// ---- the head of a decode step in ONE launch (round 6): GET_ROWS of the token embeddings, the F32 -> F16 cast of the attention mask (llama.cpp builds the mask in
+// F32 and casts it for flash attention) and the (cos, sin) table of the step's positions used to be three dependent launches at the ~4.5 us floor each, in front of
+// layer 0.  They do not depend on each other: blocks [0, n_rows) gather a row each (k_get_rows), the next n_cpy blocks cast (k_cpy's contiguous case), the last
+// n_tok blocks fill the rotary table (k_rope_table).  Element formulas are the three kernels' own.
+struct step_head_args {
+    tdesc gr_a, gr_idx, gr_d;
+    int n_rows;
+    const float * cp_src;
+    uint16_t * cp_dst;
+    int64_t cp_n;
+    int n_cpy;
+    const int32_t * pos;
+    const float * ff;
+    rope_consts rc;
+    int half, n_tok;
+    float * tab;
+};
+__global__ void __launch_bounds__(1024) k_step_head(const step_head_args h) {
+    int b = (int) blockIdx.x;
+    if (b < h.n_rows) {
+        const tdesc & a = h.gr_a, & idx = h.gr_idx, & d = h.gr_d;
+        const int64_t r = b;
+        const int64_t i10 = r % idx.ne[0], i11 = (r / idx.ne[0]) % idx.ne[1], i12 = r / (idx.ne[0] * idx.ne[1]);
+        const int32_t i01 = *(const int32_t *) (idx.data + i10 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+        const uint8_t * row = (const uint8_t *) (a.data + (int64_t) i01 * a.nb[1] + i11 * a.nb[2] + i12 * a.nb[3]);
+        float * y = (float *) (d.data + i10 * d.nb[1] + i11 * d.nb[2] + i12 * d.nb[3]);
+#pragma unroll 4
+        for (int64_t i = threadIdx.x; i < a.ne[0]; i += blockDim.x) y[i] = dequant_elem(a.type, row, i);
+        return;
+    }
+    b -= h.n_rows;
+    if (b < h.n_cpy) {
+        for (int64_t e = (int64_t) b * blockDim.x + threadIdx.x; e < h.cp_n; e += (int64_t) h.n_cpy * blockDim.x) h.cp_dst[e] = f2h(h.cp_src[e]);
+        return;
+    }
+    b -= h.n_cpy;
+    if (b < h.n_tok && (int) threadIdx.x < h.half) {
+        float cs, sn;
+        rope_cos_sin((int) threadIdx.x, (float) h.pos[b], h.ff, h.rc, cs, sn);
+        *(float2 *) (h.tab + ((size_t) b * h.half + threadIdx.x) * 2) = make_float2(cs, sn);
+    }
+}
+void rope_host_consts(const rope_params & p, float & theta_scale, float & c0, float & c1);
+// any of the three parts may be absent (idx == nullptr / cp_n == 0 / n_tok == 0)
+void launch_step_head(hipStream_t s, const tdesc * a, const tdesc * idx, const tdesc * d, const float * cp_src, void * cp_dst, int64_t cp_n,
+                      const int32_t * pos, const float * ff, const rope_params * p, int n_tok, float * tab) {
+    step_head_args h{};
+    if (a) {
+        h.gr_a = *a;
+        h.gr_idx = *idx;
+        h.gr_d = *d;
+        h.n_rows = (int) (idx->ne[0] * idx->ne[1] * idx->ne[2]);
+    }
+    h.cp_src = cp_src;
+    h.cp_dst = (uint16_t *) cp_dst;
+    h.cp_n = cp_n;
+    h.n_cpy = cp_n > 0 ? (int) std::min<int64_t>(64, (cp_n + 4095) / 4096) : 0;
+    if (n_tok > 0) {
+        rope_host_consts(*p, h.rc.theta_scale, h.rc.corr0, h.rc.corr1);
+        h.rc.freq_scale = p->freq_scale;
+        h.rc.ext_factor = p->ext_factor;
+        h.rc.attn_factor = p->attn_factor;
+        h.half = p->n_dims / 2;
+        h.n_tok = n_tok;
+        h.pos = pos;
+        h.ff = ff;
+        h.tab = tab;
+    }
+    const int grid = h.n_rows + h.n_cpy + h.n_tok;
+    if (grid <= 0) return;
+    const int64_t width = std::max<int64_t>(a ? a->ne[0] : 0, std::max<int64_t>(cp_n > 0 ? 1024 : 0, h.half));
+    hipLaunchKernelGGL(k_step_head, dim3((unsigned) grid), dim3((unsigned) std::min<int64_t>(1024, std::max<int64_t>(64, (width + 63) / 64 * 64))), 0, s, h);
+}
 void rope_host_consts(const rope_params & p, float & theta_scale, float & c0, float & c1) {
     theta_scale = powf(p.freq_base, -2.0f / (float) p.n_dims);
     // ggml_rope_yarn_corr_dims
