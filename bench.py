@@ -718,6 +718,9 @@ def main():
             # device time of one row-parallel sum (hipEvents on the backend's stream around k_p2p_all_reduce / the RCCL call, eager timing pass): fills DESIGN §6's budget row on real xGMI
             "allreduce_us": round(classes["tp_all_reduce"][1] * 1e3 / max(1, classes["tp_all_reduce"][0]), 2) if "tp_all_reduce" in classes else None,
             "tp_stats": {"allreduces": int(be.stat("allreduces")), "p2p_launches_issued": int(be.stat("p2p_allreduces")), "p2p_timeouts": int(be.stat("p2p_timeouts"))} if tp_size > 1 and not emulated else None,
+            # the decode copy (round 6): K-quant matrices kept a second time in the plane layout the batch-1 mat-vec kernels stream with non-temporal loads (csrc/repack.hip)
+            "decode_copy": {"tensors": int(be.stat("decode_copy_tensors")), "bytes": int(be.stat("decode_copy_bytes")), "launches_streaming_it": int(be.stat("decode_copy_launches")),
+                            "step_heads_in_one_launch": int(be.stat("step_heads"))},
             "graph_replayed_steps": int(graph_steps), "hipGraphLaunch_host_us": round(graph_launch_host_us, 1), "graph_compute_host_us_per_step": host_graph,
             "host_us_per_step": {"build": round(host_split[0], 1), "inputs": round(host_split[1], 1), "compute+sync": round(host_split[2], 1), "logits_d2h": round(host_split[3], 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,

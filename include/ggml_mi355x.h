@@ -55,6 +55,7 @@ ggml_backend_reg_t ggml_backend_mi355x_reg(void);
  *   "ggml_backend_mi355x_tp_p2p_attach"   ggml_backend_mi355x_tp_p2p_attach_t
  *   "ggml_backend_mi355x_tp_all_reduce"   ggml_backend_mi355x_tp_all_reduce_t
  *   "ggml_backend_mi355x_graph_key_probe" ggml_backend_mi355x_graph_key_probe_t   (tests: is graph b the graph a captured hipGraph of a stands for?)
+ *   "ggml_backend_mi355x_decode_copy_read" ggml_backend_mi355x_decode_copy_read_t (tests: the plane-layout decode copy of a weight matrix, csrc/repack.hip)
  */
 
 /* Replaces: ggml_backend_cuda_split_buffer_type(int main_device, const float * tensor_split) of the stock GPU backends, as reached
@@ -89,14 +90,20 @@ typedef ggml_backend_buffer_type_t (*ggml_backend_mi355x_tp_rowpar_buffer_type_t
  * Host arithmetic: works without a device. */
 typedef int (*ggml_backend_mi355x_graph_key_probe_t)(const struct ggml_cgraph * a, const struct ggml_cgraph * b, int64_t * n_words);
 
+/* The decode copy (round 6): K-quant weight matrices of a usage-WEIGHTS buffer are kept a second time in a line-aligned plane layout that the batch-1 mat-vec kernels
+ * stream with non-temporal loads (csrc/repack.hip, csrc/mmvq_types.h; option "decode_copy", GGML_MI355X_DECODE_COPY).  The tensor the host uploaded stays as it is:
+ * get_tensor returns its bytes, the batch kernels and GET_ROWS read it.  This entry returns the copy's bytes (tests compare them with the documented permutation):
+ * the number of bytes written to `out` (or needed, when out is NULL / too small), 0 when the tensor has no copy, -1 on error. */
+typedef int64_t (*ggml_backend_mi355x_decode_copy_read_t)(ggml_backend_t backend, const struct ggml_tensor * t, void * out, size_t size);
+
 /* Runtime options (string key/value); 0 = accepted, -1 = unknown key, -2 = refused (e.g. "tp_p2p" = 0 in a group whose only transport the mailboxes are).  Keys (INTEGRATION.md 4b lists the defaults and the
  * environment variables that set the same things): "graphs", "fusion", "prologue", "qkv", "mm_merge", "mmq_i8", "mmq_bn",
  * "mmq_skinny", "skinny_rope", "softmax_mm", "attn_nf", "mmq_min_cols", "mmvq_max_cols", "fa_splits", "fa_wo", "fa_self_merge", "small_uploads", "small_downloads",
- * "timing", "tp_p2p", "tp_p2p_reset" (forget an all-reduce time-out: every rank, all idle), "clear_failure" (forget a remembered HIP failure of a status-less entry point). */
+ * "exec_update", "decode_copy", "timing", "tp_p2p", "tp_p2p_reset" (forget an all-reduce time-out: every rank, all idle), "clear_failure" (forget a remembered HIP failure of a status-less entry point). */
 typedef int (*ggml_backend_mi355x_set_option_t)(ggml_backend_t backend, const char * key, const char * value);
 /* Counters for tests/bench: "graph_launches", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs", "kernel_launches", "fused_nodes",
  * "allreduces", "p2p_allreduces", "p2p_timeouts", "graph_launch_host_ns", "graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits", "graph_key_collisions",
- * "kernel_downloads", "kv_image_nodes", "kv_native_nodes", "skinny_launches", "wide_launches", "tiled_launches", "rope_epilogues", "fa_list_launches"; in-process tensor parallel (-sm row, csrc/tp_inproc.cpp):
+ * "kernel_downloads", "graph_exec_update_failures", "graph_evictions", "graph_cache_size", "step_heads", "decode_copy_tensors", "decode_copy_bytes", "decode_copy_launches", "kv_image_nodes", "kv_native_nodes", "skinny_launches", "wide_launches", "tiled_launches", "rope_epilogues", "fa_list_launches"; in-process tensor parallel (-sm row, csrc/tp_inproc.cpp):
  * "ip_devices", "ip_graphs", "ip_declined", "ip_plans", "ip_input_copies", "ip_output_copies", "ip_kv_gathers", "ip_kv_scatters", "ip_worker_kernel_launches",
  * "ip_worker_graph_launches", "ip_worker_p2p_timeouts". */
 typedef int64_t (*ggml_backend_mi355x_get_stat_t)(ggml_backend_t backend, const char * key);

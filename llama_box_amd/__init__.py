@@ -139,7 +139,7 @@ _SIGS = {
     "ggml_backend_buft_name": (_S, [_P]), "ggml_backend_buft_alloc_buffer": (_P, [_P, _SZ]),
     "ggml_backend_buft_get_alignment": (_SZ, [_P]), "ggml_backend_buft_is_host": (_B, [_P]),
     "ggml_backend_buffer_free": (None, [_P]), "ggml_backend_buffer_get_base": (_P, [_P]), "ggml_backend_buffer_get_size": (_SZ, [_P]),
-    "ggml_backend_buffer_clear": (None, [_P, C.c_uint8]),
+    "ggml_backend_buffer_clear": (None, [_P, C.c_uint8]), "ggml_backend_buffer_set_usage": (None, [_P, _I]),
     "ggml_backend_name": (_S, [_P]), "ggml_backend_free": (None, [_P]),
     "ggml_backend_tensor_set": (None, [TP, _P, _SZ, _SZ]), "ggml_backend_tensor_get": (None, [TP, _P, _SZ, _SZ]),
     "ggml_backend_tensor_memset": (None, [TP, C.c_uint8, _SZ, _SZ]),

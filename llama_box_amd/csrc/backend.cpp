@@ -63,11 +63,68 @@ ggml_backend_buffer_t make_backend_buffer(ggml_backend_buffer_type_t buft, const
 }
 
 static void uploader_drain(int device);
+// ---- the decode copy's bookkeeping (common.h: buffer_ctx::shadow)
+static std::atomic<uint64_t> g_decode_epoch{1};
+uint64_t decode_copy_epoch() { return g_decode_epoch.load(std::memory_order_acquire); }
+// bytes [off, off + n) of the buffer are about to change: the copies of tensors in that range are stale from now on
+static void decode_copy_drop(buffer_ctx * c, size_t off, size_t n) {
+    if (c->shadow == nullptr) return;
+    std::lock_guard<std::mutex> lk(c->sh_mtx);
+    if (c->sh_valid.empty()) return;
+    bool any = false;
+    for (auto it = c->sh_valid.begin(); it != c->sh_valid.end();) {
+        if (it->first < off + n && off < it->first + it->second) { it = c->sh_valid.erase(it); any = true; }
+        else ++it;
+    }
+    if (any) g_decode_epoch.fetch_add(1, std::memory_order_acq_rel);
+}
+static void decode_copy_drop(ggml_backend_buffer_t b, const ggml_tensor * t, size_t offset, size_t size) {
+    buffer_ctx * c = (buffer_ctx *) b->context;
+    if (c->shadow != nullptr && t->data != nullptr) decode_copy_drop(c, (size_t) ((const char *) t->data - (const char *) c->base) + offset, size);
+}
+const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w) {
+    if (!c->opt.decode_copy || w == nullptr || w->view_src != nullptr || w->data == nullptr || w->ne[2] != 1 || w->ne[3] != 1) return nullptr;
+    ggml_backend_buffer_t b = w->buffer;
+    if (b == nullptr || !buffer_is_ours(b) || b->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS || buffer_is_split(b) || buffer_is_rowpar(b)) return nullptr;
+    if (!repack_supported(w->type, w->ne[0], (int64_t) w->nb[1])) return nullptr;
+    buffer_ctx * bc = (buffer_ctx *) b->context;
+    if (bc->device != c->device || bc->shadow_failed) return nullptr;
+    const size_t off = (size_t) ((const char *) w->data - (const char *) bc->base), bytes = (size_t) w->nb[1] * (size_t) w->ne[1];
+    if (off + bytes > bc->size) return nullptr;
+    std::lock_guard<std::mutex> lk(bc->sh_mtx);
+    auto it = bc->sh_valid.find(off);
+    if (it != bc->sh_valid.end() && it->second == bytes) return (const uint8_t *) bc->shadow + off;
+    if (c->capturing) return nullptr;  // (a capture is the SECOND run of a graph: its weights were repacked by the first; anything else keeps the block layout)
+    if (bc->shadow == nullptr) {
+        // 288 GB of HBM: a second copy of the weights one GPU serves always fits beside the first — unless the user filled the device on purpose; then the
+        // mat-vecs keep reading the block layout, as before round 6
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bc->size + ((size_t) 2 << 30) || hipMalloc(&bc->shadow, bc->size) != hipSuccess) {
+            (void) hipGetLastError();
+            bc->shadow = nullptr;
+            bc->shadow_failed = true;
+            MI_INFO("decode copy: no room for a second copy of a %.1f GiB weights buffer on device %d — the mat-vec kernels read the block layout", (double) bc->size / (1 << 30), bc->device);
+            return nullptr;
+        }
+    }
+    launch_repack_planes(c->stream, w->type, w->data, (char *) bc->shadow + off, w->ne[0], (int64_t) w->nb[1], 0, w->ne[1]);
+    // (another backend instance of this device — its own stream — may find the entry valid a moment later: the copy is complete before it is announced)
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    bc->sh_valid[off] = bytes;
+    c->st.decode_copy_tensors++;
+    c->st.decode_copy_bytes += (int64_t) bytes;
+    return (const uint8_t *) bc->shadow + off;
+}
 static void buf_free(ggml_backend_buffer_t b) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     if (ip_any()) ip_host_buffer_freed(b);  // (tp_inproc.cpp mirrors host buffers on the other devices)
     HIP_SOFT(hipSetDevice(c->device));
     uploader_drain(c->device);  // a staged upload may still be writing into this arena
+    if (c->shadow) {  // (graphs captured over it must never be replayed: a new buffer may get the same addresses)
+        HIP_SOFT(hipDeviceSynchronize());
+        HIP_NOTE(hipFree(c->shadow));
+        g_decode_epoch.fetch_add(1, std::memory_order_acq_rel);
+    }
     HIP_NOTE(hipFree(c->base));
     delete c;
 }
@@ -77,6 +134,7 @@ static void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t 
     buffer_ctx * c = (buffer_ctx *) b->context;
     if (ip_any()) ip_host_access(b, true);
     HIP_SOFT(hipSetDevice(c->device));
+    decode_copy_drop(b, t, offset, size);
     uploader_drain(c->device);
     HIP_SOFT(hipMemset((char *) t->data + offset, value, size));
     HIP_SOFT(hipDeviceSynchronize());
@@ -303,6 +361,7 @@ static void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void 
     if (ip_any()) ip_host_access(b, true);  // (a cache buffer whose heads live sharded on several devices: tp_inproc.cpp)
     HIP_SOFT(hipSetDevice(c->device));
     note_mask_upload(t, data, offset, size);
+    decode_copy_drop(b, t, offset, size);
     if (size > ((size_t) 1 << 20) && staged_upload(c->device, (char *) t->data + offset, (const char *) data, size)) return;
     uploader_drain(c->device);  // (keeps the writes of one tensor ordered: a small piece behind a staged one)
     HIP_SOFT(hipMemcpy((char *) t->data + offset, data, size, hipMemcpyHostToDevice));
@@ -321,6 +380,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggm
     buffer_ctx * dc = (buffer_ctx *) b->context;
     const size_t n = ggml_abi_nbytes(src);
     forget_mask_stats(dst->data, n);
+    decode_copy_drop(b, dst, 0, n);
     if (ip_any()) { ip_host_access(sb, false); ip_host_access(b, true); }
     uploader_drain(sc->device);
     if (dc->device != sc->device) uploader_drain(dc->device);
@@ -337,6 +397,7 @@ static void buf_clear(ggml_backend_buffer_t b, uint8_t value) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     if (ip_any()) ip_host_access(b, true);
     HIP_SOFT(hipSetDevice(c->device));
+    decode_copy_drop(c, 0, c->size);
     uploader_drain(c->device);
     HIP_SOFT(hipMemset(c->base, value, c->size));
     HIP_SOFT(hipDeviceSynchronize());
@@ -467,6 +528,10 @@ static void be_set_tensor_async(ggml_backend_t be, ggml_tensor * t, const void *
     if (ip_any()) ip_host_access(t->view_src ? t->view_src->buffer : t->buffer, true);
     HIP_SOFT(hipSetDevice(c->device));
     note_mask_upload(t, data, offset, size);
+    {
+        ggml_backend_buffer_t tb = t->view_src ? t->view_src->buffer : t->buffer;
+        if (tb && buffer_is_ours(tb) && ((buffer_ctx *) tb->context)->shadow) decode_copy_drop(tb, t, offset, size);
+    }
     constexpr size_t SMALL = 64 * 1024, RING = 4u << 20;
     if (size > 0 && size <= SMALL && c->opt.small_uploads) {
         if (!c->up_ring) {
@@ -519,6 +584,7 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
     if (cd != cs) flush_uploads(cd);
     const size_t n = ggml_abi_nbytes(src);
     forget_mask_stats(dst->data, n);
+    if (((buffer_ctx *) db->context)->shadow) decode_copy_drop(db, dst, 0, n);
     if (ip_any()) { ip_host_access(sb, false); ip_host_access(db, true); }
     uploader_join(cs->device, cs->stream);
     if (cd->device != cs->device) uploader_drain(cd->device);
@@ -725,6 +791,19 @@ static int api_graph_key_probe(const ggml_cgraph * a, const ggml_cgraph * b, int
     if (n_words) *n_words = (int64_t) key.size();
     return graph_key_equals(b, key) ? 1 : 0;
 }
+// tests: the decode copy of weight matrix t (repacking it first if need be) into `out`; returns its bytes, 0 when the tensor has / gets no copy, -1 on error
+static int64_t api_decode_copy_read(ggml_backend_t be, const ggml_tensor * t, void * out, size_t size) {
+    if (!be_is_ours(be) || t == nullptr) return -1;
+    backend_ctx * c = (backend_ctx *) be->context;
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    uploader_join(c->device, c->stream);
+    const uint8_t * p = decode_copy(c, t);
+    if (!p) return 0;
+    const size_t bytes = (size_t) t->nb[1] * (size_t) t->ne[1];
+    if (out == nullptr || size < bytes) return (int64_t) bytes;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, p, bytes, hipMemcpyDeviceToHost) != hipSuccess) { (void) hipGetLastError(); return -1; }
+    return (int64_t) bytes;
+}
 static int api_set_option(ggml_backend_t be, const char * key, const char * value) {
     if (!be_is_ours(be)) return -1;
     backend_ctx * c = (backend_ctx *) be->context;
@@ -754,6 +833,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "small_downloads") c->opt.small_downloads = v != 0;
     else if (k == "timing") c->opt.timing = v != 0;
     else if (k == "exec_update") c->opt.exec_update = v;
+    else if (k == "decode_copy") c->opt.decode_copy = v != 0;
     else if (k == "clear_failure") { if (v) clear_hip_failure(); }
     else if (k == "staged_upload") g_staged_upload.store(v != 0);
     else return -1;
@@ -777,6 +857,9 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "p2p_allreduces") return c->st.p2p_allreduces;
     if (k == "p2p_timeouts") return tp_p2p_timeouts(c);
     if (k == "step_heads") return c->st.step_heads;
+    if (k == "decode_copy_tensors") return c->st.decode_copy_tensors;
+    if (k == "decode_copy_bytes") return c->st.decode_copy_bytes;
+    if (k == "decode_copy_launches") return c->st.decode_copy_launches;
     if (k == "graph_exec_update_failures") return c->st.graph_exec_update_failures;
     if (k == "graph_evictions") return c->st.graph_evictions;
     if (k == "graph_cache_size") return (int64_t) c->graphs.size();
@@ -839,6 +922,7 @@ static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (n == "ggml_backend_mi355x_tp_all_reduce") return (void *) api_tp_all_reduce;
     if (n == "ggml_backend_mi355x_tp_rowpar_buffer_type") return (void *) api_tp_rowpar_buft;
     if (n == "ggml_backend_mi355x_set_option") return (void *) api_set_option;
+    if (n == "ggml_backend_mi355x_decode_copy_read") return (void *) api_decode_copy_read;
     if (n == "ggml_backend_mi355x_get_stat") return (void *) api_get_stat;
     if (n == "ggml_backend_mi355x_timing_report") return (void *) api_timing_report;
     if (n == "ggml_backend_split_buffer_type") return (void *) api_split_buffer_type;  // -sm row (split.cpp)

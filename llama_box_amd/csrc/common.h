@@ -9,6 +9,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -132,6 +133,7 @@ struct options {
     bool small_uploads = true; // set_tensor_async of <= 64 KiB: pinned ring + copy kernel instead of a blit
     bool small_downloads = true; // get_tensor_async of <= 8 MiB into this backend's pinned host buffer type: a copy kernel instead of a blit
     bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)
+    bool decode_copy = [] { const char * e = getenv("GGML_MI355X_DECODE_COPY"); return e ? atoi(e) != 0 : true; }();  // batch-1 mat-vecs read the plane-layout copy of their weights
     int exec_update = [] { const char * e = getenv("GGML_MI355X_EXEC_UPDATE"); return e ? atoi(e) : 1; }();  // patch the predecessor's executable graph at a capture at
                                // first sighting (graph.cpp); 2 = run the update and treat it as failed (tests)
 };
@@ -155,6 +157,9 @@ struct stats {
     int64_t kernel_downloads = 0;      // get_tensor_async calls served by a copy kernel writing mapped pinned memory
     int64_t graph_early_captures = 0;  // graphs captured at their FIRST sighting (same step as the one replayed last, over a grown cache)
     int64_t graph_exec_updates = 0;    // ... of them, served by patching the predecessor's executable graph (hipGraphExecUpdate) instead of instantiating
+    int64_t decode_copy_tensors = 0;   // weight matrices repacked into the decode copy by this backend instance ...
+    int64_t decode_copy_bytes = 0;     // ... and their bytes
+    int64_t decode_copy_launches = 0;  // mat-vec / fused Q/K/V launches that streamed a decode copy
     int64_t step_heads = 0;            // decode-step heads served by one launch: GET_ROWS + mask cast + rotary table (ops.hip: k_step_head)
     int64_t graph_exec_update_failures = 0; // ... and updates that failed: the predecessor's (possibly half-patched) executable graph is destroyed, both entries start over
     int64_t graph_evictions = 0;       // cache entries dropped because they had not been used for 256 graphs
@@ -200,6 +205,7 @@ struct backend_ctx {
     cached_graph * last_graph = nullptr;  // the entry looked up last: compared first, in place (graph.cpp: key_equals)
     std::vector<uint64_t> key_scratch;
     uint64_t tick = 0;
+    uint64_t decode_epoch = 0;  // decode_copy_epoch() the cached graphs were captured under
     bool capturing = false;
     // tensor parallel
     tp_state * tp = nullptr;
@@ -251,7 +257,18 @@ struct buffer_ctx {
     void * base = nullptr;
     size_t size = 0;
     bool rowpar = false;  // tensor-parallel reducing buffer type
+    // THE DECODE COPY (round 6; repack.hip, mmvq_types.h): a weights buffer's K-quant matrices a second time, in the plane layout the batch-1 mat-vec kernels stream
+    // with non-temporal loads — same size, a tensor's copy sits at the tensor's own offset.  Allocated at the first use by a graph (never for buffers that are not
+    // usage WEIGHTS), a tensor's copy written then too; anything that writes into the buffer afterwards drops the copies it overlaps (and every captured graph).
+    void * shadow = nullptr;
+    bool shadow_failed = false;
+    std::mutex sh_mtx;
+    std::unordered_map<size_t, size_t> sh_valid;  // offset of a repacked tensor -> its bytes
 };
+// the plane-layout copy of weight matrix w for the batch-1 mat-vec kernels, or nullptr (no copy: views, split / row-parallel buffers, K % 2048 != 0, option off,
+// allocation failed, or asked during a capture for a tensor not yet repacked)
+const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w);
+uint64_t decode_copy_epoch();  // bumped whenever a copy was dropped: graphs captured before hold pointers to it
 bool buffer_is_ours(ggml_backend_buffer_t b);
 bool buffer_is_rowpar(ggml_backend_buffer_t b);
 ggml_backend_buffer_t make_backend_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * context, size_t size);

@@ -434,6 +434,10 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         mmvq_args a{};
         a.W = (const uint8_t *) w->data;
         a.W2 = w2 ? (const uint8_t *) w2->data : nullptr;
+        a.Wp = decode_copy(c, w);  // (the plane-layout copies the streaming kernels read with non-temporal loads: backend.cpp, repack.hip)
+        a.W2p = w2 && a.Wp ? decode_copy(c, w2) : nullptr;
+        if (w2 && !a.W2p) a.Wp = nullptr;
+        c->st.decode_copy_launches += a.Wp != nullptr;
         a.w_nb1 = (int64_t) w->nb[1];
         a.type = w->type;
         a.K = (int) K;
@@ -546,6 +550,12 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
     a.N = (int) N;
     a.ncols = (int) M;
     a.act = act;
+    if (M == 1) {
+        a.Wp = decode_copy(c, w);
+        a.W2p = w2 && a.Wp ? decode_copy(c, w2) : nullptr;
+        if (w2 && !a.W2p) a.Wp = nullptr;
+        c->st.decode_copy_launches += a.Wp != nullptr;
+    }
     a.dst = (float *) dst->data;
     a.dst_stride = (int64_t) (dst->nb[1] / 4);
     auto addend = [&](const ggml_tensor * t, const float *& p, int64_t & stride) {
@@ -872,6 +882,7 @@ static bool try_fuse_qkv(exec_state & st, int i) {
         }
         qkv_args a = base;
         a.nseg = 0;
+        a.planes = 1;
         double bytes = 0;
         for (size_t s = first; s < chains.size(); ++s) {
             const qkv_chain & ch = chains[s];
@@ -890,6 +901,22 @@ static bool try_fuse_qkv(exec_state & st, int i) {
             sg.out = ch.store ? (char *) ch.store->data : (char *) ch.out_f32->data;
             sg.row_stride = !ch.store ? 0 : ch.scatter ? (int64_t) (uintptr_t) ch.store->src[1]->data : (int64_t) ch.store->nb[1];
             bytes += (double) ggml_abi_row_size(w->type, w->ne[0]) * (double) w->ne[1];
+        }
+        {   // the decode copies (plane layout) of every matrix of the launch, or the block layout for all of them
+            const uint8_t * wp[3] = {nullptr, nullptr, nullptr};
+            int k = 0;
+            for (size_t s2 = first; s2 < chains.size() && a.planes; ++s2) {
+                const ggml_tensor * w = chains[s2].mm->src[0];
+                if (k >= a.nseg || (const uint8_t *) w->data != a.seg[k].W) continue;
+                wp[k] = decode_copy(c, w);
+                if (!wp[k]) a.planes = 0;
+                ++k;
+            }
+            if (k != a.nseg) a.planes = 0;
+            if (a.planes) {
+                for (int q = 0; q < a.nseg; ++q) a.seg[q].W = wp[q];
+                c->st.decode_copy_launches++;
+            }
         }
         char cls[64];
         if (type_b == type) snprintf(cls, sizeof(cls), "qkv_fused_%s_%s", type_tag(type), norm ? "normpro" : "f32pro");
@@ -2131,6 +2158,16 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         ~host_clock() { c->st.graph_compute_host_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
     } clock{c, t_enter};
     c->tick++;
+    {   // a decode copy was dropped since the cached graphs were captured (the host rewrote a weight, freed a weights buffer): they hold pointers to it
+        const uint64_t ep = decode_copy_epoch();
+        if (ep != c->decode_epoch) {
+            if (!c->graphs.empty()) {
+                (void) hipStreamSynchronize(c->stream);
+                free_graph_cache(c);
+            }
+            c->decode_epoch = ep;
+        }
+    }
     auto replay = [&](cached_graph & cg) {
         cg.last_use = c->tick;
         cg.seen++;

@@ -64,6 +64,9 @@ struct mmvq_args {
     double * ss_out;
     const double * ss_in;
     int ss_n;
+    // the decode copies of W / W2 (plane layout, repack.hip) or nullptr: the streaming forms read these instead, with non-temporal loads (launch_mmvq decides)
+    const uint8_t * Wp;
+    const uint8_t * W2p;
 };
 int launch_mmvq_ss_count(const mmvq_args & a);  // workgroups (= partial sums) a launch with ss_out will write; 0 if this launch cannot publish them
 #define FA_REC 132  // floats per attention partial record in the fat-split form (128 values + max + sum, padded to 16 bytes)
@@ -116,6 +119,7 @@ struct qkv_args {
     const int64_t * slot;
     const float * rope_tab;  // optional: [head_dim / 2][cos, sin] for this token (launch_rope_table) instead of computing them in every workgroup's prologue
     int wg_a;  // set by launch_qkv: workgroups [0, wg_a) serve the alt == 0 segments, the rest the alt == 1 segments
+    int planes;  // every segment's W is the matrix's decode copy (plane layout, repack.hip): the launch runs the plane forms of both formats
     const double * ss_in;  // as mmvq_args::ss_in / ss_n (norm prologue)
     int ss_n;
 };
@@ -317,6 +321,10 @@ bool launch_flash_attn_mma(hipStream_t s, const tdesc & q, const tdesc & k, cons
 int fattn_mma_pick_splits(const tdesc & q, const tdesc & k);
 void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const float * sinks, const tdesc & dst, int n_q, int n_head, int n_batch, int n_splits, void * q8_out = nullptr);
 
+// ---- the decode copy (repack.hip): rows [r0, r0 + n_rows) of a K-quant [K, N] matrix from the block layout at `src` into the plane layout at `dst` (same row stride)
+bool repack_supported(int type, int64_t K, int64_t nb1);
+void launch_repack_planes(hipStream_t s, int type, const void * src, void * dst, int64_t K, int64_t nb1, int64_t r0, int64_t n_rows);
+
 // ---- code-object preload (round 4).  The HIP runtime loads a translation unit's device code on the FIRST launch of one of its kernels
 // (0.3 - 2 ms each, measured as idle gaps in front of the first prompt's kernels: 5.5 ms of a 64 ms prefill).  Every kernel file ends with
 // MI_TU_TOUCH(name): an empty kernel + a launcher; init_backend launches them all once per device, so the cost moves to start-up.
@@ -337,8 +345,10 @@ void tu_touch_fattn(hipStream_t s);
 void tu_touch_fattn_mma(hipStream_t s);
 void tu_touch_tp_p2p(hipStream_t s);
 void tu_touch_kv_types(hipStream_t s);
+void tu_touch_repack(hipStream_t s);
 inline void preload_kernel_files(hipStream_t s) {
     tu_touch_kv_types(s);
+    tu_touch_repack(s);
     tu_touch_quantize(s);
     tu_touch_mmvq(s);
     tu_touch_qkv(s);

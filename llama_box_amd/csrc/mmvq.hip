@@ -21,6 +21,8 @@
 
 #include <algorithm>
 
+#include <type_traits>
+
 #include "mmvq_types.h"
 
 namespace mi355x {
@@ -495,6 +497,22 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
     mmvq_args a = a0;
     const int nblk = a.K / T::BLK;
     const bool glu = a.W2 != nullptr;
+    // the streaming forms over the decode copy (plane layout, non-temporal loads): same registers per lane, same dot products
+    typedef typename plane_of<T>::type TP;
+    if constexpr (!std::is_same<T, TP>::value) {
+        const bool planes = a0.Wp != nullptr && (!glu || a0.W2p != nullptr) && (a0.K % 2048) == 0;
+        const bool stream = a0.x != nullptr || a0.fa_part != nullptr || (a0.ncols == 1 && (size_t) nblk * sizeof(typename T::act) <= 60 * 1024);
+        if (planes && stream) {
+            mmvq_args ap = a0;
+            ap.W = a0.Wp;
+            ap.W2 = glu ? a0.W2p : nullptr;
+            if (a0.fa_part) launch_stream<TP, false, 3>(s, ap);
+            else if (a0.x && a0.norm_w) { if (glu) launch_stream<TP, true, 2>(s, ap); else launch_stream<TP, false, 2>(s, ap); }
+            else if (a0.x) { if (glu) launch_stream<TP, true, 1>(s, ap); else launch_stream<TP, false, 1>(s, ap); }
+            else { if (glu) launch_stream<TP, true, 0>(s, ap); else launch_stream<TP, false, 0>(s, ap); }
+            return;
+        }
+    }
     if (a0.x != nullptr || a0.fa_part != nullptr) {
         if ((a0.K % 256) != 0) {
             MI_ERR("launch_mmvq: the f32 prologue needs K %% 256 == 0 (K = %d)", a0.K);

@@ -14,13 +14,17 @@ namespace mi355x {
 #ifndef MI_NT_WEIGHTS
 #define MI_NT_WEIGHTS 0
 #endif
-// LAB ONLY (round 6; scripts/lab/build_ab.sh): MI_LAB_PLANES = 1 makes T_Q4K / T_Q6K::load fetch THE SAME NUMBER OF BYTES from the addresses a
-// line-aligned plane repack of the row would have (Q4_K: groups of 8 super-blocks as [8 x 16 B headers | 32 lanes x 16 B q0 | 32 lanes x 16 B q1] = 9 lines;
-// Q6_K: groups of 8 as [A | B | C planes of 512 B] = 12 lines, the scales and d of the whole row behind the groups) — every 128-byte line is touched by exactly
-// one wave-instruction.  The bytes found there are NOT the weights (nothing was repacked): results are wrong, only the timing means anything.
-#ifndef MI_LAB_PLANES
-#define MI_LAB_PLANES 0
-#endif
+// THE DECODE COPY (round 6): weights the batch-1 mat-vec kernels stream are kept a second time in a line-aligned PLANE layout (repack.hip writes it at load time;
+// 288 GB of HBM hold both copies of anything llama-box serves on one GPU), and only that copy is read with the nt bit:
+//   Q4_K, per group of 8 super-blocks (1152 B = 9 lines): [8 x 16 B {d, dmin, scales}] [32 lanes x 16 B: qs bytes 32 j .. 32 j + 15 of block b, lane 4 b + j]
+//                                                          [32 lanes x 16 B: qs bytes 32 j + 16 .. 32 j + 31]
+//   Q5_K (1408 B = 11 lines): [8 x 16 B header] [8 x 16 B qh low half] [8 x 16 B qh high half] [32 x 16 B q0] [32 x 16 B q1]
+//   Q6_K (per group 1536 B = 12 lines): [32 lanes x 16 B ql 64 h + 16 t ..] [32 x 16 B ql 64 h + 32 + 16 t ..] [32 x 16 B qh 32 h + 16 t ..], lane 4 b + 2 h + t;
+//         behind the row's groups: 16 B of scales per super-block, then the f16 d's
+// A lane receives exactly the registers T::load of the block layout gives it, so the dot products are the same code and the same bits; every 128-byte line is
+// touched by ONE wave-instruction, which is what makes the non-temporal policy pay (on the block layout it cost 15 %: header, low and high quants of a lane are
+// three instructions on the same lines).  Measured before building (same bytes from these addresses, wrong values): 541 -> 580 tok/s; the output matrix
+// 83.5 -> 67.5 us, Q6_K ffn_down 13.8 -> 11.65, gate/up 14.55 -> 14.0 (profiles/r06_lab_planes_nt.txt).  Rows need K % 2048 == 0.
 typedef uint32_t mi_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t mi_u32x2 __attribute__((ext_vector_type(2)));
 typedef mi_u32x4 mi_u32x4_a2 __attribute__((aligned(2)));
@@ -34,6 +38,8 @@ template <typename V, typename N> __device__ __forceinline__ V ld_stream_as(cons
 #endif
 }
 __device__ __forceinline__ uint4 ld_stream(const uint4 * p) { return ld_stream_as<uint4, mi_u32x4>(p); }
+__device__ __forceinline__ uint4 ld_nt(const void * p) { return __builtin_bit_cast(uint4, __builtin_nontemporal_load((const mi_u32x4 *) p)); }
+__device__ __forceinline__ uint2 ld_nt8(const void * p) { return __builtin_bit_cast(uint2, __builtin_nontemporal_load((const mi_u32x2 *) p)); }
 
 // sc/m pair extraction for K-quants' 12 packed bytes, for sub-blocks (2j, 2j+1); hy/hz/hw = bytes 0-3 / 4-7 / 8-11
 __device__ __forceinline__ void k4_scale_pair(uint32_t hy, uint32_t hz, uint32_t hw, int j, int & sc0, int & sc1, int & m0, int & m1) {
@@ -66,17 +72,10 @@ struct T_Q4K {
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk = 0) {
         (void) nblk;
         raw r;
-#if MI_LAB_PLANES
-        const uint8_t * grp = row + (size_t) (p >> 5) * (8 * BYTES);  // 8 super-blocks = 32 lanes = 1152 B = 9 lines
-        r.hdr = ld_stream((const uint4 *) (grp + 16 * ((p >> 2) & 7)));
-        r.q0 = ld_stream((const uint4 *) (grp + 128 + 16 * (p & 31)));
-        r.q1 = ld_stream((const uint4 *) (grp + 128 + 512 + 16 * (p & 31)));
-#else
         const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         r.hdr = ld_stream((const uint4 *) blk);
         r.q0 = ld_stream((const uint4 *) (blk + 16 + 32 * (p & 3)));
         r.q1 = ld_stream((const uint4 *) (blk + 32 + 32 * (p & 3)));
-#endif
         return r;
     }
     template <int NC> static __device__ __forceinline__ void dot(const raw & r, int p, const act * __restrict__ y, int nblk, float * acc) {
@@ -178,19 +177,6 @@ struct T_Q6K {
         const uint8_t * blk = row + (size_t) (p >> 2) * BYTES;
         const int h = (p >> 1) & 1, t = p & 1;
         raw r;
-#if MI_LAB_PLANES
-        {
-            const uint8_t * grp = row + (size_t) (p >> 5) * 1536;  // 8 super-blocks: three planes of 32 lanes x 16 B = 12 lines
-            const uint8_t * tail = row + (size_t) (nblk >> 3) * 1536 + (size_t) (p >> 2) * 16;  // scales: 16 B per super-block behind the groups, then the d's
-            r.a = __builtin_bit_cast(u128_a2, ld_stream((const uint4 *) (grp + 16 * (p & 31))));
-            r.b = __builtin_bit_cast(u128_a2, ld_stream((const uint4 *) (grp + 512 + 16 * (p & 31))));
-            r.c = __builtin_bit_cast(u128_a2, ld_stream((const uint4 *) (grp + 1024 + 16 * (p & 31))));
-            r.s = ld_stream((const u64_a2 *) (tail + 8 * h));
-            r.d = ld16(row + (size_t) (nblk >> 3) * 1536 + (size_t) nblk * 16 + (size_t) (p >> 2) * 2);
-            (void) blk; (void) t;
-            return r;
-        }
-#endif
         (void) nblk;
         r.a = ld_stream((const u128_a2 *) (blk + 64 * h + 16 * t));
         r.b = ld_stream((const u128_a2 *) (blk + 64 * h + 32 + 16 * t));
@@ -263,5 +249,49 @@ struct T_Q80 {
     }
 };
 
+
+
+// ------------------------------------------------------------------------------------------------ the plane layouts of the decode copy (see the top of this file)
+struct T_Q4KP : T_Q4K {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int = 0) {
+        const uint8_t * grp = row + (size_t) (p >> 5) * 1152;
+        raw r;
+        r.hdr = ld_nt(grp + 16 * ((p >> 2) & 7));
+        r.q0 = ld_nt(grp + 128 + 16 * (p & 31));
+        r.q1 = ld_nt(grp + 640 + 16 * (p & 31));
+        return r;
+    }
+};
+struct T_Q5KP : T_Q5K {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int = 0) {
+        const uint8_t * grp = row + (size_t) (p >> 5) * 1408;
+        const int b8 = (p >> 2) & 7;
+        raw r;
+        r.hdr = ld_nt(grp + 16 * b8);
+        r.h0 = ld_nt(grp + 128 + 16 * b8);
+        r.h1 = ld_nt(grp + 256 + 16 * b8);
+        r.q0 = ld_nt(grp + 384 + 16 * (p & 31));
+        r.q1 = ld_nt(grp + 896 + 16 * (p & 31));
+        return r;
+    }
+};
+struct T_Q6KP : T_Q6K {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk) {
+        const uint8_t * grp = row + (size_t) (p >> 5) * 1536;
+        const uint8_t * tail = row + (size_t) (nblk >> 3) * 1536;
+        const int h = (p >> 1) & 1;
+        raw r;
+        r.a = __builtin_bit_cast(u128_a2, ld_nt(grp + 16 * (p & 31)));
+        r.b = __builtin_bit_cast(u128_a2, ld_nt(grp + 512 + 16 * (p & 31)));
+        r.c = __builtin_bit_cast(u128_a2, ld_nt(grp + 1024 + 16 * (p & 31)));
+        r.s = __builtin_bit_cast(u64_a2, ld_nt8(tail + (size_t) (p >> 2) * 16 + 8 * h));
+        r.d = ld16(tail + (size_t) nblk * 16 + (size_t) (p >> 2) * 2);
+        return r;
+    }
+};
+template <typename T> struct plane_of { typedef T type; };
+template <> struct plane_of<T_Q4K> { typedef T_Q4KP type; };
+template <> struct plane_of<T_Q5K> { typedef T_Q5KP type; };
+template <> struct plane_of<T_Q6K> { typedef T_Q6KP type; };
 
 }  // namespace mi355x

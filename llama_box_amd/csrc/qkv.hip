@@ -340,10 +340,14 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
         else if (pipe) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false, true>), GRID, block, lds, s, a);      \
         else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                      \
     } while (0)
+    const bool planes = a.planes != 0 && (a.K % 2048) == 0 && type_a != GGML_TYPE_Q8_0;  // every segment's W is its decode copy (graph.cpp made sure): the plane forms
     if (type_a == type_b || units[1] == 0) {
         const unsigned grid = (unsigned) std::min(256, (units[0] + nw - 1) / nw);
         a.wg_a = (int) grid;
-        if (type_a == GGML_TYPE_Q4_K) QKV_LAUNCH(T_Q4K, T_Q4K, dim3(grid));
+        if (planes && type_a == GGML_TYPE_Q4_K) QKV_LAUNCH(T_Q4KP, T_Q4KP, dim3(grid));
+        else if (planes && type_a == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q5KP, T_Q5KP, dim3(grid));
+        else if (planes && type_a == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q6KP, T_Q6KP, dim3(grid));
+        else if (type_a == GGML_TYPE_Q4_K) QKV_LAUNCH(T_Q4K, T_Q4K, dim3(grid));
         else if (type_a == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q5K, T_Q5K, dim3(grid));
         else if (type_a == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q6K, T_Q6K, dim3(grid));
         else if (type_a == GGML_TYPE_Q8_0) QKV_LAUNCH(T_Q80, T_Q80, dim3(grid));
@@ -358,7 +362,10 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     }
     a.wg_a = ga;
     const dim3 grid((unsigned) (ga + gb));
-    if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4K, T_Q6K, grid);
+    if (planes && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4KP, T_Q6KP, grid);
+    else if (planes && type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5KP, T_Q6KP, grid);
+    else if (planes && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4KP, T_Q5KP, grid);
+    else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4K, T_Q6K, grid);
     else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5K, T_Q6K, grid);
     else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4K, T_Q5K, grid);
     else { MI_ERR("launch_qkv: unsupported weight format pair %d/%d", type_a, type_b); abort(); }

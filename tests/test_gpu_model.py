@@ -656,3 +656,113 @@ def test_a_failed_upload_fails_the_next_graph_instead_of_the_process(plog):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "STILL_ALIVE" in r.stdout and "GRAPH_REFUSED" in r.stdout and "GRAPH_RAN" not in r.stdout, r.stdout
     assert "HIP error" in r.stderr and "graph_compute: refused" in r.stderr, r.stderr[-1000:]
+
+
+# ------------------------------------------------------------------------------------------------ the decode copy (round 6)
+def _np_repack(raw, qtype, K):
+    """The documented plane layout of csrc/mmvq_types.h, written with numpy from the block-layout bytes of ONE row."""
+    nblk = K // 256
+    bs = {L.Q4_K: 144, L.Q5_K: 176, L.Q6_K: 210}[qtype]
+    blocks = raw.reshape(nblk, bs)
+    out = []
+    tail_s, tail_d = [], []
+    for g in range(nblk // 8):
+        b8 = blocks[8 * g: 8 * g + 8]
+        if qtype == L.Q4_K:
+            out.append(b8[:, 0:16].reshape(-1))                                           # 8 headers
+            out.append(np.stack([b8[l >> 2, 16 + 32 * (l & 3): 16 + 32 * (l & 3) + 16] for l in range(32)]).reshape(-1))   # q0 of lane 4 b + j
+            out.append(np.stack([b8[l >> 2, 32 + 32 * (l & 3): 32 + 32 * (l & 3) + 16] for l in range(32)]).reshape(-1))   # q1
+        elif qtype == L.Q5_K:
+            out.append(b8[:, 0:16].reshape(-1))
+            out.append(b8[:, 16:32].reshape(-1))
+            out.append(b8[:, 32:48].reshape(-1))
+            out.append(np.stack([b8[l >> 2, 48 + 32 * (l & 3): 48 + 32 * (l & 3) + 16] for l in range(32)]).reshape(-1))
+            out.append(np.stack([b8[l >> 2, 64 + 32 * (l & 3): 64 + 32 * (l & 3) + 16] for l in range(32)]).reshape(-1))
+        else:
+            for base in (lambda h, t: 64 * h + 16 * t, lambda h, t: 64 * h + 32 + 16 * t, lambda h, t: 128 + 32 * h + 16 * t):
+                out.append(np.stack([b8[l >> 2, base((l >> 1) & 1, l & 1): base((l >> 1) & 1, l & 1) + 16] for l in range(32)]).reshape(-1))
+    if qtype == L.Q6_K:
+        tail_s = [blocks[:, 192:208].reshape(-1)]
+        tail_d = [blocks[:, 208:210].reshape(-1)]
+    return np.concatenate(out + tail_s + tail_d)
+
+
+@pytest.mark.parametrize("qtype", [L.Q4_K, L.Q5_K, L.Q6_K])
+@pytest.mark.parametrize("K,N", [(2048, 24), (4096, 16), (14336, 8)])
+def test_decode_copy_is_the_documented_permutation_and_get_tensor_returns_the_upload(backend, H, qtype, K, N):
+    """csrc/repack.hip against a numpy statement of the plane layout (csrc/mmvq_types.h), byte for byte, row by row; the tensor itself still reads back as uploaded."""
+    rng = np.random.default_rng(qtype * 100 + K)
+    raw = T.rand_weight(qtype, K, N, rng)
+    ctx = H.ggml_init(L.InitParams(0, None, True))
+    t = H.ggml_new_tensor_2d(ctx, qtype, K, N)
+    buf = H.ggml_backend_alloc_ctx_tensors_from_buft(ctx, backend.buft)
+    assert buf
+    try:
+        H.ggml_backend_buffer_set_usage(buf, 1)  # GGML_BACKEND_BUFFER_USAGE_WEIGHTS
+        H.ggml_backend_tensor_set(t, raw.ctypes.data_as(C.c_void_p), 0, raw.nbytes)
+        fn = backend.proc("ggml_backend_mi355x_decode_copy_read", C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t])
+        got = np.empty(raw.nbytes, np.uint8)
+        assert fn(backend.backend, t, got.ctypes.data_as(C.c_void_p), got.nbytes) == raw.nbytes
+        want = np.concatenate([_np_repack(raw[r], qtype, K) for r in range(N)])
+        assert np.array_equal(got, want)
+        back = np.empty(raw.nbytes, np.uint8)
+        H.ggml_backend_tensor_get(t, back.ctypes.data_as(C.c_void_p), 0, back.nbytes)
+        assert np.array_equal(back, raw.reshape(-1))
+        # a matrix whose rows are not whole groups of 8 super-blocks has no copy
+        t2ctx = H.ggml_init(L.InitParams(0, None, True))
+        t2 = H.ggml_new_tensor_2d(t2ctx, qtype, 1024, 4)
+        b2 = H.ggml_backend_alloc_ctx_tensors_from_buft(t2ctx, backend.buft)
+        H.ggml_backend_buffer_set_usage(b2, 1)
+        assert fn(backend.backend, t2, None, 0) == 0
+        H.ggml_backend_buffer_free(b2)
+        H.ggml_free(t2ctx)
+    finally:
+        H.ggml_backend_buffer_free(buf)
+        H.ggml_free(ctx)
+
+
+def test_mat_vecs_over_the_decode_copy_are_bit_equal_and_follow_a_rewritten_weight(backend, H, plog):
+    """A model whose matrices have decode copies (K = 2048 / 4096: every K-quant format of the MIXED recipe): prompt + decode steps with the copies on and off are the
+    same logits bit for bit (a lane receives the same registers from either layout), eagerly and as replayed hipGraphs; the launches that streamed a copy are
+    counted.  Then the host REWRITES a weight (set_tensor): the copy is dropped, the captured graphs with it, and the next steps compute with the new bytes —
+    equal to a run with the copies off."""
+    hp = preset("test-llama", n_embd=2048, n_head=16, n_head_kv=4, n_embd_head=128, n_ff=4096, n_layer=3)
+    mg = Model(hp, 99, backend.buft)
+    other = Model(hp, 100, H.ggml_backend_cpu_buffer_type())
+    outs = {}
+    try:
+        name = b"blk.1.ffn_down.weight"
+        t_dev, t_new = H.llm_model_tensor(mg.m, name), H.llm_model_tensor(other.m, name)
+        n = H.ggml_nbytes(t_dev)
+        new_bytes = np.empty(n, np.uint8)
+        H.ggml_backend_tensor_get(t_new, new_bytes.ctypes.data_as(C.c_void_p), 0, n)
+        old_bytes = np.empty(n, np.uint8)
+        H.ggml_backend_tensor_get(t_dev, old_bytes.ctypes.data_as(C.c_void_p), 0, n)
+        for mode in (1, 0):
+            H.ggml_backend_tensor_set(t_dev, old_bytes.ctypes.data_as(C.c_void_p), 0, n)
+            backend.set_option("decode_copy", mode)
+            s0 = {k: backend.stat(k) for k in ("decode_copy_launches", "decode_copy_tensors", "graph_launches")}
+            c = Context(mg, backend=backend, flash_attn=1)
+            rc, lg = c.decode(PROMPT, range(len(PROMPT)), want=[0] * (len(PROMPT) - 1) + [1])
+            assert rc == 0
+            rows = [lg[-1]]
+            for i in range(8):
+                rc, l1 = c.decode([7 + i], [len(PROMPT) + i])
+                assert rc == 0
+                rows.append(l1[0])
+            H.ggml_backend_tensor_set(t_dev, new_bytes.ctypes.data_as(C.c_void_p), 0, n)  # the host rewrites a weight between two steps
+            for i in range(8, 14):
+                rc, l1 = c.decode([7 + i], [len(PROMPT) + i])
+                assert rc == 0
+                rows.append(l1[0])
+            outs[mode] = (np.stack(rows), {k: backend.stat(k) - v for k, v in s0.items()})
+            c.free()
+    finally:
+        backend.set_option("decode_copy", 1)
+        mg.free()
+        other.free()
+    plog(f"decode copy on: {outs[1][1]}; off: {outs[0][1]}")
+    assert outs[1][1]["decode_copy_launches"] > 0 and outs[1][1]["decode_copy_tensors"] > 0 and outs[1][1]["graph_launches"] >= 8
+    assert outs[0][1]["decode_copy_launches"] == 0
+    assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
+    assert not np.array_equal(outs[1][0][8], outs[1][0][9])
