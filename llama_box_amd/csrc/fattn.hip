@@ -16,6 +16,8 @@
 
 #include "dev_util.h"
 #include "kernels.h"
+#include <vector>
+#include <algorithm>
 #include "kv_dequant.h"
 
 namespace mi355x {
@@ -28,6 +30,9 @@ struct fa_geom {
     unsigned * arrive;  // != null (lane-parallel decode kernel, n_splits > 1): one counter per (batch, token, kv head); the LAST split workgroup to
                         // arrive merges the partial records itself — no combine launch (the counter is left at zero again)
     void * q8;          // with `arrive`: leave the merged result as Q8_K blocks here instead of f32 in dst (see fattn_params::q8_out)
+    int one_batch;      // q.ne[3] == 1 (every graph llama.cpp builds): the batch index is 0 and the kernels skip its integer divisions — the lane-parallel decode kernel ran
+                        // 974 instructions, four emulated 64-bit divisions among them, before it issued its first load (round 6)
+    int per;            // cells per split, as the kernels would compute it (launcher: MODE-dependent rounding)
     int merge2;         // with `arrive` (round 4): records [kv head][split][head of the group][132] written with 8-byte agent-scope stores, merged by
                         // the last workgroup to arrive in ONE round trip of 8-byte agent-scope loads (MODE 0, f32 output, <= 32 splits, any wave count)
 };
@@ -367,6 +372,14 @@ __device__ __forceinline__ void fa_merge_heads(const float * __restrict__ base0,
     }
 }
 
+// LAB (scripts/lab/fa_stamps.py, -DFA_STAMP=1): where the time of one decode-attention workgroup goes — wave 0 / lane 0 of every workgroup of the 8-wave
+// f16 form leaves s_memtime stamps at seven points; mi355x_fa_stamps_dump() prints their medians over the workgroups of the last launch.
+#ifdef FA_STAMP
+__device__ unsigned long long g_fa_stamps[1024][8];
+#define FA_STAMP_AT(i) { if (WV == 8 && MODE == 0 && threadIdx.x == 0) g_fa_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 1023][(i)] = __builtin_readcyclecounter(); }
+#else
+#define FA_STAMP_AT(i)
+#endif
 // SKIP = true (several query tokens, e.g. -np 32 decode over a unified cache where each token sees ~1/32 of the cells): the mask
 // of the whole split is read first — one round trip — and trips without a visible position for this wave load no K/V at all.
 // Q8 = true: K and V rows are block_q8_0 (quantised KV cache, -ctk/-ctv q8_0).  As in ggml-cpu the query is quantised to Q8_0
@@ -397,6 +410,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     static_assert(!(Q8 && DQ), "q8_0 has its own integer path");
     // FAT: one decode token, a few fat splits whose records the wo mat-vec's prologue merges (records also for ONE split, no Q8_K output)
     constexpr bool FAT = WV == 8 && MODE == 0;
+    FA_STAMP_AT(0)
     __shared__ float sh[WV][G][D + 2];
     __shared__ float qv[FAT ? 1 : G * D];  // one pass, Q8_K output: the normalised heads of this kv group before quantisation
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -406,8 +420,13 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     // SKIP (a few query tokens, each seeing its own part of a unified cache): the workgroup first asks the mask whether its
     // token can see anything in its split — one 8-byte load per lane covers 256 positions — and leaves an empty record
     // if not: of the 64 x 32 (split, token) pairs of a -np 32 decode step only ~1/16 touch K/V at all
-    const int tok = (int) blockIdx.z % geo.n_q, bat = (int) blockIdx.z / geo.n_q;
-    const int per = SKIP ? ((geo.n_kv + geo.n_splits - 1) / geo.n_splits + 63) / 64 * 64 : (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
+    int tok = (int) blockIdx.z, bat = 0;
+    if (!geo.one_batch) {
+        tok = (int) blockIdx.z % geo.n_q;
+        bat = (int) blockIdx.z / geo.n_q;
+    }
+    const int per_plain = geo.per > 0 ? geo.per : (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
+    const int per = SKIP ? (per_plain + 63) / 64 * 64 : per_plain;
     const int kv0 = LIST ? 0 : min(split * per, geo.n_kv);
     int kv1 = LIST ? 0 : min(geo.n_kv, kv0 + per);  // LIST: positions are list ENTRIES, [0, cnt)
     const int * tl = nullptr;  // LIST: this token's visible positions, ascending; trips [ti, ti1) of TRIP entries each are ours
@@ -447,9 +466,14 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         kv1 = cnt;
         if (geo.n_splits != 1 && !empty) FA_LIST_AHEAD(ti * TRIP)
     }
-    const int64_t kb = bat / (q.ne[3] / k.ne[3]), vb = bat / (q.ne[3] / v.ne[3]);
+    int64_t kb = 0, vb = 0, mb = 0;  // batch indices into K, V and the mask
+    if (!geo.one_batch) {
+        kb = bat / (q.ne[3] / k.ne[3]);
+        vb = bat / (q.ne[3] / v.ne[3]);
+        mb = bat % mask.ne[3];
+    }
     if constexpr (SKIP) {
-        const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]);
+        const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + mb * mask.nb[3]);
         bool any = false;
         for (int c0 = kv0; c0 < kv1; c0 += 256) {
             const int pp = c0 + 4 * lane;
@@ -469,7 +493,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         }
     }
     if (!empty) {
-    const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + (int64_t) (bat % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const uint16_t * mp = geo.has_mask ? (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + mb * mask.nb[3]) : nullptr;
     const char * kbase = k.data + (int64_t) kvh * k.nb[2] + kb * k.nb[3] + (DQ ? (sl >> 2) * kv_block_bytes_t<KVT>() : Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
     const char * vbase = v.data + (int64_t) kvh * v.nb[2] + vb * v.nb[3] + (DQ ? (sl >> 2) * kv_block_bytes_t<KVT>() : Q8 ? (sl >> 2) * 34 + 2 + (sl & 3) * 8 : sl * 16);
 
@@ -526,6 +550,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     } else {
         if (kv0 < kv1) FA_LOAD_TRIP()
     }
+    FA_STAMP_AT(1)
 
     fa_half2 qh[G][4];    // f16 cache: the query as packed f16
     int qq[G][2];         // q8_0 cache: the query's 8 int8 of this lane's block ...
@@ -570,6 +595,10 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             qh[g][3] = (fa_half2){(_Float16) (qb.z * z), (_Float16) (qb.w * z)};
         }
     }
+#ifdef FA_STAMP
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (lab: the query's loads are the youngest NG * 2 ... the K / V trip is older: roughly "q has arrived")
+    FA_STAMP_AT(2)
+#endif
     float acc[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -652,6 +681,9 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
                 }
             }
         }
+#ifdef FA_STAMP
+        if (trip == 0) { asm volatile("" :: "v"(t[0]), "v"(t[15])); FA_STAMP_AT(3) }  // the first trip's K has arrived and its dot products are done
+#endif
         const bool more = p_next < kv1 && (!SKIP || ((vis >> (trip + 1)) & 1u));
         const float mv_cur = mvl;
         const bool ok_cur = okl;
@@ -711,6 +743,10 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     }
 #undef FA_LOAD_TRIP
 #undef FA_LIST_AHEAD
+#ifdef FA_STAMP
+    asm volatile("" :: "v"(acc[0][0]), "v"(acc[G - 1][7]));
+    FA_STAMP_AT(4)
+#endif
     // ---- sum of head gl over the row groups (lanes gl, gl+G, ...) and the four rows
     if constexpr (G <= 2) l += dpp_f32<MI_DPP_ROR2>(l);
     if constexpr (G <= 4) l += dpp_f32<MI_DPP_ROR4>(l);
@@ -731,6 +767,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         sh[wave][gl][D + 1] = l;
     }
     __syncthreads();
+    FA_STAMP_AT(5)
     // ---- merge the waves; one thread per (g, d)
     for (int e = tid; e < g_real * D; e += WV * 64) {
         const int g = e / D, dd = e % D;
@@ -792,6 +829,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             }
         }
     }
+    FA_STAMP_AT(6)
     }  // !empty
     if (geo.merge2) {
         // ---- merge2: our record went out with 8-byte agent-scope (write-through) stores; once they have completed (vmcnt 0 in every storing
@@ -1012,6 +1050,11 @@ int fattn_pick_splits(const tdesc & q, const tdesc & k, const tdesc * mask, int 
     int64_t want = (768 + groups - 1) / groups;  // ~3 workgroups per CU
     const int64_t max_by_len = std::max<int64_t>(1, n_kv / 86);  // (~1.4 trips of 64 cells per split: 24 splits at 2 100 cells measure 0.8 % of a decode step ahead of 32 — fewer records for the combine pass)
     want = std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(max_by_len, 64)));
+    // an f16 cache is served by EIGHT-wave workgroups (154 VGPRs: one workgroup fills a CU's register file), so more workgroups than CUs run in rounds of
+    // one-trip latency chains: at 8 k context 64 splits x 8 KV heads measured 20.1 us per layer (split + combine), 48 splits 23.8, 32 splits — one workgroup
+    // per CU, two pipelined trips each — 18.2 (profiles/r06_fa_splits_by_context.txt).  The four-wave forms (q8_0 / block-format caches: three workgroups
+    // per CU) keep the longer list: 64 splits 17.3 us against 18.0 at 32
+    if (k.type == GGML_TYPE_F16 && q.ne[1] == 1 && want * groups > 256) want = std::max<int64_t>(1, 256 / groups);
     return (int) want;
 }
 static size_t fattn_partials_bytes(const tdesc & q, const tdesc & v, int n_splits) {
@@ -1199,6 +1242,8 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     geo.scale = p.logit_softcap != 0.0f ? p.scale / p.logit_softcap : p.scale;
     geo.softcap = p.logit_softcap;
     geo.max_bias = p.max_bias;
+    geo.one_batch = q.ne[3] == 1 ? 1 : 0;
+    geo.per = geo.n_splits > 0 ? (geo.n_kv + geo.n_splits - 1) / geo.n_splits : 0;
     geo.n_head_log2 = 1u << (uint32_t) floor(log2((double) geo.n_head));
     geo.m0 = powf(2.0f, -(p.max_bias) / (float) geo.n_head_log2);
     geo.m1 = powf(2.0f, -(p.max_bias / 2.0f) / (float) geo.n_head_log2);
@@ -1287,6 +1332,23 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     MI_ERR("launch_flash_attn: unsupported head_dim %d / group %d", D, G);
     abort();
 }
+
+#ifdef FA_STAMP
+extern "C" __attribute__((visibility("default"))) void mi355x_fa_stamps_dump(int n_wg) {
+    static unsigned long long h[1024][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fa_stamps), sizeof(h)) != hipSuccess) { printf("fa_stamps: copy failed\n"); return; }
+    n_wg = std::min(n_wg, 1024);
+    static const char * what[7] = {"entry", "K/V (+ mask) loads issued", "query arrived (vmcnt 8)", "first trip: K arrived, dots done", "all trips: P.V done", "waves met (barrier)", "records stored (issued)"};
+    unsigned long long t00 = ~0ull;
+    for (int w = 0; w < n_wg; ++w) t00 = std::min(t00, h[w][0]);
+    for (int i = 0; i < 7; ++i) {
+        std::vector<double> d, d0;
+        for (int w = 0; w < n_wg; ++w) { d.push_back((double) (h[w][i] - h[w][0])); d0.push_back((double) (h[w][i] - t00)); }
+        std::sort(d.begin(), d.end()); std::sort(d0.begin(), d0.end());
+        printf("fa_stamp %d %-34s: since own entry median %8.0f p90 %8.0f ticks | since the first workgroup's entry median %8.0f max %8.0f ticks\n", i, what[i], d[d.size() / 2], d[d.size() * 9 / 10], d0[d0.size() / 2], d0.back());
+    }
+}
+#endif
 
 MI_TU_TOUCH(fattn)
 
