@@ -420,13 +420,12 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     // SKIP (a few query tokens, each seeing its own part of a unified cache): the workgroup first asks the mask whether its
     // token can see anything in its split — one 8-byte load per lane covers 256 positions — and leaves an empty record
     // if not: of the 64 x 32 (split, token) pairs of a -np 32 decode step only ~1/16 touch K/V at all
-    int tok = (int) blockIdx.z, bat = 0;
-    if (!geo.one_batch) {
-        tok = (int) blockIdx.z % geo.n_q;
-        bat = (int) blockIdx.z / geo.n_q;
-    }
-    const int per_plain = geo.per > 0 ? geo.per : (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
-    const int per = SKIP ? (per_plain + 63) / 64 * 64 : per_plain;
+    // (no batch index, no division: the launcher issues one launch per q.ne[3] slice with the descriptors, the records, the counters and the Q8_K area moved
+    // to that slice, and passes the cells per split — the preamble used to fetch its kernel arguments in four dependent rounds around emulated divisions,
+    // ~1.9 us between a workgroup's entry and its first K / V request: profiles/r06_fa_stamps.txt)
+    const int tok = (int) blockIdx.z;
+    constexpr int bat = 0;
+    const int per = geo.per;
     const int kv0 = LIST ? 0 : min(split * per, geo.n_kv);
     int kv1 = LIST ? 0 : min(geo.n_kv, kv0 + per);  // LIST: positions are list ENTRIES, [0, cnt)
     const int * tl = nullptr;  // LIST: this token's visible positions, ascending; trips [ti, ti1) of TRIP entries each are ours
@@ -466,12 +465,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         kv1 = cnt;
         if (geo.n_splits != 1 && !empty) FA_LIST_AHEAD(ti * TRIP)
     }
-    int64_t kb = 0, vb = 0, mb = 0;  // batch indices into K, V and the mask
-    if (!geo.one_batch) {
-        kb = bat / (q.ne[3] / k.ne[3]);
-        vb = bat / (q.ne[3] / v.ne[3]);
-        mb = bat % mask.ne[3];
-    }
+    constexpr int64_t kb = 0, vb = 0, mb = 0;
     if constexpr (SKIP) {
         const uint16_t * mrow = (const uint16_t *) (mask.data + (int64_t) tok * mask.nb[1] + mb * mask.nb[3]);
         bool any = false;
@@ -1310,7 +1304,29 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         geo.arrive = self_merge ? p.arrive : nullptr;
         geo.merge2 = merge2 ? 1 : 0;
         geo.q8 = (self_merge || (geo.n_splits == 1 && !(G & 1))) ? p.q8_out : nullptr;
-        if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
+        geo.per = skip ? per : (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
+        {
+            // one launch per batch slice (q.ne[3]; 1 in every graph llama.cpp builds): the kernel has no batch arithmetic
+            const tdesc q0 = q, k0 = k, v0 = v, mk0 = mk, dst0 = dst;
+            const fa_geom geo0 = geo;
+            float * const ws0 = ws;
+            const int64_t nb_ = q0.ne[3];
+            const dim3 grid((unsigned) geo0.n_splits, (unsigned) geo0.n_kv_head, (unsigned) geo0.n_q);
+            for (int64_t b = 0; b < nb_; ++b) {
+                tdesc q = q0, k = k0, v = v0, mk = mk0, dst = dst0;
+                fa_geom geo = geo0;
+                q.data += b * q0.nb[3];
+                k.data += (b / (q0.ne[3] / k0.ne[3])) * k0.nb[3];
+                v.data += (b / (q0.ne[3] / v0.ne[3])) * v0.nb[3];
+                if (mask) mk.data += (b % mk0.ne[3]) * mk0.nb[3];
+                dst.data += b * dst0.nb[3];
+                const int64_t rows = b * geo0.n_q;  // (batch, token) pairs in front of this slice
+                float * ws = ws0 + (merge2 ? rows * geo0.n_kv_head * geo0.n_splits * G * FA_M2_REC : rows * geo0.n_head * geo0.n_splits * geo0.rec_stride);
+                if (geo.arrive) geo.arrive += rows * geo0.n_kv_head;
+                if (geo.q8) geo.q8 = (q8k_dev *) geo.q8 + rows * (geo0.n_head * 128 / 256);
+                if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
+            }
+        }
 #undef FA_DEC
 #undef FA_DEC_T
         if (geo.n_splits > 1 && !self_merge) launch_flash_attn_combine(s, 128, ws, sinks, dst, geo.n_q, geo.n_head, (int) q.ne[3], geo.n_splits, p.q8_out);
