@@ -80,8 +80,10 @@ template <typename T, bool PIPE> __device__ __forceinline__ void qkv_unit(qkv_re
 // the two, not the sum — holding both register sets in one code path spilled weight registers to scratch memory.
 // Q8S: the launch stores into a block_q8_0 KV cache (a separate instantiation: the block assembly costs registers the default
 // f16-cache kernel does not have to spare)
-template <typename TA, typename TB, bool Q8S, bool PIPE = false>
-__global__ void __launch_bounds__(PIPE ? 512 : 1024) k_qkv_stream2(const qkv_args a) {
+// BND: the workgroup size the kernel is compiled for.  1024 caps a wave at 128 registers, which the Q5_K register sets exceed by a few (6 .. 16 dwords of scratch:
+// a launch with a scratch frame pays for it at every dispatch); Qwen2-7B's launches use 9 waves, so the Q5_K forms also exist compiled for 640 threads (round 6)
+template <typename TA, typename TB, bool Q8S, bool PIPE = false, int BND = 1024>
+__global__ void __launch_bounds__(PIPE ? 512 : BND) k_qkv_stream2(const qkv_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (a generic lambda, not a device function: passing the kernel-argument struct to a function copies it to scratch)
     auto body = [&](auto tag, const int alt, const int wg, const int nwg) {
@@ -334,11 +336,16 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     if (force_nw) nw = force_nw;
     if (q8_store) nw = 16;  // a workgroup trip = 16 row pairs = one block_q8_0 of the cache row (caller checked the alignment)
     const dim3 block((unsigned) nw * 64);
+    const bool has_q5 = type_a == GGML_TYPE_Q5_K || type_b == GGML_TYPE_Q5_K;
+    const bool small_wg = has_q5 && !q8_store && !pipe && nw <= 10;  // (the 640-thread build of the Q5_K forms: no scratch)
 #define QKV_LAUNCH(TA, TB, GRID)                                                                              \
     do {                                                                                                      \
         if (q8_store) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, true>), GRID, block, lds, s, a);              \
         else if (pipe) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false, true>), GRID, block, lds, s, a);      \
-        else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                      \
+        else if constexpr (std::is_same<TA, T_Q5K>::value || std::is_same<TB, T_Q5K>::value || std::is_same<TA, T_Q5KP>::value || std::is_same<TB, T_Q5KP>::value) { \
+            if (small_wg) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false, false, 640>), GRID, block, lds, s, a); \
+            else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                  \
+        } else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                    \
     } while (0)
     const bool planes = a.planes != 0 && (a.K % 2048) == 0 && type_a != GGML_TYPE_Q8_0;  // every segment's W is its decode copy (graph.cpp made sure): the plane forms
     if (type_a == type_b || units[1] == 0) {
