@@ -405,8 +405,11 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     constexpr int D = 128, NG = 16 / G;
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr int TRIP = NG * WV * 4;  // positions per trip
-    constexpr bool DQ = KVT != 0;
-    static_assert(WV == 4 || (!Q8 && !DQ), "the eight-wave forms serve an f16 cache only");
+    // KVT == BF16 (round 6): a bf16 cache has the f16 cache's geometry (a lane's 16 bytes are its eight values), so only the arithmetic differs: as ggml-cpu's
+    // ggml_vec_dot_bf16 the query is rounded to bf16 and multiplied with K's values in f32 (a value is its 16 bits shifted up), V accumulates in f32 (to_float)
+    constexpr bool BF = KVT == GGML_TYPE_BF16;
+    constexpr bool DQ = KVT != 0 && !BF;
+    static_assert(WV == 4 || (!Q8 && !DQ && !BF), "the eight-wave forms serve an f16 cache only");
     static_assert(!(Q8 && DQ), "q8_0 has its own integer path");
     // FAT: one decode token, a few fat splits whose records the wo mat-vec's prologue merges (records also for ONE split, no Q8_K output)
     constexpr bool FAT = WV == 8 && MODE == 0;
@@ -551,13 +554,21 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     float dq[G];          // ... and the block scale (through f16, as block_q8_0.d)
     int qsb[G];           // the other block formats: the sum of the block's 32 quants ...
     float sq[G];          // ... and block_q8_1.s (q4_1 / q5_1: multiplies K's minimum)
+    float qf[BF ? G : 1][8];  // bf16 cache: the query rounded to bf16, as f32
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int h = kvh * g_real + min(g, g_real - 1);
         const float4 * qp = (const float4 *) ((const float *) (q.data + (int64_t) tok * q.nb[1] + (int64_t) h * q.nb[2] + (int64_t) bat * q.nb[3]) + sl * 8);
         const float4 qa = qp[0], qb = qp[1];
         const float z = g < g_real ? 1.0f : 0.0f;
-        if constexpr (Q8 || DQ) {  // quantize_row_q8_0 / _q8_1 of the query (the vec_dot_type of K's format): a block = the 4 lanes of a quad
+        if constexpr (BF) {
+            const float xv[8] = {qa.x * z, qa.y * z, qa.z * z, qa.w * z, qb.x * z, qb.y * z, qb.z * z, qb.w * z};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {  // ggml_compute_fp32_to_bf16: nearest even (a NaN query does not occur)
+                const uint32_t u = __float_as_uint(xv[i]);
+                qf[g][i] = __uint_as_float((u + (0x7fffu + ((u >> 16) & 1u))) & 0xffff0000u);
+            }
+        } else if constexpr (Q8 || DQ) {  // quantize_row_q8_0 / _q8_1 of the query (the vec_dot_type of K's format): a block = the 4 lanes of a quad
             const float xv[8] = {qa.x * z, qa.y * z, qa.z * z, qa.w * z, qb.x * z, qb.y * z, qb.z * z, qb.w * z};
             float amax = 0.0f;
 #pragma unroll
@@ -659,6 +670,22 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
                     isum += dpp_i32<MI_DPP_QUAD_XOR1>(isum);
                     isum += dpp_i32<MI_DPP_QUAD_XOR2>(isum);  // the block's integer sum, in all 4 lanes of the quad
                     t[u * G + g] = (sl & 3) == 0 ? (float) isum * (dk * dq[g]) : 0.0f;  // one lane per block feeds the 16-lane sum below
+                }
+            } else if constexpr (BF) {
+                float kf_[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vf[u][2 * i] = __uint_as_float(vu[i] << 16);
+                    vf[u][2 * i + 1] = __uint_as_float(vu[i] & 0xffff0000u);
+                    kf_[2 * i] = __uint_as_float(ku[i] << 16);
+                    kf_[2 * i + 1] = __uint_as_float(ku[i] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d = __builtin_fmaf(kf_[i], qf[g][i], d);
+                    t[u * G + g] = d;
                 }
             } else {
 #pragma unroll
@@ -1178,15 +1205,16 @@ void launch_fattn_tile_scan(hipStream_t s, const tdesc & mask, int n_q, int n_kv
 // K / V kept in another cache type: can the lane-parallel kernel read them in place (its KVT form)?  The shapes of that kernel (head_dim 128, 2 / 4 / 7 / 8
 // query heads per KV head, no soft-capping / ALiBi, up to 32 query tokens — bigger batches go to the matrix cores over the f16 image), K and V in the same
 // one of the integer-level formats, 2-byte-aligned strides; everything else (iq4_nl, bf16, f32, mixed pairs, head_dim 64) goes through the image
-static bool dq_type_ok(int t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL; }
+static bool dq_type_ok(int t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL || t == GGML_TYPE_BF16; }
 bool fattn_native_kv_ok(const tdesc & q, const tdesc & k, const tdesc & v, const fattn_params & p) {
     static const bool on = !getenv("GGML_MI355X_FA_NATIVE_KV") || atoi(getenv("GGML_MI355X_FA_NATIVE_KV")) != 0;
     if (!on || !dq_type_ok(k.type) || v.type != k.type || k.ne[0] != 128 || v.ne[0] != 128 || k.ne[2] <= 0 || q.ne[2] % k.ne[2] != 0) return false;
     const int G = (int) (q.ne[2] / k.ne[2]);
     if (!(G == 2 || G == 4 || G == 7 || G == 8) || p.logit_softcap != 0.0f || p.max_bias != 0.0f || q.ne[1] > 32 || p.n_splits < 1) return false;
     if ((q.nb[1] % 16) != 0 || (q.nb[2] % 16) != 0 || ((uintptr_t) q.data & 15) != 0) return false;
+    const int al = k.type == GGML_TYPE_BF16 ? 16 : 2;  // (bf16 rows are read as the f16 cache's are: 16 bytes per lane)
     for (const tdesc * t : {&k, &v})
-        if ((t->nb[1] % 2) || (t->nb[2] % 2) || (t->nb[3] % 2) || ((uintptr_t) t->data % 2)) return false;
+        if ((t->nb[1] % al) || (t->nb[2] % al) || (t->nb[3] % al) || ((uintptr_t) t->data % al)) return false;
     return true;
 }
 
@@ -1290,6 +1318,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         else if (dq) {                                                                                                                           \
             if (k.type == GGML_TYPE_Q4_0) FA_DEC_T(GG, GGML_TYPE_Q4_0) else if (k.type == GGML_TYPE_Q4_1) FA_DEC_T(GG, GGML_TYPE_Q4_1)               \
             else if (k.type == GGML_TYPE_Q5_0) FA_DEC_T(GG, GGML_TYPE_Q5_0) else if (k.type == GGML_TYPE_Q5_1) FA_DEC_T(GG, GGML_TYPE_Q5_1)           \
+            else if (k.type == GGML_TYPE_BF16) FA_DEC_T(GG, GGML_TYPE_BF16)                                                                       \
             else FA_DEC_T(GG, GGML_TYPE_IQ4_NL)                                                                                                  \
         } else if (q8) {                                                                                                                         \
             if (list) hipLaunchKernelGGL((k_fattn_dec128<GG, 2, true>), grid, dim3(256), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, p.lists, lstride);      \

@@ -143,6 +143,8 @@ FA_KV_CASES = [  # (type_k, type_v, head_dim, NH, NKV, n_q, n_kv, splits, sinks)
     (L.Q5_1, L.Q5_1, 128, 16, 2, 3, 512, 2, False),
     (L.IQ4_NL, L.IQ4_NL, 128, 32, 8, 1, 777, 0, True),
     (L.BF16, L.BF16, 128, 32, 8, 1, 1024, 0, False),
+    (L.BF16, L.BF16, 128, 28, 4, 5, 2048, 3, False),   # (round 6: bf16 read in place too — ggml_vec_dot_bf16's arithmetic: the query rounded to bf16, f32 products)
+    (L.BF16, L.BF16, 128, 64, 8, 1, 4096, 0, True),
     (L.F32, L.F32, 128, 8, 2, 2, 256, 0, False),
     (L.Q8_0, L.Q4_0, 128, 32, 8, 1, 1024, 0, False),   # llama-box users' favourite pair: -ctk q8_0 -ctv q4_0
     (L.F16, L.Q4_0, 128, 32, 8, 1, 640, 0, False),
@@ -199,7 +201,7 @@ def test_flash_attn_over_kv_types(backend, H, plog, tk, tv, HD, NH, NKV, nq, nkv
     # served either through the f16 image or, where the lane-parallel kernel reads such a cache IN PLACE (fattn.hip: fattn_native_kv_ok), by that form:
     # exactly one of the two, and the in-place form only at its shapes (head_dim 128, at most 32 query tokens)
     d_nat, d_img = backend.stat("kv_native_nodes") - nat0, backend.stat("kv_image_nodes") - img0
-    in_place = HD == 128 and nq <= 32 and tk == tv and tk in (L.Q4_0, L.Q4_1, L.Q5_0, L.Q5_1, L.IQ4_NL)  # (fattn.hip: fattn_native_kv_ok)
+    in_place = HD == 128 and nq <= 32 and tk == tv and tk in (L.Q4_0, L.Q4_1, L.Q5_0, L.Q5_1, L.IQ4_NL, L.BF16)  # (fattn.hip: fattn_native_kv_ok)
     assert (d_nat, d_img) == ((1, 0) if in_place else (0, 1)), (d_nat, d_img)
     tag = f"flash_attn K={NAME[tk]} V={NAME[tv]} hd={HD} H={NH}/{NKV} nq={nq} nkv={nkv} splits={splits} sinks={sinks}"
     # in place (round 6): ggml-cpu's own arithmetic — the query row quantised to Q8_0 / Q8_1, integer block dots, V de-quantised to f32 — so the gate is the
