@@ -1765,10 +1765,11 @@ static int run_node(exec_state & st, int i) {
                     if (st.done[k]) continue;
                     if (!cast && t->op == GGML_OP_CPY && t->src[0]->type == GGML_TYPE_F32 && t->type == GGML_TYPE_F16 && t->src[0]->op == GGML_OP_NONE &&
                         ggml_abi_is_contiguous(t->src[0]) && ggml_abi_is_contiguous(t) && same_shape(t->src[0], t) && ggml_abi_nelements(t) <= (int64_t) 1 << 22) {
-                        bool clean = !ranges_overlap(t, n) && !ranges_overlap(t, a) && !ranges_overlap(t, b);
+                        // (neither the cast's result nor its SOURCE may be touched by anything that runs between here and the cast's place in the graph)
+                        bool clean = !ranges_overlap(t, n) && !ranges_overlap(t, a) && !ranges_overlap(t, b) && !ranges_overlap(t->src[0], n);
                         for (int m = i + 1; m < k && clean; ++m) {
                             const ggml_tensor * u = g->nodes[m];
-                            clean = !ranges_overlap(t, u);
+                            clean = !ranges_overlap(t, u) && !ranges_overlap(t->src[0], u);
                             for (int q = 0; q < GGML_MAX_SRC && clean; ++q)
                                 if (u->src[q]) clean = !ranges_overlap(t, u->src[q]);
                         }
