@@ -1600,10 +1600,22 @@ enum ggml_status oracle_compute_node(struct ggml_tensor * node, int n_threads) {
     }
 }
 
+/* FAULT INJECTION for the tests of the parity gates themselves (tests/test_oracle_golden.py: does a gate trip when it should?): variant 5 scales the result of the
+   node named "result_output" (the logits) by 1 + 4e-3, variant 6 the result of every node whose name starts with "ffn_out" (a layer's FFN branch) by 1 + 1e-2 */
+static void inject_fault(struct ggml_tensor * t) {
+    float f = 1.0f;
+    if (g_variant == 5 && strcmp(t->name, "result_output") == 0) f = 1.004f;
+    else if (g_variant == 6 && strncmp(t->name, "ffn_out", 7) == 0) f = 1.01f;
+    if (f == 1.0f || t->type != GGML_TYPE_F32) return;
+    const int64_t n = t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3];
+    float * d = (float *) t->data;
+    for (int64_t i = 0; i < n; ++i) d[i] *= f;
+}
 enum ggml_status oracle_graph_compute(struct ggml_cgraph * graph, int n_threads) {
     for (int i = 0; i < graph->n_nodes; ++i) {
         enum ggml_status st = oracle_compute_node(graph->nodes[i], n_threads);
         if (st != GGML_STATUS_SUCCESS) return st;
+        if (g_variant >= 5) inject_fault(graph->nodes[i]);
     }
     return GGML_STATUS_SUCCESS;
 }

@@ -44,7 +44,8 @@ enum ggml_status oracle_graph_compute(struct ggml_cgraph * graph, int n_threads)
 int oracle_supports_op(const struct ggml_tensor * node);
 int oracle_max_threads(void);
 /* 0 = generic ggml-cpu; 1 / 2 / 3 = one-ulp sensitivity probes for the tests (reversed block order, f32 RMS_NORM sum,
- * expf one ulp up / down) — see ggml_cpu_ref.c */
+ * expf one ulp up / down); 4 = block-format K rows against the unquantised query; 5 / 6 = FAULT INJECTION for the tests of the gates themselves
+ * (the logits x 1.004 / every layer's FFN branch x 1.01) — see ggml_cpu_ref.c */
 void oracle_set_variant(int v);
 /* bench.py cpu_baseline ONLY: route the quantised block dots of MUL_MAT through the AVX2 restatement of ggml-cpu's x86 kernels
  * (same integers, another f32 accumulation order).  Returns the state actually set (0 when built without AVX2+FMA). */
