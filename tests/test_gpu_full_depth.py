@@ -72,7 +72,7 @@ def _oracle_rows(mc, toks_prompt, n_par, n_prompt, n_dec, fa, n_ctx, fast, varia
         lib.oracle_set_fast(0)
 
 
-def full_depth_parity(backend, H, plog, name, fa, n_prompt, n_dec, n_par=1, seed=11, strict=None, ref_fast=False, n_var_dec=0, kv=(0, 0), check=True):
+def full_depth_parity(backend, H, plog, name, fa, n_prompt, n_dec, n_par=1, seed=11, strict=None, ref_fast=False, n_var_dec=0, kv=(0, 0), check=True, n_var_prompt=0):
     """Returns the numbers bench.py's `parity` object is made of too.  `strict` (default: the weight set is a "-damped" one) gates north_star's bar as written.
     ref_fast: the REFERENCE run is the oracle in ggml-cpu's x86 lane order (what llama-box's CPU path executes on an AVX2 host; 3 x cheaper than the generic scalar
     order) and the generic order is the second opinion; otherwise the other way round.  The second opinion runs the prompt batch + n_var_dec steps — or, with
