@@ -99,7 +99,7 @@ const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w) {
         // 288 GB of HBM: a second copy of the weights one GPU serves always fits beside the first — unless the user filled the device on purpose; then the
         // mat-vecs keep reading the block layout, as before round 6
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bc->size + ((size_t) 2 << 30) || hipMalloc(&bc->shadow, bc->size) != hipSuccess) {
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bc->size + ((size_t) std::max(0, c->opt.decode_copy_headroom_gib) << 30) || hipMalloc(&bc->shadow, bc->size) != hipSuccess) {
             (void) hipGetLastError();
             bc->shadow = nullptr;
             bc->shadow_failed = true;
@@ -834,6 +834,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "timing") c->opt.timing = v != 0;
     else if (k == "exec_update") c->opt.exec_update = v;
     else if (k == "decode_copy") c->opt.decode_copy = v != 0;
+    else if (k == "decode_copy_headroom_gib") c->opt.decode_copy_headroom_gib = v;
     else if (k == "clear_failure") { if (v) clear_hip_failure(); }
     else if (k == "staged_upload") g_staged_upload.store(v != 0);
     else return -1;

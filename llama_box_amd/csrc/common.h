@@ -133,6 +133,7 @@ struct options {
     bool small_uploads = true; // set_tensor_async of <= 64 KiB: pinned ring + copy kernel instead of a blit
     bool small_downloads = true; // get_tensor_async of <= 8 MiB into this backend's pinned host buffer type: a copy kernel instead of a blit
     bool timing = false;       // hipEvent-bracket kernel classes (bench only; disables graphs)
+    int decode_copy_headroom_gib = 2;  // a buffer's decode copy is made only while this much device memory stays free beside it (tests raise it to force the fallback)
     bool decode_copy = [] { const char * e = getenv("GGML_MI355X_DECODE_COPY"); return e ? atoi(e) != 0 : true; }();  // batch-1 mat-vecs read the plane-layout copy of their weights
     int exec_update = [] { const char * e = getenv("GGML_MI355X_EXEC_UPDATE"); return e ? atoi(e) : 1; }();  // patch the predecessor's executable graph at a capture at
                                // first sighting (graph.cpp); 2 = run the update and treat it as failed (tests)

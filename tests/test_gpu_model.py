@@ -766,3 +766,31 @@ def test_mat_vecs_over_the_decode_copy_are_bit_equal_and_follow_a_rewritten_weig
     assert outs[0][1]["decode_copy_launches"] == 0
     assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
     assert not np.array_equal(outs[1][0][8], outs[1][0][9])
+
+
+def test_no_room_for_a_decode_copy_keeps_the_block_layout(backend, H, plog):
+    """The decode copy is an optimisation that costs device memory: when less than the weights buffer's size + the headroom is free it is not made (logged once per
+    buffer), the mat-vec kernels read the block layout, and the logits are the same bits.  Option decode_copy_headroom_gib set beyond the device's memory forces that."""
+    hp = preset("test-llama", n_embd=2048, n_head=16, n_head_kv=4, n_embd_head=128, n_ff=4096, n_layer=2)
+    outs = {}
+    try:
+        for mode in ("room", "no room"):
+            backend.set_option("decode_copy_headroom_gib", 2 if mode == "room" else 100000)
+            mg = Model(hp, 5, backend.buft)  # (a fresh weights buffer per mode: a buffer that was refused a copy stays without one)
+            s0 = {k: backend.stat(k) for k in ("decode_copy_launches", "decode_copy_tensors")}
+            c = Context(mg, backend=backend, flash_attn=1)
+            rc, lg = c.decode(PROMPT, range(len(PROMPT)), want=[0] * (len(PROMPT) - 1) + [1])
+            assert rc == 0
+            rows = [lg[-1]]
+            for i in range(6):
+                rc, l1 = c.decode([9 + i], [len(PROMPT) + i])
+                assert rc == 0
+                rows.append(l1[0])
+            outs[mode] = (np.stack(rows), {k: backend.stat(k) - v for k, v in s0.items()})
+            c.free()
+            mg.free()
+    finally:
+        backend.set_option("decode_copy_headroom_gib", 2)
+    plog(f"decode copy with / without room: {outs['room'][1]} / {outs['no room'][1]}")
+    assert outs["room"][1]["decode_copy_tensors"] > 0 and outs["no room"][1]["decode_copy_tensors"] == 0 and outs["no room"][1]["decode_copy_launches"] == 0
+    assert np.array_equal(outs["room"][0].view(np.uint32), outs["no room"][0].view(np.uint32))
