@@ -119,6 +119,8 @@ struct qkv_args {
     const int64_t * slot;
     const float * rope_tab;  // optional: [head_dim / 2][cos, sin] for this token (launch_rope_table) instead of computing them in every workgroup's prologue
     int wg_a;  // set by launch_qkv: workgroups [0, wg_a) serve the alt == 0 segments, the rest the alt == 1 segments
+    int wv_a;  // > 0 (two formats, f16 / bf16 / f32 stores — round 6): the split is by WAVES instead: waves [0, wv_a) of the launch (workgroup x waves + wave) serve the
+               // alt == 0 segments, the rest the alt == 1 segments, so that 256 workgroups x 12 waves hold Llama-3-8B's 2560 + 512 row pairs with ONE unit per wave
     int planes;  // every segment's W is the matrix's decode copy (plane layout, repack.hip): the launch runs the plane forms of both formats
     const double * ss_in;  // as mmvq_args::ss_in / ss_n (norm prologue)
     int ss_n;

@@ -86,7 +86,8 @@ template <typename TA, typename TB, bool Q8S, bool PIPE = false, int BND = 1024>
 __global__ void __launch_bounds__(PIPE ? 512 : BND) k_qkv_stream2(const qkv_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (a generic lambda, not a device function: passing the kernel-argument struct to a function copies it to scratch)
-    auto body = [&](auto tag, const int alt, const int wg, const int nwg) {
+    // (u_first / GW: this wave's first unit among the segments of its format, and the number of waves that share them)
+    auto body = [&](auto tag, const int alt, const int u_first, const int GW) {
     using T = decltype(tag);
     constexpr int MAXW = 16, QB = PIPE ? 4 : 2;  // QB activation blocks per wave per prologue trip (norm: nblk <= QB*WAVES)
     const int WAVES = (int) blockDim.x >> 6;  // 8..16 waves: the launcher sizes the workgroup so that units/WAVES ~ 256 workgroups
@@ -102,13 +103,12 @@ __global__ void __launch_bounds__(PIPE ? 512 : BND) k_qkv_stream2(const qkv_args
     double * red = (double *) (smem + (size_t) nblk * sizeof(act));
     float * cs_tab = (float *) (red + MAXW);  // [head_dim/2][2]
     float * stash = cs_tab + a.head_dim;      // [32]: one Q8_0 block of cache-row values (store == 2)
-    const int GW = nwg * WAVES;
     const int half = a.head_dim >> 1;
     const int u0 = a.seg[0].alt == alt ? a.seg[0].N >> 1 : 0;
     const int u1 = u0 + (a.nseg > 1 && a.seg[1].alt == alt ? a.seg[1].N >> 1 : 0);
     const int UT = u1 + (a.nseg > 2 && a.seg[2].alt == alt ? a.seg[2].N >> 1 : 0);
 
-    int u = wg * WAVES + wave;
+    int u = u_first;
     bool have = u < UT;
     int si = 0, r0 = 0, r1 = 0, pair_i = 0;
     qkv_seg sg = a.seg[0];
@@ -289,11 +289,27 @@ __global__ void __launch_bounds__(PIPE ? 512 : BND) k_qkv_stream2(const qkv_args
         }
     }
     };
+    const int nwv = (int) blockDim.x >> 6, wv = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     if constexpr (std::is_same<TA, TB>::value) {
-        body(TA{}, 0, (int) blockIdx.x, (int) gridDim.x);
+        body(TA{}, 0, (int) blockIdx.x * nwv + wv, (int) gridDim.x * nwv);
     } else {
-        if ((int) blockIdx.x < a.wg_a) body(TA{}, 0, (int) blockIdx.x, a.wg_a);
-        else body(TB{}, 1, (int) blockIdx.x - a.wg_a, (int) gridDim.x - a.wg_a);
+        // the two formats share the launch wave by wave (wv_a > 0, round 6): a workgroup's waves may run different instantiations — each executes the same prologue
+        // and the same number of workgroup barriers — or workgroup by workgroup (the block-format cache stores add barriers per unit).  ONE call site per
+        // instantiation: a second one stops the compiler from inlining the body and sends the argument block through scratch memory
+        bool is_a;
+        int uf, gwn;
+        if (!Q8S && a.wv_a > 0) {
+            const int gw = (int) blockIdx.x * nwv + wv, total = (int) gridDim.x * nwv;
+            is_a = gw < a.wv_a;
+            uf = is_a ? gw : gw - a.wv_a;
+            gwn = is_a ? a.wv_a : total - a.wv_a;
+        } else {
+            is_a = (int) blockIdx.x < a.wg_a;
+            uf = (is_a ? (int) blockIdx.x : (int) blockIdx.x - a.wg_a) * nwv + wv;
+            gwn = (is_a ? a.wg_a : (int) gridDim.x - a.wg_a) * nwv;
+        }
+        if (is_a) body(TA{}, 0, uf, gwn);
+        else body(TB{}, 1, uf, gwn);
     }
 }
 
@@ -345,6 +361,9 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
         else if constexpr (std::is_same<TA, T_Q5K>::value || std::is_same<TB, T_Q5K>::value || std::is_same<TA, T_Q5KP>::value || std::is_same<TB, T_Q5KP>::value) { \
             if (small_wg) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false, false, 640>), GRID, block, lds, s, a); \
             else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                  \
+        } else if constexpr (!std::is_same<TA, TB>::value) {  /* Q4_K + Q6_K: Llama-3-8B's launches use 12 waves (the 768-thread build: 170 registers, no scratch) */ \
+            if (nw <= 12) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false, false, 768>), GRID, block, lds, s, a); \
+            else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                  \
         } else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                    \
     } while (0)
     const bool planes = a.planes != 0 && (a.K % 2048) == 0 && type_a != GGML_TYPE_Q8_0;  // every segment's W is its decode copy (graph.cpp made sure): the plane forms
@@ -359,6 +378,23 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
         else if (type_a == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q6K, T_Q6K, dim3(grid));
         else if (type_a == GGML_TYPE_Q8_0) QKV_LAUNCH(T_Q80, T_Q80, dim3(grid));
         else { MI_ERR("launch_qkv: unsupported weight format %d", type_a); abort(); }
+        return;
+    }
+    static const bool wave_split = !getenv("GGML_MI355X_QKV_WAVE_SPLIT") || atoi(getenv("GGML_MI355X_QKV_WAVE_SPLIT")) != 0;
+    if (wave_split && !q8_store && !pipe) {
+        // split by waves: the smallest grid of nw-wave workgroups that holds one unit per wave (at most 256), format A's units on the first waves
+        const int total_units = units[0] + units[1];
+        const int g = std::min(256, (total_units + nw - 1) / nw), waves = g * nw;
+        a.wg_a = g;
+        a.wv_a = total_units <= waves ? units[0] : std::max(1, std::min(waves - 1, (int) ((double) waves * bytes[0] / (bytes[0] + bytes[1]) + 0.5)));
+        const dim3 grid_w((unsigned) g);
+        if (planes && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4KP, T_Q6KP, grid_w);
+        else if (planes && type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5KP, T_Q6KP, grid_w);
+        else if (planes && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4KP, T_Q5KP, grid_w);
+        else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4K, T_Q6K, grid_w);
+        else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5K, T_Q6K, grid_w);
+        else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4K, T_Q5K, grid_w);
+        else { MI_ERR("launch_qkv: unsupported weight format pair %d/%d", type_a, type_b); abort(); }
         return;
     }
     // one workgroup per CU at most; when the units would need more, share the 256 slots by weight bytes
