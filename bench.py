@@ -310,6 +310,12 @@ def main():
     prefill_tok_s = None
     prefill_host_split = [0, 0, 0, 0]
     if args.prefill > 0:
+        # an untimed pass over the weights first: the first kernels that touch a freshly uploaded model pay for page-table population and clock ramp-up (measured on
+        # one box: the first 2048-token prefill of the process 127 ms instead of 18, the 70B's first 512 tokens 1.06 s instead of 0.1) — not what a server's prompts see
+        nw_ = min(64, args.prefill)
+        rc, _ = ctx.decode(toks[:nw_], range(nw_), seq=[0] * nw_, want=[0] * (nw_ - 1) + [1])
+        assert rc == 0, f"warm-up prefill failed rc={rc}"
+        ctx.clear()
         sync()
         t0 = time.perf_counter()
         # llama-box never mixes prefill and decode in one batch (httpserver.hpp:3742, :4042), but it does fill a batch with the prompt
