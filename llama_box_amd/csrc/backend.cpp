@@ -858,6 +858,7 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "p2p_allreduces") return c->st.p2p_allreduces;
     if (k == "p2p_timeouts") return tp_p2p_timeouts(c);
     if (k == "step_heads") return c->st.step_heads;
+    if (k == "elided_conts") return c->st.elided_conts;
     if (k == "decode_copy_tensors") return c->st.decode_copy_tensors;
     if (k == "decode_copy_bytes") return c->st.decode_copy_bytes;
     if (k == "decode_copy_launches") return c->st.decode_copy_launches;

@@ -161,6 +161,7 @@ struct stats {
     int64_t decode_copy_tensors = 0;   // weight matrices repacked into the decode copy by this backend instance ...
     int64_t decode_copy_bytes = 0;     // ... and their bytes
     int64_t decode_copy_launches = 0;  // mat-vec / fused Q/K/V launches that streamed a decode copy
+    int64_t elided_conts = 0;          // cont(permute(kqv)) copies of a one-token non-flash attention whose bytes the producing launch wrote in place (round 6)
     int64_t step_heads = 0;            // decode-step heads served by one launch: GET_ROWS + mask cast + rotary table (ops.hip: k_step_head)
     int64_t graph_exec_update_failures = 0; // ... and updates that failed: the predecessor's (possibly half-patched) executable graph is destroyed, both entries start over
     int64_t graph_evictions = 0;       // cache entries dropped because they had not been used for 256 graphs

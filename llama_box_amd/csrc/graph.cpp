@@ -1855,9 +1855,33 @@ static int run_node(exec_state & st, int i) {
                     const ggml_tensor * v = mm->src[0];
                     // workgroups store rows of the product while others still read the logits: no recycled memory between the two
                     if (v->type == GGML_TYPE_F16 && !buffer_is_split(v->buffer) && ggml_abi_is_contiguous(mm) && !ranges_overlap(mm, a) && !(b && ranges_overlap(mm, b))) {
+                        // llama.cpp's non-flash graph ends the attention with cont(permute(kqv)): for ONE token the permuted view has kqv's own byte order, and the
+                        // CONT was a 16 KB device-to-device copy per layer — a blit kernel of 4.9 us + its boundary, 10 % of a `-fa 0` decode step (round 6).  When
+                        // kqv is read by nothing but that view chain, the product is written where the CONT would have put it and the CONT is done
+                        int cont_at = -1;
+                        const ggml_tensor * cont = nullptr;
+                        static const bool elide_on = !getenv("GGML_MI355X_ELIDE_CONT") || atoi(getenv("GGML_MI355X_ELIDE_CONT")) != 0;
+                        if (elide_on && use_count(st, mm) == 1 && !(mm->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                            const ggml_tensor * cur = mm;
+                            for (int k = j + 1; k < std::min(g->n_nodes, j + 6); ++k) {
+                                const ggml_tensor * t = g->nodes[k];
+                                if (st.done[k]) continue;
+                                if (is_view_op(t) && t->src[0] == cur && t->data == mm->data && use_count(st, t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT)) { cur = t; continue; }
+                                if ((t->op == GGML_OP_CONT || t->op == GGML_OP_CPY || t->op == GGML_OP_DUP) && t->src[0] == cur && cur != mm && t->type == mm->type && ggml_abi_is_contiguous(cur) &&
+                                    ggml_abi_is_contiguous(t) && ggml_abi_nelements(t) == ggml_abi_nelements(mm) && !ranges_overlap(t, a) && !ranges_overlap(t, v) && !(b && ranges_overlap(t, b)) &&
+                                    !ranges_overlap(t, mm)) {
+                                    cont = t;
+                                    cont_at = k;
+                                }
+                                break;
+                            }
+                        }
+                        tdesc out = TD(mm);
+                        if (cont) out.data = (char *) cont->data;
                         timed_scope ts(c, "soft_max_mul_mat_f", (double) ggml_abi_nbytes(v) + (double) ggml_abi_nbytes(n));
-                        if (launch_soft_max_mul_mat_f16(s, TD(v), TD(a), b ? &md : nullptr, TD(mm), ggml_abi_op_param_f32(n, 0))) {
+                        if (launch_soft_max_mul_mat_f16(s, TD(v), TD(a), b ? &md : nullptr, out, ggml_abi_op_param_f32(n, 0))) {
                             mark_done(st, j);
+                            if (cont) { mark_done(st, cont_at); c->st.fused_nodes++; c->st.elided_conts++; }
                             c->st.kernel_launches++;
                             c->st.fused_nodes++;
                             return 1;
