@@ -267,7 +267,7 @@ struct buffer_ctx {
     std::mutex sh_mtx;
     std::unordered_map<size_t, size_t> sh_valid;  // offset of a repacked tensor -> its bytes
 };
-// the plane-layout copy of weight matrix w for the batch-1 mat-vec kernels, or nullptr (no copy: views, split / row-parallel buffers, K % 2048 != 0, option off,
+// the plane-layout copy of weight matrix w for the batch-1 mat-vec kernels, or nullptr (no copy: views, split / row-parallel buffers, option off,
 // allocation failed, or asked during a capture for a tensor not yet repacked)
 const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w);
 uint64_t decode_copy_epoch();  // bumped whenever a copy was dropped: graphs captured before hold pointers to it

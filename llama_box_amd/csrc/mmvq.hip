@@ -500,7 +500,7 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
     // the streaming forms over the decode copy (plane layout, non-temporal loads): same registers per lane, same dot products
     typedef typename plane_of<T>::type TP;
     if constexpr (!std::is_same<T, TP>::value) {
-        const bool planes = a0.Wp != nullptr && (!glu || a0.W2p != nullptr) && (a0.K % 2048) == 0;
+        const bool planes = a0.Wp != nullptr && (!glu || a0.W2p != nullptr) && (a0.K % 256) == 0;
         const bool stream = a0.x != nullptr || a0.fa_part != nullptr || (a0.ncols == 1 && (size_t) nblk * sizeof(typename T::act) <= 60 * 1024);
         if (planes && stream) {
             mmvq_args ap = a0;

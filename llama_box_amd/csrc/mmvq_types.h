@@ -24,7 +24,7 @@ namespace mi355x {
 // A lane receives exactly the registers T::load of the block layout gives it, so the dot products are the same code and the same bits; every 128-byte line is
 // touched by ONE wave-instruction, which is what makes the non-temporal policy pay (on the block layout it cost 15 %: header, low and high quants of a lane are
 // three instructions on the same lines).  Measured before building (same bytes from these addresses, wrong values): 541 -> 580 tok/s; the output matrix
-// 83.5 -> 67.5 us, Q6_K ffn_down 13.8 -> 11.65, gate/up 14.55 -> 14.0 (profiles/r06_lab_planes_nt.txt).  Rows need K % 2048 == 0.
+// 83.5 -> 67.5 us, Q6_K ffn_down 13.8 -> 11.65, gate/up 14.55 -> 14.0 (profiles/r06_lab_planes_nt.txt).
 typedef uint32_t mi_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t mi_u32x2 __attribute__((ext_vector_type(2)));
 typedef mi_u32x4 mi_u32x4_a2 __attribute__((aligned(2)));
@@ -252,39 +252,45 @@ struct T_Q80 {
 
 
 // ------------------------------------------------------------------------------------------------ the plane layouts of the decode copy (see the top of this file)
+// (a row whose super-block count is not a multiple of 8 — Qwen2-7B: 14 and 74 — ends in a SHORT group of nb = nblk % 8 super-blocks with the same plane order,
+// 4 nb lanes wide; only its lines are shared between planes)
+__device__ __forceinline__ int plane_group_blocks(const int p, const int nblk) { return min(8, nblk - ((p >> 5) << 3)); }
 struct T_Q4KP : T_Q4K {
-    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int = 0) {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk) {
         const uint8_t * grp = row + (size_t) (p >> 5) * 1152;
+        const int nb = plane_group_blocks(p, nblk);
         raw r;
         r.hdr = ld_nt(grp + 16 * ((p >> 2) & 7));
-        r.q0 = ld_nt(grp + 128 + 16 * (p & 31));
-        r.q1 = ld_nt(grp + 640 + 16 * (p & 31));
+        r.q0 = ld_nt(grp + 16 * nb + 16 * (p & 31));
+        r.q1 = ld_nt(grp + 80 * nb + 16 * (p & 31));
         return r;
     }
 };
 struct T_Q5KP : T_Q5K {
-    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int = 0) {
+    static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk) {
         const uint8_t * grp = row + (size_t) (p >> 5) * 1408;
-        const int b8 = (p >> 2) & 7;
+        const int nb = plane_group_blocks(p, nblk), b8 = (p >> 2) & 7;
         raw r;
         r.hdr = ld_nt(grp + 16 * b8);
-        r.h0 = ld_nt(grp + 128 + 16 * b8);
-        r.h1 = ld_nt(grp + 256 + 16 * b8);
-        r.q0 = ld_nt(grp + 384 + 16 * (p & 31));
-        r.q1 = ld_nt(grp + 896 + 16 * (p & 31));
+        r.h0 = ld_nt(grp + 16 * nb + 16 * b8);
+        r.h1 = ld_nt(grp + 32 * nb + 16 * b8);
+        r.q0 = ld_nt(grp + 48 * nb + 16 * (p & 31));
+        r.q1 = ld_nt(grp + 112 * nb + 16 * (p & 31));
         return r;
     }
 };
+// (Q6_K rows are 210 nblk bytes: 16-byte aligned only when nblk is a multiple of 8 — the plane loads carry the format's 2-byte alignment, which gfx950 serves)
+__device__ __forceinline__ u128_a2 ld_nt_a2(const void * p) { return __builtin_bit_cast(u128_a2, __builtin_nontemporal_load((const mi_u32x4_a2 *) p)); }
 struct T_Q6KP : T_Q6K {
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk) {
         const uint8_t * grp = row + (size_t) (p >> 5) * 1536;
-        const uint8_t * tail = row + (size_t) (nblk >> 3) * 1536;
-        const int h = (p >> 1) & 1;
+        const uint8_t * tail = row + (size_t) nblk * 192;
+        const int nb = plane_group_blocks(p, nblk), h = (p >> 1) & 1;
         raw r;
-        r.a = __builtin_bit_cast(u128_a2, ld_nt(grp + 16 * (p & 31)));
-        r.b = __builtin_bit_cast(u128_a2, ld_nt(grp + 512 + 16 * (p & 31)));
-        r.c = __builtin_bit_cast(u128_a2, ld_nt(grp + 1024 + 16 * (p & 31)));
-        r.s = __builtin_bit_cast(u64_a2, ld_nt8(tail + (size_t) (p >> 2) * 16 + 8 * h));
+        r.a = ld_nt_a2(grp + 16 * (p & 31));
+        r.b = ld_nt_a2(grp + 64 * nb + 16 * (p & 31));
+        r.c = ld_nt_a2(grp + 128 * nb + 16 * (p & 31));
+        r.s = __builtin_bit_cast(u64_a2, __builtin_nontemporal_load((const mi_u32x2_a2 *) (tail + (size_t) (p >> 2) * 16 + 8 * h)));
         r.d = ld16(tail + (size_t) nblk * 16 + (size_t) (p >> 2) * 2);
         return r;
     }

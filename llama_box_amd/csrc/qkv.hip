@@ -366,7 +366,7 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
             else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                  \
         } else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                    \
     } while (0)
-    const bool planes = a.planes != 0 && (a.K % 2048) == 0 && type_a != GGML_TYPE_Q8_0;  // every segment's W is its decode copy (graph.cpp made sure): the plane forms
+    const bool planes = a.planes != 0 && (a.K % 256) == 0 && type_a != GGML_TYPE_Q8_0;  // every segment's W is its decode copy (graph.cpp made sure): the plane forms
     if (type_a == type_b || units[1] == 0) {
         const unsigned grid = (unsigned) std::min(256, (units[0] + nw - 1) / nw);
         a.wg_a = (int) grid;

@@ -20,48 +20,36 @@ __device__ __forceinline__ void st_piece_a2(uint8_t * p, const piece16 & v) {
     for (int i = 0; i < 8; ++i) *(uint16_t *) (p + 2 * i) = v.h[i];
 }
 
-// grid.x covers the pieces of one row, grid.y the rows
+// grid.x covers the SOURCE pieces of one row (per super-block: Q4_K 9, Q5_K 11, Q6_K 12 + one tail item), grid.y the rows.  Group g holds super-blocks 8 g .. 8 g + nb - 1
+// (nb = 8, or nblk % 8 for a short last group); lane l = 4 (b - 8 g) + j of the group owns the 16-byte pieces j of super-block b.
 template <int QT> __global__ void __launch_bounds__(256) k_repack_planes(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, const int nblk, const int64_t nb1) {
     const uint8_t * srow = src + (size_t) blockIdx.y * nb1;
     uint8_t * drow = dst + (size_t) blockIdx.y * nb1;
     const int e = (int) (blockIdx.x * 256 + threadIdx.x);
-    if constexpr (QT == 4) {  // per group of 8 blocks: 8 header pieces, 32 q0 pieces, 32 q1 pieces
-        const int grp = e / 72, d = e - grp * 72;
-        if (grp >= (nblk >> 3)) return;
-        const uint8_t * g0 = srow + (size_t) grp * 1152;
-        uint8_t * o = drow + (size_t) grp * 1152;
-        int so;
-        if (d < 8) so = d * 144;
-        else {
-            const int l = (d - 8) & 31, hi = (d - 8) >> 5;
-            so = (l >> 2) * 144 + 16 + 32 * (l & 3) + 16 * hi;
-        }
-        *(uint4 *) (o + 16 * d) = *(const uint4 *) (g0 + so);
-    } else if constexpr (QT == 5) {  // 8 headers, 8 qh low halves, 8 qh high halves, 32 q0, 32 q1
-        const int grp = e / 88, d = e - grp * 88;
-        if (grp >= (nblk >> 3)) return;
-        const uint8_t * g0 = srow + (size_t) grp * 1408;
-        uint8_t * o = drow + (size_t) grp * 1408;
-        int so;
-        if (d < 24) so = (d & 7) * 176 + 16 * (d >> 3);
-        else {
-            const int l = (d - 24) & 31, hi = (d - 24) >> 5;
-            so = (l >> 2) * 176 + 48 + 32 * (l & 3) + 16 * hi;
-        }
-        *(uint4 *) (o + 16 * d) = *(const uint4 *) (g0 + so);
-    } else {  // Q6_K: per group 32 A, 32 B, 32 C pieces; then per super-block of the row one tail item (scales + d)
-        const int n_grp = nblk >> 3;
-        if (e < n_grp * 96) {
-            const int grp = e / 96, d = e - grp * 96;
-            const int plane = d >> 5, l = d & 31, h = (l >> 1) & 1, t = l & 1;
-            const uint8_t * blk = srow + (size_t) (grp * 8 + (l >> 2)) * 210;
+    constexpr int PPB = QT == 4 ? 9 : QT == 5 ? 11 : 13;
+    const int b = e / PPB, k = e - b * PPB;
+    if (b >= nblk) return;
+    const int g = b >> 3, bl = b & 7, nb = min(8, nblk - (g << 3));
+    if constexpr (QT == 4) {  // pieces of a block: header, then qs in 16-byte pieces (j = piece / 2, low / high half)
+        const uint8_t * blk = srow + (size_t) b * 144;
+        uint8_t * grp = drow + (size_t) g * 1152;
+        const int j = (k - 1) >> 1, hi = (k - 1) & 1;
+        uint8_t * o = k == 0 ? grp + 16 * bl : grp + 16 * nb + hi * 64 * nb + 16 * (4 * bl + j);
+        *(uint4 *) o = *(const uint4 *) (blk + 16 * k);
+    } else if constexpr (QT == 5) {  // header, qh low half, qh high half, then qs as for Q4_K
+        const uint8_t * blk = srow + (size_t) b * 176;
+        uint8_t * grp = drow + (size_t) g * 1408;
+        const int j = (k - 3) >> 1, hi = (k - 3) & 1;
+        uint8_t * o = k < 3 ? grp + 16 * nb * k + 16 * bl : grp + 48 * nb + hi * 64 * nb + 16 * (4 * bl + j);
+        *(uint4 *) o = *(const uint4 *) (blk + 16 * k);
+    } else {  // Q6_K: 12 pieces (plane A / B / C x lane 2 h + t), then the tail item (16 scale bytes + d)
+        const uint8_t * blk = srow + (size_t) b * 210;
+        if (k < 12) {
+            const int plane = k >> 2, l4 = k & 3, h = l4 >> 1, t = l4 & 1;
             const int so = plane == 0 ? 64 * h + 16 * t : plane == 1 ? 64 * h + 32 + 16 * t : 128 + 32 * h + 16 * t;
-            st_piece_a2(drow + (size_t) grp * 1536 + 16 * d, ld_piece_a2(blk + so));
+            st_piece_a2(drow + (size_t) g * 1536 + 64 * nb * plane + 16 * (4 * bl + l4), ld_piece_a2(blk + so));
         } else {
-            const int b = e - n_grp * 96;
-            if (b >= nblk) return;
-            const uint8_t * blk = srow + (size_t) b * 210;
-            uint8_t * tail = drow + (size_t) n_grp * 1536;
+            uint8_t * tail = drow + (size_t) nblk * 192;
             st_piece_a2(tail + (size_t) b * 16, ld_piece_a2(blk + 192));
             *(uint16_t *) (tail + (size_t) nblk * 16 + (size_t) b * 2) = *(const uint16_t *) (blk + 208);
         }
@@ -69,7 +57,7 @@ template <int QT> __global__ void __launch_bounds__(256) k_repack_planes(const u
 }
 
 bool repack_supported(int type, int64_t K, int64_t nb1) {
-    if (K <= 0 || (K % 2048) != 0) return false;
+    if (K <= 0 || (K % 256) != 0) return false;
     const int64_t nblk = K / 256;
     if (type == GGML_TYPE_Q4_K) return nb1 == nblk * 144;
     if (type == GGML_TYPE_Q5_K) return nb1 == nblk * 176;
@@ -82,13 +70,15 @@ void launch_repack_planes(hipStream_t s, int type, const void * src, void * dst,
     const int nblk = (int) (K / 256);
     const uint8_t * sp = (const uint8_t *) src + (size_t) r0 * nb1;
     uint8_t * dp = (uint8_t *) dst + (size_t) r0 * nb1;
+    const int ppb = type == GGML_TYPE_Q4_K ? 9 : type == GGML_TYPE_Q5_K ? 11 : 13;
+    const unsigned gx = (unsigned) ((nblk * ppb + 255) / 256);
     for (int64_t y0 = 0; y0 < n_rows; y0 += 32768) {  // (grid.y limit)
         const unsigned ny = (unsigned) std::min<int64_t>(32768, n_rows - y0);
         const uint8_t * s1 = sp + (size_t) y0 * nb1;
         uint8_t * d1 = dp + (size_t) y0 * nb1;
-        if (type == GGML_TYPE_Q4_K) hipLaunchKernelGGL((k_repack_planes<4>), dim3((unsigned) (((nblk >> 3) * 72 + 255) / 256), ny), dim3(256), 0, s, s1, d1, nblk, nb1);
-        else if (type == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_repack_planes<5>), dim3((unsigned) (((nblk >> 3) * 88 + 255) / 256), ny), dim3(256), 0, s, s1, d1, nblk, nb1);
-        else hipLaunchKernelGGL((k_repack_planes<6>), dim3((unsigned) (((nblk >> 3) * 96 + nblk + 255) / 256), ny), dim3(256), 0, s, s1, d1, nblk, nb1);
+        if (type == GGML_TYPE_Q4_K) hipLaunchKernelGGL((k_repack_planes<4>), dim3(gx, ny), dim3(256), 0, s, s1, d1, nblk, nb1);
+        else if (type == GGML_TYPE_Q5_K) hipLaunchKernelGGL((k_repack_planes<5>), dim3(gx, ny), dim3(256), 0, s, s1, d1, nblk, nb1);
+        else hipLaunchKernelGGL((k_repack_planes<6>), dim3(gx, ny), dim3(256), 0, s, s1, d1, nblk, nb1);
     }
 }
 

@@ -666,21 +666,22 @@ def _np_repack(raw, qtype, K):
     blocks = raw.reshape(nblk, bs)
     out = []
     tail_s, tail_d = [], []
-    for g in range(nblk // 8):
-        b8 = blocks[8 * g: 8 * g + 8]
+    for g in range((nblk + 7) // 8):
+        b8 = blocks[8 * g: 8 * g + 8]   # (a SHORT last group when nblk % 8 != 0: same plane order, 4 nb lanes)
+        nl = 4 * len(b8)
         if qtype == L.Q4_K:
-            out.append(b8[:, 0:16].reshape(-1))                                           # 8 headers
-            out.append(np.stack([b8[l >> 2, 16 + 32 * (l & 3): 16 + 32 * (l & 3) + 16] for l in range(32)]).reshape(-1))   # q0 of lane 4 b + j
-            out.append(np.stack([b8[l >> 2, 32 + 32 * (l & 3): 32 + 32 * (l & 3) + 16] for l in range(32)]).reshape(-1))   # q1
+            out.append(b8[:, 0:16].reshape(-1))                                           # the headers
+            out.append(np.stack([b8[l >> 2, 16 + 32 * (l & 3): 16 + 32 * (l & 3) + 16] for l in range(nl)]).reshape(-1))   # q0 of lane 4 b + j
+            out.append(np.stack([b8[l >> 2, 32 + 32 * (l & 3): 32 + 32 * (l & 3) + 16] for l in range(nl)]).reshape(-1))   # q1
         elif qtype == L.Q5_K:
             out.append(b8[:, 0:16].reshape(-1))
             out.append(b8[:, 16:32].reshape(-1))
             out.append(b8[:, 32:48].reshape(-1))
-            out.append(np.stack([b8[l >> 2, 48 + 32 * (l & 3): 48 + 32 * (l & 3) + 16] for l in range(32)]).reshape(-1))
-            out.append(np.stack([b8[l >> 2, 64 + 32 * (l & 3): 64 + 32 * (l & 3) + 16] for l in range(32)]).reshape(-1))
+            out.append(np.stack([b8[l >> 2, 48 + 32 * (l & 3): 48 + 32 * (l & 3) + 16] for l in range(nl)]).reshape(-1))
+            out.append(np.stack([b8[l >> 2, 64 + 32 * (l & 3): 64 + 32 * (l & 3) + 16] for l in range(nl)]).reshape(-1))
         else:
             for base in (lambda h, t: 64 * h + 16 * t, lambda h, t: 64 * h + 32 + 16 * t, lambda h, t: 128 + 32 * h + 16 * t):
-                out.append(np.stack([b8[l >> 2, base((l >> 1) & 1, l & 1): base((l >> 1) & 1, l & 1) + 16] for l in range(32)]).reshape(-1))
+                out.append(np.stack([b8[l >> 2, base((l >> 1) & 1, l & 1): base((l >> 1) & 1, l & 1) + 16] for l in range(nl)]).reshape(-1))
     if qtype == L.Q6_K:
         tail_s = [blocks[:, 192:208].reshape(-1)]
         tail_d = [blocks[:, 208:210].reshape(-1)]
@@ -688,7 +689,7 @@ def _np_repack(raw, qtype, K):
 
 
 @pytest.mark.parametrize("qtype", [L.Q4_K, L.Q5_K, L.Q6_K])
-@pytest.mark.parametrize("K,N", [(2048, 24), (4096, 16), (14336, 8)])
+@pytest.mark.parametrize("K,N", [(2048, 24), (4096, 16), (14336, 8), (3584, 9), (18944, 5), (1024, 7), (256, 3)])
 def test_decode_copy_is_the_documented_permutation_and_get_tensor_returns_the_upload(backend, H, qtype, K, N):
     """csrc/repack.hip against a numpy statement of the plane layout (csrc/mmvq_types.h), byte for byte, row by row; the tensor itself still reads back as uploaded."""
     rng = np.random.default_rng(qtype * 100 + K)
@@ -708,11 +709,10 @@ def test_decode_copy_is_the_documented_permutation_and_get_tensor_returns_the_up
         back = np.empty(raw.nbytes, np.uint8)
         H.ggml_backend_tensor_get(t, back.ctypes.data_as(C.c_void_p), 0, back.nbytes)
         assert np.array_equal(back, raw.reshape(-1))
-        # a matrix whose rows are not whole groups of 8 super-blocks has no copy
+        # a matrix outside a WEIGHTS buffer has no copy
         t2ctx = H.ggml_init(L.InitParams(0, None, True))
         t2 = H.ggml_new_tensor_2d(t2ctx, qtype, 1024, 4)
         b2 = H.ggml_backend_alloc_ctx_tensors_from_buft(t2ctx, backend.buft)
-        H.ggml_backend_buffer_set_usage(b2, 1)
         assert fn(backend.backend, t2, None, 0) == 0
         H.ggml_backend_buffer_free(b2)
         H.ggml_free(t2ctx)
@@ -721,12 +721,13 @@ def test_decode_copy_is_the_documented_permutation_and_get_tensor_returns_the_up
         H.ggml_free(ctx)
 
 
-def test_mat_vecs_over_the_decode_copy_are_bit_equal_and_follow_a_rewritten_weight(backend, H, plog):
+@pytest.mark.parametrize("shape", [(2048, 16, 4, 4096), (1792, 14, 2, 4864)], ids=["whole-groups", "short-last-group"])
+def test_mat_vecs_over_the_decode_copy_are_bit_equal_and_follow_a_rewritten_weight(backend, H, plog, shape):
     """A model whose matrices have decode copies (K = 2048 / 4096: every K-quant format of the MIXED recipe): prompt + decode steps with the copies on and off are the
     same logits bit for bit (a lane receives the same registers from either layout), eagerly and as replayed hipGraphs; the launches that streamed a copy are
     counted.  Then the host REWRITES a weight (set_tensor): the copy is dropped, the captured graphs with it, and the next steps compute with the new bytes —
     equal to a run with the copies off."""
-    hp = preset("test-llama", n_embd=2048, n_head=16, n_head_kv=4, n_embd_head=128, n_ff=4096, n_layer=3)
+    hp = preset("test-llama", n_embd=shape[0], n_head=shape[1], n_head_kv=shape[2], n_embd_head=128, n_ff=shape[3], n_layer=3)  # (1792 / 4864: 7 and 19 super-blocks a row, Qwen2-7B's kind)
     mg = Model(hp, 99, backend.buft)
     other = Model(hp, 100, H.ggml_backend_cpu_buffer_type())
     outs = {}
