@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 # kernel-class tag (graph.cpp timed_scope) -> substring of the kernel symbol rocprofv3 reports
-def _class_to_symbol(cls, n_par=1, planes=False):
+def _class_to_symbol(cls, n_par=1, planes=False, short_rows=False):
     parts = cls.split("_")
     if parts[0] == "mmq" and 2 <= n_par <= 32:
         # -np decode steps: the weight-streaming matrix-core kernel; the gate/up pair takes its tile-parallel form (mmq_skinny.hip)
@@ -51,8 +51,9 @@ def _class_to_symbol(cls, n_par=1, planes=False):
         return None
     glu = "true" if "glu" in parts else "false"
     pro = "2" if cls.endswith("normpro") else "1"
-    # (planes: the launch streamed the decode copy of its weights — the plane-layout instantiation, csrc/mmvq_types.h; Q8_0 has none)
-    return f"k_mmvq_stream<mi355x::{ty}{'P' if planes and ty != 'T_Q80' else ''}, {glu}, {pro}>"
+    # (planes: the launch streamed the decode copy of its weights — the plane-layout instantiation, csrc/mmvq_types.h; Q8_0 has none; rows that are not whole groups of
+    # 8 super-blocks (Qwen2-7B) run the short-group kernels T_Q*KS)
+    return f"k_mmvq_stream<mi355x::{ty}{('S' if short_rows else 'P') if planes and ty != 'T_Q80' else ''}, {glu}, {pro}>"
 
 
 def pmc_traffic(symbol, args):
@@ -476,7 +477,7 @@ def main():
     except Exception as e:
         roofline = {"error": str(e)}
     if roofline and "kernel" in roofline and args.pmc_traffic and rank == 0 and world == 1 and not os.environ.get("BENCH_PMC_CHILD"):
-        sym = _class_to_symbol(roofline["kernel"], args.np, planes=int(be.stat("decode_copy_launches")) > 0)
+        sym = _class_to_symbol(roofline["kernel"], args.np, planes=int(be.stat("decode_copy_launches")) > 0, short_rows=(hp.n_embd % 2048) != 0)
         if sym:
             torch.cuda.synchronize()
             tr, how = pmc_traffic(sym, args)

@@ -493,6 +493,12 @@ template <typename T, int NC, int R, bool GLU, int PRO, int WAVES> static void l
     hipLaunchKernelGGL((k_mmvq<T, NC, R, GLU, PRO, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
 }
 
+template <typename TP> static void launch_planes(hipStream_t s, const mmvq_args & ap, const bool glu) {
+    if (ap.fa_part) launch_stream<TP, false, 3>(s, ap);
+    else if (ap.x && ap.norm_w) { if (glu) launch_stream<TP, true, 2>(s, ap); else launch_stream<TP, false, 2>(s, ap); }
+    else if (ap.x) { if (glu) launch_stream<TP, true, 1>(s, ap); else launch_stream<TP, false, 1>(s, ap); }
+    else { if (glu) launch_stream<TP, true, 0>(s, ap); else launch_stream<TP, false, 0>(s, ap); }
+}
 template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a0, int rows_per_wave) {
     mmvq_args a = a0;
     const int nblk = a.K / T::BLK;
@@ -506,10 +512,8 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
             mmvq_args ap = a0;
             ap.W = a0.Wp;
             ap.W2 = glu ? a0.W2p : nullptr;
-            if (a0.fa_part) launch_stream<TP, false, 3>(s, ap);
-            else if (a0.x && a0.norm_w) { if (glu) launch_stream<TP, true, 2>(s, ap); else launch_stream<TP, false, 2>(s, ap); }
-            else if (a0.x) { if (glu) launch_stream<TP, true, 1>(s, ap); else launch_stream<TP, false, 1>(s, ap); }
-            else { if (glu) launch_stream<TP, true, 0>(s, ap); else launch_stream<TP, false, 0>(s, ap); }
+            if ((nblk & 7) == 0) launch_planes<TP>(s, ap, glu);
+            else launch_planes<typename plane_of<T>::short_type>(s, ap, glu);
             return;
         }
     }

@@ -255,10 +255,11 @@ struct T_Q80 {
 // (a row whose super-block count is not a multiple of 8 — Qwen2-7B: 14 and 74 — ends in a SHORT group of nb = nblk % 8 super-blocks with the same plane order,
 // 4 nb lanes wide; only its lines are shared between planes)
 __device__ __forceinline__ int plane_group_blocks(const int p, const int nblk) { return min(8, nblk - ((p >> 5) << 3)); }
-struct T_Q4KP : T_Q4K {
+// (WHOLE: every group has 8 super-blocks — the offsets are constants; the short-group forms are separate kernels, T_Q*KS, so Llama's launches pay nothing for them)
+template <bool WHOLE> struct T_Q4KP_t : T_Q4K {
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk) {
         const uint8_t * grp = row + (size_t) (p >> 5) * 1152;
-        const int nb = plane_group_blocks(p, nblk);
+        const int nb = WHOLE ? 8 : plane_group_blocks(p, nblk);
         raw r;
         r.hdr = ld_nt(grp + 16 * ((p >> 2) & 7));
         r.q0 = ld_nt(grp + 16 * nb + 16 * (p & 31));
@@ -266,10 +267,10 @@ struct T_Q4KP : T_Q4K {
         return r;
     }
 };
-struct T_Q5KP : T_Q5K {
+template <bool WHOLE> struct T_Q5KP_t : T_Q5K {
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk) {
         const uint8_t * grp = row + (size_t) (p >> 5) * 1408;
-        const int nb = plane_group_blocks(p, nblk), b8 = (p >> 2) & 7;
+        const int nb = WHOLE ? 8 : plane_group_blocks(p, nblk), b8 = (p >> 2) & 7;
         raw r;
         r.hdr = ld_nt(grp + 16 * b8);
         r.h0 = ld_nt(grp + 16 * nb + 16 * b8);
@@ -281,11 +282,11 @@ struct T_Q5KP : T_Q5K {
 };
 // (Q6_K rows are 210 nblk bytes: 16-byte aligned only when nblk is a multiple of 8 — the plane loads carry the format's 2-byte alignment, which gfx950 serves)
 __device__ __forceinline__ u128_a2 ld_nt_a2(const void * p) { return __builtin_bit_cast(u128_a2, __builtin_nontemporal_load((const mi_u32x4_a2 *) p)); }
-struct T_Q6KP : T_Q6K {
+template <bool WHOLE> struct T_Q6KP_t : T_Q6K {
     static __device__ __forceinline__ raw load(const uint8_t * __restrict__ row, int p, int nblk) {
         const uint8_t * grp = row + (size_t) (p >> 5) * 1536;
         const uint8_t * tail = row + (size_t) nblk * 192;
-        const int nb = plane_group_blocks(p, nblk), h = (p >> 1) & 1;
+        const int nb = WHOLE ? 8 : plane_group_blocks(p, nblk), h = (p >> 1) & 1;
         raw r;
         r.a = ld_nt_a2(grp + 16 * (p & 31));
         r.b = ld_nt_a2(grp + 64 * nb + 16 * (p & 31));
@@ -295,9 +296,15 @@ struct T_Q6KP : T_Q6K {
         return r;
     }
 };
-template <typename T> struct plane_of { typedef T type; };
-template <> struct plane_of<T_Q4K> { typedef T_Q4KP type; };
-template <> struct plane_of<T_Q5K> { typedef T_Q5KP type; };
-template <> struct plane_of<T_Q6K> { typedef T_Q6KP type; };
+struct T_Q4KP : T_Q4KP_t<true> {};
+struct T_Q5KP : T_Q5KP_t<true> {};
+struct T_Q6KP : T_Q6KP_t<true> {};
+struct T_Q4KS : T_Q4KP_t<false> {};  // rows with a short last group (K % 2048 != 0)
+struct T_Q5KS : T_Q5KP_t<false> {};
+struct T_Q6KS : T_Q6KP_t<false> {};
+template <typename T> struct plane_of { typedef T type; typedef T short_type; };
+template <> struct plane_of<T_Q4K> { typedef T_Q4KP type; typedef T_Q4KS short_type; };
+template <> struct plane_of<T_Q5K> { typedef T_Q5KP type; typedef T_Q5KS short_type; };
+template <> struct plane_of<T_Q6K> { typedef T_Q6KP type; typedef T_Q6KS short_type; };
 
 }  // namespace mi355x

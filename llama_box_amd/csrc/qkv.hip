@@ -358,7 +358,7 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     do {                                                                                                      \
         if (q8_store) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, true>), GRID, block, lds, s, a);              \
         else if (pipe) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false, true>), GRID, block, lds, s, a);      \
-        else if constexpr (std::is_same<TA, T_Q5K>::value || std::is_same<TB, T_Q5K>::value || std::is_same<TA, T_Q5KP>::value || std::is_same<TB, T_Q5KP>::value) { \
+        else if constexpr (std::is_same<TA, T_Q5K>::value || std::is_same<TB, T_Q5K>::value || std::is_same<TA, T_Q5KP>::value || std::is_same<TB, T_Q5KP>::value || std::is_same<TA, T_Q5KS>::value || std::is_same<TB, T_Q5KS>::value) { \
             if (small_wg) hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false, false, 640>), GRID, block, lds, s, a); \
             else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                  \
         } else if constexpr (!std::is_same<TA, TB>::value) {  /* Q4_K + Q6_K: Llama-3-8B's launches use 12 waves (the 768-thread build: 170 registers, no scratch) */ \
@@ -366,13 +366,17 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
             else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                  \
         } else hipLaunchKernelGGL((k_qkv_stream2<TA, TB, false>), GRID, block, lds, s, a);                    \
     } while (0)
-    const bool planes = a.planes != 0 && (a.K % 256) == 0 && type_a != GGML_TYPE_Q8_0;  // every segment's W is its decode copy (graph.cpp made sure): the plane forms
+    const bool planes = a.planes != 0 && (a.K % 2048) == 0 && type_a != GGML_TYPE_Q8_0;
+    const bool planes_s = a.planes != 0 && !planes && (a.K % 256) == 0 && type_a != GGML_TYPE_Q8_0;  // rows with a short last group: the T_Q*KS forms  // every segment's W is its decode copy (graph.cpp made sure): the plane forms
     if (type_a == type_b || units[1] == 0) {
         const unsigned grid = (unsigned) std::min(256, (units[0] + nw - 1) / nw);
         a.wg_a = (int) grid;
         if (planes && type_a == GGML_TYPE_Q4_K) QKV_LAUNCH(T_Q4KP, T_Q4KP, dim3(grid));
+        else if (planes_s && type_a == GGML_TYPE_Q4_K) QKV_LAUNCH(T_Q4KS, T_Q4KS, dim3(grid));
         else if (planes && type_a == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q5KP, T_Q5KP, dim3(grid));
+        else if (planes_s && type_a == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q5KS, T_Q5KS, dim3(grid));
         else if (planes && type_a == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q6KP, T_Q6KP, dim3(grid));
+        else if (planes_s && type_a == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q6KS, T_Q6KS, dim3(grid));
         else if (type_a == GGML_TYPE_Q4_K) QKV_LAUNCH(T_Q4K, T_Q4K, dim3(grid));
         else if (type_a == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q5K, T_Q5K, dim3(grid));
         else if (type_a == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q6K, T_Q6K, dim3(grid));
@@ -389,8 +393,11 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
         a.wv_a = total_units <= waves ? units[0] : std::max(1, std::min(waves - 1, (int) ((double) waves * bytes[0] / (bytes[0] + bytes[1]) + 0.5)));
         const dim3 grid_w((unsigned) g);
         if (planes && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4KP, T_Q6KP, grid_w);
+        else if (planes_s && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4KS, T_Q6KS, grid_w);
         else if (planes && type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5KP, T_Q6KP, grid_w);
+        else if (planes_s && type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5KS, T_Q6KS, grid_w);
         else if (planes && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4KP, T_Q5KP, grid_w);
+        else if (planes_s && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4KS, T_Q5KS, grid_w);
         else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4K, T_Q6K, grid_w);
         else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5K, T_Q6K, grid_w);
         else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4K, T_Q5K, grid_w);
@@ -406,8 +413,11 @@ void launch_qkv(hipStream_t s, const qkv_args & a0, int type_a, int type_b) {
     a.wg_a = ga;
     const dim3 grid((unsigned) (ga + gb));
     if (planes && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4KP, T_Q6KP, grid);
+    else if (planes_s && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4KS, T_Q6KS, grid);
     else if (planes && type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5KP, T_Q6KP, grid);
+    else if (planes_s && type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5KS, T_Q6KS, grid);
     else if (planes && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4KP, T_Q5KP, grid);
+    else if (planes_s && type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4KS, T_Q5KS, grid);
     else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q4K, T_Q6K, grid);
     else if (type_a == GGML_TYPE_Q5_K && type_b == GGML_TYPE_Q6_K) QKV_LAUNCH(T_Q5K, T_Q6K, grid);
     else if (type_a == GGML_TYPE_Q4_K && type_b == GGML_TYPE_Q5_K) QKV_LAUNCH(T_Q4K, T_Q5K, grid);

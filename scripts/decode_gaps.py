@@ -7,7 +7,7 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-ends = [i for i, r in enumerate(rows) if ("T_Q6K, false, 2>" in r[2] or "T_Q6KP, false, 2>" in r[2])]
+ends = [i for i, r in enumerate(rows) if ("T_Q6K, false, 2>" in r[2] or "T_Q6KP, false, 2>" in r[2] or "T_Q6KS, false, 2>" in r[2])]
 steps = []
 for a, b in zip(ends[:-1], ends[1:]):
     st = rows[a + 1:b + 1]
