@@ -361,7 +361,7 @@ def main():
         pos += args.warmup
         g0 = be.stat("graph_launches")
         gl0 = be.stat("graph_launch_host_ns")
-        host0 = {k: be.stat(k) for k in ("graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs")}
+        host0 = {k: be.stat(k) for k in ("graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs", "graph_shadow_captures", "graph_capture_walk_ns", "graph_exec_update_ns", "graph_shadow_eager_ns")}
         sync()
         t0 = time.perf_counter()
         steps(args.steps)
@@ -383,7 +383,13 @@ def main():
                            # steps that were NOT replays (a -np engine outgrows its 256-cell cache view every few steps): captured at first sighting / of those,
                            # patched into the previous executable graph / run eagerly
                            "captures": int(be.stat("graph_captures") - host0["graph_captures"]), "captures_at_first_sighting": int(be.stat("graph_early_captures") - host0["graph_early_captures"]),
-                           "executable_graph_updates": int(be.stat("graph_exec_updates") - host0["graph_exec_updates"]), "eager_steps": int(be.stat("eager_graphs") - host0["eager_graphs"])})
+                           "executable_graph_updates": int(be.stat("graph_exec_updates") - host0["graph_exec_updates"]), "eager_steps": int(be.stat("eager_graphs") - host0["eager_graphs"]),
+                           # round 6: a capture at first sighting runs behind the step's own eager launches; host time per capture of the walk into the capture, of
+                           # hipGraphExecUpdate / instantiate, and of the eager walk in front of it
+                           "captures_in_the_shadow_of_the_step": int(be.stat("graph_shadow_captures") - host0["graph_shadow_captures"]),
+                           "capture_walk_us": round((be.stat("graph_capture_walk_ns") - host0["graph_capture_walk_ns"]) / 1e3 / max(1, be.stat("graph_captures") - host0["graph_captures"]), 1),
+                           "exec_update_us": round((be.stat("graph_exec_update_ns") - host0["graph_exec_update_ns"]) / 1e3 / max(1, be.stat("graph_captures") - host0["graph_captures"]), 1),
+                           "shadow_eager_walk_us": round((be.stat("graph_shadow_eager_ns") - host0["graph_shadow_eager_ns"]) / 1e3 / max(1, be.stat("graph_shadow_captures") - host0["graph_shadow_captures"]), 1)})
         return el, gs, (be.stat("graph_launch_host_ns") - gl0) / 1e3 / max(1, gs)
 
     def headline(el, extra_note=""):  # the contract's fields for a K-step time (everything else is added to it below)

@@ -833,6 +833,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "small_downloads") c->opt.small_downloads = v != 0;
     else if (k == "timing") c->opt.timing = v != 0;
     else if (k == "exec_update") c->opt.exec_update = v;
+    else if (k == "shadow_capture") c->opt.shadow_capture = v;
     else if (k == "decode_copy") c->opt.decode_copy = v != 0;
     else if (k == "decode_copy_headroom_gib") c->opt.decode_copy_headroom_gib = v;
     else if (k == "clear_failure") { if (v) clear_hip_failure(); }
@@ -874,6 +875,10 @@ static int64_t api_get_stat(ggml_backend_t be, const char * key) {
     if (k == "graph_key_fast_hits") return c->st.graph_key_fast_hits;
     if (k == "graph_key_collisions") return c->st.graph_key_collisions;
     if (k == "graph_early_captures") return c->st.graph_early_captures;
+    if (k == "graph_shadow_captures") return c->st.graph_shadow_captures;
+    if (k == "graph_capture_walk_ns") return c->st.graph_capture_walk_ns;
+    if (k == "graph_exec_update_ns") return c->st.graph_exec_update_ns;
+    if (k == "graph_shadow_eager_ns") return c->st.graph_shadow_eager_ns;
     if (k == "graph_exec_updates") return c->st.graph_exec_updates;
     if (k == "skinny_launches") return c->st.skinny_launches;
     if (k == "wide_launches") return c->st.wide_launches;

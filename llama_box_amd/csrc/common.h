@@ -136,6 +136,7 @@ struct options {
     int decode_copy_headroom_gib = 2;  // a buffer's decode copy is made only while this much device memory stays free beside it (tests raise it to force the fallback)
     bool decode_copy = [] { const char * e = getenv("GGML_MI355X_DECODE_COPY"); return e ? atoi(e) != 0 : true; }();  // batch-1 mat-vecs read the plane-layout copy of their weights
     int exec_update = [] { const char * e = getenv("GGML_MI355X_EXEC_UPDATE"); return e ? atoi(e) : 1; }();  // patch the predecessor's executable graph at a capture at
+    int shadow_capture = [] { const char * e = getenv("GGML_MI355X_SHADOW_CAPTURE"); return e ? atoi(e) : 1; }();  // a capture at first sighting runs BEHIND the step's own eager launches
                                // first sighting (graph.cpp); 2 = run the update and treat it as failed (tests)
 };
 
@@ -157,6 +158,8 @@ struct stats {
     int64_t kv_image_nodes = 0;        // FLASH_ATTN_EXT nodes whose K / V (kept in q4_0, q4_1, q5_0, q5_1, iq4_nl, bf16, f32 ...) were read through an f16 image
     int64_t kernel_downloads = 0;      // get_tensor_async calls served by a copy kernel writing mapped pinned memory
     int64_t graph_early_captures = 0;  // graphs captured at their FIRST sighting (same step as the one replayed last, over a grown cache)
+    int64_t graph_shadow_captures = 0; // ... of which the capture ran behind the step's own eager launches (the GPU busy meanwhile) and serves the NEXT step
+    int64_t graph_capture_walk_ns = 0, graph_exec_update_ns = 0, graph_shadow_eager_ns = 0;  // host time of: the walk into a capture (begin..end), hipGraphExecUpdate / instantiate, a shadow capture's eager walk
     int64_t graph_exec_updates = 0;    // ... of them, served by patching the predecessor's executable graph (hipGraphExecUpdate) instead of instantiating
     int64_t decode_copy_tensors = 0;   // weight matrices repacked into the decode copy by this backend instance ...
     int64_t decode_copy_bytes = 0;     // ... and their bytes

@@ -2279,9 +2279,32 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         c->st.eager_graphs++;
         return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
     }
+    // A capture at first sighting happens IN THE SHADOW of the step (round 6): the step's kernels are launched eagerly first — the GPU starts at once and is
+    // ~3 ms behind the host for a -np 32 step — and the same walk is then repeated into a capture while they run (~1.2 ms of host-side launches + the
+    // executable graph's update, during which the GPU used to idle: profiles/r06_ab_shadow_capture.txt).  Nothing is launched from that capture now; it
+    // serves the NEXT step.  The second walk's counters are not launches and are taken back.
+    const bool shadow = early && c->opt.shadow_capture != 0;
+    auto now_ns = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    int64_t t_mark = now_ns();
+    if (shadow && !run_nodes(c, g, wp)) return GGML_STATUS_FAILED;
+    if (shadow) c->st.graph_shadow_eager_ns += now_ns() - t_mark;
+    const stats st_step = c->st;
+    struct shadow_stats {  // (every exit below: the counters of the step as it ran, plus what the capture itself counts)
+        backend_ctx * c; const stats & keep; bool on;
+        ~shadow_stats() {
+            if (!on) return;
+            stats s = keep;
+            s.graph_captures = c->st.graph_captures; s.graph_early_captures = c->st.graph_early_captures; s.graph_shadow_captures = c->st.graph_shadow_captures;
+            s.graph_exec_updates = c->st.graph_exec_updates; s.graph_exec_update_failures = c->st.graph_exec_update_failures; s.graph_evictions = c->st.graph_evictions;
+            s.graph_capture_walk_ns = c->st.graph_capture_walk_ns; s.graph_exec_update_ns = c->st.graph_exec_update_ns;
+            c->st = s;
+        }
+    } shadow_guard{c, st_step, shadow};
     // second sighting: capture, instantiate, replay
+    t_mark = now_ns();
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
         (void) hipGetLastError();
+        if (shadow) { cg.early_failed = true; return GGML_STATUS_SUCCESS; }
         c->st.eager_graphs++;
         return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
     }
@@ -2292,9 +2315,12 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     const int64_t red_captured = c->st.allreduces - red0;
     hipGraph_t graph = nullptr;
     const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+    c->st.graph_capture_walk_ns += now_ns() - t_mark;
+    t_mark = now_ns();
     if (!ok || e_end != hipSuccess || graph == nullptr) {
         (void) hipGetLastError();
         if (graph) (void) hipGraphDestroy(graph);
+        if (shadow) { cg.early_failed = true; return GGML_STATUS_SUCCESS; }  // (the step has run; its next sighting is captured by the ordinary rule)
         if (early) {  // (the shortcut did not work for this graph: back to the ordinary rule, the next sighting tries again)
             cg.early_failed = true;
             c->st.eager_graphs++;
@@ -2334,14 +2360,20 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         (void) hipGetLastError();
         (void) hipGraphDestroy(graph);
         cg.seen = 1000001;
+        if (shadow) return GGML_STATUS_SUCCESS;
         c->st.eager_graphs++;
         return run_nodes(c, g, wp) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
     }
+    c->st.graph_exec_update_ns += now_ns() - t_mark;
     cg.graph = graph;
     cg.exec = exec;
     cg.allreduces = red_captured;
     c->st.graph_captures++;
     c->st.graph_early_captures += early ? 1 : 0;
+    if (shadow) {  // the step is already running; the executable graph waits for the next one
+        c->st.graph_shadow_captures++;
+        return GGML_STATUS_SUCCESS;
+    }
     if (hipGraphLaunch(cg.exec, c->stream) != hipSuccess) {
         (void) hipGetLastError();
         return GGML_STATUS_FAILED;

@@ -242,12 +242,14 @@ def test_hipgraph_replay_is_bit_identical_to_eager(backend, H, plog):
     assert np.array_equal(outs[1][1].view(np.uint32), outs[0][1].view(np.uint32))
 
 
+@pytest.mark.parametrize("shadow", [1, 0], ids=["shadow-capture", "capture-then-launch"])
 @pytest.mark.parametrize("fa", [1, 0])
-def test_a_grown_cache_is_captured_at_first_sighting_and_patched_into_the_previous_executable_graph(backend, H, plog, fa):
+def test_a_grown_cache_is_captured_at_first_sighting_and_patched_into_the_previous_executable_graph(backend, H, plog, fa, shadow):
     """Round 5: a continuous-batching engine (8 sequences here) moves to the next 256-cell step of its cache view every few decode steps; the graph of
     the new extent is the same step as the one replayed last, so it is captured at its FIRST sighting (stat graph_early_captures) and, where the
     kernels are the same, the predecessor's executable graph is patched with the new parameters instead of instantiated anew (graph_exec_updates).
-    Same logits, bit for bit, as eager execution across four such boundaries."""
+    Same logits, bit for bit, as eager execution across four such boundaries.  Round 6 (option shadow_capture, on by default): the step of the new extent is
+    launched eagerly FIRST and captured behind its own launches, for the next step (stat graph_shadow_captures; the second walk counts no launches)."""
     hp = preset("test-llama", n_head=4, n_head_kv=2, n_embd=512, n_embd_head=128)
     mg = Model(hp, 31, backend.buft)
     n_par, n_steps, n_prompt = 8, 120, 24
@@ -258,10 +260,11 @@ def test_a_grown_cache_is_captured_at_first_sighting_and_patched_into_the_previo
     try:
         for mode in (1, 0):
             backend.set_option("graphs", mode)
+            backend.set_option("shadow_capture", shadow)
             c = Context(mg, backend=backend, flash_attn=fa, n_ctx=2048)
             rc, _ = c.decode(toks, [i for _ in range(n_par) for i in range(n_prompt)], [k for k in range(n_par) for _ in range(n_prompt)], ([0] * (n_prompt - 1) + [1]) * n_par)
             assert rc == 0
-            s0 = {k: backend.stat(k) for k in ("graph_launches", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs")}
+            s0 = {k: backend.stat(k) for k in ("graph_launches", "graph_captures", "graph_early_captures", "graph_shadow_captures", "graph_exec_updates", "eager_graphs", "kernel_launches")}
             lg = []
             for i in range(n_steps):
                 rc, l1 = c.decode(rows[i], [n_prompt + i] * n_par, seq=list(range(n_par)))
@@ -271,9 +274,13 @@ def test_a_grown_cache_is_captured_at_first_sighting_and_patched_into_the_previo
             c.free()
     finally:
         backend.set_option("graphs", 1)
+        backend.set_option("shadow_capture", 1)
         mg.free()
     st = outs[1][1]
-    plog(f"grown-cache capture (fa={fa}): {n_steps} steps of {n_par} sequences: {st}")
+    plog(f"grown-cache capture (fa={fa}, shadow={shadow}): {n_steps} steps of {n_par} sequences: {st}")
+    assert (st["graph_shadow_captures"] == st["graph_early_captures"]) if shadow else st["graph_shadow_captures"] == 0, st
+    # every step is exactly one of: a replay, an eager run, or an eager run with its capture behind it
+    assert st["graph_launches"] + st["eager_graphs"] + st["graph_shadow_captures"] == n_steps, st
     # 8 cells per step from 192: the 256-cell view is outgrown after 8 steps, then every 32 steps: four new extents in 120 steps
     assert st["graph_captures"] >= 4 and st["graph_early_captures"] >= 3 and st["eager_graphs"] <= 2, st
     assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
