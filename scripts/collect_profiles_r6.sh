@@ -11,7 +11,11 @@ rm -rf gpurun_out/prof
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench --output-format csv -- python bench.py --no-cpu-baseline --pmc-traffic 0 > $O/bench_under_rocprof.json 2> $O/prof.err; echo "rocprof rc=$?"
 f=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1)
 python scripts/trace_stats.py $f > $O/bench_kernel_stats.csv; head -n 14 $O/bench_kernel_stats.csv | cut -c1-150
-python scripts/decode_gaps.py $f > $O/decode_gaps.txt; tail -12 $O/decode_gaps.txt
+# (the replayed-step timeline needs a trace WITHOUT the eager per-launch timing pass at its end: decode_gaps.py reads the last 16 steps)
+rm -rf gpurun_out/prof_gaps
+timeout 600 rocprofv3 --kernel-trace -d gpurun_out/prof_gaps -o bench --output-format csv -- python bench.py --no-cpu-baseline --pmc-traffic 0 --timing-steps 0 > /dev/null 2>> $O/prof.err
+python scripts/decode_gaps.py $(find gpurun_out/prof_gaps -name "*kernel_trace.csv" | head -1) > $O/decode_gaps.txt; tail -12 $O/decode_gaps.txt
+rm -rf gpurun_out/prof_gaps
 find gpurun_out/prof -size +8M -delete
 PMC_GROUPS="FETCH_SIZE;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA;SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \
   BENCH_ARGS="--steps 16 --warmup 2 --prefill 2048 --timing-steps 0 --no-cpu-baseline --pmc-traffic 0" TOPN=40 bash scripts/prof_pmc.sh > $O/pmc_passes.txt 2>&1
