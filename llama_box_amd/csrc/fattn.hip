@@ -397,14 +397,18 @@ __device__ unsigned long long g_fa_stamps[1024][8];
 // loads fly) and expands them to packed f16 where the f16 cache's values are consumed (byte permutes + one packed subtract + one packed multiply);
 // everything else is the f16 path.  Same values as the f16 image of kv_types.hip (q4_0 / q5_0: bit for bit; the offset formats within half an ulp),
 // without its pass over the cache.  A first form with the type as a RUN-TIME switch (any pair of types) lost to the image: 29 us against 12.8 + 9.2.
-template <int G, int MODE, bool Q8, int WV = 4, int KVT = 0>
+// D = 64 (round 6: TinyLlama, Llama-3.2-1B ...; f16 cache, no Q8_K output, records + combine pass): a K / V row is EIGHT lanes, a wave-instruction fetches eight
+// rows, the (row group, head) pairs of a row are 8 = NG * G; everything else is the head_dim-128 kernel — its 16-lane transpose-reduce minus the first stage,
+// probabilities broadcast per 8-lane half of a DPP row, the two halves' accumulators added before the rows meet.
+template <int G, int MODE, bool Q8, int WV = 4, int KVT = 0, int D = 128>
 __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const tdesc k, const tdesc v, const tdesc mask, const float * __restrict__ sinks,
                                                       const tdesc dst, const fa_geom geo, float * __restrict__ ws, const int g_real,
                                                       const int * __restrict__ lists, const int list_stride) {
     constexpr bool SKIP = MODE == 1, LIST = MODE == 2;
-    constexpr int D = 128, NG = 16 / G;
+    constexpr int LPR = D / 8, RPW = 64 / LPR, NG = LPR / G;  // lanes per K / V row, rows per wave-instruction, row groups per trip
+    static_assert(D == 128 || (D == 64 && !Q8 && KVT == 0 && G <= 8), "head_dim 64: f16 cache only");
     constexpr float LOG2E = 1.4426950408889634f;
-    constexpr int TRIP = NG * WV * 4;  // positions per trip
+    constexpr int TRIP = NG * WV * RPW;  // positions per trip
     // KVT == BF16 (round 6): a bf16 cache has the f16 cache's geometry (a lane's 16 bytes are its eight values), so only the arithmetic differs: as ggml-cpu's
     // ggml_vec_dot_bf16 the query is rounded to bf16 and multiplied with K's values in f32 (a value is its 16 bits shifted up), V accumulates in f32 (to_float)
     constexpr bool BF = KVT == GGML_TYPE_BF16;
@@ -417,7 +421,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     __shared__ float sh[WV][G][D + 2];
     __shared__ float qv[FAT ? 1 : G * D];  // one pass, Q8_K output: the normalised heads of this kv group before quantisation
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = lane >> 4, sl = lane & 15;
+    const int sub = lane / LPR, sl = lane & (LPR - 1);
     const int ul = sl / G, gl = sl % G;  // the (row group, head) pair this lane owns in the lane-parallel part
     const int split = blockIdx.x, kvh = blockIdx.y;
     // SKIP (a few query tokens, each seeing its own part of a unified cache): the workgroup first asks the mask whether its
@@ -440,7 +444,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     int nidx[NG];
     int first = 0;
 #define FA_LIST_AHEAD(base)                                                                                         \
-    _Pragma("unroll") for (int u = 0; u < NG; ++u) nidx[u] = tl[min((base) + u * (WV * 4) + wave * 4 + sub, geo.n_kv - 1)];
+    _Pragma("unroll") for (int u = 0; u < NG; ++u) nidx[u] = tl[min((base) + u * (WV * RPW) + wave * RPW + sub, geo.n_kv - 1)];
     if constexpr (LIST) {
         const int * lt = lists + (int64_t) tok * list_stride;
         tl = lt + 1;
@@ -453,14 +457,14 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         if (ti >= ti1) {
             if (geo.n_splits == 1) {
                 // a token that sees nothing and no combine pass to say so: the CPU's result for such a row is 0 * (1 / 0) = NaN
-                for (int e = tid; e < g_real * 128; e += WV * 64) {
-                    float * out = (float *) (dst.data + (int64_t) (kvh * g_real + e / 128) * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
-                    out[e % 128] = __builtin_nanf("");
+                for (int e = tid; e < g_real * D; e += WV * 64) {
+                    float * out = (float *) (dst.data + (int64_t) (kvh * g_real + e / D) * dst.nb[1] + (int64_t) tok * dst.nb[2] + (int64_t) bat * dst.nb[3]);
+                    out[e % D] = __builtin_nanf("");
                 }
             } else if (tid < g_real) {
-                float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + kvh * g_real + tid) * geo.n_splits + split) * (128 + 2);
-                if (geo.arrive) { st_agent(rec + 128, -INFINITY); st_agent(rec + 129, 0.0f); }
-                else { rec[128] = -INFINITY; rec[129] = 0.0f; }
+                float * rec = ws + ((((int64_t) bat * geo.n_q + tok) * geo.n_head + kvh * g_real + tid) * geo.n_splits + split) * (D + 2);
+                if (geo.arrive) { st_agent(rec + D, -INFINITY); st_agent(rec + D + 1, 0.0f); }
+                else { rec[D] = -INFINITY; rec[D + 1] = 0.0f; }
             }
             if (geo.n_splits == 1 || !geo.arrive) return;
             empty = true;  // (still has to arrive: it may be the workgroup that merges the records)
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
 #define FA_LOAD_TRIP()                                                                  \
     {                                                                                   \
         _Pragma("unroll") for (int u = 0; u < NG; ++u) {                               \
-            const int pr_ = p0 + u * (WV * 4) + wave * 4 + sub;                         \
+            const int pr_ = p0 + u * (WV * RPW) + wave * RPW + sub;                     \
             const int pc = LIST ? (pr_ < kv1 ? nidx[u] : first) : min(pr_, kv1 - 1);    \
             const char * kp_ = kbase + (int64_t) pc * k.nb[1];                          \
             const char * vp_ = vbase + (int64_t) pc * v.nb[1];                          \
@@ -517,7 +521,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
                 vraw[u] = *(const uint4 *) vp_;                                         \
             }                                                                           \
         }                                                                               \
-        const int pl = p0 + ul * (WV * 4) + wave * 4 + sub;                             \
+        const int pl = p0 + ul * (WV * RPW) + wave * RPW + sub;                         \
         okl = pl < kv1;                                                                 \
         int plc_ = min(pl, kv1 - 1);                                                    \
         if constexpr (LIST) {                                                           \
@@ -536,7 +540,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             uint16_t mraw[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int pl = kv0 + (i0 + i) * TRIP + ul * (WV * 4) + wave * 4 + sub;
+                const int pl = kv0 + (i0 + i) * TRIP + ul * (WV * RPW) + wave * RPW + sub;
                 mraw[i] = (i0 + i < ntrips && pl < kv1) ? (mp ? mp[pl] : (uint16_t) 0) : (uint16_t) 0xFC00;
             }
 #pragma unroll
@@ -631,7 +635,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
             }
         }
         // ---- partial dots of this lane's 8 dims for the 16 (u, g) pairs
-        float t[16];
+        float t[LPR];
         float vf[NG][8];
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
@@ -714,8 +718,12 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         float w8[8], w4[4], w2[2];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float keep = b3 ? t[j + 8] : t[j], send = b3 ? t[j] : t[j + 8];
-            w8[j] = keep + dpp_f32<MI_DPP_ROR8>(send);
+            if constexpr (LPR == 16) {
+                const float keep = b3 ? t[j + 8] : t[j], send = b3 ? t[j] : t[j + 8];
+                w8[j] = keep + dpp_f32<MI_DPP_ROR8>(send);
+            } else {
+                w8[j] = t[j];  // (a row is eight lanes: the reduce starts at its second stage)
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -758,8 +766,20 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
         const float pj_ = dpp_f32<MI_DPP_NEWBCAST((j))>(pe);                                \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[(j) % G][i] = fmaf(pj_, vf[(j) / G][i], acc[(j) % G][i]); \
     }
-        FA_PAIR(0) FA_PAIR(1) FA_PAIR(2) FA_PAIR(3) FA_PAIR(4) FA_PAIR(5) FA_PAIR(6) FA_PAIR(7)
-        FA_PAIR(8) FA_PAIR(9) FA_PAIR(10) FA_PAIR(11) FA_PAIR(12) FA_PAIR(13) FA_PAIR(14) FA_PAIR(15)
+        // (eight-lane rows: a DPP row of 16 lanes holds two K / V rows, pair j's probability sits in lane j of each HALF)
+#define FA_PAIR8(j)                                                                         \
+    {                                                                                       \
+        const float pa_ = dpp_f32<MI_DPP_NEWBCAST((j))>(pe), pb_ = dpp_f32<MI_DPP_NEWBCAST((j) + 8)>(pe); \
+        const float pj_ = (lane & 8) ? pb_ : pa_;                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[(j) % G][i] = fmaf(pj_, vf[(j) / G][i], acc[(j) % G][i]); \
+    }
+        if constexpr (LPR == 16) {
+            FA_PAIR(0) FA_PAIR(1) FA_PAIR(2) FA_PAIR(3) FA_PAIR(4) FA_PAIR(5) FA_PAIR(6) FA_PAIR(7)
+            FA_PAIR(8) FA_PAIR(9) FA_PAIR(10) FA_PAIR(11) FA_PAIR(12) FA_PAIR(13) FA_PAIR(14) FA_PAIR(15)
+        } else {
+            FA_PAIR8(0) FA_PAIR8(1) FA_PAIR8(2) FA_PAIR8(3) FA_PAIR8(4) FA_PAIR8(5) FA_PAIR8(6) FA_PAIR8(7)
+        }
+#undef FA_PAIR8
 #undef FA_PAIR
     }
 #undef FA_LOAD_TRIP
@@ -775,13 +795,19 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     l = xrow_allsum(l);
     // ---- accumulators: the four rows add up; pair-wise swaps reduce four values per register, row r of register kk
     //      ends with the total of value 4*kk + r (value index = g*8 + i)
+    if constexpr (LPR == 8) {  // the two K / V rows of a DPP row first (both halves end with the sum; they store the same values below)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[g][i] += dpp_f32<MI_DPP_ROR8>(acc[g][i]);
+    }
 #pragma unroll
     for (int kk = 0; kk < 2 * G; ++kk) {
         const int g = (4 * kk) / 8, i0 = (4 * kk) % 8;
         const float y1 = swap32_pairsum(acc[g][i0], acc[g][i0 + 2]);
         const float y2 = swap32_pairsum(acc[g][i0 + 1], acc[g][i0 + 3]);
         const float z = swap16_pairsum(y1, y2);
-        sh[wave][g][sl * 8 + i0 + sub] = z;
+        sh[wave][g][sl * 8 + i0 + (lane >> 4)] = z;
     }
     if (sub == 0 && ul == 0) {
         sh[wave][gl][D] = m;
@@ -852,6 +878,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
     }
     FA_STAMP_AT(6)
     }  // !empty
+    if constexpr (D == 128)
     if (geo.merge2) {
         // ---- merge2: our record went out with 8-byte agent-scope (write-through) stores; once they have completed (vmcnt 0 in every storing
         // wave, then the barrier) the arrival is counted, and the workgroup that finds n_splits - 1 arrivals before it merges all records
@@ -872,7 +899,7 @@ __global__ void __launch_bounds__(WV * 64) k_fattn_dec128(const tdesc q, const t
                   WV * 64);
         return;
     }
-    if constexpr (!FAT) {
+    if constexpr (!FAT && D == 128) {
         if (geo.n_splits == 1 && geo.q8) {
             // one pass and the readers are quantised mat-muls: quantize_row_q8_K of head pairs, as k_quantize_q8_K does it
             __syncthreads();
@@ -1368,6 +1395,38 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     if (q8) {
         MI_ERR("launch_flash_attn: q8_0 K/V reached the generic kernel (head_dim %d, group %d) — supports_op should have refused it", D, G);
         abort();
+    }
+    // one decode token at head_dim 64 over an f16 cache (round 6): the lane-parallel kernel in its eight-lane-row form, records + combine pass
+    // (generic kernel: 14.9 us per layer for TinyLlama at a 600-cell context; profiles/r06_secondary_kernel_stats.txt)
+    static const bool dec64_on = !getenv("GGML_MI355X_FA_DEC64") || atoi(getenv("GGML_MI355X_FA_DEC64")) != 0;
+    if (dec64_on && D == 64 && k.type == GGML_TYPE_F16 && v.type == GGML_TYPE_F16 && geo.n_q == 1 && p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 4 || G == 8) && !p.lists &&
+        (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 && ((uintptr_t) q.data & 15) == 0 && (k.nb[1] % 16) == 0 && (v.nb[1] % 16) == 0 && (k.nb[2] % 16) == 0 && (v.nb[2] % 16) == 0 &&
+        ((uintptr_t) k.data & 15) == 0 && ((uintptr_t) v.data & 15) == 0 && p.q8_out == nullptr) {
+        geo.arrive = nullptr;
+        geo.merge2 = 0;
+        geo.q8 = nullptr;
+        geo.per = (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
+        const tdesc q0 = q, k0 = k, v0 = v, mk0 = mk, dst0 = dst;
+        const dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, 1u);
+        const bool wide = geo.n_splits > 1;  // (eight waves: a trip covers 64 / 128 cells)
+        for (int64_t b = 0; b < q0.ne[3]; ++b) {  // one launch per batch slice: the kernel has no batch arithmetic
+            tdesc qb = q0, kb = k0, vb = v0, mb = mk0, db = dst0;
+            qb.data += b * q0.nb[3];
+            kb.data += (b / (q0.ne[3] / k0.ne[3])) * k0.nb[3];
+            vb.data += (b / (q0.ne[3] / v0.ne[3])) * v0.nb[3];
+            if (mask) mb.data += (b % mk0.ne[3]) * mk0.nb[3];
+            db.data += b * dst0.nb[3];
+            float * wsb = ws + b * geo.n_head * geo.n_splits * geo.rec_stride;
+            if (G == 4) {
+                if (wide) hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 8, 0, 64>), grid, dim3(512), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
+                else hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
+            } else {
+                if (wide) hipLaunchKernelGGL((k_fattn_dec128<8, 0, false, 8, 0, 64>), grid, dim3(512), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
+                else hipLaunchKernelGGL((k_fattn_dec128<8, 0, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
+            }
+        }
+        if (geo.n_splits > 1) launch_flash_attn_combine(s, 64, ws, sinks, dst, geo.n_q, geo.n_head, (int) q.ne[3], geo.n_splits, nullptr);
+        return;
     }
 #define FA_CASE(DD, GG) \
     if (D == DD && G == GG) { launch_fa<DD, GG>(s, q, k, v, mk, sinks, dst, geo, ws); return; }

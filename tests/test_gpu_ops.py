@@ -743,6 +743,14 @@ FA_CASES = [  # (HD, NH, NKV, n_q, n_kv, splits, softcap, alibi, sinks)
     (128, 32, 8, 3, 1000, 3, 0.0, 0.0, True),
     (128, 28, 4, 2, 1024, 5, 0.0, 0.0, False),
     (128, 16, 2, 4, 300, 1, 0.0, 0.0, True),
+    # the same kernel on head_dim 64 (eight-lane K / V rows; G = 4 / 8; TinyLlama, Llama-3.2-1B shapes): one split on four waves, several on eight, ragged ends, sinks
+    (64, 32, 4, 1, 600, 1, 0.0, 0.0, False),
+    (64, 32, 4, 1, 2048, 5, 0.0, 0.0, True),
+    (64, 32, 4, 1, 4096, 0, 0.0, 0.0, False),
+    (64, 32, 8, 1, 1000, 3, 0.0, 0.0, False),
+    (64, 16, 4, 1, 300, 1, 0.0, 0.0, True),
+    (64, 32, 8, 1, 3072, 0, 0.0, 0.0, False),  # (longer random caches leave the 1e-4 gate on the ORACLE side: its f16 V accumulator, 1.7e-4 at 8192 cells with either kernel)
+    (64, 8, 2, 1, 68, 2, 0.0, 0.0, False),
     # >= 32 query tokens: the matrix-core kernel (fattn_mma.hip); ragged query tiles, fully-masked KV tiles, KV tails
     (128, 32, 8, 64, 512, 0, 0.0, 0.0, False),
     (128, 8, 2, 200, 256, 0, 0.0, 0.0, False),
