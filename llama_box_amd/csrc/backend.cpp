@@ -834,6 +834,7 @@ static int api_set_option(ggml_backend_t be, const char * key, const char * valu
     else if (k == "timing") c->opt.timing = v != 0;
     else if (k == "exec_update") c->opt.exec_update = v;
     else if (k == "shadow_capture") c->opt.shadow_capture = v;
+    else if (k == "q80_min_cols") c->opt.q80_min_cols = v;
     else if (k == "decode_copy") c->opt.decode_copy = v != 0;
     else if (k == "decode_copy_headroom_gib") c->opt.decode_copy_headroom_gib = v;
     else if (k == "clear_failure") { if (v) clear_hip_failure(); }

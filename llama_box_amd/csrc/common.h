@@ -137,6 +137,7 @@ struct options {
     bool decode_copy = [] { const char * e = getenv("GGML_MI355X_DECODE_COPY"); return e ? atoi(e) != 0 : true; }();  // batch-1 mat-vecs read the plane-layout copy of their weights
     int exec_update = [] { const char * e = getenv("GGML_MI355X_EXEC_UPDATE"); return e ? atoi(e) : 1; }();  // patch the predecessor's executable graph at a capture at
     int shadow_capture = [] { const char * e = getenv("GGML_MI355X_SHADOW_CAPTURE"); return e ? atoi(e) : 1; }();  // a capture at first sighting runs BEHIND the step's own eager launches
+    int q80_min_cols = [] { const char * e = getenv("GGML_MI355X_Q80_MIN_COLS"); return e ? atoi(e) : 33; }();  // Q8_0 weights: batches of at least this many columns take the matrix-core GEMM (mmq_q80.hip), smaller ones 8-column mat-vec passes
                                // first sighting (graph.cpp); 2 = run the update and treat it as failed (tests)
 };
 

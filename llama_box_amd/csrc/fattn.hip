@@ -1079,7 +1079,7 @@ bool fattn_prefers_lists(const tdesc & q, const tdesc * mask, int mask_sparse) {
 int fattn_pick_splits(const tdesc & q, const tdesc & k, const tdesc * mask, int mask_sparse) {
     if (q.ne[1] >= fattn_mma_min_q() && (k.ne[0] == 64 || k.ne[0] == 128) && !fattn_prefers_lists(q, mask, mask_sparse)) return fattn_mma_pick_splits(q, k);  // (soft-capped / ALiBi batches fall back to the generic kernel with this count)
     const int64_t n_kv = k.ne[1];
-    if (q.ne[1] > 1 && k.ne[0] == 128 && q.ne[3] == 1) {
+    if (q.ne[1] > 1 && (k.ne[0] == 128 || (k.ne[0] == 64 && k.type == GGML_TYPE_F16 && k.ne[2] > 0 && (q.ne[2] == 4 * k.ne[2] || q.ne[2] == 8 * k.ne[2]))) && q.ne[3] == 1) {
         // a few tokens at head_dim 128 (continuous-batching decode, speculative batches): the tile-list kernel — every split takes a
         // share of the token's VISIBLE tiles, so the count follows the number of (token, kv head) groups, not the cache size
         const int64_t groups = k.ne[2] * q.ne[1];
@@ -1217,7 +1217,8 @@ int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const 
     const int64_t n_q = q.ne[1];
     const int G = k.ne[2] > 0 ? (int) (q.ne[2] / k.ne[2]) : 0;
     static const bool on = !getenv("GGML_MI355X_FA_LIST") || atoi(getenv("GGML_MI355X_FA_LIST")) != 0;
-    if (!on || n_q < 2 || (n_q >= fattn_mma_min_q() && !fattn_prefers_lists(q, mask, p.mask_sparse)) || !mask || q.ne[3] != 1 || mask->ne[3] != 1 || k.ne[0] != 128) return 0;
+    const bool d64 = k.ne[0] == 64 && k.type == GGML_TYPE_F16 && (G == 4 || G == 8);  // (round 6: the eight-lane-row form of the kernel; fattn_q8_out_ok refuses head_dim 64, arrival counters are not used)
+    if (!on || n_q < 2 || (n_q >= fattn_mma_min_q() && !fattn_prefers_lists(q, mask, p.mask_sparse)) || !mask || q.ne[3] != 1 || mask->ne[3] != 1 || (k.ne[0] != 128 && !d64)) return 0;
     if (p.logit_softcap != 0.0f || p.max_bias != 0.0f || !(G == 2 || G == 4 || G == 7 || G == 8) || p.n_splits < 1) return 0;
     if ((k.ne[1] % 4) != 0 || (mask->nb[1] % 8) != 0 || ((uintptr_t) mask->data & 7) != 0 || mask->type != GGML_TYPE_F16) return 0;
     if ((size_t) (n_q * (k.ne[1] + 1)) * sizeof(int) > lists_bytes) return 0;
@@ -1399,7 +1400,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     // one decode token at head_dim 64 over an f16 cache (round 6): the lane-parallel kernel in its eight-lane-row form, records + combine pass
     // (generic kernel: 14.9 us per layer for TinyLlama at a 600-cell context; profiles/r06_secondary_kernel_stats.txt)
     static const bool dec64_on = !getenv("GGML_MI355X_FA_DEC64") || atoi(getenv("GGML_MI355X_FA_DEC64")) != 0;
-    if (dec64_on && D == 64 && k.type == GGML_TYPE_F16 && v.type == GGML_TYPE_F16 && geo.n_q == 1 && p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 4 || G == 8) && !p.lists &&
+    if (dec64_on && D == 64 && k.type == GGML_TYPE_F16 && v.type == GGML_TYPE_F16 && (geo.n_q == 1 || (p.lists && q.ne[3] == 1)) && p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 4 || G == 8) &&
         (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 && ((uintptr_t) q.data & 15) == 0 && (k.nb[1] % 16) == 0 && (v.nb[1] % 16) == 0 && (k.nb[2] % 16) == 0 && (v.nb[2] % 16) == 0 &&
         ((uintptr_t) k.data & 15) == 0 && ((uintptr_t) v.data & 15) == 0 && p.q8_out == nullptr) {
         geo.arrive = nullptr;
@@ -1407,8 +1408,10 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         geo.q8 = nullptr;
         geo.per = (geo.n_kv + geo.n_splits - 1) / geo.n_splits;
         const tdesc q0 = q, k0 = k, v0 = v, mk0 = mk, dst0 = dst;
-        const dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, 1u);
-        const bool wide = geo.n_splits > 1;  // (eight waves: a trip covers 64 / 128 cells)
+        const dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, (unsigned) geo.n_q);
+        const bool list = p.lists != nullptr;  // (2 .. 32 tokens of a -np decode step: each walks the list of its own visible cells, as at head_dim 128)
+        const int lstride = geo.n_kv + 1;
+        const bool wide = !list && geo.n_splits > 1;  // (eight waves: a trip covers 64 / 128 cells)
         for (int64_t b = 0; b < q0.ne[3]; ++b) {  // one launch per batch slice: the kernel has no batch arithmetic
             tdesc qb = q0, kb = k0, vb = v0, mb = mk0, db = dst0;
             qb.data += b * q0.nb[3];
@@ -1417,7 +1420,10 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
             if (mask) mb.data += (b % mk0.ne[3]) * mk0.nb[3];
             db.data += b * dst0.nb[3];
             float * wsb = ws + b * geo.n_head * geo.n_splits * geo.rec_stride;
-            if (G == 4) {
+            if (list) {
+                if (G == 4) hipLaunchKernelGGL((k_fattn_dec128<4, 2, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, p.lists, lstride);
+                else hipLaunchKernelGGL((k_fattn_dec128<8, 2, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, p.lists, lstride);
+            } else if (G == 4) {
                 if (wide) hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 8, 0, 64>), grid, dim3(512), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
                 else hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
             } else {

@@ -488,7 +488,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         return true;
     }
     const void * act = quantized_src1(st, b, w->type);
-    if (w->type == GGML_TYPE_Q8_0 && M >= 33 && !w2 && !add2 && mmq_q80_supported(w->type, K, N, M)) {
+    if (w->type == GGML_TYPE_Q8_0 && M >= c->opt.q80_min_cols && !w2 && !add2 && mmq_q80_supported(w->type, K, N, M)) {
         timed_scope ts(c, "mmq_q8_0", wbytes);
         const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
         launch_mmq_q80(c->stream, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4),
@@ -1661,7 +1661,7 @@ static int run_node(exec_state & st, int i) {
                 if (used != 0) return used;
             }
             if (fuse && !rowpar && ((M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) ||
-                                    (M >= 33 && mmq_q80_supported(a->type, a->ne[0], a->ne[1], M)))) {
+                                    (M >= c->opt.q80_min_cols && mmq_q80_supported(a->type, a->ne[0], a->ne[1], M)))) {
                 // batches: MUL_MAT -> ADD (bias row or residual) rides in the GEMM's store
                 ggml_tensor * a1 = next(1);
                 const ggml_tensor * o1 = (a1 && single_use(st, n)) ? add_partner(a1, n) : nullptr;

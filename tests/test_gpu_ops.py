@@ -960,7 +960,8 @@ def test_flash_attn_q8_0_kv(backend, H, plog, NH, NKV, nq, nkv, splits, sinks):
     assert e_gpu <= 6e-7 and e_gpu <= e_cpu * 1.01 + 1e-12  # (f16 rounding of P: ~3e-7)
 
 
-@pytest.mark.parametrize("HD,NH,NKV,nseq,per_seq", [(128, 32, 8, 32, 64), (128, 8, 2, 12, 100), (128, 28, 4, 5, 300), (128, 16, 2, 48, 48), (64, 8, 2, 16, 64)])
+@pytest.mark.parametrize("HD,NH,NKV,nseq,per_seq", [(128, 32, 8, 32, 64), (128, 8, 2, 12, 100), (128, 28, 4, 5, 300), (128, 16, 2, 48, 48), (64, 8, 2, 16, 64), (64, 32, 4, 32, 40), (64, 32, 8, 12, 100),
+                                                    (64, 32, 4, 5, 700)])
 def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq, per_seq):
     """-np style decode batch: token i belongs to sequence i and sees only that sequence's cells of the unified cache (a block-diagonal
     mask).  The decode kernel reads the mask of its split first and skips KV trips no position of which is visible."""
@@ -982,8 +983,11 @@ def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq
         H.ggml_flash_attn_ext_set_prec(r, 10)
         return r
 
+    s0 = backend.stat("fa_list_launches")
     ref, got = both(build, backend)
     T.compare(f"flash_attn block-diagonal D={HD} H={NH}/{NKV} nseq={nseq} per_seq={per_seq}", got[0], ref[0], max_nmse=1e-4, log=plog)
+    if nseq <= 32:  # 2 .. 32 tokens walk position lists — at head_dim 64 (G = 4 / 8) too since round 6
+        assert backend.stat("fa_list_launches") > s0
 
 
 @pytest.mark.parametrize("upstream_cast", [False, True])
