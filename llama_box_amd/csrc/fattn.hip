@@ -22,6 +22,11 @@
 
 namespace mi355x {
 
+// query heads per KV head the lane-parallel kernel serves: 2 .. 8, in the template form of the next power of two (G = 3 runs as 4, G = 5 / 6 / 7 as 8: the
+// surplus head slots read the group's last head with a zero query and are never stored — Llama-3.2-3B is 24 / 8 heads, Qwen2.5-1.5B 12 / 2, Qwen2-7B 28 / 4)
+static inline bool fa_g_ok(const int64_t G) { return G >= 2 && G <= 8; }
+static inline int fa_gg(const int64_t G) { return G <= 2 ? 2 : (G <= 4 ? 4 : 8); }
+
 struct fa_geom {
     int n_q, n_head, n_kv_head, n_kv, n_splits, has_mask;
     int rec_stride;  // floats between the partial records of consecutive splits (D + 2; 132 for the records the wo prologue reads)
@@ -1079,7 +1084,7 @@ bool fattn_prefers_lists(const tdesc & q, const tdesc * mask, int mask_sparse) {
 int fattn_pick_splits(const tdesc & q, const tdesc & k, const tdesc * mask, int mask_sparse) {
     if (q.ne[1] >= fattn_mma_min_q() && (k.ne[0] == 64 || k.ne[0] == 128) && !fattn_prefers_lists(q, mask, mask_sparse)) return fattn_mma_pick_splits(q, k);  // (soft-capped / ALiBi batches fall back to the generic kernel with this count)
     const int64_t n_kv = k.ne[1];
-    if (q.ne[1] > 1 && (k.ne[0] == 128 || (k.ne[0] == 64 && k.type == GGML_TYPE_F16 && k.ne[2] > 0 && (q.ne[2] == 4 * k.ne[2] || q.ne[2] == 8 * k.ne[2]))) && q.ne[3] == 1) {
+    if (q.ne[1] > 1 && (k.ne[0] == 128 || (k.ne[0] == 64 && k.type == GGML_TYPE_F16 && k.ne[2] > 0 && q.ne[2] % k.ne[2] == 0 && fa_g_ok(q.ne[2] / k.ne[2]))) && q.ne[3] == 1) {
         // a few tokens at head_dim 128 (continuous-batching decode, speculative batches): the tile-list kernel — every split takes a
         // share of the token's VISIBLE tiles, so the count follows the number of (token, kv head) groups, not the cache size
         const int64_t groups = k.ne[2] * q.ne[1];
@@ -1117,9 +1122,9 @@ int fattn_fat_splits(const tdesc & q, const tdesc & k, const tdesc * mask, const
     if (q.ne[1] != 1 || q.ne[3] != 1 || k.ne[0] != 128 || k.ne[3] != 1 || p.kv_type != GGML_TYPE_F16 || sinks || p.logit_softcap != 0.0f || p.max_bias != 0.0f) return 0;
     if (q.ne[2] % k.ne[2] != 0 || (q.ne[2] % 2) != 0) return 0;
     const int64_t G = q.ne[2] / k.ne[2];
-    if (!(G == 2 || G == 4 || G == 7 || G == 8) || (q.nb[1] % 16) != 0 || (q.nb[2] % 16) != 0 || ((uintptr_t) q.data & 15) != 0) return 0;
+    if (!fa_g_ok(G) || (q.nb[1] % 16) != 0 || (q.nb[2] % 16) != 0 || ((uintptr_t) q.data & 15) != 0) return 0;
     if (mask && (mask->type != GGML_TYPE_F16)) return 0;
-    const int64_t trip = 32 * (16 / (G == 7 ? 8 : G));
+    const int64_t trip = 32 * (16 / fa_gg(G));
     const int64_t trips = (k.ne[1] + trip - 1) / trip;
     int64_t splits = std::min<int64_t>(12, trips);
     // whole trips per split: e.g. 9 trips -> 9 splits of 1; 32 trips -> 16 splits of 2; 33 trips -> 11 splits of 3
@@ -1217,9 +1222,9 @@ int fattn_list_tile(const tdesc & q, const tdesc & k, const tdesc * mask, const 
     const int64_t n_q = q.ne[1];
     const int G = k.ne[2] > 0 ? (int) (q.ne[2] / k.ne[2]) : 0;
     static const bool on = !getenv("GGML_MI355X_FA_LIST") || atoi(getenv("GGML_MI355X_FA_LIST")) != 0;
-    const bool d64 = k.ne[0] == 64 && k.type == GGML_TYPE_F16 && (G == 4 || G == 8);  // (round 6: the eight-lane-row form of the kernel; fattn_q8_out_ok refuses head_dim 64, arrival counters are not used)
+    const bool d64 = k.ne[0] == 64 && k.type == GGML_TYPE_F16;  // (round 6: the eight-lane-row form of the kernel; fattn_q8_out_ok refuses head_dim 64, arrival counters are not used)
     if (!on || n_q < 2 || (n_q >= fattn_mma_min_q() && !fattn_prefers_lists(q, mask, p.mask_sparse)) || !mask || q.ne[3] != 1 || mask->ne[3] != 1 || (k.ne[0] != 128 && !d64)) return 0;
-    if (p.logit_softcap != 0.0f || p.max_bias != 0.0f || !(G == 2 || G == 4 || G == 7 || G == 8) || p.n_splits < 1) return 0;
+    if (p.logit_softcap != 0.0f || p.max_bias != 0.0f || !fa_g_ok(G) || p.n_splits < 1) return 0;
     if ((k.ne[1] % 4) != 0 || (mask->nb[1] % 8) != 0 || ((uintptr_t) mask->data & 7) != 0 || mask->type != GGML_TYPE_F16) return 0;
     if ((size_t) (n_q * (k.ne[1] + 1)) * sizeof(int) > lists_bytes) return 0;
     return 1;
@@ -1238,7 +1243,7 @@ bool fattn_native_kv_ok(const tdesc & q, const tdesc & k, const tdesc & v, const
     static const bool on = !getenv("GGML_MI355X_FA_NATIVE_KV") || atoi(getenv("GGML_MI355X_FA_NATIVE_KV")) != 0;
     if (!on || !dq_type_ok(k.type) || v.type != k.type || k.ne[0] != 128 || v.ne[0] != 128 || k.ne[2] <= 0 || q.ne[2] % k.ne[2] != 0) return false;
     const int G = (int) (q.ne[2] / k.ne[2]);
-    if (!(G == 2 || G == 4 || G == 7 || G == 8) || p.logit_softcap != 0.0f || p.max_bias != 0.0f || q.ne[1] > 32 || p.n_splits < 1) return false;
+    if (!fa_g_ok(G) || p.logit_softcap != 0.0f || p.max_bias != 0.0f || q.ne[1] > 32 || p.n_splits < 1) return false;
     if ((q.nb[1] % 16) != 0 || (q.nb[2] % 16) != 0 || ((uintptr_t) q.data & 15) != 0) return false;
     const int al = k.type == GGML_TYPE_BF16 ? 16 : 2;  // (bf16 rows are read as the f16 cache's are: 16 bytes per lane)
     for (const tdesc * t : {&k, &v})
@@ -1253,7 +1258,7 @@ bool fattn_q8_out_ok(const tdesc & q, const tdesc & k, const tdesc * mask, const
     if (p.n_splits >= 2 && (!q8 || (fattn_q8_via_f16(q, p.kv_type) && k.ne[3] == 1)) && flash_attn_mma_applies(q, k, mask, sinks, dst, p)) return true;
     const int G = (int) (q.ne[2] / k.ne[2]);
     if (p.n_splits == 1 && ((G & 1) || p.fat || flash_attn_mma_applies(q, k, mask, sinks, dst, p))) return false;  // one pass: the lane-parallel kernel quantises whole head pairs of a kv group
-    return p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 2 || G == 4 || G == 7 || G == 8) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 && ((uintptr_t) q.data & 15) == 0;
+    return p.logit_softcap == 0.0f && p.max_bias == 0.0f && fa_g_ok(G) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 && ((uintptr_t) q.data & 15) == 0;
 }
 void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const tdesc & v, const tdesc * mask, const float * sinks, const tdesc & dst,
                        const fattn_params & p, void * workspace) {
@@ -1301,15 +1306,15 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     const tdesc mk = mask ? *mask : q;
     float * ws = (float *) workspace;
     // batch-1 / small-batch decode at head_dim 128 without soft-capping or ALiBi: the lane-parallel kernel
-    if (D == 128 && p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 2 || G == 4 || G == 7 || G == 8) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 &&
+    if (D == 128 && p.logit_softcap == 0.0f && p.max_bias == 0.0f && fa_g_ok(G) && (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 &&
         ((uintptr_t) q.data & 15) == 0) {
         dim3 grid((unsigned) geo.n_splits, (unsigned) geo.n_kv_head, (unsigned) (geo.n_q * q.ne[3]));
         if (p.fat) {
             // one decode token, few fat splits on 8-wave workgroups; the partial records stay in the workspace for the wo prologue
             if (q8 || p.dq || geo.n_q != 1 || q.ne[3] != 1 || sinks != nullptr) { MI_ERR("launch_flash_attn: fat-split form requested for a case it does not serve"); abort(); }
             geo.rec_stride = FA_REC;
-            if (G == 2) hipLaunchKernelGGL((k_fattn_dec128<2, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
-            else if (G == 4) hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
+            if (fa_gg(G) == 2) hipLaunchKernelGGL((k_fattn_dec128<2, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
+            else if (fa_gg(G) == 4) hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
             else hipLaunchKernelGGL((k_fattn_dec128<8, 0, false, 8>), grid, dim3(512), 0, s, q, k, v, mk, sinks, dst, geo, ws, G, nullptr, 0);
             return;
         }
@@ -1320,7 +1325,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
         const bool list = p.lists != nullptr;
         const int lstride = geo.n_kv + 1;
         const bool dq = p.dq != 0;
-        const bool skip = !list && skip_on && geo.n_q > 1 && (geo.n_q <= 64 || q8) && mask != nullptr && per <= 32 * 16 * (16 / (G == 7 ? 8 : G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
+        const bool skip = !list && skip_on && geo.n_q > 1 && (geo.n_q <= 64 || q8) && mask != nullptr && per <= 32 * 16 * (16 / fa_gg(G)) && (geo.n_kv % 4) == 0 && (mask->nb[1] % 8) == 0 &&
                           (mask->nb[3] % 8) == 0 && ((uintptr_t) mask->data & 7) == 0 && geo.n_splits > 1;
         // one decode token over an f16 cache: eight waves per workgroup (a trip covers 128 cells: splits of up to 128 cells are ONE trip)
         // (measured, 2048-token context, 24 splits: 13.45 -> 12.6 us per layer for both launches, 480.7 -> 488.5 tok/s; profiles/r03_decode_ab_fa_wv8.txt)
@@ -1381,7 +1386,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
                 float * ws = ws0 + (merge2 ? rows * geo0.n_kv_head * geo0.n_splits * G * FA_M2_REC : rows * geo0.n_head * geo0.n_splits * geo0.rec_stride);
                 if (geo.arrive) geo.arrive += rows * geo0.n_kv_head;
                 if (geo.q8) geo.q8 = (q8k_dev *) geo.q8 + rows * (geo0.n_head * 128 / 256);
-                if (G == 2) FA_DEC(2) else if (G == 4) FA_DEC(4) else FA_DEC(8)
+                if (fa_gg(G) == 2) FA_DEC(2) else if (fa_gg(G) == 4) FA_DEC(4) else FA_DEC(8)
             }
         }
 #undef FA_DEC
@@ -1400,7 +1405,7 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     // one decode token at head_dim 64 over an f16 cache (round 6): the lane-parallel kernel in its eight-lane-row form, records + combine pass
     // (generic kernel: 14.9 us per layer for TinyLlama at a 600-cell context; profiles/r06_secondary_kernel_stats.txt)
     static const bool dec64_on = !getenv("GGML_MI355X_FA_DEC64") || atoi(getenv("GGML_MI355X_FA_DEC64")) != 0;
-    if (dec64_on && D == 64 && k.type == GGML_TYPE_F16 && v.type == GGML_TYPE_F16 && (geo.n_q == 1 || (p.lists && q.ne[3] == 1)) && p.logit_softcap == 0.0f && p.max_bias == 0.0f && (G == 4 || G == 8) &&
+    if (dec64_on && D == 64 && k.type == GGML_TYPE_F16 && v.type == GGML_TYPE_F16 && (geo.n_q == 1 || (p.lists && q.ne[3] == 1)) && p.logit_softcap == 0.0f && p.max_bias == 0.0f && fa_g_ok(G) &&
         (q.nb[1] % 16) == 0 && (q.nb[2] % 16) == 0 && ((uintptr_t) q.data & 15) == 0 && (k.nb[1] % 16) == 0 && (v.nb[1] % 16) == 0 && (k.nb[2] % 16) == 0 && (v.nb[2] % 16) == 0 &&
         ((uintptr_t) k.data & 15) == 0 && ((uintptr_t) v.data & 15) == 0 && p.q8_out == nullptr) {
         geo.arrive = nullptr;
@@ -1421,9 +1426,13 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
             db.data += b * dst0.nb[3];
             float * wsb = ws + b * geo.n_head * geo.n_splits * geo.rec_stride;
             if (list) {
-                if (G == 4) hipLaunchKernelGGL((k_fattn_dec128<4, 2, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, p.lists, lstride);
+                if (fa_gg(G) == 2) hipLaunchKernelGGL((k_fattn_dec128<2, 2, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, p.lists, lstride);
+                else if (fa_gg(G) == 4) hipLaunchKernelGGL((k_fattn_dec128<4, 2, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, p.lists, lstride);
                 else hipLaunchKernelGGL((k_fattn_dec128<8, 2, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, p.lists, lstride);
-            } else if (G == 4) {
+            } else if (fa_gg(G) == 2) {
+                if (wide) hipLaunchKernelGGL((k_fattn_dec128<2, 0, false, 8, 0, 64>), grid, dim3(512), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
+                else hipLaunchKernelGGL((k_fattn_dec128<2, 0, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
+            } else if (fa_gg(G) == 4) {
                 if (wide) hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 8, 0, 64>), grid, dim3(512), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
                 else hipLaunchKernelGGL((k_fattn_dec128<4, 0, false, 4, 0, 64>), grid, dim3(256), 0, s, qb, kb, vb, mb, sinks, db, geo, wsb, G, nullptr, 0);
             } else {
@@ -1436,8 +1445,8 @@ void launch_flash_attn(hipStream_t s, const tdesc & q, const tdesc & k, const td
     }
 #define FA_CASE(DD, GG) \
     if (D == DD && G == GG) { launch_fa<DD, GG>(s, q, k, v, mk, sinks, dst, geo, ws); return; }
-    FA_CASE(64, 1) FA_CASE(64, 2) FA_CASE(64, 4) FA_CASE(64, 8)
-    FA_CASE(128, 1) FA_CASE(128, 2) FA_CASE(128, 4) FA_CASE(128, 7) FA_CASE(128, 8)
+    FA_CASE(64, 1) FA_CASE(64, 2) FA_CASE(64, 3) FA_CASE(64, 4) FA_CASE(64, 5) FA_CASE(64, 6) FA_CASE(64, 7) FA_CASE(64, 8)
+    FA_CASE(128, 1) FA_CASE(128, 2) FA_CASE(128, 3) FA_CASE(128, 4) FA_CASE(128, 5) FA_CASE(128, 6) FA_CASE(128, 7) FA_CASE(128, 8)
 #undef FA_CASE
     MI_ERR("launch_flash_attn: unsupported head_dim %d / group %d", D, G);
     abort();

@@ -160,6 +160,37 @@ def test_logits_flash_attn_path(backend, H, plog, name):
         _free(cc, cg, mc, mg)
 
 
+@pytest.mark.parametrize("heads", [(6, 2, 128), (12, 2, 64), (10, 2, 128), (28, 4, 64)], ids=["3-per-kv-d128", "6-per-kv-d64", "5-per-kv-d128", "7-per-kv-d64"])
+@pytest.mark.parametrize("type_k", [0, L.Q8_0])
+def test_flash_attn_models_with_3_5_6_7_query_heads_per_kv_head(backend, H, plog, heads, type_k):
+    """Round 6: Llama-3.2-3B is 24 / 8 heads, Qwen2.5-1.5B 12 / 2, Qwen2-0.5B 14 / 2 at head_dim 64 — until this round FLASH_ATTN_EXT of such a model was refused
+    (supports_op false: the node, and with it every copy around it, stayed on the CPU backend).  A prompt and teacher-forced decode steps with -fa on, f16 and q8_0
+    caches, against the oracle (the host library hands the whole graph to this backend: a refused node fails the llama_decode call)."""
+    n_head, n_kv, hd = heads
+    if type_k and hd != 128:
+        pytest.skip("a q8_0 cache at head_dim 64 goes through the f16 image (tests/test_gpu_kv_types.py)")
+    hp = preset("test-llama", n_head=n_head, n_head_kv=n_kv, n_embd=n_head * hd, n_embd_head=hd)
+    mc = Model(hp, 77, H.ggml_backend_cpu_buffer_type())
+    mg = Model(hp, 77, backend.buft)
+    kw = dict(type_k=type_k, type_v=type_k) if type_k else {}
+    cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=1, **kw)
+    cg = Context(mg, backend=backend, flash_attn=1, **kw)
+    try:
+        rc, ref = cc.decode(PROMPT, range(len(PROMPT)))
+        rc2, got = cg.decode(PROMPT, range(len(PROMPT)))
+        assert rc == 0 and rc2 == 0
+        rows_r, rows_g = [ref[-1]], [got[-1]]
+        for i in range(12):
+            t = int(np.argmax(rows_r[-1]))
+            rows_r.append(cc.decode([t], [len(PROMPT) + i])[1][0])
+            rows_g.append(cg.decode([t], [len(PROMPT) + i])[1][0])
+        e = T.nmse(np.stack(rows_g), np.stack(rows_r))
+        plog(f"flash attention, {n_head}/{n_kv} heads of {hd}, cache {type_k}: prompt nmse={T.nmse(got, ref):.3e}, 13 decode rows nmse={e:.3e}")
+        assert T.nmse(got, ref) <= 1e-3 and e <= 1e-3
+    finally:
+        _free(cc, cg, mc, mg)
+
+
 def test_logits_quantised_kv_cache(backend, H, plog):
     """-ctk q8_0 [-ctv q8_0]: SET_ROWS quantises the new K/V rows into block_q8_0 and FLASH_ATTN_EXT reads them
     (head_dim 128 models; llama-box exposes this as --cache-type-k / --cache-type-v)."""

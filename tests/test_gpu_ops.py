@@ -751,6 +751,21 @@ FA_CASES = [  # (HD, NH, NKV, n_q, n_kv, splits, softcap, alibi, sinks)
     (64, 16, 4, 1, 300, 1, 0.0, 0.0, True),
     (64, 32, 8, 1, 3072, 0, 0.0, 0.0, False),  # (longer random caches leave the 1e-4 gate on the ORACLE side: its f16 V accumulator, 1.7e-4 at 8192 cells with either kernel)
     (64, 8, 2, 1, 68, 2, 0.0, 0.0, False),
+    # query heads per KV head other than 2 / 4 / 7 / 8 (round 6; until then FLASH_ATTN_EXT of such models stayed on the CPU backend): 3 (Llama-3.2-3B: 24 / 8), 5, 6
+    # (Qwen2.5-1.5B: 12 / 2) on the lane-parallel kernel in the next power of two's form, at both head sizes; soft-capped / ALiBi on the generic kernel; a prompt batch
+    (128, 24, 8, 1, 1024, 0, 0.0, 0.0, False),
+    (128, 12, 2, 1, 700, 3, 0.0, 0.0, True),
+    (128, 20, 4, 3, 512, 2, 0.0, 0.0, False),
+    (128, 24, 8, 1, 333, 1, 0.0, 0.0, False),
+    (128, 24, 8, 2, 256, 2, 30.0, 0.0, False),
+    (128, 12, 2, 4, 300, 0, 0.0, 8.0, False),
+    (128, 24, 8, 64, 512, 0, 0.0, 0.0, False),
+    (64, 14, 2, 1, 900, 0, 0.0, 0.0, False),
+    (64, 24, 8, 1, 600, 2, 0.0, 0.0, True),
+    (64, 8, 4, 1, 300, 1, 0.0, 0.0, False),
+    (64, 12, 2, 1, 2048, 0, 0.0, 0.0, False),
+    (64, 24, 8, 3, 256, 2, 20.0, 0.0, False),
+    (64, 20, 4, 40, 256, 0, 0.0, 0.0, False),
     # >= 32 query tokens: the matrix-core kernel (fattn_mma.hip); ragged query tiles, fully-masked KV tiles, KV tails
     (128, 32, 8, 64, 512, 0, 0.0, 0.0, False),
     (128, 8, 2, 200, 256, 0, 0.0, 0.0, False),
@@ -883,6 +898,9 @@ FA_Q8_CASES = [  # (NH, NKV, n_q, n_kv, splits, sinks)
     (16, 2, 1, 768, 0, True),
     (16, 2, 4, 300, 1, False),
     (8, 4, 3, 512, 2, False),
+    (24, 8, 1, 1024, 0, False),   # 3, 6, 5 query heads per KV head (round 6)
+    (12, 2, 2, 600, 3, True),
+    (20, 4, 1, 333, 1, False),
     # prompt batches (>= 32 query tokens): the cells are expanded to f16 and the matrix-core kernel runs on that image
     (32, 8, 40, 512, 0, False),
     (32, 8, 200, 1024, 0, False),
@@ -961,7 +979,7 @@ def test_flash_attn_q8_0_kv(backend, H, plog, NH, NKV, nq, nkv, splits, sinks):
 
 
 @pytest.mark.parametrize("HD,NH,NKV,nseq,per_seq", [(128, 32, 8, 32, 64), (128, 8, 2, 12, 100), (128, 28, 4, 5, 300), (128, 16, 2, 48, 48), (64, 8, 2, 16, 64), (64, 32, 4, 32, 40), (64, 32, 8, 12, 100),
-                                                    (64, 32, 4, 5, 700)])
+                                                    (64, 32, 4, 5, 700), (128, 24, 8, 16, 64), (64, 24, 8, 16, 64), (128, 12, 2, 9, 120), (64, 14, 2, 32, 30)])
 def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq, per_seq):
     """-np style decode batch: token i belongs to sequence i and sees only that sequence's cells of the unified cache (a block-diagonal
     mask).  The decode kernel reads the mask of its split first and skips KV trips no position of which is visible."""
