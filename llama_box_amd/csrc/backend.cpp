@@ -345,6 +345,31 @@ void forget_mask_stats(const void * dev_ptr, size_t nbytes) {
     for (mask_entry & e : g_masks)
         if (e.stamp != 0 && (const char *) e.dev >= (const char *) dev_ptr && (const char *) e.dev < (const char *) dev_ptr + nbytes) { e.dev = nullptr; e.stamp = 0; }
 }
+// a WHOLE tensor copied between two of this library's buffers (ggml_backend_sched / -sm layer hand the graph's inputs — the mask among them — from device to
+// device through cpy_tensor): the statistics describe the same bytes at their new address, so the second device takes the kernel decisions the first one took
+// (without them a layer-split run chose the dense kernel where the one-device run walked position lists: same values to 1e-5, not the same bits)
+void copy_mask_stats(const ggml_tensor * src, const ggml_tensor * dst, size_t nbytes) {
+    if (g_mask_clock.load(std::memory_order_relaxed) == 0 || !src->data || !dst->data) return;
+    std::lock_guard<std::mutex> lock(g_mask_mtx);
+    const mask_entry * from = nullptr;
+    for (const mask_entry & e : g_masks)
+        if (e.stamp != 0 && e.dev == src->data) from = &e;
+    for (mask_entry & e : g_masks)  // whatever was on record inside the destination range is stale now
+        if (e.stamp != 0 && (const char *) e.dev >= (const char *) dst->data && (const char *) e.dev < (const char *) dst->data + nbytes) { e.dev = nullptr; e.stamp = 0; }
+    if (!from || src->view_src || dst->view_src || src->type != dst->type || src->ne[0] != dst->ne[0] || src->ne[1] != dst->ne[1] || src->ne[2] != dst->ne[2] || src->ne[3] != dst->ne[3] ||
+        src->nb[1] != dst->nb[1])
+        return;
+    const mask_stats st = from->st;
+    mask_entry * slot = &g_masks[0];
+    for (mask_entry & e : g_masks) {
+        if (e.dev == dst->data) { slot = &e; break; }
+        if (e.stamp < slot->stamp) slot = &e;
+    }
+    if (slot == from) return;  // (eight slots, the source is the oldest: leave it)
+    slot->dev = dst->data;
+    slot->st = st;
+    slot->stamp = ++g_mask_clock;
+}
 bool lookup_mask_stats(const void * dev_ptr, mask_stats * out) {
     std::lock_guard<std::mutex> lock(g_mask_mtx);
     for (const mask_entry & e : g_masks)
@@ -379,7 +404,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggm
     buffer_ctx * sc = (buffer_ctx *) sb->context;
     buffer_ctx * dc = (buffer_ctx *) b->context;
     const size_t n = ggml_abi_nbytes(src);
-    forget_mask_stats(dst->data, n);
+    copy_mask_stats(src, dst, n);
     decode_copy_drop(b, dst, 0, n);
     if (ip_any()) { ip_host_access(sb, false); ip_host_access(b, true); }
     uploader_drain(sc->device);
@@ -583,7 +608,7 @@ static bool be_cpy_tensor_async(ggml_backend_t be_src, ggml_backend_t be_dst, co
     flush_uploads(cs);
     if (cd != cs) flush_uploads(cd);
     const size_t n = ggml_abi_nbytes(src);
-    forget_mask_stats(dst->data, n);
+    copy_mask_stats(src, dst, n);
     if (((buffer_ctx *) db->context)->shadow) decode_copy_drop(db, dst, 0, n);
     if (ip_any()) { ip_host_access(sb, false); ip_host_access(db, true); }
     uploader_join(cs->device, cs->stream);

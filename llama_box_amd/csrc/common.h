@@ -346,6 +346,7 @@ struct mask_stats {
 void note_mask_upload(const ggml_tensor * t, const void * host, size_t offset, size_t size);
 bool lookup_mask_stats(const void * dev_ptr, mask_stats * out);
 void forget_mask_stats(const void * dev_ptr, size_t nbytes);  // a device-side write landed there
+void copy_mask_stats(const ggml_tensor * src, const ggml_tensor * dst, size_t nbytes);  // ... unless it was a whole-tensor copy of a tensor on record: the record follows the bytes
 // 1: the mask at dev_ptr is known and sparse enough (<= a quarter visible) that per-token position lists beat a dense tile kernel
 int mask_sparse_hint(const void * dev_ptr);
 

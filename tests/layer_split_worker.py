@@ -36,10 +36,14 @@ def main():
     assert int(H.ggml_backend_reg_dev_count(bes[0].reg)) == n_dev
     out = {"n_dev": n_dev, "cases": []}
     nt = T.host_threads(32)
-    for name, fa, n_layer, n_prompt, n_ubatch in (("test-llama", 1, 2, 40, 512), ("test-llama", 0, 2, 40, 512), ("test-qwen2", 1, 4, 150, 64), ("test-llama", 1, 4, 150, 64)):
+    D128 = dict(n_head=4, n_head_kv=2, n_embd=512, n_embd_head=128)
+    # (the last two: head_dim 128 and a 40-token prompt whose causal mask is sparse in a 512-cell cache — the mask statistics that choose the attention kernel must
+    # follow the mask through cpy_tensor to the second device, or that device picks the dense kernel where device 0 walked position lists: round 6)
+    for name, fa, n_layer, n_prompt, n_ubatch, kw in (("test-llama", 1, 2, 40, 512, {}), ("test-llama", 0, 2, 40, 512, {}), ("test-qwen2", 1, 4, 150, 64, {}), ("test-llama", 1, 4, 150, 64, {}),
+                                                      ("test-llama", 1, 2, 40, 512, D128), ("test-llama", 1, 4, 150, 64, D128)):
         if n_layer < n_dev:
             continue  # (a device without a layer: llama.cpp never builds that split)
-        hp = preset(name, n_layer=n_layer)
+        hp = preset(name, n_layer=n_layer, **kw)
         rng = np.random.default_rng(17)
         prompt = rng.integers(1, hp.n_vocab, n_prompt).tolist()
         forced = rng.integers(1, hp.n_vocab, 6).tolist()
@@ -51,7 +55,7 @@ def main():
         c1 = Context(m1, backend=bes[0], flash_attn=fa, n_ctx=512, n_ubatch=n_ubatch)
         one = rows_of(c1, prompt, forced)
         c1.free(); m1.free()
-        res = {"model": name, "fa": fa, "n_layer": n_layer, "n_prompt": n_prompt, "n_ubatch": n_ubatch, "nmse_one_device_vs_oracle": float(T.nmse(one, ref))}
+        res = {"model": name + (" (head_dim 128)" if kw else ""), "fa": fa, "n_layer": n_layer, "n_prompt": n_prompt, "n_ubatch": n_ubatch, "nmse_one_device_vs_oracle": float(T.nmse(one, ref))}
         for graphs in (0, 1):
             for b in bes:
                 b.set_option("graphs", graphs)
