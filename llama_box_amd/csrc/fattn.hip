@@ -22,9 +22,13 @@
 
 namespace mi355x {
 
-// query heads per KV head the lane-parallel kernel serves: 2 .. 8, in the template form of the next power of two (G = 3 runs as 4, G = 5 / 6 / 7 as 8: the
-// surplus head slots read the group's last head with a zero query and are never stored — Llama-3.2-3B is 24 / 8 heads, Qwen2.5-1.5B 12 / 2, Qwen2-7B 28 / 4)
-static inline bool fa_g_ok(const int64_t G) { return G >= 2 && G <= 8; }
+// query heads per KV head the lane-parallel kernel serves: 1 .. 8, in the template form of the next power of two from 2 on (G = 3 runs as 4, G = 5 / 6 / 7 as 8,
+// multi-head attention — G = 1 — as 2: the surplus head slots read the group's last head with a zero query and are never stored — Llama-3.2-3B is 24 / 8 heads,
+// Qwen2.5-1.5B 12 / 2, Qwen2-7B 28 / 4, Llama-2-7B 32 / 32: 467 -> 523 tok/s against the generic kernel, profiles/r06_other_families.txt)
+static inline bool fa_g_ok(const int64_t G) {
+    static const int g_min = getenv("GGML_MI355X_FA_G_MIN") ? atoi(getenv("GGML_MI355X_FA_G_MIN")) : 1;  // (2: multi-head attention back on the generic kernel)
+    return G >= g_min && G <= 8;
+}
 static inline int fa_gg(const int64_t G) { return G <= 2 ? 2 : (G <= 4 ? 4 : 8); }
 
 struct fa_geom {

@@ -56,10 +56,10 @@ static int fa_route(const ggml_tensor * op) {
     const ggml_tensor * m = op->src[3];
     if (!a || !k || !v || a->type != GGML_TYPE_F32) return 0;
     if (k->type == GGML_TYPE_Q8_0 && v->type == GGML_TYPE_Q8_0) {
-        // quantised KV cache: served by the lane-parallel kernel (head_dim 128, 2 .. 8 query heads per KV head, no soft-capping / ALiBi)
+        // quantised KV cache: served by the lane-parallel kernel (head_dim 128, 1 .. 8 query heads per KV head, no soft-capping / ALiBi)
         const int64_t g = k->ne[2] ? a->ne[2] / k->ne[2] : 0;
         const bool shape = k->ne[0] == 128 && v->ne[0] == 128 && a->nb[0] == 4 && !(a->nb[1] % 16) && !(a->nb[2] % 16) && a->ne[2] % k->ne[2] == 0 && k->ne[2] == v->ne[2] &&
-                           g >= 2 && g <= 8 && ggml_abi_op_param_f32(op, 1) == 0.0f && ggml_abi_op_param_f32(op, 2) == 0.0f &&
+                           g >= 1 && g <= 8 && ggml_abi_op_param_f32(op, 1) == 0.0f && ggml_abi_op_param_f32(op, 2) == 0.0f &&
                            !(k->nb[1] % 2) && !(v->nb[1] % 2) && !(k->nb[2] % 2) && !(v->nb[2] % 2);
         if (shape) return (!m || (m->type == GGML_TYPE_F16 && m->ne[2] == 1 && rows_contig(m))) ? 2 : 0;
     }

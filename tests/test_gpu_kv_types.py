@@ -153,6 +153,7 @@ FA_KV_CASES = [  # (type_k, type_v, head_dim, NH, NKV, n_q, n_kv, splits, sinks)
     (L.Q4_0, L.Q4_0, 64, 32, 4, 1, 1024, 0, False),
     (L.Q4_0, L.Q4_0, 128, 24, 8, 1, 900, 0, False),    # 3 / 6 query heads per KV head (round 6): the in-place forms in the next power of two's template
     (L.Q5_1, L.Q5_1, 128, 12, 2, 2, 300, 2, False),
+    (L.Q4_0, L.Q4_0, 128, 8, 8, 1, 400, 0, False),     # multi-head attention
     (L.BF16, L.BF16, 128, 24, 8, 1, 512, 0, False),
     (L.Q4_0, L.Q4_0, 64, 24, 8, 1, 700, 0, False),
     (L.Q4_0, L.Q4_0, 128, 32, 8, 64, 1024, 0, False),  # a prompt micro-batch: the matrix-core kernel on the image

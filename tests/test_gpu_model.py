@@ -160,9 +160,9 @@ def test_logits_flash_attn_path(backend, H, plog, name):
         _free(cc, cg, mc, mg)
 
 
-@pytest.mark.parametrize("heads", [(6, 2, 128), (12, 2, 64), (10, 2, 128), (28, 4, 64)], ids=["3-per-kv-d128", "6-per-kv-d64", "5-per-kv-d128", "7-per-kv-d64"])
+@pytest.mark.parametrize("heads", [(6, 2, 128), (12, 2, 64), (10, 2, 128), (28, 4, 64), (4, 4, 128), (8, 8, 64)], ids=["3-per-kv-d128", "6-per-kv-d64", "5-per-kv-d128", "7-per-kv-d64", "mha-d128", "mha-d64"])
 @pytest.mark.parametrize("type_k", [0, L.Q8_0])
-def test_flash_attn_models_with_3_5_6_7_query_heads_per_kv_head(backend, H, plog, heads, type_k):
+def test_flash_attn_models_with_1_3_5_6_7_query_heads_per_kv_head(backend, H, plog, heads, type_k):
     """Round 6: Llama-3.2-3B is 24 / 8 heads, Qwen2.5-1.5B 12 / 2, Qwen2-0.5B 14 / 2 at head_dim 64 — until this round FLASH_ATTN_EXT of such a model was refused
     (supports_op false: the node, and with it every copy around it, stayed on the CPU backend).  A prompt and teacher-forced decode steps with -fa on, f16 and q8_0
     caches, against the oracle (the host library hands the whole graph to this backend: a refused node fails the llama_decode call)."""

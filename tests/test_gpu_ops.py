@@ -753,6 +753,9 @@ FA_CASES = [  # (HD, NH, NKV, n_q, n_kv, splits, softcap, alibi, sinks)
     (64, 8, 2, 1, 68, 2, 0.0, 0.0, False),
     # query heads per KV head other than 2 / 4 / 7 / 8 (round 6; until then FLASH_ATTN_EXT of such models stayed on the CPU backend): 3 (Llama-3.2-3B: 24 / 8), 5, 6
     # (Qwen2.5-1.5B: 12 / 2) on the lane-parallel kernel in the next power of two's form, at both head sizes; soft-capped / ALiBi on the generic kernel; a prompt batch
+    (128, 32, 32, 1, 1024, 0, 0.0, 0.0, False),   # multi-head attention (Llama-2-7B): the two-head template with one real head
+    (64, 16, 16, 1, 512, 2, 0.0, 0.0, True),
+    (128, 8, 8, 5, 300, 3, 0.0, 0.0, False),
     (128, 24, 8, 1, 1024, 0, 0.0, 0.0, False),
     (128, 12, 2, 1, 700, 3, 0.0, 0.0, True),
     (128, 20, 4, 3, 512, 2, 0.0, 0.0, False),
@@ -898,7 +901,9 @@ FA_Q8_CASES = [  # (NH, NKV, n_q, n_kv, splits, sinks)
     (16, 2, 1, 768, 0, True),
     (16, 2, 4, 300, 1, False),
     (8, 4, 3, 512, 2, False),
-    (24, 8, 1, 1024, 0, False),   # 3, 6, 5 query heads per KV head (round 6)
+    (8, 8, 1, 512, 0, False),     # 1 (multi-head attention), 3, 6, 5 query heads per KV head (round 6)
+    (16, 16, 3, 400, 2, True),
+    (24, 8, 1, 1024, 0, False),
     (12, 2, 2, 600, 3, True),
     (20, 4, 1, 333, 1, False),
     # prompt batches (>= 32 query tokens): the cells are expanded to f16 and the matrix-core kernel runs on that image
@@ -979,7 +984,7 @@ def test_flash_attn_q8_0_kv(backend, H, plog, NH, NKV, nq, nkv, splits, sinks):
 
 
 @pytest.mark.parametrize("HD,NH,NKV,nseq,per_seq", [(128, 32, 8, 32, 64), (128, 8, 2, 12, 100), (128, 28, 4, 5, 300), (128, 16, 2, 48, 48), (64, 8, 2, 16, 64), (64, 32, 4, 32, 40), (64, 32, 8, 12, 100),
-                                                    (64, 32, 4, 5, 700), (128, 24, 8, 16, 64), (64, 24, 8, 16, 64), (128, 12, 2, 9, 120), (64, 14, 2, 32, 30)])
+                                                    (64, 32, 4, 5, 700), (128, 24, 8, 16, 64), (64, 24, 8, 16, 64), (128, 12, 2, 9, 120), (64, 14, 2, 32, 30), (128, 8, 8, 16, 64), (64, 8, 8, 12, 50)])
 def test_flash_attn_continuous_batching_mask(backend, H, plog, HD, NH, NKV, nseq, per_seq):
     """-np style decode batch: token i belongs to sequence i and sees only that sequence's cells of the unified cache (a block-diagonal
     mask).  The decode kernel reads the mask of its split first and skips KV trips no position of which is visible."""
