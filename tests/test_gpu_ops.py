@@ -854,16 +854,25 @@ def _random_fa_cases():
         nq = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 32, 33, 48, 64, 65, 130]))
         nkv = int(rng.integers(8, 700)) * 4
         nseq = int(rng.choice([1, 1, 2, 4, 8]))
-        out.append((NH, NKV, nq, nkv, nseq, i))
+        out.append((128, NH, NKV, nq, nkv, nseq, i))
+    # round 6: head_dim 64 and every number of query heads per KV head from 1 to 8, at both head sizes (own generator: the 28 cases above stay what they were)
+    rng = np.random.default_rng(78)
+    heads = [(32, 4), (32, 8), (24, 8), (12, 2), (20, 4), (14, 2), (8, 8), (6, 1), (16, 8)]
+    for i in range(28, 64):
+        NH, NKV = heads[int(rng.integers(len(heads)))]
+        HD = int(rng.choice([64, 64, 128]))
+        nq = int(rng.choice([1, 1, 2, 3, 5, 8, 16, 31, 32, 33, 48, 65]))
+        nkv = int(rng.integers(8, 700)) * 4
+        nseq = int(rng.choice([1, 1, 2, 4, 8]))
+        out.append((HD, NH, NKV, nq, nkv, nseq, i))
     return out
 
 
-@pytest.mark.parametrize("NH,NKV,nq,nkv,nseq,case", _random_fa_cases())
-def test_flash_attn_random_masks(backend, H, plog, NH, NKV, nq, nkv, nseq, case):
-    """Seeded sweep at head_dim 128: query counts on both sides of every kernel boundary (1 / 2..32 tile lists / >= 33 matrix
-    cores), ragged cache lengths, one or several sequences in a unified cache (each query sees a random causal prefix of its own
+@pytest.mark.parametrize("HD,NH,NKV,nq,nkv,nseq,case", _random_fa_cases())
+def test_flash_attn_random_masks(backend, H, plog, HD, NH, NKV, nq, nkv, nseq, case):
+    """Seeded sweep at head_dim 128 (and, round 6, 64; 1 .. 8 query heads per KV head): query counts on both sides of every kernel boundary (1 / 2..32 position
+    lists / >= 33 matrix cores), ragged cache lengths, one or several sequences in a unified cache (each query sees a random causal prefix of its own
     sequence's scattered cells — whole tiles and whole splits with nothing visible) — against the oracle."""
-    HD = 128
     rng = np.random.default_rng(1000 + case)
     q = rng.standard_normal((NH, nq, HD)).astype(np.float32)
     kc = rng.standard_normal((nkv, NKV * HD)).astype(np.float16)
@@ -888,7 +897,7 @@ def test_flash_attn_random_masks(backend, H, plog, NH, NKV, nq, nkv, nseq, case)
         return r
 
     ref, got = both(build, backend)
-    T.compare(f"flash_attn random H={NH}/{NKV} nq={nq} nkv={nkv} nseq={nseq}", got[0], ref[0], max_nmse=1e-4, log=plog)
+    T.compare(f"flash_attn random D={HD} H={NH}/{NKV} nq={nq} nkv={nkv} nseq={nseq}", got[0], ref[0], max_nmse=1e-4, log=plog)
 
 
 # quantised KV cache (-ctk q8_0 -ctv q8_0): SET_ROWS quantises f32 rows into block_q8_0, FLASH_ATTN_EXT reads the blocks
