@@ -82,11 +82,13 @@ static void decode_copy_drop(ggml_backend_buffer_t b, const ggml_tensor * t, siz
     buffer_ctx * c = (buffer_ctx *) b->context;
     if (c->shadow != nullptr && t->data != nullptr) decode_copy_drop(c, (size_t) ((const char *) t->data - (const char *) c->base) + offset, size);
 }
-const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w) {
+// (q80_panels: the OTHER second copy — Q8_0 matrices regrouped into the 32-row x 4-block tiles the 9 .. 32-column matrix-core kernel loads with whole-line
+// wave-instructions, repack.hip: k_repack_q80_panels.  A tensor has one kind of copy: the K-quants planes, Q8_0 panels; same shadow allocation, same invalidation)
+static const uint8_t * second_copy(backend_ctx * c, const ggml_tensor * w, const bool q80_panels) {
     if (!c->opt.decode_copy || w == nullptr || w->view_src != nullptr || w->data == nullptr || w->ne[2] != 1 || w->ne[3] != 1) return nullptr;
     ggml_backend_buffer_t b = w->buffer;
     if (b == nullptr || !buffer_is_ours(b) || b->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS || buffer_is_split(b) || buffer_is_rowpar(b)) return nullptr;
-    if (!repack_supported(w->type, w->ne[0], (int64_t) w->nb[1])) return nullptr;
+    if (q80_panels ? !repack_q80_supported(w->type, w->ne[0], w->ne[1], (int64_t) w->nb[1]) : !repack_supported(w->type, w->ne[0], (int64_t) w->nb[1])) return nullptr;
     buffer_ctx * bc = (buffer_ctx *) b->context;
     if (bc->device != c->device || bc->shadow_failed) return nullptr;
     const size_t off = (size_t) ((const char *) w->data - (const char *) bc->base), bytes = (size_t) w->nb[1] * (size_t) w->ne[1];
@@ -107,7 +109,8 @@ const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w) {
             return nullptr;
         }
     }
-    launch_repack_planes(c->stream, w->type, w->data, (char *) bc->shadow + off, w->ne[0], (int64_t) w->nb[1], 0, w->ne[1]);
+    if (q80_panels) launch_repack_q80_panels(c->stream, w->data, (char *) bc->shadow + off, w->ne[0], w->ne[1], (int64_t) w->nb[1]);
+    else launch_repack_planes(c->stream, w->type, w->data, (char *) bc->shadow + off, w->ne[0], (int64_t) w->nb[1], 0, w->ne[1]);
     // (another backend instance of this device — its own stream — may find the entry valid a moment later: the copy is complete before it is announced)
     if (hipStreamSynchronize(c->stream) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
     bc->sh_valid[off] = bytes;
@@ -115,6 +118,8 @@ const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w) {
     c->st.decode_copy_bytes += (int64_t) bytes;
     return (const uint8_t *) bc->shadow + off;
 }
+const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w) { return second_copy(c, w, false); }
+const uint8_t * q80_panel_copy(backend_ctx * c, const ggml_tensor * w) { return second_copy(c, w, true); }
 static void buf_free(ggml_backend_buffer_t b) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     if (ip_any()) ip_host_buffer_freed(b);  // (tp_inproc.cpp mirrors host buffers on the other devices)
@@ -822,7 +827,7 @@ static int64_t api_decode_copy_read(ggml_backend_t be, const ggml_tensor * t, vo
     backend_ctx * c = (backend_ctx *) be->context;
     if (hipSetDevice(c->device) != hipSuccess) return -1;
     uploader_join(c->device, c->stream);
-    const uint8_t * p = decode_copy(c, t);
+    const uint8_t * p = t->type == GGML_TYPE_Q8_0 ? q80_panel_copy(c, t) : decode_copy(c, t);
     if (!p) return 0;
     const size_t bytes = (size_t) t->nb[1] * (size_t) t->ne[1];
     if (out == nullptr || size < bytes) return (int64_t) bytes;

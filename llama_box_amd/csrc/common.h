@@ -274,6 +274,7 @@ struct buffer_ctx {
 // the plane-layout copy of weight matrix w for the batch-1 mat-vec kernels, or nullptr (no copy: views, split / row-parallel buffers, option off,
 // allocation failed, or asked during a capture for a tensor not yet repacked)
 const uint8_t * decode_copy(backend_ctx * c, const ggml_tensor * w);
+const uint8_t * q80_panel_copy(backend_ctx * c, const ggml_tensor * w);  // a Q8_0 matrix's panel copy (mmq_q80.hip: the 9 .. 32-column kernel), or nullptr
 uint64_t decode_copy_epoch();  // bumped whenever a copy was dropped: graphs captured before hold pointers to it
 bool buffer_is_ours(ggml_backend_buffer_t b);
 bool buffer_is_rowpar(ggml_backend_buffer_t b);

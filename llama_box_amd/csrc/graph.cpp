@@ -383,14 +383,15 @@ static bool single_use(const exec_state & st, const ggml_tensor * t) { return us
 
 // returns the device pointer of src1 quantised for weight type `wtype`, quantising only if the scratch does not
 // already hold exactly this tensor (Q/K/V and gate/up share their input)
-static const void * quantized_src1(exec_state & st, const ggml_tensor * b, int wtype) {
+static const void * quantized_src1(exec_state & st, const ggml_tensor * b, int wtype) {  // (wtype MI_ACT_Q80_PANEL: Q8_0 blocks in the panel order of the 9 .. 32-column kernel)
     backend_ctx * c = st.c;
-    const int kind = act_kind(wtype);
+    const int kind = wtype == MI_ACT_Q80_PANEL ? MI_ACT_Q80_PANEL : act_kind(wtype);
     void * dst = (char *) c->ws + st.act_off;
     if (c->q8_src == b->data && c->q8_kind == kind && c->q8_bytes == ggml_abi_nbytes(b)) return dst;
     {
         timed_scope ts(c, "quantize_act", (double) ggml_abi_nbytes(b));
-        launch_quantize_act(c->stream, kind, TD(b), dst);
+        if (kind == MI_ACT_Q80_PANEL) launch_quantize_q80_panel(c->stream, TD(b), dst);
+        else launch_quantize_act(c->stream, kind, TD(b), dst);
         c->st.kernel_launches++;
     }
     c->q8_src = b->data;
@@ -487,7 +488,19 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         c->st.kernel_launches++;
         return true;
     }
-    const void * act = quantized_src1(st, b, w->type);
+    const bool q80_skinny = w->type == GGML_TYPE_Q8_0 && !w2 && !add2 && mmq_q80_skinny_supported(w->type, K, N, M);
+    const void * act = quantized_src1(st, b, q80_skinny ? MI_ACT_Q80_PANEL : w->type);
+    if (q80_skinny) {  // 9 .. 32 columns of a -np decode step (round 6)
+        const uint8_t * wp = q80_panel_copy(c, w);
+        c->st.decode_copy_launches += wp != nullptr;
+        timed_scope ts(c, "mmq_q8_0_skinny", wbytes);
+        const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
+        launch_mmq_q80_skinny(c->stream, (const uint8_t *) w->data, wp, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4),
+                              add ? (const float *) add->data : nullptr, (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4));
+        c->st.kernel_launches++;
+        c->st.skinny_launches++;
+        return true;
+    }
     if (w->type == GGML_TYPE_Q8_0 && M >= c->opt.q80_min_cols && !w2 && !add2 && mmq_q80_supported(w->type, K, N, M)) {
         timed_scope ts(c, "mmq_q8_0", wbytes);
         const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
@@ -1661,7 +1674,7 @@ static int run_node(exec_state & st, int i) {
                 if (used != 0) return used;
             }
             if (fuse && !rowpar && ((M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) ||
-                                    (M >= c->opt.q80_min_cols && mmq_q80_supported(a->type, a->ne[0], a->ne[1], M)))) {
+                                    (M >= c->opt.q80_min_cols && mmq_q80_supported(a->type, a->ne[0], a->ne[1], M)) || mmq_q80_skinny_supported(a->type, a->ne[0], a->ne[1], M))) {
                 // batches: MUL_MAT -> ADD (bias row or residual) rides in the GEMM's store
                 ggml_tensor * a1 = next(1);
                 const ggml_tensor * o1 = (a1 && single_use(st, n)) ? add_partner(a1, n) : nullptr;

@@ -27,6 +27,9 @@ inline tdesc TD(const ggml_tensor * t) {
 // kind: GGML_TYPE_Q8_K -> q8k_dev[rows][K/256]; GGML_TYPE_Q8_0 -> q80_dev[rows][K/32]
 size_t quantized_act_bytes(int kind, int64_t K, int64_t rows);
 void launch_quantize_act(hipStream_t s, int kind, const tdesc & src, void * dst);
+// Q8_0 activations of up to 32 columns in PANEL order (mmq_q80.hip: k_mmq_q80_skinny): per block of 32 values [K half][column 0 .. 31][16 quants] + [column] f32 scales, 1152 B
+#define MI_ACT_Q80_PANEL 1008
+void launch_quantize_q80_panel(hipStream_t s, const tdesc & src, void * dst);
 
 // ---- bandwidth-bound quantised mat-vec, 1..8 activation columns (mmvq.hip)
 struct mmvq_args {
@@ -200,6 +203,9 @@ int mmq_skinny_ksplit(int64_t K, int64_t n_total);
 // Q8_0 weights x Q8_0 activations, one int8 MFMA per 32-value block + immediate f32 scale-accumulate (mmq_q80.hip)
 bool mmq_q80_supported(int type, int64_t K, int64_t N, int64_t M);
 void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
+// 9 .. 32 columns: the weights streamed once, 32-row panels, K split over the waves of a workgroup (mmq_q80.hip; round 6)
+bool mmq_q80_skinny_supported(int type, int64_t K, int64_t N, int64_t M);
+void launch_mmq_q80_skinny(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80_panel, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int ksplit, float * part);
 
 // ---- element-wise / normalisation / data movement (ops.hip)
@@ -326,6 +332,8 @@ void launch_flash_attn_combine(hipStream_t s, int D, const float * ws, const flo
 // ---- the decode copy (repack.hip): rows [r0, r0 + n_rows) of a K-quant [K, N] matrix from the block layout at `src` into the plane layout at `dst` (same row stride)
 bool repack_supported(int type, int64_t K, int64_t nb1);
 void launch_repack_planes(hipStream_t s, int type, const void * src, void * dst, int64_t K, int64_t nb1, int64_t r0, int64_t n_rows);
+bool repack_q80_supported(int type, int64_t K, int64_t N, int64_t nb1);  // Q8_0: the panel copy of the 9 .. 32-column matrix-core kernel (repack.hip)
+void launch_repack_q80_panels(hipStream_t s, const void * src, void * dst, int64_t K, int64_t N, int64_t nb1);
 
 // ---- code-object preload (round 4).  The HIP runtime loads a translation unit's device code on the FIRST launch of one of its kernels
 // (0.3 - 2 ms each, measured as idle gaps in front of the first prompt's kernels: 5.5 ms of a 64 ms prefill).  Every kernel file ends with

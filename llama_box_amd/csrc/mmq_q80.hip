@@ -9,6 +9,7 @@
 // Tile 128 weight rows x 128 columns x 128 K (4 blocks) per trip, 8 waves (32 x 64 each), double-buffered LDS: raw int8 of
 // both operands in the XOR-swizzled [row][128 B] image of mmq_i8.hip plus the 4 block scales of every row / column.
 #include <algorithm>
+#include <cstdlib>
 
 #include "dev_util.h"
 #include "kernels.h"
@@ -168,6 +169,138 @@ void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int 
     (void) ensure_dyn_lds((const void *) k_mmq_q80, lds, lds_raised);  // on failure the launch below fails and graph_compute reports it
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
     hipLaunchKernelGGL(k_mmq_q80, dim3(grid), dim3(512), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------ 9 .. 32 columns (round 6)
+// A -np decode step of a Q8_0 model: until this round every such mat-mul ran as 8-column mat-vec passes (the weights streamed once per pass, the dot products
+// on the vector ALU: 61 us per matrix of Llama-3-8B Q8_0 at 32 columns, a 16 ms step) and the 128 x 128-tile GEMM above has too few workgroups for 32 columns
+// (97 us).  Here the WEIGHTS stream once: a workgroup owns 32 weight rows, its eight waves take the K range in interleaved chunks of four blocks (128 values:
+// one cache line of every row), one v_mfma_i32_32x32x32_i8 per block gives the 32 x 32 integer block sums, and the f32 scale-accumulate follows as in the GEMM
+// (sumf += sumi * (d_w * d_x), ggml_vec_dot_q8_0_q8_0's expression).  Weight bytes go from global memory straight into the MFMA operand registers (a lane = a
+// row and a 16-value half of the block, 2-byte aligned 16-byte loads); the activations' blocks (32 columns x K / 32 x 36 B: L2-resident) likewise; the 32 row
+// scales of a block reach the 16 accumulator rows of a lane through a wave-private LDS line.  The eight partial tiles meet in LDS and are added in wave order.
+struct mmq80s_args {
+    const uint8_t * W;   // the tensor (block layout), or its panel copy (repack.hip: k_repack_q80_panels) — template WP
+    int64_t w_nb1;
+    int K, N, M;
+    const char * act;    // the activations in panel order (quantize.hip: k_quantize_q8_0<true>): 1152 B per block
+    float * dst;
+    int64_t dst_stride;
+    const float * add;
+    int64_t add_stride;
+};
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(2))) q80s_u32x4_a2;
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) q80s_u32x4_a4;
+
+constexpr int Q80S_WV = 8;
+template <bool WP> __global__ void __launch_bounds__(Q80S_WV * 64, 2) k_mmq_q80_skinny(const mmq80s_args a) {
+    constexpr bool PF = true;
+    __shared__ float dwl[Q80S_WV][4][32];       // a chunk's row scales, per wave
+    __shared__ float red[Q80S_WV][16][64];      // the waves' partial tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, kg = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int nblk = a.K / 32, nchunk = nblk / 4;
+    const uint8_t * wrow = WP ? a.W + (size_t) blockIdx.x * nchunk * 4352 : a.W + (size_t) min(n0 + fr, a.N - 1) * a.w_nb1;
+    const int colc = min(fr, a.M - 1);
+    float C[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C[r] = 0.0f;
+    int16q zi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zi[r] = 0;
+
+    int4q fa[4], fb[4], nfa[4], nfb[4];
+    uint16_t dw[4], ndw[4];
+    float dy[4], ndy[4];
+    auto load_chunk = [&](const int c, int4q * A, int4q * B, uint16_t * dW, float * dY) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if constexpr (WP) {  // the chunk's tile of the panel copy: a wave-instruction reads 1 KB of consecutive bytes
+                const uint8_t * tile = wrow + (size_t) c * 4352;
+                A[b] = *(const int4q *) (tile + b * 1024 + kg * 512 + fr * 16);
+                dW[b] = *(const uint16_t *) (tile + 4096 + b * 64 + fr * 2);
+            } else {
+                const uint8_t * blk = wrow + (size_t) (c * 4 + b) * 34;
+                dW[b] = ld16(blk);
+                A[b] = __builtin_bit_cast(int4q, *(const q80s_u32x4_a2 *) (blk + 2 + 16 * kg));
+            }
+            const char * yt = a.act + (size_t) (c * 4 + b) * 1152;
+            B[b] = *(const int4q *) (yt + kg * 512 + colc * 16);
+            dY[b] = *(const float *) (yt + 1024 + colc * 4);
+        }
+    };
+    int c = wave;
+    if (c < nchunk) load_chunk(c, fa, fb, dw, dy);
+    for (; c < nchunk; c += Q80S_WV) {
+        const int cn = c + Q80S_WV;
+        if constexpr (PF) { if (cn < nchunk) load_chunk(cn, nfa, nfb, ndw, ndy); }
+        // the block scales of the 32 rows: written by the row's first lane, read back as the 16 rows of this lane's accumulator registers
+        if (kg == 0) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dwl[wave][b][fr] = h2f(dw[b]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            float x[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v = *(const float4 *) &dwl[wave][b][8 * g4 + 4 * kg];
+                x[4 * g4] = v.x; x[4 * g4 + 1] = v.y; x[4 * g4 + 2] = v.z; x[4 * g4 + 3] = v.w;
+            }
+            const int16q s = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[b], fb[b], zi, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) C[r] += (float) s[r] * (x[r] * dy[b]);  // sumf += sumi * (d_w * d_x), as the CPU does
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the next chunk's scales overwrite the line)
+        if (cn < nchunk) {
+            if constexpr (PF) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { fa[b] = nfa[b]; fb[b] = nfb[b]; dw[b] = ndw[b]; dy[b] = ndy[b]; }
+            } else {
+                load_chunk(cn, fa, fb, dw, dy);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = C[r];
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += Q80S_WV * 64) {
+        const int r = e >> 6, l = e & 63;
+        float v = red[0][r][l];
+#pragma unroll
+        for (int w = 1; w < Q80S_WV; ++w) v += red[w][r][l];
+        const int m = l & 31, n = n0 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+        if (m < a.M && n < a.N) {
+            if (a.add) v += a.add[(size_t) m * a.add_stride + n];
+            a.dst[(size_t) m * a.dst_stride + n] = v;
+        }
+    }
+}
+
+bool mmq_q80_skinny_supported(int type, int64_t K, int64_t N, int64_t M) {
+    static const bool on = !getenv("GGML_MI355X_Q80_SKINNY") || atoi(getenv("GGML_MI355X_Q80_SKINNY")) != 0;
+    return on && type == GGML_TYPE_Q8_0 && (K % 128) == 0 && N >= 1 && M >= 9 && M <= 32;
+}
+void launch_mmq_q80_skinny(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add,
+                           int64_t add_stride) {
+    mmq80s_args a;
+    a.W = W_panels ? W_panels : W;
+    a.w_nb1 = w_nb1;
+    a.K = K;
+    a.N = N;
+    a.M = M;
+    a.act = (const char *) act_q80;
+    a.dst = dst;
+    a.dst_stride = dst_stride;
+    a.add = add;
+    a.add_stride = add_stride;
+    if (W_panels) hipLaunchKernelGGL(k_mmq_q80_skinny<true>, dim3((unsigned) ((N + 31) / 32)), dim3(Q80S_WV * 64), 0, s, a);
+    else hipLaunchKernelGGL(k_mmq_q80_skinny<false>, dim3((unsigned) ((N + 31) / 32)), dim3(Q80S_WV * 64), 0, s, a);
 }
 
 MI_TU_TOUCH(mmq_q80)

@@ -536,9 +536,37 @@ template <typename T> static void launch_type(hipStream_t s, const mmvq_args & a
         return;
     }
     // activations are laid out [ncols][nblk]; the column loop runs templates of exactly 8/4/2/1 columns
+    // Q8_0 weights (no weight-streaming matrix-core kernel for 2 .. 32 columns: mmq_skinny.hip serves the K-quants): 16 or 32 columns in ONE pass when their Q8_0
+    // blocks fit the LDS (up to 144 KB, on 16-wave workgroups so that a CU still holds 16 waves) — a -np 32 step used to stream every Q8_0 matrix four times
+    // (TinyLlama: 55 % of the step in k_mmvq<T_Q80, 8>, profiles/r06_ab_fa_dec64.txt); same dot products per column, same f32 order
+    static const int wide_cols = getenv("GGML_MI355X_Q80_WIDE_COLS") ? atoi(getenv("GGML_MI355X_Q80_WIDE_COLS")) : 1;
     int done = 0;
     while (done < a0.ncols) {
         const int left = a0.ncols - done;
+        if constexpr (std::is_same<T, T_Q80>::value) {
+            if (wide_cols && !glu && left >= 12) {
+                const int ncw = (left >= 24 && (size_t) 32 * nblk * sizeof(typename T::act) <= 144 * 1024) ? 32 : ((size_t) 16 * nblk * sizeof(typename T::act) <= 144 * 1024 ? 16 : 0);
+                if (ncw) {
+                    const int take = std::min(left, ncw);  // (the kernel computes ncw columns; a.ncols says how many exist)
+                    a.ncols = take;
+                    a.act = (const char *) a0.act + (size_t) done * nblk * sizeof(typename T::act);
+                    a.dst = a0.dst + (size_t) done * a0.dst_stride;
+                    a.add = a0.add ? a0.add + (size_t) done * a0.add_stride : nullptr;
+                    a.add2 = a0.add2 ? a0.add2 + (size_t) done * a0.add2_stride : nullptr;
+                    const size_t lds = (size_t) ncw * nblk * sizeof(typename T::act);  // (the dot products walk all ncw columns; only `take` of them are copied in and stored)
+                    static std::atomic<uint32_t> raised16{0}, raised32{0};
+                    if (ncw == 32) {
+                        (void) ensure_dyn_lds((const void *) k_mmvq<T, 32, 1, false, 0, 16>, lds, raised32);
+                        launch_one<T, 32, 1, false, 0, 16>(s, a, lds);
+                    } else {
+                        (void) ensure_dyn_lds((const void *) k_mmvq<T, 16, 1, false, 0, 16>, lds, raised16);
+                        launch_one<T, 16, 1, false, 0, 16>(s, a, lds);
+                    }
+                    done += take;
+                    continue;
+                }
+            }
+        }
         const int nc = left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
         a.ncols = nc;
         a.act = (const char *) a0.act + (size_t) done * nblk * sizeof(typename T::act);

@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(64) k_quantize_q8_K(const char * __restrict__ 
 }
 
 // Q8_0 activations: 8 lanes per 32-element block; d = amax/127 stored through fp16; q = roundf(x * (1/d))
+template <bool PANEL>
 __global__ void __launch_bounds__(64) k_quantize_q8_0(const char * __restrict__ src, int64_t ne1, int64_t ne2, int64_t nb1, int64_t nb2,
                                                       int64_t nb3, int K, int chunks_per_row, q80_dev * __restrict__ dst) {
     const int64_t gid = blockIdx.x;
@@ -51,15 +52,22 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const char * __restrict__ 
     const float d = amax / 127.0f;
     const float id = d != 0.0f ? 1.0f / d : 0.0f;
     if (!live) return;
-    q80_dev * y = dst + row * (int64_t) (K / 32) + (e0 >> 5);
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = (int) roundf(v[k] * id);
         packed |= (uint32_t) (r & 0xFF) << (8 * k);
     }
-    ((uint32_t *) y->qs)[lane & 7] = packed;
-    if ((lane & 7) == 0) y->d = h2f(f2h(d));
+    if constexpr (PANEL) {  // (row < 32: the launcher checks) the block's tile: [K half][column][16 quants], then the 32 columns' scales
+        char * tile = (char *) dst + (size_t) (e0 >> 5) * 1152;
+        const int w8 = lane & 7;
+        *(uint32_t *) (tile + (w8 >> 2) * 512 + row * 16 + (w8 & 3) * 4) = packed;
+        if (w8 == 0) *(float *) (tile + 1024 + row * 4) = h2f(f2h(d));
+    } else {
+        q80_dev * y = dst + row * (int64_t) (K / 32) + (e0 >> 5);
+        ((uint32_t *) y->qs)[lane & 7] = packed;
+        if ((lane & 7) == 0) y->d = h2f(f2h(d));
+    }
 }
 
 // ---- producers fused with the quantisation (batches: the f32 intermediate is never written).  Same f32 arithmetic as the
@@ -168,8 +176,15 @@ void launch_quantize_act(hipStream_t s, int kind, const tdesc & src, void * dst)
         hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (rows * nb)), dim3(64), 0, s, src.data, src.ne[1], src.ne[2], src.nb[1], src.nb[2], src.nb[3], nb, (q8k_dev *) dst);
     } else {
         const int chunks = (int) ((K + 255) / 256);
-        hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) (rows * chunks)), dim3(64), 0, s, src.data, src.ne[1], src.ne[2], src.nb[1], src.nb[2], src.nb[3], (int) K, chunks, (q80_dev *) dst);
+        hipLaunchKernelGGL(k_quantize_q8_0<false>, dim3((unsigned) (rows * chunks)), dim3(64), 0, s, src.data, src.ne[1], src.ne[2], src.nb[1], src.nb[2], src.nb[3], (int) K, chunks, (q80_dev *) dst);
     }
+}
+void launch_quantize_q80_panel(hipStream_t s, const tdesc & src, void * dst) {
+    const int64_t K = src.ne[0];
+    const int64_t rows = src.ne[1] * src.ne[2] * src.ne[3];
+    if (rows > 32 || rows < 1 || (K % 32) != 0) { MI_ERR("launch_quantize_q80_panel: %lld columns / K = %lld", (long long) rows, (long long) K); abort(); }
+    const int chunks = (int) ((K + 255) / 256);
+    hipLaunchKernelGGL(k_quantize_q8_0<true>, dim3((unsigned) (rows * chunks)), dim3(64), 0, s, src.data, src.ne[1], src.ne[2], src.nb[1], src.nb[2], src.nb[3], (int) K, chunks, (q80_dev *) dst);
 }
 
 MI_TU_TOUCH(quantize)

@@ -82,6 +82,30 @@ void launch_repack_planes(hipStream_t s, int type, const void * src, void * dst,
     }
 }
 
+// ---- Q8_0: the PANEL copy read by the 9 .. 32-column matrix-core kernel (mmq_q80.hip: k_mmq_q80_skinny).  Same bytes as the tensor (N x K / 32 x 34), regrouped per
+// (panel of 32 rows, chunk of 4 blocks) into a tile of 4352 bytes: [block 0 .. 3][K half 0 / 1][row 0 .. 31][16 quants] (4 KB: a wave-instruction's operand load is
+// 1 KB of consecutive bytes) + [block][row] f16 scales (256 B).  Rows a multiple of 32, K a multiple of 128, rows densely packed.
+__global__ void __launch_bounds__(256) k_repack_q80_panels(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, const int nchunk, const int64_t nb1) {
+    // grid.x = chunk, grid.y = panel; thread t: (block b = t / 64, half kg = (t / 32) & 1, row fr = t % 32)
+    const int t = threadIdx.x, b = t >> 6, kg = (t >> 5) & 1, fr = t & 31;
+    const uint8_t * blk = src + (size_t) (blockIdx.y * 32 + fr) * nb1 + (size_t) (blockIdx.x * 4 + b) * 34;
+    uint8_t * tile = dst + ((size_t) blockIdx.y * nchunk + blockIdx.x) * 4352;
+    piece16 v = ld_piece_a2(blk + 2 + 16 * kg);
+    st_piece_a2(tile + b * 1024 + kg * 512 + fr * 16, v);
+    if (kg == 0) *(uint16_t *) (tile + 4096 + b * 64 + fr * 2) = *(const uint16_t *) blk;
+}
+bool repack_q80_supported(int type, int64_t K, int64_t N, int64_t nb1) {
+    return type == GGML_TYPE_Q8_0 && K > 0 && (K % 128) == 0 && N > 0 && (N % 32) == 0 && nb1 == (K / 32) * 34;
+}
+void launch_repack_q80_panels(hipStream_t s, const void * src, void * dst, int64_t K, int64_t N, int64_t nb1) {
+    const int nchunk = (int) (K / 128);
+    const int64_t panels = N / 32;
+    for (int64_t p0 = 0; p0 < panels; p0 += 32768) {  // (grid.y limit)
+        const unsigned np = (unsigned) std::min<int64_t>(32768, panels - p0);
+        hipLaunchKernelGGL(k_repack_q80_panels, dim3((unsigned) nchunk, np), dim3(256), 0, s, (const uint8_t *) src + (size_t) p0 * 32 * nb1, (uint8_t *) dst + (size_t) p0 * nchunk * 4352, nchunk, nb1);
+    }
+}
+
 MI_TU_TOUCH(repack)
 
 }  // namespace mi355x

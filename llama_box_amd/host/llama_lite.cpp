@@ -308,6 +308,7 @@ extern "C" int llm_preset(const char * name, struct llm_hparams * hp) {
     else if (n == "qwen2-7b-q5_k_m") set("qwen2", 28, 3584, 28, 4, 128, 18944, 152064, 32768, 1000000.0f, 1e-6f, GGML_ROPE_TYPE_NEOX, 1, LLM_FTYPE_Q5_K_M);
     // shapes of other families a llama-box user brings (round 6): multi-head attention (1 query head per KV head), 3 query heads per KV head on rows of 12 / 32
     // super-blocks, head_dim 64 with 4 query heads per KV head
+    else if (n == "llama3-8b-q8_0") set("llama", 32, 4096, 32, 8, 128, 14336, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q8_0);
     else if (n == "llama2-7b-q4_k_m") set("llama", 32, 4096, 32, 32, 128, 11008, 32000, 4096, 10000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M);
     else if (n == "llama3.2-3b-q4_k_m") set("llama", 28, 3072, 24, 8, 128, 8192, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M);
     else if (n == "llama3.2-1b-q4_k_m") set("llama", 16, 2048, 32, 8, 64, 8192, 128256, 8192, 500000.0f, 1e-5f, 0, 0, LLM_FTYPE_Q4_K_M);

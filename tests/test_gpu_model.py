@@ -807,6 +807,93 @@ def test_mat_vecs_over_the_decode_copy_are_bit_equal_and_follow_a_rewritten_weig
     assert not np.array_equal(outs[1][0][8], outs[1][0][9])
 
 
+def _np_q80_panels(raw, K, N):
+    """The panel copy of a Q8_0 matrix (csrc/repack.hip: k_repack_q80_panels), written with numpy: per (32 rows, 4 blocks) a 4352-byte tile
+    [block][K half][row][16 quants] + [block][row] f16 scales."""
+    nblk = K // 32
+    blocks = raw.reshape(N, nblk, 34)
+    out = []
+    for p in range(N // 32):
+        for c in range(nblk // 4):
+            t = blocks[32 * p: 32 * p + 32, 4 * c: 4 * c + 4]            # [row][block][34]
+            qs = t[:, :, 2:].reshape(32, 4, 2, 16)                          # [row][block][half][16]
+            out.append(np.ascontiguousarray(qs.transpose(1, 2, 0, 3)).reshape(-1))
+            out.append(np.ascontiguousarray(t[:, :, :2].transpose(1, 0, 2)).reshape(-1))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("K,N", [(128, 32), (2048, 64), (4096, 96), (5632, 32)])
+def test_q8_0_panel_copy_is_the_documented_permutation(backend, H, K, N):
+    """csrc/repack.hip: k_repack_q80_panels against a numpy statement of the tile layout, byte for byte; the tensor itself still reads back as uploaded; a matrix
+    whose rows are not a multiple of 32 (or K of 128) has no panel copy."""
+    rng = np.random.default_rng(K + N)
+    raw = T.rand_weight(L.Q8_0, K, N, rng)
+    fn = backend.proc("ggml_backend_mi355x_decode_copy_read", C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t])
+    for (k2, n2, want_copy) in ((K, N, True), (K, N + 1, False), (K + 32, N, False)):
+        r2 = raw if want_copy else T.rand_weight(L.Q8_0, k2, n2, rng)
+        ctx = H.ggml_init(L.InitParams(0, None, True))
+        t = H.ggml_new_tensor_2d(ctx, L.Q8_0, k2, n2)
+        buf = H.ggml_backend_alloc_ctx_tensors_from_buft(ctx, backend.buft)
+        assert buf
+        try:
+            H.ggml_backend_buffer_set_usage(buf, 1)  # GGML_BACKEND_BUFFER_USAGE_WEIGHTS
+            H.ggml_backend_tensor_set(t, r2.ctypes.data_as(C.c_void_p), 0, r2.nbytes)
+            got = np.empty(r2.nbytes, np.uint8)
+            n = fn(backend.backend, t, got.ctypes.data_as(C.c_void_p), got.nbytes)
+            if want_copy:
+                assert n == r2.nbytes
+                assert np.array_equal(got, _np_q80_panels(r2.reshape(n2, -1), k2, n2))
+                back = np.empty(r2.nbytes, np.uint8)
+                H.ggml_backend_tensor_get(t, back.ctypes.data_as(C.c_void_p), 0, back.nbytes)
+                assert np.array_equal(back, r2.reshape(-1))
+            else:
+                assert n == 0
+        finally:
+            H.ggml_backend_buffer_free(buf)
+            H.ggml_free(ctx)
+
+
+def test_q8_0_model_batches_over_the_panel_copy_are_bit_equal(backend, H, plog):
+    """A Q8_0 model decoding 16 sequences per step (the 9 .. 32-column matrix-core kernel, csrc/mmq_q80.hip): with the panel copies of its weights and without
+    (option decode_copy) the logits are the same bits — a lane receives the same operand registers from either layout — eagerly and as replayed hipGraphs;
+    against the oracle within the usual gate."""
+    hp = preset("test-llama", ftype=preset("tinyllama-1.1b-q8_0").ftype, n_embd=512, n_head=8, n_head_kv=2, n_embd_head=64, n_ff=1536, n_vocab=1024, n_layer=2)
+    n_par, n_prompt, n_steps = 16, 6, 10
+    rng = np.random.default_rng(5)
+    toks = rng.integers(1, hp.n_vocab, n_par * n_prompt).tolist()
+    rows = [rng.integers(1, hp.n_vocab, n_par).tolist() for _ in range(n_steps)]
+    outs = {}
+    mc = Model(hp, 21, H.ggml_backend_cpu_buffer_type())
+    try:
+        for mode in (1, 0):
+            backend.set_option("decode_copy", mode)
+            mg = Model(hp, 21, backend.buft)
+            s0 = {k: backend.stat(k) for k in ("decode_copy_launches", "decode_copy_tensors", "skinny_launches")}
+            c = Context(mg, backend=backend, flash_attn=1, n_ctx=1024)
+            rc, _ = c.decode(toks, [i for _ in range(n_par) for i in range(n_prompt)], [k for k in range(n_par) for _ in range(n_prompt)], ([0] * (n_prompt - 1) + [1]) * n_par)
+            assert rc == 0
+            lg = []
+            for i in range(n_steps):
+                rc, l1 = c.decode(rows[i], [n_prompt + i] * n_par, seq=list(range(n_par)))
+                assert rc == 0
+                lg.append(l1)
+            outs[mode] = (np.stack(lg), {k: backend.stat(k) - v for k, v in s0.items()})
+            c.free()
+            mg.free()
+        cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=1, n_ctx=1024)
+        rc, _ = cc.decode(toks, [i for _ in range(n_par) for i in range(n_prompt)], [k for k in range(n_par) for _ in range(n_prompt)], ([0] * (n_prompt - 1) + [1]) * n_par)
+        ref = np.stack([cc.decode(rows[i], [n_prompt + i] * n_par, seq=list(range(n_par)))[1] for i in range(n_steps)])
+        cc.free()
+    finally:
+        backend.set_option("decode_copy", 1)
+        mc.free()
+    plog(f"Q8_0 model, 16 sequences a step: panel copies on {outs[1][1]}, off {outs[0][1]}; nmse vs oracle {T.nmse(outs[1][0], ref):.3e}")
+    assert outs[1][1]["decode_copy_tensors"] > 0 and outs[1][1]["decode_copy_launches"] > 0 and outs[1][1]["skinny_launches"] > 0
+    assert outs[0][1]["decode_copy_launches"] == 0 and outs[0][1]["skinny_launches"] > 0
+    assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
+    assert T.nmse(outs[1][0], ref) <= 1e-3
+
+
 def test_no_room_for_a_decode_copy_keeps_the_block_layout(backend, H, plog):
     """The decode copy is an optimisation that costs device memory: when less than the weights buffer's size + the headroom is free it is not made (logged once per
     buffer), the mat-vec kernels read the block layout, and the logits are the same bits.  Option decode_copy_headroom_gib set beyond the device's memory forces that."""

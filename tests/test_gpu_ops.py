@@ -69,6 +69,36 @@ def test_mul_mat_q_multi_column_mat_vec(backend, H, plog, qt, K, N, M):
     T.compare(f"mul_mat multi-column mat-vec {QNAME[qt]} K={K} N={N} M={M}", got[0], ref[0], max_nmse=1e-10, log=plog)
 
 
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("K,N,M", [(2048, 70, 32), (2048, 33, 24), (5632, 40, 32), (4096, 64, 13), (4096, 48, 20), (11008, 20, 32), (256, 19, 12), (2048, 2050, 31), (128, 7, 9), (14336, 96, 32),
+                                   (2080, 33, 24), (1056, 40, 32), (4128, 16, 13), (11040, 20, 32)])
+def test_mul_mat_q8_0_9_to_32_columns(backend, H, plog, K, N, M, bias):
+    """Q8_0 weights, 9 .. 32 columns (a -np decode step of a Q8_0 model; round 6).  K a multiple of 128: the weight-streaming matrix-core kernel (mmq_q80.hip:
+    k_mmq_q80_skinny — 32-row panels, K split over eight waves, one MFMA per block, f32 scale-accumulate in ggml-cpu's expression).  Other K (whole Q8_0 blocks only):
+    16 or 32 columns in ONE pass of the multi-column mat-vec kernel when their blocks fit the LDS — bit-equal to the same columns computed 8 at a time (same dot
+    products per column, same f32 order).  Both against the oracle; bias / residual ADD folded into the store."""
+    rng = np.random.default_rng(K + 3 * N + M)
+    w = T.rand_weight(L.Q8_0, K, N, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    x[1, :32] = 0.0
+    b = rng.standard_normal(N).astype(np.float32)
+
+    def build_cols(c0, c1):
+        def build(g):
+            r = H.ggml_mul_mat(g.ctx, g.new(L.Q8_0, [K, N], w), g.new(L.F32, [K, c1 - c0], x[c0:c1]))
+            return H.ggml_add(g.ctx, r, g.new(L.F32, [N], b)) if bias else r
+        return build
+
+    s0 = backend.stat("skinny_launches")
+    ref, got = both(build_cols(0, M), backend)
+    served = backend.stat("skinny_launches") - s0
+    T.compare(f"mul_mat q8_0 K={K} N={N} M={M} bias={bias} ({'matrix cores' if served else 'wide mat-vec passes'})", got[0], ref[0], max_nmse=1e-10, log=plog)
+    assert served == (1 if K % 128 == 0 else 0)
+    if not served:
+        by8 = np.concatenate([T.run_case(build_cols(c, min(M, c + 8)), backend)[0].reshape(-1, N) for c in range(0, M, 8)])
+        assert np.array_equal(got[0].reshape(-1, N).view(np.uint32), by8.view(np.uint32))
+
+
 @pytest.mark.parametrize("i8,bn", [(1, 64), (1, 128), (0, 0)])
 @pytest.mark.parametrize("qt", [L.Q4_K, L.Q5_K, L.Q6_K])
 @pytest.mark.parametrize("K,N,M", [(512, 128, 128), (1024, 200, 300), (2048, 384, 512), (256, 130, 33), (4096, 256, 24), (512, 200, 64), (1024, 96, 9), (2048, 384, 40), (4096, 1024, 32)])
