@@ -284,7 +284,8 @@ template <bool WP> __global__ void __launch_bounds__(Q80S_WV * 64, 2) k_mmq_q80_
 
 bool mmq_q80_skinny_supported(int type, int64_t K, int64_t N, int64_t M) {
     static const bool on = !getenv("GGML_MI355X_Q80_SKINNY") || atoi(getenv("GGML_MI355X_Q80_SKINNY")) != 0;
-    return on && type == GGML_TYPE_Q8_0 && (K % 128) == 0 && N >= 1 && M >= 9 && M <= 32;
+    static const int max_cols = getenv("GGML_MI355X_Q80_SKINNY_MAX") ? atoi(getenv("GGML_MI355X_Q80_SKINNY_MAX")) : 128;  // (up to 128 columns: four passes of 32 still beat the 128 x 128-tile GEMM's few workgroups — Llama-3-8B Q8_0, 128-token micro-batches: 8.5 k against 5.1 k tok/s)
+    return on && type == GGML_TYPE_Q8_0 && (K % 128) == 0 && N >= 1 && M >= 9 && M <= std::min(max_cols, 128);
 }
 void launch_mmq_q80_skinny(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add,
                            int64_t add_stride) {
@@ -299,8 +300,14 @@ void launch_mmq_q80_skinny(hipStream_t s, const uint8_t * W, const uint8_t * W_p
     a.dst_stride = dst_stride;
     a.add = add;
     a.add_stride = add_stride;
-    if (W_panels) hipLaunchKernelGGL(k_mmq_q80_skinny<true>, dim3((unsigned) ((N + 31) / 32)), dim3(Q80S_WV * 64), 0, s, a);
-    else hipLaunchKernelGGL(k_mmq_q80_skinny<false>, dim3((unsigned) ((N + 31) / 32)), dim3(Q80S_WV * 64), 0, s, a);
+    for (int m0 = 0; m0 < M; m0 += 32) {  // groups of 32 columns: the activations' panel tiles of group g follow those of group g - 1 (quantize.hip)
+        a.M = std::min(32, M - m0);
+        a.act = (const char *) act_q80 + (size_t) (m0 / 32) * (size_t) (K / 32) * 1152;
+        a.dst = dst + (size_t) m0 * dst_stride;
+        a.add = add ? add + (size_t) m0 * add_stride : nullptr;
+        if (W_panels) hipLaunchKernelGGL(k_mmq_q80_skinny<true>, dim3((unsigned) ((N + 31) / 32)), dim3(Q80S_WV * 64), 0, s, a);
+        else hipLaunchKernelGGL(k_mmq_q80_skinny<false>, dim3((unsigned) ((N + 31) / 32)), dim3(Q80S_WV * 64), 0, s, a);
+    }
 }
 
 MI_TU_TOUCH(mmq_q80)

@@ -58,11 +58,11 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const char * __restrict__ 
         const int r = (int) roundf(v[k] * id);
         packed |= (uint32_t) (r & 0xFF) << (8 * k);
     }
-    if constexpr (PANEL) {  // (row < 32: the launcher checks) the block's tile: [K half][column][16 quants], then the 32 columns' scales
-        char * tile = (char *) dst + (size_t) (e0 >> 5) * 1152;
-        const int w8 = lane & 7;
-        *(uint32_t *) (tile + (w8 >> 2) * 512 + row * 16 + (w8 & 3) * 4) = packed;
-        if (w8 == 0) *(float *) (tile + 1024 + row * 4) = h2f(f2h(d));
+    if constexpr (PANEL) {  // the block's tile: [K half][column][16 quants], then the 32 columns' scales
+        char * tile = (char *) dst + ((size_t) (row >> 5) * (size_t) (K / 32) + (size_t) (e0 >> 5)) * 1152;  // (columns in groups of 32, a group's tiles together)
+        const int w8 = lane & 7, cr = (int) (row & 31);
+        *(uint32_t *) (tile + (w8 >> 2) * 512 + cr * 16 + (w8 & 3) * 4) = packed;
+        if (w8 == 0) *(float *) (tile + 1024 + cr * 4) = h2f(f2h(d));
     } else {
         q80_dev * y = dst + row * (int64_t) (K / 32) + (e0 >> 5);
         ((uint32_t *) y->qs)[lane & 7] = packed;
@@ -182,7 +182,7 @@ void launch_quantize_act(hipStream_t s, int kind, const tdesc & src, void * dst)
 void launch_quantize_q80_panel(hipStream_t s, const tdesc & src, void * dst) {
     const int64_t K = src.ne[0];
     const int64_t rows = src.ne[1] * src.ne[2] * src.ne[3];
-    if (rows > 32 || rows < 1 || (K % 32) != 0) { MI_ERR("launch_quantize_q80_panel: %lld columns / K = %lld", (long long) rows, (long long) K); abort(); }
+    if (rows > 128 || rows < 1 || (K % 32) != 0) { MI_ERR("launch_quantize_q80_panel: %lld columns / K = %lld", (long long) rows, (long long) K); abort(); }
     const int chunks = (int) ((K + 255) / 256);
     hipLaunchKernelGGL(k_quantize_q8_0<true>, dim3((unsigned) (rows * chunks)), dim3(64), 0, s, src.data, src.ne[1], src.ne[2], src.nb[1], src.nb[2], src.nb[3], (int) K, chunks, (q80_dev *) dst);
 }

@@ -71,9 +71,9 @@ def test_mul_mat_q_multi_column_mat_vec(backend, H, plog, qt, K, N, M):
 
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("K,N,M", [(2048, 70, 32), (2048, 33, 24), (5632, 40, 32), (4096, 64, 13), (4096, 48, 20), (11008, 20, 32), (256, 19, 12), (2048, 2050, 31), (128, 7, 9), (14336, 96, 32),
-                                   (2080, 33, 24), (1056, 40, 32), (4128, 16, 13), (11040, 20, 32)])
+                                   (2080, 33, 24), (1056, 40, 32), (4128, 16, 13), (11040, 20, 32), (2048, 70, 48), (4096, 64, 64), (2048, 40, 33), (5632, 33, 57), (2048, 64, 128), (1024, 33, 97)])
 def test_mul_mat_q8_0_9_to_32_columns(backend, H, plog, K, N, M, bias):
-    """Q8_0 weights, 9 .. 32 columns (a -np decode step of a Q8_0 model; round 6).  K a multiple of 128: the weight-streaming matrix-core kernel (mmq_q80.hip:
+    """Q8_0 weights, 9 .. 32 columns (a -np decode step of a Q8_0 model; round 6; 33 .. 128 columns as passes of 32).  K a multiple of 128: the weight-streaming matrix-core kernel (mmq_q80.hip:
     k_mmq_q80_skinny — 32-row panels, K split over eight waves, one MFMA per block, f32 scale-accumulate in ggml-cpu's expression).  Other K (whole Q8_0 blocks only):
     16 or 32 columns in ONE pass of the multi-column mat-vec kernel when their blocks fit the LDS — bit-equal to the same columns computed 8 at a time (same dot
     products per column, same f32 order).  Both against the oracle; bias / residual ADD folded into the store."""
