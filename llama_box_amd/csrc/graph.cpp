@@ -489,7 +489,11 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         return true;
     }
     const bool q80_skinny = w->type == GGML_TYPE_Q8_0 && !w2 && !add2 && mmq_q80_skinny_supported(w->type, K, N, M);
-    const void * act = quantized_src1(st, b, q80_skinny ? MI_ACT_Q80_PANEL : w->type);
+    // the prompt GEMM over Q8_0 weights reads both operands in panel order when the weights have their panel copy (GGML_MI355X_Q80_GEMM_PANELS=0: as before round 6)
+    static const bool gemm_panels = !getenv("GGML_MI355X_Q80_GEMM_PANELS") || atoi(getenv("GGML_MI355X_Q80_GEMM_PANELS")) != 0;
+    const bool q80_gemm = !q80_skinny && w->type == GGML_TYPE_Q8_0 && M >= c->opt.q80_min_cols && !w2 && !add2 && mmq_q80_supported(w->type, K, N, M);
+    const uint8_t * q80_gemm_wp = (q80_gemm && gemm_panels) ? q80_panel_copy(c, w) : nullptr;
+    const void * act = quantized_src1(st, b, (q80_skinny || q80_gemm_wp) ? MI_ACT_Q80_PANEL : w->type);
     if (q80_skinny) {  // 9 .. 32 columns of a -np decode step (round 6)
         const uint8_t * wp = q80_panel_copy(c, w);
         c->st.decode_copy_launches += wp != nullptr;
@@ -501,10 +505,11 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         c->st.skinny_launches++;
         return true;
     }
-    if (w->type == GGML_TYPE_Q8_0 && M >= c->opt.q80_min_cols && !w2 && !add2 && mmq_q80_supported(w->type, K, N, M)) {
+    if (q80_gemm) {
         timed_scope ts(c, "mmq_q8_0", wbytes);
         const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
-        launch_mmq_q80(c->stream, (const uint8_t *) w->data, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4),
+        c->st.decode_copy_launches += q80_gemm_wp != nullptr;
+        launch_mmq_q80(c->stream, (const uint8_t *) w->data, q80_gemm_wp, (int64_t) w->nb[1], (int) K, (int) N, (int) M, act, (float *) dst->data, (int64_t) (dst->nb[1] / 4),
                        add ? (const float *) add->data : nullptr, (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4));
         c->st.kernel_launches++;
         return true;

@@ -202,7 +202,7 @@ bool mmq_skinny_supported(int type, int64_t K, int64_t N, int64_t M, int64_t w_n
 int mmq_skinny_ksplit(int64_t K, int64_t n_total);
 // Q8_0 weights x Q8_0 activations, one int8 MFMA per 32-value block + immediate f32 scale-accumulate (mmq_q80.hip)
 bool mmq_q80_supported(int type, int64_t K, int64_t N, int64_t M);
-void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
+void launch_mmq_q80(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 // 9 .. 32 columns: the weights streamed once, 32-row panels, K split over the waves of a workgroup (mmq_q80.hip; round 6)
 bool mmq_q80_skinny_supported(int type, int64_t K, int64_t N, int64_t M);
 void launch_mmq_q80_skinny(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80_panel, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);

@@ -37,7 +37,9 @@ constexpr int Q80_STAGE = 2 * Q80_T + 2 * 128 * 16;  // A | B | dw[128][4] | da[
 
 __device__ __forceinline__ int sw_offq(const int row, const int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__global__ void __launch_bounds__(512, 1) k_mmq_q80(const mmq80_args a) {
+// PANEL (round 6): the weights come from their panel copy (repack.hip: k_repack_q80_panels) and the activations in panel order (quantize.hip: k_quantize_q8_0<true>) —
+// a thread's block is two aligned 16-byte loads + its scale instead of eight 2-byte-aligned dwords + the scale, consecutive threads read consecutive bytes
+template <bool PANEL> __global__ void __launch_bounds__(512, 1) k_mmq_q80(const mmq80_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
@@ -56,7 +58,22 @@ __global__ void __launch_bounds__(512, 1) k_mmq_q80(const mmq80_args a) {
     uint32_t ga0, ga1, ga2, ga3, ga4, ga5, ga6, ga7, gb0, gb1, gb2, gb3, gb4, gb5, gb6, gb7;
     uint16_t gad = 0;
     float gbd = 0.0f;
+    // PANEL: the (32 rows, 4 blocks) tile of this thread's row for trip t, and the (block, 32 columns) tile of its column
+    const int wrow_c = min(n0 + srow, a.N - 1), ycol_c = min(m0 + srow, a.M - 1);
+    const uint8_t * wtile = a.W + (size_t) (wrow_c >> 5) * (size_t) trips * 4352 + (size_t) sq * 1024 + (size_t) (wrow_c & 31) * 16;
+    const uint8_t * wtile_d = a.W + (size_t) (wrow_c >> 5) * (size_t) trips * 4352 + 4096 + (size_t) sq * 64 + (size_t) (wrow_c & 31) * 2;
+    const char * ytile = (const char *) a.act + ((size_t) (ycol_c >> 5) * (size_t) nb32 + (size_t) sq) * 1152 + (size_t) (ycol_c & 31) * 16;
     auto issue_loads = [&](const int t) {
+        if constexpr (PANEL) {
+            const uint4 a0 = *(const uint4 *) (wtile + (size_t) t * 4352), a1 = *(const uint4 *) (wtile + (size_t) t * 4352 + 512);
+            ga0 = a0.x; ga1 = a0.y; ga2 = a0.z; ga3 = a0.w; ga4 = a1.x; ga5 = a1.y; ga6 = a1.z; ga7 = a1.w;
+            gad = *(const uint16_t *) (wtile_d + (size_t) t * 4352);
+            const char * yt = ytile + (size_t) t * 4 * 1152;
+            const uint4 b0 = *(const uint4 *) yt, b1 = *(const uint4 *) (yt + 512);
+            gb0 = b0.x; gb1 = b0.y; gb2 = b0.z; gb3 = b0.w; gb4 = b1.x; gb5 = b1.y; gb6 = b1.z; gb7 = b1.w;
+            gbd = *(const float *) (yt + 1024 - (size_t) (ycol_c & 31) * 16 + (size_t) (ycol_c & 31) * 4);
+            return;
+        }
         const uint8_t * p = wblk + (size_t) t * 4 * 34;  // Q8_0 blocks are 2-byte aligned: dword loads typed accordingly
         gad = ld16(p);
         ga0 = ld32_a2(p + 2); ga1 = ld32_a2(p + 6); ga2 = ld32_a2(p + 10); ga3 = ld32_a2(p + 14);
@@ -150,9 +167,10 @@ bool mmq_q80_supported(int type, int64_t K, int64_t N, int64_t M) {
     return type == GGML_TYPE_Q8_0 && (K % 128) == 0 && M >= 9;
 }
 
-void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride) {
+void launch_mmq_q80(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add,
+                    int64_t add_stride) {  // W_panels != nullptr: the panel copy, and act_q80 holds the activations in panel order
     mmq80_args a;
-    a.W = W;
+    a.W = W_panels ? W_panels : W;
     a.w_nb1 = w_nb1;
     a.K = K;
     a.N = N;
@@ -166,9 +184,15 @@ void launch_mmq_q80(hipStream_t s, const uint8_t * W, int64_t w_nb1, int K, int 
     a.add_stride = add_stride;
     const size_t lds = 2 * (size_t) Q80_STAGE;
     static std::atomic<uint32_t> lds_raised{0};  // one bit per device (common.h: ensure_dyn_lds)
-    (void) ensure_dyn_lds((const void *) k_mmq_q80, lds, lds_raised);  // on failure the launch below fails and graph_compute reports it
+    static std::atomic<uint32_t> lds_raised_p{0};
     const unsigned grid = (unsigned) (((a.n_panels + 7) / 8) * 8 * a.m_tiles);
-    hipLaunchKernelGGL(k_mmq_q80, dim3(grid), dim3(512), lds, s, a);
+    if (W_panels) {
+        (void) ensure_dyn_lds((const void *) k_mmq_q80<true>, lds, lds_raised_p);  // on failure the launch below fails and graph_compute reports it
+        hipLaunchKernelGGL(k_mmq_q80<true>, dim3(grid), dim3(512), lds, s, a);
+    } else {
+        (void) ensure_dyn_lds((const void *) k_mmq_q80<false>, lds, lds_raised);
+        hipLaunchKernelGGL(k_mmq_q80<false>, dim3(grid), dim3(512), lds, s, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ 9 .. 32 columns (round 6)

@@ -182,7 +182,7 @@ void launch_quantize_act(hipStream_t s, int kind, const tdesc & src, void * dst)
 void launch_quantize_q80_panel(hipStream_t s, const tdesc & src, void * dst) {
     const int64_t K = src.ne[0];
     const int64_t rows = src.ne[1] * src.ne[2] * src.ne[3];
-    if (rows > 128 || rows < 1 || (K % 32) != 0) { MI_ERR("launch_quantize_q80_panel: %lld columns / K = %lld", (long long) rows, (long long) K); abort(); }
+    if (rows < 1 || (K % 32) != 0) { MI_ERR("launch_quantize_q80_panel: %lld columns / K = %lld", (long long) rows, (long long) K); abort(); }
     const int chunks = (int) ((K + 255) / 256);
     hipLaunchKernelGGL(k_quantize_q8_0<true>, dim3((unsigned) (rows * chunks)), dim3(64), 0, s, src.data, src.ne[1], src.ne[2], src.nb[1], src.nb[2], src.nb[3], (int) K, chunks, (q80_dev *) dst);
 }

@@ -862,6 +862,7 @@ def test_q8_0_model_batches_over_the_panel_copy_are_bit_equal(backend, H, plog):
     rng = np.random.default_rng(5)
     toks = rng.integers(1, hp.n_vocab, n_par * n_prompt).tolist()
     rows = [rng.integers(1, hp.n_vocab, n_par).tolist() for _ in range(n_steps)]
+    long_prompt = rng.integers(1, hp.n_vocab, 300).tolist()
     outs = {}
     mc = Model(hp, 21, H.ggml_backend_cpu_buffer_type())
     try:
@@ -877,12 +878,18 @@ def test_q8_0_model_batches_over_the_panel_copy_are_bit_equal(backend, H, plog):
                 rc, l1 = c.decode(rows[i], [n_prompt + i] * n_par, seq=list(range(n_par)))
                 assert rc == 0
                 lg.append(l1)
-            outs[mode] = (np.stack(lg), {k: backend.stat(k) - v for k, v in s0.items()})
+            # ... and a 300-token prompt of one sequence: the 128 x 128-tile GEMM, which reads both operands in panel order when the copy exists
+            c.clear()
+            rc, lp = c.decode(long_prompt, range(len(long_prompt)), want=[0] * (len(long_prompt) - 1) + [1])
+            assert rc == 0
+            outs[mode] = (np.stack(lg), {k: backend.stat(k) - v for k, v in s0.items()}, lp[-1])
             c.free()
             mg.free()
         cc = Context(mc, compute=T.oracle_compute_fn(), flash_attn=1, n_ctx=1024)
         rc, _ = cc.decode(toks, [i for _ in range(n_par) for i in range(n_prompt)], [k for k in range(n_par) for _ in range(n_prompt)], ([0] * (n_prompt - 1) + [1]) * n_par)
         ref = np.stack([cc.decode(rows[i], [n_prompt + i] * n_par, seq=list(range(n_par)))[1] for i in range(n_steps)])
+        cc.clear()
+        ref_long = cc.decode(long_prompt, range(len(long_prompt)), want=[0] * (len(long_prompt) - 1) + [1])[1][-1]
         cc.free()
     finally:
         backend.set_option("decode_copy", 1)
@@ -892,6 +899,9 @@ def test_q8_0_model_batches_over_the_panel_copy_are_bit_equal(backend, H, plog):
     assert outs[0][1]["decode_copy_launches"] == 0 and outs[0][1]["skinny_launches"] > 0
     assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
     assert T.nmse(outs[1][0], ref) <= 1e-3
+    assert np.array_equal(outs[1][2].view(np.uint32), outs[0][2].view(np.uint32))
+    plog(f"    300-token prompt through the GEMM: nmse vs oracle {T.nmse(outs[1][2], ref_long):.3e}")
+    assert T.nmse(outs[1][2], ref_long) <= 1e-3
 
 
 def test_no_room_for_a_decode_copy_keeps_the_block_layout(backend, H, plog):
