@@ -213,6 +213,7 @@ struct backend_ctx {
     uint64_t tick = 0;
     uint64_t decode_epoch = 0;  // decode_copy_epoch() the cached graphs were captured under
     bool capturing = false;
+    bool mm_q5_major = false;  // the graph being planned / run holds more Q5_K than Q4_K weight bytes (graph.cpp: mmq_min_cols_for)
     // tensor parallel
     tp_state * tp = nullptr;
     ip_engine * ip = nullptr;  // -sm row served as in-process tensor parallelism (tp_inproc.cpp); owned by the main device's backend

@@ -17,6 +17,15 @@
 namespace mi355x {
 
 static bool is_quant(int t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }
+// batches at least this wide run on the matrix cores.  The option's default (3) is per weight type since round 6: Q4_K / Q6_K matrices take the weight-streaming
+// kernel from TWO columns on (a 2-sequence step of Llama-3-8B Q4_K_M: 2.89-3.03 -> 2.78 ms — the multi-column mat-vec path has none of the batch path's fusions,
+// 17 launches a layer), Q5_K stays at 3 (its skinny unit is slower: Qwen2-7B Q5_K_M 3.13 -> 3.79 ms with 2; profiles/r06_np2_min_cols.txt)
+// (Q6_K follows the model: with 2 where Q4_K carries the graph's weight bytes — Q4_K_M; 3 in a Q5_K_M model, whose Q6_K matrices measured slower on the unit at 2
+// columns: Qwen2 3.13 -> 3.30 ms when only they moved.  plan_ws counts the bytes.)
+static inline int mmq_min_cols_for(const backend_ctx * c, int wtype) {
+    if (c->opt.mmq_min_cols != 3) return c->opt.mmq_min_cols;
+    return (wtype == GGML_TYPE_Q4_K || (wtype == GGML_TYPE_Q6_K && !c->mm_q5_major)) ? 2 : 3;
+}
 static int act_kind(int wtype) { return wtype == GGML_TYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q8_K; }
 static bool is_f32_contig(const ggml_tensor * t) { return t->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(t); }
 static bool rows_contig(const ggml_tensor * t) { return t->nb[0] == ggml_abi_type_size(t->type); }
@@ -192,6 +201,16 @@ struct ws_plan {
 static size_t fa_image_offset(const tdesc & q, const tdesc & k, const tdesc & v) { return (fattn_workspace_bytes(q, k, v, 64, GGML_TYPE_F16) + 255) & ~(size_t) 255; }
 static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
     ws_plan p;
+    {   // which K-quant carries this graph's weight bytes (mmq_min_cols_for)
+        size_t q4 = 0, q5 = 0;
+        for (int i = 0; i < g->n_nodes; ++i) {
+            const ggml_tensor * n = g->nodes[i];
+            if (n->op != GGML_OP_MUL_MAT || !n->src[0]) continue;
+            if (n->src[0]->type == GGML_TYPE_Q4_K) q4 += ggml_abi_nbytes(n->src[0]);
+            else if (n->src[0]->type == GGML_TYPE_Q5_K) q5 += ggml_abi_nbytes(n->src[0]);
+        }
+        c->mm_q5_major = q5 > q4;
+    }
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
         if (n->op == GGML_OP_MUL_MAT && is_quant(n->src[0]->type)) {
@@ -200,7 +219,7 @@ static ws_plan plan_ws(backend_ctx * c, const ggml_cgraph * g) {
             // (2..32 columns: the skinny matrix-core kernel fetches 32 columns' worth of activation bytes whatever M is)
             // (and the wide form of the same unit fetches whole groups of 128 columns of a prompt batch)
             p.act_bytes = std::max(p.act_bytes, quantized_act_bytes(act_kind(n->src[0]->type), b->ne[0], (Mc >= 2 && Mc < 32) ? 32 : (Mc >= 33 ? (Mc + 127) / 128 * 128 : Mc)));
-            if (Mc >= c->opt.mmq_min_cols && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, 3 * mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc, c->opt.mmq_skinny));  // (x3: up to three sibling matrices share a launch)
+            if (Mc >= mmq_min_cols_for(c, n->src[0]->type) && (n->ne[0] % 4) == 0) p.aux_bytes = std::max(p.aux_bytes, 3 * mmq_workspace_bytes(n->src[0]->type, b->ne[0], n->src[0]->ne[1], Mc, c->opt.mmq_skinny));  // (x3: up to three sibling matrices share a launch)
         } else if (n->op == GGML_OP_MUL_MAT && mm_cache_image_ok(n) && !buffer_is_split(n->src[0]->buffer)) {
             const tdesc a16 = kv_image_desc(TD(n->src[0]), nullptr);
             p.aux_bytes = std::max(p.aux_bytes, ((mul_mat_f_workspace_bytes(a16, TD(n->src[1])) + 255) & ~(size_t) 255) + kv_image_bytes(a16));
@@ -515,7 +534,7 @@ static bool run_mul_mat_q(exec_state & st, const ggml_tensor * w, const ggml_ten
         return true;
     }
     const bool i8 = c->opt.mmq_i8 && mmq_i8_supported(w->type, K, N, M);
-    if (M >= c->opt.mmq_min_cols && !w2 && !add2 && (!add || i8) && (i8 || mmq_supported(w->type, K, N, M))) {
+    if (M >= mmq_min_cols_for(c, w->type) && !w2 && !add2 && (!add || i8) && (i8 || mmq_supported(w->type, K, N, M))) {
         timed_scope ts(c, (std::string("mmq_") + type_tag(w->type) + "_n" + std::to_string(N) + "_k" + std::to_string(K)).c_str(), wbytes, i8);
         const int ks = st.epi_dst == dst ? 1 : ((N % 4) == 0 && (dst->nb[1] % 16) == 0 ? mmq_pick_ksplit(K, N, M, c->opt.mmq_skinny, w->type) : 1);
         float * part = (float *) ((char *) c->ws + st.aux_off);
@@ -1674,11 +1693,11 @@ static int run_node(exec_state & st, int i) {
                     return 2;
                 }
             }
-            if (fuse && !rowpar && c->opt.mm_merge && M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) {
+            if (fuse && !rowpar && c->opt.mm_merge && M >= mmq_min_cols_for(c, a->type) && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) {
                 const int used = try_merge_mm_batch(st, i);
                 if (used != 0) return used;
             }
-            if (fuse && !rowpar && ((M >= c->opt.mmq_min_cols && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) ||
+            if (fuse && !rowpar && ((M >= mmq_min_cols_for(c, a->type) && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) ||
                                     (M >= c->opt.q80_min_cols && mmq_q80_supported(a->type, a->ne[0], a->ne[1], M)) || mmq_q80_skinny_supported(a->type, a->ne[0], a->ne[1], M))) {
                 // batches: MUL_MAT -> ADD (bias row or residual) rides in the GEMM's store
                 ggml_tensor * a1 = next(1);
