@@ -99,9 +99,9 @@ typedef int64_t (*ggml_backend_mi355x_decode_copy_read_t)(ggml_backend_t backend
 /* Runtime options (string key/value); 0 = accepted, -1 = unknown key, -2 = refused (e.g. "tp_p2p" = 0 in a group whose only transport the mailboxes are).  Keys (INTEGRATION.md 4b lists the defaults and the
  * environment variables that set the same things): "graphs", "fusion", "prologue", "qkv", "mm_merge", "mmq_i8", "mmq_bn",
  * "mmq_skinny", "skinny_rope", "softmax_mm", "attn_nf", "mmq_min_cols", "mmvq_max_cols", "fa_splits", "fa_wo", "fa_self_merge", "small_uploads", "small_downloads",
- * "exec_update", "decode_copy", "timing", "tp_p2p", "tp_p2p_reset" (forget an all-reduce time-out: every rank, all idle), "clear_failure" (forget a remembered HIP failure of a status-less entry point). */
+ * "exec_update", "shadow_capture", "decode_copy" (the K-quants' plane copy and the Q8_0 panel copy), "decode_copy_headroom_gib", "q80_min_cols", "timing", "tp_p2p", "tp_p2p_reset" (forget an all-reduce time-out: every rank, all idle), "clear_failure" (forget a remembered HIP failure of a status-less entry point). */
 typedef int (*ggml_backend_mi355x_set_option_t)(ggml_backend_t backend, const char * key, const char * value);
-/* Counters for tests/bench: "graph_launches", "graph_captures", "graph_early_captures", "graph_exec_updates", "eager_graphs", "kernel_launches", "fused_nodes",
+/* Counters for tests/bench: "graph_launches", "graph_captures", "graph_early_captures", "graph_shadow_captures", "graph_capture_walk_ns", "graph_exec_update_ns", "graph_shadow_eager_ns", "graph_exec_updates", "eager_graphs", "kernel_launches", "fused_nodes",
  * "allreduces", "p2p_allreduces", "p2p_timeouts", "graph_launch_host_ns", "graph_key_host_ns", "graph_compute_host_ns", "graph_key_fast_hits", "graph_key_collisions",
  * "kernel_downloads", "graph_exec_update_failures", "graph_evictions", "graph_cache_size", "step_heads", "decode_copy_tensors", "decode_copy_bytes", "decode_copy_launches", "kv_image_nodes", "kv_native_nodes", "skinny_launches", "wide_launches", "tiled_launches", "rope_epilogues", "fa_list_launches"; in-process tensor parallel (-sm row, csrc/tp_inproc.cpp):
  * "ip_devices", "ip_graphs", "ip_declined", "ip_plans", "ip_input_copies", "ip_output_copies", "ip_kv_gathers", "ip_kv_scatters", "ip_worker_kernel_launches",
