@@ -31,7 +31,7 @@ cp gpurun_out/pmc_0.summary.txt $O/np32_pmc_pass0.csv 2>/dev/null; head -n 5 $O/
 rm -f gpurun_out/configs.jsonl gpurun_out/configs.err
 for cfg in "--np 32 --prefill 128 --steps 64" "--np 8 --prefill 128 --steps 64" "--fa 0" "--fa 0 --np 32 --prefill 128 --steps 64" "--preset qwen2-7b-q5_k_m --prefill 8064 --steps 64" "--preset llama3-70b-q4_k_m --prefill 512 --steps 32" \
            "--preset tinyllama-1.1b-q8_0 --prefill 512" "--np 32 --prefill 128 --steps 64 --ctkv q8_0" "--prefill 7936 --steps 64 --ctkv q8_0" "--prefill 7936 --steps 64 --ctkv q4_0" "--prefill 7936 --steps 64" "--np 32 --draft 4 --prefill 128 --steps 64" "--np 1 --draft 8 --prefill 128 --steps 64" "--emulate-tp 8 --preset llama3-70b-q4_k_m --prefill 512 --steps 32" \
-           "--preset tinyllama-1.1b-q8_0 --np 32 --prefill 128 --steps 64" "--preset llama2-7b-q4_k_m --prefill 2048 --steps 64" "--preset llama3.2-3b-q4_k_m --prefill 2048 --steps 64" "--preset llama3.2-1b-q4_k_m --prefill 2048 --steps 64"; do
+           "--preset tinyllama-1.1b-q8_0 --np 32 --prefill 128 --steps 64" "--preset llama3-8b-q8_0 --np 32 --prefill 128 --steps 32" "--preset llama3-8b-q8_0 --prefill 2048 --steps 64" "--np 2 --prefill 128 --steps 64" "--preset llama2-7b-q4_k_m --prefill 2048 --steps 64" "--preset llama3.2-3b-q4_k_m --prefill 2048 --steps 64" "--preset llama3.2-1b-q4_k_m --prefill 2048 --steps 64"; do
   timeout 900 python bench.py --cpu-steps 8 --pmc-traffic 0 --timing-steps 8 $cfg 2>> gpurun_out/configs.err >> gpurun_out/configs.jsonl
 done
 cp gpurun_out/configs.jsonl $O/configs.jsonl; wc -l $O/configs.jsonl
