@@ -1221,6 +1221,82 @@ static int try_merge_mm_batch(exec_state & st, int i) {  // returns the number o
     return ms[0].n_nodes;
 }
 
+// Q8_0 weights, 9 .. 128 columns (round 6): wq / wk / wv (and gate / up) of a batch multiply the same activations — one launch of the weight-streaming matrix-core
+// kernel over the concatenated 32-row panels (mmq_q80.hip), bias ADDs folded into the store.  The member search is try_merge_mm_batch's (same dependence rules);
+// no K split, no epilogues: with the K / V projections out of the way the ropes and cache stores that follow fuse as they do for the K-quants (try_fuse_rope_store).
+static int try_merge_q80_skinny(exec_state & st, int i) {  // returns the number of nodes consumed at position i (0: not merged)
+    backend_ctx * c = st.c;
+    ggml_cgraph * g = st.g;
+    ggml_tensor * n0 = g->nodes[i];
+    const ggml_tensor * X = n0->src[1];
+    const int64_t K = n0->src[0]->ne[0], M = X->ne[1] * X->ne[2] * X->ne[3];
+    struct member { int k; ggml_tensor * dst; const ggml_tensor * add; int n_nodes; };
+    auto eligible = [&](const ggml_tensor * t) {
+        const ggml_tensor * w = t->src[0];
+        return t->op == GGML_OP_MUL_MAT && t->src[1] == X && w->type == GGML_TYPE_Q8_0 && w->ne[0] == K && w->ne[2] == 1 && w->ne[3] == 1 && rows_contig(w) && !buffer_is_split(w->buffer) &&
+               mmq_q80_skinny_supported(w->type, K, w->ne[1], M) && t->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(t) && !(tp_active(c) && buffer_is_rowpar(w->view_src ? w->view_src->buffer : w->buffer));
+    };
+    auto with_add = [&](int k) {  // member at node k, with the ADD that directly follows it folded in
+        ggml_tensor * t = g->nodes[k];
+        ggml_tensor * a1 = k + 1 < g->n_nodes ? g->nodes[k + 1] : nullptr;
+        const ggml_tensor * o1 = (a1 && !st.done[k + 1] && single_use(st, t)) ? add_partner(a1, t) : nullptr;
+        if (o1 && ggml_abi_is_contiguous(a1) && a1->type == GGML_TYPE_F32) {
+            bool ready = true;  // (the sibling runs early, at node i: what it adds must exist by then)
+            for (int j = i; j <= k && ready; ++j) ready = !ranges_overlap(g->nodes[j], o1) || is_view_op(g->nodes[j]);
+            if (ready) return member{k, a1, o1, 2};
+        }
+        return member{k, t, nullptr, 1};
+    };
+    if (!eligible(n0)) return 0;
+    std::vector<member> ms{with_add(i)};
+    const int limit = std::min(g->n_nodes, i + 24);
+    for (int k = i + ms[0].n_nodes; k < limit && ms.size() < 3; ++k) {
+        ggml_tensor * t = g->nodes[k];
+        if (st.done[k] || !eligible(t)) continue;
+        const member m = with_add(k);
+        bool ok = true;
+        for (auto & o : ms) ok = ok && !ranges_overlap(m.dst, o.dst) && !ranges_overlap(m.dst, g->nodes[o.k]);
+        for (int j = i + 1; j < k && ok; ++j) {  // everything that runs between node i and the sibling's own position
+            const ggml_tensor * u = g->nodes[j];
+            bool is_member = false;
+            for (auto & o : ms) is_member = is_member || j == o.k || (o.n_nodes == 2 && j == o.k + 1);
+            if (!is_view_op(u) && !is_member && ranges_overlap(m.dst, u)) ok = false;
+            for (int sidx = 0; sidx < GGML_MAX_SRC && ok; ++sidx)
+                if (u->src[sidx] && ranges_overlap(m.dst, u->src[sidx])) ok = false;
+        }
+        if (ok && m.add && ranges_overlap(m.dst, m.add) && m.add->data != m.dst->data) ok = false;
+        if (ok) ms.push_back(m);
+    }
+    if (ms.size() < 2) return 0;
+    mmq80s_desc mats[3];
+    double wbytes = 0;
+    int64_t n_total = 0;
+    int with_copy = 0;
+    for (size_t q = 0; q < ms.size(); ++q) {
+        const ggml_tensor * w = g->nodes[ms[q].k]->src[0];
+        const ggml_tensor * add = ms[q].add;
+        const int64_t arows = add ? add->ne[1] * add->ne[2] * add->ne[3] : 0;
+        mats[q] = {(const uint8_t *) w->data, q80_panel_copy(c, w), (int64_t) w->nb[1], (int) w->ne[1], (float *) ms[q].dst->data, (int64_t) (ms[q].dst->nb[1] / 4),
+                   add ? (const float *) add->data : nullptr, (!add || arows == 1) ? 0 : (int64_t) (add->nb[1] / 4)};
+        with_copy += mats[q].W_panels != nullptr;
+        n_total += w->ne[1];
+        wbytes += (double) ggml_abi_row_size(w->type, K) * (double) w->ne[1];
+    }
+    if (with_copy != 0 && with_copy != (int) ms.size()) return 0;  // (one template form per launch: all from their panel copies, or none)
+    const void * act = quantized_src1(st, X, MI_ACT_Q80_PANEL);
+    for (size_t q = 1; q < ms.size(); ++q)
+        for (int d = 0; d < ms[q].n_nodes; ++d) { mark_done(st, ms[q].k + d); c->st.fused_nodes++; }
+    {
+        timed_scope ts(c, (std::string("mmq_q8_0_skinny") + (ms.size() == 3 ? "_x3" : "_x2") + "_n" + std::to_string(n_total) + "_k" + std::to_string(K)).c_str(), wbytes, true);
+        launch_mmq_q80_skinny_multi(c->stream, (int) ms.size(), mats, (int) K, (int) M, act);
+    }
+    c->st.decode_copy_launches += with_copy != 0;
+    c->st.skinny_launches++;
+    c->st.kernel_launches++;
+    c->st.fused_nodes += ms[0].n_nodes - 1;
+    return ms[0].n_nodes;
+}
+
 // ------------------------------------------------------------------------------------------------ batches: rope + cache stores
 // At ROPE(q) of a batch: ROPE(k) with the same parameters and positions, SET_ROWS(k cache <- rope(k)) and SET_ROWS(v cache <- v)
 // with one index vector follow (llama.cpp's build_attn: q, k, v expanded together, then cpy_k / cpy_v) — four launches that
@@ -1692,6 +1768,10 @@ static int run_node(exec_state & st, int i) {
                     c->st.fused_nodes += 1;
                     return 2;
                 }
+            }
+            if (fuse && !rowpar && c->opt.mm_merge && a->type == GGML_TYPE_Q8_0 && mmq_q80_skinny_supported(a->type, a->ne[0], a->ne[1], M)) {
+                const int used = try_merge_q80_skinny(st, i);
+                if (used != 0) return used;
             }
             if (fuse && !rowpar && c->opt.mm_merge && M >= mmq_min_cols_for(c, a->type) && c->opt.mmq_i8 && mmq_i8_supported(a->type, a->ne[0], a->ne[1], M)) {
                 const int used = try_merge_mm_batch(st, i);

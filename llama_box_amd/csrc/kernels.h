@@ -205,6 +205,8 @@ bool mmq_q80_supported(int type, int64_t K, int64_t N, int64_t M);
 void launch_mmq_q80(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 // 9 .. 32 columns: the weights streamed once, 32-row panels, K split over the waves of a workgroup (mmq_q80.hip; round 6)
 bool mmq_q80_skinny_supported(int type, int64_t K, int64_t N, int64_t M);
+struct mmq80s_desc { const uint8_t * W; const uint8_t * W_panels; int64_t w_nb1; int N; float * dst; int64_t dst_stride; const float * add; int64_t add_stride; };
+void launch_mmq_q80_skinny_multi(hipStream_t s, int n, const mmq80s_desc * mats, int K, int M, const void * act_q80_panel);  // up to three matrices over the same activations
 void launch_mmq_q80_skinny(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80_panel, float * dst, int64_t dst_stride, const float * add, int64_t add_stride);
 void launch_mmq(hipStream_t s, int type, const uint8_t * W, int64_t w_nb1, int K, int N, int M, const void * act_q8k, float * dst, int64_t dst_stride, int ksplit, float * part);
 

@@ -203,15 +203,20 @@ void launch_mmq_q80(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, 
 // (sumf += sumi * (d_w * d_x), ggml_vec_dot_q8_0_q8_0's expression).  Weight bytes go from global memory straight into the MFMA operand registers (a lane = a
 // row and a 16-value half of the block, 2-byte aligned 16-byte loads); the activations' blocks (32 columns x K / 32 x 36 B: L2-resident) likewise; the 32 row
 // scales of a block reach the 16 accumulator rows of a lane through a wave-private LDS line.  The eight partial tiles meet in LDS and are added in wave order.
-struct mmq80s_args {
+struct mmq80s_mat {
     const uint8_t * W;   // the tensor (block layout), or its panel copy (repack.hip: k_repack_q80_panels) — template WP
     int64_t w_nb1;
-    int K, N, M;
-    const char * act;    // the activations in panel order (quantize.hip: k_quantize_q8_0<true>): 1152 B per block
+    int N;
+    int panel_end;       // workgroups [previous matrix's panel_end, panel_end) are this matrix's 32-row panels
     float * dst;
     int64_t dst_stride;
     const float * add;
     int64_t add_stride;
+};
+struct mmq80s_args {    // up to three matrices over the same activations in one launch (wq / wk / wv, gate / up: graph.cpp try_merge_q80_skinny)
+    mmq80s_mat m[3];
+    int K, M;
+    const char * act;    // the activations in panel order (quantize.hip: k_quantize_q8_0<true>): 1152 B per block
 };
 typedef uint32_t __attribute__((ext_vector_type(4), aligned(2))) q80s_u32x4_a2;
 typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) q80s_u32x4_a4;
@@ -223,9 +228,12 @@ template <bool WP> __global__ void __launch_bounds__(Q80S_WV * 64, 2) k_mmq_q80_
     __shared__ float red[Q80S_WV][16][64];      // the waves' partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, kg = lane >> 5;
-    const int n0 = blockIdx.x * 32;
+    const int mi = (int) blockIdx.x < a.m[0].panel_end ? 0 : ((int) blockIdx.x < a.m[1].panel_end ? 1 : 2);  // (uniform)
+    const mmq80s_mat & mt = a.m[mi];
+    const int panel = (int) blockIdx.x - (mi ? a.m[mi - 1].panel_end : 0);
+    const int n0 = panel * 32;
     const int nblk = a.K / 32, nchunk = nblk / 4;
-    const uint8_t * wrow = WP ? a.W + (size_t) blockIdx.x * nchunk * 4352 : a.W + (size_t) min(n0 + fr, a.N - 1) * a.w_nb1;
+    const uint8_t * wrow = WP ? mt.W + (size_t) panel * nchunk * 4352 : mt.W + (size_t) min(n0 + fr, mt.N - 1) * mt.w_nb1;
     const int colc = min(fr, a.M - 1);
     float C[16];
 #pragma unroll
@@ -299,9 +307,9 @@ template <bool WP> __global__ void __launch_bounds__(Q80S_WV * 64, 2) k_mmq_q80_
 #pragma unroll
         for (int w = 1; w < Q80S_WV; ++w) v += red[w][r][l];
         const int m = l & 31, n = n0 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
-        if (m < a.M && n < a.N) {
-            if (a.add) v += a.add[(size_t) m * a.add_stride + n];
-            a.dst[(size_t) m * a.dst_stride + n] = v;
+        if (m < a.M && n < mt.N) {
+            if (mt.add) v += mt.add[(size_t) m * mt.add_stride + n];
+            mt.dst[(size_t) m * mt.dst_stride + n] = v;
         }
     }
 }
@@ -311,27 +319,33 @@ bool mmq_q80_skinny_supported(int type, int64_t K, int64_t N, int64_t M) {
     static const int max_cols = getenv("GGML_MI355X_Q80_SKINNY_MAX") ? atoi(getenv("GGML_MI355X_Q80_SKINNY_MAX")) : 128;  // (up to 128 columns: four passes of 32 still beat the 128 x 128-tile GEMM's few workgroups — Llama-3-8B Q8_0, 128-token micro-batches: 8.5 k against 5.1 k tok/s)
     return on && type == GGML_TYPE_Q8_0 && (K % 128) == 0 && N >= 1 && M >= 9 && M <= std::min(max_cols, 128);
 }
-void launch_mmq_q80_skinny(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add,
-                           int64_t add_stride) {
+// n matrices (1 .. 3) over the same activations; panels[q] != nullptr for ALL of them or for none (the template form is per launch)
+void launch_mmq_q80_skinny_multi(hipStream_t s, int n, const mmq80s_desc * mats, int K, int M, const void * act_q80) {
     mmq80s_args a;
-    a.W = W_panels ? W_panels : W;
-    a.w_nb1 = w_nb1;
+    int pe = 0;
+    const bool wp = mats[0].W_panels != nullptr;
+    for (int q = 0; q < 3; ++q) {
+        const mmq80s_desc & d = mats[q < n ? q : n - 1];
+        if (q < n) pe += (d.N + 31) / 32;
+        a.m[q] = {wp ? d.W_panels : d.W, d.w_nb1, d.N, pe, d.dst, d.dst_stride, d.add, d.add_stride};
+    }
     a.K = K;
-    a.N = N;
-    a.M = M;
-    a.act = (const char *) act_q80;
-    a.dst = dst;
-    a.dst_stride = dst_stride;
-    a.add = add;
-    a.add_stride = add_stride;
     for (int m0 = 0; m0 < M; m0 += 32) {  // groups of 32 columns: the activations' panel tiles of group g follow those of group g - 1 (quantize.hip)
         a.M = std::min(32, M - m0);
         a.act = (const char *) act_q80 + (size_t) (m0 / 32) * (size_t) (K / 32) * 1152;
-        a.dst = dst + (size_t) m0 * dst_stride;
-        a.add = add ? add + (size_t) m0 * add_stride : nullptr;
-        if (W_panels) hipLaunchKernelGGL(k_mmq_q80_skinny<true>, dim3((unsigned) ((N + 31) / 32)), dim3(Q80S_WV * 64), 0, s, a);
-        else hipLaunchKernelGGL(k_mmq_q80_skinny<false>, dim3((unsigned) ((N + 31) / 32)), dim3(Q80S_WV * 64), 0, s, a);
+        for (int q = 0; q < 3; ++q) {
+            const mmq80s_desc & d = mats[q < n ? q : n - 1];
+            a.m[q].dst = d.dst + (size_t) m0 * d.dst_stride;
+            a.m[q].add = d.add ? d.add + (size_t) m0 * d.add_stride : nullptr;
+        }
+        if (wp) hipLaunchKernelGGL(k_mmq_q80_skinny<true>, dim3((unsigned) pe), dim3(Q80S_WV * 64), 0, s, a);
+        else hipLaunchKernelGGL(k_mmq_q80_skinny<false>, dim3((unsigned) pe), dim3(Q80S_WV * 64), 0, s, a);
     }
+}
+void launch_mmq_q80_skinny(hipStream_t s, const uint8_t * W, const uint8_t * W_panels, int64_t w_nb1, int K, int N, int M, const void * act_q80, float * dst, int64_t dst_stride, const float * add,
+                           int64_t add_stride) {
+    const mmq80s_desc d{W, W_panels, w_nb1, N, dst, dst_stride, add, add_stride};
+    launch_mmq_q80_skinny_multi(s, 1, &d, K, M, act_q80);
 }
 
 MI_TU_TOUCH(mmq_q80)

@@ -179,13 +179,24 @@ void launch_unary(hipStream_t s, int uop, const tdesc & src, const tdesc & dst) 
 }
 
 // swiglu: y = silu(a) * b (ggml_compute_forward_swiglu_f32); split form (two tensors) or the two halves of one row
+// (grid.x = row, grid.y = chunk of 1024 values: a 32-row batch of Llama-3-8B's 14336 columns used to run on 32 workgroups, 56 scalar elements per thread — 23 us;
+// VEC: rows and row starts 16-byte aligned, four values per thread as one float4)
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_swiglu(const char * __restrict__ pa, const char * __restrict__ pb, char * __restrict__ pd, const int64_t nc,
                                                 const int64_t nba1, const int64_t nbb1, const int64_t nbd1) {
     const int64_t row = blockIdx.x;
     const float * a = (const float *) (pa + row * nba1);
     const float * b = (const float *) (pb + row * nbb1);
     float * y = (float *) (pd + row * nbd1);
-    for (int64_t i = threadIdx.x; i < nc; i += blockDim.x) y[i] = silu_f(a[i]) * b[i];
+    const int64_t i0 = ((int64_t) blockIdx.y * 256 + threadIdx.x) * 4;
+    if constexpr (VEC) {
+        if (i0 < nc) {  // (nc % 4 == 0)
+            const float4 av = *(const float4 *) (a + i0), bv = *(const float4 *) (b + i0);
+            *(float4 *) (y + i0) = make_float4(silu_f(av.x) * bv.x, silu_f(av.y) * bv.y, silu_f(av.z) * bv.z, silu_f(av.w) * bv.w);
+        }
+    } else {
+        for (int64_t i = i0; i < i0 + 4 && i < nc; ++i) y[i] = silu_f(a[i]) * b[i];
+    }
 }
 void launch_swiglu(hipStream_t s, const tdesc & a, const tdesc * b, const tdesc & d, int swapped) {
     const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
@@ -196,7 +207,11 @@ void launch_swiglu(hipStream_t s, const tdesc & a, const tdesc * b, const tdesc 
         pa += swapped ? nc * 4 : 0;
         pb += swapped ? 0 : nc * 4;
     }
-    hipLaunchKernelGGL(k_swiglu, dim3((unsigned) rows), dim3(256), 0, s, pa, pb, d.data, nc, a.nb[1], b ? b->nb[1] : a.nb[1], d.nb[1]);
+    const int64_t nbb1 = b ? b->nb[1] : a.nb[1];
+    const bool vec = (nc % 4) == 0 && (((uintptr_t) pa | (uintptr_t) pb | (uintptr_t) d.data | (uintptr_t) a.nb[1] | (uintptr_t) nbb1 | (uintptr_t) d.nb[1]) & 15) == 0;
+    const dim3 grid((unsigned) rows, (unsigned) ((nc + 1023) / 1024));
+    if (vec) hipLaunchKernelGGL(k_swiglu<true>, grid, dim3(256), 0, s, pa, pb, d.data, nc, a.nb[1], nbb1, d.nb[1]);
+    else hipLaunchKernelGGL(k_swiglu<false>, grid, dim3(256), 0, s, pa, pb, d.data, nc, a.nb[1], nbb1, d.nb[1]);
 }
 
 // ------------------------------------------------------------------------------------------------ CPY / DUP / CONT

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "swiglu or glu or q8_0" 2>&1 | tail -3
+timeout 900 python -m pytest tests -x -q -m gpu -k "tinyllama or TinyLlama or tiny or prefill" 2>&1 | tail -3
+one() { timeout 600 python bench.py "$@" --pmc-traffic 0 --timing-steps 8 --cpu-steps 8 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); p=d.get('parity') or {}; print(d['value'], d['ms_per_step'], 'prefill', d.get('prefill_tok_s'), (p.get('continuous_batch') or p).get('within_bar'), {k: v for k, v in (d.get('kernel_classes_us') or {}).items() if 'swiglu' in k})" | cut -c1-600; }
+echo "== tinyllama -np 32"; one --preset tinyllama-1.1b-q8_0 --np 32 --prefill 128 --steps 64
+echo "== llama3-8b-q8_0 -np 32"; one --preset llama3-8b-q8_0 --np 32 --prefill 128 --steps 32 --no-cpu-baseline
+echo "== llama3-8b-q8_0 prefill 2048"; one --preset llama3-8b-q8_0 --prefill 2048 --steps 16 --no-cpu-baseline

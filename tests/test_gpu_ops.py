@@ -99,6 +99,44 @@ def test_mul_mat_q8_0_9_to_32_columns(backend, H, plog, K, N, M, bias):
         assert np.array_equal(got[0].reshape(-1, N).view(np.uint32), by8.view(np.uint32))
 
 
+@pytest.mark.parametrize("M,bias", [(32, False), (12, True), (64, True), (9, False)])
+def test_q8_0_sibling_mul_mats_share_a_launch(backend, H, plog, M, bias):
+    """wq / wk / wv of a Q8_0 model's batch multiply the same activations: ONE launch of the 9 .. 128-column matrix-core kernel over the concatenated 32-row panels
+    (graph.cpp: try_merge_q80_skinny), bias ADDs folded into the store — equal to the oracle, and bit-equal to the one-by-one execution (same kernel, same tiles)."""
+    rng = np.random.default_rng(M * 11 + 1)
+    K, NQ, NK = 1024, 512, 96
+    wq, wk, wv = T.rand_weight(L.Q8_0, K, NQ, rng), T.rand_weight(L.Q8_0, K, NK, rng), T.rand_weight(L.Q8_0, K, NK, rng)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    bq, bk, bv = (rng.standard_normal(n).astype(np.float32) for n in (NQ, NK, NK))
+
+    def build(g):
+        cur = g.new(L.F32, [K, M], x)
+        outs = []
+        for w, n, b in ((wq, NQ, bq), (wk, NK, bk), (wv, NK, bv)):
+            r = H.ggml_mul_mat(g.ctx, g.new(L.Q8_0, [K, n], w), cur)
+            if bias:
+                r = H.ggml_add(g.ctx, r, g.new(L.F32, [n], b))
+            outs.append(r)
+        return outs
+
+    ref = T.run_case(build, "oracle")
+    k0 = backend.stat("kernel_launches")
+    got = T.run_case(build, backend)
+    launches = backend.stat("kernel_launches") - k0
+    backend.set_option("mm_merge", 0)
+    try:
+        k1 = backend.stat("kernel_launches")
+        plain = T.run_case(build, backend)
+        launches_plain = backend.stat("kernel_launches") - k1
+    finally:
+        backend.set_option("mm_merge", 1)
+    plog(f"    Q8_0 sibling mat-muls M={M} bias={bias}: {launches} launches merged, {launches_plain} one by one")
+    assert launches == 2 and launches < launches_plain  # quantise + one matrix-core launch (M = 64: two passes inside the launcher count as one)
+    for name, a, b, c in zip("qkv", got, ref, plain):
+        T.compare(f"Q8_0 sibling mat-muls M={M} bias={bias} {name}", a, b, max_nmse=1e-10, log=plog)
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(c).view(np.uint32))
+
+
 @pytest.mark.parametrize("i8,bn", [(1, 64), (1, 128), (0, 0)])
 @pytest.mark.parametrize("qt", [L.Q4_K, L.Q5_K, L.Q6_K])
 @pytest.mark.parametrize("K,N,M", [(512, 128, 128), (1024, 200, 300), (2048, 384, 512), (256, 130, 33), (4096, 256, 24), (512, 200, 64), (1024, 96, 9), (2048, 384, 40), (4096, 1024, 32)])
