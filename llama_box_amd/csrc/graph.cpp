@@ -656,9 +656,38 @@ static bool quant_consumers_only(const exec_state & st, int at, const ggml_tenso
     }
     return true;
 }
-static void mark_q8_cache(exec_state & st, const ggml_tensor * t) {
+// ... and the same question for Q8_0 weights (round 6): every reader of t is a Q8_0 mat-mul that takes the 9 .. 128-column matrix-core kernel (its activations in panel
+// order), so a producer may leave Q8_0 panel blocks instead of f32
+static bool q80_panel_consumers_only(const exec_state & st, int at, const ggml_tensor * t) {
+    if ((t->flags & GGML_TENSOR_FLAG_OUTPUT) || t->type != GGML_TYPE_F32 || (t->ne[0] % 128) != 0) return false;
+    const int64_t M = t->ne[1] * t->ne[2] * t->ne[3];
+    const ggml_cgraph * g = st.g;
+    int last = -1, n_cons = 0;
+    for (int j = at + 1; j < g->n_nodes; ++j) {
+        const ggml_tensor * u = g->nodes[j];
+        for (int s = 0; s < GGML_MAX_SRC; ++s) {
+            if (u->src[s] != t) continue;
+            const ggml_tensor * wt = u->src[0];
+            if (!(u->op == GGML_OP_MUL_MAT && s == 1 && wt->type == GGML_TYPE_Q8_0 && wt->ne[2] == 1 && wt->ne[3] == 1 && rows_contig(wt) && !buffer_is_split(wt->buffer) &&
+                  mmq_q80_skinny_supported(wt->type, wt->ne[0], wt->ne[1], M) && u->type == GGML_TYPE_F32 && ggml_abi_is_contiguous(u)))
+                return false;
+            if (tp_active(st.c) && buffer_is_rowpar(wt->view_src ? wt->view_src->buffer : wt->buffer)) return false;
+            last = j;
+            n_cons++;
+        }
+    }
+    if (n_cons == 0 || n_cons != use_count(st, t)) return false;
+    for (int j = at + 1; j <= last; ++j) {  // (the activation area is shared: no other quantised mat-mul may run before the last reader)
+        const ggml_tensor * u = g->nodes[j];
+        if (u->op == GGML_OP_MUL_MAT && is_quant(u->src[0]->type) && u->src[1] != t) return false;
+        if (u->op == GGML_OP_MUL_MAT_ID) return false;
+    }
+    return true;
+}
+static void mark_q8_cache(exec_state & st, const ggml_tensor * t, int kind = GGML_TYPE_Q8_K);
+static void mark_q8_cache(exec_state & st, const ggml_tensor * t, int kind) {
     st.c->q8_src = t->data;
-    st.c->q8_kind = GGML_TYPE_Q8_K;
+    st.c->q8_kind = kind;
     st.c->q8_bytes = ggml_abi_nbytes(t);
     st.q8_fresh = true;
 }
@@ -1669,6 +1698,15 @@ static int run_node(exec_state & st, int i) {
                         c->st.fused_nodes += 2;
                         return 2;
                     }
+                    static const bool q80_producers = !getenv("GGML_MI355X_Q80_PRODUCERS") || atoi(getenv("GGML_MI355X_Q80_PRODUCERS")) != 0;
+                    if (q80_producers && c->opt.prologue && ggml_abi_nrows(m) >= 9 && st.sk_dst != a && rms_norm_q80_panel_ok(TD(a), (const float *) w->data) && q80_panel_consumers_only(st, i + 1, m)) {
+                        timed_scope ts(c, "rms_norm_mul_quantize_q8_0", (double) ggml_abi_nbytes(a));
+                        launch_rms_norm_mul_q80_panel(s, TD(a), ggml_abi_op_param_f32(n, 0), (const float *) w->data, (char *) c->ws + st.act_off);
+                        mark_q8_cache(st, m, MI_ACT_Q80_PANEL);
+                        c->st.kernel_launches++;
+                        c->st.fused_nodes += 2;
+                        return 2;
+                    }
                     flush_deferred_splitk(st);
                     const tdesc wd = TD(w);
                     timed_scope ts(c, "rms_norm_mul", (double) ggml_abi_nbytes(a) * 2);
@@ -1840,6 +1878,15 @@ static int run_node(exec_state & st, int i) {
                 timed_scope ts(c, "swiglu_quantize", (double) ggml_abi_nbytes(n) * 2);
                 launch_swiglu_quantize(s, TD(a), b ? &bd : nullptr, n->ne[0], n->op_params[1], (char *) c->ws + st.act_off);
                 mark_q8_cache(st, n);
+                c->st.kernel_launches++;
+                c->st.fused_nodes++;
+                return 1;
+            }
+            static const bool q80_producers = !getenv("GGML_MI355X_Q80_PRODUCERS") || atoi(getenv("GGML_MI355X_Q80_PRODUCERS")) != 0;
+            if (q80_producers && fuse && c->opt.prologue && ggml_abi_nrows(n) >= 9 && swiglu_q80_panel_ok(TD(a), b ? &bd : nullptr, n->ne[0], n->op_params[1]) && q80_panel_consumers_only(st, i, n)) {
+                timed_scope ts(c, "swiglu_quantize_q8_0", (double) ggml_abi_nbytes(n) * 2);
+                launch_swiglu_q80_panel(s, TD(a), b ? &bd : nullptr, n->ne[0], n->op_params[1], (char *) c->ws + st.act_off);
+                mark_q8_cache(st, n, MI_ACT_Q80_PANEL);
                 c->st.kernel_launches++;
                 c->st.fused_nodes++;
                 return 1;

@@ -30,6 +30,11 @@ void launch_quantize_act(hipStream_t s, int kind, const tdesc & src, void * dst)
 // Q8_0 activations of up to 32 columns in PANEL order (mmq_q80.hip: k_mmq_q80_skinny): per block of 32 values [K half][column 0 .. 31][16 quants] + [column] f32 scales, 1152 B
 #define MI_ACT_Q80_PANEL 1008
 void launch_quantize_q80_panel(hipStream_t s, const tdesc & src, void * dst);
+// producers fused with that quantisation (ops.hip; same arithmetic as the unfused kernels): RMS_NORM(x) * w, SwiGLU
+bool rms_norm_q80_panel_ok(const tdesc & src, const float * w);
+void launch_rms_norm_mul_q80_panel(hipStream_t s, const tdesc & src, float eps, const float * w, void * q80_panel);
+bool swiglu_q80_panel_ok(const tdesc & a, const tdesc * b, int64_t nc, int swapped);
+void launch_swiglu_q80_panel(hipStream_t s, const tdesc & a, const tdesc * b, int64_t nc, int swapped, void * q80_panel);
 
 // ---- bandwidth-bound quantised mat-vec, 1..8 activation columns (mmvq.hip)
 struct mmvq_args {

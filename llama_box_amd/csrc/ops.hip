@@ -38,7 +38,28 @@ __device__ __forceinline__ float block_max_f(float v, float * sh) {
 // ------------------------------------------------------------------------------------------------ RMS_NORM (+MUL)
 // ggml_compute_forward_rms_norm_f32: sum of squares accumulated in double, scale = 1/sqrtf(mean + eps), y = x*scale;
 // optional fused `* w` (the MUL node that always follows in llm_build_*)
-__global__ void __launch_bounds__(256) k_rms_norm(const tdesc a, const tdesc d, const float eps, const float * __restrict__ w) {
+// one 32-value block of a row, held four values a lane by eight consecutive lanes, quantised as k_quantize_q8_0 does it and written in PANEL order (quantize.hip;
+// mmq_q80.hip: the 9 .. 128-column kernel's activations): row = column index, blk = block index along K
+__device__ __forceinline__ void q80_panel_store(const float r0, const float r1, const float r2, const float r3, const int w8, const int64_t row, const int64_t blk, const int64_t nblk, char * __restrict__ dst) {
+    float amax = fmaxf(fmaxf(fabsf(r0), fabsf(r1)), fmaxf(fabsf(r2), fabsf(r3)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    const float v[4] = {r0, r1, r2, r3};
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) packed |= (uint32_t) ((int) roundf(v[k] * id) & 0xFF) << (8 * k);
+    char * tile = dst + ((size_t) (row >> 5) * (size_t) nblk + (size_t) blk) * 1152;
+    const int cr = (int) (row & 31);
+    *(uint32_t *) (tile + (w8 >> 2) * 512 + cr * 16 + (w8 & 3) * 4) = packed;
+    if (w8 == 0) *(float *) (tile + 1024 + cr * 4) = h2f(f2h(d));
+}
+// Q80P (round 6): the row leaves as Q8_0 blocks in panel order instead of f32 — every reader is a Q8_0 mat-mul of 9 .. 128 columns (graph.cpp: q80_panel_consumers_only);
+// the vector path only (the launcher checks), same arithmetic as the two kernels it replaces
+template <bool Q80P>
+__global__ void __launch_bounds__(256) k_rms_norm(const tdesc a, const tdesc d, const float eps, const float * __restrict__ w, char * __restrict__ q80 = nullptr) {
     __shared__ double sh[4];
     const int64_t row = blockIdx.x;
     const int64_t i1 = row % a.ne[1], i2 = (row / a.ne[1]) % a.ne[2], i3 = row / (a.ne[1] * a.ne[2]);
@@ -86,7 +107,8 @@ __global__ void __launch_bounds__(256) k_rms_norm(const tdesc a, const tdesc d, 
                     float4 r;
                     r.x = v[u].x * scale; r.y = v[u].y * scale; r.z = v[u].z * scale; r.w = v[u].w * scale;
                     if (w) { r.x = r.x * g[u].x; r.y = r.y * g[u].y; r.z = r.z * g[u].z; r.w = r.w * g[u].w; }
-                    y4[i] = r;
+                    if constexpr (Q80P) q80_panel_store(r.x, r.y, r.z, r.w, (int) (i & 7), row, i >> 3, n >> 5, q80);
+                    else y4[i] = r;
                 }
             }
         }
@@ -100,7 +122,14 @@ __global__ void __launch_bounds__(256) k_rms_norm(const tdesc a, const tdesc d, 
 }
 void launch_rms_norm(hipStream_t s, const tdesc & src, const tdesc & dst, float eps, const tdesc * mul_w) {
     const int64_t rows = src.ne[1] * src.ne[2] * src.ne[3];
-    hipLaunchKernelGGL(k_rms_norm, dim3((unsigned) rows), dim3(256), 0, s, src, dst, eps, mul_w ? (const float *) mul_w->data : nullptr);
+    hipLaunchKernelGGL(k_rms_norm<false>, dim3((unsigned) rows), dim3(256), 0, s, src, dst, eps, mul_w ? (const float *) mul_w->data : nullptr, (char *) nullptr);
+}
+bool rms_norm_q80_panel_ok(const tdesc & src, const float * w) {  // the kernel's vector path, whole Q8_0 blocks
+    return (src.ne[0] % 32) == 0 && src.nb[0] == 4 && ((((uintptr_t) src.data) | ((uintptr_t) w) | (uintptr_t) src.nb[1] | (uintptr_t) src.nb[2] | (uintptr_t) src.nb[3]) & 15) == 0;
+}
+void launch_rms_norm_mul_q80_panel(hipStream_t s, const tdesc & src, float eps, const float * w, void * q80_panel) {
+    const int64_t rows = src.ne[1] * src.ne[2] * src.ne[3];
+    hipLaunchKernelGGL(k_rms_norm<true>, dim3((unsigned) rows), dim3(256), 0, s, src, src, eps, w, (char *) q80_panel);
 }
 
 // ------------------------------------------------------------------------------------------------ ADD/SUB/MUL/DIV
@@ -181,7 +210,7 @@ void launch_unary(hipStream_t s, int uop, const tdesc & src, const tdesc & dst) 
 // swiglu: y = silu(a) * b (ggml_compute_forward_swiglu_f32); split form (two tensors) or the two halves of one row
 // (grid.x = row, grid.y = chunk of 1024 values: a 32-row batch of Llama-3-8B's 14336 columns used to run on 32 workgroups, 56 scalar elements per thread — 23 us;
 // VEC: rows and row starts 16-byte aligned, four values per thread as one float4)
-template <bool VEC>
+template <bool VEC, bool Q80P = false>
 __global__ void __launch_bounds__(256) k_swiglu(const char * __restrict__ pa, const char * __restrict__ pb, char * __restrict__ pd, const int64_t nc,
                                                 const int64_t nba1, const int64_t nbb1, const int64_t nbd1) {
     const int64_t row = blockIdx.x;
@@ -192,11 +221,28 @@ __global__ void __launch_bounds__(256) k_swiglu(const char * __restrict__ pa, co
     if constexpr (VEC) {
         if (i0 < nc) {  // (nc % 4 == 0)
             const float4 av = *(const float4 *) (a + i0), bv = *(const float4 *) (b + i0);
+            if constexpr (Q80P) q80_panel_store(silu_f(av.x) * bv.x, silu_f(av.y) * bv.y, silu_f(av.z) * bv.z, silu_f(av.w) * bv.w, (int) ((i0 >> 2) & 7), row, i0 >> 5, nc >> 5, pd);  // (nc % 32 == 0)
+            else
             *(float4 *) (y + i0) = make_float4(silu_f(av.x) * bv.x, silu_f(av.y) * bv.y, silu_f(av.z) * bv.z, silu_f(av.w) * bv.w);
         }
     } else {
         for (int64_t i = i0; i < i0 + 4 && i < nc; ++i) y[i] = silu_f(a[i]) * b[i];
     }
+}
+bool swiglu_q80_panel_ok(const tdesc & a, const tdesc * b, int64_t nc, int swapped) {
+    (void) swapped;
+    const char * pb = b ? b->data : a.data + nc * 4;
+    return (nc % 32) == 0 && (((uintptr_t) a.data | (uintptr_t) pb | (uintptr_t) a.nb[1] | (uintptr_t) (b ? b->nb[1] : a.nb[1])) & 15) == 0;
+}
+void launch_swiglu_q80_panel(hipStream_t s, const tdesc & a, const tdesc * b, int64_t nc, int swapped, void * q80_panel) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    const char * pa = a.data;
+    const char * pb = b ? b->data : a.data;
+    if (!b) {
+        pa += swapped ? nc * 4 : 0;
+        pb += swapped ? 0 : nc * 4;
+    }
+    hipLaunchKernelGGL((k_swiglu<true, true>), dim3((unsigned) rows, (unsigned) ((nc + 1023) / 1024)), dim3(256), 0, s, pa, pb, (char *) q80_panel, nc, a.nb[1], b ? b->nb[1] : a.nb[1], (int64_t) 0);
 }
 void launch_swiglu(hipStream_t s, const tdesc & a, const tdesc * b, const tdesc & d, int swapped) {
     const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
