@@ -31,6 +31,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # kernel-class tag (graph.cpp timed_scope) -> substring of the kernel symbol rocprofv3 reports
 def _class_to_symbol(cls, n_par=1, planes=False, short_rows=False):
     parts = cls.split("_")
+    if cls.startswith("mmq_q8_0_skinny"):  # Q8_0 weights x 9 .. 128 columns (mmq_q80.hip); <true>: over the panel copy of the weights
+        return f"k_mmq_q80_skinny<{'true' if planes else 'false'}>"
     if parts[0] == "mmq" and 2 <= n_par <= 32:
         # -np decode steps: the weight-streaming matrix-core kernel; the gate/up pair takes its tile-parallel form (mmq_skinny.hip)
         qt = {"q4": "4", "q5": "5", "q6": "6"}.get(parts[1])
